@@ -1,0 +1,258 @@
+/*
+ * pv_yield_hip.h — C ABI of libpvyield_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the dense hot path of openclimatefix/predict_pv_yield
+ * (SURVEY.md §8b).  Every entry point replaces one third-party operator call
+ * site of the reference; the citation after "replaces:" is the reference
+ * file:line (paths under the upstream repo; notebook lines are raw .ipynb
+ * JSON lines).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch / C++ types; all pointers are DEVICE
+ *     pointers unless a parameter says "host";
+ *   - the caller owns every buffer (including workspaces, sized by the
+ *     *_workspace_bytes queries);
+ *   - every launch goes to the caller's stream (`stream` is a hipStream_t
+ *     passed as void*; NULL = the null stream); calls are asynchronous and
+ *     never synchronise, allocate or free (graph-capturable);
+ *   - return value: PV_OK (0) or a negative PV_E* code, never throws;
+ *     pv_last_error() returns a thread-local description of the last failure;
+ *   - no global state; re-entrant across streams and devices.
+ */
+#ifndef PV_YIELD_HIP_H
+#define PV_YIELD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_ABI_VERSION 1
+
+enum {
+  PV_OK = 0,
+  PV_EINVAL = -1,   /* bad argument (null pointer, non-positive size, bad enum) */
+  PV_ESIZE = -2,    /* size not supported by this kernel / workspace too small  */
+  PV_ELAUNCH = -3   /* hip launch error (hipGetLastError() != hipSuccess)       */
+};
+
+/* cv2 border modes (same numeric values as OpenCV's cv::BorderTypes). */
+enum { PV_BORDER_CONSTANT = 0, PV_BORDER_REPLICATE = 1 };
+
+/* u8 conversions of 10-bit satellite counts. */
+enum {
+  PV_U8_ROUND_DIV4 = 0,   /* round_half_even(x / 4)      notebooks/13_...ipynb:112-119 */
+  PV_U8_TRUNC_SCALE = 1   /* trunc(x / 1023 * 255)       notebooks/optical_flow_1.ipynb:129-134 */
+};
+
+int pv_abi_version(void);
+const char* pv_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* Optical-flow advection (SURVEY.md §8a rows a-9 … a-15)                    */
+/* ------------------------------------------------------------------------ */
+
+/* replaces: convert_10bpp_to_uint8, notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:112-119
+ * (mode PV_U8_ROUND_DIV4) and the truncating variant notebooks/optical_flow_1.ipynb:129-134.
+ * `range_flag` (device int32, may be NULL) is set to 1 if any value leaves
+ * [0,255] after conversion (the reference asserts on that); values saturate. */
+int pv_u8_from_10bit_i16(const int16_t* src, uint8_t* dst, size_t n, int mode,
+                         int32_t* range_flag, void* stream);
+int pv_u8_from_10bit_f32(const float* src, uint8_t* dst, size_t n, int mode,
+                         int32_t* range_flag, void* stream);
+
+/* Farnebäck parameters = the positional arguments of cv.calcOpticalFlowFarneback.
+ * Reference call site: notebooks/13_...ipynb:133-135 (0.5, 2, 40, 3, 5, 0.7,
+ * OPTFLOW_FARNEBACK_GAUSSIAN); identical in optical_flow_1.ipynb:217. */
+typedef struct pv_farneback_params {
+  double pyr_scale;   /* 0.5 */
+  int32_t levels;     /* 2   */
+  int32_t winsize;    /* 40  */
+  int32_t iterations; /* 3   */
+  int32_t poly_n;     /* 5   (5 or 7) */
+  double poly_sigma;  /* 0.7 */
+  int32_t flags;      /* 256 = OPTFLOW_FARNEBACK_GAUSSIAN (the only mode built) */
+} pv_farneback_params;
+
+#define PV_OPTFLOW_FARNEBACK_GAUSSIAN 256
+
+/* Bytes of scratch pv_farneback_batch_u8 needs for n_pairs images of h×w. */
+int pv_farneback_workspace_bytes(int64_t n_pairs, int32_t h, int32_t w,
+                                 const pv_farneback_params* params, size_t* bytes);
+
+/* replaces: cv.calcOpticalFlowFarneback(prev, next, None, ...) called once per
+ * consecutive pair by compute_optical_flow / _compute_optical_flow
+ * (notebooks/13_...ipynb:122-135, 175-240) — the whole process-pool fan-out is
+ * one batched launch sequence here.
+ *   prev, next : u8 images, row-major h×w.  Pair i = (group g = i / pairs_per_group,
+ *                q = i % pairs_per_group) reads prev + g*group_stride + q*prev_stride (bytes) and
+ *                next + g*group_stride + q*next_stride.  For B frame stacks [B,T,h,w]:
+ *                next = prev + h*w, strides h*w, pairs_per_group = T-1, group_stride = T*h*w.
+ *                pairs_per_group <= 0 means one group.
+ *   flow       : f32 [n_pairs, h, w, 2] (x then y displacement, OpenCV layout) */
+int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next,
+                          int64_t prev_stride, int64_t next_stride,
+                          int64_t pairs_per_group, int64_t group_stride,
+                          float* flow, int64_t n_pairs, int32_t h, int32_t w,
+                          const pv_farneback_params* params,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* replaces: weighted_average = np.average(flows, axis=0, weights=range(1,N+1)).astype(f32)
+ * (notebooks/optical_flow_1.ipynb:293-294).  flows: f32 [n_groups, n_per_group, elems];
+ * weights: host double[n_per_group] (NULL = 1..n_per_group); out: f32 [n_groups, elems].
+ * Accumulates in float64 in index order, divides by the float64 weight sum, rounds once. */
+int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host,
+                              float* out, int64_t n_groups, int32_t n_per_group,
+                              int64_t elems, void* stream);
+
+/* replaces: remap_image → cv.remap(src, map1 = meshgrid − flow, None, INTER_LINEAR,
+ * borderMode, borderValue)  (notebooks/13_...ipynb:259-281 BORDER_CONSTANT/NaN;
+ * notebooks/optical_flow_1.ipynb:415-430 BORDER_REPLICATE), batched over images
+ * and over the `n_steps` extrapolation steps of compute_optical_flow_predictions
+ * (notebooks/13_...ipynb:317-323: flow * forecast_step).
+ *   src  : [n_images, h, w]            image i at src + i*src_stride (elements)
+ *   flow : f32 [n_images, h, w, 2]     field i at flow + i*flow_stride (elements)
+ *   dst  : [n_images, n_steps, h, w]   image (i,s) at dst + i*dst_image_stride + s*dst_step_stride
+ *   step s uses the displacement field  flow * (step0 + s)  (f32 multiply),
+ *   map = (x − flow.x*k, y − flow.y*k) in f32, quantised to 1/32 px as cv.remap does. */
+int pv_remap_bilinear_f32(const float* src, int64_t src_stride,
+                          const float* flow, int64_t flow_stride,
+                          float* dst, int64_t dst_image_stride, int64_t dst_step_stride,
+                          int64_t n_images, int32_t n_steps, float step0,
+                          int32_t h, int32_t w, int border_mode, float border_value,
+                          void* stream);
+int pv_remap_bilinear_u8(const uint8_t* src, int64_t src_stride,
+                         const float* flow, int64_t flow_stride,
+                         uint8_t* dst, int64_t dst_image_stride, int64_t dst_step_stride,
+                         int64_t n_images, int32_t n_steps, float step0,
+                         int32_t h, int32_t w, int border_mode, uint8_t border_value,
+                         void* stream);
+
+/* replaces: satellite_data -= SAT_IMAGE_MEAN; satellite_data /= SAT_IMAGE_STD
+ * (notebooks/13_...ipynb:345-346, 463-464; per-channel constants
+ * predict_pv_yield/netcdf_dataset.py:19-32).  dst[i] = (src[i] − mean[c]) / std[c]
+ * with c = (i / inner) % n_channels; true f32 division.  mean/std: device f32[n_channels]. */
+int pv_normalise_i16(const int16_t* src, float* dst, size_t n, int64_t inner,
+                     int32_t n_channels, const float* mean, const float* std_,
+                     void* stream);
+int pv_normalise_f32(const float* src, float* dst, size_t n, int64_t inner,
+                     int32_t n_channels, const float* mean, const float* std_,
+                     void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Conv3D PV-yield model (SURVEY.md §8a rows a-2 … a-5)                      */
+/* ------------------------------------------------------------------------ */
+
+/* Geometry of one 3x3x3, stride-1, dilation-1, groups-1 convolution
+ * (F.conv3d as called by nn.Conv3d in predict_pv_yield/models/conv3d/model.py:80-90,117-120;
+ * padding (1,0,0): model_sat_nwp.py:102-115; padding 1: perceiver_conv3d_nwp_sat.py:47-53). */
+typedef struct pv_conv3d_dims {
+  int32_t batch;
+  int32_t c_in, c_out;
+  int32_t t_in, h_in, w_in;     /* input extent                       */
+  int32_t pad_t, pad_h, pad_w;  /* symmetric zero padding, 0..2       */
+  /* output extent is t_in + 2*pad_t - 2 etc. */
+} pv_conv3d_dims;
+
+/* ---- exact-fp32 path (reference layout NCDHW, fp32 FMA chains) --------- */
+/* y[B,Co,To,Ho,Wo] = conv3d(x[B,Ci,Ti,Hi,Wi], w[Co,Ci,3,3,3]) + bias, optional fused ReLU. */
+int pv_conv3d_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                      const pv_conv3d_dims* d, int relu, void* stream);
+/* dx = conv3d_transpose(dy ⊙ (y>0 if y_relu_mask given), w); `d` describes the FORWARD conv. */
+int pv_conv3d_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w,
+                           float* dx, const pv_conv3d_dims* d, void* stream);
+/* dw[Co,Ci,3,3,3], dbias[Co] (either may be NULL) from x and dy ⊙ (y>0). Overwrites. */
+int pv_conv3d_bwd_weight_f32(const float* x, const float* dy, const float* y_relu_mask,
+                             float* dw, float* dbias, const pv_conv3d_dims* d, void* stream);
+
+/* ---- bf16 MFMA path (activations NDHWC bf16, channel count padded) ------ */
+/* Channel padding used by the bf16 path for a layer with c real channels. */
+int pv_bf16_cpad(int32_t c);   /* 16 for c<=16, 32 for c<=32, else PV_ESIZE */
+
+/* x[B,C,T,H,W] f32 (reference layout) → xp[B,T,H,W,CPAD] bf16 (zero channel padding). */
+int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c,
+                                    int32_t t, int32_t h, int32_t w, void* stream);
+/* inverse, dropping pad channels (used by tests and for the fc head's NCDHW flatten). */
+int pv_unpack_ndhwc_bf16_to_ncdhw_f32(const uint16_t* xp, float* x, int32_t batch, int32_t c,
+                                      int32_t t, int32_t h, int32_t w, void* stream);
+
+/* out[B,T,H,W,32] bf16 (NDHWC) = dy[B,C,T,H,W] ⊙ (y[B,C,T,H,W] > 0), both bf16 NCDHW (y may be NULL):
+ * brings fc1's input gradient (flatten order of model.py:122) back to the conv layout. */
+int pv_repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* dy, const uint16_t* y_relu_mask, uint16_t* out,
+                                       int32_t batch, int32_t c, int32_t t, int32_t h, int32_t w,
+                                       void* stream);
+
+/* w[Co,Ci,3,3,3] f32 → MFMA A-fragments bf16 [27][CPAD/16][64 lanes][8]
+ * (transpose_flip != 0: the dgrad weights w'[ci][co][26-tap]). c_out must be 32 (or <=32, zero padded). */
+size_t pv_conv3d_packed_weight_elems(int32_t c_in_or_out_as_k);
+int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int32_t c_in,
+                               int transpose_flip, void* stream);
+
+/* y = relu?(conv3d(x ⊙ (gate>0 if gate given)) + bias), x/gate/y NDHWC bf16 with CPAD channels.
+ * The same kernel computes dgrad when fed dy (with pad 2−p) and transpose_flip weights.
+ * y_ncdhw != 0: y is written as [B,32,To,Ho,Wo] bf16 (the flatten order fc1 expects,
+ * predict_pv_yield/models/conv3d/model.py:122) instead of NDHWC. */
+int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp,
+                       const float* bias, uint16_t* y, const pv_conv3d_dims* d,
+                       int relu, int y_ncdhw, void* stream);
+
+/* dw[Co,Ci,3,3,3] f32 and dbias[Co] f32 from x (NDHWC bf16) and dy ⊙ (y>0) (NDHWC bf16).
+ * workspace: pv_conv3d_bwd_weight_bf16_workspace_bytes(d). Overwrites dw/dbias. */
+int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* bytes);
+int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint16_t* y_relu_mask,
+                              float* dw, float* dbias, const pv_conv3d_dims* d,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fully connected head (F.linear; model.py:92-103,125-152) ------------ */
+/* y[M,N] = relu?(x[M,K] · w[N,K]^T + bias[N]); fp32, split-K with fp32 slab reduce.
+ * workspace: pv_linear_workspace_bytes(M,N,K). */
+int pv_linear_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes);
+int pv_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                      int32_t m, int32_t n, int64_t k, int relu,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* dx[M,K] = (dy ⊙ (y>0))[M,N] · w[N,K]   (dx may be NULL) ;
+ * dw[N,K] = (dy ⊙ (y>0))^T · x ; db[N] = column sums   (dw/db may be NULL). */
+int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const float* y_relu_mask,
+                      float* dx, float* dw, float* db,
+                      int32_t m, int32_t n, int64_t k, void* stream);
+
+/* bf16 variants for the big fc1 (x bf16 [M,K], w bf16 shadow [N,K], fp32 accumulate/outputs).
+ * k must be a multiple of 8, m <= 128; workspace: pv_linear_bf16_workspace_bytes(M,N,K). */
+int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes);
+int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, float* y,
+                       int32_t m, int32_t n, int64_t k, int relu,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* dx bf16 [M,K] (may be NULL), dw f32 [N,K], db f32 [N]. */
+int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy,
+                       const float* y_relu_mask, uint16_t* dx, float* dw, float* db,
+                       int32_t m, int32_t n, int64_t k, void* stream);
+
+/* dst[i] = bf16(src[i]) (round to nearest even): first fill of a parameter's bf16 shadow; afterwards
+ * pv_adam_step_f32 keeps the shadow current. */
+int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
+
+/* ---- loss + optimiser ----------------------------------------------------- */
+/* replaces: F.mse_loss / (y_hat−y).abs().mean() and WeightedLosses.get_mse_exp/get_mae_exp
+ * (predict_pv_yield/models/base_model.py:98-103).  out: device f32[4] = {mse, nmae, mse_exp, mae_exp};
+ * grad (may be NULL): d nmae / d y_hat = sign(y_hat−y)/(m*n) * grad_scale.
+ * y is read with row stride y_row_stride (elements) so the slice y[:, -forecast_len:, 0]
+ * (base_model.py:95) needs no copy: element (i,j) at y[i*y_row_stride + j*y_col_stride]. */
+int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_stride,
+                           int64_t y_col_stride, int32_t m, int32_t n, float grad_scale,
+                           float* out4, float* grad, void* stream);
+
+/* replaces: torch.optim.Adam(lr=5e-4).step()  (base_model.py:255-257); one parameter tensor.
+ * Exactly torch's single-tensor Adam order of operations in f32 (no weight decay, no amsgrad);
+ * lr/betas/eps are doubles because torch derives step_size and the bias corrections in Python floats.
+ * The gradient is read as grad * grad_scale (1/world_size after a summing all-reduce).
+ * bf16_shadow (may be NULL) receives round-to-nearest-even bf16 of the updated parameter. */
+int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2,
+                     double eps, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PV_YIELD_HIP_H */

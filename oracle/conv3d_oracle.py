@@ -1,0 +1,143 @@
+"""CPU restatement of the Conv3D PV-yield model, its loss and its optimiser.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).  Never imported by
+the product package.
+
+The reference's arithmetic for this half of the path lives in third-party torch (unpinned:
+requirements.txt:10); the same torch build runs on CPU here, so this restatement calls the SAME
+operators the reference calls -- F.conv3d, F.relu, F.linear, torch.cat, torch.optim.Adam -- in the
+order of:
+  Model.__init__ / cnn_output_size   predict_pv_yield/models/conv3d/model.py:18-105 (:74-78)
+  Model.forward                      predict_pv_yield/models/conv3d/model.py:107-156
+  timestep arithmetic                predict_pv_yield/models/base_model.py:38-76
+  loss / metrics                     predict_pv_yield/models/base_model.py:91-103
+  optimiser                          predict_pv_yield/models/base_model.py:255-257
+Pinned against the reference's own module source executed under import stubs
+(tests/golden/make_conv3d_golden.py -> tests/golden/conv3d_small.npz, bit-exact on CPU).
+WeightedLosses (nowcasting_utils, absent) is restated from its documented behaviour: parity unpinned
+for mse_exp / mae_exp, which are logging-only.
+"""
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def timestep_arithmetic(history_minutes: int, forecast_minutes: int, output_variable: str = "pv_yield") -> Dict[str, int]:
+    """base_model.py:41-73."""
+    d = dict(
+        history_len_5=history_minutes // 5, forecast_len_5=forecast_minutes // 5,
+        history_len_30=history_minutes // 30, forecast_len_30=forecast_minutes // 30,
+        history_len_60=int(np.ceil(history_minutes / 60)), forecast_len_60=forecast_minutes // 60,
+    )
+    if output_variable == "pv_yield":
+        d.update(forecast_len=d["forecast_len_5"], history_len=d["history_len_5"], number_of_samples_per_batch=128)
+    else:
+        d.update(forecast_len=d["forecast_len_30"], history_len=d["history_len_30"], number_of_samples_per_batch=32)
+    d["number_of_pv_samples_per_batch"] = 128
+    return d
+
+
+class OracleConv3dModel(nn.Module):
+    """Same layer graph and attribute names (state_dict keys) as the reference Model."""
+
+    def __init__(self, include_pv_yield=True, include_nwp=True, forecast_minutes=30, history_minutes=60,
+                 number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=64, number_sat_channels=12,
+                 fc1_output_features=128, fc2_output_features=128, fc3_output_features=64,
+                 output_variable="pv_yield"):
+        super().__init__()
+        self.include_pv_yield, self.include_nwp = include_pv_yield, include_nwp
+        self.number_of_conv3d_layers = number_of_conv3d_layers
+        self.number_of_nwp_features = 10 * 19 * 2 * 2
+        self.output_variable = output_variable
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        self.cnn_output_size = (conv3d_channels * ((image_size_pixels - 2 * number_of_conv3d_layers) ** 2)
+                                * (self.forecast_len_5 + self.history_len_5 + 1 - 2 * number_of_conv3d_layers))
+        self.sat_conv0 = nn.Conv3d(number_sat_channels, conv3d_channels, (3, 3, 3), padding=0)
+        for i in range(number_of_conv3d_layers - 1):
+            setattr(self, f"conv3d_{i + 1}", nn.Conv3d(conv3d_channels, conv3d_channels, (3, 3, 3), padding=0))
+        self.fc1 = nn.Linear(self.cnn_output_size, fc1_output_features)
+        self.fc2 = nn.Linear(fc1_output_features, fc2_output_features)
+        fc3_in = fc2_output_features
+        if include_pv_yield:
+            fc3_in += self.number_of_samples_per_batch * (self.history_len_30 + 1)
+        if include_nwp:
+            self.fc_nwp = nn.Linear(self.number_of_nwp_features, 128)
+            fc3_in += 128
+        self.fc3 = nn.Linear(fc3_in, fc3_output_features)
+        self.fc4 = nn.Linear(fc3_output_features, self.forecast_len)
+
+    def forward(self, sat_data: torch.Tensor, yield_history: Optional[torch.Tensor] = None,
+                nwp: Optional[torch.Tensor] = None, return_activations: bool = False):
+        acts = []
+        sat_data = sat_data.float()
+        batch_size = sat_data.shape[0]
+        out = F.relu(self.sat_conv0(sat_data))
+        acts.append(out)
+        for i in range(self.number_of_conv3d_layers - 1):
+            out = F.relu(getattr(self, f"conv3d_{i + 1}")(out))
+            acts.append(out)
+        out = out.reshape(batch_size, self.cnn_output_size)
+        out = F.relu(self.fc1(out))
+        acts.append(out)
+        out = F.relu(self.fc2(out))
+        acts.append(out)
+        if self.include_pv_yield:
+            h = yield_history[:, : self.history_len_30 + 1].nan_to_num(nan=0.0).float()
+            out = torch.cat((out, h.reshape(h.shape[0], h.shape[1] * h.shape[2])), dim=1)
+        if self.include_nwp:
+            out = torch.cat((out, F.relu(self.fc_nwp(nwp.float().flatten(start_dim=1)))), dim=1)
+        out = F.relu(self.fc3(out))
+        acts.append(out)
+        out = self.fc4(out).reshape(batch_size, self.forecast_len)
+        return (out, acts) if return_activations else out
+
+
+def weighted_losses_weights(forecast_length: int) -> torch.Tensor:
+    """nowcasting_utils WeightedLosses: w_i = exp(-ln2 * i), normalised to mean 1 (f32)."""
+    w = torch.FloatTensor([math.exp(-math.log(2) * i) for i in range(forecast_length)])
+    return w / w.sum() * len(w)
+
+
+def forecast_losses(y_hat: torch.Tensor, y: torch.Tensor):
+    """(mse, nmae, mse_exp, mae_exp) as in base_model.py:98-103; nmae is the training loss (:146)."""
+    mse = F.mse_loss(y_hat, y)
+    nmae = (y_hat - y).abs().mean()
+    w = weighted_losses_weights(y_hat.shape[1]).to(y_hat.device)
+    mse_exp = torch.mean(w * (y_hat - y) ** 2)
+    mae_exp = torch.mean(w * torch.abs(y_hat - y))
+    return mse, nmae, mse_exp, mae_exp
+
+
+def select_target(yield_tensor: torch.Tensor, forecast_len: int, batch_size: int = 32) -> torch.Tensor:
+    """y = yield[0:batch_size, -forecast_len:, 0]  (base_model.py:91-95)."""
+    return yield_tensor[0:batch_size, -forecast_len:, 0]
+
+
+def make_optimizer(model: nn.Module) -> torch.optim.Optimizer:
+    """base_model.py:255-257."""
+    return torch.optim.Adam(model.parameters(), lr=0.0005)
+
+
+def train_steps(model: OracleConv3dModel, sat: torch.Tensor, yield_tensor: torch.Tensor, n_steps: int = 1,
+                optimizer: Optional[torch.optim.Optimizer] = None):
+    """n optimiser steps on one fixed batch; returns the list of nmae losses (before each step)."""
+    opt = optimizer or make_optimizer(model)
+    losses = []
+    for _ in range(n_steps):
+        opt.zero_grad()
+        y_hat = model(sat)
+        _, nmae, _, _ = forecast_losses(y_hat, select_target(yield_tensor, model.forecast_len))
+        nmae.backward()
+        opt.step()
+        losses.append(float(nmae))
+    return losses
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to bf16 and back: the operand rounding of the MFMA path."""
+    return t.to(torch.bfloat16).to(torch.float32)

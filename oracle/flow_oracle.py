@@ -1,0 +1,203 @@
+"""ctypes front-end of oracle/pv_oracle.c — the CPU restatement of the flow/warp half of the path.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).  The product
+package `predict_pv_yield_amd` never imports this module.
+
+Function names mirror the reference's notebook helpers:
+  convert_10bpp_to_uint8            notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:112-119
+  calc_optical_flow_farneback       cv.calcOpticalFlowFarneback call site, 13_...ipynb:133-135
+  weighted_average                  notebooks/optical_flow_1.ipynb:293-294
+  remap_image                       13_...ipynb:259-281 / optical_flow_1.ipynb:415-430
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpvoracle.so")
+
+BORDER_CONSTANT = 0
+BORDER_REPLICATE = 1
+OPTFLOW_FARNEBACK_GAUSSIAN = 256
+
+REFERENCE_FARNEBACK_KWARGS = dict(
+    pyr_scale=0.5, levels=2, winsize=40, iterations=3, poly_n=5, poly_sigma=0.7,
+    flags=OPTFLOW_FARNEBACK_GAUSSIAN,
+)
+
+
+class FarnebackParams(ctypes.Structure):
+    _fields_ = [
+        ("pyr_scale", ctypes.c_double),
+        ("levels", ctypes.c_int32),
+        ("winsize", ctypes.c_int32),
+        ("iterations", ctypes.c_int32),
+        ("poly_n", ctypes.c_int32),
+        ("poly_sigma", ctypes.c_double),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/pv_oracle.c with gcc (seconds)."""
+    src = os.path.join(_HERE, "pv_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.pvo_farneback_u8.restype = ctypes.c_int
+        _lib.pvo_farneback_num_levels.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def convert_10bpp_to_uint8(array: np.ndarray, mode: int = 0):
+    """mode 0: round_half_even(x/4) (nb-13); mode 1: trunc(x/1023*255) (optical_flow_1).
+    Returns (u8 array, out_of_range flag)."""
+    a = np.ascontiguousarray(array)
+    out = np.empty(a.shape, np.uint8)
+    flag = ctypes.c_int(0)
+    if a.dtype == np.int16:
+        lib().pvo_u8_from_10bit_i16(_p(a), _p(out), ctypes.c_size_t(a.size), ctypes.c_int(mode), ctypes.byref(flag))
+    else:
+        a = a.astype(np.float32, copy=False)
+        lib().pvo_u8_from_10bit_f32(_p(a), _p(out), ctypes.c_size_t(a.size), ctypes.c_int(mode), ctypes.byref(flag))
+    return out, bool(flag.value)
+
+
+def weighted_average(flows: np.ndarray, weights=None) -> np.ndarray:
+    """flows [N, ...] -> [...]; np.average(flows, axis=0, weights=1..N).astype(f32)."""
+    f = np.ascontiguousarray(flows, dtype=np.float32)
+    n = f.shape[0]
+    elems = int(np.prod(f.shape[1:]))
+    out = np.empty(f.shape[1:], np.float32)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    lib().pvo_weighted_mean_f32(_p(f), None if w is None else _p(w), _p(out), ctypes.c_int64(1),
+                                ctypes.c_int(n), ctypes.c_int64(elems))
+    return out
+
+
+def normalise(x: np.ndarray, mean: np.ndarray, std: np.ndarray, inner: int) -> np.ndarray:
+    a = np.ascontiguousarray(x)
+    mean = np.ascontiguousarray(mean, np.float32)
+    std = np.ascontiguousarray(std, np.float32)
+    out = np.empty(a.shape, np.float32)
+    fn = lib().pvo_normalise_i16 if a.dtype == np.int16 else lib().pvo_normalise_f32
+    if a.dtype != np.int16:
+        a = a.astype(np.float32, copy=False)
+    fn(_p(a), _p(out), ctypes.c_size_t(a.size), ctypes.c_int64(inner), ctypes.c_int(mean.size), _p(mean), _p(std))
+    return out
+
+
+def remap_image(image: np.ndarray, flow: np.ndarray, k: float = 1.0, border_mode: int = BORDER_CONSTANT,
+                border_value=np.nan, return_indices: bool = False):
+    """cv.remap(image, meshgrid - flow*k, None, INTER_LINEAR, border_mode, border_value)."""
+    h, w = flow.shape[:2]
+    fl = np.ascontiguousarray(flow, np.float32)
+    idx = np.empty((h, w, 4), np.int32) if return_indices else None
+    if image.dtype == np.uint8:
+        img = np.ascontiguousarray(image)
+        out = np.empty((h, w), np.uint8)
+        bv = 0 if (isinstance(border_value, float) and np.isnan(border_value)) else int(border_value)
+        lib().pvo_remap_bilinear_u8(_p(img), _p(fl), ctypes.c_float(k), _p(out), ctypes.c_int(h), ctypes.c_int(w),
+                                    ctypes.c_int(border_mode), ctypes.c_uint8(bv), None if idx is None else _p(idx))
+    else:
+        img = np.ascontiguousarray(image, np.float32)
+        out = np.empty((h, w), np.float32)
+        lib().pvo_remap_bilinear_f32(_p(img), _p(fl), ctypes.c_float(k), _p(out), ctypes.c_int(h), ctypes.c_int(w),
+                                     ctypes.c_int(border_mode), ctypes.c_float(border_value),
+                                     None if idx is None else _p(idx))
+    return (out, idx) if return_indices else out
+
+
+def calc_optical_flow_farneback(prev: np.ndarray, next_: np.ndarray, flow=None, pyr_scale=0.5, levels=2,
+                                winsize=40, iterations=3, poly_n=5, poly_sigma=0.7,
+                                flags=OPTFLOW_FARNEBACK_GAUSSIAN) -> np.ndarray:
+    assert prev.dtype == np.uint8 and next_.dtype == np.uint8 and prev.shape == next_.shape and prev.ndim == 2
+    p = np.ascontiguousarray(prev)
+    n = np.ascontiguousarray(next_)
+    h, w = p.shape
+    out = np.empty((h, w, 2), np.float32)
+    params = FarnebackParams(pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags)
+    rc = lib().pvo_farneback_u8(_p(p), _p(n), _p(out), ctypes.c_int(h), ctypes.c_int(w), ctypes.byref(params))
+    if rc != 0:
+        raise ValueError("oracle Farneback: unsupported parameters")
+    return out
+
+
+def farneback_num_levels(h, w, pyr_scale=0.5, levels=2) -> int:
+    return int(lib().pvo_farneback_num_levels(ctypes.c_int(h), ctypes.c_int(w), ctypes.c_double(pyr_scale),
+                                              ctypes.c_int(levels)))
+
+
+def farneback_poly_tables(n=5, sigma=0.7):
+    g = np.empty(2 * n + 1, np.float32)
+    xg = np.empty(2 * n + 1, np.float32)
+    xxg = np.empty(2 * n + 1, np.float32)
+    ig = np.empty(4, np.float64)
+    lib().pvo_farneback_poly_tables(ctypes.c_int(n), ctypes.c_double(sigma), _p(g), _p(xg), _p(xxg), _p(ig))
+    return g, xg, xxg, ig
+
+
+def farneback_window_taps(winsize=40):
+    k = np.empty(winsize // 2 + 1, np.float32)
+    lib().pvo_farneback_window_taps(ctypes.c_int(winsize), _p(k))
+    return k
+
+
+def farneback_level_polyexp(img: np.ndarray, level: int, pyr_scale=0.5, poly_n=5, poly_sigma=0.7):
+    """(I, R) of one pyramid level: blurred+resized image f32 [h',w'] and its 5-channel expansion."""
+    a = np.ascontiguousarray(img, np.uint8)
+    h, w = a.shape
+    scale = pyr_scale ** level
+    hh, ww = int(np.rint(h * scale)), int(np.rint(w * scale))
+    I = np.empty((hh, ww), np.float32)
+    R = np.empty((hh, ww, 5), np.float32)
+    lib().pvo_farneback_level_polyexp(_p(a), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(level),
+                                      ctypes.c_double(pyr_scale), ctypes.c_int(poly_n), ctypes.c_double(poly_sigma),
+                                      _p(I), _p(R))
+    return I, R
+
+
+# ------------------------------------------------------------------------------------------------
+# the joined nb-13 / optical_flow_1 pipeline on [T, H, W] stacks (CPU reference of config 3)
+# ------------------------------------------------------------------------------------------------
+def compute_optical_flow(sat_data_u8: np.ndarray, **kwargs) -> np.ndarray:
+    """[T,H,W] u8 -> [T-1,H,W,2] f32; one Farnebäck field per consecutive pair (13_...ipynb:175-240)."""
+    t = sat_data_u8.shape[0]
+    return np.stack([calc_optical_flow_farneback(sat_data_u8[i], sat_data_u8[i + 1], **kwargs) for i in range(t - 1)])
+
+
+def advect_frames(raw: np.ndarray, mean: np.ndarray, std: np.ndarray, n_future: int,
+                  border_mode: int = BORDER_REPLICATE, border_value=np.nan, **fb_kwargs) -> np.ndarray:
+    """Config-3 pipeline for raw 10-bit counts [B, T, C, H, W] (int16 or f32):
+    u8 = round(raw/4) -> Farnebäck per consecutive pair -> weighted mean (weights 1..T-1)
+    -> normalise -> remap(frame_t0, k*flow), k = 1..n_future.  Returns f32 [B, C, T+n_future, H, W]
+    (NCDHW, the layout predict_pv_yield/models/conv3d/model.py:112-114 consumes)."""
+    b, t, c, h, w = raw.shape
+    out = np.empty((b, c, t + n_future, h, w), np.float32)
+    for bi in range(b):
+        for ci in range(c):
+            stack = np.ascontiguousarray(raw[bi, :, ci])
+            u8, _ = convert_10bpp_to_uint8(stack, 0)
+            flows = compute_optical_flow(u8, **fb_kwargs)
+            mean_flow = weighted_average(flows)
+            norm = normalise(stack, mean[ci:ci + 1], std[ci:ci + 1], inner=stack.size)
+            out[bi, ci, :t] = norm
+            for k in range(1, n_future + 1):
+                out[bi, ci, t + k - 1] = remap_image(norm[t - 1], mean_flow, float(k), border_mode, border_value)
+    return out

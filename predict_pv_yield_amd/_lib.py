@@ -1,0 +1,135 @@
+"""Loader for the C-ABI library libpvyield_hip.so (include/pv_yield_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, or a call returns a negative status,
+a RuntimeError is raised.  Tensors cross the boundary as raw device pointers + sizes; the stream is
+torch's current HIP stream.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libpvyield_hip.so")
+CSRC_DIR = os.path.join(_PKG, "csrc")
+
+PV_BORDER_CONSTANT = 0
+PV_BORDER_REPLICATE = 1
+PV_U8_ROUND_DIV4 = 0
+PV_U8_TRUNC_SCALE = 1
+PV_OPTFLOW_FARNEBACK_GAUSSIAN = 256
+
+c_i32, c_i64, c_f32, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+c_vp, c_sz, c_int, c_u8 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint8
+
+
+class FarnebackParams(ctypes.Structure):
+    """struct pv_farneback_params: the positional arguments of cv.calcOpticalFlowFarneback."""
+    _fields_ = [("pyr_scale", c_f64), ("levels", c_i32), ("winsize", c_i32), ("iterations", c_i32),
+                ("poly_n", c_i32), ("poly_sigma", c_f64), ("flags", c_i32)]
+
+
+class Conv3dDims(ctypes.Structure):
+    """struct pv_conv3d_dims."""
+    _fields_ = [("batch", c_i32), ("c_in", c_i32), ("c_out", c_i32), ("t_in", c_i32), ("h_in", c_i32),
+                ("w_in", c_i32), ("pad_t", c_i32), ("pad_h", c_i32), ("pad_w", c_i32)]
+
+    def out_shape(self):
+        return (self.t_in + 2 * self.pad_t - 2, self.h_in + 2 * self.pad_h - 2, self.w_in + 2 * self.pad_w - 2)
+
+
+# name -> argtypes; every symbol declared in include/pv_yield_hip.h (tests/test_abi.py checks both ways)
+_PFB = ctypes.POINTER(FarnebackParams)
+_PCD = ctypes.POINTER(Conv3dDims)
+SIGNATURES = {
+    "pv_abi_version": [],
+    "pv_last_error": [],
+    "pv_u8_from_10bit_i16": [c_vp, c_vp, c_sz, c_int, c_vp, c_vp],
+    "pv_u8_from_10bit_f32": [c_vp, c_vp, c_sz, c_int, c_vp, c_vp],
+    "pv_farneback_workspace_bytes": [c_i64, c_i32, c_i32, _PFB, ctypes.POINTER(c_sz)],
+    "pv_farneback_batch_u8": [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_i32, c_i32, _PFB, c_vp, c_sz, c_vp],
+    "pv_flow_weighted_mean_f32": [c_vp, ctypes.POINTER(c_f64), c_vp, c_i64, c_i32, c_i64, c_vp],
+    "pv_remap_bilinear_f32": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_i32, c_i32,
+                              c_int, c_f32, c_vp],
+    "pv_remap_bilinear_u8": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_i32, c_i32,
+                             c_int, c_u8, c_vp],
+    "pv_normalise_i16": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
+    "pv_normalise_f32": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
+    "pv_conv3d_fwd_f32": [c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_vp],
+    "pv_conv3d_bwd_data_f32": [c_vp, c_vp, c_vp, c_vp, _PCD, c_vp],
+    "pv_conv3d_bwd_weight_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp],
+    "pv_bf16_cpad": [c_i32],
+    "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_unpack_ndhwc_bf16_to_ncdhw_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_repack_gate_ncdhw_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_conv3d_packed_weight_elems": [c_i32],
+    "pv_conv3d_pack_weight_bf16": [c_vp, c_vp, c_i32, c_i32, c_int, c_vp],
+    "pv_conv3d_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_int, c_vp],
+    "pv_conv3d_bwd_weight_bf16_workspace_bytes": [_PCD, ctypes.POINTER(c_sz)],
+    "pv_conv3d_bwd_weight_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
+    "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
+    "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
+    "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_linear_bf16_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
+    "pv_linear_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
+    "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],
+    "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
+    "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
+}
+_RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz}
+
+
+def build_library(verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into lib/libpvyield_hip.so (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC_DIR, "-j8"]
+    if not verbose:
+        args.append("-s")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def get_lib():
+    """Load the library once; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C {CSRC_DIR}`). predict_pv_yield_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+        if lib.pv_abi_version() != 1:
+            raise RuntimeError("libpvyield_hip.so ABI version mismatch; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = get_lib().pv_last_error()
+        raise RuntimeError(f"libpvyield_hip {what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr():
+    """torch's current HIP stream as a void* for the C ABI."""
+    import torch
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return c_vp(0) if t is None else c_vp(t.data_ptr())
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("predict_pv_yield_amd: tensors must live on the MI355X (no CPU path is provided)")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("predict_pv_yield_amd: tensors crossing the C ABI must be contiguous")

@@ -1,0 +1,444 @@
+// bf16 MFMA Conv3D (3x3x3, stride 1) for gfx950 — the throughput path.
+// replaces: F.conv3d + F.relu forward and dgrad as called by
+//   predict_pv_yield/models/conv3d/model.py:80-90,117-120 (and model_sat_nwp.py:102-115 via pad_t = 1).
+//
+// Layout: activations NDHWC bf16 with the channel count padded to CPAD (16 or 32): one voxel is a
+// 32/64-byte vector, which is exactly the k-slice an MFMA operand lane wants.
+//
+// Kernel structure (conv3d_fwd_bf16_kernel):
+//   * one workgroup (4 waves, one per SIMD, 1 WG per CU) owns an output tile of 8 rows x 64 columns
+//     of one sample and MARCHES OVER TIME: three input time-slices (10 rows x 64 voxels each) live
+//     in an LDS ring, so every input voxel is fetched once per tile and reused by all 27 taps;
+//   * the next slice is prefetched global->registers while the MFMAs of the current one run
+//     (issue-early / write-late), 2 barriers per output slice;
+//   * out[cout, voxel] = sum_k W[cout, k] * X[k, voxel]: weights are the MFMA A operand and stay in
+//     registers for the whole kernel (27 x CPAD/16 fragments = 216 VGPR/AGPR at CPAD = 32, which is
+//     why the kernel runs one wave per SIMD with the full 512-register file); activations are the B
+//     operand, one ds_read_b128 per 32 voxels x 8 channels, reused by the 3 kh taps that share an
+//     input row (a wave owns 4 output rows x 32 columns);
+//   * the LDS image is XOR-swizzled on 16-byte chunks so that the 16 lanes of a ds_read_b128 group
+//     hit 16 distinct chunks of the 256-byte bank row for every tap shift;
+//   * bias is the initial accumulator, ReLU + bf16 rounding are fused into the epilogue; the last
+//     layer can write NCDHW (the flatten order fc1 expects, model.py:122).
+// dgrad is the same kernel on dy (zero padding 2-p, ReLU gate applied while staging) with
+// channel-swapped, mirrored weights (pv_conv3d_pack_weight_bf16(..., transpose_flip = 1)).
+#include "pv_common.h"
+
+namespace pv {
+
+constexpr int TR = 8;          // output rows per workgroup tile
+constexpr int TRI = TR + 2;    // input rows per slice
+constexpr int TW = 64;         // columns per LDS row (62 valid output columns per tile)
+constexpr int TW_VALID = TW - 2;
+
+__device__ __forceinline__ uint32_t gate_word(uint32_t x, uint32_t g) {
+  // keep each bf16 half of x only where the matching half of g is > 0
+  uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
+  uint32_t hi = ((g & 0x7fff0000u) != 0u && (g & 0x80000000u) == 0u) ? 0xffff0000u : 0u;
+  return x & (lo | hi);
+}
+
+template <int CPAD>
+struct SliceGeom {
+  static constexpr int NCH = CPAD / 8;            // 16-byte chunks per voxel
+  static constexpr int VPR = 16 / NCH;            // voxels per 256-byte bank row
+  static constexpr int VOX_BYTES = CPAD * 2;
+  static constexpr int ROW_BYTES = TW * VOX_BYTES;
+  static constexpr int SLOT_BYTES = TRI * ROW_BYTES;
+  static constexpr int CHUNKS = TRI * TW * NCH;   // 16-byte chunks per slice
+  static constexpr int NLOAD = CHUNKS / 256;      // chunks per thread
+  __device__ static __forceinline__ int swz(int v) { return (v / VPR) % NCH; }
+};
+
+template <int CPAD>
+__global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate, const uint16_t* __restrict__ wp,
+    const float* __restrict__ bias, uint16_t* __restrict__ y, int t_in, int h_in, int w_in, int t_out,
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int y_ncdhw, int n_colblk,
+    int t_chunk, int c_out) {
+  using G = SliceGeom<CPAD>;
+  constexpr int KS = CPAD / 16;
+  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * G::SLOT_BYTES + 512];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int ws = wave & 1;   // column segment (32 columns)
+  const int wr = wave >> 1;  // row half (4 rows)
+
+  const int rowblk = blockIdx.x / n_colblk;
+  const int colblk = blockIdx.x - rowblk * n_colblk;
+  const int h0 = rowblk * TR;          // first output row of the tile
+  const int w0 = colblk * TW_VALID;    // first output column of the tile
+  const int b = blockIdx.z;
+  const int tc0 = blockIdx.y * t_chunk;
+  const int tc1 = min(tc0 + t_chunk, t_out);
+  if (tc0 >= tc1) return;
+
+  // zero the slack behind the ring (tap reads of masked columns may run 2 voxels past a slot)
+  if (tid < 128) reinterpret_cast<uint32_t*>(lds + 3 * G::SLOT_BYTES)[tid] = 0u;
+
+  // ---- weights: A fragments, resident in registers ------------------------------------------
+  bf16x8 wfrag[27][KS];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wfrag[tap][ks] = *reinterpret_cast<const bf16x8*>(wp + ((size_t)(tap * KS + ks) * 64 + lane) * 8);
+
+  // ---- per-lane LDS read offsets (bytes inside a slot row 0) --------------------------------
+  int voff[3][KS];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    int v = 32 * ws + r + kw;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) voff[kw][ks] = v * G::VOX_BYTES + (((ks * 2 + hh) ^ G::swz(v)) << 4);
+  }
+
+  // ---- staging: which 16-byte chunks this thread moves --------------------------------------
+  const size_t x_plane = (size_t)h_in * w_in * CPAD;  // elements per (b, t) slice
+  const uint16_t* xb = x + (size_t)b * t_in * x_plane;
+  const uint16_t* gb = gate ? gate + (size_t)b * t_in * x_plane : nullptr;
+
+  u32x4 stage[G::NLOAD];
+  auto load_slice = [&](int s) {
+    // slice index s = input time + pad_t  (s in [tc0, tc1 + 2))
+    const int ti = s - pad_t;
+    const bool t_ok = (unsigned)ti < (unsigned)t_in;
+#pragma unroll
+    for (int i = 0; i < G::NLOAD; ++i) {
+      const int id = i * 256 + tid;
+      const int row = id / (TW * G::NCH);
+      const int rem = id - row * (TW * G::NCH);
+      const int col = rem / G::NCH;
+      const int c = rem - col * G::NCH;
+      const int hi = h0 - pad_h + row;
+      const int wi = w0 - pad_w + col;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t_ok && (unsigned)hi < (unsigned)h_in && (unsigned)wi < (unsigned)w_in) {
+        const size_t off = (size_t)ti * x_plane + ((size_t)hi * w_in + wi) * CPAD + c * 8;
+        v = *reinterpret_cast<const u32x4*>(xb + off);
+        if (gb) {
+          u32x4 g = *reinterpret_cast<const u32x4*>(gb + off);
+          v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
+          v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
+        }
+      }
+      stage[i] = v;
+    }
+  };
+  auto store_slice = [&](int s) {
+    unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
+#pragma unroll
+    for (int i = 0; i < G::NLOAD; ++i) {
+      const int id = i * 256 + tid;
+      const int row = id / (TW * G::NCH);
+      const int rem = id - row * (TW * G::NCH);
+      const int col = rem / G::NCH;
+      const int c = rem - col * G::NCH;
+      const int v = row * TW + col;
+      *reinterpret_cast<u32x4*>(slot + v * G::VOX_BYTES + ((c ^ G::swz(v)) << 4)) = stage[i];
+    }
+  };
+
+  // ---- bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh ---------
+  f32x16 acc0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int co = (j & 3) + 8 * (j >> 2) + 4 * hh;
+    acc0[j] = (bias && co < c_out) ? bias[co] : 0.f;
+  }
+
+  // ---- prologue: two slices into the ring, third in flight ------------------------------------
+  load_slice(tc0);
+  store_slice(tc0);
+  load_slice(tc0 + 1);
+  store_slice(tc0 + 1);
+  load_slice(tc0 + 2);
+
+  const int plane_out = h_out * w_out;
+  for (int t = tc0; t < tc1; ++t) {
+    store_slice(t + 2);
+    __syncthreads();
+    if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
+
+    f32x16 acc[4] = {acc0, acc0, acc0, acc0};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const unsigned char* slot = lds + ((t + kt) % 3) * G::SLOT_BYTES + (4 * wr) * G::ROW_BYTES;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const unsigned char* p = slot + voff[kw][ks];
+          bf16x8 bfr[6];
+#pragma unroll
+          for (int ir = 0; ir < 6; ++ir) bfr[ir] = *reinterpret_cast<const bf16x8*>(p + ir * G::ROW_BYTES);
+#pragma unroll
+          for (int ir = 0; ir < 6; ++ir) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              const int orow = ir - kh;
+              if (orow >= 0 && orow < 4)
+                acc[orow] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kt * 9 + kh * 3 + kw][ks], bfr[ir],
+                                                                    acc[orow], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: ReLU, bf16, store ---------------------------------------------------------
+    const int col_t = 32 * ws + r;  // column inside the tile
+    const int wo = w0 + col_t;
+    const bool col_ok = col_t < TW_VALID && wo < w_out;
+#pragma unroll
+    for (int orow = 0; orow < 4; ++orow) {
+      const int ho = h0 + 4 * wr + orow;
+      if (col_ok && ho < h_out) {
+        f32x16 a = acc[orow];
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;
+        }
+        if (!y_ncdhw) {
+          uint16_t* yp = y + ((((size_t)b * t_out + t) * h_out + ho) * w_out + wo) * 32 + 4 * hh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32x2 o;
+            o[0] = (uint32_t)f32_to_bf16_bits(a[4 * q]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 1]) << 16);
+            o[1] = (uint32_t)f32_to_bf16_bits(a[4 * q + 2]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 3]) << 16);
+            *reinterpret_cast<u32x2*>(yp + 8 * q) = o;
+          }
+        } else {
+          const size_t vox = (size_t)t * plane_out + (size_t)ho * w_out + wo;
+          const size_t cstride = (size_t)t_out * plane_out;
+          uint16_t* yp = y + (size_t)b * c_out * cstride + vox;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int co = (j & 3) + 8 * (j >> 2) + 4 * hh;
+            if (co < c_out) yp[(size_t)co * cstride] = f32_to_bf16_bits(a[j]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading slot t%3 before the next store_slice(t+3)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout packers
+// ---------------------------------------------------------------------------------------------
+// x[B,C,T,H,W] f32 -> xp[B,T,H,W,CPAD] bf16; one thread = one voxel (reads are coalesced per channel
+// plane, the CPAD*2-byte voxel is written with 16-byte stores)
+template <int CPAD>
+__global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_kernel(const float* __restrict__ x,
+                                                                   uint16_t* __restrict__ xp, int c,
+                                                                   long long vox_per_sample, long long total_vox) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vox; i += stride) {
+    long long bi = i / vox_per_sample;
+    long long v = i - bi * vox_per_sample;
+    const float* src = x + (size_t)bi * c * vox_per_sample + v;
+    uint32_t words[CPAD / 2];
+#pragma unroll
+    for (int k = 0; k < CPAD / 2; ++k) {
+      float a = (2 * k < c) ? src[(size_t)(2 * k) * vox_per_sample] : 0.f;
+      float bq = (2 * k + 1 < c) ? src[(size_t)(2 * k + 1) * vox_per_sample] : 0.f;
+      words[k] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(bq) << 16);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(xp + (size_t)i * CPAD);
+#pragma unroll
+    for (int k = 0; k < CPAD / 8; ++k) {
+      u32x4 o = {words[4 * k], words[4 * k + 1], words[4 * k + 2], words[4 * k + 3]};
+      dst[k] = o;
+    }
+  }
+}
+
+template <int CPAD>
+__global__ __launch_bounds__(256) void unpack_ndhwc_to_ncdhw_kernel(const uint16_t* __restrict__ xp,
+                                                                     float* __restrict__ x, int c,
+                                                                     long long vox_per_sample, long long total_vox) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vox; i += stride) {
+    long long bi = i / vox_per_sample;
+    long long v = i - bi * vox_per_sample;
+    const uint16_t* src = xp + (size_t)i * CPAD;
+    float* dst = x + (size_t)bi * c * vox_per_sample + v;
+    for (int k = 0; k < c; ++k) dst[(size_t)k * vox_per_sample] = bf16_bits_to_f32(src[k]);
+  }
+}
+
+// w[Co,Ci,27] f32 -> A fragments [27][KS][64 lanes][8] bf16:
+//   lane (r = lane&31, h = lane>>5), element j  <-  W[cout = r][cin = ks*16 + 8*h + j][tap]
+// transpose_flip: the dgrad operator, W'[cout' = ci][cin' = co][tap] = W[co][ci][26 - tap]
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp,
+                                                           int c_out, int c_in, int ks_count, int transpose_flip) {
+  const int total = 27 * ks_count * 64 * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int j = i & 7;
+    int lane = (i >> 3) & 63;
+    int ks = (i >> 9) % ks_count;
+    int tap = (i >> 9) / ks_count;
+    int row = lane & 31;                       // MFMA A row = output channel of this operator
+    int k = ks * 16 + 8 * (lane >> 5) + j;     // contraction index = input channel of this operator
+    float v = 0.f;
+    if (!transpose_flip) {
+      if (row < c_out && k < c_in) v = w[((size_t)row * c_in + k) * 27 + tap];
+    } else {
+      // operator maps c_out (dy channels, k) -> c_in (dx channels, row)
+      if (row < c_in && k < c_out) v = w[((size_t)k * c_in + row) * 27 + (26 - tap)];
+    }
+    wp[i] = f32_to_bf16_bits(v);
+  }
+}
+
+// dy_eff[B,T,H,W,32] bf16 = NDHWC( dy[B,32,T,H,W] ⊙ (y[B,32,T,H,W] > 0) ), both bf16 NCDHW.
+// Used to bring fc1's input gradient (flatten order) back to the conv layout.
+__global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* __restrict__ dy,
+                                                                        const uint16_t* __restrict__ yv,
+                                                                        uint16_t* __restrict__ out, int c,
+                                                                        long long vox_per_sample, long long total_vox) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vox; i += stride) {
+    long long bi = i / vox_per_sample;
+    long long v = i - bi * vox_per_sample;
+    size_t base = (size_t)bi * c * vox_per_sample + v;
+    uint32_t words[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      uint32_t lo = 0, hi = 0;
+      if (2 * k < c) {
+        uint16_t d = dy[base + (size_t)(2 * k) * vox_per_sample];
+        uint16_t g = yv ? yv[base + (size_t)(2 * k) * vox_per_sample] : (uint16_t)0x3f80;
+        lo = ((g & 0x7fff) != 0 && (g & 0x8000) == 0) ? d : 0;
+      }
+      if (2 * k + 1 < c) {
+        uint16_t d = dy[base + (size_t)(2 * k + 1) * vox_per_sample];
+        uint16_t g = yv ? yv[base + (size_t)(2 * k + 1) * vox_per_sample] : (uint16_t)0x3f80;
+        hi = ((g & 0x7fff) != 0 && (g & 0x8000) == 0) ? d : 0;
+      }
+      words[k] = lo | (hi << 16);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)i * 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      u32x4 o = {words[4 * k], words[4 * k + 1], words[4 * k + 2], words[4 * k + 3]};
+      dst[k] = o;
+    }
+  }
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_bf16_cpad(int32_t c) {
+  if (c <= 0) return PV_EINVAL;
+  if (c <= 16) return 16;
+  if (c <= 32) return 32;
+  return PV_ESIZE;
+}
+
+int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c, int32_t t, int32_t h,
+                                    int32_t w, void* stream) {
+  PV_REQUIRE(x && xp, PV_EINVAL, "pv_pack_ncdhw_f32_to_ndhwc_bf16: null pointer");
+  int cpad = pv_bf16_cpad(c);
+  PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_ncdhw_f32_to_ndhwc_bf16: c=%d not in 1..32", c);
+  long long vps = (long long)t * h * w, total = vps * batch;
+  PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_ncdhw_f32_to_ndhwc_bf16: empty tensor");
+  unsigned grid = stream_grid((size_t)total, 256);
+  if (cpad == 16)
+    hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xp, c, vps, total);
+  else
+    hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), x, xp, c, vps, total);
+  return check_launch("pv_pack_ncdhw_f32_to_ndhwc_bf16");
+}
+
+int pv_unpack_ndhwc_bf16_to_ncdhw_f32(const uint16_t* xp, float* x, int32_t batch, int32_t c, int32_t t, int32_t h,
+                                      int32_t w, void* stream) {
+  PV_REQUIRE(x && xp, PV_EINVAL, "pv_unpack_ndhwc_bf16_to_ncdhw_f32: null pointer");
+  int cpad = pv_bf16_cpad(c);
+  PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_unpack_ndhwc_bf16_to_ncdhw_f32: c=%d not in 1..32", c);
+  long long vps = (long long)t * h * w, total = vps * batch;
+  PV_REQUIRE(total > 0, PV_EINVAL, "pv_unpack_ndhwc_bf16_to_ncdhw_f32: empty tensor");
+  unsigned grid = stream_grid((size_t)total, 256);
+  if (cpad == 16)
+    hipLaunchKernelGGL(unpack_ndhwc_to_ncdhw_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), xp, x, c, vps, total);
+  else
+    hipLaunchKernelGGL(unpack_ndhwc_to_ncdhw_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), xp, x, c, vps, total);
+  return check_launch("pv_unpack_ndhwc_bf16_to_ncdhw_f32");
+}
+
+int pv_repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* dy, const uint16_t* y_relu_mask, uint16_t* out, int32_t batch,
+                                       int32_t c, int32_t t, int32_t h, int32_t w, void* stream) {
+  PV_REQUIRE(dy && out, PV_EINVAL, "pv_repack_gate_ncdhw_to_ndhwc_bf16: null pointer");
+  PV_REQUIRE(c > 0 && c <= 32, PV_ESIZE, "pv_repack_gate_ncdhw_to_ndhwc_bf16: c=%d not in 1..32", c);
+  long long vps = (long long)t * h * w, total = vps * batch;
+  PV_REQUIRE(total > 0, PV_EINVAL, "pv_repack_gate_ncdhw_to_ndhwc_bf16: empty tensor");
+  hipLaunchKernelGGL(repack_gate_ncdhw_to_ndhwc_bf16, dim3(stream_grid((size_t)total, 256)), dim3(256), 0,
+                     as_stream(stream), dy, y_relu_mask, out, c, vps, total);
+  return check_launch("pv_repack_gate_ncdhw_to_ndhwc_bf16");
+}
+
+size_t pv_conv3d_packed_weight_elems(int32_t k_channels) {
+  int cpad = pv_bf16_cpad(k_channels);
+  if (cpad <= 0) return 0;
+  return (size_t)27 * (cpad / 16) * 64 * 8;
+}
+
+int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int32_t c_in, int transpose_flip,
+                               void* stream) {
+  PV_REQUIRE(w && wp, PV_EINVAL, "pv_conv3d_pack_weight_bf16: null pointer");
+  PV_REQUIRE(c_out > 0 && c_out <= 32 && c_in > 0 && c_in <= 32, PV_ESIZE,
+             "pv_conv3d_pack_weight_bf16: channels (%d,%d) must be in 1..32", c_out, c_in);
+  int kch = transpose_flip ? c_out : c_in;  // contraction channels of the packed operator
+  int ks = pv_bf16_cpad(kch) / 16;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(27 * ks * 2), dim3(256), 0, as_stream(stream), w, wp, c_out, c_in, ks,
+                     transpose_flip ? 1 : 0);
+  return check_launch("pv_conv3d_pack_weight_bf16");
+}
+
+int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp, const float* bias, uint16_t* y,
+                       const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream) {
+  PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_bf16: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_fwd_bf16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_fwd_bf16: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_bf16: input smaller than the kernel");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_fwd_bf16: batch too large for grid.z");
+  const int cpad = pv_bf16_cpad(d->c_in);
+  const int n_rowblk = (ho + TR - 1) / TR;
+  const int n_colblk = (wo + TW_VALID - 1) / TW_VALID;
+  // split the time march only when the (sample, tile) grid alone cannot fill 256 CUs
+  long long tiles = (long long)d->batch * n_rowblk * n_colblk;
+  int n_tchunk = 1;
+  if (tiles < 256) {
+    n_tchunk = (int)((256 + tiles - 1) / tiles);
+    int max_chunks = (to + 1) / 2;  // at least 2 output slices per chunk
+    if (max_chunks < 1) max_chunks = 1;
+    if (n_tchunk > max_chunks) n_tchunk = max_chunks;
+  }
+  const int t_chunk = (to + n_tchunk - 1) / n_tchunk;
+  n_tchunk = (to + t_chunk - 1) / t_chunk;
+  dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
+  hipStream_t st = as_stream(stream);
+  if (cpad == 16) {
+    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<16>, grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in, d->h_in,
+                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, y_ncdhw ? 1 : 0, n_colblk,
+                       t_chunk, d->c_out);
+  } else {
+    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<32>, grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in, d->h_in,
+                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, y_ncdhw ? 1 : 0, n_colblk,
+                       t_chunk, d->c_out);
+  }
+  return check_launch("pv_conv3d_fwd_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+// bf16 MFMA weight gradient of the 3x3x3 Conv3D (autograd wgrad of F.conv3d,
+// predict_pv_yield/models/conv3d/model.py:117-120 under loss.backward()).
+//
+//   dW[co][tap][ci] = sum_voxels dYeff[v][co] * X[v + tap][ci],   dYeff = dY ⊙ (Y > 0)
+//
+// GEMM view: M = co (32), N = ci (CPAD), K = voxels.  The contraction index is the VOXEL, while both
+// operands are stored voxel-major / channel-minor (NDHWC), i.e. transposed with respect to what an
+// MFMA lane wants (8 consecutive k per lane).  gfx950's ds_read_b64_tr_b16 does that transpose on the
+// LDS read: a 16-lane group fetches a 4-voxel x 16-channel block and every lane receives one channel
+// of the 4 voxels.  Two such reads = one 32x32x16 operand fragment.
+//
+// Structure: same time-marching tile as the forward kernel (8 output rows x 64 columns, X ring of
+// three slices in LDS, dY tile of the current slice beside it); the 27 taps are dealt round-robin to
+// the 4 waves (7,7,7,6 accumulators of 32x32 f32); wave 3's spare accumulator multiplies dYeff by a
+// fragment of ones, which yields dbias for free.  Each workgroup writes one f32 partial slab; a
+// second kernel sums the slabs in a fixed order (deterministic, no atomics).
+#include "pv_common.h"
+
+namespace pv {
+
+constexpr int WTR = 8;
+constexpr int WTRI = WTR + 2;
+constexpr int WTW = 64;
+constexpr int WTW_VALID = WTW - 2;
+constexpr int SLAB_ELEMS = 28 * 32 * 32;  // 27 taps + ones-tap, [co][ci] each
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ uint32_t wg_gate_word(uint32_t x, uint32_t g) {
+  uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
+  uint32_t hi = ((g & 0x7fff0000u) != 0u && (g & 0x80000000u) == 0u) ? 0xffff0000u : 0u;
+  return x & (lo | hi);
+}
+
+template <int CPAD>
+__global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint16_t* __restrict__ ymask,
+    float* __restrict__ slabs, int t_in, int h_in, int w_in, int t_out, int h_out, int w_out, int pad_t,
+    int pad_h, int pad_w, int n_colblk, int t_chunk) {
+  constexpr int NCH = CPAD / 8;
+  constexpr int VPR = 16 / NCH;
+  constexpr int VOXB = CPAD * 2;
+  constexpr int ROWB = WTW * VOXB;
+  constexpr int SLOTB = WTRI * ROWB;
+  constexpr int NLOAD_X = WTRI * WTW * NCH / 256;
+  // dY tile: always 32 channels
+  constexpr int DROWB = WTW * 64;
+  constexpr int DTILEB = WTR * DROWB;
+  constexpr int NLOAD_D = WTR * WTW * 4 / 256;
+  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * SLOTB + 512 + DTILEB];
+  unsigned char* lds_dy = lds + 3 * SLOTB + 512;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // transposed-read roles of this lane
+  const int grp = lane >> 4;        // 16-lane group
+  const int qi = (lane & 15) >> 2;  // block row (voxel) this lane addresses
+  const int pi = lane & 3;          // 4-channel piece this lane addresses
+  const int hh = grp >> 1;          // k half (voxels 8*hh ..)
+  const int cb = 16 * (grp & 1);    // channel base of the group
+
+  const int rowblk = blockIdx.x / n_colblk;
+  const int colblk = blockIdx.x - rowblk * n_colblk;
+  const int h0 = rowblk * WTR;
+  const int w0 = colblk * WTW_VALID;
+  const int b = blockIdx.z;
+  const int tc0 = blockIdx.y * t_chunk;
+  const int tc1 = min(tc0 + t_chunk, t_out);
+  const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* slab = slabs + (size_t)wg_id * SLAB_ELEMS;
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  if (tc0 < tc1) {
+    if (tid < 128) reinterpret_cast<uint32_t*>(lds + 3 * SLOTB)[tid] = 0u;
+
+    // ---- per-lane byte offsets of the transposed reads --------------------------------------
+    // dY (A operand, 32 channels): voxel column 8*hh + 4*s + qi, channels cb + 4*pi .. +3
+    int aoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      int v = 8 * hh + 4 * s + qi;
+      int chunk = (cb + 4 * pi) >> 3;
+      aoff[s] = v * 64 + ((chunk ^ ((v >> 2) & 3)) << 4) + (pi & 1) * 8;
+    }
+    // X (B operand) per tap of this wave: tap = wave + 4*i
+    int boff[7][2];
+    int bkt[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      int tap = wave + 4 * i;
+      if (tap > 26) tap = 26;
+      int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      bkt[i] = kt;
+      const int cbx = (CPAD == 16) ? 0 : cb;  // CPAD 16: upper groups re-read channels 0..15, zeroed below
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        int v = kw + 8 * hh + 4 * s + qi;
+        int chunk = (cbx + 4 * pi) >> 3;
+        boff[i][s] = kh * ROWB + v * VOXB + ((chunk ^ ((v / VPR) % NCH)) << 4) + (pi & 1) * 8;
+      }
+    }
+    const bool b_zero = (CPAD == 16) && (grp & 1);  // columns 16..31 of the B operand do not exist
+
+    // ---- staging -----------------------------------------------------------------------------
+    const size_t x_plane = (size_t)h_in * w_in * CPAD;
+    const uint16_t* xb = x + (size_t)b * t_in * x_plane;
+    const size_t d_plane = (size_t)h_out * w_out * 32;
+    const uint16_t* db = dy + (size_t)b * t_out * d_plane;
+    const uint16_t* mb = ymask ? ymask + (size_t)b * t_out * d_plane : nullptr;
+
+    u32x4 stage_x[NLOAD_X];
+    u32x4 stage_d[NLOAD_D];
+    auto load_x = [&](int s) {
+      const int ti = s - pad_t;
+      const bool t_ok = (unsigned)ti < (unsigned)t_in;
+#pragma unroll
+      for (int i = 0; i < NLOAD_X; ++i) {
+        const int id = i * 256 + tid;
+        const int row = id / (WTW * NCH);
+        const int rem = id - row * (WTW * NCH);
+        const int col = rem / NCH;
+        const int c = rem - col * NCH;
+        const int hi = h0 - pad_h + row;
+        const int wi = w0 - pad_w + col;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (t_ok && (unsigned)hi < (unsigned)h_in && (unsigned)wi < (unsigned)w_in)
+          v = *reinterpret_cast<const u32x4*>(xb + (size_t)ti * x_plane + ((size_t)hi * w_in + wi) * CPAD + c * 8);
+        stage_x[i] = v;
+      }
+    };
+    auto store_x = [&](int s) {
+      unsigned char* slot = lds + (s % 3) * SLOTB;
+#pragma unroll
+      for (int i = 0; i < NLOAD_X; ++i) {
+        const int id = i * 256 + tid;
+        const int row = id / (WTW * NCH);
+        const int rem = id - row * (WTW * NCH);
+        const int col = rem / NCH;
+        const int c = rem - col * NCH;
+        const int v = row * WTW + col;
+        *reinterpret_cast<u32x4*>(slot + v * VOXB + ((c ^ ((v / VPR) % NCH)) << 4)) = stage_x[i];
+      }
+    };
+    auto load_d = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < NLOAD_D; ++i) {
+        const int id = i * 256 + tid;
+        const int row = id / (WTW * 4);
+        const int rem = id - row * (WTW * 4);
+        const int col = rem / 4;
+        const int c = rem - col * 4;
+        const int ho = h0 + row;
+        const int wo = w0 + col;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ho < h_out && col < WTW_VALID && wo < w_out) {
+          const size_t off = (size_t)t * d_plane + ((size_t)ho * w_out + wo) * 32 + c * 8;
+          v = *reinterpret_cast<const u32x4*>(db + off);
+          if (mb) {
+            u32x4 g = *reinterpret_cast<const u32x4*>(mb + off);
+            v[0] = wg_gate_word(v[0], g[0]); v[1] = wg_gate_word(v[1], g[1]);
+            v[2] = wg_gate_word(v[2], g[2]); v[3] = wg_gate_word(v[3], g[3]);
+          }
+        }
+        stage_d[i] = v;
+      }
+    };
+    auto store_d = [&]() {
+#pragma unroll
+      for (int i = 0; i < NLOAD_D; ++i) {
+        const int id = i * 256 + tid;
+        const int row = id / (WTW * 4);
+        const int rem = id - row * (WTW * 4);
+        const int col = rem / 4;
+        const int c = rem - col * 4;
+        const int v = row * WTW + col;
+        *reinterpret_cast<u32x4*>(lds_dy + v * 64 + ((c ^ ((v >> 2) & 3)) << 4)) = stage_d[i];
+      }
+    };
+
+    const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f,
+                         (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+
+    load_x(tc0);
+    store_x(tc0);
+    load_x(tc0 + 1);
+    store_x(tc0 + 1);
+    load_x(tc0 + 2);
+    load_d(tc0);
+
+    for (int t = tc0; t < tc1; ++t) {
+      store_x(t + 2);
+      store_d();
+      __syncthreads();
+      if (t + 1 < tc1) {
+        load_x(t + 3);
+        load_d(t + 1);
+      }
+      int slot_of_kt[3];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) slot_of_kt[kt] = ((t + kt) % 3) * SLOTB;
+
+      for (int rho = 0; rho < WTR; ++rho) {
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+          // A = dYeff^T fragment of the 16 voxels (row rho, columns 16*cg .. +15)
+          const unsigned char* ap = lds_dy + rho * DROWB + cg * 16 * 64;
+          s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[0]));
+          s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[1]));
+          bf16x8 afr;
+          {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            s16x8 t8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            afr = __builtin_bit_cast(bf16x8, t8);
+          }
+#pragma unroll
+          for (int i = 0; i < 7; ++i) {
+            bf16x8 bfr;
+            if (i == 6 && wave == 3) {
+              bfr = ones;
+            } else {
+              const int sb = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
+              const unsigned char* bp = lds + sb + rho * ROWB + cg * 16 * VOXB;
+              s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][0]));
+              s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][1]));
+              typedef __attribute__((ext_vector_type(8))) short s16x8;
+              s16x8 t8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+              if (b_zero) t8 = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+              bfr = __builtin_bit_cast(bf16x8, t8);
+            }
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- write the partial slab: [tapslot][co][ci], C layout: col = ci = lane&31, row = co ----------
+  const int ci = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    int tapslot = wave + 4 * i;  // 27 = ones-tap (wave 3, i = 6)
+    if (tapslot <= 27) {
+      float* dst = slab + (size_t)tapslot * 1024 + ci;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int co = (j & 3) + 8 * (j >> 2) + 4 * half;
+        dst[co * 32] = acc[i][j];
+      }
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum over slabs (fixed order); dbias[co] from the ones-tap column 0
+__global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                                   float* __restrict__ dw, float* __restrict__ dbias,
+                                                                   int c_out, int c_in) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // index into [28][32][32]
+  if (i >= SLAB_ELEMS) return;
+  const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+  float s = 0.f;
+  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * SLAB_ELEMS + i];
+  if (tap < 27) {
+    if (dw && co < c_out && ci < c_in) dw[((size_t)co * c_in + ci) * 27 + tap] = s;
+  } else if (dbias && ci == 0 && co < c_out) {
+    dbias[co] = s;
+  }
+}
+
+static void wgrad_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, int* n_tchunk, int* t_chunk) {
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  *n_rowblk = (ho + WTR - 1) / WTR;
+  *n_colblk = (wo + WTW_VALID - 1) / WTW_VALID;
+  long long tiles = (long long)d->batch * *n_rowblk * *n_colblk;
+  int ntc = 1;
+  if (tiles < 256) {
+    ntc = (int)((256 + tiles - 1) / tiles);
+    int max_chunks = (to + 1) / 2;
+    if (max_chunks < 1) max_chunks = 1;
+    if (ntc > max_chunks) ntc = max_chunks;
+  }
+  *t_chunk = (to + ntc - 1) / ntc;
+  *n_tchunk = (to + *t_chunk - 1) / *t_chunk;
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* bytes) {
+  PV_REQUIRE(d && bytes, PV_EINVAL, "pv_conv3d_bwd_weight_bf16_workspace_bytes: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->t_in > 0 && d->h_in > 0 && d->w_in > 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_bf16_workspace_bytes: bad dims");
+  int nrb, ncb, ntc, tch;
+  wgrad_grid(d, &nrb, &ncb, &ntc, &tch);
+  *bytes = (size_t)d->batch * nrb * ncb * ntc * SLAB_ELEMS * sizeof(float);
+  return PV_OK;
+}
+
+int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint16_t* y_relu_mask, float* dw,
+                              float* dbias, const pv_conv3d_dims* d, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  PV_REQUIRE(d && x && dy && workspace, PV_EINVAL, "pv_conv3d_bwd_weight_bf16: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_bwd_weight_bf16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_bwd_weight_bf16: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_bwd_weight_bf16: input smaller than the kernel");
+  int nrb, ncb, ntc, tch;
+  wgrad_grid(d, &nrb, &ncb, &ntc, &tch);
+  const int n_slabs = d->batch * nrb * ncb * ntc;
+  PV_REQUIRE(workspace_bytes >= (size_t)n_slabs * SLAB_ELEMS * sizeof(float), PV_ESIZE,
+             "pv_conv3d_bwd_weight_bf16: workspace too small");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_bwd_weight_bf16: batch too large for grid.z");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)(nrb * ncb), (unsigned)ntc, (unsigned)d->batch);
+  const int cpad = pv_bf16_cpad(d->c_in);
+  if (cpad == 16) {
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<16>, grid, dim3(256), 0, st, x, dy, y_relu_mask, (float*)workspace,
+                       d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
+  } else {
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<32>, grid, dim3(256), 0, st, x, dy, y_relu_mask, (float*)workspace,
+                       d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
+  }
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3((SLAB_ELEMS + 255) / 256), dim3(256), 0, st,
+                     (const float*)workspace, n_slabs, dw, dbias, d->c_out, d->c_in);
+  return check_launch("pv_conv3d_bwd_weight_bf16");
+}
+
+}  // extern "C"

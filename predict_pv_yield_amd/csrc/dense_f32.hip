@@ -1,0 +1,350 @@
+// fp32 fully-connected head, forecast losses and Adam.
+// replaces: F.linear / torch.cat-fed FC stack (predict_pv_yield/models/conv3d/model.py:92-103,125-152),
+//           F.mse_loss, (y_hat - y).abs().mean(), WeightedLosses (base_model.py:98-103),
+//           torch.optim.Adam(lr=5e-4) (base_model.py:255-257).
+#include "pv_common.h"
+
+namespace pv {
+
+constexpr int M_TILE = 8;
+
+// ---- forward: split-K partial products, one block = (n, k-chunk, m-tile) -----------------------
+__global__ __launch_bounds__(256) void linear_fwd_partial_f32(const float* __restrict__ x,
+                                                               const float* __restrict__ w,
+                                                               float* __restrict__ partial, int m, int n,
+                                                               long long k, long long k_chunk) {
+  const int col = blockIdx.x;      // output feature
+  const int ks = blockIdx.y;       // k-chunk
+  const int m0 = blockIdx.z * M_TILE;
+  const long long k0 = (long long)ks * k_chunk;
+  const long long k1 = k0 + k_chunk < k ? k0 + k_chunk : k;
+  float acc[M_TILE];
+#pragma unroll
+  for (int i = 0; i < M_TILE; ++i) acc[i] = 0.f;
+  const float* wr = w + (size_t)col * k;
+  for (long long kk = k0 + threadIdx.x; kk < k1; kk += blockDim.x) {
+    float wv = wr[kk];
+#pragma unroll
+    for (int i = 0; i < M_TILE; ++i) {
+      if (m0 + i < m) acc[i] = fmaf(x[(size_t)(m0 + i) * k + kk], wv, acc[i]);
+    }
+  }
+  __shared__ float red[4][M_TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < M_TILE; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < M_TILE && m0 + threadIdx.x < m) {
+    int i = threadIdx.x;
+    float s = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    partial[((size_t)ks * m + (m0 + i)) * n + col] = s;
+  }
+}
+
+// y[m,n] = relu?(bias[n] + sum_ks partial[ks][m][n]) (fixed order: deterministic)
+__global__ __launch_bounds__(256) void linear_reduce_f32(const float* __restrict__ partial,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int m, int n, int k_splits, int relu) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n) return;
+  int col = i % n;
+  float s = 0.f;
+  for (int ks = 0; ks < k_splits; ++ks) s += partial[(size_t)ks * m * n + i];
+  if (bias) s += bias[col];
+  if (relu) s = s > 0.f ? s : 0.f;
+  y[i] = s;
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+// dx[mi, kk] = sum_n g[mi, n] * w[n, kk]; thread = one kk, M_TILE rows; g tile broadcast from LDS
+__global__ __launch_bounds__(256) void linear_bwd_dx_f32(const float* __restrict__ w, const float* __restrict__ dy,
+                                                          const float* __restrict__ ymask, float* __restrict__ dx,
+                                                          int m, int n, long long k) {
+  extern __shared__ float g[];  // [n][M_TILE]
+  const int m0 = blockIdx.y * M_TILE;
+  for (int i = threadIdx.x; i < n * M_TILE; i += blockDim.x) {
+    int col = i / M_TILE, r = i % M_TILE;
+    float v = 0.f;
+    if (m0 + r < m) {
+      size_t off = (size_t)(m0 + r) * n + col;
+      v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    }
+    g[i] = v;
+  }
+  __syncthreads();
+  long long kk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (kk >= k) return;
+  float acc[M_TILE];
+#pragma unroll
+  for (int i = 0; i < M_TILE; ++i) acc[i] = 0.f;
+  for (int col = 0; col < n; ++col) {
+    float wv = w[(size_t)col * k + kk];
+#pragma unroll
+    for (int i = 0; i < M_TILE; ++i) acc[i] = fmaf(g[col * M_TILE + i], wv, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < M_TILE; ++i)
+    if (m0 + i < m) dx[(size_t)(m0 + i) * k + kk] = acc[i];
+}
+
+// dw[n0+j, kk] = sum_mi g[mi, n0+j] * x[mi, kk]; thread = one kk, N_TILE output features
+constexpr int N_TILE = 8;
+__global__ __launch_bounds__(256) void linear_bwd_dw_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ ymask, float* __restrict__ dw,
+                                                          int m, int n, long long k) {
+  extern __shared__ float g[];  // [m][N_TILE]
+  const int n0 = blockIdx.y * N_TILE;
+  for (int i = threadIdx.x; i < m * N_TILE; i += blockDim.x) {
+    int r = i / N_TILE, j = i % N_TILE;
+    float v = 0.f;
+    if (n0 + j < n) {
+      size_t off = (size_t)r * n + n0 + j;
+      v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    }
+    g[i] = v;
+  }
+  __syncthreads();
+  long long kk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (kk >= k) return;
+  float acc[N_TILE];
+#pragma unroll
+  for (int j = 0; j < N_TILE; ++j) acc[j] = 0.f;
+  for (int r = 0; r < m; ++r) {
+    float xv = x[(size_t)r * k + kk];
+#pragma unroll
+    for (int j = 0; j < N_TILE; ++j) acc[j] = fmaf(g[r * N_TILE + j], xv, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < N_TILE; ++j)
+    if (n0 + j < n) dw[(size_t)(n0 + j) * k + kk] = acc[j];
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_db_f32(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                          float* __restrict__ db, int m, int n) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < m; ++r) {
+    size_t off = (size_t)r * n + col;
+    float v = dy[off];
+    if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    s += v;
+  }
+  db[col] = s;
+}
+
+// ---- forecast losses (single block; [B, forecast_len] is tiny) ----------------------------------
+struct LossWeights { float w[64]; };
+
+__global__ __launch_bounds__(256) void forecast_losses_f32(const float* __restrict__ y_hat, const float* __restrict__ y,
+                                                            long long y_row_stride, long long y_col_stride, int m,
+                                                            int n, float grad_scale, LossWeights lw,
+                                                            float* __restrict__ out4, float* __restrict__ grad) {
+  float s_se = 0.f, s_ae = 0.f, s_wse = 0.f, s_wae = 0.f;
+  const int total = m * n;
+  const float inv = 1.0f / (float)total;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    int r = i / n, c = i - r * n;
+    float d = y_hat[i] - y[(long long)r * y_row_stride + (long long)c * y_col_stride];
+    float a = fabsf(d);
+    s_se += d * d;
+    s_ae += a;
+    s_wse += lw.w[c] * (d * d);
+    s_wae += lw.w[c] * a;
+    if (grad) grad[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv * grad_scale;
+  }
+  __shared__ float red[4][4];
+  float v[4] = {s_se, s_ae, s_wse, s_wae};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t = v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    int q = threadIdx.x;
+    out4[q] = (((red[0][q] + red[1][q]) + red[2][q]) + red[3][q]) * inv;
+  }
+}
+
+// ---- Adam: torch._single_tensor_adam order of operations, f32 ------------------------------------
+__global__ __launch_bounds__(256) void adam_step_f32(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v,
+                                                      uint16_t* __restrict__ shadow, size_t n, float one_minus_b1,
+                                                      float beta2, float one_minus_b2, float bc2_sqrt, float eps,
+                                                      float neg_step_size, float grad_scale) {
+  size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 pv4 = *reinterpret_cast<const f32x4*>(p + i);
+      f32x4 gv4 = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mv4 = *reinterpret_cast<const f32x4*>(m + i);
+      f32x4 vv4 = *reinterpret_cast<const f32x4*>(v + i);
+      uint16_t sh[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gr = gv4[j] * grad_scale;
+        float mm = mv4[j] + one_minus_b1 * (gr - mv4[j]);        // exp_avg.lerp_(grad, 1 - beta1)
+        float vv = vv4[j] * beta2 + (one_minus_b2 * gr) * gr;     // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        float denom = sqrtf(vv) / bc2_sqrt + eps;
+        float pp = pv4[j] + neg_step_size * (mm / denom);        // addcdiv_(exp_avg, denom, -step_size)
+        mv4[j] = mm; vv4[j] = vv; pv4[j] = pp;
+        sh[j] = f32_to_bf16_bits(pp);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv4;
+      *reinterpret_cast<f32x4*>(m + i) = mv4;
+      *reinterpret_cast<f32x4*>(v + i) = vv4;
+      if (shadow) {
+        u32x2 o = {(uint32_t)sh[0] | ((uint32_t)sh[1] << 16), (uint32_t)sh[2] | ((uint32_t)sh[3] << 16)};
+        *reinterpret_cast<u32x2*>(shadow + i) = o;
+      }
+    } else {
+      for (size_t q = i; q < n; ++q) {
+        float gr = g[q] * grad_scale;
+        float mm = m[q] + one_minus_b1 * (gr - m[q]);
+        float vv = v[q] * beta2 + (one_minus_b2 * gr) * gr;
+        float denom = sqrtf(vv) / bc2_sqrt + eps;
+        float pp = p[q] + neg_step_size * (mm / denom);
+        m[q] = mm; v[q] = vv; p[q] = pp;
+        if (shadow) shadow[q] = f32_to_bf16_bits(pp);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __restrict__ src,
+                                                                uint16_t* __restrict__ dst, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+      u32x2 o = {(uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16),
+                 (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16)};
+      *reinterpret_cast<u32x2*>(dst + i) = o;
+    } else {
+      for (size_t q = i; q < n; ++q) dst[q] = f32_to_bf16_bits(src[q]);
+    }
+  }
+}
+
+static long long fwd_k_chunk(long long k, int* k_splits) {
+  // ~8k elements of K per block, at most 512 splits
+  long long chunk = 8192;
+  long long splits = (k + chunk - 1) / chunk;
+  if (splits > 512) { splits = 512; chunk = (k + splits - 1) / splits; }
+  if (splits < 1) splits = 1;
+  splits = (k + chunk - 1) / chunk;
+  *k_splits = (int)splits;
+  return chunk;
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_linear_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes) {
+  PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_workspace_bytes: bad arguments");
+  int ks;
+  fwd_k_chunk(k, &ks);
+  *bytes = (size_t)ks * m * n * sizeof(float);
+  return PV_OK;
+}
+
+int pv_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int32_t m, int32_t n, int64_t k,
+                      int relu, void* workspace, size_t workspace_bytes, void* stream) {
+  PV_REQUIRE(x && w && y && workspace, PV_EINVAL, "pv_linear_fwd_f32: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_fwd_f32: bad sizes");
+  int ks;
+  long long chunk = fwd_k_chunk(k, &ks);
+  PV_REQUIRE(workspace_bytes >= (size_t)ks * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_f32: workspace too small");
+  PV_REQUIRE(n <= 65535 && ks <= 65535, PV_ESIZE, "pv_linear_fwd_f32: n too large");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)n, (unsigned)ks, (unsigned)((m + M_TILE - 1) / M_TILE));
+  hipLaunchKernelGGL(linear_fwd_partial_f32, grid, dim3(256), 0, st, x, w, (float*)workspace, m, n, (long long)k, chunk);
+  hipLaunchKernelGGL(linear_reduce_f32, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st,
+                     (const float*)workspace, bias, y, m, n, ks, relu ? 1 : 0);
+  return check_launch("pv_linear_fwd_f32");
+}
+
+int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const float* y_relu_mask, float* dx, float* dw,
+                      float* db, int32_t m, int32_t n, int64_t k, void* stream) {
+  PV_REQUIRE(dy, PV_EINVAL, "pv_linear_bwd_f32: null dy");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bwd_f32: bad sizes");
+  hipStream_t st = as_stream(stream);
+  unsigned kb = (unsigned)((k + 255) / 256);
+  if (dx) {
+    PV_REQUIRE(w, PV_EINVAL, "pv_linear_bwd_f32: dx needs w");
+    size_t lds = (size_t)n * M_TILE * sizeof(float);
+    PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_f32: n=%d too large", n);
+    hipLaunchKernelGGL(linear_bwd_dx_f32, dim3(kb, (unsigned)((m + M_TILE - 1) / M_TILE)), dim3(256), lds, st, w, dy,
+                       y_relu_mask, dx, m, n, (long long)k);
+  }
+  if (dw) {
+    PV_REQUIRE(x, PV_EINVAL, "pv_linear_bwd_f32: dw needs x");
+    size_t lds = (size_t)m * N_TILE * sizeof(float);
+    PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_f32: m=%d too large", m);
+    hipLaunchKernelGGL(linear_bwd_dw_f32, dim3(kb, (unsigned)((n + N_TILE - 1) / N_TILE)), dim3(256), lds, st, x, dy,
+                       y_relu_mask, dw, m, n, (long long)k);
+  }
+  if (db) {
+    hipLaunchKernelGGL(linear_bwd_db_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y_relu_mask, db, m, n);
+  }
+  return check_launch("pv_linear_bwd_f32");
+}
+
+int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_stride, int64_t y_col_stride, int32_t m,
+                           int32_t n, float grad_scale, float* out4, float* grad, void* stream) {
+  PV_REQUIRE(y_hat && y && out4, PV_EINVAL, "pv_forecast_losses_f32: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && n <= 64, PV_ESIZE, "pv_forecast_losses_f32: forecast length %d outside 1..64", n);
+  // WeightedLosses(forecast_length=n): w_i = exp(-ln2 * i), normalised to mean 1 (f32 like torch.FloatTensor)
+  LossWeights lw;
+  float tmp[64];
+  float sum = 0.f;
+  for (int i = 0; i < n; ++i) { tmp[i] = (float)exp(-0.6931471805599453 * i); sum += tmp[i]; }
+  for (int i = 0; i < 64; ++i) lw.w[i] = i < n ? tmp[i] / sum * (float)n : 0.f;
+  hipLaunchKernelGGL(forecast_losses_f32, dim3(1), dim3(256), 0, as_stream(stream), y_hat, y, (long long)y_row_stride,
+                     (long long)y_col_stride, m, n, grad_scale, lw, out4, grad);
+  return check_launch("pv_forecast_losses_f32");
+}
+
+int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {
+  PV_REQUIRE(src && dst, PV_EINVAL, "pv_cast_f32_to_bf16: null pointer");
+  PV_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), PV_EINVAL, "pv_cast_f32_to_bf16: unaligned");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), src,
+                     dst, n);
+  return check_launch("pv_cast_f32_to_bf16");
+}
+
+int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow,
+                     size_t n, double lr, double beta1, double beta2, double eps, int32_t step, float grad_scale,
+                     void* stream) {
+  PV_REQUIRE(param && grad && exp_avg && exp_avg_sq, PV_EINVAL, "pv_adam_step_f32: null pointer");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_adam_step_f32: step must be >= 1");
+  PV_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
+                 ((uintptr_t)exp_avg_sq % 16 == 0) && ((uintptr_t)bf16_shadow % 8 == 0),
+             PV_EINVAL, "pv_adam_step_f32: buffers must be 16-byte aligned");
+  if (n == 0) return PV_OK;
+  // python-float (double) scalars exactly as torch computes them, then narrowed to f32 at the kernel boundary
+  double bc1 = 1.0 - pow(beta1, (double)step);
+  double bc2 = 1.0 - pow(beta2, (double)step);
+  double step_size = lr / bc1;
+  double bc2_sqrt = sqrt(bc2);
+  hipLaunchKernelGGL(adam_step_f32, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), param, grad,
+                     exp_avg, exp_avg_sq, bf16_shadow, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size), grad_scale);
+  return check_launch("pv_adam_step_f32");
+}
+
+}  // extern "C"

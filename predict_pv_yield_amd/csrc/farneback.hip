@@ -1,0 +1,565 @@
+// Batched dense Farnebäck optical flow (OPTFLOW_FARNEBACK_GAUSSIAN) for gfx950.
+// replaces: cv.calcOpticalFlowFarneback(prev, next, None, 0.5, 2, 40, 3, 5, 0.7, GAUSSIAN) called once per
+// consecutive frame pair from a process pool (notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:
+// 122-135, 175-240; same arguments in notebooks/optical_flow_1.ipynb:214-221).
+// Algorithm: SURVEY.md Appendix A.1 (OpenCV modules/video/src/optflowgf.cpp), restated on the CPU in
+// oracle/pv_oracle.c; this file follows the same operation order so the two agree to float rounding.
+//
+// All pairs of the batch advance through the pyramid together: every stage is ONE launch over
+// [n_pairs] x level image, so a [B, 12, 11, 64, 64] stack (3872 pairs/32 samples) is ~25 launches.
+// Stages per level:  prep (u8 -> f32, Gaussian smooth, resize)  ->  PolyExp (vertical, horizontal)
+//                    -> UpdateMatrices -> iterations x { window blur V, window blur H + 2x2 solve,
+//                    UpdateMatrices }  -> (next level) bilinear flow upsample x 1/pyr_scale.
+#include "pv_common.h"
+
+namespace pv {
+
+struct FbTaps {
+  float k[64];  // generic tap table (smooth kernel: full ksize taps; window: k[0..m])
+  int n;
+};
+struct FbPoly {
+  float g[8], xg[8], xxg[8];  // taps 0..n (poly_n <= 7); odd symmetry handled in the kernel
+  double ig11, ig03, ig33, ig55;
+  int n;
+};
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+__device__ __forceinline__ int clampi_d(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- prep: blurred + resized f32 image of one pyramid level ---------------------------------------
+// blurred(y, x): separable Gaussian of the u8 image, rows first then columns, BORDER_REFLECT_101
+__device__ __forceinline__ float row_filter(const uint8_t* __restrict__ s, int w, int x, const FbTaps& kt) {
+  const int ks = kt.n, r = ks >> 1;
+  float acc;
+  if (ks <= 5) {
+    acc = (float)s[x] * kt.k[r];
+    for (int i = 1; i <= r; ++i)
+      acc = __fadd_rn(acc, __fmul_rn((float)s[reflect101(x - i, w)] + (float)s[reflect101(x + i, w)], kt.k[r + i]));
+  } else {
+    acc = (float)s[reflect101(x - r, w)] * kt.k[0];
+    for (int i = 1; i < ks; ++i) acc = __fadd_rn(acc, __fmul_rn((float)s[reflect101(x + i - r, w)], kt.k[i]));
+  }
+  return acc;
+}
+__device__ __forceinline__ float blurred_at(const uint8_t* __restrict__ img, int h, int w, int y, int x,
+                                            const FbTaps& kt) {
+  const int r = kt.n >> 1;
+  float acc = __fmul_rn(row_filter(img + (size_t)y * w, w, x, kt), kt.k[r]);
+  for (int i = 1; i <= r; ++i) {
+    float a = row_filter(img + (size_t)reflect101(y - i, h) * w, w, x, kt);
+    float b = row_filter(img + (size_t)reflect101(y + i, h) * w, w, x, kt);
+    acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(a, b), kt.k[r + i]));
+  }
+  return acc;
+}
+
+// images: pair p has prev at prev + p*prev_stride, next at next + p*next_stride.  I: [n_pairs][2][lh][lw]
+__global__ __launch_bounds__(256) void fb_prep_kernel(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next,
+                                                       long long prev_stride, long long next_stride,
+                                                       long long pairs_per_group, long long group_stride,
+                                                       float* __restrict__ I, long long n_pairs, int h, int w, int lh,
+                                                       int lw, int mode /*0 copy, 1 area 2x2, 2 bilinear*/,
+                                                       double inv_fx, double inv_fy, FbTaps kt) {
+  const long long per_img = (long long)lh * lw;
+  const long long total = n_pairs * 2 * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long im = i / per_img;
+    int rem = (int)(i - im * per_img);
+    int y = rem / lw, x = rem - y * lw;
+    long long p = im >> 1;
+    const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
+    const uint8_t* img = ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
+    float v;
+    if (mode == 0) {
+      v = blurred_at(img, h, w, y, x, kt);
+    } else if (mode == 1) {
+      float a = __fadd_rn(blurred_at(img, h, w, 2 * y, 2 * x, kt), blurred_at(img, h, w, 2 * y, 2 * x + 1, kt));
+      float b = __fadd_rn(blurred_at(img, h, w, 2 * y + 1, 2 * x, kt), blurred_at(img, h, w, 2 * y + 1, 2 * x + 1, kt));
+      v = __fmul_rn(__fadd_rn(a, b), 0.25f);
+    } else {
+      float fx = (float)((x + 0.5) * inv_fx - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= w - 1) { fx = 0; sx = w - 1; }
+      float fy = (float)((y + 0.5) * inv_fy - 0.5);
+      int sy = (int)floorf(fy);
+      fy -= sy;
+      if (sy < 0) { fy = 0; sy = 0; }
+      if (sy >= h - 1) { fy = 0; sy = h - 1; }
+      int sy1 = clampi_d(sy + 1, 0, h - 1);
+      float r0, r1;
+      if (sx + 1 < w) {
+        float a0 = 1.f - fx, a1 = fx;
+        r0 = __fadd_rn(__fmul_rn(blurred_at(img, h, w, sy, sx, kt), a0), __fmul_rn(blurred_at(img, h, w, sy, sx + 1, kt), a1));
+        r1 = __fadd_rn(__fmul_rn(blurred_at(img, h, w, sy1, sx, kt), a0), __fmul_rn(blurred_at(img, h, w, sy1, sx + 1, kt), a1));
+      } else {
+        r0 = blurred_at(img, h, w, sy, sx, kt);
+        r1 = blurred_at(img, h, w, sy1, sx, kt);
+      }
+      v = __fadd_rn(__fmul_rn(r0, 1.f - fy), __fmul_rn(r1, fy));
+    }
+    I[i] = v;
+  }
+}
+
+// ---- PolyExp ---------------------------------------------------------------------------------------
+// vertical pass: T[img][y][x] = (t0, t1, t2), rows replicated at the border
+__global__ __launch_bounds__(256) void fb_polyexp_v_kernel(const float* __restrict__ I, float* __restrict__ T,
+                                                            long long n_img, int lh, int lw, FbPoly pk) {
+  const long long per_img = (long long)lh * lw;
+  const long long total = n_img * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long im = i / per_img;
+    int rem = (int)(i - im * per_img);
+    int y = rem / lw, x = rem - y * lw;
+    const float* src = I + im * per_img;
+    float t0 = __fmul_rn(src[(size_t)y * lw + x], pk.g[0]), t1 = 0.f, t2 = 0.f;
+    for (int k = 1; k <= pk.n; ++k) {
+      float s0 = src[(size_t)max(y - k, 0) * lw + x];
+      float s1 = src[(size_t)min(y + k, lh - 1) * lw + x];
+      float p = __fadd_rn(s0, s1);
+      t0 = __fadd_rn(t0, __fmul_rn(pk.g[k], p));
+      t1 = __fadd_rn(t1, __fmul_rn(pk.xg[k], __fsub_rn(s1, s0)));
+      t2 = __fadd_rn(t2, __fmul_rn(pk.xxg[k], p));
+    }
+    float* dst = T + i * 3;
+    dst[0] = t0; dst[1] = t1; dst[2] = t2;
+  }
+}
+
+// horizontal pass (double accumulators, edge triples replicated) -> R[img][y][x][5]
+__global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restrict__ T, float* __restrict__ R,
+                                                            long long n_img, int lh, int lw, FbPoly pk) {
+  const long long per_img = (long long)lh * lw;
+  const long long total = n_img * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long im = i / per_img;
+    int rem = (int)(i - im * per_img);
+    int y = rem / lw, x = rem - y * lw;
+    const float* row = T + (im * per_img + (size_t)y * lw) * 3;
+    const float* c = row + (size_t)x * 3;
+    float g0 = pk.g[0];
+    double b1 = __fmul_rn(c[0], g0), b2 = 0, b3 = __fmul_rn(c[1], g0), b4 = 0, b5 = __fmul_rn(c[2], g0), b6 = 0;
+    for (int k = 1; k <= pk.n; ++k) {
+      const float* rp = row + (size_t)min(x + k, lw - 1) * 3;
+      const float* rm = row + (size_t)max(x - k, 0) * 3;
+      double tg = (double)__fadd_rn(rp[0], rm[0]);
+      g0 = pk.g[k];
+      b1 = __dadd_rn(b1, __dmul_rn(tg, (double)g0));
+      b4 = __dadd_rn(b4, __dmul_rn(tg, (double)pk.xxg[k]));
+      b2 = __dadd_rn(b2, (double)__fmul_rn(__fsub_rn(rp[0], rm[0]), pk.xg[k]));
+      b3 = __dadd_rn(b3, (double)__fmul_rn(__fadd_rn(rp[1], rm[1]), g0));
+      b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(rp[1], rm[1]), pk.xg[k]));
+      b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(rp[2], rm[2]), g0));
+    }
+    float* d = R + i * 5;
+    d[1] = (float)__dmul_rn(b2, pk.ig11);
+    d[0] = (float)__dmul_rn(b3, pk.ig11);
+    d[3] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+    d[2] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+    d[4] = (float)__dmul_rn(b6, pk.ig55);
+  }
+}
+
+// ---- UpdateMatrices --------------------------------------------------------------------------------
+// R: [n_pairs][2][lh][lw][5] (R0 = image 0, R1 = image 1); flow: [n_pairs][lh][lw][2]; M: [n_pairs][lh][lw][5]
+__global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __restrict__ R, const float* __restrict__ flow,
+                                                                  float* __restrict__ M, long long n_pairs, int height,
+                                                                  int width) {
+  const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+  const long long per_img = (long long)height * width;
+  const long long total = n_pairs * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const size_t step1 = (size_t)width * 5;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long p = i / per_img;
+    int rem = (int)(i - p * per_img);
+    int y = rem / width, x = rem - y * width;
+    const float* R0 = R + ((p * 2) * per_img + rem) * 5;
+    const float* R1 = R + (p * 2 + 1) * per_img * 5;
+    const float* fl = flow + i * 2;
+    float dx = fl[0], dy = fl[1];
+    float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx = __fsub_rn(fx, (float)x1);
+    fy = __fsub_rn(fy, (float)y1);
+    if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1)) {
+      const float* ptr = R1 + (size_t)y1 * step1 + (size_t)x1 * 5;
+      float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+      float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+#define PV_BILIN(c) \
+  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, ptr[c]), __fmul_rn(a01, ptr[5 + c])), __fmul_rn(a10, ptr[step1 + c])), \
+            __fmul_rn(a11, ptr[step1 + 5 + c]))
+      r2 = PV_BILIN(0);
+      r3 = PV_BILIN(1);
+      r4 = PV_BILIN(2);
+      r5 = PV_BILIN(3);
+      r6 = PV_BILIN(4);
+#undef PV_BILIN
+      r4 = __fmul_rn(__fadd_rn(R0[2], r4), 0.5f);
+      r5 = __fmul_rn(__fadd_rn(R0[3], r5), 0.5f);
+      r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
+    } else {
+      r2 = r3 = 0.f;
+      r4 = R0[2];
+      r5 = R0[3];
+      r6 = __fmul_rn(R0[4], 0.5f);
+    }
+    r2 = __fmul_rn(__fsub_rn(R0[0], r2), 0.5f);
+    r3 = __fmul_rn(__fsub_rn(R0[1], r3), 0.5f);
+    r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
+    r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
+    if ((unsigned)(x - 5) >= (unsigned)(width - 10) || (unsigned)(y - 5) >= (unsigned)(height - 10)) {
+      float scale = (x < 5 ? border[x] : 1.f);
+      scale = __fmul_rn(scale, (x >= width - 5 ? border[width - x - 1] : 1.f));
+      scale = __fmul_rn(scale, (y < 5 ? border[y] : 1.f));
+      scale = __fmul_rn(scale, (y >= height - 5 ? border[height - y - 1] : 1.f));
+      r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
+      r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
+    }
+    float* m = M + i * 5;
+    m[0] = __fadd_rn(__fmul_rn(r4, r4), __fmul_rn(r6, r6));
+    m[1] = __fmul_rn(__fadd_rn(r4, r5), r6);
+    m[2] = __fadd_rn(__fmul_rn(r5, r5), __fmul_rn(r6, r6));
+    m[3] = __fadd_rn(__fmul_rn(r4, r2), __fmul_rn(r6, r3));
+    m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
+  }
+}
+
+// ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
+__global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
+                                                         long long n_pairs, int height, int width, FbTaps kt) {
+  const long long row_elems = (long long)width * 5;
+  const long long per_img = (long long)height * row_elems;
+  const long long total = n_pairs * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int m = kt.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long p = i / per_img;
+    long long rem = i - p * per_img;
+    int y = (int)(rem / row_elems);
+    int xe = (int)(rem - (long long)y * row_elems);
+    const float* src = M + p * per_img + xe;
+    float s0 = __fmul_rn(src[(size_t)y * row_elems], kt.k[0]);
+    for (int k = 1; k <= m; ++k) {
+      float a = src[(size_t)min(y + k, height - 1) * row_elems];
+      float b = src[(size_t)max(y - k, 0) * row_elems];
+      s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(a, b), kt.k[k]));
+    }
+    V[i] = s0;
+  }
+}
+
+__global__ __launch_bounds__(256) void fb_blur_h_solve_kernel(const float* __restrict__ V, float* __restrict__ flow,
+                                                               long long n_pairs, int height, int width, FbTaps kt) {
+  const long long per_img = (long long)height * width;
+  const long long total = n_pairs * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int m = kt.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long p = i / per_img;
+    int rem = (int)(i - p * per_img);
+    int y = rem / width, x = rem - y * width;
+    const float* row = V + (p * per_img + (size_t)y * width) * 5;
+    float h5[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) h5[c] = __fmul_rn(row[(size_t)x * 5 + c], kt.k[0]);
+    for (int k = 1; k <= m; ++k) {
+      const float* a = row + (size_t)max(x - k, 0) * 5;
+      const float* b = row + (size_t)min(x + k, width - 1) * 5;
+      float kk = kt.k[k];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) h5[c] = __fadd_rn(h5[c], __fmul_rn(kk, __fadd_rn(a[c], b[c])));
+    }
+    double g11 = h5[0], g12 = h5[1], g22 = h5[2], h1 = h5[3], h2 = h5[4];
+    double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+    double idet = __ddiv_rn(1.0, det);
+    float* fl = flow + i * 2;
+    fl[0] = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+    fl[1] = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+  }
+}
+
+// ---- flow upsample: cv::resize(prevFlow -> (lw, lh), INTER_LINEAR) * (1 / pyr_scale) --------------
+__global__ __launch_bounds__(256) void fb_flow_upsample_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                long long n_pairs, int sh, int sw, int dh, int dw,
+                                                                double inv_fx, double inv_fy, float mul) {
+  const long long per_img = (long long)dh * dw;
+  const long long total = n_pairs * per_img;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    long long p = i / per_img;
+    int rem = (int)(i - p * per_img);
+    int y = rem / dw, x = rem - y * dw;
+    float fx = (float)((x + 0.5) * inv_fx - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    float fy = (float)((y + 0.5) * inv_fy - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= sy;
+    if (sy < 0) { fy = 0; sy = 0; }
+    if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+    int sy1 = clampi_d(sy + 1, 0, sh - 1);
+    const float* s0 = src + (p * sh * sw + (size_t)sy * sw) * 2;
+    const float* s1 = src + (p * sh * sw + (size_t)sy1 * sw) * 2;
+    float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float r0, r1;
+      if (sx + 1 < sw) {
+        r0 = __fadd_rn(__fmul_rn(s0[sx * 2 + c], a0), __fmul_rn(s0[(sx + 1) * 2 + c], a1));
+        r1 = __fadd_rn(__fmul_rn(s1[sx * 2 + c], a0), __fmul_rn(s1[(sx + 1) * 2 + c], a1));
+      } else {
+        r0 = s0[sx * 2 + c];
+        r1 = s1[sx * 2 + c];
+      }
+      dst[i * 2 + c] = __fmul_rn(__fadd_rn(__fmul_rn(r0, b0), __fmul_rn(r1, b1)), mul);
+    }
+  }
+}
+
+// ---- host-side tables (same arithmetic as oracle/pv_oracle.c) -------------------------------------
+static int host_cv_round(double v) { return (int)nearbyint(v); }
+
+static void host_smooth_taps(int n, double sigma, FbTaps* t) {
+  static const float tab3[] = {0.25f, 0.5f, 0.25f};
+  static const float tab5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+  static const float tab7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+  static const float tab1[] = {1.f};
+  const float* fixed = nullptr;
+  if ((n & 1) && n <= 7 && sigma <= 0) fixed = n == 1 ? tab1 : n == 3 ? tab3 : n == 5 ? tab5 : tab7;
+  double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+  double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    double x = i - (n - 1) * 0.5;
+    double v = fixed ? (double)fixed[i] : exp(scale2X * x * x);
+    t->k[i] = (float)v;
+    sum += t->k[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) t->k[i] = (float)(t->k[i] * sum);
+  t->n = n;
+}
+
+static void host_window_taps(int winsize, FbTaps* t) {
+  int m = winsize / 2;
+  double sigma = m * 0.3, s = 1;
+  t->k[0] = (float)s;
+  for (int i = 1; i <= m; i++) {
+    float v = (float)exp(-i * i / (2 * sigma * sigma));
+    t->k[i] = v;
+    s += v * 2;
+  }
+  s = 1. / s;
+  for (int i = 0; i <= m; i++) t->k[i] = (float)(t->k[i] * s);
+  t->n = m;
+}
+
+static void host_poly_tables(int n, double sigma, FbPoly* pk) {
+  float gb[32], xgb[32], xxgb[32];
+  float *g = gb + n, *xg = xgb + n, *xxg = xxgb + n;
+  if (sigma < 1.1920929e-07) sigma = n * 0.3;
+  double s = 0.;
+  for (int x = -n; x <= n; x++) {
+    g[x] = (float)exp(-x * x / (2 * sigma * sigma));
+    s += g[x];
+  }
+  s = 1. / s;
+  for (int x = -n; x <= n; x++) {
+    g[x] = (float)(g[x] * s);
+    xg[x] = (float)(x * g[x]);
+    xxg[x] = (float)(x * x * g[x]);
+  }
+  double G[6][6] = {{0}};
+  for (int y = -n; y <= n; y++)
+    for (int x = -n; x <= n; x++) {
+      G[0][0] += g[y] * g[x];
+      G[1][1] += g[y] * g[x] * x * x;
+      G[3][3] += g[y] * g[x] * x * x * x * x;
+      G[5][5] += g[y] * g[x] * x * x * y * y;
+    }
+  G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+  G[4][4] = G[3][3];
+  G[3][4] = G[4][3] = G[5][5];
+  double A[6][12];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 12; ++j) A[i][j] = j < 6 ? G[i][j] : (j - 6 == i ? 1.0 : 0.0);
+  for (int c = 0; c < 6; ++c) {
+    int p = c;
+    for (int r = c + 1; r < 6; ++r)
+      if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+    if (p != c)
+      for (int j = 0; j < 12; ++j) std::swap(A[c][j], A[p][j]);
+    double d = 1.0 / A[c][c];
+    for (int j = 0; j < 12; ++j) A[c][j] *= d;
+    for (int r = 0; r < 6; ++r)
+      if (r != c) {
+        double f = A[r][c];
+        if (f != 0.0)
+          for (int j = 0; j < 12; ++j) A[r][j] -= f * A[c][j];
+      }
+  }
+  pk->ig11 = A[1][7];
+  pk->ig03 = A[0][9];
+  pk->ig33 = A[3][9];
+  pk->ig55 = A[5][11];
+  pk->n = n;
+  for (int k = 0; k <= n; ++k) {
+    pk->g[k] = g[k];
+    pk->xg[k] = xg[k];
+    pk->xxg[k] = xxg[k];
+  }
+}
+
+static int fb_num_levels(int h, int w, double pyr_scale, int levels) {
+  int k;
+  double scale;
+  for (k = 0, scale = 1; k < levels; k++) {
+    scale *= pyr_scale;
+    if (w * scale < 32 || h * scale < 32) break;
+  }
+  return k;
+}
+
+struct FbLayout {
+  size_t off_I, off_T, off_R, off_M, off_V, off_flowA, off_flowB, total;
+};
+static FbLayout fb_layout(long long n_pairs, int h, int w) {
+  const size_t px = (size_t)h * w;
+  auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  FbLayout L;
+  size_t o = 0;
+  L.off_I = o; o = align(o + (size_t)n_pairs * 2 * px * 4);
+  L.off_T = o; o = align(o + (size_t)n_pairs * 2 * px * 12);
+  L.off_R = o; o = align(o + (size_t)n_pairs * 2 * px * 20);
+  L.off_M = o; o = align(o + (size_t)n_pairs * px * 20);
+  L.off_V = o; o = align(o + (size_t)n_pairs * px * 20);
+  L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
+  L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
+  L.total = o;
+  return L;
+}
+
+static int fb_check_params(const pv_farneback_params* p, int h, int w) {
+  PV_REQUIRE(p, PV_EINVAL, "pv_farneback: null params");
+  PV_REQUIRE(p->flags == PV_OPTFLOW_FARNEBACK_GAUSSIAN, PV_EINVAL,
+             "pv_farneback: only flags=OPTFLOW_FARNEBACK_GAUSSIAN (256) is built (got %d)", p->flags);
+  PV_REQUIRE(p->poly_n == 5 || p->poly_n == 7, PV_EINVAL, "pv_farneback: poly_n must be 5 or 7");
+  PV_REQUIRE(p->pyr_scale > 0 && p->pyr_scale < 1, PV_EINVAL, "pv_farneback: pyr_scale must be in (0,1)");
+  PV_REQUIRE(p->winsize >= 2 && p->winsize / 2 <= 63, PV_ESIZE, "pv_farneback: winsize must be 2..127");
+  PV_REQUIRE(p->iterations >= 1 && p->levels >= 0, PV_EINVAL, "pv_farneback: bad iterations/levels");
+  PV_REQUIRE(h >= 2 && w >= 2, PV_ESIZE, "pv_farneback: image too small");
+  return PV_OK;
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_farneback_workspace_bytes(int64_t n_pairs, int32_t h, int32_t w, const pv_farneback_params* params, size_t* bytes) {
+  PV_REQUIRE(bytes && n_pairs >= 0, PV_EINVAL, "pv_farneback_workspace_bytes: bad arguments");
+  int rc = fb_check_params(params, h, w);
+  if (rc) return rc;
+  *bytes = fb_layout(n_pairs, h, w).total;
+  return PV_OK;
+}
+
+int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev_stride, int64_t next_stride,
+                          int64_t pairs_per_group, int64_t group_stride, float* flow0, int64_t n_pairs, int32_t h, int32_t w, const pv_farneback_params* p,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = fb_check_params(p, h, w);
+  if (rc) return rc;
+  PV_REQUIRE(prev && next && flow0 && workspace, PV_EINVAL, "pv_farneback_batch_u8: null pointer");
+  PV_REQUIRE(n_pairs >= 0, PV_EINVAL, "pv_farneback_batch_u8: negative n_pairs");
+  if (pairs_per_group <= 0) { pairs_per_group = n_pairs > 0 ? n_pairs : 1; group_stride = 0; }
+  if (n_pairs == 0) return PV_OK;
+  FbLayout L = fb_layout(n_pairs, h, w);
+  PV_REQUIRE(workspace_bytes >= L.total, PV_ESIZE, "pv_farneback_batch_u8: workspace %zu < %zu bytes", workspace_bytes,
+             L.total);
+  hipStream_t st = as_stream(stream);
+  char* ws = (char*)workspace;
+  float* I = (float*)(ws + L.off_I);
+  float* T = (float*)(ws + L.off_T);
+  float* R = (float*)(ws + L.off_R);
+  float* M = (float*)(ws + L.off_M);
+  float* V = (float*)(ws + L.off_V);
+  float* flow_buf[2] = {(float*)(ws + L.off_flowA), (float*)(ws + L.off_flowB)};
+
+  FbPoly pk;
+  host_poly_tables(p->poly_n, p->poly_sigma, &pk);
+  FbTaps win;
+  host_window_taps(p->winsize, &win);
+
+  const int levels = fb_num_levels(h, w, p->pyr_scale, p->levels);
+  float* prev_flow = nullptr;
+  int prev_w = 0, prev_h = 0;
+  int pingpong = 0;
+  for (int k = levels; k >= 0; --k) {
+    double scale = 1;
+    for (int i = 0; i < k; ++i) scale *= p->pyr_scale;
+    double sigma = (1. / scale - 1) * 0.5;
+    int smooth_sz = host_cv_round(sigma * 5) | 1;
+    smooth_sz = std::max(smooth_sz, 3);
+    PV_REQUIRE(smooth_sz <= 63, PV_ESIZE, "pv_farneback_batch_u8: pyramid too deep (smoothing kernel %d taps)", smooth_sz);
+    const int lw = host_cv_round(w * scale), lh = host_cv_round(h * scale);
+    PV_REQUIRE(lw >= 2 && lh >= 2, PV_ESIZE, "pv_farneback_batch_u8: level smaller than 2x2");
+    const long long lpx = (long long)lw * lh;
+    float* flow = k > 0 ? flow_buf[pingpong] : flow0;
+    pingpong ^= 1;
+    if (!prev_flow) {
+      hipError_t e = hipMemsetAsync(flow, 0, (size_t)n_pairs * lpx * 2 * sizeof(float), st);
+      PV_REQUIRE(e == hipSuccess, PV_ELAUNCH, "pv_farneback_batch_u8: memset failed");
+    } else {
+      hipLaunchKernelGGL(fb_flow_upsample_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                         (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw, (double)prev_w / lw,
+                         (double)prev_h / lh, (float)(1. / p->pyr_scale));
+    }
+    FbTaps sm;
+    host_smooth_taps(smooth_sz, sigma, &sm);
+    int mode;
+    double inv_fx = (double)w / lw, inv_fy = (double)h / lh;
+    if (lw == w && lh == h) mode = 0;
+    else if (fabs(inv_fx - 2.0) < 2.220446049250313e-16 && fabs(inv_fy - 2.0) < 2.220446049250313e-16) mode = 1;
+    else mode = 2;
+    hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st, prev, next,
+                       (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,
+                       (long long)n_pairs, h, w, lh, lw, mode, inv_fx,
+                       inv_fy, sm);
+    hipLaunchKernelGGL(fb_polyexp_v_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
+                       (const float*)I, T, (long long)n_pairs * 2, lh, lw, pk);
+    hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
+                       (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
+    hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw);
+    for (int it = 0; it < p->iterations; ++it) {
+      hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
+                         (const float*)M, V, (long long)n_pairs, lh, lw, win);
+      hipLaunchKernelGGL(fb_blur_h_solve_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                         (const float*)V, flow, (long long)n_pairs, lh, lw, win);
+      if (it < p->iterations - 1)
+        hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                           (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw);
+    }
+    prev_flow = flow;
+    prev_w = lw;
+    prev_h = lh;
+  }
+  return check_launch("pv_farneback_batch_u8");
+}
+
+}  // extern "C"

@@ -1,0 +1,431 @@
+// HBM-bound streaming stages of the optical-flow advection path:
+// u8 conversion, weighted mean of flow fields, per-channel normalisation and the cv.remap-exact
+// bilinear warp.  All kernels are grid-stride, 16 B per lane where the layout allows it.
+#include "pv_common.h"
+
+namespace pv {
+
+static thread_local char g_err[512];
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// u8 conversion of 10-bit counts
+// ---------------------------------------------------------------------------------------------
+// mode 0: np.round(x / 4.0) (half to even), notebooks/13_...ipynb:112-119
+// mode 1: ((x - 0) / 1023) * 255 truncated,  notebooks/optical_flow_1.ipynb:129-134 (f32 arithmetic)
+__device__ __forceinline__ int u8_from_f32(float x, int mode, bool& bad) {
+  float v;
+  if (mode == PV_U8_ROUND_DIV4) {
+    v = rintf(x * 0.25f);  // x/4.0 is an exact power-of-two scaling; rint = half-to-even
+  } else {
+    v = truncf(__fmul_rn(__fdiv_rn(x, 1023.0f), 255.0f));
+  }
+  if (!(v >= 0.0f && v <= 255.0f)) {  // also catches NaN
+    bad = true;
+    v = v > 255.0f ? 255.0f : 0.0f;
+  }
+  return (int)v;
+}
+
+__device__ __forceinline__ int u8_from_i16(int x, int mode, bool& bad) {
+  if (mode == PV_U8_ROUND_DIV4) {
+    // exact integer form of round_half_even(x / 4)
+    int q = x >> 2, r = x & 3;
+    int v = q + (r > 2 ? 1 : (r == 2 ? (q & 1) : 0));
+    if (v < 0 || v > 255) {
+      bad = true;
+      v = v < 0 ? 0 : 255;
+    }
+    return v;
+  }
+  return u8_from_f32((float)x, mode, bad);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void u8_from_10bit_kernel(const T* __restrict__ src,
+                                                             uint8_t* __restrict__ dst, size_t n,
+                                                             int mode, int32_t* range_flag) {
+  bool bad = false;
+  size_t nvec = n / 8;
+  size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < nvec; i += stride) {
+    uint32_t lo = 0, hi = 0;
+    if constexpr (sizeof(T) == 2) {
+      u32x4 raw = *reinterpret_cast<const u32x4*>(src + i * 8);  // 8 x int16 = 16 B
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int x = (int)(int16_t)((raw[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+        uint32_t v = (uint32_t)u8_from_i16(x, mode, bad);
+        if (j < 4) lo |= v << (8 * j); else hi |= v << (8 * (j - 4));
+      }
+    } else {
+      f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8);
+      f32x4 b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo |= (uint32_t)u8_from_f32(a[j], mode, bad) << (8 * j);
+        hi |= (uint32_t)u8_from_f32(b[j], mode, bad) << (8 * j);
+      }
+    }
+    u32x2 out = {lo, hi};
+    *reinterpret_cast<u32x2*>(dst + i * 8) = out;
+  }
+  // tail
+  for (size_t i = nvec * 8 + tid; i < n; i += stride) {
+    if constexpr (sizeof(T) == 2) dst[i] = (uint8_t)u8_from_i16((int)src[i], mode, bad);
+    else dst[i] = (uint8_t)u8_from_f32((float)src[i], mode, bad);
+  }
+  if (range_flag && __any(bad)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weighted mean over the pair axis, float64 accumulation in index order (np.average semantics)
+// ---------------------------------------------------------------------------------------------
+struct WMeanWeights {
+  double w[64];
+  double inv_unused;
+  double sum;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void weighted_mean_kernel(const float* __restrict__ flows,
+                                                             float* __restrict__ out,
+                                                             int64_t n_groups, int n_per_group,
+                                                             int64_t elems, WMeanWeights wts) {
+  int64_t per_group = elems / VEC;
+  int64_t total = n_groups * per_group;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t g = i / per_group;
+    int64_t e = (i - g * per_group) * VEC;
+    const float* base = flows + (g * n_per_group) * elems + e;
+    double acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+    for (int k = 0; k < n_per_group; ++k) {
+      if constexpr (VEC == 4) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(base + (int64_t)k * elems);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = __dadd_rn(acc[v], __dmul_rn((double)x[v], wts.w[k]));
+      } else {
+        acc[0] = __dadd_rn(acc[0], __dmul_rn((double)base[(int64_t)k * elems], wts.w[k]));
+      }
+    }
+    if constexpr (VEC == 4) {
+      f32x4 r;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) r[v] = (float)__ddiv_rn(acc[v], wts.sum);
+      *reinterpret_cast<f32x4*>(out + g * elems + e) = r;
+    } else {
+      out[g * elems + e] = (float)__ddiv_rn(acc[0], wts.sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel normalisation (x - mean[c]) / std[c], true f32 division
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void normalise_kernel(const T* __restrict__ src,
+                                                         float* __restrict__ dst, size_t n,
+                                                         int64_t inner, int n_channels,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ std_) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c = (int)((i / (size_t)inner) % (size_t)n_channels);
+    float x = (float)src[i];
+    dst[i] = __fdiv_rn(__fsub_rn(x, mean[c]), std_[c]);
+  }
+}
+
+// vectorised variant: inner % 4 == 0 so the 4 lanes of a vector share a channel
+template <typename T>
+__global__ __launch_bounds__(256) void normalise_kernel_v4(const T* __restrict__ src,
+                                                            float* __restrict__ dst, size_t n4,
+                                                            int64_t inner4, int n_channels,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ std_) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    int c = (int)((i / (size_t)inner4) % (size_t)n_channels);
+    float m = mean[c], s = std_[c];
+    f32x4 x;
+    if constexpr (sizeof(T) == 2) {
+      u32x2 raw = *reinterpret_cast<const u32x2*>(src + i * 4);
+      x[0] = (float)(int16_t)(raw[0] & 0xffffu);
+      x[1] = (float)(int16_t)(raw[0] >> 16);
+      x[2] = (float)(int16_t)(raw[1] & 0xffffu);
+      x[3] = (float)(int16_t)(raw[1] >> 16);
+    } else {
+      x = *reinterpret_cast<const f32x4*>(src + i * 4);
+    }
+    f32x4 r;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r[v] = __fdiv_rn(__fsub_rn(x[v], m), s);
+    *reinterpret_cast<f32x4*>(dst + i * 4) = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv.remap(INTER_LINEAR) restated: 1/32-px fixed-point coordinates, 32x32 bilinear weight table
+// (SURVEY.md Appendix A.2).  One thread = VEC consecutive destination pixels of one image row,
+// all n_steps extrapolation steps: the flow vector (8 B/px, the dominant compulsory read) is read
+// once and reused for every step; the 4 source taps per pixel are gathers served by L1/L2.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cv_round_x86(float v) {
+  // cvRound(float) = cvtss2si: round-half-even; NaN / out of range -> INT_MIN
+  if (!(fabsf(v) < 2147483648.0f)) return (int)0x80000000;
+  return __float2int_rn(v);
+}
+__device__ __forceinline__ int sat_short(int v) {
+  return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <typename T>
+__device__ __forceinline__ T remap_one(const T* __restrict__ img, int h, int w, float mx, float my,
+                                       int border_mode, T border_value) {
+  int sx = cv_round_x86(mx * 32.0f);
+  int sy = cv_round_x86(my * 32.0f);
+  int fxi = sx & 31, fyi = sy & 31;
+  int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+  T p00, p01, p10, p11;
+  bool inside = (unsigned)ix < (unsigned)(w - 1) && (unsigned)iy < (unsigned)(h - 1);
+  if (inside) {
+    const T* p = img + (int64_t)iy * w + ix;
+    p00 = p[0]; p01 = p[1]; p10 = p[w]; p11 = p[w + 1];
+  } else if (border_mode == PV_BORDER_REPLICATE) {
+    int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
+    int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
+    p00 = img[(int64_t)y0 * w + x0]; p01 = img[(int64_t)y0 * w + x1];
+    p10 = img[(int64_t)y1 * w + x0]; p11 = img[(int64_t)y1 * w + x1];
+  } else {
+    if (ix >= w || ix + 1 < 0 || iy >= h || iy + 1 < 0) return border_value;
+    bool x0in = (unsigned)ix < (unsigned)w, x1in = (unsigned)(ix + 1) < (unsigned)w;
+    bool y0in = (unsigned)iy < (unsigned)h, y1in = (unsigned)(iy + 1) < (unsigned)h;
+    p00 = (x0in && y0in) ? img[(int64_t)iy * w + ix] : border_value;
+    p01 = (x1in && y0in) ? img[(int64_t)iy * w + ix + 1] : border_value;
+    p10 = (x0in && y1in) ? img[(int64_t)(iy + 1) * w + ix] : border_value;
+    p11 = (x1in && y1in) ? img[(int64_t)(iy + 1) * w + ix + 1] : border_value;
+  }
+  if constexpr (sizeof(T) == 4) {
+    // f32 table: products of (1 - k/32, k/32) -- exact multiples of 1/1024
+    float ax = (float)fxi * 0.03125f, ay = (float)fyi * 0.03125f;
+    float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay);
+    float w10 = (1.0f - ax) * ay, w11 = ax * ay;
+    float r = __fmul_rn(p00, w00);
+    r = __fadd_rn(r, __fmul_rn(p01, w01));
+    r = __fadd_rn(r, __fmul_rn(p10, w10));
+    r = __fadd_rn(r, __fmul_rn(p11, w11));
+    return r;
+  } else {
+    // u8: 15-bit fixed point weights, exact
+    int w00 = (32 - fxi) * (32 - fyi) * 32, w01 = fxi * (32 - fyi) * 32;
+    int w10 = (32 - fxi) * fyi * 32, w11 = fxi * fyi * 32;
+    if (w00 == 32768) w00 = 32767;  // saturate_cast<short> of the (0,0) table entry
+    int acc = (int)p00 * w00 + (int)p01 * w01 + (int)p10 * w10 + (int)p11 * w11;
+    int r = (acc + (1 << 14)) >> 15;
+    return (T)(r < 0 ? 0 : (r > 255 ? 255 : r));
+  }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ src, int64_t src_stride,
+                                                     const float* __restrict__ flow, int64_t flow_stride,
+                                                     T* __restrict__ dst, int64_t dst_image_stride,
+                                                     int64_t dst_step_stride, int64_t n_images,
+                                                     int n_steps, float step0, int h, int w,
+                                                     int border_mode, T border_value) {
+  int wq = w / VEC;
+  int64_t per_image = (int64_t)h * wq;
+  int64_t total = n_images * per_image;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int64_t img_i = i / per_image;
+    int rem = (int)(i - img_i * per_image);
+    int y = rem / wq;
+    int x0 = (rem - y * wq) * VEC;
+    const T* img = src + img_i * src_stride;
+    const float* fl = flow + img_i * flow_stride + ((int64_t)y * w + x0) * 2;
+    float fxv[VEC], fyv[VEC];
+    if constexpr (VEC == 4) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(fl);
+      f32x4 b = *reinterpret_cast<const f32x4*>(fl + 4);
+      fxv[0] = a[0]; fyv[0] = a[1]; fxv[1] = a[2]; fyv[1] = a[3];
+      fxv[2] = b[0]; fyv[2] = b[1]; fxv[3] = b[2]; fyv[3] = b[3];
+    } else {
+      fxv[0] = fl[0]; fyv[0] = fl[1];
+    }
+    for (int s = 0; s < n_steps; ++s) {
+      float k = step0 + (float)s;
+      T outv[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        // remap = -(flow * k); remap += arange   (f32, no fused multiply-add)
+        float mx = __fadd_rn(-__fmul_rn(fxv[v], k), (float)(x0 + v));
+        float my = __fadd_rn(-__fmul_rn(fyv[v], k), (float)y);
+        outv[v] = remap_one<T>(img, h, w, mx, my, border_mode, border_value);
+      }
+      T* d = dst + img_i * dst_image_stride + (int64_t)s * dst_step_stride + (int64_t)y * w + x0;
+      if constexpr (VEC == 4 && sizeof(T) == 4) {
+        f32x4 o = {(float)outv[0], (float)outv[1], (float)outv[2], (float)outv[3]};
+        *reinterpret_cast<f32x4*>(d) = o;
+      } else if constexpr (VEC == 4 && sizeof(T) == 1) {
+        uint32_t o = (uint32_t)outv[0] | ((uint32_t)outv[1] << 8) | ((uint32_t)outv[2] << 16) |
+                     ((uint32_t)outv[3] << 24);
+        *reinterpret_cast<uint32_t*>(d) = o;
+      } else {
+        d[0] = outv[0];
+      }
+    }
+  }
+}
+
+template <typename T>
+static int remap_launch(const T* src, int64_t src_stride, const float* flow, int64_t flow_stride,
+                        T* dst, int64_t dst_image_stride, int64_t dst_step_stride, int64_t n_images,
+                        int32_t n_steps, float step0, int32_t h, int32_t w, int border_mode,
+                        T border_value, void* stream) {
+  PV_REQUIRE(src && flow && dst, PV_EINVAL, "pv_remap_bilinear: null pointer");
+  PV_REQUIRE(n_images >= 0 && n_steps >= 0 && h > 0 && w > 0, PV_EINVAL,
+             "pv_remap_bilinear: bad sizes n_images=%lld n_steps=%d h=%d w=%d", (long long)n_images,
+             n_steps, h, w);
+  PV_REQUIRE(border_mode == PV_BORDER_CONSTANT || border_mode == PV_BORDER_REPLICATE, PV_EINVAL,
+             "pv_remap_bilinear: border_mode %d not supported", border_mode);
+  PV_REQUIRE(h <= 32767 && w <= 32767, PV_ESIZE, "pv_remap_bilinear: image larger than SHRT_MAX");
+  if (n_images == 0 || n_steps == 0) return PV_OK;
+  const size_t esz = sizeof(T);
+  bool vec_ok = (w % 4 == 0) && (flow_stride % 4 == 0) && ((uintptr_t)flow % 16 == 0) &&
+                ((dst_image_stride * esz) % (4 * esz) == 0) && ((dst_step_stride * esz) % (4 * esz) == 0) &&
+                ((uintptr_t)dst % (4 * esz) == 0);
+  hipStream_t st = as_stream(stream);
+  if (vec_ok) {
+    size_t work = (size_t)n_images * h * (w / 4);
+    hipLaunchKernelGGL((remap_kernel<T, 4>), dim3(stream_grid(work, 256)), dim3(256), 0, st, src,
+                       src_stride, flow, flow_stride, dst, dst_image_stride, dst_step_stride, n_images,
+                       n_steps, step0, h, w, border_mode, border_value);
+  } else {
+    size_t work = (size_t)n_images * h * w;
+    hipLaunchKernelGGL((remap_kernel<T, 1>), dim3(stream_grid(work, 256)), dim3(256), 0, st, src,
+                       src_stride, flow, flow_stride, dst, dst_image_stride, dst_step_stride, n_images,
+                       n_steps, step0, h, w, border_mode, border_value);
+  }
+  return check_launch("pv_remap_bilinear");
+}
+
+template <typename T>
+static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag, void* stream) {
+  PV_REQUIRE(src && dst, PV_EINVAL, "pv_u8_from_10bit: null pointer");
+  PV_REQUIRE(mode == PV_U8_ROUND_DIV4 || mode == PV_U8_TRUNC_SCALE, PV_EINVAL,
+             "pv_u8_from_10bit: bad mode %d", mode);
+  PV_REQUIRE(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), PV_EINVAL,
+             "pv_u8_from_10bit: src must be 16-byte and dst 8-byte aligned");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL((u8_from_10bit_kernel<T>), dim3(stream_grid((n + 7) / 8, 256)), dim3(256), 0,
+                     as_stream(stream), src, dst, n, mode, range_flag);
+  return check_launch("pv_u8_from_10bit");
+}
+
+template <typename T>
+static int normalise_launch(const T* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
+                            const float* mean, const float* std_, void* stream) {
+  PV_REQUIRE(src && dst && mean && std_, PV_EINVAL, "pv_normalise: null pointer");
+  PV_REQUIRE(inner > 0 && n_channels > 0, PV_EINVAL, "pv_normalise: bad inner/n_channels");
+  if (n == 0) return PV_OK;
+  hipStream_t st = as_stream(stream);
+  bool vec = (inner % 4 == 0) && (n % 4 == 0) && ((uintptr_t)src % (4 * sizeof(T)) == 0) &&
+             ((uintptr_t)dst % 16 == 0);
+  if (vec) {
+    hipLaunchKernelGGL((normalise_kernel_v4<T>), dim3(stream_grid(n / 4, 256)), dim3(256), 0, st, src,
+                       dst, n / 4, inner / 4, n_channels, mean, std_);
+  } else {
+    hipLaunchKernelGGL((normalise_kernel<T>), dim3(stream_grid(n, 256)), dim3(256), 0, st, src, dst,
+                       n, inner, n_channels, mean, std_);
+  }
+  return check_launch("pv_normalise");
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_abi_version(void) { return PV_ABI_VERSION; }
+const char* pv_last_error(void) { return pv::err_buf(); }
+
+int pv_u8_from_10bit_i16(const int16_t* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag,
+                         void* stream) {
+  return u8_launch<int16_t>(src, dst, n, mode, range_flag, stream);
+}
+int pv_u8_from_10bit_f32(const float* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag,
+                         void* stream) {
+  return u8_launch<float>(src, dst, n, mode, range_flag, stream);
+}
+
+int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host, float* out,
+                              int64_t n_groups, int32_t n_per_group, int64_t elems, void* stream) {
+  PV_REQUIRE(flows && out, PV_EINVAL, "pv_flow_weighted_mean_f32: null pointer");
+  PV_REQUIRE(n_per_group >= 1 && n_per_group <= 64, PV_ESIZE,
+             "pv_flow_weighted_mean_f32: n_per_group=%d outside 1..64", n_per_group);
+  PV_REQUIRE(n_groups >= 0 && elems > 0, PV_EINVAL, "pv_flow_weighted_mean_f32: bad sizes");
+  if (n_groups == 0) return PV_OK;
+  WMeanWeights wts;
+  double s = 0.0;
+  for (int i = 0; i < 64; ++i) wts.w[i] = 0.0;
+  for (int i = 0; i < n_per_group; ++i) {
+    wts.w[i] = weights_host ? weights_host[i] : (double)(i + 1);
+    s += wts.w[i];
+  }
+  PV_REQUIRE(s != 0.0, PV_EINVAL, "pv_flow_weighted_mean_f32: weights sum to zero");
+  wts.sum = s;
+  wts.inv_unused = 0.0;
+  hipStream_t st = as_stream(stream);
+  bool vec = (elems % 4 == 0) && ((uintptr_t)flows % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (vec) {
+    hipLaunchKernelGGL((weighted_mean_kernel<4>), dim3(stream_grid((size_t)n_groups * (elems / 4), 256)),
+                       dim3(256), 0, st, flows, out, n_groups, n_per_group, elems, wts);
+  } else {
+    hipLaunchKernelGGL((weighted_mean_kernel<1>), dim3(stream_grid((size_t)n_groups * elems, 256)),
+                       dim3(256), 0, st, flows, out, n_groups, n_per_group, elems, wts);
+  }
+  return check_launch("pv_flow_weighted_mean_f32");
+}
+
+int pv_remap_bilinear_f32(const float* src, int64_t src_stride, const float* flow, int64_t flow_stride,
+                          float* dst, int64_t dst_image_stride, int64_t dst_step_stride,
+                          int64_t n_images, int32_t n_steps, float step0, int32_t h, int32_t w,
+                          int border_mode, float border_value, void* stream) {
+  return remap_launch<float>(src, src_stride, flow, flow_stride, dst, dst_image_stride, dst_step_stride,
+                             n_images, n_steps, step0, h, w, border_mode, border_value, stream);
+}
+int pv_remap_bilinear_u8(const uint8_t* src, int64_t src_stride, const float* flow, int64_t flow_stride,
+                         uint8_t* dst, int64_t dst_image_stride, int64_t dst_step_stride,
+                         int64_t n_images, int32_t n_steps, float step0, int32_t h, int32_t w,
+                         int border_mode, uint8_t border_value, void* stream) {
+  return remap_launch<uint8_t>(src, src_stride, flow, flow_stride, dst, dst_image_stride,
+                               dst_step_stride, n_images, n_steps, step0, h, w, border_mode,
+                               border_value, stream);
+}
+
+int pv_normalise_i16(const int16_t* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
+                     const float* mean, const float* std_, void* stream) {
+  return normalise_launch<int16_t>(src, dst, n, inner, n_channels, mean, std_, stream);
+}
+int pv_normalise_f32(const float* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
+                     const float* mean, const float* std_, void* stream) {
+  return normalise_launch<float>(src, dst, n, inner, n_channels, mean, std_, stream);
+}
+
+}  // extern "C"

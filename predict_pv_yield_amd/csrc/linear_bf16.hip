@@ -1,0 +1,297 @@
+// bf16 kernels for the one big fully-connected layer, fc1 (in_features = cnn_output_size ~ 1.0e6,
+// out_features = 128; predict_pv_yield/models/conv3d/model.py:74-78,92,125).  fc1 holds 99.9 % of the
+// model's parameters: every kernel here is a single streaming pass over the [N, K] weight (or gradient)
+// matrix and is HBM-bound; the contraction runs on MFMA only so that the VALU stays out of the way.
+//
+//   fwd : y[M,N]  = x[M,K] . w[N,K]^T   split-K over workgroups, f32 slabs + fixed-order reduce
+//   bwd : dx[M,K] = g[M,N] . w[N,K]     (bf16 out);  dw[N,K] = g^T . x (f32 out);  db[N] = colsum(g)
+//         with g = dy ⊙ (y > 0)
+#include "pv_common.h"
+
+namespace pv {
+
+// ---------------------------------------------------------------------------------------------
+// forward: one workgroup = one K-range, 4 waves = 4 n-tiles of 32 output features, MT m-tiles
+// of 32 rows.  k-permutation: inside a 64-deep k-block lane (r, h) owns k = 32*h + 8*s + j for
+// k-step s, so each lane streams 64 contiguous bytes of its row; A and B use the same map.
+// ---------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ w,
+                                                               float* __restrict__ partial, int m, int n,
+                                                               long long k, int kblocks_per_wg) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt = blockIdx.y * 4 + wave;
+  const long long total_kb = (k + 63) / 64;
+  const long long kb0 = (long long)blockIdx.x * kblocks_per_wg;
+  long long kb1 = kb0 + kblocks_per_wg;
+  if (kb1 > total_kb) kb1 = total_kb;
+
+  int wrow = nt * 32 + r;
+  if (wrow > n - 1) wrow = n - 1;
+  const uint16_t* wp = w + (size_t)wrow * k + 32 * hh;
+  const uint16_t* xp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int xrow = mt * 32 + r;
+    if (xrow > m - 1) xrow = m - 1;
+    xp[mt] = x + (size_t)xrow * k + 32 * hh;
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[mt][j] = 0.f;
+
+  const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f,
+                        (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll 2
+  for (long long kb = kb0; kb < kb1; ++kb) {
+    const long long kbase = kb * 64;
+    bf16x8 wv[4];
+    bf16x8 xv[MT][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = kbase + 32 * hh + 8 * s + 8 <= k;
+      wv[s] = ok ? *reinterpret_cast<const bf16x8*>(wp + kbase + 8 * s) : zero8;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        xv[mt][s] = ok ? *reinterpret_cast<const bf16x8*>(xp[mt] + kbase + 8 * s) : zero8;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv[mt][s], wv[s], acc[mt], 0, 0, 0);
+  }
+  // C layout: col = lane&31 = output feature, row = sample
+  const int col = nt * 32 + r;
+  if (col < n) {
+    float* dst = partial + (size_t)blockIdx.x * m * n + col;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (row < m) dst[(size_t)row * n] = acc[mt][j];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __restrict__ partial,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int m, int n, int k_splits, int relu) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n) return;
+  float s = 0.f;
+  for (int ks = 0; ks < k_splits; ++ks) s += partial[(size_t)ks * m * n + i];
+  if (bias) s += bias[i % n];
+  if (relu) s = s > 0.f ? s : 0.f;
+  y[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (f32 VALU outer products; both kernels stream [N,K] once per tile row and are
+// bandwidth-bound on the 0.5 GB gradient / 0.26 GB weight matrices)
+// ---------------------------------------------------------------------------------------------
+constexpr int BT = 8;  // tile of the small dimension held in registers
+
+// dx[m0..m0+7][k..k+7] = sum_n g[m][n] * w[n][k..k+7]
+__global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t* __restrict__ w,
+                                                                  const float* __restrict__ dy,
+                                                                  const float* __restrict__ ymask,
+                                                                  uint16_t* __restrict__ dx, int m, int n, long long k) {
+  extern __shared__ float g[];  // [n][BT]
+  const int m0 = blockIdx.y * BT;
+  for (int i = threadIdx.x; i < n * BT; i += blockDim.x) {
+    int col = i / BT, rr = i % BT;
+    float v = 0.f;
+    if (m0 + rr < m) {
+      size_t off = (size_t)(m0 + rr) * n + col;
+      v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    }
+    g[i] = v;
+  }
+  __syncthreads();
+  const long long k8 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (k8 >= k) return;
+  float acc[BT][8];
+#pragma unroll
+  for (int i = 0; i < BT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  for (int col = 0; col < n; ++col) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(w + (size_t)col * k + k8);
+    float wv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      wv[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
+      wv[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
+    }
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + col * BT);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(g + col * BT + 4);
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const float gv = i < 4 ? g0[i] : g1[i - 4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(gv, wv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BT; ++i) {
+    if (m0 + i < m) {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
+      *reinterpret_cast<u32x4*>(dx + (size_t)(m0 + i) * k + k8) = o;
+    }
+  }
+}
+
+// dw[n0..n0+7][k..k+7] = sum_m g[m][n] * x[m][k..k+7]
+__global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t* __restrict__ x,
+                                                                  const float* __restrict__ dy,
+                                                                  const float* __restrict__ ymask,
+                                                                  float* __restrict__ dw, int m, int n, long long k) {
+  extern __shared__ float g[];  // [m][BT]
+  const int n0 = blockIdx.y * BT;
+  for (int i = threadIdx.x; i < m * BT; i += blockDim.x) {
+    int rr = i / BT, j = i % BT;
+    float v = 0.f;
+    if (n0 + j < n) {
+      size_t off = (size_t)rr * n + n0 + j;
+      v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    }
+    g[i] = v;
+  }
+  __syncthreads();
+  const long long k8 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (k8 >= k) return;
+  float acc[BT][8];
+#pragma unroll
+  for (int i = 0; i < BT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+  for (int rr = 0; rr < m; ++rr) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)rr * k + k8);
+    float xv[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      xv[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
+      xv[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
+    }
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + rr * BT);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(g + rr * BT + 4);
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const float gv = i < 4 ? g0[i] : g1[i - 4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(gv, xv[j], acc[i][j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BT; ++i) {
+    if (n0 + i < n) {
+      f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+      float* dst = dw + (size_t)(n0 + i) * k + k8;
+      *reinterpret_cast<f32x4*>(dst) = o0;
+      *reinterpret_cast<f32x4*>(dst + 4) = o1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                               float* __restrict__ db, int m, int n) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= n) return;
+  float s = 0.f;
+  for (int rr = 0; rr < m; ++rr) {
+    size_t off = (size_t)rr * n + col;
+    float v = dy[off];
+    if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    s += v;
+  }
+  db[col] = s;
+}
+
+static int bf16_fwd_split(long long k, int* kblocks_per_wg) {
+  long long total_kb = (k + 63) / 64;
+  long long nwg = total_kb < 512 ? total_kb : 512;
+  long long per = (total_kb + nwg - 1) / nwg;
+  nwg = (total_kb + per - 1) / per;
+  *kblocks_per_wg = (int)per;
+  return (int)nwg;
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes) {
+  PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bf16_workspace_bytes: bad arguments");
+  int per;
+  int nwg = bf16_fwd_split(k, &per);
+  *bytes = (size_t)nwg * m * n * sizeof(float);
+  return PV_OK;
+}
+
+int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, float* y, int32_t m, int32_t n,
+                       int64_t k, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+  PV_REQUIRE(x && w && y && workspace, PV_EINVAL, "pv_linear_fwd_bf16: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_fwd_bf16: bad sizes");
+  PV_REQUIRE(k % 8 == 0, PV_ESIZE, "pv_linear_fwd_bf16: k=%lld must be a multiple of 8", (long long)k);
+  PV_REQUIRE(m <= 128, PV_ESIZE, "pv_linear_fwd_bf16: m=%d > 128 rows per call", m);
+  PV_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), PV_EINVAL, "pv_linear_fwd_bf16: unaligned operand");
+  int per;
+  int nwg = bf16_fwd_split(k, &per);
+  PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)nwg, (unsigned)((n + 127) / 128));
+  const int mt = (m + 31) / 32;
+  float* part = (float*)workspace;
+  switch (mt) {
+    case 1: hipLaunchKernelGGL(linear_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
+    case 2: hipLaunchKernelGGL(linear_fwd_bf16_kernel<2>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
+    case 3: hipLaunchKernelGGL(linear_fwd_bf16_kernel<3>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
+    default: hipLaunchKernelGGL(linear_fwd_bf16_kernel<4>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
+  }
+  hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                     bias, y, m, n, nwg, relu ? 1 : 0);
+  return check_launch("pv_linear_fwd_bf16");
+}
+
+int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, const float* y_relu_mask, uint16_t* dx,
+                       float* dw, float* db, int32_t m, int32_t n, int64_t k, void* stream) {
+  PV_REQUIRE(dy, PV_EINVAL, "pv_linear_bwd_bf16: null dy");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_bwd_bf16: bad sizes (k must be a multiple of 8)");
+  hipStream_t st = as_stream(stream);
+  unsigned kb = (unsigned)((k / 8 + 255) / 256);
+  if (dx) {
+    PV_REQUIRE(w, PV_EINVAL, "pv_linear_bwd_bf16: dx needs w");
+    size_t lds = (size_t)n * BT * sizeof(float);
+    PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: n=%d too large", n);
+    hipLaunchKernelGGL(linear_bwd_dx_bf16_kernel, dim3(kb, (unsigned)((m + BT - 1) / BT)), dim3(256), lds, st, w, dy,
+                       y_relu_mask, dx, m, n, (long long)k);
+  }
+  if (dw) {
+    PV_REQUIRE(x, PV_EINVAL, "pv_linear_bwd_bf16: dw needs x");
+    size_t lds = (size_t)m * BT * sizeof(float);
+    PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: m=%d too large", m);
+    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
+                       y_relu_mask, dw, m, n, (long long)k);
+  }
+  if (db) {
+    hipLaunchKernelGGL(linear_bwd_db_bf16path, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y_relu_mask, db, m, n);
+  }
+  return check_launch("pv_linear_bwd_bf16");
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// Shared helpers for the gfx950 kernels behind include/pv_yield_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+#include <algorithm>
+#include "../../include/pv_yield_hip.h"
+
+namespace pv {
+
+// thread-local description of the last failure (pv_last_error()).
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PV_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return PV_OK;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kNumCU = 256;    // MI355X
+
+// grid for a grid-stride streaming kernel: enough blocks to fill 256 CUs x 8, no more.
+inline unsigned stream_grid(size_t work_items, unsigned block) {
+  size_t blocks = (work_items + block - 1) / block;
+  size_t cap = (size_t)kNumCU * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// ---- bf16 helpers (storage type uint16_t at the ABI, __bf16 in kernels) ----
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  // plain cast: v_cvt_pk_bf16_f32 (RNE, NaN preserved) on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t u) {
+  return __builtin_bit_cast(float, (uint32_t)u << 16);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+}  // namespace pv
+
+#define PV_REQUIRE(cond, code, ...) \
+  do { if (!(cond)) return pv::fail(code, __VA_ARGS__); } while (0)

@@ -1,0 +1,180 @@
+"""torch.autograd.Function wrappers over the HIP kernels: the operator boundary of SURVEY.md §8b.
+
+Reference operators replaced (all third-party torch in the reference):
+  F.relu(nn.Conv3d(...)(x))   predict_pv_yield/models/conv3d/model.py:117-120
+  F.relu(nn.Linear(...)(x))   model.py:125-126,151-152
+  (y_hat - y).abs().mean()    predict_pv_yield/models/base_model.py:99
+Two numeric modes:
+  "fp32": reference layout NCDHW, exact-f32 FMA kernels (tight parity with torch CPU);
+  "bf16": NDHWC bf16 activations, MFMA kernels with f32 accumulation (throughput path).
+"""
+import ctypes
+
+import torch
+
+from . import hip_ops as K
+from ._lib import check, current_stream_ptr, get_lib, ptr
+
+
+# ---------------------------------------------------------------------------------------------
+# fp32 path
+# ---------------------------------------------------------------------------------------------
+class Conv3dReLUF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding, relu):
+        x = x.contiguous()
+        y = K.conv3d_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, padding, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.padding, ctx.has_bias = padding, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv3d_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.padding)
+        dw, db = K.conv3d_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.padding, need_bias=ctx.has_bias)
+        return dx, dw, db, None, None
+
+
+class LinearF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        y = K.linear_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dx, dw, db = K.linear_bwd_f32(x, weight.contiguous(), dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_bias else None), None
+
+
+def conv3d_relu_f32(x, weight, bias, padding=(0, 0, 0), relu=True):
+    return Conv3dReLUF32.apply(x, weight, bias, tuple(padding), relu)
+
+
+def linear_f32(x, weight, bias, relu=False):
+    return LinearF32.apply(x, weight, bias, relu)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16 path
+# ---------------------------------------------------------------------------------------------
+class PackInputBF16(torch.autograd.Function):
+    """x[B,C,T,H,W] f32 -> NDHWC bf16 (channel-padded).  The satellite input needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out = K.pack_ncdhw_f32_to_ndhwc_bf16(x.contiguous())
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None
+
+
+class Conv3dReLUBF16(torch.autograd.Function):
+    """xp [B,T,H,W,CPAD] bf16 -> y bf16 NDHWC [B,To,Ho,Wo,32] (or NCDHW [B,Co,To,Ho,Wo] when y_ncdhw)."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw):
+        wp = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=False)
+        c_out = weight.shape[0]
+        y = K.conv3d_fwd_bf16(xp, None, wp, bias.contiguous() if bias is not None else None, c_in, c_out, padding, relu,
+                              y_ncdhw)
+        ctx.save_for_backward(xp, weight, y if relu else None)
+        ctx.cfg = (c_in, c_out, padding, relu, y_ncdhw, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight, y = ctx.saved_tensors
+        c_in, c_out, padding, relu, y_ncdhw, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        if y_ncdhw:
+            # fc1 hands back the gradient in flatten (NCDHW) order: gate + transpose in one pass
+            dy = K.repack_gate_ncdhw_to_ndhwc_bf16(dy, y)
+            gate = None
+        else:
+            gate = y
+        dw, db = K.conv3d_bwd_weight_bf16(xp, dy, gate, c_in, c_out, padding)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dgrad = the forward kernel on dy with padding 2-p and mirrored, channel-swapped weights
+            wpt = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=True)
+            pad_b = tuple(2 - p for p in padding)
+            dx = K.conv3d_fwd_bf16(dy, gate, wpt, None, c_out, c_in, pad_b, relu=False, y_ncdhw=False)
+            if K.bf16_cpad(c_in) != 32:
+                dx = dx[..., : K.bf16_cpad(c_in)].contiguous()
+        return dx, dw, (db if has_bias else None), None, None, None, None
+
+
+def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a big f32 parameter, kept current by HipAdam (pv_adam_step_f32 writes it)."""
+    shadow = getattr(weight, "_pv_bf16_shadow", None)
+    version = getattr(weight, "_pv_bf16_shadow_version", None)
+    if shadow is None or shadow.device != weight.device or version != weight._version:
+        shadow = torch.empty(weight.shape, dtype=torch.bfloat16, device=weight.device)
+        check(get_lib().pv_cast_f32_to_bf16(ptr(weight.detach()), ptr(shadow), weight.numel(), current_stream_ptr()),
+              "pv_cast_f32_to_bf16")
+        weight._pv_bf16_shadow = shadow
+        weight._pv_bf16_shadow_version = weight._version
+    return shadow
+
+
+class LinearBF16(torch.autograd.Function):
+    """fc1: x bf16 [B,K] . bf16(weight)[N,K]^T, f32 accumulate; dw/db f32, dx bf16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = x.contiguous()
+        wb = bf16_shadow_of(weight)
+        y = K.linear_fwd_bf16(x, wb, bias.contiguous() if bias is not None else None, relu)
+        ctx.save_for_backward(x, wb, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb, y = ctx.saved_tensors
+        dx, dw, db = K.linear_bwd_bf16(x, wb, dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_bias else None), None
+
+
+def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False):
+    return Conv3dReLUBF16.apply(xp, weight, bias, c_in, tuple(padding), relu, y_ncdhw)
+
+
+def linear_bf16(x, weight, bias, relu=False):
+    return LinearBF16.apply(x, weight, bias, relu)
+
+
+# ---------------------------------------------------------------------------------------------
+# loss
+# ---------------------------------------------------------------------------------------------
+class ForecastLosses(torch.autograd.Function):
+    """Returns f32[4] = (mse, nmae, mse_exp, mae_exp); only nmae (index 1) carries a gradient, as in the
+    reference where the returned loss is nmae (base_model.py:146)."""
+
+    @staticmethod
+    def forward(ctx, y_hat, y):
+        y_hat = y_hat.contiguous()
+        out4, grad = K.forecast_losses(y_hat, y, need_grad=True)
+        ctx.save_for_backward(grad)
+        return out4
+
+    @staticmethod
+    def backward(ctx, g4):
+        (grad,) = ctx.saved_tensors
+        return grad * g4[1], None
+
+
+def forecast_losses(y_hat, y):
+    return ForecastLosses.apply(y_hat, y)

@@ -1,0 +1,371 @@
+"""Tensor-level wrappers over the C ABI (include/pv_yield_hip.h).
+
+Every function here launches hand-written gfx950 kernels through libpvyield_hip.so on torch's current
+HIP stream.  torch is used for device memory and streams only.  There is no CPU fallback: CPU tensors
+or a missing library raise.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (Conv3dDims, FarnebackParams, PV_BORDER_CONSTANT, PV_BORDER_REPLICATE,
+                   PV_OPTFLOW_FARNEBACK_GAUSSIAN, check, current_stream_ptr, get_lib, ptr, require_cuda)
+
+c_i32, c_i64, c_f32, c_f64, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
+
+
+# ------------------------------------------------------------------------------------------------
+# optical-flow advection
+# ------------------------------------------------------------------------------------------------
+def u8_from_10bit(x: torch.Tensor, mode: int = 0, return_flag: bool = False):
+    """convert_10bpp_to_uint8 (notebooks/13_...ipynb:112-119); x int16 or float32, any shape."""
+    require_cuda(x)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    lib = get_lib()
+    if x.dtype == torch.int16:
+        fn = lib.pv_u8_from_10bit_i16
+    elif x.dtype == torch.float32:
+        fn = lib.pv_u8_from_10bit_f32
+    else:
+        raise TypeError(f"u8_from_10bit: int16 or float32 expected, got {x.dtype}")
+    check(fn(ptr(x), ptr(out), x.numel(), mode, ptr(flag), current_stream_ptr()), "pv_u8_from_10bit")
+    return (out, flag) if return_flag else out
+
+
+def make_farneback_params(pyr_scale=0.5, levels=2, winsize=40, iterations=3, poly_n=5, poly_sigma=0.7,
+                          flags=PV_OPTFLOW_FARNEBACK_GAUSSIAN) -> FarnebackParams:
+    return FarnebackParams(float(pyr_scale), int(levels), int(winsize), int(iterations), int(poly_n),
+                           float(poly_sigma), int(flags))
+
+
+_workspaces = {}
+
+
+def _workspace(key: str, nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffers owned by the host side (the C ABI never allocates)."""
+    k = (key, str(device))
+    buf = _workspaces.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[k] = buf
+    return buf
+
+
+def farneback_stack(frames_u8: torch.Tensor, **kwargs) -> torch.Tensor:
+    """compute_optical_flow (notebooks/13_...ipynb:175-240) for a batch of frame stacks.
+    frames_u8: [..., T, H, W] uint8 -> flow [..., T-1, H, W, 2] float32, one Farnebäck field per
+    consecutive pair.  One batched launch sequence replaces the reference's process pool."""
+    require_cuda(frames_u8)
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() < 3:
+        raise TypeError("farneback_stack: uint8 [..., T, H, W] expected")
+    *lead, t, h, w = frames_u8.shape
+    n_stacks = int(np.prod(lead)) if lead else 1
+    if t < 2:
+        raise ValueError("farneback_stack: need at least 2 frames")
+    params = make_farneback_params(**kwargs)
+    lib = get_lib()
+    flows = torch.empty((*lead, t - 1, h, w, 2), dtype=torch.float32, device=frames_u8.device)
+    if n_stacks == 0:
+        return flows
+    n_pairs = n_stacks * (t - 1)
+    need = c_sz(0)
+    check(lib.pv_farneback_workspace_bytes(n_pairs, h, w, ctypes.byref(params), ctypes.byref(need)),
+          "pv_farneback_workspace_bytes")
+    ws = _workspace("farneback", need.value, frames_u8.device)
+    hw = h * w
+    base = frames_u8.data_ptr()
+    check(lib.pv_farneback_batch_u8(ctypes.c_void_p(base), ctypes.c_void_p(base + hw), hw, hw, t - 1, t * hw,
+                                    ptr(flows), n_pairs, h, w, ctypes.byref(params), ptr(ws), ws.numel(),
+                                    current_stream_ptr()), "pv_farneback_batch_u8")
+    return flows
+
+
+def farneback_pairs(prev_u8: torch.Tensor, next_u8: torch.Tensor, **kwargs) -> torch.Tensor:
+    """cv.calcOpticalFlowFarneback batched: prev/next uint8 [N, H, W] -> flow f32 [N, H, W, 2]."""
+    require_cuda(prev_u8, next_u8)
+    if prev_u8.shape != next_u8.shape or prev_u8.dtype != torch.uint8 or next_u8.dtype != torch.uint8:
+        raise TypeError("farneback_pairs: two uint8 tensors of equal shape expected")
+    n, h, w = prev_u8.shape
+    params = make_farneback_params(**kwargs)
+    lib = get_lib()
+    need = c_sz(0)
+    check(lib.pv_farneback_workspace_bytes(n, h, w, ctypes.byref(params), ctypes.byref(need)),
+          "pv_farneback_workspace_bytes")
+    ws = _workspace("farneback", need.value, prev_u8.device)
+    flow = torch.empty((n, h, w, 2), dtype=torch.float32, device=prev_u8.device)
+    check(lib.pv_farneback_batch_u8(ptr(prev_u8), ptr(next_u8), h * w, h * w, 0, 0, ptr(flow), n, h, w, ctypes.byref(params),
+                                    ptr(ws), ws.numel(), current_stream_ptr()), "pv_farneback_batch_u8")
+    return flow
+
+
+def flow_weighted_mean(flows: torch.Tensor, weights: Optional[Sequence[float]] = None) -> torch.Tensor:
+    """weighted_average (notebooks/optical_flow_1.ipynb:293-294): flows [G, N, ...] -> [G, ...]."""
+    require_cuda(flows)
+    if flows.dtype != torch.float32 or flows.dim() < 3:
+        raise TypeError("flow_weighted_mean: float32 [G, N, ...] expected")
+    g, n = flows.shape[:2]
+    elems = flows[0, 0].numel()
+    out = torch.empty((g, *flows.shape[2:]), dtype=torch.float32, device=flows.device)
+    warr = None
+    if weights is not None:
+        warr = (c_f64 * n)(*[float(v) for v in weights])
+    check(get_lib().pv_flow_weighted_mean_f32(ptr(flows), warr, ptr(out), g, n, elems, current_stream_ptr()),
+          "pv_flow_weighted_mean_f32")
+    return out
+
+
+def remap_bilinear(src: torch.Tensor, flow: torch.Tensor, n_steps: int = 1, step0: float = 1.0,
+                   border_mode: int = PV_BORDER_CONSTANT, border_value: float = float("nan"),
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """remap_image batched (notebooks/13_...ipynb:259-281): src [N,H,W] (f32 or u8), flow f32 [N,H,W,2]
+    -> dst [N, n_steps, H, W]; step s is cv.remap(src, meshgrid - flow*(step0+s), INTER_LINEAR, border)."""
+    require_cuda(src, flow)
+    n, h, w = src.shape
+    if flow.shape != (n, h, w, 2) or flow.dtype != torch.float32:
+        raise TypeError("remap_bilinear: flow must be float32 [N,H,W,2] matching src")
+    if out is None:
+        out = torch.empty((n, n_steps, h, w), dtype=src.dtype, device=src.device)
+        img_stride, step_stride = n_steps * h * w, h * w
+    else:
+        require_cuda(out)
+        if out.shape != (n, n_steps, h, w) or out.dtype != src.dtype:
+            raise TypeError("remap_bilinear: bad out tensor")
+        img_stride, step_stride = out.stride(0), out.stride(1)
+    lib = get_lib()
+    if src.dtype == torch.float32:
+        check(lib.pv_remap_bilinear_f32(ptr(src), h * w, ptr(flow), h * w * 2, ptr(out), img_stride, step_stride, n,
+                                        n_steps, step0, h, w, border_mode, border_value, current_stream_ptr()),
+              "pv_remap_bilinear_f32")
+    elif src.dtype == torch.uint8:
+        bv = 0 if border_value != border_value else int(border_value)
+        check(lib.pv_remap_bilinear_u8(ptr(src), h * w, ptr(flow), h * w * 2, ptr(out), img_stride, step_stride, n,
+                                       n_steps, step0, h, w, border_mode, bv, current_stream_ptr()),
+              "pv_remap_bilinear_u8")
+    else:
+        raise TypeError("remap_bilinear: float32 or uint8 images expected")
+    return out
+
+
+def remap_bilinear_strided(src_ptr: int, src_stride: int, flow: torch.Tensor, out_ptr: int, out_image_stride: int,
+                           out_step_stride: int, n: int, n_steps: int, step0: float, h: int, w: int,
+                           border_mode: int, border_value: float) -> None:
+    """f32 remap on raw strided views (used to write advected frames straight into the conv input stack)."""
+    check(get_lib().pv_remap_bilinear_f32(ctypes.c_void_p(src_ptr), src_stride, ptr(flow), h * w * 2,
+                                          ctypes.c_void_p(out_ptr), out_image_stride, out_step_stride, n, n_steps,
+                                          step0, h, w, border_mode, border_value, current_stream_ptr()),
+          "pv_remap_bilinear_f32")
+
+
+def normalise(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, inner: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(x - mean[c]) / std[c] with c = (flat_index // inner) % len(mean); x int16 or f32."""
+    require_cuda(x, mean, std)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    lib = get_lib()
+    fn = lib.pv_normalise_i16 if x.dtype == torch.int16 else lib.pv_normalise_f32
+    if x.dtype not in (torch.int16, torch.float32):
+        raise TypeError("normalise: int16 or float32 expected")
+    check(fn(ptr(x), ptr(out), x.numel(), inner, mean.numel(), ptr(mean), ptr(std), current_stream_ptr()),
+          "pv_normalise")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv3D
+# ------------------------------------------------------------------------------------------------
+def conv_dims(batch, c_in, c_out, t, h, w, padding=(0, 0, 0)) -> Conv3dDims:
+    return Conv3dDims(batch, c_in, c_out, t, h, w, padding[0], padding[1], padding[2])
+
+
+def conv3d_fwd_f32(x, weight, bias, padding=(0, 0, 0), relu=False):
+    require_cuda(x, weight, bias)
+    b, ci, t, h, w = x.shape
+    co = weight.shape[0]
+    d = conv_dims(b, ci, co, t, h, w, padding)
+    to, ho, wo = d.out_shape()
+    y = torch.empty((b, co, to, ho, wo), dtype=torch.float32, device=x.device)
+    check(get_lib().pv_conv3d_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
+                                      current_stream_ptr()), "pv_conv3d_fwd_f32")
+    return y
+
+
+def conv3d_bwd_data_f32(dy, y_mask, weight, x_shape, padding=(0, 0, 0)):
+    require_cuda(dy, y_mask, weight)
+    b, ci, t, h, w = x_shape
+    d = conv_dims(b, ci, weight.shape[0], t, h, w, padding)
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    check(get_lib().pv_conv3d_bwd_data_f32(ptr(dy), ptr(y_mask), ptr(weight), ptr(dx), ctypes.byref(d),
+                                           current_stream_ptr()), "pv_conv3d_bwd_data_f32")
+    return dx
+
+
+def conv3d_bwd_weight_f32(x, dy, y_mask, weight_shape, padding=(0, 0, 0), need_bias=True):
+    require_cuda(x, dy, y_mask)
+    b, ci, t, h, w = x.shape
+    d = conv_dims(b, ci, weight_shape[0], t, h, w, padding)
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if need_bias else None
+    check(get_lib().pv_conv3d_bwd_weight_f32(ptr(x), ptr(dy), ptr(y_mask), ptr(dw), ptr(db), ctypes.byref(d),
+                                             current_stream_ptr()), "pv_conv3d_bwd_weight_f32")
+    return dw, db
+
+
+def bf16_cpad(c: int) -> int:
+    v = get_lib().pv_bf16_cpad(c)
+    if v <= 0:
+        raise ValueError(f"bf16 path supports 1..32 channels, got {c}")
+    return v
+
+
+def pack_ncdhw_f32_to_ndhwc_bf16(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    b, c, t, h, w = x.shape
+    xp = torch.empty((b, t, h, w, bf16_cpad(c)), dtype=torch.bfloat16, device=x.device)
+    check(get_lib().pv_pack_ncdhw_f32_to_ndhwc_bf16(ptr(x), ptr(xp), b, c, t, h, w, current_stream_ptr()),
+          "pv_pack_ncdhw_f32_to_ndhwc_bf16")
+    return xp
+
+
+def unpack_ndhwc_bf16_to_ncdhw_f32(xp: torch.Tensor, c: int) -> torch.Tensor:
+    require_cuda(xp)
+    b, t, h, w, cpad = xp.shape
+    x = torch.empty((b, c, t, h, w), dtype=torch.float32, device=xp.device)
+    check(get_lib().pv_unpack_ndhwc_bf16_to_ncdhw_f32(ptr(xp), ptr(x), b, c, t, h, w, current_stream_ptr()),
+          "pv_unpack_ndhwc_bf16_to_ncdhw_f32")
+    return x
+
+
+def repack_gate_ncdhw_to_ndhwc_bf16(dy: torch.Tensor, y_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    require_cuda(dy, y_mask)
+    b, c, t, h, w = dy.shape
+    out = torch.empty((b, t, h, w, 32), dtype=torch.bfloat16, device=dy.device)
+    check(get_lib().pv_repack_gate_ncdhw_to_ndhwc_bf16(ptr(dy), ptr(y_mask), ptr(out), b, c, t, h, w,
+                                                       current_stream_ptr()), "pv_repack_gate_ncdhw_to_ndhwc_bf16")
+    return out
+
+
+def conv3d_pack_weight_bf16(weight: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
+    require_cuda(weight)
+    co, ci = weight.shape[:2]
+    kch = co if transpose_flip else ci
+    n = get_lib().pv_conv3d_packed_weight_elems(kch)
+    wp = torch.empty(n, dtype=torch.bfloat16, device=weight.device)
+    check(get_lib().pv_conv3d_pack_weight_bf16(ptr(weight), ptr(wp), co, ci, int(transpose_flip), current_stream_ptr()),
+          "pv_conv3d_pack_weight_bf16")
+    return wp
+
+
+def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Tensor, bias: Optional[torch.Tensor],
+                    c_in: int, c_out: int, padding=(0, 0, 0), relu=True, y_ncdhw=False) -> torch.Tensor:
+    """x [B,T,H,W,CPAD(c_in)] bf16 -> y [B,To,Ho,Wo,32] bf16 (or [B,c_out,To,Ho,Wo] if y_ncdhw)."""
+    require_cuda(x, gate, wp, bias)
+    b, t, h, w, cpad = x.shape
+    if cpad != bf16_cpad(c_in) or x.dtype != torch.bfloat16:
+        raise TypeError("conv3d_fwd_bf16: x must be bf16 [B,T,H,W,CPAD(c_in)]")
+    d = conv_dims(b, c_in, c_out, t, h, w, padding)
+    to, ho, wo = d.out_shape()
+    shape = (b, c_out, to, ho, wo) if y_ncdhw else (b, to, ho, wo, 32)
+    y = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+    check(get_lib().pv_conv3d_fwd_bf16(ptr(x), ptr(gate), ptr(wp), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
+                                       int(y_ncdhw), current_stream_ptr()), "pv_conv3d_fwd_bf16")
+    return y
+
+
+def conv3d_bwd_weight_bf16(x: torch.Tensor, dy: torch.Tensor, y_mask: Optional[torch.Tensor], c_in: int, c_out: int,
+                           padding=(0, 0, 0)):
+    """x [B,T,H,W,CPAD] bf16, dy/y_mask [B,To,Ho,Wo,32] bf16 -> (dw f32 [c_out,c_in,3,3,3], db f32 [c_out])."""
+    require_cuda(x, dy, y_mask)
+    b, t, h, w, cpad = x.shape
+    d = conv_dims(b, c_in, c_out, t, h, w, padding)
+    need = c_sz(0)
+    lib = get_lib()
+    check(lib.pv_conv3d_bwd_weight_bf16_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "wgrad workspace")
+    ws = _workspace("wgrad", need.value, x.device)
+    dw = torch.empty((c_out, c_in, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+    check(lib.pv_conv3d_bwd_weight_bf16(ptr(x), ptr(dy), ptr(y_mask), ptr(dw), ptr(db), ctypes.byref(d), ptr(ws),
+                                        ws.numel(), current_stream_ptr()), "pv_conv3d_bwd_weight_bf16")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------------
+# fully connected head, losses, Adam
+# ------------------------------------------------------------------------------------------------
+def linear_fwd_f32(x, weight, bias, relu=False):
+    require_cuda(x, weight, bias)
+    m, k = x.shape
+    n = weight.shape[0]
+    need = c_sz(0)
+    lib = get_lib()
+    check(lib.pv_linear_workspace_bytes(m, n, k, ctypes.byref(need)), "pv_linear_workspace_bytes")
+    ws = _workspace("linear", need.value, x.device)
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.pv_linear_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(y), m, n, k, int(relu), ptr(ws), ws.numel(),
+                                current_stream_ptr()), "pv_linear_fwd_f32")
+    return y
+
+
+def linear_bwd_f32(x, weight, dy, y_mask, need_dx=True):
+    require_cuda(x, weight, dy, y_mask)
+    m, k = x.shape
+    n = weight.shape[0]
+    dx = torch.empty((m, k), dtype=torch.float32, device=x.device) if need_dx else None
+    dw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    db = torch.empty(n, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_linear_bwd_f32(ptr(x), ptr(weight), ptr(dy), ptr(y_mask), ptr(dx), ptr(dw), ptr(db), m, n, k,
+                                      current_stream_ptr()), "pv_linear_bwd_f32")
+    return dx, dw, db
+
+
+def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
+    require_cuda(x_bf16, w_bf16, bias)
+    m, k = x_bf16.shape
+    n = w_bf16.shape[0]
+    need = c_sz(0)
+    lib = get_lib()
+    check(lib.pv_linear_bf16_workspace_bytes(m, n, k, ctypes.byref(need)), "pv_linear_bf16_workspace_bytes")
+    ws = _workspace("linear_bf16", need.value, x_bf16.device)
+    y = torch.empty((m, n), dtype=torch.float32, device=x_bf16.device)
+    check(lib.pv_linear_fwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(bias), ptr(y), m, n, k, int(relu), ptr(ws), ws.numel(),
+                                 current_stream_ptr()), "pv_linear_fwd_bf16")
+    return y
+
+
+def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True):
+    require_cuda(x_bf16, w_bf16, dy, y_mask)
+    m, k = x_bf16.shape
+    n = w_bf16.shape[0]
+    dx = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device) if need_dx else None
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device)
+    check(get_lib().pv_linear_bwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(dy), ptr(y_mask), ptr(dx), ptr(dw), ptr(db), m, n,
+                                       k, current_stream_ptr()), "pv_linear_bwd_bf16")
+    return dx, dw, db
+
+
+def forecast_losses(y_hat: torch.Tensor, y: torch.Tensor, need_grad: bool = True, grad_scale: float = 1.0):
+    """(mse, nmae, mse_exp, mae_exp) as a device f32[4] and d nmae / d y_hat (base_model.py:98-103).
+    y may be any strided 2-D view (e.g. batch.pv.pv_yield[:, -forecast_len:, 0])."""
+    require_cuda(y_hat)
+    if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2 or y.shape != y_hat.shape:
+        raise TypeError("forecast_losses: y must be a float32 CUDA [B, forecast_len] view matching y_hat")
+    m, n = y_hat.shape
+    out4 = torch.empty(4, dtype=torch.float32, device=y_hat.device)
+    grad = torch.empty_like(y_hat) if need_grad else None
+    check(get_lib().pv_forecast_losses_f32(ptr(y_hat), ctypes.c_void_p(y.data_ptr()), y.stride(0), y.stride(1), m, n,
+                                           grad_scale, ptr(out4), ptr(grad), current_stream_ptr()),
+          "pv_forecast_losses_f32")
+    return out4, grad
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
+              bf16_shadow=None, grad_scale=1.0):
+    require_cuda(param, grad, exp_avg, exp_avg_sq, bf16_shadow)
+    check(get_lib().pv_adam_step_f32(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(bf16_shadow),
+                                     param.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
+                                     current_stream_ptr()), "pv_adam_step_f32")

@@ -1,0 +1,214 @@
+"""GPU parity: Conv3D / fully-connected / loss / Adam HIP kernels (through the C ABI) vs the torch-CPU oracle.
+
+Tolerances:
+  fp32 path : activations rtol 1e-4 / atol 1e-5, wgrad 1e-3 rel (f32 accumulation-order differences only)
+  bf16 path : compared against the oracle evaluated on bf16-ROUNDED operands (what the MFMA consumes);
+              the remaining difference is f32 accumulation order + one bf16 rounding of the output:
+              rtol 1e-2 (2 bf16 ulps) / atol 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import conv3d_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from predict_pv_yield_amd import functional, hip_ops
+    return hip_ops, functional
+
+
+def _conv_case(seed, b, ci, co_, t, h, w):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(b, ci, t, h, w, generator=g)
+    wt = torch.randn(co_, ci, 3, 3, 3, generator=g) * (1.0 / np.sqrt(ci * 27))
+    bias = torch.randn(co_, generator=g) * 0.1
+    return x, wt, bias
+
+
+CASES = [
+    # b, ci, co, t, h, w, padding
+    (2, 11, 32, 7, 16, 16, (0, 0, 0)),
+    (1, 32, 32, 5, 14, 20, (0, 0, 0)),
+    (2, 11, 32, 6, 12, 12, (1, 0, 0)),   # model_sat_nwp padding
+    (1, 10, 16, 4, 9, 9, (1, 1, 1)),     # Conv3dMaxPool padding, c_out < 32
+    (1, 32, 32, 4, 70, 66, (0, 0, 0)),   # more than one column block / row block
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_f32_forward_backward(device, case):
+    K, Fn = _mods()
+    b, ci, co_, t, h, w, pad = case
+    x, wt, bias = _conv_case(1, b, ci, co_, t, h, w)
+    x.requires_grad_(True); wt.requires_grad_(True); bias.requires_grad_(True)
+    y_ref = F.relu(F.conv3d(x, wt, bias, padding=pad))
+    gy = torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(2))
+    y_ref.backward(gy)
+
+    xd = x.detach().to(device).requires_grad_(True)
+    wd = wt.detach().to(device).requires_grad_(True)
+    bd = bias.detach().to(device).requires_grad_(True)
+    y = Fn.conv3d_relu_f32(xd, wd, bd, pad, relu=True)
+    y.backward(gy.to(device))
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), wt.grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(bd.grad.cpu(), bias.grad, rtol=1e-3, atol=1e-4)
+
+
+def test_pack_unpack_roundtrip(device):
+    K, _ = _mods()
+    for c in (11, 32, 5):
+        x = torch.randn(2, c, 3, 5, 7)
+        xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+        assert xp.shape[-1] == (16 if c <= 16 else 32)
+        ref = x.to(torch.bfloat16).permute(0, 2, 3, 4, 1)
+        assert torch.equal(xp[..., :c].cpu(), ref)
+        assert torch.count_nonzero(xp[..., c:]).item() == 0
+        back = K.unpack_ndhwc_bf16_to_ncdhw_f32(xp, c)
+        assert torch.equal(back.cpu(), co.bf16_round(x))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_bf16_forward(device, case):
+    K, _ = _mods()
+    b, ci, co_, t, h, w, pad = case
+    x, wt, bias = _conv_case(3, b, ci, co_, t, h, w)
+    y_ref = F.relu(F.conv3d(co.bf16_round(x), co.bf16_round(wt), bias, padding=pad))
+    xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+    wp = K.conv3d_pack_weight_bf16(wt.to(device))
+    y = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), ci, co_, pad, relu=True, y_ncdhw=False)
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)[:, :co_]
+    torch.testing.assert_close(got, y_ref, rtol=1e-2, atol=2e-3)
+    if co_ < 32:
+        assert torch.count_nonzero(y[..., co_:]).item() == 0
+    # NCDHW epilogue (the flatten order fc1 consumes) gives the same numbers
+    y2 = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), ci, co_, pad, relu=True, y_ncdhw=True)
+    assert torch.equal(y2.float().cpu(), got.contiguous())
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_bf16_backward(device, case):
+    """wgrad (transposed-LDS-read MFMA kernel) and dgrad (forward kernel on mirrored weights)."""
+    K, _ = _mods()
+    b, ci, co_, t, h, w, pad = case
+    if co_ != 32:
+        pytest.skip("bf16 backward is built for 32 output channels")
+    x, wt, bias = _conv_case(4, b, ci, co_, t, h, w)
+    xr = co.bf16_round(x).requires_grad_(True)
+    wr = co.bf16_round(wt).requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv3d(xr, wr, br, padding=pad))
+    gy = co.bf16_round(torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(5)))
+    y_ref.backward(gy)
+
+    xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+    wp = K.conv3d_pack_weight_bf16(wt.to(device))
+    y = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), ci, co_, pad, relu=True)
+    gyp = K.pack_ncdhw_f32_to_ndhwc_bf16(gy.to(device))
+    # the gate must come from the same activations the oracle gated on: use the oracle's y > 0 pattern
+    gate = K.pack_ncdhw_f32_to_ndhwc_bf16(y_ref.detach().to(device))
+    dw, db = K.conv3d_bwd_weight_bf16(xp, gyp, gate, ci, co_, pad)
+    scale = wr.grad.abs().max().item()
+    assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * scale + 1e-4
+    assert (db.cpu() - br.grad).abs().max().item() <= 2e-3 * br.grad.abs().max().item() + 1e-4
+    # dgrad
+    wpt = K.conv3d_pack_weight_bf16(wt.to(device), transpose_flip=True)
+    pad_b = tuple(2 - p for p in pad)
+    dx = K.conv3d_fwd_bf16(gyp, gate, wpt, None, co_, ci, pad_b, relu=False)
+    got = dx.float().cpu().permute(0, 4, 1, 2, 3)[:, :ci]
+    torch.testing.assert_close(got, xr.grad, rtol=1e-2, atol=2e-3 * max(1.0, xr.grad.abs().max().item()))
+    del y
+
+
+def test_repack_gate(device):
+    K, _ = _mods()
+    dy = torch.randn(2, 32, 3, 5, 6).to(torch.bfloat16)
+    yv = torch.relu(torch.randn(2, 32, 3, 5, 6)).to(torch.bfloat16)
+    out = K.repack_gate_ncdhw_to_ndhwc_bf16(dy.to(device), yv.to(device)).cpu()
+    ref = (dy * (yv > 0)).permute(0, 2, 3, 4, 1)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(2, 16, 34816), (5, 128, 1000), (32, 64, 128), (3, 6, 64)])
+def test_linear_f32(device, m, n, k):
+    K, Fn = _mods()
+    g = torch.Generator().manual_seed(m * n)
+    x = torch.randn(m, k, generator=g, requires_grad=True)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).requires_grad_(True)
+    bias = torch.randn(n, generator=g, requires_grad=True)
+    y_ref = F.relu(F.linear(x, w, bias))
+    gy = torch.randn(m, n, generator=g)
+    y_ref.backward(gy)
+    xd, wd, bd = (t.detach().to(device).requires_grad_(True) for t in (x, w, bias))
+    y = Fn.linear_f32(xd, wd, bd, relu=True)
+    y.backward(gy.to(device))
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bd.grad.cpu(), bias.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k", [(2, 16, 34816), (33, 128, 4096 + 64), (64, 128, 8200), (7, 5, 72)])
+def test_linear_bf16(device, m, n, k):
+    K, Fn = _mods()
+    g = torch.Generator().manual_seed(m + n)
+    x = co.bf16_round(torch.randn(m, k, generator=g)).requires_grad_(True)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k))
+    wr = co.bf16_round(w).requires_grad_(True)
+    bias = torch.randn(n, generator=g, requires_grad=True)
+    y_ref = F.relu(F.linear(x, wr, bias))
+    gy = torch.randn(m, n, generator=g)
+    y_ref.backward(gy)
+    xd = x.detach().to(torch.bfloat16).to(device).requires_grad_(True)
+    wd = w.to(device).requires_grad_(True)
+    bd = bias.detach().to(device).requires_grad_(True)
+    y = Fn.linear_bf16(xd, wd, bd, relu=True)
+    y.backward(gy.to(device))
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bd.grad.cpu(), bias.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xd.grad.float().cpu(), x.grad, rtol=1e-2, atol=1e-3)
+
+
+def test_forecast_losses(device):
+    K, Fn = _mods()
+    g = torch.Generator().manual_seed(9)
+    y_hat = torch.randn(8, 6, generator=g, requires_grad=True)
+    yield_t = torch.rand(8, 19, 128, generator=g)
+    y = co.select_target(yield_t, 6)
+    mse, nmae, mse_exp, mae_exp = co.forecast_losses(y_hat, y)
+    nmae.backward()
+    yd = y_hat.detach().to(device).requires_grad_(True)
+    out4 = Fn.forecast_losses(yd, co.select_target(yield_t.to(device), 6))  # strided view, no copy
+    out4[1].backward()
+    ref = torch.stack([mse, nmae, mse_exp, mae_exp]).detach()
+    torch.testing.assert_close(out4.detach().cpu(), ref, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(yd.grad.cpu(), y_hat.grad, rtol=1e-6, atol=0)
+
+
+def test_adam_matches_torch(device):
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(10)
+    n = 1000 + 3
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=0.0005)
+    p = p0.clone().to(device)
+    m = torch.zeros(n, device=device)
+    v = torch.zeros(n, device=device)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=device)
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step - 3))
+        p_ref.grad = grad.clone()
+        opt.step()
+        K.adam_step(p, grad.to(device), m, v, step, lr=0.0005, bf16_shadow=shadow)
+        torch.testing.assert_close(p.cpu(), p_ref.detach(), rtol=2e-6, atol=1e-9)
+    st = opt.state[p_ref]
+    torch.testing.assert_close(m.cpu(), st["exp_avg"], rtol=2e-6, atol=1e-12)
+    torch.testing.assert_close(v.cpu(), st["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))

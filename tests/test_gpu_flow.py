@@ -1,0 +1,173 @@
+"""GPU parity: HIP optical-flow advection kernels (through the C ABI) vs the CPU oracle.
+
+Bars: u8 conversion, weighted mean, normalisation and remap are BIT-EXACT (integer
+indices, exact fixed-point weights, correctly-rounded f32/f64 arithmetic in a fixed order);
+Farnebäck flow within 1e-3 px max-abs of the oracle on identical u8 inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+from predict_pv_yield_amd.data.synthetic import advected_counts, blob_texture_sequence
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from predict_pv_yield_amd import hip_ops
+    return hip_ops
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32 if a.dtype == np.float32 else a.dtype)
+
+
+def same_f32(a, b):
+    """bit-exact on every non-NaN value, NaNs in the same places (NaN payloads are not part of the contract)"""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(bits(a)[~na], bits(b)[~nb])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n", [0, 5, 4096 + 3])
+def test_u8_from_10bit_bit_exact(device, mode, n):
+    K = _ops()
+    rng = np.random.default_rng(n + mode)
+    xi = rng.integers(0, 1024, n).astype(np.int16)
+    if n > 8:
+        xi[:8] = [0, 1, 2, 3, 1021, 1022, 1023, 6]  # ties of x/4 and the top of the range
+    xf = xi.astype(np.float32)
+    for x in (xi, xf):
+        ref, ref_flag = fo.convert_10bpp_to_uint8(x, mode)
+        got, flag = K.u8_from_10bit(torch.from_numpy(x).to(device), mode, return_flag=True)
+        assert np.array_equal(got.cpu().numpy(), ref)
+        assert bool(flag.item()) == ref_flag
+
+
+def test_u8_range_flag(device):
+    K = _ops()
+    x = np.array([0, 4, 1023, 1030, -3, 8, 12, 16, 20], np.int16)
+    ref, ref_flag = fo.convert_10bpp_to_uint8(x, 0)
+    got, flag = K.u8_from_10bit(torch.from_numpy(x).to(device), 0, return_flag=True)
+    assert ref_flag and bool(flag.item())
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 8, 8, 2), (2, 11, 64, 64, 2), (1, 5, 7, 9, 2)])
+def test_weighted_mean_bit_exact(device, shape):
+    K = _ops()
+    rng = np.random.default_rng(7)
+    flows = rng.normal(0, 3, shape).astype(np.float32)
+    got = K.flow_weighted_mean(torch.from_numpy(flows).to(device)).cpu().numpy()
+    for g in range(shape[0]):
+        ref = fo.weighted_average(flows[g])
+        # the numpy one-liner of the reference (optical_flow_1.ipynb:293-294)
+        ref_np = np.average(flows[g], axis=0, weights=range(1, shape[1] + 1)).astype(np.float32)
+        assert np.array_equal(bits(ref), bits(ref_np))
+        assert np.array_equal(bits(got[g]), bits(ref))
+
+
+def test_normalise_bit_exact(device):
+    K = _ops()
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 1024, (2, 5, 3, 16, 16)).astype(np.int16)  # [B,T,C,H,W]
+    mean = np.array([93.23458, 131.6, 843.2], np.float32)
+    std = np.array([115.34247, 38.1, 53.8], np.float32)
+    for x in (raw, raw.astype(np.float32)):
+        ref = fo.normalise(x, mean, std, inner=16 * 16)
+        got = K.normalise(torch.from_numpy(x).to(device), torch.from_numpy(mean).to(device),
+                          torch.from_numpy(std).to(device), inner=16 * 16).cpu().numpy()
+        assert np.array_equal(bits(got), bits(ref))
+
+
+def _random_flow(rng, h, w, scale):
+    yy, xx = np.mgrid[0:h, 0:w]
+    fl = np.stack([np.sin(yy / 7.0) * scale + rng.normal(0, 0.3, (h, w)),
+                   np.cos(xx / 5.0) * scale + rng.normal(0, 0.3, (h, w))], -1)
+    return fl.astype(np.float32)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 50), (128, 128)])
+@pytest.mark.parametrize("border", [fo.BORDER_CONSTANT, fo.BORDER_REPLICATE])
+def test_remap_f32_bit_exact(device, h, w, border):
+    K = _ops()
+    rng = np.random.default_rng(h * w + border)
+    n = 3
+    imgs = rng.normal(0, 1, (n, h, w)).astype(np.float32)
+    flows = np.stack([_random_flow(rng, h, w, 2.5) for _ in range(n)])
+    flows[0] = np.round(flows[0] * 32) / 32           # exact 1/32 fractions
+    flows[1, :4] = np.round(flows[1, :4])             # integer shifts
+    flows[2, 0, 0] = [np.nan, 1e12]                   # NaN / overflow coordinates
+    flows[2, 1, 1] = [0.015625, -0.046875]            # cvRound ties (x.5/32)
+    n_steps = 4
+    got = K.remap_bilinear(torch.from_numpy(imgs).to(device), torch.from_numpy(flows).to(device), n_steps=n_steps,
+                           step0=1.0, border_mode=border, border_value=float("nan")).cpu().numpy()
+    for i in range(n):
+        for s in range(n_steps):
+            ref = fo.remap_image(imgs[i], flows[i], float(1 + s), border, np.nan)
+            assert same_f32(got[i, s], ref), (i, s)
+
+
+@pytest.mark.parametrize("border", [fo.BORDER_CONSTANT, fo.BORDER_REPLICATE])
+def test_remap_u8_bit_exact(device, border):
+    K = _ops()
+    rng = np.random.default_rng(11)
+    h, w, n = 48, 64, 2
+    imgs = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
+    flows = np.stack([_random_flow(rng, h, w, 3.0) for _ in range(n)])
+    got = K.remap_bilinear(torch.from_numpy(imgs).to(device), torch.from_numpy(flows).to(device), n_steps=3, step0=0.0,
+                           border_mode=border, border_value=7).cpu().numpy()
+    for i in range(n):
+        for s in range(3):
+            ref = fo.remap_image(imgs[i], flows[i], float(s), border, 7)
+            assert np.array_equal(got[i, s], ref), (i, s)
+
+
+def _pair(rng, h, w, v):
+    seq = blob_texture_sequence(rng, 2, h, w, v)
+    u8, _ = fo.convert_10bpp_to_uint8(np.clip(np.rint(seq), 0, 1023).astype(np.int16), 0)
+    return u8
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (32, 48), (96, 80), (160, 200)])
+def test_farneback_vs_oracle(device, h, w):
+    K = _ops()
+    rng = np.random.default_rng(h + w)
+    vels = [(1.0, 0.0), (1.5, 0.75), (-2.25, 1.3)]
+    pairs = [_pair(rng, h, w, v) for v in vels]
+    prev = torch.from_numpy(np.stack([p[0] for p in pairs])).to(device)
+    nxt = torch.from_numpy(np.stack([p[1] for p in pairs])).to(device)
+    got = K.farneback_pairs(prev, nxt).cpu().numpy()
+    for i, p in enumerate(pairs):
+        ref = fo.calc_optical_flow_farneback(p[0], p[1])
+        err = np.abs(got[i] - ref).max()
+        assert err <= 1e-3, (i, err)
+    # known answer: interior flow recovers the synthetic translation (K2)
+    inner = got[1][12:-12, 12:-12] if min(h, w) > 40 else got[1]
+    if min(h, w) >= 64:
+        assert abs(np.median(inner[..., 0]) - 1.5) < 0.1 and abs(np.median(inner[..., 1]) - 0.75) < 0.1
+
+
+def test_farneback_stack_and_params(device):
+    K = _ops()
+    raw, _ = advected_counts(batch=1, t=5, channels=2, h=64, w=64, seed=5)
+    stacks = np.ascontiguousarray(raw[0].transpose(1, 0, 2, 3))  # [C, T, H, W]
+    u8, _ = fo.convert_10bpp_to_uint8(stacks, 0)
+    got = K.farneback_stack(torch.from_numpy(u8).to(device), levels=3, winsize=15, iterations=2, poly_n=7,
+                            poly_sigma=1.5).cpu().numpy()
+    assert got.shape == (2, 4, 64, 64, 2)
+    for c in range(2):
+        for t in range(4):
+            ref = fo.calc_optical_flow_farneback(u8[c, t], u8[c, t + 1], levels=3, winsize=15, iterations=2, poly_n=7,
+                                                 poly_sigma=1.5)
+            assert np.abs(got[c, t] - ref).max() <= 1e-3
+
+
+def test_errors_are_loud(device):
+    K = _ops()
+    with pytest.raises(RuntimeError):
+        K.u8_from_10bit(torch.zeros(8, dtype=torch.int16), 0)  # CPU tensor: no CPU path
+    with pytest.raises(RuntimeError):
+        K.farneback_pairs(torch.zeros((1, 64, 64), dtype=torch.uint8, device=device),
+                          torch.zeros((1, 64, 64), dtype=torch.uint8, device=device), flags=0)
