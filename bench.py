@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X hot path (BASELINE.json metric, configs[1]).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one train step of the Conv3D PV-yield model (forward + NMAE loss + backward + Adam [+ gradient
+all-reduce over RCCL when N > 1]) on one batch of synthetic PV-site crop stacks [B, 11, 18, 64, 64]
+(12 observed + 6 forecast frames) already resident in HBM.  Per-GPU batch is fixed
+(weak scaling).  Rank 0 prints ONE JSON line with the whole-job samples/s plus
+  roofline     : dominant kernel (conv3d implicit-GEMM MFMA kernels), algorithmic FLOPs / measured launch time
+                 (HIP events on the launching stream) against the dense bf16 MFMA peak;
+  cpu_baseline : the torch-CPU oracle (identical arithmetic to the reference's Lightning path) timed on this
+                 host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK = 2.5e15     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def conv_layer_shapes(t, hw, c_in, c, layers):
+    """[(c_in, t_in, h_in, t_out, h_out)] for valid 3x3x3 convs."""
+    out, ci, ti, hi = [], c_in, t, hw
+    for _ in range(layers):
+        out.append((ci, ti, hi, ti - 2, hi - 2))
+        ci, ti, hi = c, ti - 2, hi - 2
+    return out
+
+
+def conv_flops(batch, c_in, c_out, t_out, h_out):
+    return 2.0 * batch * c_out * c_in * 27 * t_out * h_out * h_out
+
+
+def time_kernel(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()  # recorded on torch's current stream == the stream the C ABI launches on
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def measure_conv_roofline(batch, hist_frames, dev):
+    """Times every conv launch of one train step in isolation (same shapes, same kernels) and returns the
+    roofline object of the dominant kernel."""
+    from predict_pv_yield_amd import hip_ops as K
+    t = hist_frames
+    shapes = conv_layer_shapes(t, 64, 11, 32, 4)
+    per_kernel = {}
+    for li, (ci, ti, hi, to, ho) in enumerate(shapes):
+        cpad = K.bf16_cpad(ci)
+        x = torch.randn(batch, ti, hi, hi, cpad, device=dev).to(torch.bfloat16)
+        w = torch.randn(32, ci, 3, 3, 3, device=dev) * 0.05
+        bias = torch.zeros(32, device=dev)
+        wp = K.conv3d_pack_weight_bf16(w)
+        y = K.conv3d_fwd_bf16(x, None, wp, bias, ci, 32, (0, 0, 0), True, False)
+        dy = torch.randn_like(y)
+        fl = conv_flops(batch, ci, 32, to, ho)
+        name_f = f"conv3d_fwd_bf16_kernel<{cpad}>"
+        d = time_kernel(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, ci, 32, (0, 0, 0), True, False))
+        per_kernel.setdefault(name_f, [0.0, 0.0, 0])
+        per_kernel[name_f][0] += d; per_kernel[name_f][1] += fl; per_kernel[name_f][2] += 1
+        d = time_kernel(lambda: K.conv3d_bwd_weight_bf16(x, dy, y, ci, 32, (0, 0, 0)))
+        name_w = f"conv3d_wgrad_bf16_kernel<{cpad}>"
+        per_kernel.setdefault(name_w, [0.0, 0.0, 0])
+        per_kernel[name_w][0] += d; per_kernel[name_w][1] += fl; per_kernel[name_w][2] += 1
+        if li > 0:  # dgrad = the forward kernel on dy (32 channels) with mirrored weights
+            wpt = K.conv3d_pack_weight_bf16(w, transpose_flip=True)
+            d = time_kernel(lambda: K.conv3d_fwd_bf16(dy, y, wpt, None, 32, ci, (2, 2, 2), False, False))
+            per_kernel["conv3d_fwd_bf16_kernel<32>"][0] += d
+            per_kernel["conv3d_fwd_bf16_kernel<32>"][1] += fl
+            per_kernel["conv3d_fwd_bf16_kernel<32>"][2] += 1
+        del x, y, dy
+    dom = max(per_kernel, key=lambda k: per_kernel[k][0])
+    secs, flops, launches = per_kernel[dom]
+    achieved = flops / secs / 1e12
+    detail = {k: {"ms_per_step": round(v[0] * 1e3, 4), "tflops": round(v[1] / v[0] / 1e12, 2), "launches": v[2]}
+              for k, v in per_kernel.items()}
+    return {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK / 1e12,
+            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None,
+            "avg_launch_ms": round(secs / launches * 1e3, 4), "launches_per_step": launches,
+            "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
+
+
+def cpu_baseline(model_kwargs, t_frames, budget_s=20.0):
+    """torch-CPU oracle train step (fwd + NMAE + bwd + Adam), B = 8, on this host's cores."""
+    from oracle import conv3d_oracle as co
+    torch.manual_seed(518)
+    kw = {k: v for k, v in model_kwargs.items() if k not in ("precision", "future_frames")}
+    m = co.OracleConv3dModel(**kw)
+    b = 8
+    g = torch.Generator().manual_seed(518)
+    sat = torch.randn(b, 11, t_frames, 64, 64, generator=g)
+    pv = torch.rand(b, t_frames, 128, generator=g)
+    opt = co.make_optimizer(m)
+    co.train_steps(m, sat, pv, 1, opt)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        co.train_steps(m, sat, pv, 1, opt)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 16:
+            break
+    return {"value": round(n * b / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} train steps at B={b}, T={t_frames}, fp32, torch-CPU oracle (oracle/conv3d_oracle.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of PV-site crop stacks")
+    ap.add_argument("--history-minutes", type=int, default=55, help="55 -> T=18 (12 observed + 6 forecast frames)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from predict_pv_yield_amd import distributed as D
+    from predict_pv_yield_amd.models.conv3d.model import Model
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product has no CPU path)")
+    distributed = D.init_from_env()
+    world = torch.distributed.get_world_size() if distributed else 1
+    rank = torch.distributed.get_rank() if distributed else 0
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+
+    model_kwargs = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30,
+                        history_minutes=args.history_minutes, number_of_conv3d_layers=4, conv3d_channels=32,
+                        image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+                        fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield",
+                        precision=args.precision)
+    torch.manual_seed(518)  # configs/experiment/conv3d.yaml:16
+    model = Model(**model_kwargs).to(dev)
+    t_frames = model.history_len_5 + model.forecast_len_5 + 1
+    if distributed:
+        D.broadcast_parameters(model)
+    opt = model.configure_optimizers()
+    opt.grad_scale = 1.0 / world
+
+    g = torch.Generator(device=dev).manual_seed(518 + rank)
+    b = args.batch
+    model.batch_size = max(model.batch_size, b)  # BaseModel.batch_size slices the target (base_model.py:95)
+    batch = {"satellite": {"data": torch.randn(b, 11, t_frames, 64, 64, generator=g, device=dev)},
+             "pv": {"pv_yield": torch.rand(b, t_frames, 128, generator=g, device=dev)}}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        if distributed:
+            D.all_reduce_gradients(model)
+        opt.step()
+        return loss
+
+    first = None
+    for i in range(args.warmup):
+        l = step()
+        if i == 0:
+            first = float(l)
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if distributed:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    last = float(last)
+
+    if rank == 0:
+        value = world * b * args.steps / elapsed
+        out = {
+            "metric": "PV-site samples/sec (train step), conv3d 12->6 frames",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"conv3d train step (fwd + NMAE + bwd + Adam): sat [B,11,{t_frames},64,64] N(0,1), "
+                                   f"4x Conv3d(3x3x3, 32ch) + fc 128/128/64, {sum(p.numel() for p in model.parameters())/1e6:.1f} M params",
+                       "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "train_nmae_first_step": round(first, 6) if first is not None else None,
+            "train_nmae_last_step": round(last, 6),
+        }
+        if not args.no_roofline and world == 1:
+            out["roofline"] = measure_conv_roofline(b, t_frames, dev)
+        else:
+            out["roofline"] = None
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model_kwargs, t_frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -326,6 +326,7 @@ static int remap_launch(const T* src, int64_t src_stride, const float* flow, int
 
 template <typename T>
 static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag, void* stream) {
+  if (n == 0) return PV_OK;  // empty input: nothing to do (an empty tensor has no address)
   PV_REQUIRE(src && dst, PV_EINVAL, "pv_u8_from_10bit: null pointer");
   PV_REQUIRE(mode == PV_U8_ROUND_DIV4 || mode == PV_U8_TRUNC_SCALE, PV_EINVAL,
              "pv_u8_from_10bit: bad mode %d", mode);
@@ -340,6 +341,7 @@ static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* ra
 template <typename T>
 static int normalise_launch(const T* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
                             const float* mean, const float* std_, void* stream) {
+  if (n == 0) return PV_OK;
   PV_REQUIRE(src && dst && mean && std_, PV_EINVAL, "pv_normalise: null pointer");
   PV_REQUIRE(inner > 0 && n_channels > 0, PV_EINVAL, "pv_normalise: bad inner/n_channels");
   if (n == 0) return PV_OK;

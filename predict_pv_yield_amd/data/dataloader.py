@@ -1,0 +1,88 @@
+"""NetCDFDataModule — same constructor surface as predict_pv_yield/data/dataloader.py:38-131
+(temp_path, n_train_data, n_val_data, cloud, num_workers, pin_memory, data_path, fake_data [, shuffle_train]).
+Only `fake_data=True` is built: reading OCF's NetCDF batches is I/O outside the hot path.
+Under data-parallel training each rank takes a disjoint slice of the batch indices (Lightning's
+replace_sampler_ddp, configs/trainer/all_params.yaml:43): samples are independent, no collective."""
+import os
+from typing import Optional
+
+import torch
+import yaml
+
+from ..distributed import shard_range
+from ..lightning import LightningDataModule
+from .fake import FakeDataConfiguration, FakeDataset
+
+
+def _identity_collate(x):
+    return x
+
+
+class _Shard(torch.utils.data.Dataset):
+    def __init__(self, base, lo, hi):
+        self.base, self.lo, self.hi = base, lo, hi
+
+    def __len__(self):
+        return self.hi - self.lo
+
+    def __getitem__(self, i):
+        if i >= len(self):
+            raise IndexError(i)
+        return self.base[self.lo + i]
+
+
+class NetCDFDataModule(LightningDataModule):
+    def __init__(self, temp_path: str = ".", n_train_data: int = 24900, n_val_data: int = 1000, cloud: str = "aws",
+                 num_workers: int = 8, pin_memory: bool = True, data_path: str = "prepared_ML_training_data/v4/",
+                 fake_data: bool = False, shuffle_train: bool = True, batch_size: Optional[int] = None,
+                 configuration: Optional[FakeDataConfiguration] = None):
+        super().__init__()
+        self.temp_path, self.cloud, self.data_path = temp_path, cloud, data_path
+        self.n_train_data, self.n_val_data = n_train_data, n_val_data
+        self.num_workers, self.pin_memory = num_workers, pin_memory
+        self.fake_data, self.shuffle_train = fake_data, shuffle_train
+        if not fake_data:
+            raise NotImplementedError("predict_pv_yield_amd builds the synthetic data path only (fake_data=True); "
+                                      "NetCDF batch I/O is outside the hot path")
+        cfg = configuration or self._configuration_from_path(data_path)
+        if batch_size is not None:
+            cfg.batch_size = batch_size
+        self.configuration = cfg
+
+    @staticmethod
+    def _configuration_from_path(data_path: str) -> FakeDataConfiguration:
+        """Reads `<data_path>/configuration.yaml` (nowcasting_dataset layout, tests/configs/dataset/configuration.yaml)
+        if present; only the fields the fake data needs are used."""
+        cfg = FakeDataConfiguration()
+        f = os.path.join(data_path, "configuration.yaml")
+        if os.path.exists(f):
+            with open(f) as fh:
+                raw = yaml.safe_load(fh) or {}
+            inp = raw.get("input_data", {})
+            cfg.history_minutes = inp.get("default_history_minutes", cfg.history_minutes)
+            cfg.forecast_minutes = inp.get("default_forecast_minutes", cfg.forecast_minutes)
+            sat = inp.get("satellite", {})
+            cfg.satellite_image_size_pixels = sat.get("satellite_image_size_pixels", cfg.satellite_image_size_pixels)
+            if "satellite_channels" in sat:
+                cfg.number_sat_channels = len(sat["satellite_channels"])
+            nwp = inp.get("nwp", {})
+            cfg.nwp_image_size_pixels = nwp.get("nwp_image_size_pixels", cfg.nwp_image_size_pixels)
+            cfg.batch_size = raw.get("process", {}).get("batch_size", cfg.batch_size)
+            cfg.seed = raw.get("process", {}).get("seed", cfg.seed)
+        return cfg
+
+    def _loader(self, n_batches: int, offset: int):
+        base = FakeDataset(self.configuration, length=offset + n_batches)
+        lo, hi = shard_range(n_batches)
+        ds = _Shard(base, offset + lo, offset + hi)
+        # every item is a whole batch: batch_size=None (data/dataloader.py:82-91)
+        return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=0, pin_memory=False)
+
+    def train_dataloader(self):
+        return self._loader(min(self.n_train_data, 10), 0)
+
+    def val_dataloader(self):
+        return self._loader(min(self.n_val_data, 10), 1000)
+
+    def test_dataloader(self):
+        return self._loader(min(self.n_val_data, 10), 2000)

@@ -1,0 +1,95 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed over RCCL/xGMI (backend "nccl" on ROCm),
+gloo on CPU for tests.  The path shards by sample: flow / warp / normalise need no
+collective; the only exchange step is the gradient all-reduce (the reference gets it from Lightning DDP,
+experiments/003_...py:288-294) plus the scalar-metric all-reduce of `sync_dist=True` (base_model.py:117).
+
+Gradients are all-reduced as ONE flat bucket per dtype: fc1's gradient is 99.9 % of the bytes, so
+bucketing finer than "everything" only adds launches; xGMI is point-to-point, so one large collective
+lets RCCL use all 7 links at once.  The sum is left un-averaged: HipAdam folds 1/world_size into the
+update (grad_scale), saving a pass over 0.5 GB.
+"""
+import os
+from typing import Dict
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def init_from_env(backend: str = None) -> bool:
+    """Initialise from torchrun's RANK / WORLD_SIZE / MASTER_* environment; returns True if world_size > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+    return True
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """DDP's initial parameter broadcast from rank 0."""
+    if not is_distributed():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+        if hasattr(t, "_pv_bf16_shadow"):
+            del t._pv_bf16_shadow  # stale after the broadcast; rebuilt lazily
+
+
+def all_reduce_gradients(module: torch.nn.Module, average: bool = False) -> None:
+    """Sum (or average) gradients over ranks through one flat bucket per dtype/device."""
+    if not is_distributed():
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    buckets = {}
+    for g in grads:
+        buckets.setdefault((g.dtype, g.device), []).append(g)
+    for (_, _), gs in buckets.items():
+        big = max(gs, key=lambda g: g.numel())
+        small = [g for g in gs if g is not big]
+        # the dominant tensor (fc1.weight.grad, ~0.5 GB) is reduced in place; the rest share one flat buffer
+        work = dist.all_reduce(big, op=dist.ReduceOp.SUM, async_op=True)
+        if small:
+            flat = torch.cat([g.reshape(-1) for g in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for g in small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        work.wait()
+    if average:
+        w = dist.get_world_size()
+        for g in grads:
+            g.div_(w)
+
+
+def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, float]:
+    """All logged scalars of one log_dict call travel as ONE vector (the reference sends one tiny all-reduce each)."""
+    if not is_distributed():
+        return values
+    keys = sorted(values)
+    dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([values[k] for k in keys], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t /= dist.get_world_size()
+    return {k: float(v) for k, v in zip(keys, t.tolist())}
+
+
+def shard_range(n_items: int, rank: int = None, world: int = None):
+    """Contiguous shard of independent units (samples, flow pairs) for this rank: no collective needed."""
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    per = (n_items + world - 1) // world
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)

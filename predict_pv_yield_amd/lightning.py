@@ -1,0 +1,471 @@
+"""Minimal PyTorch-Lightning-compatible surface (pytorch_lightning is not installed in this image).
+
+Covers exactly what the reference drives (SURVEY.md §8b "Module protocol" / "Trainer/CLI"):
+  LightningModule : forward / training_step / validation_step / validation_epoch_end / test_step /
+                    configure_optimizers, self.log / self.log_dict(on_step, on_epoch, sync_dist),
+                    self.current_epoch, self.logger, self.device, self.trainer   (base_model.py:27-257)
+  Trainer         : fit / validate / test / predict, callback_metrics, checkpoint_callback,
+                    gpus, min/max_epochs, fast_dev_run, resume_from_checkpoint, precision,
+                    limit_*_batches, weights_summary, progress_bar_refresh_rate, profiler
+                    (configs/trainer/default.yaml, predict_pv_yield/training.py:63-107)
+  callbacks       : ModelCheckpoint, EarlyStopping (configs/callbacks/default.yaml)
+  loggers         : CSVLogger (configs/logger/csv.yaml)
+Under torch.distributed (one process per GPU, RCCL) the Trainer all-reduces gradients after backward
+(predict_pv_yield_amd.distributed) and logged metrics with sync_dist=True.
+"""
+import csv
+import logging
+import os
+import random
+import time
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+log = logging.getLogger(__name__)
+
+
+def seed_everything(seed: int, workers: bool = False) -> int:
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    return seed
+
+
+def _to_float(v) -> float:
+    if isinstance(v, torch.Tensor):
+        return float(v.detach().float().mean().item())
+    return float(v)
+
+
+class Callback:
+    def on_fit_start(self, trainer, module): ...
+    def on_validation_end(self, trainer, module): ...
+    def on_train_epoch_end(self, trainer, module): ...
+    def on_fit_end(self, trainer, module): ...
+
+
+class LightningLoggerBase:
+    name = "logger"
+
+    def log_metrics(self, metrics: Dict[str, float], step: int): ...
+    def log_hyperparams(self, params): ...
+    def finalize(self, status: str = "success"): ...
+
+    @property
+    def experiment(self):
+        return self
+
+
+class CSVLogger(LightningLoggerBase):
+    """pytorch_lightning.loggers.csv_logs.CSVLogger(save_dir, name)."""
+
+    def __init__(self, save_dir: str = ".", name: str = "csv/", version: Optional[str] = None, prefix: str = ""):
+        self.save_dir, self.name, self.version = save_dir, name, version or "version_0"
+        self.rows: List[Dict[str, Any]] = []
+        self.hparams: Dict[str, Any] = {}
+
+    @property
+    def log_dir(self):
+        return os.path.join(self.save_dir, self.name, self.version)
+
+    def log_metrics(self, metrics, step):
+        self.rows.append({"step": step, **metrics})
+
+    def log_hyperparams(self, params):
+        self.hparams.update(dict(params))
+
+    def finalize(self, status="success"):
+        if not self.rows:
+            return
+        os.makedirs(self.log_dir, exist_ok=True)
+        keys = sorted({k for r in self.rows for k in r})
+        with open(os.path.join(self.log_dir, "metrics.csv"), "w", newline="") as f:
+            wr = csv.DictWriter(f, fieldnames=keys)
+            wr.writeheader()
+            wr.writerows(self.rows)
+
+
+class LightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.trainer: Optional["Trainer"] = None
+        self._current_epoch = 0
+        self._logged: Dict[str, float] = {}
+
+    # -- attributes Lightning provides -------------------------------------------------------
+    @property
+    def current_epoch(self) -> int:
+        return self.trainer.current_epoch if self.trainer is not None else self._current_epoch
+
+    @property
+    def global_step(self) -> int:
+        return self.trainer.global_step if self.trainer is not None else 0
+
+    @property
+    def logger(self):
+        return self.trainer.logger if self.trainer is not None else None
+
+    @property
+    def device(self) -> torch.device:
+        for p in self.parameters():
+            return p.device
+        for b in self.buffers():
+            return b.device
+        return torch.device("cpu")
+
+    # -- logging -----------------------------------------------------------------------------
+    def log(self, name, value, on_step=None, on_epoch=None, sync_dist=False, **kwargs):
+        self.log_dict({name: value}, on_step=on_step, on_epoch=on_epoch, sync_dist=sync_dist)
+
+    def log_dict(self, dictionary, on_step=None, on_epoch=None, sync_dist=False, **kwargs):
+        if self.trainer is not None:
+            self.trainer._record(dictionary, on_step=on_step, on_epoch=on_epoch, sync_dist=sync_dist)
+        else:  # direct call outside a Trainer (tests/models/baseline/test_baseline_model_gsp.py:41-58)
+            self._logged.update({k: v for k, v in dictionary.items()})
+
+    # -- hooks (overridden by models) -----------------------------------------------------------
+    def training_step(self, batch, batch_idx): raise NotImplementedError
+    def validation_step(self, batch, batch_idx): ...
+    def test_step(self, batch, batch_idx): ...
+    def validation_epoch_end(self, outputs): ...
+    def predict_step(self, batch, batch_idx): return self(batch)
+    def configure_optimizers(self): raise NotImplementedError
+
+
+class LightningDataModule:
+    def prepare_data(self): ...
+    def setup(self, stage=None): ...
+    def train_dataloader(self): raise NotImplementedError
+    def val_dataloader(self): return None
+    def test_dataloader(self): return None
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, monitor=None, save_top_k=1, save_last=False, mode="min", dirpath="checkpoints/",
+                 filename="epoch_{epoch:03d}", **kwargs):
+        self.monitor, self.save_top_k, self.save_last, self.mode = monitor, save_top_k, save_last, mode
+        self.dirpath, self.filename = dirpath, filename
+        self.best_model_path, self.best_model_score, self.last_model_path = "", None, ""
+
+    def _save(self, trainer, module, path):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        if trainer.is_global_zero:
+            torch.save({"state_dict": module.state_dict(), "epoch": trainer.current_epoch,
+                        "global_step": trainer.global_step,
+                        "optimizer_states": [o.state_dict() for o in trainer.optimizers]}, path)
+
+    def on_validation_end(self, trainer, module):
+        if trainer.fast_dev_run or trainer.sanity_checking:
+            return
+        name = self.filename.format(epoch=trainer.current_epoch) + ".ckpt"
+        score = trainer.callback_metrics.get(self.monitor) if self.monitor else None
+        better = score is not None and (self.best_model_score is None or
+                                        (score < self.best_model_score if self.mode == "min" else score > self.best_model_score))
+        if self.save_top_k != 0 and (better or self.monitor is None):
+            if self.best_model_path and self.save_top_k == 1 and os.path.exists(self.best_model_path) and trainer.is_global_zero:
+                os.remove(self.best_model_path)
+            self.best_model_path = os.path.join(self.dirpath, name)
+            self.best_model_score = score
+            self._save(trainer, module, self.best_model_path)
+        if self.save_last:
+            self.last_model_path = os.path.join(self.dirpath, "last.ckpt")
+            self._save(trainer, module, self.last_model_path)
+
+
+class EarlyStopping(Callback):
+    def __init__(self, monitor="val_loss", patience=3, mode="min", min_delta=0.0, **kwargs):
+        self.monitor, self.patience, self.mode, self.min_delta = monitor, patience, mode, min_delta
+        self.best, self.wait = None, 0
+
+    def on_validation_end(self, trainer, module):
+        if trainer.sanity_checking:
+            return
+        score = trainer.callback_metrics.get(self.monitor)
+        if score is None:
+            return
+        improved = self.best is None or (score < self.best - self.min_delta if self.mode == "min"
+                                         else score > self.best + self.min_delta)
+        if improved:
+            self.best, self.wait = score, 0
+        else:
+            self.wait += 1
+            if self.wait >= self.patience:
+                trainer.should_stop = True
+
+
+def _move(batch, device):
+    if isinstance(batch, torch.Tensor):
+        return batch.to(device, non_blocking=True)
+    if hasattr(batch, "to") and not isinstance(batch, (str, bytes)):
+        return batch.to(device)
+    if isinstance(batch, dict):
+        return {k: _move(v, device) for k, v in batch.items()}
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(_move(v, device) for v in batch)
+    return batch
+
+
+class Trainer:
+    def __init__(self, gpus=0, min_epochs=1, max_epochs=1000, fast_dev_run=False, callbacks=None, logger=None,
+                 resume_from_checkpoint=None, precision=32, weights_summary=None, progress_bar_refresh_rate=None,
+                 profiler=None, limit_train_batches=1.0, limit_val_batches=1.0, limit_test_batches=1.0,
+                 num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
+                 default_root_dir=None, **unused):
+        self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
+        self.fast_dev_run = bool(fast_dev_run)
+        self.callbacks: List[Callback] = list(callbacks or [])
+        if isinstance(logger, (list, tuple)):
+            self.loggers = list(logger)
+        elif logger in (None, True, False):
+            self.loggers = []
+        else:
+            self.loggers = [logger]
+        self.resume_from_checkpoint = resume_from_checkpoint
+        self.precision, self.profiler = precision, profiler
+        self.limit = {"train": limit_train_batches, "val": limit_val_batches, "test": limit_test_batches}
+        self.max_steps = max_steps
+        self.terminate_on_nan = terminate_on_nan
+        self.current_epoch, self.global_step = 0, 0
+        self.callback_metrics: Dict[str, float] = {}
+        self.should_stop = False
+        self.sanity_checking = False
+        self.optimizers: List[torch.optim.Optimizer] = []
+        self.model: Optional[LightningModule] = None
+        self.datamodule = None
+        self._epoch_acc: Dict[str, List[float]] = {}
+        self._profile: Dict[str, float] = {}
+        if not any(isinstance(c, ModelCheckpoint) for c in self.callbacks):
+            self.callbacks.append(ModelCheckpoint(save_top_k=0))
+
+    # -- properties the reference reads (training.py:101-107, utils.py:172-177) -------------
+    @property
+    def logger(self):
+        if not self.loggers:
+            return None
+        return self.loggers[0] if len(self.loggers) == 1 else _LoggerCollection(self.loggers)
+
+    @property
+    def checkpoint_callback(self):
+        return next(c for c in self.callbacks if isinstance(c, ModelCheckpoint))
+
+    @property
+    def world_size(self):
+        return torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+
+    @property
+    def is_global_zero(self):
+        return not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+
+    # -- metric plumbing ------------------------------------------------------------------------
+    def _record(self, dictionary, on_step=None, on_epoch=None, sync_dist=False):
+        vals = {k: _to_float(v) for k, v in dictionary.items()}
+        if sync_dist and self.world_size > 1:
+            from .distributed import all_reduce_mean_scalars
+            vals = all_reduce_mean_scalars(vals, device=self.model.device)
+        step_metrics = {}
+        for k, v in vals.items():
+            if on_step is not False:
+                self.callback_metrics[f"{k}_step" if on_epoch else k] = v
+                step_metrics[f"{k}_step" if on_epoch else k] = v
+            if on_epoch:
+                self._epoch_acc.setdefault(k, []).append(v)
+        if step_metrics and self.is_global_zero:
+            for lg in self.loggers:
+                lg.log_metrics(step_metrics, self.global_step)
+
+    def _flush_epoch(self):
+        out = {}
+        for k, vs in self._epoch_acc.items():
+            if vs:
+                out[f"{k}_epoch"] = float(np.mean(vs))
+                out[k] = out[f"{k}_epoch"]
+        self.callback_metrics.update(out)
+        if out and self.is_global_zero:
+            for lg in self.loggers:
+                lg.log_metrics({k: v for k, v in out.items() if k.endswith("_epoch")}, self.global_step)
+        self._epoch_acc = {}
+
+    # -- loops ---------------------------------------------------------------------------------------
+    def _device(self):
+        if self.gpus not in (0, None, "0", []) and torch.cuda.is_available():
+            local = int(os.environ.get("LOCAL_RANK", 0))
+            return torch.device("cuda", local)
+        return torch.device("cpu")
+
+    def _limit(self, which, loader):
+        if self.fast_dev_run:
+            return 1
+        lim = self.limit[which]
+        try:
+            n = len(loader)
+        except TypeError:
+            n = None
+        if isinstance(lim, float) and lim <= 1.0:
+            return None if n is None or lim == 1.0 else max(1, int(n * lim))
+        return int(lim)
+
+    def _attach(self, model, datamodule=None):
+        self.model = model
+        model.trainer = self
+        if datamodule is not None:
+            self.datamodule = datamodule
+        model.to(self._device())
+
+    def _loader(self, which, dataloaders=None):
+        if dataloaders is not None:
+            return dataloaders
+        dm = self.datamodule
+        if dm is None:
+            return None
+        return {"train": dm.train_dataloader, "val": dm.val_dataloader, "test": dm.test_dataloader}[which]()
+
+    def _timed(self, key, fn, *a, **kw):
+        if self.profiler is None:
+            return fn(*a, **kw)
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        self._profile[key] = self._profile.get(key, 0.0) + time.perf_counter() - t0
+        return out
+
+    def _eval_loop(self, which, loader, step_fn, epoch_end_fn=None):
+        if loader is None:
+            return
+        model = self.model
+        model.eval()
+        outputs = []
+        lim = self._limit(which if which != "validate" else "val", loader)
+        with torch.no_grad():
+            for i, batch in enumerate(loader):
+                if lim is not None and i >= lim:
+                    break
+                outputs.append(self._timed(f"{which}_step", step_fn, _move(batch, model.device), i))
+        if epoch_end_fn is not None:
+            epoch_end_fn(outputs)
+        self._flush_epoch()
+
+    def fit(self, model, train_dataloaders=None, val_dataloaders=None, datamodule=None, train_dataloader=None):
+        if isinstance(train_dataloaders, LightningDataModule) or (train_dataloaders is not None and hasattr(train_dataloaders, "train_dataloader")):
+            datamodule, train_dataloaders = train_dataloaders, None
+        if train_dataloader is not None:
+            train_dataloaders = train_dataloader
+        self._attach(model, datamodule)
+        if datamodule is not None:
+            datamodule.prepare_data()
+            datamodule.setup("fit")
+        opt = model.configure_optimizers()
+        if isinstance(opt, dict):
+            opt = opt["optimizer"]
+        self.optimizers = list(opt) if isinstance(opt, (list, tuple)) else [opt]
+        if self.resume_from_checkpoint:
+            ckpt = torch.load(self.resume_from_checkpoint, map_location="cpu")
+            model.load_state_dict(ckpt["state_dict"])
+            for o, s in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+                o.load_state_dict(s)
+            self.current_epoch = ckpt.get("epoch", -1) + 1
+            self.global_step = ckpt.get("global_step", 0)
+        if self.world_size > 1:
+            from .distributed import broadcast_parameters
+            broadcast_parameters(model)
+        for cb in self.callbacks:
+            cb.on_fit_start(self, model)
+        max_epochs = 1 if self.fast_dev_run else self.max_epochs
+        while self.current_epoch < max_epochs and not self.should_stop:
+            model.train()
+            loader = self._loader("train", train_dataloaders)
+            lim = self._limit("train", loader)
+            for i, batch in enumerate(loader):
+                if lim is not None and i >= lim:
+                    break
+                batch = _move(batch, model.device)
+                for o in self.optimizers:
+                    o.zero_grad(set_to_none=True)
+                loss = self._timed("training_step", model.training_step, batch, i)
+                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():
+                    raise ValueError("loss is NaN or inf")
+                self._timed("backward", loss.backward)
+                if self.world_size > 1:
+                    from .distributed import all_reduce_gradients
+                    self._timed("grad_all_reduce", all_reduce_gradients, model)
+                for o in self.optimizers:
+                    self._timed("optimizer_step", o.step)
+                self.global_step += 1
+                if self.max_steps and self.global_step >= self.max_steps:
+                    self.should_stop = True
+                    break
+            self._flush_epoch()
+            for cb in self.callbacks:
+                cb.on_train_epoch_end(self, model)
+            vloader = self._loader("val", val_dataloaders)
+            if vloader is not None:
+                self._eval_loop("val", vloader, model.validation_step, model.validation_epoch_end)
+                for cb in self.callbacks:
+                    cb.on_validation_end(self, model)
+            self.current_epoch += 1
+            if self.current_epoch < self.min_epochs:
+                self.should_stop = False
+        for cb in self.callbacks:
+            cb.on_fit_end(self, model)
+        self._finish()
+
+    def validate(self, model=None, dataloaders=None, datamodule=None, val_dataloaders=None):
+        model = model or self.model
+        self._attach(model, datamodule)
+        if datamodule is not None:
+            datamodule.prepare_data()
+            datamodule.setup("validate")
+        loader = self._loader("val", dataloaders if dataloaders is not None else val_dataloaders)
+        self._eval_loop("val", loader, model.validation_step, model.validation_epoch_end)
+        self._finish()
+        return [dict(self.callback_metrics)]
+
+    def test(self, model=None, dataloaders=None, datamodule=None, test_dataloaders=None):
+        model = model or self.model
+        self._attach(model, datamodule)
+        loader = self._loader("test", dataloaders if dataloaders is not None else test_dataloaders)
+        self._eval_loop("test", loader, model.test_step)
+        self._finish()
+        return [dict(self.callback_metrics)]
+
+    def predict(self, model=None, dataloaders=None, datamodule=None):
+        model = model or self.model
+        self._attach(model, datamodule)
+        loader = self._loader("test", dataloaders)
+        model.eval()
+        outs = []
+        with torch.no_grad():
+            for i, batch in enumerate(loader):
+                if self.fast_dev_run and i >= 1:
+                    break
+                outs.append(model.predict_step(_move(batch, model.device), i))
+        return outs
+
+    def _finish(self):
+        if self.is_global_zero:
+            for lg in self.loggers:
+                lg.finalize("success")
+        if self.profiler is not None and self._profile and self.is_global_zero:
+            log.info("profiler (simple): " + ", ".join(f"{k}={v:.3f}s" for k, v in sorted(self._profile.items())))
+
+
+class _LoggerCollection(LightningLoggerBase):
+    def __init__(self, loggers):
+        self._loggers = loggers
+
+    def __getitem__(self, i):
+        return self._loggers[i]
+
+    @property
+    def experiment(self):
+        return [lg.experiment for lg in self._loggers]
+
+    def log_metrics(self, metrics, step):
+        for lg in self._loggers:
+            lg.log_metrics(metrics, step)
+
+    def log_hyperparams(self, params):
+        for lg in self._loggers:
+            lg.log_hyperparams(params)

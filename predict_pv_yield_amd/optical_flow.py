@@ -1,0 +1,196 @@
+"""Optical-flow advection of satellite tiles on the MI355X — the notebook helpers of the reference,
+batched and device-resident.
+
+Mirrors (same names, argument meaning and error behaviour):
+  convert_10bpp_to_uint8            notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:112-119
+  calcOpticalFlowFarneback          cv.calcOpticalFlowFarneback as called at 13_...ipynb:133-135
+  compute_optical_flow              13_...ipynb:175-240   (process pool -> one batched launch sequence)
+  weighted_average                  notebooks/optical_flow_1.ipynb:293-294
+  remap_image                       13_...ipynb:259-281 (BORDER_CONSTANT, NaN) / optical_flow_1.ipynb:415-430
+  compute_optical_flow_predictions  13_...ipynb:284-333   ((n-1)n/2 predictions from n frames)
+and the join the reference leaves as a TODO (`# TODO: Use optical flow, not actual sat images of the
+future!`, predict_pv_yield/models/perceiver/perceiver.py:118):
+  advect_future_frames / replace_future_frames_with_flow   
+Tensors stay on the GPU end to end; NumPy inputs are accepted for the cv2-style single-image calls and
+are copied to the device (the compute never runs on the host).
+"""
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import hip_ops as K
+from ._lib import PV_BORDER_CONSTANT, PV_BORDER_REPLICATE, PV_OPTFLOW_FARNEBACK_GAUSSIAN
+
+BORDER_CONSTANT = PV_BORDER_CONSTANT
+BORDER_REPLICATE = PV_BORDER_REPLICATE
+OPTFLOW_FARNEBACK_GAUSSIAN = PV_OPTFLOW_FARNEBACK_GAUSSIAN
+INTER_LINEAR = 1
+
+# Farnebäck arguments used everywhere in the reference (13_...ipynb:133-135)
+REFERENCE_FARNEBACK_KWARGS = dict(pyr_scale=0.5, levels=2, winsize=40, iterations=3, poly_n=5, poly_sigma=0.7,
+                                  flags=OPTFLOW_FARNEBACK_GAUSSIAN)
+
+# per-channel normalisation constants (predict_pv_yield/netcdf_dataset.py:19-32); index 0 = HRV
+SAT_MEAN = np.array([93.23458, 131.71373, 843.7779, 736.6148, 771.1189, 589.66034, 862.29816, 927.69586,
+                     90.70885, 107.58985, 618.4583, 532.47394], np.float32)
+SAT_STD = np.array([115.34247, 139.92636, 36.99538, 57.366386, 30.346825, 149.68007, 51.70631, 35.872967,
+                    115.77212, 120.997154, 98.57828, 99.76469], np.float32)
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("predict_pv_yield_amd.optical_flow needs an MI355X (no CPU path is provided)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _as_cuda(a) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.contiguous() if a.is_cuda else a.contiguous().to(_device())
+    return torch.from_numpy(np.ascontiguousarray(a)).to(_device())
+
+
+def _like_input(t: torch.Tensor, template):
+    return t if isinstance(template, torch.Tensor) else t.cpu().numpy()
+
+
+def convert_10bpp_to_uint8(array, check_range: bool = True):
+    """Convert 10 bit per pixel to uint8: round_half_even(array / 4); asserts 0 <= result <= 255."""
+    x = _as_cuda(array)
+    if x.dtype not in (torch.int16, torch.float32):
+        x = x.to(torch.float32)
+    out, flag = K.u8_from_10bit(x, 0, return_flag=True)
+    if check_range:
+        assert int(flag.item()) == 0, "convert_10bpp_to_uint8: values outside [0, 255] after conversion"
+    return _like_input(out, array)
+
+
+def calcOpticalFlowFarneback(prev, next, flow=None, pyr_scale=0.5, levels=2, winsize=40, iterations=3, poly_n=5,
+                             poly_sigma=0.7, flags=OPTFLOW_FARNEBACK_GAUSSIAN):
+    """cv.calcOpticalFlowFarneback signature; prev/next uint8 [H,W] -> float32 [H,W,2]."""
+    if flow is not None:
+        raise ValueError("an initial flow (OPTFLOW_USE_INITIAL_FLOW) is not supported")
+    p, n = _as_cuda(prev), _as_cuda(next)
+    out = K.farneback_pairs(p[None], n[None], pyr_scale=pyr_scale, levels=levels, winsize=winsize,
+                            iterations=iterations, poly_n=poly_n, poly_sigma=poly_sigma, flags=flags)[0]
+    return _like_input(out, prev)
+
+
+def compute_optical_flow(sat_data, **farneback_kwargs):
+    """[..., T, H, W] 10-bit counts -> optical flow fields [..., T-1, H, W, 2] float32, one per consecutive pair
+    (the field's time coordinate is that of the second image of the pair, as in the reference)."""
+    x = _as_cuda(sat_data)
+    if x.dtype != torch.uint8:
+        x = convert_10bpp_to_uint8(x)
+    kw = dict(REFERENCE_FARNEBACK_KWARGS)
+    kw.update(farneback_kwargs)
+    return _like_input(K.farneback_stack(x, **kw), sat_data)
+
+
+def weighted_average(flows, weights: Optional[Sequence[float]] = None):
+    """np.average(flows, axis=0, weights=range(1, N+1)).astype(np.float32) for flows [N, H, W, 2]."""
+    f = _as_cuda(flows)
+    return _like_input(K.flow_weighted_mean(f[None], weights)[0], flows)
+
+
+def remap_image(image, flow, border_mode: int = BORDER_CONSTANT, border_value: float = float("nan")):
+    """Takes an image and warps it forwards in time according to the flow field (cv.remap, INTER_LINEAR).
+    Default border = the nb-13 behaviour (BORDER_CONSTANT, NaN); pass BORDER_REPLICATE for optical_flow_1's."""
+    img, fl = _as_cuda(image), _as_cuda(flow).float()
+    if img.dtype not in (torch.float32, torch.uint8):
+        img = img.float()
+    out = K.remap_bilinear(img[None], fl[None], n_steps=1, step0=1.0, border_mode=border_mode,
+                           border_value=border_value)[0, 0]
+    return _like_input(out, image)
+
+
+def compute_optical_flow_predictions(sat_data, flows, border_mode: int = BORDER_CONSTANT,
+                                     border_value: float = float("nan")):
+    """For n source images and n-1 flows, the (n-1)n/2 linear-extrapolation predictions of nb-13:
+    prediction(flow_i, step) = remap(sat_data[flow_i], flows[flow_i] * step), step = 1 .. n-1-flow_i.
+    Returns (predictions [P, H, W], index [P, 2] int64 = (t0 index, index of the frame the forecast is about)),
+    sorted by (t0, target) like the reference's DataFrame index."""
+    imgs, fl = _as_cuda(sat_data).float(), _as_cuda(flows).float()
+    n = imgs.shape[0]
+    num_flows = n - 1
+    if fl.shape[0] != num_flows:
+        raise ValueError("compute_optical_flow_predictions: need exactly len(sat_data) - 1 flows")
+    h, w = imgs.shape[1:]
+    n_pred = num_flows * n // 2
+    preds = torch.empty((n_pred, h, w), dtype=torch.float32, device=imgs.device)
+    index = []
+    off = 0
+    for flow_i in range(num_flows):
+        steps = num_flows - flow_i
+        K.remap_bilinear(imgs[flow_i:flow_i + 1], fl[flow_i:flow_i + 1], n_steps=steps, step0=1.0,
+                         border_mode=border_mode, border_value=border_value, out=preds[off:off + steps][None])
+        index += [(flow_i, flow_i + s) for s in range(1, steps + 1)]
+        off += steps
+    idx = torch.tensor(index, dtype=torch.int64)
+    return _like_input(preds, sat_data), idx
+
+
+# ------------------------------------------------------------------------------------------------
+# the join: advected future frames feeding the Conv3D model
+# ------------------------------------------------------------------------------------------------
+def advect_future_frames(raw: torch.Tensor, n_future: int, mean: Optional[torch.Tensor] = None,
+                         std: Optional[torch.Tensor] = None, border_mode: int = BORDER_REPLICATE,
+                         border_value: float = float("nan"), out_dtype=torch.float32, **farneback_kwargs) -> torch.Tensor:
+    """Config-3 pipeline for raw 10-bit counts [B, T, C, H, W] (int16 or float32, time-major as
+    in BASELINE.json):  u8 = round(raw/4) -> T-1 Farnebäck fields per (b, c) -> weighted mean (weights 1..T-1)
+    -> normalise (raw - mean_c)/std_c -> n_future frames remap(frame_t0, k * flow), k = 1..n_future.
+    Returns [B, C, T + n_future, H, W] float32 in the model's NCDHW layout; the advected frames are written by the
+    remap kernel straight into the future time slices (no host round trip, no intermediate copy)."""
+    if not raw.is_cuda:
+        raise RuntimeError("advect_future_frames: input must be on the MI355X")
+    b, t, c, h, w = raw.shape
+    dev = raw.device
+    if mean is None:
+        mean = torch.from_numpy(SAT_MEAN[1:1 + c] if c < 12 else SAT_MEAN[:c]).to(dev)
+        std = torch.from_numpy(SAT_STD[1:1 + c] if c < 12 else SAT_STD[:c]).to(dev)
+    # [B, C, T, H, W] channel-major stacks: each (b, c) is one Farnebäck frame stack
+    stacks = raw.permute(0, 2, 1, 3, 4).contiguous()
+    u8 = K.u8_from_10bit(stacks if stacks.dtype in (torch.int16, torch.float32) else stacks.float(), 0)
+    kw = dict(REFERENCE_FARNEBACK_KWARGS)
+    kw.update(farneback_kwargs)
+    flows = K.farneback_stack(u8, **kw)                               # [B, C, T-1, H, W, 2]
+    mean_flow = K.flow_weighted_mean(flows.view(b * c, t - 1, h, w, 2))  # [B*C, H, W, 2]
+    out = torch.empty((b, c, t + n_future, h, w), dtype=torch.float32, device=dev)
+    # normalise the observed frames into out[:, :, :t]: inner = T*H*W elements share a channel
+    obs = K.normalise(stacks, mean, std, inner=t * h * w)            # [B, C, T, H, W]
+    out[:, :, :t] = obs
+    # advected frames: src = normalised frame t0 = out[b, c, t-1], dst = out[b, c, t + k - 1]
+    frame = h * w
+    img_stride = (t + n_future) * frame
+    K.remap_bilinear_strided(out.data_ptr() + (t - 1) * frame * 4, img_stride, mean_flow,
+                             out.data_ptr() + t * frame * 4, img_stride, frame, b * c, n_future, 1.0, h, w,
+                             border_mode, border_value)
+    return out if out_dtype == torch.float32 else out.to(out_dtype)
+
+
+def replace_future_frames_with_flow(sat_data: torch.Tensor, n_future: int, border_mode: int = BORDER_REPLICATE,
+                                    counts_scale: float = 255.0 / 6.0, **farneback_kwargs) -> torch.Tensor:
+    """For a NORMALISED model input [B, C, T, H, W]: recompute the last n_future time slices by advecting the
+    last observed frame along the weighted-mean Farnebäck flow of the observed frames.  The u8 images Farnebäck
+    needs are obtained by mapping the normalised values (about N(0,1)) affinely onto 0..255
+    (u8 = clip(round(128 + x * counts_scale)))."""
+    if not sat_data.is_cuda:
+        raise RuntimeError("replace_future_frames_with_flow: input must be on the MI355X")
+    b, c, t, h, w = sat_data.shape
+    t_obs = t - n_future
+    if t_obs < 2:
+        raise ValueError("need at least two observed frames to estimate a flow")
+    obs = sat_data[:, :, :t_obs].contiguous()
+    # affine map onto 10-bit-like counts, then the reference's u8 conversion
+    counts = ((obs * (4.0 * counts_scale)) + 512.0).clamp_(0.0, 1020.0)
+    u8 = K.u8_from_10bit(counts, 0)
+    kw = dict(REFERENCE_FARNEBACK_KWARGS)
+    kw.update(farneback_kwargs)
+    flows = K.farneback_stack(u8, **kw)
+    mean_flow = K.flow_weighted_mean(flows.view(b * c, t_obs - 1, h, w, 2))
+    out = sat_data.contiguous().clone()
+    frame = h * w
+    K.remap_bilinear_strided(out.data_ptr() + (t_obs - 1) * frame * 4, t * frame, mean_flow,
+                             out.data_ptr() + t_obs * frame * 4, t * frame, frame, b * c, n_future, 1.0, h, w,
+                             border_mode, float("nan"))
+    return out

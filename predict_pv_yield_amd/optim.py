@@ -1,0 +1,43 @@
+"""HipAdam — torch.optim.Adam(lr=5e-4) (predict_pv_yield/models/base_model.py:255-257) stepped by the fused
+HIP kernel pv_adam_step_f32 (one pass over p, g, m, v; torch's single-tensor Adam order of operations).
+
+It is a torch.optim.Optimizer so `configure_optimizers()` keeps the Lightning contract and state_dict()
+round-trips (`exp_avg`, `exp_avg_sq`, `step`: the same keys torch.optim.Adam uses, so checkpoints
+interchange).  Parameters that carry a `_pv_bf16_shadow` (fc1 in the bf16 path) get the shadow rewritten in
+the same pass.  `grad_scale` folds the 1/world_size of a summing gradient all-reduce into the update.
+"""
+import torch
+
+from . import hip_ops as K
+
+
+class HipAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("HipAdam: invalid hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.grad_scale = 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                K.adam_step(p, g.float(), st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), lr=group["lr"],
+                            betas=group["betas"], eps=group["eps"], bf16_shadow=getattr(p, "_pv_bf16_shadow", None),
+                            grad_scale=self.grad_scale)
+        return loss
