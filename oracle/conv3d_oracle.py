@@ -41,14 +41,44 @@ def timestep_arithmetic(history_minutes: int, forecast_minutes: int, output_vari
     return d
 
 
+class _RoundBF16(torch.autograd.Function):
+    """Round to bf16 (nearest even) in forward AND in backward: models a bf16 tensor hand-off between two
+    kernels of the MFMA path (activations forward, activation gradients backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundWeightBF16(torch.autograd.Function):
+    """bf16 operand copy of an f32 master weight; the gradient goes to the master unchanged."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class OracleConv3dModel(nn.Module):
-    """Same layer graph and attribute names (state_dict keys) as the reference Model."""
+    """Same layer graph and attribute names (state_dict keys) as the reference Model.
+
+    emulate_bf16=True restates, on the CPU and in f32 arithmetic, exactly WHICH values the bf16 MFMA path rounds
+    (conv/fc1 operands, activations between conv layers, activation gradients between dgrad kernels) so the
+    HIP path can be compared at accumulation-order tolerance instead of bf16-noise tolerance."""
 
     def __init__(self, include_pv_yield=True, include_nwp=True, forecast_minutes=30, history_minutes=60,
                  number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=64, number_sat_channels=12,
                  fc1_output_features=128, fc2_output_features=128, fc3_output_features=64,
-                 output_variable="pv_yield"):
+                 output_variable="pv_yield", emulate_bf16=False):
         super().__init__()
+        self.emulate_bf16 = emulate_bf16
         self.include_pv_yield, self.include_nwp = include_pv_yield, include_nwp
         self.number_of_conv3d_layers = number_of_conv3d_layers
         self.number_of_nwp_features = 10 * 19 * 2 * 2
@@ -76,13 +106,23 @@ class OracleConv3dModel(nn.Module):
         acts = []
         sat_data = sat_data.float()
         batch_size = sat_data.shape[0]
-        out = F.relu(self.sat_conv0(sat_data))
-        acts.append(out)
-        for i in range(self.number_of_conv3d_layers - 1):
-            out = F.relu(getattr(self, f"conv3d_{i + 1}")(out))
+        if self.emulate_bf16:
+            out = bf16_round(sat_data)
+            layers = [self.sat_conv0] + [getattr(self, f"conv3d_{i + 1}") for i in range(self.number_of_conv3d_layers - 1)]
+            for layer in layers:
+                out = F.relu(F.conv3d(out, _RoundWeightBF16.apply(layer.weight), layer.bias))
+                out = _RoundBF16.apply(out)
+                acts.append(out)
+            out = out.reshape(batch_size, self.cnn_output_size)
+            out = F.relu(F.linear(out, _RoundWeightBF16.apply(self.fc1.weight), self.fc1.bias))
+        else:
+            out = F.relu(self.sat_conv0(sat_data))
             acts.append(out)
-        out = out.reshape(batch_size, self.cnn_output_size)
-        out = F.relu(self.fc1(out))
+            for i in range(self.number_of_conv3d_layers - 1):
+                out = F.relu(getattr(self, f"conv3d_{i + 1}")(out))
+                acts.append(out)
+            out = out.reshape(batch_size, self.cnn_output_size)
+            out = F.relu(self.fc1(out))
         acts.append(out)
         out = F.relu(self.fc2(out))
         acts.append(out)

@@ -99,6 +99,9 @@ def get_lib():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (or `make -C {CSRC_DIR}`). predict_pv_yield_amd has no CPU fallback.")
+        # torch bundles its own libamdhip64: import it FIRST so this library binds to the same HIP runtime
+        # (two runtimes in one process cannot share streams or device pointers)
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -18,7 +18,7 @@ def _pair(kw, precision, device, seed=518):
     from predict_pv_yield_amd.models.conv3d.model import Model
     torch.manual_seed(seed)
     oracle = co.OracleConv3dModel(**kw)
-    model = Model(**kw, precision=precision)
+    model = Model(**{k: v for k, v in kw.items() if k != "emulate_bf16"}, precision=precision)
     model.load_state_dict(oracle.state_dict())
     return oracle, model.to(device)
 
@@ -91,8 +91,25 @@ def test_bf16_forward_and_steps(device):
     np.testing.assert_allclose(losses, ref_losses, rtol=1e-2)
 
 
-def test_bf16_gradients(device):
+def test_bf16_gradients_vs_f32_oracle_loose(device):
+    """Against the pure-f32 oracle the bf16 path carries bf16 rounding noise through four conv layers: the fc
+    gradients stay within a few percent, the earliest conv weights within ~15 % (norm-wise)."""
     oracle, model = _pair(SMALL, "bf16", device)
+    sat, pv = _data(SMALL, 4, seed=3)
+    y_ref = oracle(sat)
+    _, nmae, _, _ = co.forecast_losses(y_ref, co.select_target(pv, oracle.forecast_len))
+    nmae.backward()
+    loss = model.training_step({"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}, 0)
+    loss.backward()
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        rel = (p.grad.cpu() - q.grad).norm().item() / (q.grad.norm().item() + 1e-12)
+        assert rel <= (0.2 if "conv" in k else 5e-2), (k, rel)
+
+
+def test_bf16_gradients(device):
+    """Tight check: the oracle rounds exactly the tensors the MFMA path rounds (emulate_bf16), so what is left is
+    f32 accumulation order and isolated 1-ulp bf16 flips."""
+    oracle, model = _pair(dict(SMALL, emulate_bf16=True), "bf16", device)
     sat, pv = _data(SMALL, 4, seed=3)
     y_ref = oracle(sat)
     _, nmae, _, _ = co.forecast_losses(y_ref, co.select_target(pv, oracle.forecast_len))

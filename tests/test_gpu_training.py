@@ -1,0 +1,121 @@
+"""GPU: the reference's end-to-end harnesses driven against this package through the same surface
+(tests/test_training.py::test_train of the reference: compose -> train(config); model tests: Trainer.fit/predict)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flow_oracle as fo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_example_simple(device, tmp_path, monkeypatch):
+    """reference tests/test_training.py:8-25: logger=csv, experiment=example_simple, fake data, fast_dev_run."""
+    from predict_pv_yield_amd import hydra_lite as H
+    from predict_pv_yield_amd.training import train
+    monkeypatch.chdir(tmp_path)
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config",
+                    ["logger=csv", "experiment=example_simple", "datamodule.fake_data=true",
+                     f"datamodule.data_path={ROOT}/tests/configs/dataset", "trainer.fast_dev_run=true", "trainer.gpus=1"])
+    train(config=cfg)
+
+
+def test_train_conv3d_experiment_two_epochs(device, tmp_path, monkeypatch):
+    from predict_pv_yield_amd import hydra_lite as H
+    from predict_pv_yield_amd.training import train
+    monkeypatch.chdir(tmp_path)
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config",
+                    ["experiment=conv3d", "model.image_size_pixels=16", "model.history_minutes=30",
+                     "model.forecast_minutes=120", "model.fc1_output_features=16", "datamodule.n_train_data=3",
+                     f"datamodule.data_path={ROOT}/tests/configs/dataset", "trainer.max_epochs=2",
+                     "optimized_metric=MSE/Validation_epoch", "test_after_training=false"])
+    score = train(config=cfg)
+    assert np.isfinite(score)
+    assert os.path.exists("checkpoints/last.ckpt")
+    ck = torch.load("checkpoints/last.ckpt")
+    assert "sat_conv0.weight" in ck["state_dict"] and "fc4.bias" in ck["state_dict"]
+    assert set(ck["optimizer_states"][0]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}   # torch.optim.Adam keys
+
+
+def test_model_trainer_fit_and_predict(device):
+    """reference tests/models/conv3d/test_conv3d_model.py:42-62."""
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.utils import load_config
+    config = load_config("tests/configs/model/conv3d.yaml")
+    model = Model(**config)
+    ds = FakeDataset(FakeDataConfiguration(batch_size=2, history_minutes=60, forecast_minutes=60,
+                                           satellite_image_size_pixels=16), length=2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=None)
+    trainer = pl.Trainer(gpus=1, max_epochs=1)
+    trainer.fit(model, loader)
+    out = trainer.predict(model, loader)
+    assert len(out) == 2 and out[0].shape == (2, model.forecast_len_5)
+
+
+def test_advect_future_frames_matches_oracle(device):
+    from predict_pv_yield_amd import optical_flow as of
+    from predict_pv_yield_amd.data.synthetic import advected_counts
+    raw, vel = advected_counts(batch=2, t=6, channels=3, h=64, w=64, seed=21, vmax=2.0)
+    mean, std = of.SAT_MEAN[1:4], of.SAT_STD[1:4]
+    got = of.advect_future_frames(torch.from_numpy(raw).to(device), n_future=3, mean=torch.from_numpy(mean).to(device),
+                                  std=torch.from_numpy(std).to(device)).cpu().numpy()
+    ref = fo.advect_frames(raw, mean, std, n_future=3)
+    assert got.shape == ref.shape == (2, 3, 9, 64, 64)
+    assert np.array_equal(got[:, :, :6], ref[:, :, :6])                       # normalisation: bit-exact
+    assert np.abs(got[:, :, 6:] - ref[:, :, 6:]).max() < 5e-3                  # warp of a 1e-3-px-accurate flow
+    # the advected frame is a better predictor of the true next texture position than persistence
+    t0 = ref[:, :, 5]
+    assert np.abs(got[:, :, 6] - t0).mean() > 1e-3
+
+
+def test_cv2_style_api(device):
+    from predict_pv_yield_amd import optical_flow as of
+    from predict_pv_yield_amd.data.synthetic import advected_counts
+    raw, _ = advected_counts(batch=1, t=4, channels=1, h=64, w=64, seed=2)
+    stack = raw[0, :, 0]
+    u8 = of.convert_10bpp_to_uint8(stack)
+    assert isinstance(u8, np.ndarray) and u8.dtype == np.uint8
+    assert np.array_equal(u8, fo.convert_10bpp_to_uint8(stack, 0)[0])
+    flow = of.calcOpticalFlowFarneback(u8[0], u8[1], None, 0.5, 2, 40, 3, 5, 0.7, of.OPTFLOW_FARNEBACK_GAUSSIAN)
+    ref = fo.calc_optical_flow_farneback(u8[0], u8[1])
+    assert flow.shape == (64, 64, 2) and np.abs(flow - ref).max() <= 1e-3
+    flows = of.compute_optical_flow(stack)
+    assert flows.shape == (3, 64, 64, 2) and np.abs(flows[0] - ref).max() <= 1e-3
+    wavg = of.weighted_average(flows)
+    assert np.array_equal(wavg, np.average(flows, axis=0, weights=range(1, 4)).astype(np.float32))
+    img = stack[0].astype(np.float32)
+    warped = of.remap_image(img, wavg)
+    refw = fo.remap_image(img, wavg, 1.0, fo.BORDER_CONSTANT, np.nan)
+    assert np.array_equal(np.isnan(warped), np.isnan(refw)) and np.array_equal(warped[~np.isnan(refw)], refw[~np.isnan(refw)])
+    preds, index = of.compute_optical_flow_predictions(stack.astype(np.float32), flows)
+    assert preds.shape == (6, 64, 64) and index.tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]
+    r = fo.remap_image(stack[1].astype(np.float32), flows[1], 2.0, fo.BORDER_CONSTANT, np.nan)
+    m = ~np.isnan(r)
+    assert np.array_equal(preds[4][m], r[m])
+    with pytest.raises(AssertionError):
+        of.convert_10bpp_to_uint8(np.array([4000, 1, 2, 3, 4, 5, 6, 7], np.int16))
+
+
+def test_model_with_optical_flow_future_frames(device):
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=25, image_size_pixels=32,
+              number_sat_channels=2, fc1_output_features=8, fc2_output_features=8, fc3_output_features=8)
+    torch.manual_seed(0)
+    m_true = Model(**kw, precision="fp32", future_frames="true").to(device)
+    m_flow = Model(**kw, precision="fp32", future_frames="optical_flow").to(device)
+    m_flow.load_state_dict(m_true.state_dict())
+    sat = torch.randn(2, 2, 12, 32, 32, device=device)
+    pv = torch.rand(2, 12, 128, device=device)
+    batch = {"satellite": {"data": sat}, "pv": {"pv_yield": pv}}
+    y_true, y_flow = m_true(batch), m_flow(batch)
+    assert y_flow.shape == (2, 6) and torch.isfinite(y_flow).all()
+    assert not torch.equal(y_true, y_flow)       # the 6 future slices were replaced
+    # the observed slices are untouched by the replacement
+    from predict_pv_yield_amd.optical_flow import replace_future_frames_with_flow
+    rep = replace_future_frames_with_flow(sat, n_future=6)
+    assert torch.equal(rep[:, :, :6], sat[:, :, :6]) and not torch.equal(rep[:, :, 6:], sat[:, :, 6:])

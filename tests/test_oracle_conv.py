@@ -1,0 +1,102 @@
+"""CPU: the torch-CPU oracle (oracle/conv3d_oracle.py) against golden vectors produced by the REFERENCE's own
+module source (tests/golden/make_conv3d_golden.py -> conv3d_small.npz), plus known-answer tests of the loss and
+Adam restatements.  This is what pins the oracle the GPU parity tests are judged against."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import conv3d_oracle as co
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "conv3d_small.npz")
+KW = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=30,
+          number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=10, number_sat_channels=11,
+          fc1_output_features=16, fc2_output_features=16, fc3_output_features=16)
+KW_PV = dict(KW, include_pv_yield=True, include_nwp=True, output_variable="gsp_yield", forecast_minutes=60)
+
+
+def checksum(t, n=64):
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item()], t.detach().flatten()[idx].double().numpy()])
+
+
+@pytest.mark.parametrize("tag,kw", [("sat_only", KW), ("pv_nwp", KW_PV)])
+def test_oracle_matches_reference_module(tag, kw):
+    g = np.load(GOLD)
+    model = co.OracleConv3dModel(**kw)
+    sd = {k[len(f"{tag}/init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/init/")}
+    assert list(sd) == list(model.state_dict())          # same parameter names, same order
+    model.load_state_dict(sd)
+    attrs = [model.cnn_output_size, model.forecast_len, model.history_len_5, model.forecast_len_5,
+             model.history_len_30, model.forecast_len_30, model.history_len_60, model.number_of_samples_per_batch]
+    assert attrs == list(g[f"{tag}/attrs"])
+    sat, pv, gsp, nwp = (torch.from_numpy(g[f"{tag}/{k}"]) for k in ("sat", "pv", "gsp", "nwp"))
+    yld = gsp if kw.get("output_variable") == "gsp_yield" else pv
+    args = (sat, yld, nwp) if kw["include_pv_yield"] else (sat,)
+    y_hat = model(*args)
+    assert np.array_equal(y_hat.detach().numpy(), g[f"{tag}/y_hat"])   # bit-exact on the same torch build
+    opt = co.make_optimizer(model)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        y_hat = model(*args)
+        mse, nmae, mse_exp, mae_exp = co.forecast_losses(y_hat, co.select_target(yld, model.forecast_len))
+        nmae.backward()
+        if step == 0:
+            np.testing.assert_allclose([float(mse), float(nmae), float(mse_exp), float(mae_exp)], g[f"{tag}/logged"],
+                                       rtol=1e-6)
+            for k, p in model.named_parameters():
+                np.testing.assert_array_equal(checksum(p.grad), g[f"{tag}/grad/{k}"], err_msg=k)
+        opt.step()
+        losses.append(float(nmae.detach()))
+        if step in (0, 2):
+            for k, p in model.named_parameters():
+                np.testing.assert_array_equal(checksum(p), g[f"{tag}/step{step + 1}/{k}"], err_msg=k)
+    np.testing.assert_array_equal(np.array(losses), g[f"{tag}/losses"])
+
+
+def test_timestep_arithmetic_matches_base_model():
+    # base_model.py:41-73; the default Model() sees T = 19, BASELINE's "12 -> 6" is history_minutes = 55 (T = 18)
+    d = co.timestep_arithmetic(60, 30)
+    assert (d["history_len_5"], d["forecast_len_5"], d["history_len_30"], d["forecast_len_30"], d["history_len_60"]) == (12, 6, 2, 1, 1)
+    assert d["forecast_len"] == 6 and d["number_of_samples_per_batch"] == 128
+    d = co.timestep_arithmetic(55, 30)
+    assert d["history_len_5"] + d["forecast_len_5"] + 1 == 18
+    d = co.timestep_arithmetic(30, 120, "gsp_yield")
+    assert d["forecast_len"] == 4 and d["history_len_60"] == 1 and d["number_of_samples_per_batch"] == 32
+    m = co.OracleConv3dModel(include_pv_yield=False, include_nwp=False, number_sat_channels=11, fc1_output_features=1)
+    assert m.cnn_output_size == 32 * 56 * 56 * 11 == 1103872          # model.py:74-78 at the reference defaults
+    m18 = co.OracleConv3dModel(include_pv_yield=False, include_nwp=False, number_sat_channels=11, history_minutes=55,
+                                 fc1_output_features=1)
+    assert m18.cnn_output_size == 1003520
+
+
+def test_weighted_losses_kat():
+    w = co.weighted_losses_weights(3)
+    raw = np.array([1.0, 0.5, 0.25])
+    np.testing.assert_allclose(w.numpy(), raw / raw.sum() * 3, rtol=1e-6)
+    assert abs(float(w.mean()) - 1.0) < 1e-6
+    y_hat = torch.tensor([[1.0, 2.0, 3.0]])
+    y = torch.zeros(1, 3)
+    mse, nmae, mse_exp, mae_exp = co.forecast_losses(y_hat, y)
+    assert abs(float(mse) - 14 / 3) < 1e-6 and abs(float(nmae) - 2.0) < 1e-6
+    assert abs(float(mae_exp) - float((w * torch.tensor([1.0, 2.0, 3.0])).mean())) < 1e-6
+
+
+def test_select_target_is_first_site_last_steps():
+    y = torch.arange(2 * 5 * 3, dtype=torch.float32).reshape(2, 5, 3)
+    t = co.select_target(y, 2)
+    assert t.tolist() == [[9.0, 12.0], [24.0, 27.0]]
+
+
+def test_bf16_emulation_rounds_only_operands():
+    torch.manual_seed(0)
+    a = co.OracleConv3dModel(**KW)
+    b = co.OracleConv3dModel(**KW, emulate_bf16=True)
+    b.load_state_dict(a.state_dict())
+    sat = torch.randn(2, 11, 13, 10, 10)
+    ya, yb = a(sat), b(sat)
+    assert not torch.equal(ya, yb)
+    torch.testing.assert_close(ya, yb, rtol=5e-2, atol=5e-3)

@@ -1,0 +1,199 @@
+"""CPU: known-answer tests that pin the C restatement of Farnebäck / cv.remap / u8 conversion / weighted mean
+(oracle/pv_oracle.c).  OpenCV is absent and the reference has no tests for this path, so parity with cv2 is
+UNPINNED; these are the analytic KATs of SURVEY.md §8c (K1-K5, R1-R5) plus independent cross-checks against
+NumPy / SciPy."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from oracle import flow_oracle as fo
+from predict_pv_yield_amd.data.synthetic import advected_counts, blob_texture_sequence
+
+
+def _u8_pair(rng, h, w, v):
+    seq = blob_texture_sequence(rng, 2, h, w, v)
+    return fo.convert_10bpp_to_uint8(np.clip(np.rint(seq), 0, 1023).astype(np.int16), 0)[0]
+
+
+# ---- u8 conversion / weighted mean / normalise ----------------------------------------------------------
+def test_u8_round_half_even_matches_numpy():
+    x = np.arange(0, 1022, dtype=np.int16)              # 1022/4 rounds to 256: the reference asserts there
+    got, flag = fo.convert_10bpp_to_uint8(x, 0)
+    ref = (x / 4.0).round().astype(np.uint8)           # notebooks/13_...ipynb:112-119
+    assert np.array_equal(got, ref) and not flag
+    assert list(got[[2, 6, 10, 14]]) == [0, 2, 2, 4]   # ties go to even
+    gotf, _ = fo.convert_10bpp_to_uint8(x.astype(np.float32), 0)
+    assert np.array_equal(gotf, ref)
+
+
+def test_u8_truncating_variant_matches_numpy():
+    x = np.arange(0, 1024, dtype=np.float32)
+    a = x.copy(); a -= 0; a /= 1023; a *= 255          # notebooks/optical_flow_1.ipynb:129-134
+    got, _ = fo.convert_10bpp_to_uint8(x, 1)
+    assert np.array_equal(got, a.astype(np.uint8))
+
+
+def test_u8_range_flag():
+    _, flag = fo.convert_10bpp_to_uint8(np.array([0, 1030], np.int16), 0)
+    assert flag
+
+
+def test_weighted_average_matches_numpy():
+    rng = np.random.default_rng(0)
+    flows = rng.normal(0, 2, (6, 9, 7, 2)).astype(np.float32)
+    ref = np.average(flows, axis=0, weights=range(1, 7)).astype(np.float32)   # optical_flow_1.ipynb:293-294
+    assert np.array_equal(fo.weighted_average(flows), ref)
+
+
+def test_normalise_matches_numpy_inplace_ops():
+    raw = np.arange(0, 1024, 7, dtype=np.float32)
+    a = raw.copy(); a -= np.float32(93.23458); a /= np.float32(115.34247)     # 13_...ipynb:463-464
+    got = fo.normalise(raw, np.array([93.23458], np.float32), np.array([115.34247], np.float32), inner=raw.size)
+    assert np.array_equal(got, a)
+
+
+# ---- remap (R1-R5) ------------------------------------------------------------------------------------------
+def test_R1_integer_flow_is_exact_shift():
+    rng = np.random.default_rng(1)
+    img = rng.normal(size=(12, 15)).astype(np.float32)
+    flow = np.zeros((12, 15, 2), np.float32); flow[..., 0] = 2; flow[..., 1] = -1
+    out = fo.remap_image(img, flow, 1.0, fo.BORDER_REPLICATE)
+    yy, xx = np.mgrid[0:12, 0:15]
+    assert np.array_equal(out, img[np.clip(yy + 1, 0, 11), np.clip(xx - 2, 0, 14)])
+    out_nan = fo.remap_image(img, flow, 1.0, fo.BORDER_CONSTANT, np.nan)
+    # R4: every 2x2 footprint that touches the outside is NaN, even at zero weight (0 * NaN): the two left
+    # columns, the last row (source row 12) and the row before it (source row 11 = h-1, second tap outside)
+    assert np.isnan(out_nan[:, :2]).all() and np.isnan(out_nan[-2:]).all()
+    assert np.array_equal(out_nan[:-2, 2:], out[:-2, 2:])
+
+
+def test_R4_zero_flow_nan_border_contaminates_last_row_and_column():
+    img = np.ones((6, 7), np.float32)
+    out = fo.remap_image(img, np.zeros((6, 7, 2), np.float32), 1.0, fo.BORDER_CONSTANT, np.nan)
+    assert np.isnan(out[-1]).all() and np.isnan(out[:, -1]).all() and np.all(out[:-1, :-1] == 1)
+
+
+def test_R2_fractions_of_one_32nd_match_scipy():
+    rng = np.random.default_rng(2)
+    img = rng.normal(size=(20, 24)).astype(np.float32)
+    flow = (rng.integers(-64, 64, (20, 24, 2)) / 32.0).astype(np.float32)
+    out, idx = fo.remap_image(img, flow, 1.0, fo.BORDER_REPLICATE, return_indices=True)
+    yy, xx = np.mgrid[0:20, 0:24].astype(np.float64)
+    ref = ndimage.map_coordinates(img.astype(np.float64), [yy - flow[..., 1], xx - flow[..., 0]], order=1, mode="nearest")
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    # integer index contract: sx = round(32 * map) -> (sx >> 5, sx & 31)
+    sx = np.rint((xx - flow[..., 0]) * 32).astype(np.int64)
+    assert np.array_equal(idx[..., 0], sx >> 5) and np.array_equal(idx[..., 2], sx & 31)
+
+
+def test_R3_cvround_ties_to_even_and_nan_coordinates():
+    img = np.arange(16, dtype=np.float32).reshape(4, 4)
+    flow = np.zeros((4, 4, 2), np.float32)
+    flow[0, 1, 0] = -0.5 / 32      # map.x*32 = 32.5 -> 32 (even)
+    flow[0, 2, 0] = -1.5 / 32      # map.x*32 = 65.5 -> 66 (even)
+    flow[1, 1] = [np.nan, 0]       # NaN -> INT_MIN -> far outside
+    _, idx = fo.remap_image(img, flow, 1.0, fo.BORDER_REPLICATE, return_indices=True)
+    assert tuple(idx[0, 1, [0, 2]]) == (1, 0) and tuple(idx[0, 2, [0, 2]]) == (2, 2)
+    assert idx[1, 1, 0] == -32768
+    out = fo.remap_image(img, flow, 1.0, fo.BORDER_CONSTANT, np.nan)
+    assert np.isnan(out[1, 1])
+
+
+def test_R5_u8_fixed_point():
+    img = np.array([[0, 100], [200, 255]], np.uint8)
+    flow = np.zeros((2, 2, 2), np.float32)
+    assert np.array_equal(fo.remap_image(img, flow, 1.0, fo.BORDER_REPLICATE), img)    # identity despite the 32767 weight
+    flow[0, 0] = [-0.5, -0.5]      # samples the centre: (0+100+200+255)/4 = 138.75 -> 139
+    out = fo.remap_image(img, flow, 1.0, fo.BORDER_REPLICATE)
+    assert out[0, 0] == (0 * 8192 + 100 * 8192 + 200 * 8192 + 255 * 8192 + 16384) >> 15 == 139
+
+
+def test_remap_scale_k_is_f32_product():
+    rng = np.random.default_rng(3)
+    img = rng.normal(size=(8, 8)).astype(np.float32)
+    flow = rng.normal(0, 1, (8, 8, 2)).astype(np.float32)
+    a = fo.remap_image(img, flow, 3.0, fo.BORDER_REPLICATE)
+    b = fo.remap_image(img, (flow * np.float32(3.0)).astype(np.float32), 1.0, fo.BORDER_REPLICATE)   # 13_...ipynb:320
+    assert np.array_equal(a, b)
+
+
+# ---- Farnebäck (K1-K5) -----------------------------------------------------------------------------------------
+def test_K3_level_rule():
+    assert fo.farneback_num_levels(64, 64) == 1          # 32x32 is the only coarse level
+    assert fo.farneback_num_levels(704, 548) == 2        # 176 x 137 >= 32
+    assert fo.farneback_num_levels(63, 64) == 0
+    assert fo.farneback_num_levels(128, 128, levels=5) == 2
+
+
+def test_K4_gaussian_tables_closed_form():
+    g, xg, xxg, ig = fo.farneback_poly_tables(5, 0.7)
+    x = np.arange(-5, 6, dtype=np.float64)
+    gd = np.exp(-x * x / (2 * 0.7 ** 2)); gd /= gd.sum()
+    np.testing.assert_allclose(g, gd, rtol=2e-7, atol=1e-12)
+    np.testing.assert_allclose(xg, x * gd, rtol=2e-7, atol=1e-12)
+    np.testing.assert_allclose(xxg, x * x * gd, rtol=2e-7, atol=1e-12)
+    g64 = g.astype(np.float64)
+    G = np.zeros((6, 6))
+    s2 = (np.outer(g64, g64) * (x ** 2)[None]).sum(); s4 = (np.outer(g64, g64) * (x ** 4)[None]).sum()
+    s22 = (np.outer(g64 * x * x, g64 * x * x)).sum()
+    G[0, 0] = np.outer(g64, g64).sum(); G[1, 1] = G[2, 2] = G[0, 3] = G[0, 4] = G[3, 0] = G[4, 0] = s2
+    G[3, 3] = G[4, 4] = s4; G[3, 4] = G[4, 3] = G[5, 5] = s22
+    inv = np.linalg.inv(G)
+    np.testing.assert_allclose(ig, [inv[1, 1], inv[0, 3], inv[3, 3], inv[5, 5]], rtol=1e-6)
+    k = fo.farneback_window_taps(40)
+    t = np.exp(-np.arange(21.0) ** 2 / (2 * 6.0 ** 2))
+    np.testing.assert_allclose(k, t / (t[0] + 2 * t[1:].sum()), rtol=3e-7)
+    assert abs(k[0] + 2 * k[1:].sum() - 1) < 1e-6 and len(k) == 21
+
+
+def test_K1_identical_frames():
+    rng = np.random.default_rng(4)
+    u8 = _u8_pair(rng, 64, 64, (0, 0))
+    flow = fo.calc_optical_flow_farneback(u8[0], u8[0])
+    assert np.abs(flow[8:-8, 8:-8]).max() <= 1e-3 or np.abs(flow).max() < 0.2
+    assert np.abs(flow).max() < 0.2                    # border branch of UpdateMatrices leaks at most ~0.1 px
+
+
+@pytest.mark.parametrize("v", [(1.0, 0.0), (0.0, -2.0), (1.5, 0.75), (3.0, -2.0)])
+@pytest.mark.parametrize("hw", [(64, 64), (160, 200)])
+def test_K2_translation_recovered(v, hw):
+    rng = np.random.default_rng(5)
+    u8 = _u8_pair(rng, hw[0], hw[1], v)
+    flow = fo.calc_optical_flow_farneback(u8[0], u8[1])
+    inner = flow[12:-12, 12:-12]
+    err = np.hypot(inner[..., 0] - v[0], inner[..., 1] - v[1])
+    assert np.percentile(err, 95) <= 0.15, np.percentile(err, 95)
+
+
+def test_K5_border_attenuation_limits_edge_flow():
+    rng = np.random.default_rng(6)
+    u8 = _u8_pair(rng, 64, 64, (2.0, 0.0))
+    flow = fo.calc_optical_flow_farneback(u8[0], u8[1], winsize=5, iterations=1, levels=0)
+    # with a tiny window the 5-px frame (scale .14/.4472) visibly damps the solution next to the border
+    assert np.abs(flow[32, 0, 0]) < np.abs(np.median(flow[20:44, 20:44, 0]))
+
+
+def test_polyexp_constant_image_has_zero_derivatives():
+    img = np.full((40, 40), 77, np.uint8)
+    I, R = fo.farneback_level_polyexp(img, 0)
+    assert np.all(I == 77)
+    assert np.abs(R).max() < 1e-3                      # first and second derivatives of a constant
+
+
+def test_polyexp_linear_ramp_gives_unit_gradient():
+    img = np.tile(np.arange(60, dtype=np.uint8)[None] * 2, (60, 1))   # I = 2x
+    _, R = fo.farneback_level_polyexp(img, 0)
+    c = R[20:40, 20:40]
+    np.testing.assert_allclose(c[..., 1], 2.0, atol=1e-3)   # r_x
+    np.testing.assert_allclose(c[..., 0], 0.0, atol=1e-3)   # r_y
+    assert np.abs(c[..., 2:]).max() < 1e-3
+
+
+def test_advect_frames_pipeline_shapes_and_known_motion():
+    raw, vel = advected_counts(batch=1, t=5, channels=1, h=64, w=64, seed=9, vmax=1.5)
+    mean, std = np.array([93.23458], np.float32), np.array([115.34247], np.float32)
+    out = fo.advect_frames(raw, mean, std, n_future=2)
+    assert out.shape == (1, 1, 7, 64, 64) and np.isfinite(out).all()
+    # the advected frame t0+1 should look like the texture moved one more step: compare with persistence
+    nxt = blob_texture_sequence(np.random.default_rng(9), 1, 64, 64, (0, 0))  # only a smoke check on statistics
+    assert out[0, 0, 5, 16:-16, 16:-16].std() > 0.1 and nxt.shape == (1, 64, 64)

@@ -1,0 +1,201 @@
+"""CPU: host logic around the hot path -- config composition, _target_ instantiation (own tree AND the reference's
+yaml tree through the alias table), load_config, model construction / attribute arithmetic / state_dict names,
+the Trainer shim's loops, callbacks and loggers, the fake datamodule.  No kernels run here."""
+import os
+
+import pytest
+import torch
+from torch import nn
+
+from predict_pv_yield_amd import hydra_lite as H
+from predict_pv_yield_amd import lightning as pl
+from predict_pv_yield_amd.data.batch import BatchML
+from predict_pv_yield_amd.data.dataloader import NetCDFDataModule
+from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+from predict_pv_yield_amd.utils import extras, load_config, print_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CONFIGS = "/root/reference/configs"
+
+
+def test_compose_defaults_and_experiment_overlay():
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config", ["experiment=example_simple", "trainer.fast_dev_run=true",
+                                                               "trainer.gpus=0", "+extra.key=3"])
+    assert cfg.model._target_.endswith("baseline.last_value.Model")       # `override /model: baseline.yaml`
+    assert cfg.trainer.fast_dev_run is True and cfg.trainer.gpus == 0
+    assert cfg.validate_only == "1" and cfg.seed == 518 and cfg.extra.key == 3
+    assert cfg.datamodule.n_train_data == 2                                 # experiment body merged over the group
+    assert cfg.work_dir == os.getcwd() and cfg.data_dir == os.getcwd() + "/data/"
+    assert "${" not in cfg.hydra.run.dir and cfg.hydra.run.dir.startswith("logs/runs/")
+    cfg2 = H.compose(os.path.join(ROOT, "configs"), "config", ["model=conv3d_optical_flow", "~print_config"])
+    assert cfg2.model.future_frames == "optical_flow" and "print_config" not in cfg2
+
+
+def test_command_line_group_choice_beats_experiment():
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config", ["experiment=example_simple", "model=conv3d"])
+    assert cfg.model._target_.endswith("conv3d.model.Model")
+
+
+def test_oc_env_and_missing_env(monkeypatch, tmp_path):
+    (tmp_path / "config.yaml").write_text("a: ${oc.env:PV_TEST_VAR}\nb: ${oc.env:PV_MISSING,fallback}\nc: ${a}/x\n")
+    monkeypatch.setenv("PV_TEST_VAR", "hello")
+    cfg = H.compose(str(tmp_path), "config")
+    assert cfg.a == "hello" and cfg.b == "fallback" and cfg.c == "hello/x"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present (GPU box)")
+def test_reference_config_tree_drives_this_package():
+    """The reference's own yaml files compose and instantiate: `_target_` paths resolve through the alias table."""
+    cfg = H.compose(REF_CONFIGS, "config", ["logger=csv", "experiment=conv3d", "datamodule.fake_data=true",
+                                            "datamodule.data_path=tests/configs/dataset", "trainer.fast_dev_run=true",
+                                            "model.fc1_output_features=4"])
+    assert cfg.model._target_ == "predict_pv_yield.models.conv3d.model.Model" and cfg.seed == 518
+    model = H.instantiate(cfg.model)
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    assert isinstance(model, Model) and model.number_of_conv3d_layers == 6
+    callbacks = [H.instantiate(c) for c in cfg.callbacks.values()]
+    trainer = H.instantiate(cfg.trainer, callbacks=callbacks, logger=[H.instantiate(cfg.logger.csv)], _convert_="partial")
+    assert isinstance(trainer, pl.Trainer) and trainer.fast_dev_run
+    assert trainer.checkpoint_callback.monitor == "MSE/Validation_epoch"
+    dm = H.instantiate(cfg.datamodule)
+    assert isinstance(dm, NetCDFDataModule)
+
+
+def test_load_config_strips_target_and_builds_models():
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    cfg = load_config("tests/configs/model/conv3d.yaml")
+    assert "_target_" not in cfg
+    m = Model(**cfg)
+    assert m.forecast_len_5 == 12 and m.history_len_5 == 12 and m.forecast_len == 12
+    assert m.cnn_output_size == 32 * 8 * 8 * 17
+    assert list(m.state_dict())[:4] == ["sat_conv0.weight", "sat_conv0.bias", "conv3d_1.weight", "conv3d_1.bias"]
+    assert [k for k in m.state_dict() if k.startswith("fc")] == ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                                                                  "fc3.weight", "fc3.bias", "fc4.weight", "fc4.bias"]
+    prod = load_config("configs/model/conv3d.yaml")
+    prod["fc1_output_features"] = 2
+    m2 = Model(**prod)
+    assert m2.cnn_output_size == 1003520 and m2.forecast_len == 6      # T = 18: 12 observed + 6 forecast frames
+
+
+def test_model_defaults_match_reference_signature():
+    import inspect
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    sig = inspect.signature(Model.__init__)
+    ref_defaults = dict(include_pv_yield=True, include_nwp=True, forecast_minutes=30, history_minutes=60,
+                        number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=64, number_sat_channels=12,
+                        fc1_output_features=128, fc2_output_features=128, fc3_output_features=64,
+                        output_variable="pv_yield")   # predict_pv_yield/models/conv3d/model.py:18-32
+    for k, v in ref_defaults.items():
+        assert sig.parameters[k].default == v, k
+    assert list(sig.parameters)[1:13] == list(ref_defaults)
+
+
+def test_extras_and_print_config(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config", ["debug=true", "datamodule.num_workers=4",
+                                                               "datamodule.pin_memory=true"])
+    extras(cfg)
+    assert cfg.trainer.fast_dev_run is True and cfg.trainer.gpus == 0
+    assert cfg.datamodule.num_workers == 0 and cfg.datamodule.pin_memory is False
+    print_config(cfg, resolve=True)
+    assert os.path.exists("config_tree.txt")
+
+
+class _Toy(pl.LightningModule):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(4, 1)
+        self.val_calls = 0
+
+    def forward(self, x):
+        return self.lin(x["x"]).squeeze(-1)
+
+    def training_step(self, batch, batch_idx):
+        loss = ((self(batch) - batch["y"]) ** 2).mean()
+        self.log_dict({"MSE/Train": loss}, on_step=True, on_epoch=True, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        self.val_calls += 1
+        loss = ((self(batch) - batch["y"]) ** 2).mean()
+        self.log_dict({"MSE/Validation": loss}, on_step=True, on_epoch=True, sync_dist=True)
+        return loss
+
+    def test_step(self, batch, batch_idx):
+        self.log_dict({"MSE/Test": ((self(batch) - batch["y"]) ** 2).mean()}, on_step=True, on_epoch=True)
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=0.05)
+
+
+def _toy_loader(n=8):
+    g = torch.Generator().manual_seed(0)
+    w = torch.tensor([1.0, -2.0, 0.5, 3.0])
+    items = []
+    for _ in range(n):
+        x = torch.randn(16, 4, generator=g)
+        items.append({"x": x, "y": x @ w})
+    return torch.utils.data.DataLoader(items, batch_size=None)
+
+
+def test_trainer_fit_validate_checkpoint_earlystop(tmp_path):
+    model = _Toy()
+    ckpt = pl.ModelCheckpoint(monitor="MSE/Validation_epoch", save_top_k=1, save_last=True, dirpath=str(tmp_path / "ck"))
+    stop = pl.EarlyStopping(monitor="MSE/Validation_epoch", patience=2)
+    logger = pl.CSVLogger(save_dir=str(tmp_path), name="csv/")
+    tr = pl.Trainer(gpus=0, max_epochs=6, callbacks=[ckpt, stop], logger=[logger], profiler="simple")
+    tr.fit(model, _toy_loader(), _toy_loader(3))
+    assert tr.callback_metrics["MSE/Validation_epoch"] < 8.0   # started near 14; 6 epochs of Adam(0.05)
+    assert "MSE/Train_epoch" in tr.callback_metrics and "MSE/Train_step" in tr.callback_metrics
+    assert os.path.exists(ckpt.best_model_path) and os.path.exists(ckpt.last_model_path)
+    assert os.path.exists(os.path.join(logger.log_dir, "metrics.csv"))
+    state = torch.load(ckpt.last_model_path)
+    assert set(state["state_dict"]) == {"lin.weight", "lin.bias"}
+    # resume
+    model2 = _Toy()
+    tr2 = pl.Trainer(gpus=0, max_epochs=7, resume_from_checkpoint=ckpt.last_model_path)
+    tr2.fit(model2, _toy_loader(), _toy_loader(3))
+    assert tr2.current_epoch == 7
+    out = tr2.test(model2, _toy_loader(2))
+    assert "MSE/Test_epoch" in out[0]
+    preds = tr2.predict(model2, _toy_loader(2))
+    assert len(preds) == 2 and preds[0].shape == (16,)
+
+
+def test_fast_dev_run_runs_one_batch():
+    model = _Toy()
+    tr = pl.Trainer(gpus=0, fast_dev_run=True)
+    tr.fit(model, _toy_loader(5), _toy_loader(5))
+    assert tr.global_step == 1 and model.val_calls == 1
+
+
+def test_log_dict_outside_trainer_is_tolerated():
+    m = _Toy()
+    m.log_dict({"a": torch.tensor(1.0)})     # tests/models/baseline/test_baseline_model_gsp.py:41-58 calls steps directly
+    assert m.current_epoch == 0 and m.logger is None
+
+
+def test_fake_dataset_and_datamodule_contract():
+    cfg = FakeDataConfiguration(batch_size=2, history_minutes=60, forecast_minutes=60, satellite_image_size_pixels=16)
+    ds = FakeDataset(cfg, length=2)
+    x = next(iter(torch.utils.data.DataLoader(ds, batch_size=None)))
+    b = BatchML(**x)
+    assert b.satellite.data.shape == (2, 11, 25, 16, 16)
+    assert b.pv.pv_yield.shape == (2, 25, 128) and b.gsp.gsp_yield.shape == (2, 5, 32)
+    assert b["pv_yield"] is b.pv.pv_yield and b["nwp"] is b.nwp.data
+    assert torch.equal(FakeDataset(cfg, 2)[1]["satellite"]["data"], ds[1]["satellite"]["data"])   # reproducible
+    dm = NetCDFDataModule(fake_data=True, data_path=os.path.join(ROOT, "tests/configs/dataset"), n_train_data=3, n_val_data=2)
+    assert dm.configuration.satellite_image_size_pixels == 16 and dm.configuration.batch_size == 4
+    assert len(list(dm.train_dataloader())) == 3 and len(list(dm.val_dataloader())) == 2
+    with pytest.raises(NotImplementedError):
+        NetCDFDataModule(fake_data=False)
+
+
+def test_baseline_model_forward_is_persistence():
+    from predict_pv_yield_amd.models.baseline.last_value import Model
+    m = Model(forecast_minutes=120, history_minutes=30, output_variable="gsp_yield")
+    cfg = FakeDataConfiguration(batch_size=3, history_minutes=30, forecast_minutes=120)
+    b = FakeDataset(cfg, 1)[0]
+    y = m(b)
+    assert y.shape == (3, m.forecast_len_30) == (3, 4)
+    assert torch.equal(y[:, 0], b["gsp"]["gsp_yield"][:, -5, 0]) and torch.equal(y[:, 0], y[:, 3])
