@@ -50,15 +50,17 @@ struct SliceGeom {
   __device__ static __forceinline__ int swz(int v) { return (v / VPR) % NCH; }
 };
 
-template <int CPAD>
+template <int CPAD, bool HAS_GATE, bool Y_NCDHW>
 __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate, const uint16_t* __restrict__ wp,
     const float* __restrict__ bias, uint16_t* __restrict__ y, int t_in, int h_in, int w_in, int t_out,
-    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int y_ncdhw, int n_colblk,
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk,
     int t_chunk, int c_out) {
   using G = SliceGeom<CPAD>;
   constexpr int KS = CPAD / 16;
+  // ring of 3 slices | 256 B of zeros (tap reads of masked columns run 2 voxels past a slot) | 32 bias floats
   __shared__ __attribute__((aligned(256))) unsigned char lds[3 * G::SLOT_BYTES + 512];
+  float* lds_bias = reinterpret_cast<float*>(lds + 3 * G::SLOT_BYTES + 256);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   const int tc1 = min(tc0 + t_chunk, t_out);
   if (tc0 >= tc1) return;
 
-  // zero the slack behind the ring (tap reads of masked columns may run 2 voxels past a slot)
-  if (tid < 128) reinterpret_cast<uint32_t*>(lds + 3 * G::SLOT_BYTES)[tid] = 0u;
+  if (tid < 64) reinterpret_cast<uint32_t*>(lds + 3 * G::SLOT_BYTES)[tid] = 0u;
+  if (tid < 32) lds_bias[tid] = (bias && tid < c_out) ? bias[tid] : 0.f;
 
   // ---- weights: A fragments, resident in registers ------------------------------------------
   bf16x8 wfrag[27][KS];
@@ -96,59 +98,52 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     for (int ks = 0; ks < KS; ++ks) voff[kw][ks] = v * G::VOX_BYTES + (((ks * 2 + hh) ^ G::swz(v)) << 4);
   }
 
-  // ---- staging: which 16-byte chunks this thread moves --------------------------------------
-  const size_t x_plane = (size_t)h_in * w_in * CPAD;  // elements per (b, t) slice
+  // ---- staging geometry: chunk id = i*256 + tid; one i covers RPI rows, so the row (and the whole
+  // validity test except the column) is wave-uniform and the loads need NO branch: out-of-range taps are
+  // loaded from a clamped address and zeroed by a select, so all NLOAD loads issue back to back. ---------
+  constexpr int CPR = TW * G::NCH;   // chunks per tile row: 256 (CPAD 32) / 128 (CPAD 16)
+  constexpr int RPI = 256 / CPR;     // tile rows per i: 1 / 2
+  const int srow0 = RPI == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid / CPR);  // wave-uniform -> SGPR
+  const int srem = tid - srow0 * CPR;
+  const int scol = srem / G::NCH, sc = srem - scol * G::NCH;
+  const int swi = w0 - pad_w + scol;
+  const bool scol_ok = (unsigned)swi < (unsigned)w_in;
+  const int lane_off = min(max(swi, 0), w_in - 1) * CPAD + sc * 8;              // elements inside an image row
+  const int lds_lane = scol * G::VOX_BYTES + ((sc ^ G::swz(scol)) << 4);        // swz depends on the column only
+  const size_t x_plane = (size_t)h_in * w_in * CPAD;                             // elements per (b, t) slice
+  const size_t x_row = (size_t)w_in * CPAD;
   const uint16_t* xb = x + (size_t)b * t_in * x_plane;
-  const uint16_t* gb = gate ? gate + (size_t)b * t_in * x_plane : nullptr;
+  const uint16_t* gb = HAS_GATE ? gate + (size_t)b * t_in * x_plane : nullptr;
+  const uint32_t lane_byte = (uint32_t)lane_off * 2u;   // the only per-lane part of a staging address
 
   u32x4 stage[G::NLOAD];
   auto load_slice = [&](int s) {
     // slice index s = input time + pad_t  (s in [tc0, tc1 + 2))
     const int ti = s - pad_t;
     const bool t_ok = (unsigned)ti < (unsigned)t_in;
+    const size_t toff = (size_t)min(max(ti, 0), t_in - 1) * x_plane;
 #pragma unroll
     for (int i = 0; i < G::NLOAD; ++i) {
-      const int id = i * 256 + tid;
-      const int row = id / (TW * G::NCH);
-      const int rem = id - row * (TW * G::NCH);
-      const int col = rem / G::NCH;
-      const int c = rem - col * G::NCH;
-      const int hi = h0 - pad_h + row;
-      const int wi = w0 - pad_w + col;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t_ok && (unsigned)hi < (unsigned)h_in && (unsigned)wi < (unsigned)w_in) {
-        const size_t off = (size_t)ti * x_plane + ((size_t)hi * w_in + wi) * CPAD + c * 8;
-        v = *reinterpret_cast<const u32x4*>(xb + off);
-        if (gb) {
-          u32x4 g = *reinterpret_cast<const u32x4*>(gb + off);
-          v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
-          v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
-        }
+      const int hi = h0 - pad_h + i * RPI + srow0;
+      const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;               // scalar
+      const bool ok = row_ok && scol_ok;
+      const size_t roff = toff + (size_t)min(max(hi, 0), h_in - 1) * x_row;      // scalar (elements)
+      // scalar base + 32-bit lane offset: global_load_dwordx4 v, v_off, s[base:base+1]
+      u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xb + roff) + lane_byte);
+      if constexpr (HAS_GATE) {
+        u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gb + roff) + lane_byte);
+        v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
+        v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
       }
-      stage[i] = v;
+      const u32x4 zero = {0u, 0u, 0u, 0u};
+      stage[i] = ok ? v : zero;
     }
   };
   auto store_slice = [&](int s) {
-    unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
+    unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES + srow0 * G::ROW_BYTES + lds_lane;
 #pragma unroll
-    for (int i = 0; i < G::NLOAD; ++i) {
-      const int id = i * 256 + tid;
-      const int row = id / (TW * G::NCH);
-      const int rem = id - row * (TW * G::NCH);
-      const int col = rem / G::NCH;
-      const int c = rem - col * G::NCH;
-      const int v = row * TW + col;
-      *reinterpret_cast<u32x4*>(slot + v * G::VOX_BYTES + ((c ^ G::swz(v)) << 4)) = stage[i];
-    }
+    for (int i = 0; i < G::NLOAD; ++i) *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = stage[i];
   };
-
-  // ---- bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh ---------
-  f32x16 acc0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int co = (j & 3) + 8 * (j >> 2) + 4 * hh;
-    acc0[j] = (bias && co < c_out) ? bias[co] : 0.f;
-  }
 
   // ---- prologue: two slices into the ring, third in flight ------------------------------------
   load_slice(tc0);
@@ -158,11 +153,33 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   load_slice(tc0 + 2);
 
   const int plane_out = h_out * w_out;
+  // per-lane, t-independent store offsets (bytes) and validity of the 4 output rows of this wave
+  uint32_t st_off[4];
+  bool st_ok[4];
+  {
+    const int col_t = 32 * ws + r;  // column inside the tile
+    const int wo = w0 + col_t;
+    const bool col_ok = col_t < TW_VALID && wo < w_out;
+#pragma unroll
+    for (int orow = 0; orow < 4; ++orow) {
+      const int ho = h0 + 4 * wr + orow;
+      st_ok[orow] = col_ok && ho < h_out;
+      const uint32_t vox = (uint32_t)(ho * w_out + wo);
+      if constexpr (!Y_NCDHW) st_off[orow] = (vox * 32u + 4u * hh) * 2u;
+      else st_off[orow] = (vox + (uint32_t)(4 * hh) * (uint32_t)(t_out * plane_out)) * 2u;
+    }
+  }
   for (int t = tc0; t < tc1; ++t) {
     store_slice(t + 2);
     __syncthreads();
     if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
 
+    f32x16 acc0;  // bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(lds_bias + 8 * q + 4 * hh);
+      acc0[4 * q] = bq[0]; acc0[4 * q + 1] = bq[1]; acc0[4 * q + 2] = bq[2]; acc0[4 * q + 3] = bq[3];
+    }
     f32x16 acc[4] = {acc0, acc0, acc0, acc0};
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
@@ -189,36 +206,32 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       }
     }
 
-    // ---- epilogue: ReLU, bf16, store ---------------------------------------------------------
-    const int col_t = 32 * ws + r;  // column inside the tile
-    const int wo = w0 + col_t;
-    const bool col_ok = col_t < TW_VALID && wo < w_out;
+    // ---- epilogue: ReLU, bf16, store.  Addresses = scalar base of this (b, t) + a 32-bit per-lane offset
+    // that does not depend on t, so nothing but 4 offsets stays live across the march. -----------------
 #pragma unroll
     for (int orow = 0; orow < 4; ++orow) {
-      const int ho = h0 + 4 * wr + orow;
-      if (col_ok && ho < h_out) {
+      if (st_ok[orow]) {
         f32x16 a = acc[orow];
         if (relu) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;
         }
-        if (!y_ncdhw) {
-          uint16_t* yp = y + ((((size_t)b * t_out + t) * h_out + ho) * w_out + wo) * 32 + 4 * hh;
+        if constexpr (!Y_NCDHW) {
+          unsigned char* yt = reinterpret_cast<unsigned char*>(y + ((size_t)b * t_out + t) * plane_out * 32);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             u32x2 o;
             o[0] = (uint32_t)f32_to_bf16_bits(a[4 * q]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 1]) << 16);
             o[1] = (uint32_t)f32_to_bf16_bits(a[4 * q + 2]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 3]) << 16);
-            *reinterpret_cast<u32x2*>(yp + 8 * q) = o;
+            *reinterpret_cast<u32x2*>(yt + st_off[orow] + 16 * q) = o;
           }
         } else {
-          const size_t vox = (size_t)t * plane_out + (size_t)ho * w_out + wo;
-          const size_t cstride = (size_t)t_out * plane_out;
-          uint16_t* yp = y + (size_t)b * c_out * cstride + vox;
+          const size_t cstride = (size_t)t_out * plane_out;  // elements between channels
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            const int co = (j & 3) + 8 * (j >> 2) + 4 * hh;
-            if (co < c_out) yp[(size_t)co * cstride] = f32_to_bf16_bits(a[j]);
+            const int cj = (j & 3) + 8 * (j >> 2);           // + 4*hh folded into st_off
+            unsigned char* yc = reinterpret_cast<unsigned char*>(y + ((size_t)b * c_out + cj) * cstride + (size_t)t * plane_out);
+            if (cj + 4 * hh < c_out) *reinterpret_cast<uint16_t*>(yc + st_off[orow]) = f32_to_bf16_bits(a[j]);
           }
         }
       }
@@ -429,15 +442,18 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
+#define PV_LAUNCH_CONV(CP, HG, YN)                                                                               \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN>), grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in,    \
+                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk,      \
+                     d->c_out)
+#define PV_LAUNCH_CONV2(CP, HG) do { if (y_ncdhw) PV_LAUNCH_CONV(CP, HG, true); else PV_LAUNCH_CONV(CP, HG, false); } while (0)
   if (cpad == 16) {
-    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<16>, grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in, d->h_in,
-                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, y_ncdhw ? 1 : 0, n_colblk,
-                       t_chunk, d->c_out);
+    if (gate) PV_LAUNCH_CONV2(16, true); else PV_LAUNCH_CONV2(16, false);
   } else {
-    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<32>, grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in, d->h_in,
-                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, y_ncdhw ? 1 : 0, n_colblk,
-                       t_chunk, d->c_out);
+    if (gate) PV_LAUNCH_CONV2(32, true); else PV_LAUNCH_CONV2(32, false);
   }
+#undef PV_LAUNCH_CONV2
+#undef PV_LAUNCH_CONV
   return check_launch("pv_conv3d_fwd_bf16");
 }
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t wg_gate_word(uint32_t x, uint32_t g) {
   return x & (lo | hi);
 }
 
-template <int CPAD>
+template <int CPAD, bool HAS_GATE>
 __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint16_t* __restrict__ ymask,
     float* __restrict__ slabs, int t_in, int h_in, int w_in, int t_out, int h_out, int w_out, int pad_t,
@@ -112,75 +112,68 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     const uint16_t* xb = x + (size_t)b * t_in * x_plane;
     const size_t d_plane = (size_t)h_out * w_out * 32;
     const uint16_t* db = dy + (size_t)b * t_out * d_plane;
-    const uint16_t* mb = ymask ? ymask + (size_t)b * t_out * d_plane : nullptr;
+    const uint16_t* mb = HAS_GATE ? ymask + (size_t)b * t_out * d_plane : nullptr;
+
+    // staging geometry (see conv3d_bf16.hip): rows are wave-uniform, loads are branch-free (clamped address +
+    // select), so the NLOAD loads of a slice issue back to back under the MFMAs of the previous one
+    constexpr int CPR = WTW * NCH;
+    constexpr int RPI = 256 / CPR;
+    const int srow0 = RPI == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid / CPR);
+    const int srem = tid - srow0 * CPR;
+    const int scol = srem / NCH, sc = srem - scol * NCH;
+    const int swi = w0 - pad_w + scol;
+    const bool scol_ok = (unsigned)swi < (unsigned)w_in;
+    const uint32_t x_lane_byte = (uint32_t)(min(max(swi, 0), w_in - 1) * CPAD + sc * 8) * 2u;
+    const int x_lds_lane = scol * VOXB + ((sc ^ ((scol / VPR) % NCH)) << 4);
+    const size_t x_row = (size_t)w_in * CPAD;
+    // dY tile: 256 chunks per row, one row per i
+    const int dcol = tid >> 2, dc = tid & 3;
+    const int dwo = w0 + dcol;
+    const bool dcol_ok = dcol < WTW_VALID && dwo < w_out;
+    const uint32_t d_lane_byte = (uint32_t)(min(dwo, w_out - 1) * 32 + dc * 8) * 2u;
+    const int d_lds_lane = dcol * 64 + ((dc ^ ((dcol >> 2) & 3)) << 4);
+    const size_t d_row = (size_t)w_out * 32;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
     u32x4 stage_x[NLOAD_X];
     u32x4 stage_d[NLOAD_D];
     auto load_x = [&](int s) {
       const int ti = s - pad_t;
       const bool t_ok = (unsigned)ti < (unsigned)t_in;
+      const size_t toff = (size_t)min(max(ti, 0), t_in - 1) * x_plane;
 #pragma unroll
       for (int i = 0; i < NLOAD_X; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id / (WTW * NCH);
-        const int rem = id - row * (WTW * NCH);
-        const int col = rem / NCH;
-        const int c = rem - col * NCH;
-        const int hi = h0 - pad_h + row;
-        const int wi = w0 - pad_w + col;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (t_ok && (unsigned)hi < (unsigned)h_in && (unsigned)wi < (unsigned)w_in)
-          v = *reinterpret_cast<const u32x4*>(xb + (size_t)ti * x_plane + ((size_t)hi * w_in + wi) * CPAD + c * 8);
-        stage_x[i] = v;
+        const int hi = h0 - pad_h + i * RPI + srow0;
+        const bool ok = t_ok && (unsigned)hi < (unsigned)h_in && scol_ok;
+        const size_t roff = toff + (size_t)min(max(hi, 0), h_in - 1) * x_row;
+        u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xb + roff) + x_lane_byte);
+        stage_x[i] = ok ? v : zero4;
       }
     };
     auto store_x = [&](int s) {
-      unsigned char* slot = lds + (s % 3) * SLOTB;
+      unsigned char* slot = lds + (s % 3) * SLOTB + srow0 * ROWB + x_lds_lane;
 #pragma unroll
-      for (int i = 0; i < NLOAD_X; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id / (WTW * NCH);
-        const int rem = id - row * (WTW * NCH);
-        const int col = rem / NCH;
-        const int c = rem - col * NCH;
-        const int v = row * WTW + col;
-        *reinterpret_cast<u32x4*>(slot + v * VOXB + ((c ^ ((v / VPR) % NCH)) << 4)) = stage_x[i];
-      }
+      for (int i = 0; i < NLOAD_X; ++i) *reinterpret_cast<u32x4*>(slot + i * RPI * ROWB) = stage_x[i];
     };
     auto load_d = [&](int t) {
+      const size_t toff = (size_t)t * d_plane;
 #pragma unroll
       for (int i = 0; i < NLOAD_D; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id / (WTW * 4);
-        const int rem = id - row * (WTW * 4);
-        const int col = rem / 4;
-        const int c = rem - col * 4;
-        const int ho = h0 + row;
-        const int wo = w0 + col;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ho < h_out && col < WTW_VALID && wo < w_out) {
-          const size_t off = (size_t)t * d_plane + ((size_t)ho * w_out + wo) * 32 + c * 8;
-          v = *reinterpret_cast<const u32x4*>(db + off);
-          if (mb) {
-            u32x4 g = *reinterpret_cast<const u32x4*>(mb + off);
-            v[0] = wg_gate_word(v[0], g[0]); v[1] = wg_gate_word(v[1], g[1]);
-            v[2] = wg_gate_word(v[2], g[2]); v[3] = wg_gate_word(v[3], g[3]);
-          }
+        const int ho = h0 + i;
+        const bool ok = ho < h_out && dcol_ok;
+        const size_t roff = toff + (size_t)min(ho, h_out - 1) * d_row;
+        u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(db + roff) + d_lane_byte);
+        if constexpr (HAS_GATE) {
+          u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(mb + roff) + d_lane_byte);
+          v[0] = wg_gate_word(v[0], g[0]); v[1] = wg_gate_word(v[1], g[1]);
+          v[2] = wg_gate_word(v[2], g[2]); v[3] = wg_gate_word(v[3], g[3]);
         }
-        stage_d[i] = v;
+        stage_d[i] = ok ? v : zero4;
       }
     };
     auto store_d = [&]() {
 #pragma unroll
-      for (int i = 0; i < NLOAD_D; ++i) {
-        const int id = i * 256 + tid;
-        const int row = id / (WTW * 4);
-        const int rem = id - row * (WTW * 4);
-        const int col = rem / 4;
-        const int c = rem - col * 4;
-        const int v = row * WTW + col;
-        *reinterpret_cast<u32x4*>(lds_dy + v * 64 + ((c ^ ((v >> 2) & 3)) << 4)) = stage_d[i];
-      }
+      for (int i = 0; i < NLOAD_D; ++i) *reinterpret_cast<u32x4*>(lds_dy + i * DROWB + d_lds_lane) = stage_d[i];
     };
 
     const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f,
@@ -257,19 +250,33 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
   }
 }
 
-// dw[co][ci][tap] = sum over slabs (fixed order); dbias[co] from the ones-tap column 0
+// dw[co][ci][tap] = sum over slabs (fixed order: deterministic); dbias[co] from the ones-tap column 0.
+// block = 64 elements x 4 slab groups (one wave each, coalesced 256-byte reads), LDS combine of the 4 partials
 __global__ __launch_bounds__(256) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
                                                                    float* __restrict__ dw, float* __restrict__ dbias,
                                                                    int c_out, int c_in) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // index into [28][32][32]
-  if (i >= SLAB_ELEMS) return;
-  const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
-  float s = 0.f;
-  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * SLAB_ELEMS + i];
-  if (tap < 27) {
-    if (dw && co < c_out && ci < c_in) dw[((size_t)co * c_in + ci) * 27 + tap] = s;
-  } else if (dbias && ci == 0 && co < c_out) {
-    dbias[co] = s;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;  // index into [28][32][32]; SLAB_ELEMS % 64 == 0
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = grp;
+  for (; k + 12 < n_slabs; k += 16) {
+    s0 += slabs[(size_t)k * SLAB_ELEMS + i];
+    s1 += slabs[(size_t)(k + 4) * SLAB_ELEMS + i];
+    s2 += slabs[(size_t)(k + 8) * SLAB_ELEMS + i];
+    s3 += slabs[(size_t)(k + 12) * SLAB_ELEMS + i];
+  }
+  for (; k < n_slabs; k += 4) s0 += slabs[(size_t)k * SLAB_ELEMS + i];
+  part[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0) {
+    const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    if (tap < 27) {
+      if (dw && co < c_out && ci < c_in) dw[((size_t)co * c_in + ci) * 27 + tap] = s;
+    } else if (dbias && ci == 0 && co < c_out) {
+      dbias[co] = s;
+    }
   }
 }
 
@@ -324,14 +331,16 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)(nrb * ncb), (unsigned)ntc, (unsigned)d->batch);
   const int cpad = pv_bf16_cpad(d->c_in);
+#define PV_LAUNCH_WGRAD(CP, HG)                                                                                   \
+  hipLaunchKernelGGL((conv3d_wgrad_bf16_kernel<CP, HG>), grid, dim3(256), 0, st, x, dy, y_relu_mask, (float*)workspace, \
+                     d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
   if (cpad == 16) {
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<16>, grid, dim3(256), 0, st, x, dy, y_relu_mask, (float*)workspace,
-                       d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
+    if (y_relu_mask) PV_LAUNCH_WGRAD(16, true); else PV_LAUNCH_WGRAD(16, false);
   } else {
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<32>, grid, dim3(256), 0, st, x, dy, y_relu_mask, (float*)workspace,
-                       d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
+    if (y_relu_mask) PV_LAUNCH_WGRAD(32, true); else PV_LAUNCH_WGRAD(32, false);
   }
-  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3((SLAB_ELEMS + 255) / 256), dim3(256), 0, st,
+#undef PV_LAUNCH_WGRAD
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(SLAB_ELEMS / 64), dim3(256), 0, st,
                      (const float*)workspace, n_slabs, dw, dbias, d->c_out, d->c_in);
   return check_launch("pv_conv3d_bwd_weight_bf16");
 }

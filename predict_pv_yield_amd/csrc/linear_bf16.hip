@@ -47,24 +47,43 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const uint16_t* __
 
   const bf16x8 zero8 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f,
                         (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  // full 64-deep k-blocks: unconditional loads (4 x 16 B of W and MT x 4 x 16 B of x per lane in flight)
+  long long kb_full = kb1;
+  if (kb_full * 64 > k) kb_full = k / 64;
+  if (kb_full < kb0) kb_full = kb0;
 #pragma unroll 2
-  for (long long kb = kb0; kb < kb1; ++kb) {
+  for (long long kb = kb0; kb < kb_full; ++kb) {
     const long long kbase = kb * 64;
     bf16x8 wv[4];
     bf16x8 xv[MT][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bool ok = kbase + 32 * hh + 8 * s + 8 <= k;
-      wv[s] = ok ? *reinterpret_cast<const bf16x8*>(wp + kbase + 8 * s) : zero8;
+      wv[s] = *reinterpret_cast<const bf16x8*>(wp + kbase + 8 * s);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        xv[mt][s] = ok ? *reinterpret_cast<const bf16x8*>(xp[mt] + kbase + 8 * s) : zero8;
+      for (int mt = 0; mt < MT; ++mt) xv[mt][s] = *reinterpret_cast<const bf16x8*>(xp[mt] + kbase + 8 * s);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv[mt][s], wv[s], acc[mt], 0, 0, 0);
+  }
+  // ragged tail block (k % 64 != 0): clamped address + select, never a branch around a load
+  for (long long kb = kb_full; kb < kb1; ++kb) {
+    const long long kbase = kb * 64;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long long kk = kbase + 32 * hh + 8 * s;
+      const bool ok = kk + 8 <= k;
+      const long long kc = ok ? kbase + 8 * s : 0;
+      bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + kc);
+      wv = ok ? wv : zero8;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 xv = *reinterpret_cast<const bf16x8*>(xp[mt] + kc);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ok ? xv : zero8, wv, acc[mt], 0, 0, 0);
+      }
+    }
   }
   // C layout: col = lane&31 = output feature, row = sample
   const int col = nt * 32 + r;
@@ -80,16 +99,33 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const uint16_t* __
   }
 }
 
+// y = relu?(bias + sum of split-K slabs), fixed order.  block = 64 outputs x 4 slab groups (one wave each)
 __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __restrict__ partial,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int m, int n, int k_splits, int relu) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m * n) return;
-  float s = 0.f;
-  for (int ks = 0; ks < k_splits; ++ks) s += partial[(size_t)ks * m * n + i];
-  if (bias) s += bias[i % n];
-  if (relu) s = s > 0.f ? s : 0.f;
-  y[i] = s;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const size_t mn = (size_t)m * n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < m * n) {
+    int k = grp;
+    for (; k + 12 < k_splits; k += 16) {
+      s0 += partial[(size_t)k * mn + i];
+      s1 += partial[(size_t)(k + 4) * mn + i];
+      s2 += partial[(size_t)(k + 8) * mn + i];
+      s3 += partial[(size_t)(k + 12) * mn + i];
+    }
+    for (; k < k_splits; k += 4) s0 += partial[(size_t)k * mn + i];
+  }
+  part[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < m * n) {
+    float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (bias) s += bias[i % n];
+    if (relu) s = s > 0.f ? s : 0.f;
+    y[i] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,7 +258,7 @@ __global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __res
 
 static int bf16_fwd_split(long long k, int* kblocks_per_wg) {
   long long total_kb = (k + 63) / 64;
-  long long nwg = total_kb < 512 ? total_kb : 512;
+  long long nwg = total_kb < 256 ? total_kb : 256;  // one workgroup per CU, deep unroll inside
   long long per = (total_kb + nwg - 1) / nwg;
   nwg = (total_kb + per - 1) / per;
   *kblocks_per_wg = (int)per;
@@ -263,7 +299,7 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
     case 3: hipLaunchKernelGGL(linear_fwd_bf16_kernel<3>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
     default: hipLaunchKernelGGL(linear_fwd_bf16_kernel<4>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
   }
-  hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+  hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
                      bias, y, m, n, nwg, relu ? 1 : 0);
   return check_launch("pv_linear_fwd_bf16");
 }

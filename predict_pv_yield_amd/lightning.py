@@ -265,7 +265,7 @@ class Trainer:
         vals = {k: _to_float(v) for k, v in dictionary.items()}
         if sync_dist and self.world_size > 1:
             from .distributed import all_reduce_mean_scalars
-            vals = all_reduce_mean_scalars(vals, device=self.model.device)
+            vals = all_reduce_mean_scalars(vals, device=self.device)
         step_metrics = {}
         for k, v in vals.items():
             if on_step is not False:
@@ -313,7 +313,8 @@ class Trainer:
         model.trainer = self
         if datamodule is not None:
             self.datamodule = datamodule
-        model.to(self._device())
+        self.device = self._device()   # batches go here even when the module has no parameters (baseline model)
+        model.to(self.device)
 
     def _loader(self, which, dataloaders=None):
         if dataloaders is not None:
@@ -342,7 +343,7 @@ class Trainer:
             for i, batch in enumerate(loader):
                 if lim is not None and i >= lim:
                     break
-                outputs.append(self._timed(f"{which}_step", step_fn, _move(batch, model.device), i))
+                outputs.append(self._timed(f"{which}_step", step_fn, _move(batch, self.device), i))
         if epoch_end_fn is not None:
             epoch_end_fn(outputs)
         self._flush_epoch()
@@ -370,6 +371,9 @@ class Trainer:
         if self.world_size > 1:
             from .distributed import broadcast_parameters
             broadcast_parameters(model)
+            for o in self.optimizers:   # summing all-reduce; HipAdam folds the 1/world_size into its update
+                if hasattr(o, "grad_scale"):
+                    o.grad_scale = 1.0 / self.world_size
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
         max_epochs = 1 if self.fast_dev_run else self.max_epochs
@@ -380,7 +384,7 @@ class Trainer:
             for i, batch in enumerate(loader):
                 if lim is not None and i >= lim:
                     break
-                batch = _move(batch, model.device)
+                batch = _move(batch, self.device)
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
@@ -389,7 +393,8 @@ class Trainer:
                 self._timed("backward", loss.backward)
                 if self.world_size > 1:
                     from .distributed import all_reduce_gradients
-                    self._timed("grad_all_reduce", all_reduce_gradients, model)
+                    fold = all(hasattr(o, "grad_scale") for o in self.optimizers)
+                    self._timed("grad_all_reduce", all_reduce_gradients, model, not fold)
                 for o in self.optimizers:
                     self._timed("optimizer_step", o.step)
                 self.global_step += 1
@@ -440,7 +445,7 @@ class Trainer:
             for i, batch in enumerate(loader):
                 if self.fast_dev_run and i >= 1:
                     break
-                outs.append(model.predict_step(_move(batch, model.device), i))
+                outs.append(model.predict_step(_move(batch, self.device), i))
         return outs
 
     def _finish(self):

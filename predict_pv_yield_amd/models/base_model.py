@@ -99,12 +99,17 @@ class BaseModel(LightningModule):
             capacity = gsp.gsp_capacity[:, -self.forecast_len_30 :, 0].cpu().numpy()
             predictions = model_output[:, -self.forecast_len_30 :].detach().float().cpu().numpy() * capacity
             truths = gsp.gsp_yield[:, -self.forecast_len_30 :, 0].cpu().numpy() * capacity
-            t0 = np.asarray(batch.metadata.t0_datetime_utc) if batch.metadata is not None else None
+            t0 = batch.metadata.t0_datetime_utc if batch.metadata is not None else None
+            if isinstance(t0, torch.Tensor):
+                t0 = t0.cpu().numpy()
+            elif t0 is not None:
+                t0 = np.asarray(t0)
+            gsp_ids = gsp.gsp_id[:, 0].cpu().numpy()
             rows = []
             for b in range(predictions.shape[0]):
                 for i in range(self.forecast_len_30):
                     t0_b = np.datetime64(int(t0[b]), "ns") if t0 is not None else np.datetime64("NaT")
-                    rows.append((t0_b, t0_b + np.timedelta64(30 * (i + 1), "m"), int(gsp.gsp_id[b, 0]),
+                    rows.append((t0_b, t0_b + np.timedelta64(30 * (i + 1), "m"), int(gsp_ids[b]),
                                  float(truths[b, i]), float(predictions[b, i])))
             if batch_idx == 0:
                 self.results_dfs = []
