@@ -108,41 +108,49 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   const int scol = srem / G::NCH, sc = srem - scol * G::NCH;
   const int swi = w0 - pad_w + scol;
   const bool scol_ok = (unsigned)swi < (unsigned)w_in;
-  const int lane_off = min(max(swi, 0), w_in - 1) * CPAD + sc * 8;              // elements inside an image row
   const int lds_lane = scol * G::VOX_BYTES + ((sc ^ G::swz(scol)) << 4);        // swz depends on the column only
-  const size_t x_plane = (size_t)h_in * w_in * CPAD;                             // elements per (b, t) slice
-  const size_t x_row = (size_t)w_in * CPAD;
-  const uint16_t* xb = x + (size_t)b * t_in * x_plane;
-  const uint16_t* gb = HAS_GATE ? gate + (size_t)b * t_in * x_plane : nullptr;
-  const uint32_t lane_byte = (uint32_t)lane_off * 2u;   // the only per-lane part of a staging address
+  // Raw buffer loads with hardware range checking: a tap outside the image (padding, halo beyond the edge)
+  // gets an offset >= num_records and comes back as zeros -- no select, no branch, no VALU on the loaded
+  // data, so the NLOAD loads of a slice stay in flight under the MFMAs until store_slice needs them.
+  constexpr uint32_t INVALID = 0x40000000u;                                      // launcher checks sample bytes <= 2^30
+  const uint32_t x_plane_b = (uint32_t)h_in * w_in * CPAD * 2u;                  // bytes per (b, t) slice
+  const uint32_t x_row_b = (uint32_t)w_in * CPAD * 2u;
+  const size_t sample_elems = (size_t)t_in * h_in * w_in * CPAD;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((HAS_GATE ? gate : x) + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
+  const uint32_t lane_voff = scol_ok ? (uint32_t)(swi * CPAD + sc * 8) * 2u : INVALID;
 
   u32x4 stage[G::NLOAD];
+  u32x4 stage_g[HAS_GATE ? G::NLOAD : 1];
   auto load_slice = [&](int s) {
     // slice index s = input time + pad_t  (s in [tc0, tc1 + 2))
     const int ti = s - pad_t;
     const bool t_ok = (unsigned)ti < (unsigned)t_in;
-    const size_t toff = (size_t)min(max(ti, 0), t_in - 1) * x_plane;
+    const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
 #pragma unroll
     for (int i = 0; i < G::NLOAD; ++i) {
       const int hi = h0 - pad_h + i * RPI + srow0;
-      const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;               // scalar
-      const bool ok = row_ok && scol_ok;
-      const size_t roff = toff + (size_t)min(max(hi, 0), h_in - 1) * x_row;      // scalar (elements)
-      // scalar base + 32-bit lane offset: global_load_dwordx4 v, v_off, s[base:base+1]
-      u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xb + roff) + lane_byte);
-      if constexpr (HAS_GATE) {
-        u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(gb + roff) + lane_byte);
-        v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
-        v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
-      }
-      const u32x4 zero = {0u, 0u, 0u, 0u};
-      stage[i] = ok ? v : zero;
+      const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;                 // scalar
+      const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : INVALID);
+      const uint32_t voff = lane_voff + srow;                                    // < 2^32, >= 2^30 if anything is invalid
+      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+      if constexpr (HAS_GATE) stage_g[i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, voff, 0, 0);
     }
   };
   auto store_slice = [&](int s) {
     unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES + srow0 * G::ROW_BYTES + lds_lane;
 #pragma unroll
-    for (int i = 0; i < G::NLOAD; ++i) *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = stage[i];
+    for (int i = 0; i < G::NLOAD; ++i) {
+      u32x4 v = stage[i];
+      if constexpr (HAS_GATE) {  // ReLU gate of dgrad, applied only now (after the loads have landed)
+        const u32x4 g = stage_g[i];
+        v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
+        v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
+      }
+      *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = v;
+    }
   };
 
   // ---- prologue: two slices into the ring, third in flight ------------------------------------
@@ -427,6 +435,8 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_bf16: input smaller than the kernel");
   PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_fwd_bf16: batch too large for grid.z");
   const int cpad = pv_bf16_cpad(d->c_in);
+  PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * cpad * 2 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_fwd_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
   const int n_rowblk = (ho + TR - 1) / TR;
   const int n_colblk = (wo + TW_VALID - 1) / TW_VALID;
   // split the time march only when the (sample, tile) grid alone cannot fill 256 CUs

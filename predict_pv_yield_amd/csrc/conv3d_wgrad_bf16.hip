@@ -108,11 +108,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     const bool b_zero = (CPAD == 16) && (grp & 1);  // columns 16..31 of the B operand do not exist
 
     // ---- staging -----------------------------------------------------------------------------
-    const size_t x_plane = (size_t)h_in * w_in * CPAD;
-    const uint16_t* xb = x + (size_t)b * t_in * x_plane;
-    const size_t d_plane = (size_t)h_out * w_out * 32;
-    const uint16_t* db = dy + (size_t)b * t_out * d_plane;
-    const uint16_t* mb = HAS_GATE ? ymask + (size_t)b * t_out * d_plane : nullptr;
 
     // staging geometry (see conv3d_bf16.hip): rows are wave-uniform, loads are branch-free (clamped address +
     // select), so the NLOAD loads of a slice issue back to back under the MFMAs of the previous one
@@ -123,31 +118,39 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     const int scol = srem / NCH, sc = srem - scol * NCH;
     const int swi = w0 - pad_w + scol;
     const bool scol_ok = (unsigned)swi < (unsigned)w_in;
-    const uint32_t x_lane_byte = (uint32_t)(min(max(swi, 0), w_in - 1) * CPAD + sc * 8) * 2u;
     const int x_lds_lane = scol * VOXB + ((sc ^ ((scol / VPR) % NCH)) << 4);
-    const size_t x_row = (size_t)w_in * CPAD;
     // dY tile: 256 chunks per row, one row per i
     const int dcol = tid >> 2, dc = tid & 3;
     const int dwo = w0 + dcol;
     const bool dcol_ok = dcol < WTW_VALID && dwo < w_out;
-    const uint32_t d_lane_byte = (uint32_t)(min(dwo, w_out - 1) * 32 + dc * 8) * 2u;
     const int d_lds_lane = dcol * 64 + ((dc ^ ((dcol >> 2) & 3)) << 4);
-    const size_t d_row = (size_t)w_out * 32;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // raw buffer loads, hardware zero fill for everything outside the tensor (see conv3d_bf16.hip)
+    constexpr uint32_t INVALID = 0x40000000u;
+    const uint32_t x_plane_b = (uint32_t)h_in * w_in * CPAD * 2u, x_row_b = (uint32_t)w_in * CPAD * 2u;
+    const uint32_t d_plane_b = (uint32_t)h_out * w_out * 64u, d_row_b = (uint32_t)w_out * 64u;
+    const size_t x_sample = (size_t)t_in * h_in * w_in * CPAD, d_sample = (size_t)t_out * h_out * w_out * 32;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * x_sample), 0, (int)(x_sample * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)b * d_sample), 0, (int)(d_sample * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((HAS_GATE ? ymask : dy) + (size_t)b * d_sample), 0, (int)(d_sample * 2), 0x00020000);
+    const uint32_t x_lane_voff = scol_ok ? (uint32_t)(swi * CPAD + sc * 8) * 2u : INVALID;
+    const uint32_t d_lane_voff = dcol_ok ? (uint32_t)(dwo * 32 + dc * 8) * 2u : INVALID;
 
     u32x4 stage_x[NLOAD_X];
     u32x4 stage_d[NLOAD_D];
+    u32x4 stage_m[HAS_GATE ? NLOAD_D : 1];
     auto load_x = [&](int s) {
       const int ti = s - pad_t;
       const bool t_ok = (unsigned)ti < (unsigned)t_in;
-      const size_t toff = (size_t)min(max(ti, 0), t_in - 1) * x_plane;
+      const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
 #pragma unroll
       for (int i = 0; i < NLOAD_X; ++i) {
         const int hi = h0 - pad_h + i * RPI + srow0;
-        const bool ok = t_ok && (unsigned)hi < (unsigned)h_in && scol_ok;
-        const size_t roff = toff + (size_t)min(max(hi, 0), h_in - 1) * x_row;
-        u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(xb + roff) + x_lane_byte);
-        stage_x[i] = ok ? v : zero4;
+        const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;
+        const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : INVALID);
+        stage_x[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_lane_voff + srow, 0, 0);
       }
     };
     auto store_x = [&](int s) {
@@ -156,24 +159,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
       for (int i = 0; i < NLOAD_X; ++i) *reinterpret_cast<u32x4*>(slot + i * RPI * ROWB) = stage_x[i];
     };
     auto load_d = [&](int t) {
-      const size_t toff = (size_t)t * d_plane;
+      const uint32_t toff = (uint32_t)t * d_plane_b;
 #pragma unroll
       for (int i = 0; i < NLOAD_D; ++i) {
         const int ho = h0 + i;
-        const bool ok = ho < h_out && dcol_ok;
-        const size_t roff = toff + (size_t)min(ho, h_out - 1) * d_row;
-        u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(db + roff) + d_lane_byte);
-        if constexpr (HAS_GATE) {
-          u32x4 g = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(mb + roff) + d_lane_byte);
-          v[0] = wg_gate_word(v[0], g[0]); v[1] = wg_gate_word(v[1], g[1]);
-          v[2] = wg_gate_word(v[2], g[2]); v[3] = wg_gate_word(v[3], g[3]);
-        }
-        stage_d[i] = ok ? v : zero4;
+        const bool row_ok = ho < h_out;
+        const uint32_t srow = toff + (uint32_t)min(ho, h_out - 1) * d_row_b + (row_ok ? 0u : INVALID);
+        stage_d[i] = __builtin_amdgcn_raw_buffer_load_b128(drsrc, d_lane_voff + srow, 0, 0);
+        if constexpr (HAS_GATE) stage_m[i] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, d_lane_voff + srow, 0, 0);
       }
     };
     auto store_d = [&]() {
 #pragma unroll
-      for (int i = 0; i < NLOAD_D; ++i) *reinterpret_cast<u32x4*>(lds_dy + i * DROWB + d_lds_lane) = stage_d[i];
+      for (int i = 0; i < NLOAD_D; ++i) {
+        u32x4 v = stage_d[i];
+        if constexpr (HAS_GATE) {
+          const u32x4 g = stage_m[i];
+          v[0] = wg_gate_word(v[0], g[0]); v[1] = wg_gate_word(v[1], g[1]);
+          v[2] = wg_gate_word(v[2], g[2]); v[3] = wg_gate_word(v[3], g[3]);
+        }
+        *reinterpret_cast<u32x4*>(lds_dy + i * DROWB + d_lds_lane) = v;
+      }
     };
 
     const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f,
@@ -328,6 +334,8 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
   PV_REQUIRE(workspace_bytes >= (size_t)n_slabs * SLAB_ELEMS * sizeof(float), PV_ESIZE,
              "pv_conv3d_bwd_weight_bf16: workspace too small");
   PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_bwd_weight_bf16: batch too large for grid.z");
+  PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_bwd_weight_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)(nrb * ncb), (unsigned)ntc, (unsigned)d->batch);
   const int cpad = pv_bf16_cpad(d->c_in);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __res
 
 static int bf16_fwd_split(long long k, int* kblocks_per_wg) {
   long long total_kb = (k + 63) / 64;
-  long long nwg = total_kb < 256 ? total_kb : 256;  // one workgroup per CU, deep unroll inside
+  long long nwg = total_kb < 1024 ? total_kb : 1024;  // 4 workgroups per CU keep ~64 KB of loads in flight per CU
   long long per = (total_kb + nwg - 1) / nwg;
   nwg = (total_kb + per - 1) / per;
   *kblocks_per_wg = (int)per;
