@@ -75,13 +75,13 @@ def measure_conv_roofline(batch, hist_frames, dev):
         d = time_kernel(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, ci, 32, (0, 0, 0), True, False))
         per_kernel.setdefault(name_f, [0.0, 0.0, 0])
         per_kernel[name_f][0] += d; per_kernel[name_f][1] += fl; per_kernel[name_f][2] += 1
-        d = time_kernel(lambda: K.conv3d_bwd_weight_bf16(x, dy, y, ci, 32, (0, 0, 0)))
+        d = time_kernel(lambda: K.conv3d_bwd_weight_bf16(x, dy, None, ci, 32, (0, 0, 0)))  # dy arrives pre-gated
         name_w = f"conv3d_wgrad_bf16_kernel<{cpad}>"
         per_kernel.setdefault(name_w, [0.0, 0.0, 0])
         per_kernel[name_w][0] += d; per_kernel[name_w][1] += fl; per_kernel[name_w][2] += 1
         if li > 0:  # dgrad = the forward kernel on dy (32 channels) with mirrored weights
             wpt = K.conv3d_pack_weight_bf16(w, transpose_flip=True)
-            d = time_kernel(lambda: K.conv3d_fwd_bf16(dy, y, wpt, None, 32, ci, (2, 2, 2), False, False))
+            d = time_kernel(lambda: K.conv3d_fwd_bf16(dy, None, wpt, None, 32, ci, (2, 2, 2), False, False, out_gate=x))
             per_kernel["conv3d_fwd_bf16_kernel<32>"][0] += d
             per_kernel["conv3d_fwd_bf16_kernel<32>"][1] += fl
             per_kernel["conv3d_fwd_bf16_kernel<32>"][2] += 1

@@ -192,11 +192,14 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
 
 /* y = relu?(conv3d(x ⊙ (gate>0 if gate given)) + bias), x/gate/y NDHWC bf16 with CPAD channels.
  * The same kernel computes dgrad when fed dy (with pad 2−p) and transpose_flip weights.
+ * out_gate (may be NULL; NDHWC [B,To,Ho,Wo,32] like y): y is zeroed where out_gate <= 0 -- used by dgrad to
+ * apply the ReLU derivative of the layer that produced this layer's input (out_gate = that input), so the
+ * next backward kernels read an already-gated gradient.
  * y_ncdhw != 0: y is written as [B,32,To,Ho,Wo] bf16 (the flatten order fc1 expects,
  * predict_pv_yield/models/conv3d/model.py:122) instead of NDHWC. */
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp,
-                       const float* bias, uint16_t* y, const pv_conv3d_dims* d,
-                       int relu, int y_ncdhw, void* stream);
+                       const float* bias, uint16_t* y, const uint16_t* out_gate,
+                       const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream);
 
 /* dw[Co,Ci,3,3,3] f32 and dbias[Co] f32 from x (NDHWC bf16) and dy ⊙ (y>0) (NDHWC bf16).
  * workspace: pv_conv3d_bwd_weight_bf16_workspace_bytes(d). Overwrites dw/dbias. */

@@ -50,16 +50,18 @@ struct SliceGeom {
   __device__ static __forceinline__ int swz(int v) { return (v / VPR) % NCH; }
 };
 
-template <int CPAD, bool HAS_GATE, bool Y_NCDHW>
+template <int CPAD, bool HAS_GATE, bool Y_NCDHW, bool OUT_GATE>
 __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate, const uint16_t* __restrict__ wp,
-    const float* __restrict__ bias, uint16_t* __restrict__ y, int t_in, int h_in, int w_in, int t_out,
+    const float* __restrict__ bias, uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
     int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk,
     int t_chunk, int c_out) {
   using G = SliceGeom<CPAD>;
   constexpr int KS = CPAD / 16;
   // ring of 3 slices | 256 B of zeros (tap reads of masked columns run 2 voxels past a slot) | 32 bias floats
-  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * G::SLOT_BYTES + 512];
+  // + (NDHWC epilogue) 8 KB per wave to transpose the accumulators into whole 1-KB output lines
+  constexpr int EPI_BYTES = Y_NCDHW ? 0 : 4 * 8192;
+  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * G::SLOT_BYTES + 512 + EPI_BYTES];
   float* lds_bias = reinterpret_cast<float*>(lds + 3 * G::SLOT_BYTES + 256);
 
   const int tid = threadIdx.x;
@@ -177,6 +179,20 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       else st_off[orow] = (vox + (uint32_t)(4 * hh) * (uint32_t)(t_out * plane_out)) * 2u;
     }
   }
+  // NDHWC write-out geometry: lane -> (voxel 16*half + lane/4, chunk lane%4) of the wave's 32-column segment
+  uint32_t wr_off[4];
+  bool wr_ok[4][2];
+#pragma unroll
+  for (int orow = 0; orow < 4; ++orow) {
+    const int ho = h0 + 4 * wr + orow;
+    const int wo0 = w0 + 32 * ws + (lane >> 2);
+    wr_off[orow] = ((uint32_t)(ho * w_out + wo0) * 32u + 8u * (lane & 3)) * 2u;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int col_t = 32 * ws + 16 * half + (lane >> 2);
+      wr_ok[orow][half] = ho < h_out && col_t < TW_VALID && (w0 + col_t) < w_out;
+    }
+  }
   for (int t = tc0; t < tc1; ++t) {
     store_slice(t + 2);
     __syncthreads();
@@ -218,20 +234,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     // that does not depend on t, so nothing but 4 offsets stays live across the march. -----------------
 #pragma unroll
     for (int orow = 0; orow < 4; ++orow) {
-      if (st_ok[orow]) {
+      if (!Y_NCDHW || st_ok[orow]) {
         f32x16 a = acc[orow];
         if (relu) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;
         }
         if constexpr (!Y_NCDHW) {
-          unsigned char* yt = reinterpret_cast<unsigned char*>(y + ((size_t)b * t_out + t) * plane_out * 32);
+          // stage this 32-voxel x 32-channel tile as [voxel][channel] bf16 (2 KB) in the wave's private LDS area;
+          // 8-byte slots XOR-swizzled by the voxel so the 16 lanes of a write group spread over the banks
+          unsigned char* epi = lds + 3 * G::SLOT_BYTES + 512 + wave * 8192 + orow * 2048;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             u32x2 o;
             o[0] = (uint32_t)f32_to_bf16_bits(a[4 * q]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 1]) << 16);
             o[1] = (uint32_t)f32_to_bf16_bits(a[4 * q + 2]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 3]) << 16);
-            *reinterpret_cast<u32x2*>(yt + st_off[orow] + 16 * q) = o;
+            const int slot = (2 * q + hh) ^ (((r >> 1) & 3) << 1);
+            *reinterpret_cast<u32x2*>(epi + r * 64 + slot * 8) = o;
           }
         } else {
           const size_t cstride = (size_t)t_out * plane_out;  // elements between channels
@@ -240,6 +259,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
             const int cj = (j & 3) + 8 * (j >> 2);           // + 4*hh folded into st_off
             unsigned char* yc = reinterpret_cast<unsigned char*>(y + ((size_t)b * c_out + cj) * cstride + (size_t)t * plane_out);
             if (cj + 4 * hh < c_out) *reinterpret_cast<uint16_t*>(yc + st_off[orow]) = f32_to_bf16_bits(a[j]);
+          }
+        }
+      }
+    }
+    if constexpr (!Y_NCDHW) {
+      // write-out: each lane moves two 16-byte chunks per output row, a wave-instruction covers 1 KB of
+      // contiguous global memory (16 voxels x 64 B) instead of 64 scattered 8-byte pieces
+      unsigned char* yt = reinterpret_cast<unsigned char*>(y + ((size_t)b * t_out + t) * plane_out * 32);
+      const unsigned char* epi_w = lds + 3 * G::SLOT_BYTES + 512 + wave * 8192;
+#pragma unroll
+      for (int orow = 0; orow < 4; ++orow) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int v = 16 * half + (lane >> 2);       // voxel inside the 32-column segment
+          const int c = lane & 3;                      // 16-byte chunk = channels 8c .. 8c+7
+          const int pc = c ^ ((v >> 1) & 3);           // swizzle moves whole 16-byte chunks (even slot XOR)
+          u32x4 val = *reinterpret_cast<const u32x4*>(epi_w + orow * 2048 + v * 64 + pc * 16);
+          if (wr_ok[orow][half]) {
+            if constexpr (OUT_GATE) {  // dgrad: zero the gradient where the consumer's ReLU was inactive
+              const unsigned char* gt = reinterpret_cast<const unsigned char*>(out_gate + ((size_t)b * t_out + t) * plane_out * 32);
+              const u32x4 g = *reinterpret_cast<const u32x4*>(gt + wr_off[orow] + half * 1024);
+              val[0] = gate_word(val[0], g[0]); val[1] = gate_word(val[1], g[1]);
+              val[2] = gate_word(val[2], g[2]); val[3] = gate_word(val[3], g[3]);
+            }
+            *reinterpret_cast<u32x4*>(yt + wr_off[orow] + half * 1024) = val;
           }
         }
       }
@@ -425,7 +469,7 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
 }
 
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp, const float* bias, uint16_t* y,
-                       const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream) {
+                       const uint16_t* out_gate, const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream) {
   PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_bf16: null pointer");
   PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
              "pv_conv3d_fwd_bf16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
@@ -434,6 +478,7 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
   PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_bf16: input smaller than the kernel");
   PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_fwd_bf16: batch too large for grid.z");
+  PV_REQUIRE(!(out_gate && y_ncdhw), PV_EINVAL, "pv_conv3d_fwd_bf16: out_gate needs the NDHWC output layout");
   const int cpad = pv_bf16_cpad(d->c_in);
   PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * cpad * 2 <= 0x40000000ull, PV_ESIZE,
              "pv_conv3d_fwd_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
@@ -452,11 +497,16 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
-#define PV_LAUNCH_CONV(CP, HG, YN)                                                                               \
-  hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN>), grid, dim3(256), 0, st, x, gate, wp, bias, y, d->t_in,    \
-                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk,      \
-                     d->c_out)
-#define PV_LAUNCH_CONV2(CP, HG) do { if (y_ncdhw) PV_LAUNCH_CONV(CP, HG, true); else PV_LAUNCH_CONV(CP, HG, false); } while (0)
+#define PV_LAUNCH_CONV(CP, HG, YN, OG)                                                                           \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN, OG>), grid, dim3(256), 0, st, x, gate, wp, bias, y, out_gate, \
+                     d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk,        \
+                     t_chunk, d->c_out)
+#define PV_LAUNCH_CONV2(CP, HG)                                      \
+  do {                                                               \
+    if (y_ncdhw) PV_LAUNCH_CONV(CP, HG, true, false);                \
+    else if (out_gate) PV_LAUNCH_CONV(CP, HG, false, true);          \
+    else PV_LAUNCH_CONV(CP, HG, false, false);                       \
+  } while (0)
   if (cpad == 16) {
     if (gate) PV_LAUNCH_CONV2(16, true); else PV_LAUNCH_CONV2(16, false);
   } else {

@@ -84,24 +84,26 @@ class Conv3dReLUBF16(torch.autograd.Function):
     """xp [B,T,H,W,CPAD] bf16 -> y bf16 NDHWC [B,To,Ho,Wo,32] (or NCDHW [B,Co,To,Ho,Wo] when y_ncdhw)."""
 
     @staticmethod
-    def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw):
+    def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw, x_is_relu_output, dy_pregated):
         wp = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=False)
         c_out = weight.shape[0]
         y = K.conv3d_fwd_bf16(xp, None, wp, bias.contiguous() if bias is not None else None, c_in, c_out, padding, relu,
                               y_ncdhw)
         ctx.save_for_backward(xp, weight, y if relu else None)
-        ctx.cfg = (c_in, c_out, padding, relu, y_ncdhw, bias is not None)
+        ctx.cfg = (c_in, c_out, padding, relu, y_ncdhw, bias is not None, x_is_relu_output, dy_pregated)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xp, weight, y = ctx.saved_tensors
-        c_in, c_out, padding, relu, y_ncdhw, has_bias = ctx.cfg
+        c_in, c_out, padding, relu, y_ncdhw, has_bias, x_is_relu_output, dy_pregated = ctx.cfg
         dy = dy.contiguous()
         if y_ncdhw:
             # fc1 hands back the gradient in flatten (NCDHW) order: gate + transpose in one pass
             dy = K.repack_gate_ncdhw_to_ndhwc_bf16(dy, y)
             gate = None
+        elif dy_pregated:
+            gate = None   # the consumer's dgrad epilogue already applied this layer's ReLU derivative
         else:
             gate = y
         dw, db = K.conv3d_bwd_weight_bf16(xp, dy, gate, c_in, c_out, padding)
@@ -110,10 +112,13 @@ class Conv3dReLUBF16(torch.autograd.Function):
             # dgrad = the forward kernel on dy with padding 2-p and mirrored, channel-swapped weights
             wpt = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=True)
             pad_b = tuple(2 - p for p in padding)
-            dx = K.conv3d_fwd_bf16(dy, gate, wpt, None, c_out, c_in, pad_b, relu=False, y_ncdhw=False)
+            # x_is_relu_output: x = relu(...) of the producer, so (x > 0) IS its ReLU derivative; applying it in this
+            # kernel's epilogue hands the producer an already-gated gradient (no gate reads in its wgrad/dgrad)
+            out_gate = xp if (x_is_relu_output and xp.shape[-1] == 32) else None
+            dx = K.conv3d_fwd_bf16(dy, gate, wpt, None, c_out, c_in, pad_b, relu=False, y_ncdhw=False, out_gate=out_gate)
             if K.bf16_cpad(c_in) != 32:
                 dx = dx[..., : K.bf16_cpad(c_in)].contiguous()
-        return dx, dw, (db if has_bias else None), None, None, None, None
+        return dx, dw, (db if has_bias else None), None, None, None, None, None, None
 
 
 def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
@@ -148,8 +153,11 @@ class LinearBF16(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), None
 
 
-def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False):
-    return Conv3dReLUBF16.apply(xp, weight, bias, c_in, tuple(padding), relu, y_ncdhw)
+def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False, x_is_relu_output=False,
+                     dy_pregated=False):
+    """x_is_relu_output: xp is the ReLU output of the previous conv3d_relu_bf16 (its dgrad then gates dx itself);
+    dy_pregated: the consumer of this layer's output is such a layer, so the incoming gradient is already gated."""
+    return Conv3dReLUBF16.apply(xp, weight, bias, c_in, tuple(padding), relu, y_ncdhw, x_is_relu_output, dy_pregated)
 
 
 def linear_bf16(x, weight, bias, relu=False):

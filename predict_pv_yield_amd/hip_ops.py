@@ -261,9 +261,10 @@ def conv3d_pack_weight_bf16(weight: torch.Tensor, transpose_flip: bool = False) 
 
 
 def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Tensor, bias: Optional[torch.Tensor],
-                    c_in: int, c_out: int, padding=(0, 0, 0), relu=True, y_ncdhw=False) -> torch.Tensor:
+                    c_in: int, c_out: int, padding=(0, 0, 0), relu=True, y_ncdhw=False,
+                    out_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B,T,H,W,CPAD(c_in)] bf16 -> y [B,To,Ho,Wo,32] bf16 (or [B,c_out,To,Ho,Wo] if y_ncdhw)."""
-    require_cuda(x, gate, wp, bias)
+    require_cuda(x, gate, wp, bias, out_gate)
     b, t, h, w, cpad = x.shape
     if cpad != bf16_cpad(c_in) or x.dtype != torch.bfloat16:
         raise TypeError("conv3d_fwd_bf16: x must be bf16 [B,T,H,W,CPAD(c_in)]")
@@ -271,8 +272,10 @@ def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Ten
     to, ho, wo = d.out_shape()
     shape = (b, c_out, to, ho, wo) if y_ncdhw else (b, to, ho, wo, 32)
     y = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
-    check(get_lib().pv_conv3d_fwd_bf16(ptr(x), ptr(gate), ptr(wp), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
-                                       int(y_ncdhw), current_stream_ptr()), "pv_conv3d_fwd_bf16")
+    if out_gate is not None and tuple(out_gate.shape) != shape:
+        raise TypeError("conv3d_fwd_bf16: out_gate must have the output's NDHWC shape")
+    check(get_lib().pv_conv3d_fwd_bf16(ptr(x), ptr(gate), ptr(wp), ptr(bias), ptr(y), ptr(out_gate), ctypes.byref(d),
+                                       int(relu), int(y_ncdhw), current_stream_ptr()), "pv_conv3d_fwd_bf16")
     return y
 
 

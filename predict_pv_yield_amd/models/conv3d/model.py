@@ -123,7 +123,9 @@ class Model(BaseModel):
             c_in = self.number_sat_channels
             for i, layer in enumerate(convs):
                 last = i == len(convs) - 1
-                out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, (0, 0, 0), relu=True, y_ncdhw=last)
+                # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
+                out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, (0, 0, 0), relu=True, y_ncdhw=last,
+                                          x_is_relu_output=i > 0, dy_pregated=not last)
                 c_in = self.conv3d_channels
             out = out.reshape(batch_size, self.cnn_output_size)  # NCDHW flatten order (model.py:122)
             out = Fn.linear_bf16(out, self.fc1.weight, self.fc1.bias, relu=True)

@@ -122,6 +122,11 @@ def test_conv3d_bf16_backward(device, case):
     dx = K.conv3d_fwd_bf16(gyp, gate, wpt, None, co_, ci, pad_b, relu=False)
     got = dx.float().cpu().permute(0, 4, 1, 2, 3)[:, :ci]
     torch.testing.assert_close(got, xr.grad, rtol=1e-2, atol=2e-3 * max(1.0, xr.grad.abs().max().item()))
+    if ci == 32:
+        # out_gate: the same dgrad, zeroed where the gate tensor (here x itself) is not positive -- bit-identical
+        # to masking the ungated result afterwards
+        dxg = K.conv3d_fwd_bf16(gyp, gate, wpt, None, co_, ci, pad_b, relu=False, out_gate=xp)
+        assert torch.equal(dxg, torch.where(xp > 0, dx, torch.zeros_like(dx)))
     del y
 
 
