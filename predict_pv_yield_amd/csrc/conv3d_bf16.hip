@@ -205,29 +205,37 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       acc0[4 * q] = bq[0]; acc0[4 * q + 1] = bq[1]; acc0[4 * q + 2] = bq[2]; acc0[4 * q + 3] = bq[3];
     }
     f32x16 acc[4] = {acc0, acc0, acc0, acc0};
+    // 18 (kt, kw, ks) groups of 6 operand reads + 12 MFMAs, software-pipelined by one group: the ds_read_b128s of
+    // group g+1 are issued before the MFMAs of group g so their LDS latency hides under 12 x 32 MFMA cycles
+    // (one wave per SIMD: nothing else would cover it).
+    const unsigned char* slot_kt[3];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const unsigned char* slot = lds + ((t + kt) % 3) * G::SLOT_BYTES + (4 * wr) * G::ROW_BYTES;
+    for (int kt = 0; kt < 3; ++kt) slot_kt[kt] = lds + ((t + kt) % 3) * G::SLOT_BYTES + (4 * wr) * G::ROW_BYTES;
+    constexpr int NG = 9 * KS;
+    bf16x8 bfr[2][6];
+    auto read_group = [&](int g, bf16x8* dst) {
+      const int kt = g / (3 * KS), kw = (g / KS) % 3, ks = g % KS;
+      const unsigned char* p = slot_kt[kt] + voff[kw][ks];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
+      for (int ir = 0; ir < 6; ++ir) dst[ir] = *reinterpret_cast<const bf16x8*>(p + ir * G::ROW_BYTES);
+    };
+    read_group(0, bfr[0]);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const unsigned char* p = slot + voff[kw][ks];
-          bf16x8 bfr[6];
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) read_group(g + 1, bfr[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the 6 reads of group g+1 AHEAD of the 12 MFMAs of group g
+      const int kt = g / (3 * KS), kw = (g / KS) % 3, ks = g % KS;
 #pragma unroll
-          for (int ir = 0; ir < 6; ++ir) bfr[ir] = *reinterpret_cast<const bf16x8*>(p + ir * G::ROW_BYTES);
+      for (int ir = 0; ir < 6; ++ir) {
 #pragma unroll
-          for (int ir = 0; ir < 6; ++ir) {
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-              const int orow = ir - kh;
-              if (orow >= 0 && orow < 4)
-                acc[orow] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kt * 9 + kh * 3 + kw][ks], bfr[ir],
-                                                                    acc[orow], 0, 0, 0);
-            }
-          }
+        for (int kh = 0; kh < 3; ++kh) {
+          const int orow = ir - kh;
+          if (orow >= 0 && orow < 4)
+            acc[orow] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfrag[kt * 9 + kh * 3 + kw][ks], bfr[g & 1][ir],
+                                                                acc[orow], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: ReLU, bf16, store.  Addresses = scalar base of this (b, t) + a 32-bit per-lane offset
