@@ -1,0 +1,22 @@
+"""Runs the layer-1 conv forward (and optionally wgrad) kernel a few times: target for rocprofv3 --pmc passes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from predict_pv_yield_amd import hip_ops as K
+which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+dev = torch.device("cuda:0")
+x = torch.randn(b, 16, 62, 62, 32, device=dev).to(torch.bfloat16)
+w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+bias = torch.zeros(32, device=dev)
+wp = K.conv3d_pack_weight_bf16(w)
+y = K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False)
+dy = torch.randn_like(y)
+torch.cuda.synchronize()
+for _ in range(5):
+    if which == "fwd":
+        K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False)
+    elif which == "wgrad":
+        K.conv3d_bwd_weight_bf16(x, dy, None, 32, 32, (0, 0, 0))
+torch.cuda.synchronize()
+print("done")
