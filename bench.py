@@ -157,6 +157,8 @@ def main():
         D.broadcast_parameters(model)
     opt = model.configure_optimizers()
     opt.grad_scale = 1.0 / world
+    if distributed:
+        opt.set_fuse_large_linear(False)  # the gradient all-reduce needs the materialised fc1 gradient
 
     g = torch.Generator(device=dev).manual_seed(518 + rank)
     b = args.batch

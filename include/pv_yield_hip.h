@@ -232,6 +232,14 @@ int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy,
                        const float* y_relu_mask, uint16_t* dx, float* dw, float* db,
                        int32_t m, int32_t n, int64_t k, void* stream);
 
+/* Fused fc1 weight-gradient + Adam: param[N,K] (f32, updated in place), exp_avg, exp_avg_sq and the bf16 shadow are
+ * updated with the gradient (dy ⊙ (y>0))^T · x computed on the fly -- the 0.5 GB gradient is never materialised.
+ * Identical arithmetic to pv_linear_bwd_bf16 (dw) followed by pv_adam_step_f32 (single-GPU: no all-reduce between). */
+int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param,
+                              float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow, int32_t m, int32_t n,
+                              int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
+                              void* stream);
+
 /* dst[i] = bf16(src[i]) (round to nearest even): first fill of a parameter's bf16 shadow; afterwards
  * pv_adam_step_f32 keeps the shadow current. */
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);

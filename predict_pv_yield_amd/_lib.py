@@ -72,6 +72,8 @@ SIGNATURES = {
     "pv_linear_bf16_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_linear_wgrad_adam_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
+                                  c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],
     "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],

@@ -189,10 +189,20 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t*
 }
 
 // dw[n0..n0+7][k..k+7] = sum_m g[m][n] * x[m][k..k+7]
+// FUSE_ADAM: the gradient tile never leaves registers -- the Adam update of the same 8 x 8 weights (and of the bf16
+// shadow) is applied in place: one pass over p, m, v instead of writing 0.5 GB of dw and reading it back.
+struct AdamScalars {
+  float one_minus_b1, beta2, one_minus_b2, bc2_sqrt, eps, neg_step_size;
+};
+
+template <bool FUSE_ADAM>
 __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t* __restrict__ x,
                                                                   const float* __restrict__ dy,
                                                                   const float* __restrict__ ymask,
-                                                                  float* __restrict__ dw, int m, int n, long long k) {
+                                                                  float* __restrict__ dw, int m, int n, long long k,
+                                                                  float* __restrict__ exp_avg,
+                                                                  float* __restrict__ exp_avg_sq,
+                                                                  uint16_t* __restrict__ shadow, AdamScalars ad) {
   extern __shared__ float g[];  // [m][BT]
   const int n0 = blockIdx.y * BT;
   for (int i = threadIdx.x; i < m * BT; i += blockDim.x) {
@@ -213,6 +223,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
   for (int i = 0; i < BT; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
   for (int rr = 0; rr < m; ++rr) {
     u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)rr * k + k8);
     float xv[8];
@@ -233,11 +244,43 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
 #pragma unroll
   for (int i = 0; i < BT; ++i) {
     if (n0 + i < n) {
-      f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-      f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
-      float* dst = dw + (size_t)(n0 + i) * k + k8;
-      *reinterpret_cast<f32x4*>(dst) = o0;
-      *reinterpret_cast<f32x4*>(dst + 4) = o1;
+      const size_t off = (size_t)(n0 + i) * k + k8;
+      if constexpr (!FUSE_ADAM) {
+        f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        *reinterpret_cast<f32x4*>(dw + off) = o0;
+        *reinterpret_cast<f32x4*>(dw + off + 4) = o1;
+      } else {
+        // dw here is the PARAMETER (updated in place); same operation order as adam_step_f32 / torch
+        float pv[8], mv[8], vv[8];
+        *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(dw + off);
+        *reinterpret_cast<f32x4*>(pv + 4) = *reinterpret_cast<const f32x4*>(dw + off + 4);
+        *reinterpret_cast<f32x4*>(mv) = *reinterpret_cast<const f32x4*>(exp_avg + off);
+        *reinterpret_cast<f32x4*>(mv + 4) = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
+        *reinterpret_cast<f32x4*>(vv) = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
+        *reinterpret_cast<f32x4*>(vv + 4) = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+        uint32_t sh[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gr = acc[i][j];
+          const float mm = mv[j] + ad.one_minus_b1 * (gr - mv[j]);
+          const float v2 = vv[j] * ad.beta2 + (ad.one_minus_b2 * gr) * gr;
+          const float denom = sqrtf(v2) / ad.bc2_sqrt + ad.eps;
+          const float pp = pv[j] + ad.neg_step_size * (mm / denom);
+          mv[j] = mm; vv[j] = v2; pv[j] = pp;
+          if (j & 1) sh[j >> 1] |= (uint32_t)f32_to_bf16_bits(pp) << 16; else sh[j >> 1] = f32_to_bf16_bits(pp);
+        }
+        *reinterpret_cast<f32x4*>(dw + off) = *reinterpret_cast<const f32x4*>(pv);
+        *reinterpret_cast<f32x4*>(dw + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
+        *reinterpret_cast<f32x4*>(exp_avg + off) = *reinterpret_cast<const f32x4*>(mv);
+        *reinterpret_cast<f32x4*>(exp_avg + off + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
+        *reinterpret_cast<f32x4*>(exp_avg_sq + off) = *reinterpret_cast<const f32x4*>(vv);
+        *reinterpret_cast<f32x4*>(exp_avg_sq + off + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
+        if (shadow) {
+          u32x4 so = {sh[0], sh[1], sh[2], sh[3]};
+          *reinterpret_cast<u32x4*>(shadow + off) = so;
+        }
+      }
     }
   }
 }
@@ -321,13 +364,31 @@ int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, co
     PV_REQUIRE(x, PV_EINVAL, "pv_linear_bwd_bf16: dw needs x");
     size_t lds = (size_t)m * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: m=%d too large", m);
-    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
-                       y_relu_mask, dw, m, n, (long long)k);
+    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<false>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
+                       y_relu_mask, dw, m, n, (long long)k, (float*)nullptr, (float*)nullptr, (uint16_t*)nullptr,
+                       AdamScalars{});
   }
   if (db) {
     hipLaunchKernelGGL(linear_bwd_db_bf16path, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, y_relu_mask, db, m, n);
   }
   return check_launch("pv_linear_bwd_bf16");
+}
+
+int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                              float* exp_avg_sq, uint16_t* bf16_shadow, int32_t m, int32_t n, int64_t k, double lr,
+                              double beta1, double beta2, double eps, int32_t step, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_adam_bf16: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_adam_bf16: bad sizes (k must be a multiple of 8)");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_adam_bf16: step must be >= 1");
+  size_t lds = (size_t)m * BT * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_wgrad_adam_bf16: m=%d too large", m);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                 (float)(-(lr / bc1))};
+  unsigned kb = (unsigned)((k / 8 + 255) / 256);
+  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<true>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds,
+                     as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, bf16_shadow, ad);
+  return check_launch("pv_linear_wgrad_adam_bf16");
 }
 
 }  // extern "C"

@@ -144,12 +144,20 @@ class LinearBF16(torch.autograd.Function):
         y = K.linear_fwd_bf16(x, wb, bias.contiguous() if bias is not None else None, relu)
         ctx.save_for_backward(x, wb, y if relu else None)
         ctx.has_bias = bias is not None
+        ctx.weight_param = weight
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, wb, y = ctx.saved_tensors
-        dx, dw, db = K.linear_bwd_bf16(x, wb, dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
+        dy = dy.contiguous()
+        weight = ctx.weight_param
+        fuse = getattr(weight, "_pv_fuse_adam", False)
+        dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=not fuse)
+        if fuse:
+            # HipAdam(fuse_large_linear=True) owns this parameter: hand it (x, dy, relu mask); the weight gradient is
+            # formed inside the optimiser's pass over p/m/v and never written to memory
+            weight._pv_pending = (x, dy, y)
         return dx, dw, (db if ctx.has_bias else None), None
 
 

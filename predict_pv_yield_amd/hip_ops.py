@@ -339,12 +339,12 @@ def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
     return y
 
 
-def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True):
+def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True):
     require_cuda(x_bf16, w_bf16, dy, y_mask)
     m, k = x_bf16.shape
     n = w_bf16.shape[0]
     dx = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device) if need_dx else None
-    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device)
+    dw = torch.empty((n, k), dtype=torch.float32, device=dy.device) if need_dw else None
     db = torch.empty(n, dtype=torch.float32, device=dy.device)
     check(get_lib().pv_linear_bwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(dy), ptr(y_mask), ptr(dx), ptr(dw), ptr(db), m, n,
                                        k, current_stream_ptr()), "pv_linear_bwd_bf16")
@@ -372,3 +372,14 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 
     check(get_lib().pv_adam_step_f32(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(bf16_shadow),
                                      param.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
                                      current_stream_ptr()), "pv_adam_step_f32")
+
+
+def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
+                           betas=(0.9, 0.999), eps=1e-8):
+    """fc1: gradient (dy ⊙ (y>0))^T x computed on the fly and applied by Adam in the same pass (no dw tensor)."""
+    require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow)
+    m, k = x_bf16.shape
+    n = param.shape[0]
+    check(get_lib().pv_linear_wgrad_adam_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg),
+                                              ptr(exp_avg_sq), ptr(bf16_shadow), m, n, k, lr, betas[0], betas[1], eps,
+                                              step, current_stream_ptr()), "pv_linear_wgrad_adam_bf16")

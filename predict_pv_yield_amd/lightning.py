@@ -374,6 +374,8 @@ class Trainer:
             for o in self.optimizers:   # summing all-reduce; HipAdam folds the 1/world_size into its update
                 if hasattr(o, "grad_scale"):
                     o.grad_scale = 1.0 / self.world_size
+                if hasattr(o, "set_fuse_large_linear"):
+                    o.set_fuse_large_linear(False)   # the all-reduce needs the materialised fc1 gradient
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
         max_epochs = 1 if self.fast_dev_run else self.max_epochs

@@ -12,11 +12,24 @@ from . import hip_ops as K
 
 
 class HipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    # parameters at least this large whose gradient comes from functional.LinearBF16 are updated by the fused
+    # wgrad+Adam kernel (single process only: a data-parallel run needs the materialised gradient for its all-reduce)
+    FUSE_MIN_NUMEL = 1 << 22
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("HipAdam: invalid hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
+        self.set_fuse_large_linear(fuse_large_linear)
+
+    def set_fuse_large_linear(self, enabled: bool) -> None:
+        self.fuse_large_linear = bool(enabled)
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL:
+                    p._pv_fuse_adam = self.fuse_large_linear
+                    p._pv_pending = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -26,7 +39,8 @@ class HipAdam(torch.optim.Optimizer):
                 loss = closure()
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
+                pending = getattr(p, "_pv_pending", None)
+                if p.grad is None and pending is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
@@ -36,6 +50,13 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
+                if pending is not None and p.grad is None:
+                    from .functional import bf16_shadow_of
+                    x, dy, y = pending
+                    p._pv_pending = None
+                    K.linear_wgrad_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
+                                             int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 K.adam_step(p, g.float(), st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), lr=group["lr"],
                             betas=group["betas"], eps=group["eps"], bf16_shadow=getattr(p, "_pv_bf16_shadow", None),

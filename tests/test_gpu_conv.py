@@ -217,3 +217,24 @@ def test_adam_matches_torch(device):
     torch.testing.assert_close(m.cpu(), st["exp_avg"], rtol=2e-6, atol=1e-12)
     torch.testing.assert_close(v.cpu(), st["exp_avg_sq"], rtol=2e-6, atol=1e-12)
     assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_fused_wgrad_adam_is_bit_identical_to_two_pass(device):
+    """pv_linear_wgrad_adam_bf16 == pv_linear_bwd_bf16(dw) followed by pv_adam_step_f32, bit for bit."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(77)
+    m, n, k = 32, 128, 8192
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(m, n, generator=g).to(device)
+    y = torch.relu(torch.randn(m, n, generator=g)).to(device)
+    p0 = (torch.randn(n, k, generator=g) * 0.01).to(device)
+    wb = p0.to(torch.bfloat16)
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    sa = torch.empty(n, k, dtype=torch.bfloat16, device=device)
+    sb = torch.empty(n, k, dtype=torch.bfloat16, device=device)
+    for step in (1, 2, 3):
+        _, dw, _ = K.linear_bwd_bf16(x, wb, dy, y, need_dx=False)
+        K.adam_step(pa, dw, ma, va, step, lr=5e-4, bf16_shadow=sa)
+        K.linear_wgrad_adam_bf16(x, dy, y, pb, mb, vb, sb, step, lr=5e-4)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb), step

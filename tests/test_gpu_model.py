@@ -164,3 +164,27 @@ def test_model_on_cpu_fails_loudly():
     sat, pv = _data(SMALL, 2)
     with pytest.raises(RuntimeError, match="MI355X"):
         model({"satellite": {"data": sat}, "pv": {"pv_yield": pv}})
+
+
+def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
+    """HipAdam(fuse_large_linear): fc1's gradient is never materialised; the training trajectory is unchanged."""
+    from predict_pv_yield_amd.optim import HipAdam
+    sat, pv = _data(SMALL, 2)
+    _, model_a = _pair(SMALL, "bf16", device)
+    losses_a = _hip_steps(model_a, sat, pv, 3, device)          # fc1 is below the fusion threshold: two-pass path
+    monkeypatch.setattr(HipAdam, "FUSE_MIN_NUMEL", 1)
+    _, model_b = _pair(SMALL, "bf16", device)
+    opt = model_b.configure_optimizers()
+    assert getattr(model_b.fc1.weight, "_pv_fuse_adam", False)
+    batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+    losses_b = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model_b.training_step(batch, 0)
+        loss.backward()
+        assert model_b.fc1.weight.grad is None and model_b.fc1.weight._pv_pending is not None
+        opt.step()
+        losses_b.append(float(loss))
+    assert losses_a == losses_b
+    for (k, a), (_, b) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
+        assert torch.equal(a, b), k
