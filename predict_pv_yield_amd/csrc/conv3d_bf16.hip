@@ -179,6 +179,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       else st_off[orow] = (vox + (uint32_t)(4 * hh) * (uint32_t)(t_out * plane_out)) * 2u;
     }
   }
+  const __amdgpu_buffer_rsrc_t ogrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32), 0, (int)((size_t)t_out * plane_out * 64), 0x00020000);
   // NDHWC write-out geometry: lane -> (voxel 16*half + lane/4, chunk lane%4) of the wave's 32-column segment
   uint32_t wr_off[4];
   bool wr_ok[4][2];
@@ -197,6 +199,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     store_slice(t + 2);
     __syncthreads();
     if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
+    u32x4 og[OUT_GATE ? 4 : 1][2];
+    if constexpr (OUT_GATE) {  // dgrad: the ReLU mask of this output slice, also fetched under the MFMAs
+      const uint32_t tbase = (uint32_t)t * (uint32_t)plane_out * 64u;
+#pragma unroll
+      for (int orow = 0; orow < 4; ++orow)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          og[orow][half] = __builtin_amdgcn_raw_buffer_load_b128(
+              ogrsrc, wr_ok[orow][half] ? tbase + wr_off[orow] + half * 1024 : 0x40000000u, 0, 0);
+    }
 
     f32x16 acc0;  // bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh
 #pragma unroll
@@ -286,8 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
           u32x4 val = *reinterpret_cast<const u32x4*>(epi_w + orow * 2048 + v * 64 + pc * 16);
           if (wr_ok[orow][half]) {
             if constexpr (OUT_GATE) {  // dgrad: zero the gradient where the consumer's ReLU was inactive
-              const unsigned char* gt = reinterpret_cast<const unsigned char*>(out_gate + ((size_t)b * t_out + t) * plane_out * 32);
-              const u32x4 g = *reinterpret_cast<const u32x4*>(gt + wr_off[orow] + half * 1024);
+              const u32x4 g = og[orow][half];
               val[0] = gate_word(val[0], g[0]); val[1] = gate_word(val[1], g[1]);
               val[2] = gate_word(val[2], g[2]); val[3] = gate_word(val[3], g[3]);
             }
@@ -327,6 +338,38 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_kernel(const float* _
       u32x4 o = {words[4 * k], words[4 * k + 1], words[4 * k + 2], words[4 * k + 3]};
       dst[k] = o;
     }
+  }
+}
+
+// 4 consecutive voxels per thread: 16-byte plane reads, 4*CPAD*2 contiguous bytes written (vps % 4 == 0)
+template <int CPAD>
+__global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float* __restrict__ x,
+                                                                      uint16_t* __restrict__ xp, int c,
+                                                                      long long vox_per_sample, long long total_quads) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  const long long qps = vox_per_sample / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_quads; i += stride) {
+    long long bi = i / qps;
+    long long v = (i - bi * qps) * 4;
+    const float* src = x + (size_t)bi * c * vox_per_sample + v;
+    uint16_t h[4][CPAD];
+#pragma unroll
+    for (int k = 0; k < CPAD; ++k) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (k < c) a = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[q][k] = f32_to_bf16_bits(a[q]);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(xp + ((size_t)bi * vox_per_sample + v) * CPAD);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < CPAD / 8; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
+        dst[q * (CPAD / 8) + k] = o;
+      }
   }
 }
 
@@ -404,6 +447,43 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16(const uin
   }
 }
 
+// 4 consecutive voxels per thread: 8-byte plane reads of dy and y, 256 contiguous bytes written (vps % 4 == 0)
+__global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const uint16_t* __restrict__ dy,
+                                                                           const uint16_t* __restrict__ yv,
+                                                                           uint16_t* __restrict__ out, int c,
+                                                                           long long vox_per_sample, long long total_quads) {
+  long long stride = (long long)gridDim.x * blockDim.x;
+  const long long qps = vox_per_sample / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_quads; i += stride) {
+    long long bi = i / qps;
+    long long v = (i - bi * qps) * 4;
+    const size_t base = (size_t)bi * c * vox_per_sample + v;
+    uint16_t h[4][32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      u32x2 d = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
+      if (k < c) {
+        d = *reinterpret_cast<const u32x2*>(dy + base + (size_t)k * vox_per_sample);
+        if (yv) g = *reinterpret_cast<const u32x2*>(yv + base + (size_t)k * vox_per_sample);
+      }
+      d[0] = gate_word(d[0], g[0]);
+      d[1] = gate_word(d[1], g[1]);
+      h[0][k] = (uint16_t)(d[0] & 0xffffu); h[1][k] = (uint16_t)(d[0] >> 16);
+      h[2][k] = (uint16_t)(d[1] & 0xffffu); h[3][k] = (uint16_t)(d[1] >> 16);
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)bi * vox_per_sample + v) * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
+        dst[q * 4 + k] = o;
+      }
+  }
+}
+
 }  // namespace pv
 
 using namespace pv;
@@ -425,7 +505,13 @@ int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch,
   long long vps = (long long)t * h * w, total = vps * batch;
   PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_ncdhw_f32_to_ndhwc_bf16: empty tensor");
   unsigned grid = stream_grid((size_t)total, 256);
-  if (cpad == 16)
+  if (vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp % 16 == 0)) {
+    unsigned g4 = stream_grid((size_t)(total / 4), 256);
+    if (cpad == 16)
+      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<16>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4);
+    else
+      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4);
+  } else if (cpad == 16)
     hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xp, c, vps, total);
   else
     hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_kernel<32>, dim3(grid), dim3(256), 0, as_stream(stream), x, xp, c, vps, total);
@@ -453,8 +539,12 @@ int pv_repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* dy, const uint16_t* y_rel
   PV_REQUIRE(c > 0 && c <= 32, PV_ESIZE, "pv_repack_gate_ncdhw_to_ndhwc_bf16: c=%d not in 1..32", c);
   long long vps = (long long)t * h * w, total = vps * batch;
   PV_REQUIRE(total > 0, PV_EINVAL, "pv_repack_gate_ncdhw_to_ndhwc_bf16: empty tensor");
-  hipLaunchKernelGGL(repack_gate_ncdhw_to_ndhwc_bf16, dim3(stream_grid((size_t)total, 256)), dim3(256), 0,
-                     as_stream(stream), dy, y_relu_mask, out, c, vps, total);
+  if (vps % 4 == 0 && ((uintptr_t)dy % 8 == 0) && ((uintptr_t)y_relu_mask % 8 == 0))
+    hipLaunchKernelGGL(repack_gate_ncdhw_to_ndhwc_bf16_v4, dim3(stream_grid((size_t)(total / 4), 256)), dim3(256), 0,
+                       as_stream(stream), dy, y_relu_mask, out, c, vps, total / 4);
+  else
+    hipLaunchKernelGGL(repack_gate_ncdhw_to_ndhwc_bf16, dim3(stream_grid((size_t)total, 256)), dim3(256), 0,
+                       as_stream(stream), dy, y_relu_mask, out, c, vps, total);
   return check_launch("pv_repack_gate_ncdhw_to_ndhwc_bf16");
 }
 

@@ -204,37 +204,50 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) slot_of_kt[kt] = ((t + kt) % 3) * SLOTB;
 
-      for (int rho = 0; rho < WTR; ++rho) {
+      // 32 k-steps (8 rows x 4 column groups of 16 voxels); each = 16 transposed reads + 7 MFMAs.  Software-pipelined
+      // by one k-step: all reads of step s+1 are issued before the MFMAs of step s (one wave per SIMD: the LDS
+      // latency has nothing else to hide behind).
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const bool use_ones = (wave == 3);
+      int bslot[7];
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-          // A = dYeff^T fragment of the 16 voxels (row rho, columns 16*cg .. +15)
-          const unsigned char* ap = lds_dy + rho * DROWB + cg * 16 * 64;
-          s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[0]));
-          s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[1]));
-          bf16x8 afr;
-          {
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            s16x8 t8 = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            afr = __builtin_bit_cast(bf16x8, t8);
-          }
+      for (int i = 0; i < 7; ++i) bslot[i] = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
+      auto read_step = [&](int st, s16x4 (&ra)[2], s16x4 (&rb)[7][2]) {
+        const int rho = st >> 2, cg = st & 3;
+        const unsigned char* ap = lds_dy + rho * DROWB + cg * 16 * 64;
+        ra[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[0]));
+        ra[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[1]));
+        const int xo = rho * ROWB + cg * 16 * VOXB;
 #pragma unroll
-          for (int i = 0; i < 7; ++i) {
-            bf16x8 bfr;
-            if (i == 6 && wave == 3) {
-              bfr = ones;
-            } else {
-              const int sb = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
-              const unsigned char* bp = lds + sb + rho * ROWB + cg * 16 * VOXB;
-              s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][0]));
-              s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][1]));
-              typedef __attribute__((ext_vector_type(8))) short s16x8;
-              s16x8 t8 = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-              if (b_zero) t8 = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
-              bfr = __builtin_bit_cast(bf16x8, t8);
-            }
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
-          }
+        for (int i = 0; i < 7; ++i) {
+          const unsigned char* bp = lds + bslot[i] + xo;
+          rb[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][0]));
+          rb[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][1]));
         }
+      };
+      auto mfma_step = [&](const s16x4 (&ra)[2], const s16x4 (&rb)[7][2]) {
+        const s16x8 a8 = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2], ra[1][3]};
+        const bf16x8 afr = __builtin_bit_cast(bf16x8, a8);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          s16x8 t8 = {rb[i][0][0], rb[i][0][1], rb[i][0][2], rb[i][0][3], rb[i][1][0], rb[i][1][1], rb[i][1][2], rb[i][1][3]};
+          if (b_zero) t8 = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          bf16x8 bfr = __builtin_bit_cast(bf16x8, t8);
+          if (i == 6 && use_ones) bfr = ones;
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+        }
+      };
+      s16x4 ra0[2], ra1[2], rb0[7][2], rb1[7][2];
+      read_step(0, ra0, rb0);
+      for (int st = 0; st < WTR * 4; st += 2) {
+        read_step(st + 1, ra1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < WTR * 4) read_step(st + 2, ra0, rb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(ra1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
     }
