@@ -171,15 +171,66 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 }
 
 // ---- UpdateMatrices --------------------------------------------------------------------------------
-// R: [n_pairs][2][lh][lw][5] (R0 = image 0, R1 = image 1); flow: [n_pairs][lh][lw][2]; M: [n_pairs][lh][lw][5]
+// one pixel of FarnebackUpdateMatrices: R0 = this pixel's 5 coefficients, R1 = base of the second image's
+// coefficient plane, (dx, dy) = current flow; out = (G11, G12, G22, h1, h2)
+__device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, const float* __restrict__ R1, float dx,
+                                                float dy, int x, int y, int width, int height, float* m) {
+  const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+  const size_t step1 = (size_t)width * 5;
+  float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
+  int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  float r2, r3, r4, r5, r6;
+  fx = __fsub_rn(fx, (float)x1);
+  fy = __fsub_rn(fy, (float)y1);
+  if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1)) {
+    const float* ptr = R1 + (size_t)y1 * step1 + (size_t)x1 * 5;
+    float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+    float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+#define PV_BILIN(c) \
+  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, ptr[c]), __fmul_rn(a01, ptr[5 + c])), __fmul_rn(a10, ptr[step1 + c])), \
+            __fmul_rn(a11, ptr[step1 + 5 + c]))
+    r2 = PV_BILIN(0);
+    r3 = PV_BILIN(1);
+    r4 = PV_BILIN(2);
+    r5 = PV_BILIN(3);
+    r6 = PV_BILIN(4);
+#undef PV_BILIN
+    r4 = __fmul_rn(__fadd_rn(R0[2], r4), 0.5f);
+    r5 = __fmul_rn(__fadd_rn(R0[3], r5), 0.5f);
+    r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
+  } else {
+    r2 = r3 = 0.f;
+    r4 = R0[2];
+    r5 = R0[3];
+    r6 = __fmul_rn(R0[4], 0.5f);
+  }
+  r2 = __fmul_rn(__fsub_rn(R0[0], r2), 0.5f);
+  r3 = __fmul_rn(__fsub_rn(R0[1], r3), 0.5f);
+  r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
+  r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
+  if ((unsigned)(x - 5) >= (unsigned)(width - 10) || (unsigned)(y - 5) >= (unsigned)(height - 10)) {
+    float scale = (x < 5 ? border[x] : 1.f);
+    scale = __fmul_rn(scale, (x >= width - 5 ? border[width - x - 1] : 1.f));
+    scale = __fmul_rn(scale, (y < 5 ? border[y] : 1.f));
+    scale = __fmul_rn(scale, (y >= height - 5 ? border[height - y - 1] : 1.f));
+    r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
+    r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
+  }
+  m[0] = __fadd_rn(__fmul_rn(r4, r4), __fmul_rn(r6, r6));
+  m[1] = __fmul_rn(__fadd_rn(r4, r5), r6);
+  m[2] = __fadd_rn(__fmul_rn(r5, r5), __fmul_rn(r6, r6));
+  m[3] = __fadd_rn(__fmul_rn(r4, r2), __fmul_rn(r6, r3));
+  m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
+}
+
+// R: [n_pairs][2][lh][lw][5] (R0 = image 0, R1 = image 1); flow: [n_pairs][lh][lw][2];
+// M: [n_pairs][lh][lw][5] (planar == 0) or [n_pairs][5][lh][lw] (planar != 0, what the fused tile kernel reads)
 __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __restrict__ R, const float* __restrict__ flow,
                                                                   float* __restrict__ M, long long n_pairs, int height,
-                                                                  int width) {
-  const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+                                                                  int width, int planar) {
   const long long per_img = (long long)height * width;
   const long long total = n_pairs * per_img;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  const size_t step1 = (size_t)width * 5;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     long long p = i / per_img;
     int rem = (int)(i - p * per_img);
@@ -187,52 +238,108 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
     const float* R0 = R + ((p * 2) * per_img + rem) * 5;
     const float* R1 = R + (p * 2 + 1) * per_img * 5;
     const float* fl = flow + i * 2;
-    float dx = fl[0], dy = fl[1];
-    float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
-    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    float r2, r3, r4, r5, r6;
-    fx = __fsub_rn(fx, (float)x1);
-    fy = __fsub_rn(fy, (float)y1);
-    if ((unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1)) {
-      const float* ptr = R1 + (size_t)y1 * step1 + (size_t)x1 * 5;
-      float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
-      float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
-#define PV_BILIN(c) \
-  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, ptr[c]), __fmul_rn(a01, ptr[5 + c])), __fmul_rn(a10, ptr[step1 + c])), \
-            __fmul_rn(a11, ptr[step1 + 5 + c]))
-      r2 = PV_BILIN(0);
-      r3 = PV_BILIN(1);
-      r4 = PV_BILIN(2);
-      r5 = PV_BILIN(3);
-      r6 = PV_BILIN(4);
-#undef PV_BILIN
-      r4 = __fmul_rn(__fadd_rn(R0[2], r4), 0.5f);
-      r5 = __fmul_rn(__fadd_rn(R0[3], r5), 0.5f);
-      r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
+    float m[5];
+    fb_update_pixel(R0, R1, fl[0], fl[1], x, y, width, height, m);
+    if (planar) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) M[(p * 5 + c) * per_img + rem] = m[c];
     } else {
-      r2 = r3 = 0.f;
-      r4 = R0[2];
-      r5 = R0[3];
-      r6 = __fmul_rn(R0[4], 0.5f);
+      float* d = M + i * 5;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) d[c] = m[c];
     }
-    r2 = __fmul_rn(__fsub_rn(R0[0], r2), 0.5f);
-    r3 = __fmul_rn(__fsub_rn(R0[1], r3), 0.5f);
-    r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
-    r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
-    if ((unsigned)(x - 5) >= (unsigned)(width - 10) || (unsigned)(y - 5) >= (unsigned)(height - 10)) {
-      float scale = (x < 5 ? border[x] : 1.f);
-      scale = __fmul_rn(scale, (x >= width - 5 ? border[width - x - 1] : 1.f));
-      scale = __fmul_rn(scale, (y < 5 ? border[y] : 1.f));
-      scale = __fmul_rn(scale, (y >= height - 5 ? border[height - y - 1] : 1.f));
-      r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
-      r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
+  }
+}
+
+// ---- fused iteration for levels that fit one workgroup (<= 64 x 64): window blur (vertical + horizontal) of the 5
+// channels through LDS, 2x2 solve, and the UpdateMatrices of the next iteration, one workgroup per image pair.
+// M is planar [pair][5][lh][lw].  Thread mapping: vertical pass (x = tid & 63, 16 rows), result written TRANSPOSED
+// (padded to 65) so that the horizontal pass is again a per-thread sliding window (row y = tid & 63, 16 columns).
+// Summation order is exactly FarnebackUpdateFlow_GaussianBlur's (centre tap, then pairs outward).
+template <int MW, int SEG>  // MW = winsize / 2; SEG = outputs per thread; 64 * (64 / SEG) threads
+__global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const float* __restrict__ Min, float* __restrict__ Mout,
+                                                            const float* __restrict__ R, float* __restrict__ flow,
+                                                            int height, int width, FbTaps kt, int update) {
+  constexpr int TS = 64, WIN = SEG + 2 * MW, NT = 64 * (64 / SEG);
+  __shared__ float A[TS * TS];
+  __shared__ float Bt[TS * (TS + 1)];
+  const long long p = blockIdx.x;
+  const long long per_img = (long long)height * width;
+  const int tid = threadIdx.x;
+  const int lane64 = tid & 63, seg = tid >> 6;
+  float tap[MW + 1];
+#pragma unroll
+  for (int k = 0; k <= MW; ++k) tap[k] = kt.k[k];
+  float hres[5][SEG];
+  for (int c = 0; c < 5; ++c) {
+    const float* src = Min + (p * 5 + c) * per_img;
+    __syncthreads();  // previous channel's horizontal reads are done
+    for (int i = tid; i < height * width; i += NT) {
+      int y = i / width, x = i - y * width;
+      A[y * TS + x] = src[i];
     }
-    float* m = M + i * 5;
-    m[0] = __fadd_rn(__fmul_rn(r4, r4), __fmul_rn(r6, r6));
-    m[1] = __fmul_rn(__fadd_rn(r4, r5), r6);
-    m[2] = __fadd_rn(__fmul_rn(r5, r5), __fmul_rn(r6, r6));
-    m[3] = __fadd_rn(__fmul_rn(r4, r2), __fmul_rn(r6, r3));
-    m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
+    __syncthreads();
+    // vertical blur: column x = lane64, rows seg*16 .. +15
+    if (lane64 < width) {
+      float win[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) {
+        int y = seg * SEG - MW + i;
+        y = y < 0 ? 0 : (y > height - 1 ? height - 1 : y);
+        win[i] = A[y * TS + lane64];
+      }
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        float s0 = __fmul_rn(win[j + MW], tap[0]);
+#pragma unroll
+        for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(win[j + MW + k], win[j + MW - k]), tap[k]));
+        const int y = seg * SEG + j;
+        if (y < height) Bt[lane64 * (TS + 1) + y] = s0;
+      }
+    }
+    __syncthreads();
+    // horizontal blur: row y = lane64, columns seg*16 .. +15 (reads the transposed image: conflict-free)
+    if (lane64 < height) {
+      float win[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) {
+        int x = seg * SEG - MW + i;
+        x = x < 0 ? 0 : (x > width - 1 ? width - 1 : x);
+        win[i] = Bt[x * (TS + 1) + lane64];
+      }
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        float s0 = __fmul_rn(win[j + MW], tap[0]);
+#pragma unroll
+        for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(tap[k], __fadd_rn(win[j + MW - k], win[j + MW + k])));
+        hres[c][j] = s0;
+      }
+    }
+  }
+  if (lane64 < height) {
+    const int y = lane64;
+    const float* R1 = R + (p * 2 + 1) * per_img * 5;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+      const int x = seg * SEG + j;
+      if (x < width) {
+        double g11 = hres[0][j], g12 = hres[1][j], g22 = hres[2][j], h1 = hres[3][j], h2 = hres[4][j];
+        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+        double idet = __ddiv_rn(1.0, det);
+        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+        const long long pix = (long long)y * width + x;
+        float* fl = flow + (p * per_img + pix) * 2;
+        fl[0] = fxv;
+        fl[1] = fyv;
+        if (update) {
+          float m[5];
+          fb_update_pixel(R + ((p * 2) * per_img + pix) * 5, R1, fxv, fyv, x, y, width, height, m);
+#pragma unroll
+          for (int c = 0; c < 5; ++c) Mout[(p * 5 + c) * per_img + pix] = m[c];
+        }
+      }
+    }
   }
 }
 
@@ -544,16 +651,34 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)I, T, (long long)n_pairs * 2, lh, lw, pk);
     hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
                        (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
+    const bool tile_path = lw <= 64 && lh <= 64 && (win.n == 20 || win.n == 7 || win.n == 10) && n_pairs <= 0x7fffffffLL;
     hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw);
+                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0);
     for (int it = 0; it < p->iterations; ++it) {
+      const int update = it < p->iterations - 1 ? 1 : 0;
+      if (tile_path) {
+        // M ping-pongs between the M and V buffers (the tile kernel reads the whole old M before any new M exists,
+        // but other workgroups' tiles are independent, so a separate output buffer keeps it race-free by construction)
+        float* Min = (it & 1) ? V : M;
+        float* Mout = (it & 1) ? M : V;
+        if (win.n == 20)
+          hipLaunchKernelGGL((fb_tile_iter_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
+                             (const float*)R, flow, lh, lw, win, update);
+        else if (win.n == 10)
+          hipLaunchKernelGGL((fb_tile_iter_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
+                             (const float*)R, flow, lh, lw, win, update);
+        else
+          hipLaunchKernelGGL((fb_tile_iter_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
+                             (const float*)R, flow, lh, lw, win, update);
+        continue;
+      }
       hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
                          (const float*)M, V, (long long)n_pairs, lh, lw, win);
       hipLaunchKernelGGL(fb_blur_h_solve_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                          (const float*)V, flow, (long long)n_pairs, lh, lw, win);
-      if (it < p->iterations - 1)
+      if (update)
         hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                           (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw);
+                           (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 0);
     }
     prev_flow = flow;
     prev_w = lw;
