@@ -271,14 +271,33 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const flo
 #pragma unroll
   for (int k = 0; k <= MW; ++k) tap[k] = kt.k[k];
   float hres[5][SEG];
-  for (int c = 0; c < 5; ++c) {
-    const float* src = Min + (p * 5 + c) * per_img;
-    __syncthreads();  // previous channel's horizontal reads are done
-    for (int i = tid; i < height * width; i += NT) {
-      int y = i / width, x = i - y * width;
-      A[y * TS + x] = src[i];
+  constexpr int NE = TS * TS / NT;  // tile elements per thread
+  const int npx = height * width;
+  float nxt[NE];
+  {
+    const float* src = Min + (p * 5) * per_img;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT;
+      nxt[e] = i < npx ? src[i] : 0.f;
     }
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT;
+      if (i < npx) { const int y = i / width; A[y * TS + (i - y * width)] = nxt[e]; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {  // unrolled: hres must be indexed statically to stay in registers
+    if (c < 4) {  // prefetch the next channel's plane under this channel's arithmetic
+      const float* src = Min + (p * 5 + c + 1) * per_img;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int i = tid + e * NT;
+        nxt[e] = i < npx ? src[i] : 0.f;
+      }
+    }
     // vertical blur: column x = lane64, rows seg*16 .. +15
     if (lane64 < width) {
       float win[WIN];
@@ -297,7 +316,14 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const flo
         if (y < height) Bt[lane64 * (TS + 1) + y] = s0;
       }
     }
-    __syncthreads();
+    __syncthreads();  // vertical results visible; every read of A is done
+    if (c < 4) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int i = tid + e * NT;
+        if (i < npx) { const int y = i / width; A[y * TS + (i - y * width)] = nxt[e]; }
+      }
+    }
     // horizontal blur: row y = lane64, columns seg*16 .. +15 (reads the transposed image: conflict-free)
     if (lane64 < height) {
       float win[WIN];
@@ -315,6 +341,7 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const flo
         hres[c][j] = s0;
       }
     }
+    __syncthreads();  // Bt may be overwritten by the next channel; the new A plane is visible
   }
   if (lane64 < height) {
     const int y = lane64;
