@@ -684,19 +684,21 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     for (int it = 0; it < p->iterations; ++it) {
       const int update = it < p->iterations - 1 ? 1 : 0;
       if (tile_path) {
-        // M ping-pongs between the M and V buffers (the tile kernel reads the whole old M before any new M exists,
-        // but other workgroups' tiles are independent, so a separate output buffer keeps it race-free by construction)
-        float* Min = (it & 1) ? V : M;
-        float* Mout = (it & 1) ? M : V;
+        // blur + solve in one workgroup per pair; UpdateMatrices stays a separate high-occupancy launch: its
+        // flow-dependent R1 gathers need many waves in flight (measured: inside the tile kernel, at 2 waves/SIMD,
+        // they took 4x the time of the whole blur)
         if (win.n == 20)
-          hipLaunchKernelGGL((fb_tile_iter_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
-                             (const float*)R, flow, lh, lw, win, update);
+          hipLaunchKernelGGL((fb_tile_iter_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
+                             (const float*)R, flow, lh, lw, win, 0);
         else if (win.n == 10)
-          hipLaunchKernelGGL((fb_tile_iter_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
-                             (const float*)R, flow, lh, lw, win, update);
+          hipLaunchKernelGGL((fb_tile_iter_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
+                             (const float*)R, flow, lh, lw, win, 0);
         else
-          hipLaunchKernelGGL((fb_tile_iter_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)Min, Mout,
-                             (const float*)R, flow, lh, lw, win, update);
+          hipLaunchKernelGGL((fb_tile_iter_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
+                             (const float*)R, flow, lh, lw, win, 0);
+        if (update)
+          hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                             (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1);
         continue;
       }
       hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
