@@ -166,12 +166,14 @@ def main():
     batch = {"satellite": {"data": torch.randn(b, 11, t_frames, 64, 64, generator=g, device=dev)},
              "pv": {"pv_yield": torch.rand(b, t_frames, 128, generator=g, device=dev)}}
 
+    sync = D.OverlappedGradSync(model) if distributed else None
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss = model.training_step(batch, 0)
-        loss.backward()
-        if distributed:
-            D.all_reduce_gradients(model)
+        loss.backward()      # under N > 1 fc1's gradient all-reduce starts from a hook inside backward
+        if sync is not None:
+            sync.finish()
         opt.step()
         return loss
 

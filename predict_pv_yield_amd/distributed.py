@@ -72,6 +72,48 @@ def all_reduce_gradients(module: torch.nn.Module, average: bool = False) -> None
             g.div_(w)
 
 
+class OverlappedGradSync:
+    """DDP-style overlap: the all-reduce of a LARGE parameter's gradient is launched from an autograd hook the
+    moment that gradient is final, on RCCL's own stream, and is waited for only before the optimiser step.
+    fc1.weight.grad (99.9 % of the bytes) is produced FIRST in backward (the head runs before the conv stack), so its
+    ~0.5 GB exchange hides under the conv dgrad/wgrad kernels.  The many small gradients go as one flat bucket at
+    the end.  Sums are left un-averaged (HipAdam.grad_scale = 1/world folds the mean into the update)."""
+
+    def __init__(self, module: torch.nn.Module, large_numel: int = 1 << 22):
+        self.module = module
+        self.large = [p for p in module.parameters() if p.requires_grad and p.numel() >= large_numel]
+        self.small = [p for p in module.parameters() if p.requires_grad and p.numel() < large_numel]
+        self._pending = []
+        self._handles = []
+        if is_distributed():
+            for p in self.large:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._launch))
+
+    def _launch(self, p: torch.Tensor) -> None:
+        self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        """Call after backward, before optimizer.step()."""
+        if not is_distributed():
+            return
+        grads = [p.grad for p in self.small if p.grad is not None]
+        if grads:
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+
 def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, float]:
     """All logged scalars of one log_dict call travel as ONE vector (the reference sends one tiny all-reduce each)."""
     if not is_distributed():

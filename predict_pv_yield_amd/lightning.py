@@ -376,6 +376,8 @@ class Trainer:
                     o.grad_scale = 1.0 / self.world_size
                 if hasattr(o, "set_fuse_large_linear"):
                     o.set_fuse_large_linear(False)   # the all-reduce needs the materialised fc1 gradient
+            from .distributed import OverlappedGradSync
+            self._grad_sync = OverlappedGradSync(model)
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
         max_epochs = 1 if self.fast_dev_run else self.max_epochs
@@ -396,7 +398,10 @@ class Trainer:
                 if self.world_size > 1:
                     from .distributed import all_reduce_gradients
                     fold = all(hasattr(o, "grad_scale") for o in self.optimizers)
-                    self._timed("grad_all_reduce", all_reduce_gradients, model, not fold)
+                    if fold and getattr(self, "_grad_sync", None) is not None:
+                        self._timed("grad_all_reduce", self._grad_sync.finish)   # large grads were launched in backward
+                    else:
+                        self._timed("grad_all_reduce", all_reduce_gradients, model, True)
                 for o in self.optimizers:
                     self._timed("optimizer_step", o.step)
                 self.global_step += 1

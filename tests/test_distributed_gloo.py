@@ -29,6 +29,26 @@ def _worker(rank, world, port, ret):
         both = [torch.zeros_like(g) for _ in range(world)]
         dist.all_gather(both, g)
         assert torch.allclose(p.grad, both[0] + both[1])
+    # overlapped variant: the large tensor's all-reduce is launched from an autograd hook during backward
+    net2 = nn.Sequential(nn.Linear(6, 5), nn.Linear(5, 1))
+    D.broadcast_parameters(net2)
+    sync = D.OverlappedGradSync(net2, large_numel=20)      # the 6x5 weight counts as "large" here
+    assert len(sync.large) == 1 and len(sync.small) == 3
+    net2(x).sum().backward()
+    assert len(sync._pending) == 1                          # launched inside backward
+    local2 = None
+    sync.finish()
+    ref = nn.Sequential(nn.Linear(6, 5), nn.Linear(5, 1))
+    ref.load_state_dict(net2.state_dict())
+    tot = [torch.zeros_like(p) for p in ref.parameters()]
+    for r in range(world):
+        ref.zero_grad()
+        ref(torch.full((4, 6), float(r + 1))).sum().backward()
+        for t, p in zip(tot, ref.parameters()):
+            t += p.grad
+    for p, t in zip(net2.parameters(), tot):
+        assert torch.allclose(p.grad, t)
+    sync.remove()
     vals = D.all_reduce_mean_scalars({"MSE/Train": float(rank), "NMAE/Train": 2.0 * rank})
     assert vals == {"MSE/Train": 0.5, "NMAE/Train": 1.0}
     lo, hi = D.shard_range(11)
