@@ -195,13 +195,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       wr_ok[orow][half] = ho < h_out && col_t < TW_VALID && (w0 + col_t) < w_out;
     }
   }
-  for (int t = tc0; t < tc1; ++t) {
-    store_slice(t + 2);
-    __syncthreads();
-    if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
+  // NDHWC write-out of the tile staged in the wave's private LDS area: each lane moves two 16-byte chunks per output
+  // row, a wave-instruction covers 1 KB of contiguous global memory.  It is DEFERRED by one iteration and issued
+  // inside the next slice's MFMA stream (the accumulators are free again once the tile is staged), so its LDS
+  // round trip and store issue hide under matrix work instead of sitting between two barriers.
+  auto write_out = [&](int tw) {
+    unsigned char* yt = reinterpret_cast<unsigned char*>(y + ((size_t)b * t_out + tw) * plane_out * 32);
+    const unsigned char* epi_w = lds + 3 * G::SLOT_BYTES + 512 + wave * 8192;
     u32x4 og[OUT_GATE ? 4 : 1][2];
-    if constexpr (OUT_GATE) {  // dgrad: the ReLU mask of this output slice, also fetched under the MFMAs
-      const uint32_t tbase = (uint32_t)t * (uint32_t)plane_out * 64u;
+    if constexpr (OUT_GATE) {  // dgrad: ReLU mask of this output slice
+      const uint32_t tbase = (uint32_t)tw * (uint32_t)plane_out * 64u;
 #pragma unroll
       for (int orow = 0; orow < 4; ++orow)
 #pragma unroll
@@ -209,7 +212,30 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
           og[orow][half] = __builtin_amdgcn_raw_buffer_load_b128(
               ogrsrc, wr_ok[orow][half] ? tbase + wr_off[orow] + half * 1024 : 0x40000000u, 0, 0);
     }
+#pragma unroll
+    for (int orow = 0; orow < 4; ++orow) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int v = 16 * half + (lane >> 2);       // voxel inside the 32-column segment
+        const int c = lane & 3;                      // 16-byte chunk = channels 8c .. 8c+7
+        const int pc = c ^ ((v >> 1) & 3);           // swizzle moves whole 16-byte chunks (even slot XOR)
+        u32x4 val = *reinterpret_cast<const u32x4*>(epi_w + orow * 2048 + v * 64 + pc * 16);
+        if (wr_ok[orow][half]) {
+          if constexpr (OUT_GATE) {  // zero the gradient where the consumer's ReLU was inactive
+            const u32x4 g = og[orow][half];
+            val[0] = gate_word(val[0], g[0]); val[1] = gate_word(val[1], g[1]);
+            val[2] = gate_word(val[2], g[2]); val[3] = gate_word(val[3], g[3]);
+          }
+          *reinterpret_cast<u32x4*>(yt + wr_off[orow] + half * 1024) = val;
+        }
+      }
+    }
+  };
 
+  for (int t = tc0; t < tc1; ++t) {
+    store_slice(t + 2);
+    __syncthreads();
+    if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
     f32x16 acc0;  // bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -248,6 +274,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!Y_NCDHW) {
+        if (g == 1 && t > tc0) {  // previous slice's tile: its stores ride under the remaining 16 groups of MFMAs
+          write_out(t - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
 
     // ---- epilogue: ReLU, bf16, store.  Addresses = scalar base of this (b, t) + a 32-bit per-lane offset
@@ -283,32 +315,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
         }
       }
     }
-    if constexpr (!Y_NCDHW) {
-      // write-out: each lane moves two 16-byte chunks per output row, a wave-instruction covers 1 KB of
-      // contiguous global memory (16 voxels x 64 B) instead of 64 scattered 8-byte pieces
-      unsigned char* yt = reinterpret_cast<unsigned char*>(y + ((size_t)b * t_out + t) * plane_out * 32);
-      const unsigned char* epi_w = lds + 3 * G::SLOT_BYTES + 512 + wave * 8192;
-#pragma unroll
-      for (int orow = 0; orow < 4; ++orow) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int v = 16 * half + (lane >> 2);       // voxel inside the 32-column segment
-          const int c = lane & 3;                      // 16-byte chunk = channels 8c .. 8c+7
-          const int pc = c ^ ((v >> 1) & 3);           // swizzle moves whole 16-byte chunks (even slot XOR)
-          u32x4 val = *reinterpret_cast<const u32x4*>(epi_w + orow * 2048 + v * 64 + pc * 16);
-          if (wr_ok[orow][half]) {
-            if constexpr (OUT_GATE) {  // dgrad: zero the gradient where the consumer's ReLU was inactive
-              const u32x4 g = og[orow][half];
-              val[0] = gate_word(val[0], g[0]); val[1] = gate_word(val[1], g[1]);
-              val[2] = gate_word(val[2], g[2]); val[3] = gate_word(val[3], g[3]);
-            }
-            *reinterpret_cast<u32x4*>(yt + wr_off[orow] + half * 1024) = val;
-          }
-        }
-      }
-    }
     __syncthreads();  // every wave is done reading slot t%3 before the next store_slice(t+3)
   }
+  if constexpr (!Y_NCDHW) write_out(tc1 - 1);
 }
 
 // ---------------------------------------------------------------------------------------------
