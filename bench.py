@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--f32-grads", action="store_true", help="N > 1: all-reduce fc1's gradient in f32 instead of bf16")
     args = ap.parse_args()
 
     from predict_pv_yield_amd import distributed as D
@@ -158,7 +159,8 @@ def main():
     opt = model.configure_optimizers()
     opt.grad_scale = 1.0 / world
     if distributed:
-        opt.set_fuse_large_linear(False)  # the gradient all-reduce needs the materialised fc1 gradient
+        # the all-reduce needs a materialised fc1 gradient: bf16 on the wire (half the xGMI bytes), f32 with --f32-grads
+        opt.set_large_grad_mode("autograd" if args.f32_grads else "bf16")
 
     g = torch.Generator(device=dev).manual_seed(518 + rank)
     b = args.batch

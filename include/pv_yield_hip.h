@@ -240,6 +240,15 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
                               int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
                               void* stream);
 
+/* Data-parallel wire format for fc1's gradient (SURVEY.md §7.2 "keep bf16 grads on the wire"): the weight gradient is
+ * written once as bf16 [N,K] (half the bytes of the f32 gradient on HBM and on xGMI), all-reduced by RCCL in bf16,
+ * and consumed by pv_adam_step_bf16grad (same arithmetic as pv_adam_step_f32 after widening the gradient). */
+int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16,
+                            int32_t m, int32_t n, int64_t k, void* stream);
+int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
+                          uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,
+                          int32_t step, float grad_scale, void* stream);
+
 /* dst[i] = bf16(src[i]) (round to nearest even): first fill of a parameter's bf16 shadow; afterwards
  * pv_adam_step_f32 keeps the shadow current. */
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);

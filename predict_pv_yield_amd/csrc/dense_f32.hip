@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void forecast_losses_f32(const float* __restri
 }
 
 // ---- Adam: torch._single_tensor_adam order of operations, f32 ------------------------------------
-__global__ __launch_bounds__(256) void adam_step_f32(float* __restrict__ p, const float* __restrict__ g,
+template <typename GT>  // gradient type: float, or uint16_t holding bf16 (data-parallel wire format)
+__global__ __launch_bounds__(256) void adam_step_f32(float* __restrict__ p, const GT* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v,
                                                       uint16_t* __restrict__ shadow, size_t n, float one_minus_b1,
                                                       float beta2, float one_minus_b2, float bc2_sqrt, float eps,
@@ -186,7 +187,14 @@ __global__ __launch_bounds__(256) void adam_step_f32(float* __restrict__ p, cons
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
       f32x4 pv4 = *reinterpret_cast<const f32x4*>(p + i);
-      f32x4 gv4 = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 gv4;
+      if constexpr (sizeof(GT) == 4) {
+        gv4 = *reinterpret_cast<const f32x4*>(g + i);
+      } else {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(g + i);
+        gv4[0] = __builtin_bit_cast(float, raw[0] << 16); gv4[1] = __builtin_bit_cast(float, raw[0] & 0xffff0000u);
+        gv4[2] = __builtin_bit_cast(float, raw[1] << 16); gv4[3] = __builtin_bit_cast(float, raw[1] & 0xffff0000u);
+      }
       f32x4 mv4 = *reinterpret_cast<const f32x4*>(m + i);
       f32x4 vv4 = *reinterpret_cast<const f32x4*>(v + i);
       uint16_t sh[4];
@@ -209,7 +217,9 @@ __global__ __launch_bounds__(256) void adam_step_f32(float* __restrict__ p, cons
       }
     } else {
       for (size_t q = i; q < n; ++q) {
-        float gr = g[q] * grad_scale;
+        float gq;
+        if constexpr (sizeof(GT) == 4) gq = (float)g[q]; else gq = bf16_bits_to_f32((uint16_t)g[q]);
+        float gr = gq * grad_scale;
         float mm = m[q] + one_minus_b1 * (gr - m[q]);
         float vv = v[q] * beta2 + (one_minus_b2 * gr) * gr;
         float denom = sqrtf(vv) / bc2_sqrt + eps;
@@ -341,10 +351,27 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
   double bc2 = 1.0 - pow(beta2, (double)step);
   double step_size = lr / bc1;
   double bc2_sqrt = sqrt(bc2);
-  hipLaunchKernelGGL(adam_step_f32, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), param, grad,
+  hipLaunchKernelGGL(adam_step_f32<float>, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), param, grad,
                      exp_avg, exp_avg_sq, bf16_shadow, n, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size), grad_scale);
   return check_launch("pv_adam_step_f32");
+}
+
+int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
+                          uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps, int32_t step,
+                          float grad_scale, void* stream) {
+  PV_REQUIRE(param && grad_bf16 && exp_avg && exp_avg_sq, PV_EINVAL, "pv_adam_step_bf16grad: null pointer");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_adam_step_bf16grad: step must be >= 1");
+  PV_REQUIRE(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad_bf16 % 8 == 0) && ((uintptr_t)exp_avg % 16 == 0) &&
+                 ((uintptr_t)exp_avg_sq % 16 == 0) && ((uintptr_t)bf16_shadow % 8 == 0),
+             PV_EINVAL, "pv_adam_step_bf16grad: buffers must be 16-byte aligned");
+  if (n == 0) return PV_OK;
+  double bc1 = 1.0 - pow(beta1, (double)step);
+  double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_step_f32<uint16_t>, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), param,
+                     grad_bf16, exp_avg, exp_avg_sq, bf16_shadow, n, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-(lr / bc1)), grad_scale);
+  return check_launch("pv_adam_step_bf16grad");
 }
 
 }  // extern "C"

@@ -195,7 +195,7 @@ struct AdamScalars {
   float one_minus_b1, beta2, one_minus_b2, bc2_sqrt, eps, neg_step_size;
 };
 
-template <bool FUSE_ADAM>
+template <int MODE>  // 0: write dw f32; 1: fused Adam update (dw = parameter); 2: write dw bf16 (dw reinterpreted)
 __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t* __restrict__ x,
                                                                   const float* __restrict__ dy,
                                                                   const float* __restrict__ ymask,
@@ -245,11 +245,17 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
   for (int i = 0; i < BT; ++i) {
     if (n0 + i < n) {
       const size_t off = (size_t)(n0 + i) * k + k8;
-      if constexpr (!FUSE_ADAM) {
+      if constexpr (MODE == 0) {
         f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
         f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
         *reinterpret_cast<f32x4*>(dw + off) = o0;
         *reinterpret_cast<f32x4*>(dw + off + 4) = o1;
+      } else if constexpr (MODE == 2) {
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dw) + off) = o;
       } else {
         // dw here is the PARAMETER (updated in place); same operation order as adam_step_f32 / torch
         float pv[8], mv[8], vv[8];
@@ -364,7 +370,7 @@ int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, co
     PV_REQUIRE(x, PV_EINVAL, "pv_linear_bwd_bf16: dw needs x");
     size_t lds = (size_t)m * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: m=%d too large", m);
-    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<false>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
+    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<0>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
                        y_relu_mask, dw, m, n, (long long)k, (float*)nullptr, (float*)nullptr, (uint16_t*)nullptr,
                        AdamScalars{});
   }
@@ -386,9 +392,22 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                  (float)(-(lr / bc1))};
   unsigned kb = (unsigned)((k / 8 + 255) / 256);
-  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<true>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds,
+  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<1>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds,
                      as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, bf16_shadow, ad);
   return check_launch("pv_linear_wgrad_adam_bf16");
+}
+
+int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16, int32_t m,
+                            int32_t n, int64_t k, void* stream) {
+  PV_REQUIRE(x && dy && dw_bf16, PV_EINVAL, "pv_linear_wgrad_bf16out: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_bf16out: bad sizes (k must be a multiple of 8)");
+  size_t lds = (size_t)m * BT * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_wgrad_bf16out: m=%d too large", m);
+  unsigned kb = (unsigned)((k / 8 + 255) / 256);
+  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<2>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, as_stream(stream),
+                     x, dy, y_relu_mask, reinterpret_cast<float*>(dw_bf16), m, n, (long long)k, (float*)nullptr,
+                     (float*)nullptr, (uint16_t*)nullptr, AdamScalars{});
+  return check_launch("pv_linear_wgrad_bf16out");
 }
 
 }  // extern "C"

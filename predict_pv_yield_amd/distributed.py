@@ -88,9 +88,15 @@ class OverlappedGradSync:
         if is_distributed():
             for p in self.large:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._launch))
+                # side channel of functional.LinearBF16 (HipAdam large_grad_mode "bf16"): the bf16 gradient tensor is
+                # handed over the moment the wgrad kernel is enqueued
+                p._pv_on_grad = self._launch_tensor
 
     def _launch(self, p: torch.Tensor) -> None:
         self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+
+    def _launch_tensor(self, g: torch.Tensor) -> None:
+        self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self) -> None:
         """Call after backward, before optimizer.step()."""
@@ -112,6 +118,9 @@ class OverlappedGradSync:
         for h in self._handles:
             h.remove()
         self._handles = []
+        for p in self.large:
+            if hasattr(p, "_pv_on_grad"):
+                del p._pv_on_grad
 
 
 def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, float]:

@@ -152,12 +152,20 @@ class LinearBF16(torch.autograd.Function):
         x, wb, y = ctx.saved_tensors
         dy = dy.contiguous()
         weight = ctx.weight_param
-        fuse = getattr(weight, "_pv_fuse_adam", False)
-        dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=not fuse)
-        if fuse:
-            # HipAdam(fuse_large_linear=True) owns this parameter: hand it (x, dy, relu mask); the weight gradient is
-            # formed inside the optimiser's pass over p/m/v and never written to memory
+        mode = getattr(weight, "_pv_grad_mode", "autograd")
+        dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=(mode == "autograd"))
+        if mode == "fused":
+            # HipAdam owns this parameter (single process): hand it (x, dy, relu mask); the weight gradient is formed
+            # inside the optimiser's pass over p/m/v and never written to memory
             weight._pv_pending = (x, dy, y)
+        elif mode == "bf16":
+            # data parallel: the gradient is written once in bf16 and handed to the gradient-sync callback right
+            # away, so its all-reduce (99.9 % of the bytes of the step) runs under the conv backward that follows
+            gb = K.linear_wgrad_bf16out(x, dy, y, weight.shape[0])
+            weight._pv_grad_bf16 = gb
+            cb = getattr(weight, "_pv_on_grad", None)
+            if cb is not None:
+                cb(gb)
         return dx, dw, (db if ctx.has_bias else None), None
 
 

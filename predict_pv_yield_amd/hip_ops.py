@@ -383,3 +383,21 @@ def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_
     check(get_lib().pv_linear_wgrad_adam_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg),
                                               ptr(exp_avg_sq), ptr(bf16_shadow), m, n, k, lr, betas[0], betas[1], eps,
                                               step, current_stream_ptr()), "pv_linear_wgrad_adam_bf16")
+
+
+def linear_wgrad_bf16out(x_bf16, dy, y_mask, n: int) -> torch.Tensor:
+    """fc1 weight gradient written directly as bf16 [N,K] (data-parallel wire format)."""
+    require_cuda(x_bf16, dy, y_mask)
+    m, k = x_bf16.shape
+    dw = torch.empty((n, k), dtype=torch.bfloat16, device=dy.device)
+    check(get_lib().pv_linear_wgrad_bf16out(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(dw), m, n, k, current_stream_ptr()),
+          "pv_linear_wgrad_bf16out")
+    return dw
+
+
+def adam_step_bf16grad(param, grad_bf16, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8,
+                       bf16_shadow=None, grad_scale=1.0):
+    require_cuda(param, grad_bf16, exp_avg, exp_avg_sq, bf16_shadow)
+    check(get_lib().pv_adam_step_bf16grad(ptr(param), ptr(grad_bf16), ptr(exp_avg), ptr(exp_avg_sq), ptr(bf16_shadow),
+                                          param.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
+                                          current_stream_ptr()), "pv_adam_step_bf16grad")

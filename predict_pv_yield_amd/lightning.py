@@ -374,8 +374,8 @@ class Trainer:
             for o in self.optimizers:   # summing all-reduce; HipAdam folds the 1/world_size into its update
                 if hasattr(o, "grad_scale"):
                     o.grad_scale = 1.0 / self.world_size
-                if hasattr(o, "set_fuse_large_linear"):
-                    o.set_fuse_large_linear(False)   # the all-reduce needs the materialised fc1 gradient
+                if hasattr(o, "set_large_grad_mode"):
+                    o.set_large_grad_mode("bf16")    # the all-reduce needs a materialised fc1 gradient: bf16 on the wire
             from .distributed import OverlappedGradSync
             self._grad_sync = OverlappedGradSync(model)
         for cb in self.callbacks:

@@ -12,8 +12,10 @@ from . import hip_ops as K
 
 
 class HipAdam(torch.optim.Optimizer):
-    # parameters at least this large whose gradient comes from functional.LinearBF16 are updated by the fused
-    # wgrad+Adam kernel (single process only: a data-parallel run needs the materialised gradient for its all-reduce)
+    # 2-D parameters at least this large whose gradient comes from functional.LinearBF16 (fc1) can bypass autograd's
+    # f32 .grad:  "fused" -- wgrad + Adam in one pass, the gradient is never materialised (single process);
+    #             "bf16"  -- gradient written as bf16 and all-reduced in bf16 (data parallel);
+    #             "autograd" -- plain f32 .grad.
     FUSE_MIN_NUMEL = 1 << 22
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True):
@@ -21,15 +23,22 @@ class HipAdam(torch.optim.Optimizer):
             raise ValueError("HipAdam: invalid hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
-        self.set_fuse_large_linear(fuse_large_linear)
+        self.set_large_grad_mode("fused" if fuse_large_linear else "autograd")
+
+    def large_params(self):
+        return [p for g in self.param_groups for p in g["params"] if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL]
+
+    def set_large_grad_mode(self, mode: str) -> None:
+        if mode not in ("fused", "bf16", "autograd"):
+            raise ValueError(mode)
+        self.large_grad_mode = mode
+        for p in self.large_params():
+            p._pv_grad_mode = mode
+            p._pv_pending = None
+            p._pv_grad_bf16 = None
 
     def set_fuse_large_linear(self, enabled: bool) -> None:
-        self.fuse_large_linear = bool(enabled)
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL:
-                    p._pv_fuse_adam = self.fuse_large_linear
-                    p._pv_pending = None
+        self.set_large_grad_mode("fused" if enabled else "autograd")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -40,7 +49,8 @@ class HipAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             for p in group["params"]:
                 pending = getattr(p, "_pv_pending", None)
-                if p.grad is None and pending is None:
+                gb = getattr(p, "_pv_grad_bf16", None)
+                if p.grad is None and pending is None and gb is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
@@ -56,6 +66,13 @@ class HipAdam(torch.optim.Optimizer):
                     p._pv_pending = None
                     K.linear_wgrad_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                              int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    continue
+                if gb is not None and p.grad is None:
+                    from .functional import bf16_shadow_of
+                    p._pv_grad_bf16 = None
+                    K.adam_step_bf16grad(p, gb, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), lr=group["lr"],
+                                         betas=group["betas"], eps=group["eps"], bf16_shadow=bf16_shadow_of(p),
+                                         grad_scale=self.grad_scale)
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 K.adam_step(p, g.float(), st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), lr=group["lr"],

@@ -238,3 +238,24 @@ def test_fused_wgrad_adam_is_bit_identical_to_two_pass(device):
         K.adam_step(pa, dw, ma, va, step, lr=5e-4, bf16_shadow=sa)
         K.linear_wgrad_adam_bf16(x, dy, y, pb, mb, vb, sb, step, lr=5e-4)
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb), step
+
+
+def test_bf16_gradient_wire_format(device):
+    """pv_linear_wgrad_bf16out = bf16(RNE) of the f32 gradient; pv_adam_step_bf16grad = Adam on the widened gradient."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(78)
+    m, n, k = 16, 24, 4096
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(m, n, generator=g).to(device)
+    y = torch.relu(torch.randn(m, n, generator=g)).to(device)
+    wb = torch.zeros(n, k, dtype=torch.bfloat16, device=device)
+    _, dw, _ = K.linear_bwd_bf16(x, wb, dy, y, need_dx=False)
+    dwb = K.linear_wgrad_bf16out(x, dy, y, n)
+    assert torch.equal(dwb, dw.to(torch.bfloat16))
+    p0 = (torch.randn(n, k, generator=g) * 0.01).to(device)
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    for step in (1, 2):
+        K.adam_step(pa, dwb.float(), ma, va, step, lr=5e-4, grad_scale=0.125)
+        K.adam_step_bf16grad(pb, dwb, mb, vb, step, lr=5e-4, grad_scale=0.125)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)

@@ -188,3 +188,29 @@ def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
     assert losses_a == losses_b
     for (k, a), (_, b) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_bf16_gradient_side_channel_in_the_model(device, monkeypatch):
+    """HipAdam large_grad_mode="bf16" (the data-parallel wire format), exercised in one process: fc1's gradient goes
+    through the bf16 side channel and the sync callback; training follows the f32-gradient run closely."""
+    from predict_pv_yield_amd.optim import HipAdam
+    sat, pv = _data(SMALL, 2)
+    _, model_a = _pair(SMALL, "bf16", device)
+    losses_a = _hip_steps(model_a, sat, pv, 3, device)
+    monkeypatch.setattr(HipAdam, "FUSE_MIN_NUMEL", 1)
+    _, model_b = _pair(SMALL, "bf16", device)
+    opt = model_b.configure_optimizers()
+    opt.set_large_grad_mode("bf16")
+    seen = []
+    model_b.fc1.weight._pv_on_grad = lambda t: seen.append(t.dtype)
+    batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+    losses_b = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = model_b.training_step(batch, 0)
+        loss.backward()
+        assert model_b.fc1.weight.grad is None and model_b.fc1.weight._pv_grad_bf16.dtype == torch.bfloat16
+        opt.step()
+        losses_b.append(float(loss))
+    assert seen == [torch.bfloat16] * 3
+    np.testing.assert_allclose(losses_b, losses_a, rtol=2e-3)
