@@ -175,7 +175,7 @@ def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
     monkeypatch.setattr(HipAdam, "FUSE_MIN_NUMEL", 1)
     _, model_b = _pair(SMALL, "bf16", device)
     opt = model_b.configure_optimizers()
-    assert getattr(model_b.fc1.weight, "_pv_fuse_adam", False)
+    assert getattr(model_b.fc1.weight, "_pv_grad_mode", "autograd") == "fused"
     batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
     losses_b = []
     for _ in range(3):
