@@ -143,7 +143,7 @@ def main():
     rank = torch.distributed.get_rank() if distributed else 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", D.local_device_index())
     torch.cuda.set_device(dev)
 
     model_kwargs = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30,

@@ -26,11 +26,19 @@ def init_from_env(backend: str = None) -> bool:
         return False
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PV_DIST_BACKEND=gloo: debugging aid (e.g. two ranks sharing one GPU, where RCCL refuses to start)
+            backend = os.environ.get("PV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(local_device_index())
         dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
     return True
+
+
+def local_device_index() -> int:
+    """cuda index of this rank: LOCAL_RANK, or 0 for every rank when PV_SINGLE_DEVICE=1 (debugging on a 1-GPU box)."""
+    if os.environ.get("PV_SINGLE_DEVICE") == "1":
+        return 0
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

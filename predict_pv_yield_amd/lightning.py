@@ -292,8 +292,8 @@ class Trainer:
     # -- loops ---------------------------------------------------------------------------------------
     def _device(self):
         if self.gpus not in (0, None, "0", []) and torch.cuda.is_available():
-            local = int(os.environ.get("LOCAL_RANK", 0))
-            return torch.device("cuda", local)
+            from .distributed import local_device_index
+            return torch.device("cuda", local_device_index())
         return torch.device("cpu")
 
     def _limit(self, which, loader):
