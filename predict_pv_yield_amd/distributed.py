@@ -101,7 +101,8 @@ class OverlappedGradSync:
                 p._pv_on_grad = self._launch_tensor
 
     def _launch(self, p: torch.Tensor) -> None:
-        self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        if p.grad is not None:  # None when the gradient travels through the bf16 side channel instead
+            self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
 
     def _launch_tensor(self, g: torch.Tensor) -> None:
         self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
