@@ -97,6 +97,44 @@ def measure_conv_roofline(batch, hist_frames, dev):
             "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
 
 
+def measure_hbm_kernels(model, opt, batch_size, t_frames, dev):
+    """HBM-bound side of the step: the fused fc1 wgrad+Adam pass (one stream over p, m, v + bf16 shadow) and the
+    config-3 advection stages (remap x6 of 11 channels: 16 algorithmic bytes per output pixel)."""
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd import optical_flow as of
+    out = {}
+    p = model.fc1.weight
+    st = opt.state.get(p)
+    if st:
+        n, k = p.shape
+        x = torch.randn(batch_size, k, device=dev).to(torch.bfloat16)
+        dy = torch.randn(batch_size, n, device=dev) * 1e-6
+        from predict_pv_yield_amd.functional import bf16_shadow_of
+        sh = bf16_shadow_of(p)
+        pc, mc, vc = p.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+        d = time_kernel(lambda: K.linear_wgrad_adam_bf16(x, dy, None, pc, mc, vc, sh, 10), iters=5, warm=1)
+        byt = n * k * (3 * 4 * 2 + 2) + batch_size * k * 2   # p,m,v read+write, shadow write, x read once
+        out["fc1_wgrad_adam"] = {"bound": "hbm", "ms": round(d * 1e3, 4), "algorithmic_GB": round(byt / 1e9, 3),
+                                 "achieved": round(byt / d / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                 "frac": round(byt / d / HBM_PEAK, 4)}
+        del x, dy, pc, mc, vc
+    b = batch_size
+    src = torch.randn(b * 11, 64, 64, device=dev)
+    fl = torch.randn(b * 11, 64, 64, 2, device=dev)
+    d = time_kernel(lambda: K.remap_bilinear(src, fl, 6, 1.0, 1, 0.0), iters=20, warm=3)
+    byt = b * 11 * 6 * 4096 * 16
+    out["remap_x6"] = {"bound": "hbm", "ms": round(d * 1e3, 4), "achieved": round(byt / d / 1e9, 1),
+                       "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(byt / d / HBM_PEAK, 4),
+                       "algorithmic_bytes_per_output_pixel": 16}
+    raw = torch.randint(0, 1021, (b, 12, 11, 64, 64), dtype=torch.int16, device=dev)
+    d = time_kernel(lambda: of.advect_future_frames(raw, 6), iters=3, warm=1)
+    out["config3_advection_pipeline"] = {"ms": round(d * 1e3, 3), "samples_per_s": round(b / d, 1),
+                                         "farneback_pairs_per_s": round(b * 121 / d, 0),
+                                         "workload": f"raw [B={b},12,11,64,64] int16 -> u8 -> 121 Farneback pairs/sample -> "
+                                                     "weighted mean -> normalise -> 6 advected frames"}
+    return out
+
+
 def cpu_baseline(model_kwargs, t_frames, budget_s=20.0):
     """torch-CPU oracle train step (fwd + NMAE + bwd + Adam), B = 8, on this host's cores."""
     from oracle import conv3d_oracle as co
@@ -183,7 +221,7 @@ def main():
     for i in range(args.warmup):
         l = step()
         if i == 0:
-            first = float(l)
+            first = float(l.detach())
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -198,7 +236,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
-    last = float(last)
+    last = float(last.detach())
 
     if rank == 0:
         value = world * b * args.steps / elapsed
@@ -216,6 +254,8 @@ def main():
         }
         if not args.no_roofline and world == 1:
             out["roofline"] = measure_conv_roofline(b, t_frames, dev)
+            out["roofline"]["traffic_profile"] = "profiles/r01/pmc_hbm_traffic_bench_B32.json (FETCH_SIZE/WRITE_SIZE passes)"
+            out["hbm_bound_kernels"] = measure_hbm_kernels(model, opt, b, t_frames, dev)
         else:
             out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:
