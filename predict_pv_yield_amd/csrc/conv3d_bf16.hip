@@ -493,6 +493,13 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
   }
 }
 
+// two-waves-per-SIMD variant (conv3d_bf16_v2.hip)
+int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
+                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
+                              int n_rowblk, int n_colblk, int n_tchunk, int t_chunk, hipStream_t st);
+void launch_pack_weight_v2(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
+constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
+
 }  // namespace pv
 
 using namespace pv;
@@ -560,7 +567,8 @@ int pv_repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* dy, const uint16_t* y_rel
 size_t pv_conv3d_packed_weight_elems(int32_t k_channels) {
   int cpad = pv_bf16_cpad(k_channels);
   if (cpad <= 0) return 0;
-  return (size_t)27 * (cpad / 16) * 64 * 8;
+  // v1 fragments (32x32x16 A operands) followed by the v2 fragments (16x16x32, 32-channel contractions only)
+  return (size_t)27 * (cpad / 16) * 64 * 8 + (cpad == 32 ? V2_WEIGHT_ELEMS : 0);
 }
 
 int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int32_t c_in, int transpose_flip,
@@ -572,6 +580,7 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
   int ks = pv_bf16_cpad(kch) / 16;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(27 * ks * 2), dim3(256), 0, as_stream(stream), w, wp, c_out, c_in, ks,
                      transpose_flip ? 1 : 0);
+  if (ks == 2) launch_pack_weight_v2(w, wp + (size_t)27 * 2 * 64 * 8, c_out, c_in, transpose_flip, as_stream(stream));
   return check_launch("pv_conv3d_pack_weight_bf16");
 }
 
@@ -604,6 +613,9 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
+  if (cpad == 32 && !gate && !y_ncdhw)  // 32 -> 32 channel layers, NDHWC out: two-waves-per-SIMD kernel
+    return launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, n_rowblk,
+                                     n_colblk, n_tchunk, t_chunk, st);
 #define PV_LAUNCH_CONV(CP, HG, YN, OG)                                                                           \
   hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN, OG>), grid, dim3(256), 0, st, x, gate, wp, bias, y, out_gate, \
                      d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk,        \
