@@ -86,9 +86,11 @@ def test_conv3d_bf16_forward(device, case):
     torch.testing.assert_close(got, y_ref, rtol=1e-2, atol=2e-3)
     if co_ < 32:
         assert torch.count_nonzero(y[..., co_:]).item() == 0
-    # NCDHW epilogue (the flatten order fc1 consumes) gives the same numbers
+    # NCDHW epilogue (the flatten order fc1 consumes): same numbers up to the f32 accumulation order of the kernel
+    # variant that serves it (32 -> 32 NDHWC layers run the two-waves-per-SIMD 16x16x32 kernel)
     y2 = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), ci, co_, pad, relu=True, y_ncdhw=True)
-    assert torch.equal(y2.float().cpu(), got.contiguous())
+    torch.testing.assert_close(y2.float().cpu(), got.contiguous(), rtol=1e-2, atol=2e-3)
+    torch.testing.assert_close(y2.float().cpu(), y_ref, rtol=1e-2, atol=2e-3)
 
 
 @pytest.mark.parametrize("case", CASES)
