@@ -135,8 +135,9 @@ def measure_hbm_kernels(model, opt, batch_size, t_frames, dev):
     return out
 
 
-def cpu_baseline(model_kwargs, t_frames, budget_s=20.0):
-    """torch-CPU oracle train step (fwd + NMAE + bwd + Adam), B = 8, on this host's cores."""
+def cpu_baseline(model_kwargs, t_frames, budget_s=24.0):
+    """torch-CPU oracle train step (fwd + NMAE + bwd + Adam), B = 8, on this host's cores.  oneDNN's Conv3d does not
+    always scale to every hardware thread, so two thread counts share the budget and the faster one is reported."""
     from oracle import conv3d_oracle as co
     torch.manual_seed(518)
     kw = {k: v for k, v in model_kwargs.items() if k not in ("precision", "future_frames")}
@@ -146,16 +147,25 @@ def cpu_baseline(model_kwargs, t_frames, budget_s=20.0):
     sat = torch.randn(b, 11, t_frames, 64, 64, generator=g)
     pv = torch.rand(b, t_frames, 128, generator=g)
     opt = co.make_optimizer(m)
-    co.train_steps(m, sat, pv, 1, opt)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        co.train_steps(m, sat, pv, 1, opt)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 16:
-            break
-    return {"value": round(n * b / el, 2), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} train steps at B={b}, T={t_frames}, fp32, torch-CPU oracle (oracle/conv3d_oracle.py)"}
+    all_threads = torch.get_num_threads()
+    best = None
+    for threads in sorted({all_threads, max(1, all_threads // 4)}, reverse=True):
+        torch.set_num_threads(threads)
+        co.train_steps(m, sat, pv, 1, opt)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            co.train_steps(m, sat, pv, 1, opt)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or n >= 12:
+                break
+        rate = n * b / el
+        if best is None or rate > best[0]:
+            best = (rate, threads, n)
+    torch.set_num_threads(all_threads)
+    return {"value": round(best[0], 2), "unit": "samples/s", "cores": best[1], "kind": "port",
+            "sample": f"{best[2]} train steps at B={b}, T={t_frames}, fp32, torch-CPU oracle (oracle/conv3d_oracle.py); "
+                      f"best of {all_threads} and {max(1, all_threads // 4)} threads"}
 
 
 def main():
