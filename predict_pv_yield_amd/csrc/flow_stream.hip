@@ -204,7 +204,15 @@ __device__ __forceinline__ T remap_one(const T* __restrict__ img, int h, int w, 
   bool inside = (unsigned)ix < (unsigned)(w - 1) && (unsigned)iy < (unsigned)(h - 1);
   if (inside) {
     const T* p = img + (int64_t)iy * w + ix;
-    p00 = p[0]; p01 = p[1]; p10 = p[w]; p11 = p[w + 1];
+    if constexpr (sizeof(T) == 4) {
+      // the two taps of a row are adjacent: one 8-byte load each (4-byte aligned is all global_load_dwordx2 needs)
+      struct __attribute__((packed, aligned(4))) Pair { T a, b; };
+      const Pair r0 = *reinterpret_cast<const Pair*>(p);
+      const Pair r1 = *reinterpret_cast<const Pair*>(p + w);
+      p00 = r0.a; p01 = r0.b; p10 = r1.a; p11 = r1.b;
+    } else {
+      p00 = p[0]; p01 = p[1]; p10 = p[w]; p11 = p[w + 1];
+    }
   } else if (border_mode == PV_BORDER_REPLICATE) {
     int x0 = clampi(ix, 0, w - 1), x1 = clampi(ix + 1, 0, w - 1);
     int y0 = clampi(iy, 0, h - 1), y1 = clampi(iy + 1, 0, h - 1);
