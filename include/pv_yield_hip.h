@@ -253,6 +253,14 @@ int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_av
  * pv_adam_step_f32 keeps the shadow current. */
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 
+/* replaces: nn.Embedding(num_embeddings=940, embedding_dim=16)(id) and its backward
+ * (predict_pv_yield/models/conv3d/model_sat_nwp.py:149-151, 251-260).  ids: device int64[n_ids]; out-of-range ids give a
+ * zero row.  bwd overwrites dtable[n_rows, dim] with the per-row sums of dout (fixed order, no atomics). */
+int pv_embedding_fwd_f32(const float* table, const int64_t* ids, float* out, int32_t n_ids, int32_t dim,
+                         int32_t n_rows, void* stream);
+int pv_embedding_bwd_f32(const float* dout, const int64_t* ids, float* dtable, int32_t n_ids, int32_t dim,
+                         int32_t n_rows, void* stream);
+
 /* ---- loss + optimiser ----------------------------------------------------- */
 /* replaces: F.mse_loss / (y_hat−y).abs().mean() and WeightedLosses.get_mse_exp/get_mae_exp
  * (predict_pv_yield/models/base_model.py:98-103).  out: device f32[4] = {mse, nmae, mse_exp, mae_exp};

@@ -9,6 +9,7 @@ operators the reference calls -- F.conv3d, F.relu, F.linear, torch.cat, torch.op
 order of:
   Model.__init__ / cnn_output_size   predict_pv_yield/models/conv3d/model.py:18-105 (:74-78)
   Model.forward                      predict_pv_yield/models/conv3d/model.py:107-156
+  sat+nwp Model                      predict_pv_yield/models/conv3d/model_sat_nwp.py:14-270
   timestep arithmetic                predict_pv_yield/models/base_model.py:38-76
   loss / metrics                     predict_pv_yield/models/base_model.py:91-103
   optimiser                          predict_pv_yield/models/base_model.py:255-257
@@ -135,6 +136,95 @@ class OracleConv3dModel(nn.Module):
         acts.append(out)
         out = self.fc4(out).reshape(batch_size, self.forecast_len)
         return (out, acts) if return_activations else out
+
+
+class OracleConv3dSatNwpModel(nn.Module):
+    """Restatement of predict_pv_yield/models/conv3d/model_sat_nwp.py:14-270 (same attribute / state_dict names,
+    same join order: fc2 | yield history | pv_fc1 | nwp tower | id embedding).  Pinned against the reference
+    module's own source by tests/golden/make_conv3d_golden.py (case "sat_nwp*")."""
+
+    def __init__(self, include_pv_or_gsp_yield_history=True, include_nwp=True, forecast_minutes=30, history_minutes=60,
+                 number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=64, nwp_image_size_pixels=64,
+                 number_sat_channels=12, number_nwp_channels=10, fc1_output_features=128, fc2_output_features=128,
+                 fc3_output_features=64, output_variable="pv_yield", embedding_dem=16, include_pv_yield_history=True,
+                 include_future_satellite=True, emulate_bf16=False, batch_size=32):
+        super().__init__()
+        self.emulate_bf16 = emulate_bf16
+        self.batch_size = batch_size
+        self.include_pv_or_gsp_yield_history, self.include_nwp = include_pv_or_gsp_yield_history, include_nwp
+        self.include_pv_yield_history, self.include_future_satellite = include_pv_yield_history, include_future_satellite
+        self.embedding_dem = embedding_dem
+        self.number_of_conv3d_layers = number_of_conv3d_layers
+        self.output_variable = output_variable
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        t_sat = self.forecast_len_5 + self.history_len_5 + 1 if include_future_satellite else self.history_len_5 + 1
+        self.cnn_output_size = conv3d_channels * ((image_size_pixels - 2 * number_of_conv3d_layers) ** 2) * t_sat
+        self.nwp_cnn_output_size = (conv3d_channels * ((nwp_image_size_pixels - 2 * number_of_conv3d_layers) ** 2)
+                                    * (self.forecast_len_60 + self.history_len_60 + 1))
+
+        def tower(prefix, c_in):
+            for i in range(number_of_conv3d_layers):
+                setattr(self, f"{prefix}_conv{i}",
+                        nn.Conv3d(c_in if i == 0 else conv3d_channels, conv3d_channels, (3, 3, 3), padding=(1, 0, 0)))
+
+        tower("sat", number_sat_channels)
+        self.fc1 = nn.Linear(self.cnn_output_size, fc1_output_features)
+        self.fc2 = nn.Linear(fc1_output_features, fc2_output_features)
+        if include_nwp:
+            tower("nwp", number_nwp_channels)
+            self.nwp_fc1 = nn.Linear(self.nwp_cnn_output_size, fc1_output_features)
+            self.nwp_fc2 = nn.Linear(fc1_output_features, 128)
+        if embedding_dem:
+            self.pv_system_id_embedding = nn.Embedding(940, embedding_dem)
+        if include_pv_yield_history:
+            self.pv_fc1 = nn.Linear(self.number_of_pv_samples_per_batch * (self.history_len_5 + 1), 128)
+        fc3_in = fc2_output_features
+        if include_pv_or_gsp_yield_history:
+            fc3_in += self.number_of_samples_per_batch * (self.history_len_30 + 1)
+        if include_nwp:
+            fc3_in += 128
+        if embedding_dem:
+            fc3_in += embedding_dem
+        if include_pv_yield_history:
+            fc3_in += 128
+        self.fc3 = nn.Linear(fc3_in, fc3_output_features)
+        self.fc4 = nn.Linear(fc3_output_features, self.forecast_len)
+
+    def _tower(self, prefix, data, fc1, flat):
+        out = bf16_round(data) if self.emulate_bf16 else data
+        for i in range(self.number_of_conv3d_layers):
+            layer = getattr(self, f"{prefix}_conv{i}")
+            if self.emulate_bf16:
+                out = _RoundBF16.apply(F.relu(F.conv3d(out, _RoundWeightBF16.apply(layer.weight), layer.bias,
+                                                        padding=(1, 0, 0))))
+            else:
+                out = F.relu(layer(out))
+        out = out.reshape(data.shape[0], flat)
+        w = _RoundWeightBF16.apply(fc1.weight) if self.emulate_bf16 else fc1.weight
+        return F.relu(F.linear(out, w, fc1.bias))
+
+    def forward(self, sat_data, pv_yield=None, gsp_yield=None, nwp=None, ids=None):
+        """ids: pv.pv_system_row_number (output_variable pv_yield) or gsp.gsp_id (gsp_yield), [B, n]."""
+        sat_data = sat_data.float()
+        batch_size = sat_data.shape[0]
+        if not self.include_future_satellite:
+            sat_data = sat_data[:, :, : self.history_len_5 + 1]
+        out = F.relu(self.fc2(self._tower("sat", sat_data, self.fc1, self.cnn_output_size)))
+        if self.include_pv_or_gsp_yield_history:
+            src = gsp_yield if self.output_variable == "gsp_yield" else pv_yield
+            h = src[:, : self.history_len_30 + 1].nan_to_num(nan=0.0).float()
+            out = torch.cat((out, h.reshape(h.shape[0], h.shape[1] * h.shape[2])), dim=1)
+        if self.include_pv_yield_history:
+            h = pv_yield[:, : self.history_len_5 + 1, :128].nan_to_num(nan=0.0).float()
+            out = torch.cat((out, F.relu(self.pv_fc1(h.reshape(h.shape[0], h.shape[1] * h.shape[2])))), dim=1)
+        if self.include_nwp:
+            o = F.relu(self.nwp_fc2(self._tower("nwp", nwp.float(), self.nwp_fc1, self.nwp_cnn_output_size)))
+            out = torch.cat((out, o), dim=1)
+        if self.embedding_dem:
+            out = torch.cat((out, self.pv_system_id_embedding(ids[0 : self.batch_size, 0].long())), dim=1)
+        out = F.relu(self.fc3(out))
+        return self.fc4(out).reshape(batch_size, self.forecast_len)
 
 
 def weighted_losses_weights(forecast_length: int) -> torch.Tensor:

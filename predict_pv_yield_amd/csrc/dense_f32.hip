@@ -246,6 +246,27 @@ __global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __re
   }
 }
 
+// ---- embedding (nn.Embedding(940, 16) on pv_system_row_number / gsp_id, model_sat_nwp.py:149-151,251-260) ------------
+__global__ __launch_bounds__(256) void embedding_fwd_f32(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                                          float* __restrict__ out, int n_ids, int dim, int n_rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ids * dim) return;
+  int r = i / dim, c = i - r * dim;
+  long long id = ids[r];
+  out[i] = (id >= 0 && id < n_rows) ? table[(size_t)id * dim + c] : 0.f;
+}
+// dtable[v][c] = sum over the batch rows whose id == v (fixed order: deterministic, no atomics; the batch is tiny)
+__global__ __launch_bounds__(256) void embedding_bwd_f32(const float* __restrict__ dout, const int64_t* __restrict__ ids,
+                                                          float* __restrict__ dtable, int n_ids, int dim, int n_rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * dim) return;
+  int v = i / dim, c = i - v * dim;
+  float s = 0.f;
+  for (int r = 0; r < n_ids; ++r)
+    if (ids[r] == v) s += dout[(size_t)r * dim + c];
+  dtable[i] = s;
+}
+
 static long long fwd_k_chunk(long long k, int* k_splits) {
   // ~8k elements of K per block, at most 512 splits
   long long chunk = 8192;
@@ -372,6 +393,24 @@ int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_av
                      grad_bf16, exp_avg, exp_avg_sq, bf16_shadow, n, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-(lr / bc1)), grad_scale);
   return check_launch("pv_adam_step_bf16grad");
+}
+
+int pv_embedding_fwd_f32(const float* table, const int64_t* ids, float* out, int32_t n_ids, int32_t dim, int32_t n_rows,
+                         void* stream) {
+  PV_REQUIRE(table && ids && out, PV_EINVAL, "pv_embedding_fwd_f32: null pointer");
+  PV_REQUIRE(n_ids > 0 && dim > 0 && n_rows > 0, PV_EINVAL, "pv_embedding_fwd_f32: bad sizes");
+  hipLaunchKernelGGL(embedding_fwd_f32, dim3((unsigned)((n_ids * dim + 255) / 256)), dim3(256), 0, as_stream(stream), table,
+                     ids, out, n_ids, dim, n_rows);
+  return check_launch("pv_embedding_fwd_f32");
+}
+
+int pv_embedding_bwd_f32(const float* dout, const int64_t* ids, float* dtable, int32_t n_ids, int32_t dim, int32_t n_rows,
+                         void* stream) {
+  PV_REQUIRE(dout && ids && dtable, PV_EINVAL, "pv_embedding_bwd_f32: null pointer");
+  PV_REQUIRE(n_ids > 0 && dim > 0 && n_rows > 0, PV_EINVAL, "pv_embedding_bwd_f32: bad sizes");
+  hipLaunchKernelGGL(embedding_bwd_f32, dim3((unsigned)((n_rows * dim + 255) / 256)), dim3(256), 0, as_stream(stream), dout,
+                     ids, dtable, n_ids, dim, n_rows);
+  return check_launch("pv_embedding_bwd_f32");
 }
 
 }  // extern "C"

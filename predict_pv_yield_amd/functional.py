@@ -180,6 +180,26 @@ def linear_bf16(x, weight, bias, relu=False):
     return LinearBF16.apply(x, weight, bias, relu)
 
 
+class EmbeddingF32(torch.autograd.Function):
+    """nn.Embedding lookup (model_sat_nwp.py:251-260) as a gather kernel; backward = deterministic per-row sums."""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        ids = ids.to(device=table.device, dtype=torch.int64).contiguous()
+        ctx.save_for_backward(ids)
+        ctx.n_rows = table.shape[0]
+        return K.embedding_fwd(table.contiguous(), ids)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        return K.embedding_bwd(dout.contiguous(), ids, ctx.n_rows), None
+
+
+def embedding(table, ids):
+    return EmbeddingF32.apply(table, ids)
+
+
 # ---------------------------------------------------------------------------------------------
 # loss
 # ---------------------------------------------------------------------------------------------

@@ -401,3 +401,21 @@ def adam_step_bf16grad(param, grad_bf16, exp_avg, exp_avg_sq, step: int, lr=5e-4
     check(get_lib().pv_adam_step_bf16grad(ptr(param), ptr(grad_bf16), ptr(exp_avg), ptr(exp_avg_sq), ptr(bf16_shadow),
                                           param.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
                                           current_stream_ptr()), "pv_adam_step_bf16grad")
+
+
+def embedding_fwd(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    require_cuda(table, ids)
+    ids = ids.to(torch.int64).contiguous()
+    out = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    check(get_lib().pv_embedding_fwd_f32(ptr(table), ptr(ids), ptr(out), ids.numel(), table.shape[1], table.shape[0],
+                                         current_stream_ptr()), "pv_embedding_fwd_f32")
+    return out
+
+
+def embedding_bwd(dout: torch.Tensor, ids: torch.Tensor, n_rows: int) -> torch.Tensor:
+    require_cuda(dout, ids)
+    ids = ids.to(torch.int64).contiguous()
+    dtable = torch.empty((n_rows, dout.shape[1]), dtype=torch.float32, device=dout.device)
+    check(get_lib().pv_embedding_bwd_f32(ptr(dout), ptr(ids), ptr(dtable), ids.numel(), dout.shape[1], n_rows,
+                                         current_stream_ptr()), "pv_embedding_bwd_f32")
+    return dtable

@@ -24,6 +24,7 @@ import yaml
 # reference / third-party targets -> this package (used only if the original import fails)
 TARGET_ALIASES = {
     "predict_pv_yield.models.conv3d.model.Model": "predict_pv_yield_amd.models.conv3d.model.Model",
+    "predict_pv_yield.models.conv3d.model_sat_nwp.Model": "predict_pv_yield_amd.models.conv3d.model_sat_nwp.Model",
     "predict_pv_yield.models.baseline.last_value.Model": "predict_pv_yield_amd.models.baseline.last_value.Model",
     "predict_pv_yield.data.dataloader.NetCDFDataModule": "predict_pv_yield_amd.data.dataloader.NetCDFDataModule",
     "nowcasting_dataloader.datamodules.NetCDFDataModule": "predict_pv_yield_amd.data.dataloader.NetCDFDataModule",

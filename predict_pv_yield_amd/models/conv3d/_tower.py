@@ -1,0 +1,34 @@
+"""One Conv3D tower + its first fully-connected layer, shared by model.py (padding 0) and model_sat_nwp.py
+(padding (1,0,0), two towers).  Every FLOP runs in the gfx950 kernels behind include/pv_yield_hip.h."""
+import torch
+
+from ... import functional as Fn
+
+
+def bf16_tower_supported(c_in: int, channels: int, flat_features: int) -> bool:
+    """The MFMA path pads channels to 16 or 32 and streams fc1 in 8-element (16-byte) groups."""
+    return 16 < channels <= 32 and c_in <= 32 and flat_features % 8 == 0
+
+
+def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, padding, flat_features: int,
+                   use_bf16: bool) -> torch.Tensor:
+    """relu(fc1(flatten_NCDHW(relu(conv_n(... relu(conv_0(data))))))) — model.py:117-125 / model_sat_nwp.py:188-197,236-246."""
+    if not data.is_cuda:
+        raise RuntimeError("predict_pv_yield_amd Conv3D model runs on the MI355X only: move the module and the "
+                           "batch to cuda (there is no CPU fallback)")
+    batch_size = data.shape[0]
+    if use_bf16:
+        out = Fn.PackInputBF16.apply(data)
+        for i, layer in enumerate(convs):
+            last = i == len(convs) - 1
+            # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
+            out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, tuple(padding), relu=True, y_ncdhw=last,
+                                      x_is_relu_output=i > 0, dy_pregated=not last)
+            c_in = channels
+        out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
+        return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True)
+    out = data
+    for layer in convs:
+        out = Fn.conv3d_relu_f32(out, layer.weight, layer.bias, tuple(padding), relu=True)
+    out = out.reshape(batch_size, flat_features)
+    return Fn.linear_f32(out, fc1.weight, fc1.bias, relu=True)

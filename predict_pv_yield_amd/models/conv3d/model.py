@@ -98,7 +98,8 @@ class Model(BaseModel):
         return [self.sat_conv0] + [getattr(self, f"conv3d_{i + 1}") for i in range(self.number_of_conv3d_layers - 1)]
 
     def _bf16_supported(self) -> bool:
-        return 16 < self.conv3d_channels <= 32 and self.number_sat_channels <= 32 and self.cnn_output_size % 8 == 0
+        from ._tower import bf16_tower_supported
+        return bf16_tower_supported(self.number_sat_channels, self.conv3d_channels, self.cnn_output_size)
 
     def _satellite_input(self, x: BatchML) -> torch.Tensor:
         sat_data = x.satellite.data.float()  # [B, C, T, H, W]  (model.py:112-114)
@@ -111,30 +112,12 @@ class Model(BaseModel):
         if type(x) == dict:
             x = BatchML(**x)
         sat_data = self._satellite_input(x)
-        if not sat_data.is_cuda:
-            raise RuntimeError("predict_pv_yield_amd Conv3D model runs on the MI355X only: move the module and the "
-                               "batch to cuda (there is no CPU fallback)")
         from ... import functional as Fn
+        from ._tower import conv_tower_fc1
 
         batch_size = sat_data.shape[0]
-        convs = self._conv_layers()
-        if self.precision == "bf16" and self._bf16_supported():
-            out = Fn.PackInputBF16.apply(sat_data)
-            c_in = self.number_sat_channels
-            for i, layer in enumerate(convs):
-                last = i == len(convs) - 1
-                # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
-                out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, (0, 0, 0), relu=True, y_ncdhw=last,
-                                          x_is_relu_output=i > 0, dy_pregated=not last)
-                c_in = self.conv3d_channels
-            out = out.reshape(batch_size, self.cnn_output_size)  # NCDHW flatten order (model.py:122)
-            out = Fn.linear_bf16(out, self.fc1.weight, self.fc1.bias, relu=True)
-        else:
-            out = sat_data
-            for layer in convs:
-                out = Fn.conv3d_relu_f32(out, layer.weight, layer.bias, (0, 0, 0), relu=True)
-            out = out.reshape(batch_size, self.cnn_output_size)
-            out = Fn.linear_f32(out, self.fc1.weight, self.fc1.bias, relu=True)
+        out = conv_tower_fc1(sat_data, self._conv_layers(), self.fc1, self.number_sat_channels, self.conv3d_channels,
+                             (0, 0, 0), self.cnn_output_size, self.precision == "bf16" and self._bf16_supported())
         out = Fn.linear_f32(out, self.fc2.weight, self.fc2.bias, relu=True)
 
         if self.include_pv_yield:

@@ -1,5 +1,5 @@
 """Generates tests/golden/conv3d_small.npz by EXECUTING THE REFERENCE'S OWN MODULE SOURCE
-(/root/reference/predict_pv_yield/models/conv3d/model.py + base_model.py) on the CPU.
+(/root/reference/predict_pv_yield/models/conv3d/model.py, model_sat_nwp.py + base_model.py) on the CPU.
 
 Run here (the reference tree does not travel to the GPU box):   python tests/golden/make_conv3d_golden.py
 
@@ -133,6 +133,55 @@ def run_case(Model, kw, tag, out):
                                     model.number_of_samples_per_batch])
 
 
+SN = dict(include_pv_or_gsp_yield_history=False, include_nwp=True, forecast_minutes=60, history_minutes=60,
+          number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=10, nwp_image_size_pixels=10,
+          number_sat_channels=11, number_nwp_channels=10, fc1_output_features=16, fc2_output_features=16,
+          fc3_output_features=16, output_variable="gsp_yield", include_pv_yield_history=True)
+SN_PV = dict(SN, include_pv_or_gsp_yield_history=True, output_variable="pv_yield", include_future_satellite=False,
+             include_pv_yield_history=False,
+             forecast_minutes=30)
+
+
+def run_case_sat_nwp(Model, kw, tag, out):
+    """model_sat_nwp.Model on a 2-example batch: forward, 3 train steps (losses, gradient and parameter checksums)."""
+    torch.manual_seed(518)
+    model = Model(**kw)
+    t5 = kw["history_minutes"] // 5 + kw["forecast_minutes"] // 5 + 1
+    t30 = kw["history_minutes"] // 30 + kw["forecast_minutes"] // 30 + 1
+    t60 = int(np.ceil(kw["history_minutes"] / 60)) + kw["forecast_minutes"] // 60 + 1
+    g = torch.Generator().manual_seed(4321)
+    sat = torch.randn(2, 11, t5, kw["image_size_pixels"], kw["image_size_pixels"], generator=g)
+    pv = torch.rand(2, t5, 128, generator=g)
+    pv[0, 1, 3] = float("nan")                      # nan_to_num path (model_sat_nwp.py:206-226)
+    gsp = torch.rand(2, t30, 32, generator=g)
+    nwp = torch.randn(2, 10, t60, kw["nwp_image_size_pixels"], kw["nwp_image_size_pixels"], generator=g)
+    row = torch.randint(0, 940, (2, 128), generator=g)
+    gsp_id = torch.randint(1, 339, (2, 32), generator=g)
+    batch = {"satellite": {"data": sat}, "pv": {"pv_yield": pv, "pv_system_row_number": row},
+             "gsp": {"gsp_yield": gsp, "gsp_id": gsp_id}, "nwp": {"data": nwp}}
+    for k, v in dict(sat=sat, pv=pv, gsp=gsp, nwp=nwp, row=row, gsp_id=gsp_id).items():
+        out[f"{tag}/{k}"] = v.numpy()
+    for k, v in model.state_dict().items():
+        out[f"{tag}/init/{k}"] = v.numpy().copy()
+    out[f"{tag}/y_hat"] = model(batch).detach().numpy().copy()
+    opt = model.configure_optimizers()
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        if step == 0:
+            for k, p in model.named_parameters():
+                out[f"{tag}/grad/{k}"] = checksum(p.grad)
+        opt.step()
+        losses.append(float(loss.detach()))
+    for k, p in model.named_parameters():
+        out[f"{tag}/step3/{k}"] = checksum(p)
+    out[f"{tag}/losses"] = np.array(losses)
+    out[f"{tag}/attrs"] = np.array([model.cnn_output_size, model.nwp_cnn_output_size, model.forecast_len,
+                                    model.fc3.in_features])
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
@@ -140,6 +189,9 @@ def main():
     out = {}
     run_case(Model, KW, "sat_only", out)
     run_case(Model, KW_PV, "pv_nwp", out)
+    from predict_pv_yield.models.conv3d.model_sat_nwp import Model as SatNwpModel  # the reference's own source
+    run_case_sat_nwp(SatNwpModel, SN, "sat_nwp", out)
+    run_case_sat_nwp(SatNwpModel, SN_PV, "sat_nwp_pv", out)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB;", len(out), "arrays")
 

@@ -48,7 +48,7 @@ def test_argument_errors_without_gpu():
     lib = _lib.get_lib()
     # argument validation happens before any launch, so it can be exercised on a GPU-less box
     assert lib.pv_bf16_cpad(11) == 16 and lib.pv_bf16_cpad(32) == 32 and lib.pv_bf16_cpad(33) < 0
-    assert lib.pv_conv3d_packed_weight_elems(32) == 27 * 2 * 64 * 8
+    assert lib.pv_conv3d_packed_weight_elems(32) == 2 * 27 * 2 * 64 * 8   # v1 + v2 fragment orders
     rc = lib.pv_remap_bilinear_f32(None, 0, None, 0, None, 0, 0, 1, 1, 1.0, 4, 4, 0, 0.0, None)
     assert rc == -1 and b"null pointer" in lib.pv_last_error()
     p = _lib.FarnebackParams(0.5, 2, 40, 3, 5, 0.7, 0)

@@ -57,6 +57,49 @@ def test_oracle_matches_reference_module(tag, kw):
     np.testing.assert_array_equal(np.array(losses), g[f"{tag}/losses"])
 
 
+SN = dict(include_pv_or_gsp_yield_history=False, include_nwp=True, forecast_minutes=60, history_minutes=60,
+          number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=10, nwp_image_size_pixels=10,
+          number_sat_channels=11, number_nwp_channels=10, fc1_output_features=16, fc2_output_features=16,
+          fc3_output_features=16, output_variable="gsp_yield", include_pv_yield_history=True)
+SN_PV = dict(SN, include_pv_or_gsp_yield_history=True, output_variable="pv_yield", include_future_satellite=False,
+             include_pv_yield_history=False, forecast_minutes=30)
+
+
+def sat_nwp_case(g, tag, kw, **extra):
+    """(oracle model with the golden initial parameters, forward args, target yield) of one sat+nwp golden case."""
+    model = co.OracleConv3dSatNwpModel(**kw, **extra)
+    sd = {k[len(f"{tag}/init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/init/")}
+    assert list(sd) == list(model.state_dict())
+    model.load_state_dict(sd)
+    t = {k: torch.from_numpy(g[f"{tag}/{k}"]) for k in ("sat", "pv", "gsp", "nwp", "row", "gsp_id")}
+    gsp_out = kw["output_variable"] == "gsp_yield"
+    args = (t["sat"], t["pv"], t["gsp"], t["nwp"], t["gsp_id"] if gsp_out else t["row"])
+    return model, args, (t["gsp"] if gsp_out else t["pv"]), t
+
+
+@pytest.mark.parametrize("tag,kw", [("sat_nwp", SN), ("sat_nwp_pv", SN_PV)])
+def test_sat_nwp_oracle_matches_reference_module(tag, kw):
+    """model_sat_nwp.py executed from the reference's own source (golden) vs OracleConv3dSatNwpModel: bit-exact."""
+    g = np.load(GOLD)
+    model, args, yld, _ = sat_nwp_case(g, tag, kw)
+    assert [model.cnn_output_size, model.nwp_cnn_output_size, model.forecast_len, model.fc3.in_features] == list(g[f"{tag}/attrs"])
+    assert np.array_equal(model(*args).detach().numpy(), g[f"{tag}/y_hat"])
+    opt = co.make_optimizer(model)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        _, nmae, _, _ = co.forecast_losses(model(*args), co.select_target(yld, model.forecast_len))
+        nmae.backward()
+        if step == 0:
+            for k, p in model.named_parameters():
+                np.testing.assert_array_equal(checksum(p.grad), g[f"{tag}/grad/{k}"], err_msg=k)
+        opt.step()
+        losses.append(float(nmae.detach()))
+    for k, p in model.named_parameters():
+        np.testing.assert_array_equal(checksum(p), g[f"{tag}/step3/{k}"], err_msg=k)
+    np.testing.assert_array_equal(np.array(losses), g[f"{tag}/losses"])
+
+
 def test_timestep_arithmetic_matches_base_model():
     # base_model.py:41-73; the default Model() sees T = 19, BASELINE's "12 -> 6" is history_minutes = 55 (T = 18)
     d = co.timestep_arithmetic(60, 30)
