@@ -167,6 +167,42 @@ int pv_conv3d_bwd_data_f32(const float* dy, const float* y_relu_mask, const floa
 int pv_conv3d_bwd_weight_f32(const float* x, const float* dy, const float* y_relu_mask,
                              float* dw, float* dbias, const pv_conv3d_dims* d, void* stream);
 
+/* ---- general Conv3D / MaxPool3d / MSE (optical-flow notebook model, Conv3dMaxPool) ---------------- */
+/* Geometry of one Conv3D or MaxPool3d with kernel extents 1..3, any stride, symmetric zero (conv) / -inf (pool)
+ * padding 0..2, dilation 1, groups 1.  Output extent = (in + 2*pad - k) / stride + 1 (floor).
+ * replaces: nn.Conv3d(kernel_size=(2,3,3), padding=(0,1,1)[, stride=(1,2,2)]) of LitAutoEncoder
+ * (notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:969-985) and nn.MaxPool3d(3, stride=(1,2,2), padding=1)
+ * (predict_pv_yield/models/perceiver/perceiver_conv3d_nwp_sat.py:53-57; there c_out is ignored, set it to c_in). */
+typedef struct pv_conv3d_geom {
+  int32_t batch;
+  int32_t c_in, c_out;
+  int32_t t_in, h_in, w_in;
+  int32_t k_t, k_h, k_w;
+  int32_t stride_t, stride_h, stride_w;
+  int32_t pad_t, pad_h, pad_w;
+} pv_conv3d_geom;
+
+int pv_conv3d_general_out_extent(const pv_conv3d_geom* d, int32_t* t_out, int32_t* h_out, int32_t* w_out);
+/* y[B,Co,To,Ho,Wo] = conv3d(x[B,Ci,Ti,Hi,Wi], w[Co,Ci,kt,kh,kw], stride, padding) + bias, optional fused ReLU. */
+int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                              const pv_conv3d_geom* d, int relu, void* stream);
+/* dx from dy ⊙ (y_relu_mask > 0 if given); `d` describes the FORWARD conv. */
+int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w, float* dx,
+                                   const pv_conv3d_geom* d, void* stream);
+/* dw[Co,Ci,kt,kh,kw], dbias[Co] (either may be NULL); split over position slabs held in `ws`, summed in slab order.
+ * Kernel extents (2,3,3), (3,3,3), (1,3,3), (1,1,1). */
+int pv_conv3d_general_bwd_weight_workspace_bytes(const pv_conv3d_geom* d, size_t* bytes);
+int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const float* y_relu_mask, float* dw,
+                                     float* dbias, const pv_conv3d_geom* d, void* ws, size_t ws_bytes,
+                                     void* stream);
+/* MaxPool3d over x[B*C planes][Ti,Hi,Wi]; argmax (may be NULL) = flat winner offset inside the plane stack, first
+ * maximum wins, NaN propagates (torch CPU semantics).  bwd overwrites dx by gathering dy through argmax. */
+int pv_maxpool3d_fwd_f32(const float* x, float* y, int32_t* argmax, const pv_conv3d_geom* d, void* stream);
+int pv_maxpool3d_bwd_f32(const float* dy, const int32_t* argmax, float* dx, const pv_conv3d_geom* d, void* stream);
+/* replaces: F.mse_loss(y_hat, y) (13_…ipynb:1008).  out: device f32[1]; grad (may be NULL) = 2 (y_hat-y)/n * grad_scale */
+int pv_mse_loss_f32(const float* y_hat, const float* y, int64_t n, float grad_scale, float* out, float* grad,
+                    void* stream);
+
 /* ---- bf16 MFMA path (activations NDHWC bf16, channel count padded) ------ */
 /* Channel padding used by the bf16 path for a layer with c real channels. */
 int pv_bf16_cpad(int32_t c);   /* 16 for c<=16, 32 for c<=32, else PV_ESIZE */

@@ -227,6 +227,51 @@ class OracleConv3dSatNwpModel(nn.Module):
         return self.fc4(out).reshape(batch_size, self.forecast_len)
 
 
+class OracleConv3dMaxPool(nn.Module):
+    """predict_pv_yield/models/perceiver/perceiver_conv3d_nwp_sat.py:42-57: Conv3d(k 3, pad 1) -> MaxPool3d(3, stride
+    (1,2,2), pad 1).  Pinned by tests/golden/make_flow_model_golden.py (the reference class itself, under stubs)."""
+
+    def __init__(self, out_channels: int, in_channels: int):
+        super().__init__()
+        self.sat_conv3d = nn.Conv3d(in_channels, out_channels, kernel_size=(3, 3, 3), padding=(1, 1, 1))
+        self.sat_maxpool = nn.MaxPool3d(3, stride=(1, 2, 2), padding=(1, 1, 1))
+
+    def forward(self, x):
+        return self.sat_maxpool(self.sat_conv3d(x))
+
+
+class OracleLitAutoEncoder(nn.Module):
+    """Restatement of LitAutoEncoder, notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:962-1027 (forward,
+    mse loss, Adam lr 1e-4).  Pinned by tests/golden/make_flow_model_golden.py, which executes the notebook cell."""
+
+    def __init__(self):
+        super().__init__()
+        k, p = (2, 3, 3), (0, 1, 1)
+        self.conv = nn.Sequential(
+            nn.Conv3d(2, 16, k, padding=p), nn.ReLU(), nn.Conv3d(16, 32, k, padding=p), nn.ReLU(),
+            nn.Conv3d(32, 32, k, padding=p), nn.ReLU(), nn.Conv3d(32, 1, k, padding=p, stride=(1, 2, 2)))
+
+    def forward(self, history, flow_prediction, horizon):
+        images = torch.cat((history, flow_prediction.unsqueeze(1)), dim=1)
+        b, n, h, w = images.shape
+        hz = horizon.view(-1, 1, 1, 1, 1).expand(b, 1, n, h, w)
+        return self.conv(torch.cat((images.unsqueeze(1), hz), dim=1))
+
+    def loss(self, history, flow_prediction, horizon, target):
+        return F.mse_loss(self(history, flow_prediction, horizon).squeeze(), target)
+
+    def train_steps(self, history, flow_prediction, horizon, target, n_steps=1):
+        opt = torch.optim.Adam(self.parameters(), lr=0.0001)
+        losses = []
+        for _ in range(n_steps):
+            opt.zero_grad()
+            loss = self.loss(history, flow_prediction, horizon, target)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return losses
+
+
 def weighted_losses_weights(forecast_length: int) -> torch.Tensor:
     """nowcasting_utils WeightedLosses: w_i = exp(-ln2 * i), normalised to mean 1 (f32)."""
     w = torch.FloatTensor([math.exp(-math.log(2) * i) for i in range(forecast_length)])

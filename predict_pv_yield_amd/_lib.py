@@ -37,9 +37,22 @@ class Conv3dDims(ctypes.Structure):
         return (self.t_in + 2 * self.pad_t - 2, self.h_in + 2 * self.pad_h - 2, self.w_in + 2 * self.pad_w - 2)
 
 
+class Conv3dGeom(ctypes.Structure):
+    """struct pv_conv3d_geom: kernel extents 1..3, stride, padding."""
+    _fields_ = [(n, c_i32) for n in ("batch", "c_in", "c_out", "t_in", "h_in", "w_in", "k_t", "k_h", "k_w",
+                                     "stride_t", "stride_h", "stride_w", "pad_t", "pad_h", "pad_w")]
+
+    def out_shape(self):
+        return ((self.t_in + 2 * self.pad_t - self.k_t) // self.stride_t + 1,
+                (self.h_in + 2 * self.pad_h - self.k_h) // self.stride_h + 1,
+                (self.w_in + 2 * self.pad_w - self.k_w) // self.stride_w + 1)
+
+
 # name -> argtypes; every symbol declared in include/pv_yield_hip.h (tests/test_abi.py checks both ways)
 _PFB = ctypes.POINTER(FarnebackParams)
 _PCD = ctypes.POINTER(Conv3dDims)
+_PCG = ctypes.POINTER(Conv3dGeom)
+_PI32 = ctypes.POINTER(c_i32)
 SIGNATURES = {
     "pv_abi_version": [],
     "pv_last_error": [],
@@ -76,6 +89,14 @@ SIGNATURES = {
                                   c_i32, c_vp],
     "pv_linear_wgrad_bf16out": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_adam_step_bf16grad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
+    "pv_conv3d_general_out_extent": [_PCG, _PI32, _PI32, _PI32],
+    "pv_conv3d_general_fwd_f32": [c_vp, c_vp, c_vp, c_vp, _PCG, c_int, c_vp],
+    "pv_conv3d_general_bwd_data_f32": [c_vp, c_vp, c_vp, c_vp, _PCG, c_vp],
+    "pv_conv3d_general_bwd_weight_workspace_bytes": [_PCG, ctypes.POINTER(c_sz)],
+    "pv_conv3d_general_bwd_weight_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCG, c_vp, c_sz, c_vp],
+    "pv_maxpool3d_fwd_f32": [c_vp, c_vp, c_vp, _PCG, c_vp],
+    "pv_maxpool3d_bwd_f32": [c_vp, c_vp, c_vp, _PCG, c_vp],
+    "pv_mse_loss_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
     "pv_embedding_fwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],

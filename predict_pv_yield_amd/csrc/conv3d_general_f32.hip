@@ -1,0 +1,530 @@
+// General Conv3D (any kernel extent up to 3x3x3, any stride, any symmetric padding) in exact fp32 on the reference
+// layout NCDHW, plus MaxPool3d and the mean-squared-error loss.
+// replaces: the nn.Conv3d stack of the optical-flow notebook model
+//   notebooks/13_3d_conv_with_optical_flow_predictions.ipynb:969-1027 (LitAutoEncoder: kernel (2,3,3), padding (0,1,1),
+//   last layer stride (1,2,2); F.mse_loss; Adam lr 1e-4)
+// and nn.MaxPool3d(3, stride=(1,2,2), padding=1) of Conv3dMaxPool
+//   predict_pv_yield/models/perceiver/perceiver_conv3d_nwp_sat.py:42-57.
+// Direct convolution on the f32 VALU, one FMA chain per output in (ci, kt, kh, kw) order; weights broadcast from LDS.
+#include "pv_common.h"
+
+namespace pv {
+
+constexpr int GCO = 16;  // channels per thread (fwd: output channels, dgrad: input channels)
+
+struct Geom {
+  int c_in, c_out, t_in, h_in, w_in, t_out, h_out, w_out;
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+};
+
+// One thread = one output voxel x GCO output channels.  KT/KH/KW compile-time (0 = runtime extents from g).
+template <int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void conv3d_general_fwd_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              Geom g, int relu) {
+  extern __shared__ float wl[];  // [c_in][taps][GCO]
+  const int kt_n = KT ? KT : g.kt, kh_n = KH ? KH : g.kh, kw_n = KW ? KW : g.kw;
+  const int taps = kt_n * kh_n * kw_n;
+  const int co0 = blockIdx.y * GCO;
+  const int b = blockIdx.z;
+  for (int i = threadIdx.x; i < g.c_in * taps * GCO; i += blockDim.x) {
+    int j = i % GCO;
+    int tap = (i / GCO) % taps;
+    int ci = i / (GCO * taps);
+    int co = co0 + j;
+    wl[i] = co < g.c_out ? w[((size_t)co * g.c_in + ci) * taps + tap] : 0.f;
+  }
+  __syncthreads();
+  const int plane_out = g.h_out * g.w_out;
+  const int vox_out = g.t_out * plane_out;
+  const size_t plane_in = (size_t)g.h_in * g.w_in;
+  const size_t vox_in = (size_t)g.t_in * plane_in;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vox_out; v += gridDim.x * blockDim.x) {
+    int to = v / plane_out;
+    int r = v - to * plane_out;
+    int ho = r / g.w_out;
+    int wo = r - ho * g.w_out;
+    float acc[GCO];
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) acc[j] = (bias && co0 + j < g.c_out) ? bias[co0 + j] : 0.f;
+    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+    for (int ci = 0; ci < g.c_in; ++ci) {
+      const float* xc = x + ((size_t)b * g.c_in + ci) * vox_in;
+      const float* wc = wl + (size_t)ci * taps * GCO;
+#pragma unroll
+      for (int kt = 0; kt < kt_n; ++kt) {
+        int ti = t0 + kt;
+        bool t_ok = (unsigned)ti < (unsigned)g.t_in;
+#pragma unroll
+        for (int kh = 0; kh < kh_n; ++kh) {
+          int hi = h0 + kh;
+          bool h_ok = t_ok && (unsigned)hi < (unsigned)g.h_in;
+#pragma unroll
+          for (int kw = 0; kw < kw_n; ++kw) {
+            int wi = w0 + kw;
+            float xv = 0.f;
+            if (h_ok && (unsigned)wi < (unsigned)g.w_in) xv = xc[(size_t)ti * plane_in + (size_t)hi * g.w_in + wi];
+            const float* wt = wc + ((kt * kh_n + kh) * kw_n + kw) * GCO;
+#pragma unroll
+            for (int j = 0; j < GCO; ++j) acc[j] = fmaf(xv, wt[j], acc[j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) {
+      if (co0 + j < g.c_out) {
+        float o = acc[j];
+        if (relu) o = o > 0.f ? o : 0.f;
+        y[((size_t)b * g.c_out + co0 + j) * vox_out + v] = o;
+      }
+    }
+  }
+}
+
+// dgrad, gather form: dx[b,ci,ti,hi,wi] = sum_{co,taps : to*st - pt + kt == ti ...} dy'[b,co,to,ho,wo] * w[co,ci,tap],
+// dy' = dy gated by (gate > 0) when the forward was followed by a ReLU.  One thread = one dx voxel x GCO input channels.
+template <int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __restrict__ dy,
+                                                                const float* __restrict__ gate,
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                Geom g) {
+  extern __shared__ float wl[];  // [c_out][taps][GCO]
+  const int kt_n = KT ? KT : g.kt, kh_n = KH ? KH : g.kh, kw_n = KW ? KW : g.kw;
+  const int taps = kt_n * kh_n * kw_n;
+  const int ci0 = blockIdx.y * GCO;
+  const int b = blockIdx.z;
+  for (int i = threadIdx.x; i < g.c_out * taps * GCO; i += blockDim.x) {
+    int j = i % GCO;
+    int tap = (i / GCO) % taps;
+    int co = i / (GCO * taps);
+    int ci = ci0 + j;
+    wl[i] = ci < g.c_in ? w[((size_t)co * g.c_in + ci) * taps + tap] : 0.f;
+  }
+  __syncthreads();
+  const int plane_in = g.h_in * g.w_in;
+  const int vox_in = g.t_in * plane_in;
+  const size_t plane_out = (size_t)g.h_out * g.w_out;
+  const size_t vox_out = (size_t)g.t_out * plane_out;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < vox_in; v += gridDim.x * blockDim.x) {
+    int ti = v / plane_in;
+    int r = v - ti * plane_in;
+    int hi = r / g.w_in;
+    int wi = r - hi * g.w_in;
+    float acc[GCO];
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) acc[j] = 0.f;
+    for (int co = 0; co < g.c_out; ++co) {
+      const float* dc = dy + ((size_t)b * g.c_out + co) * vox_out;
+      const float* gc = gate ? gate + ((size_t)b * g.c_out + co) * vox_out : nullptr;
+      const float* wc = wl + (size_t)co * taps * GCO;
+#pragma unroll
+      for (int kt = 0; kt < kt_n; ++kt) {
+        int nt = ti + g.pt - kt;
+        int to = nt / g.st;
+        bool t_ok = nt >= 0 && to * g.st == nt && to < g.t_out;
+#pragma unroll
+        for (int kh = 0; kh < kh_n; ++kh) {
+          int nh = hi + g.ph - kh;
+          int ho = nh / g.sh;
+          bool h_ok = t_ok && nh >= 0 && ho * g.sh == nh && ho < g.h_out;
+#pragma unroll
+          for (int kw = 0; kw < kw_n; ++kw) {
+            int nw = wi + g.pw - kw;
+            int wo = nw / g.sw;
+            float d = 0.f;
+            if (h_ok && nw >= 0 && wo * g.sw == nw && wo < g.w_out) {
+              size_t off = (size_t)to * plane_out + (size_t)ho * g.w_out + wo;
+              d = dc[off];
+              if (gc && !(gc[off] > 0.f)) d = 0.f;
+            }
+            const float* wt = wc + ((kt * kh_n + kh) * kw_n + kw) * GCO;
+#pragma unroll
+            for (int j = 0; j < GCO; ++j) acc[j] = fmaf(d, wt[j], acc[j]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GCO; ++j)
+      if (ci0 + j < g.c_in) dx[((size_t)b * g.c_in + ci0 + j) * vox_in + v] = acc[j];
+  }
+}
+
+// wgrad: block = (ci, group of WCO output channels, slab of positions); thread-private taps x WCO partial sums, then a
+// deterministic block reduction into slabs[slab][co][ci][tap]; wgrad_reduce adds the slabs in index order.
+constexpr int WCO = 4;
+
+template <int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void conv3d_general_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ gate, float* __restrict__ slabs,
+                                                                Geom g, int batch, int n_slabs) {
+  constexpr int TAPS = KT * KH * KW;
+  const int ci = blockIdx.x;
+  const int co0 = blockIdx.y * WCO;
+  const int slab = blockIdx.z;
+  const int plane_out = g.h_out * g.w_out;
+  const int vox_out = g.t_out * plane_out;
+  const size_t plane_in = (size_t)g.h_in * g.w_in;
+  const size_t vox_in = (size_t)g.t_in * plane_in;
+  float acc[WCO][TAPS];
+#pragma unroll
+  for (int j = 0; j < WCO; ++j)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc[j][k] = 0.f;
+
+  const long long total = (long long)batch * vox_out;
+  const long long per = (total + n_slabs - 1) / n_slabs;
+  const long long i0 = (long long)slab * per;
+  const long long i1 = i0 + per < total ? i0 + per : total;
+  for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    int b = (int)(i / vox_out);
+    int v = (int)(i - (long long)b * vox_out);
+    int to = v / plane_out;
+    int r = v - to * plane_out;
+    int ho = r / g.w_out;
+    int wo = r - ho * g.w_out;
+    float d[WCO];
+#pragma unroll
+    for (int j = 0; j < WCO; ++j) {
+      float dv = 0.f;
+      if (co0 + j < g.c_out) {
+        size_t off = ((size_t)b * g.c_out + co0 + j) * vox_out + v;
+        dv = dy[off];
+        if (gate && !(gate[off] > 0.f)) dv = 0.f;
+      }
+      d[j] = dv;
+    }
+    const float* xc = x + ((size_t)b * g.c_in + ci) * vox_in;
+    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      int ti = t0 + kt;
+      bool t_ok = (unsigned)ti < (unsigned)g.t_in;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        int hi = h0 + kh;
+        bool h_ok = t_ok && (unsigned)hi < (unsigned)g.h_in;
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          int wi = w0 + kw;
+          float xv = 0.f;
+          if (h_ok && (unsigned)wi < (unsigned)g.w_in) xv = xc[(size_t)ti * plane_in + (size_t)hi * g.w_in + wi];
+#pragma unroll
+          for (int j = 0; j < WCO; ++j) acc[j][(kt * KH + kh) * KW + kw] = fmaf(d[j], xv, acc[j][(kt * KH + kh) * KW + kw]);
+        }
+      }
+    }
+  }
+  __shared__ float red[4][WCO * TAPS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < WCO; ++j)
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) {
+      float v = acc[j][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][j * TAPS + k] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < WCO * TAPS) {
+    int j = threadIdx.x / TAPS, k = threadIdx.x % TAPS;
+    if (co0 + j < g.c_out) {
+      float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      slabs[(((size_t)slab * g.c_out + co0 + j) * g.c_in + ci) * TAPS + k] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_f32(const float* __restrict__ slabs, float* __restrict__ out, int n,
+                                                       int n_slabs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * n + i];
+  out[i] = s;
+}
+
+// dbias[co] = sum over (b, voxels) of dy (gated); one block per channel, fixed order
+__global__ __launch_bounds__(256) void conv3d_general_dbias_f32(const float* __restrict__ dy, const float* __restrict__ gate,
+                                                                float* __restrict__ db, int batch, int c_out, int vox_out) {
+  const int co = blockIdx.x;
+  float s = 0.f;
+  const long long total = (long long)batch * vox_out;
+  for (long long i = threadIdx.x; i < total; i += blockDim.x) {
+    int b = (int)(i / vox_out);
+    int v = (int)(i - (long long)b * vox_out);
+    size_t off = ((size_t)b * c_out + co) * vox_out + v;
+    float d = dy[off];
+    if (gate && !(gate[off] > 0.f)) d = 0.f;
+    s += d;
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) db[co] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---- MaxPool3d -------------------------------------------------------------------------------------------------
+// Window scan order (kt, kh, kw) ascending, update on "val > max || isnan(val)": the FIRST maximum wins and NaN
+// propagates, as in torch's CPU max_pool3d; idx = flat (t*H + h)*W + w of the winner inside its input plane stack.
+__global__ __launch_bounds__(256) void maxpool3d_fwd_f32(const float* __restrict__ x, float* __restrict__ y,
+                                                         int32_t* __restrict__ idx, long long n_out, Geom g) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int plane_out = g.h_out * g.w_out;
+  const int vox_out = g.t_out * plane_out;
+  const long long p = i / vox_out;  // (b, c) plane stack
+  int v = (int)(i - p * vox_out);
+  int to = v / plane_out;
+  int r = v - to * plane_out;
+  int ho = r / g.w_out;
+  int wo = r - ho * g.w_out;
+  const float* xp = x + (size_t)p * g.t_in * g.h_in * g.w_in;
+  float best = -INFINITY;
+  int best_i = -1;
+  for (int kt = 0; kt < g.kt; ++kt) {
+    int ti = to * g.st - g.pt + kt;
+    if ((unsigned)ti >= (unsigned)g.t_in) continue;
+    for (int kh = 0; kh < g.kh; ++kh) {
+      int hi = ho * g.sh - g.ph + kh;
+      if ((unsigned)hi >= (unsigned)g.h_in) continue;
+      for (int kw = 0; kw < g.kw; ++kw) {
+        int wi = wo * g.sw - g.pw + kw;
+        if ((unsigned)wi >= (unsigned)g.w_in) continue;
+        int off = (ti * g.h_in + hi) * g.w_in + wi;
+        float val = xp[off];
+        if (best_i < 0 || val > best || val != val) {
+          best = val;
+          best_i = off;
+        }
+      }
+    }
+  }
+  y[i] = best;
+  if (idx) idx[i] = best_i;
+}
+
+// dx[p, off] = sum of dy over the output windows whose winner is off (gather: deterministic, no atomics)
+__global__ __launch_bounds__(256) void maxpool3d_bwd_f32(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                         float* __restrict__ dx, long long n_in, Geom g) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  const int plane_in = g.h_in * g.w_in;
+  const int vox_in = g.t_in * plane_in;
+  const long long p = i / vox_in;
+  int off = (int)(i - p * vox_in);
+  int ti = off / plane_in;
+  int r = off - ti * plane_in;
+  int hi = r / g.w_in;
+  int wi = r - hi * g.w_in;
+  const size_t base = (size_t)p * g.t_out * g.h_out * g.w_out;
+  float s = 0.f;
+  for (int kt = 0; kt < g.kt; ++kt) {
+    int nt = ti + g.pt - kt;
+    int to = nt / g.st;
+    if (nt < 0 || to * g.st != nt || to >= g.t_out) continue;
+    for (int kh = 0; kh < g.kh; ++kh) {
+      int nh = hi + g.ph - kh;
+      int ho = nh / g.sh;
+      if (nh < 0 || ho * g.sh != nh || ho >= g.h_out) continue;
+      for (int kw = 0; kw < g.kw; ++kw) {
+        int nw = wi + g.pw - kw;
+        int wo = nw / g.sw;
+        if (nw < 0 || wo * g.sw != nw || wo >= g.w_out) continue;
+        size_t o = base + ((size_t)to * g.h_out + ho) * g.w_out + wo;
+        if (idx[o] == off) s += dy[o];
+      }
+    }
+  }
+  dx[i] = s;
+}
+
+// ---- mean squared error ------------------------------------------------------------------------------------------
+// out[0] = mean((y_hat - y)^2) with a fixed-order single-block reduction (f64 partials); grad = 2 (y_hat - y) / n * scale
+__global__ __launch_bounds__(1024) void mse_loss_f32(const float* __restrict__ y_hat, const float* __restrict__ y,
+                                                     long long n, float grad_scale, float* __restrict__ out,
+                                                     float* __restrict__ grad) {
+  double s = 0.0;
+  const float gs = 2.0f * grad_scale / (float)n;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+    float d = y_hat[i] - y[i];
+    s += (double)d * (double)d;
+    if (grad) grad[i] = d * gs;
+  }
+  __shared__ double red[16];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    out[0] = (float)(t / (double)n);
+  }
+}
+
+static int make_geom(const pv_conv3d_geom* d, Geom* g, const char* who) {
+  PV_REQUIRE(d, PV_EINVAL, "%s: null geometry", who);
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_out > 0 && d->t_in > 0 && d->h_in > 0 && d->w_in > 0, PV_EINVAL,
+             "%s: non-positive dimension", who);
+  PV_REQUIRE(d->k_t >= 1 && d->k_t <= 3 && d->k_h >= 1 && d->k_h <= 3 && d->k_w >= 1 && d->k_w <= 3, PV_ESIZE,
+             "%s: kernel extents must be 1..3", who);
+  PV_REQUIRE(d->stride_t >= 1 && d->stride_h >= 1 && d->stride_w >= 1, PV_EINVAL, "%s: stride must be >= 1", who);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_h >= 0 && d->pad_w >= 0 && d->pad_t <= 2 && d->pad_h <= 2 && d->pad_w <= 2, PV_EINVAL,
+             "%s: padding must be 0..2", who);
+  PV_REQUIRE(d->t_in + 2 * d->pad_t >= d->k_t && d->h_in + 2 * d->pad_h >= d->k_h && d->w_in + 2 * d->pad_w >= d->k_w,
+             PV_ESIZE, "%s: input smaller than the kernel", who);
+  g->c_in = d->c_in, g->c_out = d->c_out, g->t_in = d->t_in, g->h_in = d->h_in, g->w_in = d->w_in;
+  g->kt = d->k_t, g->kh = d->k_h, g->kw = d->k_w, g->st = d->stride_t, g->sh = d->stride_h, g->sw = d->stride_w;
+  g->pt = d->pad_t, g->ph = d->pad_h, g->pw = d->pad_w;
+  g->t_out = (d->t_in + 2 * d->pad_t - d->k_t) / d->stride_t + 1;
+  g->h_out = (d->h_in + 2 * d->pad_h - d->k_h) / d->stride_h + 1;
+  g->w_out = (d->w_in + 2 * d->pad_w - d->k_w) / d->stride_w + 1;
+  return PV_OK;
+}
+
+static int wgrad_slabs(const Geom& g, int batch) {
+  const long long total = (long long)batch * g.t_out * g.h_out * g.w_out;
+  const long long blocks = (long long)g.c_in * ((g.c_out + WCO - 1) / WCO);
+  long long n = (4096 + blocks - 1) / blocks;                 // aim at >= 4096 blocks ...
+  const long long cap = (total + 4095) / 4096;                // ... of at least 4096 positions each
+  if (n > cap) n = cap;
+  if (n > 256) n = 256;
+  return n < 1 ? 1 : (int)n;
+}
+
+}  // namespace pv
+
+using namespace pv;
+
+#define PV_DISPATCH_K(KERNEL, ...)                                                                         \
+  do {                                                                                                     \
+    if (g.kt == 2 && g.kh == 3 && g.kw == 3) KERNEL<2, 3, 3> __VA_ARGS__;                                  \
+    else if (g.kt == 3 && g.kh == 3 && g.kw == 3) KERNEL<3, 3, 3> __VA_ARGS__;                             \
+    else if (g.kt == 1 && g.kh == 3 && g.kw == 3) KERNEL<1, 3, 3> __VA_ARGS__;                             \
+    else if (g.kt == 1 && g.kh == 1 && g.kw == 1) KERNEL<1, 1, 1> __VA_ARGS__;                             \
+    else KERNEL<0, 0, 0> __VA_ARGS__;                                                                      \
+  } while (0)
+
+extern "C" {
+
+int pv_conv3d_general_out_extent(const pv_conv3d_geom* d, int32_t* t_out, int32_t* h_out, int32_t* w_out) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_conv3d_general_out_extent");
+  if (rc) return rc;
+  if (t_out) *t_out = g.t_out;
+  if (h_out) *h_out = g.h_out;
+  if (w_out) *w_out = g.w_out;
+  return PV_OK;
+}
+
+int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias, float* y, const pv_conv3d_geom* d,
+                              int relu, void* stream) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_conv3d_general_fwd_f32");
+  if (rc) return rc;
+  PV_REQUIRE(x && w && y, PV_EINVAL, "pv_conv3d_general_fwd_f32: null pointer");
+  const size_t lds = (size_t)g.c_in * g.kt * g.kh * g.kw * GCO * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_conv3d_general_fwd_f32: c_in=%d too large for the LDS weight tile", g.c_in);
+  const int vox = g.t_out * g.h_out * g.w_out;
+  dim3 grid((unsigned)std::min((vox + 255) / 256, 4096), (unsigned)((g.c_out + GCO - 1) / GCO), (unsigned)d->batch);
+  PV_DISPATCH_K(conv3d_general_fwd_f32, <<<grid, dim3(256), lds, as_stream(stream)>>>(x, w, bias, y, g, relu ? 1 : 0));
+  return check_launch("pv_conv3d_general_fwd_f32");
+}
+
+int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w, float* dx,
+                                   const pv_conv3d_geom* d, void* stream) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_conv3d_general_bwd_data_f32");
+  if (rc) return rc;
+  PV_REQUIRE(dy && w && dx, PV_EINVAL, "pv_conv3d_general_bwd_data_f32: null pointer");
+  const size_t lds = (size_t)g.c_out * g.kt * g.kh * g.kw * GCO * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_conv3d_general_bwd_data_f32: c_out=%d too large for the LDS weight tile",
+             g.c_out);
+  const int vox = g.t_in * g.h_in * g.w_in;
+  dim3 grid((unsigned)std::min((vox + 255) / 256, 4096), (unsigned)((g.c_in + GCO - 1) / GCO), (unsigned)d->batch);
+  PV_DISPATCH_K(conv3d_general_dgrad_f32, <<<grid, dim3(256), lds, as_stream(stream)>>>(dy, y_relu_mask, w, dx, g));
+  return check_launch("pv_conv3d_general_bwd_data_f32");
+}
+
+int pv_conv3d_general_bwd_weight_workspace_bytes(const pv_conv3d_geom* d, size_t* bytes) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_conv3d_general_bwd_weight_workspace_bytes");
+  if (rc) return rc;
+  PV_REQUIRE(bytes, PV_EINVAL, "pv_conv3d_general_bwd_weight_workspace_bytes: null pointer");
+  *bytes = (size_t)wgrad_slabs(g, d->batch) * g.c_out * g.c_in * g.kt * g.kh * g.kw * sizeof(float);
+  return PV_OK;
+}
+
+int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const float* y_relu_mask, float* dw, float* dbias,
+                                     const pv_conv3d_geom* d, void* ws, size_t ws_bytes, void* stream) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_conv3d_general_bwd_weight_f32");
+  if (rc) return rc;
+  PV_REQUIRE(x && dy, PV_EINVAL, "pv_conv3d_general_bwd_weight_f32: null pointer");
+  if (dw) {
+    const int n_slabs = wgrad_slabs(g, d->batch);
+    const int n = g.c_out * g.c_in * g.kt * g.kh * g.kw;
+    PV_REQUIRE(ws && ws_bytes >= (size_t)n_slabs * n * sizeof(float), PV_EINVAL,
+               "pv_conv3d_general_bwd_weight_f32: workspace too small");
+    dim3 grid((unsigned)g.c_in, (unsigned)((g.c_out + WCO - 1) / WCO), (unsigned)n_slabs);
+    float* slabs = (float*)ws;
+#define PV_WG(KT_, KH_, KW_)                                                                                             \
+  conv3d_general_wgrad_f32<KT_, KH_, KW_><<<grid, dim3(256), 0, as_stream(stream)>>>(x, dy, y_relu_mask, slabs, g, d->batch, \
+                                                                                      n_slabs)
+    if (g.kt == 2 && g.kh == 3 && g.kw == 3) PV_WG(2, 3, 3);
+    else if (g.kt == 3 && g.kh == 3 && g.kw == 3) PV_WG(3, 3, 3);
+    else if (g.kt == 1 && g.kh == 3 && g.kw == 3) PV_WG(1, 3, 3);
+    else if (g.kt == 1 && g.kh == 1 && g.kw == 1) PV_WG(1, 1, 1);
+    else PV_REQUIRE(false, PV_ESIZE, "pv_conv3d_general_bwd_weight_f32: kernel extent (%d,%d,%d) not instantiated", g.kt,
+                    g.kh, g.kw);
+#undef PV_WG
+    rc = check_launch("pv_conv3d_general_bwd_weight_f32");
+    if (rc) return rc;
+    slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(slabs, dw, n, n_slabs);
+    rc = check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
+    if (rc) return rc;
+  }
+  if (dbias) {
+    conv3d_general_dbias_f32<<<dim3((unsigned)g.c_out), dim3(256), 0, as_stream(stream)>>>(
+        dy, y_relu_mask, dbias, d->batch, g.c_out, g.t_out * g.h_out * g.w_out);
+    rc = check_launch("pv_conv3d_general_bwd_weight_f32(dbias)");
+  }
+  return rc;
+}
+
+int pv_maxpool3d_fwd_f32(const float* x, float* y, int32_t* argmax, const pv_conv3d_geom* d, void* stream) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_maxpool3d_fwd_f32");
+  if (rc) return rc;
+  PV_REQUIRE(x && y, PV_EINVAL, "pv_maxpool3d_fwd_f32: null pointer");
+  PV_REQUIRE(g.pt * 2 <= g.kt && g.ph * 2 <= g.kh && g.pw * 2 <= g.kw, PV_EINVAL,
+             "pv_maxpool3d_fwd_f32: padding must be at most half the window");
+  const long long n_out = (long long)d->batch * g.c_in * g.t_out * g.h_out * g.w_out;
+  maxpool3d_fwd_f32<<<dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(x, y, argmax, n_out, g);
+  return check_launch("pv_maxpool3d_fwd_f32");
+}
+
+int pv_maxpool3d_bwd_f32(const float* dy, const int32_t* argmax, float* dx, const pv_conv3d_geom* d, void* stream) {
+  Geom g;
+  int rc = make_geom(d, &g, "pv_maxpool3d_bwd_f32");
+  if (rc) return rc;
+  PV_REQUIRE(dy && argmax && dx, PV_EINVAL, "pv_maxpool3d_bwd_f32: null pointer");
+  const long long n_in = (long long)d->batch * g.c_in * g.t_in * g.h_in * g.w_in;
+  maxpool3d_bwd_f32<<<dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(dy, argmax, dx, n_in, g);
+  return check_launch("pv_maxpool3d_bwd_f32");
+}
+
+int pv_mse_loss_f32(const float* y_hat, const float* y, int64_t n, float grad_scale, float* out, float* grad,
+                    void* stream) {
+  PV_REQUIRE(y_hat && y && out, PV_EINVAL, "pv_mse_loss_f32: null pointer");
+  PV_REQUIRE(n > 0, PV_EINVAL, "pv_mse_loss_f32: n must be positive");
+  mse_loss_f32<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(y_hat, y, (long long)n, grad_scale, out, grad);
+  return check_launch("pv_mse_loss_f32");
+}
+
+}  // extern "C"

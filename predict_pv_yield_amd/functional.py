@@ -180,6 +180,74 @@ def linear_bf16(x, weight, bias, relu=False):
     return LinearBF16.apply(x, weight, bias, relu)
 
 
+class Conv3dGeneralF32(torch.autograd.Function):
+    """nn.Conv3d with kernel extents 1..3, any stride / padding (+ optional fused ReLU) on the exact-f32 kernels:
+    the layers of the optical-flow notebook model (13_…ipynb:969-985) and Conv3dMaxPool's conv."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, relu):
+        x = x.contiguous()
+        y = K.conv3d_general_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, stride,
+                                     padding, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv3d_general_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.stride, ctx.padding)
+        dw, db = K.conv3d_general_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.stride, ctx.padding,
+                                                 need_bias=ctx.has_bias)
+        return dx, dw, db, None, None, None
+
+
+def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False):
+    return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu)
+
+
+class MaxPool3dF32(torch.autograd.Function):
+    """nn.MaxPool3d (perceiver_conv3d_nwp_sat.py:53-57): argmax saved as int32, backward is a deterministic gather."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        y, idx, geom = K.maxpool3d_fwd_f32(x.contiguous(), kernel, stride, padding)
+        ctx.save_for_backward(idx)
+        ctx.geom = geom
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return K.maxpool3d_bwd_f32(dy.contiguous(), idx, ctx.geom), None, None, None
+
+
+def maxpool3d_f32(x, kernel=3, stride=None, padding=0):
+    return MaxPool3dF32.apply(x, kernel, stride, padding)
+
+
+class MSELossF32(torch.autograd.Function):
+    """F.mse_loss(y_hat, y) (13_…ipynb:1008): scalar mean, gradient 2 (y_hat - y) / n produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, y_hat, y):
+        out, grad = K.mse_loss(y_hat.contiguous(), y.contiguous(), need_grad=True)
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None
+
+
+def mse_loss(y_hat, y):
+    return MSELossF32.apply(y_hat, y)
+
+
 class EmbeddingF32(torch.autograd.Function):
     """nn.Embedding lookup (model_sat_nwp.py:251-260) as a gather kernel; backward = deterministic per-row sums."""
 

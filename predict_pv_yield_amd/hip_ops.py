@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (Conv3dDims, FarnebackParams, PV_BORDER_CONSTANT, PV_BORDER_REPLICATE,
+from ._lib import (Conv3dDims, Conv3dGeom, FarnebackParams, PV_BORDER_CONSTANT, PV_BORDER_REPLICATE,
                    PV_OPTFLOW_FARNEBACK_GAUSSIAN, check, current_stream_ptr, get_lib, ptr, require_cuda)
 
 c_i32, c_i64, c_f32, c_f64, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_size_t
@@ -419,3 +419,79 @@ def embedding_bwd(dout: torch.Tensor, ids: torch.Tensor, n_rows: int) -> torch.T
     check(get_lib().pv_embedding_bwd_f32(ptr(dout), ptr(ids), ptr(dtable), ids.numel(), dout.shape[1], n_rows,
                                          current_stream_ptr()), "pv_embedding_bwd_f32")
     return dtable
+
+
+# ---- general Conv3D / MaxPool3d / MSE (optical-flow notebook model, Conv3dMaxPool) -----------------------------------
+def _triple(v):
+    return (v, v, v) if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+def conv_geom(batch, c_in, c_out, t, h, w, kernel, stride=1, padding=0) -> Conv3dGeom:
+    return Conv3dGeom(batch, c_in, c_out, t, h, w, *_triple(kernel), *_triple(stride), *_triple(padding))
+
+
+def conv3d_general_fwd_f32(x, weight, bias, stride=1, padding=0, relu=False):
+    require_cuda(x, weight, bias)
+    b, ci, t, h, w = x.shape
+    co = weight.shape[0]
+    g = conv_geom(b, ci, co, t, h, w, tuple(weight.shape[2:]), stride, padding)
+    y = torch.empty((b, co) + g.out_shape(), dtype=torch.float32, device=x.device)
+    check(get_lib().pv_conv3d_general_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(y), ctypes.byref(g), int(relu),
+                                              current_stream_ptr()), "pv_conv3d_general_fwd_f32")
+    return y
+
+
+def conv3d_general_bwd_data_f32(dy, y_mask, weight, x_shape, stride=1, padding=0):
+    require_cuda(dy, y_mask, weight)
+    b, ci, t, h, w = x_shape
+    g = conv_geom(b, ci, weight.shape[0], t, h, w, tuple(weight.shape[2:]), stride, padding)
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    check(get_lib().pv_conv3d_general_bwd_data_f32(ptr(dy), ptr(y_mask), ptr(weight), ptr(dx), ctypes.byref(g),
+                                                   current_stream_ptr()), "pv_conv3d_general_bwd_data_f32")
+    return dx
+
+
+def conv3d_general_bwd_weight_f32(x, dy, y_mask, weight_shape, stride=1, padding=0, need_bias=True):
+    require_cuda(x, dy, y_mask)
+    b, ci, t, h, w = x.shape
+    g = conv_geom(b, ci, weight_shape[0], t, h, w, tuple(weight_shape[2:]), stride, padding)
+    nbytes = ctypes.c_size_t(0)
+    check(get_lib().pv_conv3d_general_bwd_weight_workspace_bytes(ctypes.byref(g), ctypes.byref(nbytes)),
+          "pv_conv3d_general_bwd_weight_workspace_bytes")
+    ws = _workspace("conv3d_general_wgrad", nbytes.value, x.device)
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = torch.empty((weight_shape[0],), dtype=torch.float32, device=x.device) if need_bias else None
+    check(get_lib().pv_conv3d_general_bwd_weight_f32(ptr(x), ptr(dy), ptr(y_mask), ptr(dw), ptr(db), ctypes.byref(g),
+                                                     ptr(ws), nbytes.value, current_stream_ptr()),
+          "pv_conv3d_general_bwd_weight_f32")
+    return dw, db
+
+
+def maxpool3d_fwd_f32(x, kernel=3, stride=None, padding=0):
+    require_cuda(x)
+    b, c, t, h, w = x.shape
+    g = conv_geom(b, c, c, t, h, w, kernel, kernel if stride is None else stride, padding)
+    y = torch.empty((b, c) + g.out_shape(), dtype=torch.float32, device=x.device)
+    idx = torch.empty(y.shape, dtype=torch.int32, device=x.device)
+    check(get_lib().pv_maxpool3d_fwd_f32(ptr(x), ptr(y), ptr(idx), ctypes.byref(g), current_stream_ptr()),
+          "pv_maxpool3d_fwd_f32")
+    return y, idx, g
+
+
+def maxpool3d_bwd_f32(dy, idx, g: Conv3dGeom):
+    require_cuda(dy, idx)
+    dx = torch.empty((g.batch, g.c_in, g.t_in, g.h_in, g.w_in), dtype=torch.float32, device=dy.device)
+    check(get_lib().pv_maxpool3d_bwd_f32(ptr(dy), ptr(idx), ptr(dx), ctypes.byref(g), current_stream_ptr()),
+          "pv_maxpool3d_bwd_f32")
+    return dx
+
+
+def mse_loss(y_hat, y, need_grad=True, grad_scale=1.0):
+    require_cuda(y_hat, y)
+    if y_hat.shape != y.shape:
+        raise ValueError(f"mse_loss: shapes differ: {tuple(y_hat.shape)} vs {tuple(y.shape)}")
+    out = torch.empty((1,), dtype=torch.float32, device=y_hat.device)
+    grad = torch.empty_like(y_hat) if need_grad else None
+    check(get_lib().pv_mse_loss_f32(ptr(y_hat), ptr(y), y_hat.numel(), float(grad_scale), ptr(out), ptr(grad),
+                                    current_stream_ptr()), "pv_mse_loss_f32")
+    return out, grad
