@@ -201,3 +201,55 @@ def advect_frames(raw: np.ndarray, mean: np.ndarray, std: np.ndarray, n_future: 
             for k in range(1, n_future + 1):
                 out[bi, ci, t + k - 1] = remap_image(norm[t - 1], mean_flow, float(k), border_mode, border_value)
     return out
+
+
+# ---- nb-13 super-batch -> example sampling (13_…ipynb:604-728), NumPy restatement -------------------------------------
+class ImageHasNansError(Exception):
+    pass
+
+
+def super_batch_to_example_np(sat: np.ndarray, preds: np.ndarray, pred_index: np.ndarray, rng: np.random.Generator,
+                              n_historical_images: int = 4, history_stride: int = 3, large: int = 128,
+                              small: int = 64, max_retries: int = 128):
+    """sat [T,H,W] normalised, preds [P,H,W], pred_index [P,2] (t0 idx, target idx) sorted like the DataFrame index.
+    Follows super_batch_to_example / sample_squares statement by statement (same rng call sequence); every retry
+    crops from the full-extent images.  Returns (history [4,L,L], prediction [L,L], horizon_seconds, target [S,S])."""
+    n = len(sat)
+    total = n_historical_images * history_stride
+    max_start = n - total - 1
+    for _ in range(max_retries):
+        start = rng.integers(low=0, high=max_start)
+        end = start + total
+        t0 = end - 1
+        rows = np.flatnonzero(pred_index[:, 0] == t0)
+        row = rng.choice(rows)
+        target_idx = pred_index[row, 1]
+        horizon_s = float((target_idx - t0) * 300)
+        hist, pred, target = sat[start:end:history_stride], preds[row], sat[target_idx]
+        for _ in range(max_retries):
+            h, w = pred.shape[-2:]
+            top = rng.integers(low=0, high=h - large)
+            left = rng.integers(low=0, high=w - large)
+            b = (large - small) // 2
+            p_c = pred[top:top + large, left:left + large]
+            if np.isnan(p_c).any():
+                continue
+            h_c = hist[:, top:top + large, left:left + large]
+            if np.isnan(h_c).any():
+                continue
+            t_c = target[top + b:top + large - b, left + b:left + large - b]
+            if np.isnan(t_c).any():
+                continue
+            return h_c, p_c, horizon_s, t_c
+    raise ImageHasNansError("Cropped images still have NaNs")
+
+
+def compute_optical_flow_predictions_np(sat: np.ndarray, flows: np.ndarray):
+    """13_…ipynb:284-333: prediction(flow_i, step) = remap(sat[flow_i], flows[flow_i] * step), NaN border."""
+    preds, index = [], []
+    num_flows = len(flows)
+    for flow_i in range(num_flows):
+        for step in range(1, num_flows - flow_i + 1):
+            preds.append(remap_image(sat[flow_i], flows[flow_i], k=float(step)))
+            index.append((flow_i, flow_i + step))
+    return np.stack(preds), np.array(index, dtype=np.int64)
