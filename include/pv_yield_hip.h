@@ -186,9 +186,11 @@ int pv_conv3d_general_out_extent(const pv_conv3d_geom* d, int32_t* t_out, int32_
 /* y[B,Co,To,Ho,Wo] = conv3d(x[B,Ci,Ti,Hi,Wi], w[Co,Ci,kt,kh,kw], stride, padding) + bias, optional fused ReLU. */
 int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                               const pv_conv3d_geom* d, int relu, void* stream);
-/* dx from dy ⊙ (y_relu_mask > 0 if given); `d` describes the FORWARD conv. */
+/* dx from dy ⊙ (y_relu_mask > 0 if given); `d` describes the FORWARD conv.  x_relu_mask (may be NULL): the layer
+ * input when it is itself a ReLU output — dx is then zeroed where x <= 0, i.e. it leaves this kernel already gated
+ * for the previous layer (which passes y_relu_mask = NULL). */
 int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w, float* dx,
-                                   const pv_conv3d_geom* d, void* stream);
+                                   const float* x_relu_mask, const pv_conv3d_geom* d, void* stream);
 /* dw[Co,Ci,kt,kh,kw], dbias[Co] (either may be NULL); split over position slabs held in `ws`, summed in slab order.
  * Kernel extents (2,3,3), (3,3,3), (1,3,3), (1,1,1). */
 int pv_conv3d_general_bwd_weight_workspace_bytes(const pv_conv3d_geom* d, size_t* bytes);

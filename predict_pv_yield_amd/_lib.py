@@ -91,7 +91,7 @@ SIGNATURES = {
     "pv_adam_step_bf16grad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
     "pv_conv3d_general_out_extent": [_PCG, _PI32, _PI32, _PI32],
     "pv_conv3d_general_fwd_f32": [c_vp, c_vp, c_vp, c_vp, _PCG, c_int, c_vp],
-    "pv_conv3d_general_bwd_data_f32": [c_vp, c_vp, c_vp, c_vp, _PCG, c_vp],
+    "pv_conv3d_general_bwd_data_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCG, c_vp],
     "pv_conv3d_general_bwd_weight_workspace_bytes": [_PCG, ctypes.POINTER(c_sz)],
     "pv_conv3d_general_bwd_weight_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCG, c_vp, c_sz, c_vp],
     "pv_maxpool3d_fwd_f32": [c_vp, c_vp, c_vp, _PCG, c_vp],

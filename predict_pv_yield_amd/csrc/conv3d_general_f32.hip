@@ -82,13 +82,125 @@ __global__ __launch_bounds__(256) void conv3d_general_fwd_f32(const float* __res
   }
 }
 
+// Unit-stride fast path (forward, and dgrad as a correlation with mirrored, channel-swapped weights): one thread =
+// TW consecutive output columns x GCO channels, so each LDS weight read feeds TW FMAs and each input value KW of them.
+// Per-output summation order is still (channel, kt, kh, kw) ascending.
+constexpr int TW = 8;
+
+template <int KT, int KH, int KW, bool GATE>
+__global__ __launch_bounds__(256) void conv3d_tiled_s1_f32(const float* __restrict__ x, const float* __restrict__ gate,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, Geom g, int relu, int flip,
+                                                           int w_ci_dim, const float* __restrict__ out_gate) {
+  extern __shared__ float wl[];  // [c_in][taps][GCO]
+  constexpr int TAPS = KT * KH * KW;
+  const int co0 = blockIdx.y * GCO;
+  const int b = blockIdx.z;
+  for (int i = threadIdx.x; i < g.c_in * TAPS * GCO; i += blockDim.x) {
+    int j = i % GCO;
+    int tap = (i / GCO) % TAPS;
+    int ci = i / (GCO * TAPS);
+    int co = co0 + j;
+    float v = 0.f;
+    if (co < g.c_out)
+      v = flip ? w[((size_t)ci * w_ci_dim + co) * TAPS + (TAPS - 1 - tap)] : w[((size_t)co * w_ci_dim + ci) * TAPS + tap];
+    wl[i] = v;
+  }
+  __syncthreads();
+  const int n_wt = (g.w_out + TW - 1) / TW;
+  const int tiles = g.t_out * g.h_out * n_wt;
+  const int plane_out = g.h_out * g.w_out;
+  const int vox_out = g.t_out * plane_out;
+  const int plane_in = g.h_in * g.w_in;
+  const size_t vox_in = (size_t)g.t_in * plane_in;
+  for (int tile = blockIdx.x * blockDim.x + threadIdx.x; tile < tiles; tile += gridDim.x * blockDim.x) {
+    const int wt = tile % n_wt;
+    const int r = tile / n_wt;
+    const int ho = r % g.h_out;
+    const int to = r / g.h_out;
+    const int wo0 = wt * TW;
+    float acc[TW][GCO];
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) {
+      const float bv = (bias && co0 + j < g.c_out) ? bias[co0 + j] : 0.f;
+#pragma unroll
+      for (int v = 0; v < TW; ++v) acc[v][j] = bv;
+    }
+    const int wi0 = wo0 - g.pw;
+    for (int ci = 0; ci < g.c_in; ++ci) {
+      const float* xc = x + ((size_t)b * g.c_in + ci) * vox_in;
+      const float* gc = GATE ? gate + ((size_t)b * g.c_in + ci) * vox_in : nullptr;
+      const float* wc = wl + (size_t)ci * TAPS * GCO;
+      // one (kt, kh) input row at a time: keeps only KW x GCO weights live (a full unroll hoists every tap's weights)
+#pragma unroll 1
+      for (int row = 0; row < KT * KH; ++row) {
+        const int kt = row / KH, kh = row - kt * KH;
+        const int ti = to + kt - g.pt;
+        const int hi = ho + kh - g.ph;
+        const bool ok = (unsigned)ti < (unsigned)g.t_in && (unsigned)hi < (unsigned)g.h_in;
+        const int base = ok ? ti * plane_in + hi * g.w_in : 0;
+        float xr[TW + KW - 1];
+#pragma unroll
+        for (int i = 0; i < TW + KW - 1; ++i) {
+          const int wi = wi0 + i;
+          float xv = 0.f;
+          if (ok && (unsigned)wi < (unsigned)g.w_in) {
+            xv = xc[base + wi];
+            if (GATE && !(gc[base + wi] > 0.f)) xv = 0.f;
+          }
+          xr[i] = xv;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const float4* wt4 = reinterpret_cast<const float4*>(wc + (row * KW + kw) * GCO);
+          float wv[GCO];
+#pragma unroll
+          for (int q = 0; q < GCO / 4; ++q) {
+            const float4 t4 = wt4[q];
+            wv[4 * q] = t4.x, wv[4 * q + 1] = t4.y, wv[4 * q + 2] = t4.z, wv[4 * q + 3] = t4.w;
+          }
+#pragma unroll
+          for (int v = 0; v < TW; ++v)
+#pragma unroll
+            for (int j = 0; j < GCO; ++j) acc[v][j] = fmaf(xr[v + kw], wv[j], acc[v][j]);
+        }
+      }
+    }
+    const size_t out0 = (size_t)to * plane_out + (size_t)ho * g.w_out + wo0;
+    const bool full = wo0 + TW <= g.w_out && (g.w_out & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) {
+      if (co0 + j >= g.c_out) continue;
+      float* yo = y + ((size_t)b * g.c_out + co0 + j) * vox_out + out0;
+      float o[TW];
+#pragma unroll
+      for (int v = 0; v < TW; ++v) o[v] = relu ? fmaxf(acc[v][j], 0.f) : acc[v][j];
+      if (out_gate) {  // dgrad into a ReLU output: zero where that output was not positive
+        const float* og = out_gate + ((size_t)b * g.c_out + co0 + j) * vox_out + out0;
+#pragma unroll
+        for (int v = 0; v < TW; ++v)
+          if (wo0 + v < g.w_out && !(og[v] > 0.f)) o[v] = 0.f;
+      }
+      if (full) {
+#pragma unroll
+        for (int q = 0; q < TW / 4; ++q)
+          reinterpret_cast<float4*>(yo)[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < TW; ++v)
+          if (wo0 + v < g.w_out) yo[v] = o[v];
+      }
+    }
+  }
+}
+
 // dgrad, gather form: dx[b,ci,ti,hi,wi] = sum_{co,taps : to*st - pt + kt == ti ...} dy'[b,co,to,ho,wo] * w[co,ci,tap],
 // dy' = dy gated by (gate > 0) when the forward was followed by a ReLU.  One thread = one dx voxel x GCO input channels.
 template <int KT, int KH, int KW>
 __global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __restrict__ dy,
                                                                 const float* __restrict__ gate,
                                                                 const float* __restrict__ w, float* __restrict__ dx,
-                                                                Geom g) {
+                                                                Geom g, const float* __restrict__ out_gate) {
   extern __shared__ float wl[];  // [c_out][taps][GCO]
   const int kt_n = KT ? KT : g.kt, kh_n = KH ? KH : g.kh, kw_n = KW ? KW : g.kw;
   const int taps = kt_n * kh_n * kw_n;
@@ -147,95 +259,251 @@ __global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __r
     }
 #pragma unroll
     for (int j = 0; j < GCO; ++j)
-      if (ci0 + j < g.c_in) dx[((size_t)b * g.c_in + ci0 + j) * vox_in + v] = acc[j];
+      if (ci0 + j < g.c_in) {
+        const size_t off = ((size_t)b * g.c_in + ci0 + j) * vox_in + v;
+        dx[off] = (out_gate && !(out_gate[off] > 0.f)) ? 0.f : acc[j];
+      }
   }
 }
 
-// wgrad: block = (ci, group of WCO output channels, slab of positions); thread-private taps x WCO partial sums, then a
-// deterministic block reduction into slabs[slab][co][ci][tap]; wgrad_reduce adds the slabs in index order.
-constexpr int WCO = 4;
-
-template <int KT, int KH, int KW>
+// wgrad: block = (ci, group of WCO output channels, slab of positions); thread-private taps x WCO partial sums over
+// PW consecutive output columns per iteration (PW = 2 needs unit stride: neighbouring outputs share input columns), then
+// a deterministic block reduction into slabs[slab][co][ci][tap]; slab_reduce adds the slabs in index order.  The ci == 0
+// blocks also reduce dy itself into bias_slabs[slab][co] (dbias costs no extra pass over dy).
+template <int KT, int KH, int KW, int WCO, int PW>
 __global__ __launch_bounds__(256) void conv3d_general_wgrad_f32(const float* __restrict__ x, const float* __restrict__ dy,
                                                                 const float* __restrict__ gate, float* __restrict__ slabs,
-                                                                Geom g, int batch, int n_slabs) {
+                                                                float* __restrict__ bias_slabs, Geom g, int batch,
+                                                                int n_slabs) {
   constexpr int TAPS = KT * KH * KW;
   const int ci = blockIdx.x;
   const int co0 = blockIdx.y * WCO;
   const int slab = blockIdx.z;
+  const int n_wp = (g.w_out + PW - 1) / PW;
   const int plane_out = g.h_out * g.w_out;
   const int vox_out = g.t_out * plane_out;
-  const size_t plane_in = (size_t)g.h_in * g.w_in;
+  const int plane_in = g.h_in * g.w_in;
   const size_t vox_in = (size_t)g.t_in * plane_in;
   float acc[WCO][TAPS];
+  float bsum[WCO];
 #pragma unroll
-  for (int j = 0; j < WCO; ++j)
+  for (int j = 0; j < WCO; ++j) {
+    bsum[j] = 0.f;
 #pragma unroll
     for (int k = 0; k < TAPS; ++k) acc[j][k] = 0.f;
-
-  const long long total = (long long)batch * vox_out;
+  }
+  const long long total = (long long)batch * g.t_out * g.h_out * n_wp;
   const long long per = (total + n_slabs - 1) / n_slabs;
   const long long i0 = (long long)slab * per;
   const long long i1 = i0 + per < total ? i0 + per : total;
   for (long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    int b = (int)(i / vox_out);
-    int v = (int)(i - (long long)b * vox_out);
-    int to = v / plane_out;
-    int r = v - to * plane_out;
-    int ho = r / g.w_out;
-    int wo = r - ho * g.w_out;
-    float d[WCO];
+    const int wp = (int)(i % n_wp);
+    long long r = i / n_wp;
+    const int ho = (int)(r % g.h_out);
+    r /= g.h_out;
+    const int to = (int)(r % g.t_out);
+    const int b = (int)(r / g.t_out);
+    const int wo0 = wp * PW;
+    const int v0 = to * plane_out + ho * g.w_out + wo0;
+    float d[WCO][PW];
 #pragma unroll
-    for (int j = 0; j < WCO; ++j) {
-      float dv = 0.f;
-      if (co0 + j < g.c_out) {
-        size_t off = ((size_t)b * g.c_out + co0 + j) * vox_out + v;
-        dv = dy[off];
-        if (gate && !(gate[off] > 0.f)) dv = 0.f;
+    for (int j = 0; j < WCO; ++j)
+#pragma unroll
+      for (int u = 0; u < PW; ++u) {
+        float dv = 0.f;
+        if (co0 + j < g.c_out && wo0 + u < g.w_out) {
+          const size_t off = ((size_t)b * g.c_out + co0 + j) * vox_out + v0 + u;
+          dv = dy[off];
+          if (gate && !(gate[off] > 0.f)) dv = 0.f;
+        }
+        d[j][u] = dv;
+        bsum[j] += dv;
       }
-      d[j] = dv;
-    }
     const float* xc = x + ((size_t)b * g.c_in + ci) * vox_in;
-    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
+    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo0 * g.sw - g.pw;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-      int ti = t0 + kt;
-      bool t_ok = (unsigned)ti < (unsigned)g.t_in;
+      const int ti = t0 + kt;
+      const bool t_ok = (unsigned)ti < (unsigned)g.t_in;
 #pragma unroll
       for (int kh = 0; kh < KH; ++kh) {
-        int hi = h0 + kh;
-        bool h_ok = t_ok && (unsigned)hi < (unsigned)g.h_in;
+        const int hi = h0 + kh;
+        const bool ok = t_ok && (unsigned)hi < (unsigned)g.h_in;
+        const int base = ok ? ti * plane_in + hi * g.w_in : 0;
+        float xr[KW + PW - 1];
 #pragma unroll
-        for (int kw = 0; kw < KW; ++kw) {
-          int wi = w0 + kw;
-          float xv = 0.f;
-          if (h_ok && (unsigned)wi < (unsigned)g.w_in) xv = xc[(size_t)ti * plane_in + (size_t)hi * g.w_in + wi];
+        for (int q = 0; q < KW + PW - 1; ++q) {
+          const int wi = w0 + q;
+          xr[q] = (ok && (unsigned)wi < (unsigned)g.w_in) ? xc[base + wi] : 0.f;
+        }
 #pragma unroll
-          for (int j = 0; j < WCO; ++j) acc[j][(kt * KH + kh) * KW + kw] = fmaf(d[j], xv, acc[j][(kt * KH + kh) * KW + kw]);
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+          for (int u = 0; u < PW; ++u)
+#pragma unroll
+            for (int j = 0; j < WCO; ++j)
+              acc[j][(kt * KH + kh) * KW + kw] = fmaf(d[j][u], xr[kw + u], acc[j][(kt * KH + kh) * KW + kw]);
+      }
+    }
+  }
+  __shared__ float red[4][WCO * (TAPS + 1)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < WCO; ++j) {
+#pragma unroll
+    for (int k = 0; k <= TAPS; ++k) {
+      float v = k < TAPS ? acc[j][k < TAPS ? k : 0] : bsum[j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][j * (TAPS + 1) + k] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < WCO * (TAPS + 1)) {
+    const int j = threadIdx.x / (TAPS + 1), k = threadIdx.x % (TAPS + 1);
+    if (co0 + j < g.c_out) {
+      const float sum = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+      if (k < TAPS) slabs[(((size_t)slab * g.c_out + co0 + j) * g.c_in + ci) * TAPS + k] = sum;
+      else if (ci == 0 && bias_slabs) bias_slabs[(size_t)slab * g.c_out + co0 + j] = sum;
+    }
+  }
+}
+
+// wgrad on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation) for unit stride and
+// 16 < channels <= 32: D[co][ci] += sum_p dy[co][p] * x[ci][p + tap offset], one 32x32 accumulator tile per tap.
+// Block = 8 waves; wave (w & 3) owns taps w&3, (w&3)+4, ...; waves 0-3 take the first half of the row tile, 4-7 the
+// second half (combined through LDS in fixed order at the end).  An extra "ones" tap yields dbias = sum_p dy[co][p].
+// A step = one (b, to, ho, w-tile): dy row [32][WT] and the KT*KH input rows [32][ROWS][WT+KW-1] staged in LDS with
+// channel strides = 2 (mod 64) words, so the 32-channel x 2-position operand reads are bank-conflict free.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int KT, int KH, int KW>
+struct WgradMfmaCfg {
+  static constexpr int TAPS = KT * KH * KW;
+  static constexpr int ROWS = KT * KH;
+  static constexpr int WT = ROWS > 6 ? 64 : 128;          // output columns per step
+  static constexpr int R = WT + 2;                         // staged row length (>= WT + KW - 1)
+  static constexpr int S = WT + 2;                         // dy channel stride
+  static constexpr int CS = ((ROWS * R + 63) / 64) * 64 + 2;  // x channel stride
+  static constexpr int NSLOT = (TAPS + 1 + 3) / 4;         // taps (+ ones tap) per wave
+};
+
+template <int KT, int KH, int KW>
+__global__ __launch_bounds__(512) void conv3d_wgrad_mfma_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ gate, float* __restrict__ slabs,
+                                                             float* __restrict__ bias_slabs, Geom g, int batch,
+                                                             int n_steps, int steps_per_block) {
+  using C = WgradMfmaCfg<KT, KH, KW>;
+  constexpr int TAPS = C::TAPS, ROWS = C::ROWS, WT = C::WT, R = C::R, S = C::S, CS = C::CS, NSLOT = C::NSLOT;
+  __shared__ float dyT[32 * S];
+  // xT is reused at the end to combine the two half-row wave groups (4 waves x NSLOT tiles x 16 x 64 floats)
+  constexpr int XT_ELEMS = 32 * CS > 4 * NSLOT * 16 * 64 ? 32 * CS : 4 * NSLOT * 16 * 64;
+  __shared__ float xT[XT_ELEMS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int w4 = wave & 3, half = wave >> 2;
+  const int n_wt = (g.w_out + WT - 1) / WT;
+  const int plane_out = g.h_out * g.w_out;
+  const size_t vox_out = (size_t)g.t_out * plane_out;
+  const int plane_in = g.h_in * g.w_in;
+  const size_t vox_in = (size_t)g.t_in * plane_in;
+
+  v16f acc[NSLOT];
+  int off[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int tap = w4 + 4 * i;
+    off[i] = tap < TAPS ? (tap / KW) * R + (tap % KW) : -1;   // -1: ones tap (tap == TAPS) or unused (tap > TAPS)
+  }
+  const int a_base = (lane & 31) * S + (lane >> 5);
+  const int b_base = (lane & 31) * CS + (lane >> 5);
+
+  const int s0 = blockIdx.x * steps_per_block;
+  const int s1 = s0 + steps_per_block < n_steps ? s0 + steps_per_block : n_steps;
+  for (int s = s0; s < s1; ++s) {
+    const int wt = s % n_wt;
+    int r = s / n_wt;
+    const int ho = r % g.h_out;
+    r /= g.h_out;
+    const int to = r % g.t_out;
+    const int b = r / g.t_out;
+    const int wo0 = wt * WT;
+    // ---- stage dy row and the input rows --------------------------------------------------------------------------
+    for (int idx = tid; idx < 32 * WT; idx += 512) {
+      const int co = idx / WT, p = idx - co * WT;
+      float v = 0.f;
+      if (co < g.c_out && wo0 + p < g.w_out) {
+        const size_t o = ((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + ho * g.w_out + wo0 + p;
+        v = dy[o];
+        if (gate && !(gate[o] > 0.f)) v = 0.f;
+      }
+      dyT[co * S + p] = v;
+    }
+    for (int idx = tid; idx < 32 * ROWS * R; idx += 512) {
+      const int ci = idx / (ROWS * R);
+      const int rem = idx - ci * (ROWS * R);
+      const int row = rem / R, c = rem - row * R;
+      const int kt = row / KH, kh = row - kt * KH;
+      const int ti = to + kt - g.pt, hi = ho + kh - g.ph, wi = wo0 - g.pw + c;
+      float v = 0.f;
+      if (ci < g.c_in && (unsigned)ti < (unsigned)g.t_in && (unsigned)hi < (unsigned)g.h_in && (unsigned)wi < (unsigned)g.w_in)
+        v = x[((size_t)b * g.c_in + ci) * vox_in + (size_t)ti * plane_in + hi * g.w_in + wi];
+      xT[ci * CS + rem] = v;
+    }
+    __syncthreads();
+    // ---- MFMA over this wave's half of the row ---------------------------------------------------------------------
+    const int q0 = half * (WT / 4), q1 = q0 + WT / 4;
+#pragma unroll 2
+    for (int q = q0; q < q1; ++q) {
+      const float a = dyT[a_base + 2 * q];
+#pragma unroll
+      for (int i = 0; i < NSLOT; ++i) {
+        const int tap = w4 + 4 * i;                            // wave-uniform
+        if (tap < TAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xT[b_base + off[i] + 2 * q], acc[i], 0, 0, 0);
+        else if (tap == TAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- combine the two half-row groups (fixed order: first half + second half), write this block's slab -----------------
+  if (half == 1) {
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xT[((w4 * NSLOT + i) * 16 + r) * 64 + lane] = acc[i][r];
+  }
+  __syncthreads();
+  if (half == 0) {
+    const int ci = lane & 31;
+    const size_t slab = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const int tap = w4 + 4 * i;
+      if (tap > TAPS) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float v = acc[i][r] + xT[((w4 * NSLOT + i) * 16 + r) * 64 + lane];
+        if (co < g.c_out) {
+          if (tap < TAPS) {
+            if (ci < g.c_in) slabs[((slab * g.c_out + co) * g.c_in + ci) * TAPS + tap] = v;
+          } else if (ci == 0 && bias_slabs) {
+            bias_slabs[slab * g.c_out + co] = v;
+          }
         }
       }
     }
   }
-  __shared__ float red[4][WCO * TAPS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int j = 0; j < WCO; ++j)
-#pragma unroll
-    for (int k = 0; k < TAPS; ++k) {
-      float v = acc[j][k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave][j * TAPS + k] = v;
-    }
-  __syncthreads();
-  if (threadIdx.x < WCO * TAPS) {
-    int j = threadIdx.x / TAPS, k = threadIdx.x % TAPS;
-    if (co0 + j < g.c_out) {
-      float s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-      slabs[(((size_t)slab * g.c_out + co0 + j) * g.c_in + ci) * TAPS + k] = s;
-    }
-  }
 }
+
+static bool wgrad_mfma_ok(const Geom& g) {
+  const bool k_ok = (g.kt == 2 || g.kt == 3 || g.kt == 1) && g.kh == 3 && g.kw == 3;
+  return k_ok && g.st == 1 && g.sh == 1 && g.sw == 1 && g.c_in >= 16 && g.c_in <= 32 && g.c_out >= 16 && g.c_out <= 32 &&
+         g.w_out >= 32;
+}
+
+static int wgrad_mfma_wt(const Geom& g) { return g.kt * g.kh > 6 ? 64 : 128; }
 
 __global__ __launch_bounds__(256) void slab_reduce_f32(const float* __restrict__ slabs, float* __restrict__ out, int n,
                                                        int n_slabs) {
@@ -387,9 +655,21 @@ static int make_geom(const pv_conv3d_geom* d, Geom* g, const char* who) {
   return PV_OK;
 }
 
+static int wgrad_wco(const Geom& g) { return g.c_out >= 8 ? 8 : 4; }
+
+static int wgrad_mfma_steps(const Geom& g, int batch) {
+  return batch * g.t_out * g.h_out * ((g.w_out + wgrad_mfma_wt(g) - 1) / wgrad_mfma_wt(g));
+}
+
 static int wgrad_slabs(const Geom& g, int batch) {
+  if (wgrad_mfma_ok(g)) {  // one slab per block; one resident block per CU (LDS), two rounds
+    const int n_steps = wgrad_mfma_steps(g, batch);
+    const int per = (n_steps + 511) / 512;
+    return (n_steps + per - 1) / per;
+  }
   const long long total = (long long)batch * g.t_out * g.h_out * g.w_out;
-  const long long blocks = (long long)g.c_in * ((g.c_out + WCO - 1) / WCO);
+  const int wco = wgrad_wco(g);
+  const long long blocks = (long long)g.c_in * ((g.c_out + wco - 1) / wco);
   long long n = (4096 + blocks - 1) / blocks;                 // aim at >= 4096 blocks ...
   const long long cap = (total + 4095) / 4096;                // ... of at least 4096 positions each
   if (n > cap) n = cap;
@@ -422,6 +702,29 @@ int pv_conv3d_general_out_extent(const pv_conv3d_geom* d, int32_t* t_out, int32_
   return PV_OK;
 }
 
+// unit-stride launch of the tiled kernel; `g` is the geometry AS SEEN BY THE PASS (dgrad: channels and extents swapped)
+static bool launch_tiled_s1(const float* x, const float* gate, const float* w, const float* bias, float* y, const Geom& g,
+                            int batch, int relu, int flip, int w_ci_dim, const float* out_gate, hipStream_t stream) {
+  const size_t lds = (size_t)g.c_in * g.kt * g.kh * g.kw * GCO * sizeof(float);
+  const int tiles = g.t_out * g.h_out * ((g.w_out + TW - 1) / TW);
+  dim3 grid((unsigned)std::min((tiles + 255) / 256, 4096), (unsigned)((g.c_out + GCO - 1) / GCO), (unsigned)batch);
+#define PV_TILED(KT_, KH_, KW_)                                                                                         \
+  do {                                                                                                                  \
+    if (gate) conv3d_tiled_s1_f32<KT_, KH_, KW_, true><<<grid, dim3(256), lds, stream>>>(x, gate, w, bias, y, g, relu,    \
+                                                                                        flip, w_ci_dim, out_gate);      \
+    else conv3d_tiled_s1_f32<KT_, KH_, KW_, false><<<grid, dim3(256), lds, stream>>>(x, gate, w, bias, y, g, relu, flip,  \
+                                                                                    w_ci_dim, out_gate);                \
+    return true;                                                                                                        \
+  } while (0)
+  if (g.kt == 2 && g.kh == 3 && g.kw == 3) PV_TILED(2, 3, 3);
+  if (g.kt == 3 && g.kh == 3 && g.kw == 3) PV_TILED(3, 3, 3);
+  if (g.kt == 1 && g.kh == 3 && g.kw == 3) PV_TILED(1, 3, 3);
+#undef PV_TILED
+  return false;
+}
+
+static bool unit_stride(const Geom& g) { return g.st == 1 && g.sh == 1 && g.sw == 1; }
+
 int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias, float* y, const pv_conv3d_geom* d,
                               int relu, void* stream) {
   Geom g;
@@ -430,6 +733,9 @@ int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias,
   PV_REQUIRE(x && w && y, PV_EINVAL, "pv_conv3d_general_fwd_f32: null pointer");
   const size_t lds = (size_t)g.c_in * g.kt * g.kh * g.kw * GCO * sizeof(float);
   PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_conv3d_general_fwd_f32: c_in=%d too large for the LDS weight tile", g.c_in);
+  if (unit_stride(g) && g.w_out >= TW &&
+      launch_tiled_s1(x, nullptr, w, bias, y, g, d->batch, relu ? 1 : 0, 0, g.c_in, nullptr, as_stream(stream)))
+    return check_launch("pv_conv3d_general_fwd_f32");
   const int vox = g.t_out * g.h_out * g.w_out;
   dim3 grid((unsigned)std::min((vox + 255) / 256, 4096), (unsigned)((g.c_out + GCO - 1) / GCO), (unsigned)d->batch);
   PV_DISPATCH_K(conv3d_general_fwd_f32, <<<grid, dim3(256), lds, as_stream(stream)>>>(x, w, bias, y, g, relu ? 1 : 0));
@@ -437,7 +743,7 @@ int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias,
 }
 
 int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w, float* dx,
-                                   const pv_conv3d_geom* d, void* stream) {
+                                   const float* x_relu_mask, const pv_conv3d_geom* d, void* stream) {
   Geom g;
   int rc = make_geom(d, &g, "pv_conv3d_general_bwd_data_f32");
   if (rc) return rc;
@@ -445,9 +751,19 @@ int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, co
   const size_t lds = (size_t)g.c_out * g.kt * g.kh * g.kw * GCO * sizeof(float);
   PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_conv3d_general_bwd_data_f32: c_out=%d too large for the LDS weight tile",
              g.c_out);
+  if (unit_stride(g) && g.w_in >= TW && g.pt <= g.kt - 1 && g.ph <= g.kh - 1 && g.pw <= g.kw - 1) {
+    // dgrad = correlation of dy (padding k-1-p) with mirrored, channel-swapped weights
+    Geom t = g;
+    t.c_in = g.c_out, t.c_out = g.c_in;
+    t.t_in = g.t_out, t.h_in = g.h_out, t.w_in = g.w_out;
+    t.t_out = g.t_in, t.h_out = g.h_in, t.w_out = g.w_in;
+    t.pt = g.kt - 1 - g.pt, t.ph = g.kh - 1 - g.ph, t.pw = g.kw - 1 - g.pw;
+    if (launch_tiled_s1(dy, y_relu_mask, w, nullptr, dx, t, d->batch, 0, 1, g.c_in, x_relu_mask, as_stream(stream)))
+      return check_launch("pv_conv3d_general_bwd_data_f32");
+  }
   const int vox = g.t_in * g.h_in * g.w_in;
   dim3 grid((unsigned)std::min((vox + 255) / 256, 4096), (unsigned)((g.c_in + GCO - 1) / GCO), (unsigned)d->batch);
-  PV_DISPATCH_K(conv3d_general_dgrad_f32, <<<grid, dim3(256), lds, as_stream(stream)>>>(dy, y_relu_mask, w, dx, g));
+  PV_DISPATCH_K(conv3d_general_dgrad_f32, <<<grid, dim3(256), lds, as_stream(stream)>>>(dy, y_relu_mask, w, dx, g, x_relu_mask));
   return check_launch("pv_conv3d_general_bwd_data_f32");
 }
 
@@ -456,7 +772,7 @@ int pv_conv3d_general_bwd_weight_workspace_bytes(const pv_conv3d_geom* d, size_t
   int rc = make_geom(d, &g, "pv_conv3d_general_bwd_weight_workspace_bytes");
   if (rc) return rc;
   PV_REQUIRE(bytes, PV_EINVAL, "pv_conv3d_general_bwd_weight_workspace_bytes: null pointer");
-  *bytes = (size_t)wgrad_slabs(g, d->batch) * g.c_out * g.c_in * g.kt * g.kh * g.kw * sizeof(float);
+  *bytes = (size_t)wgrad_slabs(g, d->batch) * ((size_t)g.c_out * g.c_in * g.kt * g.kh * g.kw + g.c_out) * sizeof(float);
   return PV_OK;
 }
 
@@ -466,16 +782,41 @@ int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const floa
   int rc = make_geom(d, &g, "pv_conv3d_general_bwd_weight_f32");
   if (rc) return rc;
   PV_REQUIRE(x && dy, PV_EINVAL, "pv_conv3d_general_bwd_weight_f32: null pointer");
+  hipStream_t st = as_stream(stream);
   if (dw) {
     const int n_slabs = wgrad_slabs(g, d->batch);
     const int n = g.c_out * g.c_in * g.kt * g.kh * g.kw;
-    PV_REQUIRE(ws && ws_bytes >= (size_t)n_slabs * n * sizeof(float), PV_EINVAL,
+    PV_REQUIRE(ws && ws_bytes >= (size_t)n_slabs * ((size_t)n + g.c_out) * sizeof(float), PV_EINVAL,
                "pv_conv3d_general_bwd_weight_f32: workspace too small");
-    dim3 grid((unsigned)g.c_in, (unsigned)((g.c_out + WCO - 1) / WCO), (unsigned)n_slabs);
     float* slabs = (float*)ws;
-#define PV_WG(KT_, KH_, KW_)                                                                                             \
-  conv3d_general_wgrad_f32<KT_, KH_, KW_><<<grid, dim3(256), 0, as_stream(stream)>>>(x, dy, y_relu_mask, slabs, g, d->batch, \
-                                                                                      n_slabs)
+    float* bias_slabs = dbias ? slabs + (size_t)n_slabs * n : nullptr;
+    if (wgrad_mfma_ok(g)) {
+      const int n_steps = wgrad_mfma_steps(g, d->batch);
+      const int per = (n_steps + n_slabs - 1) / n_slabs;
+      if (g.kt == 2) conv3d_wgrad_mfma_f32<2, 3, 3><<<dim3((unsigned)n_slabs), dim3(512), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g, d->batch, n_steps, per);
+      else if (g.kt == 3) conv3d_wgrad_mfma_f32<3, 3, 3><<<dim3((unsigned)n_slabs), dim3(512), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g, d->batch, n_steps, per);
+      else conv3d_wgrad_mfma_f32<1, 3, 3><<<dim3((unsigned)n_slabs), dim3(512), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g, d->batch, n_steps, per);
+      rc = check_launch("pv_conv3d_general_bwd_weight_f32(mfma)");
+      if (rc) return rc;
+      slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(slabs, dw, n, n_slabs);
+      if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 255) / 256)), dim3(256), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
+      return check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
+    }
+    const int wco = wgrad_wco(g);
+    dim3 grid((unsigned)g.c_in, (unsigned)((g.c_out + wco - 1) / wco), (unsigned)n_slabs);
+    const bool pairs = unit_stride(g);
+#define PV_WG(KT_, KH_, KW_)                                                                                              \
+  do {                                                                                                                    \
+    if (wco == 8 && pairs)                                                                                                \
+      conv3d_general_wgrad_f32<KT_, KH_, KW_, 8, 2><<<grid, dim3(256), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g,   \
+                                                                               d->batch, n_slabs);                        \
+    else if (wco == 8)                                                                                                    \
+      conv3d_general_wgrad_f32<KT_, KH_, KW_, 8, 1><<<grid, dim3(256), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g,   \
+                                                                               d->batch, n_slabs);                        \
+    else                                                                                                                  \
+      conv3d_general_wgrad_f32<KT_, KH_, KW_, 4, 1><<<grid, dim3(256), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g,   \
+                                                                               d->batch, n_slabs);                        \
+  } while (0)
     if (g.kt == 2 && g.kh == 3 && g.kw == 3) PV_WG(2, 3, 3);
     else if (g.kt == 3 && g.kh == 3 && g.kw == 3) PV_WG(3, 3, 3);
     else if (g.kt == 1 && g.kh == 3 && g.kw == 3) PV_WG(1, 3, 3);
@@ -485,13 +826,13 @@ int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const floa
 #undef PV_WG
     rc = check_launch("pv_conv3d_general_bwd_weight_f32");
     if (rc) return rc;
-    slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(slabs, dw, n, n_slabs);
-    rc = check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
-    if (rc) return rc;
+    slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(slabs, dw, n, n_slabs);
+    if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 255) / 256)), dim3(256), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
+    return check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
   }
   if (dbias) {
-    conv3d_general_dbias_f32<<<dim3((unsigned)g.c_out), dim3(256), 0, as_stream(stream)>>>(
-        dy, y_relu_mask, dbias, d->batch, g.c_out, g.t_out * g.h_out * g.w_out);
+    conv3d_general_dbias_f32<<<dim3((unsigned)g.c_out), dim3(256), 0, st>>>(dy, y_relu_mask, dbias, d->batch, g.c_out,
+                                                                            g.t_out * g.h_out * g.w_out);
     rc = check_launch("pv_conv3d_general_bwd_weight_f32(dbias)");
   }
   return rc;

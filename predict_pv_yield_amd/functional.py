@@ -182,15 +182,18 @@ def linear_bf16(x, weight, bias, relu=False):
 
 class Conv3dGeneralF32(torch.autograd.Function):
     """nn.Conv3d with kernel extents 1..3, any stride / padding (+ optional fused ReLU) on the exact-f32 kernels:
-    the layers of the optical-flow notebook model (13_…ipynb:969-985) and Conv3dMaxPool's conv."""
+    the layers of the optical-flow notebook model (13_…ipynb:969-985) and Conv3dMaxPool's conv.
+    In a conv+ReLU chain the ReLU gating of the activation gradient is moved into the PRODUCING dgrad kernel:
+    x_is_relu_output -> this layer's dx leaves already zeroed where x <= 0; dy_pregated -> the incoming dy was gated
+    that way by the next layer, so dgrad / wgrad read it without touching y again."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, relu):
+    def forward(ctx, x, weight, bias, stride, padding, relu, x_is_relu_output, dy_pregated):
         x = x.contiguous()
         y = K.conv3d_general_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, stride,
                                      padding, relu)
-        ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, bias is not None
+        ctx.save_for_backward(x, weight, y if (relu and not dy_pregated) else None)
+        ctx.stride, ctx.padding, ctx.has_bias, ctx.x_is_relu_output = stride, padding, bias is not None, x_is_relu_output
         return y
 
     @staticmethod
@@ -199,14 +202,15 @@ class Conv3dGeneralF32(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = K.conv3d_general_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.stride, ctx.padding)
+            dx = K.conv3d_general_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.stride, ctx.padding,
+                                               x_mask=x if ctx.x_is_relu_output else None)
         dw, db = K.conv3d_general_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.stride, ctx.padding,
                                                  need_bias=ctx.has_bias)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False):
-    return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu)
+def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_relu_output=False, dy_pregated=False):
+    return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu, x_is_relu_output, dy_pregated)
 
 
 class MaxPool3dF32(torch.autograd.Function):

@@ -441,12 +441,12 @@ def conv3d_general_fwd_f32(x, weight, bias, stride=1, padding=0, relu=False):
     return y
 
 
-def conv3d_general_bwd_data_f32(dy, y_mask, weight, x_shape, stride=1, padding=0):
-    require_cuda(dy, y_mask, weight)
+def conv3d_general_bwd_data_f32(dy, y_mask, weight, x_shape, stride=1, padding=0, x_mask=None):
+    require_cuda(dy, y_mask, weight, x_mask)
     b, ci, t, h, w = x_shape
     g = conv_geom(b, ci, weight.shape[0], t, h, w, tuple(weight.shape[2:]), stride, padding)
     dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-    check(get_lib().pv_conv3d_general_bwd_data_f32(ptr(dy), ptr(y_mask), ptr(weight), ptr(dx), ctypes.byref(g),
+    check(get_lib().pv_conv3d_general_bwd_data_f32(ptr(dy), ptr(y_mask), ptr(weight), ptr(dx), ptr(x_mask), ctypes.byref(g),
                                                    current_stream_ptr()), "pv_conv3d_general_bwd_data_f32")
     return dx
 

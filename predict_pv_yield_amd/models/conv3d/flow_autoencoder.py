@@ -69,12 +69,17 @@ class LitAutoEncoder(pl.LightningModule):
             batch_size, 1, n_channels, height, width)
         out = torch.cat((images.unsqueeze(1), forecast_horizon), dim=1).float()  # [B, 2, depth, H, W]
         layers = list(self.conv)
+        prev_relu = False
         for i, layer in enumerate(layers):
             if not isinstance(layer, nn.Conv3d):
                 continue
             relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+            # a ReLU output feeds a conv: that conv's dgrad applies the ReLU gate, so this layer sees a pre-gated dy
+            feeds_conv = relu and any(isinstance(m, nn.Conv3d) for m in layers[i + 2:i + 3])
             out = Fn.conv3d_general_f32(out, layer.weight, layer.bias, stride=tuple(layer.stride),
-                                        padding=tuple(layer.padding), relu=relu)
+                                        padding=tuple(layer.padding), relu=relu, x_is_relu_output=prev_relu,
+                                        dy_pregated=feeds_conv)
+            prev_relu = relu
         return out
 
     def _training_or_validation_step(self, batch, is_train_step):

@@ -19,6 +19,11 @@ CASES = [  # (B, Ci, Co, T, H, W, kernel, stride, padding)
     (1, 4, 20, 5, 12, 12, (3, 3, 3), (2, 2, 1), (1, 0, 2)),
     (2, 3, 6, 3, 9, 10, (1, 3, 3), (1, 2, 1), (0, 1, 0)),
     (2, 6, 5, 3, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    # 16..32 channels, unit stride, wide rows: the f32-MFMA wgrad (one and two row tiles, ragged channel counts)
+    (2, 16, 32, 3, 12, 40, (2, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (1, 32, 32, 3, 9, 150, (2, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (1, 20, 24, 4, 8, 70, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 17, 32, 2, 6, 33, (1, 3, 3), (1, 1, 1), (0, 1, 0)),
 ]
 
 
