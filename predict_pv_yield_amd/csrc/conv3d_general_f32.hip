@@ -419,9 +419,24 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_mfma_f32(const float* __rest
   const int a_base = (lane & 31) * S + (lane >> 5);
   const int b_base = (lane & 31) * CS + (lane >> 5);
 
-  const int s0 = blockIdx.x * steps_per_block;
-  const int s1 = s0 + steps_per_block < n_steps ? s0 + steps_per_block : n_steps;
-  for (int s = s0; s < s1; ++s) {
+  // staging registers: every wave moves 4 dy rows and 4*ROWS input rows per step (lanes along w); the global loads of
+  // step s+1 are issued before the MFMA loop of step s and land in LDS after it
+  constexpr int DPL = WT / 64;               // dy values per lane per row
+  constexpr int XPL = R / 64;                // full-lane x values per row (columns 0 .. MAIN-1)
+  constexpr int MAIN = XPL * 64;
+  constexpr int HW = R - MAIN;               // halo columns per row (KW - 1 = 2), gathered lane-wise across rows
+  constexpr int XROWS = 32 * ROWS / 8;       // input rows per wave
+  constexpr int HPL = (XROWS * HW + 63) / 64;
+  float dreg[4][DPL];
+  float xreg[XROWS][XPL];
+  float hreg[HPL];
+
+  // raw buffer loads: per-sample resources, 32-bit byte offsets, out-of-range offset -> 0.0 (no address VGPR pairs,
+  // no selects); the launcher checks that one sample of x / dy is at most 2^30 bytes
+  constexpr uint32_t INVALID = 0x40000000u;
+  const uint32_t x_sample_b = (uint32_t)(g.c_in * vox_in * 4), dy_sample_b = (uint32_t)(g.c_out * vox_out * 4);
+
+  auto load_step = [&](int s) {
     const int wt = s % n_wt;
     int r = s / n_wt;
     const int ho = r % g.h_out;
@@ -429,39 +444,108 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_mfma_f32(const float* __rest
     const int to = r % g.t_out;
     const int b = r / g.t_out;
     const int wo0 = wt * WT;
-    // ---- stage dy row and the input rows --------------------------------------------------------------------------
-    for (int idx = tid; idx < 32 * WT; idx += 512) {
-      const int co = idx / WT, p = idx - co * WT;
-      float v = 0.f;
-      if (co < g.c_out && wo0 + p < g.w_out) {
-        const size_t o = ((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + ho * g.w_out + wo0 + p;
-        v = dy[o];
-        if (gate && !(gate[o] > 0.f)) v = 0.f;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * g.c_in * vox_in), 0, (int)x_sample_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)b * g.c_out * vox_out), 0, (int)dy_sample_b, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((gate ? gate : dy) + (size_t)b * g.c_out * vox_out), 0, (int)dy_sample_b, 0x00020000);
+    const uint32_t d_row = (uint32_t)((to * plane_out + ho * g.w_out + wo0) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int co = wave * 4 + k;
+      const uint32_t srow = (uint32_t)co * (uint32_t)(vox_out * 4) + d_row + (co < g.c_out ? 0u : INVALID);
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) {
+        const int p = lane + 64 * e;
+        const uint32_t voff = srow + (wo0 + p < g.w_out ? (uint32_t)p * 4u : INVALID);
+        float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, voff, 0, 0));
+        if (gate) {
+          const float gv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, voff, 0, 0));
+          if (!(gv > 0.f)) v = 0.f;
+        }
+        dreg[k][e] = v;
       }
-      dyT[co * S + p] = v;
     }
-    for (int idx = tid; idx < 32 * ROWS * R; idx += 512) {
-      const int ci = idx / (ROWS * R);
-      const int rem = idx - ci * (ROWS * R);
-      const int row = rem / R, c = rem - row * R;
+    const int wi0 = wo0 - g.pw;
+    auto row_off = [&](int k) -> uint32_t {   // byte offset of this wave's k-th input row (ci, kt, kh), or INVALID
+      const int ci = wave * 4 + k / ROWS, row = k % ROWS;
       const int kt = row / KH, kh = row - kt * KH;
-      const int ti = to + kt - g.pt, hi = ho + kh - g.ph, wi = wo0 - g.pw + c;
-      float v = 0.f;
-      if (ci < g.c_in && (unsigned)ti < (unsigned)g.t_in && (unsigned)hi < (unsigned)g.h_in && (unsigned)wi < (unsigned)g.w_in)
-        v = x[((size_t)b * g.c_in + ci) * vox_in + (size_t)ti * plane_in + hi * g.w_in + wi];
-      xT[ci * CS + rem] = v;
+      const int ti = to + kt - g.pt, hi = ho + kh - g.ph;
+      const bool ok = ci < g.c_in && (unsigned)ti < (unsigned)g.t_in && (unsigned)hi < (unsigned)g.h_in;
+      return ok ? (uint32_t)(((ci * g.t_in + ti) * g.h_in + hi) * g.w_in * 4) : INVALID;
+    };
+    uint32_t lane_voff[XPL];
+#pragma unroll
+    for (int e = 0; e < XPL; ++e) {
+      const int wi = wi0 + lane + 64 * e;
+      lane_voff[e] = (unsigned)wi < (unsigned)g.w_in ? (uint32_t)wi * 4u : INVALID;
     }
+#pragma unroll
+    for (int k = 0; k < XROWS; ++k) {
+      const uint32_t srow = row_off(k);
+#pragma unroll
+      for (int e = 0; e < XPL; ++e)
+        xreg[k][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, srow + lane_voff[e], 0, 0));
+    }
+#pragma unroll
+    for (int e = 0; e < HPL; ++e) {
+      const int hidx = lane + 64 * e;
+      const int k = hidx / HW, c = MAIN + hidx - k * HW;
+      const int wi = wi0 + c;
+      const uint32_t voff = (k < XROWS ? row_off(k) : INVALID) + ((unsigned)wi < (unsigned)g.w_in ? (uint32_t)wi * 4u : INVALID);
+      hreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, 0, 0));
+    }
+  };
+  // LDS store addresses = one per-lane base + compile-time offsets (wave w owns channels 4w .. 4w+3)
+  float* const dy_st = dyT + wave * 4 * S + lane;
+  float* const x_st = xT + wave * 4 * CS + lane;
+  auto store_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) dy_st[k * S + 64 * e] = dreg[k][e];
+#pragma unroll
+    for (int k = 0; k < XROWS; ++k)
+#pragma unroll
+      for (int e = 0; e < XPL; ++e) x_st[(k / ROWS) * CS + (k % ROWS) * R + 64 * e] = xreg[k][e];
+#pragma unroll
+    for (int e = 0; e < HPL; ++e) {
+      const int hidx = lane + 64 * e;
+      const int k = hidx / HW, c = MAIN + hidx - k * HW;
+      if (k < XROWS) xT[(wave * 4 + k / ROWS) * CS + (k % ROWS) * R + c] = hreg[e];
+    }
+  };
+
+  const int s0 = blockIdx.x * steps_per_block;
+  const int s1 = s0 + steps_per_block < n_steps ? s0 + steps_per_block : n_steps;
+  if (s0 < s1) load_step(s0);
+  for (int s = s0; s < s1; ++s) {
+    store_step();
     __syncthreads();
-    // ---- MFMA over this wave's half of the row ---------------------------------------------------------------------
+    if (s + 1 < s1) load_step(s + 1);
+    // ---- MFMA over this wave's half of the row: LDS operands fetched QB position pairs ahead of their MFMAs ---------
+    constexpr int QB = 4;
     const int q0 = half * (WT / 4), q1 = q0 + WT / 4;
-#pragma unroll 2
-    for (int q = q0; q < q1; ++q) {
-      const float a = dyT[a_base + 2 * q];
+    for (int q = q0; q < q1; q += QB) {
+      float av[QB];
+#pragma unroll
+      for (int u = 0; u < QB; ++u) av[u] = dyT[a_base + 2 * (q + u)];
 #pragma unroll
       for (int i = 0; i < NSLOT; ++i) {
         const int tap = w4 + 4 * i;                            // wave-uniform
-        if (tap < TAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xT[b_base + off[i] + 2 * q], acc[i], 0, 0, 0);
-        else if (tap == TAPS) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, 1.0f, acc[i], 0, 0, 0);
+        if (4 * i + 3 < TAPS || tap <= TAPS) {                 // compile-time true except in the last slot
+          const bool ones = 4 * i + 3 >= TAPS && tap == TAPS;
+          const int o = ones ? 0 : off[i];
+          float bv[QB];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) {
+            const float t = xT[b_base + o + 2 * (q + u)];
+            bv[u] = ones ? 1.0f : t;
+          }
+#pragma unroll
+          for (int u = 0; u < QB; ++u) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[i], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -500,7 +584,8 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_mfma_f32(const float* __rest
 static bool wgrad_mfma_ok(const Geom& g) {
   const bool k_ok = (g.kt == 2 || g.kt == 3 || g.kt == 1) && g.kh == 3 && g.kw == 3;
   return k_ok && g.st == 1 && g.sh == 1 && g.sw == 1 && g.c_in >= 16 && g.c_in <= 32 && g.c_out >= 16 && g.c_out <= 32 &&
-         g.w_out >= 32;
+         g.w_out >= 32 && (long long)g.c_in * g.t_in * g.h_in * g.w_in * 4 <= (1ll << 30) &&
+         (long long)g.c_out * g.t_out * g.h_out * g.w_out * 4 <= (1ll << 30);
 }
 
 static int wgrad_mfma_wt(const Geom& g) { return g.kt * g.kh > 6 ? 64 : 128; }
