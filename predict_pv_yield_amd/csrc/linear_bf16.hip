@@ -134,13 +134,27 @@ __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __res
 // ---------------------------------------------------------------------------------------------
 constexpr int BT = 8;  // tile of the small dimension held in registers
 
+// XCD-aware tile order for the two backward kernels.  Workgroups of a 1-D grid go round-robin over the 8 XCDs (each
+// with its own L2); the `inner` tiles that re-read the same k-block of the big matrix are given consecutive slots of
+// ONE XCD, so that block comes from HBM once and from that XCD's L2 afterwards.
+constexpr int N_XCD = 8;
+__device__ __forceinline__ bool xcd_tile(int inner, int n_kblocks, int* kblock, int* tile) {
+  const int xcd = blockIdx.x % N_XCD, slot = blockIdx.x / N_XCD;
+  *kblock = (slot / inner) * N_XCD + xcd;
+  *tile = slot % inner;
+  return *kblock < n_kblocks;
+}
+static unsigned xcd_grid(unsigned n_kblocks, unsigned inner) { return ((n_kblocks + N_XCD - 1) / N_XCD) * N_XCD * inner; }
+
 // dx[m0..m0+7][k..k+7] = sum_n g[m][n] * w[n][k..k+7]
 __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t* __restrict__ w,
                                                                   const float* __restrict__ dy,
                                                                   const float* __restrict__ ymask,
                                                                   uint16_t* __restrict__ dx, int m, int n, long long k) {
   extern __shared__ float g[];  // [n][BT]
-  const int m0 = blockIdx.y * BT;
+  int kblock, mtile;
+  if (!xcd_tile((m + BT - 1) / BT, (int)((k / 8 + 255) / 256), &kblock, &mtile)) return;
+  const int m0 = mtile * BT;
   for (int i = threadIdx.x; i < n * BT; i += blockDim.x) {
     int col = i / BT, rr = i % BT;
     float v = 0.f;
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t*
     g[i] = v;
   }
   __syncthreads();
-  const long long k8 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long long k8 = ((long long)kblock * blockDim.x + threadIdx.x) * 8;
   if (k8 >= k) return;
   float acc[BT][8];
 #pragma unroll
@@ -204,7 +218,9 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
                                                                   float* __restrict__ exp_avg_sq,
                                                                   uint16_t* __restrict__ shadow, AdamScalars ad) {
   extern __shared__ float g[];  // [m][BT]
-  const int n0 = blockIdx.y * BT;
+  int kblock, ntile;
+  if (!xcd_tile((n + BT - 1) / BT, (int)((k / 8 + 255) / 256), &kblock, &ntile)) return;
+  const int n0 = ntile * BT;
   for (int i = threadIdx.x; i < m * BT; i += blockDim.x) {
     int rr = i / BT, j = i % BT;
     float v = 0.f;
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
     g[i] = v;
   }
   __syncthreads();
-  const long long k8 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const long long k8 = ((long long)kblock * blockDim.x + threadIdx.x) * 8;
   if (k8 >= k) return;
   float acc[BT][8];
 #pragma unroll
@@ -305,6 +321,180 @@ __global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __res
   db[col] = s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 forward / dx for n <= 128, m <= 32 (the fc1 shapes): the [n, KC] weight panel of a k-tile is fetched with
+// row-contiguous 512-byte runs (32 lanes x 16 B per row), staged in LDS once per workgroup and consumed by MFMA from
+// there -- every weight byte crosses HBM once for the forward and once for dx.  The next tile's global loads are in
+// flight while the current one is multiplied.
+// ---------------------------------------------------------------------------------------------
+#ifndef PV_V2_KC
+#define PV_V2_KC 256
+#endif
+constexpr int V2_KC = PV_V2_KC;          // k-columns per tile
+constexpr int V2_WS = V2_KC * 2 + 64;    // LDS row stride in bytes (rows 64 B apart mod 256: conflict-free 8-row reads)
+constexpr int V2_CH = V2_KC / 8;         // 16-byte chunks per row
+constexpr int V2_RPP = 256 / V2_CH;      // rows per pass of the 256 threads
+constexpr int V2_WPASS = 128 / V2_RPP, V2_XPASS = 32 / V2_RPP;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+// rows [0, nrows) of a [*, k] bf16 matrix, columns [k0, k0 + KC): thread t owns 16-byte chunk t % CH of rows
+// t / CH + RPP * i -- a row is fetched as one contiguous KC*2-byte run
+template <int NPASS>
+__device__ __forceinline__ void v2_load(const uint16_t* __restrict__ base, int nrows, long long k, long long k0,
+                                        u32x4 (&r)[NPASS]) {
+  const int chunk = threadIdx.x % V2_CH, rg = threadIdx.x / V2_CH;
+  const long long col = k0 + chunk * 8;
+  const bool c_ok = col < k;   // k % 8 == 0: a chunk is entirely inside or outside
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) {
+    const int row = rg + V2_RPP * i;
+    const bool ok = c_ok && row < nrows;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + (ok ? (size_t)row * k + col : 0));
+    r[i] = ok ? v : (u32x4){0u, 0u, 0u, 0u};
+  }
+}
+template <int NPASS>
+__device__ __forceinline__ void v2_store(unsigned char* lds, const u32x4 (&r)[NPASS]) {
+  const int chunk = threadIdx.x % V2_CH, rg = threadIdx.x / V2_CH;
+#pragma unroll
+  for (int i = 0; i < NPASS; ++i) *reinterpret_cast<u32x4*>(lds + (rg + V2_RPP * i) * V2_WS + chunk * 16) = r[i];
+}
+
+__global__ __launch_bounds__(256) void linear_fwd_bf16_v2_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                  float* __restrict__ partial, int m, int n, long long k,
+                                                                  int n_tiles, int tiles_per_wg) {
+  __shared__ __attribute__((aligned(16))) unsigned char wt[128 * V2_WS];
+  __shared__ __attribute__((aligned(16))) unsigned char xt[32 * V2_WS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int t0 = blockIdx.x * tiles_per_wg;
+  const int t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  u32x4 wr[V2_WPASS], xr[V2_XPASS];
+  if (t0 < t1) {
+    v2_load<V2_WPASS>(w, n, k, (long long)t0 * V2_KC, wr);
+    v2_load<V2_XPASS>(x, m, k, (long long)t0 * V2_KC, xr);
+  }
+  const unsigned char* ap = xt + r * V2_WS + hh * 16;
+  const unsigned char* bp = wt + (wave * 32 + r) * V2_WS + hh * 16;
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();  // the previous tile's LDS reads are done
+    v2_store<V2_WPASS>(wt, wr);
+    v2_store<V2_XPASS>(xt, xr);
+    __syncthreads();
+    if (t + 1 < t1) {
+      v2_load<V2_WPASS>(w, n, k, (long long)(t + 1) * V2_KC, wr);
+      v2_load<V2_XPASS>(x, m, k, (long long)(t + 1) * V2_KC, xr);
+    }
+    if (wave * 32 < n) {
+#pragma unroll
+      for (int ks = 0; ks < V2_KC / 16; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + ks * 32);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int col = wave * 32 + r;
+  if (col < n) {
+    float* dst = partial + (size_t)blockIdx.x * m * n + col;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
+      if (row < m) dst[(size_t)row * n] = acc[j];
+    }
+  }
+}
+
+// dx[m][k] = sum_n g[m][n] w[n][k]: g (f32) enters the MFMA as a bf16 hi + lo pair (two MFMAs per step), so the
+// gradient keeps ~16 mantissa bits; the [n][k] panel is read transposed from LDS (ds_read_b64_tr_b16).
+// Wave w owns the KC/4 columns [w*KC/4, (w+1)*KC/4) of the tile (KC/128 column tiles of 32).
+__global__ __launch_bounds__(256) void linear_bwd_dx_bf16_v2_kernel(const uint16_t* __restrict__ w, const float* __restrict__ dy,
+                                                                     const float* __restrict__ ymask, uint16_t* __restrict__ dx,
+                                                                     int m, int n, long long k, int n_tiles, int tiles_per_wg) {
+  __shared__ __attribute__((aligned(16))) unsigned char wt[128 * V2_WS];
+  constexpr int CPW = V2_KC / 4;   // columns per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nks = (n + 15) / 16;
+  bf16x8 ahi[8], alo[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    s16x4 h0, h1, l0, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int nn = 16 * ks + 8 * hh + j;
+      float v = 0.f;
+      if (r < m && nn < n) {
+        v = dy[(size_t)r * n + nn];
+        if (ymask && !(ymask[(size_t)r * n + nn] > 0.f)) v = 0.f;
+      }
+      const uint16_t hb = f32_to_bf16_bits(v);
+      const float hf = __builtin_bit_cast(float, (uint32_t)hb << 16);
+      const uint16_t lb = f32_to_bf16_bits(v - hf);
+      if (j < 4) h0[j] = (short)hb, l0[j] = (short)lb; else h1[j - 4] = (short)hb, l1[j - 4] = (short)lb;
+    }
+    const __attribute__((ext_vector_type(8))) short h8 = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    const __attribute__((ext_vector_type(8))) short l8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    ahi[ks] = __builtin_bit_cast(bf16x8, h8);
+    alo[ks] = __builtin_bit_cast(bf16x8, l8);
+  }
+  // transposed-read address of this lane: 16-lane group G covers columns 16*(G&1).., rows 8*(G>>1) + 4*s + q
+  const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int tr_off = (8 * (G >> 1) + q) * V2_WS + (wave * CPW + 16 * (G & 1) + 4 * p) * 2;
+
+  const int t0 = blockIdx.x * tiles_per_wg;
+  const int t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+  u32x4 wr[V2_WPASS];
+  if (t0 < t1) v2_load<V2_WPASS>(w, n, k, (long long)t0 * V2_KC, wr);
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+    v2_store<V2_WPASS>(wt, wr);
+    __syncthreads();
+    if (t + 1 < t1) v2_load<V2_WPASS>(w, n, k, (long long)(t + 1) * V2_KC, wr);
+    const long long k0 = (long long)t * V2_KC;
+#pragma unroll
+    for (int c = 0; c < CPW / 32; ++c) {
+      f32x16 acc;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < nks) {
+          const unsigned char* bp = wt + tr_off + ks * 16 * V2_WS + c * 64;
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(bp));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(bp + 4 * V2_WS));
+          const __attribute__((ext_vector_type(8))) short b8s = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          const bf16x8 b8 = __builtin_bit_cast(bf16x8, b8s);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], b8, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], b8, acc, 0, 0, 0);
+        }
+      }
+      const long long kcol = k0 + wave * CPW + c * 32 + r;
+      if (kcol < k) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
+          if (row < m) dx[(size_t)row * k + kcol] = f32_to_bf16_bits(acc[j]);
+        }
+      }
+    }
+  }
+}
+
+static bool v2_shapes(int m, int n) { return m <= 32 && n <= 128 && n % 16 == 0 && n >= 32; }
+static int v2_split(long long k, int* tiles_per_wg, int* n_tiles) {
+  const long long nt = (k + V2_KC - 1) / V2_KC;
+  long long nwg = nt < 512 ? nt : 512;  // 1-2 workgroups per CU (LDS), each with one tile in flight and one in LDS
+  const long long per = (nt + nwg - 1) / nwg;
+  nwg = (nt + per - 1) / per;
+  *tiles_per_wg = (int)per;
+  *n_tiles = (int)nt;
+  return (int)nwg;
+}
+
 static int bf16_fwd_split(long long k, int* kblocks_per_wg) {
   long long total_kb = (k + 63) / 64;
   long long nwg = total_kb < 1024 ? total_kb : 1024;  // 4 workgroups per CU keep ~64 KB of loads in flight per CU
@@ -323,7 +513,7 @@ extern "C" {
 int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes) {
   PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bf16_workspace_bytes: bad arguments");
   int per;
-  int nwg = bf16_fwd_split(k, &per);
+  int nwg = bf16_fwd_split(k, &per);   // >= the v2 split (<= 512 workgroups)
   *bytes = (size_t)nwg * m * n * sizeof(float);
   return PV_OK;
 }
@@ -337,11 +527,21 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
   PV_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), PV_EINVAL, "pv_linear_fwd_bf16: unaligned operand");
   int per;
   int nwg = bf16_fwd_split(k, &per);
-  PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
   hipStream_t st = as_stream(stream);
+  float* part = (float*)workspace;
+  if (v2_shapes(m, n)) {
+    int tiles, n_tiles;
+    const int nwg2 = v2_split(k, &tiles, &n_tiles);
+    PV_REQUIRE(workspace_bytes >= (size_t)nwg2 * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
+    hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
+                       n_tiles, tiles);
+    hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
+                       bias, y, m, n, nwg2, relu ? 1 : 0);
+    return check_launch("pv_linear_fwd_bf16");
+  }
+  PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
   dim3 grid((unsigned)nwg, (unsigned)((n + 127) / 128));
   const int mt = (m + 31) / 32;
-  float* part = (float*)workspace;
   switch (mt) {
     case 1: hipLaunchKernelGGL(linear_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
     case 2: hipLaunchKernelGGL(linear_fwd_bf16_kernel<2>, grid, dim3(256), 0, st, x, w, part, m, n, (long long)k, per); break;
@@ -361,16 +561,23 @@ int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, co
   unsigned kb = (unsigned)((k / 8 + 255) / 256);
   if (dx) {
     PV_REQUIRE(w, PV_EINVAL, "pv_linear_bwd_bf16: dx needs w");
+    if (v2_shapes(m, n)) {
+      int tiles, n_tiles;
+      const int nwg2 = v2_split(k, &tiles, &n_tiles);
+      hipLaunchKernelGGL(linear_bwd_dx_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, w, dy, y_relu_mask, dx, m, n,
+                         (long long)k, n_tiles, tiles);
+    } else {
     size_t lds = (size_t)n * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: n=%d too large", n);
-    hipLaunchKernelGGL(linear_bwd_dx_bf16_kernel, dim3(kb, (unsigned)((m + BT - 1) / BT)), dim3(256), lds, st, w, dy,
+    hipLaunchKernelGGL(linear_bwd_dx_bf16_kernel, dim3(xcd_grid(kb, (unsigned)((m + BT - 1) / BT))), dim3(256), lds, st, w, dy,
                        y_relu_mask, dx, m, n, (long long)k);
+    }
   }
   if (dw) {
     PV_REQUIRE(x, PV_EINVAL, "pv_linear_bwd_bf16: dw needs x");
     size_t lds = (size_t)m * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: m=%d too large", m);
-    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<0>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, st, x, dy,
+    hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<0>, dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds, st, x, dy,
                        y_relu_mask, dw, m, n, (long long)k, (float*)nullptr, (float*)nullptr, (uint16_t*)nullptr,
                        AdamScalars{});
   }
@@ -392,7 +599,7 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                  (float)(-(lr / bc1))};
   unsigned kb = (unsigned)((k / 8 + 255) / 256);
-  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<1>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds,
+  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<1>, dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds,
                      as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, bf16_shadow, ad);
   return check_launch("pv_linear_wgrad_adam_bf16");
 }
@@ -404,7 +611,7 @@ int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_r
   size_t lds = (size_t)m * BT * sizeof(float);
   PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_wgrad_bf16out: m=%d too large", m);
   unsigned kb = (unsigned)((k / 8 + 255) / 256);
-  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<2>, dim3(kb, (unsigned)((n + BT - 1) / BT)), dim3(256), lds, as_stream(stream),
+  hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<2>, dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds, as_stream(stream),
                      x, dy, y_relu_mask, reinterpret_cast<float*>(dw_bf16), m, n, (long long)k, (float*)nullptr,
                      (float*)nullptr, (uint16_t*)nullptr, AdamScalars{});
   return check_launch("pv_linear_wgrad_bf16out");

@@ -160,7 +160,9 @@ def test_linear_f32(device, m, n, k):
     torch.testing.assert_close(bd.grad.cpu(), bias.grad, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("m,n,k", [(2, 16, 34816), (33, 128, 4096 + 64), (64, 128, 8200), (7, 5, 72)])
+@pytest.mark.parametrize("m,n,k", [(2, 16, 34816), (33, 128, 4096 + 64), (64, 128, 8200), (7, 5, 72),
+                                   # LDS-staged v2 kernels (m <= 32, n in 32..128): ragged k tiles, partial rows
+                                   (32, 128, 256 * 37), (5, 128, 256 * 3 + 72), (32, 64, 1000), (17, 96, 131072 + 8)])
 def test_linear_bf16(device, m, n, k):
     K, Fn = _mods()
     g = torch.Generator().manual_seed(m + n)
