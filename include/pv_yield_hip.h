@@ -235,6 +235,16 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
  * next backward kernels read an already-gated gradient.
  * y_ncdhw != 0: y is written as [B,32,To,Ho,Wo] bf16 (the flatten order fc1 expects,
  * predict_pv_yield/models/conv3d/model.py:122) instead of NDHWC. */
+/* Multi-job form of pv_conv3d_pack_weight_bf16: one launch packs up to PV_PACK_MAX_JOBS (weight, orientation) pairs
+ * (all conv layers, forward and dgrad operators) right after the optimiser step.  `jobs` is a HOST array. */
+#define PV_PACK_MAX_JOBS 16
+typedef struct pv_pack_job {
+  const float* w;      /* [c_out, c_in, 3,3,3] f32 */
+  uint16_t* wp;        /* pv_conv3d_packed_weight_elems(contraction channels) bf16 */
+  int32_t c_out, c_in, transpose_flip;
+} pv_pack_job;
+int pv_conv3d_pack_weights_multi_bf16(const pv_pack_job* jobs, int32_t n_jobs, void* stream);
+
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp,
                        const float* bias, uint16_t* y, const uint16_t* out_gate,
                        const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream);
@@ -283,6 +293,21 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
  * and consumed by pv_adam_step_bf16grad (same arithmetic as pv_adam_step_f32 after widening the gradient). */
 int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16,
                             int32_t m, int32_t n, int64_t k, void* stream);
+/* Multi-tensor form of pv_adam_step_f32: one launch steps up to PV_ADAM_MAX_TENSORS parameter tensors that share the
+ * hyper-parameters and the step count (the ~14 small tensors of the model: conv weights/biases, fc2..fc4).  `tensors`
+ * is a HOST array (copied into the kernel arguments).  Element-wise arithmetic identical to pv_adam_step_f32. */
+#define PV_ADAM_MAX_TENSORS 32
+typedef struct pv_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  uint16_t* bf16_shadow; /* may be NULL */
+  uint64_t n;
+} pv_adam_tensor;
+int pv_adam_step_multi_f32(const pv_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                           double eps, int32_t step, float grad_scale, void* stream);
+
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,
                           int32_t step, float grad_scale, void* stream);

@@ -37,6 +37,21 @@ class Conv3dDims(ctypes.Structure):
         return (self.t_in + 2 * self.pad_t - 2, self.h_in + 2 * self.pad_h - 2, self.w_in + 2 * self.pad_w - 2)
 
 
+class AdamTensor(ctypes.Structure):
+    """struct pv_adam_tensor."""
+    _fields_ = [("param", c_vp), ("grad", c_vp), ("exp_avg", c_vp), ("exp_avg_sq", c_vp), ("bf16_shadow", c_vp),
+                ("n", ctypes.c_uint64)]
+
+
+class PackJob(ctypes.Structure):
+    """struct pv_pack_job."""
+    _fields_ = [("w", c_vp), ("wp", c_vp), ("c_out", c_i32), ("c_in", c_i32), ("transpose_flip", c_i32)]
+
+
+PV_ADAM_MAX_TENSORS = 32
+PV_PACK_MAX_JOBS = 16
+
+
 class Conv3dGeom(ctypes.Structure):
     """struct pv_conv3d_geom: kernel extents 1..3, stride, padding."""
     _fields_ = [(n, c_i32) for n in ("batch", "c_in", "c_out", "t_in", "h_in", "w_in", "k_t", "k_h", "k_w",
@@ -97,6 +112,8 @@ SIGNATURES = {
     "pv_maxpool3d_fwd_f32": [c_vp, c_vp, c_vp, _PCG, c_vp],
     "pv_maxpool3d_bwd_f32": [c_vp, c_vp, c_vp, _PCG, c_vp],
     "pv_mse_loss_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
+    "pv_adam_step_multi_f32": [ctypes.POINTER(AdamTensor), c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
+    "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_embedding_fwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],

@@ -420,6 +420,49 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// all (weight, orientation) jobs of a model in one launch: 108 blocks per job (54 for the 32x32x16 fragments, 54 for the
+// 16x16x32 fragments of the two-waves-per-SIMD kernel, which exist only for 32 contraction channels)
+struct PackTable {
+  pv_pack_job job[PV_PACK_MAX_JOBS];
+};
+constexpr int PACK_BLOCKS_PER_JOB = 108;
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(PackTable tab) {
+  const pv_pack_job J = tab.job[blockIdx.x / PACK_BLOCKS_PER_JOB];
+  const int blk = blockIdx.x % PACK_BLOCKS_PER_JOB;
+  const int kch = J.transpose_flip ? J.c_out : J.c_in;
+  const int ks_count = kch <= 16 ? 1 : 2;
+  const float* __restrict__ w = J.w;
+  if (blk < 54) {
+    const int total = 27 * ks_count * 64 * 8;
+    for (int i = blk * 256 + threadIdx.x; i < total; i += 54 * 256) {
+      const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) % ks_count, tap = (i >> 9) / ks_count;
+      const int row = lane & 31, k = ks * 16 + 8 * (lane >> 5) + j;
+      float v = 0.f;
+      if (!J.transpose_flip) {
+        if (row < J.c_out && k < J.c_in) v = w[((size_t)row * J.c_in + k) * 27 + tap];
+      } else {
+        if (row < J.c_in && k < J.c_out) v = w[((size_t)k * J.c_in + row) * 27 + (26 - tap)];
+      }
+      J.wp[i] = f32_to_bf16_bits(v);
+    }
+  } else if (ks_count == 2) {
+    uint16_t* wp2 = J.wp + (size_t)27 * 2 * 64 * 8;
+    const int total = 27 * 2 * 64 * 8;
+    for (int i = (blk - 54) * 256 + threadIdx.x; i < total; i += 54 * 256) {
+      const int j = i & 7, lane = (i >> 3) & 63, half = (i >> 9) & 1, tap = i >> 10;
+      const int row = 16 * half + (lane & 15), k = 8 * (lane >> 4) + j;
+      float v = 0.f;
+      if (!J.transpose_flip) {
+        if (row < J.c_out && k < J.c_in) v = w[((size_t)row * J.c_in + k) * 27 + tap];
+      } else {
+        if (row < J.c_in && k < J.c_out) v = w[((size_t)k * J.c_in + row) * 27 + (26 - tap)];
+      }
+      wp2[i] = f32_to_bf16_bits(v);
+    }
+  }
+}
+
 // dy_eff[B,T,H,W,32] bf16 = NDHWC( dy[B,32,T,H,W] ⊙ (y[B,32,T,H,W] > 0) ), both bf16 NCDHW.
 // Used to bring fc1's input gradient (flatten order) back to the conv layout.
 __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* __restrict__ dy,
@@ -582,6 +625,21 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
                      transpose_flip ? 1 : 0);
   if (ks == 2) launch_pack_weight_v2(w, wp + (size_t)27 * 2 * 64 * 8, c_out, c_in, transpose_flip, as_stream(stream));
   return check_launch("pv_conv3d_pack_weight_bf16");
+}
+
+int pv_conv3d_pack_weights_multi_bf16(const pv_pack_job* jobs, int32_t n_jobs, void* stream) {
+  PV_REQUIRE(jobs && n_jobs > 0 && n_jobs <= PV_PACK_MAX_JOBS, PV_EINVAL, "pv_conv3d_pack_weights_multi_bf16: 1..%d jobs per call",
+             PV_PACK_MAX_JOBS);
+  PackTable tab;
+  for (int i = 0; i < n_jobs; ++i) {
+    PV_REQUIRE(jobs[i].w && jobs[i].wp, PV_EINVAL, "pv_conv3d_pack_weights_multi_bf16: null pointer in job %d", i);
+    PV_REQUIRE(jobs[i].c_out > 0 && jobs[i].c_out <= 32 && jobs[i].c_in > 0 && jobs[i].c_in <= 32, PV_ESIZE,
+               "pv_conv3d_pack_weights_multi_bf16: channels (%d,%d) must be in 1..32", jobs[i].c_out, jobs[i].c_in);
+    tab.job[i] = jobs[i];
+  }
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3((unsigned)(n_jobs * PACK_BLOCKS_PER_JOB)), dim3(256), 0, as_stream(stream),
+                     tab);
+  return check_launch("pv_conv3d_pack_weights_multi_bf16");
 }
 
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp, const float* bias, uint16_t* y,

@@ -267,6 +267,61 @@ __global__ __launch_bounds__(256) void embedding_bwd_f32(const float* __restrict
   dtable[i] = s;
 }
 
+// multi-tensor Adam: block -> (tensor, 1024-element chunk) through a table passed by value in the kernel arguments
+struct AdamTable {
+  pv_adam_tensor t[PV_ADAM_MAX_TENSORS];
+  int blk0[PV_ADAM_MAX_TENSORS + 1];  // first block of each tensor
+  int n_tensors;
+};
+
+__global__ __launch_bounds__(256) void adam_step_multi_f32(AdamTable tab, float one_minus_b1, float beta2, float one_minus_b2,
+                                                            float bc2_sqrt, float eps, float neg_step_size, float grad_scale) {
+  int ti = 0;
+  while (ti + 1 < tab.n_tensors && (int)blockIdx.x >= tab.blk0[ti + 1]) ++ti;
+  const pv_adam_tensor T = tab.t[ti];
+  const size_t i0 = ((size_t)(blockIdx.x - tab.blk0[ti]) * 256 + threadIdx.x) * 4;
+  if (i0 >= T.n) return;
+  const int cnt = T.n - i0 < 4 ? (int)(T.n - i0) : 4;
+  float pv[4], gv[4], mv[4], vv[4];
+  if (cnt == 4) {
+    *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(T.param + i0);
+    *reinterpret_cast<f32x4*>(gv) = *reinterpret_cast<const f32x4*>(T.grad + i0);
+    *reinterpret_cast<f32x4*>(mv) = *reinterpret_cast<const f32x4*>(T.exp_avg + i0);
+    *reinterpret_cast<f32x4*>(vv) = *reinterpret_cast<const f32x4*>(T.exp_avg_sq + i0);
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = j < cnt;
+      pv[j] = ok ? T.param[i0 + j] : 0.f, gv[j] = ok ? T.grad[i0 + j] : 0.f;
+      mv[j] = ok ? T.exp_avg[i0 + j] : 0.f, vv[j] = ok ? T.exp_avg_sq[i0 + j] : 1.f;
+    }
+  }
+  uint16_t sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // same operation order as adam_step_f32
+    const float gr = gv[j] * grad_scale;
+    const float mm = mv[j] + one_minus_b1 * (gr - mv[j]);
+    const float v2 = vv[j] * beta2 + (one_minus_b2 * gr) * gr;
+    const float denom = sqrtf(v2) / bc2_sqrt + eps;
+    const float pp = pv[j] + neg_step_size * (mm / denom);
+    mv[j] = mm, vv[j] = v2, pv[j] = pp;
+    sh[j] = f32_to_bf16_bits(pp);
+  }
+  if (cnt == 4) {
+    *reinterpret_cast<f32x4*>(T.param + i0) = *reinterpret_cast<const f32x4*>(pv);
+    *reinterpret_cast<f32x4*>(T.exp_avg + i0) = *reinterpret_cast<const f32x4*>(mv);
+    *reinterpret_cast<f32x4*>(T.exp_avg_sq + i0) = *reinterpret_cast<const f32x4*>(vv);
+    if (T.bf16_shadow) {
+      const u32x2 o = {(uint32_t)sh[0] | ((uint32_t)sh[1] << 16), (uint32_t)sh[2] | ((uint32_t)sh[3] << 16)};
+      *reinterpret_cast<u32x2*>(T.bf16_shadow + i0) = o;
+    }
+  } else {
+    for (int j = 0; j < cnt; ++j) {
+      T.param[i0 + j] = pv[j], T.exp_avg[i0 + j] = mv[j], T.exp_avg_sq[i0 + j] = vv[j];
+      if (T.bf16_shadow) T.bf16_shadow[i0 + j] = sh[j];
+    }
+  }
+}
+
 static long long fwd_k_chunk(long long k, int* k_splits) {
   // ~8k elements of K per block, at most 512 splits
   long long chunk = 8192;
@@ -376,6 +431,35 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
                      exp_avg, exp_avg_sq, bf16_shadow, n, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)(-step_size), grad_scale);
   return check_launch("pv_adam_step_f32");
+}
+
+int pv_adam_step_multi_f32(const pv_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                           double eps, int32_t step, float grad_scale, void* stream) {
+  PV_REQUIRE(tensors && n_tensors > 0 && n_tensors <= PV_ADAM_MAX_TENSORS, PV_EINVAL,
+             "pv_adam_step_multi_f32: 1..%d tensors per call", PV_ADAM_MAX_TENSORS);
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_adam_step_multi_f32: step must be >= 1");
+  AdamTable tab;
+  int blocks = 0;
+  tab.n_tensors = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const pv_adam_tensor& t = tensors[i];
+    PV_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, PV_EINVAL, "pv_adam_step_multi_f32: null pointer in tensor %d", i);
+    PV_REQUIRE(((uintptr_t)t.param % 16 == 0) && ((uintptr_t)t.grad % 16 == 0) && ((uintptr_t)t.exp_avg % 16 == 0) &&
+                   ((uintptr_t)t.exp_avg_sq % 16 == 0) && ((uintptr_t)t.bf16_shadow % 8 == 0),
+               PV_EINVAL, "pv_adam_step_multi_f32: buffers of tensor %d must be 16-byte aligned", i);
+    PV_REQUIRE(t.n < (1ull << 31), PV_ESIZE, "pv_adam_step_multi_f32: tensor %d too large for the multi-tensor path", i);
+    if (t.n == 0) continue;
+    tab.t[tab.n_tensors] = t;
+    tab.blk0[tab.n_tensors] = blocks;
+    blocks += (int)((t.n + 1023) / 1024);
+    ++tab.n_tensors;
+  }
+  if (tab.n_tensors == 0) return PV_OK;
+  tab.blk0[tab.n_tensors] = blocks;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_step_multi_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-(lr / bc1)), grad_scale);
+  return check_launch("pv_adam_step_multi_f32");
 }
 
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,

@@ -80,12 +80,39 @@ class PackInputBF16(torch.autograd.Function):
         return None
 
 
+def packed_conv_weight(weight: torch.Tensor, transpose_flip: bool) -> torch.Tensor:
+    """MFMA-fragment (bf16) image of a conv weight for the forward (transpose_flip=False) or dgrad operator, cached on
+    the parameter.  HipAdam re-packs every cached image in ONE launch right after it updates the weights; any other
+    in-place change bumps `weight._version` and invalidates the cache here."""
+    cache = getattr(weight, "_pv_packed", None)
+    if cache is None or cache.get("version") != weight._version or cache.get("device") != weight.device:
+        cache = {"version": weight._version, "device": weight.device}
+        weight._pv_packed = cache
+    wp = cache.get(transpose_flip)
+    if wp is None:
+        wp = K.conv3d_pack_weight_bf16(weight.detach().contiguous(), transpose_flip=transpose_flip)
+        cache[transpose_flip] = wp
+    return wp
+
+
+def refresh_packed_conv_weights(params) -> None:
+    """Re-pack, in one launch, every cached fragment image of the given (just updated) conv weights."""
+    jobs = []
+    for p in params:
+        cache = getattr(p, "_pv_packed", None)
+        if cache is None or cache.get("version") != p._version or cache.get("device") != p.device or not p.is_contiguous():
+            continue
+        jobs += [(p.detach(), cache[flip], flip) for flip in (False, True) if flip in cache]
+    if jobs:
+        K.conv3d_pack_weights_multi(jobs)
+
+
 class Conv3dReLUBF16(torch.autograd.Function):
     """xp [B,T,H,W,CPAD] bf16 -> y bf16 NDHWC [B,To,Ho,Wo,32] (or NCDHW [B,Co,To,Ho,Wo] when y_ncdhw)."""
 
     @staticmethod
     def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw, x_is_relu_output, dy_pregated):
-        wp = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=False)
+        wp = packed_conv_weight(weight, False)
         c_out = weight.shape[0]
         y = K.conv3d_fwd_bf16(xp, None, wp, bias.contiguous() if bias is not None else None, c_in, c_out, padding, relu,
                               y_ncdhw)
@@ -110,7 +137,7 @@ class Conv3dReLUBF16(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # dgrad = the forward kernel on dy with padding 2-p and mirrored, channel-swapped weights
-            wpt = K.conv3d_pack_weight_bf16(weight.contiguous(), transpose_flip=True)
+            wpt = packed_conv_weight(weight, True)
             pad_b = tuple(2 - p for p in padding)
             # x_is_relu_output: x = relu(...) of the producer, so (x > 0) IS its ReLU derivative; applying it in this
             # kernel's epilogue hands the producer an already-gated gradient (no gate reads in its wgrad/dgrad)

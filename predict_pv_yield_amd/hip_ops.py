@@ -374,6 +374,33 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 
                                      current_stream_ptr()), "pv_adam_step_f32")
 
 
+def adam_step_multi(items, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """items: list of (param, grad, exp_avg, exp_avg_sq, bf16_shadow | None) sharing hyper-parameters and step count;
+    one launch per _lib.PV_ADAM_MAX_TENSORS tensors instead of one per tensor."""
+    lib = get_lib()
+    for i in range(0, len(items), _lib.PV_ADAM_MAX_TENSORS):
+        chunk = items[i:i + _lib.PV_ADAM_MAX_TENSORS]
+        arr = (_lib.AdamTensor * len(chunk))()
+        for j, (p, g, m, v, sh) in enumerate(chunk):
+            require_cuda(p, g, m, v, sh)
+            arr[j] = _lib.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel())
+        check(lib.pv_adam_step_multi_f32(arr, len(chunk), lr, betas[0], betas[1], eps, step, grad_scale,
+                                         current_stream_ptr()), "pv_adam_step_multi_f32")
+
+
+def conv3d_pack_weights_multi(jobs):
+    """jobs: list of (weight f32 [Co,Ci,3,3,3], packed bf16 buffer, transpose_flip); one launch for all of them."""
+    lib = get_lib()
+    for i in range(0, len(jobs), _lib.PV_PACK_MAX_JOBS):
+        chunk = jobs[i:i + _lib.PV_PACK_MAX_JOBS]
+        arr = (_lib.PackJob * len(chunk))()
+        for j, (w, wp, flip) in enumerate(chunk):
+            require_cuda(w, wp)
+            arr[j] = _lib.PackJob(ptr(w), ptr(wp), w.shape[0], w.shape[1], int(flip))
+        check(lib.pv_conv3d_pack_weights_multi_bf16(arr, len(chunk), current_stream_ptr()),
+              "pv_conv3d_pack_weights_multi_bf16")
+
+
 def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
                            betas=(0.9, 0.999), eps=1e-8):
     """fc1: gradient (dy ⊙ (y>0))^T x computed on the fly and applied by Adam in the same pass (no dw tensor)."""

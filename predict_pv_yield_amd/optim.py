@@ -47,6 +47,8 @@ class HipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
+            plain = {}      # step count -> [(param, grad, exp_avg, exp_avg_sq, bf16 shadow)]: one multi-tensor launch each
+            stepped = []
             for p in group["params"]:
                 pending = getattr(p, "_pv_pending", None)
                 gb = getattr(p, "_pv_grad_bf16", None)
@@ -75,7 +77,13 @@ class HipAdam(torch.optim.Optimizer):
                                          grad_scale=self.grad_scale)
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.adam_step(p, g.float(), st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()), lr=group["lr"],
-                            betas=group["betas"], eps=group["eps"], bf16_shadow=getattr(p, "_pv_bf16_shadow", None),
-                            grad_scale=self.grad_scale)
+                stepped.append(p)
+                plain.setdefault(int(st["step"].item()), []).append(
+                    (p, g.float(), st["exp_avg"], st["exp_avg_sq"], getattr(p, "_pv_bf16_shadow", None)))
+            for step, items in plain.items():
+                K.adam_step_multi(items, step, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                                  grad_scale=self.grad_scale)
+            if stepped:
+                from .functional import refresh_packed_conv_weights
+                refresh_packed_conv_weights(stepped)
         return loss

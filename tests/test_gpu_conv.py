@@ -263,3 +263,51 @@ def test_bf16_gradient_wire_format(device):
         K.adam_step(pa, dwb.float(), ma, va, step, lr=5e-4, grad_scale=0.125)
         K.adam_step_bf16grad(pb, dwb, mb, vb, step, lr=5e-4, grad_scale=0.125)
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+def test_adam_multi_tensor_equals_single(device):
+    """pv_adam_step_multi_f32 = pv_adam_step_f32 applied tensor by tensor, bit for bit (ragged sizes, optional shadow)."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(12)
+    sizes = [1, 3, 1024, 1027, 4096 + 5, 32 * 11 * 27, 6]
+    def fresh():
+        gg = torch.Generator().manual_seed(13)
+        return [[torch.randn(n, generator=gg).to(device) for _ in range(2)] + [torch.rand(n, generator=gg).to(device) * 1e-3]
+                for n in sizes]
+    grads = [torch.randn(n, generator=g).to(device) for n in sizes]
+    a, b = fresh(), fresh()
+    sh_a = [torch.zeros(n, dtype=torch.bfloat16, device=device) if i % 2 == 0 else None for i, n in enumerate(sizes)]
+    sh_b = [torch.zeros(n, dtype=torch.bfloat16, device=device) if i % 2 == 0 else None for i, n in enumerate(sizes)]
+    for step in (1, 2, 7):
+        for (p, m, v), gr, sh in zip(a, grads, sh_a):
+            K.adam_step(p, gr, m, v, step, lr=3e-3, bf16_shadow=sh, grad_scale=0.5)
+        K.adam_step_multi([(p, gr, m, v, sh) for (p, m, v), gr, sh in zip(b, grads, sh_b)], step, lr=3e-3, grad_scale=0.5)
+    for (pa, ma, va), (pb, mb, vb), sa, sb in zip(a, b, sh_a, sh_b):
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+        assert sa is None or torch.equal(sa, sb)
+
+
+def test_pack_weights_multi_equals_single_and_cache_invalidation(device):
+    K, Fn = _mods()
+    g = torch.Generator().manual_seed(14)
+    ws = [torch.randn(32, 11, 3, 3, 3, generator=g).to(device), torch.randn(32, 32, 3, 3, 3, generator=g).to(device),
+          torch.randn(20, 32, 3, 3, 3, generator=g).to(device)]
+    jobs = []
+    for w in ws:
+        for flip in (False, True):
+            jobs.append((w, torch.zeros_like(K.conv3d_pack_weight_bf16(w, flip)), flip))
+    K.conv3d_pack_weights_multi(jobs)
+    for w, wp, flip in jobs:
+        assert torch.equal(wp, K.conv3d_pack_weight_bf16(w, flip))
+    # cache on the parameter: same tensor while the weight is untouched, re-packed after an in-place torch update
+    w = torch.nn.Parameter(ws[1].clone())
+    wp1 = Fn.packed_conv_weight(w, False)
+    assert Fn.packed_conv_weight(w, False) is wp1
+    with torch.no_grad():
+        w.mul_(2.0)
+    wp2 = Fn.packed_conv_weight(w, False)
+    assert wp2 is not wp1 and torch.equal(wp2, K.conv3d_pack_weight_bf16(w.detach(), False))
+    # refresh after an optimiser-style update through a raw kernel (version unchanged): same buffers, new contents
+    K.adam_step(w.detach(), torch.ones_like(w), torch.zeros_like(w), torch.zeros_like(w), 1, lr=0.1)
+    Fn.refresh_packed_conv_weights([w])
+    assert Fn.packed_conv_weight(w, False) is wp2 and torch.equal(wp2, K.conv3d_pack_weight_bf16(w.detach(), False))
