@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--overlap-update", action="store_true",
+                    help="N = 1: launch fc1's fused wgrad+Adam from backward on a side stream (under the conv backward)")
     ap.add_argument("--f32-grads", action="store_true", help="N > 1: all-reduce fc1's gradient in f32 instead of bf16")
     args = ap.parse_args()
 
@@ -206,6 +208,9 @@ def main():
         D.broadcast_parameters(model)
     opt = model.configure_optimizers()
     opt.grad_scale = 1.0 / world
+    if args.overlap_update and not distributed:
+        opt.overlap_large_update = True
+        opt.set_large_grad_mode("fused")
     if distributed:
         # the all-reduce needs a materialised fc1 gradient: bf16 on the wire (half the xGMI bytes), f32 with --f32-grads
         opt.set_large_grad_mode("autograd" if args.f32_grads else "bf16")

@@ -184,7 +184,11 @@ class LinearBF16(torch.autograd.Function):
         if mode == "fused":
             # HipAdam owns this parameter (single process): hand it (x, dy, relu mask); the weight gradient is formed
             # inside the optimiser's pass over p/m/v and never written to memory
-            weight._pv_pending = (x, dy, y)
+            eager = getattr(weight, "_pv_eager_update", None)
+            if eager is not None:
+                eager(x, dy, y)     # HBM-bound update starts now, on a side stream, under the MFMA-bound conv backward
+            else:
+                weight._pv_pending = (x, dy, y)
         elif mode == "bf16":
             # data parallel: the gradient is written once in bf16 and handed to the gradient-sync callback right
             # away, so its all-reduce (99.9 % of the bytes of the step) runs under the conv backward that follows

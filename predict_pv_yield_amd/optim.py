@@ -18,11 +18,17 @@ class HipAdam(torch.optim.Optimizer):
     #             "autograd" -- plain f32 .grad.
     FUSE_MIN_NUMEL = 1 << 22
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True, overlap_large_update=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("HipAdam: invalid hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
+        # fused mode only (opt-in): launch the big layer's wgrad+Adam pass from inside backward on a side stream; step()
+        # then only waits for it.  Measured on MI355X (B=32): no gain -- the conv kernels own a CU's whole register file
+        # and LDS, so the streaming pass cannot co-reside with them and the two still take turns
+        self.overlap_large_update = overlap_large_update
+        self._side_stream = None
+        self._inflight = []
         self.set_large_grad_mode("fused" if fuse_large_linear else "autograd")
 
     def large_params(self):
@@ -36,6 +42,48 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_grad_mode = mode
             p._pv_pending = None
             p._pv_grad_bf16 = None
+            p._pv_eager_update = self._make_eager_update(p) if (mode == "fused" and self.overlap_large_update) else None
+
+    def _group_of(self, p):
+        for g in self.param_groups:
+            if any(q is p for q in g["params"]):
+                return g
+        raise KeyError("parameter not owned by this optimiser")
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def _make_eager_update(self, p):
+        def eager(x, dy, y):
+            from .functional import bf16_shadow_of
+            group = self._group_of(p)
+            with torch.no_grad():
+                st = self._init_state(p)
+                shadow = bf16_shadow_of(p)
+                st["step"] += 1
+                main = torch.cuda.current_stream(p.device)
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=p.device)
+                ready = main.record_event()            # dx (which reads the pre-update weights) is queued before this
+                self._side_stream.wait_event(ready)
+                with torch.cuda.stream(self._side_stream):
+                    K.linear_wgrad_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], shadow, int(st["step"].item()),
+                                             lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    done = self._side_stream.record_event()
+                self._inflight.append((done, (x, dy, y)))   # keep the operands alive until step() has waited
+        return eager
+
+    def _wait_inflight(self):
+        if self._inflight:
+            main = torch.cuda.current_stream()
+            for done, _ in self._inflight:
+                main.wait_event(done)
+            self._inflight = []
 
     def set_fuse_large_linear(self, enabled: bool) -> None:
         self.set_large_grad_mode("fused" if enabled else "autograd")
@@ -46,6 +94,7 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._wait_inflight()
         for group in self.param_groups:
             plain = {}      # step count -> [(param, grad, exp_avg, exp_avg_sq, bf16 shadow)]: one multi-tensor launch each
             stepped = []
@@ -56,11 +105,7 @@ class HipAdam(torch.optim.Optimizer):
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st = self._init_state(p)
                 st["step"] += 1
                 if pending is not None and p.grad is None:
                     from .functional import bf16_shadow_of

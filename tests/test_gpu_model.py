@@ -182,12 +182,35 @@ def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
         opt.zero_grad()
         loss = model_b.training_step(batch, 0)
         loss.backward()
-        assert model_b.fc1.weight.grad is None and model_b.fc1.weight._pv_pending is not None
+        # the update was launched from inside backward on the optimiser's side stream (or left pending for step())
+        assert model_b.fc1.weight.grad is None and (opt._inflight or model_b.fc1.weight._pv_pending is not None)
         opt.step()
         losses_b.append(float(loss))
     assert losses_a == losses_b
     for (k, a), (_, b) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_deferred_and_eager_fused_updates_agree(device, monkeypatch):
+    """overlap_large_update=False (update inside step()) and True (update launched from backward on a side stream)
+    give bit-identical parameters."""
+    from predict_pv_yield_amd.optim import HipAdam
+    monkeypatch.setattr(HipAdam, "FUSE_MIN_NUMEL", 1)
+    sat, pv = _data(SMALL, 2)
+    batch = None
+    results = []
+    for overlap in (False, True):
+        _, model = _pair(SMALL, "bf16", device)
+        opt = HipAdam(model.parameters(), lr=0.0005, overlap_large_update=overlap)
+        batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+        for _ in range(3):
+            opt.zero_grad()
+            model.training_step(batch, 0).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        results.append({k: v.clone() for k, v in model.state_dict().items()})
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), k
 
 
 def test_bf16_gradient_side_channel_in_the_model(device, monkeypatch):
