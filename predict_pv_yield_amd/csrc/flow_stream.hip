@@ -300,6 +300,58 @@ __global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ src, i
   }
 }
 
+// Small images (the 64 x 64 PV-site tiles): one workgroup = one image; the source image is staged in LDS once and all
+// n_steps x 4 bilinear taps per pixel are LDS gathers instead of L1/L2 round trips.  Arithmetic = remap_one, unchanged.
+template <typename T>
+__global__ __launch_bounds__(256) void remap_lds_kernel(const T* __restrict__ src, int64_t src_stride,
+                                                         const float* __restrict__ flow, int64_t flow_stride,
+                                                         T* __restrict__ dst, int64_t dst_image_stride,
+                                                         int64_t dst_step_stride, int n_steps, float step0, int h, int w,
+                                                         int border_mode, T border_value, int split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T* img = reinterpret_cast<T*>(lds_raw);
+  const int64_t img_i = blockIdx.x / split;   // `split` workgroups share an image (each stages all of it: any tap may be needed)
+  const int part = blockIdx.x % split;
+  const T* g = src + img_i * src_stride;
+  const int n_px = h * w;
+  constexpr int PER16 = 16 / sizeof(T);
+  if (((uintptr_t)g % 16 == 0) && (n_px % PER16 == 0)) {
+    for (int i = threadIdx.x; i < n_px / PER16; i += blockDim.x)
+      reinterpret_cast<u32x4*>(img)[i] = reinterpret_cast<const u32x4*>(g)[i];
+  } else {
+    for (int i = threadIdx.x; i < n_px; i += blockDim.x) img[i] = g[i];
+  }
+  __syncthreads();
+  const int wq = w / 4;
+  const int q_per = (h * wq + split - 1) / split;
+  const int q_end = (part + 1) * q_per < h * wq ? (part + 1) * q_per : h * wq;
+  for (int i = part * q_per + threadIdx.x; i < q_end; i += blockDim.x) {
+    const int y = i / wq, x0 = (i - y * wq) * 4;
+    const float* fl = flow + img_i * flow_stride + ((int64_t)y * w + x0) * 2;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(fl);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(fl + 4);
+    const float fxv[4] = {a[0], a[2], b[0], b[2]}, fyv[4] = {a[1], a[3], b[1], b[3]};
+    for (int s = 0; s < n_steps; ++s) {
+      const float k = step0 + (float)s;
+      T outv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float mx = __fadd_rn(-__fmul_rn(fxv[v], k), (float)(x0 + v));
+        const float my = __fadd_rn(-__fmul_rn(fyv[v], k), (float)y);
+        outv[v] = remap_one<T>(img, h, w, mx, my, border_mode, border_value);
+      }
+      T* d = dst + img_i * dst_image_stride + (int64_t)s * dst_step_stride + (int64_t)y * w + x0;
+      if constexpr (sizeof(T) == 4) {
+        const f32x4 o = {(float)outv[0], (float)outv[1], (float)outv[2], (float)outv[3]};
+        *reinterpret_cast<f32x4*>(d) = o;
+      } else {
+        *reinterpret_cast<uint32_t*>(d) = (uint32_t)outv[0] | ((uint32_t)outv[1] << 8) | ((uint32_t)outv[2] << 16) |
+                                          ((uint32_t)outv[3] << 24);
+      }
+    }
+  }
+}
+
 template <typename T>
 static int remap_launch(const T* src, int64_t src_stride, const float* flow, int64_t flow_stride,
                         T* dst, int64_t dst_image_stride, int64_t dst_step_stride, int64_t n_images,
@@ -318,6 +370,17 @@ static int remap_launch(const T* src, int64_t src_stride, const float* flow, int
                 ((dst_image_stride * esz) % (4 * esz) == 0) && ((dst_step_stride * esz) % (4 * esz) == 0) &&
                 ((uintptr_t)dst % (4 * esz) == 0);
   hipStream_t st = as_stream(stream);
+  const size_t img_bytes = (size_t)h * w * esz;
+  if (vec_ok && img_bytes <= 48 * 1024 && n_images >= 128) {
+    const int quads = h * (w / 4);
+    int split = quads / 256;   // one pixel quad (x n_steps) per thread
+    if (split < 1) split = 1;
+    if (split > 8) split = 8;
+    hipLaunchKernelGGL((remap_lds_kernel<T>), dim3((unsigned)(n_images * split)), dim3(256), img_bytes, st, src, src_stride,
+                       flow, flow_stride, dst, dst_image_stride, dst_step_stride, n_steps, step0, h, w, border_mode,
+                       border_value, split);
+    return check_launch("pv_remap_bilinear");
+  }
   if (vec_ok) {
     size_t work = (size_t)n_images * h * (w / 4);
     hipLaunchKernelGGL((remap_kernel<T, 4>), dim3(stream_grid(work, 256)), dim3(256), 0, st, src,

@@ -124,6 +124,33 @@ def test_remap_u8_bit_exact(device, border):
             assert np.array_equal(got[i, s], ref), (i, s)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("border", [fo.BORDER_CONSTANT, fo.BORDER_REPLICATE])
+def test_remap_lds_path_bit_exact(device, dtype, border):
+    """>= 128 small images take the LDS-staged kernel: identical to the oracle and to the global-gather kernel."""
+    K = _ops()
+    rng = np.random.default_rng(77 + border)
+    n, h, w = 131, 64, 64
+    if dtype == "f32":
+        imgs = rng.normal(0, 1, (n, h, w)).astype(np.float32)
+        bv = float("nan")
+    else:
+        imgs = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
+        bv = 9
+    flows = np.stack([_random_flow(rng, h, w, 4.0) for _ in range(n)])
+    flows[5, 0, 0] = [np.nan, 1e12]
+    flows[6] *= 20.0                                   # mostly outside the image
+    t_img, t_fl = torch.from_numpy(imgs).to(device), torch.from_numpy(flows).to(device)
+    got = K.remap_bilinear(t_img, t_fl, n_steps=3, step0=1.0, border_mode=border, border_value=bv).cpu().numpy()
+    small = K.remap_bilinear(t_img[:40], t_fl[:40], n_steps=3, step0=1.0, border_mode=border, border_value=bv).cpu().numpy()
+    eq = same_f32 if dtype == "f32" else np.array_equal
+    assert eq(got[:40], small)
+    for i in (0, 5, 6, 130):
+        for s in range(3):
+            ref = fo.remap_image(imgs[i], flows[i], float(1 + s), border, bv if dtype == "u8" else np.nan)
+            assert eq(got[i, s], ref), (i, s)
+
+
 def _pair(rng, h, w, v):
     seq = blob_texture_sequence(rng, 2, h, w, v)
     u8, _ = fo.convert_10bpp_to_uint8(np.clip(np.rint(seq), 0, 1023).astype(np.int16), 0)
