@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--overlap-update", action="store_true",
                     help="N = 1: launch fc1's fused wgrad+Adam from backward on a side stream (under the conv backward)")
     ap.add_argument("--f32-grads", action="store_true", help="N > 1: all-reduce fc1's gradient in f32 instead of bf16")
+    ap.add_argument("--grad-sync", choices=["sharded", "allreduce"], default="sharded",
+                    help="N > 1, bf16 gradients: 'sharded' = reduce-scatter + per-rank Adam over its rows of fc1 + all-gather "
+                         "of the bf16 operand copy (default); 'allreduce' = every rank steps the whole matrix")
     args = ap.parse_args()
 
     from predict_pv_yield_amd import distributed as D
@@ -213,7 +216,7 @@ def main():
         opt.set_large_grad_mode("fused")
     if distributed:
         # the all-reduce needs a materialised fc1 gradient: bf16 on the wire (half the xGMI bytes), f32 with --f32-grads
-        opt.set_large_grad_mode("autograd" if args.f32_grads else "bf16")
+        opt.set_large_grad_mode("autograd" if args.f32_grads else ("sharded" if args.grad_sync == "sharded" else "bf16"))
 
     g = torch.Generator(device=dev).manual_seed(518 + rank)
     b = args.batch

@@ -80,6 +80,46 @@ def all_reduce_gradients(module: torch.nn.Module, average: bool = False) -> None
             g.div_(w)
 
 
+def row_shard(n_rows: int, rank: int = None, world: int = None):
+    """Equal row shard [r0, r1) of a matrix for the sharded update of the big layer; None if rows % world != 0."""
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    if n_rows % world != 0:
+        return None
+    per = n_rows // world
+    return rank * per, (rank + 1) * per
+
+
+def reduce_scatter_rows(full: torch.Tensor):
+    """Sum `full` [N, K] over ranks and keep only this rank's row shard: (shard [N/W, K], async work).  RCCL:
+    one reduce_scatter (each rank receives 1/W of the bytes of an all-reduce's second half); gloo (tests): all-reduce +
+    slice, same values."""
+    r0, r1 = row_shard(full.shape[0])
+    if dist.get_backend() == "nccl":
+        shard = torch.empty((r1 - r0,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+        work = dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, async_op=True)
+        return shard, work
+    work = dist.all_reduce(full, op=dist.ReduceOp.SUM, async_op=True)
+    return full[r0:r1], work
+
+
+def all_gather_rows(full: torch.Tensor, async_op: bool = True):
+    """Every rank contributes its own row shard of `full` [N, K] (already written in place) and receives the others."""
+    r0, r1 = row_shard(full.shape[0])
+    mine = full[r0:r1].clone()       # 1/W of the matrix; keeps the collective's input distinct from its output
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(full, mine, async_op=async_op)
+    world = dist.get_world_size()
+    per = r1 - r0
+    chunks = [torch.empty_like(mine) for _ in range(world)]
+    work = dist.all_gather(chunks, mine, async_op=False)
+    for r, c in enumerate(chunks):
+        full[r * per:(r + 1) * per].copy_(c)
+    return None
+
+
 class OverlappedGradSync:
     """DDP-style overlap: the all-reduce of a LARGE parameter's gradient is launched from an autograd hook the
     moment that gradient is final, on RCCL's own stream, and is waited for only before the optimiser step.
@@ -104,7 +144,13 @@ class OverlappedGradSync:
         if p.grad is not None:  # None when the gradient travels through the bf16 side channel instead
             self._pending.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
 
-    def _launch_tensor(self, g: torch.Tensor) -> None:
+    def _launch_tensor(self, g: torch.Tensor, param: torch.Tensor = None) -> None:
+        if param is not None and getattr(param, "_pv_grad_mode", None) == "sharded":
+            # ZeRO-1 for the big layer: this rank only needs the summed gradient of the rows it owns
+            shard, work = reduce_scatter_rows(g)
+            param._pv_grad_shard = shard
+            self._pending.append(work)
+            return
         self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self) -> None:

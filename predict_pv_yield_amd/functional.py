@@ -150,6 +150,10 @@ class Conv3dReLUBF16(torch.autograd.Function):
 
 def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a big f32 parameter, kept current by HipAdam (pv_adam_step_f32 writes it)."""
+    work = getattr(weight, "_pv_shadow_work", None)
+    if work is not None:      # all-gather of the row shards other ranks updated (HipAdam "sharded"): stream-level wait
+        work.wait()
+        weight._pv_shadow_work = None
     shadow = getattr(weight, "_pv_bf16_shadow", None)
     version = getattr(weight, "_pv_bf16_shadow_version", None)
     if shadow is None or shadow.device != weight.device or version != weight._version:
@@ -189,14 +193,21 @@ class LinearBF16(torch.autograd.Function):
                 eager(x, dy, y)     # HBM-bound update starts now, on a side stream, under the MFMA-bound conv backward
             else:
                 weight._pv_pending = (x, dy, y)
-        elif mode == "bf16":
+        elif mode in ("bf16", "sharded"):
             # data parallel: the gradient is written once in bf16 and handed to the gradient-sync callback right
-            # away, so its all-reduce (99.9 % of the bytes of the step) runs under the conv backward that follows
+            # away, so its exchange (99.9 % of the bytes of the step) runs under the conv backward that follows.
+            # "bf16": all-reduce, every rank steps the whole matrix; "sharded": reduce-scatter, every rank steps its
+            # own rows and the bf16 operand copy is all-gathered afterwards (HipAdam)
             gb = K.linear_wgrad_bf16out(x, dy, y, weight.shape[0])
-            weight._pv_grad_bf16 = gb
             cb = getattr(weight, "_pv_on_grad", None)
-            if cb is not None:
-                cb(gb)
+            if mode == "bf16":
+                weight._pv_grad_bf16 = gb
+                if cb is not None:
+                    cb(gb)
+            elif cb is not None:
+                cb(gb, weight)              # sets weight._pv_grad_shard
+            else:
+                weight._pv_grad_bf16 = gb   # single process: nothing to scatter
         return dx, dw, (db if ctx.has_bias else None), None
 
 

@@ -153,6 +153,9 @@ class ModelCheckpoint(Callback):
 
     def _save(self, trainer, module, path):
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        for o in trainer.optimizers:       # collective: every rank reaches _save
+            if hasattr(o, "consolidate_sharded"):
+                o.consolidate_sharded()
         if trainer.is_global_zero:
             torch.save({"state_dict": module.state_dict(), "epoch": trainer.current_epoch,
                         "global_step": trainer.global_step,
@@ -375,7 +378,10 @@ class Trainer:
                 if hasattr(o, "grad_scale"):
                     o.grad_scale = 1.0 / self.world_size
                 if hasattr(o, "set_large_grad_mode"):
-                    o.set_large_grad_mode("bf16")    # the all-reduce needs a materialised fc1 gradient: bf16 on the wire
+                    # fc1's gradient travels in bf16 and is reduce-scattered: each rank steps its own rows of the
+                    # matrix and the bf16 operand copy is all-gathered (falls back to a bf16 all-reduce when the rows
+                    # do not divide over the ranks)
+                    o.set_large_grad_mode("sharded")
             from .distributed import OverlappedGradSync
             self._grad_sync = OverlappedGradSync(model)
         for cb in self.callbacks:
@@ -419,6 +425,9 @@ class Trainer:
             self.current_epoch += 1
             if self.current_epoch < self.min_epochs:
                 self.should_stop = False
+        for o in self.optimizers:          # sharded large-parameter update: make every rank's f32 copy complete
+            if hasattr(o, "consolidate_sharded"):
+                o.consolidate_sharded()
         for cb in self.callbacks:
             cb.on_fit_end(self, model)
         self._finish()

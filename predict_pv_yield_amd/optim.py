@@ -35,14 +35,35 @@ class HipAdam(torch.optim.Optimizer):
         return [p for g in self.param_groups for p in g["params"] if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL]
 
     def set_large_grad_mode(self, mode: str) -> None:
-        if mode not in ("fused", "bf16", "autograd"):
+        if mode not in ("fused", "bf16", "sharded", "autograd"):
             raise ValueError(mode)
+        if mode == "sharded":
+            from . import distributed as D
+            if any(D.row_shard(p.shape[0]) is None for p in self.large_params()):
+                mode = "bf16"       # rows do not divide over the ranks: plain all-reduce
         self.large_grad_mode = mode
         for p in self.large_params():
             p._pv_grad_mode = mode
             p._pv_pending = None
             p._pv_grad_bf16 = None
+            p._pv_grad_shard = None
             p._pv_eager_update = self._make_eager_update(p) if (mode == "fused" and self.overlap_large_update) else None
+
+    def consolidate_sharded(self) -> None:
+        """After sharded steps every rank holds current f32 values (parameter, exp_avg, exp_avg_sq) only for the rows it
+        owns.  All-gather them so that state_dict() / checkpoints are complete on every rank.  Collective: call on all ranks."""
+        if not getattr(self, "_sharded_dirty", False):
+            return
+        from . import distributed as D
+        if D.is_distributed():
+            for p in self.large_params():
+                if getattr(p, "_pv_grad_mode", None) != "sharded":
+                    continue
+                st = self.state.get(p, {})
+                for t in (p.data, st.get("exp_avg"), st.get("exp_avg_sq")):
+                    if t is not None:
+                        D.all_gather_rows(t, async_op=False)
+        self._sharded_dirty = False
 
     def _group_of(self, p):
         for g in self.param_groups:
@@ -101,7 +122,8 @@ class HipAdam(torch.optim.Optimizer):
             for p in group["params"]:
                 pending = getattr(p, "_pv_pending", None)
                 gb = getattr(p, "_pv_grad_bf16", None)
-                if p.grad is None and pending is None and gb is None:
+                gs = getattr(p, "_pv_grad_shard", None)
+                if p.grad is None and pending is None and gb is None and gs is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
@@ -113,6 +135,22 @@ class HipAdam(torch.optim.Optimizer):
                     p._pv_pending = None
                     K.linear_wgrad_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                              int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    continue
+                if gs is not None and p.grad is None:
+                    # sharded update (data parallel): Adam over this rank's rows only, then every rank's bf16 operand
+                    # rows are all-gathered; the gather is waited for by the next forward (functional.bf16_shadow_of),
+                    # so it runs under the next step's conv forward.  f32 rows owned by other ranks go stale until
+                    # consolidate_sharded().
+                    from . import distributed as D
+                    from .functional import bf16_shadow_of
+                    p._pv_grad_shard = None
+                    r0, r1 = D.row_shard(p.shape[0])
+                    shadow = bf16_shadow_of(p)
+                    K.adam_step_bf16grad(p[r0:r1], gs, st["exp_avg"][r0:r1], st["exp_avg_sq"][r0:r1],
+                                         int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                                         bf16_shadow=shadow[r0:r1], grad_scale=self.grad_scale)
+                    p._pv_shadow_work = D.all_gather_rows(shadow)
+                    self._sharded_dirty = True
                     continue
                 if gb is not None and p.grad is None:
                     from .functional import bf16_shadow_of

@@ -1,0 +1,56 @@
+"""Worker of tests/test_gpu_ddp.py: one of two data-parallel ranks that SHARE the single GPU of the test box (gloo for
+the collectives, PV_SINGLE_DEVICE=1), training the reduced Conv3D model for a few steps in a given large-gradient mode
+and saving the consolidated parameters of rank 0.  Usage: python ddp_two_rank_worker.py <mode> <out.pt> <steps>"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from predict_pv_yield_amd import distributed as D
+from predict_pv_yield_amd.models.conv3d.model import Model
+from predict_pv_yield_amd.optim import HipAdam
+
+SMALL = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=60, history_minutes=60,
+             number_of_conv3d_layers=4, conv3d_channels=32, image_size_pixels=16, number_sat_channels=11,
+             fc1_output_features=16, fc2_output_features=16, fc3_output_features=16)
+
+
+def main():
+    mode, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    assert D.init_from_env()
+    rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    dev = torch.device("cuda", D.local_device_index())
+    HipAdam.FUSE_MIN_NUMEL = 1            # the reduced model's fc1 counts as the "large" layer
+    torch.manual_seed(518)
+    model = Model(**SMALL, precision="bf16").to(dev)
+    D.broadcast_parameters(model)
+    opt = model.configure_optimizers()
+    opt.grad_scale = 1.0 / world
+    opt.set_large_grad_mode(mode)
+    sync = D.OverlappedGradSync(model, large_numel=model.fc1.weight.numel())
+    g = torch.Generator().manual_seed(7)
+    sat = torch.randn(4, 11, 25, 16, 16, generator=g)
+    pv = torch.rand(4, 25, 128, generator=g)
+    lo, hi = D.shard_range(4)             # each rank trains on its half of the global batch
+    batch = {"satellite": {"data": sat[lo:hi].to(dev)}, "pv": {"pv_yield": pv[lo:hi].to(dev)}}
+    losses = []
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        sync.finish()
+        opt.step()
+        losses.append(float(loss.detach()))
+    y = model(batch).detach().cpu()        # forward AFTER the last step: waits for the all-gathered operand copy
+    opt.consolidate_sharded()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"state": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "y": y,
+                    "exp_avg_fc1": opt.state[model.fc1.weight]["exp_avg"].cpu(), "mode": opt.large_grad_mode}, out_path)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,17 @@ def _worker(rank, world, port, ret):
     sync.remove()
     vals = D.all_reduce_mean_scalars({"MSE/Train": float(rank), "NMAE/Train": 2.0 * rank})
     assert vals == {"MSE/Train": 0.5, "NMAE/Train": 1.0}
+    # row-sharded exchange of the big layer (reduce-scatter / all-gather; gloo takes the emulated forms)
+    assert D.row_shard(16) == ((0, 8) if rank == 0 else (8, 16)) and D.row_shard(15) is None
+    full = torch.arange(16 * 3, dtype=torch.float32).reshape(16, 3) * (rank + 1)
+    shard, work = D.reduce_scatter_rows(full.clone())
+    work.wait()
+    r0, r1 = D.row_shard(16)
+    assert torch.equal(shard, torch.arange(16 * 3, dtype=torch.float32).reshape(16, 3)[r0:r1] * 3)
+    mat = torch.zeros(16, 3)
+    mat[r0:r1] = float(rank + 1)            # every rank wrote only its own rows
+    assert D.all_gather_rows(mat) is None   # gloo: synchronous
+    assert torch.equal(mat[:8], torch.ones(8, 3)) and torch.equal(mat[8:], torch.full((8, 3), 2.0))
     lo, hi = D.shard_range(11)
     assert (lo, hi) == ((0, 6) if rank == 0 else (6, 11))      # independent units: disjoint shards, no collective
     # the Trainer drives the same helpers: a toy fit keeps the replicas identical
