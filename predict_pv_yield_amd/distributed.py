@@ -157,14 +157,24 @@ class OverlappedGradSync:
         """Call after backward, before optimizer.step()."""
         if not is_distributed():
             return
-        grads = [p.grad for p in self.small if p.grad is not None]
-        if grads:
-            flat = torch.cat([g.reshape(-1) for g in grads])
+        params = [p for p in self.small if p.grad is not None]
+        if params:
+            ref = params[0].grad
+            for p in [q for q in params if q.grad.dtype != ref.dtype or q.grad.device != ref.device]:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)       # odd ones out travel alone
+            params = [q for q in params if q.grad.dtype == ref.dtype and q.grad.device == ref.device]
+            # one flat bucket, segments aligned to 16 bytes; after the all-reduce every .grad BECOMES its segment of the
+            # bucket (a view), so nothing is copied back and the multi-tensor Adam reads the bucket directly
+            offs, total = [], 0
+            for p in params:
+                offs.append(total)
+                total += (p.grad.numel() + 3) // 4 * 4
+            flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+            views = [flat[o:o + p.grad.numel()].view_as(p.grad) for o, p in zip(offs, params)]
+            torch._foreach_copy_(views, [p.grad for p in params])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            for p, v in zip(params, views):
+                p.grad = v
         for w in self._pending:
             w.wait()
         self._pending = []
