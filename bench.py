@@ -97,6 +97,23 @@ def measure_conv_roofline(batch, hist_frames, dev):
             "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
 
 
+TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v7.json")
+
+
+def committed_hbm_traffic(cpad: int, batch: int):
+    """HBM bytes per launch of the dominant conv kernel family, from the COMMITTED PMC passes (tools/pmc_traffic.py:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, gfx950-corrected).  PMC counters cannot be collected from
+    inside the timed run; the figure is per launch at B=32 and only reported for that batch."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), TRAFFIC_PROFILE)
+    if batch != 32 or cpad != 32 or not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    fam = [v for k, v in ks.items() if k.startswith("pv::conv3d_fwd_bf16_v2_kernel") or
+           k.startswith("pv::conv3d_fwd_bf16_kernel<32")]
+    n = sum(v["launches"] for v in fam)
+    return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / n) if n else None
+
+
 def measure_hbm_kernels(model, opt, batch_size, t_frames, dev):
     """HBM-bound side of the step: the fused fc1 wgrad+Adam pass (one stream over p, m, v + bf16 shadow) and the
     config-3 advection stages (remap x6 of 11 channels: 16 algorithmic bytes per output pixel)."""
@@ -272,7 +289,8 @@ def main():
         }
         if not args.no_roofline and world == 1:
             out["roofline"] = measure_conv_roofline(b, t_frames, dev)
-            out["roofline"]["traffic_profile"] = "profiles/r01/pmc_hbm_traffic_bench_B32.json (FETCH_SIZE/WRITE_SIZE passes)"
+            out["roofline"]["traffic"] = committed_hbm_traffic(32, b)
+            out["roofline"]["traffic_profile"] = TRAFFIC_PROFILE + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch)"
             out["hbm_bound_kernels"] = measure_hbm_kernels(model, opt, b, t_frames, dev)
         else:
             out["roofline"] = None
