@@ -324,6 +324,42 @@ int pv_embedding_fwd_f32(const float* table, const int64_t* ids, float* out, int
 int pv_embedding_bwd_f32(const float* dout, const int64_t* ids, float* dtable, int32_t n_ids, int32_t dim,
                          int32_t n_rows, void* stream);
 
+/* ---- Perceiver path (perceiver_pytorch.Perceiver as instantiated by predict_pv_yield/models/perceiver/perceiver.py:70-80;
+ * third-party, unpinned: requirements.txt:12) -------------------------------------------------------------------------- */
+/* Batched, arbitrarily strided f32 GEMM on the f32 matrix cores: C[z](m,n) = sum_k A[z](m,k) B[z](k,n) (+bias[n]) (ReLU),
+ * A[z](m,k) at a + z1*a_bs1 + z2*a_bs2 + m*a_rs + k*a_cs (element strides), B likewise, C row-major with ldc; z = z1*batch2
+ * + z2.  k_splits > 1: the k range is cut into k_splits chunks and partial product s goes to c + s*c_ss (the caller sums
+ * them, pv_sum_slabs_f32) -- the form used for weight gradients, whose k is the (huge) row count.
+ * replaces: nn.Linear of Attention.to_q/to_kv/to_out and FeedForward, einsum('b i d, b j d -> b i j') and
+ * einsum('b i j, b j d -> b i d') of Attention.forward, and the autograd products of all of them. */
+typedef struct pv_gemm_desc {
+  int32_t m, n, k;
+  int64_t a_rs, a_cs, b_rs, b_cs, ldc;
+  int32_t batch1, batch2;
+  int64_t a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2;
+  int32_t k_splits;
+  int64_t c_ss;
+} pv_gemm_desc;
+int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream);
+int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
+/* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
+ * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */
+int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int64_t rows,
+                         int32_t d, float eps, void* stream);
+int pv_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
+int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, float* dx,
+                         float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, void* stream);
+/* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
+ * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
+int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);
+int pv_softmax_bwd_f32(const float* p, const float* dp, float* dx, int64_t rows, int32_t len, float scale, void* stream);
+/* GEGLU of FeedForward: x [rows, 2h] -> y [rows, h] = x[:, :h] * gelu_erf(x[:, h:]) and its backward. */
+int pv_geglu_fwd_f32(const float* x, float* y, int64_t rows, int32_t h, void* stream);
+int pv_geglu_bwd_f32(const float* x, const float* dy, float* dx, int64_t rows, int32_t h, void* stream);
+/* Reduce('b n d -> b d', 'mean') of to_logits and its backward. */
+int pv_mean_axis1_fwd_f32(const float* x, float* y, int32_t b, int32_t n, int32_t d, void* stream);
+int pv_mean_axis1_bwd_f32(const float* dy, float* dx, int32_t b, int32_t n, int32_t d, void* stream);
+
 /* ---- loss + optimiser ----------------------------------------------------- */
 /* replaces: F.mse_loss / (y_hat−y).abs().mean() and WeightedLosses.get_mse_exp/get_mae_exp
  * (predict_pv_yield/models/base_model.py:98-103).  out: device f32[4] = {mse, nmae, mse_exp, mae_exp};

@@ -48,6 +48,13 @@ class PackJob(ctypes.Structure):
     _fields_ = [("w", c_vp), ("wp", c_vp), ("c_out", c_i32), ("c_in", c_i32), ("transpose_flip", c_i32)]
 
 
+class GemmDesc(ctypes.Structure):
+    """struct pv_gemm_desc."""
+    _fields_ = [("m", c_i32), ("n", c_i32), ("k", c_i32), ("a_rs", c_i64), ("a_cs", c_i64), ("b_rs", c_i64), ("b_cs", c_i64),
+                ("ldc", c_i64), ("batch1", c_i32), ("batch2", c_i32), ("a_bs1", c_i64), ("a_bs2", c_i64), ("b_bs1", c_i64),
+                ("b_bs2", c_i64), ("c_bs1", c_i64), ("c_bs2", c_i64), ("k_splits", c_i32), ("c_ss", c_i64)]
+
+
 PV_ADAM_MAX_TENSORS = 32
 PV_PACK_MAX_JOBS = 16
 
@@ -114,6 +121,17 @@ SIGNATURES = {
     "pv_mse_loss_f32": [c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp],
     "pv_adam_step_multi_f32": [ctypes.POINTER(AdamTensor), c_i32, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
+    "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
+    "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
+    "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
+    "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
+    "pv_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_vp],
+    "pv_softmax_fwd_f32": [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
+    "pv_softmax_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
+    "pv_geglu_fwd_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
+    "pv_geglu_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp],
+    "pv_mean_axis1_fwd_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "pv_mean_axis1_bwd_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_fwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],

@@ -522,3 +522,141 @@ def mse_loss(y_hat, y, need_grad=True, grad_scale=1.0):
     check(get_lib().pv_mse_loss_f32(ptr(y_hat), ptr(y), y_hat.numel(), float(grad_scale), ptr(out), ptr(grad),
                                     current_stream_ptr()), "pv_mse_loss_f32")
     return out, grad
+
+
+# ---- Perceiver path: strided batched GEMM on the f32 matrix cores + row-wise kernels -----------------------------------
+def _require_device(*tensors):
+    """Like require_cuda but for STRIDED views: the GEMM reads its operands through explicit element strides."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("predict_pv_yield_amd: tensors must live on the MI355X (no CPU path is provided)")
+
+
+def _gemm_views(a: torch.Tensor, b: torch.Tensor):
+    """a [..., M, K], b [..., K, N] with the same (<= 2) leading batch dims (stride-0 broadcast allowed)."""
+    if a.dim() != b.dim() or a.dim() < 2 or a.dim() > 4 or a.shape[:-2] != b.shape[:-2] or a.shape[-1] != b.shape[-2]:
+        raise ValueError(f"gemm: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError("gemm: float32 operands expected")
+    batch = tuple(a.shape[:-2])
+    while len(batch) < 2:
+        a, b, batch = a.unsqueeze(0), b.unsqueeze(0), (1,) + batch
+    return a, b, batch
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = A @ B (+ bias) for arbitrarily STRIDED views (transposes, column slices and per-head permutes are free:
+    only the strides change).  `out`: optional view [..., M, N] with unit last stride to write into."""
+    _require_device(a, b, out)
+    require_cuda(bias)
+    lead = tuple(a.shape[:-2])
+    a4, b4, batch = _gemm_views(a, b)
+    m, k, n = a4.shape[-2], a4.shape[-1], b4.shape[-1]
+    if out is None:
+        out = torch.empty(lead + (m, n), dtype=torch.float32, device=a.device)
+    c4 = out
+    while c4.dim() < 4:
+        c4 = c4.unsqueeze(0)
+    if tuple(c4.shape) != batch + (m, n) or c4.stride(-1) != 1:
+        raise ValueError("gemm: bad output view")
+    d = _lib.GemmDesc(m, n, k, a4.stride(-2), a4.stride(-1), b4.stride(-2), b4.stride(-1), c4.stride(-2), batch[0], batch[1],
+                      a4.stride(0), a4.stride(1), b4.stride(0), b4.stride(1), c4.stride(0), c4.stride(1), 1, 0)
+    check(get_lib().pv_gemm_f32(ptr(a4), ptr(b4), ptr(bias), ptr(c4), ctypes.byref(d), int(relu), current_stream_ptr()),
+          "pv_gemm_f32")
+    return out
+
+
+def gemm_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """C[M, N] = A[M, K] @ B[K, N] for small M, N and a huge K (weight gradients): K is cut over workgroups, the partial
+    products are summed in index order (deterministic)."""
+    _require_device(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
+        raise ValueError(f"gemm_splitk: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
+    m, k, n = a.shape[0], a.shape[1], b.shape[1]
+    tiles = ((m + 127) // 128) * ((n + 63) // 64)
+    splits = max(1, min((1024 + tiles - 1) // tiles, (k + 255) // 256, 4096))
+    if splits == 1:
+        return gemm(a, b)
+    slabs = torch.empty((splits, m, n), dtype=torch.float32, device=a.device)
+    d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, splits, m * n)
+    check(get_lib().pv_gemm_f32(ptr(a), ptr(b), None, ptr(slabs), ctypes.byref(d), 0, current_stream_ptr()), "pv_gemm_f32")
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    check(get_lib().pv_sum_slabs_f32(ptr(slabs), ptr(out), m * n, splits, current_stream_ptr()), "pv_sum_slabs_f32")
+    return out
+
+
+def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    require_cuda(x, w, b)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_layernorm_fwd_f32(ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, eps,
+                                         current_stream_ptr()), "pv_layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True):
+    require_cuda(x, w, dy, mean, rstd)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    nbytes = ctypes.c_size_t(0)
+    check(get_lib().pv_layernorm_bwd_workspace_bytes(rows, d, ctypes.byref(nbytes)), "pv_layernorm_bwd_workspace_bytes")
+    ws = _workspace("layernorm_bwd", nbytes.value, x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty(d, dtype=torch.float32, device=x.device)
+    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_layernorm_bwd_f32(ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), rows, d,
+                                         ptr(ws), nbytes.value, current_stream_ptr()), "pv_layernorm_bwd_f32")
+    return dx, dw, db
+
+
+def softmax_fwd_(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place: x <- softmax(scale * x) over the last dimension (contiguous)."""
+    require_cuda(x)
+    n = x.shape[-1]
+    check(get_lib().pv_softmax_fwd_f32(ptr(x), ptr(x), x.numel() // n, n, scale, current_stream_ptr()), "pv_softmax_fwd_f32")
+    return x
+
+
+def softmax_bwd_(p: torch.Tensor, dp: torch.Tensor, scale: float) -> torch.Tensor:
+    """In place on dp: dp <- scale * p * (dp - sum(dp * p))."""
+    require_cuda(p, dp)
+    n = p.shape[-1]
+    check(get_lib().pv_softmax_bwd_f32(ptr(p), ptr(dp), ptr(dp), p.numel() // n, n, scale, current_stream_ptr()),
+          "pv_softmax_bwd_f32")
+    return dp
+
+
+def geglu_fwd(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    h = x.shape[-1] // 2
+    y = torch.empty(x.shape[:-1] + (h,), dtype=torch.float32, device=x.device)
+    check(get_lib().pv_geglu_fwd_f32(ptr(x), ptr(y), x.numel() // (2 * h), h, current_stream_ptr()), "pv_geglu_fwd_f32")
+    return y
+
+
+def geglu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    require_cuda(x, dy)
+    h = x.shape[-1] // 2
+    dx = torch.empty_like(x)
+    check(get_lib().pv_geglu_bwd_f32(ptr(x), ptr(dy), ptr(dx), x.numel() // (2 * h), h, current_stream_ptr()), "pv_geglu_bwd_f32")
+    return dx
+
+
+def mean_axis1_fwd(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    b, n, d = x.shape
+    y = torch.empty((b, d), dtype=torch.float32, device=x.device)
+    check(get_lib().pv_mean_axis1_fwd_f32(ptr(x), ptr(y), b, n, d, current_stream_ptr()), "pv_mean_axis1_fwd_f32")
+    return y
+
+
+def mean_axis1_bwd(dy: torch.Tensor, n: int) -> torch.Tensor:
+    require_cuda(dy)
+    b, d = dy.shape
+    dx = torch.empty((b, n, d), dtype=torch.float32, device=dy.device)
+    check(get_lib().pv_mean_axis1_bwd_f32(ptr(dy), ptr(dx), b, n, d, current_stream_ptr()), "pv_mean_axis1_bwd_f32")
+    return dx

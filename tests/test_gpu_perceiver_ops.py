@@ -1,0 +1,151 @@
+"""GPU parity of the Perceiver-path kernels (strided batched f32-MFMA GEMM, LayerNorm, scaled softmax, GEGLU, mean) and of
+their autograd bindings against torch CPU ops on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd import perceiver_functional as PF
+    return K, PF
+
+
+@pytest.mark.parametrize("shape", [((), 5, 37, 7), ((), 300, 70, 130), ((3,), 128, 64, 200), ((2, 4), 33, 17, 65),
+                                   ((1, 8), 128, 64, 128), ((), 1, 1000, 40)])
+def test_gemm_strided_views(shape, device):
+    K, _ = _mods()
+    batch, m, k, n = shape
+    g = torch.Generator().manual_seed(m * n + k)
+    a = torch.randn(batch + (m, k), generator=g)
+    b = torch.randn(batch + (k, n), generator=g)
+    bias = torch.randn(n, generator=g)
+    ad, bd = a.to(device), b.to(device)
+    ref = a @ b
+    tol = dict(rtol=1e-4, atol=1e-4 * np.sqrt(k))
+    torch.testing.assert_close(K.gemm(ad, bd).cpu(), ref, **tol)
+    torch.testing.assert_close(K.gemm(ad, bd, bias=bias.to(device), relu=True).cpu(), F.relu(ref + bias), **tol)
+    # transposed operands as views (no copies): a stored [.., k, m], b stored [.., n, k]
+    at = a.transpose(-1, -2).contiguous().to(device).transpose(-1, -2)
+    bt = b.transpose(-1, -2).contiguous().to(device).transpose(-1, -2)
+    torch.testing.assert_close(K.gemm(at, bt).cpu(), ref, **tol)
+    torch.testing.assert_close(K.gemm(ad, bt).cpu(), ref, **tol)
+    # column-sliced operand (k / v halves of a kv projection) and output written into a column slice
+    wide = torch.randn(batch + (k, 2 * n), generator=g).to(device)
+    out = torch.zeros(batch + (m, 2 * n), device=device)
+    K.gemm(ad, wide[..., n:], out=out[..., :n])
+    torch.testing.assert_close(out[..., :n].cpu(), a @ wide[..., n:].cpu(), **tol)
+    assert float(out[..., n:].abs().max()) == 0.0
+
+
+def test_gemm_splitk_weight_gradient_shape(device):
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(4)
+    dy, x = torch.randn(70000, 48, generator=g), torch.randn(70000, 37, generator=g)
+    got = K.gemm_splitk(dy.to(device).t(), x.to(device)).cpu()
+    ref = (dy.double().t() @ x.double()).float()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-2)
+    assert torch.equal(got, K.gemm_splitk(dy.to(device).t(), x.to(device)).cpu())     # deterministic
+
+
+def test_gemm_broadcast_batch(device):
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(20, 16, generator=g)
+    w = torch.randn(3, 16, 24, generator=g)
+    got = K.gemm(lat.to(device).unsqueeze(0).expand(3, 20, 16), w.to(device)).cpu()    # stride-0 batch
+    torch.testing.assert_close(got, lat @ w, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,d", [(5, 37), (1000, 64), (7, 200), (4099, 64)])
+def test_layernorm(rows, d, device):
+    _, PF = _mods()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 3 + 1).requires_grad_(True)
+    w = torch.randn(d, generator=g).requires_grad_(True)
+    b = torch.randn(d, generator=g).requires_grad_(True)
+    ref = F.layer_norm(x, (d,), w, b)
+    dy = torch.randn(rows, d, generator=g)
+    ref.backward(dy)
+    xd, wd, bd = (t.detach().to(device).requires_grad_(True) for t in (x, w, b))
+    y = PF.layer_norm(xd, wd, bd)
+    y.backward(dy.to(device))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("rows,n", [(6, 128), (3, 4096), (2, 5000), (5, 37)])
+def test_softmax_scaled(rows, n, device):
+    _, PF = _mods()
+    g = torch.Generator().manual_seed(rows * n)
+    x = (torch.randn(rows, n, generator=g) * 4).requires_grad_(True)
+    scale = 0.125
+    ref = (x * scale).softmax(dim=-1)
+    dy = torch.randn(rows, n, generator=g)
+    ref.backward(dy)
+    xd = x.detach().to(device).requires_grad_(True)
+    p = PF.softmax_scaled_(xd * 1.0, scale)          # in place on the temporary
+    p.backward(dy.to(device))
+    torch.testing.assert_close(p.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_geglu_and_mean(device):
+    _, PF = _mods()
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(50, 2 * 96, generator=g) * 2).requires_grad_(True)
+    a, gate = x.chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    dy = torch.randn(50, 96, generator=g)
+    ref.backward(dy)
+    xd = x.detach().to(device).requires_grad_(True)
+    y = PF.geglu(xd)
+    y.backward(dy.to(device))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-5, atol=5e-6)     # erff vs the CPU erf
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=5e-6)
+    z = torch.randn(4, 9, 13, generator=g, requires_grad=True)
+    zr = z.mean(dim=1)
+    dz = torch.randn(4, 13, generator=g)
+    zr.backward(dz)
+    zd = z.detach().to(device).requires_grad_(True)
+    m = PF.mean_axis1(zd)
+    m.backward(dz.to(device))
+    torch.testing.assert_close(m.detach().cpu(), zr.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(zd.grad.cpu(), z.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_linear_rows_and_matmul_autograd(device):
+    _, PF = _mods()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 700, 37, generator=g, requires_grad=True)
+    w = (torch.randn(128, 37, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(128, generator=g, requires_grad=True)
+    ref = F.linear(x, w, b)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd, wd, bd = (t.detach().to(device).requires_grad_(True) for t in (x, w, b))
+    y = PF.linear(xd, wd, bd)
+    y.backward(dy.to(device))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+    # attention-shaped products with per-head permuted views
+    q = torch.randn(2, 10, 3 * 8, generator=g, requires_grad=True)
+    kk = torch.randn(2, 50, 3 * 8, generator=g, requires_grad=True)
+    qh = q.view(2, 10, 3, 8).permute(0, 2, 1, 3)
+    kh = kk.view(2, 50, 3, 8).permute(0, 2, 1, 3)
+    ref = qh @ kh.transpose(-1, -2)
+    ds = torch.randn(ref.shape, generator=g)
+    ref.backward(ds)
+    qd, kd = q.detach().to(device).requires_grad_(True), kk.detach().to(device).requires_grad_(True)
+    s = PF.matmul(qd.view(2, 10, 3, 8).permute(0, 2, 1, 3), kd.view(2, 50, 3, 8).permute(0, 2, 1, 3).transpose(-1, -2))
+    s.backward(ds.to(device))
+    torch.testing.assert_close(s.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(qd.grad.cpu(), q.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(kd.grad.cpu(), kk.grad, rtol=1e-4, atol=1e-4)
