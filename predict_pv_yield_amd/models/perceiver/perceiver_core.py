@@ -1,0 +1,161 @@
+"""Perceiver — MI355X implementation of the `perceiver_pytorch.Perceiver` module the reference instantiates
+(predict_pv_yield/models/perceiver/perceiver.py:70-80, perceiver_nwp_sat.py:69-79, perceiver_conv3d_nwp_sat.py:97-107,
+experiments/003_...py:105-114; third-party, unpinned: requirements.txt:12).
+
+Same constructor keywords, same module tree and state_dict keys as the package's 0.7 series (layers.{i}.{0,1,2}.fn/.norm/
+.norm_context, to_logits.{1,2}; with weight_tie_layers layer 0 owns its blocks and layers >= 1 share one set).  The
+modules are parameter holders: every contraction (projections, q.k^T, softmax.v, feed-forward) runs on the f32 matrix
+cores through pv_gemm_f32, LayerNorm / softmax / GEGLU / mean in their own HIP kernels (perceiver_functional.py).
+
+Two things the package recomputes in every layer are computed once here because they are identical by construction:
+the Fourier position features (constant per image size) and — under weight tying — the LayerNorm'd context and its
+key/value projection, which only depend on the shared parameters: one kv tensor for layer 0 and one for all tied layers.
+"""
+from math import pi
+
+import torch
+from torch import nn
+
+from ... import perceiver_functional as PF
+
+
+def fourier_position_features(axis, max_freq: float, num_bands: int) -> torch.Tensor:
+    """[*axis, len(axis) * (2 * num_bands + 1)]: for every axis coordinate p in linspace(-1, 1): sin(p s pi), cos(p s pi) for
+    s in linspace(1, max_freq / 2, num_bands), then p itself.  Input independent: built once per image size."""
+    axis_pos = [torch.linspace(-1.0, 1.0, steps=size) for size in axis]
+    pos = torch.stack(torch.meshgrid(*axis_pos, indexing="ij"), dim=-1).unsqueeze(-1)
+    scales = torch.linspace(1.0, max_freq / 2, num_bands)
+    x = pos * scales * pi
+    enc = torch.cat([x.sin(), x.cos(), pos], dim=-1)
+    return enc.reshape(*axis, -1)
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn, context_dim=None):
+        super().__init__()
+        self.fn = fn
+        self.norm = nn.LayerNorm(dim)
+        self.norm_context = nn.LayerNorm(context_dim) if context_dim is not None else None
+
+
+class GEGLU(nn.Module):
+    pass
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), GEGLU(), nn.Linear(dim * mult, dim))
+
+
+class Attention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(context_dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Linear(inner_dim, query_dim)
+
+
+def _heads(t: torch.Tensor, h: int) -> torch.Tensor:
+    """[b, n, h*d] -> strided view [b, h, n, d] (no copy: the GEMM reads through the strides)."""
+    b, n, hd = t.shape
+    return t.view(b, n, h, hd // h).permute(0, 2, 1, 3)
+
+
+def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+    """Attention.forward given the normalised queries input and the (already projected) keys/values [b, j, 2*inner]."""
+    h = attn.heads
+    inner = attn.to_q.weight.shape[0]
+    q = PF.linear(xn, attn.to_q.weight)                                  # [b, i, inner]
+    k, v = kv[..., :inner], kv[..., inner:]                              # column slices of the kv projection
+    sim = PF.matmul(_heads(q, h), _heads(k, h).transpose(-1, -2))        # [b, h, i, j]
+    p = PF.softmax_scaled_(sim, attn.scale)
+    out = PF.matmul(p, _heads(v, h))                                     # [b, h, i, d]
+    out = out.permute(0, 2, 1, 3).reshape(q.shape[0], q.shape[1], inner)
+    return PF.linear(out, attn.to_out.weight, attn.to_out.bias)
+
+
+def _feed_forward(block: PreNorm, x: torch.Tensor) -> torch.Tensor:
+    ff = block.fn
+    y = PF.layer_norm(x, block.norm.weight, block.norm.bias, block.norm.eps)
+    y = PF.linear(y, ff.net[0].weight, ff.net[0].bias)
+    y = PF.geglu(y)
+    return PF.linear(y, ff.net[2].weight, ff.net[2].bias)
+
+
+class Perceiver(nn.Module):
+    def __init__(self, *, num_freq_bands, depth, max_freq, freq_base=2, input_channels=3, input_axis=2, num_latents=512,
+                 latent_dim=512, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64, num_classes=1000,
+                 attn_dropout=0.0, ff_dropout=0.0, weight_tie_layers=False, fourier_encode_data=True, self_per_cross_attn=1):
+        super().__init__()
+        if attn_dropout or ff_dropout:
+            raise NotImplementedError("dropout is not built (the reference never sets it)")
+        if not fourier_encode_data:
+            raise NotImplementedError("fourier_encode_data=False is not built (the reference never sets it)")
+        self.input_axis, self.max_freq, self.num_freq_bands = input_axis, max_freq, num_freq_bands
+        input_dim = input_axis * ((num_freq_bands * 2) + 1) + input_channels
+        self.latents = nn.Parameter(torch.randn(num_latents, latent_dim))
+        make = dict(
+            cross_attn=lambda: PreNorm(latent_dim, Attention(latent_dim, input_dim, heads=cross_heads, dim_head=cross_dim_head),
+                                       context_dim=input_dim),
+            cross_ff=lambda: PreNorm(latent_dim, FeedForward(latent_dim)),
+            latent_attn=lambda: PreNorm(latent_dim, Attention(latent_dim, heads=latent_heads, dim_head=latent_dim_head)),
+            latent_ff=lambda: PreNorm(latent_dim, FeedForward(latent_dim)))
+        cache = {}
+
+        def get(name, cached):
+            if not cached:
+                return make[name]()
+            if name not in cache:
+                cache[name] = make[name]()
+            return cache[name]
+
+        self.layers = nn.ModuleList([])
+        for i in range(depth):
+            c = i > 0 and weight_tie_layers
+            self_attns = nn.ModuleList([nn.ModuleList([get("latent_attn", c), get("latent_ff", c)])
+                                        for _ in range(self_per_cross_attn)])
+            self.layers.append(nn.ModuleList([get("cross_attn", c), get("cross_ff", c), self_attns]))
+        # Reduce('b n d -> b d', 'mean') has no parameters; Identity keeps the package's indices (to_logits.1 / .2)
+        self.to_logits = nn.Sequential(nn.Identity(), nn.LayerNorm(latent_dim), nn.Linear(latent_dim, num_classes))
+        self._pos_cache = {}
+
+    def _position_features(self, axis, device):
+        key = (tuple(axis), str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = fourier_position_features(axis, self.max_freq, self.num_freq_bands).to(device)
+        return self._pos_cache[key]
+
+    def forward(self, data, mask=None):
+        if mask is not None:
+            raise NotImplementedError("attention masks are not built (the reference never passes one)")
+        if not data.is_cuda:
+            raise RuntimeError("predict_pv_yield_amd Perceiver runs on the MI355X only: move the module and the batch to "
+                               "cuda (there is no CPU fallback)")
+        b, *axis, _ = data.shape
+        assert len(axis) == self.input_axis, "input data must have the right number of axis"
+        enc = self._position_features(axis, data.device)
+        data = torch.cat((data.float(), enc.unsqueeze(0).expand(b, *enc.shape)), dim=-1)
+        data = data.reshape(b, -1, data.shape[-1])                         # [b, positions, channels + fourier]
+        x = self.latents.unsqueeze(0).expand(b, -1, -1)
+        kv_of = {}                                                         # cross-attention block -> projected context
+        for cross_attn, cross_ff, self_attns in self.layers:
+            if id(cross_attn) not in kv_of:
+                ctx = PF.layer_norm(data, cross_attn.norm_context.weight, cross_attn.norm_context.bias,
+                                    cross_attn.norm_context.eps)
+                kv_of[id(cross_attn)] = PF.linear(ctx, cross_attn.fn.to_kv.weight)
+            xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
+            x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)]) + x
+            x = _feed_forward(cross_ff, x) + x
+            for self_attn, self_ff in self_attns:
+                xn = PF.layer_norm(x, self_attn.norm.weight, self_attn.norm.bias, self_attn.norm.eps)
+                kv = PF.linear(xn, self_attn.fn.to_kv.weight)
+                x = _attend(self_attn.fn, xn, kv) + x
+                x = _feed_forward(self_ff, x) + x
+        x = PF.mean_axis1(x)
+        x = PF.layer_norm(x, self.to_logits[1].weight, self.to_logits[1].bias, self.to_logits[1].eps)
+        return PF.linear(x, self.to_logits[2].weight, self.to_logits[2].bias)
