@@ -360,6 +360,16 @@ int pv_geglu_bwd_f32(const float* x, const float* dy, float* dx, int64_t rows, i
 int pv_mean_axis1_fwd_f32(const float* x, float* y, int32_t b, int32_t n, int32_t d, void* stream);
 int pv_mean_axis1_bwd_f32(const float* dy, float* dx, int32_t b, int32_t n, int32_t d, void* stream);
 
+/* Sequential part of nn.GRU (batch_first, gate order r,z,n; predict_pv_yield/models/perceiver/perceiver.py:94-109,193-196)
+ * for one layer: gi[B,T,3H] = x W_ih^T + b_ih (a GEMM), h0[B,H] or NULL (zeros) -> out[B,T,H]; saved[B,T,4H] keeps
+ * (r, z, n, W_hn h + b_hn) for the backward.  bwd: dout[B,T,H] and/or dh_last[B,H] (either may be NULL) -> dgi[B,T,3H],
+ * dh0[B,H] (may be NULL), dw_hh[3H,H], db_hh[3H]; ws >= B*(3H*H + 3H)*4 bytes.  H <= 64. */
+int pv_gru_seq_fwd_f32(const float* gi, const float* h0, const float* w_hh, const float* b_hh, float* out, float* saved,
+                       int32_t batch, int32_t t_len, int32_t hidden, void* stream);
+int pv_gru_seq_bwd_f32(const float* dout, const float* dh_last, const float* h0, const float* out, const float* saved,
+                       const float* w_hh, float* dgi, float* dh0, float* dw_hh, float* db_hh, int32_t batch, int32_t t_len,
+                       int32_t hidden, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- loss + optimiser ----------------------------------------------------- */
 /* replaces: F.mse_loss / (y_hat−y).abs().mean() and WeightedLosses.get_mse_exp/get_mae_exp
  * (predict_pv_yield/models/base_model.py:98-103).  out: device f32[4] = {mse, nmae, mse_exp, mae_exp};

@@ -145,3 +145,66 @@ class OraclePerceiver(nn.Module):
                 x = self_ff(x) + x
         x = x.mean(dim=1)
         return self.to_logits(x)
+
+
+# ---- PerceiverModel: predict_pv_yield/models/perceiver/perceiver.py:42-200 ---------------------------------------------
+N_SAT_CHANNELS = 11            # len(SAT_VARIABLE_NAMES[1:]), perceiver.py:24
+PERCEIVER_OUTPUT_SIZE = 512
+FC_OUTPUT_SIZE = 8
+RNN_HIDDEN_SIZE = 16
+
+
+class OraclePerceiverModel(nn.Module):
+    """Same layer graph and attribute (state_dict) names as the reference PerceiverModel; forward takes plain tensors.
+    nwp image size is the 64 x 64 the reference hard-codes in NWP_SIZE (perceiver.py:36)."""
+
+    def __init__(self, history_minutes=30, forecast_minutes=120, n_nwp_channels=10, batch_size=32, num_latents=128,
+                 latent_dim=64, embedding_dem=16, output_variable="pv_yield", nwp_size=None):
+        super().__init__()
+        from .conv3d_oracle import timestep_arithmetic
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        self.batch_size, self.embedding_dem, self.output_variable = batch_size, embedding_dem, output_variable
+        self.total_seq_length = history_minutes // 5 + forecast_minutes // 5 + 1
+        nwp_size = n_nwp_channels * 64 * 64 if nwp_size is None else nwp_size
+        self.perceiver = OraclePerceiver(input_channels=N_SAT_CHANNELS, input_axis=2, num_freq_bands=6, max_freq=10,
+                                         depth=self.total_seq_length, num_latents=num_latents, latent_dim=latent_dim,
+                                         num_classes=PERCEIVER_OUTPUT_SIZE, weight_tie_layers=True)
+        self.fc1 = nn.Linear(PERCEIVER_OUTPUT_SIZE, 256)
+        self.fc2 = nn.Linear(256 + embedding_dem, 128)
+        self.fc3 = nn.Linear(128, 64)
+        self.fc4 = nn.Linear(64, 32)
+        self.fc5 = nn.Linear(32, FC_OUTPUT_SIZE)
+        if embedding_dem:
+            self.pv_system_id_embedding = nn.Embedding(2048, embedding_dem)
+        self.encoder_rnn = nn.GRU(FC_OUTPUT_SIZE + 1 + nwp_size, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_rnn = nn.GRU(FC_OUTPUT_SIZE + nwp_size, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_fc1 = nn.Linear(RNN_HIDDEN_SIZE, 8)
+        self.decoder_fc2 = nn.Linear(8, 1)
+
+    def forward(self, sat, nwp, yield_history, ids):
+        """sat [B,C,T,H,W]; nwp [B,C,T_nwp,h,w]; yield_history = pv.pv_yield or gsp.gsp_yield [B,T,n]; ids [B,n]."""
+        sat = sat[: self.batch_size].float()
+        batch_size, n_chans, seq_len, width, height = sat.shape
+        x = sat.permute(0, 2, 3, 4, 1).reshape(batch_size * seq_len, width, height, n_chans)
+        out = self.perceiver(x).reshape(batch_size * seq_len, PERCEIVER_OUTPUT_SIZE)
+        out = F.relu(self.fc1(out))
+        if self.embedding_dem:
+            i = ids[: self.batch_size, 0].long().repeat_interleave(self.total_seq_length)
+            out = torch.cat((out, self.pv_system_id_embedding(i)), dim=1)
+        out = F.relu(self.fc2(out))
+        out = F.relu(self.fc3(out))
+        out = F.relu(self.fc4(out))
+        out = F.relu(self.fc5(out))
+        out = out.reshape(batch_size, self.total_seq_length, FC_OUTPUT_SIZE)
+        nwp = nwp[: self.batch_size].float().permute(0, 2, 1, 3, 4)
+        b, nwp_seq_len, c, w, h = nwp.shape
+        nwp = torch.cat([nwp, torch.zeros(b, seq_len - nwp_seq_len, c, w, h)], dim=1).reshape(b, seq_len, c * w * h)
+        rnn_input = torch.cat((out, nwp), dim=2)
+        n_hist = (self.history_len_5 if self.output_variable == "pv_yield" else self.history_len_30) + 1
+        hist = yield_history[: self.batch_size][:, :n_hist, 0].unsqueeze(-1).float()
+        encoder_input = torch.cat((rnn_input[:, :n_hist], hist), dim=2)
+        _, encoder_hidden = self.encoder_rnn(encoder_input)
+        decoder_output, _ = self.decoder_rnn(rnn_input[:, -self.forecast_len:], encoder_hidden)
+        decoder_output = F.relu(self.decoder_fc1(decoder_output))
+        return self.decoder_fc2(decoder_output).squeeze(dim=-1)

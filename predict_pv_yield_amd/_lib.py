@@ -132,6 +132,8 @@ SIGNATURES = {
     "pv_geglu_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp],
     "pv_mean_axis1_fwd_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_mean_axis1_bwd_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "pv_gru_seq_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
+    "pv_gru_seq_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp],
     "pv_embedding_fwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],

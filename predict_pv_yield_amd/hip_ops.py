@@ -660,3 +660,28 @@ def mean_axis1_bwd(dy: torch.Tensor, n: int) -> torch.Tensor:
     dx = torch.empty((b, n, d), dtype=torch.float32, device=dy.device)
     check(get_lib().pv_mean_axis1_bwd_f32(ptr(dy), ptr(dx), b, n, d, current_stream_ptr()), "pv_mean_axis1_bwd_f32")
     return dx
+
+
+def gru_seq_fwd(gi: torch.Tensor, h0: Optional[torch.Tensor], w_hh: torch.Tensor, b_hh: torch.Tensor):
+    require_cuda(gi, h0, w_hh, b_hh)
+    b, t, h3 = gi.shape
+    h = h3 // 3
+    out = torch.empty((b, t, h), dtype=torch.float32, device=gi.device)
+    saved = torch.empty((b, t, 4 * h), dtype=torch.float32, device=gi.device)
+    check(get_lib().pv_gru_seq_fwd_f32(ptr(gi), ptr(h0), ptr(w_hh), ptr(b_hh), ptr(out), ptr(saved), b, t, h,
+                                       current_stream_ptr()), "pv_gru_seq_fwd_f32")
+    return out, saved
+
+
+def gru_seq_bwd(dout, dh_last, h0, out, saved, w_hh, need_dh0: bool):
+    require_cuda(dout, dh_last, h0, out, saved, w_hh)
+    b, t, h = out.shape
+    dgi = torch.empty((b, t, 3 * h), dtype=torch.float32, device=out.device)
+    dh0 = torch.empty((b, h), dtype=torch.float32, device=out.device) if need_dh0 else None
+    dw = torch.empty((3 * h, h), dtype=torch.float32, device=out.device)
+    db = torch.empty((3 * h,), dtype=torch.float32, device=out.device)
+    nbytes = b * (3 * h * h + 3 * h) * 4
+    ws = _workspace("gru_bwd", nbytes, out.device)
+    check(get_lib().pv_gru_seq_bwd_f32(ptr(dout), ptr(dh_last), ptr(h0), ptr(out), ptr(saved), ptr(w_hh), ptr(dgi), ptr(dh0),
+                                       ptr(dw), ptr(db), b, t, h, ptr(ws), nbytes, current_stream_ptr()), "pv_gru_seq_bwd_f32")
+    return dgi, dh0, dw, db

@@ -129,3 +129,43 @@ class MeanAxis1F32(torch.autograd.Function):
 
 def mean_axis1(x):
     return MeanAxis1F32.apply(x)
+
+
+class GRUSequenceF32(torch.autograd.Function):
+    """Sequential part of one nn.GRU layer: (gi [B,T,3H], h0 [B,H] | None, w_hh, b_hh) -> (out [B,T,H], h_T [B,H])."""
+
+    @staticmethod
+    def forward(ctx, gi, h0, w_hh, b_hh):
+        gi = gi.contiguous()
+        h0c = h0.contiguous() if h0 is not None else None
+        out, saved = K.gru_seq_fwd(gi, h0c, w_hh.contiguous(), b_hh.contiguous())
+        ctx.save_for_backward(h0c, out, saved, w_hh)
+        ctx.has_h0 = h0 is not None
+        return out, out[:, -1].clone()
+
+    @staticmethod
+    def backward(ctx, dout, dh_last):
+        h0, out, saved, w_hh = ctx.saved_tensors
+        dgi, dh0, dw, db = K.gru_seq_bwd(dout.contiguous() if dout is not None else None,
+                                         dh_last.contiguous() if dh_last is not None else None, h0, out, saved,
+                                         w_hh.contiguous(), need_dh0=ctx.has_h0 and ctx.needs_input_grad[1])
+        return dgi, dh0, dw, db
+
+
+def gru(x, params, h0=None):
+    """nn.GRU(batch_first=True) forward: x [B,T,in]; params = the module's nn.GRU (weight_ih_l{k}, weight_hh_l{k}, bias_*);
+    h0 [layers,B,H] or None.  Returns (output of the last layer [B,T,H], h_n [layers,B,H])."""
+    h_n = []
+    inp = x
+    for layer in range(params.num_layers):
+        w_ih, w_hh = getattr(params, f"weight_ih_l{layer}"), getattr(params, f"weight_hh_l{layer}")
+        b_ih, b_hh = getattr(params, f"bias_ih_l{layer}"), getattr(params, f"bias_hh_l{layer}")
+        if inp.shape[-1] >= 2048:
+            # very wide input (the flattened NWP image rides along): few rows x huge K -> the split-K linear kernels
+            from .functional import linear_f32
+            gi = linear_f32(inp.reshape(-1, inp.shape[-1]), w_ih, b_ih, relu=False).view(inp.shape[0], inp.shape[1], -1)
+        else:
+            gi = linear(inp, w_ih, b_ih)                   # every time step's input projection in one GEMM
+        inp, h_last = GRUSequenceF32.apply(gi, h0[layer] if h0 is not None else None, w_hh, b_hh)
+        h_n.append(h_last)
+    return inp, torch.stack(h_n)

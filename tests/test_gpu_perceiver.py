@@ -71,3 +71,68 @@ def test_on_cpu_fails_loudly():
     from predict_pv_yield_amd.models.perceiver.perceiver_core import Perceiver
     with pytest.raises(RuntimeError, match="MI355X"):
         Perceiver(**KW)(torch.zeros(1, 4, 4, 11))
+
+
+# ---- PerceiverModel (predict_pv_yield/models/perceiver/perceiver.py:42-200) --------------------------------------------
+def _model_pair(device, **kw):
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
+    torch.manual_seed(5)
+    oracle = po.OraclePerceiverModel(**kw)
+    model = PerceiverModel(**kw)
+    assert list(model.state_dict().keys()) == list(oracle.state_dict().keys())
+    model.load_state_dict(oracle.state_dict())
+    return oracle, model.to(device)
+
+
+def _model_batch(b, t5, t30, px, seed=6):
+    g = torch.Generator().manual_seed(seed)
+    return dict(sat=torch.randn(b, 11, t5, px, px, generator=g), nwp=torch.randn(b, 10, 3, 64, 64, generator=g),
+                pv=torch.rand(b, t5, 128, generator=g), gsp=torch.rand(b, t30, 32, generator=g),
+                row=torch.randint(0, 940, (b, 128), generator=g), gsp_id=torch.randint(1, 339, (b, 32), generator=g))
+
+
+@pytest.mark.parametrize("output_variable", ["pv_yield", "gsp_yield"])
+def test_perceiver_model_train_step_vs_oracle(output_variable, device):
+    kw = dict(history_minutes=10, forecast_minutes=30 if output_variable == "pv_yield" else 60, batch_size=2, num_latents=16,
+              latent_dim=64, embedding_dem=16, output_variable=output_variable)
+    oracle, model = _model_pair(device, **kw)
+    t5 = kw["history_minutes"] // 5 + kw["forecast_minutes"] // 5 + 1
+    t30 = kw["history_minutes"] // 30 + kw["forecast_minutes"] // 30 + 1
+    d = _model_batch(2, t5, t30, 8)
+    yld, ids = (d["pv"], d["row"]) if output_variable == "pv_yield" else (d["gsp"], d["gsp_id"])
+    y_ref = oracle(d["sat"], d["nwp"], yld, ids)
+    assert y_ref.shape == (2, oracle.forecast_len)
+    target = yld[:2, -oracle.forecast_len:, 0]
+    loss_ref = (y_ref - target).abs().mean()
+    loss_ref.backward()
+    batch = {"satellite": {"data": d["sat"].to(device)}, "nwp": {"data": d["nwp"].to(device)},
+             "pv": {"pv_yield": d["pv"].to(device), "pv_system_row_number": d["row"].to(device)},
+             "gsp": {"gsp_yield": d["gsp"].to(device), "gsp_id": d["gsp_id"].to(device)}}
+    y = model(batch)
+    torch.testing.assert_close(y.detach().cpu(), y_ref.detach(), rtol=1e-3, atol=1e-4)
+    loss = model.training_step(batch, 0)
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-4 * abs(float(loss_ref)) + 1e-6
+    loss.backward()
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = q.grad.abs().max().item() + 1e-12
+        assert (p.grad.cpu() - q.grad).abs().max().item() <= 5e-3 * scale + 1e-6, k
+    opt = model.configure_optimizers()
+    opt.step()                                  # all parameters step through the multi-tensor Adam
+
+
+def test_perceiver_model_reference_test_shapes(device):
+    """tests/models/perceiver/test_perceiver.py: init with 3/3 minutes; forward with 30/60 minutes on 16 px satellite,
+    64 px NWP, batch 2 -> [2, 12]."""
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, make_fake_batch
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel, params
+    _ = PerceiverModel(history_minutes=3, forecast_minutes=3, nwp_channels=params["nwp_channels"])
+    model = PerceiverModel(history_minutes=30, forecast_minutes=60, nwp_channels=params["nwp_channels"],
+                           embedding_dem=2048).to(device)
+    cfg = FakeDataConfiguration(batch_size=2, history_minutes=30, forecast_minutes=60, satellite_image_size_pixels=16,
+                                nwp_image_size_pixels=64)
+    x = make_fake_batch(cfg, torch.Generator().manual_seed(1))
+    y = model(x.to(device))
+    assert len(y.shape) == 2 and y.shape[0] == 2 and y.shape[1] == 60 // 5

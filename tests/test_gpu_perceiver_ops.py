@@ -149,3 +149,32 @@ def test_linear_rows_and_matmul_autograd(device):
     torch.testing.assert_close(s.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(qd.grad.cpu(), q.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(kd.grad.cpu(), kk.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,t,inp,h,layers", [(3, 7, 20, 16, 2), (2, 1, 9, 16, 1), (5, 24, 33, 8, 2)])
+def test_gru_vs_torch(b, t, inp, h, layers, device):
+    """nn.GRU(batch_first) forward/backward (outputs and final hidden state both carry gradients, optional h0)."""
+    _, PF = _mods()
+    torch.manual_seed(b * t)
+    ref = torch.nn.GRU(input_size=inp, hidden_size=h, num_layers=layers, batch_first=True)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(b, t, inp, generator=g, requires_grad=True)
+    h0 = torch.randn(layers, b, h, generator=g, requires_grad=True)
+    out_r, hn_r = ref(x, h0)
+    d_out, d_hn = torch.randn(out_r.shape, generator=g), torch.randn(hn_r.shape, generator=g)
+    (out_r * d_out).sum().add((hn_r * d_hn).sum()).backward()
+    mod = torch.nn.GRU(input_size=inp, hidden_size=h, num_layers=layers, batch_first=True)
+    mod.load_state_dict(ref.state_dict())
+    mod.to(device)
+    xd, h0d = x.detach().to(device).requires_grad_(True), h0.detach().to(device).requires_grad_(True)
+    out, hn = PF.gru(xd, mod, h0d)
+    (out * d_out.to(device)).sum().add((hn * d_hn.to(device)).sum()).backward()
+    torch.testing.assert_close(out.detach().cpu(), out_r.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hn.detach().cpu(), hn_r.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(h0d.grad.cpu(), h0.grad, rtol=1e-3, atol=1e-5)
+    for (k, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        torch.testing.assert_close(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-4, msg=k)
+    # without an initial state (zeros), as the encoder is called
+    out2, _ = PF.gru(xd.detach(), mod)
+    torch.testing.assert_close(out2.cpu(), ref(x.detach())[0], rtol=1e-4, atol=1e-5)
