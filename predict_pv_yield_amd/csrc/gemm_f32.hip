@@ -116,13 +116,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
   }
 }
 
+// out[i] = sum over s of slabs[s * stride + offset + i], i < n.  Workgroup = 32 columns x 8 slab groups: thread (c, g)
+// adds slabs g, g+8, ... in index order, the 8 group sums are then added in group order -- a fixed order, 8-way parallel.
 __global__ __launch_bounds__(256) void sum_slabs_f32(const float* __restrict__ slabs, float* __restrict__ out, long long n,
-                                                     int n_slabs) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                     int n_slabs, long long stride, long long offset) {
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int k = grp; k < n_slabs; k += 8) s += slabs[(size_t)k * stride + offset + i];
+  red[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && i < n)
+    out[i] = ((((((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]) + red[4][c]) + red[5][c]) + red[6][c]) + red[7][c];
+}
+
+void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(sum_slabs_f32, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slabs, out, n, n_slabs, stride, offset);
 }
 
 }  // namespace pv
@@ -156,8 +168,7 @@ int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, con
 
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream) {
   PV_REQUIRE(slabs && out && n > 0 && n_slabs > 0, PV_EINVAL, "pv_sum_slabs_f32: bad arguments");
-  hipLaunchKernelGGL(sum_slabs_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), slabs, out,
-                     (long long)n, n_slabs);
+  launch_sum_slabs(slabs, out, (long long)n, n_slabs, (long long)n, 0, as_stream(stream));
   return check_launch("pv_sum_slabs_f32");
 }
 

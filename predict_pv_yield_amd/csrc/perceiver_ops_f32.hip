@@ -237,19 +237,12 @@ __global__ __launch_bounds__(256) void mean_axis1_bwd_f32(const float* __restric
   dx[i] = dy[(size_t)bi * d + c] / (float)n;
 }
 
-// out[c] = sum over r of part[r * stride + offset + c], fixed order
-__global__ __launch_bounds__(256) void sum_rows_strided_f32(const float* __restrict__ part, float* __restrict__ out, int n,
-                                                             int n_rows, int stride, int offset) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.f;
-  for (int r = 0; r < n_rows; ++r) s += part[(size_t)r * stride + offset + c];
-  out[c] = s;
-}
+void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
+                      hipStream_t st);   // gemm_f32.hip
 
 static int ln_blocks(long long rows, int* rows_per_block) {
   long long nb = (rows + 3) / 4;          // at least one row per wave
-  if (nb > 2048) nb = 2048;
+  if (nb > 1024) nb = 1024;
   long long per = ((rows + nb - 1) / nb + 3) / 4 * 4;
   *rows_per_block = (int)per;
   return (int)((rows + per - 1) / per);
@@ -288,8 +281,8 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
   float* part = (float*)ws;
   hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per);
   // part is [nb][2][d]: summed over blocks in index order, straight into dw and db
-  hipLaunchKernelGGL(sum_rows_strided_f32, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, part, dw, d, nb, 2 * d, 0);
-  hipLaunchKernelGGL(sum_rows_strided_f32, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, part, db, d, nb, 2 * d, d);
+  launch_sum_slabs(part, dw, d, nb, 2 * d, 0, st);
+  launch_sum_slabs(part, db, d, nb, 2 * d, d, st);
   return check_launch("pv_layernorm_bwd_f32");
 }
 

@@ -6,6 +6,17 @@ import torch
 from . import hip_ops as K
 
 
+_ONES = {}
+
+
+def _ones_row(n: int, device) -> torch.Tensor:
+    """Cached [1, n] row of ones (the bias gradient is ones @ dy)."""
+    key = (n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones((1, n), dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
 class LinearRowsF32(torch.autograd.Function):
     """y[..., out] = x[..., in] @ W[out, in]^T (+ bias): nn.Linear over an arbitrary number of rows (rows >> in, out)."""
 
@@ -25,8 +36,7 @@ class LinearRowsF32(torch.autograd.Function):
         dw = K.gemm_splitk(dy2.t(), x2)                                   # [out, rows] @ [rows, in]
         db = None
         if ctx.has_bias:
-            ones = torch.ones((1, dy2.shape[0]), dtype=torch.float32, device=dy2.device)
-            db = K.gemm_splitk(ones, dy2).view(-1)
+            db = K.gemm_splitk(_ones_row(dy2.shape[0], dy2.device), dy2).view(-1)     # column sums on the matrix cores
         return dx, dw, db
 
 
