@@ -60,22 +60,10 @@ class Attention(nn.Module):
         self.to_out = nn.Linear(inner_dim, query_dim)
 
 
-def _heads(t: torch.Tensor, h: int) -> torch.Tensor:
-    """[b, n, h*d] -> strided view [b, h, n, d] (no copy: the GEMM reads through the strides)."""
-    b, n, hd = t.shape
-    return t.view(b, n, h, hd // h).permute(0, 2, 1, 3)
-
-
 def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
-    """Attention.forward given the normalised queries input and the (already projected) keys/values [b, j, 2*inner]."""
-    h = attn.heads
-    inner = attn.to_q.weight.shape[0]
+    """Attention.forward given the normalised query input and the (already projected) keys/values [b, j, 2*inner]."""
     q = PF.linear(xn, attn.to_q.weight)                                  # [b, i, inner]
-    k, v = kv[..., :inner], kv[..., inner:]                              # column slices of the kv projection
-    sim = PF.matmul(_heads(q, h), _heads(k, h).transpose(-1, -2))        # [b, h, i, j]
-    p = PF.softmax_scaled_(sim, attn.scale)
-    out = PF.matmul(p, _heads(v, h))                                     # [b, h, i, d]
-    out = out.permute(0, 2, 1, 3).reshape(q.shape[0], q.shape[1], inner)
+    out = PF.attention_core(q, kv, attn.heads, attn.scale)               # softmax(scale q k^T) v, per head
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias)
 
 

@@ -65,6 +65,52 @@ def matmul(a, b):
     return MatmulF32.apply(a, b)
 
 
+def _head_view(t: torch.Tensor, h: int, lo: int, hi: int) -> torch.Tensor:
+    """Columns [lo, hi) of t [b, n, c] as a strided per-head view [b, h, n, (hi-lo)/h]: no copy, the GEMM reads / writes
+    through the strides."""
+    b, n, _ = t.shape
+    return t[..., lo:hi].unflatten(-1, (h, (hi - lo) // h)).permute(0, 2, 1, 3)
+
+
+class AttentionCoreF32(torch.autograd.Function):
+    """softmax(scale * q k^T) v of Attention.forward for q [b, i, h*d] and the fused key/value projection kv [b, j, 2*h*d]
+    (k = first half, v = second half of the last dimension, heads interleaved as '(h d)').  The four GEMMs of the forward
+    and the five of the backward read q / k / v / dout per head through strided views and WRITE out, dq and the two halves
+    of dkv in place through strided views as well, so no chunk / permute / slice-gradient copies or zero fills exist;
+    the scores tensor is softmax'ed in place and kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        q, kv = q.contiguous(), kv.contiguous()
+        inner = q.shape[-1]
+        qh, kh, vh = _head_view(q, heads, 0, inner), _head_view(kv, heads, 0, inner), _head_view(kv, heads, inner, 2 * inner)
+        p = K.softmax_fwd_(K.gemm(qh, kh.transpose(-1, -2)), scale)                 # [b, h, i, j]
+        out = torch.empty_like(q)
+        K.gemm(p, vh, out=_head_view(out, heads, 0, inner))
+        ctx.save_for_backward(q, kv, p)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, p = ctx.saved_tensors
+        h, inner = ctx.heads, q.shape[-1]
+        dout = dout.contiguous()
+        qh, kh, vh = _head_view(q, h, 0, inner), _head_view(kv, h, 0, inner), _head_view(kv, h, inner, 2 * inner)
+        doh = _head_view(dout, h, 0, inner)
+        dkv = torch.empty_like(kv)
+        K.gemm(p.transpose(-1, -2), doh, out=_head_view(dkv, h, inner, 2 * inner))          # dv = p^T dout
+        ds = K.softmax_bwd_(p, K.gemm(doh, vh.transpose(-1, -2)), ctx.scale)                # dp -> ds, in place
+        dq = torch.empty_like(q)
+        K.gemm(ds, kh, out=_head_view(dq, h, 0, inner))                                     # dq = ds k
+        K.gemm(ds.transpose(-1, -2), qh, out=_head_view(dkv, h, 0, inner))                  # dk = ds^T q
+        return dq, dkv, None, None
+
+
+def attention_core(q, kv, heads, scale):
+    return AttentionCoreF32.apply(q, kv, heads, scale)
+
+
 class SoftmaxScaledF32(torch.autograd.Function):
     """softmax(scale * x, dim=-1), computed IN PLACE on x (the scores are a fresh GEMM output nobody else reads);
     the backward overwrites the incoming gradient the same way."""
