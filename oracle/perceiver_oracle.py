@@ -208,3 +208,89 @@ class OraclePerceiverModel(nn.Module):
         decoder_output, _ = self.decoder_rnn(rnn_input[:, -self.forecast_len:], encoder_hidden)
         decoder_output = F.relu(self.decoder_fc1(decoder_output))
         return self.decoder_fc2(decoder_output).squeeze(dim=-1)
+
+
+class _OracleHeadMixin:
+    def _make_head(self, embedding_dem, rnn_extra):
+        self.fc1 = nn.Linear(PERCEIVER_OUTPUT_SIZE, 256)
+        self.fc2 = nn.Linear(256 + embedding_dem, 128)
+        self.fc3 = nn.Linear(128, 64)
+        self.fc4 = nn.Linear(64, 32)
+        self.fc5 = nn.Linear(32, FC_OUTPUT_SIZE)
+        if embedding_dem:
+            self.pv_system_id_embedding = nn.Embedding(2048, embedding_dem)
+        self.encoder_rnn = nn.GRU(FC_OUTPUT_SIZE + 1 + rnn_extra, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_rnn = nn.GRU(FC_OUTPUT_SIZE + rnn_extra, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_fc1 = nn.Linear(RNN_HIDDEN_SIZE, 8)
+        self.decoder_fc2 = nn.Linear(8, 1)
+
+    def _head(self, out, batch_size, yield_history, row_ids):
+        out = F.relu(self.fc1(out.reshape(-1, PERCEIVER_OUTPUT_SIZE)))
+        if self.embedding_dem:
+            i = row_ids[: self.batch_size, 0].long().repeat_interleave(self.total_seq_length)
+            out = torch.cat((out, self.pv_system_id_embedding(i)), dim=1)
+        out = F.relu(self.fc5(F.relu(self.fc4(F.relu(self.fc3(F.relu(self.fc2(out))))))))
+        rnn_input = out.reshape(batch_size, self.total_seq_length, FC_OUTPUT_SIZE)
+        n_hist = (self.history_len_5 if self.output_variable == "pv_yield" else self.history_len_30) + 1
+        hist = yield_history[: self.batch_size][:, :n_hist, 0].unsqueeze(-1).float()
+        _, hidden = self.encoder_rnn(torch.cat((rnn_input[:, :n_hist], hist), dim=2))
+        dec, _ = self.decoder_rnn(rnn_input[:, -self.forecast_len:], hidden)
+        return self.decoder_fc2(F.relu(self.decoder_fc1(dec))).squeeze(dim=-1)
+
+
+def _stack(sat, nwp):
+    b, c, t, w, h = sat.shape
+    sat = sat.permute(0, 2, 3, 4, 1).reshape(b * t, w, h, c)
+    nwp = nwp.permute(0, 2, 3, 4, 1)
+    _, tn, wn, hn, cn = nwp.shape
+    nwp = torch.cat([nwp, torch.zeros(b, t - tn, wn, hn, cn)], dim=1).reshape(b * t, wn, hn, cn)
+    return torch.cat((sat, nwp), dim=-1), b
+
+
+class OraclePerceiverNwpSatModel(nn.Module, _OracleHeadMixin):
+    """predict_pv_yield/models/perceiver/perceiver_nwp_sat.py:41-204."""
+
+    def __init__(self, history_minutes, forecast_minutes, n_nwp_channels=10, batch_size=32, num_latents=128, latent_dim=64,
+                 embedding_dem=16, output_variable="pv_yield"):
+        super().__init__()
+        from .conv3d_oracle import timestep_arithmetic
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        self.batch_size, self.embedding_dem, self.output_variable = batch_size, embedding_dem, output_variable
+        self.total_seq_length = history_minutes // 5 + forecast_minutes // 5 + 1
+        self.perceiver = OraclePerceiver(input_channels=N_SAT_CHANNELS + n_nwp_channels, input_axis=2, num_freq_bands=6,
+                                         max_freq=10, depth=self.total_seq_length, num_latents=num_latents,
+                                         latent_dim=latent_dim, num_classes=PERCEIVER_OUTPUT_SIZE, weight_tie_layers=True)
+        self._make_head(embedding_dem, 0)
+
+    def forward(self, sat, nwp, yield_history, row_ids):
+        data, b = _stack(sat[: self.batch_size].float(), nwp[: self.batch_size].float())
+        return self._head(self.perceiver(data), b, yield_history, row_ids)
+
+
+class OraclePerceiverConv3dNwpSatModel(nn.Module, _OracleHeadMixin):
+    """predict_pv_yield/models/perceiver/perceiver_conv3d_nwp_sat.py:60-235."""
+
+    def __init__(self, history_minutes, forecast_minutes, n_nwp_channels=10, batch_size=32, num_latents=128, latent_dim=64,
+                 embedding_dem=16, output_variable="pv_yield", conv3d_channels=16, use_future_satellite_images=True):
+        super().__init__()
+        from .conv3d_oracle import OracleConv3dMaxPool, timestep_arithmetic
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        self.batch_size, self.embedding_dem, self.output_variable = batch_size, embedding_dem, output_variable
+        self.use_future_satellite_images = use_future_satellite_images
+        self.total_seq_length = history_minutes // 5 + forecast_minutes // 5 + 1
+        self.sat_conv3d_maxpool = OracleConv3dMaxPool(out_channels=conv3d_channels, in_channels=N_SAT_CHANNELS)
+        self.nwp_conv3d_maxpool = OracleConv3dMaxPool(out_channels=conv3d_channels, in_channels=n_nwp_channels)
+        self.perceiver = OraclePerceiver(input_channels=2 * conv3d_channels, input_axis=2, num_freq_bands=6, max_freq=10,
+                                         depth=self.total_seq_length, num_latents=num_latents, latent_dim=latent_dim,
+                                         num_classes=PERCEIVER_OUTPUT_SIZE, weight_tie_layers=True)
+        self._make_head(embedding_dem, 0)
+
+    def forward(self, sat, nwp, yield_history, row_ids):
+        sat = sat[: self.batch_size].float()
+        if not self.use_future_satellite_images:
+            sat = sat.clone()
+            sat[:, -self.forecast_len_5:] = 0          # dim 1 (channels), as written in the reference
+        data, b = _stack(self.sat_conv3d_maxpool(sat), self.nwp_conv3d_maxpool(nwp[: self.batch_size].float()))
+        return self._head(self.perceiver(data), b, yield_history, row_ids)

@@ -39,6 +39,76 @@ FC_OUTPUT_SIZE = 8
 RNN_HIDDEN_SIZE = 16
 
 
+def perceiver_head(model, out, x, batch_size, id_from_output_variable: bool, rnn_extra=None):
+    """Everything after the Perceiver, shared by the three Perceiver models (perceiver.py:131-200,
+    perceiver_nwp_sat.py:140-204, perceiver_conv3d_nwp_sat.py:172-235): fc1 -> [system-id embedding] -> fc2..fc5 -> per-step
+    features [B, T, 8] (+ rnn_extra [B, T, E]) -> GRU encoder over the history (+ yield history) -> GRU decoder over the
+    forecast steps -> decoder_fc1/2 -> [B, forecast_len]."""
+    from ... import functional as Fn
+    from ... import perceiver_functional as PF
+    out = out.reshape(-1, PERCEIVER_OUTPUT_SIZE)
+    out = Fn.linear_f32(out, model.fc1.weight, model.fc1.bias, relu=True)
+
+    # ********************** Embedding of PV system ID ********************
+    if model.embedding_dem:
+        if id_from_output_variable and model.output_variable != "pv_yield":
+            id = x.gsp.gsp_id[0 : model.batch_size, 0]
+        else:
+            id = x.pv.pv_system_row_number[0 : model.batch_size, 0]
+        id = id.to(device=out.device, dtype=torch.int64).repeat_interleave(model.total_seq_length)
+        out = torch.cat((out, Fn.embedding(model.pv_system_id_embedding.weight, id)), dim=1)
+
+    # Fully connected layers.
+    out = Fn.linear_f32(out, model.fc2.weight, model.fc2.bias, relu=True)
+    out = Fn.linear_f32(out, model.fc3.weight, model.fc3.bias, relu=True)
+    out = Fn.linear_f32(out, model.fc4.weight, model.fc4.bias, relu=True)
+    out = Fn.linear_f32(out, model.fc5.weight, model.fc5.bias, relu=True)
+
+    # ******************* PREP DATA FOR RNN *******************************
+    out = out.reshape(batch_size, model.total_seq_length, FC_OUTPUT_SIZE)
+    rnn_input = out if rnn_extra is None else torch.cat((out, rnn_extra), dim=2)
+
+    if model.output_variable == "pv_yield":
+        # the history of the pv yield of this system
+        pv_yield_history = x.pv.pv_yield[0 : model.batch_size][:, : model.history_len_5 + 1, 0].unsqueeze(-1).float()
+        encoder_input = torch.cat((rnn_input[:, : model.history_len_5 + 1], pv_yield_history), dim=2)
+    elif model.output_variable == "gsp_yield":
+        gsp_history = x.gsp.gsp_yield[0 : model.batch_size][:, : model.history_len_30 + 1, 0].unsqueeze(-1).float()
+        encoder_input = torch.cat((rnn_input[:, : model.history_len_30 + 1], gsp_history), dim=2)
+
+    _, encoder_hidden = PF.gru(encoder_input, model.encoder_rnn)
+    decoder_output, _ = PF.gru(rnn_input[:, -model.forecast_len :], model.decoder_rnn, encoder_hidden)
+    # decoder_output is shape batch_size, seq_len, rnn_hidden_size
+
+    b, t, h = decoder_output.shape
+    decoder_output = Fn.linear_f32(decoder_output.reshape(b * t, h), model.decoder_fc1.weight, model.decoder_fc1.bias, relu=True)
+    decoder_output = Fn.linear_f32(decoder_output, model.decoder_fc2.weight, model.decoder_fc2.bias, relu=False)
+    return decoder_output.reshape(b, t)
+
+
+def make_perceiver_head(model, rnn_extra_size: int):
+    """The layers perceiver_head() uses, with the reference's attribute names (state_dict keys)."""
+    model.fc1 = nn.Linear(in_features=PERCEIVER_OUTPUT_SIZE, out_features=256)
+    model.fc2 = nn.Linear(in_features=256 + model.embedding_dem, out_features=128)
+    model.fc3 = nn.Linear(in_features=128, out_features=64)
+    model.fc4 = nn.Linear(in_features=64, out_features=32)
+    model.fc5 = nn.Linear(in_features=32, out_features=FC_OUTPUT_SIZE)
+    if model.embedding_dem:
+        model.pv_system_id_embedding = nn.Embedding(num_embeddings=2048, embedding_dim=model.embedding_dem)
+    model.encoder_rnn = nn.GRU(input_size=FC_OUTPUT_SIZE + 1 + rnn_extra_size, hidden_size=RNN_HIDDEN_SIZE, num_layers=2,
+                               batch_first=True)   # plus 1 for history
+    model.decoder_rnn = nn.GRU(input_size=FC_OUTPUT_SIZE + rnn_extra_size, hidden_size=RNN_HIDDEN_SIZE, num_layers=2,
+                               batch_first=True)
+    model.decoder_fc1 = nn.Linear(in_features=RNN_HIDDEN_SIZE, out_features=8)
+    model.decoder_fc2 = nn.Linear(in_features=8, out_features=1)
+
+
+def require_cuda_input(t, who):
+    if not t.is_cuda:
+        raise RuntimeError(f"predict_pv_yield_amd {who} runs on the MI355X only: move the module and the batch to cuda "
+                           "(there is no CPU fallback)")
+
+
 class PerceiverModel(BaseModel):
 
     name = "perceiver"
@@ -79,43 +149,15 @@ class PerceiverModel(BaseModel):
             weight_tie_layers=True,
         )
 
-        self.fc1 = nn.Linear(in_features=PERCEIVER_OUTPUT_SIZE, out_features=256)
-        self.fc2 = nn.Linear(in_features=256 + self.embedding_dem, out_features=128)
-        self.fc3 = nn.Linear(in_features=128, out_features=64)
-        self.fc4 = nn.Linear(in_features=64, out_features=32)
-        self.fc5 = nn.Linear(in_features=32, out_features=FC_OUTPUT_SIZE)
-
-        if self.embedding_dem:
-            self.pv_system_id_embedding = nn.Embedding(num_embeddings=2048, embedding_dim=self.embedding_dem)
-
-        self.encoder_rnn = nn.GRU(
-            input_size=FC_OUTPUT_SIZE + 1 + NWP_SIZE,  # plus 1 for history
-            hidden_size=RNN_HIDDEN_SIZE,
-            num_layers=2,
-            batch_first=True,
-        )
-        self.decoder_rnn = nn.GRU(
-            input_size=FC_OUTPUT_SIZE + NWP_SIZE,
-            hidden_size=RNN_HIDDEN_SIZE,
-            num_layers=2,
-            batch_first=True,
-        )
-
-        self.decoder_fc1 = nn.Linear(in_features=RNN_HIDDEN_SIZE, out_features=8)
-        self.decoder_fc2 = nn.Linear(in_features=8, out_features=1)
+        make_perceiver_head(self, rnn_extra_size=NWP_SIZE)
 
     def forward(self, x):
         if type(x) == dict:
             x = BatchML(**x)
-        from ... import functional as Fn
-        from ... import perceiver_functional as PF
-
         # ******************* Satellite imagery *************************
         # Shape: batch_size, channel, seq_length, height, width
         sat_data = x.satellite.data[0 : self.batch_size].float()
-        if not sat_data.is_cuda:
-            raise RuntimeError("predict_pv_yield_amd PerceiverModel runs on the MI355X only: move the module and the batch "
-                               "to cuda (there is no CPU fallback)")
+        require_cuda_input(sat_data, "PerceiverModel")
         batch_size, n_chans, seq_len, width, height = sat_data.shape
 
         # Stack timesteps as examples (to make a large batch), channels last
@@ -124,28 +166,8 @@ class PerceiverModel(BaseModel):
         sat_data = sat_data.reshape(new_batch_size, width, height, n_chans)
 
         out = self.perceiver(sat_data)
-        out = out.reshape(new_batch_size, PERCEIVER_OUTPUT_SIZE)
-        out = Fn.linear_f32(out, self.fc1.weight, self.fc1.bias, relu=True)
 
-        # ********************** Embedding of PV system ID ********************
-        if self.embedding_dem:
-            if self.output_variable == "pv_yield":
-                id = x.pv.pv_system_row_number[0 : self.batch_size, 0]
-            else:
-                id = x.gsp.gsp_id[0 : self.batch_size, 0]
-            id = id.to(device=out.device, dtype=torch.int64).repeat_interleave(self.total_seq_length)
-            out = torch.cat((out, Fn.embedding(self.pv_system_id_embedding.weight, id)), dim=1)
-
-        # Fully connected layers.
-        out = Fn.linear_f32(out, self.fc2.weight, self.fc2.bias, relu=True)
-        out = Fn.linear_f32(out, self.fc3.weight, self.fc3.bias, relu=True)
-        out = Fn.linear_f32(out, self.fc4.weight, self.fc4.bias, relu=True)
-        out = Fn.linear_f32(out, self.fc5.weight, self.fc5.bias, relu=True)
-
-        # ******************* PREP DATA FOR RNN *******************************
-        out = out.reshape(batch_size, self.total_seq_length, FC_OUTPUT_SIZE)
-
-        # *********************** NWP Data ************************************
+        # *********************** NWP Data (rides along into the RNNs, flattened) ************************************
         # Shape: batch_size, channel, seq_length, width, height -> seq_len to dim 1
         nwp_data = x.nwp.data[0 : self.batch_size].float().permute(0, 2, 1, 3, 4)
         batch_size, nwp_seq_len, n_nwp_chans, nwp_width, nwp_height = nwp_data.shape
@@ -154,23 +176,4 @@ class PerceiverModel(BaseModel):
                                      device=nwp_data.device)
         nwp_data = torch.cat([nwp_data, nwp_data_zeros], dim=1)
         nwp_data = nwp_data.reshape(batch_size, seq_len, n_nwp_chans * nwp_width * nwp_height)
-
-        rnn_input = torch.cat((out, nwp_data), dim=2)
-
-        if self.output_variable == "pv_yield":
-            # the history of the pv yield of this system
-            pv_yield_history = x.pv.pv_yield[0 : self.batch_size][:, : self.history_len_5 + 1, 0].unsqueeze(-1).float()
-            encoder_input = torch.cat((rnn_input[:, : self.history_len_5 + 1], pv_yield_history), dim=2)
-        elif self.output_variable == "gsp_yield":
-            gsp_history = x.gsp.gsp_yield[0 : self.batch_size][:, : self.history_len_30 + 1, 0].unsqueeze(-1).float()
-            encoder_input = torch.cat((rnn_input[:, : self.history_len_30 + 1], gsp_history), dim=2)
-
-        _, encoder_hidden = PF.gru(encoder_input, self.encoder_rnn)
-        decoder_output, _ = PF.gru(rnn_input[:, -self.forecast_len :], self.decoder_rnn, encoder_hidden)
-        # decoder_output is shape batch_size, seq_len, rnn_hidden_size
-
-        b, t, h = decoder_output.shape
-        decoder_output = Fn.linear_f32(decoder_output.reshape(b * t, h), self.decoder_fc1.weight, self.decoder_fc1.bias,
-                                       relu=True)
-        decoder_output = Fn.linear_f32(decoder_output, self.decoder_fc2.weight, self.decoder_fc2.bias, relu=False)
-        return decoder_output.reshape(b, t)
+        return perceiver_head(self, out, x, batch_size, id_from_output_variable=True, rnn_extra=nwp_data)
