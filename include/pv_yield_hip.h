@@ -342,6 +342,26 @@ typedef struct pv_gemm_desc {
 } pv_gemm_desc;
 int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
+/* Fused attention out = softmax(scale q k^T) v with an online softmax on the f32 matrix cores (the scores never reach
+ * memory).  Element (b, h, i, d) of q / out at q + b*q_batch_stride + i*q_row_stride + h*64 + d; of k / v (separate base
+ * pointers, e.g. the two halves of a fused kv projection) at k + b*k_batch_stride + j*k_row_stride + h*64 + d.
+ * lse[b, h, i] = log sum_j exp(scale q_i.k_j) is saved for the backward.  head_dim must be 64.
+ * replaces: the two einsums and the softmax of perceiver_pytorch's Attention.forward (see pv_gemm_f32). */
+typedef struct pv_attention_desc {
+  int32_t batch, heads, n_q, n_k, head_dim;
+  int64_t q_batch_stride, q_row_stride, k_batch_stride, k_row_stride;
+  float scale;
+} pv_attention_desc;
+int pv_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
+                         void* stream);
+/* Backward of pv_attention_fwd_f32 for n_q <= 128: the probabilities are recomputed tile by tile from lse; dq has the
+ * layout of q, dk / dv the layout of k / v (separate base pointers); delta_ws: scratch of
+ * pv_attention_bwd_workspace_floats(d) floats (row terms + per-key-range dQ partials; q must be dense per batch:
+ * q_batch_stride = n_q * q_row_stride). */
+size_t pv_attention_bwd_workspace_floats(const pv_attention_desc* d);
+int pv_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
+                         float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream);
+
 /* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
  * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */
 int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int64_t rows,

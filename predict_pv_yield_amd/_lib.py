@@ -55,6 +55,13 @@ class GemmDesc(ctypes.Structure):
                 ("b_bs2", c_i64), ("c_bs1", c_i64), ("c_bs2", c_i64), ("k_splits", c_i32), ("c_ss", c_i64)]
 
 
+class AttentionDesc(ctypes.Structure):
+    """struct pv_attention_desc."""
+    _fields_ = [("batch", c_i32), ("heads", c_i32), ("n_q", c_i32), ("n_k", c_i32), ("head_dim", c_i32),
+                ("q_batch_stride", c_i64), ("q_row_stride", c_i64), ("k_batch_stride", c_i64), ("k_row_stride", c_i64),
+                ("scale", c_f32)]
+
+
 PV_ADAM_MAX_TENSORS = 32
 PV_PACK_MAX_JOBS = 16
 
@@ -123,6 +130,9 @@ SIGNATURES = {
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
     "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
+    "pv_attention_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
+    "pv_attention_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
+    "pv_attention_bwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
     "pv_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_vp],
@@ -140,7 +150,8 @@ SIGNATURES = {
     "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp],
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }
-_RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz}
+_RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz,
+             "pv_attention_bwd_workspace_floats": c_sz}
 
 
 def build_library(verbose: bool = False) -> str:

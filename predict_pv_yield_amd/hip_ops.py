@@ -685,3 +685,38 @@ def gru_seq_bwd(dout, dh_last, h0, out, saved, w_hh, need_dh0: bool):
     check(get_lib().pv_gru_seq_bwd_f32(ptr(dout), ptr(dh_last), ptr(h0), ptr(out), ptr(saved), ptr(w_hh), ptr(dgi), ptr(dh0),
                                        ptr(dw), ptr(db), b, t, h, ptr(ws), nbytes, current_stream_ptr()), "pv_gru_seq_bwd_f32")
     return dgi, dh0, dw, db
+
+
+def attention_desc(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float) -> "_lib.AttentionDesc":
+    b, n_q, inner = q.shape
+    return _lib.AttentionDesc(b, heads, n_q, kv.shape[1], inner // heads, q.stride(0), q.stride(1), kv.stride(0), kv.stride(1),
+                              scale)
+
+
+def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float):
+    """q [b, i, h*64], kv [b, j, 2*h*64] (k | v halves) contiguous -> (out [b, i, h*64], lse [b, h, i])."""
+    require_cuda(q, kv)
+    b, n_q, inner = q.shape
+    d = attention_desc(q, kv, heads, scale)
+    out = torch.empty_like(q)
+    lse = torch.empty((b, heads, n_q), dtype=torch.float32, device=q.device)
+    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
+    check(get_lib().pv_attention_fwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
+          "pv_attention_fwd_f32")
+    return out, lse
+
+
+def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float):
+    """Backward of attention_fwd (n_q <= 128): returns (dq like q, dkv like kv)."""
+    require_cuda(q, kv, out, dout, lse)
+    b, n_q, inner = q.shape
+    d = attention_desc(q, kv, heads, scale)
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    n_ws = get_lib().pv_attention_bwd_workspace_floats(ctypes.byref(d))
+    delta = _workspace("attention_bwd", n_ws * 4, q.device)
+    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
+    dv_ptr = ctypes.c_void_p(dkv.data_ptr() + inner * 4)
+    check(get_lib().pv_attention_bwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
+                                         dv_ptr, ctypes.byref(d), current_stream_ptr()), "pv_attention_bwd_f32")
+    return dq, dkv

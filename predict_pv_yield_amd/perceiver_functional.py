@@ -83,16 +83,27 @@ class AttentionCoreF32(torch.autograd.Function):
     def forward(ctx, q, kv, heads, scale):
         q, kv = q.contiguous(), kv.contiguous()
         inner = q.shape[-1]
+        ctx.heads, ctx.scale = heads, scale
+        ctx.fused = inner // heads == 64 and q.shape[1] <= 128
+        if ctx.fused:
+            # online-softmax kernels: the [queries x keys] scores / probabilities never reach memory; the backward
+            # recomputes them tile by tile from the saved log-sum-exp
+            out, lse = K.attention_fwd(q, kv, heads, scale)
+            ctx.save_for_backward(q, kv, out, lse)
+            return out
         qh, kh, vh = _head_view(q, heads, 0, inner), _head_view(kv, heads, 0, inner), _head_view(kv, heads, inner, 2 * inner)
         p = K.softmax_fwd_(K.gemm(qh, kh.transpose(-1, -2)), scale)                 # [b, h, i, j]
         out = torch.empty_like(q)
         K.gemm(p, vh, out=_head_view(out, heads, 0, inner))
         ctx.save_for_backward(q, kv, p)
-        ctx.heads, ctx.scale = heads, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.fused:
+            q, kv, out, lse = ctx.saved_tensors
+            dq, dkv = K.attention_bwd(q, kv, out, dout.contiguous(), lse, ctx.heads, ctx.scale)
+            return dq, dkv, None, None
         q, kv, p = ctx.saved_tensors
         h, inner = ctx.heads, q.shape[-1]
         dout = dout.contiguous()

@@ -178,3 +178,42 @@ def test_gru_vs_torch(b, t, inp, h, layers, device):
     # without an initial state (zeros), as the encoder is called
     out2, _ = PF.gru(xd.detach(), mod)
     torch.testing.assert_close(out2.cpu(), ref(x.detach())[0], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,h,nq,nk", [(3, 1, 128, 4096), (2, 8, 128, 128), (2, 2, 40, 70), (1, 1, 130, 33)])
+def test_fused_attention_forward(b, h, nq, nk, device):
+    """pv_attention_fwd_f32 (online softmax, scores never materialised) vs softmax(scale q k^T) v with torch on the CPU."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(b * nq + nk)
+    q = torch.randn(b, nq, h * 64, generator=g)
+    kv = torch.randn(b, nk, 2 * h * 64, generator=g)
+    scale = 0.125
+    qh = q.view(b, nq, h, 64).permute(0, 2, 1, 3)
+    kh = kv[..., :h * 64].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    vh = kv[..., h * 64:].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    sim = (qh @ kh.transpose(-1, -2)) * scale
+    ref = (sim.softmax(dim=-1) @ vh).permute(0, 2, 1, 3).reshape(b, nq, h * 64)
+    out, lse = K.attention_fwd(q.to(device), kv.to(device), h, scale)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(sim, dim=-1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,h,nq,nk", [(2, 1, 128, 4096), (2, 8, 128, 128), (2, 2, 40, 70), (1, 1, 97, 33)])
+def test_fused_attention_backward(b, h, nq, nk, device):
+    """pv_attention_bwd_f32 (probabilities recomputed from the saved log-sum-exp) vs torch autograd on the CPU."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(b * nq + nk + 1)
+    q = torch.randn(b, nq, h * 64, generator=g, requires_grad=True)
+    kv = torch.randn(b, nk, 2 * h * 64, generator=g, requires_grad=True)
+    scale = 0.125
+    qh = q.view(b, nq, h, 64).permute(0, 2, 1, 3)
+    kh = kv[..., :h * 64].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    vh = kv[..., h * 64:].reshape(b, nk, h, 64).permute(0, 2, 1, 3)
+    ref = (((qh @ kh.transpose(-1, -2)) * scale).softmax(dim=-1) @ vh).permute(0, 2, 1, 3).reshape(b, nq, h * 64)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    qd, kvd = q.detach().to(device), kv.detach().to(device)
+    out, lse = K.attention_fwd(qd, kvd, h, scale)
+    dq, dkv = K.attention_bwd(qd, kvd, out, dout.to(device), lse, h, scale)
+    torch.testing.assert_close(dq.cpu(), q.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(dkv.cpu(), kv.grad, rtol=1e-3, atol=1e-5)

@@ -30,3 +30,10 @@ dy = torch.randn(bp * 4096, 128, device=dev)
 bench("to_kv dW (split-K) [128 x 4.06M] x [4.06M x 37]", lambda: K.gemm_splitk(dy.t(), ctx), 2 * bp * 4096 * 37 * 128)
 x = torch.randn(bp * 128, 64, device=dev); w1 = torch.randn(512, 64, device=dev)
 bench("ff1     [127k x 64] x [64 x 512]", lambda: K.gemm(x, w1.t()), 2 * bp * 128 * 64 * 512)
+bench("fused attention fwd (cross, 128 x 4096)", lambda: K.attention_fwd(q, kv, 1, 0.125), 2 * 2 * bp * 128 * 64 * 4096)
+ql = torch.randn(bp, 128, 512, device=dev); kvl = torch.randn(bp, 128, 1024, device=dev)
+bench("fused attention fwd (latent, 8 heads 128 x 128)", lambda: K.attention_fwd(ql, kvl, 8, 0.125), 2 * 2 * bp * 8 * 128 * 64 * 128)
+o, l = K.attention_fwd(q, kv, 1, 0.125); do = torch.randn_like(o)
+bench("fused attention bwd (cross, 128 x 4096)", lambda: K.attention_bwd(q, kv, o, do, l, 1, 0.125), 2 * 5 * bp * 128 * 64 * 4096)
+o, l = K.attention_fwd(ql, kvl, 8, 0.125); do = torch.randn_like(o)
+bench("fused attention bwd (latent, 8 heads 128 x 128)", lambda: K.attention_bwd(ql, kvl, o, do, l, 8, 0.125), 2 * 5 * bp * 8 * 128 * 64 * 128)
