@@ -176,6 +176,22 @@ def test_farneback_vs_oracle(device, h, w):
         assert abs(np.median(inner[..., 0]) - 1.5) < 0.1 and abs(np.median(inner[..., 1]) - 0.75) < 0.1
 
 
+def test_farneback_full_extent_vs_oracle(device):
+    """The reference's own image size (704 x 548 HRV frames, 13_...ipynb; two coarse pyramid levels): one pair."""
+    K = _ops()
+    rng = np.random.default_rng(704)
+    u8 = _pair(rng, 704, 548, (2.2, -1.4))
+    assert fo.farneback_num_levels(704, 548) == 2
+    got = K.farneback_pairs(torch.from_numpy(u8[0:1]).to(device), torch.from_numpy(u8[1:2]).to(device))[0].cpu().numpy()
+    ref = fo.calc_optical_flow_farneback(u8[0], u8[1])
+    assert got.shape == ref.shape == (704, 548, 2)
+    assert np.abs(got - ref).max() < 1e-3
+    inner = ref[60:-60, 60:-60]
+    # and both recover the known translation in the interior (algorithmic accuracy of Farnebäck on this texture)
+    assert np.median(np.abs(inner[..., 0] - 2.2)) < 0.1 and np.median(np.abs(inner[..., 1] + 1.4)) < 0.1
+    assert np.percentile(np.abs(inner[..., 0] - 2.2), 95) < 0.25 and np.percentile(np.abs(inner[..., 1] + 1.4), 95) < 0.25
+
+
 def test_farneback_stack_and_params(device):
     K = _ops()
     raw, _ = advected_counts(batch=1, t=5, channels=2, h=64, w=64, seed=5)

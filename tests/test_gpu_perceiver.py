@@ -194,3 +194,20 @@ def test_perceiver_conv3d_nwp_sat_model_vs_oracle(use_future, device):
     sat_before = d["sat"].clone()
     _variant_step(oracle, model, d, "pv_yield", device)
     assert torch.equal(d["sat"], sat_before)                 # the caller's batch is not modified
+
+
+def test_perceiver_model_trainer_fit(device):
+    """The Lightning-shim Trainer drives PerceiverModel like any other module: fit one epoch, predict."""
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
+    torch.manual_seed(11)
+    model = PerceiverModel(history_minutes=10, forecast_minutes=20, batch_size=2, num_latents=16, latent_dim=64)
+    ds = FakeDataset(FakeDataConfiguration(batch_size=2, history_minutes=10, forecast_minutes=20, satellite_image_size_pixels=8,
+                                           nwp_image_size_pixels=64), length=2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=None)
+    trainer = pl.Trainer(gpus=1, max_epochs=1)
+    trainer.fit(model, loader)
+    out = trainer.predict(model, loader)
+    assert len(out) == 2 and out[0].shape == (2, model.forecast_len_5)
+    assert all(torch.isfinite(p).all() for p in model.parameters())

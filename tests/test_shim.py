@@ -199,3 +199,44 @@ def test_baseline_model_forward_is_persistence():
     y = m(b)
     assert y.shape == (3, m.forecast_len_30) == (3, 4)
     assert torch.equal(y[:, 0], b["gsp"]["gsp_yield"][:, -5, 0]) and torch.equal(y[:, 0], y[:, 3])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name,module,cls", [
+    ("conv3d_sat_nwp", "predict_pv_yield_amd.models.conv3d.model_sat_nwp", "Model"),
+    ("perceiver", "predict_pv_yield_amd.models.perceiver.perceiver", "PerceiverModel"),
+    ("perceiver_sat_nwp", "predict_pv_yield_amd.models.perceiver.perceiver_nwp_sat", "Model"),
+    ("perceiver_conv3d_sat_nwp", "predict_pv_yield_amd.models.perceiver.perceiver_conv3d_nwp_sat", "Model")])
+def test_reference_model_yamls_instantiate_here(name, module, cls):
+    """Every model yaml of the reference (configs/model/*.yaml) resolves, through the alias table, to the class of this
+    package with the reference's keyword arguments; our own configs/model/<name>.yaml names the same class directly."""
+    import importlib
+    ref_cfg = H._load_yaml(os.path.join(REF_CONFIGS, "model", name + ".yaml"))
+    model = H.instantiate(ref_cfg)
+    want = getattr(importlib.import_module(module), cls)
+    assert type(model) is want
+    ours = H._load_yaml(os.path.join(ROOT, "configs", "model", name + ".yaml"))
+    assert ours["_target_"] == f"{module}.{cls}"
+    assert {k: v for k, v in ours.items() if k != "_target_"} == {k: v for k, v in ref_cfg.items() if k != "_target_"}
+
+
+def test_new_model_signatures_match_reference():
+    import inspect
+    from predict_pv_yield_amd.models.conv3d.model_sat_nwp import Model as SatNwp
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
+    from predict_pv_yield_amd.models.perceiver.perceiver_conv3d_nwp_sat import Model as PConv
+    sig = inspect.signature(SatNwp.__init__)          # model_sat_nwp.py:18-37
+    assert list(sig.parameters)[1:18] == ["include_pv_or_gsp_yield_history", "include_nwp", "forecast_minutes", "history_minutes",
+                                          "number_of_conv3d_layers", "conv3d_channels", "image_size_pixels",
+                                          "nwp_image_size_pixels", "number_sat_channels", "number_nwp_channels",
+                                          "fc1_output_features", "fc2_output_features", "fc3_output_features",
+                                          "output_variable", "embedding_dem", "include_pv_yield_history",
+                                          "include_future_satellite"]
+    assert sig.parameters["embedding_dem"].default == 16 and sig.parameters["number_nwp_channels"].default == 10
+    sig = inspect.signature(PerceiverModel.__init__)  # perceiver.py:46-56
+    assert [sig.parameters[k].default for k in ("history_minutes", "forecast_minutes", "batch_size", "num_latents", "latent_dim",
+                                                "embedding_dem", "output_variable")] == [30, 120, 32, 128, 64, 16, "pv_yield"]
+    sig = inspect.signature(PConv.__init__)           # perceiver_conv3d_nwp_sat.py:64-76
+    assert sig.parameters["conv3d_channels"].default == 16 and sig.parameters["use_future_satellite_images"].default is True
+    m = PerceiverModel(history_minutes=3, forecast_minutes=3)           # tests/models/perceiver/test_perceiver.py:9
+    assert m.total_seq_length == 1 and len(m.perceiver.layers) == 1
