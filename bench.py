@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of PV-site crop stacks")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fix the GLOBAL batch (e.g. 512) and give each of the N GPUs global/N samples; "
+                         "default 0 = weak scaling with --batch samples per GPU")
     ap.add_argument("--history-minutes", type=int, default=55, help="55 -> T=18 (12 observed + 6 forecast frames)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,6 +240,10 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(518 + rank)
     b = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of GPUs")
+        b = args.global_batch // world
     model.batch_size = max(model.batch_size, b)  # BaseModel.batch_size slices the target (base_model.py:95)
     batch = {"satellite": {"data": torch.randn(b, 11, t_frames, 64, 64, generator=g, device=dev)},
              "pv": {"pv_yield": torch.rand(b, t_frames, 128, generator=g, device=dev)}}
@@ -279,7 +286,7 @@ def main():
             "metric": "PV-site samples/sec (train step), conv3d 12->6 frames",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"conv3d train step (fwd + NMAE + bwd + Adam): sat [B,11,{t_frames},64,64] N(0,1), "
                                    f"4x Conv3d(3x3x3, 32ch) + fc 128/128/64, {sum(p.numel() for p in model.parameters())/1e6:.1f} M params",
                        "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
