@@ -270,13 +270,12 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
     }
   }
   // ---- add the four waves' dQ^T partials (wave order) and write dq; two query tiles per round through Qs | Os ----------
-  float* red = Qs;   // 2 * 128 * 68 floats available (Qs and Os are adjacent? not guaranteed) -> use Qs and Os separately
   for (int round = 0; round < 2; ++round) {
     __syncthreads();   // everyone is done with Qs / Os (first round) or with the previous round's sums
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = 2 * round + u;
-      float* dst = (u == 0 ? Qs : Os);   // [wave][d 64][i 32] = 4 * 2048 floats <= 128 * 68
+      float* dst = (u == 0 ? Qs : Os);   // reused as [wave][d 64][i 32] = 4 * 2048 floats <= 128 * 68
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -295,7 +294,6 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
       }
     }
   }
-  (void)red;
 }
 
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
