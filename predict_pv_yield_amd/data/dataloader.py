@@ -1,6 +1,8 @@
 """NetCDFDataModule — same constructor surface as predict_pv_yield/data/dataloader.py:38-131
 (temp_path, n_train_data, n_val_data, cloud, num_workers, pin_memory, data_path, fake_data [, shuffle_train]).
-Only `fake_data=True` is built: reading OCF's NetCDF batches is I/O outside the hot path.
+`fake_data=True` generates seeded synthetic batches; otherwise whole-batch files (`000000.npz` / `.nc`, see
+data/netcdf_dataset.py) are read from `<data_path>/train` and `<data_path>/test` like the reference does
+(data/dataloader.py:93-131); cloud download and NetCDF-4 decoding are outside the hot path.
 Under data-parallel training each rank takes a disjoint slice of the batch indices (Lightning's
 replace_sampler_ddp, configs/trainer/all_params.yaml:43): samples are independent, no collective."""
 import os
@@ -41,9 +43,6 @@ class NetCDFDataModule(LightningDataModule):
         self.n_train_data, self.n_val_data = n_train_data, n_val_data
         self.num_workers, self.pin_memory = num_workers, pin_memory
         self.fake_data, self.shuffle_train = fake_data, shuffle_train
-        if not fake_data:
-            raise NotImplementedError("predict_pv_yield_amd builds the synthetic data path only (fake_data=True); "
-                                      "NetCDF batch I/O is outside the hot path")
         cfg = configuration or self._configuration_from_path(data_path)
         if batch_size is not None:
             cfg.batch_size = batch_size
@@ -71,18 +70,25 @@ class NetCDFDataModule(LightningDataModule):
             cfg.seed = raw.get("process", {}).get("seed", cfg.seed)
         return cfg
 
-    def _loader(self, n_batches: int, offset: int):
-        base = FakeDataset(self.configuration, length=offset + n_batches)
+    def _loader(self, n_batches: int, offset: int, split: str = "train"):
         lo, hi = shard_range(n_batches)
-        ds = _Shard(base, offset + lo, offset + hi)
+        if self.fake_data:
+            base = FakeDataset(self.configuration, length=offset + n_batches)
+            ds = _Shard(base, offset + lo, offset + hi)
+        else:
+            from .netcdf_dataset import NetCDFDataset
+            base = NetCDFDataset(n_batches, os.path.join(self.data_path, split), os.path.join(self.temp_path, split),
+                                 configuration=self.configuration)
+            ds = _Shard(base, lo, hi)
         # every item is a whole batch: batch_size=None (data/dataloader.py:82-91)
         return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=0, pin_memory=False)
 
     def train_dataloader(self):
-        return self._loader(min(self.n_train_data, 10), 0)
+        return self._loader(self.n_train_data if not self.fake_data else min(self.n_train_data, 10), 0, "train")
 
     def val_dataloader(self):
-        return self._loader(min(self.n_val_data, 10), 1000)
+        return self._loader(self.n_val_data if not self.fake_data else min(self.n_val_data, 10), 1000, "test")
 
     def test_dataloader(self):
-        return self._loader(min(self.n_val_data, 10), 2000)
+        # the reference reads the "test" folder for both (data/dataloader.py:120-129)
+        return self._loader(self.n_val_data if not self.fake_data else min(self.n_val_data, 10), 2000, "test")

@@ -200,15 +200,33 @@ class EarlyStopping(Callback):
                 trainer.should_stop = True
 
 
+def _raw_satellite(batch) -> bool:
+    """True for a whole batch whose satellite imagery is still raw int16 counts (data/netcdf_dataset.py)."""
+    try:
+        sat = batch["satellite"]["data"] if isinstance(batch, dict) else batch.satellite.data
+    except (KeyError, AttributeError, TypeError):
+        return False
+    return isinstance(sat, torch.Tensor) and sat.dtype == torch.int16
+
+
 def _move(batch, device):
+    moved = _move_only(batch, device)
+    if torch.device(device).type == "cuda" and _raw_satellite(moved):
+        # the int16 counts crossed PCIe; normalise on the device (netcdf_dataset.py:96-101 semantics)
+        from .data.netcdf_dataset import normalise_satellite_on_device
+        moved = normalise_satellite_on_device(moved)
+    return moved
+
+
+def _move_only(batch, device):
     if isinstance(batch, torch.Tensor):
         return batch.to(device, non_blocking=True)
     if hasattr(batch, "to") and not isinstance(batch, (str, bytes)):
         return batch.to(device)
     if isinstance(batch, dict):
-        return {k: _move(v, device) for k, v in batch.items()}
+        return {k: _move_only(v, device) for k, v in batch.items()}
     if isinstance(batch, (list, tuple)):
-        return type(batch)(_move(v, device) for v in batch)
+        return type(batch)(_move_only(v, device) for v in batch)
     return batch
 
 
