@@ -12,7 +12,9 @@
 // Structure: same time-marching tile as the forward kernel (8 output rows x 64 columns, X ring of
 // three slices in LDS, dY tile of the current slice beside it); the 27 taps are dealt round-robin to
 // the 4 waves (7,7,7,6 accumulators of 32x32 f32); wave 3's spare accumulator multiplies dYeff by a
-// fragment of ones, which yields dbias for free.  Each workgroup writes one f32 partial slab; a
+// fragment of ones, which yields dbias for free.  With 16 (padded) input channels the 32 B-operand columns hold TWO
+// taps (columns 0..15: tap 2p, columns 16..31: tap 2p+1, the ones-tap being tap 27), so 14 accumulators (4,4,3,3)
+// cover all taps instead of 28 half-empty ones.  Each workgroup writes one f32 partial slab; a
 // second kernel sums the slabs in a fixed order (deterministic, no atomics).
 #include "pv_common.h"
 
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
   const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   float* slab = slabs + (size_t)wg_id * SLAB_ELEMS;
 
-  f32x16 acc[7];
+  constexpr bool PAIRED = CPAD == 16;      // two taps per accumulator
+  constexpr int NACC = PAIRED ? 4 : 7;
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < NACC; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
@@ -88,16 +92,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
       int chunk = (cb + 4 * pi) >> 3;
       aoff[s] = v * 64 + ((chunk ^ ((v >> 2) & 3)) << 4) + (pi & 1) * 8;
     }
-    // X (B operand) per tap of this wave: tap = wave + 4*i
-    int boff[7][2];
-    int bkt[7];
+    // X (B operand) per tap of this wave: tap = wave + 4*i; PAIRED: this LANE's tap = 2*(wave + 4*i) + (grp & 1)
+    int boff[NACC][2];
+    int bkt[NACC];
+    int my_tap[NACC];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      int tap = wave + 4 * i;
+    for (int i = 0; i < NACC; ++i) {
+      int tap = PAIRED ? 2 * (wave + 4 * i) + (grp & 1) : wave + 4 * i;
+      my_tap[i] = tap;
       if (tap > 26) tap = 26;
       int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       bkt[i] = kt;
-      const int cbx = (CPAD == 16) ? 0 : cb;  // CPAD 16: upper groups re-read channels 0..15, zeroed below
+      const int cbx = PAIRED ? 0 : cb;  // PAIRED: both column halves read channels 0..15, each at its own tap
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         int v = kw + 8 * hh + 4 * s + qi;
@@ -105,7 +111,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
         boff[i][s] = kh * ROWB + v * VOXB + ((chunk ^ ((v / VPR) % NCH)) << 4) + (pi & 1) * 8;
       }
     }
-    const bool b_zero = (CPAD == 16) && (grp & 1);  // columns 16..31 of the B operand do not exist
 
     // ---- staging -----------------------------------------------------------------------------
 
@@ -209,35 +214,41 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
       // latency has nothing else to hide behind).
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       const bool use_ones = (wave == 3);
-      int bslot[7];
+      int bslot[NACC];
 #pragma unroll
-      for (int i = 0; i < 7; ++i) bslot[i] = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
-      auto read_step = [&](int st, s16x4 (&ra)[2], s16x4 (&rb)[7][2]) {
+      for (int i = 0; i < NACC; ++i) bslot[i] = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
+      auto read_step = [&](int st, s16x4 (&ra)[2], s16x4 (&rb)[NACC][2]) {
         const int rho = st >> 2, cg = st & 3;
         const unsigned char* ap = lds_dy + rho * DROWB + cg * 16 * 64;
         ra[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[0]));
         ra[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ap + aoff[1]));
         const int xo = rho * ROWB + cg * 16 * VOXB;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NACC; ++i) {
           const unsigned char* bp = lds + bslot[i] + xo;
           rb[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][0]));
           rb[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][1]));
         }
       };
-      auto mfma_step = [&](const s16x4 (&ra)[2], const s16x4 (&rb)[7][2]) {
+      auto mfma_step = [&](const s16x4 (&ra)[2], const s16x4 (&rb)[NACC][2]) {
         const s16x8 a8 = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2], ra[1][3]};
         const bf16x8 afr = __builtin_bit_cast(bf16x8, a8);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NACC; ++i) {
           s16x8 t8 = {rb[i][0][0], rb[i][0][1], rb[i][0][2], rb[i][0][3], rb[i][1][0], rb[i][1][1], rb[i][1][2], rb[i][1][3]};
-          if (b_zero) t8 = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
           bf16x8 bfr = __builtin_bit_cast(bf16x8, t8);
-          if (i == 6 && use_ones) bfr = ones;
+          if constexpr (PAIRED) {
+            if (i == NACC - 1) {               // only the last slot can reach the ones-tap (27) or run past it
+              if (my_tap[i] == 27) bfr = ones;
+              else if (my_tap[i] > 27) bfr = __builtin_bit_cast(bf16x8, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
+            }
+          } else {
+            if (i == 6 && use_ones) bfr = ones;
+          }
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
         }
       };
-      s16x4 ra0[2], ra1[2], rb0[7][2], rb1[7][2];
+      s16x4 ra0[2], ra1[2], rb0[NACC][2], rb1[NACC][2];
       read_step(0, ra0, rb0);
       for (int st = 0; st < WTR * 4; st += 2) {
         read_step(st + 1, ra1, rb1);
@@ -254,10 +265,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
   }
 
   // ---- write the partial slab: [tapslot][co][ci], C layout: col = ci = lane&31, row = co ----------
-  const int ci = lane & 31, half = lane >> 5;
+  const int half = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    int tapslot = wave + 4 * i;  // 27 = ones-tap (wave 3, i = 6)
+  for (int i = 0; i < NACC; ++i) {
+    // PAIRED: column c of the accumulator belongs to tap 2p + (c >> 4), input channel c & 15
+    const int tapslot = PAIRED ? 2 * (wave + 4 * i) + ((lane & 31) >> 4) : wave + 4 * i;  // 27 = ones-tap
+    const int ci = PAIRED ? (lane & 15) : (lane & 31);
     if (tapslot <= 27) {
       float* dst = slab + (size_t)tapslot * 1024 + ci;
 #pragma unroll
