@@ -7,6 +7,7 @@
 namespace pv {
 
 constexpr int M_TILE = 8;
+constexpr long long SMALL_K = 4096, SMALL_MN = 1 << 16;   // "small layer": single-launch forward / backward
 
 // ---- forward: split-K partial products, one block = (n, k-chunk, m-tile) -----------------------
 __global__ __launch_bounds__(256) void linear_fwd_partial_f32(const float* __restrict__ x,
@@ -62,11 +63,10 @@ __global__ __launch_bounds__(256) void linear_reduce_f32(const float* __restrict
 
 // ---- backward ------------------------------------------------------------------------------------
 // dx[mi, kk] = sum_n g[mi, n] * w[n, kk]; thread = one kk, M_TILE rows; g tile broadcast from LDS
-__global__ __launch_bounds__(256) void linear_bwd_dx_f32(const float* __restrict__ w, const float* __restrict__ dy,
-                                                          const float* __restrict__ ymask, float* __restrict__ dx,
-                                                          int m, int n, long long k) {
-  extern __shared__ float g[];  // [n][M_TILE]
-  const int m0 = blockIdx.y * M_TILE;
+__device__ __forceinline__ void linear_bwd_dx_body(float* g /* LDS [n][M_TILE] */, const float* __restrict__ w,
+                                                   const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                   float* __restrict__ dx, int m, int n, long long k, int bx, int by) {
+  const int m0 = by * M_TILE;
   for (int i = threadIdx.x; i < n * M_TILE; i += blockDim.x) {
     int col = i / M_TILE, r = i % M_TILE;
     float v = 0.f;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_f32(const float* __restrict
     g[i] = v;
   }
   __syncthreads();
-  long long kk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long kk = (long long)bx * blockDim.x + threadIdx.x;
   if (kk >= k) return;
   float acc[M_TILE];
 #pragma unroll
@@ -93,13 +93,19 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_f32(const float* __restrict
     if (m0 + i < m) dx[(size_t)(m0 + i) * k + kk] = acc[i];
 }
 
+__global__ __launch_bounds__(256) void linear_bwd_dx_f32(const float* __restrict__ w, const float* __restrict__ dy,
+                                                          const float* __restrict__ ymask, float* __restrict__ dx,
+                                                          int m, int n, long long k) {
+  extern __shared__ float g[];  // [n][M_TILE]
+  linear_bwd_dx_body(g, w, dy, ymask, dx, m, n, k, blockIdx.x, blockIdx.y);
+}
+
 // dw[n0+j, kk] = sum_mi g[mi, n0+j] * x[mi, kk]; thread = one kk, N_TILE output features
 constexpr int N_TILE = 8;
-__global__ __launch_bounds__(256) void linear_bwd_dw_f32(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ ymask, float* __restrict__ dw,
-                                                          int m, int n, long long k) {
-  extern __shared__ float g[];  // [m][N_TILE]
-  const int n0 = blockIdx.y * N_TILE;
+__device__ __forceinline__ void linear_bwd_dw_body(float* g /* LDS [m][N_TILE] */, const float* __restrict__ x,
+                                                   const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                   float* __restrict__ dw, int m, int n, long long k, int bx, int by) {
+  const int n0 = by * N_TILE;
   for (int i = threadIdx.x; i < m * N_TILE; i += blockDim.x) {
     int r = i / N_TILE, j = i % N_TILE;
     float v = 0.f;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_f32(const float* __restrict
     g[i] = v;
   }
   __syncthreads();
-  long long kk = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long kk = (long long)bx * blockDim.x + threadIdx.x;
   if (kk >= k) return;
   float acc[N_TILE];
 #pragma unroll
@@ -126,9 +132,24 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_f32(const float* __restrict
     if (n0 + j < n) dw[(size_t)(n0 + j) * k + kk] = acc[j];
 }
 
+__global__ __launch_bounds__(256) void linear_bwd_dw_f32(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ ymask, float* __restrict__ dw,
+                                                          int m, int n, long long k) {
+  extern __shared__ float g[];  // [m][N_TILE]
+  linear_bwd_dw_body(g, x, dy, ymask, dw, m, n, k, blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ void linear_bwd_db_body(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                   float* __restrict__ db, int m, int n, int bx);
+
 __global__ __launch_bounds__(256) void linear_bwd_db_f32(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                           float* __restrict__ db, int m, int n) {
-  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  linear_bwd_db_body(dy, ymask, db, m, n, blockIdx.x);
+}
+
+__device__ __forceinline__ void linear_bwd_db_body(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                   float* __restrict__ db, int m, int n, int bx) {
+  int col = bx * blockDim.x + threadIdx.x;
   if (col >= n) return;
   float s = 0.f;
   for (int r = 0; r < m; ++r) {
@@ -138,6 +159,49 @@ __global__ __launch_bounds__(256) void linear_bwd_db_f32(const float* __restrict
     s += v;
   }
   db[col] = s;
+}
+
+// The small layers of the head (fc2..fc4, decoder_fc*: k <= a few thousand): the whole backward in ONE launch -- the
+// dx, dw and db tiles are the same device functions, selected by block index -- and the forward without the split-K
+// round trip: one thread per output, k-loop in registers (fixed order).
+__global__ __launch_bounds__(256) void linear_bwd_small_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                             float* __restrict__ dx, float* __restrict__ dw,
+                                                             float* __restrict__ db, int m, int n, long long k, int kb,
+                                                             int n_dx, int n_dw) {
+  extern __shared__ float g[];  // max(n * M_TILE, m * N_TILE) floats
+  int blk = blockIdx.x;
+  if (blk < n_dx) {
+    linear_bwd_dx_body(g, w, dy, ymask, dx, m, n, k, blk % kb, blk / kb);
+  } else if (blk < n_dx + n_dw) {
+    blk -= n_dx;
+    linear_bwd_dw_body(g, x, dy, ymask, dw, m, n, k, blk % kb, blk / kb);
+  } else {
+    linear_bwd_db_body(dy, ymask, db, m, n, blk - n_dx - n_dw);
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_fwd_small_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int m,
+                                                             int n, int k, int relu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * n) return;
+  const int r = i / n, col = i - r * n;
+  const float* xr = x + (size_t)r * k;
+  const float* wr = w + (size_t)col * k;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int kk = 0;
+  for (; kk + 4 <= k; kk += 4) {
+    s0 = fmaf(xr[kk], wr[kk], s0);
+    s1 = fmaf(xr[kk + 1], wr[kk + 1], s1);
+    s2 = fmaf(xr[kk + 2], wr[kk + 2], s2);
+    s3 = fmaf(xr[kk + 3], wr[kk + 3], s3);
+  }
+  for (; kk < k; ++kk) s0 = fmaf(xr[kk], wr[kk], s0);
+  float s = (s0 + s1) + (s2 + s3);
+  if (bias) s += bias[col];
+  if (relu) s = s > 0.f ? s : 0.f;
+  y[i] = s;
 }
 
 // ---- forecast losses (single block; [B, forecast_len] is tiny) ----------------------------------
@@ -356,6 +420,11 @@ int pv_linear_fwd_f32(const float* x, const float* w, const float* bias, float* 
   PV_REQUIRE(workspace_bytes >= (size_t)ks * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_f32: workspace too small");
   PV_REQUIRE(n <= 65535 && ks <= 65535, PV_ESIZE, "pv_linear_fwd_f32: n too large");
   hipStream_t st = as_stream(stream);
+  if (k <= SMALL_K && (long long)m * n <= SMALL_MN) {
+    hipLaunchKernelGGL(linear_fwd_small_f32, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st, x, w, bias, y, m, n, (int)k,
+                       relu ? 1 : 0);
+    return check_launch("pv_linear_fwd_f32");
+  }
   dim3 grid((unsigned)n, (unsigned)ks, (unsigned)((m + M_TILE - 1) / M_TILE));
   hipLaunchKernelGGL(linear_fwd_partial_f32, grid, dim3(256), 0, st, x, w, (float*)workspace, m, n, (long long)k, chunk);
   hipLaunchKernelGGL(linear_reduce_f32, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st,
@@ -369,6 +438,16 @@ int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const flo
   PV_REQUIRE(m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bwd_f32: bad sizes");
   hipStream_t st = as_stream(stream);
   unsigned kb = (unsigned)((k + 255) / 256);
+  if (dx && dw && db && k <= SMALL_K && (long long)m * n <= SMALL_MN) {
+    PV_REQUIRE(w && x, PV_EINVAL, "pv_linear_bwd_f32: dx needs w, dw needs x");
+    const size_t lds = (size_t)std::max(n * M_TILE, m * N_TILE) * sizeof(float);
+    PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_f32: m=%d / n=%d too large", m, n);
+    const int n_dx = (int)kb * ((m + M_TILE - 1) / M_TILE), n_dw = (int)kb * ((n + N_TILE - 1) / N_TILE);
+    const int n_db = (n + 255) / 256;
+    hipLaunchKernelGGL(linear_bwd_small_f32, dim3((unsigned)(n_dx + n_dw + n_db)), dim3(256), lds, st, x, w, dy, y_relu_mask,
+                       dx, dw, db, m, n, (long long)k, (int)kb, n_dx, n_dw);
+    return check_launch("pv_linear_bwd_f32");
+  }
   if (dx) {
     PV_REQUIRE(w, PV_EINVAL, "pv_linear_bwd_f32: dx needs w");
     size_t lds = (size_t)n * M_TILE * sizeof(float);
