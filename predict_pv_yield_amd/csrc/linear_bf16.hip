@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __res
 // backward (f32 VALU outer products; both kernels stream [N,K] once per tile row and are
 // bandwidth-bound on the 0.5 GB gradient / 0.26 GB weight matrices)
 // ---------------------------------------------------------------------------------------------
-constexpr int BT = 8;  // tile of the small dimension held in registers
+constexpr int BT = 16;  // tile of the small dimension held in registers
 
 // XCD-aware tile order for the two backward kernels.  Workgroups of a 1-D grid go round-robin over the 8 XCDs (each
 // with its own L2); the `inner` tiles that re-read the same k-block of the big matrix are given consecutive slots of
@@ -181,11 +181,12 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t*
       wv[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
       wv[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
     }
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + col * BT);
-    const f32x4 g1 = *reinterpret_cast<const f32x4*>(g + col * BT + 4);
+    f32x4 gq[BT / 4];
+#pragma unroll
+    for (int q = 0; q < BT / 4; ++q) gq[q] = *reinterpret_cast<const f32x4*>(g + col * BT + 4 * q);
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
-      const float gv = i < 4 ? g0[i] : g1[i - 4];
+      const float gv = gq[i >> 2][i & 3];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(gv, wv[j], acc[i][j]);
     }
@@ -248,11 +249,12 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
       xv[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
       xv[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
     }
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + rr * BT);
-    const f32x4 g1 = *reinterpret_cast<const f32x4*>(g + rr * BT + 4);
+    f32x4 gq[BT / 4];
+#pragma unroll
+    for (int q = 0; q < BT / 4; ++q) gq[q] = *reinterpret_cast<const f32x4*>(g + rr * BT + 4 * q);
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
-      const float gv = i < 4 ? g0[i] : g1[i - 4];
+      const float gv = gq[i >> 2][i & 3];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(gv, xv[j], acc[i][j]);
     }
