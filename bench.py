@@ -152,6 +152,66 @@ def measure_hbm_kernels(model, opt, batch_size, t_frames, dev):
     return out
 
 
+def measure_other_models(dev):
+    """Train-step throughput of the other models built on the same kernels (not the headline metric; outside the timed
+    region): the optical-flow notebook's 3-D CNN at its own batch size, and the PerceiverModel at the reference's
+    configs/model/perceiver.yaml (T = 19, 64 x 64, batch 8)."""
+    out = {}
+
+    def time_steps(step, n, warm):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    from predict_pv_yield_amd.models.conv3d import flow_autoencoder as fa
+    torch.manual_seed(0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    b = 64
+    batch = {fa.HISTORICAL_SAT_IMAGES: torch.randn(b, 4, 128, 128, generator=g, device=dev),
+             fa.OPTICAL_FLOW_PREDICTIONS: torch.randn(b, 128, 128, generator=g, device=dev),
+             fa.FORECAST_HORIZON: torch.randn(b, generator=g, device=dev),
+             fa.TARGET_SAT_IMAGE: torch.randn(b, 64, 64, generator=g, device=dev)}
+    ae = fa.LitAutoEncoder().to(dev)
+    opt = ae.configure_optimizers()
+
+    def ae_step():
+        opt.zero_grad(set_to_none=True)
+        ae.training_step(batch, 0).backward()
+        opt.step()
+
+    d = time_steps(ae_step, 5, 2)
+    out["flow_autoencoder"] = {"workload": "LitAutoEncoder train step (notebook 13), [64,2,5,128,128] -> [64,1,1,64,64], f32",
+                               "ms_per_step": round(d * 1e3, 2), "samples_per_s": round(b / d, 1),
+                               "tflops_f32": round(3 * 2 * 1.097e9 * b / d / 1e12, 1)}
+    del ae, opt, batch
+
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, make_fake_batch
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
+    b = 8
+    pm = PerceiverModel(history_minutes=60, forecast_minutes=30, batch_size=b, num_latents=128, latent_dim=64,
+                        embedding_dem=16, output_variable="gsp_yield").to(dev)
+    cfg = FakeDataConfiguration(batch_size=b, history_minutes=60, forecast_minutes=30, satellite_image_size_pixels=64,
+                                nwp_image_size_pixels=64)
+    pbatch = make_fake_batch(cfg, torch.Generator().manual_seed(2)).to(dev)
+    popt = pm.configure_optimizers()
+
+    def p_step():
+        popt.zero_grad(set_to_none=True)
+        pm.training_step(pbatch, 0).backward()
+        popt.step()
+
+    d = time_steps(p_step, 3, 1)
+    out["perceiver"] = {"workload": "PerceiverModel train step (configs/model/perceiver.yaml): B=8, T=19 frames = 19 weight-tied "
+                                    "layers, 64x64x11, 128 latents x 64, f32 MFMA",
+                        "ms_per_step": round(d * 1e3, 1), "samples_per_s": round(b / d, 1)}
+    return out
+
+
 def cpu_baseline(model_kwargs, t_frames, budget_s=24.0):
     """torch-CPU oracle train step (fwd + NMAE + bwd + Adam), B = 8, on this host's cores.  oneDNN's Conv3d does not
     always scale to every hardware thread, so two thread counts share the budget and the faster one is reported."""
@@ -299,6 +359,9 @@ def main():
             out["roofline"]["traffic"] = committed_hbm_traffic(32, b)
             out["roofline"]["traffic_profile"] = TRAFFIC_PROFILE + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch)"
             out["hbm_bound_kernels"] = measure_hbm_kernels(model, opt, b, t_frames, dev)
+            del model, opt, batch
+            torch.cuda.empty_cache()
+            out["other_models"] = measure_other_models(dev)
         else:
             out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:

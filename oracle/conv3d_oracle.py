@@ -309,7 +309,7 @@ def train_steps(model: OracleConv3dModel, sat: torch.Tensor, yield_tensor: torch
         _, nmae, _, _ = forecast_losses(y_hat, select_target(yield_tensor, model.forecast_len))
         nmae.backward()
         opt.step()
-        losses.append(float(nmae))
+        losses.append(float(nmae.detach()))
     return losses
 
 
