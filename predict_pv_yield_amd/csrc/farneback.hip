@@ -371,6 +371,130 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const flo
   }
 }
 
+// Packed-f32 version of the tile kernel (v_pk_add_f32 / v_pk_fma_f32: two channels per VALU instruction).  Plain f32
+// adds / fmas issue at half the rate of the packed forms on CDNA3/4, and the first tile kernel spent as many
+// instructions on clamped window addresses as on arithmetic (ISA: 3240 math + ~3000 address ops per thread).  Here
+//   * channels are processed in PAIRS (g11|g12, g22|h1, h2|-) as float2 lanes of the same instruction,
+//   * both LDS images are stored with REPLICATED BORDERS (MW rows above / below the tile for the vertical pass, MW
+//     transposed rows left / right for the horizontal pass), so every window element is one ds_read_b64 at a constant
+//     offset from a per-thread base: no clamps, no address arithmetic in the loops.
+// Same summation order and the same single rounding per fused multiply-add as fb_tile_iter_kernel.
+typedef float fb_f2 __attribute__((ext_vector_type(2)));
+
+template <int MW, int SEG>
+__global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const float* __restrict__ Min,
+                                                                         const float* __restrict__ R,
+                                                                         float* __restrict__ flow, int height, int width,
+                                                                         FbTaps kt) {
+  constexpr int TS = 64, WIN = SEG + 2 * MW, NT = 64 * (64 / SEG), PR = TS + 2 * MW, TP = TS + 1;
+  __shared__ fb_f2 A2[PR * TS];   // rows -MW .. TS+MW-1 (replicated above row 0 / below row height-1)
+  __shared__ fb_f2 B2[PR * TP];   // transposed: rows = x + MW (replicated left of x = 0 / right of x = width-1), cols = y
+  const long long p = blockIdx.x;
+  const long long per_img = (long long)height * width;
+  const int tid = threadIdx.x;
+  const int lane64 = tid & 63, seg = tid >> 6;
+  float tap[MW + 1];
+#pragma unroll
+  for (int k = 0; k <= MW; ++k) tap[k] = kt.k[k];
+  fb_f2 hres[3][SEG];
+  constexpr int NE = TS * TS / NT;
+  const int npx = height * width;
+  fb_f2 nxt[NE];
+  auto load_pair = [&](int cp) {
+    const float* s0 = Min + (p * 5 + 2 * cp) * per_img;
+    const float* s1 = Min + (p * 5 + (2 * cp + 1 < 5 ? 2 * cp + 1 : 4)) * per_img;   // channel 4 is paired with itself
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT;
+      nxt[e] = i < npx ? (fb_f2){s0[i], s1[i]} : (fb_f2){0.f, 0.f};
+    }
+  };
+  auto store_pair = [&]() {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int i = tid + e * NT;
+      if (i < npx) {
+        const int y = i / width, x = i - y * width;
+        A2[(y + MW) * TS + x] = nxt[e];
+        if (y == 0) {
+#pragma unroll
+          for (int r = 0; r < MW; ++r) A2[r * TS + x] = nxt[e];
+        }
+        if (y == height - 1) {
+#pragma unroll
+          for (int r = 0; r < MW; ++r) A2[(height + MW + r) * TS + x] = nxt[e];
+        }
+      }
+    }
+  };
+  load_pair(0);
+  store_pair();
+  __syncthreads();
+#pragma unroll
+  for (int cp = 0; cp < 3; ++cp) {
+    if (cp < 2) load_pair(cp + 1);   // next pair's planes in flight under this pair's arithmetic
+    // vertical blur: column x = lane64, output rows seg*SEG .. +SEG-1; window rows at constant offsets
+    if (lane64 < width) {
+      const fb_f2* base = A2 + (seg * SEG) * TS + lane64;
+      fb_f2 win[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) win[i] = base[i * TS];
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        fb_f2 s0 = win[j + MW] * tap[0];
+#pragma unroll
+        for (int k = 1; k <= MW; ++k)
+          s0 = __builtin_elementwise_fma(win[j + MW + k] + win[j + MW - k], (fb_f2){tap[k], tap[k]}, s0);
+        const int y = seg * SEG + j;
+        if (y < height) B2[(lane64 + MW) * TP + y] = s0;
+      }
+    }
+    __syncthreads();   // vertical results visible; every read of A2 is done
+    if (cp < 2) store_pair();
+    // replicate the first / last transposed rows MW times on either side
+    for (int idx = tid; idx < 2 * MW * height; idx += NT) {
+      const int side = idx / (MW * height), rem = idx - side * (MW * height);
+      const int r = rem / height, y = rem - r * height;
+      if (side == 0) B2[r * TP + y] = B2[MW * TP + y];
+      else B2[(width + MW + r) * TP + y] = B2[(width - 1 + MW) * TP + y];
+    }
+    __syncthreads();
+    // horizontal blur: row y = lane64, output columns seg*SEG .. +SEG-1
+    if (lane64 < height) {
+      const fb_f2* base = B2 + (seg * SEG) * TP + lane64;
+      fb_f2 win[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) win[i] = base[i * TP];
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) {
+        fb_f2 s0 = win[j + MW] * tap[0];
+#pragma unroll
+        for (int k = 1; k <= MW; ++k)
+          s0 = __builtin_elementwise_fma((fb_f2){tap[k], tap[k]}, win[j + MW - k] + win[j + MW + k], s0);
+        hres[cp][j] = s0;
+      }
+    }
+    __syncthreads();   // B2 may be overwritten by the next pair; the new A2 planes are visible
+  }
+  if (lane64 < height) {
+    const int y = lane64;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+      const int x = seg * SEG + j;
+      if (x < width) {
+        double g11 = hres[0][j].x, g12 = hres[0][j].y, g22 = hres[1][j].x, h1 = hres[1][j].y, h2 = hres[2][j].x;
+        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+        double idet = __ddiv_rn(1.0, det);
+        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+        float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
+        fl[0] = fxv;
+        fl[1] = fyv;
+      }
+    }
+  }
+}
+
 // ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
 __global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
                                                          long long n_pairs, int height, int width, FbTaps kt) {
@@ -689,14 +813,14 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         // flow-dependent R1 gathers need many waves in flight (measured: inside the tile kernel, at 2 waves/SIMD,
         // they took 4x the time of the whole blur)
         if (win.n == 20)
-          hipLaunchKernelGGL((fb_tile_iter_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
-                             (const float*)R, flow, lh, lw, win, 0);
+          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
+                             (const float*)R, flow, lh, lw, win);
         else if (win.n == 10)
-          hipLaunchKernelGGL((fb_tile_iter_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
-                             (const float*)R, flow, lh, lw, win, 0);
+          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
+                             (const float*)R, flow, lh, lw, win);
         else
-          hipLaunchKernelGGL((fb_tile_iter_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M, V,
-                             (const float*)R, flow, lh, lw, win, 0);
+          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
+                             (const float*)R, flow, lh, lw, win);
         if (update)
           hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                              (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1);
