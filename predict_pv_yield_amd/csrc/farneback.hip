@@ -385,11 +385,10 @@ template <int MW, int SEG>
 __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const float* __restrict__ Min,
                                                                          const float* __restrict__ R,
                                                                          float* __restrict__ flow, int height, int width,
-                                                                         FbTaps kt) {
+                                                                         FbTaps kt, long long n_pairs) {
   constexpr int TS = 64, WIN = SEG + 2 * MW, NT = 64 * (64 / SEG), PR = TS + 2 * MW, TP = TS + 1;
   __shared__ fb_f2 A2[PR * TS];   // rows -MW .. TS+MW-1 (replicated above row 0 / below row height-1)
   __shared__ fb_f2 B2[PR * TP];   // transposed: rows = x + MW (replicated left of x = 0 / right of x = width-1), cols = y
-  const long long p = blockIdx.x;
   const long long per_img = (long long)height * width;
   const int tid = threadIdx.x;
   const int lane64 = tid & 63, seg = tid >> 6;
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const 
   constexpr int NE = TS * TS / NT;
   const int npx = height * width;
   fb_f2 nxt[NE];
-  auto load_pair = [&](int cp) {
+  auto load_pair = [&](long long p, int cp) {
     const float* s0 = Min + (p * 5 + 2 * cp) * per_img;
     const float* s1 = Min + (p * 5 + (2 * cp + 1 < 5 ? 2 * cp + 1 : 4)) * per_img;   // channel 4 is paired with itself
 #pragma unroll
@@ -427,12 +426,17 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const 
       }
     }
   };
-  load_pair(0);
+  // persistent workgroups: each walks image pairs blockIdx.x, += gridDim.x, and the first planes of its NEXT image pair
+  // are fetched under the last channel pair of the current one (one resident workgroup per CU: nothing else would hide
+  // that latency)
+  load_pair(blockIdx.x, 0);
+  for (long long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
   store_pair();
   __syncthreads();
 #pragma unroll
   for (int cp = 0; cp < 3; ++cp) {
-    if (cp < 2) load_pair(cp + 1);   // next pair's planes in flight under this pair's arithmetic
+    if (cp < 2) load_pair(p, cp + 1);   // next channel pair's planes in flight under this pair's arithmetic
+    else if (p + gridDim.x < n_pairs) load_pair(p + gridDim.x, 0);
     // vertical blur: column x = lane64, output rows seg*SEG .. +SEG-1; window rows at constant offsets
     if (lane64 < width) {
       const fb_f2* base = A2 + (seg * SEG) * TS + lane64;
@@ -490,6 +494,144 @@ __global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const 
         float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
         fl[0] = fxv;
         fl[1] = fyv;
+      }
+    }
+  }
+  }  // image pairs
+}
+
+// ---- window blur on the f32 matrix cores ----------------------------------------------------------------------------
+// For images up to 64 x 64 the separable, border-replicated window blur is two small matrix products per channel,
+//   U = X Gh^T (along x),  Out = Gv U (along y),   G[y][y'] = sum of the taps k with clamp(y + k) == y'
+// (a banded 64 x 64 matrix that already contains the border replication), evaluated with v_mfma_f32_32x32x2_f32: exact
+// f32 products, f32 accumulation; only the summation order differs from the tap loop (~1e-7 relative, like the fused
+// multiply-adds of the VALU kernels; the parity bar is 1e-3 px).  640 MFMAs replace ~2800 VALU instructions per wave.
+// Workgroup = 4 waves.  Images wider / taller than 32: one image pair per workgroup, wave (yt, xt) owns a 32 x 32 output
+// quadrant (the horizontal pass of an x half is computed by both waves that need it).  Images up to 32 x 32 (the coarse
+// pyramid level): one image pair PER WAVE.  The horizontal result stays in the accumulator registers and is consumed as
+// the B operand of the vertical pass (its contraction index simply follows the accumulator's row order).
+typedef float fb_v16f __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt) {
+  // G[64][64]; rows / columns >= n stay zero
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 64; i += gridDim.x * blockDim.x) {
+    const int y = i >> 6, yp = i & 63;
+    float s = 0.f;
+    if (y < n && yp < n) {
+      for (int k = -kt.n; k <= kt.n; ++k) {
+        int yy = y + k;
+        yy = yy < 0 ? 0 : (yy > n - 1 ? n - 1 : yy);
+        if (yy == yp) s += kt.k[k < 0 ? -k : k];
+      }
+    }
+    G[i] = s;
+  }
+}
+
+__device__ __forceinline__ int fb_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <bool SMALL>   // SMALL: height, width <= 32, one image pair per wave
+__global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
+                                                            const float* __restrict__ Gh, float* __restrict__ flow,
+                                                            int height, int width, long long n_pairs) {
+  constexpr int XS = 65;                        // LDS row stride (words)
+  constexpr int IMG = SMALL ? 32 * XS : 64 * XS;
+  __shared__ float Xs[SMALL ? 4 * IMG : 2 * IMG];   // SMALL: one image per wave; else: double-buffered channel image
+  __shared__ float Us[SMALL ? 1 : IMG];             // horizontal result of the current channel (4 tiles, one per wave)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int xt = SMALL ? 0 : (wave & 1), yt = SMALL ? 0 : (wave >> 1);
+  const long long per_img = (long long)height * width;
+  // operands that do not change: Gh^T as B operand (k = x', column x), Gv as A operand (row y, k = accumulator row order)
+  float ghreg[32], gvreg[2][16];
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) ghreg[kk] = Gh[(32 * xt + col) * 64 + 2 * kk + half];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) gvreg[a][kk] = Gv[(32 * yt + col) * 64 + 32 * a + fb_acc_row(kk, half)];
+  float gvnat[32];   // !SMALL: Gv as A operand with the contraction index in natural order (k = y' = 2 kk + half)
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) gvnat[kk] = SMALL ? 0.f : Gv[(32 * yt + col) * 64 + 2 * kk + half];
+
+  const long long groups = SMALL ? (n_pairs + 3) / 4 : n_pairs;
+  for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const long long p = SMALL ? grp * 4 + wave : grp;
+    const bool p_ok = p < n_pairs;
+    fb_v16f res[5];
+    float* Xw = SMALL ? Xs + wave * IMG : Xs;
+    float stg[16];   // one channel image in flight: the loads of channel c+1 are issued before the MFMAs of channel c
+    auto load_channel = [&](int c) {
+      const float* src = Min + ((p_ok ? p : 0) * 5 + c) * per_img;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = SMALL ? lane + 64 * e : tid + 256 * e;
+        const int y = SMALL ? i >> 5 : i >> 6, x = SMALL ? i & 31 : i & 63;
+        stg[e] = (p_ok && y < height && x < width) ? src[(long long)y * width + x] : 0.f;
+      }
+    };
+    load_channel(0);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      // ---- channel c (zero padded to the tile) into LDS; next channel's loads start right away ---------------------------
+      float* Xc = SMALL ? Xw : Xs + (c & 1) * IMG;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = SMALL ? lane + 64 * e : tid + 256 * e;
+        if (SMALL) Xc[(i >> 5) * XS + (i & 31)] = stg[e];
+        else Xc[(i >> 6) * XS + (i & 63)] = stg[e];
+      }
+      if (!SMALL) __syncthreads();   // image visible to the 4 waves (double buffered: the previous channel may still be read)
+      if (c < 4) load_channel(c + 1);
+      fb_v16f o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] = 0.f;
+      if constexpr (SMALL) {
+        // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'] (x' < 32) -------------------------------------------------
+        fb_v16f u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.f;
+        const float* xa = Xc + col * XS + half;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) u = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk], ghreg[kk], u, 0, 0, 0);
+        // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x]; contraction slot kk of lane-half h is row fb_acc_row(kk, h):
+        // the horizontal result goes from the accumulator straight into the B operand
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(gvreg[0][kk], u[kk], o, 0, 0, 0);
+      } else {
+        // ---- horizontal: this wave's 32 x 32 tile U[32 yt + y'][32 xt + x], shared with the other waves through LDS ------
+        fb_v16f u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.f;
+        const float* xa = Xc + (32 * yt + col) * XS + half;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) u = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk], ghreg[kk], u, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Us[(32 * yt + fb_acc_row(r, half)) * XS + 32 * xt + col] = u[r];
+        __syncthreads();   // all four U tiles visible
+        // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x], y' = 0..63 in natural order ----------------------------------
+        const float* ub = Us + half * XS + 32 * xt + col;
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(gvnat[kk], ub[2 * kk * XS], o, 0, 0, 0);
+      }
+      res[c] = o;
+    }
+    if (!SMALL) __syncthreads();   // both image buffers free before the next pair's channel 0 / 1 are staged
+    // ---- 2x2 solve; accumulator register r = row y, lane = column x: coalesced flow rows ---------------------------------
+    if (p_ok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int y = 32 * yt + fb_acc_row(r, half), x = 32 * xt + col;
+        if (y < height && x < width) {
+          double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+          double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+          double idet = __ddiv_rn(1.0, det);
+          const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+          const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+          float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
+          fl[0] = fxv;
+          fl[1] = fyv;
+        }
       }
     }
   }
@@ -694,7 +836,7 @@ static int fb_num_levels(int h, int w, double pyr_scale, int levels) {
 }
 
 struct FbLayout {
-  size_t off_I, off_T, off_R, off_M, off_V, off_flowA, off_flowB, total;
+  size_t off_I, off_T, off_R, off_M, off_V, off_flowA, off_flowB, off_G, total;
 };
 static FbLayout fb_layout(long long n_pairs, int h, int w) {
   const size_t px = (size_t)h * w;
@@ -708,6 +850,7 @@ static FbLayout fb_layout(long long n_pairs, int h, int w) {
   L.off_V = o; o = align(o + (size_t)n_pairs * px * 20);
   L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
+  L.off_G = o; o = align(o + 2 * 64 * 64 * sizeof(float));   // window matrices of the current pyramid level
   L.total = o;
   return L;
 }
@@ -803,24 +946,29 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)I, T, (long long)n_pairs * 2, lh, lw, pk);
     hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
                        (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
-    const bool tile_path = lw <= 64 && lh <= 64 && (win.n == 20 || win.n == 7 || win.n == 10) && n_pairs <= 0x7fffffffLL;
+    const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                        (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0);
     for (int it = 0; it < p->iterations; ++it) {
       const int update = it < p->iterations - 1 ? 1 : 0;
       if (tile_path) {
-        // blur + solve in one workgroup per pair; UpdateMatrices stays a separate high-occupancy launch: its
-        // flow-dependent R1 gathers need many waves in flight (measured: inside the tile kernel, at 2 waves/SIMD,
-        // they took 4x the time of the whole blur)
-        if (win.n == 20)
-          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<20, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
-                             (const float*)R, flow, lh, lw, win);
-        else if (win.n == 10)
-          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<10, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
-                             (const float*)R, flow, lh, lw, win);
-        else
-          hipLaunchKernelGGL((fb_tile_iter_pk_kernel<7, 8>), dim3((unsigned)n_pairs), dim3(512), 0, st, (const float*)M,
-                             (const float*)R, flow, lh, lw, win);
+        // window blur + solve on the matrix cores (UpdateMatrices stays a separate high-occupancy launch: its
+        // flow-dependent R1 gathers need many waves in flight)
+        float* Gv = (float*)(ws + L.off_G);
+        float* Gh = Gv + 64 * 64;
+        if (it == 0) {
+          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
+          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
+        }
+        if (lh <= 32 && lw <= 32) {
+          const unsigned grid = (unsigned)std::min<long long>((n_pairs + 3) / 4, 2048);
+          hipLaunchKernelGGL(fb_tile_mfma_kernel<true>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+                             (const float*)Gh, flow, lh, lw, (long long)n_pairs);
+        } else {
+          const unsigned grid = (unsigned)std::min<long long>(n_pairs, 2048);
+          hipLaunchKernelGGL(fb_tile_mfma_kernel<false>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+                             (const float*)Gh, flow, lh, lw, (long long)n_pairs);
+        }
         if (update)
           hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                              (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1);
