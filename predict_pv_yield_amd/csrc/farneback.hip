@@ -170,6 +170,137 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
   }
 }
 
+// ---- prep + PolyExp fused for source images up to 64 x 64 (the PV-site tiles) ---------------------------------------
+// One workgroup = one image of a pair: the u8 image, its separable Gaussian, the resized level image I and the vertical
+// PolyExp triples T all live in LDS; only the 5 polynomial coefficients R go to memory (the three-kernel path writes and
+// re-reads I and T: 130 bytes per level-pixel of extra traffic and two more launches).  Every expression is the one of
+// fb_prep_kernel / fb_polyexp_v_kernel / fb_polyexp_h_kernel, evaluated in the same order: bit-identical results.
+__global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
+                                                                    const uint8_t* __restrict__ next, long long prev_stride,
+                                                                    long long next_stride, long long pairs_per_group,
+                                                                    long long group_stride, float* __restrict__ R,
+                                                                    long long n_img, int h, int w, int lh, int lw, int mode,
+                                                                    double inv_fx, double inv_fy, FbTaps kt, FbPoly pk) {
+  __shared__ float bufA[64 * 64];        // source as float, later the blurred image
+  __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
+  __shared__ float Tt[3 * 64 * 64];      // vertical PolyExp triples, planar
+  const int tid = threadIdx.x;
+  const int ks = kt.n, r = ks >> 1;
+  for (long long im = blockIdx.x; im < n_img; im += gridDim.x) {
+    const long long p = im >> 1;
+    const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
+    const uint8_t* img = ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
+    const int npx = h * w, lpx = lh * lw;
+    for (int i = tid; i < npx; i += 256) bufA[i] = (float)img[i];
+    __syncthreads();
+    // row filter (BORDER_REFLECT_101), same tap order as row_filter()
+    for (int i = tid; i < npx; i += 256) {
+      const int y = i / w, x = i - y * w;
+      const float* srow = bufA + y * w;
+      float acc;
+      if (ks <= 5) {
+        acc = srow[x] * kt.k[r];
+        for (int t = 1; t <= r; ++t)
+          acc = __fadd_rn(acc, __fmul_rn(srow[reflect101(x - t, w)] + srow[reflect101(x + t, w)], kt.k[r + t]));
+      } else {
+        acc = srow[reflect101(x - r, w)] * kt.k[0];
+        for (int t = 1; t < ks; ++t) acc = __fadd_rn(acc, __fmul_rn(srow[reflect101(x + t - r, w)], kt.k[t]));
+      }
+      bufB[i] = acc;
+    }
+    __syncthreads();
+    // column filter -> blurred image (over the source, which is no longer needed)
+    for (int i = tid; i < npx; i += 256) {
+      const int y = i / w, x = i - y * w;
+      float acc = __fmul_rn(bufB[i], kt.k[r]);
+      for (int t = 1; t <= r; ++t) {
+        const float a = bufB[reflect101(y - t, h) * w + x], b = bufB[reflect101(y + t, h) * w + x];
+        acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(a, b), kt.k[r + t]));
+      }
+      bufA[i] = acc;
+    }
+    __syncthreads();
+    // resize to the level image I (into bufB)
+    for (int i = tid; i < lpx; i += 256) {
+      const int y = i / lw, x = i - y * lw;
+      float v;
+      if (mode == 0) {
+        v = bufA[i];
+      } else if (mode == 1) {
+        const float a = __fadd_rn(bufA[(2 * y) * w + 2 * x], bufA[(2 * y) * w + 2 * x + 1]);
+        const float b = __fadd_rn(bufA[(2 * y + 1) * w + 2 * x], bufA[(2 * y + 1) * w + 2 * x + 1]);
+        v = __fmul_rn(__fadd_rn(a, b), 0.25f);
+      } else {
+        float fx = (float)((x + 0.5) * inv_fx - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= w - 1) { fx = 0; sx = w - 1; }
+        float fy = (float)((y + 0.5) * inv_fy - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= h - 1) { fy = 0; sy = h - 1; }
+        const int sy1 = clampi_d(sy + 1, 0, h - 1);
+        float r0, r1;
+        if (sx + 1 < w) {
+          const float a0 = 1.f - fx, a1 = fx;
+          r0 = __fadd_rn(__fmul_rn(bufA[sy * w + sx], a0), __fmul_rn(bufA[sy * w + sx + 1], a1));
+          r1 = __fadd_rn(__fmul_rn(bufA[sy1 * w + sx], a0), __fmul_rn(bufA[sy1 * w + sx + 1], a1));
+        } else {
+          r0 = bufA[sy * w + sx];
+          r1 = bufA[sy1 * w + sx];
+        }
+        v = __fadd_rn(__fmul_rn(r0, 1.f - fy), __fmul_rn(r1, fy));
+      }
+      bufB[i] = v;
+    }
+    __syncthreads();
+    // PolyExp, vertical pass -> T (planar)
+    for (int i = tid; i < lpx; i += 256) {
+      const int y = i / lw, x = i - y * lw;
+      float t0 = __fmul_rn(bufB[i], pk.g[0]), t1 = 0.f, t2 = 0.f;
+      for (int k = 1; k <= pk.n; ++k) {
+        const float s0 = bufB[max(y - k, 0) * lw + x];
+        const float s1 = bufB[min(y + k, lh - 1) * lw + x];
+        const float pp = __fadd_rn(s0, s1);
+        t0 = __fadd_rn(t0, __fmul_rn(pk.g[k], pp));
+        t1 = __fadd_rn(t1, __fmul_rn(pk.xg[k], __fsub_rn(s1, s0)));
+        t2 = __fadd_rn(t2, __fmul_rn(pk.xxg[k], pp));
+      }
+      Tt[i] = t0, Tt[lpx + i] = t1, Tt[2 * lpx + i] = t2;
+    }
+    __syncthreads();
+    // PolyExp, horizontal pass (double accumulators) -> R
+    for (int i = tid; i < lpx; i += 256) {
+      const int y = i / lw, x = i - y * lw;
+      const float* t0r = Tt + y * lw;
+      const float* t1r = Tt + lpx + y * lw;
+      const float* t2r = Tt + 2 * lpx + y * lw;
+      float g0 = pk.g[0];
+      double b1 = __fmul_rn(t0r[x], g0), b2 = 0, b3 = __fmul_rn(t1r[x], g0), b4 = 0, b5 = __fmul_rn(t2r[x], g0), b6 = 0;
+      for (int k = 1; k <= pk.n; ++k) {
+        const int xp = min(x + k, lw - 1), xm = max(x - k, 0);
+        const double tg = (double)__fadd_rn(t0r[xp], t0r[xm]);
+        g0 = pk.g[k];
+        b1 = __dadd_rn(b1, __dmul_rn(tg, (double)g0));
+        b4 = __dadd_rn(b4, __dmul_rn(tg, (double)pk.xxg[k]));
+        b2 = __dadd_rn(b2, (double)__fmul_rn(__fsub_rn(t0r[xp], t0r[xm]), pk.xg[k]));
+        b3 = __dadd_rn(b3, (double)__fmul_rn(__fadd_rn(t1r[xp], t1r[xm]), g0));
+        b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[xp], t1r[xm]), pk.xg[k]));
+        b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[xp], t2r[xm]), g0));
+      }
+      float* d = R + (im * lpx + i) * 5;
+      d[1] = (float)__dmul_rn(b2, pk.ig11);
+      d[0] = (float)__dmul_rn(b3, pk.ig11);
+      d[3] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+      d[2] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+      d[4] = (float)__dmul_rn(b6, pk.ig55);
+    }
+    __syncthreads();   // LDS is reused by the next image
+  }
+}
+
 // ---- UpdateMatrices --------------------------------------------------------------------------------
 // one pixel of FarnebackUpdateMatrices: R0 = this pixel's 5 coefficients, R1 = base of the second image's
 // coefficient plane, (dx, dy) = current flow; out = (G11, G12, G22, h1, h2)
@@ -938,6 +1069,12 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     if (lw == w && lh == h) mode = 0;
     else if (fabs(inv_fx - 2.0) < 2.220446049250313e-16 && fabs(inv_fy - 2.0) < 2.220446049250313e-16) mode = 1;
     else mode = 2;
+    if (h <= 64 && w <= 64 && smooth_sz <= 63) {
+      const unsigned grid = (unsigned)std::min<long long>(n_pairs * 2, 4096);
+      hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(256), 0, st, prev, next, (long long)prev_stride,
+                         (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
+                         (long long)n_pairs * 2, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk);
+    } else {
     hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st, prev, next,
                        (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,
                        (long long)n_pairs, h, w, lh, lw, mode, inv_fx,
@@ -946,6 +1083,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)I, T, (long long)n_pairs * 2, lh, lw, pk);
     hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
                        (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
+    }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                        (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0);
