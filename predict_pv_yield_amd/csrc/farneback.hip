@@ -186,6 +186,10 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
   __shared__ float Tt[3 * 64 * 64];      // vertical PolyExp triples, planar
   const int tid = threadIdx.x;
   const int ks = kt.n, r = ks >> 1;
+  // row index of a flat pixel index: a shift for power-of-two widths (the usual 64 / 32), else a division
+  const int sh_w = (w & (w - 1)) == 0 ? __builtin_ctz(w) : -1, sh_lw = (lw & (lw - 1)) == 0 ? __builtin_ctz(lw) : -1;
+  auto row_w = [&](int i) { return sh_w >= 0 ? i >> sh_w : i / w; };
+  auto row_lw = [&](int i) { return sh_lw >= 0 ? i >> sh_lw : i / lw; };
   for (long long im = blockIdx.x; im < n_img; im += gridDim.x) {
     const long long p = im >> 1;
     const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     __syncthreads();
     // row filter (BORDER_REFLECT_101), same tap order as row_filter()
     for (int i = tid; i < npx; i += 256) {
-      const int y = i / w, x = i - y * w;
+      const int y = row_w(i), x = i - y * w;
       const float* srow = bufA + y * w;
       float acc;
       if (ks <= 5) {
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     __syncthreads();
     // column filter -> blurred image (over the source, which is no longer needed)
     for (int i = tid; i < npx; i += 256) {
-      const int y = i / w, x = i - y * w;
+      const int y = row_w(i), x = i - y * w;
       float acc = __fmul_rn(bufB[i], kt.k[r]);
       for (int t = 1; t <= r; ++t) {
         const float a = bufB[reflect101(y - t, h) * w + x], b = bufB[reflect101(y + t, h) * w + x];
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     __syncthreads();
     // resize to the level image I (into bufB)
     for (int i = tid; i < lpx; i += 256) {
-      const int y = i / lw, x = i - y * lw;
+      const int y = row_lw(i), x = i - y * lw;
       float v;
       if (mode == 0) {
         v = bufA[i];
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     __syncthreads();
     // PolyExp, vertical pass -> T (planar)
     for (int i = tid; i < lpx; i += 256) {
-      const int y = i / lw, x = i - y * lw;
+      const int y = row_lw(i), x = i - y * lw;
       float t0 = __fmul_rn(bufB[i], pk.g[0]), t1 = 0.f, t2 = 0.f;
       for (int k = 1; k <= pk.n; ++k) {
         const float s0 = bufB[max(y - k, 0) * lw + x];
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     __syncthreads();
     // PolyExp, horizontal pass (double accumulators) -> R
     for (int i = tid; i < lpx; i += 256) {
-      const int y = i / lw, x = i - y * lw;
+      const int y = row_lw(i), x = i - y * lw;
       const float* t0r = Tt + y * lw;
       const float* t1r = Tt + lpx + y * lw;
       const float* t2r = Tt + 2 * lpx + y * lw;
