@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 // PolyExp triples T all live in LDS; only the 5 polynomial coefficients R go to memory (the three-kernel path writes and
 // re-reads I and T: 130 bytes per level-pixel of extra traffic and two more launches).  Every expression is the one of
 // fb_prep_kernel / fb_polyexp_v_kernel / fb_polyexp_h_kernel, evaluated in the same order: bit-identical results.
-__global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
+constexpr int FB_PP_NT = 1024;   // 16 waves per workgroup: the 80 KB of LDS allow one workgroup per CU, so it must be a big one
+__global__ __launch_bounds__(FB_PP_NT) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
                                                                     const uint8_t* __restrict__ next, long long prev_stride,
                                                                     long long next_stride, long long pairs_per_group,
                                                                     long long group_stride, float* __restrict__ R,
@@ -195,10 +196,10 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
     const uint8_t* img = ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
     const int npx = h * w, lpx = lh * lw;
-    for (int i = tid; i < npx; i += 256) bufA[i] = (float)img[i];
+    for (int i = tid; i < npx; i += FB_PP_NT) bufA[i] = (float)img[i];
     __syncthreads();
     // row filter (BORDER_REFLECT_101), same tap order as row_filter()
-    for (int i = tid; i < npx; i += 256) {
+    for (int i = tid; i < npx; i += FB_PP_NT) {
       const int y = row_w(i), x = i - y * w;
       const float* srow = bufA + y * w;
       float acc;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     }
     __syncthreads();
     // column filter -> blurred image (over the source, which is no longer needed)
-    for (int i = tid; i < npx; i += 256) {
+    for (int i = tid; i < npx; i += FB_PP_NT) {
       const int y = row_w(i), x = i - y * w;
       float acc = __fmul_rn(bufB[i], kt.k[r]);
       for (int t = 1; t <= r; ++t) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     }
     __syncthreads();
     // resize to the level image I (into bufB)
-    for (int i = tid; i < lpx; i += 256) {
+    for (int i = tid; i < lpx; i += FB_PP_NT) {
       const int y = row_lw(i), x = i - y * lw;
       float v;
       if (mode == 0) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     }
     __syncthreads();
     // PolyExp, vertical pass -> T (planar)
-    for (int i = tid; i < lpx; i += 256) {
+    for (int i = tid; i < lpx; i += FB_PP_NT) {
       const int y = row_lw(i), x = i - y * lw;
       float t0 = __fmul_rn(bufB[i], pk.g[0]), t1 = 0.f, t2 = 0.f;
       for (int k = 1; k <= pk.n; ++k) {
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void fb_prep_polyexp_tile_kernel(const uint8_t
     }
     __syncthreads();
     // PolyExp, horizontal pass (double accumulators) -> R
-    for (int i = tid; i < lpx; i += 256) {
+    for (int i = tid; i < lpx; i += FB_PP_NT) {
       const int y = row_lw(i), x = i - y * lw;
       const float* t0r = Tt + y * lw;
       const float* t1r = Tt + lpx + y * lw;
@@ -1075,7 +1076,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     else mode = 2;
     if (h <= 64 && w <= 64 && smooth_sz <= 63) {
       const unsigned grid = (unsigned)std::min<long long>(n_pairs * 2, 4096);
-      hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(256), 0, st, prev, next, (long long)prev_stride,
+      hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
                          (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
                          (long long)n_pairs * 2, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk);
     } else {
