@@ -97,7 +97,7 @@ def measure_conv_roofline(batch, hist_frames, dev):
             "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v7.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v10.json")
 
 
 def committed_hbm_traffic(cpad: int, batch: int):
@@ -108,8 +108,8 @@ def committed_hbm_traffic(cpad: int, batch: int):
     if batch != 32 or cpad != 32 or not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
-    fam = [v for k, v in ks.items() if k.startswith("pv::conv3d_fwd_bf16_v2_kernel") or
-           k.startswith("pv::conv3d_fwd_bf16_kernel<32")]
+    fam = [v for k, v in ks.items() if k.startswith("pv::conv3d_fwd_bf16_v3_kernel") or
+           k.startswith("pv::conv3d_fwd_bf16_v2_kernel") or k.startswith("pv::conv3d_fwd_bf16_kernel<32")]
     n = sum(v["launches"] for v in fam)
     return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / n) if n else None
 

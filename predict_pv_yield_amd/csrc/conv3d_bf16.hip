@@ -23,6 +23,7 @@
 // dgrad is the same kernel on dy (zero padding 2-p, ReLU gate applied while staging) with
 // channel-swapped, mirrored weights (pv_conv3d_pack_weight_bf16(..., transpose_flip = 1)).
 #include "pv_common.h"
+#include <stdlib.h>
 
 namespace pv {
 
@@ -540,6 +541,10 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
 int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
                               int n_rowblk, int n_colblk, int n_tchunk, int t_chunk, hipStream_t st);
+// input-stationary variant (conv3d_bf16_v3.hip, its own 8 x 32 tiling); 1 = shape not covered
+int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
+                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
+                              hipStream_t st);
 void launch_pack_weight_v2(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
 constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
 
@@ -671,9 +676,15 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
-  if (cpad == 32 && !gate && !y_ncdhw)  // 32 -> 32 channel layers, NDHWC out: two-waves-per-SIMD kernel
+  if (cpad == 32 && !gate && !y_ncdhw) {  // 32 -> 32 channel layers, NDHWC out: two-waves-per-SIMD kernels
+    static const bool force_v2 = getenv("PV_CONV_V2") != nullptr;
+    if (!force_v2) {
+      const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, st);
+      if (rc != 1) return rc;
+    }
     return launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, n_rowblk,
                                      n_colblk, n_tchunk, t_chunk, st);
+  }
 #define PV_LAUNCH_CONV(CP, HG, YN, OG)                                                                           \
   hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN, OG>), grid, dim3(256), 0, st, x, gate, wp, bias, y, out_gate, \
                      d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk,        \

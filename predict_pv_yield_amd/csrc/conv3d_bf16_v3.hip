@@ -1,0 +1,333 @@
+// bf16 MFMA Conv3D for 32 -> 32 channel layers, INPUT-STATIONARY time march (forward L1..L2 and every dgrad).
+//
+// conv3d_bf16_v2.hip computes one output slice at a time from the three input slices it needs: every B fragment
+// (activations, 32 cin x 16 voxels) read from LDS feeds only the 3 kh taps of one kt plane, and the two waves of a
+// cout pair read the same fragments -- 864 ds_read_b128 per slice and CU = 6912 LDS cycles, exactly the 6912 matrix-pipe
+// cycles per SIMD: LDS bandwidth co-limits the kernel (measured matrix pipe busy 60 %).
+//
+// Here the march is turned around: each step takes ONE INPUT slice s and adds its contribution to the three output
+// slices s, s-1, s-2 (tap planes kt = 0, 1, 2) that are in flight in registers.  A fragment is read once and feeds up
+// to 3 kh x 3 kt MFMAs: a third of the LDS operand traffic.  To make room for 3 x 32 accumulator registers inside the
+// 256-register budget of two waves per SIMD:
+//   * the kt = 2 tap plane of the weights lives in LDS (3 fragment reads per (slice, kw)), kt = 0, 1 stay in registers;
+//   * input slices are staged global -> LDS directly (buffer_load_dwordx4 ... lds, gfx950), no staging registers: the
+//     LDS destination of a wave instruction is 1 KB linear by lane, so the XOR swizzle of the image is applied to the
+//     SOURCE address of each lane instead;
+//   * the finished tile goes from registers straight to global memory (8 B per lane = 4 consecutive couts of a voxel;
+//     the two waves of a cout pair fill the two 32-byte halves of every voxel) -- no LDS staging, no second barrier.
+// One barrier per slice, and because a step only needs the slice being read plus the one being fetched, the ring is
+// TWO slots deep.  That shrinks the LDS footprint enough to run two independent 4-wave workgroups per CU (tile 8 rows x
+// 32 columns each, one wave of each workgroup per SIMD): the two workgroups drift apart, so while one sits at its
+// barrier or converts / stores a finished tile the other keeps the matrix pipe busy -- without the lock-step a single
+// 8-wave workgroup imposes.  Same swizzled LDS image and weight fragments (pack_weight_v2_kernel) as v2.
+#include "pv_common.h"
+
+namespace pv {
+
+constexpr int V3_TR = 8, V3_TRI = 10, V3_TW = 34, V3_TW_VALID = 32;  // input row 34 voxels -> 32 output columns
+constexpr int V3_VOXB = 64, V3_ROWB = V3_TW * V3_VOXB, V3_SLOTB = V3_TRI * V3_ROWB;
+constexpr int V3_W2B = 9 * 2 * 64 * 16;  // tap plane kt = 2: [9 taps][2 cout halves][64 lanes] x 16 B
+constexpr uint32_t V3_INVALID = 0x40000000u;
+
+// ReLU-derivative gate of a bf16 pair: 2 bits (low half > 0, high half > 0); and its application to a bf16 pair
+__device__ __forceinline__ uint32_t v3_gate_bits(uint32_t g) {
+  const uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 1u : 0u;
+  const uint32_t hi = ((g & 0x7fff0000u) != 0u && (g & 0x80000000u) == 0u) ? 2u : 0u;
+  return lo | hi;
+}
+__device__ __forceinline__ uint32_t v3_apply_gate(uint32_t x, uint32_t bits) {
+  return x & (((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u));
+}
+
+// One input slice's contribution to output slices s - kt, kt in [KT_LO, KT_HI] (compile-time: head and tail steps of
+// the march feed fewer slices).  P = (s - tc0) % 3 names the accumulator slot of output slice s.
+template <int P, int KT_LO, int KT_HI, int KW>
+__device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3][2], const bf16x8 (&wfrag)[18],
+                                              const unsigned char* w2, f32x4 (&acc)[3][4][2]) {
+  {
+    constexpr int kw = KW;
+    bf16x8 cur[2], nxt[2], wk2[3];
+    if (KT_HI == 2) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) wk2[kh] = *reinterpret_cast<const bf16x8*>(w2 + (kh * 3 + kw) * 2048);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) cur[half] = *reinterpret_cast<const bf16x8*>(slot + voff[kw][half]);
+#pragma unroll
+    for (int ir = 0; ir < 6; ++ir) {
+      if (ir < 5) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          nxt[half] = *reinterpret_cast<const bf16x8*>(slot + (ir + 1) * V3_ROWB + voff[kw][half]);
+      }
+#pragma unroll
+      for (int kt = KT_LO; kt <= KT_HI; ++kt) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int orow = ir - kh;
+          if (orow >= 0 && orow < 4) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+              acc[(P - kt + 3) % 3][orow][half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  kt == 2 ? wk2[kh] : wfrag[kt * 9 + kh * 3 + kw], cur[half], acc[(P - kt + 3) % 3][orow][half], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) cur[half] = nxt[half];
+    }
+  }
+}
+
+template <bool OUT_GATE>
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
+    uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out) {
+  // ring of 2 slices | kt = 2 weight plane | 32 bias floats   (78 KB: two workgroups per CU)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * V3_SLOTB + V3_W2B + 128];
+  unsigned char* lds_w2 = lds + 2 * V3_SLOTB;
+  float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = wave & 1;   // output-channel half (16 couts)
+  const int wr = wave >> 1;  // row quad
+  const int vox = lane & 15, kg = lane >> 4;
+
+  const int rowblk = blockIdx.x / n_colblk;
+  const int colblk = blockIdx.x - rowblk * n_colblk;
+  const int h0 = rowblk * V3_TR;
+  const int w0 = colblk * V3_TW_VALID;
+  const int b = blockIdx.z;
+  const int tc0 = blockIdx.y * t_chunk;
+  const int tc1 = min(tc0 + t_chunk, t_out);
+  if (tc1 - tc0 < 2) return;  // the launcher sends single-slice chunks to the v2 kernel
+
+  if (tid < 32) lds_bias[tid] = (bias && tid < c_out) ? bias[tid] : 0.f;
+
+  // ---- weights: tap planes kt = 0, 1 resident in registers (18 A fragments, 16 couts x 32 cin), kt = 2 in LDS ----
+  bf16x8 wfrag[18];
+#pragma unroll
+  for (int tap = 0; tap < 18; ++tap)
+    wfrag[tap] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)(tap * 2 + ch) * 64 + lane) * 8);
+  for (int i = tid; i < V3_W2B / 16; i += 256)
+    reinterpret_cast<u32x4*>(lds_w2)[i] = reinterpret_cast<const u32x4*>(wp2 + (size_t)18 * 2 * 64 * 8)[i];
+  const unsigned char* w2 = lds_w2 + ch * 1024 + lane * 16;
+
+  // ---- per-lane LDS read offsets of the B operand: voxel 16*half + vox + kw, 16-byte chunk kg ---------------------
+  int voff[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int v = 16 * half + vox + kw;
+      voff[kw][half] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
+    }
+
+  // ---- staging: global -> LDS direct.  A wave instruction fills 16 voxels x 64 B = 1 KB (lane -> voxel lane/4, chunk
+  // position lane%4); a row of 34 voxels = 2 full instructions + one with lanes 0..7.  Wave w stages rows w, w+4, w+8.
+  // The lane fetches the source chunk that the swizzle maps to its position (the swizzle has period 8 voxels, so the
+  // three segments of a row share it). -----------------------------------------------------------------------------
+  const int svox = lane >> 2;
+  const int ssrc = (lane & 3) ^ (((svox >> 2) & 1) << 1);
+  uint32_t lane_voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int swi = w0 - pad_w + 16 * j + svox;
+    lane_voff[j] = ((unsigned)swi < (unsigned)w_in) ? (uint32_t)(swi * 32 + ssrc * 8) * 2u : V3_INVALID;
+  }
+  const uint32_t x_plane_b = (uint32_t)h_in * w_in * 64u, x_row_b = (uint32_t)w_in * 64u;
+  const size_t sample_elems = (size_t)t_in * h_in * w_in * 32;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
+  auto load_slice = [&](int s) {
+    const int ti = s - pad_t;
+    const bool t_ok = (unsigned)ti < (unsigned)t_in;
+    const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
+    unsigned char* dst = lds + (s & 1) * V3_SLOTB + wave * V3_ROWB;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (wave + 4 * i < V3_TRI) {
+        const int hi = h0 - pad_h + 4 * i + wave;
+        const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;
+        const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : V3_INVALID);
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB), 16, lane_voff[0] + srow, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB + 1024), 16, lane_voff[1] + srow, 0,
+                                                 0, 0);
+        if (lane < 8)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB + 2048), 16, lane_voff[2] + srow,
+                                                   0, 0, 0);
+      }
+    }
+  };
+
+  // ---- write-out geometry: lane (vox, kg) of accumulator [orow][half] holds couts 16ch + 4kg .. +3 of voxel
+  // (row h0 + 4wr + orow, column w0 + 16half + vox): 8 bytes ----------------------------------------------------
+  const int plane_out = h_out * w_out;
+  uint32_t st_off[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int col_t = 16 * half + vox;
+    const bool ok = (w0 + col_t) < w_out;
+    st_off[half] = ok ? ((uint32_t)((h0 + 4 * wr) * w_out + w0 + col_t) * 32u + 16u * ch + 4u * kg) * 2u : V3_INVALID;
+  }
+  const size_t out_sample_b = (size_t)t_out * plane_out * 64;
+  const __amdgpu_buffer_rsrc_t yrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ogrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
+  auto row_off = [&](int o, int orow) -> uint32_t {  // wave-uniform part of the byte offset of (slice o, tile row orow)
+    const bool ok = (h0 + 4 * wr + orow) < h_out;
+    return ok ? (uint32_t)o * (uint32_t)plane_out * 64u + (uint32_t)orow * (uint32_t)w_out * 64u : V3_INVALID;
+  };
+
+  u32x2 pend[4][2];  // finished tile (bf16 pairs), stored one step later so the stores never sit in front of a wait
+  u32x2 og[OUT_GATE ? 4 : 1][2];
+  uint32_t gbits = 0u;  // the tile's gate, 4 bits per (row, half): the 16 gate registers live only through the kw = 0 phase
+  auto store_pending = [&](int o) {
+#pragma unroll
+    for (int orow = 0; orow < 4; ++orow) {
+      const uint32_t ro = row_off(o, orow);
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+        __builtin_amdgcn_raw_buffer_store_b64(pend[orow][half], yrsrc, st_off[half] + ro, 0, 0);
+    }
+  };
+  auto load_gate = [&](int o) {
+    if constexpr (OUT_GATE) {
+#pragma unroll
+      for (int orow = 0; orow < 4; ++orow) {
+        const uint32_t ro = row_off(o, orow);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) og[orow][half] = __builtin_amdgcn_raw_buffer_load_b64(ogrsrc, st_off[half] + ro, 0, 0);
+      }
+    }
+  };
+
+  // accumulators of the three output slices in flight: acc[(o - tc0) % 3][row][half], 16 couts x 16 voxels each,
+  // initialised with the bias of couts 16*ch + 4*kg + reg
+  f32x4 acc[3][4][2];
+
+  // ---- prologue ------------------------------------------------------------------------------------------------
+  load_slice(tc0);
+  __syncthreads();  // lds_bias, lds_w2 written
+  {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) acc[j][r4][half] = b4;
+  }
+  const int s_last = tc1 + 1;  // last input slice any output slice of this chunk needs
+
+  // One step of the march.  The loads of slice s+1 (into the slot slice s-1 occupied) and the stores of output slice s-3
+  // are issued right after the barrier and have the whole step to complete; the wait at the top of the next step then
+  // costs nothing.
+#define PV_V3_STEP(P, KT_LO, KT_HI)                                                                               \
+  {                                                                                                               \
+    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's LDS-direct loads of slice s have landed */        \
+    __syncthreads();                    /* ... everybody's; and every wave is done reading slice s-1 */            \
+    if (s + 1 <= s_last) load_slice(s + 1);                                                                       \
+    if (s - 3 >= tc0) store_pending(s - 3);                                                                       \
+    if (KT_HI == 2) load_gate(s - 2);                                                                             \
+    const unsigned char* slot = lds + (s & 1) * V3_SLOTB + (4 * wr) * V3_ROWB;                                    \
+    v3_accumulate<P, KT_LO, KT_HI, 0>(slot, voff, wfrag, w2, acc);                                                \
+    if constexpr (OUT_GATE && KT_HI == 2) {                                                                       \
+      gbits = 0u;                                                                                                 \
+      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) \
+        gbits |= (v3_gate_bits(og[orow][half][0]) | (v3_gate_bits(og[orow][half][1]) << 2)) << (4 * (2 * orow + half)); \
+    }                                                                                                             \
+    v3_accumulate<P, KT_LO, KT_HI, 1>(slot, voff, wfrag, w2, acc);                                                \
+    v3_accumulate<P, KT_LO, KT_HI, 2>(slot, voff, wfrag, w2, acc);                                                \
+    if (KT_HI == 2) { /* output slice s-2 is complete: convert it, re-arm its accumulators */                     \
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);                              \
+      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
+        f32x4 a = acc[((P) + 1) % 3][orow][half];                                                                 \
+        acc[((P) + 1) % 3][orow][half] = b4;                                                                      \
+        if (relu) {                                                                                               \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;                           \
+        }                                                                                                         \
+        u32x2 o;                                                                                                  \
+        o[0] = (uint32_t)f32_to_bf16_bits(a[0]) | ((uint32_t)f32_to_bf16_bits(a[1]) << 16);                       \
+        o[1] = (uint32_t)f32_to_bf16_bits(a[2]) | ((uint32_t)f32_to_bf16_bits(a[3]) << 16);                       \
+        if constexpr (OUT_GATE) {                                                                                 \
+          o[0] = v3_apply_gate(o[0], gbits >> (4 * (2 * orow + half)));                                           \
+          o[1] = v3_apply_gate(o[1], gbits >> (4 * (2 * orow + half) + 2));                                       \
+        }                                                                                                         \
+        pend[orow][half] = o;                                                                                     \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+
+  int s = tc0;
+  PV_V3_STEP(0, 0, 0);
+  ++s;
+  PV_V3_STEP(1, 0, 1);
+  ++s;
+  for (;;) {  // interior steps: all three tap planes
+    if (s >= tc1) break;
+    PV_V3_STEP(2, 0, 2);
+    ++s;
+    if (s >= tc1) break;
+    PV_V3_STEP(0, 0, 2);
+    ++s;
+    if (s >= tc1) break;
+    PV_V3_STEP(1, 0, 2);
+    ++s;
+  }
+  // tail: s = tc1 feeds output slices tc1-1, tc1-2; s = tc1+1 only tc1-1
+  const int ptail = (tc1 - tc0) % 3;
+  if (ptail == 0) {
+    PV_V3_STEP(0, 1, 2);
+    ++s;
+    PV_V3_STEP(1, 2, 2);
+  } else if (ptail == 1) {
+    PV_V3_STEP(1, 1, 2);
+    ++s;
+    PV_V3_STEP(2, 2, 2);
+  } else {
+    PV_V3_STEP(2, 1, 2);
+    ++s;
+    PV_V3_STEP(0, 2, 2);
+  }
+#undef PV_V3_STEP
+  store_pending(tc1 - 1);  // the tile the last step finished
+}
+
+// Returns 1 (not a PV_* code) when the shape does not fit this kernel (fewer than 2 output slices per time chunk): the caller falls back
+// to the v2 kernel.
+int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
+                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
+                              hipStream_t st) {
+  if (to < 2) return 1;
+  const int n_rowblk = (ho + V3_TR - 1) / V3_TR;
+  const int n_colblk = (wo + V3_TW_VALID - 1) / V3_TW_VALID;
+  // two workgroups per CU: split the time march only when the (sample, tile) grid alone cannot fill 512 slots
+  const long long tiles = (long long)d->batch * n_rowblk * n_colblk;
+  int n_tchunk = 1;
+  if (tiles < 512) n_tchunk = (int)((512 + tiles - 1) / tiles);
+  if (n_tchunk > to / 2) n_tchunk = to / 2;  // at least 2 output slices per chunk
+  int t_chunk = (to + n_tchunk - 1) / n_tchunk;
+  n_tchunk = (to + t_chunk - 1) / t_chunk;
+  if (to - (n_tchunk - 1) * t_chunk < 2) {  // a single-slice remainder: fold it into longer chunks
+    ++t_chunk;
+    n_tchunk = (to + t_chunk - 1) / t_chunk;
+    if (to - (n_tchunk - 1) * t_chunk < 2) return 1;
+  }
+  dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
+  if (out_gate)
+    hipLaunchKernelGGL(conv3d_fwd_bf16_v3_kernel<true>, grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in, d->h_in,
+                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out);
+  else
+    hipLaunchKernelGGL(conv3d_fwd_bf16_v3_kernel<false>, grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in, d->h_in,
+                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out);
+  return check_launch("pv_conv3d_fwd_bf16(v3)");
+}
+
+}  // namespace pv

@@ -132,6 +132,39 @@ def test_conv3d_bf16_backward(device, case):
     del y
 
 
+V3_SHAPES = [
+    # b, t, h, w, padding: the input-stationary 32 -> 32 kernel (8 x 32 tiles, >= 2 output slices per time chunk)
+    (1, 4, 10, 34, (0, 0, 0)),    # to = 2: head + tail steps only, one full-width tile
+    (1, 5, 11, 35, (0, 0, 0)),    # to = 3, 33 output columns: second column block holds a single column
+    (2, 9, 9, 20, (0, 0, 0)),     # to = 7, split into time chunks (few tiles); ragged rows / columns
+    (1, 7, 19, 67, (1, 0, 0)),    # to = 7 with time padding, three column blocks
+    (1, 3, 12, 12, (2, 2, 2)),    # dgrad-style full padding, to = 5 -> chunks of 3 + 2
+    (3, 6, 8, 8, (2, 2, 2)),      # to = 8 in chunks
+    (1, 3, 6, 6, (0, 0, 0)),      # to = 1: not covered by v3, served by the v2 kernel
+]
+
+
+@pytest.mark.parametrize("shape", V3_SHAPES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv3d_bf16_input_stationary_kernel(device, shape, relu):
+    """conv3d_fwd_bf16_v3_kernel (conv3d_bf16_v3.hip): every step kind of the time march (head, interior, tail for all
+    three accumulator phases), time chunking, ragged tiles; and its OUT_GATE epilogue = masking the plain result."""
+    K, _ = _mods()
+    b, t, h, w, pad = shape
+    x, wt, bias = _conv_case(11, b, 32, 32, t, h, w)
+    y_ref = F.conv3d(co.bf16_round(x), co.bf16_round(wt), bias, padding=pad)
+    if relu:
+        y_ref = F.relu(y_ref)
+    xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+    wp = K.conv3d_pack_weight_bf16(wt.to(device))
+    y = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False)
+    torch.testing.assert_close(y.float().cpu().permute(0, 4, 1, 2, 3), y_ref, rtol=1e-2, atol=2e-3)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(12)).to(device).to(torch.bfloat16)
+    g[0, 0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, float("inf"), float("-inf"), 1e-30, -1e-30]).to(g)
+    yg = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, out_gate=g)
+    assert torch.equal(yg, torch.where(g > 0, y, torch.zeros_like(y)))
+
+
 def test_repack_gate(device):
     K, _ = _mods()
     dy = torch.randn(2, 32, 3, 5, 6).to(torch.bfloat16)

@@ -1,0 +1,39 @@
+"""Times the 32 -> 32 channel bf16 Conv3D forward / dgrad-shaped launches (the kernels behind bench.py's roofline line)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from predict_pv_yield_amd import hip_ops as K
+
+b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev = torch.device("cuda:0")
+w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+bias = torch.randn(32, device=dev) * 0.1
+wp = K.conv3d_pack_weight_bf16(w)
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for (t, h) in [(17, 62), (15, 60), (13, 58)]:
+    x = torch.randn(b, t, h, h, 32, device=dev).to(torch.bfloat16)
+    ms = timeit(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False))
+    to, ho = t - 2, h - 2
+    fl = 2.0 * b * 32 * 32 * 27 * to * ho * ho
+    print(f"fwd   in {t}x{h}x{h}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s")
+    # dgrad shape: dy [to, ho, ho] padded by 2 -> dx [t, h, h], gated by the producer's input
+    dy = torch.randn(b, to, ho, ho, 32, device=dev).to(torch.bfloat16)
+    gate = torch.randn(b, t, h, h, 32, device=dev).to(torch.bfloat16)
+    ms = timeit(lambda: K.conv3d_fwd_bf16(dy, None, wp, None, 32, 32, (2, 2, 2), False, False, out_gate=gate))
+    fl = 2.0 * b * 32 * 32 * 27 * t * h * h
+    print(f"dgrad out {t}x{h}x{h}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (padded-tap flops)")
