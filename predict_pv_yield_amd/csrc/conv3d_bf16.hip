@@ -23,7 +23,6 @@
 // dgrad is the same kernel on dy (zero padding 2-p, ReLU gate applied while staging) with
 // channel-swapped, mirrored weights (pv_conv3d_pack_weight_bf16(..., transpose_flip = 1)).
 #include "pv_common.h"
-#include <stdlib.h>
 
 namespace pv {
 
@@ -351,35 +350,66 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_kernel(const float* _
   }
 }
 
+// A wave holds NCH 16-byte chunks per lane that belong to one contiguous output run of NCH * 1 KB (lane l owns bytes
+// [l * NCH * 16, (l + 1) * NCH * 16)).  Written straight from registers every store instruction would touch 64 different
+// cache lines; here the run goes through a wave-private LDS patch (XOR-swizzled rows: conflict-free both ways) and
+// leaves as NCH instructions of 1 KB each, lane-contiguous.  valid_bytes clips the tail of the tensor.
+template <int NCH>
+__device__ __forceinline__ void wave_store_run(unsigned char* patch, const u32x4 (&o)[NCH], unsigned char* gdst,
+                                               long long valid_bytes) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+    *reinterpret_cast<u32x4*>(patch + lane * (NCH * 16) + ((k ^ (lane & (NCH - 1))) << 4)) = o[k];
+  __builtin_amdgcn_wave_barrier();  // LDS executes a wave's instructions in order; this only pins the compiler's order
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int g = i * 64 + lane;  // linear chunk of the run
+    const int row = g / NCH, k = g % NCH;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * (NCH * 16) + ((k ^ (row & (NCH - 1))) << 4));
+    if ((long long)g * 16 < valid_bytes) *reinterpret_cast<u32x4*>(gdst + (size_t)g * 16) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // 4 consecutive voxels per thread: 16-byte plane reads, 4*CPAD*2 contiguous bytes written (vps % 4 == 0)
 template <int CPAD>
 __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float* __restrict__ x,
                                                                       uint16_t* __restrict__ xp, int c,
                                                                       long long vox_per_sample, long long total_quads) {
-  long long stride = (long long)gridDim.x * blockDim.x;
+  constexpr int NCH = 4 * CPAD * 2 / 16;  // 16-byte chunks per lane (4 voxels)
+  __shared__ __attribute__((aligned(16))) unsigned char patch[4][NCH * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long stride = (long long)gridDim.x * blockDim.x;
   const long long qps = vox_per_sample / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_quads; i += stride) {
-    long long bi = i / qps;
-    long long v = (i - bi * qps) * 4;
-    const float* src = x + (size_t)bi * c * vox_per_sample + v;
-    uint16_t h[4][CPAD];
+  for (long long base = (long long)blockIdx.x * blockDim.x + wave * 64; base < total_quads; base += stride) {
+    const long long i = base + lane;
+    u32x4 o[NCH];
 #pragma unroll
-    for (int k = 0; k < CPAD; ++k) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (k < c) a = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
+    for (int k = 0; k < NCH; ++k) o[k] = (u32x4){0u, 0u, 0u, 0u};
+    if (i < total_quads) {
+      const long long bi = i / qps;
+      const long long v = (i - bi * qps) * 4;
+      const float* src = x + (size_t)bi * c * vox_per_sample + v;
+      uint16_t h[4][CPAD];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) h[q][k] = f32_to_bf16_bits(a[q]);
-    }
-    u32x4* dst = reinterpret_cast<u32x4*>(xp + ((size_t)bi * vox_per_sample + v) * CPAD);
+      for (int k = 0; k < CPAD; ++k) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (k < c) a = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < CPAD / 8; ++k) {
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
-        dst[q * (CPAD / 8) + k] = o;
+        for (int q = 0; q < 4; ++q) h[q][k] = f32_to_bf16_bits(a[q]);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < CPAD / 8; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[q * (CPAD / 8) + k][e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
+    }
+    // quads are numbered through the whole [B][voxel] range, so the wave's 64 quads are one contiguous output run
+    wave_store_run<NCH>(patch[wave], o, reinterpret_cast<unsigned char*>(xp) + (size_t)base * (NCH * 16),
+                        (total_quads - base) * (NCH * 16));
   }
 }
 
@@ -505,35 +535,40 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
                                                                            const uint16_t* __restrict__ yv,
                                                                            uint16_t* __restrict__ out, int c,
                                                                            long long vox_per_sample, long long total_quads) {
-  long long stride = (long long)gridDim.x * blockDim.x;
+  __shared__ __attribute__((aligned(16))) unsigned char patch[4][16 * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long stride = (long long)gridDim.x * blockDim.x;
   const long long qps = vox_per_sample / 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_quads; i += stride) {
-    long long bi = i / qps;
-    long long v = (i - bi * qps) * 4;
-    const size_t base = (size_t)bi * c * vox_per_sample + v;
-    uint16_t h[4][32];
+  for (long long wbase = (long long)blockIdx.x * blockDim.x + wave * 64; wbase < total_quads; wbase += stride) {
+    const long long i = wbase + lane;
+    u32x4 o[16];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      u32x2 d = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
-      if (k < c) {
-        d = *reinterpret_cast<const u32x2*>(dy + base + (size_t)k * vox_per_sample);
-        if (yv) g = *reinterpret_cast<const u32x2*>(yv + base + (size_t)k * vox_per_sample);
+    for (int k = 0; k < 16; ++k) o[k] = (u32x4){0u, 0u, 0u, 0u};
+    if (i < total_quads) {
+      const long long bi = i / qps;
+      const long long v = (i - bi * qps) * 4;
+      const size_t base = (size_t)bi * c * vox_per_sample + v;
+      uint16_t h[4][32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        u32x2 d = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
+        if (k < c) {
+          d = *reinterpret_cast<const u32x2*>(dy + base + (size_t)k * vox_per_sample);
+          if (yv) g = *reinterpret_cast<const u32x2*>(yv + base + (size_t)k * vox_per_sample);
+        }
+        d[0] = gate_word(d[0], g[0]);
+        d[1] = gate_word(d[1], g[1]);
+        h[0][k] = (uint16_t)(d[0] & 0xffffu); h[1][k] = (uint16_t)(d[0] >> 16);
+        h[2][k] = (uint16_t)(d[1] & 0xffffu); h[3][k] = (uint16_t)(d[1] >> 16);
       }
-      d[0] = gate_word(d[0], g[0]);
-      d[1] = gate_word(d[1], g[1]);
-      h[0][k] = (uint16_t)(d[0] & 0xffffu); h[1][k] = (uint16_t)(d[0] >> 16);
-      h[2][k] = (uint16_t)(d[1] & 0xffffu); h[3][k] = (uint16_t)(d[1] >> 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[q * 4 + k][e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
     }
-    u32x4* dst = reinterpret_cast<u32x4*>(out + ((size_t)bi * vox_per_sample + v) * 32);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
-        dst[q * 4 + k] = o;
-      }
+    wave_store_run<16>(patch[wave], o, reinterpret_cast<unsigned char*>(out) + (size_t)wbase * 256, (total_quads - wbase) * 256);
   }
 }
 
@@ -677,11 +712,8 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
   if (cpad == 32 && !gate && !y_ncdhw) {  // 32 -> 32 channel layers, NDHWC out: two-waves-per-SIMD kernels
-    static const bool force_v2 = getenv("PV_CONV_V2") != nullptr;
-    if (!force_v2) {
-      const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, st);
-      if (rc != 1) return rc;
-    }
+    const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, st);
+    if (rc != 1) return rc;
     return launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, n_rowblk,
                                      n_colblk, n_tchunk, t_chunk, st);
   }

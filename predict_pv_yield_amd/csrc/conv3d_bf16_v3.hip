@@ -108,25 +108,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
 
   if (tid < 32) lds_bias[tid] = (bias && tid < c_out) ? bias[tid] : 0.f;
 
-  // ---- weights: tap planes kt = 0, 1 resident in registers (18 A fragments, 16 couts x 32 cin), kt = 2 in LDS ----
-  bf16x8 wfrag[18];
-#pragma unroll
-  for (int tap = 0; tap < 18; ++tap)
-    wfrag[tap] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)(tap * 2 + ch) * 64 + lane) * 8);
-  for (int i = tid; i < V3_W2B / 16; i += 256)
-    reinterpret_cast<u32x4*>(lds_w2)[i] = reinterpret_cast<const u32x4*>(wp2 + (size_t)18 * 2 * 64 * 8)[i];
-  const unsigned char* w2 = lds_w2 + ch * 1024 + lane * 16;
-
-  // ---- per-lane LDS read offsets of the B operand: voxel 16*half + vox + kw, 16-byte chunk kg ---------------------
-  int voff[3][2];
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int v = 16 * half + vox + kw;
-      voff[kw][half] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
-    }
-
   // ---- staging: global -> LDS direct.  A wave instruction fills 16 voxels x 64 B = 1 KB (lane -> voxel lane/4, chunk
   // position lane%4); a row of 34 voxels = 2 full instructions + one with lanes 0..7.  Wave w stages rows w, w+4, w+8.
   // The lane fetches the source chunk that the swizzle maps to its position (the swizzle has period 8 voxels, so the
@@ -164,6 +145,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
       }
     }
   };
+
+  load_slice(tc0);  // first: its HBM latency hides under the weight loads below
+
+  // ---- weights: tap planes kt = 0, 1 resident in registers (18 A fragments, 16 couts x 32 cin), kt = 2 in LDS ----
+  bf16x8 wfrag[18];
+#pragma unroll
+  for (int tap = 0; tap < 18; ++tap)
+    wfrag[tap] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)(tap * 2 + ch) * 64 + lane) * 8);
+  for (int i = tid; i < V3_W2B / 16; i += 256)
+    reinterpret_cast<u32x4*>(lds_w2)[i] = reinterpret_cast<const u32x4*>(wp2 + (size_t)18 * 2 * 64 * 8)[i];
+  const unsigned char* w2 = lds_w2 + ch * 1024 + lane * 16;
+
+  // ---- per-lane LDS read offsets of the B operand: voxel 16*half + vox + kw, 16-byte chunk kg ---------------------
+  int voff[3][2];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int v = 16 * half + vox + kw;
+      voff[kw][half] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
+    }
 
   // ---- write-out geometry: lane (vox, kg) of accumulator [orow][half] holds couts 16ch + 4kg .. +3 of voxel
   // (row h0 + 4wr + orow, column w0 + 16half + vox): 8 bytes ----------------------------------------------------
@@ -213,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   f32x4 acc[3][4][2];
 
   // ---- prologue ------------------------------------------------------------------------------------------------
-  load_slice(tc0);
   __syncthreads();  // lds_bias, lds_w2 written
   {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);

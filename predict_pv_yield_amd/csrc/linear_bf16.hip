@@ -486,6 +486,99 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_v2_kernel(const uint16
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3 forward for the fc1 shapes: the same k-tile march, but the tile ([128 weight rows + 32 x rows] x 128 k-columns,
+// 40 KB) goes global -> LDS directly (buffer_load_dwordx4 ... lds) into a 3-stage ring: two tiles (80 KB per CU) are
+// always in flight, no staging registers, no ds_write, one barrier per tile.  A wave instruction fills 1 KB = 4 rows x
+// 256 B; the LDS image of a row is rotated by its row number (16-byte chunk c of row r sits at position (c + r) & 15)
+// so the 16 rows an MFMA operand read touches fall into 16 different bank slots; the rotation is applied to the SOURCE
+// chunk each lane fetches, the LDS side of the instruction being linear by lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int V3_KC = 128, V3_ROWS = 160, V3_TILEB = V3_ROWS * 256, V3_STAGES = 3;
+
+__global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                                  float* __restrict__ partial, int m, int n, long long k,
+                                                                  int n_tiles, int tiles_per_wg) {
+  __shared__ __attribute__((aligned(1024))) unsigned char ring[V3_STAGES * V3_TILEB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int t0 = blockIdx.x * tiles_per_wg;
+  const int t1 = t0 + tiles_per_wg < n_tiles ? t0 + tiles_per_wg : n_tiles;
+  if (t0 >= t1) return;
+  constexpr uint32_t INVALID = 0xfffffff0u;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((size_t)n * k * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)m * k * 2), 0x00020000);
+  // staging role of this lane: row (lane >> 4) of a 4-row block, position lane & 15 -> source chunk (pos - row) & 15
+  const int srow = lane >> 4, spos = lane & 15;
+  auto load_tile = [&](int t) {
+    unsigned char* dst = ring + (t % V3_STAGES) * V3_TILEB;
+    const long long k0 = (long long)t * V3_KC;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#pragma unroll
+    for (int i = 0; i < V3_ROWS / 16; ++i) {
+      const int blk = wave + 4 * i;  // 4-row block 0..39: 0..31 weight rows, 32..39 x rows
+      const int row = 4 * blk + srow;
+      const int c = (spos - row) & 15;
+      const bool c_ok = k0 + c * 8 < k;
+      if (blk < 32) {
+        const uint32_t off = (c_ok && row < n) ? (uint32_t)(((size_t)row * k + k0 + c * 8) * 2) : INVALID;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(dst + blk * 1024), 16, off, 0, 0, 0);
+      } else {
+        const int xr = row - 128;
+        const uint32_t off = (c_ok && xr < m) ? (uint32_t)(((size_t)xr * k + k0 + c * 8) * 2) : INVALID;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + blk * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  // operand reads: x row r / weight row 32*wave + r, k-chunk 2*ks + hh, both rotated by r & 15
+  int pos[V3_KC / 16];
+#pragma unroll
+  for (int ks = 0; ks < V3_KC / 16; ++ks) pos[ks] = ((2 * ks + hh + r) & 15) * 16;
+  const int a_row = (128 + r) * 256, b_row = (wave * 32 + r) * 256;
+
+  load_tile(t0);
+  if (t0 + 1 < t1) load_tile(t0 + 1);
+  for (int t = t0; t < t1; ++t) {
+    // this wave issues 10 loads per tile, in order: all but the newest tile's have landed
+    if (t + 1 < t1) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();  // tile t complete for every wave; every wave is done with tile t-1 (whose stage tile t+2 reuses)
+    if (t + 2 < t1) load_tile(t + 2);
+    const unsigned char* tile = ring + (t % V3_STAGES) * V3_TILEB;
+    if (wave * 32 < n) {
+#pragma unroll
+      for (int ks = 0; ks < V3_KC / 16; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + a_row + pos[ks]);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(tile + b_row + pos[ks]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    }
+  }
+  const int col = wave * 32 + r;
+  if (col < n) {
+    float* dst = partial + (size_t)blockIdx.x * m * n + col;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
+      if (row < m) dst[(size_t)row * n] = acc[j];
+    }
+  }
+}
+
+static int v3_split(long long k, int* tiles_per_wg, int* n_tiles) {
+  const long long nt = (k + V3_KC - 1) / V3_KC;
+  long long nwg = nt < 256 ? nt : 256;  // one 120 KB ring per CU
+  const long long per = (nt + nwg - 1) / nwg;
+  nwg = (nt + per - 1) / per;
+  *tiles_per_wg = (int)per;
+  *n_tiles = (int)nt;
+  return (int)nwg;
+}
+
 static bool v2_shapes(int m, int n) { return m <= 32 && n <= 128 && n % 16 == 0 && n >= 32; }
 static int v2_split(long long k, int* tiles_per_wg, int* n_tiles) {
   const long long nt = (k + V2_KC - 1) / V2_KC;
@@ -533,10 +626,15 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
   float* part = (float*)workspace;
   if (v2_shapes(m, n)) {
     int tiles, n_tiles;
-    const int nwg2 = v2_split(k, &tiles, &n_tiles);
+    const bool fits32 = (size_t)n * k * 2 < 0xfffffff0ull;  // the v3 kernel's raw-buffer offsets are 32-bit
+    const int nwg2 = !fits32 ? v2_split(k, &tiles, &n_tiles) : v3_split(k, &tiles, &n_tiles);
     PV_REQUIRE(workspace_bytes >= (size_t)nwg2 * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
-    hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
-                       n_tiles, tiles);
+    if (!fits32)
+      hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
+                         n_tiles, tiles);
+    else
+      hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
+                         n_tiles, tiles);
     hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
                        bias, y, m, n, nwg2, relu ? 1 : 0);
     return check_launch("pv_linear_fwd_bf16");

@@ -187,8 +187,10 @@ def test_fake_dataset_and_datamodule_contract():
     dm = NetCDFDataModule(fake_data=True, data_path=os.path.join(ROOT, "tests/configs/dataset"), n_train_data=3, n_val_data=2)
     assert dm.configuration.satellite_image_size_pixels == 16 and dm.configuration.batch_size == 4
     assert len(list(dm.train_dataloader())) == 3 and len(list(dm.val_dataloader())) == 2
-    with pytest.raises(NotImplementedError):
-        NetCDFDataModule(fake_data=False)
+    # fake_data=False reads whole-batch files from <data_path>/train|test and fails loudly when they are missing
+    real = NetCDFDataModule(fake_data=False, data_path=os.path.join(ROOT, "tests/configs/dataset"), n_train_data=1)
+    with pytest.raises(FileNotFoundError):
+        next(iter(real.train_dataloader()))
 
 
 def test_baseline_model_forward_is_persistence():
