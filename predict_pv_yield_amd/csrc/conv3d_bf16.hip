@@ -579,7 +579,7 @@ int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const floa
 // input-stationary variant (conv3d_bf16_v3.hip, its own 8 x 32 tiling); 1 = shape not covered
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              hipStream_t st);
+                              int y_ncdhw, hipStream_t st);
 void launch_pack_weight_v2(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
 constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
 
@@ -711,9 +711,12 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
-  if (cpad == 32 && !gate && !y_ncdhw) {  // 32 -> 32 channel layers, NDHWC out: two-waves-per-SIMD kernels
-    const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, st);
+  if (cpad == 32 && !gate) {  // 32 -> 32 channel layers: two-waves-per-SIMD kernels
+    const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu,
+                                             y_ncdhw, st);
     if (rc != 1) return rc;
+  }
+  if (cpad == 32 && !gate && !y_ncdhw) {
     return launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, n_rowblk,
                                      n_colblk, n_tchunk, t_chunk, st);
   }

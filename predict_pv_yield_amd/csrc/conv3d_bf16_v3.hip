@@ -28,6 +28,8 @@ constexpr int V3_TR = 8, V3_TRI = 10, V3_TW = 34, V3_TW_VALID = 32;  // input ro
 constexpr int V3_VOXB = 64, V3_ROWB = V3_TW * V3_VOXB, V3_SLOTB = V3_TRI * V3_ROWB;
 constexpr int V3_W2B = 9 * 2 * 64 * 16;  // tap plane kt = 2: [9 taps][2 cout halves][64 lanes] x 16 B
 constexpr uint32_t V3_INVALID = 0x40000000u;
+constexpr int V3_PATCH_CS = 4 * 64 + 16;        // NCDHW epilogue patch: bytes per cout ([4 rows][32 voxels] bf16 + pad)
+constexpr int V3_PATCHB = 16 * V3_PATCH_CS;     // per wave: 16 couts
 
 // ReLU-derivative gate of a bf16 pair: 2 bits (low half > 0, high half > 0); and its application to a bf16 pair
 __device__ __forceinline__ uint32_t v3_gate_bits(uint32_t g) {
@@ -80,15 +82,19 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
   }
 }
 
-template <bool OUT_GATE>
+// Y_NCDHW (the last conv layer, whose output fc1 consumes in the reference's flatten order): the finished tile is
+// transposed through a wave-private LDS patch ([cout][row][voxel]) and leaves as 16-byte pieces of a (cout, row) line
+// (w_out % 8 == 0, checked by the launcher).
+template <bool OUT_GATE, bool Y_NCDHW>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
     int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out) {
   // ring of 2 slices | kt = 2 weight plane | 32 bias floats   (78 KB: two workgroups per CU)
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * V3_SLOTB + V3_W2B + 128];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? 4 * V3_PATCHB : 0)];
   unsigned char* lds_w2 = lds + 2 * V3_SLOTB;
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
+  static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -190,13 +196,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   u32x2 pend[4][2];  // finished tile (bf16 pairs), stored one step later so the stores never sit in front of a wait
   u32x2 og[OUT_GATE ? 4 : 1][2];
   uint32_t gbits = 0u;  // the tile's gate, 4 bits per (row, half): the 16 gate registers live only through the kw = 0 phase
+  // NCDHW: lane -> 16-byte piece (lane & 3) of line (cout 4i + lane/16, row (lane/4) & 3) for store instruction i
+  unsigned char* patch = lds + 2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? (tid >> 6) * V3_PATCHB : 0);
+  const int n_orow = (lane >> 2) & 3, n_piece = lane & 3, n_co = lane >> 4;
+  const size_t cstride = (size_t)t_out * plane_out;
+  const bool n_ok = (h0 + 4 * wr + n_orow) < h_out && (w0 + n_piece * 8) < w_out;
+  const size_t n_base = ((size_t)b * c_out + 16 * ch + n_co) * cstride + (size_t)(h0 + 4 * wr + n_orow) * w_out + w0 + n_piece * 8;
   auto store_pending = [&](int o) {
+    if constexpr (Y_NCDHW) {
 #pragma unroll
-    for (int orow = 0; orow < 4; ++orow) {
-      const uint32_t ro = row_off(o, orow);
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + (4 * i + n_co) * V3_PATCH_CS + n_orow * 64 + n_piece * 16);
+        if (n_ok && 16 * ch + 4 * i + n_co < c_out)
+          *reinterpret_cast<u32x4*>(y + n_base + (size_t)(4 * i) * cstride + (size_t)o * plane_out) = v;
+      }
+    } else {
 #pragma unroll
-      for (int half = 0; half < 2; ++half)
-        __builtin_amdgcn_raw_buffer_store_b64(pend[orow][half], yrsrc, st_off[half] + ro, 0, 0);
+      for (int orow = 0; orow < 4; ++orow) {
+        const uint32_t ro = row_off(o, orow);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          __builtin_amdgcn_raw_buffer_store_b64(pend[orow][half], yrsrc, st_off[half] + ro, 0, 0);
+      }
     }
   };
   auto load_gate = [&](int o) {
@@ -261,7 +282,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
           o[0] = v3_apply_gate(o[0], gbits >> (4 * (2 * orow + half)));                                           \
           o[1] = v3_apply_gate(o[1], gbits >> (4 * (2 * orow + half) + 2));                                       \
         }                                                                                                         \
-        pend[orow][half] = o;                                                                                     \
+        if constexpr (Y_NCDHW) {                                                                                  \
+          unsigned char* pp = patch + (4 * kg) * V3_PATCH_CS + orow * 64 + (16 * half + vox) * 2;                   \
+          *reinterpret_cast<uint16_t*>(pp) = (uint16_t)o[0];                                                      \
+          *reinterpret_cast<uint16_t*>(pp + V3_PATCH_CS) = (uint16_t)(o[0] >> 16);                                \
+          *reinterpret_cast<uint16_t*>(pp + 2 * V3_PATCH_CS) = (uint16_t)o[1];                                    \
+          *reinterpret_cast<uint16_t*>(pp + 3 * V3_PATCH_CS) = (uint16_t)(o[1] >> 16);                            \
+        } else {                                                                                                  \
+          pend[orow][half] = o;                                                                                   \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -305,8 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
 // to the v2 kernel.
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              hipStream_t st) {
+                              int y_ncdhw, hipStream_t st) {
   if (to < 2) return 1;
+  if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
   const int n_rowblk = (ho + V3_TR - 1) / V3_TR;
   const int n_colblk = (wo + V3_TW_VALID - 1) / V3_TW_VALID;
   // two workgroups per CU: split the time march only when the (sample, tile) grid alone cannot fill 512 slots
@@ -322,12 +352,13 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
     if (to - (n_tchunk - 1) * t_chunk < 2) return 1;
   }
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
-  if (out_gate)
-    hipLaunchKernelGGL(conv3d_fwd_bf16_v3_kernel<true>, grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in, d->h_in,
-                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out);
-  else
-    hipLaunchKernelGGL(conv3d_fwd_bf16_v3_kernel<false>, grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in, d->h_in,
-                       d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out);
+#define PV_LAUNCH_V3(OG, YN)                                                                                          \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in,     \
+                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out)
+  if (y_ncdhw) PV_LAUNCH_V3(false, true);
+  else if (out_gate) PV_LAUNCH_V3(true, false);
+  else PV_LAUNCH_V3(false, false);
+#undef PV_LAUNCH_V3
   return check_launch("pv_conv3d_fwd_bf16(v3)");
 }
 

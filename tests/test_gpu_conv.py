@@ -141,6 +141,8 @@ V3_SHAPES = [
     (1, 3, 12, 12, (2, 2, 2)),    # dgrad-style full padding, to = 5 -> chunks of 3 + 2
     (3, 6, 8, 8, (2, 2, 2)),      # to = 8 in chunks
     (1, 3, 6, 6, (0, 0, 0)),      # to = 1: not covered by v3, served by the v2 kernel
+    (2, 5, 12, 18, (0, 0, 0)),    # w_out = 16: the NCDHW epilogue of v3 (16-byte pieces of an output line)
+    (1, 6, 9, 42, (0, 0, 0)),     # w_out = 40: NCDHW epilogue with a ragged second column block, ragged rows
 ]
 
 
@@ -163,6 +165,12 @@ def test_conv3d_bf16_input_stationary_kernel(device, shape, relu):
     g[0, 0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, float("inf"), float("-inf"), 1e-30, -1e-30]).to(g)
     yg = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, out_gate=g)
     assert torch.equal(yg, torch.where(g > 0, y, torch.zeros_like(y)))
+    # NCDHW epilogue (what fc1 consumes): same kernel and accumulation order when w_out % 8 == 0 -> bit-identical
+    yn = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=True)
+    if y.shape[3] % 8 == 0 and y.shape[1] >= 2:
+        assert torch.equal(yn, y.permute(0, 4, 1, 2, 3))
+    else:
+        torch.testing.assert_close(yn.float(), y.permute(0, 4, 1, 2, 3).float(), rtol=1e-2, atol=2e-3)
 
 
 def test_repack_gate(device):
