@@ -235,54 +235,84 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
   __syncthreads();
   const long long k8 = ((long long)kblock * blockDim.x + threadIdx.x) * 8;
   if (k8 >= k) return;
-  float acc[BT][8];
+  // the 32 x (BT x 8) FMAs per thread run as packed f32 (v_pk_fma_f32, the gradient value broadcast to both halves):
+  // as plain v_fma_f32 they cost ~125 us of SIMD time per pass over the matrix, a fifth of this HBM-bound kernel
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[BT][4];
 #pragma unroll
   for (int i = 0; i < BT; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
 #pragma unroll 4
   for (int rr = 0; rr < m; ++rr) {
     u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)rr * k + k8);
-    float xv[8];
+    f32x2_t xv2[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      xv[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
-      xv[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
-    }
+    for (int q = 0; q < 4; ++q)
+      xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
     f32x4 gq[BT / 4];
 #pragma unroll
     for (int q = 0; q < BT / 4; ++q) gq[q] = *reinterpret_cast<const f32x4*>(g + rr * BT + 4 * q);
 #pragma unroll
     for (int i = 0; i < BT; ++i) {
       const float gv = gq[i >> 2][i & 3];
+      const f32x2_t g2 = {gv, gv};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = fmaf(gv, xv[j], acc[i][j]);
+      for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
     }
   }
+  float acc[BT][8];
 #pragma unroll
-  for (int i = 0; i < BT; ++i) {
-    if (n0 + i < n) {
-      const size_t off = (size_t)(n0 + i) * k + k8;
-      if constexpr (MODE == 0) {
-        f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-        f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
-        *reinterpret_cast<f32x4*>(dw + off) = o0;
-        *reinterpret_cast<f32x4*>(dw + off + 4) = o1;
-      } else if constexpr (MODE == 2) {
-        u32x4 o;
+  for (int i = 0; i < BT; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dw) + off) = o;
-      } else {
-        // dw here is the PARAMETER (updated in place); same operation order as adam_step_f32 / torch
-        float pv[8], mv[8], vv[8];
-        *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(dw + off);
-        *reinterpret_cast<f32x4*>(pv + 4) = *reinterpret_cast<const f32x4*>(dw + off + 4);
-        *reinterpret_cast<f32x4*>(mv) = *reinterpret_cast<const f32x4*>(exp_avg + off);
-        *reinterpret_cast<f32x4*>(mv + 4) = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
-        *reinterpret_cast<f32x4*>(vv) = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
-        *reinterpret_cast<f32x4*>(vv + 4) = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+    for (int j = 0; j < 4; ++j) acc[i][2 * j] = acc2[i][j][0], acc[i][2 * j + 1] = acc2[i][j][1];
+  if constexpr (MODE != 1) {
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      if (n0 + i < n) {
+        const size_t off = (size_t)(n0 + i) * k + k8;
+        if constexpr (MODE == 0) {
+          f32x4 o0 = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+          f32x4 o1 = {acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+          *reinterpret_cast<f32x4*>(dw + off) = o0;
+          *reinterpret_cast<f32x4*>(dw + off + 4) = o1;
+        } else {
+          u32x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dw) + off) = o;
+        }
+      }
+    }
+  } else {
+    // dw here is the PARAMETER (updated in place); same operation order as adam_step_f32 / torch.  The correctly rounded
+    // sqrt and the two divisions expand to ~40 VALU instructions per element (a few thousand cycles per row of the
+    // tile), so the NEXT row's p / m / v are fetched before the current row's arithmetic: without that a wave has its
+    // 6 loads in flight only between rows and the HBM pipe drains while it computes.
+    f32x4 nxt[6];
+    auto fetch = [&](int i) {
+      const size_t off = (size_t)min(n0 + i, n - 1) * k + k8;
+      nxt[0] = *reinterpret_cast<const f32x4*>(dw + off);
+      nxt[1] = *reinterpret_cast<const f32x4*>(dw + off + 4);
+      nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + off);
+      nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
+      nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
+      nxt[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+    };
+    fetch(0);
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      float pv[8], mv[8], vv[8];
+      *reinterpret_cast<f32x4*>(pv) = nxt[0];
+      *reinterpret_cast<f32x4*>(pv + 4) = nxt[1];
+      *reinterpret_cast<f32x4*>(mv) = nxt[2];
+      *reinterpret_cast<f32x4*>(mv + 4) = nxt[3];
+      *reinterpret_cast<f32x4*>(vv) = nxt[4];
+      *reinterpret_cast<f32x4*>(vv + 4) = nxt[5];
+      if (i + 1 < BT) fetch(i + 1);
+      if (n0 + i < n) {
+        const size_t off = (size_t)(n0 + i) * k + k8;
         uint32_t sh[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -415,8 +445,21 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v2_kernel(const uint16_t*
 // Wave w owns the KC/4 columns [w*KC/4, (w+1)*KC/4) of the tile (KC/128 column tiles of 32).
 __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_v2_kernel(const uint16_t* __restrict__ w, const float* __restrict__ dy,
                                                                      const float* __restrict__ ymask, uint16_t* __restrict__ dx,
-                                                                     int m, int n, long long k, int n_tiles, int tiles_per_wg) {
+                                                                     int m, int n, long long k, int n_tiles, int tiles_per_wg,
+                                                                     float* __restrict__ db) {
   __shared__ __attribute__((aligned(16))) unsigned char wt[128 * V2_WS];
+  // the bias gradient (column sums of the gated dy, rows added in index order like linear_bwd_db_bf16path) rides along
+  // in workgroup 0: one launch less on a path where every launch costs ~5 us
+  if (db && blockIdx.x == 0 && (int)threadIdx.x < n) {
+    float sb = 0.f;
+    for (int rr = 0; rr < m; ++rr) {
+      const size_t off = (size_t)rr * n + threadIdx.x;
+      float v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+      sb += v;
+    }
+    db[threadIdx.x] = sb;
+  }
   constexpr int CPW = V2_KC / 4;   // columns per wave
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -665,7 +708,8 @@ int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, co
       int tiles, n_tiles;
       const int nwg2 = v2_split(k, &tiles, &n_tiles);
       hipLaunchKernelGGL(linear_bwd_dx_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, w, dy, y_relu_mask, dx, m, n,
-                         (long long)k, n_tiles, tiles);
+                         (long long)k, n_tiles, tiles, db);
+      db = nullptr;  // done by the dx kernel
     } else {
     size_t lds = (size_t)n * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: n=%d too large", n);

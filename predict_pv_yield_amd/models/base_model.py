@@ -60,8 +60,7 @@ class BaseModel(LightningModule):
         if y_hat.is_cuda:
             from ..functional import forecast_losses
             y = y.float()
-            out4 = forecast_losses(y_hat.float(), y)
-            return out4[0], out4[1], out4[2], out4[3]
+            return forecast_losses(y_hat.float(), y)
         raise RuntimeError("predict_pv_yield_amd: losses run on the MI355X only (no CPU path); model is on "
                            f"{y_hat.device}")
 

@@ -236,8 +236,9 @@ def test_forecast_losses(device):
     yd = y_hat.detach().to(device).requires_grad_(True)
     out4 = Fn.forecast_losses(yd, co.select_target(yield_t.to(device), 6))  # strided view, no copy
     out4[1].backward()
+    assert not out4[0].requires_grad and not out4[2].requires_grad and not out4[3].requires_grad
     ref = torch.stack([mse, nmae, mse_exp, mae_exp]).detach()
-    torch.testing.assert_close(out4.detach().cpu(), ref, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(torch.stack(out4).detach().cpu(), ref, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(yd.grad.cpu(), y_hat.grad, rtol=1e-6, atol=0)
 
 
