@@ -97,7 +97,7 @@ def measure_conv_roofline(batch, hist_frames, dev):
             "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v10.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v11.json")
 
 
 def committed_hbm_traffic(cpad: int, batch: int):
