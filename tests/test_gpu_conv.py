@@ -173,6 +173,34 @@ def test_conv3d_bf16_input_stationary_kernel(device, shape, relu):
         torch.testing.assert_close(yn.float(), y.permute(0, 4, 1, 2, 3).float(), rtol=1e-2, atol=2e-3)
 
 
+def test_conv3d_bf16_random_shapes(device):
+    """Seeded sweep over ragged shapes / paddings / batch sizes of the 32 -> 32 bf16 forward (all three epilogues): the
+    time-chunking, head / tail phases and tile clipping of the marching kernels depend on every one of these numbers."""
+    K, _ = _mods()
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        b = int(rng.integers(1, 4))
+        pad = tuple(int(v) for v in rng.integers(0, 3, size=3))
+        t = int(rng.integers(max(1, 3 - 2 * pad[0]), 9))
+        h = int(rng.integers(max(1, 3 - 2 * pad[1]), 21))
+        w = int(rng.integers(max(1, 3 - 2 * pad[2]), 71))
+        relu = bool(rng.integers(0, 2))
+        x, wt, bias = _conv_case(100 + it, b, 32, 32, t, h, w)
+        y_ref = F.conv3d(co.bf16_round(x), co.bf16_round(wt), bias, padding=pad)
+        if relu:
+            y_ref = F.relu(y_ref)
+        xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+        wp = K.conv3d_pack_weight_bf16(wt.to(device))
+        y = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False)
+        msg = f"shape #{it}: b={b} t={t} h={h} w={w} pad={pad} relu={relu}"
+        torch.testing.assert_close(y.float().cpu().permute(0, 4, 1, 2, 3), y_ref, rtol=1e-2, atol=2e-3, msg=msg)
+        yn = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=True)
+        torch.testing.assert_close(yn.float().cpu(), y_ref, rtol=1e-2, atol=2e-3, msg=msg + " (NCDHW)")
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(it)).to(device).to(torch.bfloat16)
+        yg = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, out_gate=g)
+        assert torch.equal(yg, torch.where(g > 0, y, torch.zeros_like(y))), msg + " (out_gate)"
+
+
 def test_repack_gate(device):
     K, _ = _mods()
     dy = torch.randn(2, 32, 3, 5, 6).to(torch.bfloat16)
