@@ -249,6 +249,13 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
                        const float* bias, uint16_t* y, const uint16_t* out_gate,
                        const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream);
 
+/* First-layer form: x is the reference's own input tensor, f32 NCDHW [B, c_in, T, H, W] (sat_data of
+ * predict_pv_yield/models/conv3d/model.py:112-117), c_in <= 16.  Same result as pv_pack_ncdhw_f32_to_ndhwc_bf16 followed
+ * by pv_conv3d_fwd_bf16 (NDHWC output), in one pass over the input: the staging rounds to bf16 on the way into LDS.
+ * xp_out (may be NULL): receives the NDHWC bf16 [B,T,H,W,16] image of x that pv_conv3d_bwd_weight_bf16 consumes. */
+int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
+                             const pv_conv3d_dims* d, int relu, void* stream);
+
 /* dw[Co,Ci,3,3,3] f32 and dbias[Co] f32 from x (NDHWC bf16) and dy ⊙ (y>0) (NDHWC bf16).
  * workspace: pv_conv3d_bwd_weight_bf16_workspace_bytes(d). Overwrites dw/dbias. */
 int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* bytes);

@@ -50,12 +50,16 @@ struct SliceGeom {
   __device__ static __forceinline__ int swz(int v) { return (v / VPR) % NCH; }
 };
 
-template <int CPAD, bool HAS_GATE, bool Y_NCDHW, bool OUT_GATE>
+// X_F32 (first layer only, pad_w == 0): x is the reference's f32 NCDHW tensor [B, c_in_real, T, H, W]; the staging
+// fetches 4 consecutive voxels of each of a chunk's 8 channel planes with one dwordx4 load, rounds to bf16 on the way
+// into LDS and -- for the voxels this workgroup owns -- also writes the NDHWC bf16 image the weight-gradient kernel
+// will read (xp_out).  That replaces the separate pack pass over the input (read 104 MB + write 75 MB + read 75 MB at B = 32).
+template <int CPAD, bool HAS_GATE, bool Y_NCDHW, bool OUT_GATE, bool X_F32 = false>
 __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate, const uint16_t* __restrict__ wp,
     const float* __restrict__ bias, uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
     int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk,
-    int t_chunk, int c_out) {
+    int t_chunk, int c_out, int c_in_real = 0, uint16_t* __restrict__ xp_out = nullptr) {
   using G = SliceGeom<CPAD>;
   constexpr int KS = CPAD / 16;
   // ring of 3 slices | 256 B of zeros (tap reads of masked columns run 2 voxels past a slot) | 32 bias floats
@@ -118,40 +122,106 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   const uint32_t x_plane_b = (uint32_t)h_in * w_in * CPAD * 2u;                  // bytes per (b, t) slice
   const uint32_t x_row_b = (uint32_t)w_in * CPAD * 2u;
   const size_t sample_elems = (size_t)t_in * h_in * w_in * CPAD;
+  const size_t f32_sample_b = (size_t)c_in_real * t_in * h_in * w_in * 4;       // X_F32: bytes of one NCDHW sample
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
+      X_F32 ? __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(x) + (size_t)b * f32_sample_b),
+                                                0, (int)f32_sample_b, 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((HAS_GATE ? gate : x) + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
   const uint32_t lane_voff = scol_ok ? (uint32_t)(swi * CPAD + sc * 8) * 2u : INVALID;
+  // X_F32 staging tasks: (tile row 0..9) x (chunk half sc) x (quad of 4 consecutive voxels) = 320 tasks, thread t takes
+  // tasks t and 256 + t (wave 0 only).  A task = 8 dwordx4 loads (8 channel planes x 4 voxels, pad_w == 0) -> 4 chunks.
+  const uint32_t f_plane_b = (uint32_t)t_in * h_in * w_in * 4u, f_slice_b = (uint32_t)h_in * w_in * 4u, f_row_b = (uint32_t)w_in * 4u;
+  constexpr int F_PASS = 2;
+  int f_row[F_PASS], f_sc[F_PASS], f_col[F_PASS];
+  if constexpr (X_F32) {
+#pragma unroll
+    for (int i = 0; i < F_PASS; ++i) {
+      const int t = i * 256 + tid;
+      f_row[i] = t >> 5;          // >= TRI: no task
+      f_sc[i] = (t >> 4) & 1;
+      f_col[i] = 4 * (t & 15);    // first tile column of the quad
+    }
+  }
+  const bool own_last_row = (h0 + TR >= h_out), own_last_col = (w0 + TW_VALID >= w_out), own_last_t = (tc1 >= t_out);
 
-  u32x4 stage[G::NLOAD];
+  u32x4 stage[X_F32 ? 1 : G::NLOAD];
+  f32x4 stage_f[X_F32 ? F_PASS : 1][8];
   u32x4 stage_g[HAS_GATE ? G::NLOAD : 1];
   auto load_slice = [&](int s) {
     // slice index s = input time + pad_t  (s in [tc0, tc1 + 2))
     const int ti = s - pad_t;
     const bool t_ok = (unsigned)ti < (unsigned)t_in;
-    const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
+    if constexpr (X_F32) {
+      const uint32_t toff = t_ok ? (uint32_t)ti * f_slice_b : INVALID;
 #pragma unroll
-    for (int i = 0; i < G::NLOAD; ++i) {
-      const int hi = h0 - pad_h + i * RPI + srow0;
-      const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;                 // scalar
-      const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : INVALID);
-      const uint32_t voff = lane_voff + srow;                                    // < 2^32, >= 2^30 if anything is invalid
-      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
-      if constexpr (HAS_GATE) stage_g[i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, voff, 0, 0);
+      for (int i = 0; i < F_PASS; ++i) {
+        if (i == 0 || wave == 0) {   // the second pass holds tasks 256..319 only
+          const int hi = h0 - pad_h + f_row[i];
+          const bool ok = f_row[i] < TRI && (unsigned)hi < (unsigned)h_in;
+          const uint32_t base = ok ? toff + (uint32_t)hi * f_row_b + (uint32_t)(w0 + f_col[i]) * 4u : INVALID;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ch = f_sc[i] * 8 + j;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ch < c_in_real ? base + (uint32_t)ch * f_plane_b : INVALID, 0, 0);
+            stage_f[i][j] = __builtin_bit_cast(f32x4, v);
+          }
+        }
+      }
+    } else {
+      const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
+#pragma unroll
+      for (int i = 0; i < G::NLOAD; ++i) {
+        const int hi = h0 - pad_h + i * RPI + srow0;
+        const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;                 // scalar
+        const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : INVALID);
+        const uint32_t voff = lane_voff + srow;                                    // < 2^32, >= 2^30 if anything is invalid
+        stage[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+        if constexpr (HAS_GATE) stage_g[i] = __builtin_amdgcn_raw_buffer_load_b128(grsrc, voff, 0, 0);
+      }
     }
   };
   auto store_slice = [&](int s) {
-    unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES + srow0 * G::ROW_BYTES + lds_lane;
+    if constexpr (X_F32) {
+      // the NDHWC bf16 image for the weight gradient: every input voxel is written by exactly one workgroup (the tile
+      // it belongs to as an OUTPUT position; the last row / column block and time chunk also own the 2-voxel rim)
+      const int ti = s - pad_t;
+      const bool t_own = xp_out && (unsigned)ti < (unsigned)t_in && (s < tc1 || own_last_t);
+      unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
 #pragma unroll
-    for (int i = 0; i < G::NLOAD; ++i) {
-      u32x4 v = stage[i];
-      if constexpr (HAS_GATE) {  // ReLU gate of dgrad, applied only now (after the loads have landed)
-        const u32x4 g = stage_g[i];
-        v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
-        v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
+      for (int i = 0; i < F_PASS; ++i) {
+        if ((i == 0 || wave == 0) && f_row[i] < TRI) {
+          const int hi = h0 - pad_h + f_row[i];
+          const bool row_own = t_own && (unsigned)hi < (unsigned)h_in && (f_row[i] < TR || own_last_row);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int scol = f_col[i] + q, swi = w0 + scol;
+            const bool col_ok = swi < w_in;   // a quad may straddle the right image edge: those voxels are zero
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = col_ok ? stage_f[i][2 * e][q] : 0.f, hi2 = col_ok ? stage_f[i][2 * e + 1][q] : 0.f;
+              v[e] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi2) << 16);
+            }
+            *reinterpret_cast<u32x4*>(slot + f_row[i] * G::ROW_BYTES + scol * G::VOX_BYTES + ((f_sc[i] ^ G::swz(scol)) << 4)) = v;
+            if (row_own && col_ok && (scol < TW_VALID || own_last_col))
+              *reinterpret_cast<u32x4*>(xp_out + ((((size_t)b * t_in + ti) * h_in + hi) * w_in + swi) * CPAD + f_sc[i] * 8) = v;
+          }
+        }
       }
-      *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = v;
+    } else {
+      unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES + srow0 * G::ROW_BYTES + lds_lane;
+#pragma unroll
+      for (int i = 0; i < G::NLOAD; ++i) {
+        u32x4 v = stage[i];
+        if constexpr (HAS_GATE) {  // ReLU gate of dgrad, applied only now (after the loads have landed)
+          const u32x4 g = stage_g[i];
+          v[0] = gate_word(v[0], g[0]); v[1] = gate_word(v[1], g[1]);
+          v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
+        }
+        *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = v;
+      }
     }
   };
 
@@ -738,6 +808,41 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
 #undef PV_LAUNCH_CONV2
 #undef PV_LAUNCH_CONV
   return check_launch("pv_conv3d_fwd_bf16");
+}
+
+int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
+                             const pv_conv3d_dims* d, int relu, void* stream) {
+  PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_bf16_f32in: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 16 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_fwd_bf16_f32in: channels (%d -> %d) must be in 1..16 -> 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_fwd_bf16_f32in: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_bf16_f32in: input smaller than the kernel");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_fwd_bf16_f32in: batch too large for grid.z");
+  PV_REQUIRE((size_t)d->c_in * d->t_in * d->h_in * d->w_in * 4 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_fwd_bf16_f32in: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
+  PV_REQUIRE(((uintptr_t)x % 4 == 0) && (!xp_out || (uintptr_t)xp_out % 16 == 0), PV_EINVAL,
+             "pv_conv3d_fwd_bf16_f32in: unaligned operand");
+  PV_REQUIRE(d->pad_w == 0, PV_EINVAL, "pv_conv3d_fwd_bf16_f32in: built for pad_w == 0 (quads of voxels start inside the image)");
+  const int n_rowblk = (ho + TR - 1) / TR;
+  const int n_colblk = (wo + TW_VALID - 1) / TW_VALID;
+  long long tiles = (long long)d->batch * n_rowblk * n_colblk;
+  int n_tchunk = 1;
+  if (tiles < 256) {
+    n_tchunk = (int)((256 + tiles - 1) / tiles);
+    int max_chunks = (to + 1) / 2;
+    if (max_chunks < 1) max_chunks = 1;
+    if (n_tchunk > max_chunks) n_tchunk = max_chunks;
+  }
+  const int t_chunk = (to + n_tchunk - 1) / n_tchunk;
+  n_tchunk = (to + t_chunk - 1) / t_chunk;
+  dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
+  hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<16, false, false, false, true>), grid, dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint16_t*>(x), (const uint16_t*)nullptr, wp, bias, y, (const uint16_t*)nullptr,
+                     d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk,
+                     d->c_out, d->c_in, xp_out);
+  return check_launch("pv_conv3d_fwd_bf16_f32in");
 }
 
 }  // extern "C"

@@ -148,6 +148,35 @@ class Conv3dReLUBF16(torch.autograd.Function):
         return dx, dw, (db if has_bias else None), None, None, None, None, None, None
 
 
+class Conv3dFirstLayerBF16(torch.autograd.Function):
+    """First conv layer straight from the reference's f32 NCDHW input (<= 16 channels): y bf16 NDHWC, and -- when a
+    weight gradient will be wanted -- the NDHWC bf16 image of the input as a by-product of the same pass (no separate
+    pack kernel).  Bit-identical to PackInputBF16 + Conv3dReLUBF16."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding, relu, dy_pregated):
+        wp = packed_conv_weight(weight, False)
+        c_out, c_in = weight.shape[0], weight.shape[1]
+        need_bwd = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]   # grad mode is off inside forward()
+        y, xp = K.conv3d_fwd_bf16_f32in(x.contiguous(), wp, bias.contiguous() if bias is not None else None, c_out, padding,
+                                        relu, want_packed=need_bwd)
+        ctx.save_for_backward(xp, weight, y if relu else None)
+        ctx.cfg = (c_in, c_out, padding, bias is not None, dy_pregated)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight, y = ctx.saved_tensors
+        c_in, c_out, padding, has_bias, dy_pregated = ctx.cfg
+        gate = None if dy_pregated else y
+        dw, db = K.conv3d_bwd_weight_bf16(xp, dy.contiguous(), gate, c_in, c_out, padding)
+        return None, dw, (db if has_bias else None), None, None, None
+
+
+def conv3d_first_layer_bf16(x, weight, bias, padding=(0, 0, 0), relu=True, dy_pregated=False):
+    return Conv3dFirstLayerBF16.apply(x, weight, bias, tuple(padding), relu, dy_pregated)
+
+
 def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
     """bf16 copy of a big f32 parameter, kept current by HipAdam (pv_adam_step_f32 writes it)."""
     work = getattr(weight, "_pv_shadow_work", None)

@@ -279,6 +279,25 @@ def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Ten
     return y
 
 
+def conv3d_fwd_bf16_f32in(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_out: int, padding=(0, 0, 0),
+                          relu=True, want_packed=True):
+    """First layer: x f32 NCDHW [B,C<=16,T,H,W] -> (y bf16 NDHWC [B,To,Ho,Wo,32], xp bf16 NDHWC [B,T,H,W,16] or None).
+    One pass over the input instead of pack + conv; xp is what conv3d_bwd_weight_bf16 reads."""
+    require_cuda(x, wp, bias)
+    if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
+        raise TypeError("conv3d_fwd_bf16_f32in: x must be a contiguous f32 [B,C,T,H,W] tensor")
+    b, c_in, t, h, w = x.shape
+    if bf16_cpad(c_in) != 16:
+        raise TypeError("conv3d_fwd_bf16_f32in: built for c_in <= 16")
+    d = conv_dims(b, c_in, c_out, t, h, w, padding)
+    to, ho, wo = d.out_shape()
+    y = torch.empty((b, to, ho, wo, 32), dtype=torch.bfloat16, device=x.device)
+    xp = torch.empty((b, t, h, w, 16), dtype=torch.bfloat16, device=x.device) if want_packed else None
+    check(get_lib().pv_conv3d_fwd_bf16_f32in(ptr(x), ptr(xp), ptr(wp), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
+                                             current_stream_ptr()), "pv_conv3d_fwd_bf16_f32in")
+    return y, xp
+
+
 def conv3d_bwd_weight_bf16(x: torch.Tensor, dy: torch.Tensor, y_mask: Optional[torch.Tensor], c_in: int, c_out: int,
                            padding=(0, 0, 0)):
     """x [B,T,H,W,CPAD] bf16, dy/y_mask [B,To,Ho,Wo,32] bf16 -> (dw f32 [c_out,c_in,3,3,3], db f32 [c_out])."""

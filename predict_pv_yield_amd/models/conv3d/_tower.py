@@ -18,8 +18,18 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
                            "batch to cuda (there is no CPU fallback)")
     batch_size = data.shape[0]
     if use_bf16:
-        out = Fn.PackInputBF16.apply(data)
+        from ...hip_ops import bf16_cpad
+        fused_first = (len(convs) > 1 and data.dtype == torch.float32 and bf16_cpad(c_in) == 16 and padding[2] == 0
+                       and not data.requires_grad)
+        if fused_first:
+            # the first layer reads the f32 NCDHW input itself and leaves the NDHWC bf16 image for its wgrad behind
+            out = Fn.conv3d_first_layer_bf16(data, convs[0].weight, convs[0].bias, tuple(padding), relu=True, dy_pregated=True)
+            c_in = channels
+        else:
+            out = Fn.PackInputBF16.apply(data)
         for i, layer in enumerate(convs):
+            if fused_first and i == 0:
+                continue
             last = i == len(convs) - 1
             # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
             out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, tuple(padding), relu=True, y_ncdhw=last,

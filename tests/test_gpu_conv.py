@@ -173,6 +173,40 @@ def test_conv3d_bf16_input_stationary_kernel(device, shape, relu):
         torch.testing.assert_close(yn.float(), y.permute(0, 4, 1, 2, 3).float(), rtol=1e-2, atol=2e-3)
 
 
+@pytest.mark.parametrize("shape", [
+    # b, ci, t, h, w, padding
+    (2, 11, 7, 16, 16, (0, 0, 0)),
+    (1, 11, 6, 12, 70, (1, 0, 0)),     # two column blocks, time padding (model_sat_nwp)
+    (3, 12, 5, 21, 9, (1, 1, 0)),      # ragged rows and a ragged last voxel quad, t / h padding
+    (1, 1, 3, 8, 8, (0, 0, 0)),        # a single input channel, one output slice
+    (2, 16, 9, 10, 67, (2, 2, 0)),     # all 16 channels, widest t / h padding, time chunks, odd width
+])
+def test_conv3d_first_layer_from_f32_input(device, shape):
+    """pv_conv3d_fwd_bf16_f32in = pack + conv in one pass: same bits for y, and the NDHWC bf16 image it leaves behind
+    for the weight gradient equals the pack kernel's (every input voxel written exactly once)."""
+    K, Fn = _mods()
+    b, ci, t, h, w, pad = shape
+    x, wt, bias = _conv_case(21, b, ci, 32, t, h, w)
+    xd = x.to(device)
+    wp = K.conv3d_pack_weight_bf16(wt.to(device))
+    xp_ref = K.pack_ncdhw_f32_to_ndhwc_bf16(xd)
+    y_ref = K.conv3d_fwd_bf16(xp_ref, None, wp, bias.to(device), ci, 32, pad, relu=True, y_ncdhw=False)
+    xp_got = torch.full_like(xp_ref, float("nan"))
+    y, xp = K.conv3d_fwd_bf16_f32in(xd, wp, bias.to(device), 32, pad, relu=True)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(xp, xp_ref)
+    y2, none = K.conv3d_fwd_bf16_f32in(xd, wp, bias.to(device), 32, pad, relu=True, want_packed=False)
+    assert none is None and torch.equal(y2, y_ref)
+    del xp_got
+    # autograd wrapper: same weight / bias gradients as the two-kernel path
+    w1 = wt.to(device).requires_grad_(True); b1 = bias.to(device).requires_grad_(True)
+    w2 = wt.to(device).requires_grad_(True); b2 = bias.to(device).requires_grad_(True)
+    g = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(device).to(torch.bfloat16)
+    Fn.conv3d_first_layer_bf16(xd, w1, b1, pad, relu=True, dy_pregated=False).backward(g)
+    Fn.conv3d_relu_bf16(Fn.PackInputBF16.apply(xd), w2, b2, ci, pad, relu=True, y_ncdhw=False).backward(g)
+    assert torch.equal(w1.grad, w2.grad) and torch.equal(b1.grad, b2.grad)
+
+
 def test_conv3d_bf16_random_shapes(device):
     """Seeded sweep over ragged shapes / paddings / batch sizes of the 32 -> 32 bf16 forward (all three epilogues): the
     time-chunking, head / tail phases and tile clipping of the marching kernels depend on every one of these numbers."""

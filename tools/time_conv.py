@@ -37,3 +37,17 @@ for (t, h) in [(17, 62), (15, 60), (13, 58)]:
     ms = timeit(lambda: K.conv3d_fwd_bf16(dy, None, wp, None, 32, 32, (2, 2, 2), False, False, out_gate=gate))
     fl = 2.0 * b * 32 * 32 * 27 * t * h * h
     print(f"dgrad out {t}x{h}x{h}: {ms * 1e3:7.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s (padded-tap flops)")
+
+# first layer: f32 NCDHW input, 11 channels
+x = torch.randn(b, 11, 18, 64, 64, device=dev)
+w1 = torch.randn(32, 11, 3, 3, 3, device=dev) * 0.05
+wp1 = K.conv3d_pack_weight_bf16(w1)
+ms = timeit(lambda: K.conv3d_fwd_bf16(K.pack_ncdhw_f32_to_ndhwc_bf16(x), None, wp1, bias, 11, 32, (0, 0, 0), True, False))
+print(f"layer 1 pack + conv        : {ms * 1e3:7.1f} us")
+ms = timeit(lambda: K.conv3d_fwd_bf16_f32in(x, wp1, bias, 32, (0, 0, 0), True, want_packed=True))
+print(f"layer 1 fused (with xp)    : {ms * 1e3:7.1f} us")
+ms = timeit(lambda: K.conv3d_fwd_bf16_f32in(x, wp1, bias, 32, (0, 0, 0), True, want_packed=False))
+print(f"layer 1 fused (no xp)      : {ms * 1e3:7.1f} us")
+xp1 = K.pack_ncdhw_f32_to_ndhwc_bf16(x)
+ms = timeit(lambda: K.conv3d_fwd_bf16(xp1, None, wp1, bias, 11, 32, (0, 0, 0), True, False))
+print(f"layer 1 conv on packed bf16: {ms * 1e3:7.1f} us")
