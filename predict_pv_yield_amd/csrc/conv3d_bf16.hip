@@ -184,16 +184,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   };
   auto store_slice = [&](int s) {
     if constexpr (X_F32) {
-      // the NDHWC bf16 image for the weight gradient: every input voxel is written by exactly one workgroup (the tile
-      // it belongs to as an OUTPUT position; the last row / column block and time chunk also own the 2-voxel rim)
-      const int ti = s - pad_t;
-      const bool t_own = xp_out && (unsigned)ti < (unsigned)t_in && (s < tc1 || own_last_t);
       unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
 #pragma unroll
       for (int i = 0; i < F_PASS; ++i) {
         if ((i == 0 || wave == 0) && f_row[i] < TRI) {
-          const int hi = h0 - pad_h + f_row[i];
-          const bool row_own = t_own && (unsigned)hi < (unsigned)h_in && (f_row[i] < TR || own_last_row);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int scol = f_col[i] + q, swi = w0 + scol;
@@ -205,8 +199,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
               v[e] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi2) << 16);
             }
             *reinterpret_cast<u32x4*>(slot + f_row[i] * G::ROW_BYTES + scol * G::VOX_BYTES + ((f_sc[i] ^ G::swz(scol)) << 4)) = v;
-            if (row_own && col_ok && (scol < TW_VALID || own_last_col))
-              *reinterpret_cast<u32x4*>(xp_out + ((((size_t)b * t_in + ti) * h_in + hi) * w_in + swi) * CPAD + f_sc[i] * 8) = v;
           }
         }
       }
@@ -221,6 +213,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
           v[2] = gate_word(v[2], g[2]); v[3] = gate_word(v[3], g[3]);
         }
         *reinterpret_cast<u32x4*>(slot + i * RPI * G::ROW_BYTES) = v;
+      }
+    }
+  };
+
+  // X_F32: the NDHWC bf16 image for the weight gradient leaves from the staged LDS slot, lane-contiguous (a tile row of
+  // 64 voxels x 32 B is one 2 KB run of xp).  Every input voxel is written by exactly one workgroup: the tile it belongs
+  // to as an OUTPUT position; the last row / column block and time chunk also own the 2-voxel rim.
+  auto write_xp = [&](int s) {
+    if constexpr (X_F32) {
+      const int ti = s - pad_t;
+      if (!xp_out || (unsigned)ti >= (unsigned)t_in || !(s < tc1 || own_last_t)) return;
+      const unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
+#pragma unroll
+      for (int i = 0; i < G::NLOAD; ++i) {
+        const int rowi = i * RPI + srow0, hi = h0 - pad_h + rowi;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(slot + rowi * G::ROW_BYTES + lds_lane);
+        if ((unsigned)hi < (unsigned)h_in && scol_ok && (rowi < TR || own_last_row) && (scol < TW_VALID || own_last_col))
+          *reinterpret_cast<u32x4*>(xp_out + ((((size_t)b * t_in + ti) * h_in + hi) * w_in + swi) * CPAD + sc * 8) = v;
       }
     }
   };
@@ -306,6 +316,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     store_slice(t + 2);
     __syncthreads();
     if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
+    if constexpr (X_F32) {
+      if (t == tc0) {
+        write_xp(tc0);
+        write_xp(tc0 + 1);
+      }
+      write_xp(t + 2);
+    }
     f32x16 acc0;  // bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
