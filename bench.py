@@ -72,7 +72,13 @@ def measure_conv_roofline(batch, hist_frames, dev):
         dy = torch.randn_like(y)
         fl = conv_flops(batch, ci, 32, to, ho)
         name_f = f"conv3d_fwd_bf16_kernel<{cpad}>"
-        d = time_kernel(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, ci, 32, (0, 0, 0), True, False))
+        if li == 0:   # the step's first layer reads the f32 NCDHW input itself and leaves the bf16 image for its wgrad
+            xf = torch.randn(batch, ci, ti, hi, hi, device=dev)
+            name_f = f"conv3d_fwd_bf16_kernel<{cpad}> (f32 NCDHW input + bf16 NDHWC copy out)"
+            d = time_kernel(lambda: K.conv3d_fwd_bf16_f32in(xf, wp, bias, 32, (0, 0, 0), True, want_packed=True))
+            del xf
+        else:
+            d = time_kernel(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, ci, 32, (0, 0, 0), True, False))
         per_kernel.setdefault(name_f, [0.0, 0.0, 0])
         per_kernel[name_f][0] += d; per_kernel[name_f][1] += fl; per_kernel[name_f][2] += 1
         d = time_kernel(lambda: K.conv3d_bwd_weight_bf16(x, dy, None, ci, 32, (0, 0, 0)))  # dy arrives pre-gated
@@ -97,7 +103,7 @@ def measure_conv_roofline(batch, hist_frames, dev):
             "algorithmic_gflop_per_step": round(flops / 1e9, 2), "kernels": detail}
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v11.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r01", "pmc_hbm_traffic_bench_B32_v12.json")
 
 
 def committed_hbm_traffic(cpad: int, batch: int):
