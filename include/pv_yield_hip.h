@@ -130,6 +130,15 @@ int pv_remap_bilinear_u8(const uint8_t* src, int64_t src_stride,
                          int32_t h, int32_t w, int border_mode, uint8_t border_value,
                          void* stream);
 
+/* Config-3 prologue in one pass: raw counts [B, T, C, frame] (time-major) -> u8 [B, C, T, frame] (pv_u8_from_10bit
+ * rounding, `mode`) and the normalised frames (x - mean[c]) / std[c] written into slices 0..T-1 of out
+ * [B, C, t_out, frame] f32 (t_out >= T: room for the advected frames).  Same bits as pv_u8_from_10bit + pv_normalise on
+ * the permuted tensor; frame must be a multiple of 8. */
+int pv_prepare_stacks_i16(const int16_t* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
+                          int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream);
+int pv_prepare_stacks_f32(const float* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
+                          int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream);
+
 /* replaces: satellite_data -= SAT_IMAGE_MEAN; satellite_data /= SAT_IMAGE_STD
  * (notebooks/13_...ipynb:345-346, 463-464; per-channel constants
  * predict_pv_yield/netcdf_dataset.py:19-32).  dst[i] = (src[i] − mean[c]) / std[c]

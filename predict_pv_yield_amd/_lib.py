@@ -94,6 +94,8 @@ SIGNATURES = {
                               c_int, c_f32, c_vp],
     "pv_remap_bilinear_u8": [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i32, c_f32, c_i32, c_i32,
                              c_int, c_u8, c_vp],
+    "pv_prepare_stacks_i16": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp],
+    "pv_prepare_stacks_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp],
     "pv_normalise_i16": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
     "pv_normalise_f32": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
     "pv_conv3d_fwd_f32": [c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_vp],

@@ -828,16 +828,20 @@ __global__ __launch_bounds__(256) void fb_blur_h_solve_kernel(const float* __res
 }
 
 // ---- flow upsample: cv::resize(prevFlow -> (lw, lh), INTER_LINEAR) * (1 / pyr_scale) --------------
+// IDX = int when the whole output fits 31 bits (the per-element 64-bit division otherwise dominates the kernel); both
+// flow components of a tap travel as one 8-byte load / store.
+template <typename IDX>
 __global__ __launch_bounds__(256) void fb_flow_upsample_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                                 long long n_pairs, int sh, int sw, int dh, int dw,
                                                                 double inv_fx, double inv_fy, float mul) {
-  const long long per_img = (long long)dh * dw;
-  const long long total = n_pairs * per_img;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    long long p = i / per_img;
-    int rem = (int)(i - p * per_img);
-    int y = rem / dw, x = rem - y * dw;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const IDX per_img = (IDX)dh * dw;
+  const IDX total = (IDX)n_pairs * per_img;
+  const IDX stride = (IDX)gridDim.x * blockDim.x;
+  for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const IDX p = i / per_img;
+    const int rem = (int)(i - p * per_img);
+    const int y = rem / dw, x = rem - y * dw;
     float fx = (float)((x + 0.5) * inv_fx - 0.5);
     int sx = (int)floorf(fx);
     fx -= sx;
@@ -848,22 +852,24 @@ __global__ __launch_bounds__(256) void fb_flow_upsample_kernel(const float* __re
     fy -= sy;
     if (sy < 0) { fy = 0; sy = 0; }
     if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
-    int sy1 = clampi_d(sy + 1, 0, sh - 1);
-    const float* s0 = src + (p * sh * sw + (size_t)sy * sw) * 2;
-    const float* s1 = src + (p * sh * sw + (size_t)sy1 * sw) * 2;
-    float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const int sy1 = clampi_d(sy + 1, 0, sh - 1);
+    const f32x2_t* s0 = reinterpret_cast<const f32x2_t*>(src) + ((size_t)p * sh + sy) * sw;
+    const f32x2_t* s1 = reinterpret_cast<const f32x2_t*>(src) + ((size_t)p * sh + sy1) * sw;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const f32x2_t t00 = s0[sx], t10 = s1[sx];
+    f32x2_t r0 = t00, r1 = t10;
+    if (sx + 1 < sw) {
+      const f32x2_t t01 = s0[sx + 1], t11 = s1[sx + 1];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float r0, r1;
-      if (sx + 1 < sw) {
-        r0 = __fadd_rn(__fmul_rn(s0[sx * 2 + c], a0), __fmul_rn(s0[(sx + 1) * 2 + c], a1));
-        r1 = __fadd_rn(__fmul_rn(s1[sx * 2 + c], a0), __fmul_rn(s1[(sx + 1) * 2 + c], a1));
-      } else {
-        r0 = s0[sx * 2 + c];
-        r1 = s1[sx * 2 + c];
+      for (int c = 0; c < 2; ++c) {
+        r0[c] = __fadd_rn(__fmul_rn(t00[c], a0), __fmul_rn(t01[c], a1));
+        r1[c] = __fadd_rn(__fmul_rn(t10[c], a0), __fmul_rn(t11[c], a1));
       }
-      dst[i * 2 + c] = __fmul_rn(__fadd_rn(__fmul_rn(r0, b0), __fmul_rn(r1, b1)), mul);
     }
+    f32x2_t o;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) o[c] = __fmul_rn(__fadd_rn(__fmul_rn(r0[c], b0), __fmul_rn(r1[c], b1)), mul);
+    reinterpret_cast<f32x2_t*>(dst)[i] = o;
   }
 }
 
@@ -1063,9 +1069,14 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
       hipError_t e = hipMemsetAsync(flow, 0, (size_t)n_pairs * lpx * 2 * sizeof(float), st);
       PV_REQUIRE(e == hipSuccess, PV_ELAUNCH, "pv_farneback_batch_u8: memset failed");
     } else {
-      hipLaunchKernelGGL(fb_flow_upsample_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                         (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw, (double)prev_w / lw,
-                         (double)prev_h / lh, (float)(1. / p->pyr_scale));
+      if ((long long)n_pairs * lpx < 0x7fffffffLL)
+        hipLaunchKernelGGL(fb_flow_upsample_kernel<int>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                           (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw, (double)prev_w / lw,
+                           (double)prev_h / lh, (float)(1. / p->pyr_scale));
+      else
+        hipLaunchKernelGGL(fb_flow_upsample_kernel<long long>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0,
+                           st, (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw,
+                           (double)prev_w / lw, (double)prev_h / lh, (float)(1. / p->pyr_scale));
     }
     FbTaps sm;
     host_smooth_taps(smooth_sz, sigma, &sm);

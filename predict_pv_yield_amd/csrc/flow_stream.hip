@@ -409,6 +409,82 @@ static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* ra
   return check_launch("pv_u8_from_10bit");
 }
 
+// Config-3 prologue in one pass (optical_flow.advect_future_frames): raw counts [B, T, C, H, W] (time-major, as the
+// prepared batches hold them) -> (a) u8 frame stacks [B, C, T, H, W] for Farneback (same rounding as
+// u8_from_10bit_kernel) and (b) the normalised f32 frames (x - mean_c) / std_c written straight into the model input
+// [B, C, T + n_future, H, W] (slices 0..T-1).  Replaces a permute copy, the u8 pass, the normalise pass and a strided
+// copy: the raw tensor is read once.  One thread = 8 consecutive pixels of one (b, t, c) frame; frame % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void prepare_stacks_kernel(const T* __restrict__ raw, uint8_t* __restrict__ u8,
+                                                              float* __restrict__ out, long long n_vec, int t, int c,
+                                                              int frame8, int t_out, int mode,
+                                                              const float* __restrict__ mean, const float* __restrict__ std_,
+                                                              int32_t* range_flag) {
+  bool bad = false;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    // i enumerates [B][T][C][frame8] (source order)
+    const int px = (int)(i % frame8);
+    long long f = i / frame8;
+    const int ci = (int)(f % c);
+    f /= c;
+    const int ti = (int)(f % t);
+    const long long bi = f / t;
+    float x[8];
+    uint32_t lo = 0, hi = 0;
+    if constexpr (sizeof(T) == 2) {
+      const u32x4 r = *reinterpret_cast<const u32x4*>(raw + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int xi = (int)(int16_t)((r[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+        x[j] = (float)xi;
+        const uint32_t v = (uint32_t)u8_from_i16(xi, mode, bad);
+        if (j < 4) lo |= v << (8 * j); else hi |= v << (8 * (j - 4));
+      }
+    } else {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(raw + i * 8);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(raw + i * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = a[j]; x[j + 4] = b4[j];
+        lo |= (uint32_t)u8_from_f32(a[j], mode, bad) << (8 * j);
+        hi |= (uint32_t)u8_from_f32(b4[j], mode, bad) << (8 * j);
+      }
+    }
+    const long long bc = bi * c + ci;
+    const u32x2 o8 = {lo, hi};
+    *reinterpret_cast<u32x2*>(u8 + ((bc * t + ti) * (long long)frame8 + px) * 8) = o8;
+    const float m = mean[ci], sd = std_[ci];
+    f32x4 r0, r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r0[j] = __fdiv_rn(__fsub_rn(x[j], m), sd);
+      r1[j] = __fdiv_rn(__fsub_rn(x[j + 4], m), sd);
+    }
+    float* dst = out + ((bc * t_out + ti) * (long long)frame8 + px) * 8;
+    *reinterpret_cast<f32x4*>(dst) = r0;
+    *reinterpret_cast<f32x4*>(dst + 4) = r1;
+  }
+  if (range_flag && bad) atomicOr(range_flag, 1);
+}
+
+template <typename T>
+static int prepare_stacks_launch(const T* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
+                                 int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag,
+                                 void* stream) {
+  PV_REQUIRE(raw && u8 && out && mean && std_, PV_EINVAL, "pv_prepare_stacks: null pointer");
+  PV_REQUIRE(batch > 0 && t > 0 && c > 0 && frame > 0 && t_out >= t, PV_EINVAL, "pv_prepare_stacks: bad sizes");
+  PV_REQUIRE(frame % 8 == 0 && frame / 8 <= 0x7fffffffLL, PV_ESIZE, "pv_prepare_stacks: frame size %lld must be a multiple of 8",
+             (long long)frame);
+  PV_REQUIRE(mode == PV_U8_ROUND_DIV4 || mode == PV_U8_TRUNC_SCALE, PV_EINVAL, "pv_prepare_stacks: bad mode");
+  PV_REQUIRE(((uintptr_t)raw % 16 == 0) && ((uintptr_t)u8 % 8 == 0) && ((uintptr_t)out % 16 == 0), PV_EINVAL,
+             "pv_prepare_stacks: unaligned operand");
+  const long long n_vec = (long long)batch * t * c * (frame / 8);
+  hipLaunchKernelGGL((prepare_stacks_kernel<T>), dim3(stream_grid((size_t)n_vec, 256)), dim3(256), 0, as_stream(stream), raw, u8,
+                     out, n_vec, t, c, (int)(frame / 8), t_out, mode, mean, std_, range_flag);
+  return check_launch("pv_prepare_stacks");
+}
+
 template <typename T>
 static int normalise_launch(const T* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
                             const float* mean, const float* std_, void* stream) {
@@ -445,6 +521,15 @@ int pv_u8_from_10bit_i16(const int16_t* src, uint8_t* dst, size_t n, int mode, i
 int pv_u8_from_10bit_f32(const float* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag,
                          void* stream) {
   return u8_launch<float>(src, dst, n, mode, range_flag, stream);
+}
+
+int pv_prepare_stacks_i16(const int16_t* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
+                          int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream) {
+  return prepare_stacks_launch<int16_t>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
+}
+int pv_prepare_stacks_f32(const float* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
+                          int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream) {
+  return prepare_stacks_launch<float>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
 }
 
 int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host, float* out,

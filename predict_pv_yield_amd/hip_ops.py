@@ -160,6 +160,22 @@ def remap_bilinear_strided(src_ptr: int, src_stride: int, flow: torch.Tensor, ou
           "pv_remap_bilinear_f32")
 
 
+def prepare_stacks(raw: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, t_out: int, mode: int = 0):
+    """raw [B,T,C,H,W] int16/f32 counts -> (u8 [B,C,T,H,W], out f32 [B,C,t_out,H,W] with slices 0..T-1 normalised).
+    One pass over raw (pv_prepare_stacks_*); H*W must be a multiple of 8."""
+    require_cuda(raw, mean, std)
+    if raw.dtype not in (torch.int16, torch.float32) or raw.dim() != 5 or not raw.is_contiguous():
+        raise TypeError("prepare_stacks: contiguous int16 or float32 [B,T,C,H,W] expected")
+    b, t, c, h, w = raw.shape
+    u8 = torch.empty((b, c, t, h, w), dtype=torch.uint8, device=raw.device)
+    out = torch.empty((b, c, t_out, h, w), dtype=torch.float32, device=raw.device)
+    lib = get_lib()
+    fn = lib.pv_prepare_stacks_i16 if raw.dtype == torch.int16 else lib.pv_prepare_stacks_f32
+    check(fn(ptr(raw), ptr(u8), ptr(out), b, t, c, h * w, t_out, mode, ptr(mean), ptr(std), None, current_stream_ptr()),
+          "pv_prepare_stacks")
+    return u8, out
+
+
 def normalise(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, inner: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(x - mean[c]) / std[c] with c = (flat_index // inner) % len(mean); x int16 or f32."""

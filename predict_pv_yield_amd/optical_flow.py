@@ -148,17 +148,21 @@ def advect_future_frames(raw: torch.Tensor, n_future: int, mean: Optional[torch.
     if mean is None:
         mean = torch.from_numpy(SAT_MEAN[1:1 + c] if c < 12 else SAT_MEAN[:c]).to(dev)
         std = torch.from_numpy(SAT_STD[1:1 + c] if c < 12 else SAT_STD[:c]).to(dev)
-    # [B, C, T, H, W] channel-major stacks: each (b, c) is one Farnebäck frame stack
-    stacks = raw.permute(0, 2, 1, 3, 4).contiguous()
-    u8 = K.u8_from_10bit(stacks if stacks.dtype in (torch.int16, torch.float32) else stacks.float(), 0)
     kw = dict(REFERENCE_FARNEBACK_KWARGS)
     kw.update(farneback_kwargs)
+    if raw.dtype not in (torch.int16, torch.float32):
+        raw = raw.float()
+    if (h * w) % 8 == 0:
+        # one pass over the raw counts: channel-major u8 stacks (each (b, c) is one Farnebäck frame stack) and the
+        # normalised observed frames written straight into out[:, :, :t]
+        u8, out = K.prepare_stacks(raw.contiguous(), mean, std, t + n_future)
+    else:
+        stacks = raw.permute(0, 2, 1, 3, 4).contiguous()
+        u8 = K.u8_from_10bit(stacks, 0)
+        out = torch.empty((b, c, t + n_future, h, w), dtype=torch.float32, device=dev)
+        out[:, :, :t] = K.normalise(stacks, mean, std, inner=t * h * w)
     flows = K.farneback_stack(u8, **kw)                               # [B, C, T-1, H, W, 2]
     mean_flow = K.flow_weighted_mean(flows.view(b * c, t - 1, h, w, 2))  # [B*C, H, W, 2]
-    out = torch.empty((b, c, t + n_future, h, w), dtype=torch.float32, device=dev)
-    # normalise the observed frames into out[:, :, :t]: inner = T*H*W elements share a channel
-    obs = K.normalise(stacks, mean, std, inner=t * h * w)            # [B, C, T, H, W]
-    out[:, :, :t] = obs
     # advected frames: src = normalised frame t0 = out[b, c, t-1], dst = out[b, c, t + k - 1]
     frame = h * w
     img_stride = (t + n_future) * frame

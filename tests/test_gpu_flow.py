@@ -207,6 +207,23 @@ def test_farneback_stack_and_params(device):
             assert np.abs(got[c, t] - ref).max() <= 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 5, 3, 8, 8), (1, 12, 11, 64, 64), (3, 2, 1, 4, 6)])
+def test_prepare_stacks_equals_permute_u8_normalise(device, dtype, shape):
+    """pv_prepare_stacks_* (one pass over the time-major raw counts) = permute + pv_u8_from_10bit + pv_normalise, bit for
+    bit; the slices past T of the model input stay untouched."""
+    from predict_pv_yield_amd import hip_ops as K
+    b, t, c, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randint(0, 1024, shape, generator=g).to(dtype).to(device)
+    mean = (torch.rand(c, generator=g) * 300 + 100).to(device)
+    std = (torch.rand(c, generator=g) * 100 + 50).to(device)
+    u8, out = K.prepare_stacks(raw, mean, std, t + 3)
+    stacks = raw.permute(0, 2, 1, 3, 4).contiguous()
+    assert torch.equal(u8, K.u8_from_10bit(stacks, 0))
+    assert torch.equal(out[:, :, :t], K.normalise(stacks, mean, std, inner=t * h * w))
+
+
 def test_errors_are_loud(device):
     K = _ops()
     with pytest.raises(RuntimeError):
