@@ -1109,10 +1109,10 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         // window blur + solve on the matrix cores (UpdateMatrices stays a separate high-occupancy launch: its
         // flow-dependent R1 gathers need many waves in flight)
         float* Gv = (float*)(ws + L.off_G);
-        float* Gh = Gv + 64 * 64;
+        float* Gh = lh == lw ? Gv : Gv + 64 * 64;   // square levels: the vertical and horizontal window matrices coincide
         if (it == 0) {
           hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
-          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
+          if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
         }
         if (lh <= 32 && lw <= 32) {
           const unsigned grid = (unsigned)std::min<long long>((n_pairs + 3) / 4, 2048);
