@@ -194,6 +194,188 @@ __global__ __launch_bounds__(256) void conv3d_tiled_s1_f32(const float* __restri
   }
 }
 
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// Unit-stride forward / dgrad on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulation)
+// for 16 <= c_in <= 32, c_out <= 32 and the notebook model's (2,3,3) layers:
+//   D[co][pos] = sum_{tap, ci} W[co][ci][tap] * X[ci][pos + tap],   one 32 x 32 accumulator per wave.
+// Workgroup = 4 waves (one per SIMD, so a wave may use the whole register file) = 2 position tiles (64 output columns
+// of one output row) x 2 halves of the input channels; a wave keeps the weights of its channel half as MFMA A operands
+// in registers (TAPS x 8 VGPRs = 144 for (2,3,3)) for the whole launch, the B operand (2 channels x 32 positions) is a
+// ds_read_b32 from the staged input rows, fetched one (kt, kh) row ahead of its MFMAs.  The workgroup marches down a
+// segment of output rows: the KT x (KH + 1) input rows live in an LDS ring (channel stride = 32 mod 64 words: the two
+// channels of an operand read hit disjoint banks) filled global -> LDS directly, each step fetching only the KT new
+// rows while the MFMAs of the current row run.  The two channel halves are added through LDS (fixed order), then
+// bias / ReLU / out_gate and 128-byte row stores.  Same flip / out_gate conventions as conv3d_tiled_s1_f32.
+template <int KT, int KH, int KW>
+struct FwdMfmaCfg {
+  static constexpr int TAPS = KT * KH * KW;
+  static constexpr int SLOTS = KH + 1;                            // ring slots per kt: KH rows in use + the one in flight
+  static constexpr int WT = 64;
+  static constexpr int R = WT + KW - 1;
+  static constexpr int CS = ((KT * SLOTS * R + 31) / 64) * 64 + 32;   // channel stride, = 32 (mod 64) words
+};
+
+// SPLIT_CI: the two wave pairs split the contraction by input-channel half (c_in > 16); otherwise (c_in <= 16, all
+// channel pairs fit one half) by tap plane kt, so that neither pair multiplies zero padding.
+template <int KT, int KH, int KW, bool SPLIT_CI>
+__global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, Geom g,
+                                                           int relu, int flip, int w_ci_dim,
+                                                           const float* __restrict__ out_gate, int hseg, int n_hseg) {
+  using C = FwdMfmaCfg<KT, KH, KW>;
+  constexpr int TAPS = C::TAPS, SLOTS = C::SLOTS, WT = C::WT, R = C::R, CS = C::CS;
+  __shared__ __attribute__((aligned(16))) float xT[32 * CS];
+  __shared__ float red[2 * 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pt = wave & 1, kk = wave >> 1, h = lane >> 5, l32 = lane & 31;
+  const int n_wt = (g.w_out + WT - 1) / WT;
+  int item = blockIdx.x;
+  const int hs = item % n_hseg;
+  item /= n_hseg;
+  const int wt = item % n_wt;
+  item /= n_wt;
+  const int to = item % g.t_out;
+  const int b = item / g.t_out;
+  const int ho0 = hs * hseg, ho1 = min(ho0 + hseg, g.h_out);
+  const int wo0 = wt * WT;
+  const int plane_in = g.h_in * g.w_in, plane_out = g.h_out * g.w_out;
+  const size_t vox_in = (size_t)g.t_in * plane_in, vox_out = (size_t)g.t_out * plane_out;
+
+  // ---- weights of this wave's channel half: A operand of tap t, channel pair p = W[co = l32][ci = 16kk + 2p + h][t] -----
+  constexpr int NT = SPLIT_CI ? TAPS : KH * KW;   // taps this wave multiplies (tap-plane split: only plane kt = kk)
+  float areg[NT][8];
+#pragma unroll
+  for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int t = SPLIT_CI ? tl : kk * KH * KW + tl;
+      const int ci = (SPLIT_CI ? 16 * kk : 0) + 2 * p + h, co = l32;
+      float v = 0.f;
+      if (co < g.c_out && ci < g.c_in)
+        v = flip ? w[((size_t)ci * w_ci_dim + co) * TAPS + (TAPS - 1 - t)] : w[((size_t)co * w_ci_dim + ci) * TAPS + t];
+      areg[tl][p] = v;
+    }
+  static_assert(SPLIT_CI || KT == 2, "the tap-plane split deals one kt plane to each wave pair");
+
+  // ---- staging, global -> LDS direct (buffer_load_dword ... lds): one wave instruction = 64 consecutive columns of one
+  // (channel, input row); a row of R = WT + KW - 1 columns = one full instruction + one with KW - 1 lanes.  Wave w stages
+  // channels 8w .. 8w+7.  Out-of-range positions (padding, image edge, channels >= c_in) read as zeros. ----------------
+  constexpr uint32_t INVALID = 0x40000000u;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * g.c_in * vox_in), 0,
+                                                                        (int)(g.c_in * vox_in * 4), 0x00020000);
+  uint32_t col_off[2];   // byte offset of this lane's column inside an input row, per 64-column segment
+#pragma unroll
+  for (int sgm = 0; sgm < 2; ++sgm) {
+    const int wi = wo0 - g.pw + 64 * sgm + lane;
+    col_off[sgm] = (unsigned)wi < (unsigned)g.w_in ? (uint32_t)wi * 4u : INVALID;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto stage_chan = [&](int kt, int c8, int hi) {   // input row (to + kt - pt, hi) of channel 8w + c8 -> slot hi mod SLOTS
+    const int ti = to + kt - g.pt;
+    const bool ok = (unsigned)ti < (unsigned)g.t_in && (unsigned)hi < (unsigned)g.h_in;
+    const uint32_t ro = ok ? (uint32_t)((ti * plane_in + hi * g.w_in) * 4) : INVALID;
+    const int slot = ((hi % SLOTS) + SLOTS) % SLOTS;
+    const int ci = 8 * wave + c8;
+    const uint32_t co = ci < g.c_in ? (uint32_t)((size_t)ci * vox_in * 4) + ro : INVALID;
+    float* dst = xT + ci * CS + (kt * SLOTS + slot) * R;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)dst, 4, col_off[0] + co, 0, 0, 0);
+    if (lane < R - 64) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + 64), 4, col_off[1] + co, 0, 0, 0);
+  };
+  auto stage_row = [&](int kt, int hi) {
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) stage_chan(kt, c8, hi);
+  };
+
+  // ---- prologue: the KH input rows of the segment's first output row -----------------------------------------------
+#pragma unroll 1
+  for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) stage_row(kt, ho0 - g.ph + kh);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+
+  const int b_lane = ((SPLIT_CI ? 16 * kk : 0) + h) * CS + 32 * pt + l32;
+  float bias_r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+    bias_r[r] = (bias && co < g.c_out) ? bias[co] : 0.f;
+  }
+  for (int ho = ho0; ho < ho1; ++ho) {
+    const bool more = ho + 1 < ho1;
+    // two accumulation chains (even / odd channel pairs): a dependent 32x32x2 MFMA cannot start before its predecessor
+    // has left the pipe, and with one wave per SIMD nothing else would fill that gap
+    v16f acc, acc_b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc_b[r] = 0.f;
+    // B operands of one (kt, kh) input row: 8 channel pairs x KW consecutive columns; the next row's 24 values are read
+    // while the current row's 24 MFMAs (1.5k matrix cycles) run.  The staging of the next step's new input rows (16
+    // LDS-direct instructions per kt and wave, ~50 issue cycles each) is spread over the row loop as well.
+    constexpr int NR = SPLIT_CI ? KT * KH : KH;           // (kt, kh) rows this wave multiplies
+    const int r0 = SPLIT_CI ? 0 : kk * KH;                // first of them
+    float bv[2][8][KW];
+    auto read_row = [&](int rr, float (&dstv)[8][KW]) {
+      const int kt = rr / KH, kh = rr - kt * KH;
+      const int hi = ho - g.ph + kh;
+      const int slot = ((hi % SLOTS) + SLOTS) % SLOTS;
+      const float* rowp = xT + b_lane + (kt * SLOTS + slot) * R;
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) dstv[p][kw] = rowp[2 * p * CS + kw];
+    };
+    read_row(r0, bv[0]);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int rr = r0 + i;
+      if (i + 1 < NR) read_row(rr + 1, bv[(i + 1) & 1]);
+      if (more) {   // this row's share of the staging
+        constexpr int PER = (KT * 8 + NR - 1) / NR;
+#pragma unroll
+        for (int q = i * PER; q < (i + 1) * PER && q < KT * 8; ++q) stage_chan(q / 8, q % 8, ho + KH - g.ph);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+        for (int p = 0; p < 8; p += 2) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p], bv[i & 1][p][kw], acc, 0, 0, 0);
+          acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p + 1], bv[i & 1][p + 1][kw], acc_b, 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc_b[r];
+    // ---- add the two partial tiles: each wave pair parks the half of its tile that the OTHER pair finishes (registers
+    // 8kk' .. 8kk'+7, kk' = 1 - kk) in LDS, then both pairs run the epilogue on 8 registers each --------------------
+#pragma unroll
+    for (int r = 0; r < 8; ++r) red[(pt * 16 + 8 * (1 - kk) + r) * 64 + lane] = kk == 0 ? acc[8 + r] : acc[r];
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of the next row has landed
+    __syncthreads();
+    {
+      const int pos = wo0 + 32 * pt + l32;
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = 8 * kk + r8;
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float mine = kk == 0 ? acc[r8] : acc[8 + r8];
+        const float other = red[(pt * 16 + r) * 64 + lane];
+        float v = kk == 0 ? mine + other : other + mine;   // always (lower pair's partial) + (upper pair's partial)
+        if (co < g.c_out && pos < g.w_out) {
+          v += kk == 0 ? bias_r[r8] : bias_r[8 + r8];
+          if (relu) v = fmaxf(v, 0.f);
+          const size_t o = ((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos;
+          if (out_gate && !(out_gate[o] > 0.f)) v = 0.f;
+          y[o] = v;
+        }
+      }
+    }
+    __syncthreads();   // red is free again before the next step's upper half writes it
+  }
+}
+
 // dgrad, gather form: dx[b,ci,ti,hi,wi] = sum_{co,taps : to*st - pt + kt == ti ...} dy'[b,co,to,ho,wo] * w[co,ci,tap],
 // dy' = dy gated by (gate > 0) when the forward was followed by a ReLU.  One thread = one dx voxel x GCO input channels.
 template <int KT, int KH, int KW>
@@ -808,6 +990,30 @@ static bool launch_tiled_s1(const float* x, const float* gate, const float* w, c
   return false;
 }
 
+// unit-stride launch of the matrix-core kernel (same argument conventions as launch_tiled_s1); false = shape not covered
+static bool launch_mfma_s1(const float* x, const float* gate, const float* w, const float* bias, float* y, const Geom& g,
+                           int batch, int relu, int flip, int w_ci_dim, const float* out_gate, hipStream_t stream) {
+  if (!(g.kt == 2 && g.kh == 3 && g.kw == 3)) return false;
+  if (g.c_in < 16 || g.c_in > 32 || g.c_out > 32 || g.w_out < 64) return false;
+  if ((size_t)g.c_in * g.t_in * g.h_in * g.w_in * 4 > 0x40000000ull) return false;   // 32-bit raw-buffer offsets
+  const int n_wt = (g.w_out + 63) / 64;
+  const long long cols = (long long)batch * g.t_out * n_wt;
+  // output rows are marched in segments; enough segments for ~2 work items per CU, none shorter than 8 rows
+  int n_hseg = (int)std::min<long long>(std::max<long long>((512 + cols - 1) / cols, 1), std::max(g.h_out / 8, 1));
+  const int hseg = (g.h_out + n_hseg - 1) / n_hseg;
+  n_hseg = (g.h_out + hseg - 1) / hseg;
+  const long long items = cols * n_hseg;
+  if (items > 0x7fffffffLL) return false;
+  if (gate) return false;   // an input gate cannot be applied on the global -> LDS path: the tiled kernel serves it
+  if (g.c_in > 16)
+    conv3d_fwd_mfma_f32<2, 3, 3, true><<<dim3((unsigned)items), dim3(256), 0, stream>>>(x, w, bias, y, g, relu, flip,
+                                                                                         w_ci_dim, out_gate, hseg, n_hseg);
+  else
+    conv3d_fwd_mfma_f32<2, 3, 3, false><<<dim3((unsigned)items), dim3(256), 0, stream>>>(x, w, bias, y, g, relu, flip,
+                                                                                          w_ci_dim, out_gate, hseg, n_hseg);
+  return true;
+}
+
 static bool unit_stride(const Geom& g) { return g.st == 1 && g.sh == 1 && g.sw == 1; }
 
 int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias, float* y, const pv_conv3d_geom* d,
@@ -818,6 +1024,8 @@ int pv_conv3d_general_fwd_f32(const float* x, const float* w, const float* bias,
   PV_REQUIRE(x && w && y, PV_EINVAL, "pv_conv3d_general_fwd_f32: null pointer");
   const size_t lds = (size_t)g.c_in * g.kt * g.kh * g.kw * GCO * sizeof(float);
   PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_conv3d_general_fwd_f32: c_in=%d too large for the LDS weight tile", g.c_in);
+  if (unit_stride(g) && launch_mfma_s1(x, nullptr, w, bias, y, g, d->batch, relu ? 1 : 0, 0, g.c_in, nullptr, as_stream(stream)))
+    return check_launch("pv_conv3d_general_fwd_f32");
   if (unit_stride(g) && g.w_out >= TW &&
       launch_tiled_s1(x, nullptr, w, bias, y, g, d->batch, relu ? 1 : 0, 0, g.c_in, nullptr, as_stream(stream)))
     return check_launch("pv_conv3d_general_fwd_f32");
@@ -843,6 +1051,8 @@ int pv_conv3d_general_bwd_data_f32(const float* dy, const float* y_relu_mask, co
     t.t_in = g.t_out, t.h_in = g.h_out, t.w_in = g.w_out;
     t.t_out = g.t_in, t.h_out = g.h_in, t.w_out = g.w_in;
     t.pt = g.kt - 1 - g.pt, t.ph = g.kh - 1 - g.ph, t.pw = g.kw - 1 - g.pw;
+    if (launch_mfma_s1(dy, y_relu_mask, w, nullptr, dx, t, d->batch, 0, 1, g.c_in, x_relu_mask, as_stream(stream)))
+      return check_launch("pv_conv3d_general_bwd_data_f32");
     if (launch_tiled_s1(dy, y_relu_mask, w, nullptr, dx, t, d->batch, 0, 1, g.c_in, x_relu_mask, as_stream(stream)))
       return check_launch("pv_conv3d_general_bwd_data_f32");
   }
