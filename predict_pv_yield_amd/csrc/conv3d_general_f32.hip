@@ -772,13 +772,30 @@ static bool wgrad_mfma_ok(const Geom& g) {
 
 static int wgrad_mfma_wt(const Geom& g) { return g.kt * g.kh > 6 ? 64 : 128; }
 
-__global__ __launch_bounds__(256) void slab_reduce_f32(const float* __restrict__ slabs, float* __restrict__ out, int n,
+// out[i] = sum over slabs (fixed order: deterministic).  Block = 64 elements x 8 slab groups (one wave each, four
+// independent partial sums in flight), LDS combine of the 8 partials in a fixed order -- the one-thread-per-element loop
+// over 512 slabs it replaces was latency-bound at 0.4 TB/s.
+__global__ __launch_bounds__(512) void slab_reduce_f32(const float* __restrict__ slabs, float* __restrict__ out, int n,
                                                        int n_slabs) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < n_slabs; ++k) s += slabs[(size_t)k * n + i];
-  out[i] = s;
+  __shared__ float part[8][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = grp;
+    for (; k + 24 < n_slabs; k += 32) {
+      s0 += slabs[(size_t)k * n + i];
+      s1 += slabs[(size_t)(k + 8) * n + i];
+      s2 += slabs[(size_t)(k + 16) * n + i];
+      s3 += slabs[(size_t)(k + 24) * n + i];
+    }
+    for (; k < n_slabs; k += 8) s0 += slabs[(size_t)k * n + i];
+  }
+  part[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && i < n)
+    out[i] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+             ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
 }
 
 // dbias[co] = sum over (b, voxels) of dy (gated); one block per channel, fixed order
@@ -1093,8 +1110,8 @@ int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const floa
       else conv3d_wgrad_mfma_f32<1, 3, 3><<<dim3((unsigned)n_slabs), dim3(512), 0, st>>>(x, dy, y_relu_mask, slabs, bias_slabs, g, d->batch, n_steps, per);
       rc = check_launch("pv_conv3d_general_bwd_weight_f32(mfma)");
       if (rc) return rc;
-      slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(slabs, dw, n, n_slabs);
-      if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 255) / 256)), dim3(256), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
+      slab_reduce_f32<<<dim3((unsigned)((n + 63) / 64)), dim3(512), 0, st>>>(slabs, dw, n, n_slabs);
+      if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 63) / 64)), dim3(512), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
       return check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
     }
     const int wco = wgrad_wco(g);
@@ -1121,8 +1138,8 @@ int pv_conv3d_general_bwd_weight_f32(const float* x, const float* dy, const floa
 #undef PV_WG
     rc = check_launch("pv_conv3d_general_bwd_weight_f32");
     if (rc) return rc;
-    slab_reduce_f32<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(slabs, dw, n, n_slabs);
-    if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 255) / 256)), dim3(256), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
+    slab_reduce_f32<<<dim3((unsigned)((n + 63) / 64)), dim3(512), 0, st>>>(slabs, dw, n, n_slabs);
+    if (dbias) slab_reduce_f32<<<dim3((unsigned)((g.c_out + 63) / 64)), dim3(512), 0, st>>>(bias_slabs, dbias, g.c_out, n_slabs);
     return check_launch("pv_conv3d_general_bwd_weight_f32(reduce)");
   }
   if (dbias) {
