@@ -305,6 +305,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
   }
   for (int ho = ho0; ho < ho1; ++ho) {
     const bool more = ho + 1 < ho1;
+    // out_gate values of this wave's 8 outputs, fetched now so that their latency hides under the MFMAs
+    float og[8];
+    const int pos = wo0 + 32 * pt + l32;
+#pragma unroll
+    for (int r8 = 0; r8 < 8; ++r8) {
+      const int r = 8 * kk + r8;
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+      og[r8] = 1.f;
+      if (out_gate && co < g.c_out && pos < g.w_out)
+        og[r8] = out_gate[((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos];
+    }
     // two accumulation chains (even / odd channel pairs): a dependent 32x32x2 MFMA cannot start before its predecessor
     // has left the pipe, and with one wave per SIMD nothing else would fill that gap
     v16f acc, acc_b;
@@ -355,7 +366,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of the next row has landed
     __syncthreads();
     {
-      const int pos = wo0 + 32 * pt + l32;
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = 8 * kk + r8;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
           v += kk == 0 ? bias_r[r8] : bias_r[8 + r8];
           if (relu) v = fmaxf(v, 0.f);
           const size_t o = ((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos;
-          if (out_gate && !(out_gate[o] > 0.f)) v = 0.f;
+          if (!(og[r8] > 0.f)) v = 0.f;
           y[o] = v;
         }
       }
@@ -897,24 +907,33 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_f32(const float* __restrict
 
 // ---- mean squared error ------------------------------------------------------------------------------------------
 // out[0] = mean((y_hat - y)^2) with a fixed-order single-block reduction (f64 partials); grad = 2 (y_hat - y) / n * scale
-__global__ __launch_bounds__(1024) void mse_loss_f32(const float* __restrict__ y_hat, const float* __restrict__ y,
-                                                     long long n, float grad_scale, float* __restrict__ out,
-                                                     float* __restrict__ grad) {
+// nn.MSELoss (mean) + its gradient: MSE_BLOCKS blocks leave one double partial sum each (thread-strided double
+// accumulation, fixed-order combine), a one-block second pass adds the partials in index order.
+constexpr int MSE_BLOCKS = 128;
+__global__ __launch_bounds__(256) void mse_partial_f32(const float* __restrict__ y_hat, const float* __restrict__ y,
+                                                       long long n, float grad_scale, double* __restrict__ partial,
+                                                       float* __restrict__ grad) {
   double s = 0.0;
   const float gs = 2.0f * grad_scale / (float)n;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-    float d = y_hat[i] - y[i];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = y_hat[i] - y[i];
     s += (double)d * (double)d;
     if (grad) grad[i] = d * gs;
   }
-  __shared__ double red[16];
+  __shared__ double red[4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(64) void mse_final_f32(const double* __restrict__ partial, int n_partial, long long n,
+                                                    float* __restrict__ out) {
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int k = 0; k < 16; ++k) t += red[k];
+    for (int k = 0; k < n_partial; ++k) t += partial[k];
     out[0] = (float)(t / (double)n);
   }
 }
@@ -1176,7 +1195,17 @@ int pv_mse_loss_f32(const float* y_hat, const float* y, int64_t n, float grad_sc
                     void* stream) {
   PV_REQUIRE(y_hat && y && out, PV_EINVAL, "pv_mse_loss_f32: null pointer");
   PV_REQUIRE(n > 0, PV_EINVAL, "pv_mse_loss_f32: n must be positive");
-  mse_loss_f32<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(y_hat, y, (long long)n, grad_scale, out, grad);
+  // per-device scratch for the block partials (1 KB, allocated on first use, never freed)
+  static double* partial_ws[64] = {nullptr};
+  int dev = 0;
+  PV_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, PV_ELAUNCH, "pv_mse_loss_f32: hipGetDevice failed");
+  if (!partial_ws[dev])
+    PV_REQUIRE(hipMalloc((void**)&partial_ws[dev], MSE_BLOCKS * sizeof(double)) == hipSuccess, PV_ELAUNCH,
+               "pv_mse_loss_f32: scratch allocation failed");
+  const int blocks = (int)std::min<long long>(MSE_BLOCKS, (n + 255) / 256);
+  mse_partial_f32<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(y_hat, y, (long long)n, grad_scale,
+                                                                               partial_ws[dev], grad);
+  mse_final_f32<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(partial_ws[dev], blocks, (long long)n, out);
   return check_launch("pv_mse_loss_f32");
 }
 
