@@ -199,20 +199,32 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
   const int tile0 = blockIdx.x * tiles_per_split;
   const int tile1 = tile0 + tiles_per_split < n_tiles ? tile0 + tiles_per_split : n_tiles;
   dq += blockIdx.x * dq_ss;     // this key range's partial dQ (summed over the splits afterwards)
+  // K, V of a tile as B operands: lane (key = col, d = 2 kk + half).  The NEXT tile's 64 loads per lane are issued before
+  // the current tile's ~640 MFMAs (one wave per SIMD: nothing else would hide their issue time and latency).
+  float kreg[32], vreg[32], knxt[32], vnxt[32];
+  auto load_kv = [&](int tile, float (&kd)[32], float (&vd)[32]) {
+    const int jj = tile * AT_TJ + col;
+    const bool ok = tile < tile1 && jj < g.n_k;
+    const float* kp = kb + (long long)(ok ? jj : 0) * g.k_rs + half;
+    const float* vp = vb + (long long)(ok ? jj : 0) * g.k_rs + half;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      kd[kk] = ok ? kp[2 * kk] : 0.f;
+      vd[kk] = ok ? vp[2 * kk] : 0.f;
+    }
+  };
+  load_kv(tile0 + wave, knxt, vnxt);
   for (int tile = tile0 + wave; tile < tile1; tile += 4) {
     const int j0 = tile * AT_TJ;
     const int j = j0 + col;                       // this lane's key (B-operand column)
     const bool j_ok = j < g.n_k;
-    // K, V of the tile as B operands: lane (key = col, d = 2 kk + half); K also into LDS for the transposed use
-    float kreg[32], vreg[32];
-    const float* kp = kb + (long long)(j_ok ? j : 0) * g.k_rs + half;
-    const float* vp = vb + (long long)(j_ok ? j : 0) * g.k_rs + half;
 #pragma unroll
     for (int kk = 0; kk < 32; ++kk) {
-      kreg[kk] = j_ok ? kp[2 * kk] : 0.f;
-      vreg[kk] = j_ok ? vp[2 * kk] : 0.f;
-      Kt[col * AT_LD + 2 * kk + half] = kreg[kk];
+      kreg[kk] = knxt[kk];
+      vreg[kk] = vnxt[kk];
+      Kt[col * AT_LD + 2 * kk + half] = kreg[kk];   // K also into LDS for the transposed use
     }
+    load_kv(tile + 4, knxt, vnxt);
     v16f_a dv0, dv1, dk0, dk1;   // dV^T / dK^T of this key tile: rows d, column = key
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv0[r] = 0.f, dv1[r] = 0.f, dk0[r] = 0.f, dk1[r] = 0.f;
