@@ -207,29 +207,35 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // channels of an operand read hit disjoint banks) filled global -> LDS directly, each step fetching only the KT new
 // rows while the MFMAs of the current row run.  The two channel halves are added through LDS (fixed order), then
 // bias / ReLU / out_gate and 128-byte row stores.  Same flip / out_gate conventions as conv3d_tiled_s1_f32.
-template <int KT, int KH, int KW>
+template <int KT, int KH, int KW, bool M16>
 struct FwdMfmaCfg {
   static constexpr int TAPS = KT * KH * KW;
   static constexpr int SLOTS = KH + 1;                            // ring slots per kt: KH rows in use + the one in flight
   static constexpr int WT = 64;
   static constexpr int R = WT + KW - 1;
-  static constexpr int CS = ((KT * SLOTS * R + 31) / 64) * 64 + 32;   // channel stride, = 32 (mod 64) words
+  // channel stride in words: = 32 (mod 64) for the 32x32x2 operand (2 channels x 32 positions per read),
+  //                          = 16 (mod 64) for the 16x16x4 operand (4 channels x 16 positions)
+  static constexpr int CS = M16 ? ((KT * SLOTS * R + 47) / 64) * 64 + 16 : ((KT * SLOTS * R + 31) / 64) * 64 + 32;
 };
 
 // SPLIT_CI: the two wave pairs split the contraction by input-channel half (c_in > 16); otherwise (c_in <= 16, all
 // channel pairs fit one half) by tap plane kt, so that neither pair multiplies zero padding.
-template <int KT, int KH, int KW, bool SPLIT_CI>
+// M16 (c_out <= 16, SPLIT_CI): v_mfma_f32_16x16x4_f32 instead -- 16 output channels x 16 positions, 4 channels per
+// step; a wave's 32 positions are two such tiles, so no half of the matrix tile multiplies zero rows.
+template <int KT, int KH, int KW, bool SPLIT_CI, bool M16 = false>
 __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, Geom g,
                                                            int relu, int flip, int w_ci_dim,
                                                            const float* __restrict__ out_gate, int hseg, int n_hseg) {
-  using C = FwdMfmaCfg<KT, KH, KW>;
+  using C = FwdMfmaCfg<KT, KH, KW, M16>;
+  static_assert(!M16 || SPLIT_CI, "the 16-row variant splits the contraction by channel half");
   constexpr int TAPS = C::TAPS, SLOTS = C::SLOTS, WT = C::WT, R = C::R, CS = C::CS;
   __shared__ __attribute__((aligned(16))) float xT[32 * CS];
   __shared__ float red[2 * 16 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pt = wave & 1, kk = wave >> 1, h = lane >> 5, l32 = lane & 31;
+  const int kq = lane >> 4, l16 = lane & 15;   // M16 roles: channel of a 4-channel step, row / column of a 16 x 16 tile
   const int n_wt = (g.w_out + WT - 1) / WT;
   int item = blockIdx.x;
   const int hs = item % n_hseg;
@@ -245,13 +251,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
 
   // ---- weights of this wave's channel half: A operand of tap t, channel pair p = W[co = l32][ci = 16kk + 2p + h][t] -----
   constexpr int NT = SPLIT_CI ? TAPS : KH * KW;   // taps this wave multiplies (tap-plane split: only plane kt = kk)
-  float areg[NT][8];
+  constexpr int NP = M16 ? 4 : 8;                 // contraction steps per tap: 4-channel steps / channel pairs
+  float areg[NT][NP];
 #pragma unroll
   for (int tl = 0; tl < NT; ++tl)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    for (int p = 0; p < NP; ++p) {
       const int t = SPLIT_CI ? tl : kk * KH * KW + tl;
-      const int ci = (SPLIT_CI ? 16 * kk : 0) + 2 * p + h, co = l32;
+      const int ci = M16 ? 16 * kk + 4 * p + kq : (SPLIT_CI ? 16 * kk : 0) + 2 * p + h;
+      const int co = M16 ? l16 : l32;
       float v = 0.f;
       if (co < g.c_out && ci < g.c_in)
         v = flip ? w[((size_t)ci * w_ci_dim + co) * TAPS + (TAPS - 1 - t)] : w[((size_t)co * w_ci_dim + ci) * TAPS + t];
@@ -296,90 +304,140 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
 
-  const int b_lane = ((SPLIT_CI ? 16 * kk : 0) + h) * CS + 32 * pt + l32;
-  float bias_r[16];
+  const int b_lane = M16 ? (16 * kk + kq) * CS + 32 * pt + l16 : ((SPLIT_CI ? 16 * kk : 0) + h) * CS + 32 * pt + l32;
+  // epilogue roles: (M16) this wave finishes N tile kk: channel 4 kq + r, position 32 pt + 16 kk + l16, r < 4;
+  //                 (else) registers 8 kk .. 8 kk + 7 of the 32 x 32 tile: channel acc_row, position 32 pt + l32
+  constexpr int NE = M16 ? 4 : 8;
+  const int pos = wo0 + 32 * pt + (M16 ? 16 * kk + l16 : l32);
+  int e_co[NE];
+  float bias_r[NE];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-    bias_r[r] = (bias && co < g.c_out) ? bias[co] : 0.f;
+  for (int e = 0; e < NE; ++e) {
+    const int r = 8 * kk + e;
+    e_co[e] = M16 ? 4 * kq + e : (r & 3) + 8 * (r >> 2) + 4 * h;
+    bias_r[e] = (bias && e_co[e] < g.c_out) ? bias[e_co[e]] : 0.f;
   }
   for (int ho = ho0; ho < ho1; ++ho) {
     const bool more = ho + 1 < ho1;
-    // out_gate values of this wave's 8 outputs, fetched now so that their latency hides under the MFMAs
-    float og[8];
-    const int pos = wo0 + 32 * pt + l32;
+    // out_gate values of this wave's outputs, fetched now so that their latency hides under the MFMAs
+    float og[NE];
 #pragma unroll
-    for (int r8 = 0; r8 < 8; ++r8) {
-      const int r = 8 * kk + r8;
-      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
-      og[r8] = 1.f;
-      if (out_gate && co < g.c_out && pos < g.w_out)
-        og[r8] = out_gate[((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos];
+    for (int e = 0; e < NE; ++e) {
+      og[e] = 1.f;
+      if (out_gate && e_co[e] < g.c_out && pos < g.w_out)
+        og[e] = out_gate[((size_t)b * g.c_out + e_co[e]) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos];
     }
-    // two accumulation chains (even / odd channel pairs): a dependent 32x32x2 MFMA cannot start before its predecessor
-    // has left the pipe, and with one wave per SIMD nothing else would fill that gap
-    v16f acc, acc_b;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc_b[r] = 0.f;
-    // B operands of one (kt, kh) input row: 8 channel pairs x KW consecutive columns; the next row's 24 values are read
-    // while the current row's 24 MFMAs (1.5k matrix cycles) run.  The staging of the next step's new input rows (16
-    // LDS-direct instructions per kt and wave, ~50 issue cycles each) is spread over the row loop as well.
     constexpr int NR = SPLIT_CI ? KT * KH : KH;           // (kt, kh) rows this wave multiplies
     const int r0 = SPLIT_CI ? 0 : kk * KH;                // first of them
-    float bv[2][8][KW];
-    auto read_row = [&](int rr, float (&dstv)[8][KW]) {
+    // B operands of one (kt, kh) input row (24 values) are read while the previous row's MFMAs run; the staging of the
+    // next step's new input rows (16 LDS-direct instructions per kt and wave, ~50 issue cycles each) is spread over the
+    // row loop as well.  Two accumulation chains per tile: a dependent MFMA cannot start before its predecessor has left
+    // the pipe, and with one wave per SIMD nothing else would fill that gap.
+    auto row_base = [&](int rr) {
       const int kt = rr / KH, kh = rr - kt * KH;
       const int hi = ho - g.ph + kh;
       const int slot = ((hi % SLOTS) + SLOTS) % SLOTS;
-      const float* rowp = xT + b_lane + (kt * SLOTS + slot) * R;
-#pragma unroll
-      for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int kw = 0; kw < KW; ++kw) dstv[p][kw] = rowp[2 * p * CS + kw];
+      return xT + b_lane + (kt * SLOTS + slot) * R;
     };
-    read_row(r0, bv[0]);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      const int rr = r0 + i;
-      if (i + 1 < NR) read_row(rr + 1, bv[(i + 1) & 1]);
-      if (more) {   // this row's share of the staging
+    auto stage_share = [&](int i) {
+      if (more) {
         constexpr int PER = (KT * 8 + NR - 1) / NR;
 #pragma unroll
         for (int q = i * PER; q < (i + 1) * PER && q < KT * 8; ++q) stage_chan(q / 8, q % 8, ho + KH - g.ph);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    float outv[NE];   // this wave's finished values
+    if constexpr (M16) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f a0[2], a1[2];   // [N tile], two chains
 #pragma unroll
-      for (int kw = 0; kw < KW; ++kw)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int p = 0; p < 8; p += 2) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p], bv[i & 1][p][kw], acc, 0, 0, 0);
-          acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p + 1], bv[i & 1][p + 1][kw], acc_b, 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int r = 0; r < 4; ++r) a0[nt][r] = 0.f, a1[nt][r] = 0.f;
+      float bv[2][4][KW][2];
+      auto read_row = [&](int rr, float (&dstv)[4][KW][2]) {
+        const float* rowp = row_base(rr);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += acc_b[r];
-    // ---- add the two partial tiles: each wave pair parks the half of its tile that the OTHER pair finishes (registers
-    // 8kk' .. 8kk'+7, kk' = 1 - kk) in LDS, then both pairs run the epilogue on 8 registers each --------------------
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) red[(pt * 16 + 8 * (1 - kk) + r) * 64 + lane] = kk == 0 ? acc[8 + r] : acc[r];
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of the next row has landed
-    __syncthreads();
-    {
+          for (int kw = 0; kw < KW; ++kw) dstv[p][kw][0] = rowp[4 * p * CS + kw], dstv[p][kw][1] = rowp[4 * p * CS + kw + 16];
+      };
+      read_row(r0, bv[0]);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        if (i + 1 < NR) read_row(r0 + i + 1, bv[(i + 1) & 1]);
+        stage_share(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+          for (int p = 0; p < 4; p += 2)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              a0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i * KW + kw][p], bv[i & 1][p][kw][nt], a0[nt], 0, 0, 0);
+              a1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[i * KW + kw][p + 1], bv[i & 1][p + 1][kw][nt], a1[nt], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // each wave pair parks the N tile the OTHER pair finishes, then adds the partner's copy of its own tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(pt * 8 + 4 * (1 - kk) + r) * 64 + lane] = a0[1 - kk][r] + a1[1 - kk][r];
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of the next row has landed
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float mine = a0[kk][r] + a1[kk][r], other = red[(pt * 8 + 4 * kk + r) * 64 + lane];
+        outv[r] = kk == 0 ? mine + other : other + mine;   // always (lower pair's partial) + (upper pair's partial)
+      }
+    } else {
+      v16f acc, acc_b;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f, acc_b[r] = 0.f;
+      float bv[2][8][KW];
+      auto read_row = [&](int rr, float (&dstv)[8][KW]) {
+        const float* rowp = row_base(rr);
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+          for (int kw = 0; kw < KW; ++kw) dstv[p][kw] = rowp[2 * p * CS + kw];
+      };
+      read_row(r0, bv[0]);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        if (i + 1 < NR) read_row(r0 + i + 1, bv[(i + 1) & 1]);
+        stage_share(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+          for (int p = 0; p < 8; p += 2) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p], bv[i & 1][p][kw], acc, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i * KW + kw][p + 1], bv[i & 1][p + 1][kw], acc_b, 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc_b[r];
+      // each wave pair parks the half of its tile that the OTHER pair finishes (registers 8kk' .. 8kk'+7, kk' = 1 - kk)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) red[(pt * 16 + 8 * (1 - kk) + r) * 64 + lane] = kk == 0 ? acc[8 + r] : acc[r];
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's part of the next row has landed
+      __syncthreads();
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
-        const int r = 8 * kk + r8;
-        const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float mine = kk == 0 ? acc[r8] : acc[8 + r8];
-        const float other = red[(pt * 16 + r) * 64 + lane];
-        float v = kk == 0 ? mine + other : other + mine;   // always (lower pair's partial) + (upper pair's partial)
-        if (co < g.c_out && pos < g.w_out) {
-          v += kk == 0 ? bias_r[r8] : bias_r[8 + r8];
-          if (relu) v = fmaxf(v, 0.f);
-          const size_t o = ((size_t)b * g.c_out + co) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos;
-          if (!(og[r8] > 0.f)) v = 0.f;
-          y[o] = v;
-        }
+        const float other = red[(pt * 16 + 8 * kk + r8) * 64 + lane];
+        outv[r8] = kk == 0 ? mine + other : other + mine;   // always (lower pair's partial) + (upper pair's partial)
+      }
+    }
+    // ---- epilogue: bias, ReLU, out_gate, 64 / 128-byte row stores -------------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (e_co[e] < g.c_out && pos < g.w_out) {
+        float v = outv[e] + bias_r[e];
+        if (relu) v = fmaxf(v, 0.f);
+        if (!(og[e] > 0.f)) v = 0.f;
+        y[((size_t)b * g.c_out + e_co[e]) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos] = v;
       }
     }
     __syncthreads();   // red is free again before the next step's upper half writes it
@@ -1041,7 +1099,10 @@ static bool launch_mfma_s1(const float* x, const float* gate, const float* w, co
   const long long items = cols * n_hseg;
   if (items > 0x7fffffffLL) return false;
   if (gate) return false;   // an input gate cannot be applied on the global -> LDS path: the tiled kernel serves it
-  if (g.c_in > 16)
+  if (g.c_in > 16 && g.c_out <= 16)
+    conv3d_fwd_mfma_f32<2, 3, 3, true, true><<<dim3((unsigned)items), dim3(256), 0, stream>>>(
+        x, w, bias, y, g, relu, flip, w_ci_dim, out_gate, hseg, n_hseg);
+  else if (g.c_in > 16)
     conv3d_fwd_mfma_f32<2, 3, 3, true><<<dim3((unsigned)items), dim3(256), 0, stream>>>(x, w, bias, y, g, relu, flip,
                                                                                          w_ci_dim, out_gate, hseg, n_hseg);
   else

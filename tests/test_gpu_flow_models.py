@@ -24,6 +24,13 @@ CASES = [  # (B, Ci, Co, T, H, W, kernel, stride, padding)
     (1, 32, 32, 3, 9, 150, (2, 3, 3), (1, 1, 1), (0, 1, 1)),
     (1, 20, 24, 4, 8, 70, (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 17, 32, 2, 6, 33, (1, 3, 3), (1, 1, 1), (0, 1, 0)),
+    # rows >= 64 columns wide, (2,3,3), unit stride: the f32-MFMA forward / dgrad (conv3d_fwd_mfma_f32) in its three
+    # forms -- channel-half split (c_in > 16), tap-plane split (c_in = 16), 16-row tiles (c_out <= 16) -- with ragged
+    # column tiles, several row segments and time padding
+    (2, 16, 32, 3, 10, 70, (2, 3, 3), (1, 1, 1), (0, 1, 1)),    # fwd: tap-plane split; dgrad (32 -> 16): 16-row tiles
+    (1, 24, 12, 4, 9, 100, (2, 3, 3), (1, 1, 1), (0, 1, 1)),    # fwd: 16-row tiles, ragged channel counts
+    (1, 32, 16, 2, 40, 64, (2, 3, 3), (1, 1, 1), (0, 1, 1)),    # one full column tile, five row segments
+    (2, 32, 32, 3, 7, 129, (2, 3, 3), (1, 1, 1), (1, 1, 1)),    # time padding, a single ragged column in the third tile
 ]
 
 
