@@ -273,6 +273,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
   constexpr uint32_t INVALID = 0x40000000u;
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * g.c_in * vox_in), 0,
                                                                         (int)(g.c_in * vox_in * 4), 0x00020000);
+  const bool gated = out_gate != nullptr;
+  const __amdgpu_buffer_rsrc_t grs_out = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(gated ? out_gate + (size_t)b * g.c_out * vox_out : y), 0, gated ? (int)(g.c_out * vox_out * 4) : 0, 0x00020000);
   uint32_t col_off[2];   // byte offset of this lane's column inside an input row, per 64-column segment
 #pragma unroll
   for (int sgm = 0; sgm < 2; ++sgm) {
@@ -319,13 +322,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
   }
   for (int ho = ho0; ho < ho1; ++ho) {
     const bool more = ho + 1 < ho1;
-    // out_gate values of this wave's outputs, fetched now so that their latency hides under the MFMAs
+    // out_gate values of this wave's outputs, fetched now so that their latency hides under the MFMAs.  Branch-free raw
+    // buffer loads (no gate: a zero-sized resource, every load returns 0 and `gated` is false): a conditional load would
+    // be waited for at the join of its branch, eight serialized memory latencies per step (measured +6.5k cycles).
     float og[NE];
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-      og[e] = 1.f;
-      if (out_gate && e_co[e] < g.c_out && pos < g.w_out)
-        og[e] = out_gate[((size_t)b * g.c_out + e_co[e]) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos];
+      const bool ok = e_co[e] < g.c_out && pos < g.w_out;
+      const uint32_t off = ok ? (uint32_t)(((size_t)e_co[e] * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos) * 4)
+                              : INVALID;
+      og[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs_out, off, 0, 0));
     }
     constexpr int NR = SPLIT_CI ? KT * KH : KH;           // (kt, kh) rows this wave multiplies
     const int r0 = SPLIT_CI ? 0 : kk * KH;                // first of them
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_mfma_f32(const float* __res
       if (e_co[e] < g.c_out && pos < g.w_out) {
         float v = outv[e] + bias_r[e];
         if (relu) v = fmaxf(v, 0.f);
-        if (!(og[e] > 0.f)) v = 0.f;
+        if (gated && !(og[e] > 0.f)) v = 0.f;
         y[((size_t)b * g.c_out + e_co[e]) * vox_out + (size_t)to * plane_out + (size_t)ho * g.w_out + pos] = v;
       }
     }
@@ -1090,6 +1096,7 @@ static bool launch_mfma_s1(const float* x, const float* gate, const float* w, co
   if (!(g.kt == 2 && g.kh == 3 && g.kw == 3)) return false;
   if (g.c_in < 16 || g.c_in > 32 || g.c_out > 32 || g.w_out < 64) return false;
   if ((size_t)g.c_in * g.t_in * g.h_in * g.w_in * 4 > 0x40000000ull) return false;   // 32-bit raw-buffer offsets
+  if ((size_t)g.c_out * g.t_out * g.h_out * g.w_out * 4 > 0x40000000ull) return false;
   const int n_wt = (g.w_out + 63) / 64;
   const long long cols = (long long)batch * g.t_out * n_wt;
   // output rows are marched in segments; enough segments for ~2 work items per CU, none shorter than 8 rows
