@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void conv3d_general_fwd_f32(const float* __res
 #pragma unroll
           for (int kw = 0; kw < kw_n; ++kw) {
             int wi = w0 + kw;
-            float xv = 0.f;
-            if (h_ok && (unsigned)wi < (unsigned)g.w_in) xv = xc[(size_t)ti * plane_in + (size_t)hi * g.w_in + wi];
+            // unconditional load from a clamped address + select: a load inside an `if` is waited for at the join of
+            // its branch, one memory latency per tap instead of one per batch of taps
+            const bool ok = h_ok && (unsigned)wi < (unsigned)g.w_in;
+            float xv = xc[ok ? (size_t)ti * plane_in + (size_t)hi * g.w_in + wi : 0];
+            xv = ok ? xv : 0.f;
             const float* wt = wc + ((kt * kh_n + kh) * kw_n + kw) * GCO;
 #pragma unroll
             for (int j = 0; j < GCO; ++j) acc[j] = fmaf(xv, wt[j], acc[j]);
@@ -484,7 +487,8 @@ __global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __r
     for (int j = 0; j < GCO; ++j) acc[j] = 0.f;
     for (int co = 0; co < g.c_out; ++co) {
       const float* dc = dy + ((size_t)b * g.c_out + co) * vox_out;
-      const float* gc = gate ? gate + ((size_t)b * g.c_out + co) * vox_out : nullptr;
+      const bool gated = gate != nullptr;
+      const float* gc = gated ? gate + ((size_t)b * g.c_out + co) * vox_out : dc;
       const float* wc = wl + (size_t)co * taps * GCO;
 #pragma unroll
       for (int kt = 0; kt < kt_n; ++kt) {
@@ -500,12 +504,13 @@ __global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __r
           for (int kw = 0; kw < kw_n; ++kw) {
             int nw = wi + g.pw - kw;
             int wo = nw / g.sw;
-            float d = 0.f;
-            if (h_ok && nw >= 0 && wo * g.sw == nw && wo < g.w_out) {
-              size_t off = (size_t)to * plane_out + (size_t)ho * g.w_out + wo;
-              d = dc[off];
-              if (gc && !(gc[off] > 0.f)) d = 0.f;
-            }
+            // unconditional loads from a clamped address + selects (see conv3d_general_fwd_f32); without a gate the
+            // "gate" pointer is dy itself and its value is ignored
+            const bool ok = h_ok && nw >= 0 && wo * g.sw == nw && wo < g.w_out;
+            const size_t off = ok ? (size_t)to * plane_out + (size_t)ho * g.w_out + wo : 0;
+            float d = dc[off];
+            const float gv = gc[off];
+            d = (ok && !(gated && !(gv > 0.f))) ? d : 0.f;
             const float* wt = wc + ((kt * kh_n + kh) * kw_n + kw) * GCO;
 #pragma unroll
             for (int j = 0; j < GCO; ++j) acc[j] = fmaf(d, wt[j], acc[j]);
@@ -513,11 +518,20 @@ __global__ __launch_bounds__(256) void conv3d_general_dgrad_f32(const float* __r
         }
       }
     }
+    // the out_gate values of the GCO channels are fetched back to back (no gate: dx's own, ignored, contents)
+    const bool og_on = out_gate != nullptr;
+    const float* ogp = og_on ? out_gate : dx;
+    float ogv[GCO];
+#pragma unroll
+    for (int j = 0; j < GCO; ++j) {
+      const int cj = min(ci0 + j, g.c_in - 1);
+      ogv[j] = ogp[((size_t)b * g.c_in + cj) * vox_in + v];
+    }
 #pragma unroll
     for (int j = 0; j < GCO; ++j)
       if (ci0 + j < g.c_in) {
         const size_t off = ((size_t)b * g.c_in + ci0 + j) * vox_in + v;
-        dx[off] = (out_gate && !(out_gate[off] > 0.f)) ? 0.f : acc[j];
+        dx[off] = (og_on && !(ogv[j] > 0.f)) ? 0.f : acc[j];
       }
   }
 }
