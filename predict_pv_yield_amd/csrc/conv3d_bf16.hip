@@ -481,9 +481,8 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float
       uint16_t h[4][CPAD];
 #pragma unroll
       for (int k = 0; k < CPAD; ++k) {
-        // unconditional load from a clamped plane + select (a load inside an `if` is waited for at the join of its branch)
-        f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)min(k, c - 1) * vox_per_sample);
-        if (k >= c) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (k < c) a = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
 #pragma unroll
         for (int q = 0; q < 4; ++q) h[q][k] = f32_to_bf16_bits(a[q]);
       }
@@ -639,12 +638,11 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
       uint16_t h[4][32];
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
-        // unconditional loads from a clamped plane + selects; without a mask the "mask" pointer is dy itself, ignored
-        const size_t po = base + (size_t)min(k, c - 1) * vox_per_sample;
-        u32x2 d = *reinterpret_cast<const u32x2*>(dy + po);
-        u32x2 g = *reinterpret_cast<const u32x2*>((yv ? yv : dy) + po);
-        if (!yv) g = (u32x2){0x3f803f80u, 0x3f803f80u};
-        if (k >= c) d = (u32x2){0u, 0u};
+        u32x2 d = {0u, 0u}, g = {0x3f803f80u, 0x3f803f80u};
+        if (k < c) {
+          d = *reinterpret_cast<const u32x2*>(dy + base + (size_t)k * vox_per_sample);
+          if (yv) g = *reinterpret_cast<const u32x2*>(yv + base + (size_t)k * vox_per_sample);
+        }
         d[0] = gate_word(d[0], g[0]);
         d[1] = gate_word(d[1], g[1]);
         h[0][k] = (uint16_t)(d[0] & 0xffffu); h[1][k] = (uint16_t)(d[0] >> 16);
