@@ -185,7 +185,18 @@ class DeviceBatchPrefetcher:
                 if isinstance(item, BaseException):
                     raise item
                 batch, done = item
-                torch.cuda.current_stream(self.device).wait_event(done)
+                consumer = torch.cuda.current_stream(self.device)
+                consumer.wait_event(done)
+                # the tensors were allocated under the side stream: tell the caching allocator that the consumer's stream
+                # uses them too, otherwise a block freed by the consumer is handed back to the side-stream pool at once
+                # and the reader thread may overwrite it (batch N+depth+1's copy) while kernels of batch N still read it
+                for name in BatchML.SECTIONS:
+                    sec = getattr(batch, name)
+                    if sec is None:
+                        continue
+                    for v in vars(sec).values():
+                        if isinstance(v, torch.Tensor) and v.is_cuda:
+                            v.record_stream(consumer)
                 yield batch
         finally:
             stop.set()

@@ -105,16 +105,33 @@ def reduce_scatter_rows(full: torch.Tensor):
     return full[r0:r1], work
 
 
+_GATHER_STAGING = {}
+
+
+def _gather_staging(full: torch.Tensor, rows: int) -> torch.Tensor:
+    """One persistent staging buffer per (matrix, shard shape): the all-gather's input must not alias its output, but
+    it does not have to be a fresh allocation every step (it was: 1/W of the matrix cloned per call)."""
+    key = (full.data_ptr(), rows, tuple(full.shape[1:]), full.dtype, str(full.device))
+    buf = _GATHER_STAGING.get(key)
+    if buf is None:
+        if len(_GATHER_STAGING) > 16:
+            _GATHER_STAGING.clear()
+        buf = torch.empty((rows,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+        _GATHER_STAGING[key] = buf
+    return buf
+
+
 def all_gather_rows(full: torch.Tensor, async_op: bool = True):
     """Every rank contributes its own row shard of `full` [N, K] (already written in place) and receives the others."""
     r0, r1 = row_shard(full.shape[0])
-    mine = full[r0:r1].clone()       # 1/W of the matrix; keeps the collective's input distinct from its output
+    mine = _gather_staging(full, r1 - r0)
+    mine.copy_(full[r0:r1])          # 1/W of the matrix; keeps the collective's input distinct from its output
     if dist.get_backend() == "nccl":
         return dist.all_gather_into_tensor(full, mine, async_op=async_op)
     world = dist.get_world_size()
     per = r1 - r0
     chunks = [torch.empty_like(mine) for _ in range(world)]
-    work = dist.all_gather(chunks, mine, async_op=False)
+    dist.all_gather(chunks, mine, async_op=False)
     for r, c in enumerate(chunks):
         full[r * per:(r + 1) * per].copy_(c)
     return None
@@ -133,6 +150,8 @@ class OverlappedGradSync:
         self.small = [p for p in module.parameters() if p.requires_grad and p.numel() < large_numel]
         self._pending = []
         self._handles = []
+        self._flat = None          # the small-gradient bucket, laid out once (finish())
+        self._flat_key = None
         if is_distributed():
             for p in self.large:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._launch))
@@ -165,13 +184,22 @@ class OverlappedGradSync:
             params = [q for q in params if q.grad.dtype == ref.dtype and q.grad.device == ref.device]
             # one flat bucket, segments aligned to 16 bytes; after the all-reduce every .grad BECOMES its segment of the
             # bucket (a view), so nothing is copied back and the multi-tensor Adam reads the bucket directly
-            offs, total = [], 0
-            for p in params:
-                offs.append(total)
-                total += (p.grad.numel() + 3) // 4 * 4
-            flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-            views = [flat[o:o + p.grad.numel()].view_as(p.grad) for o, p in zip(offs, params)]
-            torch._foreach_copy_(views, [p.grad for p in params])
+            key = (tuple(id(p) for p in params), ref.dtype, ref.device)
+            if self._flat is None or self._flat_key != key:
+                # laid out once: the bucket and its per-parameter views persist across steps (the padding between
+                # segments is zeroed here and never written again)
+                offs, total = [], 0
+                for p in params:
+                    offs.append(total)
+                    total += (p.grad.numel() + 3) // 4 * 4
+                self._flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+                self._views = [self._flat[o:o + p.grad.numel()].view_as(p.grad) for o, p in zip(offs, params)]
+                self._flat_key = key
+            flat, views = self._flat, self._views
+            src = [p.grad for p in params]
+            stale = [(v, g) for v, g in zip(views, src) if g.data_ptr() != v.data_ptr()]
+            if stale:       # a gradient that already IS its bucket segment (accumulated in place) needs no copy
+                torch._foreach_copy_([v for v, _ in stale], [g for _, g in stale])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             for p, v in zip(params, views):
                 p.grad = v
@@ -201,11 +229,15 @@ def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, 
 
 
 def shard_range(n_items: int, rank: int = None, world: int = None):
-    """Contiguous shard of independent units (samples, flow pairs) for this rank: no collective needed."""
+    """Contiguous shard of independent units (whole batches, samples, flow pairs) for this rank: no collective needed.
+    EVERY rank gets the same count, n_items // world (the tail n_items % world is dropped, DistributedSampler's
+    drop_last): the train loop issues collectives every step, so a rank with fewer steps would leave the others
+    waiting in a gradient exchange it never joins.  Fewer items than ranks is an error, not an empty shard."""
     if rank is None:
         rank = dist.get_rank() if is_distributed() else 0
     if world is None:
         world = dist.get_world_size() if is_distributed() else 1
-    per = (n_items + world - 1) // world
-    lo = min(rank * per, n_items)
-    return lo, min(lo + per, n_items)
+    per = n_items // world
+    if per == 0:
+        raise ValueError(f"shard_range: {n_items} item(s) cannot be split over {world} ranks (every rank needs >= 1)")
+    return rank * per, (rank + 1) * per

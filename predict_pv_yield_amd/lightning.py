@@ -26,6 +26,9 @@ from torch import nn
 
 log = logging.getLogger(__name__)
 
+# checkpoint dialect written by ModelCheckpoint (the reference pins pytorch-lightning 1.4/1.5, requirements.txt)
+PL_COMPAT_VERSION = "1.5.10"
+
 
 def seed_everything(seed: int, workers: bool = False) -> int:
     random.seed(seed)
@@ -157,8 +160,13 @@ class ModelCheckpoint(Callback):
             if hasattr(o, "consolidate_sharded"):
                 o.consolidate_sharded()
         if trainer.is_global_zero:
-            torch.save({"state_dict": module.state_dict(), "epoch": trainer.current_epoch,
+            # the keys pytorch_lightning 1.4/1.5 writes and its resume path indexes without a default
+            # (`lr_schedulers`, `callbacks`); `epoch` follows PL's convention: the NEXT epoch to run, restored as-is
+            torch.save({"state_dict": module.state_dict(), "epoch": trainer.current_epoch + 1,
                         "global_step": trainer.global_step,
+                        "pytorch-lightning_version": PL_COMPAT_VERSION,
+                        "callbacks": {}, "lr_schedulers": [],
+                        "hyper_parameters": dict(getattr(module, "hparams", {}) or {}),
                         "optimizer_states": [o.state_dict() for o in trainer.optimizers]}, path)
 
     def on_validation_end(self, trainer, module):
@@ -235,7 +243,7 @@ class Trainer:
                  resume_from_checkpoint=None, precision=32, weights_summary=None, progress_bar_refresh_rate=None,
                  profiler=None, limit_train_batches=1.0, limit_val_batches=1.0, limit_test_batches=1.0,
                  num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
-                 default_root_dir=None, **unused):
+                 default_root_dir=None, log_every_n_steps=50, **unused):
         self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
         self.fast_dev_run = bool(fast_dev_run)
         self.callbacks: List[Callback] = list(callbacks or [])
@@ -251,7 +259,9 @@ class Trainer:
         self.max_steps = max_steps
         self.terminate_on_nan = terminate_on_nan
         self.current_epoch, self.global_step = 0, 0
-        self.callback_metrics: Dict[str, float] = {}
+        self._callback_metrics: Dict[str, float] = {}
+        self._pending_logs: List[tuple] = []
+        self.log_every_n_steps = max(1, int(log_every_n_steps))
         self.should_stop = False
         self.sanity_checking = False
         self.optimizers: List[torch.optim.Optimizer] = []
@@ -282,29 +292,59 @@ class Trainer:
         return not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
 
     # -- metric plumbing ------------------------------------------------------------------------
+    # Logged values stay DEVICE tensors until they are needed as floats: `_record` stacks one log_dict call into one
+    # small f64 vector (and, for sync_dist, enqueues ONE all-reduce of that vector on the device -- a collective at a
+    # fixed program point on every rank, no host wait); `_drain` turns the backlog into floats with one `.tolist()` per
+    # entry.  Drained every `log_every_n_steps` train steps, at every epoch flush and whenever `callback_metrics` is
+    # read -- so the train step itself never blocks the host between forward and backward.
+    @property
+    def callback_metrics(self) -> Dict[str, float]:
+        self._drain()
+        return self._callback_metrics
+
     def _record(self, dictionary, on_step=None, on_epoch=None, sync_dist=False):
-        vals = {k: _to_float(v) for k, v in dictionary.items()}
+        keys = list(dictionary)
+        vals = [dictionary[k] for k in keys]
+        tensors = [v for v in vals if isinstance(v, torch.Tensor)]
+        dev = next((v.device for v in tensors if v.is_cuda), torch.device("cpu"))
+        if tensors:
+            vec = torch.stack([(v.detach().to(dtype=torch.float64).mean().to(dev) if isinstance(v, torch.Tensor)
+                                else torch.tensor(float(v), dtype=torch.float64, device=dev)) for v in vals])
+        else:
+            vec = torch.tensor([float(v) for v in vals], dtype=torch.float64)
         if sync_dist and self.world_size > 1:
-            from .distributed import all_reduce_mean_scalars
-            vals = all_reduce_mean_scalars(vals, device=self.device)
-        step_metrics = {}
-        for k, v in vals.items():
-            if on_step is not False:
-                self.callback_metrics[f"{k}_step" if on_epoch else k] = v
-                step_metrics[f"{k}_step" if on_epoch else k] = v
-            if on_epoch:
-                self._epoch_acc.setdefault(k, []).append(v)
-        if step_metrics and self.is_global_zero:
-            for lg in self.loggers:
-                lg.log_metrics(step_metrics, self.global_step)
+            if torch.distributed.get_backend() != "nccl":
+                vec = vec.cpu()
+            elif not vec.is_cuda:
+                vec = vec.to(self.device)
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
+            vec = vec / self.world_size
+        self._pending_logs.append((keys, vec, on_step, on_epoch, self.global_step))
+
+    def _drain(self):
+        if not self._pending_logs:
+            return
+        pending, self._pending_logs = self._pending_logs, []
+        for keys, vec, on_step, on_epoch, step in pending:
+            step_metrics = {}
+            for k, v in zip(keys, vec.tolist()):
+                if on_step is not False:
+                    self._callback_metrics[f"{k}_step" if on_epoch else k] = v
+                    step_metrics[f"{k}_step" if on_epoch else k] = v
+                if on_epoch:
+                    self._epoch_acc.setdefault(k, []).append(v)
+            if step_metrics and self.is_global_zero:
+                for lg in self.loggers:
+                    lg.log_metrics(step_metrics, step)
 
     def _flush_epoch(self):
+        self._drain()
         out = {}
         for k, vs in self._epoch_acc.items():
             if vs:
                 out[f"{k}_epoch"] = float(np.mean(vs))
                 out[k] = out[f"{k}_epoch"]
-        self.callback_metrics.update(out)
+        self._callback_metrics.update(out)
         if out and self.is_global_zero:
             for lg in self.loggers:
                 lg.log_metrics({k: v for k, v in out.items() if k.endswith("_epoch")}, self.global_step)
@@ -330,6 +370,11 @@ class Trainer:
         return int(lim)
 
     def _attach(self, model, datamodule=None):
+        # `python -m torch.distributed.run --nproc-per-node N run.py ...`: join the process group from
+        # torchrun's environment HERE, in this process, before the module touches the GPU.  Without it every rank
+        # would see world_size 1 and train the whole dataset on its own, racing on the same checkpoint files.
+        from .distributed import init_from_env
+        init_from_env()
         self.model = model
         model.trainer = self
         if datamodule is not None:
@@ -387,7 +432,7 @@ class Trainer:
             model.load_state_dict(ckpt["state_dict"])
             for o, s in zip(self.optimizers, ckpt.get("optimizer_states", [])):
                 o.load_state_dict(s)
-            self.current_epoch = ckpt.get("epoch", -1) + 1
+            self.current_epoch = ckpt.get("epoch", 0)      # PL convention: the stored value is the next epoch to run
             self.global_step = ckpt.get("global_step", 0)
         if self.world_size > 1:
             from .distributed import broadcast_parameters
@@ -400,8 +445,18 @@ class Trainer:
                     # matrix and the bf16 operand copy is all-gathered (falls back to a bf16 all-reduce when the rows
                     # do not divide over the ranks)
                     o.set_large_grad_mode("sharded")
-            from .distributed import OverlappedGradSync
-            self._grad_sync = OverlappedGradSync(model)
+            # the in-backward exchange leaves SUMS; only optimisers that fold 1/world into their update (HipAdam) can
+            # consume them.  Any other optimiser gets the plain averaged all-reduce after backward (no hooks: a hook
+            # would have summed the large gradients already and they would be reduced twice)
+            self._fold_mean = all(hasattr(o, "grad_scale") for o in self.optimizers)
+            if self._fold_mean:
+                from .distributed import OverlappedGradSync
+                self._grad_sync = OverlappedGradSync(model)
+            else:
+                self._grad_sync = None
+                for o in self.optimizers:
+                    if hasattr(o, "set_large_grad_mode"):
+                        o.set_large_grad_mode("autograd")
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
         max_epochs = 1 if self.fast_dev_run else self.max_epochs
@@ -416,19 +471,20 @@ class Trainer:
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
-                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():
-                    raise ValueError("loss is NaN or inf")
                 self._timed("backward", loss.backward)
+                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():   # host wait: after backward is queued
+                    raise ValueError("loss is NaN or inf")
                 if self.world_size > 1:
                     from .distributed import all_reduce_gradients
-                    fold = all(hasattr(o, "grad_scale") for o in self.optimizers)
-                    if fold and getattr(self, "_grad_sync", None) is not None:
+                    if self._grad_sync is not None:
                         self._timed("grad_all_reduce", self._grad_sync.finish)   # large grads were launched in backward
                     else:
                         self._timed("grad_all_reduce", all_reduce_gradients, model, True)
                 for o in self.optimizers:
                     self._timed("optimizer_step", o.step)
                 self.global_step += 1
+                if self.global_step % self.log_every_n_steps == 0:
+                    self._drain()
                 if self.max_steps and self.global_step >= self.max_steps:
                     self.should_stop = True
                     break
@@ -446,6 +502,9 @@ class Trainer:
         for o in self.optimizers:          # sharded large-parameter update: make every rank's f32 copy complete
             if hasattr(o, "consolidate_sharded"):
                 o.consolidate_sharded()
+        if getattr(self, "_grad_sync", None) is not None:
+            self._grad_sync.remove()
+            self._grad_sync = None
         for cb in self.callbacks:
             cb.on_fit_end(self, model)
         self._finish()

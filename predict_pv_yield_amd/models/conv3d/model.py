@@ -102,11 +102,21 @@ class Model(BaseModel):
         return bf16_tower_supported(self.number_sat_channels, self.conv3d_channels, self.cnn_output_size)
 
     def _satellite_input(self, x: BatchML) -> torch.Tensor:
-        sat_data = x.satellite.data.float()  # [B, C, T, H, W]  (model.py:112-114)
+        sat = x.satellite.data
         if self.future_frames == "optical_flow":
+            if sat.dtype == torch.int16:
+                # config 3 proper: the batch carries the OBSERVED frames only, as raw 10-bit counts in
+                # the zarr's time-major order [B, T_obs, C, H, W] (13_...ipynb:415-441).  Flow is computed on the
+                # counts, frames are normalised, and the forecast_len_5 future slices are advected from the last
+                # observed frame -- one device-resident pipeline straight into the model input [B, C, T, H, W].
+                from ...optical_flow import advect_future_frames
+                if sat.dim() != 5 or sat.shape[1] != self.history_len_5 + 1 or sat.shape[2] != self.number_sat_channels:
+                    raise ValueError(f"raw satellite counts must be [B, {self.history_len_5 + 1}, "
+                                     f"{self.number_sat_channels}, H, W] int16, got {tuple(sat.shape)}")
+                return advect_future_frames(sat, n_future=self.forecast_len_5)
             from ...optical_flow import replace_future_frames_with_flow
-            sat_data = replace_future_frames_with_flow(sat_data, n_future=self.forecast_len_5)
-        return sat_data
+            return replace_future_frames_with_flow(sat.float(), n_future=self.forecast_len_5)
+        return sat.float()  # [B, C, T, H, W]  (model.py:112-114)
 
     def forward(self, x):
         if type(x) == dict:

@@ -11,16 +11,18 @@ import predict_pv_yield_amd
 from .hydra_lite import DictConfig, to_yaml
 
 
+def _repo_root() -> str:
+    return os.path.normpath(os.path.join(os.path.dirname(predict_pv_yield_amd.__file__), os.pardir))
+
+
 def load_config(config_file):
-    """Open a yaml configuration file and drop the `_target_` line (utils.py:16-32); paths are relative to the
-    repository root like the reference (`configs/model/conv3d.yaml`, `tests/configs/model/conv3d.yaml`)."""
-    path = os.path.dirname(predict_pv_yield_amd.__file__)
-    full = config_file if os.path.isabs(config_file) else f"{path}/../{config_file}"
-    with open(full, "r") as cfg:
-        config = yaml.load(cfg, Loader=yaml.FullLoader)
-    if "_target_" in config.keys():
-        config.pop("_target_")  # This is only for Hydra
-    return config
+    """yaml file -> constructor kwargs: the mapping with Hydra's `_target_` entry removed, so tests can call
+    `Model(**load_config("tests/configs/model/conv3d.yaml"))` (contract of predict_pv_yield/utils.py:16-32).
+    Relative paths resolve against the repository root, like the reference's."""
+    location = config_file if os.path.isabs(config_file) else os.path.join(_repo_root(), config_file)
+    with open(location, "r") as stream:
+        mapping = yaml.safe_load(stream)
+    return {key: value for key, value in mapping.items() if key != "_target_"}
 
 
 def _is_rank_zero() -> bool:
@@ -37,8 +39,14 @@ def get_logger(name=__name__, level=logging.INFO) -> logging.Logger:
     return logger
 
 
+# what a debugger-friendly run switches off (section, key, replacement) -- predict_pv_yield/utils.py:77-85
+_FAST_DEV_RUN_OVERRIDES = (("trainer", "gpus", 0), ("datamodule", "pin_memory", False), ("datamodule", "num_workers", 0))
+
+
 def extras(config: DictConfig) -> None:
-    """utils.py:49-88: ignore_warnings, debug -> fast_dev_run, fast_dev_run -> debug-friendly settings."""
+    """Optional conveniences driven by the main config, applied in place (contract of utils.py:49-88):
+    `ignore_warnings` silences python warnings; `debug` turns on `trainer.fast_dev_run`; and a fast_dev_run drops GPUs,
+    pinned memory and loader workers (whatever is currently enabled)."""
     log = get_logger()
     if config.get("ignore_warnings"):
         log.info("Disabling python warnings! <config.ignore_warnings=True>")
@@ -46,14 +54,12 @@ def extras(config: DictConfig) -> None:
     if config.get("debug"):
         log.info("Running in debug mode! <config.debug=True>")
         config.trainer.fast_dev_run = True
-    if config.trainer.get("fast_dev_run"):
-        log.info("Forcing debugger friendly configuration! <config.trainer.fast_dev_run=True>")
-        if config.trainer.get("gpus"):
-            config.trainer.gpus = 0
-        if config.datamodule.get("pin_memory"):
-            config.datamodule.pin_memory = False
-        if config.datamodule.get("num_workers"):
-            config.datamodule.num_workers = 0
+    if not config.trainer.get("fast_dev_run"):
+        return
+    log.info("Forcing debugger friendly configuration! <config.trainer.fast_dev_run=True>")
+    for section, key, off in _FAST_DEV_RUN_OVERRIDES:
+        if config[section].get(key):
+            config[section][key] = off
 
 
 def print_config(config: DictConfig,
@@ -86,21 +92,28 @@ def empty(*args, **kwargs):
     pass
 
 
+def _parameter_census(model) -> dict:
+    counts = {"total": 0, "trainable": 0, "not_trainable": 0}
+    for p in (model.parameters() if hasattr(model, "parameters") else ()):
+        n = p.numel()
+        counts["total"] += n
+        counts["trainable" if p.requires_grad else "not_trainable"] += n
+    return {f"model/params_{k}": v for k, v in counts.items()}
+
+
 def log_hyperparameters(config: DictConfig, model, datamodule, trainer, callbacks: List, logger: List) -> None:
-    """utils.py:136-177: send config sections and parameter counts to all loggers."""
+    """Rank 0 sends the trainer / model / datamodule (and seed / callbacks when present) config sections plus the
+    model's parameter counts to the trainer's loggers, once: afterwards `log_hyperparams` is made a no-op so the
+    trainer does not log the module's own hparams again (contract of utils.py:136-177)."""
     if not _is_rank_zero():
         return
-    hparams = {"trainer": config["trainer"], "model": config["model"], "datamodule": config["datamodule"]}
-    if "seed" in config:
-        hparams["seed"] = config["seed"]
-    if "callbacks" in config:
-        hparams["callbacks"] = config["callbacks"]
-    params = list(model.parameters()) if hasattr(model, "parameters") else []
-    hparams["model/params_total"] = sum(p.numel() for p in params)
-    hparams["model/params_trainable"] = sum(p.numel() for p in params if p.requires_grad)
-    hparams["model/params_not_trainable"] = sum(p.numel() for p in params if not p.requires_grad)
-    if trainer.logger is not None:
-        trainer.logger.log_hyperparams(hparams)
+    hparams = {name: config[name] for name in ("trainer", "model", "datamodule")}
+    hparams.update({name: config[name] for name in ("seed", "callbacks") if name in config})
+    hparams.update(_parameter_census(model))
+    target = trainer.logger
+    if target is not None:
+        target.log_hyperparams(hparams)
+        target.log_hyperparams = empty
 
 
 def finish(config: DictConfig, model, datamodule, trainer, callbacks: List, logger: List) -> None:

@@ -63,7 +63,15 @@ def _worker(rank, world, port, ret):
     assert D.all_gather_rows(mat) is None   # gloo: synchronous
     assert torch.equal(mat[:8], torch.ones(8, 3)) and torch.equal(mat[8:], torch.full((8, 3), 2.0))
     lo, hi = D.shard_range(11)
-    assert (lo, hi) == ((0, 6) if rank == 0 else (6, 11))      # independent units: disjoint shards, no collective
+    # independent units: disjoint shards, no collective -- and the SAME count on every rank (the tail item is dropped):
+    # the train loop issues collectives every step, so unequal step counts would deadlock
+    assert (lo, hi) == ((0, 5) if rank == 0 else (5, 10))
+    for n, w in ((24900, 8), (10, 4), (10, 8), (7, 2)):
+        spans = [D.shard_range(n, r, w) for r in range(w)]
+        assert len({b - a for a, b in spans}) == 1 and spans[0][0] == 0 and all(s[1] == t[0] for s, t in zip(spans, spans[1:]))
+        assert spans[-1][1] == (n // w) * w
+    with pytest.raises(ValueError):
+        D.shard_range(3, 0, 8)                                   # fewer items than ranks: hard error, not an empty shard
     # the Trainer drives the same helpers: a toy fit keeps the replicas identical
     from predict_pv_yield_amd import lightning as pl
 
@@ -105,3 +113,78 @@ def test_two_rank_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret.get(0) and ret.get(1)
+
+
+def _trainer_worker(rank, world, port, tmp, ret):
+    """What `python -m torch.distributed.run --nproc-per-node 2 run.py ...` gives a rank: torchrun's environment and
+    nothing else.  The Trainer itself must join the process group (it did not, so every rank trained alone
+    and raced on the same checkpoint files)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.dataloader import NetCDFDataModule
+    assert not dist.is_initialized()
+
+    class Toy(pl.LightningModule):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 1)
+            self.seen = []
+
+        def forward(self, batch):
+            return self.lin(batch["satellite"]["data"].float().mean(dim=(1, 2, 3))[:, :4])
+
+        def training_step(self, batch, i):
+            self.seen.append(float(batch["satellite"]["data"].float().sum()))
+            loss = (self(batch) ** 2).mean()
+            self.log_dict({"L/Train": loss}, on_step=True, on_epoch=True, sync_dist=True)
+            return loss
+
+        def validation_step(self, batch, i):
+            self.log_dict({"L/Validation": (self(batch) ** 2).mean()}, on_step=True, on_epoch=True, sync_dist=True)
+
+        def configure_optimizers(self):
+            return torch.optim.SGD(self.parameters(), lr=0.05)      # no grad_scale: the averaged all-reduce path
+
+    if rank != 0:
+        def no_write(*a, **k):
+            raise AssertionError("only rank 0 may write checkpoints")
+        torch.save = no_write
+    torch.manual_seed(7 + rank)                                     # ranks start DIFFERENT: fit must broadcast rank 0's
+    toy = Toy()
+    dm = NetCDFDataModule(fake_data=True, n_train_data=5, n_val_data=2, data_path=os.path.join(tmp, "none"), batch_size=2)
+    ck = pl.ModelCheckpoint(dirpath=os.path.join(tmp, "ckpt"), save_last=True, save_top_k=0)
+    logger = pl.CSVLogger(save_dir=tmp, name="csv")
+    tr = pl.Trainer(gpus=0, max_epochs=1, callbacks=[ck], logger=logger)
+    tr.fit(toy, datamodule=dm)
+    assert dist.is_initialized() and tr.world_size == 2 and tr.is_global_zero == (rank == 0)
+    assert len(toy.seen) == 2                                       # 5 train batches over 2 ranks: 2 each, the tail is dropped
+    w = torch.cat([p.detach().flatten() for p in toy.parameters()])
+    ws = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    assert torch.equal(ws[0], ws[1])                                # replicas stayed identical
+    seen = [None, None]
+    dist.all_gather_object(seen, toy.seen)
+    assert not set(seen[0]) & set(seen[1])                          # disjoint data shards
+    ms = [None, None]
+    dist.all_gather_object(ms, tr.callback_metrics["L/Train_epoch"])
+    assert abs(ms[0] - ms[1]) < 1e-12
+    ret[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_trainer_joins_the_process_group_from_torchrun_env(tmp_path):
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, port, str(tmp_path), ret), nprocs=world, join=True)
+    assert ret.get(0) and ret.get(1)
+    assert os.path.exists(tmp_path / "ckpt" / "last.ckpt")
+    ck = torch.load(tmp_path / "ckpt" / "last.ckpt")
+    assert {"state_dict", "epoch", "global_step", "optimizer_states", "pytorch-lightning_version", "callbacks",
+            "lr_schedulers", "hyper_parameters"} <= set(ck)
+    assert ck["epoch"] == 1 and ck["global_step"] == 2             # PL convention: the next epoch to run
+    assert os.path.exists(tmp_path / "csv" / "version_0" / "metrics.csv")
