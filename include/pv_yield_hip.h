@@ -410,11 +410,14 @@ int pv_gru_seq_bwd_f32(const float* dout, const float* dh_last, const float* h0,
 /* replaces: F.mse_loss / (y_hat−y).abs().mean() and WeightedLosses.get_mse_exp/get_mae_exp
  * (predict_pv_yield/models/base_model.py:98-103).  out: device f32[4] = {mse, nmae, mse_exp, mae_exp};
  * grad (may be NULL): d nmae / d y_hat = sign(y_hat−y)/(m*n) * grad_scale.
+ * per_horizon (may be NULL): device f32[2n] = {mse per forecast step [n], mae per forecast step [n]}, the batch-axis
+ * means of nowcasting_utils' mse_each_forecast_horizon / mae_each_forecast_horizon (base_model.py:121-141),
+ * produced by the same launch.
  * y is read with row stride y_row_stride (elements) so the slice y[:, -forecast_len:, 0]
  * (base_model.py:95) needs no copy: element (i,j) at y[i*y_row_stride + j*y_col_stride]. */
 int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_stride,
                            int64_t y_col_stride, int32_t m, int32_t n, float grad_scale,
-                           float* out4, float* grad, void* stream);
+                           float* out4, float* grad, float* per_horizon, void* stream);
 
 /* replaces: torch.optim.Adam(lr=5e-4).step()  (base_model.py:255-257); one parameter tensor.
  * Exactly torch's single-tensor Adam order of operations in f32 (no weight decay, no amsgrad);

@@ -288,6 +288,40 @@ def forecast_losses(y_hat: torch.Tensor, y: torch.Tensor):
     return mse, nmae, mse_exp, mae_exp
 
 
+def horizon_metrics(y_hat: torch.Tensor, y: torch.Tensor):
+    """(mse per forecast step, mae per forecast step): nowcasting_utils' mse_each_forecast_horizon /
+    mae_each_forecast_horizon as called at base_model.py:123-124 = means over the batch axis."""
+    return torch.mean((y_hat - y) ** 2, dim=0), torch.mean(torch.abs(y_hat - y), dim=0)
+
+
+def logged_horizon_metrics(y_hat: torch.Tensor, y: torch.Tensor, forecast_len_30: int, tag: str) -> Dict[str, float]:
+    """The dictionary base_model.py:126-135 logs: metrics_mse and metrics_mae are BOTH keyed
+    `MSE_forecast_horizon_{i}/{tag}` for i in range(forecast_len_30) and merged as {**mse, **mae}, so the value that
+    survives under the MSE name is the MAE."""
+    mse_h, mae_h = horizon_metrics(y_hat, y)
+    metrics_mse = {f"MSE_forecast_horizon_{i}/{tag}": float(mse_h[i]) for i in range(forecast_len_30)}
+    metrics_mae = {f"MSE_forecast_horizon_{i}/{tag}": float(mae_h[i]) for i in range(forecast_len_30)}
+    return {**metrics_mse, **metrics_mae}
+
+
+def validation_results_rows(model_output: np.ndarray, gsp_yield: np.ndarray, gsp_capacity: np.ndarray, gsp_id: np.ndarray,
+                            t0_datetime_utc_ns: np.ndarray, forecast_len_30: int):
+    """Rows of the validation results table, base_model.py:223-239 -> nowcasting_utils.make_validation_results:
+    (t0, target time = t0 + 30 min * (i + 1), gsp_id, actual MW, forecast MW) per example and 30-minute step, MW =
+    normalised value * capacity.  The reference pins the row count and these five columns
+    (tests/models/baseline/test_baseline_model_gsp.py:104-111)."""
+    capacity = gsp_capacity[:, -forecast_len_30:, 0]
+    predictions = model_output[:, -forecast_len_30:] * capacity
+    truths = gsp_yield[:, -forecast_len_30:, 0] * capacity
+    rows = []
+    for b in range(predictions.shape[0]):
+        t0 = np.datetime64(int(t0_datetime_utc_ns[b]), "ns")
+        for i in range(forecast_len_30):
+            rows.append((t0, t0 + np.timedelta64(30 * (i + 1), "m"), int(gsp_id[b, 0]), float(truths[b, i]),
+                         float(predictions[b, i])))
+    return rows
+
+
 def select_target(yield_tensor: torch.Tensor, forecast_len: int, batch_size: int = 32) -> torch.Tensor:
     """y = yield[0:batch_size, -forecast_len:, 0]  (base_model.py:91-95)."""
     return yield_tensor[0:batch_size, -forecast_len:, 0]

@@ -210,7 +210,8 @@ struct LossWeights { float w[64]; };
 __global__ __launch_bounds__(256) void forecast_losses_f32(const float* __restrict__ y_hat, const float* __restrict__ y,
                                                             long long y_row_stride, long long y_col_stride, int m,
                                                             int n, float grad_scale, LossWeights lw,
-                                                            float* __restrict__ out4, float* __restrict__ grad) {
+                                                            float* __restrict__ out4, float* __restrict__ grad,
+                                                            float* __restrict__ per_horizon) {
   float s_se = 0.f, s_ae = 0.f, s_wse = 0.f, s_wae = 0.f;
   const int total = m * n;
   const float inv = 1.0f / (float)total;
@@ -237,6 +238,19 @@ __global__ __launch_bounds__(256) void forecast_losses_f32(const float* __restri
   if (threadIdx.x < 4) {
     int q = threadIdx.x;
     out4[q] = (((red[0][q] + red[1][q]) + red[2][q]) + red[3][q]) * inv;
+  }
+  // mse_each_forecast_horizon / mae_each_forecast_horizon (base_model.py:123-124): mean over the batch axis for every
+  // forecast step; one thread per step walks the rows in index order (deterministic; m * n is a few hundred values)
+  if (per_horizon && (int)threadIdx.x < n) {
+    const int c = threadIdx.x;
+    float se = 0.f, ae = 0.f;
+    for (int r = 0; r < m; ++r) {
+      float d = y_hat[r * n + c] - y[(long long)r * y_row_stride + (long long)c * y_col_stride];
+      se += d * d;
+      ae += fabsf(d);
+    }
+    per_horizon[c] = se / (float)m;
+    per_horizon[n + c] = ae / (float)m;
   }
 }
 
@@ -469,7 +483,7 @@ int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const flo
 }
 
 int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_stride, int64_t y_col_stride, int32_t m,
-                           int32_t n, float grad_scale, float* out4, float* grad, void* stream) {
+                           int32_t n, float grad_scale, float* out4, float* grad, float* per_horizon, void* stream) {
   PV_REQUIRE(y_hat && y && out4, PV_EINVAL, "pv_forecast_losses_f32: null pointer");
   PV_REQUIRE(m > 0 && n > 0 && n <= 64, PV_ESIZE, "pv_forecast_losses_f32: forecast length %d outside 1..64", n);
   // WeightedLosses(forecast_length=n): w_i = exp(-ln2 * i), normalised to mean 1 (f32 like torch.FloatTensor)
@@ -479,7 +493,7 @@ int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_str
   for (int i = 0; i < n; ++i) { tmp[i] = (float)exp(-0.6931471805599453 * i); sum += tmp[i]; }
   for (int i = 0; i < 64; ++i) lw.w[i] = i < n ? tmp[i] / sum * (float)n : 0.f;
   hipLaunchKernelGGL(forecast_losses_f32, dim3(1), dim3(256), 0, as_stream(stream), y_hat, y, (long long)y_row_stride,
-                     (long long)y_col_stride, m, n, grad_scale, lw, out4, grad);
+                     (long long)y_col_stride, m, n, grad_scale, lw, out4, grad, per_horizon);
   return check_launch("pv_forecast_losses_f32");
 }
 

@@ -371,3 +371,10 @@ class ForecastLosses(torch.autograd.Function):
 
 def forecast_losses(y_hat, y):
     return ForecastLosses.apply(y_hat, y)
+
+
+def forecast_losses_with_horizons(y_hat, y):
+    """Validation / test form (no gradient): ((mse, nmae, mse_exp, mae_exp), per-step mse [n], per-step mae [n]) from
+    ONE launch of pv_forecast_losses_f32 (base_model.py:98-103,121-141)."""
+    out4, _, horizons = K.forecast_losses(y_hat.detach().contiguous(), y, need_grad=False, per_horizon=True)
+    return tuple(out4.unbind(0)), horizons[0], horizons[1]

@@ -386,19 +386,23 @@ def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True):
     return dx, dw, db
 
 
-def forecast_losses(y_hat: torch.Tensor, y: torch.Tensor, need_grad: bool = True, grad_scale: float = 1.0):
+def forecast_losses(y_hat: torch.Tensor, y: torch.Tensor, need_grad: bool = True, grad_scale: float = 1.0,
+                    per_horizon: bool = False):
     """(mse, nmae, mse_exp, mae_exp) as a device f32[4] and d nmae / d y_hat (base_model.py:98-103).
-    y may be any strided 2-D view (e.g. batch.pv.pv_yield[:, -forecast_len:, 0])."""
+    y may be any strided 2-D view (e.g. batch.pv.pv_yield[:, -forecast_len:, 0]).
+    per_horizon=True additionally returns f32[2, forecast_len] = (mse, mae) per forecast step (base_model.py:121-141),
+    computed by the same launch."""
     require_cuda(y_hat)
     if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2 or y.shape != y_hat.shape:
         raise TypeError("forecast_losses: y must be a float32 CUDA [B, forecast_len] view matching y_hat")
     m, n = y_hat.shape
     out4 = torch.empty(4, dtype=torch.float32, device=y_hat.device)
     grad = torch.empty_like(y_hat) if need_grad else None
+    horizons = torch.empty((2, n), dtype=torch.float32, device=y_hat.device) if per_horizon else None
     check(get_lib().pv_forecast_losses_f32(ptr(y_hat), ctypes.c_void_p(y.data_ptr()), y.stride(0), y.stride(1), m, n,
-                                           grad_scale, ptr(out4), ptr(grad), current_stream_ptr()),
+                                           grad_scale, ptr(out4), ptr(grad), ptr(horizons), current_stream_ptr()),
           "pv_forecast_losses_f32")
-    return out4, grad
+    return (out4, grad, horizons) if per_horizon else (out4, grad)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8,

@@ -302,6 +302,12 @@ def test_forecast_losses(device):
     ref = torch.stack([mse, nmae, mse_exp, mae_exp]).detach()
     torch.testing.assert_close(torch.stack(out4).detach().cpu(), ref, rtol=1e-5, atol=1e-7)
     torch.testing.assert_close(yd.grad.cpu(), y_hat.grad, rtol=1e-6, atol=0)
+    # per-horizon metrics from the same launch (base_model.py:121-141)
+    four, mse_h, mae_h = Fn.forecast_losses_with_horizons(yd.detach(), co.select_target(yield_t.to(device), 6))
+    torch.testing.assert_close(torch.stack(four).cpu(), ref, rtol=1e-5, atol=1e-7)
+    ref_mse_h, ref_mae_h = co.horizon_metrics(y_hat.detach(), y)
+    torch.testing.assert_close(mse_h.cpu(), ref_mse_h, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(mae_h.cpu(), ref_mae_h, rtol=1e-6, atol=1e-7)
 
 
 def test_adam_matches_torch(device):

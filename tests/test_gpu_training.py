@@ -170,3 +170,44 @@ def test_matched_validation_nmae_after_training(device):
     ref, got = val_nmae_oracle(), val_nmae_hip()
     assert ref < 0.95 * before and got < 0.95 * before, (before, ref, got)      # both learned (16 samples: modest)
     assert abs(got - ref) <= 2e-2 * ref, (ref, got)                            # and ended at the same validation NMAE
+
+
+def test_validation_results_csv_and_horizon_metrics_on_the_gpu(device, tmp_path):
+    """SURVEY §8f row 4 on the device path: Trainer.validate of the Conv3D model (gsp_yield output) writes
+    `{results_file_name}_0.csv` with n_batches * batch * forecast_len_30 rows / the five reference columns
+    (reference tests/models/baseline/test_baseline_model_gsp.py:81-111), and logs, under `MSE_forecast_horizon_i`,
+    the per-horizon MAE (base_model.py:121-141) -- both compared with the oracle's restatement on the model's outputs."""
+    import pandas as pd
+    from oracle import conv3d_oracle as co
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.batch import BatchML
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    torch.manual_seed(0)
+    model = Model(include_pv_yield=False, include_nwp=False, forecast_minutes=120, history_minutes=30, image_size_pixels=16,
+                  number_sat_channels=11, number_of_conv3d_layers=4, fc1_output_features=16, output_variable="gsp_yield")
+    cfg = FakeDataConfiguration(batch_size=4, history_minutes=30, forecast_minutes=120, satellite_image_size_pixels=16)
+    ds = FakeDataset(cfg, length=3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=None)
+    model.results_file_name = f"{tmp_path}/temp"
+    trainer = pl.Trainer(gpus=1, max_epochs=1)
+    out = trainer.validate(model, loader)[0]
+    results_df = pd.read_csv(f"{model.results_file_name}_0.csv")
+    assert len(results_df) == len(loader) * cfg.batch_size * model.forecast_len_30 == 48
+    assert list(results_df.keys()) == ["t0_datetime_utc", "target_datetime_utc", "gsp_id", "actual_gsp_pv_outturn_mw",
+                                       "forecast_gsp_pv_outturn_mw"]
+    want_rows, horizon = [], {}
+    with torch.no_grad():
+        for item in ds:
+            b = BatchML(**item)
+            y_hat = model(b.to(device)).cpu()
+            want_rows += co.validation_results_rows(y_hat.numpy(), b.gsp.gsp_yield.numpy(), b.gsp.gsp_capacity.numpy(),
+                                                    b.gsp.gsp_id.numpy(), b.metadata.t0_datetime_utc.numpy(), 4)
+            for k, v in co.logged_horizon_metrics(y_hat, b.gsp.gsp_yield[:, -4:, 0], 4, "Validation").items():
+                horizon.setdefault(k, []).append(v)
+    assert np.allclose(results_df["forecast_gsp_pv_outturn_mw"], [r[4] for r in want_rows], rtol=1e-5, atol=1e-6)
+    assert np.allclose(results_df["actual_gsp_pv_outturn_mw"], [r[3] for r in want_rows], rtol=1e-6)
+    assert list(results_df["gsp_id"]) == [r[2] for r in want_rows]
+    for k, vs in horizon.items():                      # epoch value = mean of the per-batch values
+        assert out[f"{k}_epoch"] == pytest.approx(np.mean(vs), rel=1e-5), k
+    assert "MSE_forecast_horizon_4/Validation_epoch" not in out

@@ -3,6 +3,8 @@ yaml tree through the alias table), load_config, model construction / attribute 
 the Trainer shim's loops, callbacks and loggers, the fake datamodule.  No kernels run here."""
 import os
 
+import numpy as np
+
 import pytest
 import torch
 from torch import nn
@@ -242,3 +244,115 @@ def test_new_model_signatures_match_reference():
     assert sig.parameters["conv3d_channels"].default == 16 and sig.parameters["use_future_satellite_images"].default is True
     m = PerceiverModel(history_minutes=3, forecast_minutes=3)           # tests/models/perceiver/test_perceiver.py:9
     assert m.total_seq_length == 1 and len(m.perceiver.layers) == 1
+
+
+# ---- step after the path: validation results CSV + per-horizon metrics, on the host with the
+# ---- parameter-free baseline, exactly as the reference's own tests drive them ------------------------------------------
+def _gsp_baseline_and_loader(n_batches=3, batch_size=4):
+    from predict_pv_yield_amd.models.baseline.last_value import Model
+    cfg = FakeDataConfiguration(batch_size=batch_size, history_minutes=30, forecast_minutes=120, satellite_image_size_pixels=8)
+    model = Model(forecast_minutes=cfg.forecast_minutes, history_minutes=cfg.history_minutes, output_variable="gsp_yield")
+    loader = torch.utils.data.DataLoader(FakeDataset(cfg, length=n_batches), batch_size=None)
+    return model, loader, cfg
+
+
+def test_baseline_trainer_validation_writes_the_results_csv(tmp_path):
+    """reference tests/models/baseline/test_baseline_model_gsp.py:81-111: validate -> `{results_file_name}_0.csv` with
+    len(loader) * batch_size * forecast_len_30 rows and the five named columns."""
+    import pandas as pd
+    from oracle import conv3d_oracle as co
+    model, loader, cfg = _gsp_baseline_and_loader()
+    trainer = pl.Trainer(gpus=0, max_epochs=1)
+    model.results_file_name = f"{tmp_path}/temp"
+    _ = trainer.validate(model, loader)
+    results_df = pd.read_csv(f"{model.results_file_name}_0.csv")
+    assert len(results_df) == len(loader) * cfg.batch_size * model.forecast_len_30
+    for column in ("t0_datetime_utc", "target_datetime_utc", "gsp_id", "actual_gsp_pv_outturn_mw", "forecast_gsp_pv_outturn_mw"):
+        assert column in results_df.keys()
+    assert len(results_df.keys()) == 5
+    # content: every row against the oracle's restatement of make_validation_results
+    want = []
+    for item in loader:
+        b = BatchML(**item)
+        want += co.validation_results_rows(model(b).numpy(), b.gsp.gsp_yield.numpy(), b.gsp.gsp_capacity.numpy(),
+                                           b.gsp.gsp_id.numpy(), b.metadata.t0_datetime_utc.numpy(), model.forecast_len_30)
+    assert list(results_df["gsp_id"]) == [r[2] for r in want]
+    assert np.allclose(results_df["actual_gsp_pv_outturn_mw"], [r[3] for r in want], rtol=1e-6)
+    assert np.allclose(results_df["forecast_gsp_pv_outturn_mw"], [r[4] for r in want], rtol=1e-6)
+    assert list(pd.to_datetime(results_df["target_datetime_utc"])) == [pd.Timestamp(r[1]) for r in want]
+    # a second model object starts with its own, empty table (results_dfs used to be a shared class attribute)
+    other, _, _ = _gsp_baseline_and_loader()
+    assert other.results_dfs == [] and other.results_dfs is not model.results_dfs
+
+
+def test_baseline_trainer_test_and_direct_step_calls():
+    """reference test_baseline_model_gsp.py:41-78: steps called directly (no trainer) and trainer.test()."""
+    model, loader, _ = _gsp_baseline_and_loader(2)
+    batch = next(iter(loader))
+    model.validation_step(batch, 0)
+    model.training_step(batch, 0)
+    model.test_step(batch, 0)
+    out = pl.Trainer(gpus=0, max_epochs=1).test(model, loader)
+    assert np.isfinite(out[0]["NMAE/Test_epoch"])
+
+
+def test_per_horizon_metrics_kat_mae_overwrites_mse():
+    """base_model.py:121-141: `MSE_forecast_horizon_{i}/{tag}` carries the MAE of horizon i (the MAE dictionary reuses
+    the MSE key names and is merged last), for i < forecast_len_30 only."""
+    from oracle import conv3d_oracle as co
+    model, loader, _ = _gsp_baseline_and_loader(1, batch_size=3)
+    batch = BatchML(**next(iter(loader)))
+    # hand-made case: errors of 1, 2, 3, 4 at the four horizons for every example
+    y_hat = model(batch)
+    batch.gsp.gsp_yield[:, -4:, 0] = y_hat - torch.tensor([1.0, 2.0, 3.0, 4.0])
+    model.validation_step(batch, 0)
+    logged = {k: float(v) for k, v in model._logged.items()}
+    for i, err in enumerate([1.0, 2.0, 3.0, 4.0]):
+        assert logged[f"MSE_forecast_horizon_{i}/Validation"] == pytest.approx(err)         # the MAE, not err ** 2
+    assert f"MSE_forecast_horizon_4/Validation" not in logged
+    assert logged["NMAE/Validation"] == pytest.approx(2.5) and logged["MSE/Validation"] == pytest.approx(7.5)
+    want = co.logged_horizon_metrics(model(batch), batch.gsp.gsp_yield[:, -4:, 0], 4, "Validation")
+    assert {k: v for k, v in logged.items() if "horizon" in k} == pytest.approx(want)
+    # pv_yield output with 30 forecast minutes: six 5-minute steps but forecast_len_30 == 1 -> only horizon 0 is logged
+    from predict_pv_yield_amd.models.baseline.last_value import Model
+    pv_model = Model(forecast_minutes=30, history_minutes=60, output_variable="pv_yield")
+    cfg = FakeDataConfiguration(batch_size=2, history_minutes=60, forecast_minutes=30, satellite_image_size_pixels=8)
+    pv_model.test_step(FakeDataset(cfg, 1)[0], 0)
+    assert [k for k in pv_model._logged if "horizon" in k] == ["MSE_forecast_horizon_0/Test"]
+
+
+def test_trainable_models_still_refuse_the_cpu():
+    from predict_pv_yield_amd.models.base_model import BaseModel
+
+    class Tiny(BaseModel):
+        history_minutes, forecast_minutes = 30, 30
+
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(1, 1)
+
+    with pytest.raises(RuntimeError, match="MI355X"):
+        Tiny()._losses(torch.zeros(2, 6), torch.zeros(2, 6))
+
+
+def test_config1_exp001_shaped_cpu_plumbing_run(tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: experiments/001-shaped synthetic data (19 five-minute steps, HRV only, 128 x 128, NWP
+    [32,10,19,2,2], PV [32,19,128]) through run.py's surface on the HOST, world_size 1: it runs and the loss is finite."""
+    from predict_pv_yield_amd.training import train
+    from predict_pv_yield_amd.utils import extras
+    monkeypatch.chdir(tmp_path)
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config",
+                    ["experiment=exp001_plumbing", f"datamodule.data_path={ROOT}/configs/dataset/exp001",
+                     "optimized_metric=NMAE/Validation_epoch"])
+    extras(cfg)
+    assert cfg.trainer.gpus == 0
+    dm = H.instantiate(cfg.datamodule)
+    batch = BatchML(**next(iter(dm.val_dataloader())))
+    # experiments/001_...py:225-251,288-293: history_len 6 + forecast_len 12 + 1 = 19 steps; the first 7 frames are the
+    # Conv2d's time-as-channel input
+    assert batch.satellite.data.shape == (32, 1, 19, 128, 128) and batch.satellite.data[:, :, :7].shape[2] == 7
+    assert batch.nwp.data.shape[:2] == (32, 10) and batch.nwp.data.shape[-2:] == (2, 2)
+    assert batch.pv.pv_yield.shape == (32, 19, 128)
+    score = train(cfg)
+    assert np.isfinite(score) and 0.0 < score < 1.0
+    assert os.path.exists("results_epoch_0.csv")
