@@ -254,8 +254,15 @@ typedef struct pv_pack_job {
 } pv_pack_job;
 int pv_conv3d_pack_weights_multi_bf16(const pv_pack_job* jobs, int32_t n_jobs, void* stream);
 
+/* 1-bit ReLU masks (both may be NULL): relu_mask_out receives, per output voxel, a u32 whose bit c is (y[.., c] > 0)
+ * (NDHWC output only) -- 4 bytes per voxel instead of the 64-byte bf16 voxel; out_gate_mask is such a mask OF out_gate
+ * (pass both: kernels without a mask path read the bf16 tensor) and replaces the read of out_gate in the dgrad epilogue.
+ * A mask is laid out [B][T][hp][wp] u32 with the plane padded to whole 8 x 32 tiles: pv_relu_mask_dims(h, w, &hp, &wp);
+ * the padding words are never read for a voxel that exists. */
+int pv_relu_mask_dims(int32_t h, int32_t w, int32_t* hp, int32_t* wp);
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp,
                        const float* bias, uint16_t* y, const uint16_t* out_gate,
+                       const uint32_t* out_gate_mask, uint32_t* relu_mask_out,
                        const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream);
 
 /* First-layer form: x is the reference's own input tensor, f32 NCDHW [B, c_in, T, H, W] (sat_data of
@@ -263,7 +270,7 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
  * by pv_conv3d_fwd_bf16 (NDHWC output), in one pass over the input: the staging rounds to bf16 on the way into LDS.
  * xp_out (may be NULL): receives the NDHWC bf16 [B,T,H,W,16] image of x that pv_conv3d_bwd_weight_bf16 consumes. */
 int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
-                             const pv_conv3d_dims* d, int relu, void* stream);
+                             uint32_t* relu_mask_out, const pv_conv3d_dims* d, int relu, void* stream);
 
 /* dw[Co,Ci,3,3,3] f32 and dbias[Co] f32 from x (NDHWC bf16) and dy ⊙ (y>0) (NDHWC bf16).
  * workspace: pv_conv3d_bwd_weight_bf16_workspace_bytes(d). Overwrites dw/dbias. */

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ gate, const uint16_t* __restrict__ wp,
     const float* __restrict__ bias, uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
     int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk,
-    int t_chunk, int c_out, int c_in_real = 0, uint16_t* __restrict__ xp_out = nullptr) {
+    int t_chunk, int c_out, int c_in_real = 0, uint16_t* __restrict__ xp_out = nullptr,
+    uint32_t* __restrict__ mask_out = nullptr) {
   using G = SliceGeom<CPAD>;
   constexpr int KS = CPAD / 16;
   // ring of 3 slices | 256 B of zeros (tap reads of masked columns run 2 voxels past a slot) | 32 bias floats
@@ -307,6 +308,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
             val[2] = gate_word(val[2], g[2]); val[3] = gate_word(val[3], g[3]);
           }
           *reinterpret_cast<u32x4*>(yt + wr_off[orow] + half * 1024) = val;
+        }
+        if constexpr (!OUT_GATE) {
+          if (mask_out) {
+            // 1-bit relu mask of the output (u32 per voxel, bit = channel): this lane's 8 channels are byte c of the
+            // voxel's word; the 64 lanes of the instruction write 64 consecutive bytes
+            const uint32_t words[4] = {val[0], val[1], val[2], val[3]};
+            const uint32_t mb = relu_bits_of_8(words);
+            if (wr_ok[orow][half]) {   // planes padded to [ceil8(h_out)][ceil32(w_out)] words (pv_relu_mask_dims)
+              const int mw = (w_out + 31) & ~31, mh = (h_out + 7) & ~7;
+              reinterpret_cast<unsigned char*>(mask_out)[((((size_t)b * t_out + tw) * mh + (h0 + 4 * wr + orow)) * mw + w0 +
+                                                          32 * ws + 16 * half + (lane >> 2)) * 4 + c] = (unsigned char)mb;
+            }
+          }
         }
       }
     }
@@ -659,6 +673,22 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
   }
 }
 
+// relu_mask[v] (u32 per voxel, bit c = channel c > 0) from an NDHWC bf16 [.., 32] activation: the fallback producer for
+// launches whose kernel does not emit the mask itself (v2 kernel, gated v1 variants).  4 lanes per voxel.
+__global__ __launch_bounds__(256) void relu_mask_from_ndhwc32_kernel(const uint16_t* __restrict__ y, uint32_t* __restrict__ mask,
+                                                                     long long total_vox, int h, int w) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int mw = (w + 31) & ~31, mh = (h + 7) & ~7;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_vox * 4; i += stride) {
+    const int c = (int)(i & 3);
+    const u32x4 val = *reinterpret_cast<const u32x4*>(y + (size_t)i * 8);
+    const uint32_t words[4] = {val[0], val[1], val[2], val[3]};
+    const long long v = i >> 2, bt = v / ((long long)h * w);
+    const int rem = (int)(v - bt * h * w), hy = rem / w;
+    reinterpret_cast<unsigned char*>(mask)[((bt * mh + hy) * mw + (rem - hy * w)) * 4 + c] = (unsigned char)relu_bits_of_8(words);
+  }
+}
+
 // two-waves-per-SIMD variant (conv3d_bf16_v2.hip)
 int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
@@ -666,7 +696,8 @@ int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const floa
 // input-stationary variant (conv3d_bf16_v3.hip, its own 8 x 32 tiling); 1 = shape not covered
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int y_ncdhw, hipStream_t st);
+                              int y_ncdhw, hipStream_t st, const uint32_t* out_gate_mask, uint32_t* mask_out);
+bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void* out_gate_mask);
 void launch_pack_weight_v2(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
 constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
 
@@ -675,6 +706,13 @@ constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
 using namespace pv;
 
 extern "C" {
+
+int pv_relu_mask_dims(int32_t h, int32_t w, int32_t* hp, int32_t* wp) {
+  PV_REQUIRE(h > 0 && w > 0 && hp && wp, PV_EINVAL, "pv_relu_mask_dims: bad arguments");
+  *hp = (h + 7) & ~7;    // whole 8 x 32 output tiles of the conv kernels
+  *wp = (w + 31) & ~31;
+  return PV_OK;
+}
 
 int pv_bf16_cpad(int32_t c) {
   if (c <= 0) return PV_EINVAL;
@@ -770,7 +808,8 @@ int pv_conv3d_pack_weights_multi_bf16(const pv_pack_job* jobs, int32_t n_jobs, v
 }
 
 int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* wp, const float* bias, uint16_t* y,
-                       const uint16_t* out_gate, const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream) {
+                       const uint16_t* out_gate, const uint32_t* out_gate_mask, uint32_t* relu_mask_out,
+                       const pv_conv3d_dims* d, int relu, int y_ncdhw, void* stream) {
   PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_bf16: null pointer");
   PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
              "pv_conv3d_fwd_bf16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
@@ -780,6 +819,10 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_bf16: input smaller than the kernel");
   PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_fwd_bf16: batch too large for grid.z");
   PV_REQUIRE(!(out_gate && y_ncdhw), PV_EINVAL, "pv_conv3d_fwd_bf16: out_gate needs the NDHWC output layout");
+  PV_REQUIRE(!out_gate_mask || out_gate, PV_EINVAL,
+             "pv_conv3d_fwd_bf16: out_gate_mask accompanies out_gate (kernels without a mask path read the bf16 tensor)");
+  PV_REQUIRE(!relu_mask_out || (!y_ncdhw && d->c_out <= 32), PV_EINVAL,
+             "pv_conv3d_fwd_bf16: relu_mask_out needs the NDHWC output layout");
   const int cpad = pv_bf16_cpad(d->c_in);
   PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * cpad * 2 <= 0x40000000ull, PV_ESIZE,
              "pv_conv3d_fwd_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
@@ -798,19 +841,29 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipStream_t st = as_stream(stream);
+  // relu_mask_out: written by the kernel itself where it can (v3 plain forward, v1 NDHWC epilogue), else by a pass over y
+  auto mask_fallback = [&](int rc) -> int {
+    if (rc != PV_OK || !relu_mask_out) return rc;
+    const long long total_vox = (long long)d->batch * to * ho * wo;
+    hipLaunchKernelGGL(relu_mask_from_ndhwc32_kernel, dim3(stream_grid((size_t)total_vox * 4, 256)), dim3(256), 0, st, y,
+                       relu_mask_out, total_vox, ho, wo);
+    return check_launch("pv_conv3d_fwd_bf16(relu mask)");
+  };
   if (cpad == 32 && !gate) {  // 32 -> 32 channel layers: two-waves-per-SIMD kernels
+    const bool in_kernel = relu_mask_out && v3_writes_mask(y_ncdhw, out_gate, out_gate_mask);
     const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu,
-                                             y_ncdhw, st);
-    if (rc != 1) return rc;
+                                             y_ncdhw, st, out_gate_mask, in_kernel ? relu_mask_out : nullptr);
+    if (rc != 1) return in_kernel ? rc : mask_fallback(rc);
   }
   if (cpad == 32 && !gate && !y_ncdhw) {
-    return launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu, n_rowblk,
-                                     n_colblk, n_tchunk, t_chunk, st);
+    return mask_fallback(launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu,
+                                                   n_rowblk, n_colblk, n_tchunk, t_chunk, st));
   }
+  uint32_t* v1_mask = (relu_mask_out && !out_gate && !y_ncdhw) ? relu_mask_out : nullptr;
 #define PV_LAUNCH_CONV(CP, HG, YN, OG)                                                                           \
   hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<CP, HG, YN, OG>), grid, dim3(256), 0, st, x, gate, wp, bias, y, out_gate, \
                      d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk,        \
-                     t_chunk, d->c_out)
+                     t_chunk, d->c_out, 0, (uint16_t*)nullptr, v1_mask)
 #define PV_LAUNCH_CONV2(CP, HG)                                      \
   do {                                                               \
     if (y_ncdhw) PV_LAUNCH_CONV(CP, HG, true, false);                \
@@ -824,11 +877,12 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
   }
 #undef PV_LAUNCH_CONV2
 #undef PV_LAUNCH_CONV
-  return check_launch("pv_conv3d_fwd_bf16");
+  const int rc = check_launch("pv_conv3d_fwd_bf16");
+  return v1_mask ? rc : mask_fallback(rc);
 }
 
 int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
-                             const pv_conv3d_dims* d, int relu, void* stream) {
+                             uint32_t* relu_mask_out, const pv_conv3d_dims* d, int relu, void* stream) {
   PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_bf16_f32in: null pointer");
   PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 16 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
              "pv_conv3d_fwd_bf16_f32in: channels (%d -> %d) must be in 1..16 -> 1..32", d->c_in, d->c_out);
@@ -858,7 +912,7 @@ int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* w
   hipLaunchKernelGGL((conv3d_fwd_bf16_kernel<16, false, false, false, true>), grid, dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const uint16_t*>(x), (const uint16_t*)nullptr, wp, bias, y, (const uint16_t*)nullptr,
                      d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk,
-                     d->c_out, d->c_in, xp_out);
+                     d->c_out, d->c_in, xp_out, relu_mask_out);
   return check_launch("pv_conv3d_fwd_bf16_f32in");
 }
 

@@ -32,19 +32,47 @@ constexpr int V3_PATCH_CS = 4 * 64 + 16;        // NCDHW epilogue patch: bytes p
 constexpr int V3_PATCHB = 16 * V3_PATCH_CS;     // per wave: 16 couts
 
 // ReLU-derivative gate of a bf16 pair: 2 bits (low half > 0, high half > 0); and its application to a bf16 pair
-__device__ __forceinline__ uint32_t v3_gate_bits(uint32_t g) {
-  const uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 1u : 0u;
-  const uint32_t hi = ((g & 0x7fff0000u) != 0u && (g & 0x80000000u) == 0u) ? 2u : 0u;
-  return lo | hi;
-}
+__device__ __forceinline__ uint32_t v3_gate_bits(uint32_t g) { return relu_bits_of_pair(g); }
 __device__ __forceinline__ uint32_t v3_apply_gate(uint32_t x, uint32_t bits) {
   return x & (((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u));
+}
+
+// ---- 1-bit ReLU masks ------------------------------------------------------------------------------------------
+// relu_mask[b][t][h][w] (u32 per voxel): bit c = (activation of channel c > 0).  A forward launch writes it next to
+// its bf16 output; the dgrad whose epilogue applies that ReLU's derivative reads 4 bytes per voxel instead of the 64-byte
+// bf16 voxel (the gated dgrad was 16 us slower per launch than the ungated one: 85 MB of extra reads at B = 32).
+// In this kernel a lane (vox, kg) of wave (ch, wr) owns channels 16ch + 4kg .. +3 of the 8 voxels (orow, half) of its
+// tile rows: 8 nibbles = `gbits`, nibble index 2 * orow + half.  Memory wants, per voxel, the 16 bits of a channel
+// half: the four kg lanes (16 lanes apart) transpose their 4 x 4 bytes (byte = the two nibbles of one orow) with two
+// ds_bpermute rounds, after which lane kg holds row orow = kg complete.  The transpose is its own inverse, so the
+// consumer runs the same routine on what it loaded.
+__device__ __forceinline__ uint32_t v3_kg_transpose(uint32_t x, int lane) {
+  const bool b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
+  const uint32_t ev = (x & 0xffu) | ((x >> 8) & 0xff00u), od = ((x >> 8) & 0xffu) | ((x >> 16) & 0xff00u);
+  const uint32_t keep = b0 ? od : ev, send = b0 ? ev : od;
+  const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)send);
+  const uint32_t lo = b0 ? recv : keep, hi = b0 ? keep : recv;
+  const uint32_t y = (lo & 0xffu) | ((hi & 0xffu) << 8) | (((lo >> 8) & 0xffu) << 16) | (((hi >> 8) & 0xffu) << 24);
+  const uint32_t keep2 = b1 ? (y >> 16) : (y & 0xffffu), send2 = b1 ? (y & 0xffffu) : (y >> 16);
+  const uint32_t recv2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)send2);
+  return b1 ? (recv2 | (keep2 << 16)) : (keep2 | (recv2 << 16));
+}
+// low nibbles of the 4 bytes of x <-> 16 contiguous bits
+__device__ __forceinline__ uint32_t v3_nibbles_to_u16(uint32_t x) {
+  uint32_t y = x & 0x0f0f0f0fu;
+  y = (y | (y >> 4)) & 0x00ff00ffu;
+  return (y | (y >> 8)) & 0xffffu;
+}
+__device__ __forceinline__ uint32_t v3_u16_to_nibbles(uint32_t v) {
+  uint32_t y = v & 0xffffu;
+  y = (y | (y << 8)) & 0x00ff00ffu;
+  return (y | (y << 4)) & 0x0f0f0f0fu;
 }
 
 // One input slice's contribution to output slices s - kt, kt in [KT_LO, KT_HI] (compile-time: head and tail steps of
 // the march feed fewer slices).  P = (s - tc0) % 3 names the accumulator slot of output slice s.
 template <int P, int KT_LO, int KT_HI, int KW>
-__device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3][2], const bf16x8 (&wfrag)[18],
+__device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3], const bf16x8 (&wfrag)[18],
                                               const unsigned char* w2, f32x4 (&acc)[3][4][2]) {
   {
     constexpr int kw = KW;
@@ -54,13 +82,13 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
       for (int kh = 0; kh < 3; ++kh) wk2[kh] = *reinterpret_cast<const bf16x8*>(w2 + (kh * 3 + kw) * 2048);
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) cur[half] = *reinterpret_cast<const bf16x8*>(slot + voff[kw][half]);
+    for (int half = 0; half < 2; ++half) cur[half] = *reinterpret_cast<const bf16x8*>(slot + voff[kw] + half * (16 * V3_VOXB));
 #pragma unroll
     for (int ir = 0; ir < 6; ++ir) {
       if (ir < 5) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
-          nxt[half] = *reinterpret_cast<const bf16x8*>(slot + (ir + 1) * V3_ROWB + voff[kw][half]);
+          nxt[half] = *reinterpret_cast<const bf16x8*>(slot + (ir + 1) * V3_ROWB + voff[kw] + half * (16 * V3_VOXB));
       }
 #pragma unroll
       for (int kt = KT_LO; kt <= KT_HI; ++kt) {
@@ -85,16 +113,20 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
 // Y_NCDHW (the last conv layer, whose output fc1 consumes in the reference's flatten order): the finished tile is
 // transposed through a wave-private LDS patch ([cout][row][voxel]) and leaves as 16-byte pieces of a (cout, row) line
 // (w_out % 8 == 0, checked by the launcher).
-template <bool OUT_GATE, bool Y_NCDHW>
+// OUT_GATE: 0 = none, 1 = bf16 tensor of the gating activation, 2 = its 1-bit relu mask (out_gate then points to u32
+// words).  MASK_OUT: also write the relu mask of THIS launch's output (forward, NDHWC).
+template <int OUT_GATE, bool Y_NCDHW, bool MASK_OUT = false>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
-    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out) {
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out,
+    uint32_t* __restrict__ mask_out = nullptr) {
   // ring of 2 slices | kt = 2 weight plane | 32 bias floats   (78 KB: two workgroups per CU)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? 4 * V3_PATCHB : 0)];
   unsigned char* lds_w2 = lds + 2 * V3_SLOTB;
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
   static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
+  static_assert(!(MASK_OUT && (Y_NCDHW || OUT_GATE)), "the relu mask is written by the plain NDHWC forward");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -164,14 +196,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   const unsigned char* w2 = lds_w2 + ch * 1024 + lane * 16;
 
   // ---- per-lane LDS read offsets of the B operand: voxel 16*half + vox + kw, 16-byte chunk kg ---------------------
-  int voff[3][2];
+  // (the column half 16 voxels further right has the same swizzle phase: + 1024 bytes, an immediate of the ds_read)
+  int voff[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int v = 16 * half + vox + kw;
-      voff[kw][half] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
-    }
+  for (int kw = 0; kw < 3; ++kw) {
+    const int v = vox + kw;
+    voff[kw] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
+  }
 
   // ---- write-out geometry: lane (vox, kg) of accumulator [orow][half] holds couts 16ch + 4kg .. +3 of voxel
   // (row h0 + 4wr + orow, column w0 + 16half + vox): 8 bytes ----------------------------------------------------
@@ -187,14 +218,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   const __amdgpu_buffer_rsrc_t yrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
   const __amdgpu_buffer_rsrc_t ogrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
+      (void*)((OUT_GATE == 1 ? out_gate : y) + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
+  // relu-mask addressing (read: OUT_GATE == 2, write: MASK_OUT): lane (vox, kg) handles tile row orow = kg, the voxels
+  // of columns vox and 16 + vox, 16-bit half ch of the per-voxel word
+  // The mask planes are padded to whole tiles ([B][T][ceil8(H)][ceil32(W)] words, pv_relu_mask_dims), so every lane's
+  // address is in range and the second column half is a constant 64 bytes further.
+  const int mask_w = n_colblk * V3_TW_VALID, mask_plane = ((h_out + V3_TR - 1) / V3_TR) * V3_TR * mask_w;
+  const size_t mask_sample_b = (size_t)t_out * mask_plane * 4;
+  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((OUT_GATE == 2 ? reinterpret_cast<const unsigned char*>(out_gate) : reinterpret_cast<const unsigned char*>(mask_out)) +
+              (size_t)b * mask_sample_b),
+      0, (OUT_GATE == 2 || MASK_OUT) ? (int)mask_sample_b : 0, 0x00020000);
+  const uint32_t m_off = (uint32_t)((h0 + 4 * wr + kg) * mask_w + w0 + vox) * 4u + 2u * ch;
   auto row_off = [&](int o, int orow) -> uint32_t {  // wave-uniform part of the byte offset of (slice o, tile row orow)
     const bool ok = (h0 + 4 * wr + orow) < h_out;
     return ok ? (uint32_t)o * (uint32_t)plane_out * 64u + (uint32_t)orow * (uint32_t)w_out * 64u : V3_INVALID;
   };
 
   u32x2 pend[4][2];  // finished tile (bf16 pairs), stored one step later so the stores never sit in front of a wait
-  u32x2 og[OUT_GATE ? 4 : 1][2];
+  u32x2 og[OUT_GATE == 1 ? 4 : 1][2];
+  // MASK_OUT: the finished tile's relu bits of (row kg, column vox) in the low and (row kg, column 16 + vox) in the high
+  // half, stored with the tile; OUT_GATE 2: the same two 16-bit words as loaded
+  uint32_t mpend = 0u, mpend_hi = 0u;
   uint32_t gbits = 0u;  // the tile's gate, 4 bits per (row, half): the 16 gate registers live only through the kw = 0 phase
   // NCDHW: lane -> 16-byte piece (lane & 3) of line (cout 4i + lane/16, row (lane/4) & 3) for store instruction i
   unsigned char* patch = lds + 2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? (tid >> 6) * V3_PATCHB : 0);
@@ -218,16 +263,37 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         for (int half = 0; half < 2; ++half)
           __builtin_amdgcn_raw_buffer_store_b64(pend[orow][half], yrsrc, st_off[half] + ro, 0, 0);
       }
+      if constexpr (MASK_OUT) {
+        // relu bits of the tile being stored, taken from the very registers that are stored (nothing extra is carried
+        // across the step); the kg transpose runs here, at the top of the step, where register pressure is lowest
+        uint32_t obits = 0u;
+#pragma unroll
+        for (int orow = 0; orow < 4; ++orow)
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+          {
+            const uint32_t t = relu_pair01(pend[orow][half][0]) | (relu_pair01(pend[orow][half][1]) << 2);   // bits 0, 16, 2, 18
+            obits |= ((t | (t >> 15)) & 0xfu) << (4 * (2 * orow + half));
+          }
+        const uint32_t tr = v3_kg_transpose(obits, lane);  // bytes [kg']: (nibble of column vox | nibble of column 16 + vox << 4)
+        const uint32_t mo = m_off + (uint32_t)o * (uint32_t)mask_plane * 4u;
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v3_nibbles_to_u16(tr), mrsrc, mo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v3_nibbles_to_u16(tr >> 4), mrsrc, mo + 64u, 0, 0);
+      }
     }
   };
   auto load_gate = [&](int o) {
-    if constexpr (OUT_GATE) {
+    if constexpr (OUT_GATE == 1) {
 #pragma unroll
       for (int orow = 0; orow < 4; ++orow) {
         const uint32_t ro = row_off(o, orow);
 #pragma unroll
         for (int half = 0; half < 2; ++half) og[orow][half] = __builtin_amdgcn_raw_buffer_load_b64(ogrsrc, st_off[half] + ro, 0, 0);
       }
+    } else if constexpr (OUT_GATE == 2) {
+      const uint32_t mo = m_off + (uint32_t)o * (uint32_t)mask_plane * 4u;
+      mpend = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrsrc, mo, 0, 0);
+      mpend_hi = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrsrc, mo + 64u, 0, 0);
     }
   };
 
@@ -257,13 +323,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     __syncthreads();                    /* ... everybody's; and every wave is done reading slice s-1 */            \
     if (s + 1 <= s_last) load_slice(s + 1);                                                                       \
     if (s - 3 >= tc0) store_pending(s - 3);                                                                       \
-    if (KT_HI == 2) load_gate(s - 2);                                                                             \
+    if (OUT_GATE == 1 && KT_HI == 2) load_gate(s - 2);                                                            \
     const unsigned char* slot = lds + (s & 1) * V3_SLOTB + (4 * wr) * V3_ROWB;                                    \
     v3_accumulate<P, KT_LO, KT_HI, 0>(slot, voff, wfrag, w2, acc);                                                \
-    if constexpr (OUT_GATE && KT_HI == 2) {                                                                       \
+    if constexpr (OUT_GATE == 1 && KT_HI == 2) {                                                                  \
       gbits = 0u;                                                                                                 \
       _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) \
         gbits |= (v3_gate_bits(og[orow][half][0]) | (v3_gate_bits(og[orow][half][1]) << 2)) << (4 * (2 * orow + half)); \
+    }                                                                                                             \
+    if constexpr (OUT_GATE == 2 && KT_HI == 2) { /* row kg of both column halves -> this lane's 8 nibbles */       \
+      gbits = v3_kg_transpose(v3_u16_to_nibbles(mpend) | (v3_u16_to_nibbles(mpend_hi) << 4), lane);                \
     }                                                                                                             \
     v3_accumulate<P, KT_LO, KT_HI, 1>(slot, voff, wfrag, w2, acc);                                                \
     v3_accumulate<P, KT_LO, KT_HI, 2>(slot, voff, wfrag, w2, acc);                                                \
@@ -278,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         u32x2 o;                                                                                                  \
         o[0] = (uint32_t)f32_to_bf16_bits(a[0]) | ((uint32_t)f32_to_bf16_bits(a[1]) << 16);                       \
         o[1] = (uint32_t)f32_to_bf16_bits(a[2]) | ((uint32_t)f32_to_bf16_bits(a[3]) << 16);                       \
-        if constexpr (OUT_GATE) {                                                                                 \
+        if constexpr (OUT_GATE != 0) {                                                                            \
           o[0] = v3_apply_gate(o[0], gbits >> (4 * (2 * orow + half)));                                           \
           o[1] = v3_apply_gate(o[1], gbits >> (4 * (2 * orow + half) + 2));                                       \
         }                                                                                                         \
@@ -293,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
+    if constexpr (OUT_GATE == 2 && KT_HI >= 1) load_gate(s - 1); /* mask of the slice the NEXT step finishes */   \
   }
 
   int s = tc0;
@@ -332,9 +402,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
 
 // Returns 1 (not a PV_* code) when the shape does not fit this kernel (fewer than 2 output slices per time chunk): the caller falls back
 // to the v2 kernel.
+// out_gate_mask (u32 per voxel of y) takes precedence over out_gate; mask_out (may be NULL) receives the relu mask of y
+// and is only honoured for the plain NDHWC forward (no gate): the caller checks v3_writes_mask().
+bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void* out_gate_mask) { return !y_ncdhw && !out_gate && !out_gate_mask; }
+
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int y_ncdhw, hipStream_t st) {
+                              int y_ncdhw, hipStream_t st, const uint32_t* out_gate_mask, uint32_t* mask_out) {
   if (to < 2) return 1;
   if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
   const int n_rowblk = (ho + V3_TR - 1) / V3_TR;
@@ -352,12 +426,16 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
     if (to - (n_tchunk - 1) * t_chunk < 2) return 1;
   }
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
-#define PV_LAUNCH_V3(OG, YN)                                                                                          \
-  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in,     \
-                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out)
-  if (y_ncdhw) PV_LAUNCH_V3(false, true);
-  else if (out_gate) PV_LAUNCH_V3(true, false);
-  else PV_LAUNCH_V3(false, false);
+  const uint16_t* og_ptr = out_gate_mask ? reinterpret_cast<const uint16_t*>(out_gate_mask) : out_gate;
+#define PV_LAUNCH_V3(OG, YN, MO)                                                                                      \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN, MO>), grid, dim3(256), 0, st, x, wp2, bias, y, og_ptr, d->t_in,   \
+                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out, \
+                     mask_out)
+  if (y_ncdhw) PV_LAUNCH_V3(0, true, false);
+  else if (out_gate_mask) PV_LAUNCH_V3(2, false, false);
+  else if (out_gate) PV_LAUNCH_V3(1, false, false);
+  else if (mask_out) PV_LAUNCH_V3(0, false, true);
+  else PV_LAUNCH_V3(0, false, false);
 #undef PV_LAUNCH_V3
   return check_launch("pv_conv3d_fwd_bf16(v3)");
 }

@@ -44,6 +44,25 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint16_t u) {
   return __builtin_bit_cast(float, (uint32_t)u << 16);
 }
 
+// ReLU-derivative bits of a packed bf16 pair.  As 16-bit integers a bf16 is > 0 exactly when the signed value is
+// (sign clear, not +0): clamp to [0, 1] with two packed ops (v_pk_max_i16, v_pk_min_u16).
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
+__device__ __forceinline__ uint32_t relu_pair01(uint32_t g) {   // bit 0 = (low half > 0), bit 16 = (high half > 0)
+  const s16x2_t pos = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, g), (s16x2_t){0, 0});
+  const u16x2_t one = __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, pos), (u16x2_t){1, 1});
+  return __builtin_bit_cast(uint32_t, one);
+}
+__device__ __forceinline__ uint32_t relu_bits_of_pair(uint32_t g) {   // bit 0 = (low half > 0), bit 1 = (high half > 0)
+  const uint32_t t = relu_pair01(g);
+  return (t | (t >> 15)) & 3u;
+}
+// the 8 relu bits (bit i = element i > 0) of 8 packed bf16
+__device__ __forceinline__ uint32_t relu_bits_of_8(const uint32_t (&w)[4]) {
+  const uint32_t t = relu_pair01(w[0]) | (relu_pair01(w[1]) << 2) | (relu_pair01(w[2]) << 4) | (relu_pair01(w[3]) << 6);
+  return (t | (t >> 15)) & 0xffu;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -66,6 +66,15 @@ def linear_f32(x, weight, bias, relu=False):
 # ---------------------------------------------------------------------------------------------
 # bf16 path
 # ---------------------------------------------------------------------------------------------
+# The conv towers CAN hand 1-bit relu masks from each layer's forward to the next layer's dgrad (see Conv3dReLUBF16),
+# replacing the dgrad epilogue's 64-byte-per-voxel read of the bf16 activation by 4 bytes.  Measured in one process on
+# MI355X (tools/ab_step.py, B = 32): inside the train step the mask-gated dgrad runs exactly as fast as the bf16-gated
+# one (81.1 vs 81.0 us average: the activation was just read by the layer's wgrad and is still in the 256 MB MALL), while
+# writing the masks costs the producing forwards 7-8 us each -- 1.843 vs 1.829 ms per step.  So the default is OFF; the
+# path stays parity-tested (tests/test_gpu_conv.py) for larger batches / models whose activations outgrow the cache.
+USE_RELU_MASKS = False
+
+
 class PackInputBF16(torch.autograd.Function):
     """x[B,C,T,H,W] f32 -> NDHWC bf16 (channel-padded).  The satellite input needs no gradient."""
 
@@ -108,21 +117,30 @@ def refresh_packed_conv_weights(params) -> None:
 
 
 class Conv3dReLUBF16(torch.autograd.Function):
-    """xp [B,T,H,W,CPAD] bf16 -> y bf16 NDHWC [B,To,Ho,Wo,32] (or NCDHW [B,Co,To,Ho,Wo] when y_ncdhw)."""
+    """xp [B,T,H,W,CPAD] bf16 -> y bf16 NDHWC [B,To,Ho,Wo,32] (or NCDHW [B,Co,To,Ho,Wo] when y_ncdhw), plus -- when
+    want_relu_mask -- the 1-bit relu mask of y (int32 [B,To,Ho,Wo]) that the NEXT layer hands back as `x_relu_mask`:
+    its dgrad epilogue gates dx with 4 bytes per voxel instead of re-reading the bf16 activation."""
 
     @staticmethod
-    def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw, x_is_relu_output, dy_pregated):
+    def forward(ctx, xp, weight, bias, c_in, padding, relu, y_ncdhw, x_is_relu_output, dy_pregated, x_relu_mask,
+                want_relu_mask):
         wp = packed_conv_weight(weight, False)
         c_out = weight.shape[0]
-        y = K.conv3d_fwd_bf16(xp, None, wp, bias.contiguous() if bias is not None else None, c_in, c_out, padding, relu,
-                              y_ncdhw)
-        ctx.save_for_backward(xp, weight, y if relu else None)
+        want_relu_mask = bool(want_relu_mask and relu and not y_ncdhw)
+        out = K.conv3d_fwd_bf16(xp, None, wp, bias.contiguous() if bias is not None else None, c_in, c_out, padding, relu,
+                                y_ncdhw, want_relu_mask=want_relu_mask)
+        y, mask = out if want_relu_mask else (out, None)
+        ctx.save_for_backward(xp, weight, y if relu else None, x_relu_mask)
         ctx.cfg = (c_in, c_out, padding, relu, y_ncdhw, bias is not None, x_is_relu_output, dy_pregated)
-        return y
+        if mask is None:
+            mask = torch.empty(0, dtype=torch.int32, device=y.device)
+        ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient" for the mask output
+        return y, mask
 
     @staticmethod
-    def backward(ctx, dy):
-        xp, weight, y = ctx.saved_tensors
+    def backward(ctx, dy, _dmask):
+        xp, weight, y, x_relu_mask = ctx.saved_tensors
         c_in, c_out, padding, relu, y_ncdhw, has_bias, x_is_relu_output, dy_pregated = ctx.cfg
         dy = dy.contiguous()
         if y_ncdhw:
@@ -142,10 +160,12 @@ class Conv3dReLUBF16(torch.autograd.Function):
             # x_is_relu_output: x = relu(...) of the producer, so (x > 0) IS its ReLU derivative; applying it in this
             # kernel's epilogue hands the producer an already-gated gradient (no gate reads in its wgrad/dgrad)
             out_gate = xp if (x_is_relu_output and xp.shape[-1] == 32) else None
-            dx = K.conv3d_fwd_bf16(dy, gate, wpt, None, c_out, c_in, pad_b, relu=False, y_ncdhw=False, out_gate=out_gate)
+            gate_mask = x_relu_mask if (out_gate is not None and x_relu_mask is not None and x_relu_mask.numel()) else None
+            dx = K.conv3d_fwd_bf16(dy, gate, wpt, None, c_out, c_in, pad_b, relu=False, y_ncdhw=False, out_gate=out_gate,
+                                   out_gate_mask=gate_mask)
             if K.bf16_cpad(c_in) != 32:
                 dx = dx[..., : K.bf16_cpad(c_in)].contiguous()
-        return dx, dw, (db if has_bias else None), None, None, None, None, None, None
+        return dx, dw, (db if has_bias else None), None, None, None, None, None, None, None, None
 
 
 class Conv3dFirstLayerBF16(torch.autograd.Function):
@@ -154,27 +174,34 @@ class Conv3dFirstLayerBF16(torch.autograd.Function):
     pack kernel).  Bit-identical to PackInputBF16 + Conv3dReLUBF16."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, padding, relu, dy_pregated):
+    def forward(ctx, x, weight, bias, padding, relu, dy_pregated, want_relu_mask):
         wp = packed_conv_weight(weight, False)
         c_out, c_in = weight.shape[0], weight.shape[1]
         need_bwd = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]   # grad mode is off inside forward()
-        y, xp = K.conv3d_fwd_bf16_f32in(x.contiguous(), wp, bias.contiguous() if bias is not None else None, c_out, padding,
-                                        relu, want_packed=need_bwd)
+        want_relu_mask = bool(want_relu_mask and relu and need_bwd)
+        out = K.conv3d_fwd_bf16_f32in(x.contiguous(), wp, bias.contiguous() if bias is not None else None, c_out, padding,
+                                      relu, want_packed=need_bwd, want_relu_mask=want_relu_mask)
+        y, xp = out[0], out[1]
+        mask = out[2] if want_relu_mask else torch.empty(0, dtype=torch.int32, device=y.device)
         ctx.save_for_backward(xp, weight, y if relu else None)
         ctx.cfg = (c_in, c_out, padding, bias is not None, dy_pregated)
-        return y
+        ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)
+        return y, mask
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dmask):
         xp, weight, y = ctx.saved_tensors
         c_in, c_out, padding, has_bias, dy_pregated = ctx.cfg
         gate = None if dy_pregated else y
         dw, db = K.conv3d_bwd_weight_bf16(xp, dy.contiguous(), gate, c_in, c_out, padding)
-        return None, dw, (db if has_bias else None), None, None, None
+        return None, dw, (db if has_bias else None), None, None, None, None
 
 
-def conv3d_first_layer_bf16(x, weight, bias, padding=(0, 0, 0), relu=True, dy_pregated=False):
-    return Conv3dFirstLayerBF16.apply(x, weight, bias, tuple(padding), relu, dy_pregated)
+def conv3d_first_layer_bf16(x, weight, bias, padding=(0, 0, 0), relu=True, dy_pregated=False, want_relu_mask=False):
+    """Returns y, or (y, relu mask of y) when want_relu_mask."""
+    y, mask = Conv3dFirstLayerBF16.apply(x, weight, bias, tuple(padding), relu, dy_pregated, want_relu_mask)
+    return (y, mask) if want_relu_mask else y
 
 
 def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
@@ -241,10 +268,14 @@ class LinearBF16(torch.autograd.Function):
 
 
 def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False, x_is_relu_output=False,
-                     dy_pregated=False):
+                     dy_pregated=False, x_relu_mask=None, want_relu_mask=False):
     """x_is_relu_output: xp is the ReLU output of the previous conv3d_relu_bf16 (its dgrad then gates dx itself);
-    dy_pregated: the consumer of this layer's output is such a layer, so the incoming gradient is already gated."""
-    return Conv3dReLUBF16.apply(xp, weight, bias, c_in, tuple(padding), relu, y_ncdhw, x_is_relu_output, dy_pregated)
+    dy_pregated: the consumer of this layer's output is such a layer, so the incoming gradient is already gated;
+    x_relu_mask: the 1-bit relu mask of xp the previous layer produced (want_relu_mask=True there).
+    Returns y, or (y, relu mask of y) when want_relu_mask."""
+    y, mask = Conv3dReLUBF16.apply(xp, weight, bias, c_in, tuple(padding), relu, y_ncdhw, x_is_relu_output, dy_pregated,
+                                   x_relu_mask, want_relu_mask)
+    return (y, mask) if want_relu_mask else y
 
 
 def linear_bf16(x, weight, bias, relu=False):

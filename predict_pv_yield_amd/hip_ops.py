@@ -276,11 +276,23 @@ def conv3d_pack_weight_bf16(weight: torch.Tensor, transpose_flip: bool = False) 
     return wp
 
 
+def relu_mask_shape(b: int, t: int, h: int, w: int):
+    """Shape of the 1-bit relu mask of an NDHWC activation [b, t, h, w, 32]: int32 [b, t, hp, wp], the plane padded to
+    whole 8 x 32 tiles (pv_relu_mask_dims)."""
+    hp, wp = ctypes.c_int32(), ctypes.c_int32()
+    check(get_lib().pv_relu_mask_dims(h, w, ctypes.byref(hp), ctypes.byref(wp)), "pv_relu_mask_dims")
+    return (b, t, hp.value, wp.value)
+
+
 def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Tensor, bias: Optional[torch.Tensor],
                     c_in: int, c_out: int, padding=(0, 0, 0), relu=True, y_ncdhw=False,
-                    out_gate: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [B,T,H,W,CPAD(c_in)] bf16 -> y [B,To,Ho,Wo,32] bf16 (or [B,c_out,To,Ho,Wo] if y_ncdhw)."""
-    require_cuda(x, gate, wp, bias, out_gate)
+                    out_gate: Optional[torch.Tensor] = None, out_gate_mask: Optional[torch.Tensor] = None,
+                    want_relu_mask: bool = False):
+    """x [B,T,H,W,CPAD(c_in)] bf16 -> y [B,To,Ho,Wo,32] bf16 (or [B,c_out,To,Ho,Wo] if y_ncdhw).
+    want_relu_mask: also return the 1-bit relu mask of y, int32 relu_mask_shape(B,To,Ho,Wo) (bit c = y[..., c] > 0):
+    (y, mask).
+    out_gate_mask: such a mask of `out_gate` (the dgrad epilogue then reads 4 instead of 64 bytes per voxel)."""
+    require_cuda(x, gate, wp, bias, out_gate, out_gate_mask)
     b, t, h, w, cpad = x.shape
     if cpad != bf16_cpad(c_in) or x.dtype != torch.bfloat16:
         raise TypeError("conv3d_fwd_bf16: x must be bf16 [B,T,H,W,CPAD(c_in)]")
@@ -290,14 +302,21 @@ def conv3d_fwd_bf16(x: torch.Tensor, gate: Optional[torch.Tensor], wp: torch.Ten
     y = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
     if out_gate is not None and tuple(out_gate.shape) != shape:
         raise TypeError("conv3d_fwd_bf16: out_gate must have the output's NDHWC shape")
-    check(get_lib().pv_conv3d_fwd_bf16(ptr(x), ptr(gate), ptr(wp), ptr(bias), ptr(y), ptr(out_gate), ctypes.byref(d),
-                                       int(relu), int(y_ncdhw), current_stream_ptr()), "pv_conv3d_fwd_bf16")
-    return y
+    if out_gate_mask is not None and (out_gate is None or out_gate_mask.dtype != torch.int32
+                                      or tuple(out_gate_mask.shape) != relu_mask_shape(*shape[:4])
+                                      or not out_gate_mask.is_contiguous()):
+        raise TypeError("conv3d_fwd_bf16: out_gate_mask must be the contiguous int32 relu mask of out_gate (relu_mask_shape)")
+    mask = torch.empty(relu_mask_shape(*shape[:4]), dtype=torch.int32, device=x.device) if want_relu_mask else None
+    check(get_lib().pv_conv3d_fwd_bf16(ptr(x), ptr(gate), ptr(wp), ptr(bias), ptr(y), ptr(out_gate), ptr(out_gate_mask),
+                                       ptr(mask), ctypes.byref(d), int(relu), int(y_ncdhw), current_stream_ptr()),
+          "pv_conv3d_fwd_bf16")
+    return (y, mask) if want_relu_mask else y
 
 
 def conv3d_fwd_bf16_f32in(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], c_out: int, padding=(0, 0, 0),
-                          relu=True, want_packed=True):
-    """First layer: x f32 NCDHW [B,C<=16,T,H,W] -> (y bf16 NDHWC [B,To,Ho,Wo,32], xp bf16 NDHWC [B,T,H,W,16] or None).
+                          relu=True, want_packed=True, want_relu_mask=False):
+    """First layer: x f32 NCDHW [B,C<=16,T,H,W] -> (y bf16 NDHWC [B,To,Ho,Wo,32], xp bf16 NDHWC [B,T,H,W,16] or None
+    [, relu mask of y int32 [B,To,Ho,Wo] when want_relu_mask]).
     One pass over the input instead of pack + conv; xp is what conv3d_bwd_weight_bf16 reads."""
     require_cuda(x, wp, bias)
     if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
@@ -309,9 +328,10 @@ def conv3d_fwd_bf16_f32in(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torc
     to, ho, wo = d.out_shape()
     y = torch.empty((b, to, ho, wo, 32), dtype=torch.bfloat16, device=x.device)
     xp = torch.empty((b, t, h, w, 16), dtype=torch.bfloat16, device=x.device) if want_packed else None
-    check(get_lib().pv_conv3d_fwd_bf16_f32in(ptr(x), ptr(xp), ptr(wp), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
-                                             current_stream_ptr()), "pv_conv3d_fwd_bf16_f32in")
-    return y, xp
+    mask = torch.empty(relu_mask_shape(b, to, ho, wo), dtype=torch.int32, device=x.device) if want_relu_mask else None
+    check(get_lib().pv_conv3d_fwd_bf16_f32in(ptr(x), ptr(xp), ptr(wp), ptr(bias), ptr(y), ptr(mask), ctypes.byref(d),
+                                             int(relu), current_stream_ptr()), "pv_conv3d_fwd_bf16_f32in")
+    return (y, xp, mask) if want_relu_mask else (y, xp)
 
 
 def conv3d_bwd_weight_bf16(x: torch.Tensor, dy: torch.Tensor, y_mask: Optional[torch.Tensor], c_in: int, c_out: int,

@@ -21,9 +21,16 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
         from ...hip_ops import bf16_cpad
         fused_first = (len(convs) > 1 and data.dtype == torch.float32 and bf16_cpad(c_in) == 16 and padding[2] == 0
                        and not data.requires_grad)
+        # training: every layer but the last also emits the 1-bit relu mask of its output; the next layer's dgrad gates
+        # dx with it (4 bytes per voxel instead of re-reading the 64-byte bf16 activation)
+        masks = Fn.USE_RELU_MASKS and torch.is_grad_enabled() and any(p.requires_grad for c in convs for p in c.parameters())
+        mask = None
         if fused_first:
             # the first layer reads the f32 NCDHW input itself and leaves the NDHWC bf16 image for its wgrad behind
-            out = Fn.conv3d_first_layer_bf16(data, convs[0].weight, convs[0].bias, tuple(padding), relu=True, dy_pregated=True)
+            out = Fn.conv3d_first_layer_bf16(data, convs[0].weight, convs[0].bias, tuple(padding), relu=True, dy_pregated=True,
+                                             want_relu_mask=masks)
+            if masks:
+                out, mask = out
             c_in = channels
         else:
             out = Fn.PackInputBF16.apply(data)
@@ -33,7 +40,11 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
             last = i == len(convs) - 1
             # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
             out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, tuple(padding), relu=True, y_ncdhw=last,
-                                      x_is_relu_output=i > 0, dy_pregated=not last)
+                                      x_is_relu_output=i > 0, dy_pregated=not last, x_relu_mask=mask if i > 0 else None,
+                                      want_relu_mask=masks and not last)
+            mask = None
+            if masks and not last:
+                out, mask = out
             c_in = channels
         out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
         return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True)

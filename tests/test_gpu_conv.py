@@ -233,6 +233,67 @@ def test_conv3d_bf16_random_shapes(device):
         g = torch.randn(y.shape, generator=torch.Generator().manual_seed(it)).to(device).to(torch.bfloat16)
         yg = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, out_gate=g)
         assert torch.equal(yg, torch.where(g > 0, y, torch.zeros_like(y))), msg + " (out_gate)"
+        # 1-bit relu masks: the mask written next to y holds exactly (y > 0) per channel bit, and a dgrad-style launch
+        # gated through the mask of g equals the one that reads the bf16 tensor g
+        y2, mask = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, want_relu_mask=True)
+        assert torch.equal(y2, y), msg + " (mask variant changed y)"
+        assert torch.equal(_mask_bits(mask, y.shape), y > 0), msg + " (relu mask)"
+        gmask = _mask_of(g, K)
+        ygm = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), 32, 32, pad, relu=relu, y_ncdhw=False, out_gate=g,
+                                out_gate_mask=gmask)
+        assert torch.equal(ygm, yg), msg + " (out_gate_mask)"
+
+
+def _mask_bits(mask, y_shape):
+    """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
+    b, t, h, w, c = y_shape
+    m = mask[:, :, :h, :w].to(torch.int64) & 0xFFFFFFFF
+    return ((m.unsqueeze(-1) >> torch.arange(32, device=mask.device)) & 1).bool()
+
+
+def _mask_of(act, K):
+    """Reference construction of the padded relu mask of an NDHWC bf16 activation."""
+    b, t, h, w, c = act.shape
+    bits = ((act > 0).to(torch.int64) << torch.arange(32, device=act.device)).sum(-1)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    mask = torch.zeros(K.relu_mask_shape(b, t, h, w), dtype=torch.int32, device=act.device)
+    mask[:, :, :h, :w] = bits
+    return mask
+
+
+def test_first_layer_relu_mask_and_tower_gradients_with_masks(device):
+    """The f32-input first-layer kernel (v1 tile geometry) writes the same mask; and a 3-layer tower trained with the masks
+    wired through (functional.conv3d_relu_bf16 x_relu_mask / want_relu_mask) has bit-identical gradients to the one that
+    gates with the bf16 activations."""
+    K, Fn = _mods()
+    for (b, ci, t, h, w, pad) in [(2, 11, 7, 16, 16, (0, 0, 0)), (1, 11, 6, 12, 70, (1, 0, 0)), (2, 16, 9, 10, 67, (2, 2, 0))]:
+        x, wt, bias = _conv_case(31, b, ci, 32, t, h, w)
+        wp = K.conv3d_pack_weight_bf16(wt.to(device))
+        y, xp = K.conv3d_fwd_bf16_f32in(x.to(device), wp, bias.to(device), 32, pad, relu=True)
+        y2, xp2, mask = K.conv3d_fwd_bf16_f32in(x.to(device), wp, bias.to(device), 32, pad, relu=True, want_relu_mask=True)
+        assert torch.equal(y, y2) and torch.equal(xp, xp2)
+        assert torch.equal(_mask_bits(mask, y.shape), y > 0)
+    # tower: layer 0 (f32 input) -> layer 1 -> layer 2, with and without masks
+    torch.manual_seed(5)
+    x = torch.randn(2, 11, 9, 20, 40).to(device)
+    ws = [(torch.randn(32, 11 if i == 0 else 32, 3, 3, 3) * 0.08).to(device) for i in range(3)]
+    bs = [(torch.randn(32) * 0.1).to(device) for _ in range(3)]
+    grads = []
+    for use_masks in (False, True):
+        w = [v.clone().requires_grad_(True) for v in ws]
+        bb = [v.clone().requires_grad_(True) for v in bs]
+        out = Fn.conv3d_first_layer_bf16(x, w[0], bb[0], (0, 0, 0), relu=True, dy_pregated=True, want_relu_mask=use_masks)
+        out, mask = out if use_masks else (out, None)
+        out = Fn.conv3d_relu_bf16(out, w[1], bb[1], 32, (0, 0, 0), relu=True, x_is_relu_output=True, dy_pregated=True,
+                                  x_relu_mask=mask, want_relu_mask=use_masks)
+        out, mask = out if use_masks else (out, None)
+        out = Fn.conv3d_relu_bf16(out, w[2], bb[2], 32, (0, 0, 0), relu=True, x_is_relu_output=True, dy_pregated=False,
+                                  x_relu_mask=mask)
+        g = torch.randn(out.shape, generator=torch.Generator().manual_seed(8)).to(device).to(torch.bfloat16)
+        out.backward(g)
+        grads.append([v.grad.clone() for v in w + bb])
+    for a, c in zip(*grads):
+        assert torch.equal(a, c)
 
 
 def test_repack_gate(device):
