@@ -435,6 +435,16 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
                      uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2,
                      double eps, int32_t step, float grad_scale, void* stream);
 
+/* ---- tracing: opt-in per-stage device timing ---------------------------------------------------------------------
+ * The reference times its pipeline stages with wall-clock `%%time` cells (notebooks/optical_flow_1.ipynb:269,
+ * 13_...ipynb:1161); here the multi-kernel entry points (pv_farneback_batch_u8, pv_prepare_stacks_*,
+ * pv_flow_weighted_mean_f32, pv_remap_bilinear_*) record one HIP event per stage boundary on the caller's stream while
+ * a timing session is armed.  pv_stage_timing_end waits for the last event and returns, per distinct stage label
+ * (static strings, first-seen order), the summed milliseconds and the number of occurrences.  Process-global, one
+ * session / one stream at a time; nothing is recorded on a stream that is being captured into a graph. */
+int pv_stage_timing_begin(void);
+int pv_stage_timing_end(const char** names, float* ms, int32_t* counts, int32_t capacity, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1065,6 +1065,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     const long long lpx = (long long)lw * lh;
     float* flow = k > 0 ? flow_buf[pingpong] : flow0;
     pingpong ^= 1;
+    const bool coarse = k > 0;
+    stage_mark(coarse ? "farneback.coarse.flow_init" : "farneback.level0.flow_upsample", st);
     if (!prev_flow) {
       hipError_t e = hipMemsetAsync(flow, 0, (size_t)n_pairs * lpx * 2 * sizeof(float), st);
       PV_REQUIRE(e == hipSuccess, PV_ELAUNCH, "pv_farneback_batch_u8: memset failed");
@@ -1085,6 +1087,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     if (lw == w && lh == h) mode = 0;
     else if (fabs(inv_fx - 2.0) < 2.220446049250313e-16 && fabs(inv_fy - 2.0) < 2.220446049250313e-16) mode = 1;
     else mode = 2;
+    stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
     if (h <= 64 && w <= 64 && smooth_sz <= 63) {
       const unsigned grid = (unsigned)std::min<long long>(n_pairs * 2, 4096);
       hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
@@ -1101,6 +1104,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
     }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
+    stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
     hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                        (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0);
     for (int it = 0; it < p->iterations; ++it) {
@@ -1110,6 +1114,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         // flow-dependent R1 gathers need many waves in flight)
         float* Gv = (float*)(ws + L.off_G);
         float* Gh = lh == lw ? Gv : Gv + 64 * 64;   // square levels: the vertical and horizontal window matrices coincide
+        stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
         if (it == 0) {
           hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
           if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
@@ -1123,23 +1128,29 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
           hipLaunchKernelGGL(fb_tile_mfma_kernel<false>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
                              (const float*)Gh, flow, lh, lw, (long long)n_pairs);
         }
-        if (update)
+        if (update) {
+          stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
           hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                              (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1);
+        }
         continue;
       }
+      stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
       hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
                          (const float*)M, V, (long long)n_pairs, lh, lw, win);
       hipLaunchKernelGGL(fb_blur_h_solve_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                          (const float*)V, flow, (long long)n_pairs, lh, lw, win);
-      if (update)
+      if (update) {
+        stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
         hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                            (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 0);
+      }
     }
     prev_flow = flow;
     prev_w = lw;
     prev_h = lh;
   }
+  stage_mark(nullptr, st);
   return check_launch("pv_farneback_batch_u8");
 }
 

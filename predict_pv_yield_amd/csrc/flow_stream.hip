@@ -525,11 +525,17 @@ int pv_u8_from_10bit_f32(const float* src, uint8_t* dst, size_t n, int mode, int
 
 int pv_prepare_stacks_i16(const int16_t* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
                           int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream) {
-  return prepare_stacks_launch<int16_t>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
+  stage_mark("prepare_stacks (raw -> u8 stacks + normalised frames)", as_stream(stream));
+  const int rc = prepare_stacks_launch<int16_t>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
+  stage_mark(nullptr, as_stream(stream));
+  return rc;
 }
 int pv_prepare_stacks_f32(const float* raw, uint8_t* u8, float* out, int64_t batch, int32_t t, int32_t c, int64_t frame,
                           int32_t t_out, int mode, const float* mean, const float* std_, int32_t* range_flag, void* stream) {
-  return prepare_stacks_launch<float>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
+  stage_mark("prepare_stacks (raw -> u8 stacks + normalised frames)", as_stream(stream));
+  const int rc = prepare_stacks_launch<float>(raw, u8, out, batch, t, c, frame, t_out, mode, mean, std_, range_flag, stream);
+  stage_mark(nullptr, as_stream(stream));
+  return rc;
 }
 
 int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host, float* out,
@@ -550,6 +556,7 @@ int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host, fl
   wts.sum = s;
   wts.inv_unused = 0.0;
   hipStream_t st = as_stream(stream);
+  stage_mark("flow_weighted_mean", st);
   bool vec = (elems % 4 == 0) && ((uintptr_t)flows % 16 == 0) && ((uintptr_t)out % 16 == 0);
   if (vec) {
     hipLaunchKernelGGL((weighted_mean_kernel<4>), dim3(stream_grid((size_t)n_groups * (elems / 4), 256)),
@@ -558,6 +565,7 @@ int pv_flow_weighted_mean_f32(const float* flows, const double* weights_host, fl
     hipLaunchKernelGGL((weighted_mean_kernel<1>), dim3(stream_grid((size_t)n_groups * elems, 256)),
                        dim3(256), 0, st, flows, out, n_groups, n_per_group, elems, wts);
   }
+  stage_mark(nullptr, st);
   return check_launch("pv_flow_weighted_mean_f32");
 }
 
@@ -565,8 +573,11 @@ int pv_remap_bilinear_f32(const float* src, int64_t src_stride, const float* flo
                           float* dst, int64_t dst_image_stride, int64_t dst_step_stride,
                           int64_t n_images, int32_t n_steps, float step0, int32_t h, int32_t w,
                           int border_mode, float border_value, void* stream) {
-  return remap_launch<float>(src, src_stride, flow, flow_stride, dst, dst_image_stride, dst_step_stride,
-                             n_images, n_steps, step0, h, w, border_mode, border_value, stream);
+  stage_mark("remap_bilinear", as_stream(stream));
+  const int rc = remap_launch<float>(src, src_stride, flow, flow_stride, dst, dst_image_stride, dst_step_stride,
+                                     n_images, n_steps, step0, h, w, border_mode, border_value, stream);
+  stage_mark(nullptr, as_stream(stream));
+  return rc;
 }
 int pv_remap_bilinear_u8(const uint8_t* src, int64_t src_stride, const float* flow, int64_t flow_stride,
                          uint8_t* dst, int64_t dst_image_stride, int64_t dst_step_stride,

@@ -22,6 +22,10 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// opt-in per-stage device timing (stage_timer.hip): everything enqueued on `st` up to the next mark belongs to `label`
+// (a string literal); nullptr closes the current stage.  A no-op unless pv_stage_timing_begin() armed it.
+void stage_mark(const char* label, hipStream_t st);
+
 constexpr int kWave = 64;      // CDNA wavefront
 constexpr int kNumCU = 256;    // MI355X
 

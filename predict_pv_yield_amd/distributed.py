@@ -216,6 +216,73 @@ class OverlappedGradSync:
                 del p._pv_on_grad
 
 
+_FALLBACKS = {"sharded": ("sharded", "bf16", "autograd"), "bf16": ("bf16", "autograd"), "autograd": ("autograd",)}
+
+
+def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> str:
+    """Collective.  Tries the requested gradient-exchange mode of the big layer with ONE untimed train step in THIS
+    process -- "sharded" (reduce-scatter -> row-sharded Adam -> all-gather of the bf16 operand copy), "bf16" (one bf16
+    all-reduce), "autograd" (f32 all-reduce of .grad) -- and, if the step raises on any rank, moves every rank to the
+    next simpler mode together (the outcome is agreed with an all-reduce, parameters are re-broadcast).  Returns the
+    mode in force.  Exits non-zero with a clear message if none works; never re-executes the process (the GPU is
+    initialised: an exec would take the node down)."""
+    if mode not in _FALLBACKS:
+        raise ValueError(mode)
+    if not is_distributed():
+        optimizer.set_large_grad_mode(mode)
+        return optimizer.large_grad_mode
+    dev = next(model.parameters()).device
+    flag_dev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+    errors = []
+    def all_ok(ok: int) -> bool:
+        agreed = torch.tensor([ok], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        return int(agreed.item()) == 1
+
+    for candidate in _FALLBACKS[mode]:
+        ok, sync = 1, None
+        # phase 1, local: switching the optimiser over.  Agreed on BEFORE any collective of the trial step is issued, so a
+        # rank that cannot even set the mode does not leave the others inside a gradient exchange it never joins
+        try:
+            optimizer.set_large_grad_mode(candidate)
+        except Exception as e:      # noqa: BLE001
+            ok = 0
+            errors.append(f"{candidate}: {type(e).__name__}: {e}")
+        if all_ok(ok):
+            # phase 2: one whole train step with the real collectives
+            try:
+                sync = OverlappedGradSync(model)
+                optimizer.zero_grad(set_to_none=True)
+                model.training_step(batch, 0).backward()
+                sync.finish()
+                optimizer.step()
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+            except Exception as e:      # noqa: BLE001 -- any failure of the trial step demotes the mode
+                ok = 0
+                errors.append(f"{candidate}: {type(e).__name__}: {e}")
+            finally:
+                if sync is not None:
+                    sync.remove()
+            ok = 1 if all_ok(ok) else 0
+        else:
+            ok = 0
+        if ok:
+            return optimizer.large_grad_mode
+        if dist.get_rank() == 0:
+            print(f"[predict_pv_yield_amd] gradient exchange mode '{candidate}' failed on at least one rank"
+                  f" ({errors[-1] if errors else 'on another rank'}); trying the next simpler mode", flush=True)
+        # drop whatever the failed attempt left behind, then make the replicas identical again
+        for p in optimizer.large_params():
+            p._pv_pending = p._pv_grad_bf16 = p._pv_grad_shard = None
+            p._pv_shadow_work = None
+            if hasattr(p, "_pv_bf16_shadow"):
+                del p._pv_bf16_shadow
+        optimizer._sharded_dirty = False
+        broadcast_parameters(model)
+    raise SystemExit("predict_pv_yield_amd: no gradient-exchange mode works on this job (" + "; ".join(errors) + ")")
+
+
 def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, float]:
     """All logged scalars of one log_dict call travel as ONE vector (the reference sends one tiny all-reduce each)."""
     if not is_distributed():

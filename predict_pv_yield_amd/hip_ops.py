@@ -276,6 +276,29 @@ def conv3d_pack_weight_bf16(weight: torch.Tensor, transpose_flip: bool = False) 
     return wp
 
 
+class stage_timing:
+    """Context manager around pv_stage_timing_begin / _end: per-stage device milliseconds of the multi-kernel entry points
+    (Farnebäck pyramid, advection stages) recorded with HIP events on the launching stream.
+        with K.stage_timing() as st: ...pv calls...
+        st.stages  ->  {label: (total_ms, occurrences)} in first-seen order"""
+
+    def __init__(self, capacity: int = 64):
+        self.capacity, self.stages = capacity, {}
+
+    def __enter__(self):
+        check(get_lib().pv_stage_timing_begin(), "pv_stage_timing_begin")
+        return self
+
+    def __exit__(self, *exc):
+        names = (ctypes.c_char_p * self.capacity)()
+        ms = (ctypes.c_float * self.capacity)()
+        counts = (ctypes.c_int32 * self.capacity)()
+        n = ctypes.c_int32(0)
+        check(get_lib().pv_stage_timing_end(names, ms, counts, self.capacity, ctypes.byref(n)), "pv_stage_timing_end")
+        self.stages = {names[i].decode(): (float(ms[i]), int(counts[i])) for i in range(n.value)}
+        return False
+
+
 def relu_mask_shape(b: int, t: int, h: int, w: int):
     """Shape of the 1-bit relu mask of an NDHWC activation [b, t, h, w, 32]: int32 [b, t, hp, wp], the plane padded to
     whole 8 x 32 tiles (pv_relu_mask_dims)."""

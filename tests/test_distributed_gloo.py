@@ -72,6 +72,34 @@ def _worker(rank, world, port, ret):
         assert spans[-1][1] == (n // w) * w
     with pytest.raises(ValueError):
         D.shard_range(3, 0, 8)                                   # fewer items than ranks: hard error, not an empty shard
+    # negotiate_grad_sync: a mode that fails on ONE rank moves EVERY rank to the next simpler mode, in-process
+    class _Opt(torch.optim.SGD):
+        def __init__(self, params):
+            super().__init__(params, lr=0.1)
+            self.large_grad_mode, self.tried = None, []
+
+        def large_params(self):
+            return []
+
+        def set_large_grad_mode(self, mode):
+            self.tried.append(mode)
+            if mode == "sharded" and rank == 1:
+                raise RuntimeError("simulated: reduce_scatter unsupported")
+            self.large_grad_mode = mode
+
+    class _M(nn.Linear):
+        def training_step(self, batch, i):
+            return (self(batch) ** 2).mean()
+
+    m = _M(3, 1)
+    D.broadcast_parameters(m)
+    o = _Opt(m.parameters())
+    assert D.negotiate_grad_sync(m, o, torch.ones(2, 3), "sharded") == "bf16"
+    assert o.tried == ["sharded", "bf16"] and o.large_grad_mode == "bf16"
+    wv = torch.cat([p.detach().flatten() for p in m.parameters()])
+    both = [torch.zeros_like(wv) for _ in range(world)]
+    dist.all_gather(both, wv)
+    assert torch.equal(both[0], both[1])                # re-broadcast after the failed attempt, then one common step
     # the Trainer drives the same helpers: a toy fit keeps the replicas identical
     from predict_pv_yield_amd import lightning as pl
 
