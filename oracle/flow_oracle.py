@@ -173,6 +173,35 @@ def farneback_level_polyexp(img: np.ndarray, level: int, pyr_scale=0.5, poly_n=5
     return I, R
 
 
+def poly_exp(image_f32: np.ndarray, poly_n=5, poly_sigma=0.7) -> np.ndarray:
+    """FarnebackPolyExp of a float image [h,w] -> [h,w,5] = (r_y, r_x, r_yy, r_xx, r_xy)."""
+    a = np.ascontiguousarray(image_f32, np.float32)
+    h, w = a.shape
+    R = np.empty((h, w, 5), np.float32)
+    lib().pvo_poly_exp_f32(_p(a), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(poly_n), ctypes.c_double(poly_sigma), _p(R))
+    return R
+
+
+def update_matrices(R0: np.ndarray, R1: np.ndarray, flow: np.ndarray) -> np.ndarray:
+    """FarnebackUpdateMatrices: R0, R1 [h,w,5], flow [h,w,2] -> M [h,w,5] = (G11, G12, G22, h1, h2)."""
+    R0, R1 = np.ascontiguousarray(R0, np.float32), np.ascontiguousarray(R1, np.float32)
+    fl = np.ascontiguousarray(flow, np.float32)
+    h, w = fl.shape[:2]
+    M = np.empty((h, w, 5), np.float32)
+    lib().pvo_update_matrices_f32(_p(R0), _p(R1), _p(fl), ctypes.c_int(h), ctypes.c_int(w), _p(M))
+    return M
+
+
+def window_blur_solve(M: np.ndarray, winsize=40):
+    """One window-blur + 2x2-solve pass over M [h,w,5]: (blurred M [h,w,5], flow [h,w,2])."""
+    Mc = np.ascontiguousarray(M, np.float32)
+    h, w = Mc.shape[:2]
+    blurred = np.empty((h, w, 5), np.float32)
+    flow = np.empty((h, w, 2), np.float32)
+    lib().pvo_window_blur_solve_f32(_p(Mc), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(winsize), _p(blurred), _p(flow))
+    return blurred, flow
+
+
 # ------------------------------------------------------------------------------------------------
 # the joined nb-13 / optical_flow_1 pipeline on [T, H, W] stacks (CPU reference of config 3)
 # ------------------------------------------------------------------------------------------------

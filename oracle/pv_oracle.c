@@ -576,7 +576,8 @@ void pvo_farneback_window_taps(int winsize, float* kernel) {
 
 /* FarnebackUpdateFlow_GaussianBlur (scalar path), including the lagging row-stripe matrix update */
 static void update_flow_gaussian_blur(const float* R0, const float* R1, float* flowa, float* matM,
-                                      int height, int width, int block_size, int update_matrices_flag) {
+                                      int height, int width, int block_size, int update_matrices_flag,
+                                      float* blurred_out /* may be NULL: the window-blurred M, [h][w][5] */) {
   int m = block_size / 2;
   int y0 = 0, y1;
   int min_update_stripe = (1 << 10) / width > block_size ? (1 << 10) / width : block_size;
@@ -611,6 +612,7 @@ static void update_flow_gaussian_blur(const float* R0, const float* R1, float* f
       for (int i = 1; i <= m; i++) sum += kernel[i] * (vsum[x - i * 5] + vsum[x + i * 5]);
       hsum[x] = sum;
     }
+    if (blurred_out) memcpy(blurred_out + (size_t)y * width * 5, hsum, sizeof(float) * (size_t)width * 5);
     for (int x = 0; x < width; x++) {
       g11 = hsum[x * 5];
       g12 = hsum[x * 5 + 1];
@@ -687,7 +689,7 @@ int pvo_farneback_u8(const uint8_t* prev0, const uint8_t* next0, float* flow0, i
     float* M = (float*)malloc(sizeof(float) * npx * 5);
     update_matrices(R[0], R[1], flow, M, height, width, 0, height);
     for (int i = 0; i < p->iterations; i++)
-      update_flow_gaussian_blur(R[0], R[1], flow, M, height, width, p->winsize, i < p->iterations - 1);
+      update_flow_gaussian_blur(R[0], R[1], flow, M, height, width, p->winsize, i < p->iterations - 1, NULL);
     free(M); free(R[0]); free(R[1]);
     if (prevFlow) free(prevFlow);
     prevFlow = k > 0 ? flow : NULL;
@@ -716,4 +718,25 @@ int pvo_farneback_level_polyexp(const uint8_t* img, int rows, int cols, int leve
   poly_exp(I_out, R_out, height, width, poly_n, poly_sigma);
   free(fimg); free(fblur);
   return 0;
+}
+
+/* ---- stage-level access for the analytic pins of tests/test_oracle_flow.py (each is the static routine above, unchanged) ---- */
+
+/* FarnebackPolyExp of a float image: R[h][w][5] = (r_y, r_x, r_yy, r_xx, r_xy) */
+void pvo_poly_exp_f32(const float* src, int rows, int cols, int poly_n, double poly_sigma, float* R_out) {
+  poly_exp(src, R_out, rows, cols, poly_n, poly_sigma);
+}
+
+/* FarnebackUpdateMatrices over the whole image: M[h][w][5] = (G11, G12, G22, h1, h2) */
+void pvo_update_matrices_f32(const float* R0, const float* R1, const float* flow, int rows, int cols, float* M_out) {
+  update_matrices(R0, R1, flow, M_out, rows, cols, 0, rows);
+}
+
+/* one FarnebackUpdateFlow_GaussianBlur pass WITHOUT the matrix update: M (read only) -> window-blurred M and the flow of
+ * the 2x2 solve */
+void pvo_window_blur_solve_f32(const float* M, int rows, int cols, int winsize, float* blurred_out, float* flow_out) {
+  float* Mc = (float*)malloc(sizeof(float) * (size_t)rows * cols * 5);
+  memcpy(Mc, M, sizeof(float) * (size_t)rows * cols * 5);
+  update_flow_gaussian_blur(NULL, NULL, flow_out, Mc, rows, cols, winsize, 0, blurred_out);
+  free(Mc);
 }

@@ -189,6 +189,79 @@ def test_polyexp_linear_ramp_gives_unit_gradient():
     assert np.abs(c[..., 2:]).max() < 1e-3
 
 
+def test_polyexp_quadratic_image_closed_form():
+    """A polynomial of degree 2 is reproduced exactly by the weighted least-squares fit of PolyExp (basis 1, x, y, x^2,
+    y^2, xy under the separable Gaussian weight): at pixel (x0, y0) the expansion of
+        I = a + bx x + by y + cxx x^2 + cyy y^2 + cxy x y
+    is r_x = bx + 2 cxx x0 + cxy y0, r_y = by + 2 cyy y0 + cxy x0, r_xx = cxx, r_yy = cyy, r_xy = cxy (interior pixels:
+    the replicated border is not a polynomial)."""
+    h, w = 36, 44
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    a, bx, by, cxx, cyy, cxy = 7.0, 3.0, -2.0, 0.5, 0.25, 0.125          # every value of I is exact in f32
+    img = (a + bx * xx + by * yy + cxx * xx * xx + cyy * yy * yy + cxy * xx * yy).astype(np.float32)
+    R = fo.poly_exp(img)
+    inner = (slice(5, h - 5), slice(5, w - 5))
+    np.testing.assert_allclose(R[..., 1][inner], (bx + 2 * cxx * xx + cxy * yy)[inner], rtol=2e-5, atol=2e-4)   # r_x
+    np.testing.assert_allclose(R[..., 0][inner], (by + 2 * cyy * yy + cxy * xx)[inner], rtol=2e-5, atol=2e-4)   # r_y
+    np.testing.assert_allclose(R[..., 3][inner], cxx, rtol=0, atol=2e-4)                                        # r_xx
+    np.testing.assert_allclose(R[..., 2][inner], cyy, rtol=0, atol=2e-4)                                        # r_yy
+    np.testing.assert_allclose(R[..., 4][inner], cxy, rtol=0, atol=2e-4)                                        # r_xy
+
+
+def test_window_blur_rows_and_columns_match_scipy_correlate1d():
+    """The 41-tap Gaussian window (winsize 40: m = 20, sigma = 6) is a separable, border-REPLICATED correlation:
+    scipy.ndimage.correlate1d(mode="nearest") with the symmetric tap vector, vertical then horizontal, per channel."""
+    rng = np.random.default_rng(11)
+    M = rng.normal(0, 1, (50, 70, 5)).astype(np.float32)
+    blurred, flow = fo.window_blur_solve(M, 40)
+    k = fo.farneback_window_taps(40).astype(np.float64)
+    taps = np.concatenate([k[:0:-1], k])                                  # k20 .. k1 k0 k1 .. k20
+    ref = ndimage.correlate1d(ndimage.correlate1d(M.astype(np.float64), taps, axis=0, mode="nearest"), taps, axis=1,
+                              mode="nearest")
+    np.testing.assert_allclose(blurred, ref, rtol=0, atol=5e-6)
+    # a narrow window exercises the replicated border on every pixel of a small image
+    b3, _ = fo.window_blur_solve(M[:7, :9], 6)
+    k3 = fo.farneback_window_taps(6).astype(np.float64)
+    t3 = np.concatenate([k3[:0:-1], k3])
+    ref3 = ndimage.correlate1d(ndimage.correlate1d(M[:7, :9].astype(np.float64), t3, axis=0, mode="nearest"), t3, axis=1,
+                               mode="nearest")
+    np.testing.assert_allclose(b3, ref3, rtol=0, atol=5e-6)
+    # 2x2 solve on the blurred matrices: flow = G^-1 h with the +1e-3 regulariser on the determinant
+    g11, g12, g22, h1, h2 = (blurred[..., i].astype(np.float64) for i in range(5))
+    idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3)
+    np.testing.assert_allclose(flow[..., 0], (g11 * h2 - g12 * h1) * idet, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(flow[..., 1], (g22 * h1 - g12 * h2) * idet, rtol=1e-6, atol=1e-6)
+
+
+def test_update_matrices_closed_form_for_a_pure_translation_of_a_quadratic():
+    """For R1 = the expansion of the same quadratic image shifted by d and flow = d, UpdateMatrices' sampled R1
+    coefficients equal R0's second-order terms exactly and r2/r3 reduce to A d: the solve then returns d itself.
+    Checked on interior pixels with a constant (hence trivially blurred) coefficient field."""
+    h, w = 40, 40
+    cxx, cyy, cxy = 0.5, 0.25, 0.125
+    d = np.array([1.5, -0.75])                       # (dx, dy)
+    # PolyExp fields of I(p) and of I2(p) = I(p - d): same A, linear term shifted by -2 A d
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    def field(ox, oy):
+        rx = 3.0 + 2 * cxx * (xx - ox) + cxy * (yy - oy)
+        ry = -2.0 + 2 * cyy * (yy - oy) + cxy * (xx - ox)
+        return np.stack([ry, rx, np.full_like(xx, cyy), np.full_like(xx, cxx), np.full_like(xx, cxy)], -1).astype(np.float32)
+    R0, R1 = field(0.0, 0.0), field(d[0], d[1])
+    flow = np.broadcast_to(d.astype(np.float32), (h, w, 2)).copy()
+    M = fo.update_matrices(R0, R1, flow)
+    inner = (slice(8, h - 8), slice(8, w - 8))
+    g11, g12, g22, h1, h2 = (M[..., i][inner].astype(np.float64) for i in range(5))
+    # A = [[r_yy, r_xy/2], [r_xy/2, r_xx]] in (y, x) order: G = A^T A, h = A^T (A d) with d = (dy, dx)
+    A = np.array([[cyy, cxy / 2], [cxy / 2, cxx]])
+    G = A.T @ A
+    hv = A.T @ (A @ np.array([d[1], d[0]]))
+    np.testing.assert_allclose(g11, G[0, 0], rtol=1e-5)
+    np.testing.assert_allclose(g12, G[0, 1], rtol=1e-5)
+    np.testing.assert_allclose(g22, G[1, 1], rtol=1e-5)
+    np.testing.assert_allclose(h1, hv[0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(h2, hv[1], rtol=1e-4, atol=1e-6)
+
+
 def test_advect_frames_pipeline_shapes_and_known_motion():
     raw, vel = advected_counts(batch=1, t=5, channels=1, h=64, w=64, seed=9, vmax=1.5)
     mean, std = np.array([93.23458], np.float32), np.array([115.34247], np.float32)
