@@ -175,16 +175,18 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 // PolyExp triples T all live in LDS; only the 5 polynomial coefficients R go to memory (the three-kernel path writes and
 // re-reads I and T: 130 bytes per level-pixel of extra traffic and two more launches).  Every expression is the one of
 // fb_prep_kernel / fb_polyexp_v_kernel / fb_polyexp_h_kernel, evaluated in the same order: bit-identical results.
-constexpr int FB_PP_NT = 1024;   // 16 waves per workgroup: the 80 KB of LDS allow one workgroup per CU, so it must be a big one
-__global__ __launch_bounds__(FB_PP_NT) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
+// 64 KB of LDS (the first PolyExp plane reuses the buffer of the blurred image, dead by then) and <= 64 registers: TWO
+// 16-wave workgroups share a CU, so one's barrier-separated phases overlap the other's.
+constexpr int FB_PP_NT = 1024;
+__global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
                                                                     const uint8_t* __restrict__ next, long long prev_stride,
                                                                     long long next_stride, long long pairs_per_group,
                                                                     long long group_stride, float* __restrict__ R,
                                                                     long long n_img, int h, int w, int lh, int lw, int mode,
                                                                     double inv_fx, double inv_fy, FbTaps kt, FbPoly pk) {
-  __shared__ float bufA[64 * 64];        // source as float, later the blurred image
+  __shared__ float bufA[64 * 64];        // source as float, later the blurred image, later PolyExp plane t0
   __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
-  __shared__ float Tt[3 * 64 * 64];      // vertical PolyExp triples, planar
+  __shared__ float Tt12[2 * 64 * 64];    // vertical PolyExp planes t1, t2
   const int tid = threadIdx.x;
   const int ks = kt.n, r = ks >> 1;
   // row index of a flat pixel index: a shift for power-of-two widths (the usual 64 / 32), else a division
@@ -273,15 +275,15 @@ __global__ __launch_bounds__(FB_PP_NT) void fb_prep_polyexp_tile_kernel(const ui
         t1 = __fadd_rn(t1, __fmul_rn(pk.xg[k], __fsub_rn(s1, s0)));
         t2 = __fadd_rn(t2, __fmul_rn(pk.xxg[k], pp));
       }
-      Tt[i] = t0, Tt[lpx + i] = t1, Tt[2 * lpx + i] = t2;
+      bufA[i] = t0, Tt12[i] = t1, Tt12[lpx + i] = t2;   // bufA (blurred image) was consumed by the resize above
     }
     __syncthreads();
     // PolyExp, horizontal pass (double accumulators) -> R
     for (int i = tid; i < lpx; i += FB_PP_NT) {
       const int y = row_lw(i), x = i - y * lw;
-      const float* t0r = Tt + y * lw;
-      const float* t1r = Tt + lpx + y * lw;
-      const float* t2r = Tt + 2 * lpx + y * lw;
+      const float* t0r = bufA + y * lw;
+      const float* t1r = Tt12 + y * lw;
+      const float* t2r = Tt12 + lpx + y * lw;
       float g0 = pk.g[0];
       double b1 = __fmul_rn(t0r[x], g0), b2 = 0, b3 = __fmul_rn(t1r[x], g0), b4 = 0, b5 = __fmul_rn(t2r[x], g0), b6 = 0;
       for (int k = 1; k <= pk.n; ++k) {
