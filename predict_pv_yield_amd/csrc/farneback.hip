@@ -389,265 +389,24 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
   }
 }
 
-// ---- fused iteration for levels that fit one workgroup (<= 64 x 64): window blur (vertical + horizontal) of the 5
-// channels through LDS, 2x2 solve, and the UpdateMatrices of the next iteration, one workgroup per image pair.
-// M is planar [pair][5][lh][lw].  Thread mapping: vertical pass (x = tid & 63, 16 rows), result written TRANSPOSED
-// (padded to 65) so that the horizontal pass is again a per-thread sliding window (row y = tid & 63, 16 columns).
-// Summation order is FarnebackUpdateFlow_GaussianBlur's (centre tap, then pairs outward); the multiply-adds are fused
-// (one rounding instead of two per tap: ~1e-7 relative, far inside the 1e-3 px parity bar) to halve the VALU work.
-template <int MW, int SEG>  // MW = winsize / 2; SEG = outputs per thread; 64 * (64 / SEG) threads
-__global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_kernel(const float* __restrict__ Min, float* __restrict__ Mout,
-                                                            const float* __restrict__ R, float* __restrict__ flow,
-                                                            int height, int width, FbTaps kt, int update) {
-  constexpr int TS = 64, WIN = SEG + 2 * MW, NT = 64 * (64 / SEG);
-  __shared__ float A[TS * TS];
-  __shared__ float Bt[TS * (TS + 1)];
-  const long long p = blockIdx.x;
-  const long long per_img = (long long)height * width;
-  const int tid = threadIdx.x;
-  const int lane64 = tid & 63, seg = tid >> 6;
-  float tap[MW + 1];
-#pragma unroll
-  for (int k = 0; k <= MW; ++k) tap[k] = kt.k[k];
-  float hres[5][SEG];
-  constexpr int NE = TS * TS / NT;  // tile elements per thread
-  const int npx = height * width;
-  float nxt[NE];
-  {
-    const float* src = Min + (p * 5) * per_img;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = tid + e * NT;
-      nxt[e] = i < npx ? src[i] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = tid + e * NT;
-      if (i < npx) { const int y = i / width; A[y * TS + (i - y * width)] = nxt[e]; }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < 5; ++c) {  // unrolled: hres must be indexed statically to stay in registers
-    if (c < 4) {  // prefetch the next channel's plane under this channel's arithmetic
-      const float* src = Min + (p * 5 + c + 1) * per_img;
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int i = tid + e * NT;
-        nxt[e] = i < npx ? src[i] : 0.f;
-      }
-    }
-    // vertical blur: column x = lane64, rows seg*16 .. +15
-    if (lane64 < width) {
-      float win[WIN];
-#pragma unroll
-      for (int i = 0; i < WIN; ++i) {
-        int y = seg * SEG - MW + i;
-        y = y < 0 ? 0 : (y > height - 1 ? height - 1 : y);
-        win[i] = A[y * TS + lane64];
-      }
-#pragma unroll
-      for (int j = 0; j < SEG; ++j) {
-        float s0 = __fmul_rn(win[j + MW], tap[0]);
-#pragma unroll
-        for (int k = 1; k <= MW; ++k) s0 = fmaf(__fadd_rn(win[j + MW + k], win[j + MW - k]), tap[k], s0);
-        const int y = seg * SEG + j;
-        if (y < height) Bt[lane64 * (TS + 1) + y] = s0;
-      }
-    }
-    __syncthreads();  // vertical results visible; every read of A is done
-    if (c < 4) {
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int i = tid + e * NT;
-        if (i < npx) { const int y = i / width; A[y * TS + (i - y * width)] = nxt[e]; }
-      }
-    }
-    // horizontal blur: row y = lane64, columns seg*16 .. +15 (reads the transposed image: conflict-free)
-    if (lane64 < height) {
-      float win[WIN];
-#pragma unroll
-      for (int i = 0; i < WIN; ++i) {
-        int x = seg * SEG - MW + i;
-        x = x < 0 ? 0 : (x > width - 1 ? width - 1 : x);
-        win[i] = Bt[x * (TS + 1) + lane64];
-      }
-#pragma unroll
-      for (int j = 0; j < SEG; ++j) {
-        float s0 = __fmul_rn(win[j + MW], tap[0]);
-#pragma unroll
-        for (int k = 1; k <= MW; ++k) s0 = fmaf(tap[k], __fadd_rn(win[j + MW - k], win[j + MW + k]), s0);
-        hres[c][j] = s0;
-      }
-    }
-    __syncthreads();  // Bt may be overwritten by the next channel; the new A plane is visible
-  }
-  if (lane64 < height) {
-    const int y = lane64;
-    const float* R1 = R + (p * 2 + 1) * per_img * 5;
-#pragma unroll
-    for (int j = 0; j < SEG; ++j) {
-      const int x = seg * SEG + j;
-      if (x < width) {
-        double g11 = hres[0][j], g12 = hres[1][j], g22 = hres[2][j], h1 = hres[3][j], h2 = hres[4][j];
-        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-        double idet = __ddiv_rn(1.0, det);
-        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-        const long long pix = (long long)y * width + x;
-        float* fl = flow + (p * per_img + pix) * 2;
-        fl[0] = fxv;
-        fl[1] = fyv;
-        if (update) {
-          float m[5];
-          fb_update_pixel(R + ((p * 2) * per_img + pix) * 5, R1, fxv, fyv, x, y, width, height, m);
-#pragma unroll
-          for (int c = 0; c < 5; ++c) Mout[(p * 5 + c) * per_img + pix] = m[c];
-        }
-      }
-    }
-  }
-}
-
-// Packed-f32 version of the tile kernel (v_pk_add_f32 / v_pk_fma_f32: two channels per VALU instruction).  Plain f32
-// adds / fmas issue at half the rate of the packed forms on CDNA3/4, and the first tile kernel spent as many
-// instructions on clamped window addresses as on arithmetic (ISA: 3240 math + ~3000 address ops per thread).  Here
-//   * channels are processed in PAIRS (g11|g12, g22|h1, h2|-) as float2 lanes of the same instruction,
-//   * both LDS images are stored with REPLICATED BORDERS (MW rows above / below the tile for the vertical pass, MW
-//     transposed rows left / right for the horizontal pass), so every window element is one ds_read_b64 at a constant
-//     offset from a per-thread base: no clamps, no address arithmetic in the loops.
-// Same summation order and the same single rounding per fused multiply-add as fb_tile_iter_kernel.
-typedef float fb_f2 __attribute__((ext_vector_type(2)));
-
-template <int MW, int SEG>
-__global__ __launch_bounds__(64 * (64 / SEG)) void fb_tile_iter_pk_kernel(const float* __restrict__ Min,
-                                                                         const float* __restrict__ R,
-                                                                         float* __restrict__ flow, int height, int width,
-                                                                         FbTaps kt, long long n_pairs) {
-  constexpr int TS = 64, WIN = SEG + 2 * MW, NT = 64 * (64 / SEG), PR = TS + 2 * MW, TP = TS + 1;
-  __shared__ fb_f2 A2[PR * TS];   // rows -MW .. TS+MW-1 (replicated above row 0 / below row height-1)
-  __shared__ fb_f2 B2[PR * TP];   // transposed: rows = x + MW (replicated left of x = 0 / right of x = width-1), cols = y
-  const long long per_img = (long long)height * width;
-  const int tid = threadIdx.x;
-  const int lane64 = tid & 63, seg = tid >> 6;
-  float tap[MW + 1];
-#pragma unroll
-  for (int k = 0; k <= MW; ++k) tap[k] = kt.k[k];
-  fb_f2 hres[3][SEG];
-  constexpr int NE = TS * TS / NT;
-  const int npx = height * width;
-  fb_f2 nxt[NE];
-  auto load_pair = [&](long long p, int cp) {
-    const float* s0 = Min + (p * 5 + 2 * cp) * per_img;
-    const float* s1 = Min + (p * 5 + (2 * cp + 1 < 5 ? 2 * cp + 1 : 4)) * per_img;   // channel 4 is paired with itself
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = tid + e * NT;
-      nxt[e] = i < npx ? (fb_f2){s0[i], s1[i]} : (fb_f2){0.f, 0.f};
-    }
-  };
-  auto store_pair = [&]() {
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int i = tid + e * NT;
-      if (i < npx) {
-        const int y = i / width, x = i - y * width;
-        A2[(y + MW) * TS + x] = nxt[e];
-        if (y == 0) {
-#pragma unroll
-          for (int r = 0; r < MW; ++r) A2[r * TS + x] = nxt[e];
-        }
-        if (y == height - 1) {
-#pragma unroll
-          for (int r = 0; r < MW; ++r) A2[(height + MW + r) * TS + x] = nxt[e];
-        }
-      }
-    }
-  };
-  // persistent workgroups: each walks image pairs blockIdx.x, += gridDim.x, and the first planes of its NEXT image pair
-  // are fetched under the last channel pair of the current one (one resident workgroup per CU: nothing else would hide
-  // that latency)
-  load_pair(blockIdx.x, 0);
-  for (long long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-  store_pair();
-  __syncthreads();
-#pragma unroll
-  for (int cp = 0; cp < 3; ++cp) {
-    if (cp < 2) load_pair(p, cp + 1);   // next channel pair's planes in flight under this pair's arithmetic
-    else if (p + gridDim.x < n_pairs) load_pair(p + gridDim.x, 0);
-    // vertical blur: column x = lane64, output rows seg*SEG .. +SEG-1; window rows at constant offsets
-    if (lane64 < width) {
-      const fb_f2* base = A2 + (seg * SEG) * TS + lane64;
-      fb_f2 win[WIN];
-#pragma unroll
-      for (int i = 0; i < WIN; ++i) win[i] = base[i * TS];
-#pragma unroll
-      for (int j = 0; j < SEG; ++j) {
-        fb_f2 s0 = win[j + MW] * tap[0];
-#pragma unroll
-        for (int k = 1; k <= MW; ++k)
-          s0 = __builtin_elementwise_fma(win[j + MW + k] + win[j + MW - k], (fb_f2){tap[k], tap[k]}, s0);
-        const int y = seg * SEG + j;
-        if (y < height) B2[(lane64 + MW) * TP + y] = s0;
-      }
-    }
-    __syncthreads();   // vertical results visible; every read of A2 is done
-    if (cp < 2) store_pair();
-    // replicate the first / last transposed rows MW times on either side
-    for (int idx = tid; idx < 2 * MW * height; idx += NT) {
-      const int side = idx / (MW * height), rem = idx - side * (MW * height);
-      const int r = rem / height, y = rem - r * height;
-      if (side == 0) B2[r * TP + y] = B2[MW * TP + y];
-      else B2[(width + MW + r) * TP + y] = B2[(width - 1 + MW) * TP + y];
-    }
-    __syncthreads();
-    // horizontal blur: row y = lane64, output columns seg*SEG .. +SEG-1
-    if (lane64 < height) {
-      const fb_f2* base = B2 + (seg * SEG) * TP + lane64;
-      fb_f2 win[WIN];
-#pragma unroll
-      for (int i = 0; i < WIN; ++i) win[i] = base[i * TP];
-#pragma unroll
-      for (int j = 0; j < SEG; ++j) {
-        fb_f2 s0 = win[j + MW] * tap[0];
-#pragma unroll
-        for (int k = 1; k <= MW; ++k)
-          s0 = __builtin_elementwise_fma((fb_f2){tap[k], tap[k]}, win[j + MW - k] + win[j + MW + k], s0);
-        hres[cp][j] = s0;
-      }
-    }
-    __syncthreads();   // B2 may be overwritten by the next pair; the new A2 planes are visible
-  }
-  if (lane64 < height) {
-    const int y = lane64;
-#pragma unroll
-    for (int j = 0; j < SEG; ++j) {
-      const int x = seg * SEG + j;
-      if (x < width) {
-        double g11 = hres[0][j].x, g12 = hres[0][j].y, g22 = hres[1][j].x, h1 = hres[1][j].y, h2 = hres[2][j].x;
-        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-        double idet = __ddiv_rn(1.0, det);
-        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-        float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
-        fl[0] = fxv;
-        fl[1] = fyv;
-      }
-    }
-  }
-  }  // image pairs
-}
-
-// ---- window blur on the f32 matrix cores ----------------------------------------------------------------------------
+// ---- window blur on the matrix cores ----------------------------------------------------------------------------------
 // For images up to 64 x 64 the separable, border-replicated window blur is two small matrix products per channel,
 //   U = X Gh^T (along x),  Out = Gv U (along y),   G[y][y'] = sum of the taps k with clamp(y + k) == y'
-// (a banded 64 x 64 matrix that already contains the border replication), evaluated with v_mfma_f32_32x32x2_f32: exact
-// f32 products, f32 accumulation; only the summation order differs from the tap loop (~1e-7 relative, like the fused
-// multiply-adds of the VALU kernels; the parity bar is 1e-3 px).  640 MFMAs replace ~2800 VALU instructions per wave.
-// Workgroup = 4 waves.  Images wider / taller than 32: one image pair per workgroup, wave (yt, xt) owns a 32 x 32 output
-// quadrant (the horizontal pass of an x half is computed by both waves that need it).  Images up to 32 x 32 (the coarse
-// pyramid level): one image pair PER WAVE.  The horizontal result stays in the accumulator registers and is consumed as
-// the B operand of the vertical pass (its contraction index simply follows the accumulator's row order).
+// (a banded 64 x 64 matrix that already contains the border replication, built per level by fb_window_matrix_kernel).
+//
+// The products run on the bf16 matrix cores at f32 accuracy: every f32 operand is split, by truncation, into three bf16
+// terms x = h + m + l (8 + 8 + 8 mantissa bits; the two subtractions are exact), and a product keeps the six partial
+// products down to 2^-16 (hh, hm, mh, hl, lh, mm) -- what is dropped is <= 2^-23 relative, the rounding of one f32
+// operation.  v_mfma_f32_32x32x16_bf16 contracts 16 elements in 8 passes where the exact-f32 v_mfma_f32_32x32x2_f32 needs
+// 8 instructions of 16 passes: six bf16 products cost 3/8 of the matrix-pipe time of one f32 product (the first version
+// of this kernel ran on the f32 cores: 314 us per level-0 iteration at B = 32, 41 % of that pipe's peak).  Accumulation
+// is f32 in both; only the summation order differs from the tap loop (parity bar: 1e-3 px, measured ~1e-6).
+//
+// One wave owns a (image pair, 32-column strip): the horizontal pass gives it U[all rows][its 32 columns] in accumulator
+// registers, which ARE the B operand of the vertical pass (the contraction index simply follows the accumulator's row
+// order, Gv is gathered accordingly once per launch) -- no exchange of U through LDS.  NB = 2 (images up to 64 x 64): two
+// waves per pair, two pairs per workgroup; NB = 1 (up to 32 x 32, the coarse level): one wave per pair, four per workgroup.
+// The channel image is staged zero-padded in LDS (double buffered, next channel's loads in flight under the MFMAs).
 typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt) {
@@ -668,109 +427,181 @@ __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict
 
 __device__ __forceinline__ int fb_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <bool SMALL>   // SMALL: height, width <= 32, one image pair per wave
+struct FbSplit3 { bf16x8 h, m, l; };
+
+// x[0..7] -> three bf16x8 with x = h + m + l up to 2^-24 |x| (truncation split; element i in bf16 slot i)
+__device__ __forceinline__ FbSplit3 fb_split3(const float (&x)[8]) {
+  u32x4 hw, mw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, x[2 * j]), b = __builtin_bit_cast(uint32_t, x[2 * j + 1]);
+    hw[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);                 // (b & 0xffff0000) | (a >> 16)
+    const float ra = x[2 * j] - __builtin_bit_cast(float, a & 0xffff0000u);
+    const float rb = x[2 * j + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
+    const uint32_t a1 = __builtin_bit_cast(uint32_t, ra), b1 = __builtin_bit_cast(uint32_t, rb);
+    mw[j] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+    const float sa = ra - __builtin_bit_cast(float, a1 & 0xffff0000u);
+    const float sb = rb - __builtin_bit_cast(float, b1 & 0xffff0000u);
+    lw[j] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
+  }
+  FbSplit3 o;
+  o.h = __builtin_bit_cast(bf16x8, hw);
+  o.m = __builtin_bit_cast(bf16x8, mw);
+  o.l = __builtin_bit_cast(bf16x8, lw);
+  return o;
+}
+
+// acc += A B with both operands split: the six partial products above 2^-24, smallest first
+__device__ __forceinline__ fb_v16f fb_mfma3(const FbSplit3& a, const FbSplit3& b, fb_v16f acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+  return acc;
+}
+
+template <int NB>   // tile edge = 32 NB; NB waves per image pair, 4 / NB pairs per workgroup
 __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
                                                             const float* __restrict__ Gh, float* __restrict__ flow,
                                                             int height, int width, long long n_pairs) {
-  constexpr int XS = 65;                        // LDS row stride (words)
-  constexpr int IMG = SMALL ? 32 * XS : 64 * XS;
-  __shared__ float Xs[SMALL ? 4 * IMG : 2 * IMG];   // SMALL: one image per wave; else: double-buffered channel image
-  __shared__ float Us[SMALL ? 1 : IMG];             // horizontal result of the current channel (4 tiles, one per wave)
+  constexpr int T = 32 * NB, XS = T + 4, IMG = T * XS, PPW = 4 / NB, KS = 2 * NB;   // KS contraction steps of 16
+  constexpr int NE = T * T / (64 * NB);      // staged elements per lane and channel
+  __shared__ __attribute__((aligned(16))) float Xs[PPW][2][IMG];
+  // Gv split operands, lane-major: the same for every wave (they depend on the output row = lane, not on the strip)
+  __shared__ u32x4 GvS[NB * KS * 3][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
-  const int xt = SMALL ? 0 : (wave & 1), yt = SMALL ? 0 : (wave >> 1);
+  const int pw = wave / NB, strip = wave % NB;
   const long long per_img = (long long)height * width;
-  // operands that do not change: Gh^T as B operand (k = x', column x), Gv as A operand (row y, k = accumulator row order)
-  float ghreg[32], gvreg[2][16];
-#pragma unroll
-  for (int kk = 0; kk < 32; ++kk) ghreg[kk] = Gh[(32 * xt + col) * 64 + 2 * kk + half];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) gvreg[a][kk] = Gv[(32 * yt + col) * 64 + 32 * a + fb_acc_row(kk, half)];
-  float gvnat[32];   // !SMALL: Gv as A operand with the contraction index in natural order (k = y' = 2 kk + half)
-#pragma unroll
-  for (int kk = 0; kk < 32; ++kk) gvnat[kk] = SMALL ? 0.f : Gv[(32 * yt + col) * 64 + 2 * kk + half];
 
-  const long long groups = SMALL ? (n_pairs + 3) / 4 : n_pairs;
+  // ---- constant operands, split once: Gh^T as B operand of the horizontal pass (k = x' in natural order), Gv as A operand of
+  // the vertical pass (k-slot i of lane-half h in step (blk, s) = accumulator row fb_acc_row(8 s + i, h) of row block blk)
+  FbSplit3 gh[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    gh[ks] = fb_split3(t);
+  }
+  for (int j = wave; j < NB * KS; j += 4) {      // (mbo, ks) pairs dealt to the four waves
+    const int mbo = j / KS, ks = j - mbo * KS;
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    const FbSplit3 g = fb_split3(t);
+    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
+    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
+    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
+  }
+  __syncthreads();
+
+  const bool vec = (width & 3) == 0 && ((uintptr_t)Min & 15) == 0;
+  const long long groups = (n_pairs + PPW - 1) / PPW;
   for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const long long p = SMALL ? grp * 4 + wave : grp;
+    const long long p = grp * PPW + pw;
     const bool p_ok = p < n_pairs;
-    fb_v16f res[5];
-    float* Xw = SMALL ? Xs + wave * IMG : Xs;
-    float stg[16];   // one channel image in flight: the loads of channel c+1 are issued before the MFMAs of channel c
+    fb_v16f res[5][NB];
+    float stg[NE];   // one channel image in flight: the loads of channel c + 1 are issued before the MFMAs of channel c
     auto load_channel = [&](int c) {
       const float* src = Min + ((p_ok ? p : 0) * 5 + c) * per_img;
+      if (vec) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = SMALL ? lane + 64 * e : tid + 256 * e;
-        const int y = SMALL ? i >> 5 : i >> 6, x = SMALL ? i & 31 : i & 63;
-        stg[e] = (p_ok && y < height && x < width) ? src[(long long)y * width + x] : 0.f;
+        for (int e = 0; e < NE / 4; ++e) {
+          const int q = strip * 64 + lane + 64 * NB * e;      // quad of 4 consecutive columns
+          const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (p_ok && y < height && x < width) v = *reinterpret_cast<const f32x4*>(src + (long long)y * width + x);
+          stg[4 * e] = v[0]; stg[4 * e + 1] = v[1]; stg[4 * e + 2] = v[2]; stg[4 * e + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int i = strip * 64 + lane + 64 * NB * e;
+          const int y = i / T, x = i - y * T;
+          stg[e] = (p_ok && y < height && x < width) ? src[(long long)y * width + x] : 0.f;
+        }
       }
     };
     load_channel(0);
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      // ---- channel c (zero padded to the tile) into LDS; next channel's loads start right away ---------------------------
-      float* Xc = SMALL ? Xw : Xs + (c & 1) * IMG;
+      // ---- channel c (zero padded to the tile) into this pair's LDS image; next channel's loads start right away ---------
+      float* Xc = Xs[pw][c & 1];
+      if (vec) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = SMALL ? lane + 64 * e : tid + 256 * e;
-        if (SMALL) Xc[(i >> 5) * XS + (i & 31)] = stg[e];
-        else Xc[(i >> 6) * XS + (i & 63)] = stg[e];
-      }
-      if (!SMALL) __syncthreads();   // image visible to the 4 waves (double buffered: the previous channel may still be read)
-      if (c < 4) load_channel(c + 1);
-      fb_v16f o;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] = 0.f;
-      if constexpr (SMALL) {
-        // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'] (x' < 32) -------------------------------------------------
-        fb_v16f u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.f;
-        const float* xa = Xc + col * XS + half;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) u = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk], ghreg[kk], u, 0, 0, 0);
-        // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x]; contraction slot kk of lane-half h is row fb_acc_row(kk, h):
-        // the horizontal result goes from the accumulator straight into the B operand
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(gvreg[0][kk], u[kk], o, 0, 0, 0);
+        for (int e = 0; e < NE / 4; ++e) {
+          const int q = strip * 64 + lane + 64 * NB * e;
+          const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
+          *reinterpret_cast<f32x4*>(Xc + y * XS + x) = (f32x4){stg[4 * e], stg[4 * e + 1], stg[4 * e + 2], stg[4 * e + 3]};
+        }
       } else {
-        // ---- horizontal: this wave's 32 x 32 tile U[32 yt + y'][32 xt + x], shared with the other waves through LDS ------
-        fb_v16f u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.f;
-        const float* xa = Xc + (32 * yt + col) * XS + half;
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) u = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk], ghreg[kk], u, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Us[(32 * yt + fb_acc_row(r, half)) * XS + 32 * xt + col] = u[r];
-        __syncthreads();   // all four U tiles visible
-        // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x], y' = 0..63 in natural order ----------------------------------
-        const float* ub = Us + half * XS + 32 * xt + col;
-#pragma unroll
-        for (int kk = 0; kk < 32; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(gvnat[kk], ub[2 * kk * XS], o, 0, 0, 0);
+        for (int e = 0; e < NE; ++e) {
+          const int i = strip * 64 + lane + 64 * NB * e;
+          const int y = i / T;
+          Xc[y * XS + (i - y * T)] = stg[e];
+        }
       }
-      res[c] = o;
+      if (NB > 1) __syncthreads();   // the image is staged by both waves of the pair (the buffer of channel c - 1 may still be read)
+      else __builtin_amdgcn_wave_barrier();
+      if (c < 4) load_channel(c + 1);
+      // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'], all row blocks, this wave's 32 columns ----------------------
+      fb_v16f u[NB];
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa), x1 = *reinterpret_cast<const f32x4*>(xa + 4);
+          const float t[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          u[mb] = fb_mfma3(fb_split3(t), gh[ks], u[mb]);
+        }
+      }
+      // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x]: the accumulators of the horizontal pass are the B operand -------
+#pragma unroll
+      for (int mbo = 0; mbo < NB; ++mbo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[c][mbo][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+        const FbSplit3 b = fb_split3(t);
+#pragma unroll
+        for (int mbo = 0; mbo < NB; ++mbo) {
+          FbSplit3 g;
+          g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
+          g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
+          g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
+          res[c][mbo] = fb_mfma3(g, b, res[c][mbo]);
+        }
+      }
     }
-    if (!SMALL) __syncthreads();   // both image buffers free before the next pair's channel 0 / 1 are staged
+    if (NB > 1) __syncthreads();   // both image buffers free before the next pair's channels 0 / 1 are staged
     // ---- 2x2 solve; accumulator register r = row y, lane = column x: coalesced flow rows ---------------------------------
     if (p_ok) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int y = 32 * yt + fb_acc_row(r, half), x = 32 * xt + col;
-        if (y < height && x < width) {
-          double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
-          double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-          double idet = __ddiv_rn(1.0, det);
-          const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-          const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-          float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
-          fl[0] = fxv;
-          fl[1] = fyv;
+      for (int mbo = 0; mbo < NB; ++mbo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
+          if (y < height && x < width) {
+            double g11 = res[0][mbo][r], g12 = res[1][mbo][r], g22 = res[2][mbo][r], h1 = res[3][mbo][r], h2 = res[4][mbo][r];
+            double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+            double idet = __ddiv_rn(1.0, det);
+            const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+            const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+            float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
+            fl[0] = fxv;
+            fl[1] = fyv;
+          }
         }
-      }
     }
   }
 }
@@ -1123,11 +954,11 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         }
         if (lh <= 32 && lw <= 32) {
           const unsigned grid = (unsigned)std::min<long long>((n_pairs + 3) / 4, 2048);
-          hipLaunchKernelGGL(fb_tile_mfma_kernel<true>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+          hipLaunchKernelGGL(fb_tile_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
                              (const float*)Gh, flow, lh, lw, (long long)n_pairs);
         } else {
-          const unsigned grid = (unsigned)std::min<long long>(n_pairs, 2048);
-          hipLaunchKernelGGL(fb_tile_mfma_kernel<false>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+          const unsigned grid = (unsigned)std::min<long long>((n_pairs + 1) / 2, 2048);
+          hipLaunchKernelGGL(fb_tile_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
                              (const float*)Gh, flow, lh, lw, (long long)n_pairs);
         }
         if (update) {
