@@ -385,6 +385,15 @@ size_t pv_attention_bwd_workspace_floats(const pv_attention_desc* d);
 int pv_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream);
 
+/* The same two entry points with bf16 OPERANDS on the bf16 matrix cores (f32 tensors in memory, f32 accumulation, f32 online
+ * softmax): q, k, v, dO are rounded to bf16 on their way into the products, the probabilities and dS when they become
+ * operands.  replaces: the same einsums as run under Lightning `precision=16`
+ * (experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294).  Same descriptor, workspace and layouts. */
+int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
+                          void* stream);
+int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
+                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream);
+
 /* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
  * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */
 int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int64_t rows,

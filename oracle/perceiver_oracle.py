@@ -73,6 +73,21 @@ class FeedForward(nn.Module):
         return self.net(x)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """bf16 round-trip in forward and backward: the operand rounding of a 16-bit matrix product (precision=16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+EMULATE_BF16_ATTENTION = False   # tests flip this to compare the bf16-operand HIP kernels at tighter tolerance
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
         super().__init__()
@@ -92,8 +107,12 @@ class Attention(nn.Module):
         b, n, _ = q.shape
         split = lambda t: t.reshape(b, t.shape[1], h, -1).permute(0, 2, 1, 3).reshape(b * h, t.shape[1], -1)
         q, k, v = map(split, (q, k, v))
+        if EMULATE_BF16_ATTENTION:
+            q, k, v = _RoundBF16.apply(q), _RoundBF16.apply(k), _RoundBF16.apply(v)
         sim = torch.einsum("b i d, b j d -> b i j", q, k) * self.scale
         attn = sim.softmax(dim=-1)
+        if EMULATE_BF16_ATTENTION:
+            attn = _RoundBF16.apply(attn)
         out = torch.einsum("b i j, b j d -> b i d", attn, v)
         out = out.reshape(b, h, n, -1).permute(0, 2, 1, 3).reshape(b, n, -1)
         return self.to_out(out)
@@ -294,3 +313,51 @@ class OraclePerceiverConv3dNwpSatModel(nn.Module, _OracleHeadMixin):
             sat[:, -self.forecast_len_5:] = 0          # dim 1 (channels), as written in the reference
         data, b = _stack(self.sat_conv3d_maxpool(sat), self.nwp_conv3d_maxpool(nwp[: self.batch_size].float()))
         return self._head(self.perceiver(data), b, yield_history, row_ids)
+
+
+# ---- experiments/003_perceiver_processes_single_sat_image_then_rnn.py:95-253 (BASELINE configs[4]) -------------------------
+class OracleExp003LitModel(nn.Module):
+    """Same layer graph and state_dict names as the experiment's LitModel: Perceiver(depth 2, untied, 12 channels, 128 x 64
+    latents, 512 classes) -> fc1 (+ Embedding(940, 16)) .. fc5 -> 2-layer GRU encoder / decoder over [8 features | NWP 40 |
+    4 datetime features (| PV history)] -> decoder_fc1/2.  forward takes the experiment's dict batch."""
+
+    def __init__(self, history_len=6, forecast_len=12):
+        super().__init__()
+        self.history_len, self.forecast_len = history_len, forecast_len
+        self.total_seq_len = history_len + forecast_len + 1
+        self.perceiver = OraclePerceiver(input_channels=12, input_axis=2, num_freq_bands=6, max_freq=10, depth=2,
+                                         num_latents=128, latent_dim=64, num_classes=PERCEIVER_OUTPUT_SIZE)
+        self.fc1 = nn.Linear(PERCEIVER_OUTPUT_SIZE, 256)
+        self.fc2 = nn.Linear(256 + 16, 128)
+        self.fc3 = nn.Linear(128, 64)
+        self.fc4 = nn.Linear(64, 32)
+        self.fc5 = nn.Linear(32, FC_OUTPUT_SIZE)
+        self.pv_system_id_embedding = nn.Embedding(940, 16)
+        nwp_size, n_datetime = 10 * 2 * 2, 4
+        self.encoder_rnn = nn.GRU(FC_OUTPUT_SIZE + n_datetime + 1 + nwp_size, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_rnn = nn.GRU(FC_OUTPUT_SIZE + n_datetime + nwp_size, RNN_HIDDEN_SIZE, num_layers=2, batch_first=True)
+        self.decoder_fc1 = nn.Linear(RNN_HIDDEN_SIZE, 8)
+        self.decoder_fc2 = nn.Linear(8, 1)
+
+    def forward(self, x):
+        sat = x["sat_data"]
+        b, t, w, h, c = sat.shape
+        out = self.perceiver(sat.reshape(b * t, w, h, c)).reshape(b * t, PERCEIVER_OUTPUT_SIZE)
+        out = F.relu(self.fc1(out))
+        row = x["pv_system_row_number"].long().repeat_interleave(self.total_seq_len)
+        out = torch.cat((out, self.pv_system_id_embedding(row)), dim=1)
+        out = F.relu(self.fc5(F.relu(self.fc4(F.relu(self.fc3(F.relu(self.fc2(out))))))))
+        out = out.reshape(b, self.total_seq_len, FC_OUTPUT_SIZE)
+        nwp = x["nwp"].float().permute(0, 2, 1, 3, 4)
+        nwp = nwp.reshape(b, nwp.shape[1], -1)
+        rnn_input = torch.cat((out, nwp, x["hour_of_day_sin"].unsqueeze(-1), x["hour_of_day_cos"].unsqueeze(-1),
+                               x["day_of_year_sin"].unsqueeze(-1), x["day_of_year_cos"].unsqueeze(-1)), dim=2)
+        hist = x["pv_yield"][:, : self.history_len + 1].unsqueeze(-1)
+        _, hidden = self.encoder_rnn(torch.cat((rnn_input[:, : self.history_len + 1], hist), dim=2))
+        dec, _ = self.decoder_rnn(rnn_input[:, -self.forecast_len:], hidden)
+        return self.decoder_fc2(F.relu(self.decoder_fc1(dec))).squeeze(dim=-1)
+
+    def losses(self, batch):
+        y_hat = self(batch)
+        y = batch["pv_yield"][:, -self.forecast_len:]
+        return F.mse_loss(y_hat, y), (y_hat - y).abs().mean()

@@ -138,6 +138,8 @@ SIGNATURES = {
     "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
     "pv_attention_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
+    "pv_attention_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
+    "pv_attention_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],

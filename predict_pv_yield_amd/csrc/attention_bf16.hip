@@ -1,0 +1,411 @@
+// Fused attention softmax(scale * q k^T) v with bf16 OPERANDS on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16), f32
+// accumulation and an f32 online softmax -- the 16-bit form the reference trains its Perceiver in
+// (experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294: Lightning precision=16 runs the two
+// einsums of perceiver_pytorch's Attention.forward in half precision).  Tensors stay f32 in memory (the surrounding
+// GEMMs / LayerNorms are the exact-f32 kernels); q, k, v, dO are rounded to bf16 (nearest even) on their way into
+// registers / LDS, the probabilities and dS when they become matrix operands.
+//
+// Same decomposition as attention_f32.hip (4 waves x 32 queries, key tiles of 32, S^T layout so that a lane owns ONE
+// query's scores), but a contraction of 64 is 4 instructions of 8 passes instead of 32 instructions of 16 passes: 16x
+// less matrix-pipe time, which makes staging and the softmax arithmetic the bound.  Operand layouts of the 32x32x16
+// instruction: A lane (row = lane % 32, k = 8 (lane / 32) + 0..7), B lane (k = 8 (lane / 32) + 0..7, column = lane % 32):
+// every operand is 8 CONSECUTIVE elements, one ds_read_b128 from a bf16 LDS image.  Where the contraction runs over an
+// accumulator's rows (P, dS as B operands straight from registers) the other operand is staged TRANSPOSED with its
+// contraction index permuted into the accumulator's row order (att_pos).
+#include "pv_common.h"
+
+namespace pv {
+
+typedef float v16f_b __attribute__((ext_vector_type(16)));
+
+constexpr int BD = 64;         // head dimension
+constexpr int BTJ = 32;        // keys per tile
+constexpr int B_KLD = 72;      // bf16 per row of a [rows][64 d] image (144 B: 16-byte aligned rows, banks rotate by 36 words)
+constexpr int B_TLD = 40;      // bf16 per row of a [.][32] transposed tile (80 B)
+constexpr int B_QLD = 136;     // bf16 per row of the [64 d][128 queries] transposed images (272 B)
+
+struct AttnGeomB {
+  int n_q, n_k, heads;
+  long long q_bs, q_rs, k_bs, k_rs;
+  float scale;
+};
+
+__device__ __forceinline__ int att_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// position of row j (0..31) of a 32-row accumulator tile in contraction order: register r = 8 st + t of lane-half h holds
+// row att_acc_row(r, h); slot = 16 st + 8 h + t
+__device__ __forceinline__ int att_pos(int j) {
+  const int r = (j & 3) + 4 * (j >> 3), h = (j >> 2) & 1;
+  return 16 * (r >> 3) + 8 * h + (r & 7);
+}
+__device__ __forceinline__ bf16x8 att_pack8(const float (&x)[8]) {
+  u32x4 w;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16_bits(x[2 * j]) | ((uint32_t)f32_to_bf16_bits(x[2 * j + 1]) << 16);
+  return __builtin_bit_cast(bf16x8, w);
+}
+__device__ __forceinline__ bf16x8 att_load8(const float* p, bool ok) {   // 8 consecutive floats (16-byte aligned) -> bf16x8
+  f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+  if (ok) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return att_pack8(x);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, float* __restrict__ o,
+                                                      float* __restrict__ lse, AttnGeomB g) {
+  __shared__ __attribute__((aligned(16))) uint16_t Ks[BTJ * B_KLD];   // [key][d]
+  __shared__ __attribute__((aligned(16))) uint16_t Vt[BD * B_TLD];    // [d][att_pos(key)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i = blockIdx.x * 128 + wave * 32 + col;           // this lane's query
+  const float* qb = q + b * g.q_bs + h * BD;
+  const float* kb = k + b * g.k_bs + h * BD;
+  const float* vb = v + b * g.k_bs + h * BD;
+  // B operand of S^T = K Q^T: lane (query = col, d = 16 ks + 8 half + 0..7)
+  bf16x8 qreg[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qreg[ks] = att_load8(qb + (long long)(i < g.n_q ? i : 0) * g.q_rs + 16 * ks + 8 * half, i < g.n_q);
+
+  v16f_b acc0, acc1;   // O^T rows d = 0..31 / 32..63, column = query
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: thread t moves 8 floats of K and of V of the 32 x 64 tile: key t / 8, d = 8 (t % 8) ..
+  const int st_row = tid >> 3, st_col = (tid & 7) * 8;
+  const int st_pos = att_pos(st_row);
+  f32x4 k0, k1, v0, v1;
+  auto load_tile = [&](int j0) {
+    const int j = j0 + st_row;
+    const bool ok = j < g.n_k;
+    const float* kp = kb + (long long)(ok ? j : 0) * g.k_rs + st_col;
+    const float* vp = vb + (long long)(ok ? j : 0) * g.k_rs + st_col;
+    k0 = *reinterpret_cast<const f32x4*>(kp); k1 = *reinterpret_cast<const f32x4*>(kp + 4);
+    v0 = *reinterpret_cast<const f32x4*>(vp); v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+    if (!ok) { k0 = k1 = v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  };
+  load_tile(0);
+  for (int j0 = 0; j0 < g.n_k; j0 += BTJ) {
+    __syncthreads();
+    {
+      const float kx[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+      *reinterpret_cast<bf16x8*>(Ks + st_row * B_KLD + st_col) = att_pack8(kx);
+      const float vx[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Vt[(st_col + e) * B_TLD + st_pos] = f32_to_bf16_bits(vx[e]);
+    }
+    __syncthreads();
+    if (j0 + BTJ < g.n_k) load_tile(j0 + BTJ);
+    // S^T tile: rows = keys, column = this lane's query
+    v16f_b s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ks + col * B_KLD + 16 * ks + 8 * half),
+                                                  qreg[ks], s, 0, 0, 0);
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = j0 + att_acc_row(r, half) < g.n_k;
+      s[r] = ok ? s[r] * g.scale : -INFINITY;
+      m_tile = fmaxf(m_tile, s[r]);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    const float alpha = expf(m_run - m_new);          // first tile: exp(-inf) = 0 on zero accumulators
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = expf(s[r] - m_new);
+      psum += s[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] *= alpha, acc1[r] *= alpha;
+    // O^T += V^T P^T: contraction slot 8 half + t of step st is key att_acc_row(8 st + t, half): P comes straight from
+    // the S accumulator, V^T from the permuted transposed tile
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const float px[8] = {s[8 * st], s[8 * st + 1], s[8 * st + 2], s[8 * st + 3], s[8 * st + 4], s[8 * st + 5], s[8 * st + 6],
+                           s[8 * st + 7]};
+      const bf16x8 pb = att_pack8(px);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vt + col * B_TLD + 16 * st + 8 * half), pb,
+                                                     acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          *reinterpret_cast<const bf16x8*>(Vt + (32 + col) * B_TLD + 16 * st + 8 * half), pb, acc1, 0, 0, 0);
+    }
+  }
+  if (i < g.n_q) {
+    const float inv = 1.0f / l_run;
+    float* ob = o + b * g.q_bs + (long long)i * g.q_rs + h * BD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = att_acc_row(r, half);
+      ob[d] = acc0[r] * inv;
+      ob[32 + d] = acc1[r] * inv;
+    }
+    if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run + logf(l_run);
+  }
+}
+
+// Backward for n_q <= 128: one workgroup per (b, h, key range).  Q and dO of all (<= 128) queries sit in LDS as bf16, both
+// row-major (A operands of S = Q K^T, dP = dO V^T) and transposed with the query index in accumulator order (A operands of
+// dV^T += dO^T P, dK^T += Q^T dS).  Wave w walks the key tiles w, w+4, ... on its own (no barriers inside the loop): K and V
+// of the tile are B operands in registers, K^T a per-wave LDS tile (A operand of dQ^T += K^T dS^T), dS goes through a
+// per-wave LDS tile to be read back along the keys.
+__global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const float* __restrict__ dout,
+                                                      const float* __restrict__ lse, const float* __restrict__ delta,
+                                                      float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                      AttnGeomB g, int tiles_per_split, long long dq_ss) {
+  constexpr int QS_B = 128 * B_KLD * 2, QT_B = BD * B_QLD * 2, KT_B = BD * B_TLD * 2, TW_B = 32 * B_TLD * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B];
+  __shared__ float Ls[128], Ds[128];
+  uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);                       // [query][d]
+  uint16_t* Os = reinterpret_cast<uint16_t*>(smem + QS_B);                // dO, same layout
+  uint16_t* QtT = reinterpret_cast<uint16_t*>(smem + 2 * QS_B);           // [d][32 it + att_pos(query % 32)]
+  uint16_t* OtT = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + QT_B);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint16_t* Kt = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + 2 * QT_B + wave * KT_B);            // [d][key of the tile]
+  uint16_t* Tw = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + 2 * QT_B + 4 * KT_B + wave * TW_B);  // dS [query][key]
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const float* qb = q + b * g.q_bs + h * BD;
+  const float* ob = dout + b * g.q_bs + h * BD;
+  const float* kb = k + b * g.k_bs + h * BD;
+  const float* vb = v + b * g.k_bs + h * BD;
+  // ---- stage Q, dO (zero rows beyond n_q), lse (+inf beyond n_q so that P = 0 there), delta ---------------------------
+  for (int idx = tid; idx < 128 * 8; idx += 256) {
+    const int i = idx >> 3, c8 = (idx & 7) * 8;
+    const bool ok = i < g.n_q;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    if (ok) {
+      a0 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8); a1 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8 + 4);
+      b0 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8); b1 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8 + 4);
+    }
+    const float qx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float ox[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    *reinterpret_cast<bf16x8*>(Qs + i * B_KLD + c8) = att_pack8(qx);
+    *reinterpret_cast<bf16x8*>(Os + i * B_KLD + c8) = att_pack8(ox);
+    const int tp = (i & ~31) + att_pos(i & 31);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      QtT[(c8 + e) * B_QLD + tp] = f32_to_bf16_bits(qx[e]);
+      OtT[(c8 + e) * B_QLD + tp] = f32_to_bf16_bits(ox[e]);
+    }
+  }
+  if (tid < 128) {
+    const long long li = ((long long)b * g.heads + h) * g.n_q + tid;
+    Ls[tid] = tid < g.n_q ? lse[li] : INFINITY;
+    Ds[tid] = tid < g.n_q ? delta[li] : 0.f;
+  }
+  __syncthreads();
+
+  v16f_b dqa[4][2];   // dQ^T partial of this wave: [query tile][d half], rows d, column = query
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
+  const int n_tiles = (g.n_k + BTJ - 1) / BTJ;
+  const int n_qt = (g.n_q + 31) / 32;
+  const int tile0 = blockIdx.x * tiles_per_split;
+  const int tile1 = tile0 + tiles_per_split < n_tiles ? tile0 + tiles_per_split : n_tiles;
+  dq += blockIdx.x * dq_ss;     // this key range's partial dQ (summed over the splits afterwards)
+  // K, V of a tile as B operands: lane (key = col, d = 16 ks + 8 half + 0..7); the NEXT tile's loads are issued before the
+  // current tile's arithmetic (one wave per SIMD walks its tiles alone)
+  f32x4 kn[4][2], vn[4][2];
+  auto load_kv = [&](int tile) {
+    const int jj = tile * BTJ + col;
+    const bool ok = tile < tile1 && jj < g.n_k;
+    const float* kp = kb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
+    const float* vp = vb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kn[ks][0] = *reinterpret_cast<const f32x4*>(kp + 16 * ks); kn[ks][1] = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4);
+      vn[ks][0] = *reinterpret_cast<const f32x4*>(vp + 16 * ks); vn[ks][1] = *reinterpret_cast<const f32x4*>(vp + 16 * ks + 4);
+      if (!ok) kn[ks][0] = kn[ks][1] = vn[ks][0] = vn[ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  load_kv(tile0 + wave);
+  for (int tile = tile0 + wave; tile < tile1; tile += 4) {
+    const int j0 = tile * BTJ;
+    const int j = j0 + col;                       // this lane's key (B-operand column)
+    const bool j_ok = j < g.n_k;
+    bf16x8 kreg[4], vreg[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float kx[8] = {kn[ks][0][0], kn[ks][0][1], kn[ks][0][2], kn[ks][0][3], kn[ks][1][0], kn[ks][1][1], kn[ks][1][2], kn[ks][1][3]};
+      const float vx[8] = {vn[ks][0][0], vn[ks][0][1], vn[ks][0][2], vn[ks][0][3], vn[ks][1][0], vn[ks][1][1], vn[ks][1][2], vn[ks][1][3]};
+      kreg[ks] = att_pack8(kx);
+      vreg[ks] = att_pack8(vx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Kt[(16 * ks + 8 * half + e) * B_TLD + col] = f32_to_bf16_bits(kx[e]);   // K^T for dQ
+    }
+    load_kv(tile + 4);
+    v16f_b dv0, dv1, dk0, dk1;   // dV^T / dK^T of this key tile: rows d, column = key
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv0[r] = 0.f, dv1[r] = 0.f, dk0[r] = 0.f, dk1[r] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (it < n_qt) {
+        // S[i][j] = Q K^T and dP[i][j] = dO V^T: rows = queries of tile it, column = key
+        v16f_b sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              *reinterpret_cast<const bf16x8*>(Qs + (32 * it + col) * B_KLD + 16 * ks + 8 * half), kreg[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              *reinterpret_cast<const bf16x8*>(Os + (32 * it + col) * B_KLD + 16 * ks + 8 * half), vreg[ks], dp, 0, 0, 0);
+        }
+        // P = exp(scale S - lse_i), dS = scale * P * (dP - delta_i); masked keys give P = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = it * 32 + att_acc_row(r, half);
+          const float pv_ = j_ok ? expf(sc[r] * g.scale - Ls[i]) : 0.f;
+          sc[r] = pv_;                                      // sc now holds P
+          dp[r] = g.scale * pv_ * (dp[r] - Ds[i]);          // dp now holds dS
+          Tw[att_acc_row(r, half) * B_TLD + col] = f32_to_bf16_bits(dp[r]);
+        }
+        // dV^T += dO^T P, dK^T += Q^T dS: contraction slot 8 half + t of step st is query att_acc_row(8 st + t, half)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const float px[8] = {sc[8 * st], sc[8 * st + 1], sc[8 * st + 2], sc[8 * st + 3], sc[8 * st + 4], sc[8 * st + 5],
+                               sc[8 * st + 6], sc[8 * st + 7]};
+          const float sx[8] = {dp[8 * st], dp[8 * st + 1], dp[8 * st + 2], dp[8 * st + 3], dp[8 * st + 4], dp[8 * st + 5],
+                               dp[8 * st + 6], dp[8 * st + 7]};
+          const bf16x8 pb = att_pack8(px), sb = att_pack8(sx);
+          const int off = 32 * it + 16 * st + 8 * half;
+          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(OtT + col * B_QLD + off), pb, dv0, 0, 0, 0);
+          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(OtT + (32 + col) * B_QLD + off), pb, dv1, 0, 0, 0);
+          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(QtT + col * B_QLD + off), sb, dk0, 0, 0, 0);
+          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(QtT + (32 + col) * B_QLD + off), sb, dk1, 0, 0, 0);
+        }
+        // dQ^T[d][i] += K^T[d][j] dS^T[j][i]: B operand lane (query = col, keys 16 st + 8 half + 0..7) read back from Tw
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 dsb = *reinterpret_cast<const bf16x8*>(Tw + col * B_TLD + 16 * st + 8 * half);
+          dqa[it][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Kt + col * B_TLD + 16 * st + 8 * half),
+                                                               dsb, dqa[it][0], 0, 0, 0);
+          dqa[it][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              *reinterpret_cast<const bf16x8*>(Kt + (32 + col) * B_TLD + 16 * st + 8 * half), dsb, dqa[it][1], 0, 0, 0);
+        }
+      }
+    }
+    if (j_ok) {
+      float* dkp = dk + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+      float* dvp = dv + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = att_acc_row(r, half);
+        dkp[d] = dk0[r], dkp[32 + d] = dk1[r];
+        dvp[d] = dv0[r], dvp[32 + d] = dv1[r];
+      }
+    }
+  }
+  // ---- add the four waves' dQ^T partials (wave order) and write dq; two query tiles per round through the Q / dO images ----
+  float* scratch = reinterpret_cast<float*>(smem);     // 2 x [wave][d 64][i 32] floats = 64 KB <= 2 QS_B + 2 QT_B
+  static_assert(2 * 4 * 64 * 32 * 4 <= 2 * QS_B + 2 * QT_B, "dQ scratch does not fit");
+  for (int round = 0; round < 2; ++round) {
+    __syncthreads();   // everyone is done with the Q / dO images (first round) or with the previous round's sums
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int it = 2 * round + u;
+      float* dst = scratch + u * (4 * 64 * 32);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(wave * 64 + 32 * t + att_acc_row(r, half)) * 32 + col] = dqa[it][t][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * 32 * 64; idx += 256) {
+      const int u = idx / (32 * 64), rem = idx % (32 * 64);
+      const int il = rem / 64, d = rem % 64;
+      const int i = (2 * round + u) * 32 + il;
+      if (i < g.n_q) {
+        const float* src = scratch + u * (4 * 64 * 32);
+        const float sum = ((src[(0 * 64 + d) * 32 + il] + src[(1 * 64 + d) * 32 + il]) + src[(2 * 64 + d) * 32 + il]) +
+                          src[(3 * 64 + d) * 32 + il];
+        dq[b * g.q_bs + (long long)i * g.q_rs + h * BD + d] = sum;
+      }
+    }
+  }
+}
+
+void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
+                      hipStream_t st);   // gemm_f32.hip
+void launch_attn_delta(const float* o, const float* dout, float* delta, const pv_attention_desc* d, hipStream_t st);   // attention_f32.hip
+
+}  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+static int attn_geom_b(const pv_attention_desc* d, AttnGeomB* g, const char* who) {
+  PV_REQUIRE(d, PV_EINVAL, "%s: null descriptor", who);
+  PV_REQUIRE(d->batch > 0 && d->heads > 0 && d->n_q > 0 && d->n_k > 0, PV_EINVAL, "%s: non-positive extent", who);
+  PV_REQUIRE(d->head_dim == BD, PV_ESIZE, "%s: head_dim must be %d", who, BD);
+  PV_REQUIRE(d->q_row_stride % 4 == 0 && d->k_row_stride % 4 == 0 && d->q_batch_stride % 4 == 0 && d->k_batch_stride % 4 == 0,
+             PV_EINVAL, "%s: strides must be multiples of 4 elements (16-byte rows)", who);
+  PV_REQUIRE(d->batch <= 65535 && d->heads <= 65535, PV_ESIZE, "%s: batch / heads exceed the grid limit", who);
+  g->n_q = d->n_q, g->n_k = d->n_k, g->heads = d->heads;
+  g->q_bs = d->q_batch_stride, g->q_rs = d->q_row_stride, g->k_bs = d->k_batch_stride, g->k_rs = d->k_row_stride;
+  g->scale = d->scale;
+  return PV_OK;
+}
+
+int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
+                          void* stream) {
+  AttnGeomB g;
+  int rc = attn_geom_b(d, &g, "pv_attention_fwd_bf16");
+  if (rc) return rc;
+  PV_REQUIRE(q && k && v && o && lse, PV_EINVAL, "pv_attention_fwd_bf16: null pointer");
+  PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0), PV_EINVAL,
+             "pv_attention_fwd_bf16: q / k / v must be 16-byte aligned");
+  dim3 grid((unsigned)((d->n_q + 127) / 128), (unsigned)d->heads, (unsigned)d->batch);
+  hipLaunchKernelGGL(attn_fwd_bf16, grid, dim3(256), 0, as_stream(stream), q, k, v, o, lse, g);
+  return check_launch("pv_attention_fwd_bf16");
+}
+
+int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
+                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream) {
+  AttnGeomB g;
+  int rc = attn_geom_b(d, &g, "pv_attention_bwd_bf16");
+  if (rc) return rc;
+  PV_REQUIRE(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, PV_EINVAL, "pv_attention_bwd_bf16: null pointer");
+  PV_REQUIRE(d->n_q <= 128, PV_ESIZE, "pv_attention_bwd_bf16: n_q=%d > 128 queries per (batch, head) is not built", d->n_q);
+  PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0),
+             PV_EINVAL, "pv_attention_bwd_bf16: q / dout / k / v must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const long long rows = (long long)d->batch * d->heads * d->n_q;
+  launch_attn_delta(o, dout, delta_ws, d, st);    // the row term sum_d dO * O stays f32 (same kernel as the f32 path)
+  // key splits exactly as pv_attention_bwd_f32 / pv_attention_bwd_workspace_floats lay them out
+  const long long groups = (long long)d->batch * d->heads;
+  const int n_tiles = (d->n_k + BTJ - 1) / BTJ;
+  int splits = (int)((1024 + groups - 1) / groups);
+  if (splits > n_tiles / 8) splits = n_tiles / 8;
+  if (splits < 1) splits = 1;
+  const int per = ((n_tiles + splits - 1) / splits + 3) / 4 * 4;
+  const int nsp = (n_tiles + per - 1) / per;
+  if (nsp > 1) {
+    float* part = delta_ws + rows;
+    const long long n = (long long)d->batch * d->q_batch_stride;
+    hipLaunchKernelGGL(attn_bwd_bf16, dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
+                       lse, (const float*)delta_ws, part, dk, dv, g, per, n);
+    launch_sum_slabs(part, dq, n, nsp, n, 0, st);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_bf16, dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
+                       (const float*)delta_ws, dq, dk, dv, g, n_tiles, 0ll);
+  }
+  return check_launch("pv_attention_bwd_bf16");
+}
+
+}  // extern "C"

@@ -311,6 +311,16 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
                       hipStream_t st);   // gemm_f32.hip
 
+// delta = rowsum(dO * O), shared with the bf16-operand backward (attention_bf16.hip)
+void launch_attn_delta(const float* o, const float* dout, float* delta, const pv_attention_desc* d, hipStream_t st) {
+  AttnGeom g;
+  g.n_q = d->n_q, g.n_k = d->n_k, g.heads = d->heads;
+  g.q_bs = d->q_batch_stride, g.q_rs = d->q_row_stride, g.k_bs = d->k_batch_stride, g.k_rs = d->k_row_stride;
+  g.scale = d->scale;
+  const long long rows = (long long)d->batch * d->heads * d->n_q;
+  hipLaunchKernelGGL(attn_delta_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, o, dout, delta, g, d->batch);
+}
+
 }  // namespace pv
 
 using namespace pv;

@@ -775,20 +775,22 @@ def attention_desc(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float) 
                               scale)
 
 
-def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float):
-    """q [b, i, h*64], kv [b, j, 2*h*64] (k | v halves) contiguous -> (out [b, i, h*64], lse [b, h, i])."""
+def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, bf16_operands: bool = False):
+    """q [b, i, h*64], kv [b, j, 2*h*64] (k | v halves) contiguous -> (out [b, i, h*64], lse [b, h, i]).
+    bf16_operands: the two products take bf16 operands on the bf16 matrix cores (f32 accumulation, f32 softmax)."""
     require_cuda(q, kv)
     b, n_q, inner = q.shape
     d = attention_desc(q, kv, heads, scale)
     out = torch.empty_like(q)
     lse = torch.empty((b, heads, n_q), dtype=torch.float32, device=q.device)
     v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
-    check(get_lib().pv_attention_fwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
-          "pv_attention_fwd_f32")
+    fn = get_lib().pv_attention_fwd_bf16 if bf16_operands else get_lib().pv_attention_fwd_f32
+    check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
+          "pv_attention_fwd_bf16" if bf16_operands else "pv_attention_fwd_f32")
     return out, lse
 
 
-def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float):
+def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands: bool = False):
     """Backward of attention_fwd (n_q <= 128): returns (dq like q, dkv like kv)."""
     require_cuda(q, kv, out, dout, lse)
     b, n_q, inner = q.shape
@@ -799,6 +801,7 @@ def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float):
     delta = _workspace("attention_bwd", n_ws * 4, q.device)
     v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
     dv_ptr = ctypes.c_void_p(dkv.data_ptr() + inner * 4)
-    check(get_lib().pv_attention_bwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
-                                         dv_ptr, ctypes.byref(d), current_stream_ptr()), "pv_attention_bwd_f32")
+    fn = get_lib().pv_attention_bwd_bf16 if bf16_operands else get_lib().pv_attention_bwd_f32
+    check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv), dv_ptr, ctypes.byref(d),
+             current_stream_ptr()), "pv_attention_bwd_bf16" if bf16_operands else "pv_attention_bwd_f32")
     return dq, dkv

@@ -123,7 +123,9 @@ class PerceiverModel(BaseModel):
         latent_dim: int = 64,
         embedding_dem: int = 16,
         output_variable: str = "pv_yield",
+        operand_dtype: str = "f32",
     ):
+        # operand_dtype (new, optional): "bf16" runs the attention products on the bf16 matrix cores (Lightning precision=16)
         self.history_minutes = history_minutes
         self.forecast_minutes = forecast_minutes
         self.nwp_channels = nwp_channels
@@ -147,6 +149,7 @@ class PerceiverModel(BaseModel):
             latent_dim=self.latent_dim,
             num_classes=PERCEIVER_OUTPUT_SIZE,
             weight_tie_layers=True,
+            operand_dtype=operand_dtype,
         )
 
         make_perceiver_head(self, rnn_extra_size=NWP_SIZE)

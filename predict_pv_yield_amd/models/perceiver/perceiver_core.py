@@ -60,10 +60,10 @@ class Attention(nn.Module):
         self.to_out = nn.Linear(inner_dim, query_dim)
 
 
-def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
     """Attention.forward given the normalised query input and the (already projected) keys/values [b, j, 2*inner]."""
     q = PF.linear(xn, attn.to_q.weight)                                  # [b, i, inner]
-    out = PF.attention_core(q, kv, attn.heads, attn.scale)               # softmax(scale q k^T) v, per head
+    out = PF.attention_core(q, kv, attn.heads, attn.scale, bf16_operands=bf16_operands)   # softmax(scale q k^T) v, per head
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias)
 
 
@@ -78,8 +78,15 @@ def _feed_forward(block: PreNorm, x: torch.Tensor) -> torch.Tensor:
 class Perceiver(nn.Module):
     def __init__(self, *, num_freq_bands, depth, max_freq, freq_base=2, input_channels=3, input_axis=2, num_latents=512,
                  latent_dim=512, cross_heads=1, latent_heads=8, cross_dim_head=64, latent_dim_head=64, num_classes=1000,
-                 attn_dropout=0.0, ff_dropout=0.0, weight_tie_layers=False, fourier_encode_data=True, self_per_cross_attn=1):
+                 attn_dropout=0.0, ff_dropout=0.0, weight_tie_layers=False, fourier_encode_data=True, self_per_cross_attn=1,
+                 operand_dtype: str = "f32"):
         super().__init__()
+        # operand_dtype (new, optional): "f32" = exact-f32 matrix-core products everywhere; "bf16" = the attention products
+        # (q k^T, p v and their backward) take bf16 operands with f32 accumulation and an f32 softmax -- what Lightning's
+        # precision=16 does to them in experiments/003 (:40, :290)
+        if operand_dtype not in ("f32", "bf16"):
+            raise ValueError("operand_dtype must be 'f32' or 'bf16'")
+        self.operand_dtype = operand_dtype
         if attn_dropout or ff_dropout:
             raise NotImplementedError("dropout is not built (the reference never sets it)")
         if not fourier_encode_data:
@@ -137,12 +144,12 @@ class Perceiver(nn.Module):
                                     cross_attn.norm_context.eps)
                 kv_of[id(cross_attn)] = PF.linear(ctx, cross_attn.fn.to_kv.weight)
             xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-            x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)]) + x
+            x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], self.operand_dtype == "bf16") + x
             x = _feed_forward(cross_ff, x) + x
             for self_attn, self_ff in self_attns:
                 xn = PF.layer_norm(x, self_attn.norm.weight, self_attn.norm.bias, self_attn.norm.eps)
                 kv = PF.linear(xn, self_attn.fn.to_kv.weight)
-                x = _attend(self_attn.fn, xn, kv) + x
+                x = _attend(self_attn.fn, xn, kv, self.operand_dtype == "bf16") + x
                 x = _feed_forward(self_ff, x) + x
         x = PF.mean_axis1(x)
         x = PF.layer_norm(x, self.to_logits[1].weight, self.to_logits[1].bias, self.to_logits[1].eps)

@@ -80,15 +80,18 @@ class AttentionCoreF32(torch.autograd.Function):
     the scores tensor is softmax'ed in place and kept for the backward."""
 
     @staticmethod
-    def forward(ctx, q, kv, heads, scale):
+    def forward(ctx, q, kv, heads, scale, bf16_operands=False):
         q, kv = q.contiguous(), kv.contiguous()
         inner = q.shape[-1]
         ctx.heads, ctx.scale = heads, scale
         ctx.fused = inner // heads == 64 and q.shape[1] <= 128
+        ctx.bf16 = bool(bf16_operands)
+        if ctx.bf16 and not ctx.fused:
+            raise NotImplementedError("bf16 attention operands are built for the fused kernels (head_dim 64, <= 128 queries)")
         if ctx.fused:
             # online-softmax kernels: the [queries x keys] scores / probabilities never reach memory; the backward
             # recomputes them tile by tile from the saved log-sum-exp
-            out, lse = K.attention_fwd(q, kv, heads, scale)
+            out, lse = K.attention_fwd(q, kv, heads, scale, bf16_operands=ctx.bf16)
             ctx.save_for_backward(q, kv, out, lse)
             return out
         qh, kh, vh = _head_view(q, heads, 0, inner), _head_view(kv, heads, 0, inner), _head_view(kv, heads, inner, 2 * inner)
@@ -102,8 +105,8 @@ class AttentionCoreF32(torch.autograd.Function):
     def backward(ctx, dout):
         if ctx.fused:
             q, kv, out, lse = ctx.saved_tensors
-            dq, dkv = K.attention_bwd(q, kv, out, dout.contiguous(), lse, ctx.heads, ctx.scale)
-            return dq, dkv, None, None
+            dq, dkv = K.attention_bwd(q, kv, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=ctx.bf16)
+            return dq, dkv, None, None, None
         q, kv, p = ctx.saved_tensors
         h, inner = ctx.heads, q.shape[-1]
         dout = dout.contiguous()
@@ -115,11 +118,11 @@ class AttentionCoreF32(torch.autograd.Function):
         dq = torch.empty_like(q)
         K.gemm(ds, kh, out=_head_view(dq, h, 0, inner))                                     # dq = ds k
         K.gemm(ds.transpose(-1, -2), qh, out=_head_view(dkv, h, 0, inner))                  # dk = ds^T q
-        return dq, dkv, None, None
+        return dq, dkv, None, None, None
 
 
-def attention_core(q, kv, heads, scale):
-    return AttentionCoreF32.apply(q, kv, heads, scale)
+def attention_core(q, kv, heads, scale, bf16_operands=False):
+    return AttentionCoreF32.apply(q, kv, heads, scale, bf16_operands)
 
 
 class SoftmaxScaledF32(torch.autograd.Function):
