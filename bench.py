@@ -327,22 +327,65 @@ def measure_other_models(dev):
     from predict_pv_yield_amd.data.fake import FakeDataConfiguration, make_fake_batch
     from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
     b = 8
-    pm = PerceiverModel(history_minutes=60, forecast_minutes=30, batch_size=b, num_latents=128, latent_dim=64,
-                        embedding_dem=16, output_variable="gsp_yield").to(dev)
     cfg = FakeDataConfiguration(batch_size=b, history_minutes=60, forecast_minutes=30, satellite_image_size_pixels=64,
                                 nwp_image_size_pixels=64)
     pbatch = make_fake_batch(cfg, torch.Generator().manual_seed(2)).to(dev)
-    popt = pm.configure_optimizers()
-
-    def p_step():
-        popt.zero_grad(set_to_none=True)
-        pm.training_step(pbatch, 0).backward()
-        popt.step()
-
-    d = time_steps(p_step, 3, 1)
     out["perceiver"] = {"workload": "PerceiverModel train step (configs/model/perceiver.yaml): B=8, T=19 frames = 19 weight-tied "
-                                    "layers, 64x64x11, 128 latents x 64, f32 MFMA",
-                        "ms_per_step": round(d * 1e3, 1), "samples_per_s": round(b / d, 1)}
+                                    "layers, 64x64x11, 128 latents x 64"}
+    for dt in ("f32", "bf16"):
+        torch.manual_seed(0)
+        pm = PerceiverModel(history_minutes=60, forecast_minutes=30, batch_size=b, num_latents=128, latent_dim=64,
+                            embedding_dem=16, output_variable="gsp_yield", operand_dtype=dt).to(dev)
+        popt = pm.configure_optimizers()
+
+        def p_step():
+            popt.zero_grad(set_to_none=True)
+            pm.training_step(pbatch, 0).backward()
+            popt.step()
+
+        d = time_steps(p_step, 3, 1)
+        out["perceiver"][f"attention_operands_{dt}"] = {"ms_per_step": round(d * 1e3, 1), "samples_per_s": round(b / d, 1)}
+        del pm, popt
+        torch.cuda.empty_cache()
+    del pbatch
+
+    # BASELINE configs[4]: experiments/003 LitModel, 128 x 128 x 12 images (16 384-position context), NWP, precision 16
+    from predict_pv_yield_amd.models.perceiver.exp003 import LitModel, make_fake_exp003_batch
+    b = 8
+    ebatch = {k: v.to(dev) for k, v in make_fake_exp003_batch(b, 128, torch.Generator().manual_seed(3)).items()}
+    out["exp003_perceiver_rnn"] = {"workload": f"experiments/003 LitModel train step: B={b} x 19 images of 128x128x12 (context 16384 "
+                                               "positions x 38 ch), Perceiver depth 2 (128 latents x 64) -> fc -> 2-layer GRU "
+                                               "encoder / decoder with NWP + datetime features"}
+    n_frames, n_k = b * 19, 128 * 128
+    fwd_flop = 2 * 2.0 * n_frames * 128 * n_k * 64          # q k^T and p v of one cross-attention launch
+    for dt in ("f32", "bf16"):
+        torch.manual_seed(0)
+        em = LitModel(operand_dtype=dt).to(dev)
+        eopt = em.configure_optimizers()
+
+        def e_step():
+            eopt.zero_grad(set_to_none=True)
+            em.training_step(ebatch, 0).backward()
+            eopt.step()
+
+        d = time_steps(e_step, 4, 2)
+        entry = {"ms_per_step": round(d * 1e3, 2), "samples_per_s": round(b / d, 1)}
+        with LaunchTimer(("attention_fwd", "attention_bwd")) as lt:
+            for _ in range(2):
+                e_step()
+        peak = MFMA_BF16_PEAK if dt == "bf16" else MFMA_F32_PEAK
+        per = {}
+        for (name, shape, _), (secs, n) in lt.summary().items():
+            per.setdefault(name, []).append((secs, n))
+        for name, lst in per.items():
+            secs = max(s_ for s_, _ in lst)                 # the cross-attention launches (16 384 keys) are the long ones
+            fl = fwd_flop * (1.0 if name == "attention_fwd" else 2.5)
+            entry[f"cross_{name}"] = {"us_per_launch": round(secs * 1e6, 1), "tflops": round(fl / secs / 1e12, 1),
+                                      "frac_of_peak": round(fl / secs / peak, 4),
+                                      "peak": "bf16 dense 2.5 PF" if dt == "bf16" else "f32 matrix 157 TF"}
+        out["exp003_perceiver_rnn"][f"attention_operands_{dt}"] = entry
+        del em, eopt
+        torch.cuda.empty_cache()
     return out
 
 
