@@ -256,6 +256,40 @@ def measure_config3(dev, b, history_minutes):
     return out
 
 
+def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10):
+    """The same bf16 train step at the other per-GPU batch sizes of SURVEY.md §8d: the fc1 update (0.6 ms) is a fixed cost
+    per step, so samples/s grows with the batch."""
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    out = {}
+    for b in batches:
+        torch.manual_seed(518)
+        model = Model(**MODEL_KW, history_minutes=history_minutes, precision="bf16").to(dev)
+        model.batch_size = max(model.batch_size, b)
+        opt = model.configure_optimizers()
+        t = model.history_len_5 + model.forecast_len_5 + 1
+        g = torch.Generator(device=dev).manual_seed(518)
+        batch = {"satellite": {"data": torch.randn(b, 11, t, 64, 64, generator=g, device=dev)},
+                 "pv": {"pv_yield": torch.rand(b, t, 128, generator=g, device=dev)}}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            model.training_step(batch, 0).backward()
+            opt.step()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        out[f"B={b}"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1)}
+        del model, opt, batch
+        torch.cuda.empty_cache()
+    return out
+
+
 def measure_fp32_headline(dev, b, history_minutes, steps=5):
     from predict_pv_yield_amd.models.conv3d.model import Model
     torch.manual_seed(518)
@@ -615,6 +649,7 @@ def main():
                 out["config3"] = measure_config3(dev, b, args.history_minutes)
                 torch.cuda.empty_cache()
                 if args.precision == "bf16":
+                    out["batch_sweep"] = measure_batch_sweep(dev, args.history_minutes)
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()
                 out["other_models"] = measure_other_models(dev)
