@@ -466,9 +466,14 @@ template <int NB>   // tile edge = 32 NB; NB waves per image pair, 4 / NB pairs 
 __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
                                                             const float* __restrict__ Gh, float* __restrict__ flow,
                                                             int height, int width, long long n_pairs) {
-  constexpr int T = 32 * NB, XS = T + 4, IMG = T * XS, PPW = 4 / NB, KS = 2 * NB;   // KS contraction steps of 16
+  constexpr int T = 32 * NB, XS = T + 8, PLANE = T * XS, PPW = 4 / NB, KS = 2 * NB;   // KS contraction steps of 16
   constexpr int NE = T * T / (64 * NB);      // staged elements per lane and channel
-  __shared__ __attribute__((aligned(16))) float Xs[PPW][2][IMG];
+  // NB > 1: the channel image is split ONCE, while it is staged: three bf16 planes (h, m, l) per buffer -- both strips of a
+  // pair read the same image as their A operand, so splitting at the read would do the work twice (level-0 iteration
+  // 238 -> 218 us).  NB == 1: one wave per pair reads its image once, so it stays f32 in LDS (a third of the LDS bytes) and is
+  // split at the read (planes 1, 2 unused: 2 bf16 = 1 float per element of plane 0 ... the f32 image takes planes 0 and 1).
+  constexpr bool PRESPLIT = NB > 1;
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[PPW][2][PRESPLIT ? 3 : 2][PLANE];
   // Gv split operands, lane-major: the same for every wave (they depend on the output row = lane, not on the strip)
   __shared__ u32x4 GvS[NB * KS * 3][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -505,6 +510,8 @@ __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restri
     const bool p_ok = p < n_pairs;
     fb_v16f res[5][NB];
     float stg[NE];   // one channel image in flight: the loads of channel c + 1 are issued before the MFMAs of channel c
+    // staging element e of this lane: vec: quad q = strip*64 + lane + 64 NB (e / 4), column 4 (q % (T/4)) + e % 4;
+    // scalar: index i = strip*64 + lane + 64 NB e
     auto load_channel = [&](int c) {
       const float* src = Min + ((p_ok ? p : 0) * 5 + c) * per_img;
       if (vec) {
@@ -528,21 +535,52 @@ __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restri
     load_channel(0);
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      // ---- channel c (zero padded to the tile) into this pair's LDS image; next channel's loads start right away ---------
-      float* Xc = Xs[pw][c & 1];
-      if (vec) {
+      // ---- channel c (zero padded to the tile), split into its three bf16 planes, into this pair's LDS image; the next
+      // channel's loads start right away -----------------------------------------------------------------------------------
+      uint16_t* Xc = &Xs[pw][c & 1][0][0];
+      float* Xf = reinterpret_cast<float*>(Xc);     // !PRESPLIT: f32 image, row stride XS floats
+      if constexpr (!PRESPLIT) {
+        if (vec) {
 #pragma unroll
-        for (int e = 0; e < NE / 4; ++e) {
-          const int q = strip * 64 + lane + 64 * NB * e;
-          const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
-          *reinterpret_cast<f32x4*>(Xc + y * XS + x) = (f32x4){stg[4 * e], stg[4 * e + 1], stg[4 * e + 2], stg[4 * e + 3]};
+          for (int e = 0; e < NE / 4; ++e) {
+            const int q = strip * 64 + lane + 64 * NB * e;
+            const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
+            *reinterpret_cast<f32x4*>(Xf + y * XS + x) = (f32x4){stg[4 * e], stg[4 * e + 1], stg[4 * e + 2], stg[4 * e + 3]};
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int i = strip * 64 + lane + 64 * NB * e;
+            const int y = i / T;
+            Xf[y * XS + (i - y * T)] = stg[e];
+          }
         }
-      } else {
+      } else
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const int i = strip * 64 + lane + 64 * NB * e;
-          const int y = i / T;
-          Xc[y * XS + (i - y * T)] = stg[e];
+      for (int e8 = 0; e8 < NE / 8; ++e8) {
+        const float t[8] = {stg[8 * e8], stg[8 * e8 + 1], stg[8 * e8 + 2], stg[8 * e8 + 3],
+                            stg[8 * e8 + 4], stg[8 * e8 + 5], stg[8 * e8 + 6], stg[8 * e8 + 7]};
+        const FbSplit3 sp = fb_split3(t);
+        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
+        if (vec) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {        // two quads of 4 consecutive columns
+            const int q = strip * 64 + lane + 64 * NB * (2 * e8 + u);
+            const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
+            *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u], hw[2 * u + 1]};
+            *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u], mw[2 * u + 1]};
+            *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u], lw[2 * u + 1]};
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = strip * 64 + lane + 64 * NB * (8 * e8 + u);
+            const int y = i / T, x = i - y * T;
+            const int sh = (u & 1) * 16;
+            Xc[y * XS + x] = (uint16_t)(hw[u >> 1] >> sh);
+            Xc[PLANE + y * XS + x] = (uint16_t)(mw[u >> 1] >> sh);
+            Xc[2 * PLANE + y * XS + x] = (uint16_t)(lw[u >> 1] >> sh);
+          }
         }
       }
       if (NB > 1) __syncthreads();   // the image is staged by both waves of the pair (the buffer of channel c - 1 may still be read)
@@ -556,10 +594,19 @@ __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const float* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa), x1 = *reinterpret_cast<const f32x4*>(xa + 4);
-          const float t[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          u[mb] = fb_mfma3(fb_split3(t), gh[ks], u[mb]);
+          FbSplit3 a;
+          if constexpr (PRESPLIT) {
+            const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+            a.h = *reinterpret_cast<const bf16x8*>(xa);
+            a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
+            a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
+          } else {
+            const float* xa = Xf + (32 * mb + col) * XS + 16 * ks + 8 * half;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa), x1 = *reinterpret_cast<const f32x4*>(xa + 4);
+            const float t[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            a = fb_split3(t);
+          }
+          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
         }
       }
       // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x]: the accumulators of the horizontal pass are the B operand -------
