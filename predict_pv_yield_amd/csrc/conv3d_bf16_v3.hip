@@ -325,7 +325,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     if (s - 3 >= tc0) store_pending(s - 3);                                                                       \
     if (OUT_GATE == 1 && KT_HI == 2) load_gate(s - 2);                                                            \
     const unsigned char* slot = lds + (s & 1) * V3_SLOTB + (4 * wr) * V3_ROWB;                                    \
-    v3_accumulate<P, KT_LO, KT_HI, 0>(slot, voff, wfrag, w2, acc);                                                \
+    /* an input slice that lies in the time padding (dgrad: pad_t = 2 -> the two head and the two tail steps of a    \
+       whole march) is all zeros: its MFMAs are skipped (wave-uniform branch), the bookkeeping of the step is not.    \
+       Only the head / tail instances test it: an interior step of a chunk never reads padding of a whole march's    \
+       ends unless the march has fewer than three slices, and its code stays branch-free */                          \
+    const bool slice_live = ((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in;             \
+    if (slice_live) v3_accumulate<P, KT_LO, KT_HI, 0>(slot, voff, wfrag, w2, acc);                                \
     if constexpr (OUT_GATE == 1 && KT_HI == 2) {                                                                  \
       gbits = 0u;                                                                                                 \
       _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) \
@@ -334,8 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     if constexpr (OUT_GATE == 2 && KT_HI == 2) { /* row kg of both column halves -> this lane's 8 nibbles */       \
       gbits = v3_kg_transpose(v3_u16_to_nibbles(mpend) | (v3_u16_to_nibbles(mpend_hi) << 4), lane);                \
     }                                                                                                             \
-    v3_accumulate<P, KT_LO, KT_HI, 1>(slot, voff, wfrag, w2, acc);                                                \
-    v3_accumulate<P, KT_LO, KT_HI, 2>(slot, voff, wfrag, w2, acc);                                                \
+    if (slice_live) {                                                                                             \
+      v3_accumulate<P, KT_LO, KT_HI, 1>(slot, voff, wfrag, w2, acc);                                              \
+      v3_accumulate<P, KT_LO, KT_HI, 2>(slot, voff, wfrag, w2, acc);                                              \
+    }                                                                                                             \
     if (KT_HI == 2) { /* output slice s-2 is complete: convert it, re-arm its accumulators */                     \
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);                              \
       _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
