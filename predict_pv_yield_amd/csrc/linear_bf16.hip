@@ -339,6 +339,189 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fc1 backward in ONE pass over the matrix (single GPU): weight gradient + Adam update (as linear_bwd_dw_bf16_kernel<1>)
+// AND dx = g . W from the very weights the pass streams anyway.  The separate dx kernel re-reads the 257 MB bf16 operand
+// copy of the matrix (84-93 us of the 1.83 ms step) shortly before the update streams the f32 master of the same matrix.
+// Tile = ALL n <= 128 rows x 128 k-columns per workgroup (dx needs every row of a k-range): thread (kq = tid % 16,
+// rg = tid / 16) owns rows 8 rg .. +7 x columns 8 kq .. +7.  x [m <= 32][128] (bf16) and g [32][128] (f32) sit in LDS; the
+// 8 x 8 gradient tile is formed in registers and applied row by row like the two-kernel path (same operation order:
+// bit-identical parameters / moments / operand copy); the PRE-update weights are rounded to bf16 -- the values the operand
+// copy held during the forward -- and parked transposed in LDS ([k][n]) as the B operand of dx = g W on the bf16 matrix
+// cores, g as a bf16 hi + lo pair (two MFMAs per step, ~16 mantissa bits) exactly like linear_bwd_dx_bf16_v2_kernel; the dx
+// tile leaves through LDS as 256-byte runs.  The x tile and the outgoing dx tile share bytes with the weight tile: 50 KB
+// of LDS and 152 registers = three workgroups per CU (the update pass needs the occupancy to keep HBM busy while a
+// workgroup sits in its prologue / matrix tail).  Measured alone: 684 us against 620 us for the update-only kernel plus
+// 85-99 us for the dx kernel it replaces.
+// ---------------------------------------------------------------------------------------------
+constexpr int FD_KT = 128;                 // k-columns per workgroup
+constexpr int FD_XLD = FD_KT + 8;          // bf16 row stride of the x / dx tile
+constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed weight tile [k][n]
+
+__global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
+    int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
+    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad) {
+  __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g = dy (.) relu'  [b][n], zero padded
+  __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
+  // the x tile [b][k] lives in the first 8.5 KB of wt until the gradient tile is formed (wt is written after that), and the
+  // dx tile [b][k] goes through the same bytes on its way out
+  uint16_t* xs = wt;
+  static_assert(32 * FD_XLD <= FD_KT * FD_WLD, "x tile does not fit inside the weight tile");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = tid & 15, rg = tid >> 4;
+  const long long k0 = (long long)blockIdx.x * FD_KT;
+  for (int i = tid; i < 32 * 128; i += 256) {
+    const int b = i >> 7, nn = i & 127;
+    float v = 0.f;
+    if (b < m && nn < n) {
+      const size_t off = (size_t)b * n + nn;
+      v = dy[off];
+      if (ymask && !(ymask[off] > 0.f)) v = 0.f;
+    }
+    gs[i] = v;
+  }
+  for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks of the x tile
+    const int b = i / (FD_KT / 8), c = i - b * (FD_KT / 8);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (b < m && k0 + 8 * c < k) v = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+    *reinterpret_cast<u32x4*>(xs + b * FD_XLD + 8 * c) = v;
+  }
+  __syncthreads();
+  if (db && blockIdx.x == 0 && tid < n) {    // db[n] = column sums of g (index order), by the first workgroup
+    float sacc = 0.f;
+    for (int b = 0; b < m; ++b) sacc += gs[b * 128 + tid];
+    db[tid] = sacc;
+  }
+  const long long k8 = k0 + 8 * kq;
+  const bool k_ok = k8 < k;
+  // ---- weight gradient tile: rows 8 rg .. +7, columns k8 .. +7 (packed f32 FMAs, gradient value broadcast) ----------------
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
+#pragma unroll 4
+  for (int b = 0; b < m; ++b) {
+    const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * kq);
+    f32x2_t xv2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg), g1 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float gv = i < 4 ? g0[i] : g1[i - 4];
+      const f32x2_t g2 = {gv, gv};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
+    }
+  }
+  // ---- Adam, row by row (next row's p / m / v in flight under this row's arithmetic); the old weights are kept as bf16 ------
+  uint32_t wold[8][4];     // bf16 pairs of the PRE-update weights: [row i][column pair]
+  f32x4 nxt[6];
+  auto fetch = [&](int i) {
+    const size_t off = (size_t)min(8 * rg + i, n - 1) * k + (k_ok ? k8 : 0);
+    nxt[0] = *reinterpret_cast<const f32x4*>(w + off);
+    nxt[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
+    nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + off);
+    nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
+    nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
+    nxt[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+  };
+  fetch(0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float pv[8], mv[8], vv[8];
+    *reinterpret_cast<f32x4*>(pv) = nxt[0];
+    *reinterpret_cast<f32x4*>(pv + 4) = nxt[1];
+    *reinterpret_cast<f32x4*>(mv) = nxt[2];
+    *reinterpret_cast<f32x4*>(mv + 4) = nxt[3];
+    *reinterpret_cast<f32x4*>(vv) = nxt[4];
+    *reinterpret_cast<f32x4*>(vv + 4) = nxt[5];
+    if (i + 1 < 8) fetch(i + 1);
+    const bool row_ok = 8 * rg + i < n && k_ok;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      wold[i][q] = row_ok ? ((uint32_t)f32_to_bf16_bits(pv[2 * q]) | ((uint32_t)f32_to_bf16_bits(pv[2 * q + 1]) << 16)) : 0u;
+    if (row_ok) {
+      const size_t off = (size_t)(8 * rg + i) * k + k8;
+      uint32_t sh[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gr = acc2[i][j >> 1][j & 1];
+        const float mm = mv[j] + ad.one_minus_b1 * (gr - mv[j]);
+        const float v2 = vv[j] * ad.beta2 + (ad.one_minus_b2 * gr) * gr;
+        const float denom = sqrtf(v2) / ad.bc2_sqrt + ad.eps;
+        const float pp = pv[j] + ad.neg_step_size * (mm / denom);
+        mv[j] = mm; vv[j] = v2; pv[j] = pp;
+        if (j & 1) sh[j >> 1] |= (uint32_t)f32_to_bf16_bits(pp) << 16; else sh[j >> 1] = f32_to_bf16_bits(pp);
+      }
+      *reinterpret_cast<f32x4*>(w + off) = *reinterpret_cast<const f32x4*>(pv);
+      *reinterpret_cast<f32x4*>(w + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg + off) = *reinterpret_cast<const f32x4*>(mv);
+      *reinterpret_cast<f32x4*>(exp_avg + off + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + off) = *reinterpret_cast<const f32x4*>(vv);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + off + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
+      if (shadow) {
+        u32x4 so = {sh[0], sh[1], sh[2], sh[3]};
+        *reinterpret_cast<u32x4*>(shadow + off) = so;
+      }
+    }
+  }
+  if (!dx) return;
+  __syncthreads();   // every thread is done reading the x tile: its bytes now become part of wt
+  // transposed into wt: column kk = 8 kq + j holds rows 8 rg .. +7 as one 16-byte piece
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32x4 piece;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = (wold[2 * q][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      const uint32_t hi = (wold[2 * q + 1][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      piece[q] = lo | (hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(wt + (8 * kq + j) * FD_WLD + 8 * rg) = piece;
+  }
+  __syncthreads();
+  // ---- dx[b][k0 + 32 wave + col] = sum_n g[b][n] w_old[n][k]: A = g rows b (hi + lo), B = wt rows k ---------------------------
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half + 4);
+    const float gx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    u32x4 hw, lw;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint16_t h0 = f32_to_bf16_bits(gx[2 * q]), h1 = f32_to_bf16_bits(gx[2 * q + 1]);
+      const uint16_t l0 = f32_to_bf16_bits(gx[2 * q] - bf16_bits_to_f32(h0)), l1 = f32_to_bf16_bits(gx[2 * q + 1] - bf16_bits_to_f32(h1));
+      hw[q] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      lw[q] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+    const bf16x8 bw = *reinterpret_cast<const bf16x8*>(wt + (32 * wave + col) * FD_WLD + 16 * st + 8 * half);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lw), bw, o, 0, 0, 0);
+    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hw), bw, o, 0, 0, 0);
+  }
+  __syncthreads();   // all four waves are done reading wt / gs: the dx tile [b][k] is assembled in wt's first bytes
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = (r & 3) + 8 * (r >> 2) + 4 * half;
+    xs[b * FD_XLD + 32 * wave + col] = f32_to_bf16_bits(o[r]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks: 256 contiguous bytes per row of dx
+    const int b = i / (FD_KT / 8), c = i - b * (FD_KT / 8);
+    if (b < m && k0 + 8 * c < k)
+      *reinterpret_cast<u32x4*>(dx + (size_t)b * k + k0 + 8 * c) = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * c);
+  }
+}
+
 __global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                                float* __restrict__ db, int m, int n) {
   int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -746,6 +929,23 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
   hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<1>, dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds,
                      as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, bf16_shadow, ad);
   return check_launch("pv_linear_wgrad_adam_bf16");
+}
+
+int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                                 float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
+                                 int64_t k, double lr, double beta1, double beta2, double eps, int32_t step, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_dx_adam_bf16: null pointer");
+  PV_REQUIRE(m > 0 && m <= 32 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
+             "pv_linear_wgrad_dx_adam_bf16: built for m <= 32 rows of x and n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
+  PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_bf16: k must be a multiple of 8");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_dx_adam_bf16: step must be >= 1");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                 (float)(-(lr / bc1))};
+  const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
+  hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad);
+  return check_launch("pv_linear_wgrad_dx_adam_bf16");
 }
 
 int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16, int32_t m,

@@ -494,6 +494,25 @@ def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_
                                               step, current_stream_ptr()), "pv_linear_wgrad_adam_bf16")
 
 
+def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
+                              betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False):
+    """fc1's whole backward in ONE pass over the matrix: weight gradient applied by Adam in place (as
+    linear_wgrad_adam_bf16, bit-identical) AND dx = (dy ⊙ (y>0)) . W_old (bf16 [M, K]) from the weights it streams."""
+    require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow)
+    m, k = x_bf16.shape
+    n = param.shape[0]
+    dx = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device) if need_dx else None
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
+    check(get_lib().pv_linear_wgrad_dx_adam_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
+                                                 ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, lr, betas[0], betas[1], eps,
+                                                 step, current_stream_ptr()), "pv_linear_wgrad_dx_adam_bf16")
+    return (dx, db) if need_db else dx
+
+
+def fused_dx_update_supported(m: int, n: int, k: int) -> bool:
+    return m <= 32 and n <= 128 and n % 8 == 0 and k % 8 == 0
+
+
 def linear_wgrad_bf16out(x_bf16, dy, y_mask, n: int) -> torch.Tensor:
     """fc1 weight gradient written directly as bf16 [N,K] (data-parallel wire format)."""
     require_cuda(x_bf16, dy, y_mask)

@@ -415,6 +415,30 @@ def test_fused_wgrad_adam_is_bit_identical_to_two_pass(device):
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb), step
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 128, 8192), (7, 128, 1024 + 8), (32, 16, 4096), (4, 128, 128 * 33)])
+def test_fused_wgrad_dx_adam_single_pass(device, m, n, k):
+    """pv_linear_wgrad_dx_adam_bf16: parameters / moments / operand copy bit-identical to pv_linear_wgrad_adam_bf16, and dx
+    equal to the dx kernel's (same bf16 hi + lo gradient operand, same bf16 weights; only the f32 summation order of the
+    128-deep contraction differs: isolated 1-ulp bf16 flips)."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(m, n, generator=g).to(device)
+    y = torch.relu(torch.randn(m, n, generator=g)).to(device)
+    p0 = (torch.randn(n, k, generator=g) * 0.01).to(device)
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    sa, sb = p0.to(torch.bfloat16), p0.to(torch.bfloat16)
+    for step in (1, 2, 3):
+        dx_ref, _, _ = K.linear_bwd_bf16(x, sa, dy, y, need_dx=True, need_dw=False)       # from the PRE-update operand copy
+        K.linear_wgrad_adam_bf16(x, dy, y, pa, ma, va, sa, step, lr=5e-4)
+        dx = K.linear_wgrad_dx_adam_bf16(x, dy, y, pb, mb, vb, sb, step, lr=5e-4)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb), step
+        d = (dx.float() - dx_ref.float()).abs()
+        scale = dx_ref.float().abs().max().item()
+        assert d.max().item() <= 2 ** -7 * scale and (d > 0).float().mean().item() < 0.02, (d.max().item(), scale)
+
+
 def test_bf16_gradient_wire_format(device):
     """pv_linear_wgrad_bf16out = bf16(RNE) of the f32 gradient; pv_adam_step_bf16grad = Adam on the widened gradient."""
     K, _ = _mods()
