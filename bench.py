@@ -95,6 +95,7 @@ class LaunchTimer:
 
 
 TIMED_OPS = ("conv3d_fwd_bf16", "conv3d_fwd_bf16_f32in", "conv3d_bwd_weight_bf16", "linear_wgrad_adam_bf16",
+             "linear_wgrad_dx_adam_bf16",
              "linear_fwd_bf16", "linear_bwd_bf16", "repack_gate_ncdhw_to_ndhwc_bf16", "adam_step_multi",
              "conv3d_pack_weights_multi")
 
@@ -138,13 +139,17 @@ def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
         kernels[label] = entry
     out = {}
     # --- the single largest kernel of the step: fc1 fused wgrad + Adam (one pass over p, m, v + the bf16 operand copy)
-    fc1 = [(k, v) for k, v in per.items() if k[0] == "linear_wgrad_adam_bf16"]
+    fc1 = [(k, v) for k, v in per.items() if k[0] in ("linear_wgrad_adam_bf16", "linear_wgrad_dx_adam_bf16")]
     if fc1:
         (name, shape, _), (secs, n) = fc1[0]
         nrows, kcols = model.fc1.weight.shape
-        byt = nrows * kcols * (3 * 4 * 2 + 2) + b * kcols * 2          # p, m, v read + written, shadow written, x read once
-        tr = traffic.get("pv::linear_bwd_dw_bf16_kernel<1>", {}).get("hbm_bytes_per_launch")
-        out.update({"bound": "hbm", "kernel": "linear_bwd_dw_bf16_kernel<1> (fc1 wgrad + Adam fused, 128.45 M weights)",
+        single_pass = name == "linear_wgrad_dx_adam_bf16"
+        # p, m, v read + written, shadow written, x read once (+ dx written by the single-pass form)
+        byt = nrows * kcols * (3 * 4 * 2 + 2) + b * kcols * 2 * (2 if single_pass else 1)
+        kname = "pv::linear_bwd_dw_dx_adam_kernel" if single_pass else "pv::linear_bwd_dw_bf16_kernel<1>"
+        tr = traffic.get(kname, {}).get("hbm_bytes_per_launch")
+        out.update({"bound": "hbm", "kernel": (kname[4:] + " (fc1 backward in one pass: wgrad + Adam + dx + db, 128.45 M weights)")
+                    if single_pass else "linear_bwd_dw_bf16_kernel<1> (fc1 wgrad + Adam fused, 128.45 M weights)",
                     "achieved": round(byt / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(byt / secs / HBM_PEAK, 4), "traffic": tr, "avg_launch_ms": round(secs * 1e3, 4),
                     "launches_per_step": 1, "algorithmic_bytes_per_launch": byt,

@@ -240,6 +240,13 @@ class LinearBF16(torch.autograd.Function):
         dy = dy.contiguous()
         weight = ctx.weight_param
         mode = getattr(weight, "_pv_grad_mode", "autograd")
+        if mode == "fused":
+            fused = getattr(weight, "_pv_fused_backward", None)
+            out = fused(x, dy, y, ctx.needs_input_grad[0], ctx.has_bias) if fused is not None else None
+            if out is not None:
+                # HipAdam owns this parameter (single process): dx, db, the weight gradient and its Adam update came out of
+                # ONE pass over the matrix; nothing is left for step()
+                return out[0], None, out[1], None
         dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=(mode == "autograd"))
         if mode == "fused":
             # HipAdam owns this parameter (single process): hand it (x, dy, relu mask); the weight gradient is formed

@@ -11,6 +11,13 @@ import torch
 from . import hip_ops as K
 
 
+# Single process, "fused" mode: fc1's whole backward (dx, db, weight gradient, Adam) runs as ONE pass over the matrix,
+# launched from inside backward (functional.LinearBF16) -- the parameter is therefore updated when backward() returns and
+# step() only counts it.  A second backward before step() would differentiate against already-updated weights: it raises.
+# tools/ab_step.py flips this switch to time the two arrangements in one process.
+FUSE_DX_INTO_UPDATE = True
+
+
 class HipAdam(torch.optim.Optimizer):
     # 2-D parameters at least this large whose gradient comes from functional.LinearBF16 (fc1) can bypass autograd's
     # f32 .grad:  "fused" -- wgrad + Adam in one pass, the gradient is never materialised (single process);
@@ -48,6 +55,8 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_grad_bf16 = None
             p._pv_grad_shard = None
             p._pv_eager_update = self._make_eager_update(p) if (mode == "fused" and self.overlap_large_update) else None
+            p._pv_fused_backward = self._make_fused_backward(p) if (mode == "fused" and not self.overlap_large_update) else None
+            p._pv_applied = False
 
     def consolidate_sharded(self) -> None:
         """After sharded steps every rank holds current f32 values (parameter, exp_avg, exp_avg_sq) only for the rows it
@@ -99,6 +108,28 @@ class HipAdam(torch.optim.Optimizer):
                 self._inflight.append((done, (x, dy, y)))   # keep the operands alive until step() has waited
         return eager
 
+    def _make_fused_backward(self, p):
+        def fused(x, dy, y, need_dx, need_db):
+            """(dx, db) of the layer, with the Adam update of p applied in the same pass; None if the shape is not covered
+            (the caller then takes the two-kernel path) or the switch is off."""
+            from .functional import bf16_shadow_of
+            if not FUSE_DX_INTO_UPDATE or not need_dx or not K.fused_dx_update_supported(x.shape[0], p.shape[0], p.shape[1]):
+                return None
+            if p._pv_applied:
+                raise RuntimeError("HipAdam: backward() ran twice without optimizer.step() in between; the fused fc1 pass has "
+                                   "already applied the first update (gradient accumulation needs HipAdam(fuse_large_linear="
+                                   "False))")
+            group = self._group_of(p)
+            with torch.no_grad():
+                st = self._init_state(p)
+                st["step"] += 1
+                out = K.linear_wgrad_dx_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
+                                                  int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                                                  need_dx=True, need_db=need_db)
+            p._pv_applied = True
+            return out if need_db else (out, None)
+        return fused
+
     def _wait_inflight(self):
         if self._inflight:
             main = torch.cuda.current_stream()
@@ -116,6 +147,8 @@ class HipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._wait_inflight()
+        for p in self.large_params():
+            p._pv_applied = False          # the update of this step was applied from inside backward
         for group in self.param_groups:
             plain = {}      # step count -> [(param, grad, exp_avg, exp_avg_sq, bf16 shadow)]: one multi-tensor launch each
             stepped = []

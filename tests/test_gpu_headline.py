@@ -140,7 +140,8 @@ def test_bf16_adam_steps_with_the_fused_fc1_kernel(device, emulate):
         opt.zero_grad()
         loss = model.training_step(batch, 0)
         loss.backward()
-        assert model.fc1.weight.grad is None and model.fc1.weight._pv_pending is not None   # the fused path is live
+        # the fused path is live: no gradient tensor; the single-pass kernel applied the update from inside backward
+        assert model.fc1.weight.grad is None and model.fc1.weight._pv_applied
         opt.step()
         losses.append(float(loss))
         if step == 0:

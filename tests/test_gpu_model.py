@@ -183,19 +183,27 @@ def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
         loss = model_b.training_step(batch, 0)
         loss.backward()
         # the update was launched from inside backward on the optimiser's side stream (or left pending for step())
-        assert model_b.fc1.weight.grad is None and (opt._inflight or model_b.fc1.weight._pv_pending is not None)
+        # applied from inside backward by the single-pass kernel (or launched / left pending for step() by the older forms)
+        assert model_b.fc1.weight.grad is None and (model_b.fc1.weight._pv_applied or opt._inflight
+                                                    or model_b.fc1.weight._pv_pending is not None)
         opt.step()
         losses_b.append(float(loss))
-    assert losses_a == losses_b
+    # fc1's dx comes from a different kernel in the single-pass form (same operands, another summation order): isolated
+    # 1-ulp bf16 differences in dx, so the trajectories agree closely instead of bit for bit
+    np.testing.assert_allclose(losses_a, losses_b, rtol=1e-5)
+    # (Adam turns a sign flip of a near-zero gradient into a difference of 2 lr per step: bound the mean tightly, the maximum by that)
     for (k, a), (_, b) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
-        assert torch.equal(a, b), k
+        d = (a - b).abs()
+        assert d.mean().item() <= 0.1 * 5e-4 and d.max().item() <= 3 * 2.05 * 5e-4, (k, d.mean().item(), d.max().item())
 
 
 def test_deferred_and_eager_fused_updates_agree(device, monkeypatch):
     """overlap_large_update=False (update inside step()) and True (update launched from backward on a side stream)
     give bit-identical parameters."""
+    from predict_pv_yield_amd import optim
     from predict_pv_yield_amd.optim import HipAdam
     monkeypatch.setattr(HipAdam, "FUSE_MIN_NUMEL", 1)
+    monkeypatch.setattr(optim, "FUSE_DX_INTO_UPDATE", False)   # both arms use the two-kernel form (dx kernel + update pass)
     sat, pv = _data(SMALL, 2)
     batch = None
     results = []
