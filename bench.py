@@ -595,10 +595,12 @@ def main():
         grad_sync_mode = D.negotiate_grad_sync(model, opt, batch, grad_sync_mode)
         sync = D.OverlappedGradSync(model)
 
+    from predict_pv_yield_amd.lightning import Trainer
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss = model.training_step(batch, 0)
-        loss.backward()      # under N > 1 fc1's gradient exchange starts from a hook inside backward
+        Trainer._backward(loss)      # = loss.backward() as the Trainer issues it; under N > 1 fc1's exchange starts inside
         if sync is not None:
             sync.finish()
         opt.step()

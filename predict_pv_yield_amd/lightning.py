@@ -390,6 +390,15 @@ class Trainer:
             return None
         return {"train": dm.train_dataloader, "val": dm.val_dataloader, "test": dm.test_dataloader}[which]()
 
+    @staticmethod
+    def _backward(loss):
+        """loss.backward() with a cached unit root gradient on the device (no per-step fill / multiply launches)."""
+        if loss.is_cuda and loss.dim() == 0:
+            from .functional import unit_gradient
+            loss.backward(unit_gradient(loss))
+        else:
+            loss.backward()
+
     def _timed(self, key, fn, *a, **kw):
         if self.profiler is None:
             return fn(*a, **kw)
@@ -471,7 +480,7 @@ class Trainer:
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
-                self._timed("backward", loss.backward)
+                self._timed("backward", self._backward, loss)
                 if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():   # host wait: after backward is queued
                     raise ValueError("loss is NaN or inf")
                 if self.world_size > 1:
