@@ -16,7 +16,7 @@ for f in glob.glob(f"{path}/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")))
 rows.sort()
 # a step starts at the first launch of the satellite normalise / pack kernel; use the fc1 fused update as the step end marker
-ends = [i for i, r in enumerate(rows) if "linear_bwd_dw_bf16_kernel" in r[2]]
+ends = [i for i, r in enumerate(rows) if "linear_bwd_dw_" in r[2]]
 ends = ends[-(n_steps + 1):]
 tot_busy = tot_wall = 0
 for a, b in zip(ends[:-1], ends[1:]):
