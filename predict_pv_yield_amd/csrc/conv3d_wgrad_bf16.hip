@@ -34,6 +34,17 @@ __device__ __forceinline__ uint32_t wg_gate_word(uint32_t x, uint32_t g) {
   return x & (lo | hi);
 }
 
+// scheduling shape of one k-step: MFMA q, then the q-th share of the 2 + 2 * NACC LDS reads of the next k-step
+template <int NACC, int Q>
+__device__ __forceinline__ void wg_interleave() {
+  if constexpr (Q < NACC) {
+    constexpr int R = 2 + 2 * NACC;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, R / NACC + (Q < R % NACC ? 1 : 0), 0);
+    wg_interleave<NACC, Q + 1>();
+  }
+}
+
 template <int CPAD, bool HAS_GATE>
 __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, const uint16_t* __restrict__ ymask,
@@ -49,8 +60,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
   constexpr int DROWB = WTW * 64;
   constexpr int DTILEB = WTR * DROWB;
   constexpr int NLOAD_D = WTR * WTW * 4 / 256;
-  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * SLOTB + 512 + DTILEB];
-  unsigned char* lds_dy = lds + 3 * SLOTB + 512;
+  // [X ring: 3 slots][512 B of zeros: reads of the last row run past the ring][128 B of bf16 ones + 128 B of zeros: the
+  // B operand of the ones-tap (dbias) and of the empty tap slots, fetched like any other fragment][dY tile]
+  __shared__ __attribute__((aligned(256))) unsigned char lds[3 * SLOTB + 512 + 256 + DTILEB];
+  unsigned char* lds_const = lds + 3 * SLOTB + 512;
+  unsigned char* lds_dy = lds_const + 256;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,6 +96,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
 
   if (tc0 < tc1) {
     if (tid < 128) reinterpret_cast<uint32_t*>(lds + 3 * SLOTB)[tid] = 0u;
+    if (tid < 64) reinterpret_cast<uint32_t*>(lds_const)[tid] = tid < 32 ? 0x3f803f80u : 0u;
 
     // ---- per-lane byte offsets of the transposed reads --------------------------------------
     // dY (A operand, 32 channels): voxel column 8*hh + 4*s + qi, channels cb + 4*pi .. +3
@@ -187,8 +202,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
       }
     };
 
-    const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f,
-                         (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 
     load_x(tc0);
     store_x(tc0);
@@ -213,7 +226,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
       // by one k-step: all reads of step s+1 are issued before the MFMAs of step s (one wave per SIMD: the LDS
       // latency has nothing else to hide behind).
       typedef __attribute__((ext_vector_type(8))) short s16x8;
-      const bool use_ones = (wave == 3);
+      // this lane's constant fragment for the last slot: ones for tap 27, zeros past it, none (nullptr) for a real tap
+      const int last_tap = PAIRED ? my_tap[NACC - 1] : (wave == 3 ? 27 : 0);
+      const unsigned char* const_frag =
+          last_tap < 27 ? nullptr : lds_const + (last_tap == 27 ? 0 : 128) + (lane & 15) * 8;
       int bslot[NACC];
 #pragma unroll
       for (int i = 0; i < NACC; ++i) bslot[i] = bkt[i] == 0 ? slot_of_kt[0] : (bkt[i] == 1 ? slot_of_kt[1] : slot_of_kt[2]);
@@ -226,8 +242,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
           const unsigned char* bp = lds + bslot[i] + xo;
-          rb[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][0]));
-          rb[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + boff[i][1]));
+          const unsigned char* p0 = bp + boff[i][0];
+          const unsigned char* p1 = bp + boff[i][1];
+          if (i == NACC - 1) {  // only the last slot can hold the ones-tap (27) or run past it: the select is on the
+            p0 = const_frag ? const_frag : p0;  // ADDRESS, so nothing waits for the data (a select on the fragment put an
+            p1 = const_frag ? const_frag : p1;  // lgkmcnt(0) behind every k-step's reads)
+          }
+          rb[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+          rb[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
         }
       };
       auto mfma_step = [&](const s16x4 (&ra)[2], const s16x4 (&rb)[NACC][2]) {
@@ -237,27 +259,27 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
         for (int i = 0; i < NACC; ++i) {
           s16x8 t8 = {rb[i][0][0], rb[i][0][1], rb[i][0][2], rb[i][0][3], rb[i][1][0], rb[i][1][1], rb[i][1][2], rb[i][1][3]};
           bf16x8 bfr = __builtin_bit_cast(bf16x8, t8);
-          if constexpr (PAIRED) {
-            if (i == NACC - 1) {               // only the last slot can reach the ones-tap (27) or run past it
-              if (my_tap[i] == 27) bfr = ones;
-              else if (my_tap[i] > 27) bfr = __builtin_bit_cast(bf16x8, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
-            }
-          } else {
-            if (i == 6 && use_ones) bfr = ones;
-          }
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
         }
       };
       s16x4 ra0[2], ra1[2], rb0[NACC][2], rb1[NACC][2];
       read_step(0, ra0, rb0);
+      // The 2 + 2 * NACC transposed reads of k-step s+1 are dealt out between the NACC MFMAs of k-step s: a read issued in
+      // an MFMA gap costs about a cycle, a block of 16 reads in front of 7 back-to-back MFMAs left the matrix pipe idle
+      // for the whole block (PMC, round 2: pipe busy 50 % of the wave's residency).
       for (int st = 0; st < WTR * 4; st += 2) {
+        __builtin_amdgcn_sched_barrier(0);
         read_step(st + 1, ra1, rb1);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_step(ra0, rb0);
+        wg_interleave<NACC, 0>();
         __builtin_amdgcn_sched_barrier(0);
-        if (st + 2 < WTR * 4) read_step(st + 2, ra0, rb0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_step(ra1, rb1);
+        if (st + 2 < WTR * 4) {
+          read_step(st + 2, ra0, rb0);
+          mfma_step(ra1, rb1);
+          wg_interleave<NACC, 0>();
+        } else {
+          mfma_step(ra1, rb1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();

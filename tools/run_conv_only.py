@@ -1,4 +1,4 @@
-"""Runs the layer-1 conv forward (and optionally wgrad) kernel a few times: target for rocprofv3 --pmc passes."""
+"""Runs the layer-1 conv forward (or dgrad, or wgrad) kernel a few times: target for rocprofv3 --pmc passes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,12 +10,15 @@ x = torch.randn(b, 16, 62, 62, 32, device=dev).to(torch.bfloat16)
 w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
 bias = torch.zeros(32, device=dev)
 wp = K.conv3d_pack_weight_bf16(w)
+wpT = K.conv3d_pack_weight_bf16(w, transpose_flip=True)
 y = K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False)
 dy = torch.randn_like(y)
 torch.cuda.synchronize()
 for _ in range(5):
     if which == "fwd":
         K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False)
+    elif which == "dgrad":      # layer-1 dgrad: dy [B,14,60,60,32] -> dx [B,16,62,62,32], gated by the producer's activation x
+        K.conv3d_fwd_bf16(dy, None, wpT, None, 32, 32, (2, 2, 2), False, False, out_gate=x)
     elif which == "wgrad":
         K.conv3d_bwd_weight_bf16(x, dy, None, 32, 32, (0, 0, 0))
 torch.cuda.synchronize()
