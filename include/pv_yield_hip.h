@@ -374,6 +374,14 @@ typedef struct pv_gemm_desc {
 } pv_gemm_desc;
 int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
+/* accumulate != 0: out += the sum -- a weight that several layers share (weight_tie_layers=True,
+ * predict_pv_yield/models/perceiver/perceiver.py:70-80) collects its gradient contributions in place, in arrival order,
+ * instead of through one autograd add per use. */
+int pv_sum_slabs_acc_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, int32_t accumulate, void* stream);
+/* out[c] (+)= sum over rows of x[r][c] (the bias gradient of nn.Linear): chunk partials in `workspace`
+ * (pv_colsum_workspace_floats floats), summed in chunk order. */
+size_t pv_colsum_workspace_floats(int64_t rows, int32_t cols);
+int pv_colsum_f32(const float* x, float* out, int64_t rows, int32_t cols, float* workspace, int32_t accumulate, void* stream);
 /* Fused attention out = softmax(scale q k^T) v with an online softmax on the f32 matrix cores (the scores never reach
  * memory).  Element (b, h, i, d) of q / out at q + b*q_batch_stride + i*q_row_stride + h*64 + d; of k / v (separate base
  * pointers, e.g. the two halves of a fused kv projection) at k + b*k_batch_stride + j*k_row_stride + h*64 + d.
@@ -409,7 +417,8 @@ int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* 
                          int32_t d, float eps, void* stream);
 int pv_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
 int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, float* dx,
-                         float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, void* stream);
+                         float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, int32_t accumulate,
+                         void* stream);   /* accumulate != 0: dw, db += (see pv_sum_slabs_acc_f32); db == dw + d: one launch */
 /* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
  * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);

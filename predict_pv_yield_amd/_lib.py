@@ -138,6 +138,9 @@ SIGNATURES = {
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
     "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
+    "pv_sum_slabs_acc_f32": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
+    "pv_colsum_f32": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp],
+    "pv_colsum_workspace_floats": [c_i64, c_i32],
     "pv_attention_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
@@ -145,7 +148,7 @@ SIGNATURES = {
     "pv_attention_bwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
-    "pv_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_vp],
+    "pv_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_i32, c_vp],
     "pv_softmax_fwd_f32": [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_softmax_bwd_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_geglu_fwd_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
@@ -161,7 +164,7 @@ SIGNATURES = {
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }
 _RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz,
-             "pv_attention_bwd_workspace_floats": c_sz}
+             "pv_attention_bwd_workspace_floats": c_sz, "pv_colsum_workspace_floats": c_sz}
 
 
 def build_library(verbose: bool = False) -> str:

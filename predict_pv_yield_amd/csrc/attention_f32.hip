@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
 }
 
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
-                      hipStream_t st);   // gemm_f32.hip
+                      hipStream_t st, int accumulate = 0);   // gemm_f32.hip
 
 // delta = rowsum(dO * O), shared with the bf16-operand backward (attention_bf16.hip)
 void launch_attn_delta(const float* o, const float* dout, float* delta, const pv_attention_desc* d, hipStream_t st) {

@@ -116,10 +116,184 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
   }
 }
 
+// ---- the same GEMM on the bf16 matrix cores at f32 accuracy ------------------------------------------------------------
+// Every f32 operand is split by truncation into three bf16 terms x = h + m + l (8 + 8 + 8 mantissa bits, both
+// subtractions exact) and a product keeps the six partial products down to 2^-16 (mm, lh, hl, mh, hm, hh: what is
+// dropped is <= 2^-23 relative, one f32 rounding; farneback.hip's window blur uses the same scheme).
+// v_mfma_f32_32x32x16_bf16 contracts 16 elements in 8 passes where v_mfma_f32_32x32x2_f32 needs 8 x 16 passes, so the six
+// products cost 3/8 of the f32 instruction's matrix-pipe time -- and these GEMMs (19 456 rows = 152 workgroups, one
+// wave per SIMD, K up to 1 024) are bound by exactly that.  The split happens ONCE per element, on the way into LDS.
+// LDS image of an operand panel (32 deep), per bf16 plane, follows the operand's unit stride in memory so that the
+// staging stores are packed pairs either way:
+//   KC (k contiguous in memory):  [row][k], 80-byte rows   -> an MFMA operand (8 consecutive k) is one ds_read_b128
+//   MC (m / n contiguous):        [k][row], 320 / 192-byte rows -> two ds_read_b64_tr_b16 (the transposing LDS read)
+constexpr int X3_BK = 32;
+constexpr int X3_KC_RS = 80;                      // bytes per row of a KC plane (16 rows x 16 B cover the 64 banks)
+constexpr int X3_A_MC_RS = 320, X3_B_MC_RS = 192; // bytes per k-row of an MC plane (4 rows x 64 B cover the 64 banks)
+constexpr int X3_A_PLANE = 10240, X3_B_PLANE = 6144;
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_g;
+
+__device__ __forceinline__ void x3_split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const uint32_t a = __builtin_bit_cast(uint32_t, x0), b = __builtin_bit_cast(uint32_t, x1);
+  h = __builtin_amdgcn_perm(b, a, 0x07060302u);                 // (b & 0xffff0000) | (a >> 16)
+  const float ra = x0 - __builtin_bit_cast(float, a & 0xffff0000u);
+  const float rb = x1 - __builtin_bit_cast(float, b & 0xffff0000u);
+  const uint32_t a1 = __builtin_bit_cast(uint32_t, ra), b1 = __builtin_bit_cast(uint32_t, rb);
+  m = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+  const float sa = ra - __builtin_bit_cast(float, a1 & 0xffff0000u);
+  const float sb = rb - __builtin_bit_cast(float, b1 & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[3 * X3_A_PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * X3_B_PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int z = blockIdx.z / g.k_splits, split = blockIdx.z % g.k_splits;
+  const int z1 = z / g.batch2, z2 = z % g.batch2;
+  const float* __restrict__ A = g.a + z1 * g.a_bs1 + z2 * g.a_bs2;
+  const float* __restrict__ B = g.b + z1 * g.b_bs1 + z2 * g.b_bs2;
+  float* __restrict__ C = g.c + z1 * g.c_bs1 + z2 * g.c_bs2 + split * g.c_ss;
+  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+  const int kbeg = split * g.k_chunk;
+  const int kend = kbeg + g.k_chunk < g.k ? kbeg + g.k_chunk : g.k;
+
+  // staging: a thread moves PAIRS adjacent along the operand's unit stride (8 pairs of A, 4 of B per 32-deep panel)
+  int a_m[8], a_k[8], a_w[8], b_n[4], b_k[4], b_w[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + 256 * i;
+    if (A_KC) { a_k[i] = 2 * (idx % 16); a_m[i] = idx / 16; a_w[i] = a_m[i] * X3_KC_RS + a_k[i] * 2; }
+    else      { a_m[i] = 2 * (idx % 64); a_k[i] = idx / 64; a_w[i] = a_k[i] * X3_A_MC_RS + a_m[i] * 2; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    if (B_KC) { b_k[i] = 2 * (idx % 16); b_n[i] = idx / 16; b_w[i] = b_n[i] * X3_KC_RS + b_k[i] * 2; }
+    else      { b_n[i] = 2 * (idx % 32); b_k[i] = idx / 32; b_w[i] = b_k[i] * X3_B_MC_RS + b_n[i] * 2; }
+  }
+  float ar[8][2], br[4][2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int mm = m0 + a_m[i] + (A_KC ? 0 : e), kk = k0 + a_k[i] + (A_KC ? e : 0);
+        ar[i][e] = (mm < g.m && kk < kend) ? A[mm * g.a_rs + kk * g.a_cs] : 0.f;
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int nn = n0 + b_n[i] + (B_KC ? 0 : e), kk = k0 + b_k[i] + (B_KC ? e : 0);
+        br[i][e] = (nn < g.n && kk < kend) ? B[kk * g.b_rs + nn * g.b_cs] : 0.f;
+      }
+  };
+  v16f_t acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+
+  // operand read offsets (bytes inside a plane) for K-step ks = 0 of the panel; ks = 1 adds 32 B (KC) / 16 rows (MC)
+  const int row = lane & 31, half = lane >> 5;
+  const int grp = lane >> 4, qi = (lane & 15) >> 2, pi = lane & 3, cb = 16 * (grp & 1);
+  int a_rd[2], b_rd[2][2];
+  if (A_KC) {
+    a_rd[0] = (wave * 32 + row) * X3_KC_RS + 16 * half;
+    a_rd[1] = 0;
+  } else {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) a_rd[s2] = (8 * half + 4 * s2 + qi) * X3_A_MC_RS + (wave * 32 + cb + 4 * pi) * 2;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (B_KC) {
+      b_rd[t][0] = (32 * t + row) * X3_KC_RS + 16 * half;
+      b_rd[t][1] = 0;
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) b_rd[t][s2] = (8 * half + 4 * s2 + qi) * X3_B_MC_RS + (32 * t + cb + 4 * pi) * 2;
+    }
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8g;
+  auto fetch = [&](const unsigned char* plane, const int (&rd)[2], bool kc, int ks, int mc_rs) -> bf16x8 {
+    if (kc) return *reinterpret_cast<const bf16x8*>(plane + rd[0] + 32 * ks);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_g*)(plane + rd[0] + 16 * ks * mc_rs));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_g*)(plane + rd[1] + 16 * ks * mc_rs));
+    const s16x8g v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  if (kbeg < kend) load(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += X3_BK) {
+    __syncthreads();  // previous panel fully consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t h, m, l;
+      x3_split_pair(ar[i][0], ar[i][1], h, m, l);
+      *reinterpret_cast<uint32_t*>(As + a_w[i]) = h;
+      *reinterpret_cast<uint32_t*>(As + X3_A_PLANE + a_w[i]) = m;
+      *reinterpret_cast<uint32_t*>(As + 2 * X3_A_PLANE + a_w[i]) = l;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t h, m, l;
+      x3_split_pair(br[i][0], br[i][1], h, m, l);
+      *reinterpret_cast<uint32_t*>(Bs + b_w[i]) = h;
+      *reinterpret_cast<uint32_t*>(Bs + X3_B_PLANE + b_w[i]) = m;
+      *reinterpret_cast<uint32_t*>(Bs + 2 * X3_B_PLANE + b_w[i]) = l;
+    }
+    __syncthreads();
+    if (k0 + X3_BK < kend) load(k0 + X3_BK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a3[3], b3[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a3[p] = fetch(As + p * X3_A_PLANE, a_rd, A_KC, ks, X3_A_MC_RS);
+        b3[0][p] = fetch(Bs + p * X3_B_PLANE, b_rd[0], B_KC, ks, X3_B_MC_RS);
+        b3[1][p] = fetch(Bs + p * X3_B_PLANE, b_rd[1], B_KC, ks, X3_B_MC_RS);
+      }
+      // smallest partial products first: mm, lh, hl, mh, hm, hh
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1][2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1][0], acc1, 0, 0, 0);
+    }
+  }
+  // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int col = lane & 31;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int nn = n0 + 32 * t + col;
+    if (nn >= g.n) continue;
+    const float bv = g.bias ? g.bias[nn] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (mm < g.m) {
+        float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        C[(long long)mm * g.ldc + nn] = v;
+      }
+    }
+  }
+}
+
 // out[i] = sum over s of slabs[s * stride + offset + i], i < n.  Workgroup = 32 columns x 8 slab groups: thread (c, g)
 // adds slabs g, g+8, ... in index order, the 8 group sums are then added in group order -- a fixed order, 8-way parallel.
+// accumulate != 0: out[i] += the sum (a tied weight's gradient contributions added in arrival order, as autograd would).
 __global__ __launch_bounds__(256) void sum_slabs_f32(const float* __restrict__ slabs, float* __restrict__ out, long long n,
-                                                     int n_slabs, long long stride, long long offset) {
+                                                     int n_slabs, long long stride, long long offset, int accumulate) {
   __shared__ float red[8][32];
   const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const long long i = (long long)blockIdx.x * 32 + c;
@@ -128,13 +302,38 @@ __global__ __launch_bounds__(256) void sum_slabs_f32(const float* __restrict__ s
     for (int k = grp; k < n_slabs; k += 8) s += slabs[(size_t)k * stride + offset + i];
   red[grp][c] = s;
   __syncthreads();
-  if (grp == 0 && i < n)
-    out[i] = ((((((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]) + red[4][c]) + red[5][c]) + red[6][c]) + red[7][c];
+  if (grp == 0 && i < n) {
+    const float t = ((((((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]) + red[4][c]) + red[5][c]) + red[6][c]) + red[7][c];
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
-                      hipStream_t st) {
-  hipLaunchKernelGGL(sum_slabs_f32, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slabs, out, n, n_slabs, stride, offset);
+                      hipStream_t st, int accumulate) {
+  hipLaunchKernelGGL(sum_slabs_f32, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, slabs, out, n, n_slabs, stride, offset,
+                     accumulate);
+}
+
+// partial column sums of x [rows][cols]: block (column block of 64, row chunk) -> part[chunk][cols]; thread = (column, row lane)
+__global__ __launch_bounds__(256) void colsum_partial_f32(const float* __restrict__ x, float* __restrict__ part, long long rows,
+                                                          int cols, long long rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c;
+  const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+  const long long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < cols) {
+    long long r = r0 + rl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += x[r * cols + col];
+      s1 += x[(r + 4) * cols + col];
+    }
+    if (r < r1) s0 += x[r * cols + col];
+  }
+  red[rl][c] = s0 + s1;
+  __syncthreads();
+  if (rl == 0 && col < cols) part[(long long)blockIdx.y * cols + col] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
 }
 
 }  // namespace pv
@@ -162,14 +361,52 @@ int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, con
   g.relu = relu ? 1 : 0;
   dim3 grid((unsigned)((d->n + G_BN - 1) / G_BN), (unsigned)((d->m + G_BM - 1) / G_BM), (unsigned)zs);
   PV_REQUIRE(grid.y <= 65535, PV_ESIZE, "pv_gemm_f32: m too large for one launch");
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), g);
+  // default: the bf16 x 3 form (f32 accuracy at 3/8 of the matrix-pipe time); PV_GEMM_EXACT_F32=1 keeps the products on the
+  // f32 matrix instruction (bit-exact f32 products)
+  static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;
+  if (exact_f32) {
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), g);
+  } else {
+    const bool a_kc = d->a_cs == 1 && d->a_rs != 1;
+    const bool b_kc = d->b_cs != 1;
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), g);
+    else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), g);
+    else if (b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, as_stream(stream), g);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), g);
+  }
   return check_launch("pv_gemm_f32");
 }
 
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream) {
   PV_REQUIRE(slabs && out && n > 0 && n_slabs > 0, PV_EINVAL, "pv_sum_slabs_f32: bad arguments");
-  launch_sum_slabs(slabs, out, (long long)n, n_slabs, (long long)n, 0, as_stream(stream));
+  launch_sum_slabs(slabs, out, (long long)n, n_slabs, (long long)n, 0, as_stream(stream), 0);
   return check_launch("pv_sum_slabs_f32");
+}
+
+int pv_sum_slabs_acc_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, int32_t accumulate, void* stream) {
+  PV_REQUIRE(slabs && out && n > 0 && n_slabs > 0, PV_EINVAL, "pv_sum_slabs_acc_f32: bad arguments");
+  launch_sum_slabs(slabs, out, (long long)n, n_slabs, (long long)n, 0, as_stream(stream), accumulate);
+  return check_launch("pv_sum_slabs_acc_f32");
+}
+
+size_t pv_colsum_workspace_floats(int64_t rows, int32_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  long long chunks = (rows + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  return (size_t)chunks * cols;
+}
+
+int pv_colsum_f32(const float* x, float* out, int64_t rows, int32_t cols, float* workspace, int32_t accumulate, void* stream) {
+  PV_REQUIRE(x && out && workspace && rows > 0 && cols > 0, PV_EINVAL, "pv_colsum_f32: bad arguments");
+  long long chunks = (rows + 255) / 256;
+  if (chunks > 64) chunks = 64;
+  const long long per = (rows + chunks - 1) / chunks;
+  chunks = (rows + per - 1) / per;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_partial_f32, dim3((unsigned)((cols + 63) / 64), (unsigned)chunks), dim3(256), 0, st, x, workspace,
+                     (long long)rows, cols, per);
+  launch_sum_slabs(workspace, out, cols, (int)chunks, cols, 0, st, accumulate);
+  return check_launch("pv_colsum_f32");
 }
 
 }  // extern "C"

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void mean_axis1_bwd_f32(const float* __restric
 }
 
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
-                      hipStream_t st);   // gemm_f32.hip
+                      hipStream_t st, int accumulate = 0);   // gemm_f32.hip
 
 static int ln_blocks(long long rows, int* rows_per_block) {
   long long nb = (rows + 3) / 4;          // at least one row per wave
@@ -271,7 +271,8 @@ int pv_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes) {
 }
 
 int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, float* dx,
-                         float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, void* stream) {
+                         float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, int32_t accumulate,
+                         void* stream) {
   PV_REQUIRE(x && w && dy && mean && rstd && dw && db, PV_EINVAL, "pv_layernorm_bwd_f32: null pointer");
   PV_REQUIRE(rows > 0 && d > 0 && d <= 64 * LN_MAXPL, PV_ESIZE, "pv_layernorm_bwd_f32: d=%d must be in 1..%d", d, 64 * LN_MAXPL);
   int per;
@@ -281,8 +282,12 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
   float* part = (float*)ws;
   hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per);
   // part is [nb][2][d]: summed over blocks in index order, straight into dw and db
-  launch_sum_slabs(part, dw, d, nb, 2 * d, 0, st);
-  launch_sum_slabs(part, db, d, nb, 2 * d, d, st);
+  if (db == dw + d) {   // one [2 d] vector: one launch
+    launch_sum_slabs(part, dw, 2 * d, nb, 2 * d, 0, st, accumulate);
+  } else {
+    launch_sum_slabs(part, dw, d, nb, 2 * d, 0, st, accumulate);
+    launch_sum_slabs(part, db, d, nb, 2 * d, d, st, accumulate);
+  }
   return check_launch("pv_layernorm_bwd_f32");
 }
 

@@ -668,22 +668,40 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
-def gemm_splitk(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, N] = A[M, K] @ B[K, N] for small M, N and a huge K (weight gradients): K is cut over workgroups, the partial
-    products are summed in index order (deterministic)."""
-    _require_device(a, b)
+    products are summed in index order (deterministic).  accumulate_into: a contiguous [M, N] tensor that receives
+    `+= C` (the slab sum adds into it) and is returned."""
+    _require_device(a, b, accumulate_into)
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
         raise ValueError(f"gemm_splitk: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
     m, k, n = a.shape[0], a.shape[1], b.shape[1]
+    if accumulate_into is not None and (tuple(accumulate_into.shape) != (m, n) or not accumulate_into.is_contiguous()):
+        raise ValueError("gemm_splitk: accumulate_into must be a contiguous [M, N] tensor")
     tiles = ((m + 127) // 128) * ((n + 63) // 64)
     splits = max(1, min((1024 + tiles - 1) // tiles, (k + 255) // 256, 4096))
-    if splits == 1:
+    if splits == 1 and accumulate_into is None:
         return gemm(a, b)
-    slabs = torch.empty((splits, m, n), dtype=torch.float32, device=a.device)
+    slabs = _workspace("gemm_splitk", splits * m * n * 4, a.device)
     d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, splits, m * n)
     check(get_lib().pv_gemm_f32(ptr(a), ptr(b), None, ptr(slabs), ctypes.byref(d), 0, current_stream_ptr()), "pv_gemm_f32")
-    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    check(get_lib().pv_sum_slabs_f32(ptr(slabs), ptr(out), m * n, splits, current_stream_ptr()), "pv_sum_slabs_f32")
+    out = accumulate_into if accumulate_into is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
+    check(get_lib().pv_sum_slabs_acc_f32(ptr(slabs), ptr(out), m * n, splits, int(accumulate_into is not None),
+                                         current_stream_ptr()), "pv_sum_slabs_acc_f32")
+    return out
+
+
+def colsum(x: torch.Tensor, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Column sums of a contiguous [rows, cols] tensor (the bias gradient of nn.Linear), chunk partials added in order."""
+    require_cuda(x, accumulate_into)
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise TypeError("colsum: a contiguous float32 [rows, cols] tensor is expected")
+    rows, cols = x.shape
+    n_ws = get_lib().pv_colsum_workspace_floats(rows, cols)
+    ws = _workspace("colsum", n_ws * 4, x.device)
+    out = accumulate_into if accumulate_into is not None else torch.empty(cols, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_colsum_f32(ptr(x), ptr(out), rows, cols, ptr(ws), int(accumulate_into is not None),
+                                  current_stream_ptr()), "pv_colsum_f32")
     return out
 
 
@@ -699,7 +717,9 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float 
     return y, mean, rstd
 
 
-def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True):
+def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True, accumulate_into=None):
+    """-> (dx | None, dw, db).  For d % 4 == 0, dw and db are the two halves of ONE [2 d] tensor (one reduction launch).
+    accumulate_into: a (dw, db) pair returned by an earlier call, which receives `+=` instead."""
     require_cuda(x, w, dy, mean, rstd)
     d = x.shape[-1]
     rows = x.numel() // d
@@ -707,10 +727,17 @@ def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True):
     check(get_lib().pv_layernorm_bwd_workspace_bytes(rows, d, ctypes.byref(nbytes)), "pv_layernorm_bwd_workspace_bytes")
     ws = _workspace("layernorm_bwd", nbytes.value, x.device)
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty(d, dtype=torch.float32, device=x.device)
-    db = torch.empty(d, dtype=torch.float32, device=x.device)
+    if accumulate_into is not None:
+        dw, db = accumulate_into
+    elif d % 4 == 0:     # halves of one buffer stay 16-byte aligned (the optimizer kernels require it)
+        dwdb = torch.empty(2 * d, dtype=torch.float32, device=x.device)
+        dw, db = dwdb[:d], dwdb[d:]
+    else:
+        dw = torch.empty(d, dtype=torch.float32, device=x.device)
+        db = torch.empty(d, dtype=torch.float32, device=x.device)
     check(get_lib().pv_layernorm_bwd_f32(ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), rows, d,
-                                         ptr(ws), nbytes.value, current_stream_ptr()), "pv_layernorm_bwd_f32")
+                                         ptr(ws), nbytes.value, int(accumulate_into is not None), current_stream_ptr()),
+          "pv_layernorm_bwd_f32")
     return dx, dw, db
 
 

@@ -6,15 +6,29 @@ import torch
 from . import hip_ops as K
 
 
-_ONES = {}
+# ---- gradients of weights that several layers share ---------------------------------------------------------------------
+# perceiver_pytorch's weight_tie_layers=True (predict_pv_yield/models/perceiver/perceiver.py:70-80) applies the same
+# nn.Linear / nn.LayerNorm up to 19 times per forward; autograd then sums the 19 gradient contributions with one add
+# kernel each.  Here the first contribution that arrives in a backward pass is handed to autograd as usual and KEPT; every
+# later one of the same pass is added into that very tensor by the kernel that produces it (same order of additions as
+# autograd's: arrival order) and autograd is told "no gradient" -- it still holds the first tensor, which now carries the sum.
+ACCUMULATE_TIED_GRADS = True
+_TIED = {}
 
 
-def _ones_row(n: int, device) -> torch.Tensor:
-    """Cached [1, n] row of ones (the bias gradient is ones @ dy)."""
-    key = (n, str(device))
-    if key not in _ONES:
-        _ONES[key] = torch.ones((1, n), dtype=torch.float32, device=device)
-    return _ONES[key]
+def _tied_slot(param: torch.Tensor):
+    """-> (key, buffer | None): the tensor this backward pass already handed out for `param`, if any."""
+    task = torch._C._current_graph_task_id()
+    key = (param.data_ptr(), param.numel())
+    if not ACCUMULATE_TIED_GRADS or task < 0:
+        return None, None
+    hit = _TIED.get(key)
+    return key, (hit[1] if hit is not None and hit[0] == task else None)
+
+
+def _tied_keep(key, grad: torch.Tensor):
+    if key is not None:
+        _TIED[key] = (torch._C._current_graph_task_id(), grad)
 
 
 class LinearRowsF32(torch.autograd.Function):
@@ -24,19 +38,30 @@ class LinearRowsF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         x2 = x.contiguous().view(-1, x.shape[-1])
         y = K.gemm(x2, weight.t(), bias=bias)
-        ctx.save_for_backward(x2, weight)
+        ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         return y.view(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight = ctx.saved_tensors
+        x2, weight, bias = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, weight.shape[0])
         dx = K.gemm(dy2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        dw = K.gemm_splitk(dy2.t(), x2)                                   # [out, rows] @ [rows, in]
+        key, acc = _tied_slot(weight)
+        if acc is not None:
+            K.gemm_splitk(dy2.t(), x2, accumulate_into=acc)                # [out, rows] @ [rows, in], += into the kept tensor
+            dw = None
+        else:
+            dw = K.gemm_splitk(dy2.t(), x2)
+            _tied_keep(key, dw)
         db = None
         if ctx.has_bias:
-            db = K.gemm_splitk(_ones_row(dy2.shape[0], dy2.device), dy2).view(-1)     # column sums on the matrix cores
+            key, acc = _tied_slot(bias)
+            if acc is not None:
+                K.colsum(dy2, accumulate_into=acc)
+            else:
+                db = K.colsum(dy2)
+                _tied_keep(key, db)
         return dx, dw, db
 
 
@@ -161,7 +186,13 @@ class LayerNormF32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
+        key, acc = _tied_slot(weight)      # (dw | db) live in one [2 d] tensor, keyed by the weight
+        if acc is not None:
+            dx, _, _ = K.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd, need_dx=ctx.needs_input_grad[0],
+                                       accumulate_into=acc)
+            return dx, None, None, None
         dx, dw, db = K.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd, need_dx=ctx.needs_input_grad[0])
+        _tied_keep(key, (dw, db))
         return dx, dw, db, None
 
 

@@ -11,12 +11,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--cpu", action="store_true")
+ap.add_argument("--operands", default="bf16", choices=["f32", "bf16"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 kw = dict(history_minutes=60, forecast_minutes=30, batch_size=args.batch, num_latents=128, latent_dim=64, embedding_dem=16,
           output_variable="gsp_yield")
 torch.manual_seed(0)
-model = PerceiverModel(**kw).to(dev)
+model = PerceiverModel(**kw, operand_dtype=args.operands).to(dev)
 cfg = FakeDataConfiguration(batch_size=args.batch, history_minutes=60, forecast_minutes=30, satellite_image_size_pixels=64,
                             nwp_image_size_pixels=64)
 batch = make_fake_batch(cfg, torch.Generator().manual_seed(1)).to(dev)
