@@ -406,8 +406,9 @@ int pv_attention_bwd_f32(const float* q, const float* k, const float* v, const f
  * softmax): q, k, v, dO are rounded to bf16 on their way into the products, the probabilities and dS when they become
  * operands.  replaces: the same einsums as run under Lightning `precision=16`
  * (experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294).  Same descriptor, workspace and layouts. */
+size_t pv_attention_fwd_workspace_floats(const pv_attention_desc* d);   /* key-split partials of the bf16 forward; 0 = none */
 int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
-                          void* stream);
+                          float* workspace, void* stream);   /* workspace NULL: no key split */
 int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
                           float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream);
 

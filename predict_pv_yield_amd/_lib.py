@@ -143,7 +143,8 @@ SIGNATURES = {
     "pv_colsum_workspace_floats": [c_i64, c_i32],
     "pv_attention_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
-    "pv_attention_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
+    "pv_attention_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp, c_vp],
+    "pv_attention_fwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_attention_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
@@ -164,7 +165,8 @@ SIGNATURES = {
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }
 _RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz,
-             "pv_attention_bwd_workspace_floats": c_sz, "pv_colsum_workspace_floats": c_sz}
+             "pv_attention_bwd_workspace_floats": c_sz, "pv_colsum_workspace_floats": c_sz,
+             "pv_attention_fwd_workspace_floats": c_sz}
 
 
 def build_library(verbose: bool = False) -> str:

@@ -50,15 +50,24 @@ __device__ __forceinline__ bf16x8 att_load8(const float* p, bool ok) {   // 8 co
   return att_pack8(x);
 }
 
+// n_splits > 1: blockIdx.x = split * n_qtiles + query tile; a workgroup walks the keys [split * keys_per_split, ...) only
+// and leaves its UNNORMALISED accumulator, running maximum and running sum in `part` ([split][b][h][query][64 + 2]);
+// attn_fwd_combine merges the splits in split order.  (152 (batch, head) groups of one query tile each leave 40 % of
+// the chip idle and one wave per SIMD: with 4 splits two or three workgroups share a CU and overlap each other's softmax.)
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ o,
-                                                      float* __restrict__ lse, AttnGeomB g) {
+                                                      float* __restrict__ lse, AttnGeomB g, int n_splits, int keys_per_split,
+                                                      float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[BTJ * B_KLD];   // [key][d]
   __shared__ __attribute__((aligned(16))) uint16_t Vt[BD * B_TLD];    // [d][att_pos(key)]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int i = blockIdx.x * 128 + wave * 32 + col;           // this lane's query
+  const int n_qt = (g.n_q + 127) / 128;
+  const int split = blockIdx.x / n_qt, qt = blockIdx.x - split * n_qt;
+  const int key_lo = split * keys_per_split;
+  const int key_hi = key_lo + keys_per_split < g.n_k ? key_lo + keys_per_split : g.n_k;
+  const int i = qt * 128 + wave * 32 + col;           // this lane's query
   const float* qb = q + b * g.q_bs + h * BD;
   const float* kb = k + b * g.k_bs + h * BD;
   const float* vb = v + b * g.k_bs + h * BD;
@@ -78,15 +87,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
   f32x4 k0, k1, v0, v1;
   auto load_tile = [&](int j0) {
     const int j = j0 + st_row;
-    const bool ok = j < g.n_k;
+    const bool ok = j < key_hi;
     const float* kp = kb + (long long)(ok ? j : 0) * g.k_rs + st_col;
     const float* vp = vb + (long long)(ok ? j : 0) * g.k_rs + st_col;
     k0 = *reinterpret_cast<const f32x4*>(kp); k1 = *reinterpret_cast<const f32x4*>(kp + 4);
     v0 = *reinterpret_cast<const f32x4*>(vp); v1 = *reinterpret_cast<const f32x4*>(vp + 4);
     if (!ok) { k0 = k1 = v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   };
-  load_tile(0);
-  for (int j0 = 0; j0 < g.n_k; j0 += BTJ) {
+  load_tile(key_lo);
+  for (int j0 = key_lo; j0 < key_hi; j0 += BTJ) {
     __syncthreads();
     {
       const float kx[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       for (int e = 0; e < 8; ++e) Vt[(st_col + e) * B_TLD + st_pos] = f32_to_bf16_bits(vx[e]);
     }
     __syncthreads();
-    if (j0 + BTJ < g.n_k) load_tile(j0 + BTJ);
+    if (j0 + BTJ < key_hi) load_tile(j0 + BTJ);
     // S^T tile: rows = keys, column = this lane's query
     v16f_b s;
 #pragma unroll
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
     float m_tile = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = j0 + att_acc_row(r, half) < g.n_k;
+      const bool ok = j0 + att_acc_row(r, half) < key_hi;
       s[r] = ok ? s[r] * g.scale : -INFINITY;
       m_tile = fmaxf(m_tile, s[r]);
     }
@@ -139,6 +148,19 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
           *reinterpret_cast<const bf16x8*>(Vt + (32 + col) * B_TLD + 16 * st + 8 * half), pb, acc1, 0, 0, 0);
     }
   }
+  if (n_splits > 1) {
+    if (i < g.n_q) {
+      float* pb = part + ((((long long)split * gridDim.z + b) * g.heads + h) * g.n_q + i) * (BD + 2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = att_acc_row(r, half);
+        pb[d] = acc0[r];
+        pb[32 + d] = acc1[r];
+      }
+      if (half == 0) pb[BD] = m_run, pb[BD + 1] = l_run;
+    }
+    return;
+  }
   if (i < g.n_q) {
     const float inv = 1.0f / l_run;
     float* ob = o + b * g.q_bs + (long long)i * g.q_rs + h * BD;
@@ -150,6 +172,29 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
     }
     if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run + logf(l_run);
   }
+}
+
+// merges the key splits of attn_fwd_bf16: thread = (row (b, h, query), d); splits in index order
+__global__ __launch_bounds__(256) void attn_fwd_combine(const float* __restrict__ part, float* __restrict__ o,
+                                                         float* __restrict__ lse, AttnGeomB g, int n_splits, long long rows,
+                                                         int batch) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int d = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int i = (int)(row % g.n_q);
+  const long long bh = row / g.n_q;
+  const int h = (int)(bh % g.heads), b = (int)(bh / g.heads);
+  float m = -INFINITY;
+  for (int s2 = 0; s2 < n_splits; ++s2) m = fmaxf(m, part[((long long)s2 * rows + row) * (BD + 2) + BD]);
+  float l = 0.f, acc = 0.f;
+  for (int s2 = 0; s2 < n_splits; ++s2) {
+    const float* pb = part + ((long long)s2 * rows + row) * (BD + 2);
+    const float w = expf(pb[BD] - m);        // a split without keys in range carries m = -inf, l = 0: weight 0
+    l += pb[BD + 1] * w;
+    acc += pb[d] * w;
+  }
+  o[b * g.q_bs + (long long)i * g.q_rs + h * BD + d] = acc / l;
+  if (d == 0) lse[row] = m + logf(l);
 }
 
 // Backward for n_q <= 128: one workgroup per (b, h, key range).  Q and dO of all (<= 128) queries sit in LDS as bf16, both
@@ -362,16 +407,43 @@ static int attn_geom_b(const pv_attention_desc* d, AttnGeomB* g, const char* who
   return PV_OK;
 }
 
+static int attn_fwd_splits(const pv_attention_desc* d, int* keys_per_split) {
+  const long long groups = (long long)d->batch * d->heads * ((d->n_q + 127) / 128);
+  const int n_tiles = (d->n_k + BTJ - 1) / BTJ;
+  int splits = (int)((768 + groups - 1) / groups);       // aim at three workgroups per CU
+  if (splits > n_tiles / 16) splits = n_tiles / 16;       // at least 16 key tiles (512 keys) per workgroup
+  if (splits < 1) splits = 1;
+  const int per = (n_tiles + splits - 1) / splits;
+  *keys_per_split = per * BTJ;
+  return (n_tiles + per - 1) / per;
+}
+
+size_t pv_attention_fwd_workspace_floats(const pv_attention_desc* d) {
+  if (!d || d->batch <= 0 || d->heads <= 0 || d->n_q <= 0 || d->n_k <= 0) return 0;
+  int per;
+  const int nsp = attn_fwd_splits(d, &per);
+  return nsp > 1 ? (size_t)nsp * d->batch * d->heads * d->n_q * (BD + 2) : 0;
+}
+
 int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
-                          void* stream) {
+                          float* workspace, void* stream) {
   AttnGeomB g;
   int rc = attn_geom_b(d, &g, "pv_attention_fwd_bf16");
   if (rc) return rc;
   PV_REQUIRE(q && k && v && o && lse, PV_EINVAL, "pv_attention_fwd_bf16: null pointer");
   PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0), PV_EINVAL,
              "pv_attention_fwd_bf16: q / k / v must be 16-byte aligned");
-  dim3 grid((unsigned)((d->n_q + 127) / 128), (unsigned)d->heads, (unsigned)d->batch);
-  hipLaunchKernelGGL(attn_fwd_bf16, grid, dim3(256), 0, as_stream(stream), q, k, v, o, lse, g);
+  int per = d->n_k;
+  const int nsp = workspace ? attn_fwd_splits(d, &per) : 1;     // no workspace: one workgroup walks all keys
+  const int n_qt = (d->n_q + 127) / 128;
+  hipStream_t st = as_stream(stream);
+  dim3 grid((unsigned)(n_qt * nsp), (unsigned)d->heads, (unsigned)d->batch);
+  hipLaunchKernelGGL(attn_fwd_bf16, grid, dim3(256), 0, st, q, k, v, o, lse, g, nsp, nsp > 1 ? per : d->n_k, workspace);
+  if (nsp > 1) {
+    const long long rows = (long long)d->batch * d->heads * d->n_q;
+    hipLaunchKernelGGL(attn_fwd_combine, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)workspace, o, lse, g,
+                       nsp, rows, d->batch);
+  }
   return check_launch("pv_attention_fwd_bf16");
 }
 
@@ -390,7 +462,10 @@ int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const 
   // key splits exactly as pv_attention_bwd_f32 / pv_attention_bwd_workspace_floats lay them out
   const long long groups = (long long)d->batch * d->heads;
   const int n_tiles = (d->n_k + BTJ - 1) / BTJ;
-  int splits = (int)((1024 + groups - 1) / groups);
+  // whole rounds of one workgroup per CU (102 KB of LDS each): at most 3 x 256 workgroups -- every workgroup pays the
+  // staging of Q / dO in two layouts and the dQ reduction once, so fewer, longer key ranges win over a ragged fifth round.
+  // Never more splits than pv_attention_bwd_workspace_floats (attention_f32.hip) provides for.
+  int splits = (int)(768 / groups);
   if (splits > n_tiles / 8) splits = n_tiles / 8;
   if (splits < 1) splits = 1;
   const int per = ((n_tiles + splits - 1) / splits + 3) / 4 * 4;

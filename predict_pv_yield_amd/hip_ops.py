@@ -830,9 +830,14 @@ def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, b
     out = torch.empty_like(q)
     lse = torch.empty((b, heads, n_q), dtype=torch.float32, device=q.device)
     v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
-    fn = get_lib().pv_attention_fwd_bf16 if bf16_operands else get_lib().pv_attention_fwd_f32
-    check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
-          "pv_attention_fwd_bf16" if bf16_operands else "pv_attention_fwd_f32")
+    if bf16_operands:
+        n_ws = get_lib().pv_attention_fwd_workspace_floats(ctypes.byref(d))
+        ws = _workspace("attention_fwd", n_ws * 4, q.device) if n_ws else None
+        check(get_lib().pv_attention_fwd_bf16(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), ptr(ws),
+                                              current_stream_ptr()), "pv_attention_fwd_bf16")
+    else:
+        check(get_lib().pv_attention_fwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
+              "pv_attention_fwd_f32")
     return out, lse
 
 

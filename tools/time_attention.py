@@ -20,8 +20,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for name, b, nq, nk, heads in [("PerceiverModel cross (B=8, 64x64 context)", 8, 128, 4096, 1),
-                               ("PerceiverModel latent self-attention", 8, 128, 128, 8),
+for name, b, nq, nk, heads in [("PerceiverModel cross (8 x 19 frames, 64x64 context)", 152, 128, 4096, 1),
                                ("exp003 cross (8 x 19 images, 128x128 context)", 152, 128, 16384, 1),
                                ("exp003 latent self-attention", 152, 128, 128, 8)]:
     q = torch.randn(b, nq, heads * 64, device=dev)
