@@ -257,6 +257,26 @@ def measure_config3(dev, b, history_minutes):
     d = (time.perf_counter() - t0) / n
     out["joined_train_step"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1),
                                 "workload": "advection pipeline + conv3d train step (fwd + NMAE + bwd + Adam) per batch"}
+    # the same work as a two-stage pipeline: optical_flow.AdvectingLoader advects batch i+1 on a side stream under the
+    # train step of batch i
+    raw2 = (torch.rand(raw.shape, device=dev) * 1023).to(torch.int16)
+    pv = batch["pv"]
+
+    def epoch(k):
+        for bt in of.AdvectingLoader(({"satellite": {"data": raw if i & 1 else raw2}, "pv": pv} for i in range(k)), n_future):
+            opt.zero_grad(set_to_none=True)
+            model.training_step(bt, 0).backward()
+            opt.step()
+
+    epoch(6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    epoch(n)
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / n
+    out["joined_train_step_pipelined"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1),
+                                          "workload": "the same, advection of batch i+1 on a side HIP stream under the train "
+                                                      "step of batch i (optical_flow.AdvectingLoader)"}
     del model, opt
     return out
 

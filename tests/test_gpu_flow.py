@@ -231,3 +231,34 @@ def test_errors_are_loud(device):
     with pytest.raises(RuntimeError):
         K.farneback_pairs(torch.zeros((1, 64, 64), dtype=torch.uint8, device=device),
                           torch.zeros((1, 64, 64), dtype=torch.uint8, device=device), flags=0)
+
+
+@pytest.mark.gpu
+def test_advecting_loader_matches_inline_pipeline(device):
+    """optical_flow.AdvectingLoader (advection one batch ahead on a side stream) hands out exactly what the inline call
+    computes, for every batch and in order, and Model(future_frames="optical_flow") consumes the tagged tensor as is."""
+    from predict_pv_yield_amd import optical_flow as of
+    g = torch.Generator(device=device).manual_seed(7)
+    raws = [(torch.rand(2, 12, 11, 64, 64, generator=g, device=device) * 1023).to(torch.int16) for _ in range(3)]
+    batches = [{"satellite": {"data": r}, "tag": i} for i, r in enumerate(raws)]
+    want = [of.advect_future_frames(r, 6) for r in raws]
+    got = list(of.AdvectingLoader(batches, n_future=6))
+    assert [b["tag"] for b in got] == [0, 1, 2]
+    torch.cuda.synchronize()
+    for w, b in zip(want, got):
+        x = b["satellite"]["data"]
+        assert getattr(x, "_pv_advected", False) and x.shape == w.shape
+        assert torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(w, nan=-7.0))
+    assert batches[0]["satellite"]["data"].dtype == torch.int16          # the caller's batches are not modified
+    assert list(of.AdvectingLoader([], n_future=6)) == []
+
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    torch.manual_seed(0)
+    model = Model(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+                  conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+                  fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16",
+                  future_frames="optical_flow").to(device)
+    with torch.no_grad():
+        y_inline = model({"satellite": {"data": raws[1]}, "pv": {"pv_yield": torch.rand(2, 18, 128, device=device)}})
+        y_loader = model({"satellite": {"data": got[1]["satellite"]["data"]}, "pv": {"pv_yield": torch.rand(2, 18, 128, device=device)}})
+    assert torch.equal(y_inline, y_loader)
