@@ -103,6 +103,155 @@ __global__ __launch_bounds__(256) void layernorm_bwd_f32(const float* __restrict
   }
 }
 
+// ---- LayerNorm of SHORT rows (d <= 64, d % 8 in {2, 4, 6}): one THREAD per row, rows staged through LDS -------------------
+// The wave-per-row kernels above spend ~70 instructions on a 152-byte row (d = 38: the Perceiver's context of 11 + 27
+// channels, 2.5 M rows per step in experiments/003) and ran at 1.1 TB/s.  Here a workgroup copies 256 consecutive rows
+// (one contiguous 256 d-float stretch) into LDS with coalesced 16-byte loads, every lane then owns one row: it reads it
+// with 8-byte LDS loads (row pitch d words with d/2 odd or d/4 odd: the 32 lanes of a read group fall on distinct bank
+// pairs), does the whole row arithmetic alone, writes the result back in place, and the stretch leaves with coalesced
+// 16-byte stores.  gamma / beta are wave-uniform (scalar loads).  The backward accumulates d gamma / d beta per lane over the
+// rows it walks and reduces them once per workgroup through LDS, in a fixed order.
+template <int NT>
+__device__ __forceinline__ void ln_stage_in(float* lds, const float* __restrict__ src, long long n_valid) {
+  // lds[i] = src[i] for i < n_valid (<= NT * DMAX), 16 bytes per lane; src is 16-byte aligned
+  for (int i4 = threadIdx.x; i4 * 4 < n_valid; i4 += NT) {
+    if ((long long)i4 * 4 + 3 < n_valid) {
+      *reinterpret_cast<float4*>(lds + i4 * 4) = *reinterpret_cast<const float4*>(src + (long long)i4 * 4);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if ((long long)i4 * 4 + e < n_valid) lds[i4 * 4 + e] = src[(long long)i4 * 4 + e];
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void ln_stage_out(const float* lds, float* __restrict__ dst, long long n_valid) {
+  for (int i4 = threadIdx.x; i4 * 4 < n_valid; i4 += NT) {
+    if ((long long)i4 * 4 + 3 < n_valid) {
+      *reinterpret_cast<float4*>(dst + (long long)i4 * 4) = *reinterpret_cast<const float4*>(lds + i4 * 4);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if ((long long)i4 * 4 + e < n_valid) dst[(long long)i4 * 4 + e] = lds[i4 * 4 + e];
+    }
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void layernorm_fwd_rows_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y,
+                                                               float* __restrict__ mean, float* __restrict__ rstd,
+                                                               long long rows, int d, float eps) {
+  __shared__ __attribute__((aligned(16))) float buf[256 * DMAX];
+  const long long r0 = (long long)blockIdx.x * 256;
+  const long long n_valid = (rows - r0 < 256 ? rows - r0 : 256) * d;
+  ln_stage_in<256>(buf, x + r0 * d, n_valid);
+  __syncthreads();
+  const long long row = r0 + threadIdx.x;
+  if (row < rows) {
+    float2* rr = reinterpret_cast<float2*>(buf + threadIdx.x * d);
+    float2 v[DMAX / 2];
+#pragma unroll
+    for (int j = 0; j < DMAX / 2; ++j) v[j] = 2 * j < d ? rr[j] : make_float2(0.f, 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < DMAX / 2; ++j) s += v[j].x + v[j].y;
+    const float mu = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < DMAX / 2; ++j)
+      if (2 * j < d) {
+        const float t0 = v[j].x - mu, t1 = v[j].y - mu;
+        q += t0 * t0 + t1 * t1;
+      }
+    const float rs = 1.0f / sqrtf(q / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < DMAX / 2; ++j)
+      if (2 * j < d) rr[j] = make_float2((v[j].x - mu) * rs * w[2 * j] + b[2 * j], (v[j].y - mu) * rs * w[2 * j + 1] + b[2 * j + 1]);
+    mean[row] = mu, rstd[row] = rs;
+  }
+  __syncthreads();
+  ln_stage_out<256>(buf, y + r0 * d, n_valid);
+}
+
+constexpr int LNR_BT = 256;   // threads = rows per chunk of the backward (128 with four workgroups per CU and 4096 blocks measured slower: the per-block column reduction and the longer slab sum cost more than the overlap gains)
+template <int DMAX>
+__global__ __launch_bounds__(LNR_BT) void layernorm_bwd_rows_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ dy, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx,
+                                                               float* __restrict__ part /* [grid][2][d] */, long long rows, int d,
+                                                               int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float bxg[2 * LNR_BT * DMAX];   // x rows | dy rows; reused by the final reduction
+  float* bx = bxg;
+  float* bg = bxg + LNR_BT * DMAX;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2 dwp[DMAX / 2], dbp[DMAX / 2];
+#pragma unroll
+  for (int j = 0; j < DMAX / 2; ++j) dwp[j] = make_float2(0.f, 0.f), dbp[j] = make_float2(0.f, 0.f);
+  const long long rb0 = (long long)blockIdx.x * rows_per_block;
+  const long long rb1 = rb0 + rows_per_block < rows ? rb0 + rows_per_block : rows;
+  for (long long r0 = rb0; r0 < rb1; r0 += LNR_BT) {   // rows_per_block is a multiple of LNR_BT: chunks stay 16-byte aligned
+    const long long n_valid = (rb1 - r0 < LNR_BT ? rb1 - r0 : LNR_BT) * d;
+    __syncthreads();                                    // the previous chunk has left the buffers
+    ln_stage_in<LNR_BT>(bx, x + r0 * d, n_valid);
+    ln_stage_in<LNR_BT>(bg, dy + r0 * d, n_valid);
+    __syncthreads();
+    const long long row = r0 + threadIdx.x;
+    if (row < rb1) {
+      const float mu = mean[row], rs = rstd[row];
+      const float2* xr = reinterpret_cast<const float2*>(bx + threadIdx.x * d);
+      float2* gr = reinterpret_cast<float2*>(bg + threadIdx.x * d);
+      float2 xh[DMAX / 2], g[DMAX / 2];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < DMAX / 2; ++j) {
+        if (2 * j < d) {
+          const float2 xv = xr[j], dv = gr[j];
+          xh[j] = make_float2((xv.x - mu) * rs, (xv.y - mu) * rs);
+          g[j] = make_float2(dv.x * w[2 * j], dv.y * w[2 * j + 1]);
+          s1 += g[j].x + g[j].y;
+          s2 += g[j].x * xh[j].x + g[j].y * xh[j].y;
+          dwp[j].x += dv.x * xh[j].x, dwp[j].y += dv.y * xh[j].y;
+          dbp[j].x += dv.x, dbp[j].y += dv.y;
+        } else {
+          xh[j] = make_float2(0.f, 0.f), g[j] = make_float2(0.f, 0.f);
+        }
+      }
+      if (dx) {
+        const float m1 = s1 / (float)d, m2 = s2 / (float)d;
+#pragma unroll
+        for (int j = 0; j < DMAX / 2; ++j)
+          if (2 * j < d) gr[j] = make_float2(rs * (g[j].x - m1 - xh[j].x * m2), rs * (g[j].y - m1 - xh[j].y * m2));
+      }
+    }
+    if (dx) {
+      __syncthreads();
+      ln_stage_out<LNR_BT>(bg, dx + r0 * d, n_valid);
+    }
+  }
+  // column sums over the lanes: wave by wave through LDS (lane order inside a wave, then wave order: fixed)
+  float* red = bx;                                     // [2 * DMAX][65]
+  float tot = 0.f;
+  for (int wv = 0; wv < LNR_BT / 64; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int j = 0; j < DMAX / 2; ++j) {
+        red[(2 * j) * 65 + lane] = dwp[j].x, red[(2 * j + 1) * 65 + lane] = dwp[j].y;
+        red[(DMAX + 2 * j) * 65 + lane] = dbp[j].x, red[(DMAX + 2 * j + 1) * 65 + lane] = dbp[j].y;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * DMAX) {
+      float t = 0.f;
+      for (int l = 0; l < 64; ++l) t += red[threadIdx.x * 65 + l];
+      tot += t;
+    }
+  }
+  if (threadIdx.x < 2 * DMAX) {
+    const int which = threadIdx.x / DMAX, c = threadIdx.x - which * DMAX;
+    if (c < d) part[((size_t)blockIdx.x * 2 + which) * d + c] = tot;
+  }
+}
+
 // ---- softmax(scale * x) over rows of length len; one workgroup per row; len <= 4096 keeps the row in registers ----------
 constexpr int SM_PT = 16;
 
@@ -240,9 +389,10 @@ __global__ __launch_bounds__(256) void mean_axis1_bwd_f32(const float* __restric
 void launch_sum_slabs(const float* slabs, float* out, long long n, int n_slabs, long long stride, long long offset,
                       hipStream_t st, int accumulate = 0);   // gemm_f32.hip
 
+constexpr int LN_MAX_BLOCKS = 1024;
 static int ln_blocks(long long rows, int* rows_per_block) {
   long long nb = (rows + 3) / 4;          // at least one row per wave
-  if (nb > 1024) nb = 1024;
+  if (nb > LN_MAX_BLOCKS) nb = LN_MAX_BLOCKS;
   long long per = ((rows + nb - 1) / nb + 3) / 4 * 4;
   *rows_per_block = (int)per;
   return (int)((rows + per - 1) / per);
@@ -258,8 +408,16 @@ int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* 
                          int32_t d, float eps, void* stream) {
   PV_REQUIRE(x && w && b && y && mean && rstd, PV_EINVAL, "pv_layernorm_fwd_f32: null pointer");
   PV_REQUIRE(rows > 0 && d > 0 && d <= 64 * LN_MAXPL, PV_ESIZE, "pv_layernorm_fwd_f32: d=%d must be in 1..%d", d, 64 * LN_MAXPL);
-  hipLaunchKernelGGL(layernorm_fwd_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, w, b, y, mean, rstd,
-                     (long long)rows, d, eps);
+  const bool short_rows = d <= 64 && d % 2 == 0 && d % 8 != 0 && rows >= 65536 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  if (short_rows && d <= 40)
+    hipLaunchKernelGGL(layernorm_fwd_rows_f32<40>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, b,
+                       y, mean, rstd, (long long)rows, d, eps);
+  else if (short_rows)
+    hipLaunchKernelGGL(layernorm_fwd_rows_f32<64>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), x, w, b,
+                       y, mean, rstd, (long long)rows, d, eps);
+  else
+    hipLaunchKernelGGL(layernorm_fwd_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, w, b, y, mean,
+                       rstd, (long long)rows, d, eps);
   return check_launch("pv_layernorm_fwd_f32");
 }
 
@@ -280,13 +438,27 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
   PV_REQUIRE(ws && ws_bytes >= (size_t)nb * 2 * d * sizeof(float), PV_EINVAL, "pv_layernorm_bwd_f32: workspace too small");
   hipStream_t st = as_stream(stream);
   float* part = (float*)ws;
-  hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per);
+  const bool short_rows = d <= 64 && d % 2 == 0 && d % 8 != 0 && rows >= 65536 && ((uintptr_t)x % 16 == 0) &&
+                          ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
+  int nbl = nb;
+  if (short_rows) {   // one thread per row: whole multiples of 256 rows per block (never more blocks than ln_blocks sized)
+    const long long per_r = ((rows + LN_MAX_BLOCKS - 1) / LN_MAX_BLOCKS + LNR_BT - 1) / LNR_BT * LNR_BT;
+    nbl = (int)((rows + per_r - 1) / per_r);
+    if (d <= 40)
+      hipLaunchKernelGGL(layernorm_bwd_rows_f32<40>, dim3((unsigned)nbl), dim3(LNR_BT), 0, st, x, w, dy, mean, rstd, dx, part,
+                         (long long)rows, d, (int)per_r);
+    else
+      hipLaunchKernelGGL(layernorm_bwd_rows_f32<64>, dim3((unsigned)nbl), dim3(LNR_BT), 0, st, x, w, dy, mean, rstd, dx, part,
+                         (long long)rows, d, (int)per_r);
+  } else {
+    hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per);
+  }
   // part is [nb][2][d]: summed over blocks in index order, straight into dw and db
   if (db == dw + d) {   // one [2 d] vector: one launch
-    launch_sum_slabs(part, dw, 2 * d, nb, 2 * d, 0, st, accumulate);
+    launch_sum_slabs(part, dw, 2 * d, nbl, 2 * d, 0, st, accumulate);
   } else {
-    launch_sum_slabs(part, dw, d, nb, 2 * d, 0, st, accumulate);
-    launch_sum_slabs(part, db, d, nb, 2 * d, d, st, accumulate);
+    launch_sum_slabs(part, dw, d, nbl, 2 * d, 0, st, accumulate);
+    launch_sum_slabs(part, db, d, nbl, 2 * d, d, st, accumulate);
   }
   return check_launch("pv_layernorm_bwd_f32");
 }
