@@ -289,6 +289,134 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   }
 }
 
+// ---- "rows" form: C[M, N] = A[M, K] B[K, N] for a tall row-major A with a short K (<= 64) ------------------------------
+// The Perceiver's linears over 19 456 ... 2.5 M rows with 38 ... 128 input features.  The tiled kernel above walks such a
+// product as thousands of workgroups that each load one or two panels, synchronise, multiply for a microsecond and store:
+// a serial latency chain per workgroup (8-57 TFLOP/s, 2 TB/s on the memory-bound ones).  Here
+//   * the weights' [K x 64] column block is split and laid into LDS ONCE per (persistent) workgroup;
+//   * a wave owns blocks of 32 rows and fetches their A operand STRAIGHT INTO REGISTERS in MFMA layout (lane = (row, k half):
+//     8 consecutive k of its own row, 32 bytes) -- no LDS image of A, no barrier anywhere in the loop; the next block's
+//     rows are in flight while the current block is split, multiplied and stored.
+template <int KSTEPS, int VEC>
+__global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks) {
+  constexpr int KP = 16 * KSTEPS;
+  constexpr int BRS = 2 * KP + 16;                       // bytes per n-row of a B plane (16 rows x 16 B cover the 64 banks)
+  constexpr int BPLANE = G_BN * BRS;
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BPLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * G_BN;
+  const float* __restrict__ A = g.a;
+  const float* __restrict__ B = g.b;
+  float* __restrict__ C = g.c;
+  // ---- the weights' column block: pairs (k, k+1) of column n -> three packed bf16 words -------------------------------
+  for (int idx = tid; idx < G_BN * (KP / 2); idx += 256) {
+    const int n = idx / (KP / 2), kp = idx - n * (KP / 2);
+    const int nn = n0 + n, k = 2 * kp;
+    const float x0 = (nn < g.n && k < g.k) ? B[(long long)k * g.b_rs + (long long)nn * g.b_cs] : 0.f;
+    const float x1 = (nn < g.n && k + 1 < g.k) ? B[(long long)(k + 1) * g.b_rs + (long long)nn * g.b_cs] : 0.f;
+    uint32_t h, m, l;
+    x3_split_pair(x0, x1, h, m, l);
+    const int off = n * BRS + k * 2;
+    *reinterpret_cast<uint32_t*>(Bs + off) = h;
+    *reinterpret_cast<uint32_t*>(Bs + BPLANE + off) = m;
+    *reinterpret_cast<uint32_t*>(Bs + 2 * BPLANE + off) = l;
+  }
+  __syncthreads();
+
+  const int row = lane & 31, half = lane >> 5;
+  const int b_rd0 = row * BRS + 16 * half, b_rd1 = (32 + row) * BRS + 16 * half;
+  const float bias0 = (g.bias && n0 + row < g.n) ? g.bias[n0 + row] : 0.f;
+  const float bias1 = (g.bias && n0 + 32 + row < g.n) ? g.bias[n0 + 32 + row] : 0.f;
+  const int stride = gridDim.y * 4;
+  float araw[2][KSTEPS][8];
+  auto load_a = [&](int rb, float (&dst)[KSTEPS][8]) {
+    const long long mm = (long long)rb * 32 + row;
+    const bool row_ok = rb < n_rowblocks && mm < g.m;
+    const float* ap = A + (row_ok ? mm : 0) * g.a_rs;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int k0 = 16 * ks + 8 * half;
+      if constexpr (VEC == 4) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row_ok && k0 + 4 * v < g.k) t = *reinterpret_cast<const float4*>(ap + k0 + 4 * v);   // K % 4 == 0
+          dst[ks][4 * v] = t.x, dst[ks][4 * v + 1] = t.y, dst[ks][4 * v + 2] = t.z, dst[ks][4 * v + 3] = t.w;
+        }
+      } else if constexpr (VEC == 2) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float2 t = make_float2(0.f, 0.f);
+          if (row_ok && k0 + 2 * v < g.k) t = *reinterpret_cast<const float2*>(ap + k0 + 2 * v);   // K % 2 == 0
+          dst[ks][2 * v] = t.x, dst[ks][2 * v + 1] = t.y;
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) dst[ks][v] = (row_ok && k0 + v < g.k) ? ap[k0 + v] : 0.f;
+      }
+    }
+  };
+  auto process = [&](int rb, const float (&ar)[KSTEPS][8]) {
+    v16f_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      u32x4 hw, mw, lw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t h_, m_, l_;
+        x3_split_pair(ar[ks][2 * j], ar[ks][2 * j + 1], h_, m_, l_);
+        hw[j] = h_, mw[j] = m_, lw[j] = l_;
+      }
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, hw), am = __builtin_bit_cast(bf16x8, mw), al = __builtin_bit_cast(bf16x8, lw);
+      const bf16x8 b0h = *reinterpret_cast<const bf16x8*>(Bs + b_rd0 + 32 * ks);
+      const bf16x8 b0m = *reinterpret_cast<const bf16x8*>(Bs + BPLANE + b_rd0 + 32 * ks);
+      const bf16x8 b0l = *reinterpret_cast<const bf16x8*>(Bs + 2 * BPLANE + b_rd0 + 32 * ks);
+      const bf16x8 b1h = *reinterpret_cast<const bf16x8*>(Bs + b_rd1 + 32 * ks);
+      const bf16x8 b1m = *reinterpret_cast<const bf16x8*>(Bs + BPLANE + b_rd1 + 32 * ks);
+      const bf16x8 b1l = *reinterpret_cast<const bf16x8*>(Bs + 2 * BPLANE + b_rd1 + 32 * ks);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0m, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1m, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b1h, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0l, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1l, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b1h, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0m, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1m, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
+    }
+    // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int nn = n0 + 32 * t + row;
+      if (nn >= g.n) continue;
+      const float bv = t == 0 ? bias0 : bias1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long mm = (long long)rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (mm < g.m) {
+          float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+          if (g.relu) v = v > 0.f ? v : 0.f;
+          C[mm * g.ldc + nn] = v;
+        }
+      }
+    }
+  };
+  int rb = blockIdx.y * 4 + wave;
+  load_a(rb, araw[0]);
+  for (; rb < n_rowblocks; rb += 2 * stride) {      // two blocks per trip: the register sets alternate at compile time
+    load_a(rb + stride, araw[1]);
+    process(rb, araw[0]);
+    if (rb + stride >= n_rowblocks) break;
+    load_a(rb + 2 * stride, araw[0]);
+    process(rb + stride, araw[1]);
+  }
+}
+
 // out[i] = sum over s of slabs[s * stride + offset + i], i < n.  Workgroup = 32 columns x 8 slab groups: thread (c, g)
 // adds slabs g, g+8, ... in index order, the 8 group sums are then added in group order -- a fixed order, 8-way parallel.
 // accumulate != 0: out[i] += the sum (a tied weight's gradient contributions added in arrival order, as autograd would).
@@ -364,8 +492,26 @@ int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, con
   // default: the bf16 x 3 form (f32 accuracy at 3/8 of the matrix-pipe time); PV_GEMM_EXACT_F32=1 keeps the products on the
   // f32 matrix instruction (bit-exact f32 products)
   static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;
+  static const bool no_rows_form = getenv("PV_GEMM_NO_ROWS_FORM") != nullptr;
+  const bool rows_form = !exact_f32 && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 && d->m >= 2048 &&
+                         ((uintptr_t)a % 16 == 0);
   if (exact_f32) {
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), g);
+  } else if (rows_form) {
+    const int n_tiles = (d->n + G_BN - 1) / G_BN;
+    const int n_rb = (d->m + 31) / 32;
+    int per_col = 768 / n_tiles;                    // ~3 workgroups per CU over all column blocks
+    if (per_col < 1) per_col = 1;
+    if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
+    dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
+    const int vec = (d->a_rs % 4 == 0 && d->k % 4 == 0) ? 4 : ((d->a_rs % 2 == 0 && d->k % 2 == 0) ? 2 : 1);
+    const int ksteps = (d->k + 15) / 16;
+#define PV_ROWS(KS)                                                                                                   \
+    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
+    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
+    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
+    if (ksteps <= 3) { PV_ROWS(3); } else { PV_ROWS(4); }
+#undef PV_ROWS
   } else {
     const bool a_kc = d->a_cs == 1 && d->a_rs != 1;
     const bool b_kc = d->b_cs != 1;

@@ -217,3 +217,27 @@ def test_fused_attention_backward(b, h, nq, nk, device):
     dq, dkv = K.attention_bwd(qd, kvd, out, dout.to(device), lse, h, scale)
     torch.testing.assert_close(dq.cpu(), q.grad, rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(dkv.cpu(), kv.grad, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n,bias,relu", [(2048, 64, 64, True, False), (4099, 38, 128, False, False), (2500, 37, 70, True, True),
+                                             (19456, 64, 1024, True, False), (3000, 16, 5, False, False), (2048, 6, 64, True, False)])
+def test_gemm_rows_form_matches_f64(m, k, n, bias, relu):
+    """pv_gemm_f32's persistent "rows" form (tall row-major A, K <= 64: A operands straight into registers, weights split
+    once per workgroup) against an f64 product: every vector width (K % 4, K % 2, odd K), ragged M and N, bias and ReLU,
+    and B given as a transposed view (nn.Linear's weight.t()) as well as row-major."""
+    K, _ = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(m + k + n)
+    a = torch.randn(m, k, generator=g, device=dev)
+    w = torch.randn(n, k, generator=g, device=dev)
+    bv = torch.randn(n, generator=g, device=dev) if bias else None
+    for b_op in (w.t(), w.t().contiguous()):
+        c = K.gemm(a, b_op, bias=bv, relu=relu)
+        ref = a.double() @ w.double().t()
+        if bias:
+            ref = ref + bv.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        err = float((c.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (m, k, n, err)
