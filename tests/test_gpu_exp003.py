@@ -33,7 +33,7 @@ def _attention_reference(q, kv, h, scale, round_bf16):
     return (r(sim.softmax(dim=-1)) @ vh).permute(0, 2, 1, 3).reshape(b, nq, h * 64), sim
 
 
-@pytest.mark.parametrize("b,h,nq,nk", [(2, 1, 128, 16384), (2, 8, 128, 128), (2, 2, 40, 70), (1, 1, 97, 33)])
+@pytest.mark.parametrize("b,h,nq,nk", [(2, 1, 128, 16384), (2, 8, 128, 128), (2, 2, 40, 70), (1, 1, 97, 33), (1, 1, 100, 2100)])
 def test_bf16_attention_forward_and_backward(b, h, nq, nk, device):
     """pv_attention_fwd_bf16 / pv_attention_bwd_bf16 against torch on the CPU: tight against the reference that rounds the
     same operands to bf16 (q, k, v, p in forward AND backward), loose against the exact-f32 attention."""

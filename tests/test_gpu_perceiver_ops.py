@@ -60,8 +60,9 @@ def test_gemm_broadcast_batch(device):
     torch.testing.assert_close(got, lat @ w, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("rows,d", [(5, 37), (1000, 64), (7, 200), (4099, 64)])
+@pytest.mark.parametrize("rows,d", [(5, 37), (1000, 64), (7, 200), (4099, 64), (70001, 38), (65536, 12), (66000, 6)])
 def test_layernorm(rows, d, device):
+    """(the last three take the thread-per-row kernels for short rows: d <= 64, d % 8 != 0, >= 65 536 rows)"""
     _, PF = _mods()
     g = torch.Generator().manual_seed(rows + d)
     x = (torch.randn(rows, d, generator=g) * 3 + 1).requires_grad_(True)
