@@ -373,6 +373,10 @@ typedef struct pv_gemm_desc {
   int64_t c_ss;
 } pv_gemm_desc;
 int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream);
+/* C = A B + bias + residual (row-major [m][ldr], 2-D products only): the `fn(x) + x` of the Perceiver's PreNorm blocks
+ * (perceiver_pytorch: `x = cross_attn(x, ...) + x`, `x = cross_ff(x) + x`, ...) folded into the epilogue of fn's last Linear. */
+int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                    const pv_gemm_desc* d, int relu, void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
 /* accumulate != 0: out += the sum -- a weight that several layers share (weight_tie_layers=True,
  * predict_pv_yield/models/perceiver/perceiver.py:70-80) collects its gradient contributions in place, in arrival order,
@@ -410,7 +414,8 @@ size_t pv_attention_fwd_workspace_floats(const pv_attention_desc* d);   /* key-s
 int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
                           float* workspace, void* stream);   /* workspace NULL: no key split */
 int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
-                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream);
+                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
+                          void* stream);   /* accumulate_dkv != 0: dk, dv += (keys / values shared by weight-tied layers) */
 
 /* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
  * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */
@@ -419,7 +424,9 @@ int pv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* 
 int pv_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
 int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, float* dx,
                          float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, int32_t accumulate,
-                         void* stream);   /* accumulate != 0: dw, db += (see pv_sum_slabs_acc_f32); db == dw + d: one launch */
+                         const float* dx_add, void* stream);
+/* accumulate != 0: dw, db += (see pv_sum_slabs_acc_f32); db == dw + d: one launch; dx_add (may be NULL): dx = ... + dx_add,
+ * the gradient that reaches x past the block (the residual branch of `fn(norm(x)) + x`) folded into this kernel's store */
 /* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
  * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);

@@ -206,9 +206,11 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
                                                       const float* __restrict__ v, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
-                                                      AttnGeomB g, int tiles_per_split, long long dq_ss) {
+                                                      AttnGeomB g, int tiles_per_split, long long dq_ss, int accumulate_dkv) {
   constexpr int QS_B = 128 * B_KLD * 2, QT_B = BD * B_QLD * 2, KT_B = BD * B_TLD * 2, TW_B = 32 * B_TLD * 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B];
+  constexpr int PLD = BD + 4;                       // floats per key row of the dK / dV store patch (16-byte aligned rows)
+  constexpr int PT_B = BTJ * PLD * 4;               // per wave
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B + 4 * PT_B];
   __shared__ float Ls[128], Ds[128];
   uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);                       // [query][d]
   uint16_t* Os = reinterpret_cast<uint16_t*>(smem + QS_B);                // dO, same layout
@@ -344,14 +346,34 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
         }
       }
     }
-    if (j_ok) {
-      float* dkp = dk + b * g.k_bs + (long long)j * g.k_rs + h * BD;
-      float* dvp = dv + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+    // dK / dV of the tile leave through a wave-private LDS patch [key][d]: a lane owns ONE key (accumulator column), so
+    // direct stores were 16-byte pieces 512 bytes apart; from the patch 16 lanes write a key's 256-byte row together
+    // (accumulate_dkv: ... and add what is there -- the keys / values of weight-tied layers collect their gradient over
+    // the layers in place, instead of through one 1-GB elementwise add per layer)
+    {
+      float* patch = reinterpret_cast<float*>(smem + 2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B + wave * PT_B);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int d = att_acc_row(r, half);
-        dkp[d] = dk0[r], dkp[32 + d] = dk1[r];
-        dvp[d] = dv0[r], dvp[32 + d] = dv1[r];
+      for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int d = att_acc_row(r, half);
+          patch[col * PLD + d] = which == 0 ? dk0[r] : dv0[r];
+          patch[col * PLD + 32 + d] = which == 0 ? dk1[r] : dv1[r];
+        }
+        float* outp = (which == 0 ? dk : dv) + b * g.k_bs + h * BD;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int key = (lane >> 4) + 4 * i, d4 = (lane & 15) * 4;
+          float4 v = *reinterpret_cast<const float4*>(patch + key * PLD + d4);
+          if (j0 + key < g.n_k) {
+            float4* gp = reinterpret_cast<float4*>(outp + (long long)(j0 + key) * g.k_rs + d4);
+            if (accumulate_dkv) {
+              const float4 o = *gp;
+              v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+            }
+            *gp = v;
+          }
+        }
       }
     }
   }
@@ -448,14 +470,16 @@ int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float*
 }
 
 int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
-                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, void* stream) {
+                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
+                          void* stream) {
   AttnGeomB g;
   int rc = attn_geom_b(d, &g, "pv_attention_bwd_bf16");
   if (rc) return rc;
   PV_REQUIRE(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, PV_EINVAL, "pv_attention_bwd_bf16: null pointer");
   PV_REQUIRE(d->n_q <= 128, PV_ESIZE, "pv_attention_bwd_bf16: n_q=%d > 128 queries per (batch, head) is not built", d->n_q);
-  PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0),
-             PV_EINVAL, "pv_attention_bwd_bf16: q / dout / k / v must be 16-byte aligned");
+  PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                 ((uintptr_t)dk % 16 == 0) && ((uintptr_t)dv % 16 == 0),
+             PV_EINVAL, "pv_attention_bwd_bf16: q / dout / k / v / dk / dv must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
   const long long rows = (long long)d->batch * d->heads * d->n_q;
   launch_attn_delta(o, dout, delta_ws, d, st);    // the row term sum_d dO * O stays f32 (same kernel as the f32 path)
@@ -474,11 +498,11 @@ int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const 
     float* part = delta_ws + rows;
     const long long n = (long long)d->batch * d->q_batch_stride;
     hipLaunchKernelGGL(attn_bwd_bf16, dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
-                       lse, (const float*)delta_ws, part, dk, dv, g, per, n);
+                       lse, (const float*)delta_ws, part, dk, dv, g, per, n, accumulate_dkv);
     launch_sum_slabs(part, dq, n, nsp, n, 0, st);
   } else {
     hipLaunchKernelGGL(attn_bwd_bf16, dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
-                       (const float*)delta_ws, dq, dk, dv, g, n_tiles, 0ll);
+                       (const float*)delta_ws, dq, dk, dv, g, n_tiles, 0ll, accumulate_dkv);
   }
   return check_launch("pv_attention_bwd_bf16");
 }

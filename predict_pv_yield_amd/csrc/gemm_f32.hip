@@ -29,6 +29,8 @@ struct GemmK {
   int batch2, k_splits, k_chunk;
   long long a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2, c_ss;
   int relu;
+  const float* res;      // optional residual added in the epilogue: C = A B + bias + res (2-D products only)
+  long long ldr;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
       const int mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (mm < g.m) {
         float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+        if (g.res) v += g.res[(long long)mm * g.ldr + nn];
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[(long long)mm * g.ldc + nn] = v;
       }
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
       const int mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (mm < g.m) {
         float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+        if (g.res) v += g.res[(long long)mm * g.ldr + nn];
         if (g.relu) v = v > 0.f ? v : 0.f;
         C[(long long)mm * g.ldc + nn] = v;
       }
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
         const long long mm = (long long)rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (mm < g.m) {
           float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+          if (g.res) v += g.res[mm * g.ldr + nn];
           if (g.relu) v = v > 0.f ? v : 0.f;
           C[mm * g.ldc + nn] = v;
         }
@@ -470,16 +475,28 @@ using namespace pv;
 
 extern "C" {
 
+int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                    const pv_gemm_desc* d, int relu, void* stream);
+
 int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream) {
+  return pv_gemm_res_f32(a, b, bias, nullptr, 0, c, d, relu, stream);
+}
+
+int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                    const pv_gemm_desc* d, int relu, void* stream) {
   PV_REQUIRE(a && b && c && d, PV_EINVAL, "pv_gemm_f32: null pointer");
   PV_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, PV_EINVAL, "pv_gemm_f32: non-positive extent (%d,%d,%d)", d->m, d->n, d->k);
   PV_REQUIRE(d->batch1 > 0 && d->batch2 > 0 && d->k_splits > 0, PV_EINVAL, "pv_gemm_f32: batch counts and k_splits must be >= 1");
   PV_REQUIRE(d->ldc >= d->n, PV_EINVAL, "pv_gemm_f32: ldc < n");
-  PV_REQUIRE(!(d->k_splits > 1 && (bias || relu)), PV_EINVAL, "pv_gemm_f32: bias / ReLU cannot be applied to split-K partial products");
+  PV_REQUIRE(!(d->k_splits > 1 && (bias || relu || residual)), PV_EINVAL,
+             "pv_gemm_f32: bias / ReLU / residual cannot be applied to split-K partial products");
+  PV_REQUIRE(!residual || ((long long)d->batch1 * d->batch2 == 1 && ldr >= d->n), PV_EINVAL,
+             "pv_gemm_res_f32: the residual form is for 2-D products (ldr >= n)");
   const long long zs = (long long)d->batch1 * d->batch2 * d->k_splits;
   PV_REQUIRE(zs <= 65535, PV_ESIZE, "pv_gemm_f32: batch1*batch2*k_splits = %lld exceeds the grid limit", zs);
   GemmK g;
   g.a = a, g.b = b, g.bias = bias, g.c = c;
+  g.res = residual, g.ldr = ldr;
   g.m = d->m, g.n = d->n, g.k = d->k;
   g.a_rs = d->a_rs, g.a_cs = d->a_cs, g.b_rs = d->b_rs, g.b_cs = d->b_cs, g.ldc = d->ldc;
   g.batch2 = d->batch2, g.k_splits = d->k_splits;

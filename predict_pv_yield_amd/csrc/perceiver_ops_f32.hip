@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_f32(const float* __restrict
                                                           const float* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ dx,
                                                           float* __restrict__ part /* [grid][2][d] */, long long rows, int d,
-                                                          int rows_per_block) {
+                                                          int rows_per_block, const float* __restrict__ dx_add) {
   __shared__ float red[4][2][LN_MAXPL * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float dwp[LN_MAXPL], dbp[LN_MAXPL], wv[LN_MAXPL];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_f32(const float* __restrict
 #pragma unroll
       for (int i = 0; i < LN_MAXPL; ++i) {
         const int c = lane + 64 * i;
-        if (c < d) dx[row * d + c] = rs * (g[i] - m1 - xh[i] * m2);
+        if (c < d) dx[row * d + c] = rs * (g[i] - m1 - xh[i] * m2) + (dx_add ? dx_add[row * d + c] : 0.f);
       }
     }
   }
@@ -124,13 +124,20 @@ __device__ __forceinline__ void ln_stage_in(float* lds, const float* __restrict_
   }
 }
 template <int NT>
-__device__ __forceinline__ void ln_stage_out(const float* lds, float* __restrict__ dst, long long n_valid) {
+__device__ __forceinline__ void ln_stage_out(const float* lds, float* __restrict__ dst, long long n_valid,
+                                             const float* __restrict__ add = nullptr) {
+  // dst[i] = lds[i] (+ add[i]); add, if given, is laid out and aligned like dst
   for (int i4 = threadIdx.x; i4 * 4 < n_valid; i4 += NT) {
     if ((long long)i4 * 4 + 3 < n_valid) {
-      *reinterpret_cast<float4*>(dst + (long long)i4 * 4) = *reinterpret_cast<const float4*>(lds + i4 * 4);
+      float4 v = *reinterpret_cast<const float4*>(lds + i4 * 4);
+      if (add) {
+        const float4 a = *reinterpret_cast<const float4*>(add + (long long)i4 * 4);
+        v.x += a.x, v.y += a.y, v.z += a.z, v.w += a.w;
+      }
+      *reinterpret_cast<float4*>(dst + (long long)i4 * 4) = v;
     } else {
       for (int e = 0; e < 4; ++e)
-        if ((long long)i4 * 4 + e < n_valid) dst[(long long)i4 * 4 + e] = lds[i4 * 4 + e];
+        if ((long long)i4 * 4 + e < n_valid) dst[(long long)i4 * 4 + e] = lds[i4 * 4 + e] + (add ? add[(long long)i4 * 4 + e] : 0.f);
     }
   }
 }
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(LNR_BT) void layernorm_bwd_rows_f32(const float* __
                                                                const float* __restrict__ dy, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, float* __restrict__ dx,
                                                                float* __restrict__ part /* [grid][2][d] */, long long rows, int d,
-                                                               int rows_per_block) {
+                                                               int rows_per_block, const float* __restrict__ dx_add) {
   __shared__ __attribute__((aligned(16))) float bxg[2 * LNR_BT * DMAX];   // x rows | dy rows; reused by the final reduction
   float* bx = bxg;
   float* bg = bxg + LNR_BT * DMAX;
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(LNR_BT) void layernorm_bwd_rows_f32(const float* __
     }
     if (dx) {
       __syncthreads();
-      ln_stage_out<LNR_BT>(bg, dx + r0 * d, n_valid);
+      ln_stage_out<LNR_BT>(bg, dx + r0 * d, n_valid, dx_add ? dx_add + r0 * d : nullptr);
     }
   }
   // column sums over the lanes: wave by wave through LDS (lane order inside a wave, then wave order: fixed)
@@ -430,7 +437,7 @@ int pv_layernorm_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes) {
 
 int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, float* dx,
                          float* dw, float* db, int64_t rows, int32_t d, void* ws, size_t ws_bytes, int32_t accumulate,
-                         void* stream) {
+                         const float* dx_add, void* stream) {
   PV_REQUIRE(x && w && dy && mean && rstd && dw && db, PV_EINVAL, "pv_layernorm_bwd_f32: null pointer");
   PV_REQUIRE(rows > 0 && d > 0 && d <= 64 * LN_MAXPL, PV_ESIZE, "pv_layernorm_bwd_f32: d=%d must be in 1..%d", d, 64 * LN_MAXPL);
   int per;
@@ -438,20 +445,22 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
   PV_REQUIRE(ws && ws_bytes >= (size_t)nb * 2 * d * sizeof(float), PV_EINVAL, "pv_layernorm_bwd_f32: workspace too small");
   hipStream_t st = as_stream(stream);
   float* part = (float*)ws;
+  PV_REQUIRE(!dx_add || dx, PV_EINVAL, "pv_layernorm_bwd_f32: dx_add without dx");
   const bool short_rows = d <= 64 && d % 2 == 0 && d % 8 != 0 && rows >= 65536 && ((uintptr_t)x % 16 == 0) &&
-                          ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0);
+                          ((uintptr_t)dy % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0) && ((uintptr_t)dx_add % 16 == 0);
   int nbl = nb;
   if (short_rows) {   // one thread per row: whole multiples of 256 rows per block (never more blocks than ln_blocks sized)
     const long long per_r = ((rows + LN_MAX_BLOCKS - 1) / LN_MAX_BLOCKS + LNR_BT - 1) / LNR_BT * LNR_BT;
     nbl = (int)((rows + per_r - 1) / per_r);
     if (d <= 40)
       hipLaunchKernelGGL(layernorm_bwd_rows_f32<40>, dim3((unsigned)nbl), dim3(LNR_BT), 0, st, x, w, dy, mean, rstd, dx, part,
-                         (long long)rows, d, (int)per_r);
+                         (long long)rows, d, (int)per_r, dx_add);
     else
       hipLaunchKernelGGL(layernorm_bwd_rows_f32<64>, dim3((unsigned)nbl), dim3(LNR_BT), 0, st, x, w, dy, mean, rstd, dx, part,
-                         (long long)rows, d, (int)per_r);
+                         (long long)rows, d, (int)per_r, dx_add);
   } else {
-    hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per);
+    hipLaunchKernelGGL(layernorm_bwd_f32, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, mean, rstd, dx, part, (long long)rows, d, per,
+                       dx_add);
   }
   // part is [nb][2][d]: summed over blocks in index order, straight into dw and db
   if (db == dw + d) {   // one [2 d] vector: one launch

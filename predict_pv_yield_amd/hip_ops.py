@@ -646,10 +646,11 @@ def _gemm_views(a: torch.Tensor, b: torch.Tensor):
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C = A @ B (+ bias) for arbitrarily STRIDED views (transposes, column slices and per-head permutes are free:
-    only the strides change).  `out`: optional view [..., M, N] with unit last stride to write into."""
-    _require_device(a, b, out)
+         out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = A @ B (+ bias) (+ residual) for arbitrarily STRIDED views (transposes, column slices and per-head permutes are
+    free: only the strides change).  `out`: optional view [..., M, N] with unit last stride to write into.
+    `residual`: a [M, N] tensor with unit last stride added in the epilogue (2-D products only)."""
+    _require_device(a, b, out, residual)
     require_cuda(bias)
     lead = tuple(a.shape[:-2])
     a4, b4, batch = _gemm_views(a, b)
@@ -663,6 +664,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         raise ValueError("gemm: bad output view")
     d = _lib.GemmDesc(m, n, k, a4.stride(-2), a4.stride(-1), b4.stride(-2), b4.stride(-1), c4.stride(-2), batch[0], batch[1],
                       a4.stride(0), a4.stride(1), b4.stride(0), b4.stride(1), c4.stride(0), c4.stride(1), 1, 0)
+    if residual is not None:
+        if batch != (1, 1) or tuple(residual.shape) != (m, n) or residual.stride(-1) != 1 or residual.dtype != torch.float32:
+            raise ValueError("gemm: residual must be a float32 [M, N] tensor with unit last stride (2-D products only)")
+        check(get_lib().pv_gemm_res_f32(ptr(a4), ptr(b4), ptr(bias), ptr(residual), residual.stride(0), ptr(c4),
+                                        ctypes.byref(d), int(relu), current_stream_ptr()), "pv_gemm_res_f32")
+        return out
     check(get_lib().pv_gemm_f32(ptr(a4), ptr(b4), ptr(bias), ptr(c4), ctypes.byref(d), int(relu), current_stream_ptr()),
           "pv_gemm_f32")
     return out
@@ -717,10 +724,13 @@ def layernorm_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float 
     return y, mean, rstd
 
 
-def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True, accumulate_into=None):
+def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True, accumulate_into=None, dx_add=None):
     """-> (dx | None, dw, db).  For d % 4 == 0, dw and db are the two halves of ONE [2 d] tensor (one reduction launch).
-    accumulate_into: a (dw, db) pair returned by an earlier call, which receives `+=` instead."""
-    require_cuda(x, w, dy, mean, rstd)
+    accumulate_into: a (dw, db) pair returned by an earlier call, which receives `+=` instead.
+    dx_add: a tensor like x added to dx in the kernel's store (the gradient that reaches x past the normalised branch)."""
+    require_cuda(x, w, dy, mean, rstd, dx_add)
+    if dx_add is not None and (not need_dx or dx_add.shape != x.shape or not dx_add.is_contiguous()):
+        raise ValueError("layernorm_bwd: dx_add must be a contiguous tensor like x (and need_dx)")
     d = x.shape[-1]
     rows = x.numel() // d
     nbytes = ctypes.c_size_t(0)
@@ -736,8 +746,8 @@ def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True, accumulate_into=No
         dw = torch.empty(d, dtype=torch.float32, device=x.device)
         db = torch.empty(d, dtype=torch.float32, device=x.device)
     check(get_lib().pv_layernorm_bwd_f32(ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), rows, d,
-                                         ptr(ws), nbytes.value, int(accumulate_into is not None), current_stream_ptr()),
-          "pv_layernorm_bwd_f32")
+                                         ptr(ws), nbytes.value, int(accumulate_into is not None), ptr(dx_add),
+                                         current_stream_ptr()), "pv_layernorm_bwd_f32")
     return dx, dw, db
 
 
@@ -841,18 +851,28 @@ def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, b
     return out, lse
 
 
-def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands: bool = False):
-    """Backward of attention_fwd (n_q <= 128): returns (dq like q, dkv like kv)."""
-    require_cuda(q, kv, out, dout, lse)
+def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands: bool = False, accumulate_dkv_into=None):
+    """Backward of attention_fwd (n_q <= 128): returns (dq like q, dkv like kv).
+    accumulate_dkv_into (bf16 operands only): a tensor like kv that receives `+= dkv` in the kernel's store."""
+    require_cuda(q, kv, out, dout, lse, accumulate_dkv_into)
     b, n_q, inner = q.shape
     d = attention_desc(q, kv, heads, scale)
     dq = torch.empty_like(q)
-    dkv = torch.empty_like(kv)
+    if accumulate_dkv_into is not None:
+        if not bf16_operands or accumulate_dkv_into.shape != kv.shape or not accumulate_dkv_into.is_contiguous():
+            raise ValueError("attention_bwd: accumulate_dkv_into needs the bf16-operand kernels and a contiguous tensor like kv")
+        dkv = accumulate_dkv_into
+    else:
+        dkv = torch.empty_like(kv)
     n_ws = get_lib().pv_attention_bwd_workspace_floats(ctypes.byref(d))
     delta = _workspace("attention_bwd", n_ws * 4, q.device)
     v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
     dv_ptr = ctypes.c_void_p(dkv.data_ptr() + inner * 4)
-    fn = get_lib().pv_attention_bwd_bf16 if bf16_operands else get_lib().pv_attention_bwd_f32
-    check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv), dv_ptr, ctypes.byref(d),
-             current_stream_ptr()), "pv_attention_bwd_bf16" if bf16_operands else "pv_attention_bwd_f32")
+    if bf16_operands:
+        check(get_lib().pv_attention_bwd_bf16(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
+                                              dv_ptr, ctypes.byref(d), int(accumulate_dkv_into is not None), current_stream_ptr()),
+              "pv_attention_bwd_bf16")
+    else:
+        check(get_lib().pv_attention_bwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
+                                             dv_ptr, ctypes.byref(d), current_stream_ptr()), "pv_attention_bwd_f32")
     return dq, dkv

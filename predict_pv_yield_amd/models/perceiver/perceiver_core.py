@@ -60,19 +60,29 @@ class Attention(nn.Module):
         self.to_out = nn.Linear(inner_dim, query_dim)
 
 
-def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False) -> torch.Tensor:
-    """Attention.forward given the normalised query input and the (already projected) keys/values [b, j, 2*inner]."""
+FUSE_RESIDUALS = True   # `fn(norm(x)) + x`: by-pass added in fn's last GEMM epilogue / the LayerNorm backward store (False: torch adds)
+
+
+def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False, residual=None) -> torch.Tensor:
+    """Attention.forward given the normalised query input and the (already projected) keys/values [b, j, 2*inner];
+    `residual` (the block's `+ x`) is added in the epilogue of to_out."""
     q = PF.linear(xn, attn.to_q.weight)                                  # [b, i, inner]
     out = PF.attention_core(q, kv, attn.heads, attn.scale, bf16_operands=bf16_operands)   # softmax(scale q k^T) v, per head
-    return PF.linear(out, attn.to_out.weight, attn.to_out.bias)
+    return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
 
 
 def _feed_forward(block: PreNorm, x: torch.Tensor) -> torch.Tensor:
+    """`block(x) + x` of a PreNorm(FeedForward): the by-pass rides in the last Linear's epilogue forward and in the LayerNorm
+    kernel backward."""
     ff = block.fn
-    y = PF.layer_norm(x, block.norm.weight, block.norm.bias, block.norm.eps)
+    if not FUSE_RESIDUALS:
+        y = PF.layer_norm(x, block.norm.weight, block.norm.bias, block.norm.eps)
+        y = PF.geglu(PF.linear(y, ff.net[0].weight, ff.net[0].bias))
+        return PF.linear(y, ff.net[2].weight, ff.net[2].bias) + x
+    y, x_pass = PF.layer_norm_fork(x, block.norm.weight, block.norm.bias, block.norm.eps)
     y = PF.linear(y, ff.net[0].weight, ff.net[0].bias)
     y = PF.geglu(y)
-    return PF.linear(y, ff.net[2].weight, ff.net[2].bias)
+    return PF.linear(y, ff.net[2].weight, ff.net[2].bias, residual=x_pass)
 
 
 class Perceiver(nn.Module):
@@ -142,15 +152,27 @@ class Perceiver(nn.Module):
             if id(cross_attn) not in kv_of:
                 ctx = PF.layer_norm(data, cross_attn.norm_context.weight, cross_attn.norm_context.bias,
                                     cross_attn.norm_context.eps)
-                kv_of[id(cross_attn)] = PF.linear(ctx, cross_attn.fn.to_kv.weight)
-            xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-            x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], self.operand_dtype == "bf16") + x
-            x = _feed_forward(cross_ff, x) + x
+                kv_of[id(cross_attn)] = PF.mark_shared(PF.linear(ctx, cross_attn.fn.to_kv.weight))   # consumed by every tied layer
+            # every `fn(norm(x)) + x`: the by-pass is added in the epilogue of fn's last Linear (forward) and in the LayerNorm
+            # backward kernel's store (backward) -- no elementwise launches
+            bf = self.operand_dtype == "bf16"
+            if FUSE_RESIDUALS:
+                xn, x_pass = PF.layer_norm_fork(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
+                x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], bf, residual=x_pass)
+            else:
+                xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
+                x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], bf) + x
+            x = _feed_forward(cross_ff, x)
             for self_attn, self_ff in self_attns:
-                xn = PF.layer_norm(x, self_attn.norm.weight, self_attn.norm.bias, self_attn.norm.eps)
-                kv = PF.linear(xn, self_attn.fn.to_kv.weight)
-                x = _attend(self_attn.fn, xn, kv, self.operand_dtype == "bf16") + x
-                x = _feed_forward(self_ff, x) + x
+                if FUSE_RESIDUALS:
+                    xn, x_pass = PF.layer_norm_fork(x, self_attn.norm.weight, self_attn.norm.bias, self_attn.norm.eps)
+                    kv = PF.linear(xn, self_attn.fn.to_kv.weight)
+                    x = _attend(self_attn.fn, xn, kv, bf, residual=x_pass)
+                else:
+                    xn = PF.layer_norm(x, self_attn.norm.weight, self_attn.norm.bias, self_attn.norm.eps)
+                    kv = PF.linear(xn, self_attn.fn.to_kv.weight)
+                    x = _attend(self_attn.fn, xn, kv, bf) + x
+                x = _feed_forward(self_ff, x)
         x = PF.mean_axis1(x)
         x = PF.layer_norm(x, self.to_logits[1].weight, self.to_logits[1].bias, self.to_logits[1].eps)
         return PF.linear(x, self.to_logits[2].weight, self.to_logits[2].bias)

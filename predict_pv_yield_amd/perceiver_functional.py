@@ -31,13 +31,38 @@ def _tied_keep(key, grad: torch.Tensor):
         _TIED[key] = (torch._C._current_graph_task_id(), grad)
 
 
+# the same for an ACTIVATION that several layers consume (the projected context of weight-tied cross-attention layers,
+# tagged `_pv_shared` by its producer): entries live for one backward pass only -- they are dropped as soon as another pass
+# is seen, so no gradient tensor outlives its step here
+_SHARED_ACT = {}
+_SHARED_ACT_TASK = [-1]
+
+
+def mark_shared(t: torch.Tensor) -> torch.Tensor:
+    t._pv_shared = True
+    return t
+
+
+def _shared_activation_slot(t: torch.Tensor):
+    task = torch._C._current_graph_task_id()
+    if not ACCUMULATE_TIED_GRADS or task < 0 or not getattr(t, "_pv_shared", False):
+        return None, None
+    if _SHARED_ACT_TASK[0] != task:
+        _SHARED_ACT.clear()
+        _SHARED_ACT_TASK[0] = task
+    key = (t.data_ptr(), t.numel())
+    return key, _SHARED_ACT.get(key)
+
+
 class LinearRowsF32(torch.autograd.Function):
-    """y[..., out] = x[..., in] @ W[out, in]^T (+ bias): nn.Linear over an arbitrary number of rows (rows >> in, out)."""
+    """y[..., out] = x[..., in] @ W[out, in]^T (+ bias) (+ residual): nn.Linear over an arbitrary number of rows
+    (rows >> in, out); `residual` (shaped like y) rides in the GEMM epilogue and receives dy unchanged."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None):
         x2 = x.contiguous().view(-1, x.shape[-1])
-        y = K.gemm(x2, weight.t(), bias=bias)
+        res2 = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
+        y = K.gemm(x2, weight.t(), bias=bias, residual=res2)
         ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         return y.view(x.shape[:-1] + (weight.shape[0],))
@@ -45,7 +70,8 @@ class LinearRowsF32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, weight, bias = ctx.saved_tensors
-        dy2 = dy.contiguous().view(-1, weight.shape[0])
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, weight.shape[0])
         dx = K.gemm(dy2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         key, acc = _tied_slot(weight)
         if acc is not None:
@@ -62,11 +88,11 @@ class LinearRowsF32(torch.autograd.Function):
             else:
                 db = K.colsum(dy2)
                 _tied_keep(key, db)
-        return dx, dw, db
+        return dx, dw, db, (dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
 
 
-def linear(x, weight, bias=None):
-    return LinearRowsF32.apply(x, weight, bias)
+def linear(x, weight, bias=None, residual=None):
+    return LinearRowsF32.apply(x, weight, bias, residual)
 
 
 class MatmulF32(torch.autograd.Function):
@@ -130,7 +156,16 @@ class AttentionCoreF32(torch.autograd.Function):
     def backward(ctx, dout):
         if ctx.fused:
             q, kv, out, lse = ctx.saved_tensors
+            # the projected context of weight-tied layers is ONE tensor used by every layer: its gradient collects in the
+            # first arrival's tensor (see _tied_slot), added by the backward kernel's own dK / dV store
+            key, acc = _shared_activation_slot(kv) if ctx.bf16 else (None, None)
+            if acc is not None:
+                dq, _ = K.attention_bwd(q, kv, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=True,
+                                        accumulate_dkv_into=acc)
+                return dq, None, None, None, None
             dq, dkv = K.attention_bwd(q, kv, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=ctx.bf16)
+            if key is not None:
+                _SHARED_ACT[key] = dkv
             return dq, dkv, None, None, None
         q, kv, p = ctx.saved_tensors
         h, inner = ctx.heads, q.shape[-1]
@@ -198,6 +233,40 @@ class LayerNormF32(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps=1e-5):
     return LayerNormF32.apply(x, weight, bias, eps)
+
+
+class LayerNormForkF32(torch.autograd.Function):
+    """(norm(x), x) of a PreNorm residual block `fn(norm(x)) + x`: the second output is x itself, routed through this node so
+    that BOTH gradients of x -- through the normalised branch and past it -- arrive here and leave as one tensor: the
+    LayerNorm backward kernel adds the by-pass gradient while it stores dx (autograd otherwise adds the two with one
+    elementwise launch per block and step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x, weight, bias, eps)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        x, weight, mean, rstd = ctx.saved_tensors
+        if dy is None:                       # only the by-pass was used
+            return dpass, None, None, None
+        add = dpass.contiguous() if dpass is not None and ctx.needs_input_grad[0] else None
+        key, acc = _tied_slot(weight)
+        if acc is not None:
+            dx, _, _ = K.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd, need_dx=ctx.needs_input_grad[0],
+                                       accumulate_into=acc, dx_add=add)
+            return dx, None, None, None
+        dx, dw, db = K.layernorm_bwd(x, weight, dy.contiguous(), mean, rstd, need_dx=ctx.needs_input_grad[0], dx_add=add)
+        _tied_keep(key, (dw, db))
+        return dx, dw, db, None
+
+
+def layer_norm_fork(x, weight, bias, eps=1e-5):
+    """-> (layer_norm(x), x): see LayerNormForkF32."""
+    return LayerNormForkF32.apply(x, weight, bias, eps)
 
 
 class GEGLUF32(torch.autograd.Function):
