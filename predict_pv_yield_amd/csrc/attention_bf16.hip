@@ -207,58 +207,37 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                       AttnGeomB g, int tiles_per_split, long long dq_ss, int accumulate_dkv) {
-  constexpr int QS_B = 128 * B_KLD * 2, QT_B = BD * B_QLD * 2, KT_B = BD * B_TLD * 2, TW_B = 32 * B_TLD * 2;
-  constexpr int PLD = BD + 4;                       // floats per key row of the dK / dV store patch (16-byte aligned rows)
-  constexpr int PT_B = BTJ * PLD * 4;               // per wave
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B + 4 * PT_B];
+  // LDS: Q and dO of all (<= 128) queries, row-major bf16 [query][d] (A operands of S = Q K^T and dP = dO V^T with one
+  // ds_read_b128; the TRANSPOSED operands of dV^T += dO^T P and dK^T += Q^T dS come from the same images through
+  // ds_read_b64_tr_b16 -- round 2 kept separate transposed images, built with 2-byte scatter stores, 35 KB more LDS and
+  // one workgroup per CU); per wave the K tile [key][d] (transposed-read for dQ^T += K^T dS^T) and dS [key][query].
+  constexpr int QS_B = 128 * B_KLD * 2, KR_B = BTJ * B_KLD * 2, TW_B = BTJ * B_TLD * 2;
+  constexpr int SLD = BD + 1;                                         // dQ reduction scratch pitch (floats)
+  constexpr int SMEM_B = 2 * QS_B + 4 * (KR_B + TW_B) > 2 * 4 * 32 * SLD * 4 ? 2 * QS_B + 4 * (KR_B + TW_B) : 2 * 4 * 32 * SLD * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
   __shared__ float Ls[128], Ds[128];
   uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);                       // [query][d]
   uint16_t* Os = reinterpret_cast<uint16_t*>(smem + QS_B);                // dO, same layout
-  uint16_t* QtT = reinterpret_cast<uint16_t*>(smem + 2 * QS_B);           // [d][32 it + att_pos(query % 32)]
-  uint16_t* OtT = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + QT_B);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint16_t* Kt = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + 2 * QT_B + wave * KT_B);            // [d][key of the tile]
-  uint16_t* Tw = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + 2 * QT_B + 4 * KT_B + wave * TW_B);  // dS [query][key]
+  uint16_t* Kr = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + wave * (KR_B + TW_B));            // [key of the tile][d]
+  uint16_t* Tw = reinterpret_cast<uint16_t*>(smem + 2 * QS_B + wave * (KR_B + TW_B) + KR_B);     // dS [key][query of tile it]
+  // transposed 8-element operand: rows row_lo + 0..3 and row_hi + 0..3 of an [row][column] bf16 image, this lane's column
+  // = colbase + lane % 32 (16-lane groups fetch 4 x 16 blocks: lane (qi, pi) supplies row qi, 4-column piece pi)
+  const int tr_qi = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  auto tr8 = [&](const uint16_t* img, int ld, int row_lo, int row_hi, int colbase) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + (row_lo + tr_qi) * ld + colbase + tr_col));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(img + (row_hi + tr_qi) * ld + colbase + tr_col));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const float* qb = q + b * g.q_bs + h * BD;
   const float* ob = dout + b * g.q_bs + h * BD;
   const float* kb = k + b * g.k_bs + h * BD;
   const float* vb = v + b * g.k_bs + h * BD;
-  // ---- stage Q, dO (zero rows beyond n_q), lse (+inf beyond n_q so that P = 0 there), delta ---------------------------
-  for (int idx = tid; idx < 128 * 8; idx += 256) {
-    const int i = idx >> 3, c8 = (idx & 7) * 8;
-    const bool ok = i < g.n_q;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
-    if (ok) {
-      a0 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8); a1 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8 + 4);
-      b0 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8); b1 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8 + 4);
-    }
-    const float qx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-    const float ox[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-    *reinterpret_cast<bf16x8*>(Qs + i * B_KLD + c8) = att_pack8(qx);
-    *reinterpret_cast<bf16x8*>(Os + i * B_KLD + c8) = att_pack8(ox);
-    const int tp = (i & ~31) + att_pos(i & 31);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      QtT[(c8 + e) * B_QLD + tp] = f32_to_bf16_bits(qx[e]);
-      OtT[(c8 + e) * B_QLD + tp] = f32_to_bf16_bits(ox[e]);
-    }
-  }
-  if (tid < 128) {
-    const long long li = ((long long)b * g.heads + h) * g.n_q + tid;
-    Ls[tid] = tid < g.n_q ? lse[li] : INFINITY;
-    Ds[tid] = tid < g.n_q ? delta[li] : 0.f;
-  }
-  __syncthreads();
-
-  v16f_b dqa[4][2];   // dQ^T partial of this wave: [query tile][d half], rows d, column = query
-#pragma unroll
-  for (int it = 0; it < 4; ++it)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
   const int n_tiles = (g.n_k + BTJ - 1) / BTJ;
   const int n_qt = (g.n_q + 31) / 32;
   const int tile0 = blockIdx.x * tiles_per_split;
@@ -279,7 +258,35 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       if (!ok) kn[ks][0] = kn[ks][1] = vn[ks][0] = vn[ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  load_kv(tile0 + wave);
+  load_kv(tile0 + wave);   // in flight while Q / dO are staged
+  // ---- stage Q, dO (zero rows beyond n_q), lse (+inf beyond n_q so that P = 0 there), delta ---------------------------
+  for (int idx = tid; idx < 128 * 8; idx += 256) {
+    const int i = idx >> 3, c8 = (idx & 7) * 8;
+    const bool ok = i < g.n_q;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    if (ok) {
+      a0 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8); a1 = *reinterpret_cast<const f32x4*>(qb + (long long)i * g.q_rs + c8 + 4);
+      b0 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8); b1 = *reinterpret_cast<const f32x4*>(ob + (long long)i * g.q_rs + c8 + 4);
+    }
+    const float qx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const float ox[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    *reinterpret_cast<bf16x8*>(Qs + i * B_KLD + c8) = att_pack8(qx);
+    *reinterpret_cast<bf16x8*>(Os + i * B_KLD + c8) = att_pack8(ox);
+  }
+  if (tid < 128) {
+    const long long li = ((long long)b * g.heads + h) * g.n_q + tid;
+    Ls[tid] = tid < g.n_q ? lse[li] : INFINITY;
+    Ds[tid] = tid < g.n_q ? delta[li] : 0.f;
+  }
+  __syncthreads();
+
+  v16f_b dqa[4][2];   // dQ^T partial of this wave: [query tile][d half], rows d, column = query
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
   for (int tile = tile0 + wave; tile < tile1; tile += 4) {
     const int j0 = tile * BTJ;
     const int j = j0 + col;                       // this lane's key (B-operand column)
@@ -291,8 +298,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       const float vx[8] = {vn[ks][0][0], vn[ks][0][1], vn[ks][0][2], vn[ks][0][3], vn[ks][1][0], vn[ks][1][1], vn[ks][1][2], vn[ks][1][3]};
       kreg[ks] = att_pack8(kx);
       vreg[ks] = att_pack8(vx);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Kt[(16 * ks + 8 * half + e) * B_TLD + col] = f32_to_bf16_bits(kx[e]);   // K^T for dQ
+      *reinterpret_cast<bf16x8*>(Kr + col * B_KLD + 16 * ks + 8 * half) = kreg[ks];   // row-major; read transposed for dQ
     }
     load_kv(tile + 4);
     v16f_b dv0, dv1, dk0, dk1;   // dV^T / dK^T of this key tile: rows d, column = key
@@ -319,7 +325,14 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
           const float pv_ = j_ok ? expf(sc[r] * g.scale - Ls[i]) : 0.f;
           sc[r] = pv_;                                      // sc now holds P
           dp[r] = g.scale * pv_ * (dp[r] - Ds[i]);          // dp now holds dS
-          Tw[att_acc_row(r, half) * B_TLD + col] = f32_to_bf16_bits(dp[r]);
+        }
+        // dS of this lane's key, queries 8 g + 4 half + 0..3 per register quad g: four packed 8-byte stores into [key][query]
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          u32x2 w2;
+          w2[0] = (uint32_t)f32_to_bf16_bits(dp[4 * q4]) | ((uint32_t)f32_to_bf16_bits(dp[4 * q4 + 1]) << 16);
+          w2[1] = (uint32_t)f32_to_bf16_bits(dp[4 * q4 + 2]) | ((uint32_t)f32_to_bf16_bits(dp[4 * q4 + 3]) << 16);
+          *reinterpret_cast<u32x2*>(Tw + col * B_TLD + 8 * q4 + 4 * half) = w2;
         }
         // dV^T += dO^T P, dK^T += Q^T dS: contraction slot 8 half + t of step st is query att_acc_row(8 st + t, half)
 #pragma unroll
@@ -329,67 +342,65 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
           const float sx[8] = {dp[8 * st], dp[8 * st + 1], dp[8 * st + 2], dp[8 * st + 3], dp[8 * st + 4], dp[8 * st + 5],
                                dp[8 * st + 6], dp[8 * st + 7]};
           const bf16x8 pb = att_pack8(px), sb = att_pack8(sx);
-          const int off = 32 * it + 16 * st + 8 * half;
-          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(OtT + col * B_QLD + off), pb, dv0, 0, 0, 0);
-          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(OtT + (32 + col) * B_QLD + off), pb, dv1, 0, 0, 0);
-          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(QtT + col * B_QLD + off), sb, dk0, 0, 0, 0);
-          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(QtT + (32 + col) * B_QLD + off), sb, dk1, 0, 0, 0);
+          // contraction slots 8 half + 0..7 of step st = queries 32 it + 16 st + 4 half + {0..3, 8..11}: two 4-row runs
+          const int q_lo = 32 * it + 16 * st + 4 * half;
+          dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Os, B_KLD, q_lo, q_lo + 8, 0), pb, dv0, 0, 0, 0);
+          dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Os, B_KLD, q_lo, q_lo + 8, 32), pb, dv1, 0, 0, 0);
+          dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Qs, B_KLD, q_lo, q_lo + 8, 0), sb, dk0, 0, 0, 0);
+          dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Qs, B_KLD, q_lo, q_lo + 8, 32), sb, dk1, 0, 0, 0);
         }
-        // dQ^T[d][i] += K^T[d][j] dS^T[j][i]: B operand lane (query = col, keys 16 st + 8 half + 0..7) read back from Tw
+        // dQ^T[d][i] += K^T[d][j] dS^T[j][i]: keys 16 st + 8 half + 0..7 of the tile; both operands read transposed
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          const bf16x8 dsb = *reinterpret_cast<const bf16x8*>(Tw + col * B_TLD + 16 * st + 8 * half);
-          dqa[it][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Kt + col * B_TLD + 16 * st + 8 * half),
-                                                               dsb, dqa[it][0], 0, 0, 0);
-          dqa[it][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              *reinterpret_cast<const bf16x8*>(Kt + (32 + col) * B_TLD + 16 * st + 8 * half), dsb, dqa[it][1], 0, 0, 0);
+          const int k_lo = 16 * st + 8 * half;
+          const bf16x8 dsb = tr8(Tw, B_TLD, k_lo, k_lo + 4, 0);          // B: lane (query = col, 8 keys)
+          dqa[it][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Kr, B_KLD, k_lo, k_lo + 4, 0), dsb, dqa[it][0], 0, 0, 0);
+          dqa[it][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Kr, B_KLD, k_lo, k_lo + 4, 32), dsb, dqa[it][1], 0, 0, 0);
         }
       }
     }
-    // dK / dV of the tile leave through a wave-private LDS patch [key][d]: a lane owns ONE key (accumulator column), so
-    // direct stores were 16-byte pieces 512 bytes apart; from the patch 16 lanes write a key's 256-byte row together
-    // (accumulate_dkv: ... and add what is there -- the keys / values of weight-tied layers collect their gradient over
-    // the layers in place, instead of through one 1-GB elementwise add per layer)
-    {
-      float* patch = reinterpret_cast<float*>(smem + 2 * QS_B + 2 * QT_B + 4 * KT_B + 4 * TW_B + wave * PT_B);
+    // dK / dV of the tile: a lane owns ONE key (accumulator column) and, per register quad, 4 consecutive d: 16-byte pieces
+    // (accumulate_dkv: added to what is there -- the keys / values of weight-tied layers collect their gradient over the
+    // layers in place, instead of through one 1-GB elementwise add per layer)
+    if (j_ok) {
+      float* dkp = dk + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+      float* dvp = dv + b * g.k_bs + (long long)j * g.k_rs + h * BD;
 #pragma unroll
-      for (int which = 0; which < 2; ++which) {
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int d = 8 * q4 + 4 * half;            // att_acc_row(4 q4 + 0..3, half) = d + 0..3
+        float4 o[4] = {make_float4(dk0[4 * q4], dk0[4 * q4 + 1], dk0[4 * q4 + 2], dk0[4 * q4 + 3]),
+                       make_float4(dk1[4 * q4], dk1[4 * q4 + 1], dk1[4 * q4 + 2], dk1[4 * q4 + 3]),
+                       make_float4(dv0[4 * q4], dv0[4 * q4 + 1], dv0[4 * q4 + 2], dv0[4 * q4 + 3]),
+                       make_float4(dv1[4 * q4], dv1[4 * q4 + 1], dv1[4 * q4 + 2], dv1[4 * q4 + 3])};
+        float4* gp[4] = {reinterpret_cast<float4*>(dkp + d), reinterpret_cast<float4*>(dkp + 32 + d),
+                         reinterpret_cast<float4*>(dvp + d), reinterpret_cast<float4*>(dvp + 32 + d)};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int d = att_acc_row(r, half);
-          patch[col * PLD + d] = which == 0 ? dk0[r] : dv0[r];
-          patch[col * PLD + 32 + d] = which == 0 ? dk1[r] : dv1[r];
-        }
-        float* outp = (which == 0 ? dk : dv) + b * g.k_bs + h * BD;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int key = (lane >> 4) + 4 * i, d4 = (lane & 15) * 4;
-          float4 v = *reinterpret_cast<const float4*>(patch + key * PLD + d4);
-          if (j0 + key < g.n_k) {
-            float4* gp = reinterpret_cast<float4*>(outp + (long long)(j0 + key) * g.k_rs + d4);
-            if (accumulate_dkv) {
-              const float4 o = *gp;
-              v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
-            }
-            *gp = v;
+        for (int w4 = 0; w4 < 4; ++w4) {
+          if (accumulate_dkv) {
+            const float4 old = *gp[w4];
+            o[w4].x += old.x, o[w4].y += old.y, o[w4].z += old.z, o[w4].w += old.w;
           }
+          *gp[w4] = o[w4];
         }
       }
     }
   }
   // ---- add the four waves' dQ^T partials (wave order) and write dq; two query tiles per round through the Q / dO images ----
-  float* scratch = reinterpret_cast<float*>(smem);     // 2 x [wave][d 64][i 32] floats = 64 KB <= 2 QS_B + 2 QT_B
-  static_assert(2 * 4 * 64 * 32 * 4 <= 2 * QS_B + 2 * QT_B, "dQ scratch does not fit");
+  // 2 x [wave][query 32][d 64 (+1)] floats: a lane writes its query's column (pitch 65 words: 32 lanes on 32 banks), the sum
+  // reads run along d -- the [d][query] form this replaces was read 32-way bank-conflicted (PMC: 84 % of the kernel's LDS
+  // cycles were conflict cycles)
+  float* scratch = reinterpret_cast<float*>(smem);
+  static_assert(2 * 4 * 32 * SLD * 4 <= SMEM_B, "dQ scratch does not fit");
   for (int round = 0; round < 2; ++round) {
     __syncthreads();   // everyone is done with the Q / dO images (first round) or with the previous round's sums
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = 2 * round + u;
-      float* dst = scratch + u * (4 * 64 * 32);
+      float* dst = scratch + u * (4 * 32 * SLD);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(wave * 64 + 32 * t + att_acc_row(r, half)) * 32 + col] = dqa[it][t][r];
+        for (int r = 0; r < 16; ++r) dst[(wave * 32 + col) * SLD + 32 * t + att_acc_row(r, half)] = dqa[it][t][r];
     }
     __syncthreads();
     for (int idx = tid; idx < 2 * 32 * 64; idx += 256) {
@@ -397,9 +408,9 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       const int il = rem / 64, d = rem % 64;
       const int i = (2 * round + u) * 32 + il;
       if (i < g.n_q) {
-        const float* src = scratch + u * (4 * 64 * 32);
-        const float sum = ((src[(0 * 64 + d) * 32 + il] + src[(1 * 64 + d) * 32 + il]) + src[(2 * 64 + d) * 32 + il]) +
-                          src[(3 * 64 + d) * 32 + il];
+        const float* src = scratch + u * (4 * 32 * SLD);
+        const float sum = ((src[(0 * 32 + il) * SLD + d] + src[(1 * 32 + il) * SLD + d]) + src[(2 * 32 + il) * SLD + d]) +
+                          src[(3 * 32 + il) * SLD + d];
         dq[b * g.q_bs + (long long)i * g.q_rs + h * BD + d] = sum;
       }
     }
