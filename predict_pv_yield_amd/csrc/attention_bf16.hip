@@ -9,9 +9,13 @@
 // query's scores), but a contraction of 64 is 4 instructions of 8 passes instead of 32 instructions of 16 passes: 16x
 // less matrix-pipe time, which makes staging and the softmax arithmetic the bound.  Operand layouts of the 32x32x16
 // instruction: A lane (row = lane % 32, k = 8 (lane / 32) + 0..7), B lane (k = 8 (lane / 32) + 0..7, column = lane % 32):
-// every operand is 8 CONSECUTIVE elements, one ds_read_b128 from a bf16 LDS image.  Where the contraction runs over an
-// accumulator's rows (P, dS as B operands straight from registers) the other operand is staged TRANSPOSED with its
-// contraction index permuted into the accumulator's row order (att_pos).
+// every operand is 8 CONSECUTIVE elements, one ds_read_b128 from a row-major bf16 LDS image.  Where the contraction runs
+// over an accumulator's rows (P, dS go from registers straight into the B operand) the other operand is needed TRANSPOSED
+// and in the accumulator's row order: contraction slots 8 half + 0..7 of step st are rows 16 st + 4 half + {0..3, 8..11},
+// i.e. two runs of four consecutive rows -- exactly what two ds_read_b64_tr_b16 (the transposing LDS read: a 16-lane
+// group fetches a 4-row x 16-column block and every lane receives one column) deliver from the SAME row-major image.
+// (Round 2 first kept separate transposed images filled by 2-byte scatter stores: PMC showed 84 % of the backward's LDS
+// cycles as bank conflicts; the largest single source was the dQ reduction scratch, read 32-way conflicted.)
 #include "pv_common.h"
 
 namespace pv {
@@ -21,8 +25,7 @@ typedef float v16f_b __attribute__((ext_vector_type(16)));
 constexpr int BD = 64;         // head dimension
 constexpr int BTJ = 32;        // keys per tile
 constexpr int B_KLD = 72;      // bf16 per row of a [rows][64 d] image (144 B: 16-byte aligned rows, banks rotate by 36 words)
-constexpr int B_TLD = 40;      // bf16 per row of a [.][32] transposed tile (80 B)
-constexpr int B_QLD = 136;     // bf16 per row of the [64 d][128 queries] transposed images (272 B)
+constexpr int B_TLD = 40;      // bf16 per row of a [.][32] tile (80 B)
 
 struct AttnGeomB {
   int n_q, n_k, heads;
@@ -31,12 +34,6 @@ struct AttnGeomB {
 };
 
 __device__ __forceinline__ int att_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-// position of row j (0..31) of a 32-row accumulator tile in contraction order: register r = 8 st + t of lane-half h holds
-// row att_acc_row(r, h); slot = 16 st + 8 h + t
-__device__ __forceinline__ int att_pos(int j) {
-  const int r = (j & 3) + 4 * (j >> 3), h = (j >> 2) & 1;
-  return 16 * (r >> 3) + 8 * h + (r & 7);
-}
 __device__ __forceinline__ bf16x8 att_pack8(const float (&x)[8]) {
   u32x4 w;
 #pragma unroll
@@ -59,8 +56,17 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
                                                       float* __restrict__ lse, AttnGeomB g, int n_splits, int keys_per_split,
                                                       float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[BTJ * B_KLD];   // [key][d]
-  __shared__ __attribute__((aligned(16))) uint16_t Vt[BD * B_TLD];    // [d][att_pos(key)]
+  __shared__ __attribute__((aligned(16))) uint16_t Vs[BTJ * B_KLD];   // [key][d]; read transposed (ds_read_b64_tr_b16) for V^T
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tr_qi = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4_f;
+  typedef __attribute__((ext_vector_type(8))) short s16x8_f;
+  auto tr8 = [&](const uint16_t* img, int ld, int row_lo, int row_hi, int colbase) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_f*)(img + (row_lo + tr_qi) * ld + colbase + tr_col));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_f*)(img + (row_hi + tr_qi) * ld + colbase + tr_col));
+    const s16x8_f v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int n_qt = (g.n_q + 127) / 128;
@@ -83,7 +89,6 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
 
   // staging: thread t moves 8 floats of K and of V of the 32 x 64 tile: key t / 8, d = 8 (t % 8) ..
   const int st_row = tid >> 3, st_col = (tid & 7) * 8;
-  const int st_pos = att_pos(st_row);
   f32x4 k0, k1, v0, v1;
   auto load_tile = [&](int j0) {
     const int j = j0 + st_row;
@@ -101,8 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       const float kx[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
       *reinterpret_cast<bf16x8*>(Ks + st_row * B_KLD + st_col) = att_pack8(kx);
       const float vx[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) Vt[(st_col + e) * B_TLD + st_pos] = f32_to_bf16_bits(vx[e]);
+      *reinterpret_cast<bf16x8*>(Vs + st_row * B_KLD + st_col) = att_pack8(vx);
     }
     __syncthreads();
     if (j0 + BTJ < key_hi) load_tile(j0 + BTJ);
@@ -142,10 +146,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       const float px[8] = {s[8 * st], s[8 * st + 1], s[8 * st + 2], s[8 * st + 3], s[8 * st + 4], s[8 * st + 5], s[8 * st + 6],
                            s[8 * st + 7]};
       const bf16x8 pb = att_pack8(px);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Vt + col * B_TLD + 16 * st + 8 * half), pb,
-                                                     acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-          *reinterpret_cast<const bf16x8*>(Vt + (32 + col) * B_TLD + 16 * st + 8 * half), pb, acc1, 0, 0, 0);
+      // contraction slots 8 half + 0..7 of step st = keys 16 st + 4 half + {0..3, 8..11} of the tile (accumulator-row order)
+      const int k_lo = 16 * st + 4 * half;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Vs, B_KLD, k_lo, k_lo + 8, 0), pb, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Vs, B_KLD, k_lo, k_lo + 8, 32), pb, acc1, 0, 0, 0);
     }
   }
   if (n_splits > 1) {
