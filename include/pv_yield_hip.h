@@ -314,11 +314,13 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
 /* The same pass ALSO produces dx = (dy ⊙ (y>0)) · W (bf16 [M,K], may be NULL) from the pre-update weights it streams, rounded
  * to bf16 as the operand copy held them during the forward: fc1's whole backward in one pass over the matrix (m <= 32,
  * n <= 128) and db[N] = column sums of dy ⊙ (y>0) (may be NULL).  Parameters / moments / operand copy are bit-identical
- * to pv_linear_wgrad_adam_bf16. */
+ * to pv_linear_wgrad_adam_bf16.  gate_dx_by_x != 0: dx is also multiplied by (x > 0) -- x being a ReLU output, that is the
+ * ReLU derivative of the layer that produced x (the last Conv3d of model.py:117-120), applied here instead of by the
+ * consumer of dx. */
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param,
                                  float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db,
                                  int32_t m, int32_t n, int64_t k, double lr, double beta1, double beta2, double eps,
-                                 int32_t step, void* stream);
+                                 int32_t step, int32_t gate_dx_by_x, void* stream);
 
 /* Data-parallel wire format for fc1's gradient (SURVEY.md §7.2 "keep bf16 grads on the wire"): the weight gradient is
  * written once as bf16 [N,K] (half the bytes of the f32 gradient on HBM and on xGMI), all-reduced by RCCL in bf16,

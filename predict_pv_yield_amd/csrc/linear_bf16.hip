@@ -362,7 +362,7 @@ constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed 
 __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
     int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
-    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad) {
+    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad, int gate_dx) {
   __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g = dy (.) relu'  [b][n], zero padded
   __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
   // the x tile [b][k] lives in the first 8.5 KB of wt until the gradient tile is formed (wt is written after that), and the
@@ -517,8 +517,18 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   __syncthreads();
   for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks: 256 contiguous bytes per row of dx
     const int b = i / (FD_KT / 8), c = i - b * (FD_KT / 8);
-    if (b < m && k0 + 8 * c < k)
-      *reinterpret_cast<u32x4*>(dx + (size_t)b * k + k0 + 8 * c) = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * c);
+    if (b < m && k0 + 8 * c < k) {
+      u32x4 o = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * c);
+      if (gate_dx) {
+        // x is a ReLU output: (x > 0) is its producer's ReLU derivative.  Applying it here (x of this tile is L2-resident)
+        // hands the producer an already-gated gradient: the NCDHW -> NDHWC repack that follows reads dx only, not dx + x
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          o[q] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, relu_pair01(xv[q])) * (u16x2_t){0xffff, 0xffff});
+      }
+      *reinterpret_cast<u32x4*>(dx + (size_t)b * k + k0 + 8 * c) = o;
+    }
   }
 }
 
@@ -933,7 +943,8 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
 
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
                                  float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
-                                 int64_t k, double lr, double beta1, double beta2, double eps, int32_t step, void* stream) {
+                                 int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
+                                 int32_t gate_dx_by_x, void* stream) {
   PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_dx_adam_bf16: null pointer");
   PV_REQUIRE(m > 0 && m <= 32 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
              "pv_linear_wgrad_dx_adam_bf16: built for m <= 32 rows of x and n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
@@ -944,7 +955,7 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
                  (float)(-(lr / bc1))};
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
-                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad);
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
 }
 

@@ -144,8 +144,9 @@ class Conv3dReLUBF16(torch.autograd.Function):
         c_in, c_out, padding, relu, y_ncdhw, has_bias, x_is_relu_output, dy_pregated = ctx.cfg
         dy = dy.contiguous()
         if y_ncdhw:
-            # fc1 hands back the gradient in flatten (NCDHW) order: gate + transpose in one pass
-            dy = K.repack_gate_ncdhw_to_ndhwc_bf16(dy, y)
+            # fc1 hands back the gradient in flatten (NCDHW) order: gate + transpose in one pass (transpose only when the
+            # fc1 kernel already applied this layer's ReLU derivative)
+            dy = K.repack_gate_ncdhw_to_ndhwc_bf16(dy, None if _take_pregated(dy) else y)
             gate = None
         elif dy_pregated:
             gate = None   # the consumer's dgrad epilogue already applied this layer's ReLU derivative
@@ -221,11 +222,29 @@ def bf16_shadow_of(weight: torch.Tensor) -> torch.Tensor:
     return shadow
 
 
+# dx tensors that already carry their producer's ReLU derivative (keyed by storage address, valid inside one backward pass):
+# the fc1 single-pass kernel can apply (x > 0) while it stores dx, and the last conv layer's backward then repacks without
+# reading its activation again
+_PREGATED_DX = {}
+
+
+def _mark_pregated(t: torch.Tensor) -> None:
+    _PREGATED_DX[t.data_ptr()] = torch._C._current_graph_task_id()
+
+
+def _take_pregated(t: torch.Tensor) -> bool:
+    task = _PREGATED_DX.pop(t.data_ptr(), None)
+    return task is not None and task == torch._C._current_graph_task_id() and task >= 0
+
+
 class LinearBF16(torch.autograd.Function):
-    """fc1: x bf16 [B,K] . bf16(weight)[N,K]^T, f32 accumulate; dw/db f32, dx bf16."""
+    """fc1: x bf16 [B,K] . bf16(weight)[N,K]^T, f32 accumulate; dw/db f32, dx bf16.
+    x_is_relu_output: x = relu(...) of the producing layer, so (x > 0) is that layer's ReLU derivative; the fused backward
+    then applies it to dx itself and marks the tensor (see _PREGATED_DX)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, x_is_relu_output=False):
+        ctx.x_is_relu_output = bool(x_is_relu_output)
         x = x.contiguous()
         wb = bf16_shadow_of(weight)
         y = K.linear_fwd_bf16(x, wb, bias.contiguous() if bias is not None else None, relu)
@@ -242,11 +261,14 @@ class LinearBF16(torch.autograd.Function):
         mode = getattr(weight, "_pv_grad_mode", "autograd")
         if mode == "fused":
             fused = getattr(weight, "_pv_fused_backward", None)
-            out = fused(x, dy, y, ctx.needs_input_grad[0], ctx.has_bias) if fused is not None else None
+            out = (fused(x, dy, y, ctx.needs_input_grad[0], ctx.has_bias, gate_dx=ctx.x_is_relu_output)
+                   if fused is not None else None)
             if out is not None:
                 # HipAdam owns this parameter (single process): dx, db, the weight gradient and its Adam update came out of
                 # ONE pass over the matrix; nothing is left for step()
-                return out[0], None, out[1], None
+                if ctx.x_is_relu_output:
+                    _mark_pregated(out[0])
+                return out[0], None, out[1], None, None
         dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=(mode == "autograd"))
         if mode == "fused":
             # HipAdam owns this parameter (single process): hand it (x, dy, relu mask); the weight gradient is formed
@@ -271,7 +293,7 @@ class LinearBF16(torch.autograd.Function):
                 cb(gb, weight)              # sets weight._pv_grad_shard
             else:
                 weight._pv_grad_bf16 = gb   # single process: nothing to scatter
-        return dx, dw, (db if ctx.has_bias else None), None
+        return dx, dw, (db if ctx.has_bias else None), None, None
 
 
 def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False, x_is_relu_output=False,
@@ -285,8 +307,8 @@ def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncd
     return (y, mask) if want_relu_mask else y
 
 
-def linear_bf16(x, weight, bias, relu=False):
-    return LinearBF16.apply(x, weight, bias, relu)
+def linear_bf16(x, weight, bias, relu=False, x_is_relu_output=False):
+    return LinearBF16.apply(x, weight, bias, relu, x_is_relu_output)
 
 
 class Conv3dGeneralF32(torch.autograd.Function):

@@ -495,9 +495,10 @@ def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_
 
 
 def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
-                              betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False):
+                              betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False, gate_dx_by_x=False):
     """fc1's whole backward in ONE pass over the matrix: weight gradient applied by Adam in place (as
-    linear_wgrad_adam_bf16, bit-identical) AND dx = (dy ⊙ (y>0)) . W_old (bf16 [M, K]) from the weights it streams."""
+    linear_wgrad_adam_bf16, bit-identical) AND dx = (dy ⊙ (y>0)) . W_old (bf16 [M, K]) from the weights it streams.
+    gate_dx_by_x: dx is also multiplied by (x > 0), the ReLU derivative of the layer that produced x."""
     require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow)
     m, k = x_bf16.shape
     n = param.shape[0]
@@ -505,7 +506,8 @@ def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf
     db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
     check(get_lib().pv_linear_wgrad_dx_adam_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
                                                  ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, lr, betas[0], betas[1], eps,
-                                                 step, current_stream_ptr()), "pv_linear_wgrad_dx_adam_bf16")
+                                                 step, int(bool(gate_dx_by_x)), current_stream_ptr()),
+          "pv_linear_wgrad_dx_adam_bf16")
     return (dx, db) if need_db else dx
 
 

@@ -47,7 +47,7 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
                 out, mask = out
             c_in = channels
         out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
-        return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True)
+        return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True, x_is_relu_output=True)   # out = relu(last conv)
     out = data
     for layer in convs:
         out = Fn.conv3d_relu_f32(out, layer.weight, layer.bias, tuple(padding), relu=True)

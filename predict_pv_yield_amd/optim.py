@@ -109,7 +109,7 @@ class HipAdam(torch.optim.Optimizer):
         return eager
 
     def _make_fused_backward(self, p):
-        def fused(x, dy, y, need_dx, need_db):
+        def fused(x, dy, y, need_dx, need_db, gate_dx=False):
             """(dx, db) of the layer, with the Adam update of p applied in the same pass; None if the shape is not covered
             (the caller then takes the two-kernel path) or the switch is off."""
             from .functional import bf16_shadow_of
@@ -125,7 +125,7 @@ class HipAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 out = K.linear_wgrad_dx_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                                   int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"],
-                                                  need_dx=True, need_db=need_db)
+                                                  need_dx=True, need_db=need_db, gate_dx_by_x=gate_dx)
             p._pv_applied = True
             return out if need_db else (out, None)
         return fused

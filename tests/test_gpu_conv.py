@@ -437,6 +437,15 @@ def test_fused_wgrad_dx_adam_single_pass(device, m, n, k):
         d = (dx.float() - dx_ref.float()).abs()
         scale = dx_ref.float().abs().max().item()
         assert d.max().item() <= 2 ** -7 * scale and (d > 0).float().mean().item() < 0.02, (d.max().item(), scale)
+    # gate_dx_by_x: the same dx with (x > 0) applied (x as a ReLU output: some zeros, no negatives), bit for bit
+    xr = torch.relu(x.float()).to(torch.bfloat16)
+    pc, mc, vc, sc = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), p0.to(torch.bfloat16)
+    pd, md, vd, sd = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), p0.to(torch.bfloat16)
+    dx_plain = K.linear_wgrad_dx_adam_bf16(xr, dy, y, pc, mc, vc, sc, 1, lr=5e-4)
+    dx_gated = K.linear_wgrad_dx_adam_bf16(xr, dy, y, pd, md, vd, sd, 1, lr=5e-4, gate_dx_by_x=True)
+    assert torch.equal(pc, pd) and torch.equal(sc, sd)
+    assert torch.equal(dx_gated, torch.where(xr > 0, dx_plain, torch.zeros_like(dx_plain)))
+    assert (xr == 0).any() and (dx_gated == 0).sum() > (dx_plain == 0).sum()
 
 
 def test_bf16_gradient_wire_format(device):
