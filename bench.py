@@ -281,6 +281,43 @@ def measure_config3(dev, b, history_minutes):
     return out
 
 
+def measure_graph_step(dev, b, history_minutes, steps=20):
+    """The same train step captured ONCE as a HIP graph (graphs.GraphedTrainStep: forward + NMAE + backward + HipAdam with
+    its step counter and bias corrections in device memory) and replayed: what is left when no Python, autograd or launch
+    work sits between the kernels.  `replay_ms` replays on the resident batch (the headline's condition);
+    `with_batch_copy_ms` copies a fresh batch into the graph's static input first."""
+    from predict_pv_yield_amd.graphs import GraphedTrainStep
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+    torch.manual_seed(518)
+    model = Model(**MODEL_KW, history_minutes=history_minutes, precision="bf16").to(dev)
+    model.batch_size = max(model.batch_size, b)
+    t = model.history_len_5 + model.forecast_len_5 + 1
+    g = torch.Generator(device=dev).manual_seed(518)
+    batch = {"satellite": {"data": torch.randn(b, 11, t, 64, 64, generator=g, device=dev)},
+             "pv": {"pv_yield": torch.rand(b, t, 128, generator=g, device=dev)}}
+    opt = HipAdam(model.parameters(), lr=5e-4, capturable=True)
+    step = GraphedTrainStep(model, opt, batch, warmup=3)
+    for _ in range(3):
+        step.graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.graph.replay()
+    torch.cuda.synchronize()
+    d = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(batch)
+    torch.cuda.synchronize()
+    d2 = (time.perf_counter() - t0) / steps
+    out = {"replay_ms": round(d * 1e3, 3), "samples_per_s": round(b / d, 1), "with_batch_copy_ms": round(d2 * 1e3, 3),
+           "loss_after": round(float(step.static_loss), 6), "optimizer_steps_on_device": opt.device_step(),
+           "what": "forward + NMAE + backward + Adam of the headline step as ONE captured HIP graph, replayed"}
+    del step, model, opt
+    return out
+
+
 def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10):
     """The same bf16 train step at the other per-GPU batch sizes of SURVEY.md §8d: the fc1 update (0.6 ms) is a fixed cost
     per step, so samples/s grows with the batch."""
@@ -676,6 +713,8 @@ def main():
                 out["config3"] = measure_config3(dev, b, args.history_minutes)
                 torch.cuda.empty_cache()
                 if args.precision == "bf16":
+                    out["hip_graph_step"] = measure_graph_step(dev, b, args.history_minutes)
+                    torch.cuda.empty_cache()
                     out["batch_sweep"] = measure_batch_sweep(dev, args.history_minutes)
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()

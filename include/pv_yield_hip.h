@@ -341,6 +341,17 @@ typedef struct pv_adam_tensor {
 } pv_adam_tensor;
 int pv_adam_step_multi_f32(const pv_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
                            double eps, int32_t step, float grad_scale, void* stream);
+/* The same Adam step with its six scalars (1-b1, b2, 1-b2, sqrt(1-b2^t), eps, -lr/(1-b1^t)) and the step counter t in DEVICE
+ * memory: pv_adam_scalars_advance increments t and recomputes them (one thread), the `_dev` kernels read them.  This is
+ * the form a captured HIP graph of the whole train step replays (base_model.py:255-257 stepped every replay; kernel
+ * arguments are frozen at capture, device memory is not). */
+int pv_adam_scalars_advance(float* scalars_dev /* [6] */, int32_t* step_dev, double lr, double beta1, double beta2, double eps,
+                            void* stream);
+int pv_adam_step_multi_dev_f32(const pv_adam_tensor* tensors, int32_t n_tensors, const float* scalars_dev, float grad_scale,
+                               void* stream);
+int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                                     float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
+                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, void* stream);
 
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,

@@ -352,8 +352,28 @@ struct AdamTable {
   int n_tensors;
 };
 
+// one thread: step <- step + 1 and the six scalars every Adam kernel of that step reads (the host computes the same numbers
+// for the by-value form; here they live in device memory so that a captured HIP graph can be replayed step after step)
+__global__ void adam_scalars_advance_kernel(float* __restrict__ scalars, int* __restrict__ step, double lr, double beta1,
+                                            double beta2, double eps) {
+  const int s = *step + 1;
+  *step = s;
+  const double bc1 = 1.0 - pow(beta1, (double)s), bc2 = 1.0 - pow(beta2, (double)s);
+  scalars[0] = (float)(1.0 - beta1);
+  scalars[1] = (float)beta2;
+  scalars[2] = (float)(1.0 - beta2);
+  scalars[3] = (float)sqrt(bc2);
+  scalars[4] = (float)eps;
+  scalars[5] = (float)(-(lr / bc1));
+}
+
 __global__ __launch_bounds__(256) void adam_step_multi_f32(AdamTable tab, float one_minus_b1, float beta2, float one_minus_b2,
-                                                            float bc2_sqrt, float eps, float neg_step_size, float grad_scale) {
+                                                            float bc2_sqrt, float eps, float neg_step_size, float grad_scale,
+                                                            const float* __restrict__ ad_dev) {
+  if (ad_dev) {   // scalars of this step from device memory (pv_adam_scalars_advance): the graph-replayable form
+    one_minus_b1 = ad_dev[0], beta2 = ad_dev[1], one_minus_b2 = ad_dev[2], bc2_sqrt = ad_dev[3], eps = ad_dev[4];
+    neg_step_size = ad_dev[5];
+  }
   int ti = 0;
   while (ti + 1 < tab.n_tensors && (int)blockIdx.x >= tab.blk0[ti + 1]) ++ti;
   const pv_adam_tensor T = tab.t[ti];
@@ -526,33 +546,63 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
   return check_launch("pv_adam_step_f32");
 }
 
+static int adam_multi_table(const pv_adam_tensor* tensors, int32_t n_tensors, AdamTable* tab, int* blocks_out, const char* who) {
+  PV_REQUIRE(tensors && n_tensors > 0 && n_tensors <= PV_ADAM_MAX_TENSORS, PV_EINVAL, "%s: 1..%d tensors per call", who,
+             PV_ADAM_MAX_TENSORS);
+  int blocks = 0;
+  tab->n_tensors = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const pv_adam_tensor& t = tensors[i];
+    PV_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, PV_EINVAL, "%s: null pointer in tensor %d", who, i);
+    PV_REQUIRE(((uintptr_t)t.param % 16 == 0) && ((uintptr_t)t.grad % 16 == 0) && ((uintptr_t)t.exp_avg % 16 == 0) &&
+                   ((uintptr_t)t.exp_avg_sq % 16 == 0) && ((uintptr_t)t.bf16_shadow % 8 == 0),
+               PV_EINVAL, "%s: buffers of tensor %d must be 16-byte aligned", who, i);
+    PV_REQUIRE(t.n < (1ull << 31), PV_ESIZE, "%s: tensor %d too large for the multi-tensor path", who, i);
+    if (t.n == 0) continue;
+    tab->t[tab->n_tensors] = t;
+    tab->blk0[tab->n_tensors] = blocks;
+    blocks += (int)((t.n + 1023) / 1024);
+    ++tab->n_tensors;
+  }
+  tab->blk0[tab->n_tensors] = blocks;
+  *blocks_out = blocks;
+  return PV_OK;
+}
+
 int pv_adam_step_multi_f32(const pv_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
                            double eps, int32_t step, float grad_scale, void* stream) {
-  PV_REQUIRE(tensors && n_tensors > 0 && n_tensors <= PV_ADAM_MAX_TENSORS, PV_EINVAL,
-             "pv_adam_step_multi_f32: 1..%d tensors per call", PV_ADAM_MAX_TENSORS);
   PV_REQUIRE(step >= 1, PV_EINVAL, "pv_adam_step_multi_f32: step must be >= 1");
   AdamTable tab;
   int blocks = 0;
-  tab.n_tensors = 0;
-  for (int i = 0; i < n_tensors; ++i) {
-    const pv_adam_tensor& t = tensors[i];
-    PV_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, PV_EINVAL, "pv_adam_step_multi_f32: null pointer in tensor %d", i);
-    PV_REQUIRE(((uintptr_t)t.param % 16 == 0) && ((uintptr_t)t.grad % 16 == 0) && ((uintptr_t)t.exp_avg % 16 == 0) &&
-                   ((uintptr_t)t.exp_avg_sq % 16 == 0) && ((uintptr_t)t.bf16_shadow % 8 == 0),
-               PV_EINVAL, "pv_adam_step_multi_f32: buffers of tensor %d must be 16-byte aligned", i);
-    PV_REQUIRE(t.n < (1ull << 31), PV_ESIZE, "pv_adam_step_multi_f32: tensor %d too large for the multi-tensor path", i);
-    if (t.n == 0) continue;
-    tab.t[tab.n_tensors] = t;
-    tab.blk0[tab.n_tensors] = blocks;
-    blocks += (int)((t.n + 1023) / 1024);
-    ++tab.n_tensors;
-  }
+  int rc = adam_multi_table(tensors, n_tensors, &tab, &blocks, "pv_adam_step_multi_f32");
+  if (rc) return rc;
   if (tab.n_tensors == 0) return PV_OK;
-  tab.blk0[tab.n_tensors] = blocks;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_step_multi_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab, (float)(1.0 - beta1),
-                     (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-(lr / bc1)), grad_scale);
+                     (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(-(lr / bc1)), grad_scale,
+                     (const float*)nullptr);
   return check_launch("pv_adam_step_multi_f32");
+}
+
+int pv_adam_scalars_advance(float* scalars_dev, int32_t* step_dev, double lr, double beta1, double beta2, double eps,
+                            void* stream) {
+  PV_REQUIRE(scalars_dev && step_dev, PV_EINVAL, "pv_adam_scalars_advance: null pointer");
+  hipLaunchKernelGGL(adam_scalars_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), scalars_dev, step_dev, lr, beta1, beta2,
+                     eps);
+  return check_launch("pv_adam_scalars_advance");
+}
+
+int pv_adam_step_multi_dev_f32(const pv_adam_tensor* tensors, int32_t n_tensors, const float* scalars_dev, float grad_scale,
+                               void* stream) {
+  PV_REQUIRE(scalars_dev, PV_EINVAL, "pv_adam_step_multi_dev_f32: null scalars");
+  AdamTable tab;
+  int blocks = 0;
+  int rc = adam_multi_table(tensors, n_tensors, &tab, &blocks, "pv_adam_step_multi_dev_f32");
+  if (rc) return rc;
+  if (tab.n_tensors == 0) return PV_OK;
+  hipLaunchKernelGGL(adam_step_multi_f32, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab, 0.f, 0.f, 0.f, 1.f, 0.f,
+                     0.f, grad_scale, scalars_dev);
+  return check_launch("pv_adam_step_multi_dev_f32");
 }
 
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,

@@ -362,7 +362,10 @@ constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed 
 __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
     int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
-    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad, int gate_dx) {
+    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad, int gate_dx, const float* __restrict__ ad_dev) {
+  // ad_dev (may be NULL): the six Adam scalars in device memory (pv_adam_scalars_advance) -- the form a captured HIP graph
+  // replays, where the bias corrections must change from replay to replay and kernel arguments cannot
+  if (ad_dev) ad = AdamScalars{ad_dev[0], ad_dev[1], ad_dev[2], ad_dev[3], ad_dev[4], ad_dev[5]};
   __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g = dy (.) relu'  [b][n], zero padded
   __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
   // the x tile [b][k] lives in the first 8.5 KB of wt until the gradient tile is formed (wt is written after that), and the
@@ -955,8 +958,22 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
                  (float)(-(lr / bc1))};
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
-                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x);
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
+}
+
+int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                                     float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
+                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq && adam_scalars_dev, PV_EINVAL,
+             "pv_linear_wgrad_dx_adam_dev_bf16: null pointer");
+  PV_REQUIRE(m > 0 && m <= 32 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
+             "pv_linear_wgrad_dx_adam_dev_bf16: built for m <= 32 rows of x and n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
+  PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_dev_bf16: k must be a multiple of 8");
+  const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
+  hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, AdamScalars{}, gate_dx_by_x, adam_scalars_dev);
+  return check_launch("pv_linear_wgrad_dx_adam_dev_bf16");
 }
 
 int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16, int32_t m,

@@ -1,0 +1,85 @@
+"""HIP-graph capture of a whole train step: forward + loss + backward + optimiser step recorded once on a capture stream
+and replayed per batch -- no Python, autograd or launch work between the ~30 kernels of a step.
+
+What makes the step replayable here:
+  * every kernel of the path launches on torch's current stream through the C ABI, so a `torch.cuda.graph` capture records
+    them like any other work (workspaces that grow during the capture come from the graph's private pool);
+  * `HipAdam(capturable=True)` keeps the step counter and the bias-correction scalars in device memory, advanced by a
+    one-thread kernel inside the graph (kernel ARGUMENTS are frozen at capture; device memory is not);
+  * the batch is copied into static input tensors before each replay; the loss is read from a static output tensor.
+The reference has no counterpart (Lightning drives eager PyTorch); the semantics are those of
+`opt.zero_grad(); loss = model.training_step(batch, i); loss.backward(); opt.step()` (base_model.py:91-99, 255-257).
+"""
+from typing import Any, Dict
+
+import torch
+
+
+def _map_tensors(obj: Any, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _map_tensors(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_map_tensors(v, fn) for v in obj)
+    return obj
+
+
+def _copy_into(dst: Any, src: Any) -> None:
+    if torch.is_tensor(dst):
+        if dst.shape != src.shape or dst.dtype != src.dtype:
+            raise ValueError(f"GraphedTrainStep: batch tensor {tuple(src.shape)} {src.dtype} does not match the captured "
+                             f"{tuple(dst.shape)} {dst.dtype} (a graph replays fixed shapes)")
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_into(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _copy_into(d, s)
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, optimizer, example_batch); loss = step(batch) for every batch of the same shapes.
+
+    `optimizer` must be a HipAdam(capturable=True).  Three eager steps run first on a side stream (they ARE training steps:
+    allocator warm-up, lazily built operand copies and workspaces), then one step is captured."""
+
+    def __init__(self, model, optimizer, example_batch: Dict, batch_idx: int = 0, warmup: int = 3):
+        if not getattr(optimizer, "capturable", False):
+            raise ValueError("GraphedTrainStep needs HipAdam(capturable=True): the by-value Adam step would be frozen at capture")
+        self.model, self.optimizer = model, optimizer
+        self.static_batch = _map_tensors(example_batch, lambda t: t.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager_step(batch_idx)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            loss = model.training_step(self.static_batch, batch_idx)
+            self._backward(loss)
+            optimizer.step()
+        self.static_loss = loss.detach()
+        self.replays = 0
+
+    @staticmethod
+    def _backward(loss):
+        from .functional import unit_gradient
+        loss.backward(unit_gradient(loss))
+
+    def _eager_step(self, batch_idx):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model.training_step(self.static_batch, batch_idx)
+        self._backward(loss)
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, batch: Dict) -> torch.Tensor:
+        _copy_into(self.static_batch, batch)
+        self.graph.replay()
+        self.replays += 1
+        return self.static_loss

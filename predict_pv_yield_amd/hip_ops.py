@@ -470,6 +470,30 @@ def adam_step_multi(items, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, gra
                                          current_stream_ptr()), "pv_adam_step_multi_f32")
 
 
+def adam_scalars_advance(scalars: torch.Tensor, step: torch.Tensor, lr=5e-4, betas=(0.9, 0.999), eps=1e-8) -> None:
+    """step (int32 [1], device) += 1 and scalars (float32 [>= 6], device) = the Adam scalars of that step: what the `_dev`
+    forms of the Adam kernels read, so that a captured HIP graph can replay the optimiser step."""
+    require_cuda(scalars, step)
+    if scalars.dtype != torch.float32 or scalars.numel() < 6 or step.dtype != torch.int32:
+        raise TypeError("adam_scalars_advance: float32 [6] scalars and an int32 step on the device")
+    check(get_lib().pv_adam_scalars_advance(ptr(scalars), ptr(step), lr, betas[0], betas[1], eps, current_stream_ptr()),
+          "pv_adam_scalars_advance")
+
+
+def adam_step_multi_dev(items, scalars: torch.Tensor, grad_scale=1.0):
+    """adam_step_multi with the step's scalars taken from device memory (adam_scalars_advance)."""
+    lib = get_lib()
+    require_cuda(scalars)
+    for i in range(0, len(items), _lib.PV_ADAM_MAX_TENSORS):
+        chunk = items[i:i + _lib.PV_ADAM_MAX_TENSORS]
+        arr = (_lib.AdamTensor * len(chunk))()
+        for j, (p, g, m, v, sh) in enumerate(chunk):
+            require_cuda(p, g, m, v, sh)
+            arr[j] = _lib.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(sh), p.numel())
+        check(lib.pv_adam_step_multi_dev_f32(arr, len(chunk), ptr(scalars), grad_scale, current_stream_ptr()),
+              "pv_adam_step_multi_dev_f32")
+
+
 def conv3d_pack_weights_multi(jobs):
     """jobs: list of (weight f32 [Co,Ci,3,3,3], packed bf16 buffer, transpose_flip); one launch for all of them."""
     lib = get_lib()
@@ -508,6 +532,21 @@ def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf
                                                  ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, lr, betas[0], betas[1], eps,
                                                  step, int(bool(gate_dx_by_x)), current_stream_ptr()),
           "pv_linear_wgrad_dx_adam_bf16")
+    return (dx, db) if need_db else dx
+
+
+def linear_wgrad_dx_adam_dev_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, scalars, need_db=False,
+                                  gate_dx_by_x=False):
+    """linear_wgrad_dx_adam_bf16 with the step's Adam scalars in device memory (adam_scalars_advance)."""
+    require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, scalars)
+    m, k = x_bf16.shape
+    n = param.shape[0]
+    dx = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
+    check(get_lib().pv_linear_wgrad_dx_adam_dev_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
+                                                     ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, ptr(scalars),
+                                                     int(bool(gate_dx_by_x)), current_stream_ptr()),
+          "pv_linear_wgrad_dx_adam_dev_bf16")
     return (dx, db) if need_db else dx
 
 

@@ -25,11 +25,20 @@ class HipAdam(torch.optim.Optimizer):
     #             "autograd" -- plain f32 .grad.
     FUSE_MIN_NUMEL = 1 << 22
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True, overlap_large_update=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True, overlap_large_update=False,
+                 capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("HipAdam: invalid hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.grad_scale = 1.0
+        # capturable: the step counter and the bias-correction scalars live in device memory and are advanced by a
+        # one-thread kernel, so that forward + backward + step can be captured in ONE HIP graph and replayed
+        # (graphs.GraphedTrainStep); the by-value form freezes the step at capture.  One parameter group, every parameter
+        # stepping together.
+        self.capturable = bool(capturable)
+        self._dev_scalars = None
+        self._dev_step = None
+        self._dev_fresh = False
         # fused mode only (opt-in): launch the big layer's wgrad+Adam pass from inside backward on a side stream; step()
         # then only waits for it.  Measured on MI355X (B=32): no gain -- the conv kernels own a CU's whole register file
         # and LDS, so the streaming pass cannot co-reside with them and the two still take turns
@@ -37,6 +46,31 @@ class HipAdam(torch.optim.Optimizer):
         self._side_stream = None
         self._inflight = []
         self.set_large_grad_mode("fused" if fuse_large_linear else "autograd")
+
+    def _advance_device_scalars(self, device) -> torch.Tensor:
+        """The device-side scalars of the CURRENT optimiser step (advanced once per step, by whoever needs them first: the
+        fused fc1 backward inside backward(), or step())."""
+        self._ensure_device_state(device)
+        if not self._dev_fresh:
+            g = self.param_groups[0]
+            K.adam_scalars_advance(self._dev_scalars, self._dev_step, lr=g["lr"], betas=g["betas"], eps=g["eps"])
+            self._dev_fresh = True
+        return self._dev_scalars
+
+    def _ensure_device_state(self, device) -> None:
+        """Creates the device-side counter from the host-side step counts.  Called BEFORE any host counter of the current
+        step is incremented (top of the fused fc1 backward, top of step())."""
+        if not self.capturable or self._dev_scalars is not None:
+            return
+        if len(self.param_groups) != 1:
+            raise RuntimeError("HipAdam(capturable=True) takes one parameter group")
+        steps = [int(st["step"].item()) for st in self.state.values() if "step" in st]
+        self._dev_scalars = torch.zeros(8, dtype=torch.float32, device=device)
+        self._dev_step = torch.full((1,), max(steps) if steps else 0, dtype=torch.int32, device=device)
+
+    def device_step(self) -> int:
+        """Steps taken so far as counted on the device (capturable mode; synchronises)."""
+        return int(self._dev_step.item()) if self._dev_step is not None else 0
 
     def large_params(self):
         return [p for g in self.param_groups for p in g["params"] if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL]
@@ -121,11 +155,17 @@ class HipAdam(torch.optim.Optimizer):
                                    "False))")
             group = self._group_of(p)
             with torch.no_grad():
+                self._ensure_device_state(p.device)
                 st = self._init_state(p)
                 st["step"] += 1
-                out = K.linear_wgrad_dx_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
-                                                  int(st["step"].item()), lr=group["lr"], betas=group["betas"], eps=group["eps"],
-                                                  need_dx=True, need_db=need_db, gate_dx_by_x=gate_dx)
+                if self.capturable:
+                    out = K.linear_wgrad_dx_adam_dev_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
+                                                          self._advance_device_scalars(p.device), need_db=need_db,
+                                                          gate_dx_by_x=gate_dx)
+                else:
+                    out = K.linear_wgrad_dx_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
+                                                      int(st["step"].item()), lr=group["lr"], betas=group["betas"],
+                                                      eps=group["eps"], need_dx=True, need_db=need_db, gate_dx_by_x=gate_dx)
             p._pv_applied = True
             return out if need_db else (out, None)
         return fused
@@ -147,6 +187,10 @@ class HipAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._wait_inflight()
+        if self.capturable:
+            first = next((p for g in self.param_groups for p in g["params"] if p.is_cuda), None)
+            if first is not None:
+                self._ensure_device_state(first.device)
         for p in self.large_params():
             p._pv_applied = False          # the update of this step was applied from inside backward
         for group in self.param_groups:
@@ -162,6 +206,9 @@ class HipAdam(torch.optim.Optimizer):
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
                 st = self._init_state(p)
                 st["step"] += 1
+                if self.capturable and (pending is not None or gs is not None or gb is not None):
+                    raise NotImplementedError("HipAdam(capturable=True) covers the single-process paths (fc1's one-pass "
+                                              "backward + the multi-tensor step); not the deferred / exchanged fc1 gradients")
                 if pending is not None and p.grad is None:
                     from .functional import bf16_shadow_of
                     x, dy, y = pending
@@ -196,10 +243,15 @@ class HipAdam(torch.optim.Optimizer):
                 stepped.append(p)
                 plain.setdefault(int(st["step"].item()), []).append(
                     (p, g.float(), st["exp_avg"], st["exp_avg_sq"], getattr(p, "_pv_bf16_shadow", None)))
-            for step, items in plain.items():
-                K.adam_step_multi(items, step, lr=group["lr"], betas=group["betas"], eps=group["eps"],
-                                  grad_scale=self.grad_scale)
+            if self.capturable and plain:
+                scalars = self._advance_device_scalars(stepped[0].device)
+                K.adam_step_multi_dev([it for items in plain.values() for it in items], scalars, grad_scale=self.grad_scale)
+            else:
+                for step, items in plain.items():
+                    K.adam_step_multi(items, step, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                                      grad_scale=self.grad_scale)
             if stepped:
                 from .functional import refresh_packed_conv_weights
                 refresh_packed_conv_weights(stepped)
+        self._dev_fresh = False        # the next backward / step advances the device-side scalars again
         return loss

@@ -211,3 +211,54 @@ def test_validation_results_csv_and_horizon_metrics_on_the_gpu(device, tmp_path)
     for k, vs in horizon.items():                      # epoch value = mean of the per-batch values
         assert out[f"{k}_epoch"] == pytest.approx(np.mean(vs), rel=1e-5), k
     assert "MSE_forecast_horizon_4/Validation_epoch" not in out
+
+
+@pytest.mark.gpu
+def test_hip_graph_train_step_matches_eager(device):
+    """graphs.GraphedTrainStep (forward + NMAE + backward + HipAdam(capturable=True) in ONE captured HIP graph, replayed per
+    batch) against the same steps taken eagerly with the same device-side Adam scalars: identical losses and parameters,
+    bit for bit, over replays with different batches; and against the default (host-scalar) HipAdam within float rounding."""
+    import copy
+    from predict_pv_yield_amd.graphs import GraphedTrainStep
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+              conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16")
+    torch.manual_seed(3)
+    base = Model(**kw).to(device)
+    g = torch.Generator(device=device).manual_seed(5)
+    batches = [{"satellite": {"data": torch.randn(4, 11, 18, 64, 64, generator=g, device=device)},
+                "pv": {"pv_yield": torch.rand(4, 18, 128, generator=g, device=device)}} for _ in range(6)]
+
+    def run(make_opt, graphed):
+        model = copy.deepcopy(base)
+        opt = make_opt(model)
+        losses = []
+        if graphed:
+            step = GraphedTrainStep(model, opt, batches[0], warmup=3)       # 3 eager steps on batches[0]; the capture only records
+            for b in batches[1:]:
+                losses.append(float(step(b)))
+        else:
+            for b in [batches[0]] * 3 + batches[1:]:
+                opt.zero_grad(set_to_none=True)
+                loss = model.training_step(b, 0)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+            losses = losses[3:]
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in model.parameters()], opt
+
+    cap = lambda m: HipAdam(m.parameters(), lr=5e-4, capturable=True)
+    l_graph, p_graph, o_graph = run(cap, True)
+    l_eager, p_eager, o_eager = run(cap, False)
+    assert l_graph == l_eager, (l_graph, l_eager)
+    for a, b in zip(p_graph, p_eager):
+        assert torch.equal(a, b)
+    assert o_graph.device_step() == o_eager.device_step() == 8
+    l_host, p_host, _ = run(lambda m: HipAdam(m.parameters(), lr=5e-4), False)
+    for a, b in zip(p_graph, p_host):
+        torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
+    assert max(abs(x - y) for x, y in zip(l_graph, l_host)) < 1e-5
