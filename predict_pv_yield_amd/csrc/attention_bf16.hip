@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float scale_log2e = g.scale * 1.44269504088896340736f;
 
   // staging: thread t moves 8 floats of K and of V of the 32 x 64 tile: key t / 8, d = 8 (t % 8) ..
   const int st_row = tid >> 3, st_col = (tid & 7) * 8;
@@ -122,16 +123,16 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = j0 + att_acc_row(r, half) < key_hi;
-      s[r] = ok ? s[r] * g.scale : -INFINITY;
+      s[r] = ok ? s[r] * scale_log2e : -INFINITY;        // scores in log2 units: every exponential below is one v_exp_f32
       m_tile = fmaxf(m_tile, s[r]);
     }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
     const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = expf(m_run - m_new);          // first tile: exp(-inf) = 0 on zero accumulators
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0 on zero accumulators
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += s[r];
     }
     psum += __shfl_xor(psum, 32, 64);
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
         pb[d] = acc0[r];
         pb[32 + d] = acc1[r];
       }
-      if (half == 0) pb[BD] = m_run, pb[BD + 1] = l_run;
+      if (half == 0) pb[BD] = m_run * 0.69314718055994530942f, pb[BD + 1] = l_run;   // maximum back in natural-log units
     }
     return;
   }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       ob[d] = acc0[r] * inv;
       ob[32 + d] = acc1[r] * inv;
     }
-    if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run + logf(l_run);
+    if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run * 0.69314718055994530942f + logf(l_run);
   }
 }
 
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   constexpr int SLD = BD + 1;                                         // dQ reduction scratch pitch (floats)
   constexpr int SMEM_B = 2 * QS_B + 4 * (KR_B + TW_B) > 2 * 4 * 32 * SLD * 4 ? 2 * QS_B + 4 * (KR_B + TW_B) : 2 * 4 * 32 * SLD * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_B];
-  __shared__ float Ls[128], Ds[128];
+  __shared__ __attribute__((aligned(16))) float Ls[128];
+  __shared__ __attribute__((aligned(16))) float Ds[128];
   uint16_t* Qs = reinterpret_cast<uint16_t*>(smem);                       // [query][d]
   uint16_t* Os = reinterpret_cast<uint16_t*>(smem + QS_B);                // dO, same layout
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   const float* vb = v + b * g.k_bs + h * BD;
   const int n_tiles = (g.n_k + BTJ - 1) / BTJ;
   const int n_qt = (g.n_q + 31) / 32;
+  const float scale_log2e = g.scale * 1.44269504088896340736f;
   const int tile0 = blockIdx.x * tiles_per_split;
   const int tile1 = tile0 + tiles_per_split < n_tiles ? tile0 + tiles_per_split : n_tiles;
   dq += blockIdx.x * dq_ss;     // this key range's partial dQ (summed over the splits afterwards)
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   }
   if (tid < 128) {
     const long long li = ((long long)b * g.heads + h) * g.n_q + tid;
-    Ls[tid] = tid < g.n_q ? lse[li] : INFINITY;
+    Ls[tid] = tid < g.n_q ? lse[li] * 1.44269504088896340736f : INFINITY;   // in log2 units: P = exp2(scale log2e S - lse log2e)
     Ds[tid] = tid < g.n_q ? delta[li] : 0.f;
   }
   __syncthreads();
@@ -324,11 +327,16 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
         }
         // P = exp(scale S - lse_i), dS = scale * P * (dP - delta_i); masked keys give P = 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = it * 32 + att_acc_row(r, half);
-          const float pv_ = j_ok ? expf(sc[r] * g.scale - Ls[i]) : 0.f;
-          sc[r] = pv_;                                      // sc now holds P
-          dp[r] = g.scale * pv_ * (dp[r] - Ds[i]);          // dp now holds dS
+        for (int q4 = 0; q4 < 4; ++q4) {     // registers 4 q4 + 0..3 hold queries 32 it + 8 q4 + 4 half + 0..3: one 16-byte read each
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + it * 32 + 8 * q4 + 4 * half);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + it * 32 + 8 * q4 + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q4 + e;
+            const float pv_ = j_ok ? __builtin_amdgcn_exp2f(sc[r] * scale_log2e - l4[e]) : 0.f;   // one v_exp_f32
+            sc[r] = pv_;                                      // sc now holds P
+            dp[r] = g.scale * pv_ * (dp[r] - d4[e]);          // dp now holds dS
+          }
         }
         // dS of this lane's key, queries 8 g + 4 half + 0..3 per register quad g: four packed 8-byte stores into [key][query]
 #pragma unroll
