@@ -37,7 +37,7 @@ __device__ __forceinline__ int att_acc_row(int r, int half) { return (r & 3) + 8
 __device__ __forceinline__ bf16x8 att_pack8(const float (&x)[8]) {
   u32x4 w;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16_bits(x[2 * j]) | ((uint32_t)f32_to_bf16_bits(x[2 * j + 1]) << 16);
+  for (int j = 0; j < 4; ++j) w[j] = pack_bf16_pair(x[2 * j], x[2 * j + 1]);
   return __builtin_bit_cast(bf16x8, w);
 }
 __device__ __forceinline__ bf16x8 att_load8(const float* p, bool ok) {   // 8 consecutive floats (16-byte aligned) -> bf16x8
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
           u32x2 w2;
-          w2[0] = (uint32_t)f32_to_bf16_bits(dp[4 * q4]) | ((uint32_t)f32_to_bf16_bits(dp[4 * q4 + 1]) << 16);
-          w2[1] = (uint32_t)f32_to_bf16_bits(dp[4 * q4 + 2]) | ((uint32_t)f32_to_bf16_bits(dp[4 * q4 + 3]) << 16);
+          w2[0] = pack_bf16_pair(dp[4 * q4], dp[4 * q4 + 1]);
+          w2[1] = pack_bf16_pair(dp[4 * q4 + 2], dp[4 * q4 + 3]);
           *reinterpret_cast<u32x2*>(Tw + col * B_TLD + 8 * q4 + 4 * half) = w2;
         }
         // dV^T += dO^T P, dK^T += Q^T dS: contraction slot 8 half + t of step st is query att_acc_row(8 st + t, half)

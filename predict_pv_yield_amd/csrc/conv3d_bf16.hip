@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float lo = col_ok ? stage_f[i][2 * e][q] : 0.f, hi2 = col_ok ? stage_f[i][2 * e + 1][q] : 0.f;
-              v[e] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi2) << 16);
+              v[e] = pack_bf16_pair(lo, hi2);
             }
             *reinterpret_cast<u32x4*>(slot + f_row[i] * G::ROW_BYTES + scol * G::VOX_BYTES + ((f_sc[i] ^ G::swz(scol)) << 4)) = v;
           }
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             u32x2 o;
-            o[0] = (uint32_t)f32_to_bf16_bits(a[4 * q]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 1]) << 16);
-            o[1] = (uint32_t)f32_to_bf16_bits(a[4 * q + 2]) | ((uint32_t)f32_to_bf16_bits(a[4 * q + 3]) << 16);
+            o[0] = pack_bf16_pair(a[4 * q], a[4 * q + 1]);
+            o[1] = pack_bf16_pair(a[4 * q + 2], a[4 * q + 3]);
             const int slot = (2 * q + hh) ^ (((r >> 1) & 3) << 1);
             *reinterpret_cast<u32x2*>(epi + r * 64 + slot * 8) = o;
           }
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_kernel(const float* _
     for (int k = 0; k < CPAD / 2; ++k) {
       float a = (2 * k < c) ? src[(size_t)(2 * k) * vox_per_sample] : 0.f;
       float bq = (2 * k + 1 < c) ? src[(size_t)(2 * k + 1) * vox_per_sample] : 0.f;
-      words[k] = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(bq) << 16);
+      words[k] = pack_bf16_pair(a, bq);
     }
     u32x4* dst = reinterpret_cast<u32x4*>(xp + (size_t)i * CPAD);
 #pragma unroll

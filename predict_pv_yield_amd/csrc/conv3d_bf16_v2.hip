@@ -217,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_fwd_bf16_v2_kernel(
           for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;
         }
         u32x2 o;
-        o[0] = (uint32_t)f32_to_bf16_bits(a[0]) | ((uint32_t)f32_to_bf16_bits(a[1]) << 16);
-        o[1] = (uint32_t)f32_to_bf16_bits(a[2]) | ((uint32_t)f32_to_bf16_bits(a[3]) << 16);
+        o[0] = pack_bf16_pair(a[0], a[1]);
+        o[1] = pack_bf16_pair(a[2], a[3]);
         const int v = 16 * half + vox;
         const int slot8 = (4 * ch + kg) ^ (((v >> 1) & 3) << 1);  // 8-byte slot = couts (16ch + 4kg ..+3), even-XOR swizzle
         *reinterpret_cast<u32x2*>(epi_pair + orow * 2048 + v * 64 + slot8 * 8) = o;

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
           _Pragma("unroll") for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;                           \
         }                                                                                                         \
         u32x2 o;                                                                                                  \
-        o[0] = (uint32_t)f32_to_bf16_bits(a[0]) | ((uint32_t)f32_to_bf16_bits(a[1]) << 16);                       \
-        o[1] = (uint32_t)f32_to_bf16_bits(a[2]) | ((uint32_t)f32_to_bf16_bits(a[3]) << 16);                       \
+        o[0] = pack_bf16_pair(a[0], a[1]);                       \
+        o[1] = pack_bf16_pair(a[2], a[3]);                       \
         if constexpr (OUT_GATE != 0) {                                                                            \
           o[0] = v3_apply_gate(o[0], gbits >> (4 * (2 * orow + half)));                                           \
           o[1] = v3_apply_gate(o[1], gbits >> (4 * (2 * orow + half) + 2));                                       \

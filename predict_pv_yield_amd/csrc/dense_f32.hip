@@ -315,8 +315,8 @@ __global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __re
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
       f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
-      u32x2 o = {(uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16),
-                 (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16)};
+      u32x2 o = {pack_bf16_pair(v[0], v[1]),
+                 pack_bf16_pair(v[2], v[3])};
       *reinterpret_cast<u32x2*>(dst + i) = o;
     } else {
       for (size_t q = i; q < n; ++q) dst[q] = f32_to_bf16_bits(src[q]);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_kernel(const uint16_t*
       u32x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
+        o[q] = pack_bf16_pair(acc[i][2 * q], acc[i][2 * q + 1]);
       *reinterpret_cast<u32x4*>(dx + (size_t)(m0 + i) * k + k8) = o;
     }
   }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
           u32x4 o;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            o[q] = (uint32_t)f32_to_bf16_bits(acc[i][2 * q]) | ((uint32_t)f32_to_bf16_bits(acc[i][2 * q + 1]) << 16);
+            o[q] = pack_bf16_pair(acc[i][2 * q], acc[i][2 * q + 1]);
           *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dw) + off) = o;
         }
       }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const bool row_ok = 8 * rg + i < n && k_ok;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      wold[i][q] = row_ok ? ((uint32_t)f32_to_bf16_bits(pv[2 * q]) | ((uint32_t)f32_to_bf16_bits(pv[2 * q + 1]) << 16)) : 0u;
+      wold[i][q] = row_ok ? (pack_bf16_pair(pv[2 * q], pv[2 * q + 1])) : 0u;
     if (row_ok) {
       const size_t off = (size_t)(8 * rg + i) * k + k8;
       uint32_t sh[4];

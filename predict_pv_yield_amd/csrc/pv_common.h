@@ -44,6 +44,14 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(uint16_t, b);
 }
+// two floats -> packed bf16 pair (a in the low half): ONE v_cvt_pk_bf16_f32 (RNE), where converting the halves one by one
+// and or-ing them costs a convert, a shift and an or per value
+typedef __attribute__((ext_vector_type(2))) float pv_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 pv_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16_pair(float a, float b) {
+  const pv_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pv_bf16x2_t));
+}
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t u) {
   return __builtin_bit_cast(float, (uint32_t)u << 16);
 }
