@@ -27,6 +27,8 @@ constexpr int BTJ = 32;        // keys per tile
 constexpr int B_KLD = 72;      // bf16 per row of a [rows][64 d] image (144 B: 16-byte aligned rows, banks rotate by 36 words)
 constexpr int B_TLD = 40;      // bf16 per row of a [.][32] tile (80 B)
 
+constexpr bool ATT_BWD_PREFETCH = false;   // backward: next tile's K / V in registers while the current one is processed
+
 struct AttnGeomB {
   int n_q, n_k, heads;
   long long q_bs, q_rs, k_bs, k_rs;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       if (!ok) kn[ks][0] = kn[ks][1] = vn[ks][0] = vn[ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  load_kv(tile0 + wave);   // in flight while Q / dO are staged
+  if (ATT_BWD_PREFETCH) load_kv(tile0 + wave);   // in flight while Q / dO are staged
   // ---- stage Q, dO (zero rows beyond n_q), lse (+inf beyond n_q so that P = 0 there), delta ---------------------------
   for (int idx = tid; idx < 128 * 8; idx += 256) {
     const int i = idx >> 3, c8 = (idx & 7) * 8;
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
   for (int tile = tile0 + wave; tile < tile1; tile += 4) {
+    if (!ATT_BWD_PREFETCH) load_kv(tile);
     const int j0 = tile * BTJ;
     const int j = j0 + col;                       // this lane's key (B-operand column)
     const bool j_ok = j < g.n_k;
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       vreg[ks] = att_pack8(vx);
       *reinterpret_cast<bf16x8*>(Kr + col * B_KLD + 16 * ks + 8 * half) = kreg[ks];   // row-major; read transposed for dQ
     }
-    load_kv(tile + 4);
+    if (ATT_BWD_PREFETCH) load_kv(tile + 4);
     v16f_b dv0, dv1, dk0, dk1;   // dV^T / dK^T of this key tile: rows d, column = key
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv0[r] = 0.f, dv1[r] = 0.f, dk0[r] = 0.f, dk1[r] = 0.f;
