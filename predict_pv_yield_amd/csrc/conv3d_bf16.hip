@@ -192,13 +192,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int scol = f_col[i] + q, swi = w0 + scol;
-            const bool col_ok = swi < w_in;   // a quad may straddle the right image edge: those voxels are zero
             u32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = col_ok ? stage_f[i][2 * e][q] : 0.f, hi2 = col_ok ? stage_f[i][2 * e + 1][q] : 0.f;
-              v[e] = pack_bf16_pair(lo, hi2);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16_pair(stage_f[i][2 * e][q], stage_f[i][2 * e + 1][q]);
+            // a quad may straddle the right image edge: those voxels are zero (one select per chunk, and only where a tile
+            // reaches the edge at all -- it was two selects per element on every tile)
+            if (swi >= w_in) v = (u32x4){0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4*>(slot + f_row[i] * G::ROW_BYTES + scol * G::VOX_BYTES + ((f_sc[i] ^ G::swz(scol)) << 4)) = v;
           }
         }
