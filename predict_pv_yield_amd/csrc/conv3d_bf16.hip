@@ -131,24 +131,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((HAS_GATE ? gate : x) + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
   const uint32_t lane_voff = scol_ok ? (uint32_t)(swi * CPAD + sc * 8) * 2u : INVALID;
-  // X_F32 staging tasks: (tile row 0..9) x (chunk half sc) x (quad of 4 consecutive voxels) = 320 tasks, thread t takes
-  // tasks t and 256 + t (wave 0 only).  A task = 8 dwordx4 loads (8 channel planes x 4 voxels, pad_w == 0) -> 4 chunks.
+  // X_F32 staging tasks: (tile row 0..9) x (quad of 4 consecutive voxels) = 160 tasks of ALL channels, 40 per wave (lanes
+  // 0..39 of every wave), so the four waves stage the same amount.  (The first version dealt 320 half-channel tasks over
+  // 256 threads: wave 0 took two of them per lane and everyone waited for it at the barrier.)  A task = one dwordx4 load
+  // per real channel (4 voxels of its plane, pad_w == 0) -> 4 voxels x 2 chunks of 8 channels.
   const uint32_t f_plane_b = (uint32_t)t_in * h_in * w_in * 4u, f_slice_b = (uint32_t)h_in * w_in * 4u, f_row_b = (uint32_t)w_in * 4u;
-  constexpr int F_PASS = 2;
-  int f_row[F_PASS], f_sc[F_PASS], f_col[F_PASS];
-  if constexpr (X_F32) {
-#pragma unroll
-    for (int i = 0; i < F_PASS; ++i) {
-      const int t = i * 256 + tid;
-      f_row[i] = t >> 5;          // >= TRI: no task
-      f_sc[i] = (t >> 4) & 1;
-      f_col[i] = 4 * (t & 15);    // first tile column of the quad
-    }
-  }
+  constexpr int F_CH = 16;                      // channel slots of a task (c_in_real <= 16 are loaded)
+  const int f_lane = tid & 63;
+  const int f_task = (tid >> 6) * 40 + f_lane;  // valid for f_lane < 40
+  const bool f_has = X_F32 && f_lane < 40;
+  const int f_row = f_task >> 4;                // 0..9
+  const int f_col = 4 * (f_task & 15);          // first tile column of the quad
   const bool own_last_row = (h0 + TR >= h_out), own_last_col = (w0 + TW_VALID >= w_out), own_last_t = (tc1 >= t_out);
 
   u32x4 stage[X_F32 ? 1 : G::NLOAD];
-  f32x4 stage_f[X_F32 ? F_PASS : 1][8];
+  f32x4 stage_f[X_F32 ? F_CH : 1];
   u32x4 stage_g[HAS_GATE ? G::NLOAD : 1];
   auto load_slice = [&](int s) {
     // slice index s = input time + pad_t  (s in [tc0, tc1 + 2))
@@ -156,17 +153,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     const bool t_ok = (unsigned)ti < (unsigned)t_in;
     if constexpr (X_F32) {
       const uint32_t toff = t_ok ? (uint32_t)ti * f_slice_b : INVALID;
+      if (f_has) {
+        const int hi = h0 - pad_h + f_row;
+        const bool ok = (unsigned)hi < (unsigned)h_in;
+        const uint32_t base = ok ? toff + (uint32_t)hi * f_row_b + (uint32_t)(w0 + f_col) * 4u : INVALID;
 #pragma unroll
-      for (int i = 0; i < F_PASS; ++i) {
-        if (i == 0 || wave == 0) {   // the second pass holds tasks 256..319 only
-          const int hi = h0 - pad_h + f_row[i];
-          const bool ok = f_row[i] < TRI && (unsigned)hi < (unsigned)h_in;
-          const uint32_t base = ok ? toff + (uint32_t)hi * f_row_b + (uint32_t)(w0 + f_col[i]) * 4u : INVALID;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ch = f_sc[i] * 8 + j;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ch < c_in_real ? base + (uint32_t)ch * f_plane_b : INVALID, 0, 0);
-            stage_f[i][j] = __builtin_bit_cast(f32x4, v);
+        for (int ch = 0; ch < F_CH; ++ch) {
+          if (ch < c_in_real) {        // uniform: absent channels are never fetched
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, base + (uint32_t)ch * f_plane_b, 0, 0);
+            stage_f[ch] = __builtin_bit_cast(f32x4, v);
+          } else {
+            stage_f[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
       }
@@ -186,19 +183,18 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
   auto store_slice = [&](int s) {
     if constexpr (X_F32) {
       unsigned char* slot = lds + (s % 3) * G::SLOT_BYTES;
+      if (f_has) {
 #pragma unroll
-      for (int i = 0; i < F_PASS; ++i) {
-        if ((i == 0 || wave == 0) && f_row[i] < TRI) {
+        for (int q = 0; q < 4; ++q) {
+          const int scol = f_col + q, swi = w0 + scol;
+          const bool col_ok = swi < w_in;   // a quad may straddle the right image edge: those voxels are zero
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int scol = f_col[i] + q, swi = w0 + scol;
+          for (int sc = 0; sc < 2; ++sc) {
             u32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = pack_bf16_pair(stage_f[i][2 * e][q], stage_f[i][2 * e + 1][q]);
-            // a quad may straddle the right image edge: those voxels are zero (one select per chunk, and only where a tile
-            // reaches the edge at all -- it was two selects per element on every tile)
-            if (swi >= w_in) v = (u32x4){0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(slot + f_row[i] * G::ROW_BYTES + scol * G::VOX_BYTES + ((f_sc[i] ^ G::swz(scol)) << 4)) = v;
+            for (int e = 0; e < 4; ++e) v[e] = pack_bf16_pair(stage_f[8 * sc + 2 * e][q], stage_f[8 * sc + 2 * e + 1][q]);
+            if (!col_ok) v = (u32x4){0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(slot + f_row * G::ROW_BYTES + scol * G::VOX_BYTES + ((sc ^ G::swz(scol)) << 4)) = v;
           }
         }
       }
