@@ -229,7 +229,10 @@ _PREGATED_DX = {}
 
 
 def _mark_pregated(t: torch.Tensor) -> None:
-    _PREGATED_DX[t.data_ptr()] = torch._C._current_graph_task_id()
+    task = torch._C._current_graph_task_id()
+    if any(v != task for v in _PREGATED_DX.values()):
+        _PREGATED_DX.clear()          # marks of an earlier backward pass that nobody consumed
+    _PREGATED_DX[t.data_ptr()] = task
 
 
 def _take_pregated(t: torch.Tensor) -> bool:
