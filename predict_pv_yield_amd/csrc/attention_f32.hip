@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ q,
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  const float scale_log2e = g.scale * 1.44269504088896340736f;
 
   // staging: thread t moves 8 floats (two float4) of the 32 x 64 tile: row t / 8, columns 8 (t % 8) ..
   const int st_row = tid >> 3, st_col = (tid & 7) * 8;
@@ -88,16 +89,16 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ q,
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const bool ok = j0 + acc_row(r, half) < g.n_k;
-      s[r] = ok ? s[r] * g.scale : -INFINITY;
+      s[r] = ok ? s[r] * scale_log2e : -INFINITY;        // scores in log2 units: every exponential below is one v_exp_f32
       m_tile = fmaxf(m_tile, s[r]);
     }
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
     const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = expf(m_run - m_new);          // first tile: exp(-inf) = 0 on zero accumulators
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0 on zero accumulators
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = expf(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += s[r];
     }
     psum += __shfl_xor(psum, 32, 64);
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32(const float* __restrict__ q,
       ob[d] = acc0[r] * inv;
       ob[32 + d] = acc1[r] * inv;
     }
-    if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run + logf(l_run);
+    if (half == 0) lse[((long long)b * g.heads + h) * g.n_q + i] = m_run * 0.69314718055994530942f + logf(l_run);
   }
 }
 
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
   __shared__ __attribute__((aligned(16))) float Os[128 * AT_LD];        // dO
   __shared__ __attribute__((aligned(16))) float Kw[4][AT_TJ * AT_LD];   // per-wave K tile (A operand of dQ^T = K^T dS^T)
   __shared__ float Tw[4][32 * AB_TS];                                    // per-wave dS tile, read back transposed
-  __shared__ float Ls[128], Ds[128];
+  __shared__ __attribute__((aligned(16))) float Ls[128];
+  __shared__ __attribute__((aligned(16))) float Ds[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
   }
   if (tid < 128) {
     const long long li = ((long long)b * g.heads + h) * g.n_q + tid;
-    Ls[tid] = tid < g.n_q ? lse[li] : INFINITY;
+    Ls[tid] = tid < g.n_q ? lse[li] * 1.44269504088896340736f : INFINITY;   // log2 units: P = exp2(scale log2e S - lse log2e)
     Ds[tid] = tid < g.n_q ? delta[li] : 0.f;
   }
   __syncthreads();
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
       for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
   float* Kt = Kw[wave];
   float* Tt = Tw[wave];
+  const float scale_log2e = g.scale * 1.44269504088896340736f;
   const int n_tiles = (g.n_k + AT_TJ - 1) / AT_TJ;
   const int n_qt = (g.n_q + 31) / 32;
   const int tile0 = blockIdx.x * tiles_per_split;
@@ -244,12 +247,17 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
         }
         // P = exp(scale S - lse_i), dS = scale * P * (dP - delta_i); masked keys give P = 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = it * 32 + acc_row(r, half);
-          const float pv_ = j_ok ? expf(sc[r] * g.scale - Ls[i]) : 0.f;
-          sc[r] = pv_;                                      // sc now holds P
-          dp[r] = g.scale * pv_ * (dp[r] - Ds[i]);          // dp now holds dS
-          Tt[acc_row(r, half) * AB_TS + col] = dp[r];
+        for (int q4 = 0; q4 < 4; ++q4) {     // registers 4 q4 + 0..3 hold queries 32 it + 8 q4 + 4 half + 0..3: one 16-byte read each
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + it * 32 + 8 * q4 + 4 * half);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ds + it * 32 + 8 * q4 + 4 * half);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q4 + e;
+            const float pv_ = j_ok ? __builtin_amdgcn_exp2f(sc[r] * scale_log2e - l4[e]) : 0.f;
+            sc[r] = pv_;                                      // sc now holds P
+            dp[r] = g.scale * pv_ * (dp[r] - d4[e]);          // dp now holds dS
+            Tt[acc_row(r, half) * AB_TS + col] = dp[r];
+          }
         }
         // dV^T += dO^T P, dK^T += Q^T dS: contraction slot kk of lane-half `half` is query acc_row(kk, half)
 #pragma unroll
@@ -287,11 +295,12 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int it = 2 * round + u;
-      float* dst = (u == 0 ? Qs : Os);   // reused as [wave][d 64][i 32] = 4 * 2048 floats <= 128 * 68
+      float* dst = (u == 0 ? Qs : Os);   // reused as [wave][query 32][d 64 (+1)] = 4 * 2080 floats <= 128 * 68: a lane writes
+                                         // its query's column (pitch 65: 32 lanes on 32 banks), the sums read along d
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(wave * 64 + 32 * t + acc_row(r, half)) * 32 + col] = dqa[it][t][r];
+        for (int r = 0; r < 16; ++r) dst[(wave * 32 + col) * 65 + 32 * t + acc_row(r, half)] = dqa[it][t][r];
     }
     __syncthreads();
     for (int idx = tid; idx < 2 * 32 * 64; idx += 256) {
@@ -300,8 +309,8 @@ __global__ __launch_bounds__(256) void attn_bwd_f32(const float* __restrict__ q,
       const int i = (2 * round + u) * 32 + il;
       if (i < g.n_q) {
         const float* src = (u == 0 ? Qs : Os);
-        const float sum = ((src[(0 * 64 + d) * 32 + il] + src[(1 * 64 + d) * 32 + il]) + src[(2 * 64 + d) * 32 + il]) +
-                          src[(3 * 64 + d) * 32 + il];
+        const float sum = ((src[(0 * 32 + il) * 65 + d] + src[(1 * 32 + il) * 65 + d]) + src[(2 * 32 + il) * 65 + d]) +
+                          src[(3 * 32 + il) * 65 + d];
         dq[b * g.q_bs + (long long)i * g.q_rs + h * AT_D + d] = sum;
       }
     }
