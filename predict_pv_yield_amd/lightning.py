@@ -243,8 +243,11 @@ class Trainer:
                  resume_from_checkpoint=None, precision=32, weights_summary=None, progress_bar_refresh_rate=None,
                  profiler=None, limit_train_batches=1.0, limit_val_batches=1.0, limit_test_batches=1.0,
                  num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
-                 default_root_dir=None, log_every_n_steps=50, **unused):
+                 default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, **unused):
         self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
+        # config 3 only (Model(future_frames="optical_flow") fed raw int16 counts): run the optical-flow advection of batch
+        # i+1 on a side HIP stream under the train step of batch i (optical_flow.AdvectingLoader); same batches, bit for bit
+        self.advect_on_side_stream = bool(advect_on_side_stream)
         self.fast_dev_run = bool(fast_dev_run)
         self.callbacks: List[Callback] = list(callbacks or [])
         if isinstance(logger, (list, tuple)):
@@ -390,6 +393,36 @@ class Trainer:
             return None
         return {"train": dm.train_dataloader, "val": dm.val_dataloader, "test": dm.test_dataloader}[which]()
 
+    def _to_device(self, batch, model):
+        """Batch onto the device; raw int16 satellite counts are normalised there (f-3) -- unless the model advects future
+        frames itself (config 3: the optical-flow pipeline works on the COUNTS and normalises inside)."""
+        if getattr(model, "future_frames", None) == "optical_flow":
+            return _move_only(batch, self.device)
+        return _move(batch, self.device)
+
+    def _train_batches(self, loader, model, lim):
+        """The epoch's batches on the device; with advect_on_side_stream (and a model / batch pair of config 3) the advection
+        pipeline of the next batch runs one batch ahead on its own stream."""
+        def moved():
+            for i, batch in enumerate(loader):
+                if lim is not None and i >= lim:
+                    break
+                yield self._to_device(batch, model)
+
+        it = moved()
+        if not (self.advect_on_side_stream and getattr(model, "future_frames", None) == "optical_flow"):
+            return it
+        first = next(it, None)
+        if first is None:
+            return iter(())
+        import itertools
+        rest = itertools.chain([first], it)
+        sat = first.get("satellite") if isinstance(first, dict) else None
+        if not (isinstance(sat, dict) and torch.is_tensor(sat.get("data")) and sat["data"].dtype == torch.int16 and sat["data"].is_cuda):
+            return rest
+        from .optical_flow import AdvectingLoader
+        return iter(AdvectingLoader(rest, n_future=model.forecast_len_5))
+
     @staticmethod
     def _backward(loss):
         """loss.backward() with a cached unit root gradient on the device (no per-step fill / multiply launches)."""
@@ -418,7 +451,7 @@ class Trainer:
             for i, batch in enumerate(loader):
                 if lim is not None and i >= lim:
                     break
-                outputs.append(self._timed(f"{which}_step", step_fn, _move(batch, self.device), i))
+                outputs.append(self._timed(f"{which}_step", step_fn, self._to_device(batch, model), i))
         if epoch_end_fn is not None:
             epoch_end_fn(outputs)
         self._flush_epoch()
@@ -473,10 +506,7 @@ class Trainer:
             model.train()
             loader = self._loader("train", train_dataloaders)
             lim = self._limit("train", loader)
-            for i, batch in enumerate(loader):
-                if lim is not None and i >= lim:
-                    break
-                batch = _move(batch, self.device)
+            for i, batch in enumerate(self._train_batches(loader, model, lim)):
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
@@ -547,7 +577,7 @@ class Trainer:
             for i, batch in enumerate(loader):
                 if self.fast_dev_run and i >= 1:
                     break
-                outs.append(model.predict_step(_move(batch, self.device), i))
+                outs.append(model.predict_step(self._to_device(batch, model), i))
         return outs
 
     def _finish(self):

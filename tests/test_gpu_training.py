@@ -262,3 +262,32 @@ def test_hip_graph_train_step_matches_eager(device):
     for a, b in zip(p_graph, p_host):
         torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
     assert max(abs(x - y) for x, y in zip(l_graph, l_host)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_trainer_advects_on_a_side_stream(device):
+    """Trainer(advect_on_side_stream=True) on config 3 (raw int16 counts -> Model(future_frames="optical_flow")): the same
+    parameters after the same batches as the inline pipeline, bit for bit."""
+    import copy
+    from predict_pv_yield_amd.lightning import Trainer
+    from predict_pv_yield_amd.models.conv3d.model import Model
+
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+              conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16",
+              future_frames="optical_flow")
+    torch.manual_seed(11)
+    base = Model(**kw)
+    g = torch.Generator().manual_seed(12)
+    batches = [{"satellite": {"data": (torch.rand(2, 12, 11, 64, 64, generator=g) * 1023).to(torch.int16)},
+                "pv": {"pv_yield": torch.rand(2, 18, 128, generator=g)}} for _ in range(4)]
+    finals = []
+    for side in (False, True):
+        model = copy.deepcopy(base)
+        trainer = Trainer(gpus=1, max_epochs=1, advect_on_side_stream=side)
+        trainer.fit(model, train_dataloaders=batches)
+        torch.cuda.synchronize()
+        finals.append([p.detach().clone() for p in model.parameters()])
+        assert trainer.global_step == 4
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
