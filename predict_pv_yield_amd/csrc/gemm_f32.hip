@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmK g) {
   const float* __restrict__ A = g.a + z1 * g.a_bs1 + z2 * g.a_bs2;
   const float* __restrict__ B = g.b + z1 * g.b_bs1 + z2 * g.b_bs2;
   float* __restrict__ C = g.c + z1 * g.c_bs1 + z2 * g.c_bs2 + split * g.c_ss;
-  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+  const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;   // row tiles along grid.x (2^31 - 1 of them), column tiles along y
   const int kbeg = split * g.k_chunk;
   const int kend = kbeg + g.k_chunk < g.k ? kbeg + g.k_chunk : g.k;
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   const float* __restrict__ A = g.a + z1 * g.a_bs1 + z2 * g.a_bs2;
   const float* __restrict__ B = g.b + z1 * g.b_bs1 + z2 * g.b_bs2;
   float* __restrict__ C = g.c + z1 * g.c_bs1 + z2 * g.c_bs2 + split * g.c_ss;
-  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+  const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;   // row tiles along grid.x (2^31 - 1 of them), column tiles along y
   const int kbeg = split * g.k_chunk;
   const int kend = kbeg + g.k_chunk < g.k ? kbeg + g.k_chunk : g.k;
 
@@ -504,8 +504,8 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
   g.a_bs1 = d->a_bs1, g.a_bs2 = d->a_bs2, g.b_bs1 = d->b_bs1, g.b_bs2 = d->b_bs2, g.c_bs1 = d->c_bs1, g.c_bs2 = d->c_bs2;
   g.c_ss = d->c_ss;
   g.relu = relu ? 1 : 0;
-  dim3 grid((unsigned)((d->n + G_BN - 1) / G_BN), (unsigned)((d->m + G_BM - 1) / G_BM), (unsigned)zs);
-  PV_REQUIRE(grid.y <= 65535, PV_ESIZE, "pv_gemm_f32: m too large for one launch");
+  dim3 grid((unsigned)((d->m + G_BM - 1) / G_BM), (unsigned)((d->n + G_BN - 1) / G_BN), (unsigned)zs);
+  PV_REQUIRE(grid.y <= 65535, PV_ESIZE, "pv_gemm_f32: n too large for one launch");
   // default: the bf16 x 3 form (f32 accuracy at 3/8 of the matrix-pipe time); PV_GEMM_EXACT_F32=1 keeps the products on the
   // f32 matrix instruction (bit-exact f32 products)
   static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;

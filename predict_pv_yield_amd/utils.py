@@ -58,6 +58,13 @@ def extras(config: DictConfig) -> None:
         return
     log.info("Forcing debugger friendly configuration! <config.trainer.fast_dev_run=True>")
     for section, key, off in _FAST_DEV_RUN_OVERRIDES:
+        if (section, key) == ("trainer", "gpus"):
+            # the reference drops to the CPU for a debug run (utils.py:80-81); the models of this build have no CPU path,
+            # so with an MI355X present the one-batch run stays on it
+            import torch
+            if torch.cuda.is_available():
+                log.info("fast_dev_run: keeping trainer.gpus (the HIP models have no CPU path)")
+                continue
         if config[section].get(key):
             config[section][key] = off
 

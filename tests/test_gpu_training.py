@@ -291,3 +291,21 @@ def test_trainer_advects_on_a_side_stream(device):
         assert trainer.global_step == 4
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("experiment", ["conv3d", "conv3d_optical_flow"])
+def test_shipped_experiments_run_with_their_own_shapes(device, tmp_path, monkeypatch, experiment):
+    """`python run.py experiment=<name> trainer.fast_dev_run=true` as shipped: the model yaml (BASELINE config 2 / 3: T = 18,
+    64 px, 11 channels, batch 32) and the dataset configuration the experiment points at must agree, and a fast_dev_run
+    stays on the GPU (utils.extras)."""
+    from predict_pv_yield_amd import hydra_lite as H
+    from predict_pv_yield_amd import utils
+    from predict_pv_yield_amd.training import train
+    monkeypatch.chdir(tmp_path)
+    cfg = H.compose(os.path.join(ROOT, "configs"), "config",
+                    [f"experiment={experiment}", "trainer.fast_dev_run=true", "~print_config",
+                     f"datamodule.data_path={ROOT}/configs/dataset/conv3d"])
+    utils.extras(cfg)
+    assert cfg.trainer.gpus == 1 and cfg.trainer.fast_dev_run is True
+    train(config=cfg)
