@@ -227,6 +227,44 @@ class OracleConv3dSatNwpModel(nn.Module):
         return self.fc4(out).reshape(batch_size, self.forecast_len)
 
 
+class OracleConv3dNwpModel(nn.Module):
+    """Restatement of predict_pv_yield/models/conv3d/model_nwp.py:14-153: the NWP tower (3x3x3 convolutions, padding
+    (1,0,0)) -> nwp_fc1 -> nwp_fc2 -> fc3 -> fc4.  The id embedding and pv_fc1 are registered (model_nwp.py:112-121)
+    but carry no data in forward (model_nwp.py:127-153).  Pinned against the reference module's own source by
+    tests/golden/make_conv3d_nwp_golden.py."""
+
+    def __init__(self, include_pv_or_gsp_yield_history=True, include_nwp=True, forecast_minutes=30, history_minutes=60,
+                 number_of_conv3d_layers=4, conv3d_channels=32, nwp_image_size_pixels=64, number_nwp_channels=10,
+                 fc1_output_features=128, fc2_output_features=128, fc3_output_features=64, output_variable="gsp_yield",
+                 embedding_dem=16, include_pv_yield_history=True, include_future_satellite=True, emulate_bf16=False):
+        super().__init__()
+        self.emulate_bf16 = emulate_bf16
+        self.number_of_conv3d_layers = number_of_conv3d_layers
+        self.output_variable = output_variable
+        for k, v in timestep_arithmetic(history_minutes, forecast_minutes, output_variable).items():
+            setattr(self, k, v)
+        self.nwp_cnn_output_size = (conv3d_channels * ((nwp_image_size_pixels - 2 * number_of_conv3d_layers) ** 2)
+                                    * (self.forecast_len_60 + self.history_len_60 + 1))
+        for i in range(number_of_conv3d_layers):
+            setattr(self, f"nwp_conv{i}",
+                    nn.Conv3d(number_nwp_channels if i == 0 else conv3d_channels, conv3d_channels, (3, 3, 3), padding=(1, 0, 0)))
+        self.nwp_fc1 = nn.Linear(self.nwp_cnn_output_size, fc1_output_features)
+        self.nwp_fc2 = nn.Linear(fc1_output_features, 128)
+        if embedding_dem:
+            self.pv_system_id_embedding = nn.Embedding(940, embedding_dem)
+        if include_pv_yield_history:
+            self.pv_fc1 = nn.Linear(self.number_of_pv_samples_per_batch * (self.history_len_5 + 1), 128)
+        self.fc3 = nn.Linear(128, fc3_output_features)
+        self.fc4 = nn.Linear(fc3_output_features, self.forecast_len)
+
+    _tower = OracleConv3dSatNwpModel._tower
+
+    def forward(self, nwp):
+        out = F.relu(self.nwp_fc2(self._tower("nwp", nwp.float(), self.nwp_fc1, self.nwp_cnn_output_size)))
+        out = F.relu(self.fc3(out))
+        return self.fc4(out).reshape(nwp.shape[0], self.forecast_len)
+
+
 class OracleConv3dMaxPool(nn.Module):
     """predict_pv_yield/models/perceiver/perceiver_conv3d_nwp_sat.py:42-57: Conv3d(k 3, pad 1) -> MaxPool3d(3, stride
     (1,2,2), pad 1).  Pinned by tests/golden/make_flow_model_golden.py (the reference class itself, under stubs)."""

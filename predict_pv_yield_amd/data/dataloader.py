@@ -5,6 +5,7 @@ data/netcdf_dataset.py) are read from `<data_path>/train` and `<data_path>/test`
 (data/dataloader.py:93-131); cloud download and NetCDF-4 decoding are outside the hot path.
 Under data-parallel training each rank takes a disjoint slice of the batch indices (Lightning's
 replace_sampler_ddp, configs/trainer/all_params.yaml:43): samples are independent, no collective."""
+import logging
 import os
 from typing import Optional
 
@@ -14,6 +15,8 @@ import yaml
 from ..distributed import shard_range
 from ..lightning import LightningDataModule
 from .fake import FakeDataConfiguration, FakeDataset
+
+_LOG = logging.getLogger(__name__)
 
 
 def _identity_collate(x):
@@ -66,8 +69,14 @@ class NetCDFDataModule(LightningDataModule):
                 cfg.number_sat_channels = len(sat["satellite_channels"])
             nwp = inp.get("nwp", {})
             cfg.nwp_image_size_pixels = nwp.get("nwp_image_size_pixels", cfg.nwp_image_size_pixels)
+            if "nwp_channels" in nwp:
+                cfg.number_nwp_channels = len(nwp["nwp_channels"])
             cfg.batch_size = raw.get("process", {}).get("batch_size", cfg.batch_size)
             cfg.seed = raw.get("process", {}).get("seed", cfg.seed)
+        else:
+            _LOG.warning(f"no configuration.yaml under data_path={data_path!r}: using the default shapes "
+                         f"({cfg.history_minutes}/{cfg.forecast_minutes} minutes, {cfg.satellite_image_size_pixels} px, "
+                         f"batch {cfg.batch_size})")
         return cfg
 
     def _loader(self, n_batches: int, offset: int, split: str = "train"):

@@ -25,6 +25,7 @@ import yaml
 TARGET_ALIASES = {
     "predict_pv_yield.models.conv3d.model.Model": "predict_pv_yield_amd.models.conv3d.model.Model",
     "predict_pv_yield.models.conv3d.model_sat_nwp.Model": "predict_pv_yield_amd.models.conv3d.model_sat_nwp.Model",
+    "predict_pv_yield.models.conv3d.model_nwp.Model": "predict_pv_yield_amd.models.conv3d.model_nwp.Model",
     "predict_pv_yield.models.perceiver.perceiver.PerceiverModel": "predict_pv_yield_amd.models.perceiver.perceiver.PerceiverModel",
     "predict_pv_yield.models.perceiver.perceiver_nwp_sat.Model": "predict_pv_yield_amd.models.perceiver.perceiver_nwp_sat.Model",
     "predict_pv_yield.models.perceiver.perceiver_conv3d_nwp_sat.Model": "predict_pv_yield_amd.models.perceiver.perceiver_conv3d_nwp_sat.Model",

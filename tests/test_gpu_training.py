@@ -293,19 +293,19 @@ def test_trainer_advects_on_a_side_stream(device):
         assert torch.equal(a, b)
 
 
+SHIPPED_EXPERIMENTS = ["baseline", "conv3d", "conv3d_nwp", "conv3d_optical_flow", "conv3d_sat_nwp", "example_simple",
+                       "exp001_plumbing", "exp003_perceiver", "perceiver", "perceiver_conv3d_sat_nwp", "perceiver_sat_nwp"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("experiment", ["conv3d", "conv3d_optical_flow"])
-def test_shipped_experiments_run_with_their_own_shapes(device, tmp_path, monkeypatch, experiment):
-    """`python run.py experiment=<name> trainer.fast_dev_run=true` as shipped: the model yaml (BASELINE config 2 / 3: T = 18,
-    64 px, 11 channels, batch 32) and the dataset configuration the experiment points at must agree, and a fast_dev_run
-    stays on the GPU (utils.extras)."""
-    from predict_pv_yield_amd import hydra_lite as H
-    from predict_pv_yield_amd import utils
-    from predict_pv_yield_amd.training import train
-    monkeypatch.chdir(tmp_path)
-    cfg = H.compose(os.path.join(ROOT, "configs"), "config",
-                    [f"experiment={experiment}", "trainer.fast_dev_run=true", "~print_config",
-                     f"datamodule.data_path={ROOT}/configs/dataset/conv3d"])
-    utils.extras(cfg)
-    assert cfg.trainer.gpus == 1 and cfg.trainer.fast_dev_run is True
-    train(config=cfg)
+@pytest.mark.parametrize("experiment", SHIPPED_EXPERIMENTS)
+def test_shipped_experiments_run_with_their_own_shapes(device, tmp_path, experiment):
+    """`python run.py experiment=<name> trainer.fast_dev_run=true` exactly as a user types it, from the repository root with
+    the run directory elsewhere: the model yaml and the dataset configuration the experiment points at must agree, relative
+    paths must survive the change into hydra.run.dir, and a fast_dev_run stays on the GPU (utils.extras)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "run.py", f"experiment={experiment}", "trainer.fast_dev_run=true",
+                        f"hydra.run.dir={tmp_path}"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "no configuration.yaml under data_path" not in r.stderr + r.stdout

@@ -143,3 +143,49 @@ def test_bf16_emulation_rounds_only_operands():
     ya, yb = a(sat), b(sat)
     assert not torch.equal(ya, yb)
     torch.testing.assert_close(ya, yb, rtol=5e-2, atol=5e-3)
+
+
+# ---- NWP-only model (predict_pv_yield/models/conv3d/model_nwp.py) ---------------------------------------------------
+GOLD_NWP = os.path.join(os.path.dirname(__file__), "golden", "conv3d_nwp_small.npz")
+NWP = dict(forecast_minutes=120, history_minutes=30, number_of_conv3d_layers=4, conv3d_channels=32, nwp_image_size_pixels=12,
+           number_nwp_channels=10, fc1_output_features=16, fc2_output_features=16, fc3_output_features=16,
+           output_variable="gsp_yield")
+NWP_1CH = dict(NWP, number_nwp_channels=1, number_of_conv3d_layers=2, nwp_image_size_pixels=6, output_variable="pv_yield",
+               forecast_minutes=60, embedding_dem=0, include_pv_yield_history=False)
+
+
+def nwp_case(g, tag, kw, **extra):
+    """(oracle model with the golden initial parameters, tensors) of one NWP-only golden case."""
+    model = co.OracleConv3dNwpModel(**kw, **extra)
+    sd = {k[len(f"{tag}/init/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}/init/")}
+    assert list(sd) == list(model.state_dict())
+    model.load_state_dict(sd)
+    return model, {k: torch.from_numpy(g[f"{tag}/{k}"]) for k in ("pv", "gsp", "nwp")}
+
+
+@pytest.mark.parametrize("tag,kw", [("nwp", NWP), ("nwp_1ch", NWP_1CH)])
+def test_nwp_oracle_matches_reference_module(tag, kw):
+    """model_nwp.py executed from the reference's own source (golden) vs OracleConv3dNwpModel: bit-exact, including
+    the parameters forward never touches (no gradient, unchanged after three Adam steps)."""
+    g = np.load(GOLD_NWP)
+    model, t = nwp_case(g, tag, kw)
+    yld = t["gsp"] if kw["output_variable"] == "gsp_yield" else t["pv"]
+    assert [model.nwp_cnn_output_size, model.forecast_len, model.fc3.in_features] == list(g[f"{tag}/attrs"])
+    assert np.array_equal(model(t["nwp"]).detach().numpy(), g[f"{tag}/y_hat"])
+    opt = co.make_optimizer(model)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        _, nmae, _, _ = co.forecast_losses(model(t["nwp"]), co.select_target(yld, model.forecast_len))
+        nmae.backward()
+        if step == 0:
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    assert f"{tag}/grad/{k}" not in g.files and k.split(".")[0] in ("pv_system_id_embedding", "pv_fc1")
+                else:
+                    np.testing.assert_array_equal(checksum(p.grad), g[f"{tag}/grad/{k}"], err_msg=k)
+        opt.step()
+        losses.append(float(nmae.detach()))
+    for k, p in model.named_parameters():
+        np.testing.assert_array_equal(checksum(p), g[f"{tag}/step3/{k}"], err_msg=k)
+    np.testing.assert_array_equal(np.array(losses), g[f"{tag}/losses"])

@@ -356,3 +356,22 @@ def test_config1_exp001_shaped_cpu_plumbing_run(tmp_path, monkeypatch):
     score = train(cfg)
     assert np.isfinite(score) and 0.0 < score < 1.0
     assert os.path.exists("results_epoch_0.csv")
+
+
+def test_every_experiment_names_an_existing_dataset_configuration():
+    """Each shipped experiment composes, and the dataset configuration it points at exists (a missing one silently fell back
+    to default shapes once)."""
+    from predict_pv_yield_amd import hydra_lite as H
+    from tests.test_gpu_training import SHIPPED_EXPERIMENTS
+    found = sorted(f[:-5] for f in os.listdir(os.path.join(ROOT, "configs", "experiment")) if f.endswith(".yaml"))
+    assert found == SHIPPED_EXPERIMENTS
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        for name in found:
+            cfg = H.compose(os.path.join(ROOT, "configs"), "config", [f"experiment={name}"])
+            path = cfg.datamodule.get("data_path")
+            if path is not None:
+                assert os.path.isabs(path) and os.path.exists(os.path.join(path, "configuration.yaml")), (name, path)
+    finally:
+        os.chdir(cwd)
