@@ -11,6 +11,7 @@
 //                    -> UpdateMatrices -> iterations x { window blur V, window blur H + 2x2 solve,
 //                    UpdateMatrices }  -> (next level) bilinear flow upsample x 1/pyr_scale.
 #include "pv_common.h"
+#include <stdlib.h>
 
 namespace pv {
 
@@ -58,23 +59,51 @@ __device__ __forceinline__ float blurred_at(const uint8_t* __restrict__ img, int
   return acc;
 }
 
-// images: pair p has prev at prev + p*prev_stride, next at next + p*next_stride.  I: [n_pairs][2][lh][lw]
+// Image index -> source image.  Unchained: image im = (pair im / 2, prev | next).  CHAINED (chain_f = frames per group > 0:
+// the pairs of a group are consecutive frames of one stack, next == prev + prev_stride): image im = frame (im % chain_f) of
+// group (im / chain_f) -- a frame is the `next` of one pair and the `prev` of the following one, and everything computed per
+// image (smoothing, resize, PolyExp) depends on the image alone, so it is computed ONCE per frame: T frames instead of
+// 2 (T - 1) images per group (12 instead of 22 for the 12-frame stacks of the advection pipeline).
+__device__ __forceinline__ const uint8_t* fb_image_of(long long im, const uint8_t* __restrict__ prev,
+                                                      const uint8_t* __restrict__ next, long long prev_stride,
+                                                      long long next_stride, long long pairs_per_group,
+                                                      long long group_stride, int chain_f) {
+  if (chain_f > 0) {
+    const long long grp = im / chain_f, f = im - grp * chain_f;
+    return prev + grp * group_stride + f * prev_stride;
+  }
+  const long long p = im >> 1;
+  const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
+  return ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
+}
+
+// index of the R images of pair p: (first, second)
+__device__ __forceinline__ void fb_r_images_of(long long p, long long pairs_per_group, int chain_f, long long* r0, long long* r1) {
+  if (chain_f > 0) {
+    const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
+    *r0 = grp * chain_f + q;
+    *r1 = *r0 + 1;
+  } else {
+    *r0 = 2 * p;
+    *r1 = 2 * p + 1;
+  }
+}
+
+// images: see fb_image_of.  I: [n_img][lh][lw]
 __global__ __launch_bounds__(256) void fb_prep_kernel(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next,
                                                        long long prev_stride, long long next_stride,
                                                        long long pairs_per_group, long long group_stride,
-                                                       float* __restrict__ I, long long n_pairs, int h, int w, int lh,
+                                                       float* __restrict__ I, long long n_img, int chain_f, int h, int w, int lh,
                                                        int lw, int mode /*0 copy, 1 area 2x2, 2 bilinear*/,
                                                        double inv_fx, double inv_fy, FbTaps kt) {
   const long long per_img = (long long)lh * lw;
-  const long long total = n_pairs * 2 * per_img;
+  const long long total = n_img * per_img;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     long long im = i / per_img;
     int rem = (int)(i - im * per_img);
     int y = rem / lw, x = rem - y * lw;
-    long long p = im >> 1;
-    const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
-    const uint8_t* img = ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
+    const uint8_t* img = fb_image_of(im, prev, next, prev_stride, next_stride, pairs_per_group, group_stride, chain_f);
     float v;
     if (mode == 0) {
       v = blurred_at(img, h, w, y, x, kt);
@@ -182,7 +211,7 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                                     const uint8_t* __restrict__ next, long long prev_stride,
                                                                     long long next_stride, long long pairs_per_group,
                                                                     long long group_stride, float* __restrict__ R,
-                                                                    long long n_img, int h, int w, int lh, int lw, int mode,
+                                                                    long long n_img, int chain_f, int h, int w, int lh, int lw, int mode,
                                                                     double inv_fx, double inv_fy, FbTaps kt, FbPoly pk) {
   __shared__ float bufA[64 * 64];        // source as float, later the blurred image, later PolyExp plane t0
   __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
@@ -194,9 +223,7 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
   auto row_w = [&](int i) { return sh_w >= 0 ? i >> sh_w : i / w; };
   auto row_lw = [&](int i) { return sh_lw >= 0 ? i >> sh_lw : i / lw; };
   for (long long im = blockIdx.x; im < n_img; im += gridDim.x) {
-    const long long p = im >> 1;
-    const long long grp = p / pairs_per_group, q = p - grp * pairs_per_group;
-    const uint8_t* img = ((im & 1) ? next + q * next_stride : prev + q * prev_stride) + grp * group_stride;
+    const uint8_t* img = fb_image_of(im, prev, next, prev_stride, next_stride, pairs_per_group, group_stride, chain_f);
     const int npx = h * w, lpx = lh * lw;
     for (int i = tid; i < npx; i += FB_PP_NT) bufA[i] = (float)img[i];
     __syncthreads();
@@ -361,11 +388,12 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
   m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
 }
 
-// R: [n_pairs][2][lh][lw][5] (R0 = image 0, R1 = image 1); flow: [n_pairs][lh][lw][2];
+// R: [n_img][lh][lw][5], the two images of pair p per fb_r_images_of; flow: [n_pairs][lh][lw][2];
 // M: [n_pairs][lh][lw][5] (planar == 0) or [n_pairs][5][lh][lw] (planar != 0, what the fused tile kernel reads)
 __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __restrict__ R, const float* __restrict__ flow,
                                                                   float* __restrict__ M, long long n_pairs, int height,
-                                                                  int width, int planar) {
+                                                                  int width, int planar, long long pairs_per_group,
+                                                                  int chain_f) {
   const long long per_img = (long long)height * width;
   const long long total = n_pairs * per_img;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -373,8 +401,10 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
     long long p = i / per_img;
     int rem = (int)(i - p * per_img);
     int y = rem / width, x = rem - y * width;
-    const float* R0 = R + ((p * 2) * per_img + rem) * 5;
-    const float* R1 = R + (p * 2 + 1) * per_img * 5;
+    long long i0, i1;
+    fb_r_images_of(p, pairs_per_group, chain_f, &i0, &i1);
+    const float* R0 = R + (i0 * per_img + rem) * 5;
+    const float* R1 = R + i1 * per_img * 5;
     const float* fl = flow + i * 2;
     float m[5];
     fb_update_pixel(R0, R1, fl[0], fl[1], x, y, width, height, m);
@@ -924,6 +954,12 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
   float* V = (float*)(ws + L.off_V);
   float* flow_buf[2] = {(float*)(ws + L.off_flowA), (float*)(ws + L.off_flowB)};
 
+  // consecutive frames of one stack per group: per-image work once per frame (fb_image_of)
+  int chain_f = 0;
+  if (next == prev + prev_stride && next_stride == prev_stride && n_pairs % pairs_per_group == 0 &&
+      pairs_per_group + 1 <= 0x7fffffffLL && !getenv("PV_FARNEBACK_NO_FRAME_CHAIN"))
+    chain_f = (int)(pairs_per_group + 1);
+  const long long n_img = chain_f ? (n_pairs / pairs_per_group) * chain_f : n_pairs * 2;
   FbPoly pk;
   host_poly_tables(p->poly_n, p->poly_sigma, &pk);
   FbTaps win;
@@ -969,24 +1005,25 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     else mode = 2;
     stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
     if (h <= 64 && w <= 64 && smooth_sz <= 63) {
-      const unsigned grid = (unsigned)std::min<long long>(n_pairs * 2, 4096);
+      const unsigned grid = (unsigned)std::min<long long>(n_img, 4096);
       hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
                          (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
-                         (long long)n_pairs * 2, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk);
+                         n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk);
     } else {
-    hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st, prev, next,
+    hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st, prev, next,
                        (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,
-                       (long long)n_pairs, h, w, lh, lw, mode, inv_fx,
+                       n_img, chain_f, h, w, lh, lw, mode, inv_fx,
                        inv_fy, sm);
-    hipLaunchKernelGGL(fb_polyexp_v_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
-                       (const float*)I, T, (long long)n_pairs * 2, lh, lw, pk);
-    hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_pairs * 2 * lpx), 256)), dim3(256), 0, st,
-                       (const float*)T, R, (long long)n_pairs * 2, lh, lw, pk);
+    hipLaunchKernelGGL(fb_polyexp_v_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st,
+                       (const float*)I, T, n_img, lh, lw, pk);
+    hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st,
+                       (const float*)T, R, n_img, lh, lw, pk);
     }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
     hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0);
+                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0,
+                       (long long)pairs_per_group, chain_f);
     for (int it = 0; it < p->iterations; ++it) {
       const int update = it < p->iterations - 1 ? 1 : 0;
       if (tile_path) {
@@ -1011,7 +1048,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         if (update) {
           stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
           hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                             (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1);
+                             (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1, (long long)pairs_per_group,
+                             chain_f);
         }
         continue;
       }
@@ -1023,7 +1061,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
       if (update) {
         stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
         hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                           (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 0);
+                           (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 0, (long long)pairs_per_group,
+                           chain_f);
       }
     }
     prev_flow = flow;

@@ -207,6 +207,28 @@ def test_farneback_stack_and_params(device):
             assert np.abs(got[c, t] - ref).max() <= 1e-3
 
 
+@pytest.mark.parametrize("h,w,t", [(64, 64, 12), (40, 56, 3), (96, 80, 4)])
+def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkeypatch, h, w, t):
+    """Consecutive frames of a stack: the per-image stages (smoothing, resize, PolyExp) run once per FRAME instead of once
+    per pair side.  The flows must equal, bit for bit, those of the unchained path (PV_FARNEBACK_NO_FRAME_CHAIN=1) and of
+    the same pairs handed over as separate prev / next tensors (tile kernels at 64 x 64, generic kernels above)."""
+    K = _ops()
+    raw, _ = advected_counts(batch=2, t=t, channels=2, h=h, w=w, seed=h + t)
+    stacks = np.ascontiguousarray(raw.transpose(0, 2, 1, 3, 4)).reshape(4, t, h, w)  # [B*C, T, H, W]
+    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(stacks, 0)[0]).to(device)
+    chained = K.farneback_stack(u8)
+    monkeypatch.setenv("PV_FARNEBACK_NO_FRAME_CHAIN", "1")
+    unchained = K.farneback_stack(u8)
+    monkeypatch.delenv("PV_FARNEBACK_NO_FRAME_CHAIN")
+    assert chained.shape == (4, t - 1, h, w, 2)
+    assert torch.equal(chained, unchained)
+    prev = u8[:, :-1].reshape(-1, h, w).contiguous()
+    nxt = u8[:, 1:].reshape(-1, h, w).contiguous()
+    assert torch.equal(chained.reshape(-1, h, w, 2), K.farneback_pairs(prev, nxt))
+    ref = fo.calc_optical_flow_farneback(u8[1, 0].cpu().numpy(), u8[1, 1].cpu().numpy())
+    assert np.abs(chained[1, 0].cpu().numpy() - ref).max() <= 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 5, 3, 8, 8), (1, 12, 11, 64, 64), (3, 2, 1, 4, 6)])
 def test_prepare_stacks_equals_permute_u8_normalise(device, dtype, shape):
