@@ -388,12 +388,51 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
   m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
 }
 
+// one pixel of cv::resize(prevFlow -> (dw, dh), INTER_LINEAR) * (1 / pyr_scale): the expressions of fb_flow_upsample_kernel
+typedef float fb_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fb_f32x2_t fb_upsampled_flow(const float* __restrict__ src, size_t p, int sh, int sw, int x, int y,
+                                                        double inv_fx, double inv_fy, float mul) {
+  float fx = (float)((x + 0.5) * inv_fx - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  if (sx < 0) { fx = 0; sx = 0; }
+  if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+  float fy = (float)((y + 0.5) * inv_fy - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= sy;
+  if (sy < 0) { fy = 0; sy = 0; }
+  if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+  const int sy1 = clampi_d(sy + 1, 0, sh - 1);
+  const fb_f32x2_t* s0 = reinterpret_cast<const fb_f32x2_t*>(src) + (p * sh + sy) * sw;
+  const fb_f32x2_t* s1 = reinterpret_cast<const fb_f32x2_t*>(src) + (p * sh + sy1) * sw;
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+  const fb_f32x2_t t00 = s0[sx], t10 = s1[sx];
+  fb_f32x2_t r0 = t00, r1 = t10;
+  if (sx + 1 < sw) {
+    const fb_f32x2_t t01 = s0[sx + 1], t11 = s1[sx + 1];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      r0[c] = __fadd_rn(__fmul_rn(t00[c], a0), __fmul_rn(t01[c], a1));
+      r1[c] = __fadd_rn(__fmul_rn(t10[c], a0), __fmul_rn(t11[c], a1));
+    }
+  }
+  fb_f32x2_t o;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) o[c] = __fmul_rn(__fadd_rn(__fmul_rn(r0[c], b0), __fmul_rn(r1[c], b1)), mul);
+  return o;
+}
+
 // R: [n_img][lh][lw][5], the two images of pair p per fb_r_images_of; flow: [n_pairs][lh][lw][2];
+// FLOW_SRC: 0 = the flow field is read; 1 = it is the previous (coarser) level's flow resized on the fly -- the resized
+// field has no other reader before the blur + solve overwrites it, so the 16 bytes per pixel of writing and re-reading
+// it (and the launch) are saved; 2 = zero (the coarsest level starts from no motion: no memset, no read).
 // M: [n_pairs][lh][lw][5] (planar == 0) or [n_pairs][5][lh][lw] (planar != 0, what the fused tile kernel reads)
+struct FbUpsample { int sh, sw; double inv_fx, inv_fy; float mul; };
+template <int FLOW_SRC>
 __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __restrict__ R, const float* __restrict__ flow,
                                                                   float* __restrict__ M, long long n_pairs, int height,
                                                                   int width, int planar, long long pairs_per_group,
-                                                                  int chain_f) {
+                                                                  int chain_f, FbUpsample up) {
   const long long per_img = (long long)height * width;
   const long long total = n_pairs * per_img;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -405,9 +444,15 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
     fb_r_images_of(p, pairs_per_group, chain_f, &i0, &i1);
     const float* R0 = R + (i0 * per_img + rem) * 5;
     const float* R1 = R + i1 * per_img * 5;
-    const float* fl = flow + i * 2;
+    float fdx = 0.f, fdy = 0.f;
+    if constexpr (FLOW_SRC == 0) {
+      fdx = flow[i * 2], fdy = flow[i * 2 + 1];
+    } else if constexpr (FLOW_SRC == 1) {
+      const fb_f32x2_t f = fb_upsampled_flow(flow, (size_t)p, up.sh, up.sw, x, y, up.inv_fx, up.inv_fy, up.mul);
+      fdx = f[0], fdy = f[1];
+    }
     float m[5];
-    fb_update_pixel(R0, R1, fl[0], fl[1], x, y, width, height, m);
+    fb_update_pixel(R0, R1, fdx, fdy, x, y, width, height, m);
     if (planar) {
 #pragma unroll
       for (int c = 0; c < 5; ++c) M[(p * 5 + c) * per_img + rem] = m[c];
@@ -982,19 +1027,24 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     float* flow = k > 0 ? flow_buf[pingpong] : flow0;
     pingpong ^= 1;
     const bool coarse = k > 0;
-    stage_mark(coarse ? "farneback.coarse.flow_init" : "farneback.level0.flow_upsample", st);
-    if (!prev_flow) {
-      hipError_t e = hipMemsetAsync(flow, 0, (size_t)n_pairs * lpx * 2 * sizeof(float), st);
-      PV_REQUIRE(e == hipSuccess, PV_ELAUNCH, "pv_farneback_batch_u8: memset failed");
-    } else {
-      if ((long long)n_pairs * lpx < 0x7fffffffLL)
-        hipLaunchKernelGGL(fb_flow_upsample_kernel<int>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                           (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw, (double)prev_w / lw,
-                           (double)prev_h / lh, (float)(1. / p->pyr_scale));
-      else
-        hipLaunchKernelGGL(fb_flow_upsample_kernel<long long>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0,
-                           st, (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw,
-                           (double)prev_w / lw, (double)prev_h / lh, (float)(1. / p->pyr_scale));
+    // the level's starting flow (zero, or the coarser level's result resized) is consumed only by the first
+    // UpdateMatrices, which forms it on the fly; it is materialised only when no iteration follows to overwrite it
+    const bool fuse_init = p->iterations >= 1;
+    if (!fuse_init) {
+      stage_mark(coarse ? "farneback.coarse.flow_init" : "farneback.level0.flow_upsample", st);
+      if (!prev_flow) {
+        hipError_t e = hipMemsetAsync(flow, 0, (size_t)n_pairs * lpx * 2 * sizeof(float), st);
+        PV_REQUIRE(e == hipSuccess, PV_ELAUNCH, "pv_farneback_batch_u8: memset failed");
+      } else {
+        if ((long long)n_pairs * lpx < 0x7fffffffLL)
+          hipLaunchKernelGGL(fb_flow_upsample_kernel<int>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+                             (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw, (double)prev_w / lw,
+                             (double)prev_h / lh, (float)(1. / p->pyr_scale));
+        else
+          hipLaunchKernelGGL(fb_flow_upsample_kernel<long long>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0,
+                             st, (const float*)prev_flow, flow, (long long)n_pairs, prev_h, prev_w, lh, lw,
+                             (double)prev_w / lw, (double)prev_h / lh, (float)(1. / p->pyr_scale));
+      }
     }
     FbTaps sm;
     host_smooth_taps(smooth_sz, sigma, &sm);
@@ -1021,9 +1071,20 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
-    hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                       (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, tile_path ? 1 : 0,
-                       (long long)pairs_per_group, chain_f);
+    {
+      const dim3 um_grid(stream_grid((size_t)(n_pairs * lpx), 256));
+      FbUpsample up = {prev_h, prev_w, prev_flow ? (double)prev_w / lw : 1.0, prev_flow ? (double)prev_h / lh : 1.0,
+                       (float)(1. / p->pyr_scale)};
+      if (!fuse_init)
+        hipLaunchKernelGGL(fb_update_matrices_kernel<0>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)flow, M,
+                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+      else if (prev_flow)
+        hipLaunchKernelGGL(fb_update_matrices_kernel<1>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)prev_flow, M,
+                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+      else
+        hipLaunchKernelGGL(fb_update_matrices_kernel<2>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)nullptr, M,
+                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+    }
     for (int it = 0; it < p->iterations; ++it) {
       const int update = it < p->iterations - 1 ? 1 : 0;
       if (tile_path) {
@@ -1047,9 +1108,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         }
         if (update) {
           stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
-          hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+          hipLaunchKernelGGL(fb_update_matrices_kernel<0>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                              (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1, (long long)pairs_per_group,
-                             chain_f);
+                             chain_f, FbUpsample{});
         }
         continue;
       }
@@ -1060,9 +1121,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                          (const float*)V, flow, (long long)n_pairs, lh, lw, win);
       if (update) {
         stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
-        hipLaunchKernelGGL(fb_update_matrices_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(fb_update_matrices_kernel<0>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                            (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 0, (long long)pairs_per_group,
-                           chain_f);
+                           chain_f, FbUpsample{});
       }
     }
     prev_flow = flow;
