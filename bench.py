@@ -200,17 +200,18 @@ def measure_config3(dev, b, history_minutes):
     px0, px1 = hw * hw, (hw // 2) * (hw // 2)
     # algorithmic work per stage: bytes = compulsory traffic of the stage's inputs/outputs as the stage is
     # defined (R = 5 coefficient channels f32, M = 5 channels f32, flow 2 channels f32), flops per level-pixel:
-    # PolyExp 2 x 140, UpdateMatrices 75, window blur + solve 620
+    # PolyExp 140 per image pixel, UpdateMatrices 75, window blur + solve 620.  The per-image stages run once per FRAME
+    # (a frame is `next` of one pair and `prev` of the following one): frames = B * C * T, not 2 * pairs; a level's starting
+    # flow is formed inside its first UpdateMatrices (launch group 1 of 3 reads the coarser flow instead of a flow field).
+    frames = b * c * t_obs
     alg = {
         "prepare_stacks (raw -> u8 stacks + normalised frames)": dict(bytes=b * t_obs * c * px0 * (2 + 1 + 4), flops=0),
-        "farneback.coarse.prep_polyexp": dict(bytes=pairs * 2 * (px0 + px1 * 20), flops=pairs * 2 * px1 * 140),
-        "farneback.level0.prep_polyexp": dict(bytes=pairs * 2 * (px0 + px0 * 20), flops=pairs * 2 * px0 * 140),
+        "farneback.coarse.prep_polyexp": dict(bytes=frames * (px0 + px1 * 20), flops=frames * px1 * 140),
+        "farneback.level0.prep_polyexp": dict(bytes=frames * (px0 + px0 * 20), flops=frames * px0 * 140),
         "farneback.coarse.update_matrices": dict(bytes=pairs * px1 * (40 + 8 + 20), flops=pairs * px1 * 75),
         "farneback.level0.update_matrices": dict(bytes=pairs * px0 * (40 + 8 + 20), flops=pairs * px0 * 75),
         "farneback.coarse.window_blur_solve": dict(bytes=pairs * px1 * (20 + 8), flops=pairs * px1 * 620),
         "farneback.level0.window_blur_solve": dict(bytes=pairs * px0 * (20 + 8), flops=pairs * px0 * 620),
-        "farneback.coarse.flow_init": dict(bytes=pairs * px1 * 8, flops=0),
-        "farneback.level0.flow_upsample": dict(bytes=pairs * (px1 * 8 + px0 * 8), flops=pairs * px0 * 8),
         "flow_weighted_mean": dict(bytes=b * c * px0 * 8 * (t_obs - 1 + 1), flops=b * c * px0 * 2 * 2 * (t_obs - 1)),
         "remap_bilinear": dict(bytes=b * c * n_future * px0 * 16, flops=b * c * n_future * px0 * 10),
     }
