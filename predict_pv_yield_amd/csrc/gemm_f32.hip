@@ -163,36 +163,63 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   const int kbeg = split * g.k_chunk;
   const int kend = kbeg + g.k_chunk < g.k ? kbeg + g.k_chunk : g.k;
 
-  // staging: a thread moves PAIRS adjacent along the operand's unit stride (8 pairs of A, 4 of B per 32-deep panel)
-  int a_m[8], a_k[8], a_w[8], b_n[4], b_k[4], b_w[4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int idx = tid + 256 * i;
-    if (A_KC) { a_k[i] = 2 * (idx % 16); a_m[i] = idx / 16; a_w[i] = a_m[i] * X3_KC_RS + a_k[i] * 2; }
-    else      { a_m[i] = 2 * (idx % 64); a_k[i] = idx / 64; a_w[i] = a_k[i] * X3_A_MC_RS + a_m[i] * 2; }
-  }
+  // staging: a thread moves QUADS of four elements adjacent along the operand's unit stride (4 quads of A, 2 of B per
+  // 32-deep panel).  Inside the matrix (whole tile, whole panel) with a unit stride, the other stride a multiple of 4 and a
+  // 16-byte aligned base a quad is ONE dwordx4 load from a precomputed 64-bit offset; the earlier form (pairs, two
+  // predicated dword loads each, a 64-bit multiply per address) spent ~3 000 cycles of vector ALU per panel on addresses
+  // and bounds against 768 cycles of matrix work -- the K = 19 456 weight-gradient products ran at 1.5 us per panel and
+  // workgroup whatever the split.  Edge tiles / ragged panels / odd strides keep per-element predicated loads.
+  int a_m[4], a_k[4], a_w[4], b_n[2], b_k[2], b_w[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
-    if (B_KC) { b_k[i] = 2 * (idx % 16); b_n[i] = idx / 16; b_w[i] = b_n[i] * X3_KC_RS + b_k[i] * 2; }
-    else      { b_n[i] = 2 * (idx % 32); b_k[i] = idx / 32; b_w[i] = b_k[i] * X3_B_MC_RS + b_n[i] * 2; }
+    if (A_KC) { a_k[i] = 4 * (idx % 8); a_m[i] = idx / 8; a_w[i] = a_m[i] * X3_KC_RS + a_k[i] * 2; }
+    else      { a_m[i] = 4 * (idx % 32); a_k[i] = idx / 32; a_w[i] = a_k[i] * X3_A_MC_RS + a_m[i] * 2; }
   }
-  float ar[8][2], br[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i;
+    if (B_KC) { b_k[i] = 4 * (idx % 8); b_n[i] = idx / 8; b_w[i] = b_n[i] * X3_KC_RS + b_k[i] * 2; }
+    else      { b_n[i] = 4 * (idx % 16); b_k[i] = idx / 16; b_w[i] = b_k[i] * X3_B_MC_RS + b_n[i] * 2; }
+  }
+  const long long a_us = A_KC ? g.a_cs : g.a_rs, a_os = A_KC ? g.a_rs : g.a_cs;   // unit / other stride of A
+  const long long b_us = B_KC ? g.b_rs : g.b_cs, b_os = B_KC ? g.b_cs : g.b_rs;
+  const bool a_fast = a_us == 1 && (a_os & 3) == 0 && ((uintptr_t)A & 15) == 0 && m0 + G_BM <= g.m;
+  const bool b_fast = b_us == 1 && (b_os & 3) == 0 && ((uintptr_t)B & 15) == 0 && n0 + G_BN <= g.n;
+  long long a_off[4], b_off[2];   // element offset of the quad at k = 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = (long long)(m0 + a_m[i]) * g.a_rs + (long long)a_k[i] * g.a_cs;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b_off[i] = (long long)(n0 + b_n[i]) * g.b_cs + (long long)b_k[i] * g.b_rs;
+  f32x4 ar[4], br[2];
   auto load = [&](int k0) {
+    const bool full_k = k0 + X3_BK <= kend;
+    if (a_fast && full_k) {
+      const float* ap = A + (long long)k0 * g.a_cs;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i) ar[i] = *reinterpret_cast<const f32x4*>(ap + a_off[i]);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int mm = m0 + a_m[i] + (A_KC ? 0 : e), kk = k0 + a_k[i] + (A_KC ? e : 0);
-        ar[i][e] = (mm < g.m && kk < kend) ? A[mm * g.a_rs + kk * g.a_cs] : 0.f;
-      }
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 4; ++e) {
+          const int mm = m0 + a_m[i] + (A_KC ? 0 : e), kk = k0 + a_k[i] + (A_KC ? e : 0);
+          ar[i][e] = (mm < g.m && kk < kend) ? A[(long long)mm * g.a_rs + (long long)kk * g.a_cs] : 0.f;
+        }
+    }
+    if (b_fast && full_k) {
+      const float* bp = B + (long long)k0 * g.b_rs;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int nn = n0 + b_n[i] + (B_KC ? 0 : e), kk = k0 + b_k[i] + (B_KC ? e : 0);
-        br[i][e] = (nn < g.n && kk < kend) ? B[kk * g.b_rs + nn * g.b_cs] : 0.f;
-      }
+      for (int i = 0; i < 2; ++i) br[i] = *reinterpret_cast<const f32x4*>(bp + b_off[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int nn = n0 + b_n[i] + (B_KC ? 0 : e), kk = k0 + b_k[i] + (B_KC ? e : 0);
+          br[i][e] = (nn < g.n && kk < kend) ? B[(long long)kk * g.b_rs + (long long)nn * g.b_cs] : 0.f;
+        }
+    }
   };
   v16f_t acc0, acc1;
 #pragma unroll
@@ -232,20 +259,24 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   for (int k0 = kbeg; k0 < kend; k0 += X3_BK) {
     __syncthreads();  // previous panel fully consumed
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      uint32_t h, m, l;
-      x3_split_pair(ar[i][0], ar[i][1], h, m, l);
-      *reinterpret_cast<uint32_t*>(As + a_w[i]) = h;
-      *reinterpret_cast<uint32_t*>(As + X3_A_PLANE + a_w[i]) = m;
-      *reinterpret_cast<uint32_t*>(As + 2 * X3_A_PLANE + a_w[i]) = l;
+    for (int i = 0; i < 4; ++i) {
+      uint32_t h0, m0_, l0, h1, m1_, l1;
+      x3_split_pair(ar[i][0], ar[i][1], h0, m0_, l0);
+      x3_split_pair(ar[i][2], ar[i][3], h1, m1_, l1);
+      const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
+      *reinterpret_cast<u32x2*>(As + a_w[i]) = h;
+      *reinterpret_cast<u32x2*>(As + X3_A_PLANE + a_w[i]) = m;
+      *reinterpret_cast<u32x2*>(As + 2 * X3_A_PLANE + a_w[i]) = l;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint32_t h, m, l;
-      x3_split_pair(br[i][0], br[i][1], h, m, l);
-      *reinterpret_cast<uint32_t*>(Bs + b_w[i]) = h;
-      *reinterpret_cast<uint32_t*>(Bs + X3_B_PLANE + b_w[i]) = m;
-      *reinterpret_cast<uint32_t*>(Bs + 2 * X3_B_PLANE + b_w[i]) = l;
+    for (int i = 0; i < 2; ++i) {
+      uint32_t h0, m0_, l0, h1, m1_, l1;
+      x3_split_pair(br[i][0], br[i][1], h0, m0_, l0);
+      x3_split_pair(br[i][2], br[i][3], h1, m1_, l1);
+      const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
+      *reinterpret_cast<u32x2*>(Bs + b_w[i]) = h;
+      *reinterpret_cast<u32x2*>(Bs + X3_B_PLANE + b_w[i]) = m;
+      *reinterpret_cast<u32x2*>(Bs + 2 * X3_B_PLANE + b_w[i]) = l;
     }
     __syncthreads();
     if (k0 + X3_BK < kend) load(k0 + X3_BK);

@@ -716,6 +716,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+# split-K sizing: enough workgroups to fill the chip, but a K chunk long enough to amortise a workgroup's fixed costs
+SPLITK_TARGET_WORKGROUPS = 1024
+SPLITK_MIN_CHUNK = 256
+
+
 def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, N] = A[M, K] @ B[K, N] for small M, N and a huge K (weight gradients): K is cut over workgroups, the partial
     products are summed in index order (deterministic).  accumulate_into: a contiguous [M, N] tensor that receives
@@ -727,7 +732,7 @@ def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torc
     if accumulate_into is not None and (tuple(accumulate_into.shape) != (m, n) or not accumulate_into.is_contiguous()):
         raise ValueError("gemm_splitk: accumulate_into must be a contiguous [M, N] tensor")
     tiles = ((m + 127) // 128) * ((n + 63) // 64)
-    splits = max(1, min((1024 + tiles - 1) // tiles, (k + 255) // 256, 4096))
+    splits = max(1, min((SPLITK_TARGET_WORKGROUPS + tiles - 1) // tiles, (k + SPLITK_MIN_CHUNK - 1) // SPLITK_MIN_CHUNK, 4096))
     if splits == 1 and accumulate_into is None:
         return gemm(a, b)
     slabs = _workspace("gemm_splitk", splits * m * n * 4, a.device)
