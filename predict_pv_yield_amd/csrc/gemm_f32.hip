@@ -343,21 +343,6 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
   const float* __restrict__ A = g.a;
   const float* __restrict__ B = g.b;
   float* __restrict__ C = g.c;
-  // ---- the weights' column block: pairs (k, k+1) of column n -> three packed bf16 words -------------------------------
-  for (int idx = tid; idx < G_BN * (KP / 2); idx += 256) {
-    const int n = idx / (KP / 2), kp = idx - n * (KP / 2);
-    const int nn = n0 + n, k = 2 * kp;
-    const float x0 = (nn < g.n && k < g.k) ? B[(long long)k * g.b_rs + (long long)nn * g.b_cs] : 0.f;
-    const float x1 = (nn < g.n && k + 1 < g.k) ? B[(long long)(k + 1) * g.b_rs + (long long)nn * g.b_cs] : 0.f;
-    uint32_t h, m, l;
-    x3_split_pair(x0, x1, h, m, l);
-    const int off = n * BRS + k * 2;
-    *reinterpret_cast<uint32_t*>(Bs + off) = h;
-    *reinterpret_cast<uint32_t*>(Bs + BPLANE + off) = m;
-    *reinterpret_cast<uint32_t*>(Bs + 2 * BPLANE + off) = l;
-  }
-  __syncthreads();
-
   const int row = lane & 31, half = lane >> 5;
   const int b_rd0 = row * BRS + 16 * half, b_rd1 = (32 + row) * BRS + 16 * half;
   const float bias0 = (g.bias && n0 + row < g.n) ? g.bias[n0 + row] : 0.f;
@@ -424,26 +409,66 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b0h, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b1h, acc1, 0, 0, 0);
     }
-    // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  One 64-bit
+    // address per (block, column half) and lane; the row offsets are wave-uniform.  Only a ragged last block tests rows.
+    const bool whole = (long long)rb * 32 + 32 <= g.m;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int nn = n0 + 32 * t + row;
       if (nn >= g.n) continue;
       const float bv = t == 0 ? bias0 : bias1;
+      const long long m_lane = (long long)rb * 32 + 4 * half;
+      float* cp = C + m_lane * g.ldc + nn;
+      const float* rp = g.res ? g.res + m_lane * g.ldr + nn : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long mm = (long long)rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (mm < g.m) {
+        const int dr = (r & 3) + 8 * (r >> 2);
+        if (whole || m_lane + dr < g.m) {
           float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
-          if (g.res) v += g.res[mm * g.ldr + nn];
+          if (rp) v += rp[(long long)dr * g.ldr];
           if (g.relu) v = v > 0.f ? v : 0.f;
-          C[mm * g.ldc + nn] = v;
+          cp[(long long)dr * g.ldc] = v;
         }
       }
     }
   };
   int rb = blockIdx.y * 4 + wave;
-  load_a(rb, araw[0]);
+  load_a(rb, araw[0]);      // in flight under the weight staging below
+  // ---- the weights' column block: pairs (k, k+1) of column n -> three packed bf16 words -------------------------------
+  // k-contiguous weights (B = W^T of an nn.Linear: b_rs == 1) with K % 4 == 0 and a 16-byte aligned base move as quads:
+  // one dwordx4 load, two splits, three 8-byte LDS stores, all of a thread's loads in flight at once -- the per-pair form
+  // (two predicated dword loads behind 64-bit multiplies) made this prologue ~4 us of a workgroup that then multiplies
+  // for about as long
+  const bool b_quads = g.b_rs == 1 && (g.k & 3) == 0 && (g.b_cs & 3) == 0 && ((uintptr_t)B & 15) == 0 && n0 + G_BN <= g.n;
+  if (b_quads) {
+    const int kq = g.k >> 2;                               // quads per column
+    for (int idx = tid; idx < G_BN * (KP / 4); idx += 256) {
+      const int n = idx / (KP / 4), q = idx - n * (KP / 4);
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (q < kq) x = *reinterpret_cast<const f32x4*>(B + (long long)(n0 + n) * g.b_cs + 4 * q);
+      uint32_t h0, m0_, l0, h1, m1_, l1;
+      x3_split_pair(x[0], x[1], h0, m0_, l0);
+      x3_split_pair(x[2], x[3], h1, m1_, l1);
+      const int off = n * BRS + q * 8;
+      *reinterpret_cast<u32x2*>(Bs + off) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(Bs + BPLANE + off) = u32x2{m0_, m1_};
+      *reinterpret_cast<u32x2*>(Bs + 2 * BPLANE + off) = u32x2{l0, l1};
+    }
+  } else {
+    for (int idx = tid; idx < G_BN * (KP / 2); idx += 256) {
+      const int n = idx / (KP / 2), kp = idx - n * (KP / 2);
+      const int nn = n0 + n, k = 2 * kp;
+      const float x0 = (nn < g.n && k < g.k) ? B[(long long)k * g.b_rs + (long long)nn * g.b_cs] : 0.f;
+      const float x1 = (nn < g.n && k + 1 < g.k) ? B[(long long)(k + 1) * g.b_rs + (long long)nn * g.b_cs] : 0.f;
+      uint32_t h, m, l;
+      x3_split_pair(x0, x1, h, m, l);
+      const int off = n * BRS + k * 2;
+      *reinterpret_cast<uint32_t*>(Bs + off) = h;
+      *reinterpret_cast<uint32_t*>(Bs + BPLANE + off) = m;
+      *reinterpret_cast<uint32_t*>(Bs + 2 * BPLANE + off) = l;
+    }
+  }
+  __syncthreads();
   for (; rb < n_rowblocks; rb += 2 * stride) {      // two blocks per trip: the register sets alternate at compile time
     load_a(rb + stride, araw[1]);
     process(rb, araw[0]);
@@ -573,7 +598,7 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
   } else if (rows_form) {
     const int n_tiles = (d->n + G_BN - 1) / G_BN;
     const int n_rb = (d->m + 31) / 32;
-    int per_col = 768 / n_tiles;                    // ~3 workgroups per CU over all column blocks
+    int per_col = 512 / n_tiles;                    // one round of two workgroups per CU over all column blocks
     if (per_col < 1) per_col = 1;
     if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
     dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
