@@ -304,21 +304,26 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1][0], acc1, 0, 0, 0);
     }
   }
-  // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  One 64-bit address
+  // per column half and lane, wave-uniform row offsets; only a ragged last row tile tests rows.
   const int col = lane & 31;
+  const int m_lane = m0 + wave * 32 + 4 * (lane >> 5);
+  const bool whole = m0 + G_BM <= g.m;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int nn = n0 + 32 * t + col;
     if (nn >= g.n) continue;
     const float bv = g.bias ? g.bias[nn] : 0.f;
+    float* cp = C + (long long)m_lane * g.ldc + nn;
+    const float* rp = g.res ? g.res + (long long)m_lane * g.ldr + nn : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (mm < g.m) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      if (whole || m_lane + dr < g.m) {
         float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
-        if (g.res) v += g.res[(long long)mm * g.ldr + nn];
+        if (rp) v += rp[(long long)dr * g.ldr];
         if (g.relu) v = v > 0.f ? v : 0.f;
-        C[(long long)mm * g.ldc + nn] = v;
+        cp[(long long)dr * g.ldc] = v;
       }
     }
   }
