@@ -339,12 +339,18 @@ static void wgrad_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, in
   *n_rowblk = (ho + WTR - 1) / WTR;
   *n_colblk = (wo + WTW_VALID - 1) / WTW_VALID;
   long long tiles = (long long)d->batch * *n_rowblk * *n_colblk;
+  // One workgroup per CU and launch round.  Cutting the time march gives more workgroups but every chunk re-stages two
+  // halo slices: pick the cut that minimises rounds x (slices per chunk + 2).  (224 tiles -- 56 output rows at B = 32 --
+  // were cut in two: 2 rounds x 7 slice loads instead of 1 round x 12.)
+  int max_chunks = (to + 1) / 2;
+  if (max_chunks < 1) max_chunks = 1;
   int ntc = 1;
-  if (tiles < 256) {
-    ntc = (int)((256 + tiles - 1) / tiles);
-    int max_chunks = (to + 1) / 2;
-    if (max_chunks < 1) max_chunks = 1;
-    if (ntc > max_chunks) ntc = max_chunks;
+  long long best = -1;
+  for (int c = 1; c <= max_chunks && tiles * c <= 8 * 256; ++c) {
+    const int tch = (to + c - 1) / c, nch = (to + tch - 1) / tch;
+    const long long rounds = (tiles * nch + 255) / 256;
+    const long long cost = rounds * (tch + 2);
+    if (best < 0 || cost < best) best = cost, ntc = nch;
   }
   *t_chunk = (to + ntc - 1) / ntc;
   *n_tchunk = (to + *t_chunk - 1) / *t_chunk;
