@@ -422,9 +422,18 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
   const int n_colblk = (wo + V3_TW_VALID - 1) / V3_TW_VALID;
   // two workgroups per CU: split the time march only when the (sample, tile) grid alone cannot fill 512 slots
   const long long tiles = (long long)d->batch * n_rowblk * n_colblk;
+  // (a chunk of t output slices marches t + 2 input slices, the two extra ones with 1/3 and 2/3 of the taps: ~t + 1.5
+  // steps; the cut that minimises rounds of 512 workgroups x steps wins -- 448 tiles are NOT cut: 1 x 11.5 < 2 x 6.5)
   int n_tchunk = 1;
-  if (tiles < 512) n_tchunk = (int)((512 + tiles - 1) / tiles);
-  if (n_tchunk > to / 2) n_tchunk = to / 2;  // at least 2 output slices per chunk
+  {
+    long long best = -1;
+    for (int c = 1; c <= (to / 2 > 0 ? to / 2 : 1) && tiles * c <= 8 * 512; ++c) {
+      const int tch = (to + c - 1) / c, nch = (to + tch - 1) / tch;
+      const long long rounds = (tiles * nch + 511) / 512;
+      const long long cost = rounds * (2 * tch + 3);
+      if (best < 0 || cost < best) best = cost, n_tchunk = nch;
+    }
+  }
   int t_chunk = (to + n_tchunk - 1) / n_tchunk;
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   if (to - (n_tchunk - 1) * t_chunk < 2) {  // a single-slice remainder: fold it into longer chunks
