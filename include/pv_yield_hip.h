@@ -316,11 +316,14 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
  * n <= 128) and db[N] = column sums of dy ⊙ (y>0) (may be NULL).  Parameters / moments / operand copy are bit-identical
  * to pv_linear_wgrad_adam_bf16.  gate_dx_by_x != 0: dx is also multiplied by (x > 0) -- x being a ReLU output, that is the
  * ReLU derivative of the layer that produced x (the last Conv3d of model.py:117-120), applied here instead of by the
- * consumer of dx. */
+ * consumer of dx.
+ * moments_tiled != 0 (k % 128 == 0): exp_avg / exp_avg_sq are stored tile by tile, [k/128][N][128] (element (n, k) at
+ * (k/128)*N*128 + n*128 + k%128), so that a workgroup's share of each is one contiguous block instead of N segments
+ * 4*K bytes apart; the caller owns the layout (optim.HipAdam converts at state_dict() / mode changes). */
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param,
                                  float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db,
                                  int32_t m, int32_t n, int64_t k, double lr, double beta1, double beta2, double eps,
-                                 int32_t step, int32_t gate_dx_by_x, void* stream);
+                                 int32_t step, int32_t gate_dx_by_x, int32_t moments_tiled, void* stream);
 
 /* Data-parallel wire format for fc1's gradient (SURVEY.md §7.2 "keep bf16 grads on the wire"): the weight gradient is
  * written once as bf16 [N,K] (half the bytes of the f32 gradient on HBM and on xGMI), all-reduced by RCCL in bf16,
@@ -351,7 +354,8 @@ int pv_adam_step_multi_dev_f32(const pv_adam_tensor* tensors, int32_t n_tensors,
                                void* stream);
 int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
                                      float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
-                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, void* stream);
+                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, int32_t moments_tiled,
+                                     void* stream);
 
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,

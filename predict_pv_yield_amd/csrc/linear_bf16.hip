@@ -362,7 +362,8 @@ constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed 
 __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
     int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
-    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad, int gate_dx, const float* __restrict__ ad_dev) {
+    uint16_t* __restrict__ dx, float* __restrict__ db, AdamScalars ad, int gate_dx, const float* __restrict__ ad_dev,
+    int mv_tiled) {
   // ad_dev (may be NULL): the six Adam scalars in device memory (pv_adam_scalars_advance) -- the form a captured HIP graph
   // replays, where the bias corrections must change from replay to replay and kernel arguments cannot
   if (ad_dev) ad = AdamScalars{ad_dev[0], ad_dev[1], ad_dev[2], ad_dev[3], ad_dev[4], ad_dev[5]};
@@ -425,14 +426,19 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   // ---- Adam, row by row (next row's p / m / v in flight under this row's arithmetic); the old weights are kept as bf16 ------
   uint32_t wold[8][4];     // bf16 pairs of the PRE-update weights: [row i][column pair]
   f32x4 nxt[6];
+  // mv_tiled: the two moment arrays are stored tile by tile, [k / 128][n][128]: a workgroup's share is ONE contiguous
+  // n x 512-byte block per array instead of n segments 4 MB apart
+  const size_t mv_tile_base = (size_t)blockIdx.x * (size_t)n * FD_KT + 8 * kq;
   auto fetch = [&](int i) {
-    const size_t off = (size_t)min(8 * rg + i, n - 1) * k + (k_ok ? k8 : 0);
+    const int r = min(8 * rg + i, n - 1);
+    const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
+    const size_t moff = mv_tiled ? mv_tile_base + (size_t)r * FD_KT : off;
     nxt[0] = *reinterpret_cast<const f32x4*>(w + off);
     nxt[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
-    nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + off);
-    nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
-    nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
-    nxt[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+    nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + moff);
+    nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + moff + 4);
+    nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff);
+    nxt[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff + 4);
   };
   fetch(0);
 #pragma unroll
@@ -464,10 +470,11 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
       }
       *reinterpret_cast<f32x4*>(w + off) = *reinterpret_cast<const f32x4*>(pv);
       *reinterpret_cast<f32x4*>(w + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
-      *reinterpret_cast<f32x4*>(exp_avg + off) = *reinterpret_cast<const f32x4*>(mv);
-      *reinterpret_cast<f32x4*>(exp_avg + off + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
-      *reinterpret_cast<f32x4*>(exp_avg_sq + off) = *reinterpret_cast<const f32x4*>(vv);
-      *reinterpret_cast<f32x4*>(exp_avg_sq + off + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
+      const size_t moff = mv_tiled ? mv_tile_base + (size_t)(8 * rg + i) * FD_KT : off;
+      *reinterpret_cast<f32x4*>(exp_avg + moff) = *reinterpret_cast<const f32x4*>(mv);
+      *reinterpret_cast<f32x4*>(exp_avg + moff + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + moff) = *reinterpret_cast<const f32x4*>(vv);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + moff + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
       if (shadow) {
         u32x4 so = {sh[0], sh[1], sh[2], sh[3]};
         *reinterpret_cast<u32x4*>(shadow + off) = so;
@@ -947,32 +954,37 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
                                  float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
                                  int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
-                                 int32_t gate_dx_by_x, void* stream) {
+                                 int32_t gate_dx_by_x, int32_t moments_tiled, void* stream) {
   PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_dx_adam_bf16: null pointer");
   PV_REQUIRE(m > 0 && m <= 32 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
              "pv_linear_wgrad_dx_adam_bf16: built for m <= 32 rows of x and n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_bf16: k must be a multiple of 8");
   PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_dx_adam_bf16: step must be >= 1");
+  PV_REQUIRE(!moments_tiled || k % FD_KT == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_bf16: tiled moments need k %% %d == 0", FD_KT);
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                  (float)(-(lr / bc1))};
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
-                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr);
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr,
+                     moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
 }
 
 int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
                                      float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
-                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, void* stream) {
+                                     int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, int32_t moments_tiled,
+                                     void* stream) {
   PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq && adam_scalars_dev, PV_EINVAL,
              "pv_linear_wgrad_dx_adam_dev_bf16: null pointer");
   PV_REQUIRE(m > 0 && m <= 32 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
              "pv_linear_wgrad_dx_adam_dev_bf16: built for m <= 32 rows of x and n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_dev_bf16: k must be a multiple of 8");
+  PV_REQUIRE(!moments_tiled || k % FD_KT == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_dev_bf16: tiled moments need k %% %d == 0", FD_KT);
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
-                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, AdamScalars{}, gate_dx_by_x, adam_scalars_dev);
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, AdamScalars{}, gate_dx_by_x, adam_scalars_dev,
+                     moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_dev_bf16");
 }
 

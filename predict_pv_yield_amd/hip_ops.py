@@ -519,10 +519,12 @@ def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_
 
 
 def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
-                              betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False, gate_dx_by_x=False):
+                              betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False, gate_dx_by_x=False,
+                              moments_tiled=False):
     """fc1's whole backward in ONE pass over the matrix: weight gradient applied by Adam in place (as
     linear_wgrad_adam_bf16, bit-identical) AND dx = (dy ⊙ (y>0)) . W_old (bf16 [M, K]) from the weights it streams.
-    gate_dx_by_x: dx is also multiplied by (x > 0), the ReLU derivative of the layer that produced x."""
+    gate_dx_by_x: dx is also multiplied by (x > 0), the ReLU derivative of the layer that produced x.
+    moments_tiled: exp_avg / exp_avg_sq hold the [K/128][N][128] tile layout (moments_to_tiled)."""
     require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow)
     m, k = x_bf16.shape
     n = param.shape[0]
@@ -530,13 +532,14 @@ def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf
     db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
     check(get_lib().pv_linear_wgrad_dx_adam_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
                                                  ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, lr, betas[0], betas[1], eps,
-                                                 step, int(bool(gate_dx_by_x)), current_stream_ptr()),
+                                                 step, int(bool(gate_dx_by_x)), int(bool(moments_tiled)),
+                                                 current_stream_ptr()),
           "pv_linear_wgrad_dx_adam_bf16")
     return (dx, db) if need_db else dx
 
 
 def linear_wgrad_dx_adam_dev_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, scalars, need_db=False,
-                                  gate_dx_by_x=False):
+                                  gate_dx_by_x=False, moments_tiled=False):
     """linear_wgrad_dx_adam_bf16 with the step's Adam scalars in device memory (adam_scalars_advance)."""
     require_cuda(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, scalars)
     m, k = x_bf16.shape
@@ -545,9 +548,25 @@ def linear_wgrad_dx_adam_dev_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq
     db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
     check(get_lib().pv_linear_wgrad_dx_adam_dev_bf16(ptr(x_bf16), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
                                                      ptr(bf16_shadow), ptr(dx), ptr(db), m, n, k, ptr(scalars),
-                                                     int(bool(gate_dx_by_x)), current_stream_ptr()),
+                                                     int(bool(gate_dx_by_x)), int(bool(moments_tiled)), current_stream_ptr()),
           "pv_linear_wgrad_dx_adam_dev_bf16")
     return (dx, db) if need_db else dx
+
+
+MOMENT_TILE = 128      # FD_KT of linear_bf16.hip: k-columns per workgroup of the one-pass fc1 backward
+
+
+def moments_to_tiled(t: torch.Tensor) -> torch.Tensor:
+    """Row-major [N, K] -> the tile layout [K/128][N][128] of pv_linear_wgrad_dx_adam_bf16(moments_tiled=1), as a tensor
+    that keeps the shape [N, K] (only its bytes are permuted)."""
+    n, k = t.shape
+    return t.view(n, k // MOMENT_TILE, MOMENT_TILE).permute(1, 0, 2).contiguous().view(n, k)
+
+
+def moments_to_rows(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of moments_to_tiled."""
+    n, k = t.shape
+    return t.view(k // MOMENT_TILE, n, MOMENT_TILE).permute(1, 0, 2).contiguous().view(n, k)
 
 
 def fused_dx_update_supported(m: int, n: int, k: int) -> bool:

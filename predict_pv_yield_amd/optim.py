@@ -17,6 +17,13 @@ from . import hip_ops as K
 # tools/ab_step.py flips this switch to time the two arrangements in one process.
 FUSE_DX_INTO_UPDATE = True
 
+# The one-pass fc1 backward keeps exp_avg / exp_avg_sq of its matrix TILE BY TILE ([K/128][N][128], hip_ops.moments_to_tiled):
+# a workgroup's share of each moment array is one contiguous 64 KB block instead of 128 segments 4 MB apart (the row-major
+# form left the HBM-bound pass at the mercy of how the arrays' rows fell onto the DRAM banks: 690-780 us by device and
+# placement; tiled 680-730 us).  The layout is private to that pass: state_dict(), a change of the gradient mode and every
+# other update path see row-major tensors again (HipAdam.moments / _moments_rows).
+TILE_LARGE_MOMENTS = True
+
 
 class HipAdam(torch.optim.Optimizer):
     # 2-D parameters at least this large whose gradient comes from functional.LinearBF16 (fc1) can bypass autograd's
@@ -45,6 +52,7 @@ class HipAdam(torch.optim.Optimizer):
         self.overlap_large_update = overlap_large_update
         self._side_stream = None
         self._inflight = []
+        self._tiled = set()            # id(p) of the parameters whose moments currently hold the tile layout
         self.set_large_grad_mode("fused" if fuse_large_linear else "autograd")
 
     def _advance_device_scalars(self, device) -> torch.Tensor:
@@ -83,6 +91,8 @@ class HipAdam(torch.optim.Optimizer):
             if any(D.row_shard(p.shape[0]) is None for p in self.large_params()):
                 mode = "bf16"       # rows do not divide over the ranks: plain all-reduce
         self.large_grad_mode = mode
+        if hasattr(self, "_tiled"):
+            self._moments_rows()
         for p in self.large_params():
             p._pv_grad_mode = mode
             p._pv_pending = None
@@ -97,6 +107,7 @@ class HipAdam(torch.optim.Optimizer):
         owns.  All-gather them so that state_dict() / checkpoints are complete on every rank.  Collective: call on all ranks."""
         if not getattr(self, "_sharded_dirty", False):
             return
+        self._moments_rows()
         from . import distributed as D
         if D.is_distributed():
             for p in self.large_params():
@@ -107,6 +118,45 @@ class HipAdam(torch.optim.Optimizer):
                     if t is not None:
                         D.all_gather_rows(t, async_op=False)
         self._sharded_dirty = False
+
+    # ---- layout of the large matrix's moments --------------------------------------------------------------------------
+    def _moments_tiled(self, p) -> bool:
+        """Puts exp_avg / exp_avg_sq of p into the tile layout (if the shape allows); True when they are tiled afterwards."""
+        if not TILE_LARGE_MOMENTS or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
+            self._moments_rows(p)
+            return False
+        if id(p) in self._tiled:
+            return True
+        st = self._init_state(p)
+        for key in ("exp_avg", "exp_avg_sq"):
+            st[key] = K.moments_to_tiled(st[key])
+        self._tiled.add(id(p))
+        return True
+
+    def _moments_rows(self, p=None) -> None:
+        """Back to row-major (torch's layout) for p, or for every parameter: before anything but the one-pass backward
+        reads or writes the moments."""
+        for q in ([p] if p is not None else [q for g in self.param_groups for q in g["params"]]):
+            if id(q) in self._tiled:
+                st = self.state[q]
+                for key in ("exp_avg", "exp_avg_sq"):
+                    st[key] = K.moments_to_rows(st[key])
+                self._tiled.discard(id(q))
+
+    def moments(self, p):
+        """(exp_avg, exp_avg_sq) of p in torch's row-major layout (copies when the stored layout is tiled)."""
+        st = self.state[p]
+        if id(p) in self._tiled:
+            return K.moments_to_rows(st["exp_avg"]), K.moments_to_rows(st["exp_avg_sq"])
+        return st["exp_avg"], st["exp_avg_sq"]
+
+    def state_dict(self):
+        self._moments_rows()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._tiled.clear()             # whatever is loaded is row-major
+        return super().load_state_dict(state_dict)
 
     def _group_of(self, p):
         for g in self.param_groups:
@@ -128,6 +178,7 @@ class HipAdam(torch.optim.Optimizer):
             group = self._group_of(p)
             with torch.no_grad():
                 st = self._init_state(p)
+                self._moments_rows(p)
                 shadow = bf16_shadow_of(p)
                 st["step"] += 1
                 main = torch.cuda.current_stream(p.device)
@@ -157,15 +208,17 @@ class HipAdam(torch.optim.Optimizer):
             with torch.no_grad():
                 self._ensure_device_state(p.device)
                 st = self._init_state(p)
+                tiled = self._moments_tiled(p)
                 st["step"] += 1
                 if self.capturable:
                     out = K.linear_wgrad_dx_adam_dev_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                                           self._advance_device_scalars(p.device), need_db=need_db,
-                                                          gate_dx_by_x=gate_dx)
+                                                          gate_dx_by_x=gate_dx, moments_tiled=tiled)
                 else:
                     out = K.linear_wgrad_dx_adam_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                                       int(st["step"].item()), lr=group["lr"], betas=group["betas"],
-                                                      eps=group["eps"], need_dx=True, need_db=need_db, gate_dx_by_x=gate_dx)
+                                                      eps=group["eps"], need_dx=True, need_db=need_db, gate_dx_by_x=gate_dx,
+                                                      moments_tiled=tiled)
             p._pv_applied = True
             return out if need_db else (out, None)
         return fused
@@ -205,6 +258,7 @@ class HipAdam(torch.optim.Optimizer):
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
                 st = self._init_state(p)
+                self._moments_rows(p)       # (a no-op unless an earlier step of p went through the one-pass backward)
                 st["step"] += 1
                 if self.capturable and (pending is not None or gs is not None or gb is not None):
                     raise NotImplementedError("HipAdam(capturable=True) covers the single-process paths (fc1's one-pass "

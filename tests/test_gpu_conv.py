@@ -446,6 +446,22 @@ def test_fused_wgrad_dx_adam_single_pass(device, m, n, k):
     assert torch.equal(pc, pd) and torch.equal(sc, sd)
     assert torch.equal(dx_gated, torch.where(xr > 0, dx_plain, torch.zeros_like(dx_plain)))
     assert (xr == 0).any() and (dx_gated == 0).sum() > (dx_plain == 0).sum()
+    # moments_tiled: exp_avg / exp_avg_sq held tile by tile ([K/128][N][128]); three steps give the row-major run's numbers
+    if k % K.MOMENT_TILE == 0:
+        pe, se = p0.clone(), p0.to(torch.bfloat16)
+        me, ve = K.moments_to_tiled(torch.zeros_like(p0)), K.moments_to_tiled(torch.zeros_like(p0))
+        pf, mf, vf, sf = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), p0.to(torch.bfloat16)
+        for step in (1, 2, 3):
+            dx_t = K.linear_wgrad_dx_adam_bf16(x, dy, y, pe, me, ve, se, step, lr=5e-4, moments_tiled=True)
+            dx_r = K.linear_wgrad_dx_adam_bf16(x, dy, y, pf, mf, vf, sf, step, lr=5e-4)
+            assert torch.equal(dx_t, dx_r) and torch.equal(pe, pf) and torch.equal(se, sf), step
+            assert torch.equal(K.moments_to_rows(me), mf) and torch.equal(K.moments_to_rows(ve), vf), step
+        probe = torch.arange(n * k, dtype=torch.float32, device=device).view(n, k)
+        assert torch.equal(K.moments_to_rows(K.moments_to_tiled(probe)), probe)
+        assert K.moments_to_tiled(probe).view(k // K.MOMENT_TILE, n, K.MOMENT_TILE)[3, 5, 7] == probe[5, 3 * K.MOMENT_TILE + 7]
+    else:
+        with pytest.raises(RuntimeError):
+            K.linear_wgrad_dx_adam_bf16(x, dy, y, pc, mc, vc, sc, 2, lr=5e-4, moments_tiled=True)
 
 
 def test_bf16_gradient_wire_format(device):

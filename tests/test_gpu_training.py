@@ -264,6 +264,67 @@ def test_hip_graph_train_step_matches_eager(device):
     assert max(abs(x - y) for x, y in zip(l_graph, l_host)) < 1e-5
 
 
+def test_tiled_moments_are_private_to_the_one_pass_backward(device, monkeypatch):
+    """HipAdam keeps exp_avg / exp_avg_sq of fc1 tile by tile while the one-pass backward owns them.  Whatever leaves the
+    optimiser is torch's row-major layout: state_dict() between steps, a resumed optimiser, a change of gradient mode --
+    and every number equals the run that never tiles (optim.TILE_LARGE_MOMENTS = False), bit for bit."""
+    import copy
+    from predict_pv_yield_amd import optim as O
+    from predict_pv_yield_amd.models.conv3d.model import Model
+
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+              conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16")
+    torch.manual_seed(11)
+    base = Model(**kw).to(device)
+    g = torch.Generator(device=device).manual_seed(12)
+    batches = [{"satellite": {"data": torch.randn(4, 11, 18, 64, 64, generator=g, device=device)},
+                "pv": {"pv_yield": torch.rand(4, 18, 128, generator=g, device=device)}} for _ in range(5)]
+
+    def run(tile):
+        monkeypatch.setattr(O, "TILE_LARGE_MOMENTS", tile)
+        model = copy.deepcopy(base)
+        opt = model.configure_optimizers()
+        fc1 = model.fc1.weight
+        snaps = []
+
+        def step(b):
+            opt.zero_grad(set_to_none=True)
+            model.training_step(b, 0).backward()
+            opt.step()
+
+        step(batches[0]); step(batches[1])
+        assert (id(fc1) in opt._tiled) == tile
+        sd = copy.deepcopy(opt.state_dict())                 # row-major, whatever the stored layout was
+        assert id(fc1) not in opt._tiled
+        snaps.append([t.clone() for t in opt.moments(fc1)])
+        step(batches[2])                                     # the next one-pass backward tiles again
+        assert (id(fc1) in opt._tiled) == tile
+        snaps.append([t.clone() for t in opt.moments(fc1)])
+        # resume in a fresh optimiser from the state saved after step 2 (and the weights of that moment are gone: only the
+        # optimiser round trip is under test, so the moments are compared right after loading)
+        opt2 = copy.deepcopy(base).configure_optimizers()
+        opt2.load_state_dict(sd)
+        p2 = [q for grp in opt2.param_groups for q in grp["params"] if q.shape == fc1.shape][0]
+        assert all(torch.equal(a, b) for a, b in zip(opt2.moments(p2), snaps[0]))
+        # leaving the fused mode hands the moments back row-major; the two-kernel path continues from them
+        opt.set_large_grad_mode("autograd")
+        assert id(fc1) not in opt._tiled
+        step(batches[3])
+        opt.set_large_grad_mode("fused")
+        step(batches[4])
+        snaps.append([t.clone() for t in opt.moments(fc1)])
+        return snaps, {k: v.detach().clone() for k, v in model.state_dict().items()}, sd
+
+    (a_m, a_w, a_sd), (b_m, b_w, b_sd) = run(True), run(False)
+    for x, y in zip(a_m, b_m):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+    for k in a_w:
+        assert torch.equal(a_w[k], b_w[k]), k
+    for sa, sb in zip(a_sd["state"].values(), b_sd["state"].values()):
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
 @pytest.mark.gpu
 def test_trainer_advects_on_a_side_stream(device):
     """Trainer(advect_on_side_stream=True) on config 3 (raw int16 counts -> Model(future_frames="optical_flow")): the same
