@@ -208,6 +208,7 @@ def test_baseline_model_forward_is_persistence():
 @pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("name,module,cls", [
     ("conv3d_sat_nwp", "predict_pv_yield_amd.models.conv3d.model_sat_nwp", "Model"),
+    ("conv3d_nwp", "predict_pv_yield_amd.models.conv3d.model_nwp", "Model"),
     ("perceiver", "predict_pv_yield_amd.models.perceiver.perceiver", "PerceiverModel"),
     ("perceiver_sat_nwp", "predict_pv_yield_amd.models.perceiver.perceiver_nwp_sat", "Model"),
     ("perceiver_conv3d_sat_nwp", "predict_pv_yield_amd.models.perceiver.perceiver_conv3d_nwp_sat", "Model")])
@@ -244,6 +245,31 @@ def test_new_model_signatures_match_reference():
     assert sig.parameters["conv3d_channels"].default == 16 and sig.parameters["use_future_satellite_images"].default is True
     m = PerceiverModel(history_minutes=3, forecast_minutes=3)           # tests/models/perceiver/test_perceiver.py:9
     assert m.total_seq_length == 1 and len(m.perceiver.layers) == 1
+
+
+def test_nwp_only_model_mirrors_the_reference_signature_and_parameter_names():
+    """models/conv3d/model_nwp.py: constructor keywords / defaults of model_nwp.py:18-35, the registration order of its
+    layers (state_dict keys = the oracle's, which is pinned on the reference module), the class name quirk, and no CPU path."""
+    import inspect
+    from oracle import conv3d_oracle as co
+    from predict_pv_yield_amd.models.conv3d.model_nwp import Model
+    sig = inspect.signature(Model.__init__)
+    assert list(sig.parameters)[1:16] == ["include_pv_or_gsp_yield_history", "include_nwp", "forecast_minutes", "history_minutes",
+                                          "number_of_conv3d_layers", "conv3d_channels", "nwp_image_size_pixels",
+                                          "number_nwp_channels", "fc1_output_features", "fc2_output_features",
+                                          "fc3_output_features", "output_variable", "embedding_dem",
+                                          "include_pv_yield_history", "include_future_satellite"]
+    assert [sig.parameters[k].default for k in ("forecast_minutes", "history_minutes", "nwp_image_size_pixels",
+                                                "number_nwp_channels", "output_variable", "embedding_dem")] == [30, 60, 64, 10, "gsp_yield", 16]
+    kw = dict(forecast_minutes=120, history_minutes=30, number_of_conv3d_layers=2, nwp_image_size_pixels=8, number_nwp_channels=3,
+              fc1_output_features=8, fc3_output_features=8)
+    m, o = Model(**kw), co.OracleConv3dNwpModel(**kw)
+    assert Model.name == "conv3d_sat_nwp"                      # model_nwp.py:16 keeps the sat+nwp name
+    assert list(m.state_dict()) == list(o.state_dict())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in o.state_dict().values()]
+    assert m.nwp_cnn_output_size == o.nwp_cnn_output_size == 32 * 4 * 4 * 4 and m.forecast_len == o.forecast_len == 4
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m({"nwp": {"data": torch.zeros(1, 3, 4, 8, 8)}})
 
 
 # ---- step after the path (SURVEY §8f row 4): validation results CSV + per-horizon metrics, on the host with the
