@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __res
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < m * n) {
     int k = grp;
+    for (; k + 60 < k_splits; k += 64) {     // sixteen loads in flight (four trips of the loop below; same order of additions)
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = partial[(size_t)(k + 4 * j) * mn + i];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) s0 += v[j], s1 += v[j + 1], s2 += v[j + 2], s3 += v[j + 3];
+    }
     for (; k + 12 < k_splits; k += 16) {
       s0 += partial[(size_t)k * mn + i];
       s1 += partial[(size_t)(k + 4) * mn + i];
