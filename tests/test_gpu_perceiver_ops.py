@@ -41,6 +41,29 @@ def test_gemm_strided_views(shape, device):
     assert float(out[..., n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("off,ld_pad", [(0, 0), (1, 0), (2, 3), (4, 4), (0, 1)])
+def test_gemm_quad_staging_falls_back_on_misaligned_views(off, ld_pad, device):
+    """gemm_bf16x3's staging takes one 16-byte load per four elements only for whole tiles with a 16-byte aligned base, a
+    unit stride and the other stride a multiple of 4; views that break any of these (column offset, padded leading
+    dimension) must take the per-element path and give the same product.  256 x 192 outputs = whole tiles only, K = 96."""
+    K, _ = _mods()
+    m, k, n = 256, 96, 192
+    g = torch.Generator().manual_seed(off * 10 + ld_pad)
+    a_store = torch.randn(m, k + off + ld_pad, generator=g)
+    b_store = torch.randn(k, n + off + ld_pad, generator=g)
+    a, b = a_store[:, off:off + k], b_store[:, off:off + n]
+    ref = (a.double() @ b.double()).float()
+    ad, bd = a_store.to(device)[:, off:off + k], b_store.to(device)[:, off:off + n]
+    tol = dict(rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(K.gemm(ad, bd).cpu(), ref, **tol)
+    # the same operands stored transposed (m / n contiguous): the MC layouts of both operands
+    at = a_store.t().contiguous().to(device)[off:off + k, :].t()
+    bt = b_store.t().contiguous().to(device)[off:off + n, :].t()
+    torch.testing.assert_close(K.gemm(at, bt).cpu(), ref, **tol)
+    torch.testing.assert_close(K.gemm(ad, bt).cpu(), ref, **tol)
+    torch.testing.assert_close(K.gemm(at, bd).cpu(), ref, **tol)
+
+
 def test_gemm_splitk_weight_gradient_shape(device):
     K, _ = _mods()
     g = torch.Generator().manual_seed(4)
