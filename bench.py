@@ -589,8 +589,10 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=24, batch=8,
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: long enough for the device to settle (same box, alternating: W=5 / K=20 reads 1.744-1.758 ms, W=40 / K=100 and
+    # W=100 / K=200 read 1.716-1.728 ms) and still a fraction of a second of timed work
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of PV-site crop stacks")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: fix the GLOBAL batch (e.g. 512) and give each of the N GPUs global/N samples; "
