@@ -52,7 +52,6 @@ class HipAdam(torch.optim.Optimizer):
         self.overlap_large_update = overlap_large_update
         self._side_stream = None
         self._inflight = []
-        self._tiled = set()            # id(p) of the parameters whose moments currently hold the tile layout
         self.set_large_grad_mode("fused" if fuse_large_linear else "autograd")
 
     def _advance_device_scalars(self, device) -> torch.Tensor:
@@ -91,8 +90,7 @@ class HipAdam(torch.optim.Optimizer):
             if any(D.row_shard(p.shape[0]) is None for p in self.large_params()):
                 mode = "bf16"       # rows do not divide over the ranks: plain all-reduce
         self.large_grad_mode = mode
-        if hasattr(self, "_tiled"):
-            self._moments_rows()
+        self._moments_rows()
         for p in self.large_params():
             p._pv_grad_mode = mode
             p._pv_pending = None
@@ -120,43 +118,44 @@ class HipAdam(torch.optim.Optimizer):
         self._sharded_dirty = False
 
     # ---- layout of the large matrix's moments --------------------------------------------------------------------------
+    # The flag travels ON the state tensor (`exp_avg._pv_tiled`), so copies of the optimiser (deepcopy) and replaced state
+    # (load_state_dict) cannot disagree with what the bytes actually hold.
+    def _is_tiled(self, p) -> bool:
+        st = self.state.get(p)
+        return bool(st) and getattr(st.get("exp_avg"), "_pv_tiled", False)
+
     def _moments_tiled(self, p) -> bool:
         """Puts exp_avg / exp_avg_sq of p into the tile layout (if the shape allows); True when they are tiled afterwards."""
         if not TILE_LARGE_MOMENTS or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
             self._moments_rows(p)
             return False
-        if id(p) in self._tiled:
+        if self._is_tiled(p):
             return True
         st = self._init_state(p)
         for key in ("exp_avg", "exp_avg_sq"):
             st[key] = K.moments_to_tiled(st[key])
-        self._tiled.add(id(p))
+            st[key]._pv_tiled = True
         return True
 
     def _moments_rows(self, p=None) -> None:
         """Back to row-major (torch's layout) for p, or for every parameter: before anything but the one-pass backward
         reads or writes the moments."""
         for q in ([p] if p is not None else [q for g in self.param_groups for q in g["params"]]):
-            if id(q) in self._tiled:
+            if self._is_tiled(q):
                 st = self.state[q]
                 for key in ("exp_avg", "exp_avg_sq"):
                     st[key] = K.moments_to_rows(st[key])
-                self._tiled.discard(id(q))
 
     def moments(self, p):
         """(exp_avg, exp_avg_sq) of p in torch's row-major layout (copies when the stored layout is tiled)."""
         st = self.state[p]
-        if id(p) in self._tiled:
+        if self._is_tiled(p):
             return K.moments_to_rows(st["exp_avg"]), K.moments_to_rows(st["exp_avg_sq"])
         return st["exp_avg"], st["exp_avg_sq"]
 
     def state_dict(self):
         self._moments_rows()
         return super().state_dict()
-
-    def load_state_dict(self, state_dict):
-        self._tiled.clear()             # whatever is loaded is row-major
-        return super().load_state_dict(state_dict)
 
     def _group_of(self, p):
         for g in self.param_groups:

@@ -294,13 +294,17 @@ def test_tiled_moments_are_private_to_the_one_pass_backward(device, monkeypatch)
             opt.step()
 
         step(batches[0]); step(batches[1])
-        assert (id(fc1) in opt._tiled) == tile
+        assert opt._is_tiled(fc1) == tile
         sd = copy.deepcopy(opt.state_dict())                 # row-major, whatever the stored layout was
-        assert id(fc1) not in opt._tiled
+        assert not opt._is_tiled(fc1)
         snaps.append([t.clone() for t in opt.moments(fc1)])
         step(batches[2])                                     # the next one-pass backward tiles again
-        assert (id(fc1) in opt._tiled) == tile
+        assert opt._is_tiled(fc1) == tile
         snaps.append([t.clone() for t in opt.moments(fc1)])
+        twin = copy.deepcopy(opt)                            # the layout flag travels with the state tensors
+        pt = [q for grp in twin.param_groups for q in grp["params"] if q.shape == fc1.shape][0]
+        assert twin._is_tiled(pt) == tile and all(torch.equal(a, b) for a, b in zip(twin.moments(pt), snaps[-1]))
+        del twin, pt
         # resume in a fresh optimiser from the state saved after step 2 (and the weights of that moment are gone: only the
         # optimiser round trip is under test, so the moments are compared right after loading)
         opt2 = copy.deepcopy(base).configure_optimizers()
@@ -309,7 +313,7 @@ def test_tiled_moments_are_private_to_the_one_pass_backward(device, monkeypatch)
         assert all(torch.equal(a, b) for a, b in zip(opt2.moments(p2), snaps[0]))
         # leaving the fused mode hands the moments back row-major; the two-kernel path continues from them
         opt.set_large_grad_mode("autograd")
-        assert id(fc1) not in opt._tiled
+        assert not opt._is_tiled(fc1)
         step(batches[3])
         opt.set_large_grad_mode("fused")
         step(batches[4])
