@@ -126,7 +126,8 @@ class HipAdam(torch.optim.Optimizer):
 
     def _moments_tiled(self, p) -> bool:
         """Puts exp_avg / exp_avg_sq of p into the tile layout (if the shape allows); True when they are tiled afterwards."""
-        if not TILE_LARGE_MOMENTS or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
+        # (capturable: a captured HIP graph holds the state tensors' addresses, so they must never be replaced -- no tiling)
+        if not TILE_LARGE_MOMENTS or self.capturable or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
             self._moments_rows(p)
             return False
         if self._is_tiled(p):
