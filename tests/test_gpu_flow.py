@@ -207,7 +207,7 @@ def test_farneback_stack_and_params(device):
             assert np.abs(got[c, t] - ref).max() <= 1e-3
 
 
-@pytest.mark.parametrize("h,w,t", [(64, 64, 12), (40, 56, 3), (96, 80, 4)])
+@pytest.mark.parametrize("h,w,t", [(64, 64, 12), (40, 56, 3), (96, 80, 4), (64, 64, 2)])
 def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkeypatch, h, w, t):
     """Consecutive frames of a stack: the per-image stages (smoothing, resize, PolyExp) run once per FRAME instead of once
     per pair side.  The flows must equal, bit for bit, those of the unchained path (PV_FARNEBACK_NO_FRAME_CHAIN=1) and of
