@@ -3,8 +3,9 @@
 `fake_data=True` generates seeded synthetic batches; otherwise whole-batch files (`000000.npz` / `.nc`, see
 data/netcdf_dataset.py) are read from `<data_path>/train` and `<data_path>/test` like the reference does
 (data/dataloader.py:93-131); cloud download and NetCDF-4 decoding are outside the hot path.
-Under data-parallel training each rank takes a disjoint slice of the batch indices (Lightning's
-replace_sampler_ddp, configs/trainer/all_params.yaml:43): samples are independent, no collective."""
+Under data-parallel training each rank takes every world-th batch index, padded by wrapping to equal counts
+(DistributedSampler as Lightning's replace_sampler_ddp installs it, configs/trainer/all_params.yaml:43): samples are
+independent, no collective."""
 import logging
 import os
 from typing import Optional
@@ -12,7 +13,7 @@ from typing import Optional
 import torch
 import yaml
 
-from ..distributed import shard_range
+from ..distributed import shard_indices
 from ..lightning import LightningDataModule
 from .fake import FakeDataConfiguration, FakeDataset
 
@@ -24,16 +25,18 @@ def _identity_collate(x):
 
 
 class _Shard(torch.utils.data.Dataset):
-    def __init__(self, base, lo, hi):
-        self.base, self.lo, self.hi = base, lo, hi
+    """The items of `base` at `indices` (this rank's share: distributed.shard_indices), shifted by `offset`."""
+
+    def __init__(self, base, indices, offset=0):
+        self.base, self.indices, self.offset = base, list(indices), offset
 
     def __len__(self):
-        return self.hi - self.lo
+        return len(self.indices)
 
     def __getitem__(self, i):
         if i >= len(self):
             raise IndexError(i)
-        return self.base[self.lo + i]
+        return self.base[self.offset + self.indices[i]]
 
 
 class NetCDFDataModule(LightningDataModule):
@@ -80,15 +83,15 @@ class NetCDFDataModule(LightningDataModule):
         return cfg
 
     def _loader(self, n_batches: int, offset: int, split: str = "train"):
-        lo, hi = shard_range(n_batches)
+        mine = shard_indices(n_batches)
         if self.fake_data:
             base = FakeDataset(self.configuration, length=offset + n_batches)
-            ds = _Shard(base, offset + lo, offset + hi)
+            ds = _Shard(base, mine, offset)
         else:
             from .netcdf_dataset import NetCDFDataset
             base = NetCDFDataset(n_batches, os.path.join(self.data_path, split), os.path.join(self.temp_path, split),
                                  configuration=self.configuration)
-            ds = _Shard(base, lo, hi)
+            ds = _Shard(base, mine)
         # every item is a whole batch: batch_size=None (data/dataloader.py:82-91)
         return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=0, pin_memory=False)
 

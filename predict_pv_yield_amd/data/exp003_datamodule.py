@@ -1,24 +1,24 @@
 """DataModule for the dict batches of experiments/003_perceiver_processes_single_sat_image_then_rnn.py (synthetic: the
-experiment's own loaders read the OCF zarr stores, outside the hot path).  Whole batches per item, disjoint equal shards
-per rank like data/dataloader.py."""
+experiment's own loaders read the OCF zarr stores, outside the hot path).  Whole batches per item, equal shards
+per rank (padded by wrapping) like data/dataloader.py."""
 import torch
 
-from ..distributed import shard_range
+from ..distributed import shard_indices
 from ..lightning import LightningDataModule
 from ..models.perceiver.exp003 import FakeExp003Dataset
 
 
 class _Slice(torch.utils.data.Dataset):
-    def __init__(self, base, lo, hi):
-        self.base, self.lo, self.hi = base, lo, hi
+    def __init__(self, base, indices):
+        self.base, self.indices = base, list(indices)
 
     def __len__(self):
-        return self.hi - self.lo
+        return len(self.indices)
 
     def __getitem__(self, i):
         if i >= len(self):
             raise IndexError(i)
-        return self.base[self.lo + i]
+        return self.base[self.indices[i]]
 
 
 class Exp003DataModule(LightningDataModule):
@@ -29,8 +29,7 @@ class Exp003DataModule(LightningDataModule):
         self.n_train_data, self.n_val_data, self.seed = n_train_data, n_val_data, seed
 
     def _loader(self, n, seed):
-        lo, hi = shard_range(n)
-        ds = _Slice(FakeExp003Dataset(self.batch_size, self.image_size_pixels, length=n, seed=seed), lo, hi)
+        ds = _Slice(FakeExp003Dataset(self.batch_size, self.image_size_pixels, length=n, seed=seed), shard_indices(n))
         return torch.utils.data.DataLoader(ds, batch_size=None, num_workers=0)
 
     def train_dataloader(self):

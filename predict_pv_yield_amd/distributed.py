@@ -8,7 +8,10 @@ bucketing finer than "everything" only adds launches; xGMI is point-to-point, so
 lets RCCL use all 7 links at once.  The sum is left un-averaged: HipAdam folds 1/world_size into the
 update (grad_scale), saving a pass over 0.5 GB.
 """
+import datetime
 import os
+import sys
+import threading
 from typing import Dict
 
 import torch
@@ -16,13 +19,26 @@ import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients / metrics must be exchanged.  PV_DIST_SINGLE_RANK=1 also counts an initialised ONE-rank group:
+    every collective of the N > 1 path then really runs (RCCL reduce_scatter_tensor / all_gather_into_tensor / all_reduce
+    on one GPU) -- how tests/test_gpu_ddp.py executes the "nccl" branches on the single-GPU test box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PV_DIST_SINGLE_RANK") == "1"
 
 
-def init_from_env(backend: str = None) -> bool:
-    """Initialise from torchrun's RANK / WORLD_SIZE / MASTER_* environment; returns True if world_size > 1."""
+def collective_timeout_s() -> float:
+    """Upper bound on any one collective (PV_DIST_TIMEOUT_S, default 300 s instead of torch's 10 / 30 minutes).  A failed
+    RCCL exchange usually shows as a HANG, not as an exception: with this bound the process-group watchdog aborts the rank
+    (non-zero exit, torchrun then takes the job down) instead of leaving the job stuck."""
+    return float(os.environ.get("PV_DIST_TIMEOUT_S", "300"))
+
+
+def init_from_env(backend: str = None, force: bool = False) -> bool:
+    """Initialise from torchrun's RANK / WORLD_SIZE / MASTER_* environment; returns True if world_size > 1.
+    `force` initialises a one-rank group too (the RCCL code paths can then be exercised on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force:
         return False
     if not dist.is_initialized():
         if backend is None:
@@ -30,8 +46,9 @@ def init_from_env(backend: str = None) -> bool:
             backend = os.environ.get("PV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_device_index())
-        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
-    return True
+        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world,
+                                timeout=datetime.timedelta(seconds=collective_timeout_s()))
+    return world > 1
 
 
 def local_device_index() -> int:
@@ -90,6 +107,22 @@ def row_shard(n_rows: int, rank: int = None, world: int = None):
         return None
     per = n_rows // world
     return rank * per, (rank + 1) * per
+
+
+def shard_indices(n_items: int, rank: int = None, world: int = None):
+    """Item indices of this rank's loader shard, DistributedSampler's rule without shuffling (what Lightning's
+    replace_sampler_ddp installs, configs/trainer/all_params.yaml:43): the index list is PADDED by wrapping around to
+    ceil(n_items / world) * world entries and rank r takes entries r, r + world, ...  Every rank gets the same count (the
+    loops issue collectives per step / per logged metric, so no rank may run short) and no item is dropped; a split with
+    fewer items than ranks (the shipped experiments validate on n_val_data = 2 batches) repeats items instead of failing."""
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    if n_items <= 0:
+        return []
+    per = -(-n_items // world)
+    return [(rank + k * world) % n_items for k in range(per)]
 
 
 def reduce_scatter_rows(full: torch.Tensor):
@@ -239,6 +272,23 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> 
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
         return int(agreed.item()) == 1
 
+    def trial_watchdog(candidate: str):
+        """A trial step that HANGS (the usual face of an RCCL failure) cannot be demoted: no rank can tell the others.
+        After PV_TRIAL_TIMEOUT_S (default 120 s) this rank prints why and exits with status 3 -- os._exit, never an exec
+        (the GPU is initialised) -- and torchrun ends the job."""
+        limit = float(os.environ.get("PV_TRIAL_TIMEOUT_S", "120"))
+        done = threading.Event()
+
+        def watch():
+            if not done.wait(limit):
+                print(f"[predict_pv_yield_amd] rank {dist.get_rank()}: the trial step of gradient exchange mode "
+                      f"'{candidate}' did not finish within {limit:.0f} s (hung collective?); exiting with status 3. "
+                      f"Re-run with a simpler mode (Trainer(large_grad_mode='autograd')) or a longer PV_TRIAL_TIMEOUT_S.",
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+        threading.Thread(target=watch, daemon=True).start()
+        return done
+
     for candidate in _FALLBACKS[mode]:
         ok, sync = 1, None
         # phase 1, local: switching the optimiser over.  Agreed on BEFORE any collective of the trial step is issued, so a
@@ -250,6 +300,7 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> 
             errors.append(f"{candidate}: {type(e).__name__}: {e}")
         if all_ok(ok):
             # phase 2: one whole train step with the real collectives
+            finished = trial_watchdog(candidate)
             try:
                 sync = OverlappedGradSync(model)
                 optimizer.zero_grad(set_to_none=True)
@@ -265,6 +316,7 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> 
                 if sync is not None:
                     sync.remove()
             ok = 1 if all_ok(ok) else 0
+            finished.set()
         else:
             ok = 0
         if ok:
@@ -308,3 +360,19 @@ def shard_range(n_items: int, rank: int = None, world: int = None):
     if per == 0:
         raise ValueError(f"shard_range: {n_items} item(s) cannot be split over {world} ranks (every rank needs >= 1)")
     return rank * per, (rank + 1) * per
+
+
+def shard_indices(n_items: int, rank: int = None, world: int = None):
+    """Item indices of this rank's loader shard, DistributedSampler's rule without shuffling (what Lightning's
+    replace_sampler_ddp installs, configs/trainer/all_params.yaml:43): the index list is PADDED by wrapping around to
+    ceil(n_items / world) * world entries and rank r takes entries r, r + world, ...  Every rank gets the same count (the
+    loops issue collectives per step / per logged metric, so no rank may run short) and no item is dropped; a split with
+    fewer items than ranks (the shipped experiments validate on n_val_data = 2 batches) repeats items instead of failing."""
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    if n_items <= 0:
+        return []
+    per = -(-n_items // world)
+    return [(rank + k * world) % n_items for k in range(per)]

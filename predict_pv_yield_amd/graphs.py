@@ -65,6 +65,26 @@ class GraphedTrainStep:
             optimizer.step()
         self.static_loss = loss.detach()
         self.replays = 0
+        # kernel ARGUMENTS are frozen in the graph: the scratch buffers the captured kernels write to must stay where they
+        # are (hip_ops._workspace refuses to replace them while this graph lives), and the Adam hyper-parameters that
+        # pv_adam_scalars_advance received by value cannot change any more
+        from . import hip_ops as K
+        self._pins = K.pin_workspaces()
+        g = optimizer.param_groups[0]
+        self._hyper = (g["lr"], tuple(g["betas"]), g["eps"])
+
+    def close(self) -> None:
+        """Releases the graph and the workspaces it pinned."""
+        from . import hip_ops as K
+        K.unpin_workspaces(getattr(self, "_pins", None))
+        self._pins = None
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
 
     @staticmethod
     def _backward(loss):
@@ -79,6 +99,13 @@ class GraphedTrainStep:
         return loss
 
     def __call__(self, batch: Dict) -> torch.Tensor:
+        if self.graph is None:
+            raise RuntimeError("GraphedTrainStep: closed")
+        g = self.optimizer.param_groups[0]
+        if (g["lr"], tuple(g["betas"]), g["eps"]) != self._hyper:
+            raise RuntimeError(f"GraphedTrainStep: lr / betas / eps changed after capture ({self._hyper} -> "
+                               f"{(g['lr'], tuple(g['betas']), g['eps'])}); they were frozen as kernel arguments of the "
+                               f"captured step -- capture a new GraphedTrainStep after changing them")
         _copy_into(self.static_batch, batch)
         self.graph.replay()
         self.replays += 1

@@ -43,16 +43,42 @@ def make_farneback_params(pyr_scale=0.5, levels=2, winsize=40, iterations=3, pol
 
 
 _workspaces = {}
+_pinned_workspaces = {}      # key -> number of live HIP graphs whose kernel arguments hold that buffer's address
 
 
 def _workspace(key: str, nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffers owned by the host side (the C ABI never allocates)."""
+    """Grow-only scratch buffers owned by the host side (the C ABI never allocates).  A buffer that a live HIP graph
+    replays into (pin_workspaces) is never replaced: a request that outgrows it raises instead of freeing memory the graph
+    still writes."""
     k = (key, str(device))
     buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and _pinned_workspaces.get(k, 0) > 0:
+            raise RuntimeError(
+                f"workspace '{key}' ({buf.numel()} bytes) is held by a captured HIP graph (graphs.GraphedTrainStep) and a call "
+                f"now needs {nbytes} bytes: replacing it would leave the graph replaying into freed memory.  Run the larger "
+                f"call (e.g. a bigger validation batch, a second model) once BEFORE capturing, or release the graph "
+                f"(GraphedTrainStep.close()).")
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _workspaces[k] = buf
     return buf
+
+
+def pin_workspaces():
+    """Marks every workspace that exists now as held by a captured graph; returns the token for unpin_workspaces."""
+    keys = list(_workspaces)
+    for k in keys:
+        _pinned_workspaces[k] = _pinned_workspaces.get(k, 0) + 1
+    return keys
+
+
+def unpin_workspaces(keys) -> None:
+    for k in keys or ():
+        n = _pinned_workspaces.get(k, 0) - 1
+        if n > 0:
+            _pinned_workspaces[k] = n
+        else:
+            _pinned_workspaces.pop(k, None)
 
 
 def farneback_stack(frames_u8: torch.Tensor, **kwargs) -> torch.Tensor:

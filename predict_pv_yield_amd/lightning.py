@@ -510,8 +510,15 @@ class Trainer:
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
+                # terminate_on_nan: with a fused optimiser (HipAdam "fused": fc1 is stepped inside backward) the loss is
+                # tested BEFORE backward, so a non-finite step leaves weights and moments untouched (one host wait, only
+                # in this opt-in mode); otherwise after backward has been queued
+                nan_first = self.terminate_on_nan and any(getattr(o, "large_grad_mode", None) == "fused"
+                                                          for o in self.optimizers)
+                if nan_first and not torch.isfinite(loss.detach()).all():
+                    raise ValueError("loss is NaN or inf")
                 self._timed("backward", self._backward, loss)
-                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():   # host wait: after backward is queued
+                if self.terminate_on_nan and not nan_first and not torch.isfinite(loss.detach()).all():
                     raise ValueError("loss is NaN or inf")
                 if self.world_size > 1:
                     from .distributed import all_reduce_gradients

@@ -1,6 +1,11 @@
 """HipAdam — torch.optim.Adam(lr=5e-4) (predict_pv_yield/models/base_model.py:255-257) stepped by the fused
 HIP kernel pv_adam_step_f32 (one pass over p, g, m, v; torch's single-tensor Adam order of operations).
 
+Contract of the default single-process mode ("fused", FUSE_DX_INTO_UPDATE): fc1's weight, its bf16 operand copy and both
+moments are updated INSIDE loss.backward() (the one-pass fc1 backward); optimizer.step() then steps the other tensors.
+A backward() without a following step() therefore still changes fc1, a second backward() before step() raises, and
+gradient clipping / accumulation need HipAdam(fuse_large_linear=False).  INTEGRATION.md states this first.
+
 It is a torch.optim.Optimizer so `configure_optimizers()` keeps the Lightning contract and state_dict()
 round-trips (`exp_avg`, `exp_avg_sq`, `step`: the same keys torch.optim.Adam uses, so checkpoints
 interchange).  Parameters that carry a `_pv_bf16_shadow` (fc1 in the bf16 path) get the shadow rewritten in
@@ -156,7 +161,23 @@ class HipAdam(torch.optim.Optimizer):
 
     def state_dict(self):
         self._moments_rows()
+        if self.capturable and self._dev_step is not None:
+            # graph replays advance only the DEVICE counter: it is the truth, the host-side `step` entries are brought up to
+            # it so that a checkpoint resumes with the right bias corrections
+            n = float(self.device_step())
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"].fill_(n)
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self.capturable:
+            steps = [int(st["step"].item()) for st in self.state.values() if "step" in st]
+            if self._dev_step is not None:
+                # in place: a captured graph holds this tensor's address
+                self._dev_step.fill_(max(steps) if steps else 0)
+            self._dev_fresh = False
 
     def _group_of(self, p):
         for g in self.param_groups:

@@ -14,21 +14,42 @@ from . import hip_ops as K
 # autograd's: arrival order) and autograd is told "no gradient" -- it still holds the first tensor, which now carries the sum.
 ACCUMULATE_TIED_GRADS = True
 _TIED = {}
+_TIED_TASK = [-1]
+
+
+def _note_use(ctx, index: int, param) -> None:
+    """Forward side: counts how often `param` is applied in the graph being built (only applications that will receive a
+    gradient).  A parameter applied ONCE per forward (exp-003's untied layers, every Linear of the heads) is never
+    registered below: holding a second reference to its gradient would keep AccumulateGrad from taking the tensor over (one
+    extra copy kernel per parameter and step) and keep a second copy of every gradient alive."""
+    if param is not None and ctx.needs_input_grad[index]:
+        param._pv_uses = getattr(param, "_pv_uses", 0) + 1
 
 
 def _tied_slot(param: torch.Tensor):
-    """-> (key, buffer | None): the tensor this backward pass already handed out for `param`, if any."""
+    """-> (key, buffer | None): the tensor this backward pass already handed out for `param`, if any.  key is None when
+    nothing has to be kept (the parameter was applied once)."""
     task = torch._C._current_graph_task_id()
-    key = (param.data_ptr(), param.numel())
     if not ACCUMULATE_TIED_GRADS or task < 0:
         return None, None
+    if _TIED_TASK[0] != task:               # entries live for one backward pass (as _SHARED_ACT below)
+        _TIED.clear()
+        _TIED_TASK[0] = task
+    uses = getattr(param, "_pv_uses", 0)
+    if uses > 0:
+        param._pv_uses = uses - 1           # this call consumes one of the forward's applications
+    key = (param.data_ptr(), param.numel())
     hit = _TIED.get(key)
-    return key, (hit[1] if hit is not None and hit[0] == task else None)
+    if hit is not None:
+        if uses <= 1:                       # the last contribution: nothing more will be added to the kept tensor
+            _TIED.pop(key, None)
+        return key, hit
+    return (key, None) if uses > 1 else (None, None)
 
 
-def _tied_keep(key, grad: torch.Tensor):
+def _tied_keep(key, grad) -> None:
     if key is not None:
-        _TIED[key] = (torch._C._current_graph_task_id(), grad)
+        _TIED[key] = grad
 
 
 # the same for an ACTIVATION that several layers consume (the projected context of weight-tied cross-attention layers,
@@ -63,6 +84,8 @@ class LinearRowsF32(torch.autograd.Function):
         x2 = x.contiguous().view(-1, x.shape[-1])
         res2 = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
         y = K.gemm(x2, weight.t(), bias=bias, residual=res2)
+        _note_use(ctx, 1, weight)
+        _note_use(ctx, 2, bias)
         ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         return y.view(x.shape[:-1] + (weight.shape[0],))
@@ -215,6 +238,7 @@ class LayerNormF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_fwd(x, weight, bias, eps)
+        _note_use(ctx, 1, weight)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
@@ -245,6 +269,7 @@ class LayerNormForkF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_fwd(x, weight, bias, eps)
+        _note_use(ctx, 1, weight)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y, x.view_as(x)
 

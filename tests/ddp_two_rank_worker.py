@@ -1,6 +1,9 @@
-"""Worker of tests/test_gpu_ddp.py: one of two data-parallel ranks that SHARE the single GPU of the test box (gloo for
-the collectives, PV_SINGLE_DEVICE=1), training the reduced Conv3D model for a few steps in a given large-gradient mode
-and saving the consolidated parameters of rank 0.  Usage: python ddp_two_rank_worker.py <mode> <out.pt> <steps>"""
+"""Worker of tests/test_gpu_ddp.py: one data-parallel rank training the reduced Conv3D model for a few steps in a given
+large-gradient mode and saving the consolidated parameters of rank 0.  Either one of two ranks that SHARE the single GPU of
+the test box (gloo for the collectives, PV_SINGLE_DEVICE=1), or the only rank of a one-rank RCCL group
+(WORLD_SIZE=1, PV_DIST_SINGLE_RANK=1, backend "nccl": the collectives of the N > 1 path really run through RCCL).
+The process group is initialised BEFORE anything touches the GPU.
+Usage: python ddp_two_rank_worker.py <mode> <out.pt> <steps>"""
 import os
 import sys
 
@@ -18,7 +21,8 @@ SMALL = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=60, his
 
 def main():
     mode, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    assert D.init_from_env()
+    D.init_from_env(force=True)
+    assert D.is_distributed()
     rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
     dev = torch.device("cuda", D.local_device_index())
     HipAdam.FUSE_MIN_NUMEL = 1            # the reduced model's fc1 counts as the "large" layer
@@ -46,7 +50,7 @@ def main():
     opt.consolidate_sharded()
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"state": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "y": y,
+        torch.save({"backend": torch.distributed.get_backend(), "world": world, "state": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "y": y,
                     "exp_avg_fc1": opt.state[model.fc1.weight]["exp_avg"].cpu(), "mode": opt.large_grad_mode}, out_path)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

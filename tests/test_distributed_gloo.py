@@ -72,6 +72,12 @@ def _worker(rank, world, port, ret):
         assert spans[-1][1] == (n // w) * w
     with pytest.raises(ValueError):
         D.shard_range(3, 0, 8)                                   # fewer items than ranks: hard error, not an empty shard
+    # loader shards (DistributedSampler's rule): equal counts, padded by wrapping, nothing dropped, never an error
+    assert D.shard_indices(5) == ([0, 2, 4] if rank == 0 else [1, 3, 0])
+    for n, w in ((24900, 8), (10, 4), (2, 8), (7, 2), (1, 3)):
+        parts = [D.shard_indices(n, r, w) for r in range(w)]
+        assert len({len(p) for p in parts}) == 1 and len(parts[0]) == -(-n // w)
+        assert set(i for p in parts for i in p) == set(range(n))
     # negotiate_grad_sync: a mode that fails on ONE rank moves EVERY rank to the next simpler mode, in-process
     class _Opt(torch.optim.SGD):
         def __init__(self, params):
@@ -186,14 +192,14 @@ def _trainer_worker(rank, world, port, tmp, ret):
     tr = pl.Trainer(gpus=0, max_epochs=1, callbacks=[ck], logger=logger)
     tr.fit(toy, datamodule=dm)
     assert dist.is_initialized() and tr.world_size == 2 and tr.is_global_zero == (rank == 0)
-    assert len(toy.seen) == 2                                       # 5 train batches over 2 ranks: 2 each, the tail is dropped
+    assert len(toy.seen) == 3                                       # 5 train batches over 2 ranks: 3 each, padded by wrapping
     w = torch.cat([p.detach().flatten() for p in toy.parameters()])
     ws = [torch.zeros_like(w) for _ in range(world)]
     dist.all_gather(ws, w)
     assert torch.equal(ws[0], ws[1])                                # replicas stayed identical
     seen = [None, None]
     dist.all_gather_object(seen, toy.seen)
-    assert not set(seen[0]) & set(seen[1])                          # disjoint data shards
+    assert len(set(seen[0]) | set(seen[1])) == 5 and len(set(seen[0]) & set(seen[1])) == 1   # all 5 batches, one repeated
     ms = [None, None]
     dist.all_gather_object(ms, tr.callback_metrics["L/Train_epoch"])
     assert abs(ms[0] - ms[1]) < 1e-12
@@ -214,5 +220,54 @@ def test_trainer_joins_the_process_group_from_torchrun_env(tmp_path):
     ck = torch.load(tmp_path / "ckpt" / "last.ckpt")
     assert {"state_dict", "epoch", "global_step", "optimizer_states", "pytorch-lightning_version", "callbacks",
             "lr_schedulers", "hyper_parameters"} <= set(ck)
-    assert ck["epoch"] == 1 and ck["global_step"] == 2             # PL convention: the next epoch to run
+    assert ck["epoch"] == 1 and ck["global_step"] == 3             # PL convention: the next epoch to run
     assert os.path.exists(tmp_path / "csv" / "version_0" / "metrics.csv")
+
+
+def _eight_rank_worker(rank, world, port, ret):
+    """config 4 runs on 8 ranks: the row-sharded exchange, the shard arithmetic and the bf16-on-the-wire sum at that width."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from predict_pv_yield_amd import distributed as D
+    assert D.init_from_env(backend="gloo")
+    n, k = 128, 24                                     # fc1 has 128 rows: 16 per rank
+    assert D.row_shard(n) == (16 * rank, 16 * (rank + 1)) and D.row_shard(100) is None
+    g = torch.Generator().manual_seed(1000 + rank)
+    mine = torch.randn(n, k, generator=g)
+    every = [torch.randn(n, k, generator=torch.Generator().manual_seed(1000 + r)) for r in range(world)]
+    total = torch.stack(every).sum(0)                  # f32 sum in rank order == what gloo's all-reduce may reorder: allclose
+    shard, work = D.reduce_scatter_rows(mine.clone())
+    if work is not None:
+        work.wait()
+    r0, r1 = D.row_shard(n)
+    assert torch.allclose(shard, total[r0:r1], rtol=1e-5, atol=1e-5)
+    mat = torch.full((n, k), -1.0)
+    mat[r0:r1] = float(rank)
+    D.all_gather_rows(mat)
+    assert torch.equal(mat, torch.arange(world, dtype=torch.float32).repeat_interleave(16)[:, None].expand(n, k))
+    assert D.shard_range(64) == (8 * rank, 8 * rank + 8)
+    assert D.shard_indices(2) == [rank % 2]            # the shipped experiments validate on 2 batches: no rank fails or idles
+    # bf16 on the wire (HipAdam large_grad_mode "bf16" / "sharded" exchange fc1's gradient as bf16; the reference
+    # all-reduces f32): 8 bf16 addends summed in bf16 stay within a few bf16 ulps of the f32 sum, norm-wise well under 1 %
+    wire = mine.bfloat16()
+    dist.all_reduce(wire, op=dist.ReduceOp.SUM)
+    exact = torch.stack([e.bfloat16().float() for e in every]).sum(0)
+    rel = ((wire.float() - exact).norm() / exact.norm()).item()
+    assert rel < 6e-3, rel
+    worst = ((wire.float() - exact).abs() / (torch.stack([e.abs() for e in every]).sum(0))).max().item()
+    assert worst < 8 * 2.0 ** -8, worst                # each of the 7 additions rounds to 8 significant bits
+    vals = D.all_reduce_mean_scalars({"NMAE/Train": float(rank)})
+    assert vals == {"NMAE/Train": 3.5}
+    ret[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_eight_rank_gloo_row_shards_and_bf16_wire_sum():
+    world = 8
+    port = 33500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_eight_rank_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))

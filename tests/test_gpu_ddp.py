@@ -65,8 +65,57 @@ def test_sharded_update_equals_allreduce_update(device, tmp_path):
     finally:
         HipAdam.FUSE_MIN_NUMEL = old
     for k, v in model.state_dict().items():
-        # 3 Adam steps of lr 5e-4 (Adam moves a weight by up to lr per step whatever the gradient size, so isolated
-        # near-zero gradients may differ by a step or two: the two half-batch gradients are rounded to bf16
-        # separately before they are summed)
+        # 3 Adam steps of lr 5e-4.  Adam moves a weight by up to lr per step whatever the gradient's size, so a bound on
+        # the LARGEST difference (<= 3 lr) cannot fail; what carries information is how many weights disagree by a whole
+        # step (isolated near-zero gradients whose sign differs: the two half-batch gradients are rounded to bf16
+        # separately before they are summed) and the mean distance in units of lr
         d = (v.cpu() - b["state"][k]).abs()
-        assert d.max().item() <= 1.6e-3 and d.mean().item() <= 1e-4, (k, d.max().item(), d.mean().item())
+        whole_step = (d > 5e-4).float().mean().item()
+        assert whole_step <= 0.01 and d.mean().item() <= 0.2 * 5e-4, (k, whole_step, d.mean().item())
+
+
+def _run_one_rank_rccl(mode, out_path, steps=3):
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               PV_DIST_SINGLE_RANK="1", PV_DIST_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PV_DIST_BACKEND", None)
+    env.pop("PV_SINGLE_DEVICE", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "ddp_two_rank_worker.py"), mode, out_path, str(steps)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    return torch.load(out_path)
+
+
+def test_rccl_branches_run_on_one_rank(device, tmp_path):
+    """backend "nccl" (= RCCL), world_size 1, initialised before any GPU call: reduce_scatter_tensor /
+    all_gather_into_tensor / all_reduce of bf16 tensors and the flat f32 bucket really execute (on 8 GPUs this is the code
+    that runs; `dist.get_backend() == "nccl"` selects it).  With one rank every collective is the identity, so both modes
+    must reproduce the single-process bf16-gradient run bit for bit."""
+    a = _run_one_rank_rccl("sharded", str(tmp_path / "sharded.pt"))
+    b = _run_one_rank_rccl("bf16", str(tmp_path / "bf16.pt"))
+    assert a["backend"] == "nccl" and a["world"] == 1 and a["mode"] == "sharded" and b["mode"] == "bf16"
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+    from tests.ddp_two_rank_worker import SMALL
+    old = HipAdam.FUSE_MIN_NUMEL
+    HipAdam.FUSE_MIN_NUMEL = 1
+    try:
+        torch.manual_seed(518)
+        model = Model(**SMALL, precision="bf16").to(device)
+        opt = model.configure_optimizers()
+        opt.set_large_grad_mode("bf16")
+        g = torch.Generator().manual_seed(7)
+        sat, pv = torch.randn(4, 11, 25, 16, 16, generator=g), torch.rand(4, 25, 128, generator=g)
+        batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    finally:
+        HipAdam.FUSE_MIN_NUMEL = old
+    for run in (a, b):
+        assert run["losses"] == losses
+        for k, v in model.state_dict().items():
+            assert torch.equal(v.cpu(), run["state"][k]), (run["mode"], k)

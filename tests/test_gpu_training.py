@@ -264,6 +264,67 @@ def test_hip_graph_train_step_matches_eager(device):
     assert max(abs(x - y) for x, y in zip(l_graph, l_host)) < 1e-5
 
 
+def test_capturable_checkpoint_carries_the_device_step(device):
+    """graph replays advance only the device-side step counter.  state_dict() must store THAT count, and a
+    resumed optimiser (capturable or not) must continue with its bias corrections; lr frozen in the graph may not change
+    silently; a workspace the graph replays into may not be replaced."""
+    import copy
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd.graphs import GraphedTrainStep
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+              conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
+              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16")
+    torch.manual_seed(11)
+    model = Model(**kw).to(device)
+    g = torch.Generator(device=device).manual_seed(6)
+    batches = [{"satellite": {"data": torch.randn(2, 11, 18, 64, 64, generator=g, device=device)},
+                "pv": {"pv_yield": torch.rand(2, 18, 128, generator=g, device=device)}} for _ in range(7)]
+    opt = HipAdam(model.parameters(), lr=5e-4, capturable=True)
+    step = GraphedTrainStep(model, opt, batches[0], warmup=3)
+    for b in batches[1:6]:
+        step(b)
+    torch.cuda.synchronize()
+    assert opt.device_step() == 8
+    sd = copy.deepcopy(opt.state_dict())
+    assert all(float(st["step"]) == 8.0 for st in sd["state"].values())
+
+    def resume_and_step(capturable):
+        m = copy.deepcopy(model)
+        o = HipAdam(m.parameters(), lr=5e-4, capturable=capturable)
+        o.load_state_dict(copy.deepcopy(sd))
+        o.zero_grad(set_to_none=True)
+        m.training_step(batches[6], 0).backward()
+        o.step()
+        torch.cuda.synchronize()
+        if capturable:
+            assert o.device_step() == 9
+        return [p.detach().clone() for p in m.parameters()]
+
+    p_host, p_dev = resume_and_step(False), resume_and_step(True)
+    step(batches[6])                                   # the original optimiser simply goes on
+    torch.cuda.synchronize()
+    for a, b, c in zip(p_host, p_dev, model.parameters()):
+        torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
+        assert torch.equal(b, c.detach())              # same device-side scalars: bit for bit
+    # a loaded state dict lands in the live device counter in place (the graph holds its address)
+    opt.load_state_dict(copy.deepcopy(sd))
+    assert opt.device_step() == 8
+    # kernel arguments are frozen: changing lr must not be ignored silently
+    opt.param_groups[0]["lr"] = 1e-4
+    with pytest.raises(RuntimeError, match="changed after capture"):
+        step(batches[1])
+    opt.param_groups[0]["lr"] = 5e-4
+    # ... and a workspace the graph replays into is not replaced under it
+    key = next(k for k in K._workspaces if k in K._pinned_workspaces)
+    with pytest.raises(RuntimeError, match="held by a captured HIP graph"):
+        K._workspace(key[0], K._workspaces[key].numel() * 2 + 1, torch.device(key[1]))
+    step.close()
+    K._workspace(key[0], K._workspaces[key].numel() + 1, torch.device(key[1]))       # released: grows again
+
+
 def test_tiled_moments_are_private_to_the_one_pass_backward(device, monkeypatch):
     """HipAdam keeps exp_avg / exp_avg_sq of fc1 tile by tile while the one-pass backward owns them.  Whatever leaves the
     optimiser is torch's row-major layout: state_dict() between steps, a resumed optimiser, a change of gradient mode --
