@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libpvyield_hip.so")
+# PV_YIELD_LIB: tools/diag_stamps.py points this at lib/libpvyield_diag.so (the same sources with s_memtime stamps; `make diag`)
+LIB_PATH = os.environ.get("PV_YIELD_LIB") or os.path.join(_PKG, "lib", "libpvyield_hip.so")
 CSRC_DIR = os.path.join(_PKG, "csrc")
 
 PV_BORDER_CONSTANT = 0

@@ -31,6 +31,10 @@ constexpr int TRI = TR + 2;    // input rows per slice
 constexpr int TW = 64;         // columns per LDS row (62 valid output columns per tile)
 constexpr int TW_VALID = TW - 2;
 
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long v1_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
+
 __device__ __forceinline__ uint32_t gate_word(uint32_t x, uint32_t g) {
   // keep each bf16 half of x only where the matching half of g is > 0
   uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
@@ -321,10 +325,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
     }
   };
 
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, q0, q1, q2, q3, q4, q5, q6, q7;
+#endif
   for (int t = tc0; t < tc1; ++t) {
+    PV_STAMP(q0);
     store_slice(t + 2);
+    PV_STAMP(q1);
     __syncthreads();
+    PV_STAMP(q2);
     if (t + 1 < tc1) load_slice(t + 3);  // prefetch under the MFMAs below
+    PV_STAMP(q3);
     if constexpr (X_F32) {
       if (t == tc0) {
         write_xp(tc0);
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       }
       write_xp(t + 2);
     }
+    PV_STAMP(q4);
     f32x16 acc0;  // bias as the initial accumulator: row(reg j, half hh) = (j&3) + 8*(j>>2) + 4*hh
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
       }
     }
 
+    PV_STAMP(q5);
     // ---- epilogue: ReLU, bf16, store.  Addresses = scalar base of this (b, t) + a 32-bit per-lane offset
     // that does not depend on t, so nothing but 4 offsets stays live across the march. -----------------
 #pragma unroll
@@ -411,9 +424,28 @@ __global__ __launch_bounds__(256, 1) void conv3d_fwd_bf16_kernel(
         }
       }
     }
+    PV_STAMP(q6);
     __syncthreads();  // every wave is done reading slot t%3 before the next store_slice(t+3)
+#ifdef PV_DIAG_STAMPS
+    PV_STAMP(q7);
+    dg[0] += q1 - q0;  // wait for the prefetched slice + convert + LDS writes
+    dg[1] += q2 - q1;  // barrier
+    dg[2] += q3 - q2;  // issue of the next slice's loads
+    dg[3] += q4 - q3;  // xp copy (LDS -> global)
+    dg[4] += q5 - q4;  // MFMA groups (+ deferred write-out of the previous tile)
+    dg[5] += q6 - q5;  // epilogue: relu, pack, LDS transpose writes
+    dg[6] += q7 - q6;  // barrier
+    dg[7] += 1;
+#endif
   }
   if constexpr (!Y_NCDHW) write_out(tc1 - 1);
+#ifdef PV_DIAG_STAMPS
+  {
+    const int wgl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (lane == 0 && wgl * 4 + wave < PV_DIAG_WAVES)
+      for (int i = 0; i < PV_DIAG_SLOTS; ++i) v1_diag[(size_t)(wgl * 4 + wave) * PV_DIAG_SLOTS + i] = dg[i];
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -910,5 +942,11 @@ int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* w
                      d->c_out, d->c_in, xp_out, relu_mask_out);
   return check_launch("pv_conv3d_fwd_bf16_f32in");
 }
+
+#ifdef PV_DIAG_STAMPS
+int pv_diag_read_v1(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::v1_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

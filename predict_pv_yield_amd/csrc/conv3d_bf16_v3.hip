@@ -31,55 +31,51 @@ constexpr uint32_t V3_INVALID = 0x40000000u;
 constexpr int V3_PATCH_CS = 4 * 64 + 16;        // NCDHW epilogue patch: bytes per cout ([4 rows][32 voxels] bf16 + pad)
 constexpr int V3_PATCHB = 16 * V3_PATCH_CS;     // per wave: 16 couts
 
-// ReLU-derivative gate of a bf16 pair: 2 bits (low half > 0, high half > 0); and its application to a bf16 pair
-__device__ __forceinline__ uint32_t v3_gate_bits(uint32_t g) { return relu_bits_of_pair(g); }
-__device__ __forceinline__ uint32_t v3_apply_gate(uint32_t x, uint32_t bits) {
-  return x & (((bits & 1u) ? 0x0000ffffu : 0u) | ((bits & 2u) ? 0xffff0000u : 0u));
-}
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long v3_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#define PV_V3_DIAG(i, a, b) dg[i] += (b) - (a)
+#else
+#define PV_V3_DIAG(i, a, b) do { } while (0)
+#endif
 
-// ---- 1-bit ReLU masks ------------------------------------------------------------------------------------------
-// relu_mask[b][t][h][w] (u32 per voxel): bit c = (activation of channel c > 0).  A forward launch writes it next to
-// its bf16 output; the dgrad whose epilogue applies that ReLU's derivative reads 4 bytes per voxel instead of the 64-byte
-// bf16 voxel (the gated dgrad was 16 us slower per launch than the ungated one: 85 MB of extra reads at B = 32).
-// In this kernel a lane (vox, kg) of wave (ch, wr) owns channels 16ch + 4kg .. +3 of the 8 voxels (orow, half) of its
-// tile rows: 8 nibbles = `gbits`, nibble index 2 * orow + half.  Memory wants, per voxel, the 16 bits of a channel
-// half: the four kg lanes (16 lanes apart) transpose their 4 x 4 bytes (byte = the two nibbles of one orow) with two
-// ds_bpermute rounds, after which lane kg holds row orow = kg complete.  The transpose is its own inverse, so the
-// consumer runs the same routine on what it loaded.
-__device__ __forceinline__ uint32_t v3_kg_transpose(uint32_t x, int lane) {
-  const bool b0 = (lane >> 4) & 1, b1 = (lane >> 5) & 1;
-  const uint32_t ev = (x & 0xffu) | ((x >> 8) & 0xff00u), od = ((x >> 8) & 0xffu) | ((x >> 16) & 0xff00u);
-  const uint32_t keep = b0 ? od : ev, send = b0 ? ev : od;
-  const uint32_t recv = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, (int)send);
-  const uint32_t lo = b0 ? recv : keep, hi = b0 ? keep : recv;
-  const uint32_t y = (lo & 0xffu) | ((hi & 0xffu) << 8) | (((lo >> 8) & 0xffu) << 16) | (((hi >> 8) & 0xffu) << 24);
-  const uint32_t keep2 = b1 ? (y >> 16) : (y & 0xffffu), send2 = b1 ? (y & 0xffffu) : (y >> 16);
-  const uint32_t recv2 = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, (int)send2);
-  return b1 ? (recv2 | (keep2 << 16)) : (keep2 | (recv2 << 16));
+// Packed bf16-pair helpers of the epilogue (one instruction per pair; hipcc turns the equivalent builtins into two compares,
+// two selects and a byte permute).  As 16-bit integers a bf16 is > 0 exactly when the signed value is.
+__device__ __forceinline__ uint32_t v3_pk_max(uint32_t x, uint32_t floor2) {   // signed 16-bit max on both halves
+  uint32_t r;   // floor2 = 0: ReLU (negative floats -> +0); floor2 = 0x80008000 (most negative): no-op
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(floor2));
+  return r;
 }
-// low nibbles of the 4 bytes of x <-> 16 contiguous bits
-__device__ __forceinline__ uint32_t v3_nibbles_to_u16(uint32_t x) {
-  uint32_t y = x & 0x0f0f0f0fu;
-  y = (y | (y >> 4)) & 0x00ff00ffu;
-  return (y | (y >> 8)) & 0xffffu;
-}
-__device__ __forceinline__ uint32_t v3_u16_to_nibbles(uint32_t v) {
-  uint32_t y = v & 0xffffu;
-  y = (y | (y << 8)) & 0x00ff00ffu;
-  return (y | (y << 4)) & 0x0f0f0f0fu;
+__device__ __forceinline__ uint32_t v3_pk_gate(uint32_t x, uint32_t g) {   // keep each half of x where that half of g is > 0
+  uint32_t m, r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(m) : "v"(g));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "s"(0x00010001u));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+  return r;
 }
 
 // One input slice's contribution to output slices s - kt, kt in [KT_LO, KT_HI] (compile-time: head and tail steps of
 // the march feed fewer slices).  P = (s - tc0) % 3 names the accumulator slot of output slice s.
-template <int P, int KT_LO, int KT_HI, int KW>
-__device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3], const bf16x8 (&wfrag)[18],
-                                              const unsigned char* w2, f32x4 (&acc)[3][4][2]) {
+// FIRST (KW == 0 call of a step with KT_LO == 0): the tap (kt 0, kh 0, kw 0) is the first contribution output slice s ever
+// receives, so its MFMA takes the bias vector as the C operand instead of the accumulator -- the 32 accumulator registers
+// of a finished tile need no re-initialisation moves.
+// side(j), j = 6 KW + ir: one vector-memory instruction of the step's staging / write-out work, issued between two rows of
+// MFMAs (see PV_V3_STEP): a burst of them right behind the barrier kept the wave at the issue of its 10..17 memory
+// instructions for a fifth of the step (in-kernel stamps), the queue of the texture-address unit being a few entries deep.
+// W1_LDS: the kt = 1 tap plane of the weights is read from LDS like kt = 2 (w2 - V3_W2B), only kt = 0 stays in registers.
+template <int P, int KT_LO, int KT_HI, int KW, bool W1_LDS, typename Side>
+__device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3],
+                                              const bf16x8 (&wfrag)[W1_LDS ? 9 : 18], const unsigned char* w2,
+                                              f32x4 (&acc)[3][4][2], const f32x4& b4, Side&& side) {
   {
     constexpr int kw = KW;
-    bf16x8 cur[2], nxt[2], wk2[3];
+    bf16x8 cur[2], nxt[2], wk2[3], wk1[W1_LDS ? 3 : 1];
     if (KT_HI == 2) {
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) wk2[kh] = *reinterpret_cast<const bf16x8*>(w2 + (kh * 3 + kw) * 2048);
+    }
+    if (W1_LDS && KT_LO <= 1 && KT_HI >= 1) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) wk1[kh] = *reinterpret_cast<const bf16x8*>(w2 - V3_W2B + (kh * 3 + kw) * 2048);
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) cur[half] = *reinterpret_cast<const bf16x8*>(slot + voff[kw] + half * (16 * V3_VOXB));
@@ -90,6 +86,7 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
         for (int half = 0; half < 2; ++half)
           nxt[half] = *reinterpret_cast<const bf16x8*>(slot + (ir + 1) * V3_ROWB + voff[kw] + half * (16 * V3_VOXB));
       }
+      side(6 * KW + ir);
 #pragma unroll
       for (int kt = KT_LO; kt <= KT_HI; ++kt) {
 #pragma unroll
@@ -99,7 +96,8 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
 #pragma unroll
             for (int half = 0; half < 2; ++half)
               acc[(P - kt + 3) % 3][orow][half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  kt == 2 ? wk2[kh] : wfrag[kt * 9 + kh * 3 + kw], cur[half], acc[(P - kt + 3) % 3][orow][half], 0, 0, 0);
+                  kt == 2 ? wk2[kh] : ((W1_LDS && kt == 1) ? wk1[kh] : wfrag[kt * 9 + kh * 3 + kw]), cur[half],
+                  (kt == 0 && kh == 0 && KW == 0) ? b4 : acc[(P - kt + 3) % 3][orow][half], 0, 0, 0);
           }
         }
       }
@@ -113,20 +111,32 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
 // Y_NCDHW (the last conv layer, whose output fc1 consumes in the reference's flatten order): the finished tile is
 // transposed through a wave-private LDS patch ([cout][row][voxel]) and leaves as 16-byte pieces of a (cout, row) line
 // (w_out % 8 == 0, checked by the launcher).
-// OUT_GATE: 0 = none, 1 = bf16 tensor of the gating activation, 2 = its 1-bit relu mask (out_gate then points to u32
-// words).  MASK_OUT: also write the relu mask of THIS launch's output (forward, NDHWC).
-template <int OUT_GATE, bool Y_NCDHW, bool MASK_OUT = false>
+// OUT_GATE: the dgrad epilogue zeroes dx where the gating activation (the producer layer's ReLU output, bf16 NDHWC, same
+// shape as y) is not > 0.
+//
+// Write-out and gate read (round 3).  An accumulator tile gives a lane 4 couts of one voxel (8 bytes); stored like that,
+// the 64 lanes of an instruction touch 64 different cache lines, and in-kernel stamps (tools/diag_stamps.py) showed the
+// waves parked at the ISSUE of these instructions for a third (forward) to a half (gated dgrad: the gate was fetched the
+// same way) of a step -- the texture-address unit works through an instruction line by line.  Now the two column halves
+// of a tile row swap registers between 16-lane rows (v_permlane16_swap: odd rows of one <-> even rows of the other), after
+// which a lane holds 8 consecutive couts = 16 bytes of a voxel and an instruction covers 32 half-lines instead of 64
+// eighth-lines: 4 dwordx4 stores (and 4 dwordx4 gate loads in the same lane geometry) per step instead of 8 + 8 dwordx2.
+// The gate is applied to the packed bf16 pairs in that swapped geometry (3 packed integer ops per pair), ReLU likewise.
+template <bool OUT_GATE, bool Y_NCDHW>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
-    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out,
-    uint32_t* __restrict__ mask_out = nullptr) {
-  // ring of 2 slices | kt = 2 weight plane | 32 bias floats   (78 KB: two workgroups per CU)
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? 4 * V3_PATCHB : 0)];
-  unsigned char* lds_w2 = lds + 2 * V3_SLOTB;
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out) {
+  // ring of 2 slices | [kt = 1 weight plane] | kt = 2 weight plane | 32 bias floats | [NCDHW patches]
+  // NDHWC variants: 80 512 B, two workgroups per CU use 161 024 of the 163 840 B; the NCDHW variant keeps the kt = 1 plane
+  // in registers (its patches take the room) and issues its memory work in bursts
+  constexpr bool W1_LDS = !Y_NCDHW;
+  constexpr int NWREG = W1_LDS ? 9 : 18;
+  __shared__ __attribute__((aligned(1024))) unsigned char
+      lds[2 * V3_SLOTB + (W1_LDS ? 2 : 1) * V3_W2B + 128 + (Y_NCDHW ? 4 * V3_PATCHB : 0)];
+  unsigned char* lds_w2 = lds + 2 * V3_SLOTB + (W1_LDS ? V3_W2B : 0);
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
   static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
-  static_assert(!(MASK_OUT && (Y_NCDHW || OUT_GATE)), "the relu mask is written by the plain NDHWC forward");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,39 +170,54 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   }
   const uint32_t x_plane_b = (uint32_t)h_in * w_in * 64u, x_row_b = (uint32_t)w_in * 64u;
   const size_t sample_elems = (size_t)t_in * h_in * w_in * 32;
-  const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)b * sample_elems), 0, (int)(sample_elems * 2), 0x00020000);
-  auto load_slice = [&](int s) {
-    const int ti = s - pad_t;
-    const bool t_ok = (unsigned)ti < (unsigned)t_in;
-    const uint32_t toff = (uint32_t)min(max(ti, 0), t_in - 1) * x_plane_b;
-    unsigned char* dst = lds + (s & 1) * V3_SLOTB + wave * V3_ROWB;
+  // piece j = 3 i + p of slice s: row wave + 4 i of the slot, 16-voxel segment p (p = 2: the last two voxels).
+  // Addressing keeps the loop free of vector address arithmetic and of scalar-register pressure (once the loop runs out of
+  // SGPRs hipcc keeps wave-uniform values in vector registers and turns uniform tests into exec-masked branches): the lane
+  // part of an address (column, chunk; or the out-of-range mark) is the instruction's VGPR offset and never changes; the
+  // wave-uniform part (time slice + row) goes into the SGPR offset, which the hardware adds WITHOUT range checking it; a
+  // wave-uniform "nothing there" (row outside the image, time padding, no such slice) selects a descriptor of ZERO
+  // records, for which every lane is out of range: an LDS-direct load then writes zeros (what padding is), a store is
+  // dropped.
+  uint32_t row_src[3];
+  bool row_in[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (wave + 4 * i < V3_TRI) {
-        const int hi = h0 - pad_h + 4 * i + wave;
-        const bool row_ok = t_ok && (unsigned)hi < (unsigned)h_in;
-        const uint32_t srow = toff + (uint32_t)min(max(hi, 0), h_in - 1) * x_row_b + (row_ok ? 0u : V3_INVALID);
-        typedef __attribute__((address_space(3))) void* lds_ptr_t;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB), 16, lane_voff[0] + srow, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB + 1024), 16, lane_voff[1] + srow, 0,
-                                                 0, 0);
-        if (lane < 8)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_ptr_t)(dst + 4 * i * V3_ROWB + 2048), 16, lane_voff[2] + srow,
-                                                   0, 0, 0);
-      }
-    }
+  for (int i = 0; i < 3; ++i) {
+    const int hi = h0 - pad_h + 4 * i + wave;
+    row_in[i] = (unsigned)hi < (unsigned)h_in;
+    row_src[i] = row_in[i] ? (uint32_t)hi * x_row_b : 0u;
+  }
+  const bool wave_has_third_row = wave + 8 < V3_TRI;
+  const void* const x_sample = x + (size_t)b * sample_elems;
+  const int x_sample_b = (int)(sample_elems * 2);
+  auto load_piece = [&](int s, int j, bool live) {   // live: slice s exists (wave-uniform)
+    const int i = j / 3, pc = j - 3 * i;
+    if (i == 2 && !wave_has_third_row) return;
+    const int ti = s - pad_t;
+    const bool ok = live && row_in[i] && (unsigned)ti < (unsigned)t_in;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x_sample, 0, ok ? x_sample_b : 0, 0x00020000);
+    unsigned char* dst = lds + (s & 1) * V3_SLOTB + (wave + 4 * i) * V3_ROWB + pc * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    if (pc < 2 || lane < 8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, lane_voff[pc],
+                                               ok ? (uint32_t)ti * x_plane_b + row_src[i] : 0u, 0, 0);
+  };
+  auto load_slice = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) load_piece(s, j, true);
   };
 
   load_slice(tc0);  // first: its HBM latency hides under the weight loads below
 
   // ---- weights: tap planes kt = 0, 1 resident in registers (18 A fragments, 16 couts x 32 cin), kt = 2 in LDS ----
-  bf16x8 wfrag[18];
+  bf16x8 wfrag[NWREG];
 #pragma unroll
-  for (int tap = 0; tap < 18; ++tap)
+  for (int tap = 0; tap < NWREG; ++tap)
     wfrag[tap] = *reinterpret_cast<const bf16x8*>(wp2 + ((size_t)(tap * 2 + ch) * 64 + lane) * 8);
-  for (int i = tid; i < V3_W2B / 16; i += 256)
-    reinterpret_cast<u32x4*>(lds_w2)[i] = reinterpret_cast<const u32x4*>(wp2 + (size_t)18 * 2 * 64 * 8)[i];
+  {
+    unsigned char* wdst = lds_w2 - (W1_LDS ? V3_W2B : 0);
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wp2 + (size_t)NWREG * 2 * 64 * 8);
+    for (int i = tid; i < (W1_LDS ? 2 : 1) * V3_W2B / 16; i += 256) reinterpret_cast<u32x4*>(wdst)[i] = wsrc[i];
+  }
   const unsigned char* w2 = lds_w2 + ch * 1024 + lane * 16;
 
   // ---- per-lane LDS read offsets of the B operand: voxel 16*half + vox + kw, 16-byte chunk kg ---------------------
@@ -204,49 +229,47 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     voff[kw] = v * V3_VOXB + ((kg ^ (((v >> 2) & 1) << 1)) << 4);
   }
 
-  // ---- write-out geometry: lane (vox, kg) of accumulator [orow][half] holds couts 16ch + 4kg .. +3 of voxel
-  // (row h0 + 4wr + orow, column w0 + 16half + vox): 8 bytes ----------------------------------------------------
+  // ---- write-out geometry.  Accumulator [orow][half] gives lane (vox, kg) couts 16ch + 4kg .. +3 of voxel (row h0 + 4wr +
+  // orow, column w0 + 16half + vox).  After the row swap of the two halves the lane holds couts 16ch + 8(kg>>1) .. +7 of
+  // voxel (same row, column w0 + 16(kg&1) + vox): 16 bytes. --------------------------------------------------------------
   const int plane_out = h_out * w_out;
-  uint32_t st_off[2];
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int col_t = 16 * half + vox;
+  uint32_t st_off;
+  {
+    const int col_t = 16 * (kg & 1) + vox;
     const bool ok = (w0 + col_t) < w_out;
-    st_off[half] = ok ? ((uint32_t)((h0 + 4 * wr) * w_out + w0 + col_t) * 32u + 16u * ch + 4u * kg) * 2u : V3_INVALID;
+    st_off = ok ? ((uint32_t)((h0 + 4 * wr) * w_out + w0 + col_t) * 32u + 16u * ch + 8u * (kg >> 1)) * 2u : V3_INVALID;
   }
   const size_t out_sample_b = (size_t)t_out * plane_out * 64;
-  const __amdgpu_buffer_rsrc_t yrsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(y + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ogrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((OUT_GATE == 1 ? out_gate : y) + (size_t)b * t_out * plane_out * 32), 0, (int)out_sample_b, 0x00020000);
-  // relu-mask addressing (read: OUT_GATE == 2, write: MASK_OUT): lane (vox, kg) handles tile row orow = kg, the voxels
-  // of columns vox and 16 + vox, 16-bit half ch of the per-voxel word
-  // The mask planes are padded to whole tiles ([B][T][ceil8(H)][ceil32(W)] words, pv_relu_mask_dims), so every lane's
-  // address is in range and the second column half is a constant 64 bytes further.
-  const int mask_w = n_colblk * V3_TW_VALID, mask_plane = ((h_out + V3_TR - 1) / V3_TR) * V3_TR * mask_w;
-  const size_t mask_sample_b = (size_t)t_out * mask_plane * 4;
-  const __amdgpu_buffer_rsrc_t mrsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((OUT_GATE == 2 ? reinterpret_cast<const unsigned char*>(out_gate) : reinterpret_cast<const unsigned char*>(mask_out)) +
-              (size_t)b * mask_sample_b),
-      0, (OUT_GATE == 2 || MASK_OUT) ? (int)mask_sample_b : 0, 0x00020000);
-  const uint32_t m_off = (uint32_t)((h0 + 4 * wr + kg) * mask_w + w0 + vox) * 4u + 2u * ch;
-  auto row_off = [&](int o, int orow) -> uint32_t {  // wave-uniform part of the byte offset of (slice o, tile row orow)
-    const bool ok = (h0 + 4 * wr + orow) < h_out;
-    return ok ? (uint32_t)o * (uint32_t)plane_out * 64u + (uint32_t)orow * (uint32_t)w_out * 64u : V3_INVALID;
-  };
-
-  u32x2 pend[4][2];  // finished tile (bf16 pairs), stored one step later so the stores never sit in front of a wait
-  u32x2 og[OUT_GATE == 1 ? 4 : 1][2];
-  // MASK_OUT: the finished tile's relu bits of (row kg, column vox) in the low and (row kg, column 16 + vox) in the high
-  // half, stored with the tile; OUT_GATE 2: the same two 16-bit words as loaded
-  uint32_t mpend = 0u, mpend_hi = 0u;
-  uint32_t gbits = 0u;  // the tile's gate, 4 bits per (row, half): the 16 gate registers live only through the kw = 0 phase
+  // wave-uniform part of an output address: slice o, tile row orow (SGPR offset); rows below the image select the
+  // zero-sized descriptor
+  const uint32_t out_plane_b = (uint32_t)plane_out * 64u, out_row_b = (uint32_t)w_out * 64u;
+  const int rows_left = h_out - (h0 + 4 * wr);   // tile rows orow < rows_left exist
+  void* const y_sample = y + (size_t)b * t_out * plane_out * 32;
+  const void* const og_sample = (OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32;
+  // finished tile in the store geometry (16 bytes per lane and tile row), stored one step later so the stores never sit in
+  // front of a wait; its gate, fetched in the same geometry during the last two thirds of the step that finishes the tile
+  // (the tile of the previous step has left by then, so the two never hold registers at the same time)
   // NCDHW: lane -> 16-byte piece (lane & 3) of line (cout 4i + lane/16, row (lane/4) & 3) for store instruction i
-  unsigned char* patch = lds + 2 * V3_SLOTB + V3_W2B + 128 + (Y_NCDHW ? (tid >> 6) * V3_PATCHB : 0);
+  unsigned char* patch = lds + 2 * V3_SLOTB + (W1_LDS ? 2 : 1) * V3_W2B + 128 + (Y_NCDHW ? (tid >> 6) * V3_PATCHB : 0);
   const int n_orow = (lane >> 2) & 3, n_piece = lane & 3, n_co = lane >> 4;
   const size_t cstride = (size_t)t_out * plane_out;
   const bool n_ok = (h0 + 4 * wr + n_orow) < h_out && (w0 + n_piece * 8) < w_out;
   const size_t n_base = ((size_t)b * c_out + 16 * ch + n_co) * cstride + (size_t)(h0 + 4 * wr + n_orow) * w_out + w0 + n_piece * 8;
+  u32x4 pend[4];
+  u32x4 og[OUT_GATE ? 4 : 1];
+  auto store_row = [&](int o, int orow, bool live) {   // NDHWC only; live: the tile exists (wave-uniform)
+    const bool ok = live && orow < rows_left;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(y_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(pend[orow], rs, st_off, ok ? (uint32_t)o * out_plane_b + (uint32_t)orow * out_row_b : 0u, 0);
+  };
+  auto load_gate_row = [&](int o, int orow) {
+    if constexpr (OUT_GATE) {
+      const bool ok = orow < rows_left;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)og_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
+      og[orow] = __builtin_amdgcn_raw_buffer_load_b128(rs, st_off, ok ? (uint32_t)o * out_plane_b + (uint32_t)orow * out_row_b : 0u, 0);
+    }
+  };
   auto store_pending = [&](int o) {
     if constexpr (Y_NCDHW) {
 #pragma unroll
@@ -257,119 +280,119 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
       }
     } else {
 #pragma unroll
-      for (int orow = 0; orow < 4; ++orow) {
-        const uint32_t ro = row_off(o, orow);
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-          __builtin_amdgcn_raw_buffer_store_b64(pend[orow][half], yrsrc, st_off[half] + ro, 0, 0);
-      }
-      if constexpr (MASK_OUT) {
-        // relu bits of the tile being stored, taken from the very registers that are stored (nothing extra is carried
-        // across the step); the kg transpose runs here, at the top of the step, where register pressure is lowest
-        uint32_t obits = 0u;
-#pragma unroll
-        for (int orow = 0; orow < 4; ++orow)
-#pragma unroll
-          for (int half = 0; half < 2; ++half)
-          {
-            const uint32_t t = relu_pair01(pend[orow][half][0]) | (relu_pair01(pend[orow][half][1]) << 2);   // bits 0, 16, 2, 18
-            obits |= ((t | (t >> 15)) & 0xfu) << (4 * (2 * orow + half));
-          }
-        const uint32_t tr = v3_kg_transpose(obits, lane);  // bytes [kg']: (nibble of column vox | nibble of column 16 + vox << 4)
-        const uint32_t mo = m_off + (uint32_t)o * (uint32_t)mask_plane * 4u;
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v3_nibbles_to_u16(tr), mrsrc, mo, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v3_nibbles_to_u16(tr >> 4), mrsrc, mo + 64u, 0, 0);
-      }
+      for (int orow = 0; orow < 4; ++orow) store_row(o, orow, true);
     }
   };
-  auto load_gate = [&](int o) {
-    if constexpr (OUT_GATE == 1) {
-#pragma unroll
-      for (int orow = 0; orow < 4; ++orow) {
-        const uint32_t ro = row_off(o, orow);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) og[orow][half] = __builtin_amdgcn_raw_buffer_load_b64(ogrsrc, st_off[half] + ro, 0, 0);
-      }
-    } else if constexpr (OUT_GATE == 2) {
-      const uint32_t mo = m_off + (uint32_t)o * (uint32_t)mask_plane * 4u;
-      mpend = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrsrc, mo, 0, 0);
-      mpend_hi = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(mrsrc, mo + 64u, 0, 0);
-    }
-  };
-
-  // accumulators of the three output slices in flight: acc[(o - tc0) % 3][row][half], 16 couts x 16 voxels each,
-  // initialised with the bias of couts 16*ch + 4*kg + reg
+  // accumulators of the three output slices in flight: acc[(o - tc0) % 3][row][half], 16 couts x 16 voxels each; the first
+  // MFMA of an output slice takes the bias of couts 16*ch + 4*kg + reg as its C operand
   f32x4 acc[3][4][2];
 
   // ---- prologue ------------------------------------------------------------------------------------------------
   __syncthreads();  // lds_bias, lds_w2 written
-  {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) acc[j][r4][half] = b4;
-  }
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);
   const int s_last = tc1 + 1;  // last input slice any output slice of this chunk needs
+  const uint32_t relu_floor = relu ? 0u : 0x80008000u;
+
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, q0, q1, q2, q3, q4, q5, q6, q7;
+#endif
 
   // One step of the march.  The loads of slice s+1 (into the slot slice s-1 occupied) and the stores of output slice s-3
   // are issued right after the barrier and have the whole step to complete; the wait at the top of the next step then
-  // costs nothing.
+  // costs nothing.  The gate of the tile a step finishes is requested after the first third of that step and applied when the
+  // tile is converted at its end.
 #define PV_V3_STEP(P, KT_LO, KT_HI)                                                                               \
   {                                                                                                               \
-    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's LDS-direct loads of slice s have landed */        \
+    PV_STAMP(q0);                                                                                                 \
+    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's LDS-direct loads of slice s (and the gate) landed */ \
+    PV_STAMP(q1);                                                                                                 \
     __syncthreads();                    /* ... everybody's; and every wave is done reading slice s-1 */            \
-    if (s + 1 <= s_last) load_slice(s + 1);                                                                       \
-    if (s - 3 >= tc0) store_pending(s - 3);                                                                       \
-    if (OUT_GATE == 1 && KT_HI == 2) load_gate(s - 2);                                                            \
+    PV_STAMP(q2);                                                                                                 \
+    /* the step's vector-memory work, one instruction per MFMA row (side job j = 6 kw + ir): first the 4 stores of the   \
+       tile the previous step finished (their registers are free again after four rows; NCDHW: one burst, the tile comes \
+       from the LDS patch), then the gate of the tile THIS step finishes (consumed at the end of the step; never live    \
+       together with the previous tile), then the 9 staging pieces of slice s+1 (into the slot slice s-1 occupied) */    \
+    const bool do_load = s + 1 <= s_last, do_store = s - 3 >= tc0;                                                \
+    auto side = [&](int j) {                                                                                      \
+      if (j < 4) {                                                                                                \
+        if (!Y_NCDHW) store_row(s - 3, j, do_store);                                                              \
+      } else if (j < 8) {                                                                                         \
+        if (OUT_GATE && KT_HI == 2) load_gate_row(s - 2, j - 4);                                                  \
+      } else if (j < 17) {                                                                                        \
+        load_piece(s + 1, j - 8, do_load);                                                                        \
+      }                                                                                                           \
+    };                                                                                                            \
+    auto no_side = [](int) {};                                                                                    \
+    if (Y_NCDHW) { /* burst form: the tile comes out of the LDS patch, the staging pieces follow */               \
+      if (do_store) store_pending(s - 3);                                                                         \
+      if (do_load) load_slice(s + 1);                                                                             \
+    }                                                                                                             \
+    PV_STAMP(q3);                                                                                                 \
     const unsigned char* slot = lds + (s & 1) * V3_SLOTB + (4 * wr) * V3_ROWB;                                    \
     /* an input slice that lies in the time padding (dgrad: pad_t = 2 -> the two head and the two tail steps of a    \
        whole march) is all zeros: its MFMAs are skipped (wave-uniform branch), the bookkeeping of the step is not.    \
        Only the head / tail instances test it: an interior step of a chunk never reads padding of a whole march's    \
        ends unless the march has fewer than three slices, and its code stays branch-free */                          \
     const bool slice_live = ((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in;             \
-    if (slice_live) v3_accumulate<P, KT_LO, KT_HI, 0>(slot, voff, wfrag, w2, acc);                                \
-    if constexpr (OUT_GATE == 1 && KT_HI == 2) {                                                                  \
-      gbits = 0u;                                                                                                 \
-      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) \
-        gbits |= (v3_gate_bits(og[orow][half][0]) | (v3_gate_bits(og[orow][half][1]) << 2)) << (4 * (2 * orow + half)); \
+    if (slice_live && Y_NCDHW) {                                                                                  \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      PV_STAMP(q4);                                                                                               \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+    } else if (slice_live) {                                                                                      \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      PV_STAMP(q4);                                                                                               \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
+    } else {                                                                                                      \
+      if ((KT_LO) == 0) { /* output slice s receives nothing from this step: arm its accumulators */              \
+        _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) _Pragma("unroll") for (int half = 0; half < 2; ++half)   \
+          acc[P][r4][half] = b4;                                                                                  \
+      }                                                                                                           \
+      if (!Y_NCDHW) {                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 18; ++j) side(j);                                                   \
+      }                                                                                                           \
+      PV_STAMP(q4);                                                                                               \
     }                                                                                                             \
-    if constexpr (OUT_GATE == 2 && KT_HI == 2) { /* row kg of both column halves -> this lane's 8 nibbles */       \
-      gbits = v3_kg_transpose(v3_u16_to_nibbles(mpend) | (v3_u16_to_nibbles(mpend_hi) << 4), lane);                \
-    }                                                                                                             \
-    if (slice_live) {                                                                                             \
-      v3_accumulate<P, KT_LO, KT_HI, 1>(slot, voff, wfrag, w2, acc);                                              \
-      v3_accumulate<P, KT_LO, KT_HI, 2>(slot, voff, wfrag, w2, acc);                                              \
-    }                                                                                                             \
-    if (KT_HI == 2) { /* output slice s-2 is complete: convert it, re-arm its accumulators */                     \
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(lds_bias + 16 * ch + 4 * kg);                              \
-      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
-        f32x4 a = acc[((P) + 1) % 3][orow][half];                                                                 \
-        acc[((P) + 1) % 3][orow][half] = b4;                                                                      \
-        if (relu) {                                                                                               \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j) a[j] = a[j] > 0.f ? a[j] : 0.f;                           \
+    PV_STAMP(q6);                                                                                                 \
+    if (KT_HI == 2) { /* output slice s-2 is complete: convert it into the store geometry */                      \
+      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) {                                                    \
+        u32x2 o[2];                                                                                               \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
+          const f32x4 a = acc[((P) + 1) % 3][orow][half];                                                         \
+          o[half][0] = pack_bf16_pair(a[0], a[1]);                                                                \
+          o[half][1] = pack_bf16_pair(a[2], a[3]);                                                                \
+          o[half][0] = v3_pk_max(o[half][0], relu_floor);                                                         \
+          o[half][1] = v3_pk_max(o[half][1], relu_floor);                                                         \
+          if constexpr (Y_NCDHW) {                                                                                \
+            unsigned char* pp = patch + (4 * kg) * V3_PATCH_CS + orow * 64 + (16 * half + vox) * 2;                 \
+            *reinterpret_cast<uint16_t*>(pp) = (uint16_t)o[half][0];                                              \
+            *reinterpret_cast<uint16_t*>(pp + V3_PATCH_CS) = (uint16_t)(o[half][0] >> 16);                        \
+            *reinterpret_cast<uint16_t*>(pp + 2 * V3_PATCH_CS) = (uint16_t)o[half][1];                            \
+            *reinterpret_cast<uint16_t*>(pp + 3 * V3_PATCH_CS) = (uint16_t)(o[half][1] >> 16);                    \
+          }                                                                                                       \
         }                                                                                                         \
-        u32x2 o;                                                                                                  \
-        o[0] = pack_bf16_pair(a[0], a[1]);                       \
-        o[1] = pack_bf16_pair(a[2], a[3]);                       \
-        if constexpr (OUT_GATE != 0) {                                                                            \
-          o[0] = v3_apply_gate(o[0], gbits >> (4 * (2 * orow + half)));                                           \
-          o[1] = v3_apply_gate(o[1], gbits >> (4 * (2 * orow + half) + 2));                                       \
-        }                                                                                                         \
-        if constexpr (Y_NCDHW) {                                                                                  \
-          unsigned char* pp = patch + (4 * kg) * V3_PATCH_CS + orow * 64 + (16 * half + vox) * 2;                   \
-          *reinterpret_cast<uint16_t*>(pp) = (uint16_t)o[0];                                                      \
-          *reinterpret_cast<uint16_t*>(pp + V3_PATCH_CS) = (uint16_t)(o[0] >> 16);                                \
-          *reinterpret_cast<uint16_t*>(pp + 2 * V3_PATCH_CS) = (uint16_t)o[1];                                    \
-          *reinterpret_cast<uint16_t*>(pp + 3 * V3_PATCH_CS) = (uint16_t)(o[1] >> 16);                            \
-        } else {                                                                                                  \
-          pend[orow][half] = o;                                                                                   \
+        if constexpr (!Y_NCDHW) {                                                                                 \
+          /* odd 16-lane rows of half 0 <-> even rows of half 1: rows 0 / 2 now hold column half 0, rows 1 / 3 half 1, \
+             every lane 8 consecutive couts (first the word pair that came from kg even, then the one from kg odd) */ \
+          const auto r0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);                       \
+          const auto r1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);                       \
+          u32x4 v = {r0[0], r1[0], r0[1], r1[1]};                                                                 \
+          if constexpr (OUT_GATE) {                                                                               \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = v3_pk_gate(v[j], og[orow][j]);                   \
+          }                                                                                                       \
+          pend[orow] = v;                                                                                         \
         }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
-    if constexpr (OUT_GATE == 2 && KT_HI >= 1) load_gate(s - 1); /* mask of the slice the NEXT step finishes */   \
+    PV_STAMP(q7);                                                                                                 \
+    PV_V3_DIAG(0, q0, q1); /* vmcnt(0) */                                                                         \
+    PV_V3_DIAG(1, q1, q2); /* barrier */                                                                          \
+    PV_V3_DIAG(2, q2, q3); /* (NCDHW: tile stores) */                                                             \
+    PV_V3_DIAG(3, q3, q4); /* MFMA kw = 0 + gate request + staging pieces */                                      \
+    PV_V3_DIAG(5, q4, q6); /* MFMA kw = 1, 2 + staging pieces + tile stores */                                    \
+    PV_V3_DIAG(6, q6, q7); /* convert + swap + gate */                                                           \
+    PV_V3_DIAG(7, q0, q0 + 1); /* steps */                                                                        \
   }
 
   int s = tc0;
@@ -405,19 +428,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   }
 #undef PV_V3_STEP
   store_pending(tc1 - 1);  // the tile the last step finished
+#ifdef PV_DIAG_STAMPS
+  {
+    const int wgl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (lane == 0 && wgl * 4 + wave < PV_DIAG_WAVES)
+      for (int i = 0; i < PV_DIAG_SLOTS; ++i) v3_diag[(size_t)(wgl * 4 + wave) * PV_DIAG_SLOTS + i] = dg[i];
+  }
+#endif
 }
 
 // Returns 1 (not a PV_* code) when the shape does not fit this kernel (fewer than 2 output slices per time chunk): the caller falls back
-// to the v2 kernel.
-// out_gate_mask (u32 per voxel of y) takes precedence over out_gate; mask_out (may be NULL) receives the relu mask of y
-// and is only honoured for the plain NDHWC forward (no gate): the caller checks v3_writes_mask().
-bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void* out_gate_mask) { return !y_ncdhw && !out_gate && !out_gate_mask; }
+// to the v2 kernel.  The 1-bit relu masks of the C ABI (out_gate_mask / relu_mask_out) have no path of their own here any
+// more: with the gate fetched as 16-byte pieces the bf16 tensor is as cheap to read as the mask was, so a mask that
+// accompanies out_gate is ignored (same result by definition) and a requested mask is written by the caller's pass over y
+// (v3_writes_mask() == false).
+bool v3_writes_mask(int, const void*, const void*) { return false; }
 
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int y_ncdhw, hipStream_t st, const uint32_t* out_gate_mask, uint32_t* mask_out) {
+                              int y_ncdhw, hipStream_t st, const uint32_t* /*out_gate_mask*/, uint32_t* /*mask_out*/) {
   if (to < 2) return 1;
   if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
+  if (!y_ncdhw && (((uintptr_t)y % 16) != 0 || ((uintptr_t)out_gate % 16) != 0)) return 1;
   const int n_rowblk = (ho + V3_TR - 1) / V3_TR;
   const int n_colblk = (wo + V3_TW_VALID - 1) / V3_TW_VALID;
   // two workgroups per CU: split the time march only when the (sample, tile) grid alone cannot fill 512 slots
@@ -442,18 +474,20 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
     if (to - (n_tchunk - 1) * t_chunk < 2) return 1;
   }
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
-  const uint16_t* og_ptr = out_gate_mask ? reinterpret_cast<const uint16_t*>(out_gate_mask) : out_gate;
-#define PV_LAUNCH_V3(OG, YN, MO)                                                                                      \
-  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN, MO>), grid, dim3(256), 0, st, x, wp2, bias, y, og_ptr, d->t_in,   \
-                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out, \
-                     mask_out)
-  if (y_ncdhw) PV_LAUNCH_V3(0, true, false);
-  else if (out_gate_mask) PV_LAUNCH_V3(2, false, false);
-  else if (out_gate) PV_LAUNCH_V3(1, false, false);
-  else if (mask_out) PV_LAUNCH_V3(0, false, true);
-  else PV_LAUNCH_V3(0, false, false);
+#define PV_LAUNCH_V3(OG, YN)                                                                                          \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in,     \
+                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out)
+  if (y_ncdhw) PV_LAUNCH_V3(false, true);
+  else if (out_gate) PV_LAUNCH_V3(true, false);
+  else PV_LAUNCH_V3(false, false);
 #undef PV_LAUNCH_V3
   return check_launch("pv_conv3d_fwd_bf16(v3)");
 }
 
 }  // namespace pv
+
+#ifdef PV_DIAG_STAMPS
+extern "C" int pv_diag_read_v3(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::v3_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

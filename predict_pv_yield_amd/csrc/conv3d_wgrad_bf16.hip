@@ -28,6 +28,10 @@ constexpr int SLAB_ELEMS = 28 * 32 * 32;  // 27 taps + ones-tap, [co][ci] each
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long wgrad_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
+
 __device__ __forceinline__ uint32_t wg_gate_word(uint32_t x, uint32_t g) {
   uint32_t lo = ((g & 0x7fffu) != 0u && (g & 0x8000u) == 0u) ? 0x0000ffffu : 0u;
   uint32_t hi = ((g & 0x7fff0000u) != 0u && (g & 0x80000000u) == 0u) ? 0xffff0000u : 0u;
@@ -210,14 +214,21 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
     load_x(tc0 + 2);
     load_d(tc0);
 
+#ifdef PV_DIAG_STAMPS
+    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3, s4, s5;
+#endif
     for (int t = tc0; t < tc1; ++t) {
+      PV_STAMP(s0);
       store_x(t + 2);
       store_d();
+      PV_STAMP(s1);
       __syncthreads();
+      PV_STAMP(s2);
       if (t + 1 < tc1) {
         load_x(t + 3);
         load_d(t + 1);
       }
+      PV_STAMP(s3);
       int slot_of_kt[3];
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) slot_of_kt[kt] = ((t + kt) % 3) * SLOTB;
@@ -282,8 +293,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_wgrad_bf16_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      PV_STAMP(s4);
       __syncthreads();
+#ifdef PV_DIAG_STAMPS
+      PV_STAMP(s5);
+      dg[0] += s1 - s0;   // wait for the staged loads + LDS writes of the next slice
+      dg[1] += s2 - s1;   // barrier
+      dg[2] += s3 - s2;   // issue of the next slice's global loads
+      dg[3] += s4 - s3;   // 32 k-steps
+      dg[4] += s5 - s4;   // barrier
+      dg[5] += 1;
+#endif
     }
+#ifdef PV_DIAG_STAMPS
+    if (lane == 0 && wg_id * 4 + wave < PV_DIAG_WAVES)
+      for (int i = 0; i < PV_DIAG_SLOTS; ++i) wgrad_diag[(size_t)(wg_id * 4 + wave) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
   }
 
   // ---- write the partial slab: [tapslot][co][ci], C layout: col = ci = lane&31, row = co ----------
@@ -415,5 +440,11 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
                      (const float*)workspace, n_slabs, dw, dbias, d->c_out, d->c_in);
   return check_launch("pv_conv3d_bwd_weight_bf16");
 }
+
+#ifdef PV_DIAG_STAMPS
+int pv_diag_read_wgrad(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(wgrad_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

@@ -85,5 +85,21 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 }  // namespace pv
 
+// ---- diagnostic build only (make diag: -DPV_DIAG_STAMPS -> lib/libpvyield_diag.so, tools/diag_stamps.py) --------------------
+// s_memtime stamps around the phases of a kernel's main loop; the per-phase sums leave through a buffer of their own that no
+// kernel reads.  The product library is built without the macro: no stamp executes there.
+#ifdef PV_DIAG_STAMPS
+#define PV_STAMP(var)                                                                       \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#define PV_DIAG_SLOTS 8
+#define PV_DIAG_WAVES (1 << 14)
+#else
+#define PV_STAMP(var) do { } while (0)
+#endif
+
 #define PV_REQUIRE(cond, code, ...) \
   do { if (!(cond)) return pv::fail(code, __VA_ARGS__); } while (0)

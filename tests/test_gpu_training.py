@@ -292,7 +292,8 @@ def test_capturable_checkpoint_carries_the_device_step(device):
     assert all(float(st["step"]) == 8.0 for st in sd["state"].values())
 
     def resume_and_step(capturable):
-        m = copy.deepcopy(model)
+        m = Model(**kw).to(device)                     # (a trained module holds non-leaf caches: rebuild, then load)
+        m.load_state_dict(model.state_dict())
         o = HipAdam(m.parameters(), lr=5e-4, capturable=capturable)
         o.load_state_dict(copy.deepcopy(sd))
         o.zero_grad(set_to_none=True)
