@@ -390,6 +390,11 @@ static void wgrad_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, in
   *n_tchunk = (to + *t_chunk - 1) / *t_chunk;
 }
 
+// LDS-direct form (conv3d_wgrad_bf16_v2.hip): serves every launch whose dY needs no gate while it is staged
+size_t wgrad_v2_workspace_bytes(const pv_conv3d_dims* d);
+int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* slabs, const pv_conv3d_dims* d, int to, int ho,
+                                int wo, hipStream_t st, int* n_slabs);
+
 }  // namespace pv
 
 using namespace pv;
@@ -402,7 +407,7 @@ int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* b
              "pv_conv3d_bwd_weight_bf16_workspace_bytes: bad dims");
   int nrb, ncb, ntc, tch;
   wgrad_grid(d, &nrb, &ncb, &ntc, &tch);
-  *bytes = (size_t)d->batch * nrb * ncb * ntc * SLAB_ELEMS * sizeof(float);
+  *bytes = std::max((size_t)d->batch * nrb * ncb * ntc * SLAB_ELEMS * sizeof(float), wgrad_v2_workspace_bytes(d));
   return PV_OK;
 }
 
@@ -425,6 +430,14 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
   PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
              "pv_conv3d_bwd_weight_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
   hipStream_t st = as_stream(stream);
+  if (!y_relu_mask && workspace_bytes >= wgrad_v2_workspace_bytes(d)) {
+    int n2 = 0;
+    if (launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2) == 0) {
+      hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st,
+                         (const float*)workspace, n2, dw, dbias, d->c_out, d->c_in);
+      return check_launch("pv_conv3d_bwd_weight_bf16(v2)");
+    }
+  }
   dim3 grid((unsigned)(nrb * ncb), (unsigned)ntc, (unsigned)d->batch);
   const int cpad = pv_bf16_cpad(d->c_in);
 #define PV_LAUNCH_WGRAD(CP, HG)                                                                                   \
