@@ -319,7 +319,7 @@ def measure_graph_step(dev, b, history_minutes, steps=20):
     return out
 
 
-def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10):
+def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10, warmup=3):
     """The same bf16 train step at the other per-GPU batch sizes of SURVEY.md §8d: the fc1 update (0.6 ms) is a fixed cost
     per step, so samples/s grows with the batch."""
     from predict_pv_yield_amd.models.conv3d.model import Model
@@ -339,7 +339,7 @@ def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10):
             model.training_step(batch, 0).backward()
             opt.step()
 
-        for _ in range(3):
+        for _ in range(warmup):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -502,51 +502,63 @@ def learnable_task(n, t_frames, seed):
     return sat, pv
 
 
-def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=24, batch=8, n_val=16, n_evals=6):
-    """The torch-CPU oracle (oracle/conv3d_oracle.py: the reference's arithmetic) and the HIP bf16 model start from the same
-    weights and take the same n Adam steps on the same batches; both are scored on the same held-out set at the same
-    checkpoints (every second step of the last half of the run).  A single checkpoint of an Adam(5e-4) run at batch 8
-    swings by a factor of two from step to step on either side, so the compared figure is the MEAN over the checkpoints.
-    The oracle's train steps are timed (evaluation excluded): that is the cpu_baseline."""
+def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8, n_val=256, first_eval=16, eval_every=8,
+                                      hip_steps=256):
+    """Three training runs from the same initial weights on the same batches of a learnable synthetic task: the torch-CPU
+    oracle (oracle/conv3d_oracle.py: the reference's f32 arithmetic), the HIP bf16 path (the benched one) and the HIP fp32
+    path.  All three are scored on the same 256 held-out samples at the same step counts.  A single checkpoint of an
+    Adam(5e-4) run of this model swings from step to step on every side (each step moves all 128 M fc1 weights by ~lr), so
+    the compared figure is the MEAN over the checkpoints of the second half of the common run.  The oracle's checkpoints
+    are scored by loading its weights into the HIP fp32 model (parity-tested forward, ms instead of ~7 s of CPU per
+    checkpoint); the LAST one is also scored on the CPU by the oracle itself, and both figures are reported.  The two HIP
+    runs then go on to `hip_steps` (the CPU cannot follow in the time a bench line may take).  The oracle's train steps
+    are timed (evaluation excluded): that is the cpu_baseline."""
     from oracle import conv3d_oracle as co
     from predict_pv_yield_amd.models.conv3d.model import Model
     torch.manual_seed(518)
     oracle = co.OracleConv3dModel(**MODEL_KW, history_minutes=history_minutes)
-    model = Model(**MODEL_KW, history_minutes=history_minutes, precision="bf16")
-    model.load_state_dict(oracle.state_dict())
-    model.to(dev)
-    t_frames = model.history_len_5 + model.forecast_len_5 + 1
+    init = {k: v.clone() for k, v in oracle.state_dict().items()}
+    models = {}
+    for prec in ("bf16", "fp32"):
+        m = Model(**MODEL_KW, history_minutes=history_minutes, precision=prec)
+        m.load_state_dict(init)
+        m.to(dev)
+        m.batch_size = max(m.batch_size, n_val)
+        models[prec] = m
+    scorer = Model(**MODEL_KW, history_minutes=history_minutes, precision="fp32").to(dev)   # scores oracle checkpoints
+    scorer.batch_size = max(scorer.batch_size, n_val)
+    t_frames = models["bf16"].history_len_5 + models["bf16"].forecast_len_5 + 1
     val_sat, val_pv = learnable_task(n_val, t_frames, seed=2)
     y_val = co.select_target(val_pv, 6, batch_size=n_val)
-    eval_at = sorted({n_steps - 2 * i for i in range(n_evals) if n_steps - 2 * i > 0})
+    val_sat_d, val_pv_d, y_val_d = val_sat.to(dev), val_pv.to(dev), y_val.to(dev)
+    eval_at = list(range(first_eval, n_steps + 1, eval_every))
+    hip_eval_at = eval_at + list(range(n_steps + 2 * eval_every, hip_steps + 1, 2 * eval_every))
 
-    def hip_val():
+    def hip_val(m):
         with torch.no_grad():
-            y = model({"satellite": {"data": val_sat.to(dev)}, "pv": {"pv_yield": val_pv.to(dev)}}).cpu()
-        return float((y - y_val).abs().mean())
+            ys = [m({"satellite": {"data": val_sat_d[i:i + 64]}, "pv": {"pv_yield": val_pv_d[i:i + 64]}}) for i in range(0, n_val, 64)]
+        return float((torch.cat(ys) - y_val_d).abs().mean())
 
-    def oracle_val():
-        with torch.no_grad():
-            return float((oracle(val_sat) - y_val).abs().mean())
-
-    model.batch_size = max(model.batch_size, n_val)
-    untrained = hip_val()
-    batches = [learnable_task(batch, t_frames, seed=100 + i) for i in range(n_steps)]
-    # HIP
-    opt = model.configure_optimizers()
-    hip_curve = []
-    for i, (sat, pv) in enumerate(batches):
-        opt.zero_grad(set_to_none=True)
-        model.training_step({"satellite": {"data": sat.to(dev)}, "pv": {"pv_yield": pv.to(dev)}}, 0).backward()
-        opt.step()
-        if i + 1 in eval_at:
-            hip_curve.append(hip_val())
+    untrained = hip_val(models["bf16"])
+    batches = [learnable_task(batch, t_frames, seed=100 + i) for i in range(hip_steps)]
+    curves = {}
+    for prec, m in models.items():
+        opt = m.configure_optimizers()
+        curve = {}
+        for i, (sat, pv) in enumerate(batches):
+            opt.zero_grad(set_to_none=True)
+            m.training_step({"satellite": {"data": sat.to(dev)}, "pv": {"pv_yield": pv.to(dev)}}, 0).backward()
+            opt.step()
+            if i + 1 in hip_eval_at:
+                curve[i + 1] = hip_val(m)
+        curves[prec] = curve
+        del opt
     # oracle on the host cores, train steps timed; oneDNN's Conv3d does not always scale to every hardware thread, so the
     # first steps probe two thread counts and the rest of the run uses the faster one
     ref_opt = co.make_optimizer(oracle)
     all_threads = torch.get_num_threads()
     plans = sorted({all_threads, max(1, all_threads // 4)}, reverse=True)
-    oracle_curve, rates, train_s, done = [], {}, 0.0, 0
+    oracle_curve, rates, train_s, done = {}, {}, 0.0, 0
 
     def oracle_steps(k, threads, record=True):
         nonlocal done, train_s
@@ -562,28 +574,86 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=24, batch=8,
                 acc[0] += dt
                 acc[1] += 1
             if done in eval_at:
-                oracle_curve.append(oracle_val())
+                scorer.load_state_dict(oracle.state_dict())
+                oracle_curve[done] = hip_val(scorer)
 
     oracle_steps(1, plans[0], record=False)                     # first step: one-time oneDNN primitive creation
     for threads in plans:
         oracle_steps(2, threads)
     best_threads = max(plans, key=lambda th: rates[th][1] / rates[th][0])
     oracle_steps(n_steps - done, best_threads)
+    with torch.no_grad():                                        # the last checkpoint once more, by the oracle itself
+        t0 = time.perf_counter()
+        own = float((torch.cat([oracle(val_sat[i:i + 32]) for i in range(0, n_val, 32)]) - y_val).abs().mean())
+        own_s = time.perf_counter() - t0
+    # the same oracle at the benched batch size (a few steps): the figure that stands beside the GPU line's B = 32
+    big = [learnable_task(32, t_frames, seed=900 + i) for i in range(3)]
+    t0 = time.perf_counter()
+    for sat, pv in big[1:]:
+        co.train_steps(oracle, sat, pv, 1, ref_opt)
+    rate_b32 = 32 * len(big[1:]) / (time.perf_counter() - t0)
     torch.set_num_threads(all_threads)
     rate = {th: round(n * batch / sec, 2) for th, (sec, n) in rates.items()}
-    hip_mean, oracle_mean = sum(hip_curve) / len(hip_curve), sum(oracle_curve) / len(oracle_curve)
-    val = {"hip_bf16": round(hip_mean, 6), "oracle_f32_cpu": round(oracle_mean, 6), "untrained": round(untrained, 6),
-           "rel_diff": round(abs(hip_mean - oracle_mean) / oracle_mean, 4),
-           "definition": f"mean validation NMAE over the checkpoints after steps {eval_at}",
-           "checkpoints": {"after_step": eval_at, "hip_bf16": [round(v, 5) for v in hip_curve],
-                           "oracle_f32_cpu": [round(v, 5) for v in oracle_curve]},
+    tail = [k for k in eval_at if k > n_steps // 2]
+    mean = lambda c, ks: sum(c[k] for k in ks) / len(ks)
+    o_mean, b_mean, f_mean = mean(oracle_curve, tail), mean(curves["bf16"], tail), mean(curves["fp32"], tail)
+    late = [k for k in hip_eval_at if k > hip_steps // 2]
+    val = {"hip_bf16": round(b_mean, 6), "hip_fp32": round(f_mean, 6), "oracle_f32_cpu": round(o_mean, 6),
+           "untrained": round(untrained, 6),
+           "rel_diff": round(abs(b_mean - o_mean) / o_mean, 4),
+           "rel_diff_hip_fp32_vs_oracle": round(abs(f_mean - o_mean) / o_mean, 4),
+           "rel_diff_hip_bf16_vs_hip_fp32": round(abs(b_mean - f_mean) / f_mean, 4),
+           "definition": f"mean validation NMAE over the checkpoints after steps {tail} ({n_val} held-out samples, batch {batch})",
+           "checkpoints": {"after_step": eval_at, "hip_bf16": [round(curves['bf16'][k], 5) for k in eval_at],
+                           "hip_fp32": [round(curves['fp32'][k], 5) for k in eval_at],
+                           "oracle_f32_cpu": [round(oracle_curve[k], 5) for k in eval_at]},
+           "oracle_last_checkpoint": {"scored_by_the_oracle_on_cpu": round(own, 6),
+                                      "scored_through_hip_fp32_forward": round(oracle_curve[eval_at[-1]], 6),
+                                      "cpu_scoring_seconds": round(own_s, 1)},
+           "hip_only_continuation": {"steps": hip_steps, "mean_over_steps": late,
+                                     "hip_bf16": round(mean(curves["bf16"], late), 6), "hip_fp32": round(mean(curves["fp32"], late), 6),
+                                     "rel_diff": round(abs(mean(curves["bf16"], late) - mean(curves["fp32"], late))
+                                                       / mean(curves["fp32"], late), 4)},
            "train_steps": done, "train_batch": batch, "val_samples": n_val,
            "task": "BASELINE config 2 model (T=18, 64 px, fc 128/128/64), same initial weights, same batches; every sample has "
                    "a brightness offset u ~ U(-1, 1) on 3 channels of its observed frames, yield = sigmoid(2 u + 0.2 step)"}
     cpu = {"value": rate[best_threads], "unit": "samples/s", "cores": best_threads, "kind": "port",
            "sample": f"{done} Adam steps at B={batch}, T={t_frames}, fp32, torch-CPU oracle (oracle/conv3d_oracle.py), "
-                     f"{train_s:.1f} s of train steps; samples/s by thread count {rate}"}
+                     f"{train_s:.1f} s of train steps; samples/s by thread count {rate}",
+           "at_benched_batch": {"value": round(rate_b32, 2), "unit": "samples/s", "per_step_batch": 32, "steps": len(big) - 1}}
     return val, cpu
+
+
+def flow_cpu_baseline(n_single=4, per_thread=2):
+    """The advection pipeline of config 3 on the host: oracle/pv_oracle.c (the restatement of cv.calcOpticalFlowFarneback /
+    cv.remap; OpenCV itself is not installable here) on the same [12, 11, 64, 64] count stacks, 121 Farneback pairs per
+    sample.  One thread, and one stack per hardware thread in a thread pool (the C library runs with the GIL released; the
+    reference fans the pairs of a stack out over a process pool, notebooks/13_...ipynb:202-232)."""
+    import concurrent.futures as cf
+    import numpy as np
+    from oracle import flow_oracle as fo
+    from predict_pv_yield_amd import optical_flow as of
+    from predict_pv_yield_amd.data.synthetic import advected_counts
+    mean, std = of.SAT_MEAN[1:12], of.SAT_STD[1:12]
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    raw, _ = advected_counts(batch=max(n_single, min(threads * per_thread, 256)), t=12, channels=11, h=64, w=64, seed=1234)
+    one = lambda i: fo.advect_frames(raw[i:i + 1], mean, std, n_future=6)
+    one(0)
+    t0 = time.perf_counter()
+    for i in range(n_single):
+        one(i)
+    single = n_single / (time.perf_counter() - t0)
+    n_pool = min(threads * per_thread, raw.shape[0])
+    with cf.ThreadPoolExecutor(max_workers=threads) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(one, range(n_pool)))
+        pooled = n_pool / (time.perf_counter() - t0)
+    return {"kind": "port", "unit": "samples/s (121 Farneback pairs + weighted mean + normalise + 6 remaps per sample)",
+            "one_thread": {"samples_per_s": round(single, 2), "pairs_per_s": round(121 * single, 1), "ms_per_pair": round(1e3 / (121 * single), 3)},
+            "all_threads": {"samples_per_s": round(pooled, 2), "pairs_per_s": round(121 * pooled, 1), "cores": threads,
+                            "sample": f"{n_pool} stacks in a pool of {threads} threads"},
+            "reference_figure": "cv.calcOpticalFlowFarneback on the 704 x 548 frames of the notebook: ~173 ms per pair on its "
+                                "author's CPU (notebooks/optical_flow_1.ipynb:269) = 2.2 Mpx/s; a 64 x 64 tile is 1/94 of that frame"}
 
 
 def main():
@@ -718,6 +788,10 @@ def main():
                 if args.precision == "bf16":
                     out["hip_graph_step"] = measure_graph_step(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()
+                    if args.history_minutes != 60:   # the reference default (model.py:22-23 history_minutes=60): 19 frames
+                        out["t19"] = dict(measure_batch_sweep(dev, 60, batches=(b,), steps=30, warmup=8)[f"B={b}"], t_frames=19,
+                                          history_minutes=60, per_gpu_batch=b)
+                        out["t19"]["whole_step_frac_of_bf16_mfma_peak"] = round(out["t19"]["samples_per_s"] * 25.27e9 / MFMA_BF16_PEAK, 4)
                     out["batch_sweep"] = measure_batch_sweep(dev, args.history_minutes)
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()
@@ -727,6 +801,12 @@ def main():
             out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["val_nmae"], out["cpu_baseline"] = matched_training_and_cpu_baseline(dev, args.history_minutes)
+            flow_cpu = flow_cpu_baseline()
+            if "config3" in out:
+                out["config3"]["cpu_baseline"] = flow_cpu
+                out["config3"]["speedup_vs_all_threads"] = round(out["config3"]["samples_per_s"] / flow_cpu["all_threads"]["samples_per_s"], 1)
+            else:
+                out["flow_cpu_baseline"] = flow_cpu
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

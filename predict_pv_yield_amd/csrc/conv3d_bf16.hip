@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
 }
 
 // all (weight, orientation) jobs of a model in one launch: 108 blocks per job (54 for the 32x32x16 fragments, 54 for the
-// 16x16x32 fragments of the two-waves-per-SIMD kernel, which exist only for 32 contraction channels)
+// 16x16x32 fragments of the input-stationary kernel (conv3d_bf16_v3.hip), which exist only for 32 contraction channels)
 struct PackTable {
   pv_pack_job job[PV_PACK_MAX_JOBS];
 };
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void repack_gate_ncdhw_to_ndhwc_bf16_v4(const 
 }
 
 // relu_mask[v] (u32 per voxel, bit c = channel c > 0) from an NDHWC bf16 [.., 32] activation: the fallback producer for
-// launches whose kernel does not emit the mask itself (v2 kernel, gated v1 variants).  4 lanes per voxel.
+// launches whose kernel does not emit the mask itself (v3 kernel, gated v1 variants).  4 lanes per voxel.
 __global__ __launch_bounds__(256) void relu_mask_from_ndhwc32_kernel(const uint16_t* __restrict__ y, uint32_t* __restrict__ mask,
                                                                      long long total_vox, int h, int w) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -716,17 +716,13 @@ __global__ __launch_bounds__(256) void relu_mask_from_ndhwc32_kernel(const uint1
   }
 }
 
-// two-waves-per-SIMD variant (conv3d_bf16_v2.hip)
-int launch_conv3d_fwd_bf16_v2(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
-                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int n_rowblk, int n_colblk, int n_tchunk, int t_chunk, hipStream_t st);
 // input-stationary variant (conv3d_bf16_v3.hip, its own 8 x 32 tiling); 1 = shape not covered
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
                               int y_ncdhw, hipStream_t st, const uint32_t* out_gate_mask, uint32_t* mask_out);
 bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void* out_gate_mask);
-void launch_pack_weight_v2(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
-constexpr size_t V2_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;
+void launch_pack_weight_v3(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
+constexpr size_t V3_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;   // the 16x16x32 fragments of conv3d_bf16_v3.hip
 
 }  // namespace pv
 
@@ -802,8 +798,8 @@ int pv_repack_gate_ncdhw_to_ndhwc_bf16(const uint16_t* dy, const uint16_t* y_rel
 size_t pv_conv3d_packed_weight_elems(int32_t k_channels) {
   int cpad = pv_bf16_cpad(k_channels);
   if (cpad <= 0) return 0;
-  // v1 fragments (32x32x16 A operands) followed by the v2 fragments (16x16x32, 32-channel contractions only)
-  return (size_t)27 * (cpad / 16) * 64 * 8 + (cpad == 32 ? V2_WEIGHT_ELEMS : 0);
+  // v1 fragments (32x32x16 A operands) followed by the v3 fragments (16x16x32, 32-channel contractions only)
+  return (size_t)27 * (cpad / 16) * 64 * 8 + (cpad == 32 ? V3_WEIGHT_ELEMS : 0);
 }
 
 int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int32_t c_in, int transpose_flip,
@@ -815,7 +811,7 @@ int pv_conv3d_pack_weight_bf16(const float* w, uint16_t* wp, int32_t c_out, int3
   int ks = pv_bf16_cpad(kch) / 16;
   hipLaunchKernelGGL(pack_weight_kernel, dim3(27 * ks * 2), dim3(256), 0, as_stream(stream), w, wp, c_out, c_in, ks,
                      transpose_flip ? 1 : 0);
-  if (ks == 2) launch_pack_weight_v2(w, wp + (size_t)27 * 2 * 64 * 8, c_out, c_in, transpose_flip, as_stream(stream));
+  if (ks == 2) launch_pack_weight_v3(w, wp + (size_t)27 * 2 * 64 * 8, c_out, c_in, transpose_flip, as_stream(stream));
   return check_launch("pv_conv3d_pack_weight_bf16");
 }
 
@@ -876,15 +872,11 @@ int pv_conv3d_fwd_bf16(const uint16_t* x, const uint16_t* gate, const uint16_t* 
                        relu_mask_out, total_vox, ho, wo);
     return check_launch("pv_conv3d_fwd_bf16(relu mask)");
   };
-  if (cpad == 32 && !gate) {  // 32 -> 32 channel layers: two-waves-per-SIMD kernels
+  if (cpad == 32 && !gate) {  // 32 -> 32 channel layers: the input-stationary kernel (two workgroups per CU)
     const bool in_kernel = relu_mask_out && v3_writes_mask(y_ncdhw, out_gate, out_gate_mask);
     const int rc = launch_conv3d_fwd_bf16_v3(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu,
                                              y_ncdhw, st, out_gate_mask, in_kernel ? relu_mask_out : nullptr);
     if (rc != 1) return in_kernel ? rc : mask_fallback(rc);
-  }
-  if (cpad == 32 && !gate && !y_ncdhw) {
-    return mask_fallback(launch_conv3d_fwd_bf16_v2(x, wp + (size_t)27 * 2 * 64 * 8, bias, y, out_gate, d, to, ho, wo, relu,
-                                                   n_rowblk, n_colblk, n_tchunk, t_chunk, st));
   }
   uint32_t* v1_mask = (relu_mask_out && !out_gate && !y_ncdhw) ? relu_mask_out : nullptr;
 #define PV_LAUNCH_CONV(CP, HG, YN, OG)                                                                           \

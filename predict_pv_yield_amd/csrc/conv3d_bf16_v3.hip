@@ -1,9 +1,9 @@
-// bf16 MFMA Conv3D for 32 -> 32 channel layers, INPUT-STATIONARY time march (forward L1..L2 and every dgrad).
+// bf16 MFMA Conv3D for 32 -> 32 channel layers, INPUT-STATIONARY time march (forward L1..L3 and every dgrad).
 //
-// conv3d_bf16_v2.hip computes one output slice at a time from the three input slices it needs: every B fragment
-// (activations, 32 cin x 16 voxels) read from LDS feeds only the 3 kh taps of one kt plane, and the two waves of a
-// cout pair read the same fragments -- 864 ds_read_b128 per slice and CU = 6912 LDS cycles, exactly the 6912 matrix-pipe
-// cycles per SIMD: LDS bandwidth co-limits the kernel (measured matrix pipe busy 60 %).
+// Its predecessor (two waves per SIMD, 16 couts per wave, one output slice at a time from the three input slices it needs;
+// removed in round 3) read every B fragment (activations, 32 cin x 16 voxels) for only the 3 kh taps of one kt plane, and
+// the two waves of a cout pair read the same fragments -- 864 ds_read_b128 per slice and CU = 6912 LDS cycles, exactly the
+// 6912 matrix-pipe cycles per SIMD: LDS bandwidth co-limited it (measured matrix pipe busy 60 %).
 //
 // Here the march is turned around: each step takes ONE INPUT slice s and adds its contribution to the three output
 // slices s, s-1, s-2 (tap planes kt = 0, 1, 2) that are in flight in registers.  A fragment is read once and feeds up
@@ -19,7 +19,7 @@
 // TWO slots deep.  That shrinks the LDS footprint enough to run two independent 4-wave workgroups per CU (tile 8 rows x
 // 32 columns each, one wave of each workgroup per SIMD): the two workgroups drift apart, so while one sits at its
 // barrier or converts / stores a finished tile the other keeps the matrix pipe busy -- without the lock-step a single
-// 8-wave workgroup imposes.  Same swizzled LDS image and weight fragments (pack_weight_v2_kernel) as v2.
+// 8-wave workgroup imposes.  Weight fragments: pack_weight_v3_kernel below.
 #include "pv_common.h"
 
 namespace pv {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   const int b = blockIdx.z;
   const int tc0 = blockIdx.y * t_chunk;
   const int tc1 = min(tc0 + t_chunk, t_out);
-  if (tc1 - tc0 < 2) return;  // the launcher sends single-slice chunks to the v2 kernel
+  if (tc1 - tc0 < 2) return;  // (the launcher never forms single-slice chunks: such launches take the v1 kernel)
 
   if (tid < 32) lds_bias[tid] = (bias && tid < c_out) ? bias[tid] : 0.f;
 
@@ -437,8 +437,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
 #endif
 }
 
+// w[Co,Ci,27] f32 -> 16x16x32 A fragments [27][2 cout halves][64 lanes][8]:
+//   lane (co = lane&15, kg = lane>>4), element j  <-  W[cout = 16*half + co][cin = 8*kg + j][tap]
+// transpose_flip: the dgrad operator, W'[cout' = ci][cin' = co][tap] = W[co][ci][26 - tap]
+__global__ __launch_bounds__(256) void pack_weight_v3_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp2,
+                                                              int c_out, int c_in, int transpose_flip) {
+  const int total = 27 * 2 * 64 * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, half = (i >> 9) & 1, tap = i >> 10;
+    const int row = 16 * half + (lane & 15);  // output channel of this operator
+    const int k = 8 * (lane >> 4) + j;        // input channel of this operator
+    float v = 0.f;
+    if (!transpose_flip) {
+      if (row < c_out && k < c_in) v = w[((size_t)row * c_in + k) * 27 + tap];
+    } else {
+      if (row < c_in && k < c_out) v = w[((size_t)k * c_in + row) * 27 + (26 - tap)];
+    }
+    wp2[i] = f32_to_bf16_bits(v);
+  }
+}
+
+void launch_pack_weight_v3(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st) {
+  hipLaunchKernelGGL(pack_weight_v3_kernel, dim3(54), dim3(256), 0, st, w, wp2, c_out, c_in, transpose_flip ? 1 : 0);
+}
+
 // Returns 1 (not a PV_* code) when the shape does not fit this kernel (fewer than 2 output slices per time chunk): the caller falls back
-// to the v2 kernel.  The 1-bit relu masks of the C ABI (out_gate_mask / relu_mask_out) have no path of their own here any
+// to the one-wave-per-SIMD kernel of conv3d_bf16.hip.  The 1-bit relu masks of the C ABI (out_gate_mask / relu_mask_out) have no path of their own here any
 // more: with the gate fetched as 16-byte pieces the bf16 tensor is as cheap to read as the mask was, so a mask that
 // accompanies out_gate is ignored (same result by definition) and a requested mask is written by the caller's pass over y
 // (v3_writes_mask() == false).

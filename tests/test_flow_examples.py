@@ -47,6 +47,31 @@ def test_host_sampling_matches_notebook_restatement():
     assert batch[fa.HISTORICAL_SAT_IMAGES].shape == (3, 4, 64, 64) and batch[fa.FORECAST_HORIZON].shape == (3,)
 
 
+def test_sampler_matches_the_notebook_cells_themselves():
+    """tests/golden/flow_sampler.npz was produced by exec'ing the notebook's sample_squares / normalise_forecast_horizon /
+    super_batch_to_example cells (13_...ipynb:604-728; make_flow_sampler_golden.py) on this very super batch with rng 42:
+    the NumPy restatement (the oracle of the GPU tests) and the product's host sampler reproduce every draw -- crops,
+    horizons and the position of the random stream."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "flow_sampler.npz"))
+    n_draws, seed, rng_seed = (int(v) for v in g["params"])
+    sat, preds, index = _fake_super_batch(seed=seed)
+    sb = {fe.SAT_IMAGES: torch.from_numpy(sat), fe.OPTICAL_FLOW_PREDICTIONS: torch.from_numpy(preds),
+          fe.PREDICTION_INDEX: torch.from_numpy(index)}
+    rng_a, rng_b = np.random.default_rng(rng_seed), np.random.default_rng(rng_seed)
+    for i in range(n_draws):
+        h_c, p_c, horizon_s, t_c = fo.super_batch_to_example_np(sat, preds, index, rng_b)           # 128 / 64 px defaults
+        ex = fe.super_batch_to_example(sb, rng=rng_a)
+        for name, ours, prod in (("hist", h_c, ex[fa.HISTORICAL_SAT_IMAGES]), ("pred", p_c, ex[fa.OPTICAL_FLOW_PREDICTIONS]),
+                                 ("target", t_c, ex[fa.TARGET_SAT_IMAGE])):
+            assert ours.astype(np.float64).sum() == g[f"{name}_sum"][i], (i, name)
+            assert np.float32(ours.reshape(-1)[0]) == g[f"{name}_corner"][i], (i, name)
+            assert np.array_equal(prod.numpy(), ours), (i, name)
+        assert np.float32(fa.normalise_forecast_horizon(horizon_s)) == g["horizon"][i]
+        assert float(ex[fa.FORECAST_HORIZON]) == float(g["horizon"][i])
+    assert rng_a.integers(0, 1 << 30) == rng_b.integers(0, 1 << 30) == int(g["rng_probe"])
+
+
 def test_pick_example_indices_ranges():
     _, _, index = _fake_super_batch(t=14, h=8, w=8)
     rng = np.random.default_rng(1)

@@ -113,14 +113,15 @@ def test_bf16_gradients_vs_f32_oracle_loose(device):
         _check(f"loose grad {k} rel", _rel(p.grad.cpu(), q.grad), 0.2 if "conv" in k else 5e-2)
 
 
-def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, lr_frac_p999, tag=""):
-    """Parameters: mean abs difference and the 99.9th percentile, in units of one Adam step (lr)."""
+def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, frac_whole_step, tag=""):
+    """Parameters after the same number of Adam steps on both sides: mean abs difference in units of one step (lr), and
+    the FRACTION of weights that disagree by more than a whole step.  (Adam moves a weight by at most ~lr per step whatever
+    the gradient's size, so a bound on the largest difference -- 2 lr after one step, 6 lr after three -- can never fail;
+    a weight that is a whole step apart went the other way on one side: the sign of a near-zero gradient flipped.)"""
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         d = (p.detach().cpu() - q.detach()).abs().flatten()
-        sample = d if d.numel() <= 4_000_000 else d[:: d.numel() // 4_000_000]
-        mean, p999 = d.mean().item() / LR, torch.quantile(sample, 0.999).item() / LR
-        _check(f"{tag} {k} mean |dp|/lr", mean, lr_frac_mean)
-        _check(f"{tag} {k} p99.9 |dp|/lr", p999, lr_frac_p999)
+        _check(f"{tag} {k} mean |dp|/lr", d.mean().item() / LR, lr_frac_mean)
+        _check(f"{tag} {k} fraction with |dp| > lr", (d > LR).float().mean().item(), frac_whole_step)
 
 
 @pytest.mark.parametrize("emulate", [True, False])
@@ -157,9 +158,9 @@ def test_bf16_adam_steps_with_the_fused_fc1_kernel(device, emulate):
             from predict_pv_yield_amd.functional import bf16_shadow_of
             assert torch.equal(bf16_shadow_of(model.fc1.weight), model.fc1.weight.detach().to(torch.bfloat16))
             # one Adam step moves a weight by <= lr; disagreement needs a sign flip of a near-zero gradient
-            _adam_compare(model, opt, oracle, ref_opt, 0.02 if emulate else 0.5, 2.05, f"emulate={emulate} step1")
+            _adam_compare(model, opt, oracle, ref_opt, 0.02 if emulate else 0.5, 0.5, f"emulate={emulate} step1")
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-3 if emulate else 3e-2)
-    _adam_compare(model, opt, oracle, ref_opt, 0.1 if emulate else 1.0, 6.1, f"emulate={emulate} step3")
+    _adam_compare(model, opt, oracle, ref_opt, 0.1 if emulate else 1.0, 0.5, f"emulate={emulate} step3")
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         st, rst = opt.state[p], ref_opt.state[q]
         assert float(st["step"]) == 3.0, k
@@ -192,7 +193,7 @@ def test_fp32_path_at_headline_size(device):
     ref_opt = co.make_optimizer(oracle)
     ref_opt.step()
     opt.step()
-    _adam_compare(model, opt, oracle, ref_opt, 0.01, 2.05, "fp32 step1")
+    _adam_compare(model, opt, oracle, ref_opt, 0.01, 0.5, "fp32 step1")
 
 
 def test_b32_first_step_loss(device):
