@@ -102,7 +102,9 @@ def test_bf16_forward_losses_and_all_gradients_tight(device, batch):
 
 
 def test_bf16_gradients_vs_f32_oracle_loose(device):
-    """Against the pure-f32 reference arithmetic the bf16 path carries operand-rounding noise through four conv layers."""
+    """Against the pure-f32 reference arithmetic the bf16 path carries operand-rounding noise through four conv layers and
+    the ReLU units it flips (measured norm-wise, round 3: conv weights / biases 3-11 %, fc1 / fc2 0.3 %, fc3 / fc4 0.03 %);
+    the bounds are those figures with a margin of ~1.4, per layer group, so a regression of the rounding points shows."""
     oracle, model = _pair("bf16", device)
     sat, pv = _data(4, seed=3)
     y_ref, ref_losses = _oracle_backward(oracle, sat, pv)
@@ -110,7 +112,8 @@ def test_bf16_gradients_vs_f32_oracle_loose(device):
     assert abs(float(loss) - ref_losses[1]) <= 1e-2 * ref_losses[1]
     loss.backward()
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
-        _check(f"loose grad {k} rel", _rel(p.grad.cpu(), q.grad), 0.2 if "conv" in k else 5e-2)
+        bound = 0.15 if "conv" in k else (6e-3 if k.startswith(("fc1", "fc2")) else 1e-3)
+        _check(f"loose grad {k} rel", _rel(p.grad.cpu(), q.grad), bound)
 
 
 def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, frac_whole_step, tag=""):
@@ -158,9 +161,9 @@ def test_bf16_adam_steps_with_the_fused_fc1_kernel(device, emulate):
             from predict_pv_yield_amd.functional import bf16_shadow_of
             assert torch.equal(bf16_shadow_of(model.fc1.weight), model.fc1.weight.detach().to(torch.bfloat16))
             # one Adam step moves a weight by <= lr; disagreement needs a sign flip of a near-zero gradient
-            _adam_compare(model, opt, oracle, ref_opt, 0.02 if emulate else 0.5, 0.5, f"emulate={emulate} step1")
+            _adam_compare(model, opt, oracle, ref_opt, 0.01 if emulate else 0.35, 6e-3 if emulate else 0.2, f"emulate={emulate} step1")
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-3 if emulate else 3e-2)
-    _adam_compare(model, opt, oracle, ref_opt, 0.1 if emulate else 1.0, 0.5, f"emulate={emulate} step3")
+    _adam_compare(model, opt, oracle, ref_opt, 0.06 if emulate else 0.45, 6e-3 if emulate else 0.2, f"emulate={emulate} step3")
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         st, rst = opt.state[p], ref_opt.state[q]
         assert float(st["step"]) == 3.0, k
@@ -193,7 +196,7 @@ def test_fp32_path_at_headline_size(device):
     ref_opt = co.make_optimizer(oracle)
     ref_opt.step()
     opt.step()
-    _adam_compare(model, opt, oracle, ref_opt, 0.01, 0.5, "fp32 step1")
+    _adam_compare(model, opt, oracle, ref_opt, 1e-3, 2e-4, "fp32 step1")
 
 
 def test_b32_first_step_loss(device):

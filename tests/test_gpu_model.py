@@ -191,10 +191,12 @@ def test_fused_fc1_adam_path_in_the_model(device, monkeypatch):
     # fc1's dx comes from a different kernel in the single-pass form (same operands, another summation order): isolated
     # 1-ulp bf16 differences in dx, so the trajectories agree closely instead of bit for bit
     np.testing.assert_allclose(losses_a, losses_b, rtol=1e-5)
-    # (Adam turns a sign flip of a near-zero gradient into a difference of 2 lr per step: bound the mean tightly, the maximum by that)
+    # (Adam turns a sign flip of a near-zero gradient into a difference of up to 2 lr per step, so the LARGEST difference is
+    # bounded by construction and says nothing: the mean distance and the share of weights a whole step apart do)
     for (k, a), (_, b) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
         d = (a - b).abs()
-        assert d.mean().item() <= 0.1 * 5e-4 and d.max().item() <= 3 * 2.05 * 5e-4, (k, d.mean().item(), d.max().item())
+        whole_step = (d > 5e-4).float().mean().item()
+        assert d.mean().item() <= 0.1 * 5e-4 and whole_step <= 0.02, (k, d.mean().item(), whole_step)
 
 
 def test_deferred_and_eager_fused_updates_agree(device, monkeypatch):
