@@ -365,6 +365,12 @@ int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_av
  * pv_adam_step_f32 keeps the shadow current. */
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);
 
+/* replaces: the backward of F.relu (predict_pv_yield/models/conv3d/model.py:117-120 under loss.backward()) as its own pass:
+ * out[i] = y[i] > 0 ? dy[i] : 0 (f32, n % 4 == 0, 16-byte aligned; out may alias dy).  The exact-f32 model uses it on fc1's
+ * input gradient so that the last conv layer's dgrad / wgrad receive an already gated gradient (their matrix-core kernels
+ * stage operands global -> LDS directly and cannot gate on the way). */
+int pv_relu_gate_f32(const float* dy, const float* y, float* out, size_t n, void* stream);
+
 /* replaces: nn.Embedding(num_embeddings=940, embedding_dim=16)(id) and its backward
  * (predict_pv_yield/models/conv3d/model_sat_nwp.py:149-151, 251-260).  ids: device int64[n_ids]; out-of-range ids give a
  * zero row.  bwd overwrites dtable[n_rows, dim] with the per-row sums of dout (fixed order, no atomics). */

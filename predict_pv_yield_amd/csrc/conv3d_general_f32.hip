@@ -853,7 +853,7 @@ __global__ __launch_bounds__(512) void conv3d_wgrad_mfma_f32(const float* __rest
 
 static bool wgrad_mfma_ok(const Geom& g) {
   const bool k_ok = (g.kt == 2 || g.kt == 3 || g.kt == 1) && g.kh == 3 && g.kw == 3;
-  return k_ok && g.st == 1 && g.sh == 1 && g.sw == 1 && g.c_in >= 16 && g.c_in <= 32 && g.c_out >= 16 && g.c_out <= 32 &&
+  return k_ok && g.st == 1 && g.sh == 1 && g.sw == 1 && g.c_in >= 8 && g.c_in <= 32 && g.c_out >= 16 && g.c_out <= 32 &&
          g.w_out >= 32 && (long long)g.c_in * g.t_in * g.h_in * g.w_in * 4 <= (1ll << 30) &&
          (long long)g.c_out * g.t_out * g.h_out * g.w_out * 4 <= (1ll << 30);
 }
@@ -1107,8 +1107,11 @@ static bool launch_tiled_s1(const float* x, const float* gate, const float* w, c
 // unit-stride launch of the matrix-core kernel (same argument conventions as launch_tiled_s1); false = shape not covered
 static bool launch_mfma_s1(const float* x, const float* gate, const float* w, const float* bias, float* y, const Geom& g,
                            int batch, int relu, int flip, int w_ci_dim, const float* out_gate, hipStream_t stream) {
-  if (!(g.kt == 2 && g.kh == 3 && g.kw == 3)) return false;
-  if (g.c_in < 16 || g.c_in > 32 || g.c_out > 32 || g.w_out < 64) return false;
+  if (!((g.kt == 2 || g.kt == 3) && g.kh == 3 && g.kw == 3)) return false;
+  // (3,3,3): the 32 -> 32 layers of the PV-yield model in exact f32 (precision="fp32"); its 11-channel first layer would
+  // leave one wave pair multiplying zero channels (the tap-plane split needs two planes) and takes the tiled kernel
+  if (g.c_in < 16 || g.c_in > 32 || g.c_out > 32 || g.w_out < 48) return false;
+  if (g.kt == 3 && g.c_in <= 16) return false;
   if ((size_t)g.c_in * g.t_in * g.h_in * g.w_in * 4 > 0x40000000ull) return false;   // 32-bit raw-buffer offsets
   if ((size_t)g.c_out * g.t_out * g.h_out * g.w_out * 4 > 0x40000000ull) return false;
   const int n_wt = (g.w_out + 63) / 64;
@@ -1120,15 +1123,16 @@ static bool launch_mfma_s1(const float* x, const float* gate, const float* w, co
   const long long items = cols * n_hseg;
   if (items > 0x7fffffffLL) return false;
   if (gate) return false;   // an input gate cannot be applied on the global -> LDS path: the tiled kernel serves it
-  if (g.c_in > 16 && g.c_out <= 16)
-    conv3d_fwd_mfma_f32<2, 3, 3, true, true><<<dim3((unsigned)items), dim3(256), 0, stream>>>(
-        x, w, bias, y, g, relu, flip, w_ci_dim, out_gate, hseg, n_hseg);
-  else if (g.c_in > 16)
-    conv3d_fwd_mfma_f32<2, 3, 3, true><<<dim3((unsigned)items), dim3(256), 0, stream>>>(x, w, bias, y, g, relu, flip,
-                                                                                         w_ci_dim, out_gate, hseg, n_hseg);
-  else
-    conv3d_fwd_mfma_f32<2, 3, 3, false><<<dim3((unsigned)items), dim3(256), 0, stream>>>(x, w, bias, y, g, relu, flip,
-                                                                                          w_ci_dim, out_gate, hseg, n_hseg);
+#define PV_MFMA_S1(KT_, ...)                                                                                     \
+  conv3d_fwd_mfma_f32<KT_, 3, 3, __VA_ARGS__><<<dim3((unsigned)items), dim3(256), 0, stream>>>(                  \
+      x, w, bias, y, g, relu, flip, w_ci_dim, out_gate, hseg, n_hseg)
+  if (g.kt == 3) {
+    if (g.c_out <= 16) PV_MFMA_S1(3, true, true);
+    else PV_MFMA_S1(3, true);
+  } else if (g.c_in > 16 && g.c_out <= 16) PV_MFMA_S1(2, true, true);
+  else if (g.c_in > 16) PV_MFMA_S1(2, true);
+  else PV_MFMA_S1(2, false);
+#undef PV_MFMA_S1
   return true;
 }
 

@@ -343,6 +343,25 @@ class Conv3dGeneralF32(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class ReluGateF32(torch.autograd.Function):
+    """Identity on a ReLU output y; its backward applies that ReLU's derivative (dy where y > 0) in one streaming pass, so
+    the layer that produced y can be told `dy_pregated` (its matrix-core dgrad / wgrad then read dy as it is)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return K.relu_gate_f32(dy, y)
+
+
+def relu_gate_f32(y):
+    return ReluGateF32.apply(y)
+
+
 def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_relu_output=False, dy_pregated=False):
     return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu, x_is_relu_output, dy_pregated)
 

@@ -644,6 +644,17 @@ def conv_geom(batch, c_in, c_out, t, h, w, kernel, stride=1, padding=0) -> Conv3
     return Conv3dGeom(batch, c_in, c_out, t, h, w, *_triple(kernel), *_triple(stride), *_triple(padding))
 
 
+def relu_gate_f32(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dy where y > 0, else 0 (the backward of F.relu, model.py:117-120), f32."""
+    require_cuda(dy, y)
+    if dy.dtype != torch.float32 or y.dtype != torch.float32 or dy.numel() != y.numel() or dy.numel() % 4:
+        raise TypeError("relu_gate_f32: two float32 tensors of equal size (a multiple of 4 elements)")
+    dy, y = dy.contiguous(), y.contiguous()
+    out = torch.empty_like(dy)
+    check(get_lib().pv_relu_gate_f32(ptr(dy), ptr(y), ptr(out), dy.numel(), current_stream_ptr()), "pv_relu_gate_f32")
+    return out
+
+
 def conv3d_general_fwd_f32(x, weight, bias, stride=1, padding=0, relu=False):
     require_cuda(x, weight, bias)
     b, ci, t, h, w = x.shape

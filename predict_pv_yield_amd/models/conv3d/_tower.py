@@ -48,8 +48,18 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
             c_in = channels
         out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
         return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True, x_is_relu_output=True)   # out = relu(last conv)
-    out = data
-    for layer in convs:
-        out = Fn.conv3d_relu_f32(out, layer.weight, layer.bias, tuple(padding), relu=True)
+    # precision="fp32": exact-f32 arithmetic on the reference layout.  32-channel 3x3x3 layers run on the f32 matrix cores
+    # (v_mfma_f32_32x32x2_f32: forward / dgrad conv3d_fwd_mfma_f32<3,3,3>, weight gradient conv3d_wgrad_mfma_f32<3,3,3>),
+    # the first layer and odd shapes on the register-tiled FMA kernels; each dgrad gates dx with its producer's ReLU
+    out = data.float() if data.dtype != torch.float32 else data
+    n = len(convs)
+    # every layer receives an already gated gradient: from the next layer's dgrad epilogue, the last one from a streaming
+    # gate of fc1's input gradient (sizes that are no multiple of 4: the last layer gates while it stages, on the tiled kernel)
+    gate_last = (batch_size * flat_features) % 4 == 0
+    for i, layer in enumerate(convs):
+        out = Fn.conv3d_general_f32(out, layer.weight, layer.bias, stride=(1, 1, 1), padding=tuple(padding), relu=True,
+                                    x_is_relu_output=i > 0, dy_pregated=(i + 1 < n) or gate_last)
+    if gate_last:
+        out = Fn.relu_gate_f32(out)
     out = out.reshape(batch_size, flat_features)
     return Fn.linear_f32(out, fc1.weight, fc1.bias, relu=True)
