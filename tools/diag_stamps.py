@@ -23,6 +23,7 @@ LABELS = {
     "wgrad_v1": ("pv_diag_read_wgrad", ["wait loads + LDS writes", "barrier", "issue next loads", "32 k-steps (MFMA)", "barrier", "slices"]),
     "v3": ("pv_diag_read_v3", ["vmcnt(0)", "barrier", "issue loads/stores", "MFMA kw=0", "(unused)", "gate request + MFMA kw=1,2",
                                "convert + swap + gate", "steps"]),
+    "first": ("pv_diag_read_first", ["barrier (waiting for the loaders)", "MFMA groups", "epilogue", "slices"]),
     "v1": ("pv_diag_read_v1", ["wait + convert + LDS writes", "barrier", "issue next loads", "xp copy", "MFMA groups",
                                "epilogue", "barrier", "slices"]),
 }
@@ -55,7 +56,7 @@ def run():
         wp = K.conv3d_pack_weight_bf16(w, transpose_flip=False)
         bias = torch.zeros(32, device=dev)
         fn = lambda: K.conv3d_fwd_bf16_f32in(x, wp, bias, 32, (0, 0, 0), True, want_packed=True)
-        return fn, "v1"
+        return fn, "first"
     raise SystemExit(__doc__)
 
 
