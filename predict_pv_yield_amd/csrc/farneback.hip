@@ -538,7 +538,8 @@ __device__ __forceinline__ fb_v16f fb_mfma3(const FbSplit3& a, const FbSplit3& b
 }
 
 template <int NB>   // tile edge = 32 NB; NB waves per image pair, 4 / NB pairs per workgroup
-__global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
+// (NB == 1: 80 accumulator registers and 47 KB of LDS -- two workgroups per CU)
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
                                                             const float* __restrict__ Gh, float* __restrict__ flow,
                                                             int height, int width, long long n_pairs) {
   constexpr int T = 32 * NB, XS = T + 8, PLANE = T * XS, PPW = 4 / NB, KS = 2 * NB;   // KS contraction steps of 16
@@ -724,6 +725,136 @@ __global__ __launch_bounds__(256) void fb_tile_mfma_kernel(const float* __restri
             fl[1] = fyv;
           }
         }
+    }
+  }
+}
+
+// ---- 64 x 64 tiles, second form: one wave per QUADRANT of the output, two workgroups per CU ---------------------------
+// fb_tile_mfma_kernel<2> gives a wave a 64-row x 32-column strip: 5 channels x 2 row blocks of results = 160 accumulator
+// registers, which pins the kernel at one wave per SIMD -- and its counters read: matrix pipe busy 23 %, vector ALU 38 %,
+// parked 38 % of the wave's cycles (nothing covers a wave's splits, LDS round trips and barriers).  Here a wave owns ONE
+// 32 x 32 quadrant (strip, output row block mbo): the vertical pass needs U of both row blocks of its strip, so the
+// horizontal pass is computed by both waves of a strip (48 + 24 instead of 48 + 48 MFMA triples per channel and wave: half as
+// many again matrix instructions per pair), but the results are 5 x 16 registers and the workgroup (= one pair, 79 KB of
+// LDS) fits a CU TWICE: two waves per SIMD, each running while the other splits operands or waits.  Staging is shared by the
+// four waves (16 values per lane and channel, split once into the three bf16 planes), double buffered over the channels.
+// Same arithmetic as fb_tile_mfma_kernel<2> per output element (the products and their order inside fb_mfma3; the
+// contraction order of both passes), so the flows are bit-identical to it.
+__global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
+                                                                const float* __restrict__ Gh, float* __restrict__ flow,
+                                                                int height, int width, long long n_pairs) {
+  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
+  constexpr int NE = T * T / 256;            // staged elements per lane and channel
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][3][PLANE];
+  __shared__ u32x4 GvS[2 * KS * 3][64];      // [mbo][ks][plane], lane-major
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int strip = wave & 1, mbo = wave >> 1;
+  const long long per_img = (long long)height * width;
+
+  FbSplit3 gh[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    gh[ks] = fb_split3(t);
+  }
+  for (int j = wave; j < 2 * KS; j += 4) {      // (mbo, ks) pairs dealt to the four waves
+    const int mb = j / KS, ks = j - mb * KS;
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    const FbSplit3 g = fb_split3(t);
+    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
+    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
+    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
+  }
+  __syncthreads();
+
+  for (long long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+    fb_v16f res[5];
+    float stg[NE];
+    // staging element e of this thread: quad q = tid + 256 (e / 4) of 4 consecutive columns, column 4 (q % 16) + e % 4
+    auto load_channel = [&](int c) {
+      const float* src = Min + (p * 5 + c) * per_img;
+#pragma unroll
+      for (int e = 0; e < NE / 4; ++e) {
+        const int q = tid + 256 * e;
+        const int y = q >> 4, x = (q & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < height && x < width) v = *reinterpret_cast<const f32x4*>(src + (long long)y * width + x);
+        stg[4 * e] = v[0]; stg[4 * e + 1] = v[1]; stg[4 * e + 2] = v[2]; stg[4 * e + 3] = v[3];
+      }
+    };
+    load_channel(0);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      uint16_t* Xc = &Xs[c & 1][0][0];
+#pragma unroll
+      for (int e8 = 0; e8 < NE / 8; ++e8) {
+        const float t[8] = {stg[8 * e8], stg[8 * e8 + 1], stg[8 * e8 + 2], stg[8 * e8 + 3],
+                            stg[8 * e8 + 4], stg[8 * e8 + 5], stg[8 * e8 + 6], stg[8 * e8 + 7]};
+        const FbSplit3 sp = fb_split3(t);
+        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {        // two quads of 4 consecutive columns
+          const int q = tid + 256 * (2 * e8 + u2);
+          const int y = q >> 4, x = (q & 15) * 4;
+          *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u2], hw[2 * u2 + 1]};
+          *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u2], mw[2 * u2 + 1]};
+          *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u2], lw[2 * u2 + 1]};
+        }
+      }
+      __syncthreads();   // the image is staged by all four waves (the buffer of channel c - 1 may still be read)
+      if (c < 4) load_channel(c + 1);
+      // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'], both row blocks, this wave's 32 columns ----------------------
+      fb_v16f u[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          FbSplit3 a;
+          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+          a.h = *reinterpret_cast<const bf16x8*>(xa);
+          a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
+          a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
+          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
+        }
+      }
+      // ---- vertical, this wave's output row block: Out[y][x] = sum_y' Gv[y][y'] U[y'][x] -----------------------------------
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+        const FbSplit3 b = fb_split3(t);
+        FbSplit3 g;
+        g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
+        g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
+        g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
+        res[c] = fb_mfma3(g, b, res[c]);
+      }
+    }
+    __syncthreads();   // both image buffers free before the next pair's channels 0 / 1 are staged
+    // ---- 2x2 solve; accumulator register r = row y, lane = column x: coalesced flow rows ---------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
+      if (y < height && x < width) {
+        double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+        double idet = __ddiv_rn(1.0, det);
+        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+        float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
+        fl[0] = fxv;
+        fl[1] = fyv;
+      }
     }
   }
 }
@@ -1102,9 +1233,16 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
           hipLaunchKernelGGL(fb_tile_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
                              (const float*)Gh, flow, lh, lw, (long long)n_pairs);
         } else {
-          const unsigned grid = (unsigned)std::min<long long>((n_pairs + 1) / 2, 2048);
-          hipLaunchKernelGGL(fb_tile_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
-                             (const float*)Gh, flow, lh, lw, (long long)n_pairs);
+          // (width % 4 and the alignment of M decide between the quadrant kernel's 16-byte staging and the strip kernel)
+          if ((lw & 3) == 0 && ((uintptr_t)M & 15) == 0 && !getenv("PV_FARNEBACK_STRIP_KERNEL")) {
+            const unsigned grid = (unsigned)std::min<long long>(n_pairs, 4096);
+            hipLaunchKernelGGL(fb_tile_mfma_q_kernel, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+                               (const float*)Gh, flow, lh, lw, (long long)n_pairs);
+          } else {
+            const unsigned grid = (unsigned)std::min<long long>((n_pairs + 1) / 2, 2048);
+            hipLaunchKernelGGL(fb_tile_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
+                               (const float*)Gh, flow, lh, lw, (long long)n_pairs);
+          }
         }
         if (update) {
           stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
