@@ -1,13 +1,27 @@
 """One Conv3D tower + its first fully-connected layer, shared by model.py (padding 0) and model_sat_nwp.py
 (padding (1,0,0), two towers).  Every FLOP runs in the gfx950 kernels behind include/pv_yield_hip.h."""
+import logging
+
 import torch
 
 from ... import functional as Fn
 
+_LOG = logging.getLogger(__name__)
+_WARNED = set()
+
 
 def bf16_tower_supported(c_in: int, channels: int, flat_features: int) -> bool:
-    """The MFMA path pads channels to 16 or 32 and streams fc1 in 8-element (16-byte) groups."""
-    return 16 < channels <= 32 and c_in <= 32 and flat_features % 8 == 0
+    """The MFMA path pads channels to 16 or 32 and streams fc1 in 8-element (16-byte) groups.  Asked only by models built
+    with precision="bf16": a shape outside it falls to the exact-f32 kernels (several times slower: the f32 matrix cores
+    run at 1/16 of the bf16 rate, and shapes they do not cover take register-tiled FMA kernels) -- said once per shape."""
+    ok = 16 < channels <= 32 and c_in <= 32 and flat_features % 8 == 0
+    if not ok and (c_in, channels, flat_features) not in _WARNED:
+        _WARNED.add((c_in, channels, flat_features))
+        _LOG.warning("predict_pv_yield_amd: precision='bf16' was requested, but a Conv3D tower with %d input channels, %d conv "
+                     "channels and %d flattened features is outside the bf16 matrix-core kernels (conv channels 17..32, input "
+                     "channels <= 32, features %% 8 == 0): it runs on the exact-f32 kernels, expect a several times slower step",
+                     c_in, channels, flat_features)
+    return ok
 
 
 def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, padding, flat_features: int,
