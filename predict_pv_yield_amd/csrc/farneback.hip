@@ -340,7 +340,6 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
 // coefficient plane, (dx, dy) = current flow; out = (G11, G12, G22, h1, h2)
 __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, const float* __restrict__ R1, float dx,
                                                 float dy, int x, int y, int width, int height, float* m) {
-  const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
   const size_t step1 = (size_t)width * 5;
   float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
   int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
@@ -374,10 +373,13 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
   r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
   r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
   if ((unsigned)(x - 5) >= (unsigned)(width - 10) || (unsigned)(y - 5) >= (unsigned)(height - 10)) {
-    float scale = (x < 5 ? border[x] : 1.f);
-    scale = __fmul_rn(scale, (x >= width - 5 ? border[width - x - 1] : 1.f));
-    scale = __fmul_rn(scale, (y < 5 ? border[y] : 1.f));
-    scale = __fmul_rn(scale, (y >= height - 5 ? border[height - y - 1] : 1.f));
+    // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge, as selects (an indexed local array is a
+    // memory load per lookup)
+    auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
+    float scale = border(x);
+    scale = __fmul_rn(scale, border(width - x - 1));
+    scale = __fmul_rn(scale, border(y));
+    scale = __fmul_rn(scale, border(height - y - 1));
     r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
     r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
   }
@@ -859,6 +861,299 @@ __global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __r
   }
 }
 
+// ---- one whole Farneback iteration per launch for 64 x 64 tiles: UpdateMatrices + window blur + 2x2 solve --------------
+// The two-launch form writes M (5 floats per pixel and pair) and reads it back a few microseconds later, and its
+// UpdateMatrices launch gathers the four bilinear neighbours of R1 as 20 dword loads of 20-byte records per pixel (ten cache
+// lines per wave instruction).  Here M never leaves the chip and the gathers are LDS reads.  A workgroup owns a contiguous
+// range of pairs and has two kinds of waves:
+//   * waves 4..7 PRODUCE: they bring the second image's coefficient plane R1 (<= 80 KB) into LDS with LDS-direct loads,
+//     evaluate FarnebackUpdateMatrices (fb_update_pixel, the expressions of fb_update_matrices_kernel in the same order) for
+//     16 pixels per lane -- 4 quads of 4 consecutive columns, R0 and the flow read as 16-byte loads -- and keep the 80
+//     results in registers; channel by channel they split them into the three bf16 planes of the blur's A operand and write
+//     them into a double-buffered LDS image;
+//   * waves 0..3 MULTIPLY: the quadrant scheme of fb_tile_mfma_q_kernel (horizontal pass of both row blocks of the strip,
+//     vertical pass of the own row block, six bf16 partial products per f32 product), then the 2x2 solve and the flow store.
+// One barrier per channel (k = running channel number) hands an image over: before barrier k the producers wrote channel k
+// and the multiplying waves finished channel k-1, so the producers may overwrite the buffer of channel k-1 (= that of k+1)
+// right after it.  The same barriers order the producers among themselves: R1 of the next pair is requested after the
+// barrier of channel 0 (every producer has finished the pair's gathers before it wrote channel 0), each wave waits for its
+// own requests before the barrier of channel 4, and the next pair's pixels are evaluated after that barrier, under the
+// multiplying waves' last channel and solve.
+// FLOW_SRC as in fb_update_matrices_kernel (0: flow_in is this level's flow -- the launch updates it in place, a pair's flow
+// is read in full by its producers before its multiplying waves store the new one; 1: the coarser level's flow, resized on
+// the fly; 2: zero).  Same arithmetic per output element as UpdateMatrices + fb_tile_mfma_q_kernel: bit-identical flows.
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long fb_fused_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
+typedef int fb_i32x4 __attribute__((ext_vector_type(4)));
+typedef float fb_f32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char* fb_lds_ptr;
+// 16 bytes per lane from a raw buffer straight into LDS at lds_addr + 16 * lane (inline assembly: see w2_lds_dma16 in
+// conv3d_wgrad_bf16_v2.hip for why not the builtin); lanes whose voff is outside the descriptor write zeros
+__device__ __forceinline__ void fb_lds_dma16(uint32_t lds_addr, uint32_t voff, fb_i32x4 rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+template <int FLOW_SRC>
+__global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __restrict__ R, const float* flow_in,
+                                                                 float* flow_out, const float* __restrict__ Gv,
+                                                                 const float* __restrict__ Gh, int height, int width,
+                                                                 long long n_pairs, long long pairs_per_group, int chain_f,
+                                                                 FbUpsample up) {
+  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
+  __shared__ __attribute__((aligned(16))) float R1s[T * T * 5];
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][3][PLANE];
+  __shared__ u32x4 GvS[2 * KS * 3][64];      // [mbo][ks][plane], lane-major
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int col = lane & 31, half = lane >> 5;
+  const long long per_img = (long long)height * width;
+  const long long p_lo = n_pairs * blockIdx.x / gridDim.x, p_hi = n_pairs * (blockIdx.x + 1) / gridDim.x;
+
+  for (int j = wave8; j < 2 * KS; j += 8) {      // Gv split operands, dealt to the eight waves
+    const int mb = j / KS, ks = j - mb * KS;
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    const FbSplit3 g = fb_split3(t);
+    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
+    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
+    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
+  }
+
+  // coefficient image i1 -> LDS, a quarter per producing wave
+  const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
+  const int img_bytes = (int)per_img * 20;
+  const uint32_t lane16 = (uint32_t)lane * 16;
+  auto request_r1 = [&](long long i1) {
+    const uintptr_t a = (uintptr_t)(R + i1 * per_img * 5);
+#pragma unroll
+    for (int j = 0; j < 20; ++j) {      // 1 KB per wave instruction, the four waves interleaved
+      const int off = (4 * j + (wave8 & 3)) * 1024;
+      if (off < img_bytes) {      // one lane offset for all: the chunk's start goes into the descriptor, which still ends at the image
+        const uintptr_t ac = a + (uintptr_t)off;
+        fb_lds_dma16(r1_lds + (uint32_t)off, lane16, (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
+      }
+    }
+  };
+
+  if (producer) {
+    // ================================ producing waves ===================================================================
+    const int ptid = tid - 256;
+    auto i0_of = [&](long long p) {
+      long long i0, i1;
+      fb_r_images_of(p, pairs_per_group, chain_f, &i0, &i1);
+      return i0;
+    };
+    float m[16][5];
+    // R0 and the flow of a pair's first 8 pixels are requested a whole pair ahead (right after the R1 request: their latency
+    // is covered by the four channel hand-overs in between; all 16 would not fit the registers next to m)
+    fb_f32x4_t r0q[4][5], flq[4][2];
+    // raw buffer loads: one lane offset for R0 and one for the flow, the quad's rows in the scalar offset; a quad below the
+    // image reads zeros (one beside it is never used: update_pair zero-fills it)
+    const uint32_t quad_px = (uint32_t)((ptid >> 4) * width + (ptid & 15) * 4);
+    const uint32_t r0_lane = quad_px * 20, fl_lane = quad_px * 8;
+    auto prefetch_pair = [&](long long p, long long i0, int e_lo, int e_hi) {
+      const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0 * per_img * 5), 0, img_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t flrs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? p * per_img * 2 : 0)), 0, (int)per_img * 8, 0x00020000);
+#pragma unroll
+      for (int e = e_lo; e < e_hi; ++e) {
+        const uint32_t rows = (uint32_t)(16 * e * width);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
+        if constexpr (FLOW_SRC == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
+        }
+      }
+    };
+    auto update_pair = [&](long long p, long long i0) {
+      prefetch_pair(p, i0, 2, 4);      // the second half arrives under the first half's arithmetic
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = ptid + 256 * e;
+        const int y = q >> 4, x0 = (q & 15) * 4;
+        if (y < height && x0 < width) {
+          float r0[20];
+#pragma unroll
+          for (int i = 0; i < 20; ++i) r0[i] = r0q[e][i >> 2][i & 3];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float fdx = 0.f, fdy = 0.f;
+            if constexpr (FLOW_SRC == 0) {
+              fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
+            } else if constexpr (FLOW_SRC == 1) {
+              const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, x0 + j, y, up.inv_fx, up.inv_fy, up.mul);
+              fdx = f[0], fdy = f[1];
+            }
+            fb_update_pixel(r0 + 5 * j, R1s, fdx, fdy, x0 + j, y, width, height, m[4 * e + j]);
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two pixels' gathers in flight, not sixteen (registers)
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) m[4 * e + j][c] = 0.f;     // zero padding of the tile
+        }
+      }
+    };
+    auto write_channel = [&](int c, int buf) {
+      uint16_t* Xc = &Xs[buf][0][0];
+#pragma unroll
+      for (int e8 = 0; e8 < 2; ++e8) {
+        const float t[8] = {m[8 * e8][c], m[8 * e8 + 1][c], m[8 * e8 + 2][c], m[8 * e8 + 3][c],
+                            m[8 * e8 + 4][c], m[8 * e8 + 5][c], m[8 * e8 + 6][c], m[8 * e8 + 7][c]};
+        const FbSplit3 sp = fb_split3(t);
+        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {        // two quads of 4 consecutive columns
+          const int q = ptid + 256 * (2 * e8 + u2);
+          const int y = q >> 4, x = (q & 15) * 4;
+          *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u2], hw[2 * u2 + 1]};
+          *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u2], mw[2 * u2 + 1]};
+          *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u2], lw[2 * u2 + 1]};
+        }
+      }
+    };
+    request_r1(i0_of(p_lo) + 1);
+    prefetch_pair(p_lo, i0_of(p_lo), 0, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // R1 of the first pair (and GvS) in place
+    update_pair(p_lo, i0_of(p_lo));
+    // the pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along
+    // the range without the 64-bit division per pair
+    long long i0_cur = i0_of(p_lo), q_cur = chain_f > 0 ? p_lo % pairs_per_group : 0;
+    int k = 0;
+#ifdef PV_DIAG_STAMPS
+    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3, s4, s5;
+#endif
+    for (long long p = p_lo; p < p_hi; ++p) {
+      const bool more = p + 1 < p_hi;
+      long long i0_next = i0_cur + 2;
+      if (chain_f > 0) {
+        i0_next = i0_cur + 1;
+        if (++q_cur == pairs_per_group) q_cur = 0, i0_next += chain_f - pairs_per_group;      // the next stack's first frame
+      }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        PV_STAMP(s0);
+        write_channel(c, k & 1);
+        ++k;
+        PV_STAMP(s1);
+        if (c == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
+        PV_STAMP(s2);
+        __syncthreads();
+        PV_STAMP(s3);
+        if (c == 0 && more) {
+          request_r1(i0_next + 1);
+          prefetch_pair(p + 1, i0_next, 0, 2);
+        }
+        PV_STAMP(s4);
+        if (c == 4 && more) update_pair(p + 1, i0_next);
+        PV_STAMP(s5);
+#ifdef PV_DIAG_STAMPS
+        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[2] += s3 - s2, dg[3] += s4 - s3, dg[4] += s5 - s4;
+#endif
+      }
+      i0_cur = i0_next;
+#ifdef PV_DIAG_STAMPS
+      dg[7] += 1;
+#endif
+    }
+#ifdef PV_DIAG_STAMPS
+    if (lane == 0 && blockIdx.x * 8 + wave8 < PV_DIAG_WAVES)
+      for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_fused_diag[(size_t)(blockIdx.x * 8 + wave8) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+    return;
+  }
+
+  // ================================ multiplying waves =====================================================================
+  const int wave = wave8, strip = wave & 1, mbo = wave >> 1;
+  FbSplit3 gh[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    gh[ks] = fb_split3(t);
+  }
+  __syncthreads();      // the producers' prologue barrier; GvS published
+  int k = 0;
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2;
+#endif
+  for (long long p = p_lo; p < p_hi; ++p) {
+    fb_v16f res[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      PV_STAMP(s0);
+      __syncthreads();      // channel k is in its buffer
+      PV_STAMP(s1);
+      const uint16_t* Xc = &Xs[k & 1][0][0];
+      ++k;
+      fb_v16f u[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          FbSplit3 a;
+          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+          a.h = *reinterpret_cast<const bf16x8*>(xa);
+          a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
+          a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
+          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+        const FbSplit3 b = fb_split3(t);
+        FbSplit3 g;
+        g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
+        g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
+        g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
+        res[c] = fb_mfma3(g, b, res[c]);
+      }
+      PV_STAMP(s2);
+#ifdef PV_DIAG_STAMPS
+      dg[0] += s1 - s0, dg[1] += s2 - s1;
+#endif
+    }
+    PV_STAMP(s0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
+      if (y < height && x < width) {
+        double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+        double idet = __ddiv_rn(1.0, det);
+        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
+        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
+        float* fl = flow_out + (p * per_img + (long long)y * width + x) * 2;
+        fl[0] = fxv;
+        fl[1] = fyv;
+      }
+    }
+    PV_STAMP(s1);
+#ifdef PV_DIAG_STAMPS
+    dg[2] += s1 - s0, dg[7] += 1;
+#endif
+  }
+#ifdef PV_DIAG_STAMPS
+  if (lane == 0 && blockIdx.x * 8 + wave8 < PV_DIAG_WAVES)
+    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_fused_diag[(size_t)(blockIdx.x * 8 + wave8) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+}
+
 // ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
 __global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
                                                          long long n_pairs, int height, int width, FbTaps kt) {
@@ -1201,6 +1496,36 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)T, R, n_img, lh, lw, pk);
     }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
+    // 33..64-pixel levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the
+    // window blur and the solve (fb_fused_iter_q_kernel); M is never written
+    const bool fused_iter = tile_path && fuse_init && (lh > 32 || lw > 32) && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION");
+    if (fused_iter) {
+      float* Gv = (float*)(ws + L.off_G);
+      float* Gh = lh == lw ? Gv : Gv + 64 * 64;
+      stage_mark(coarse ? "farneback.coarse.iterations_fused" : "farneback.level0.iterations_fused", st);
+      hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
+      if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
+      FbUpsample up = {prev_h, prev_w, prev_flow ? (double)prev_w / lw : 1.0, prev_flow ? (double)prev_h / lh : 1.0,
+                       (float)(1. / p->pyr_scale)};
+      const unsigned grid = (unsigned)std::min<long long>(n_pairs, kNumCU);      // one workgroup per CU (LDS)
+      for (int it = 0; it < p->iterations; ++it) {
+        if (it > 0)
+          hipLaunchKernelGGL(fb_fused_iter_q_kernel<0>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)flow, flow,
+                             (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up);
+        else if (prev_flow)
+          hipLaunchKernelGGL(fb_fused_iter_q_kernel<1>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)prev_flow,
+                             flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group,
+                             chain_f, up);
+        else
+          hipLaunchKernelGGL(fb_fused_iter_q_kernel<2>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)nullptr,
+                             flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group,
+                             chain_f, up);
+      }
+      prev_flow = flow;
+      prev_w = lw;
+      prev_h = lh;
+      continue;
+    }
     stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
     {
       const dim3 um_grid(stream_grid((size_t)(n_pairs * lpx), 256));
@@ -1273,3 +1598,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
 }
 
 }  // extern "C"
+
+#ifdef PV_DIAG_STAMPS
+extern "C" int pv_diag_read_fb_fused(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_fused_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

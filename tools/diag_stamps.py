@@ -57,7 +57,25 @@ def run():
         bias = torch.zeros(32, device=dev)
         fn = lambda: K.conv3d_fwd_bf16_f32in(x, wp, bias, 32, (0, 0, 0), True, want_packed=True)
         return fn, "first"
+    if which == "flow":
+        from predict_pv_yield_amd import optical_flow as of
+        raw = torch.randint(0, 1021, (b, 12, 11, 64, 64), dtype=torch.int16, device=dev)
+        return (lambda: of.advect_future_frames(raw, 6)), "flow"
     raise SystemExit(__doc__)
+
+
+def flow_report(d):
+    """fb_fused_iter_q_kernel: waves 0..3 of a workgroup multiply, waves 4..7 produce; the last launch's stamps"""
+    d = d[: (d[:, 7] > 0).nonzero()[0].max() + 1].reshape(-1, 8, SLOTS)
+    for name, sl, labels in (("multiplying waves", slice(0, 4), ["barrier (waiting for a channel)", "channel: 24 + 12 products", "solve + flow store"]),
+                             ("producing waves", slice(4, 8), ["split + write a channel", "vmcnt(0) (next R1)", "barrier", "request R1",
+                                                               "UpdateMatrices of the next pair"])):
+        w = d[:, sl].reshape(-1, SLOTS)
+        w = w[w[:, 7] > 0]
+        tot = w[:, : len(labels)].sum(1).mean()
+        print(f"  {name}: {len(w)} waves, {w[:, 7].mean():.1f} pairs per wave, {tot / w[:, 7].mean():.0f} cycles / pair")
+        for i, lab in enumerate(labels):
+            print(f"    {lab:36s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / pair  {100 * w[:, i].mean() / tot:5.1f} %")
 
 
 fn, kind = run()
@@ -69,13 +87,17 @@ e0.record()
 fn()
 e1.record()
 torch.cuda.synchronize()
-sym, labels = LABELS[kind]
+sym, labels = LABELS.get(kind, ("pv_diag_read_fb_fused", None))
 buf = np.zeros(WAVES * SLOTS, dtype=np.uint64)
 lib = get_lib()
 f = getattr(lib, sym)
 f.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert f(buf.ctypes.data, buf.size) == 0
 d = buf.reshape(WAVES, SLOTS).astype(np.float64)
+if kind == "flow":
+    print(f"flow B={b}: stamped pipeline {e0.elapsed_time(e1) * 1e3:.1f} us")
+    flow_report(d)
+    raise SystemExit(0)
 count_col = len(labels) - 1
 live = d[:, count_col] > 0
 d = d[live]
