@@ -390,6 +390,60 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
   m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
 }
 
+// fb_update_pixel without control flow and in two halves, for a wave that evaluates many pixels in a row
+// (fb_fused_iter_q_kernel): fb_gather_r1 reads the 2 x 2 neighbourhood of R1 at a clamped position whether or not the
+// displaced point lies inside the image, fb_update_pixel_finish does the arithmetic and selects the results -- the caller
+// issues the next pixel's reads before this pixel's arithmetic.  Same expressions and operation order on either side of
+// every select as in fb_update_pixel (interior pixels multiply by a border scale of exactly 1): bit-identical.
+struct FbGather { float v[20]; float fx, fy; bool inside; };
+__device__ __forceinline__ void fb_gather_r1(const float* __restrict__ R1, float dx, float dy, int x, int y, int width,
+                                             int height, FbGather& g) {
+  const int step1 = width * 5;
+  float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
+  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+  g.fx = __fsub_rn(fx, (float)x1);
+  g.fy = __fsub_rn(fy, (float)y1);
+  g.inside = (unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1);
+  const float* ptr = R1 + (g.inside ? y1 * step1 + x1 * 5 : 0);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) g.v[i] = ptr[i], g.v[10 + i] = ptr[step1 + i];
+}
+__device__ __forceinline__ void fb_update_pixel_finish(const float* __restrict__ R0, const FbGather& g, float dx, float dy, int x,
+                                                       int y, int width, int height, bool valid, float* m) {
+  const float fx = g.fx, fy = g.fy;
+  const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+  const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+#define PV_BILIN(c) \
+  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, g.v[c]), __fmul_rn(a01, g.v[5 + c])), __fmul_rn(a10, g.v[10 + c])), \
+            __fmul_rn(a11, g.v[15 + c]))
+  float r2 = PV_BILIN(0), r3 = PV_BILIN(1), r4 = PV_BILIN(2), r5 = PV_BILIN(3), r6 = PV_BILIN(4);
+#undef PV_BILIN
+  r4 = __fmul_rn(__fadd_rn(R0[2], r4), 0.5f);
+  r5 = __fmul_rn(__fadd_rn(R0[3], r5), 0.5f);
+  r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
+  r2 = g.inside ? r2 : 0.f;
+  r3 = g.inside ? r3 : 0.f;
+  r4 = g.inside ? r4 : R0[2];
+  r5 = g.inside ? r5 : R0[3];
+  r6 = g.inside ? r6 : __fmul_rn(R0[4], 0.5f);
+  r2 = __fmul_rn(__fsub_rn(R0[0], r2), 0.5f);
+  r3 = __fmul_rn(__fsub_rn(R0[1], r3), 0.5f);
+  r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
+  r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
+  auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
+  float scale = border(x);
+  scale = __fmul_rn(scale, border(width - x - 1));
+  scale = __fmul_rn(scale, border(y));
+  scale = __fmul_rn(scale, border(height - y - 1));
+  r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
+  r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
+  m[0] = valid ? __fadd_rn(__fmul_rn(r4, r4), __fmul_rn(r6, r6)) : 0.f;      // !valid: zero padding of the tile
+  m[1] = valid ? __fmul_rn(__fadd_rn(r4, r5), r6) : 0.f;
+  m[2] = valid ? __fadd_rn(__fmul_rn(r5, r5), __fmul_rn(r6, r6)) : 0.f;
+  m[3] = valid ? __fadd_rn(__fmul_rn(r4, r2), __fmul_rn(r6, r3)) : 0.f;
+  m[4] = valid ? __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3)) : 0.f;
+}
+
 // one pixel of cv::resize(prevFlow -> (dw, dh), INTER_LINEAR) * (1 / pyr_scale): the expressions of fb_flow_upsample_kernel
 typedef float fb_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fb_f32x2_t fb_upsampled_flow(const float* __restrict__ src, size_t p, int sh, int sw, int x, int y,
@@ -876,9 +930,9 @@ __global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __r
 // One barrier per channel (k = running channel number) hands an image over: before barrier k the producers wrote channel k
 // and the multiplying waves finished channel k-1, so the producers may overwrite the buffer of channel k-1 (= that of k+1)
 // right after it.  The same barriers order the producers among themselves: R1 of the next pair is requested after the
-// barrier of channel 0 (every producer has finished the pair's gathers before it wrote channel 0), each wave waits for its
-// own requests before the barrier of channel 4, and the next pair's pixels are evaluated after that barrier, under the
-// multiplying waves' last channel and solve.
+// barriers of channels 0..3, a quarter each (every producer has finished the pair's gathers before it wrote channel 0), each
+// wave waits for its own requests before the barrier of channel 4, and the next pair's pixels are evaluated after that
+// barrier, under the multiplying waves' last channel and solve.
 // FLOW_SRC as in fb_update_matrices_kernel (0: flow_in is this level's flow -- the launch updates it in place, a pair's flow
 // is read in full by its producers before its multiplying waves store the new one; 1: the coarser level's flow, resized on
 // the fly; 2: zero).  Same arithmetic per output element as UpdateMatrices + fb_tile_mfma_q_kernel: bit-identical flows.
@@ -925,10 +979,10 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
   const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
   const int img_bytes = (int)per_img * 20;
   const uint32_t lane16 = (uint32_t)lane * 16;
-  auto request_r1 = [&](long long i1) {
+  auto request_r1 = [&](long long i1, int j_lo, int j_hi) {
     const uintptr_t a = (uintptr_t)(R + i1 * per_img * 5);
 #pragma unroll
-    for (int j = 0; j < 20; ++j) {      // 1 KB per wave instruction, the four waves interleaved
+    for (int j = j_lo; j < j_hi; ++j) {      // 1 KB per wave instruction, the four waves interleaved
       const int off = (4 * j + (wave8 & 3)) * 1024;
       if (off < img_bytes) {      // one lane offset for all: the chunk's start goes into the descriptor, which still ends at the image
         const uintptr_t ac = a + (uintptr_t)off;
@@ -946,8 +1000,8 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
       return i0;
     };
     float m[16][5];
-    // R0 and the flow of a pair's first 8 pixels are requested a whole pair ahead (right after the R1 request: their latency
-    // is covered by the four channel hand-overs in between; all 16 would not fit the registers next to m)
+    // R0 and the flow of a pair's first quad are requested a whole pair ahead (their latency is covered by the channel
+    // hand-overs in between; all four would not fit the registers next to m), those of quad e + 1 when quad e is evaluated
     fb_f32x4_t r0q[4][5], flq[4][2];
     // raw buffer loads: one lane offset for R0 and one for the flow, the quad's rows in the scalar offset; a quad below the
     // image reads zeros (one beside it is never used: update_pair zero-fills it)
@@ -971,33 +1025,43 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
       }
     };
     auto update_pair = [&](long long p, long long i0) {
-      prefetch_pair(p, i0, 2, 4);      // the second half arrives under the first half's arithmetic
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = ptid + 256 * e;
-        const int y = q >> 4, x0 = (q & 15) * 4;
-        if (y < height && x0 < width) {
-          float r0[20];
-#pragma unroll
-          for (int i = 0; i < 20; ++i) r0[i] = r0q[e][i >> 2][i & 3];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float fdx = 0.f, fdy = 0.f;
-            if constexpr (FLOW_SRC == 0) {
-              fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
-            } else if constexpr (FLOW_SRC == 1) {
-              const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, x0 + j, y, up.inv_fx, up.inv_fy, up.mul);
-              fdx = f[0], fdy = f[1];
-            }
-            fb_update_pixel(r0 + 5 * j, R1s, fdx, fdy, x0 + j, y, width, height, m[4 * e + j]);
-            if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two pixels' gathers in flight, not sixteen (registers)
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < 5; ++c) m[4 * e + j][c] = 0.f;     // zero padding of the tile
+      prefetch_pair(p, i0, 1, 2);      // quad e + 1 arrives under quad e's arithmetic
+      // the lane's pixel coordinates, border scales, ... are the same for every pair: hidden from the loop-invariant code
+      // motion, which would otherwise keep dozens of them in registers around the whole pair loop
+      int pt = ptid;
+      asm volatile("" : "+v"(pt));
+      // pixel n = 4 e + j: quad e, column j; its R1 neighbourhood is read while pixel n - 1 is computed
+      FbGather g[2];
+      auto flow_of = [&](int n, float& fdx, float& fdy) {
+        const int e = n >> 2, j = n & 3;
+        fdx = 0.f, fdy = 0.f;
+        if constexpr (FLOW_SRC == 0) {
+          fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
+        } else if constexpr (FLOW_SRC == 1) {
+          const int q = pt + 256 * e;
+          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, (q & 15) * 4 + j, min(q >> 4, height - 1), up.inv_fx,
+                                                 up.inv_fy, up.mul);
+          fdx = f[0], fdy = f[1];
         }
+      };
+      float dxs[2], dys[2];
+      flow_of(0, dxs[0], dys[0]);
+      fb_gather_r1(R1s, dxs[0], dys[0], (pt & 15) * 4, pt >> 4, width, height, g[0]);
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        const int e = n >> 2, j = n & 3, q = pt + 256 * e;
+        const int y = q >> 4, x = (q & 15) * 4 + j;
+        if (j == 0 && e >= 1 && e < 3) prefetch_pair(p, i0, e + 1, e + 2);
+        if (n + 1 < 16) {
+          const int q1 = pt + 256 * ((n + 1) >> 2);
+          flow_of(n + 1, dxs[(n + 1) & 1], dys[(n + 1) & 1]);
+          fb_gather_r1(R1s, dxs[(n + 1) & 1], dys[(n + 1) & 1], (q1 & 15) * 4 + ((n + 1) & 3), q1 >> 4, width, height, g[(n + 1) & 1]);
+        }
+        float r0[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) r0[c] = r0q[e][(5 * j + c) >> 2][(5 * j + c) & 3];
+        fb_update_pixel_finish(r0, g[n & 1], dxs[n & 1], dys[n & 1], x, y, width, height, y < height && x < width, m[n]);
+        __builtin_amdgcn_sched_barrier(0);      // one pixel's reads ahead, not all sixteen (registers)
       }
     };
     auto write_channel = [&](int c, int buf) {
@@ -1018,8 +1082,8 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         }
       }
     };
-    request_r1(i0_of(p_lo) + 1);
-    prefetch_pair(p_lo, i0_of(p_lo), 0, 2);
+    request_r1(i0_of(p_lo) + 1, 0, 20);
+    prefetch_pair(p_lo, i0_of(p_lo), 0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // R1 of the first pair (and GvS) in place
     update_pair(p_lo, i0_of(p_lo));
@@ -1047,10 +1111,10 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         PV_STAMP(s2);
         __syncthreads();
         PV_STAMP(s3);
-        if (c == 0 && more) {
-          request_r1(i0_next + 1);
-          prefetch_pair(p + 1, i0_next, 0, 2);
-        }
+        // the vector-memory path takes ~100 cycles per 1 KB instruction when the four waves issue together: a quarter of
+        // R1 per hand-over, under the multiplying waves' channel, instead of 80 instructions in one place
+        if (c < 4 && more) request_r1(i0_next + 1, 5 * c, 5 * c + 5);
+        if (c == 0 && more) prefetch_pair(p + 1, i0_next, 0, 1);
         PV_STAMP(s4);
         if (c == 4 && more) update_pair(p + 1, i0_next);
         PV_STAMP(s5);
