@@ -975,7 +975,8 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
     GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
   }
 
-  // coefficient image i1 -> LDS, a quarter per producing wave
+  // coefficient image i1 -> LDS, a quarter per producing wave (measured: the same requests issued by the multiplying waves in
+  // their waiting time cost them ~300 cycles apiece and the hand-over waits for the data: 825 -> 926 us per level)
   const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
   const int img_bytes = (int)per_img * 20;
   const uint32_t lane16 = (uint32_t)lane * 16;
@@ -994,77 +995,63 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
   if (producer) {
     // ================================ producing waves ===================================================================
     const int ptid = tid - 256;
-    auto i0_of = [&](long long p) {
-      long long i0, i1;
-      fb_r_images_of(p, pairs_per_group, chain_f, &i0, &i1);
-      return i0;
-    };
-    float m[16][5];
-    // R0 and the flow of a pair's first quad are requested a whole pair ahead (their latency is covered by the channel
-    // hand-overs in between; all four would not fit the registers next to m), those of quad e + 1 when quad e is evaluated
+    // two sets of results: the pair being handed over and the next one, which is evaluated quad by quad between the
+    // hand-overs (a channel's 16 registers are free once it is written, so the two sets overlap in the register file)
+    float mA[16][5], mB[16][5];
     fb_f32x4_t r0q[4][5], flq[4][2];
     // raw buffer loads: one lane offset for R0 and one for the flow, the quad's rows in the scalar offset; a quad below the
-    // image reads zeros (one beside it is never used: update_pair zero-fills it)
+    // image reads zeros (one beside it is never used: its results are zero-filled)
     const uint32_t quad_px = (uint32_t)((ptid >> 4) * width + (ptid & 15) * 4);
     const uint32_t r0_lane = quad_px * 20, fl_lane = quad_px * 8;
-    auto prefetch_pair = [&](long long p, long long i0, int e_lo, int e_hi) {
+    auto prefetch_quad = [&](long long p, long long i0, int e) {      // R0 and flow of pixels 4 e .. 4 e + 3 of pair p
       const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0 * per_img * 5), 0, img_bytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t flrs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? p * per_img * 2 : 0)), 0, (int)per_img * 8, 0x00020000);
+      const uint32_t rows = (uint32_t)(16 * e * width);
 #pragma unroll
-      for (int e = e_lo; e < e_hi; ++e) {
-        const uint32_t rows = (uint32_t)(16 * e * width);
+      for (int i = 0; i < 5; ++i)
+        r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
+      if constexpr (FLOW_SRC == 0) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
-        if constexpr (FLOW_SRC == 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
-        }
+        for (int i = 0; i < 2; ++i)
+          flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
       }
     };
-    auto update_pair = [&](long long p, long long i0) {
-      prefetch_pair(p, i0, 1, 2);      // quad e + 1 arrives under quad e's arithmetic
+    // FarnebackUpdateMatrices of quad e of pair p -> mo[4 e .. 4 e + 3]; pixel j's R1 neighbourhood is read while pixel
+    // j - 1 is computed
+    auto update_quad = [&](float (&mo)[16][5], long long p, int e) {
       // the lane's pixel coordinates, border scales, ... are the same for every pair: hidden from the loop-invariant code
       // motion, which would otherwise keep dozens of them in registers around the whole pair loop
       int pt = ptid;
       asm volatile("" : "+v"(pt));
-      // pixel n = 4 e + j: quad e, column j; its R1 neighbourhood is read while pixel n - 1 is computed
+      const int q = pt + 256 * e, y = q >> 4, x0 = (q & 15) * 4;
       FbGather g[2];
-      auto flow_of = [&](int n, float& fdx, float& fdy) {
-        const int e = n >> 2, j = n & 3;
+      float dxs[2], dys[2];
+      auto flow_of = [&](int j, float& fdx, float& fdy) {
         fdx = 0.f, fdy = 0.f;
         if constexpr (FLOW_SRC == 0) {
           fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
         } else if constexpr (FLOW_SRC == 1) {
-          const int q = pt + 256 * e;
-          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, (q & 15) * 4 + j, min(q >> 4, height - 1), up.inv_fx,
-                                                 up.inv_fy, up.mul);
+          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, x0 + j, min(y, height - 1), up.inv_fx, up.inv_fy, up.mul);
           fdx = f[0], fdy = f[1];
         }
       };
-      float dxs[2], dys[2];
       flow_of(0, dxs[0], dys[0]);
-      fb_gather_r1(R1s, dxs[0], dys[0], (pt & 15) * 4, pt >> 4, width, height, g[0]);
+      fb_gather_r1(R1s, dxs[0], dys[0], x0, y, width, height, g[0]);
 #pragma unroll
-      for (int n = 0; n < 16; ++n) {
-        const int e = n >> 2, j = n & 3, q = pt + 256 * e;
-        const int y = q >> 4, x = (q & 15) * 4 + j;
-        if (j == 0 && e >= 1 && e < 3) prefetch_pair(p, i0, e + 1, e + 2);
-        if (n + 1 < 16) {
-          const int q1 = pt + 256 * ((n + 1) >> 2);
-          flow_of(n + 1, dxs[(n + 1) & 1], dys[(n + 1) & 1]);
-          fb_gather_r1(R1s, dxs[(n + 1) & 1], dys[(n + 1) & 1], (q1 & 15) * 4 + ((n + 1) & 3), q1 >> 4, width, height, g[(n + 1) & 1]);
+      for (int j = 0; j < 4; ++j) {
+        if (j + 1 < 4) {
+          flow_of(j + 1, dxs[(j + 1) & 1], dys[(j + 1) & 1]);
+          fb_gather_r1(R1s, dxs[(j + 1) & 1], dys[(j + 1) & 1], x0 + j + 1, y, width, height, g[(j + 1) & 1]);
         }
         float r0[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) r0[c] = r0q[e][(5 * j + c) >> 2][(5 * j + c) & 3];
-        fb_update_pixel_finish(r0, g[n & 1], dxs[n & 1], dys[n & 1], x, y, width, height, y < height && x < width, m[n]);
-        __builtin_amdgcn_sched_barrier(0);      // one pixel's reads ahead, not all sixteen (registers)
+        fb_update_pixel_finish(r0, g[j & 1], dxs[j & 1], dys[j & 1], x0 + j, y, width, height, y < height && x0 + j < width, mo[4 * e + j]);
+        __builtin_amdgcn_sched_barrier(0);      // one pixel's reads ahead, not more (registers)
       }
     };
-    auto write_channel = [&](int c, int buf) {
+    auto write_channel = [&](const float (&m)[16][5], int c, int buf) {
       uint16_t* Xc = &Xs[buf][0][0];
 #pragma unroll
       for (int e8 = 0; e8 < 2; ++e8) {
@@ -1082,20 +1069,33 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         }
       }
     };
-    request_r1(i0_of(p_lo) + 1, 0, 20);
-    prefetch_pair(p_lo, i0_of(p_lo), 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();      // R1 of the first pair (and GvS) in place
-    update_pair(p_lo, i0_of(p_lo));
     // the pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along
     // the range without the 64-bit division per pair
-    long long i0_cur = i0_of(p_lo), q_cur = chain_f > 0 ? p_lo % pairs_per_group : 0;
+    long long i0_cur, i1_unused;
+    fb_r_images_of(p_lo, pairs_per_group, chain_f, &i0_cur, &i1_unused);
+    long long q_cur = chain_f > 0 ? p_lo % pairs_per_group : 0;
+    request_r1(i0_cur + 1, 0, 20);
+    prefetch_quad(p_lo, i0_cur, 0);
+    prefetch_quad(p_lo, i0_cur, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();      // R1 of the first pair (and GvS) in place
+    update_quad(mA, p_lo, 0);
+    prefetch_quad(p_lo, i0_cur, 2);
+    update_quad(mA, p_lo, 1);
+    prefetch_quad(p_lo, i0_cur, 3);
+    update_quad(mA, p_lo, 2);
+    update_quad(mA, p_lo, 3);
     int k = 0;
 #ifdef PV_DIAG_STAMPS
-    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3, s4, s5;
+    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
 #endif
-    for (long long p = p_lo; p < p_hi; ++p) {
-      const bool more = p + 1 < p_hi;
+    // pair p: its results mc are complete on entry; channel c is written before hand-over c, and between the hand-overs
+    // the next pair is prepared -- R1 requested after hand-overs 0 and 1 (every producer is through with this pair's R1
+    // when it arrives at hand-over 0; ~100 cycles per 1 KB request when the four waves issue together, so not in one
+    // place), waited for before hand-over 2, quad 0 evaluated after hand-over 2, quad 1 after 3, quads 2 and 3 after 4 (under
+    // the multiplying waves' last channel and solve); each quad's R0 / flow requested one step before its evaluation
+    auto pair_body = [&](float (&mc)[16][5], float (&mn)[16][5], long long p, auto more_tag) {
+      constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
       long long i0_next = i0_cur + 2;
       if (chain_f > 0) {
         i0_next = i0_cur + 1;
@@ -1104,29 +1104,39 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
 #pragma unroll
       for (int c = 0; c < 5; ++c) {
         PV_STAMP(s0);
-        write_channel(c, k & 1);
+        write_channel(mc, c, k & 1);
         ++k;
+        if (c == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
         PV_STAMP(s1);
-        if (c == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
-        PV_STAMP(s2);
         __syncthreads();
+        PV_STAMP(s2);
+        if constexpr (more) {
+          if (c == 0) request_r1(i0_next + 1, 0, 10), prefetch_quad(p + 1, i0_next, 0);
+          if (c == 1) request_r1(i0_next + 1, 10, 20);
+          if (c == 2) prefetch_quad(p + 1, i0_next, 1), update_quad(mn, p + 1, 0);
+          if (c == 3) prefetch_quad(p + 1, i0_next, 2), update_quad(mn, p + 1, 1);
+          if (c == 4) prefetch_quad(p + 1, i0_next, 3), update_quad(mn, p + 1, 2), update_quad(mn, p + 1, 3);
+        }
         PV_STAMP(s3);
-        // the vector-memory path takes ~100 cycles per 1 KB instruction when the four waves issue together: a quarter of
-        // R1 per hand-over, under the multiplying waves' channel, instead of 80 instructions in one place
-        if (c < 4 && more) request_r1(i0_next + 1, 5 * c, 5 * c + 5);
-        if (c == 0 && more) prefetch_pair(p + 1, i0_next, 0, 1);
-        PV_STAMP(s4);
-        if (c == 4 && more) update_pair(p + 1, i0_next);
-        PV_STAMP(s5);
 #ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[2] += s3 - s2, dg[3] += s4 - s3, dg[4] += s5 - s4;
+        dg[0] += s1 - s0, dg[2] += s2 - s1, dg[c < 2 ? 3 : 4] += s3 - s2;
 #endif
       }
       i0_cur = i0_next;
 #ifdef PV_DIAG_STAMPS
       dg[7] += 1;
 #endif
+    };
+    // one copy of the body in the loop (the register moves at its end are ~1 % of a pair; two copies with the sets swapped
+    // would not fit the instruction cache next to the multiplying waves' loop), the last pair peeled
+    for (long long p = p_lo; p + 1 < p_hi; ++p) {
+      pair_body(mA, mB, p, std::true_type{});
+#pragma unroll
+      for (int n = 0; n < 16; ++n)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) mA[n][c] = mB[n][c];
     }
+    pair_body(mA, mB, p_hi - 1, std::false_type{});
 #ifdef PV_DIAG_STAMPS
     if (lane == 0 && blockIdx.x * 8 + wave8 < PV_DIAG_WAVES)
       for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_fused_diag[(size_t)(blockIdx.x * 8 + wave8) * PV_DIAG_SLOTS + i] = dg[i];
