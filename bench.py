@@ -502,7 +502,7 @@ def learnable_task(n, t_frames, seed):
     return sat, pv
 
 
-def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8, n_val=256, first_eval=16, eval_every=8,
+def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8, n_val=256, first_eval=16, eval_every=4,
                                       hip_steps=256):
     """Three training runs from the same initial weights on the same batches of a learnable synthetic task: the torch-CPU
     oracle (oracle/conv3d_oracle.py: the reference's f32 arithmetic), the HIP bf16 path (the benched one) and the HIP fp32
@@ -598,11 +598,21 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
     mean = lambda c, ks: sum(c[k] for k in ks) / len(ks)
     o_mean, b_mean, f_mean = mean(oracle_curve, tail), mean(curves["bf16"], tail), mean(curves["fp32"], tail)
     late = [k for k in hip_eval_at if k > hip_steps // 2]
+    # how much a mean over the tail checkpoints can differ between two runs by the step-to-step swing alone: the standard
+    # error of the difference of two such means (checkpoints treated as independent draws around each run's level)
+    std = lambda c, ks: (sum((c[k] - mean(c, ks)) ** 2 for k in ks) / max(len(ks) - 1, 1)) ** 0.5
+    sd = {"hip_bf16": std(curves["bf16"], tail), "hip_fp32": std(curves["fp32"], tail), "oracle_f32_cpu": std(oracle_curve, tail)}
+    sem_diff = lambda a, b: ((sd[a] ** 2 + sd[b] ** 2) / len(tail)) ** 0.5
     val = {"hip_bf16": round(b_mean, 6), "hip_fp32": round(f_mean, 6), "oracle_f32_cpu": round(o_mean, 6),
            "untrained": round(untrained, 6),
            "rel_diff": round(abs(b_mean - o_mean) / o_mean, 4),
            "rel_diff_hip_fp32_vs_oracle": round(abs(f_mean - o_mean) / o_mean, 4),
            "rel_diff_hip_bf16_vs_hip_fp32": round(abs(b_mean - f_mean) / f_mean, 4),
+           "checkpoint_swing": {"std_over_the_tail_checkpoints": {k: round(v, 5) for k, v in sd.items()},
+                                "hip_bf16_minus_oracle_in_standard_errors": round(abs(b_mean - o_mean) / sem_diff("hip_bf16", "oracle_f32_cpu"), 2),
+                                "hip_fp32_minus_oracle_in_standard_errors": round(abs(f_mean - o_mean) / sem_diff("hip_fp32", "oracle_f32_cpu"), 2),
+                                "note": "the two f32 runs differ only by summation order inside a step and still drift apart: "
+                                        "a difference of the means within ~2 standard errors is the run's own swing"},
            "definition": f"mean validation NMAE over the checkpoints after steps {tail} ({n_val} held-out samples, batch {batch})",
            "checkpoints": {"after_step": eval_at, "hip_bf16": [round(curves['bf16'][k], 5) for k in eval_at],
                            "hip_fp32": [round(curves['fp32'][k], 5) for k in eval_at],

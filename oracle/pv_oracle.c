@@ -18,6 +18,12 @@
  *   normalisation                notebooks/13_...ipynb:345-346,463-464
  * and pinned by the analytic known-answer tests in tests/test_oracle_flow.py (SURVEY.md §8c K1-K5,
  * R1-R5).  Build with -ffp-contract=off so every product is rounded before it is added.
+ *
+ * Attribution: the algorithms restated here are those of OpenCV (https://opencv.org, (C) the OpenCV
+ * contributors, Apache License 2.0); the Farnebäck method is G. Farnebäck, "Two-Frame Motion Estimation
+ * Based on Polynomial Expansion", SCIA 2003.  This file is an independent restatement written against the
+ * published behaviour (operation order, border rules, fixed-point quantisation) so that it can serve as a
+ * bit-level checker; it contains no OpenCV source.
  */
 #include <math.h>
 #include <stdint.h>

@@ -9,7 +9,9 @@
 // slices s, s-1, s-2 (tap planes kt = 0, 1, 2) that are in flight in registers.  A fragment is read once and feeds up
 // to 3 kh x 3 kt MFMAs: a third of the LDS operand traffic.  To make room for 3 x 32 accumulator registers inside the
 // 256-register budget of two waves per SIMD:
-//   * the kt = 2 tap plane of the weights lives in LDS (3 fragment reads per (slice, kw)), kt = 0, 1 stay in registers;
+//   * the kt = 2 tap plane of the weights lives in LDS (3 fragment reads per (slice, kw)); the NDHWC-writing variants keep
+//     kt = 1 there as well (W1_LDS: 9 instead of 18 weight fragments in registers, which is what lets the epilogue's pending
+//     stores and gate loads stay in registers without spills), the NCDHW-writing variant keeps kt = 0, 1 in registers;
 //   * input slices are staged global -> LDS directly (buffer_load_dwordx4 ... lds, gfx950), no staging registers: the
 //     LDS destination of a wave instruction is 1 KB linear by lane, so the XOR swizzle of the image is applied to the
 //     SOURCE address of each lane instead;

@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/flowpmc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03flowpmc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/A -o p -- python3 $R/tools/time_flow_stages.py 32 > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/B -o p -- python3 $R/tools/time_flow_stages.py 32 > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/C -o p -- python3 $R/tools/time_flow_stages.py 32 > /dev/null 2>&1
