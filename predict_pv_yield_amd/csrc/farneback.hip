@@ -1572,7 +1572,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     // 33..64-pixel levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the
     // window blur and the solve (fb_fused_iter_q_kernel); M is never written
-    const bool fused_iter = tile_path && fuse_init && (lh > 32 || lw > 32) && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION");
+    // (rows of whole 4-pixel quads: the producers read R0 / flow as 16-byte vectors)
+    const bool fused_iter =
+        tile_path && fuse_init && (lh > 32 || lw > 32) && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION");
     if (fused_iter) {
       float* Gv = (float*)(ws + L.off_G);
       float* Gh = lh == lw ? Gv : Gv + 64 * 64;

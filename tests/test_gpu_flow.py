@@ -229,6 +229,33 @@ def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkey
     assert np.abs(chained[1, 0].cpu().numpy() - ref).max() <= 1e-3
 
 
+@pytest.mark.parametrize("h,w,t,batch", [(64, 64, 12, 3), (64, 64, 4, 100), (40, 56, 3, 3), (48, 64, 4, 3), (64, 36, 2, 3),
+                                         (50, 62, 3, 3)])
+def test_fused_iteration_equals_the_two_launch_form_bit_for_bit(device, monkeypatch, h, w, t, batch):
+    """33..64-pixel levels run UpdateMatrices + window blur + solve as ONE launch per iteration (fb_fused_iter_q_kernel:
+    producer waves + matrix-core waves, M never written).  Same arithmetic per output element as the two-launch form
+    (PV_FARNEBACK_TWO_LAUNCH_ITERATION=1): identical bits, for frame stacks (chained R images, ranges of pairs that cross
+    stack boundaries), for separate pairs, for partial tiles, and for a width that is no multiple of 4 (which the fused
+    form does not take: both calls then run the same kernels)."""
+    K = _ops()
+    # batch = 100: 200 stacks x 3 pairs = 600 pairs over 256 workgroups -- ranges of 2..3 pairs that cross stack boundaries
+    raw, _ = advected_counts(batch=batch, t=t, channels=2, h=h, w=w, seed=3 * h + t)
+    stacks = np.ascontiguousarray(raw.transpose(0, 2, 1, 3, 4)).reshape(2 * batch, t, h, w)
+    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(stacks, 0)[0]).to(device)
+    prev = u8[:, :-1].reshape(-1, h, w).contiguous()
+    nxt = u8[:, 1:].reshape(-1, h, w).contiguous()
+    fused_stack, fused_pairs = K.farneback_stack(u8), K.farneback_pairs(prev, nxt)
+    fused_it1 = K.farneback_stack(u8, iterations=1)
+    monkeypatch.setenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION", "1")
+    two_stack, two_pairs = K.farneback_stack(u8), K.farneback_pairs(prev, nxt)
+    two_it1 = K.farneback_stack(u8, iterations=1)
+    monkeypatch.delenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION")
+    assert torch.equal(fused_stack, two_stack) and torch.equal(fused_pairs, two_pairs) and torch.equal(fused_it1, two_it1)
+    assert torch.isfinite(fused_stack).all()
+    ref = fo.calc_optical_flow_farneback(u8[2, 0].cpu().numpy(), u8[2, 1].cpu().numpy())
+    assert np.abs(fused_stack[2, 0].cpu().numpy() - ref).max() <= 1e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 5, 3, 8, 8), (1, 12, 11, 64, 64), (3, 2, 1, 4, 6)])
 def test_prepare_stacks_equals_permute_u8_normalise(device, dtype, shape):
