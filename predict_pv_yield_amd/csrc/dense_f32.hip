@@ -521,9 +521,13 @@ __global__ __launch_bounds__(256) void adam_step_multi_f32(AdamTable tab, float 
   }
 }
 
+// k from which the forward goes to pv_gemm_f32 (gemm_f32.hip: bf16 x 3 on the matrix cores, f32-accurate to ~1e-6): fc1 of
+// the f32 model, 32 x 1 003 520 -> 128, 920 us on the register-tile kernel below against 305 us
+constexpr long long GEMM_K = 1 << 16;
+
 static long long fwd_k_chunk(long long k, int* k_splits) {
-  // ~8k elements of K per block, at most 512 splits
-  long long chunk = 8192;
+  // ~8k elements of K per block (2k for the matrix-core path: two output tiles per chunk), at most 512 splits
+  long long chunk = k >= GEMM_K ? 2048 : 8192;
   long long splits = (k + chunk - 1) / chunk;
   if (splits > 512) { splits = 512; chunk = (k + splits - 1) / splits; }
   if (splits < 1) splits = 1;
@@ -560,7 +564,12 @@ int pv_linear_fwd_f32(const float* x, const float* w, const float* bias, float* 
                        relu ? 1 : 0);
     return check_launch("pv_linear_fwd_f32");
   }
-  if (k % 4 == 0 && chunk % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
+  if (k >= GEMM_K && k < (1ll << 31)) {
+    // partial[s] = x[:, chunk s] W[:, chunk s]^T : A = x (row stride k), B = W^T as a strided view (contraction index contiguous)
+    pv_gemm_desc d = {m, n, (int32_t)k, k, 1, 1, k, n, 1, 1, 0, 0, 0, 0, 0, 0, ks, (int64_t)m * n};
+    const int rc = pv_gemm_f32(x, w, nullptr, (float*)workspace, &d, 0, stream);
+    if (rc != PV_OK) return rc;
+  } else if (k % 4 == 0 && chunk % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0) {
     dim3 grid((unsigned)((n + FT_N - 1) / FT_N), (unsigned)ks, (unsigned)((m + FT_M - 1) / FT_M));
     hipLaunchKernelGGL(linear_fwd_tile_f32, grid, dim3(256), 0, st, x, w, (float*)workspace, m, n, (long long)k, chunk);
   } else {
