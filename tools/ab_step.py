@@ -1,6 +1,7 @@
 """Same-process A/B of the headline train step (B = 32, T = 18, bf16): alternates module-level switches and reports
 ms/step per setting (median of rounds), so that box-to-box and warm-up drift cancel.
-   python tools/ab_step.py functional.USE_RELU_MASKS"""
+   python tools/ab_step.py functional.USE_RELU_MASKS
+   python tools/ab_step.py env:PV_FC1_NT          (an environment switch the library reads at every launch: set / unset)"""
 import os
 import statistics
 import sys
@@ -14,8 +15,17 @@ import torch
 from predict_pv_yield_amd.models.conv3d.model import Model
 
 switch = sys.argv[1] if len(sys.argv) > 1 else "functional.USE_RELU_MASKS"
-mod_name, attr = switch.rsplit(".", 1)
-mod = importlib.import_module("predict_pv_yield_amd." + mod_name)
+if switch.startswith("env:"):
+    class _Env:      # setattr(mod, NAME, True / False) sets / removes the environment variable
+        def __setattr__(self, name, value):
+            if value:
+                os.environ[name] = "1"
+            else:
+                os.environ.pop(name, None)
+    mod, attr = _Env(), switch[4:]
+else:
+    mod_name, attr = switch.rsplit(".", 1)
+    mod = importlib.import_module("predict_pv_yield_amd." + mod_name)
 b = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = torch.device("cuda:0")
 torch.manual_seed(518)
