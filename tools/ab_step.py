@@ -19,7 +19,7 @@ if switch.startswith("env:"):
     class _Env:      # setattr(mod, NAME, True / False) sets / removes the environment variable
         def __setattr__(self, name, value):
             if value:
-                os.environ[name] = "1"
+                os.environ[name] = os.environ.get("AB_ENV_VALUE", "1")
             else:
                 os.environ.pop(name, None)
     mod, attr = _Env(), switch[4:]
