@@ -268,7 +268,7 @@ def measure_config3(dev, b, history_minutes):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 10
+    n = 40      # as many as amortise the host's head start over an idle device (the 100-step timing of the headline does)
     for _ in range(n):
         step()
     torch.cuda.synchronize()
