@@ -228,6 +228,7 @@ def measure_config3(dev, b, history_minutes):
         # one launch per iteration does UpdateMatrices + blur + solve: R0 + R1 + flow in + flow out, M never leaves the chip;
         # the stage mark covers the level's three iterations
         "farneback.level0.iterations_fused": dict(bytes=3 * pairs * px0 * (40 + 8 + 8), flops=3 * pairs * px0 * (75 + 620)),
+        "farneback.coarse.iterations_fused": dict(bytes=3 * pairs * px1 * (40 + 8 + 8), flops=3 * pairs * px1 * (75 + 620)),
         "flow_weighted_mean": dict(bytes=b * c * px0 * 8 * (t_obs - 1 + 1), flops=b * c * px0 * 2 * 2 * (t_obs - 1)),
         "remap_bilinear": dict(bytes=b * c * n_future * px0 * 16, flops=b * c * n_future * px0 * 10),
     }

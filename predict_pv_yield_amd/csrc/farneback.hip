@@ -540,12 +540,15 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
 // The channel image is staged zero-padded in LDS (double buffered, next channel's loads in flight under the MFMAs).
 typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt) {
-  // G[64][64]; rows / columns >= n stay zero
+__global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt, int mosaic) {
+  // G[64][64]; rows / columns >= n stay zero.  mosaic (n <= 32): the n x n matrix twice on the diagonal, at 0 and at 32 --
+  // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_fused_iter_q_kernel<.., true>)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 64; i += gridDim.x * blockDim.x) {
-    const int y = i >> 6, yp = i & 63;
+    int y = i >> 6, yp = i & 63;
+    const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
+    if (mosaic) y &= 31, yp &= 31;
     float s = 0.f;
-    if (y < n && yp < n) {
+    if (same_block && y < n && yp < n) {
       for (int k = -kt.n; k <= kt.n; ++k) {
         int yy = y + k;
         yy = yy < 0 ? 0 : (yy > n - 1 ? n - 1 : yy);
@@ -948,7 +951,7 @@ __device__ __forceinline__ void fb_lds_dma16(uint32_t lds_addr, uint32_t voff, f
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
                : "memory");
 }
-template <int FLOW_SRC>
+template <int FLOW_SRC, bool MOSAIC>
 __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __restrict__ R, const float* flow_in,
                                                                  float* flow_out, const float* __restrict__ Gv,
                                                                  const float* __restrict__ Gh, int height, int width,
@@ -962,7 +965,16 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
   const bool producer = wave8 >= 4;
   const int col = lane & 31, half = lane >> 5;
   const long long per_img = (long long)height * width;
-  const long long p_lo = n_pairs * blockIdx.x / gridDim.x, p_hi = n_pairs * (blockIdx.x + 1) / gridDim.x;
+  // MOSAIC: levels up to 32 x 32 (height, width = the level's size).  A unit of work is FOUR consecutive pairs laid out as
+  // the 2 x 2 tiles of one 64 x 64 image: pair 4 u + 2 ty + tx at rows 32 ty.., columns 32 tx...  Gv / Gh are then block
+  // diagonal (fb_window_matrix_kernel), so the two matrix products below blur the four tiles independently -- the zero
+  // blocks add exact zeros -- and everything the multiplying waves do stays as it is; the producers address R0 / R1 / flow
+  // per tile.  p_lo .. p_hi count units.
+  constexpr int NP = MOSAIC ? 4 : 1;
+  constexpr int TILE_F = 32 * 32 * 5;      // floats of one tile's R1 slot in LDS
+  constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside the 2 GB descriptors below: reads zeros
+  const long long n_units = (n_pairs + NP - 1) / NP;
+  const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
 
   for (int j = wave8; j < 2 * KS; j += 8) {      // Gv split operands, dealt to the eight waves
     const int mb = j / KS, ks = j - mb * KS;
@@ -980,14 +992,32 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
   const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
   const int img_bytes = (int)per_img * 20;
   const uint32_t lane16 = (uint32_t)lane * 16;
-  auto request_r1 = [&](long long i1, int j_lo, int j_hi) {
-    const uintptr_t a = (uintptr_t)(R + i1 * per_img * 5);
+  // not MOSAIC: chunks j_lo .. j_hi - 1 (of 20) of image i1[0]; MOSAIC: the whole images of tiles j_lo .. j_hi - 1 (of 4)
+  auto request_r1 = [&](const long long (&i1)[NP], long long unit, int j_lo, int j_hi) {
+    if constexpr (MOSAIC) {
 #pragma unroll
-    for (int j = j_lo; j < j_hi; ++j) {      // 1 KB per wave instruction, the four waves interleaved
-      const int off = (4 * j + (wave8 & 3)) * 1024;
-      if (off < img_bytes) {      // one lane offset for all: the chunk's start goes into the descriptor, which still ends at the image
-        const uintptr_t ac = a + (uintptr_t)off;
-        fb_lds_dma16(r1_lds + (uint32_t)off, lane16, (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
+      for (int t = j_lo; t < j_hi; ++t) {
+        if (unit * 4 + t >= n_pairs) continue;
+        const uintptr_t a = (uintptr_t)(R + i1[t] * per_img * 5);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int off = (4 * j + (wave8 & 3)) * 1024;
+          if (off < img_bytes) {
+            const uintptr_t ac = a + (uintptr_t)off;
+            fb_lds_dma16(r1_lds + (uint32_t)(t * TILE_F * 4 + off), lane16,
+                         (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
+          }
+        }
+      }
+    } else {
+      const uintptr_t a = (uintptr_t)(R + i1[0] * per_img * 5);
+#pragma unroll
+      for (int j = j_lo; j < j_hi; ++j) {      // 1 KB per wave instruction, the four waves interleaved
+        const int off = (4 * j + (wave8 & 3)) * 1024;
+        if (off < img_bytes) {      // one lane offset for all: the chunk's start goes into the descriptor, which still ends at the image
+          const uintptr_t ac = a + (uintptr_t)off;
+          fb_lds_dma16(r1_lds + (uint32_t)off, lane16, (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
+        }
       }
     }
   };
@@ -1000,31 +1030,60 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
     float mA[16][5], mB[16][5];
     fb_f32x4_t r0q[4][5], flq[4][2];
     // raw buffer loads: one lane offset for R0 and one for the flow, the quad's rows in the scalar offset; a quad below the
-    // image reads zeros (one beside it is never used: its results are zero-filled)
-    const uint32_t quad_px = (uint32_t)((ptid >> 4) * width + (ptid & 15) * 4);
+    // image reads zeros (one beside it is never used: its results are zero-filled).  MOSAIC: the lane's tile column picks one
+    // of two pairs, so the image / pair part of the address is per lane too (descriptors over the whole arrays)
+    const int m_tx = (ptid & 15) >> 3, m_xl0 = ((ptid & 15) & 7) * 4;      // MOSAIC: tile column, first local column of the quad
+    const uint32_t quad_px = (uint32_t)((ptid >> 4) * width + (MOSAIC ? m_xl0 : (ptid & 15) * 4));
     const uint32_t r0_lane = quad_px * 20, fl_lane = quad_px * 8;
-    auto prefetch_quad = [&](long long p, long long i0, int e) {      // R0 and flow of pixels 4 e .. 4 e + 3 of pair p
-      const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0 * per_img * 5), 0, img_bytes, 0x00020000);
-      const __amdgpu_buffer_rsrc_t flrs =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? p * per_img * 2 : 0)), 0, (int)per_img * 8, 0x00020000);
-      const uint32_t rows = (uint32_t)(16 * e * width);
+    auto prefetch_quad = [&](long long unit, const long long (&i0)[NP], int e) {      // R0 and flow of pixels 4 e .. 4 e + 3
+      if constexpr (MOSAIC) {
+        const int ty = e >> 1, yl = (ptid >> 4) + 16 * (e & 1);
+        const long long pl = unit * 4 + 2 * ty + m_tx;
+        const bool ok = yl < height && m_xl0 < width && pl < n_pairs;
+        const long long img = m_tx ? i0[2 * ty + 1] : i0[2 * ty];
+        const uint32_t rows = (uint32_t)(16 * (e & 1) * width);
+        const uint32_t r0_off = ok ? (uint32_t)(img * img_bytes) + r0_lane + rows * 20 : NOT_THERE;
+        const uint32_t fl_off = ok ? (uint32_t)(pl * per_img * 8) + fl_lane + rows * 8 : NOT_THERE;
+        const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
-        r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
-      if constexpr (FLOW_SRC == 0) {
+        for (int i = 0; i < 5; ++i)
+          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_off + 16 * i, 0, 0));
+        if constexpr (FLOW_SRC == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
+          for (int i = 0; i < 2; ++i)
+            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_off + 16 * i, 0, 0));
+        }
+      } else {
+        const long long p = unit;
+        const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0[0] * per_img * 5), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t flrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? p * per_img * 2 : 0)), 0, (int)per_img * 8, 0x00020000);
+        const uint32_t rows = (uint32_t)(16 * e * width);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
+        if constexpr (FLOW_SRC == 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
+        }
       }
     };
     // FarnebackUpdateMatrices of quad e of pair p -> mo[4 e .. 4 e + 3]; pixel j's R1 neighbourhood is read while pixel
     // j - 1 is computed
-    auto update_quad = [&](float (&mo)[16][5], long long p, int e) {
+    auto update_quad = [&](float (&mo)[16][5], long long unit, int e) {
       // the lane's pixel coordinates, border scales, ... are the same for every pair: hidden from the loop-invariant code
       // motion, which would otherwise keep dozens of them in registers around the whole pair loop
       int pt = ptid;
       asm volatile("" : "+v"(pt));
-      const int q = pt + 256 * e, y = q >> 4, x0 = (q & 15) * 4;
+      // (y, x0): the quad's position inside its image; p: its pair; R1t: its R1 in LDS
+      const int q = pt + 256 * e;
+      const int y = MOSAIC ? (q >> 4) & 31 : q >> 4, x0 = MOSAIC ? ((q & 15) & 7) * 4 : (q & 15) * 4;
+      const int tile = MOSAIC ? 2 * (q >> 9) + ((q & 15) >> 3) : 0;
+      const long long p = MOSAIC ? unit * 4 + tile : unit;
+      const float* R1t = R1s + tile * TILE_F;
+      const bool pair_there = !MOSAIC || p < n_pairs;
       FbGather g[2];
       float dxs[2], dys[2];
       auto flow_of = [&](int j, float& fdx, float& fdy) {
@@ -1032,22 +1091,23 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         if constexpr (FLOW_SRC == 0) {
           fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
         } else if constexpr (FLOW_SRC == 1) {
-          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)p, up.sh, up.sw, x0 + j, min(y, height - 1), up.inv_fx, up.inv_fy, up.mul);
+          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)(pair_there ? p : 0), up.sh, up.sw, min(x0 + j, width - 1),
+                                                 min(y, height - 1), up.inv_fx, up.inv_fy, up.mul);
           fdx = f[0], fdy = f[1];
         }
       };
       flow_of(0, dxs[0], dys[0]);
-      fb_gather_r1(R1s, dxs[0], dys[0], x0, y, width, height, g[0]);
+      fb_gather_r1(R1t, dxs[0], dys[0], x0, y, width, height, g[0]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j + 1 < 4) {
           flow_of(j + 1, dxs[(j + 1) & 1], dys[(j + 1) & 1]);
-          fb_gather_r1(R1s, dxs[(j + 1) & 1], dys[(j + 1) & 1], x0 + j + 1, y, width, height, g[(j + 1) & 1]);
+          fb_gather_r1(R1t, dxs[(j + 1) & 1], dys[(j + 1) & 1], x0 + j + 1, y, width, height, g[(j + 1) & 1]);
         }
         float r0[5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) r0[c] = r0q[e][(5 * j + c) >> 2][(5 * j + c) & 3];
-        fb_update_pixel_finish(r0, g[j & 1], dxs[j & 1], dys[j & 1], x0 + j, y, width, height, y < height && x0 + j < width, mo[4 * e + j]);
+        fb_update_pixel_finish(r0, g[j & 1], dxs[j & 1], dys[j & 1], x0 + j, y, width, height, pair_there && y < height && x0 + j < width, mo[4 * e + j]);
         __builtin_amdgcn_sched_barrier(0);      // one pixel's reads ahead, not more (registers)
       }
     };
@@ -1069,20 +1129,34 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         }
       }
     };
-    // the pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along
-    // the range without the 64-bit division per pair
-    long long i0_cur, i1_unused;
-    fb_r_images_of(p_lo, pairs_per_group, chain_f, &i0_cur, &i1_unused);
-    long long q_cur = chain_f > 0 ? p_lo % pairs_per_group : 0;
-    request_r1(i0_cur + 1, 0, 20);
-    prefetch_quad(p_lo, i0_cur, 0);
-    prefetch_quad(p_lo, i0_cur, 1);
+    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
+    // range without a 64-bit division per pair: i0_run / q_run describe the next pair not yet handed out
+    long long i0_run, i1_unused;
+    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
+    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
+    auto take_unit = [&](long long (&i0)[NP], long long (&i1)[NP]) {
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        i0[t] = i0_run, i1[t] = i0_run + 1;
+        if (chain_f > 0) {
+          i0_run += 1;
+          if (++q_run == pairs_per_group) q_run = 0, i0_run += chain_f - pairs_per_group;      // the next stack's first frame
+        } else {
+          i0_run += 2;
+        }
+      }
+    };
+    long long i0a[NP], i1a[NP];
+    take_unit(i0a, i1a);
+    request_r1(i1a, p_lo, 0, MOSAIC ? 4 : 20);
+    prefetch_quad(p_lo, i0a, 0);
+    prefetch_quad(p_lo, i0a, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();      // R1 of the first pair (and GvS) in place
+    __syncthreads();      // R1 of the first unit (and GvS) in place
     update_quad(mA, p_lo, 0);
-    prefetch_quad(p_lo, i0_cur, 2);
+    prefetch_quad(p_lo, i0a, 2);
     update_quad(mA, p_lo, 1);
-    prefetch_quad(p_lo, i0_cur, 3);
+    prefetch_quad(p_lo, i0a, 3);
     update_quad(mA, p_lo, 2);
     update_quad(mA, p_lo, 3);
     int k = 0;
@@ -1096,11 +1170,8 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
     // the multiplying waves' last channel and solve); each quad's R0 / flow requested one step before its evaluation
     auto pair_body = [&](float (&mc)[16][5], float (&mn)[16][5], long long p, auto more_tag) {
       constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
-      long long i0_next = i0_cur + 2;
-      if (chain_f > 0) {
-        i0_next = i0_cur + 1;
-        if (++q_cur == pairs_per_group) q_cur = 0, i0_next += chain_f - pairs_per_group;      // the next stack's first frame
-      }
+      long long i0n[NP], i1n[NP];
+      if constexpr (more) take_unit(i0n, i1n);
 #pragma unroll
       for (int c = 0; c < 5; ++c) {
         PV_STAMP(s0);
@@ -1111,18 +1182,17 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
         __syncthreads();
         PV_STAMP(s2);
         if constexpr (more) {
-          if (c == 0) request_r1(i0_next + 1, 0, 10), prefetch_quad(p + 1, i0_next, 0);
-          if (c == 1) request_r1(i0_next + 1, 10, 20);
-          if (c == 2) prefetch_quad(p + 1, i0_next, 1), update_quad(mn, p + 1, 0);
-          if (c == 3) prefetch_quad(p + 1, i0_next, 2), update_quad(mn, p + 1, 1);
-          if (c == 4) prefetch_quad(p + 1, i0_next, 3), update_quad(mn, p + 1, 2), update_quad(mn, p + 1, 3);
+          if (c == 0) request_r1(i1n, p + 1, 0, MOSAIC ? 2 : 10), prefetch_quad(p + 1, i0n, 0);
+          if (c == 1) request_r1(i1n, p + 1, MOSAIC ? 2 : 10, MOSAIC ? 4 : 20);
+          if (c == 2) prefetch_quad(p + 1, i0n, 1), update_quad(mn, p + 1, 0);
+          if (c == 3) prefetch_quad(p + 1, i0n, 2), update_quad(mn, p + 1, 1);
+          if (c == 4) prefetch_quad(p + 1, i0n, 3), update_quad(mn, p + 1, 2), update_quad(mn, p + 1, 3);
         }
         PV_STAMP(s3);
 #ifdef PV_DIAG_STAMPS
         dg[0] += s1 - s0, dg[2] += s2 - s1, dg[c < 2 ? 3 : 4] += s3 - s2;
 #endif
       }
-      i0_cur = i0_next;
 #ifdef PV_DIAG_STAMPS
       dg[7] += 1;
 #endif
@@ -1205,14 +1275,16 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
     PV_STAMP(s0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
-      if (y < height && x < width) {
+      // MOSAIC: this wave's quadrant IS tile (mbo, strip) = pair 4 p + 2 mbo + strip, (y, x) local to it
+      const int y = (MOSAIC ? 0 : 32 * mbo) + fb_acc_row(r, half), x = (MOSAIC ? 0 : 32 * strip) + col;
+      const long long pr = MOSAIC ? p * 4 + 2 * mbo + strip : p;
+      if (y < height && x < width && pr < n_pairs) {
         double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
         double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
         double idet = __ddiv_rn(1.0, det);
         const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
         const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-        float* fl = flow_out + (p * per_img + (long long)y * width + x) * 2;
+        float* fl = flow_out + (pr * per_img + (long long)y * width + x) * 2;
         fl[0] = fxv;
         fl[1] = fyv;
       }
@@ -1570,33 +1642,40 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)T, R, n_img, lh, lw, pk);
     }
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
-    // 33..64-pixel levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the
-    // window blur and the solve (fb_fused_iter_q_kernel); M is never written
-    // (rows of whole 4-pixel quads: the producers read R0 / flow as 16-byte vectors)
-    const bool fused_iter =
-        tile_path && fuse_init && (lh > 32 || lw > 32) && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION");
+    // Levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the window blur and the
+    // solve (fb_fused_iter_q_kernel); M is never written.  33..64-pixel levels: one pair per 64 x 64 tile; levels up to
+    // 32 x 32: four pairs per tile (MOSAIC; its buffer offsets are 31-bit).  Rows of whole 4-pixel quads: the producers read
+    // R0 / flow as 16-byte vectors.
+    const bool small_level = lh <= 32 && lw <= 32;
+    const bool fused_iter = tile_path && fuse_init && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
+                            (!small_level || ((long long)n_img * lpx * 20 < 0x7fffffffLL && n_pairs * lpx * 8 < 0x7fffffffLL &&
+                                              (long long)prev_h * prev_w * n_pairs * 8 < 0x7fffffffLL &&
+                                              !getenv("PV_FARNEBACK_TWO_LAUNCH_SMALL_LEVELS")));
     if (fused_iter) {
       float* Gv = (float*)(ws + L.off_G);
       float* Gh = lh == lw ? Gv : Gv + 64 * 64;
       stage_mark(coarse ? "farneback.coarse.iterations_fused" : "farneback.level0.iterations_fused", st);
-      hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
-      if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
+      hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win, small_level ? 1 : 0);
+      if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win, small_level ? 1 : 0);
       FbUpsample up = {prev_h, prev_w, prev_flow ? (double)prev_w / lw : 1.0, prev_flow ? (double)prev_h / lh : 1.0,
                        (float)(1. / p->pyr_scale)};
-      const unsigned grid = (unsigned)std::min<long long>(n_pairs, kNumCU);      // one workgroup per CU (LDS)
+      const long long n_units = small_level ? (n_pairs + 3) / 4 : n_pairs;
+      const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);      // one workgroup per CU (LDS)
+#define PV_FUSED_ITER(SRC, FLOW_IN)                                                                                       \
+  do {                                                                                                                    \
+    if (small_level)                                                                                                      \
+      hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, true>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
+                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, false>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
+                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
+  } while (0)
       for (int it = 0; it < p->iterations; ++it) {
-        if (it > 0)
-          hipLaunchKernelGGL(fb_fused_iter_q_kernel<0>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)flow, flow,
-                             (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up);
-        else if (prev_flow)
-          hipLaunchKernelGGL(fb_fused_iter_q_kernel<1>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)prev_flow,
-                             flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group,
-                             chain_f, up);
-        else
-          hipLaunchKernelGGL(fb_fused_iter_q_kernel<2>, dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)nullptr,
-                             flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group,
-                             chain_f, up);
+        if (it > 0) PV_FUSED_ITER(0, flow);
+        else if (prev_flow) PV_FUSED_ITER(1, prev_flow);
+        else PV_FUSED_ITER(2, nullptr);
       }
+#undef PV_FUSED_ITER
       prev_flow = flow;
       prev_w = lw;
       prev_h = lh;
@@ -1626,8 +1705,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         float* Gh = lh == lw ? Gv : Gv + 64 * 64;   // square levels: the vertical and horizontal window matrices coincide
         stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
         if (it == 0) {
-          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win);
-          if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win);
+          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win, 0);
+          if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win, 0);
         }
         if (lh <= 32 && lw <= 32) {
           const unsigned grid = (unsigned)std::min<long long>((n_pairs + 3) / 4, 2048);
