@@ -1,3 +1,5 @@
+"""Config-3 advection pipeline at B = 32, timed as the product runs it (20 batches back to back) and with pv_stage_timing
+events at every stage boundary: what the instrumentation of the per-stage table costs."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
