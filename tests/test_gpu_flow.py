@@ -229,8 +229,8 @@ def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkey
     assert np.abs(chained[1, 0].cpu().numpy() - ref).max() <= 1e-3
 
 
-@pytest.mark.parametrize("h,w,t,batch", [(64, 64, 12, 3), (64, 64, 4, 100), (40, 56, 3, 3), (48, 64, 4, 3), (64, 36, 2, 3),
-                                         (50, 62, 3, 3)])
+@pytest.mark.parametrize("h,w,t,batch", [(64, 64, 12, 3), (64, 64, 4, 100), (64, 64, 12, 100), (40, 56, 3, 3), (48, 64, 4, 3),
+                                         (64, 36, 2, 3), (50, 62, 3, 3)])
 def test_fused_iteration_equals_the_two_launch_form_bit_for_bit(device, monkeypatch, h, w, t, batch):
     """Levels up to 64 x 64 run UpdateMatrices + window blur + solve as ONE launch per iteration (fb_fused_iter_q_kernel:
     producer waves + matrix-core waves, M never written; levels up to 32 x 32 as four pairs per 64 x 64 tile with
@@ -239,7 +239,8 @@ def test_fused_iteration_equals_the_two_launch_form_bit_for_bit(device, monkeypa
     stack boundaries, a last unit of fewer than four pairs), for separate pairs, for partial tiles, and for a width that is
     no multiple of 4 (which the fused form does not take: both calls then run the same kernels)."""
     K = _ops()
-    # batch = 100: 200 stacks x 3 pairs = 600 pairs over 256 workgroups -- ranges of 2..3 pairs that cross stack boundaries
+    # batch = 100: 200 stacks x 3 pairs = 600 pairs over 256 workgroups -- ranges of 2..3 pairs that cross stack boundaries;
+    # with t = 12 (2 200 pairs) the coarse level's units of four pairs come in ranges of two or more as well
     raw, _ = advected_counts(batch=batch, t=t, channels=2, h=h, w=w, seed=3 * h + t)
     stacks = np.ascontiguousarray(raw.transpose(0, 2, 1, 3, 4)).reshape(2 * batch, t, h, w)
     u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(stacks, 0)[0]).to(device)

@@ -7,7 +7,7 @@ from oracle import flow_oracle as fo
 from predict_pv_yield_amd.data.synthetic import advected_counts
 dev = torch.device("cuda:0")
 bad = 0
-for (h, w, t, batch, seed) in [(64, 64, 4, 100, 196), (64, 64, 12, 32, 7), (64, 64, 3, 300, 11), (48, 64, 5, 80, 3)]:
+for (h, w, t, batch, seed) in [(64, 64, 4, 100, 196), (64, 64, 12, 100, 7), (64, 64, 3, 300, 11), (48, 64, 5, 80, 3)]:
     raw, _ = advected_counts(batch=batch, t=t, channels=2, h=h, w=w, seed=seed)
     stacks = np.ascontiguousarray(raw.transpose(0, 2, 1, 3, 4)).reshape(2 * batch, t, h, w)
     u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(stacks, 0)[0]).to(dev)
