@@ -1,0 +1,36 @@
+"""Random sizes / parameters: the fused Farneback iteration (both forms) against the two-launch form, bit for bit."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from predict_pv_yield_amd import hip_ops as K
+
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+bad = 0
+for case in range(n_cases):
+    h, w = int(rng.integers(3, 17)) * 4, int(rng.integers(3, 17)) * 4          # 12 .. 64, multiples of 4
+    if rng.random() < 0.2:
+        w += int(rng.integers(1, 4))                                           # a width the fused form does not take
+    t = int(rng.integers(2, 7))
+    stacks = int(rng.integers(1, 90))
+    kw = dict(levels=int(rng.integers(1, 4)), winsize=int(rng.choice([5, 9, 15, 21])), iterations=int(rng.integers(1, 4)),
+              poly_n=int(rng.choice([5, 7])), poly_sigma=float(rng.choice([1.1, 1.5])))
+    base = rng.integers(0, 256, (stacks, 1, h + 8, w + 8), dtype=np.uint8)
+    frames = np.stack([np.roll(base[:, 0], (i, 2 * i), axis=(1, 2))[:, 4:4 + h, 4:4 + w] for i in range(t)], axis=1)
+    frames = np.ascontiguousarray((frames.astype(np.int16) + rng.integers(0, 6, frames.shape)).clip(0, 255).astype(np.uint8))
+    u8 = torch.from_numpy(frames).to(dev)
+    try:
+        os.environ["PV_FARNEBACK_TWO_LAUNCH_ITERATION"] = "1"
+        ref = K.farneback_stack(u8, **kw)
+        del os.environ["PV_FARNEBACK_TWO_LAUNCH_ITERATION"]
+        got = K.farneback_stack(u8, **kw)
+        prev, nxt = u8[:, :-1].reshape(-1, h, w).contiguous(), u8[:, 1:].reshape(-1, h, w).contiguous()
+        got_pairs = K.farneback_pairs(prev, nxt, **kw)
+    finally:
+        os.environ.pop("PV_FARNEBACK_TWO_LAUNCH_ITERATION", None)
+    ok = torch.equal(got, ref) and torch.equal(got_pairs.reshape(ref.shape), ref) and bool(torch.isfinite(got).all())
+    if not ok:
+        bad += 1
+        print("MISMATCH", (h, w, t, stacks), kw, int((got != ref).sum()), float((got - ref).abs().max()))
+print(f"{n_cases} cases, {bad} mismatches")
