@@ -244,6 +244,48 @@ def test_conv3d_bf16_random_shapes(device):
         assert torch.equal(ygm, yg), msg + " (out_gate_mask)"
 
 
+def test_conv3d_bf16_weight_gradient_and_first_layer_random_shapes(device):
+    """Seeded sweep over ragged shapes / paddings / batch sizes / channel counts of (a) the weight gradient -- the
+    loader-wave kernel (no gate handed over: dY arrives gated) and the register-staged one (gate handed over), 16 and 32
+    padded input channels, one to three column tiles, time chunks -- and (b) the first layer from the f32 NCDHW input
+    (loader-wave kernel where w % 4 == 0 and no width padding, the one-role kernel otherwise): against torch on
+    bf16-rounded operands, and the two first-layer paths against pack + conv bit for bit."""
+    K, _ = _mods()
+    rng = np.random.default_rng(77)
+    for it in range(20):
+        b = int(rng.integers(1, 4))
+        ci = int(rng.choice([3, 11, 16, 32, 32]))
+        pad = tuple(int(v) for v in rng.integers(0, 2, size=3))
+        t = int(rng.integers(3, 8))
+        h = int(rng.integers(4, 24))
+        w = int(rng.integers(4, 72))
+        msg = f"case #{it}: b={b} ci={ci} t={t} h={h} w={w} pad={pad}"
+        x, wt, bias = _conv_case(300 + it, b, ci, 32, t, h, w)
+        xr = co.bf16_round(x)
+        wr = co.bf16_round(wt).requires_grad_(True)
+        br = bias.clone().requires_grad_(True)
+        y_ref = F.relu(F.conv3d(xr, wr, br, padding=pad))
+        gy = co.bf16_round(torch.randn(y_ref.shape, generator=torch.Generator().manual_seed(it)))
+        y_ref.backward(gy)
+        xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+        gate = K.pack_ncdhw_f32_to_ndhwc_bf16(y_ref.detach().to(device))
+        gy_gated = torch.where(y_ref.detach() > 0, gy, torch.zeros_like(gy))
+        scale_w, scale_b = wr.grad.abs().max().item(), br.grad.abs().max().item()
+        for gated_outside in (True, False):
+            if gated_outside:       # dY already carries the ReLU derivative: the loader-wave kernel
+                dw, db = K.conv3d_bwd_weight_bf16(xp, K.pack_ncdhw_f32_to_ndhwc_bf16(gy_gated.to(device)), None, ci, 32, pad)
+            else:                   # the kernel gates while it stages: the register-staged kernel
+                dw, db = K.conv3d_bwd_weight_bf16(xp, K.pack_ncdhw_f32_to_ndhwc_bf16(gy.to(device)), gate, ci, 32, pad)
+            assert (dw.cpu() - wr.grad).abs().max().item() <= 2e-3 * scale_w + 1e-4, msg + f" dw (gated_outside={gated_outside})"
+            assert (db.cpu() - br.grad).abs().max().item() <= 2e-3 * scale_b + 1e-4, msg + f" db (gated_outside={gated_outside})"
+        if ci <= 16 and pad[2] == 0:      # (the entry point takes no width padding)
+            wp = K.conv3d_pack_weight_bf16(wt.to(device))
+            y1, xp1 = K.conv3d_fwd_bf16_f32in(x.to(device), wp, bias.to(device), 32, pad, relu=True)
+            y2 = K.conv3d_fwd_bf16(xp, None, wp, bias.to(device), ci, 32, pad, relu=True)
+            assert torch.equal(y1, y2) and torch.equal(xp1, xp), msg + " first layer vs pack + conv"
+            torch.testing.assert_close(y1.float().cpu().permute(0, 4, 1, 2, 3), y_ref.detach(), rtol=1e-2, atol=2e-3, msg=msg)
+
+
 def _mask_bits(mask, y_shape):
     """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
     b, t, h, w, c = y_shape
