@@ -2,7 +2,7 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O; cd $R
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 $R/bench.py --steps 10 --warmup 3 --no-roofline --no-cpu-baseline --no-extras > $O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 $R/bench.py --no-roofline --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $O/write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/flow -o p -- python3 $R/tools/time_flow_stages.py 32 > $O/flow_stage_times.txt 2>&1
