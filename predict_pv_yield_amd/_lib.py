@@ -104,6 +104,7 @@ SIGNATURES = {
     "pv_conv3d_bwd_weight_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp],
     "pv_bf16_cpad": [c_i32],
     "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_unpack_ndhwc_bf16_to_ncdhw_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_repack_gate_ncdhw_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_conv3d_packed_weight_elems": [c_i32],

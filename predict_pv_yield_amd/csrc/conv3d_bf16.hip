@@ -504,13 +504,21 @@ __device__ __forceinline__ void wave_store_run(unsigned char* patch, const u32x4
 template <int CPAD>
 __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float* __restrict__ x,
                                                                       uint16_t* __restrict__ xp, int c,
-                                                                      long long vox_per_sample, long long total_quads) {
+                                                                      long long vox_per_sample, long long total_quads,
+                                                                      uint16_t* __restrict__ xp_m = nullptr,
+                                                                      uint16_t* __restrict__ xp_l = nullptr) {
+  // xp_m / xp_l given: the THREE-WAY TRUNCATION SPLIT x = h + m + l (8 + 8 + 8 mantissa bits, both subtractions exact; what is
+  // dropped is below 2^-24 |x|) instead of one rounded image -- the operand planes with which the bf16 matrix-core kernels
+  // form an f32-accurate product from six partial products (hh, hm, mh, hl, lh, mm).  One pass per plane; the second and third
+  // read the 32 KB a wave just touched from the L2.
+  const int n_planes = xp_m ? 3 : 1;
   constexpr int NCH = 4 * CPAD * 2 / 16;  // 16-byte chunks per lane (4 voxels)
   __shared__ __attribute__((aligned(16))) unsigned char patch[4][NCH * 1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long qps = vox_per_sample / 4;
   for (long long base = (long long)blockIdx.x * blockDim.x + wave * 64; base < total_quads; base += stride) {
+   for (int plane = 0; plane < n_planes; ++plane) {
     const long long i = base + lane;
     u32x4 o[NCH];
 #pragma unroll
@@ -525,7 +533,16 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (k < c) a = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) h[q][k] = f32_to_bf16_bits(a[q]);
+        for (int q = 0; q < 4; ++q) {
+          if (n_planes == 1) {
+            h[q][k] = f32_to_bf16_bits(a[q]);
+          } else {      // plane 0: h = trunc(x); 1: m = trunc(x - h); 2: l = trunc(x - h - m)
+            float r = a[q];
+            if (plane >= 1) r = r - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r) & 0xffff0000u);
+            if (plane >= 2) r = r - __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, r) & 0xffff0000u);
+            h[q][k] = (uint16_t)(__builtin_bit_cast(uint32_t, r) >> 16);
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -536,8 +553,10 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float
             o[q * (CPAD / 8) + k][e] = (uint32_t)h[q][8 * k + 2 * e] | ((uint32_t)h[q][8 * k + 2 * e + 1] << 16);
     }
     // quads are numbered through the whole [B][voxel] range, so the wave's 64 quads are one contiguous output run
-    wave_store_run<NCH>(patch[wave], o, reinterpret_cast<unsigned char*>(xp) + (size_t)base * (NCH * 16),
+    uint16_t* dst = plane == 0 ? xp : (plane == 1 ? xp_m : xp_l);
+    wave_store_run<NCH>(patch[wave], o, reinterpret_cast<unsigned char*>(dst) + (size_t)base * (NCH * 16),
                         (total_quads - base) * (NCH * 16));
+   }
   }
 }
 
@@ -747,6 +766,26 @@ int pv_bf16_cpad(int32_t c) {
   return PV_ESIZE;
 }
 
+int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint16_t* xp_m, uint16_t* xp_l, int32_t batch,
+                                           int32_t c, int32_t t, int32_t h, int32_t w, void* stream) {
+  PV_REQUIRE(x && xp_h && xp_m && xp_l, PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: null pointer");
+  const int cpad = pv_bf16_cpad(c);
+  PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: c=%d not in 1..32", c);
+  const long long vps = (long long)t * h * w, total = vps * batch;
+  PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: empty tensor");
+  PV_REQUIRE(vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp_h % 16 == 0) && ((uintptr_t)xp_m % 16 == 0) &&
+                 ((uintptr_t)xp_l % 16 == 0),
+             PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: needs t*h*w %% 4 == 0 and 16-byte aligned buffers");
+  const unsigned g4 = stream_grid((size_t)(total / 4), 256);
+  if (cpad == 16)
+    hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<16>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp_h, c, vps, total / 4,
+                       xp_m, xp_l);
+  else
+    hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp_h, c, vps, total / 4,
+                       xp_m, xp_l);
+  return check_launch("pv_pack_split3_ncdhw_f32_to_ndhwc_bf16");
+}
+
 int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c, int32_t t, int32_t h,
                                     int32_t w, void* stream) {
   PV_REQUIRE(x && xp, PV_EINVAL, "pv_pack_ncdhw_f32_to_ndhwc_bf16: null pointer");
@@ -758,9 +797,11 @@ int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch,
   if (vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp % 16 == 0)) {
     unsigned g4 = stream_grid((size_t)(total / 4), 256);
     if (cpad == 16)
-      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<16>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4);
+      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<16>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4,
+                         (uint16_t*)nullptr, (uint16_t*)nullptr);
     else
-      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4);
+      hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp, c, vps, total / 4,
+                         (uint16_t*)nullptr, (uint16_t*)nullptr);
   } else if (cpad == 16)
     hipLaunchKernelGGL(pack_ncdhw_to_ndhwc_kernel<16>, dim3(grid), dim3(256), 0, as_stream(stream), x, xp, c, vps, total);
   else
