@@ -286,6 +286,33 @@ def test_conv3d_bf16_weight_gradient_and_first_layer_random_shapes(device):
             torch.testing.assert_close(y1.float().cpu().permute(0, 4, 1, 2, 3), y_ref.detach(), rtol=1e-2, atol=2e-3, msg=msg)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 4, 6, 6), (3, 11, 5, 8, 8), (1, 16, 3, 10, 14), (2, 3, 2, 4, 6)])
+def test_three_way_split_is_exact_and_the_weight_gradient_built_on_it_is_f32_accurate(device, shape):
+    """pv_pack_split3_...: x = h + m + l EXACTLY for these magnitudes (24 mantissa bits in three bf16 images), h is the
+    truncation of x, padded channels are zero; and the weight gradient formed from six bf16 matrix-core launches on the planes
+    equals torch's f32 gradient to a few 1e-6 (the bf16 path proper is 1e-2)."""
+    K, _ = _mods()
+    b, c, t, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 3).to(device)
+    hh, mm, ll = K.pack_split3_ncdhw_f32_to_ndhwc_bf16(x)
+    rec = (hh.double() + mm.double() + ll.double()).permute(0, 4, 1, 2, 3)[:, :c]
+    assert torch.equal(rec, x.double())
+    assert torch.equal(K.unpack_ndhwc_bf16_to_ncdhw_f32(hh, c), (x.view(torch.int32) & -65536).view(torch.float32))
+    assert bool((hh[..., c:] == 0).all()) and bool((mm[..., c:] == 0).all()) and bool((ll[..., c:] == 0).all())
+    if t >= 3 and h >= 3 and w >= 3 and ((t - 2) * (h - 2) * (w - 2)) % 4 == 0:
+        wt = torch.randn(32, c, 3, 3, 3, generator=g) * 0.1
+        xr = x.cpu().double()
+        wr = wt.double().requires_grad_(True)
+        br = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xr, wr, br)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy.double())
+        dw, db = K.conv3d_bwd_weight_f32_on_bf16x3(x, gy.to(device).contiguous())
+        assert (dw.cpu().double() - wr.grad).abs().max().item() <= 2e-5 * wr.grad.abs().max().item()
+        assert (db.cpu().double() - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item()
+
+
 def _mask_bits(mask, y_shape):
     """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
     b, t, h, w, c = y_shape
