@@ -287,8 +287,8 @@ def measure_config3(dev, b, history_minutes):
             model.training_step(bt, 0).backward()
             opt.step()
 
-    epoch(6)
-    torch.cuda.synchronize()
+    epoch(n)      # a whole epoch of warm-up: the side stream's allocator pool reaches its steady size (record_stream defers
+    torch.cuda.synchronize()      # the reuse of a block until the consumer is through with it; growing the pool synchronises)
     t0 = time.perf_counter()
     epoch(n)
     torch.cuda.synchronize()
