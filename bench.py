@@ -35,6 +35,7 @@ MFMA_BF16_PEAK = 2.5e15     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12    # f32 matrix cores (xf32-free exact f32)
 HBM_PEAK = 8.0e12
 TRAFFIC_PROFILE = os.path.join("profiles", "r03", "pmc_hbm_traffic_bench_B32.json")
+FLOW_TRAFFIC_PROFILE = os.path.join("profiles", "r04", "pmc_flow_traffic_B32.json")
 
 MODEL_KW = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, number_of_conv3d_layers=4,
                 conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
@@ -109,6 +110,16 @@ def committed_hbm_traffic():
     return json.load(open(path))["kernels"]
 
 
+def committed_flow_traffic(b):
+    """HBM bytes of one batch of the advection pipeline from the committed FETCH_SIZE / WRITE_SIZE passes over
+    tools/time_flow_stages.py (tools/pmc_flow_traffic.py; {} until a collection for this batch size is committed)."""
+    path = os.path.join(ROOT, FLOW_TRAFFIC_PROFILE)
+    if not os.path.exists(path):
+        return {}
+    d = json.load(open(path))
+    return d if d.get("batch") == b else {}
+
+
 def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
     """Runs n instrumented steps (same tensors, same launch sequence as the timed region) and prices the kernels."""
     with LaunchTimer(TIMED_OPS) as lt:
@@ -169,6 +180,9 @@ def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
     tot_s = sum(v["us_per_launch"] * v["launches_per_step"] for _, v in conv_all)
     out["all_conv_kernels"] = {"gflop_per_step": round(tot_fl, 1), "us_per_step": round(tot_s, 1),
                                "frac_of_bf16_mfma_peak": round(tot_fl * 1e9 / (tot_s * 1e-6) / MFMA_BF16_PEAK, 4)}
+    out["all_conv_frac"] = out["all_conv_kernels"]["frac_of_bf16_mfma_peak"]
+    if fam_n:
+        out["conv_fwd_dgrad_frac"] = out["mfma_conv3d"]["frac"]
     out["kernels"] = kernels
     out["method"] = (f"{n_steps} extra train steps with a HIP event pair around every launch (torch's current stream = the "
                      "launching stream); traffic = committed rocprofv3 --pmc passes (" + TRAFFIC_PROFILE + ")")
@@ -182,8 +196,12 @@ def measure_config3(dev, b, history_minutes):
     from predict_pv_yield_amd import hip_ops as K
     from predict_pv_yield_amd import optical_flow as of
     from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.data.synthetic import advected_counts
     t_obs, c, hw, n_future = 12, 11, 64, 6
-    raw = torch.randint(0, 1021, (b, t_obs, c, hw, hw), dtype=torch.int16, device=dev)
+    # the SURVEY section-8(d) workload: dense blob textures advected by a constant sub-pixel velocity, seed 1234 -- the very
+    # tensor the CPU leg (flow_cpu_baseline) and tests/test_gpu_headline.py's joined-model parity test use.  The fused
+    # iteration's LDS gathers follow the flow, so its time depends on the data: noise is not this workload.
+    raw = torch.from_numpy(advected_counts(batch=b, t=t_obs, channels=c, h=hw, w=hw, seed=1234)[0]).to(dev)
     for _ in range(5):
         of.advect_future_frames(raw, n_future)
     iters = 10
@@ -244,12 +262,21 @@ def measure_config3(dev, b, history_minutes):
                          "GBps": round(a["bytes"] * per / secs / 1e9, 1), "TFLOPs_f32": round(a["flops"] * per / secs / 1e12, 2),
                          "frac": round(max(t_mem, t_fl) / secs, 4)}
     compulsory = b * (t_obs * c * px0 * 2 + n_future * c * px0 * 4)
+    # per sample 2.16 MB compulsory (raw counts in, six f32 frames out) and 1.49 GFLOP f32 (121 pairs
+    # x 4096 px x 3.0 kflop); the pipeline's roofline is whichever of the two takes longer at its peak
+    survey_s = max(compulsory / HBM_PEAK, pairs * px0 * 3.0e3 / MFMA_F32_PEAK)
+    flow_traffic = committed_flow_traffic(b)
     out = {"workload": f"raw [B={b},12,11,64,64] int16 -> u8 -> 121 Farneback pairs/sample -> weighted mean -> normalise -> "
                        "6 advected frames written into the model input [B,11,18,64,64]",
            "pipeline_ms": round(total * 1e3, 3), "pipeline_ms_with_stage_events": round(total_staged * 1e3, 3),
            "samples_per_s": round(b / total, 1),
            "farneback_pairs_per_s": round(pairs / total, 0),
            "compulsory_GB": round(compulsory / 1e9, 4), "compulsory_GBps": round(compulsory / total / 1e9, 1),
+           "survey_roofline_us": round(survey_s * 1e6, 1), "frac_of_survey_roofline": round(survey_s / total, 4),
+           "hbm_traffic_GB": flow_traffic.get("GB_per_batch"),
+           "traffic_over_compulsory": round(flow_traffic["GB_per_batch"] * 1e9 / compulsory, 2) if flow_traffic else None,
+           "traffic_profile": FLOW_TRAFFIC_PROFILE if flow_traffic else None,
+           "input": "data.synthetic.advected_counts(seed=1234): blob textures advected by U(-3,3) px/frame",
            "stages": stages,
            "stage_method": "pv_stage_timing_begin/_end: one HIP event per stage boundary on the launching stream; peak = "
                            "8 TB/s HBM or 157.3 TFLOP/s f32 matrix cores, whichever bounds the stage's algorithmic work"}
@@ -278,7 +305,7 @@ def measure_config3(dev, b, history_minutes):
                                 "workload": "advection pipeline + conv3d train step (fwd + NMAE + bwd + Adam) per batch"}
     # the same work as a two-stage pipeline: optical_flow.AdvectingLoader advects batch i+1 on a side stream under the
     # train step of batch i
-    raw2 = (torch.rand(raw.shape, device=dev) * 1023).to(torch.int16)
+    raw2 = torch.from_numpy(advected_counts(batch=b, t=t_obs, channels=c, h=hw, w=hw, seed=4321)[0]).to(dev)
     pv = batch["pv"]
 
     def epoch(k):
@@ -738,7 +765,8 @@ def main():
     if args.global_batch:
         if args.global_batch % world:
             raise SystemExit("--global-batch must be a multiple of the number of GPUs")
-        b = args.global_batch // world
+        lo, hi = D.shard_range(args.global_batch)      # this rank's samples of the global batch (contiguous, equal counts)
+        b = hi - lo
     model.batch_size = max(model.batch_size, b)  # BaseModel.batch_size slices the target (base_model.py:95)
     batch = {"satellite": {"data": torch.randn(b, 11, t_frames, 64, 64, generator=g, device=dev)},
              "pv": {"pv_yield": torch.rand(b, t_frames, 128, generator=g, device=dev)}}
@@ -813,6 +841,10 @@ def main():
             if not args.no_extras:
                 out["config3"] = measure_config3(dev, b, args.history_minutes)
                 torch.cuda.empty_cache()
+                if out["roofline"] is not None:      # scalars the driver's record keeps (it drops nested objects)
+                    out["roofline"]["config3_pipeline_ms"] = out["config3"]["pipeline_ms"]
+                    out["roofline"]["config3_frac"] = out["config3"]["frac_of_survey_roofline"]
+                    out["roofline"]["config3_joined_step_ms"] = out["config3"]["joined_train_step"]["ms_per_step"]
                 if args.precision == "bf16":
                     out["hip_graph_step"] = measure_graph_step(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()

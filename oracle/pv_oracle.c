@@ -6,7 +6,7 @@
  * PARITY UNPINNED for Farnebäck and remap: the arithmetic lives in OpenCV (cv2), which the
  * reference neither pins nor declares (absent from requirements.txt / environment.yml; notebooks
  * link the 4.5.0 docs) and which is not installed here; the reference has no tests or golden
- * vectors for this path.  What follows restates the published algorithm of
+ * vectors for this path.  What follows is a C transcription (see the licence note below) of
  * modules/video/src/optflowgf.cpp (FarnebackPolyExp / FarnebackUpdateMatrices /
  * FarnebackUpdateFlow_GaussianBlur / FarnebackOpticalFlowImpl::calc) and
  * modules/imgproc/src/imgwarp.cpp (remapBilinear, 1/32-px fixed-point maps) of OpenCV 4.5,
@@ -19,11 +19,22 @@
  * and pinned by the analytic known-answer tests in tests/test_oracle_flow.py (SURVEY.md §8c K1-K5,
  * R1-R5).  Build with -ffp-contract=off so every product is rounded before it is added.
  *
- * Attribution: the algorithms restated here are those of OpenCV (https://opencv.org, (C) the OpenCV
- * contributors, Apache License 2.0); the Farnebäck method is G. Farnebäck, "Two-Frame Motion Estimation
- * Based on Polynomial Expansion", SCIA 2003.  This file is an independent restatement written against the
- * published behaviour (operation order, border rules, fixed-point quantisation) so that it can serve as a
- * bit-level checker; it contains no OpenCV source.
+ * Attribution and licence.  poly_exp / update_matrices / update_flow_gaussian_blur / prepare_gaussian / the pyramid driver
+ * and remap_bilinear below are TRANSCRIBED into C from OpenCV 4.5
+ *   modules/video/src/optflowgf.cpp   (FarnebackPolyExp, FarnebackUpdateMatrices, FarnebackUpdateFlow_GaussianBlur,
+ *                                      FarnebackPrepareGaussian, FarnebackOpticalFlowImpl::calc)
+ *   modules/imgproc/src/imgwarp.cpp   (remapBilinear, the 1/32-px fixed-point map conversion)
+ * statement by statement (same operation order, temporaries, border tables and fixed-point quantisation), so that this
+ * file can serve as a bit-level checker of those functions.  OpenCV is
+ *   Copyright (C) 2000-2020, Intel Corporation, Willow Garage Inc., NVIDIA Corporation, Advanced Micro Devices, Inc.,
+ *   OpenCV Foundation, Itseez Inc., Xperience AI and the other OpenCV contributors, all rights reserved,
+ * and is licensed under the Apache License, Version 2.0 (http://www.apache.org/licenses/LICENSE-2.0); this derived file is
+ * distributed under the same licence: you may not use it except in compliance with the Licence; software distributed
+ * under the Licence is distributed on an "AS IS" BASIS, WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or
+ * implied.  Changes made: C++ templates / cv::Mat / parallel_for_ replaced by plain C arrays and loops, f32 only, the
+ * OPTFLOW_FARNEBACK_GAUSSIAN branch only, no SIMD paths.  The method is G. Farnebäck, "Two-Frame Motion Estimation Based
+ * on Polynomial Expansion", SCIA 2003.  OpenCV is not part of /root/reference (the reference calls it through cv2), and
+ * nothing in the product path includes, links or imports this file.
  */
 #include <math.h>
 #include <stdint.h>

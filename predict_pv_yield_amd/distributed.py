@@ -348,10 +348,11 @@ def all_reduce_mean_scalars(values: Dict[str, float], device=None) -> Dict[str, 
 
 
 def shard_range(n_items: int, rank: int = None, world: int = None):
-    """Contiguous shard of independent units (whole batches, samples, flow pairs) for this rank: no collective needed.
-    EVERY rank gets the same count, n_items // world (the tail n_items % world is dropped, DistributedSampler's
-    drop_last): the train loop issues collectives every step, so a rank with fewer steps would leave the others
-    waiting in a gradient exchange it never joins.  Fewer items than ranks is an error, not an empty shard."""
+    """Contiguous shard [lo, hi) of a GLOBAL batch of independent samples for this rank (bench.py --global-batch, the
+    strong-scaling mode; tests/ddp_two_rank_worker.py): no collective needed.  EVERY rank gets the same count,
+    n_items // world (a tail n_items % world is dropped, DistributedSampler's drop_last): the train loop issues
+    collectives every step, so a rank with fewer samples per step than the others is fine but one with none is not --
+    fewer items than ranks is an error, not an empty shard."""
     if rank is None:
         rank = dist.get_rank() if is_distributed() else 0
     if world is None:
@@ -360,19 +361,3 @@ def shard_range(n_items: int, rank: int = None, world: int = None):
     if per == 0:
         raise ValueError(f"shard_range: {n_items} item(s) cannot be split over {world} ranks (every rank needs >= 1)")
     return rank * per, (rank + 1) * per
-
-
-def shard_indices(n_items: int, rank: int = None, world: int = None):
-    """Item indices of this rank's loader shard, DistributedSampler's rule without shuffling (what Lightning's
-    replace_sampler_ddp installs, configs/trainer/all_params.yaml:43): the index list is PADDED by wrapping around to
-    ceil(n_items / world) * world entries and rank r takes entries r, r + world, ...  Every rank gets the same count (the
-    loops issue collectives per step / per logged metric, so no rank may run short) and no item is dropped; a split with
-    fewer items than ranks (the shipped experiments validate on n_val_data = 2 batches) repeats items instead of failing."""
-    if rank is None:
-        rank = dist.get_rank() if is_distributed() else 0
-    if world is None:
-        world = dist.get_world_size() if is_distributed() else 1
-    if n_items <= 0:
-        return []
-    per = -(-n_items // world)
-    return [(rank + k * world) % n_items for k in range(per)]

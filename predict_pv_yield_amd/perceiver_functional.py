@@ -17,13 +17,22 @@ _TIED = {}
 _TIED_TASK = [-1]
 
 
-def _note_use(ctx, index: int, param) -> None:
-    """Forward side: counts how often `param` is applied in the graph being built (only applications that will receive a
-    gradient).  A parameter applied ONCE per forward (exp-003's untied layers, every Linear of the heads) is never
-    registered below: holding a second reference to its gradient would keep AccumulateGrad from taking the tensor over (one
-    extra copy kernel per parameter and step) and keep a second copy of every gradient alive."""
-    if param is not None and ctx.needs_input_grad[index]:
-        param._pv_uses = getattr(param, "_pv_uses", 0) + 1
+_GRAPH_GEN = [0]      # number of backward passes seen so far: a use count noted before the latest one is stale
+
+
+def _note_use(param) -> None:
+    """Forward side, called by the wrappers below BEFORE Function.apply (inside Function.forward the grad mode is always
+    off and ctx.needs_input_grad ignores it): counts how often `param` is applied in the graph being built.  A parameter
+    applied ONCE per forward (exp-003's untied layers, every Linear of the heads) is never registered below: holding a
+    second reference to its gradient would keep AccumulateGrad from taking the tensor over (one extra copy kernel per
+    parameter and step) and keep a second copy of every gradient alive.  A forward under torch.no_grad() (validation, the
+    sanity check) builds no graph and is not counted; counts left over by a graph that was never backpropagated are dropped
+    at the first use after the next backward pass (they carry the generation they were noted in)."""
+    if param is None or not param.requires_grad or not torch.is_grad_enabled():
+        return
+    if getattr(param, "_pv_uses_gen", -1) != _GRAPH_GEN[0]:
+        param._pv_uses, param._pv_uses_gen = 0, _GRAPH_GEN[0]
+    param._pv_uses += 1
 
 
 def _tied_slot(param: torch.Tensor):
@@ -35,6 +44,7 @@ def _tied_slot(param: torch.Tensor):
     if _TIED_TASK[0] != task:               # entries live for one backward pass (as _SHARED_ACT below)
         _TIED.clear()
         _TIED_TASK[0] = task
+        _GRAPH_GEN[0] += 1
     uses = getattr(param, "_pv_uses", 0)
     if uses > 0:
         param._pv_uses = uses - 1           # this call consumes one of the forward's applications
@@ -84,8 +94,6 @@ class LinearRowsF32(torch.autograd.Function):
         x2 = x.contiguous().view(-1, x.shape[-1])
         res2 = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
         y = K.gemm(x2, weight.t(), bias=bias, residual=res2)
-        _note_use(ctx, 1, weight)
-        _note_use(ctx, 2, bias)
         ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         return y.view(x.shape[:-1] + (weight.shape[0],))
@@ -115,6 +123,8 @@ class LinearRowsF32(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, residual=None):
+    _note_use(weight)
+    _note_use(bias)
     return LinearRowsF32.apply(x, weight, bias, residual)
 
 
@@ -238,7 +248,6 @@ class LayerNormF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_fwd(x, weight, bias, eps)
-        _note_use(ctx, 1, weight)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y
 
@@ -256,6 +265,7 @@ class LayerNormF32(torch.autograd.Function):
 
 
 def layer_norm(x, weight, bias, eps=1e-5):
+    _note_use(weight)
     return LayerNormF32.apply(x, weight, bias, eps)
 
 
@@ -269,7 +279,6 @@ class LayerNormForkF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps):
         x = x.contiguous()
         y, mean, rstd = K.layernorm_fwd(x, weight, bias, eps)
-        _note_use(ctx, 1, weight)
         ctx.save_for_backward(x, weight, mean, rstd)
         return y, x.view_as(x)
 
@@ -291,6 +300,7 @@ class LayerNormForkF32(torch.autograd.Function):
 
 def layer_norm_fork(x, weight, bias, eps=1e-5):
     """-> (layer_norm(x), x): see LayerNormForkF32."""
+    _note_use(weight)
     return LayerNormForkF32.apply(x, weight, bias, eps)
 
 

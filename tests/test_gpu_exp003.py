@@ -165,3 +165,27 @@ def test_exp003_config_composes_and_trains(device, tmp_path, monkeypatch):
                      "optimized_metric=NMAE/Validation_epoch"])
     assert cfg.model._target_.endswith("exp003.LitModel") and cfg.trainer.precision == 16
     assert np.isfinite(train(cfg))
+
+
+def test_no_grad_forward_does_not_register_untied_gradients(device):
+    """a validation / sanity-check forward (torch.no_grad) must not count as an application of a parameter --
+    otherwise every once-applied parameter looks tied from the first validation pass on, its gradient is kept in _TIED and
+    AccumulateGrad has to copy it.  exp-003's perceiver is NOT weight-tied: nothing may be registered, ever."""
+    from predict_pv_yield_amd import perceiver_functional as PF
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    _, model = _pair(device, "f32")
+    batch = _to(make_fake_exp003_batch(2, 32, torch.Generator().manual_seed(5)), device)
+    seen = []
+    keep = PF._tied_keep
+    PF._tied_keep = lambda key, grad: (seen.append(key), keep(key, grad))[1]
+    try:
+        for _ in range(2):
+            with torch.no_grad():
+                model(batch)                                   # validation-style forward: builds no graph
+            model.zero_grad(set_to_none=True)
+            model.training_step(batch, 0).backward()
+            assert all(k is None for k in seen), "a once-applied parameter was registered as tied"
+            assert not PF._TIED
+            assert all(getattr(p, "_pv_uses", 0) == 0 for p in model.parameters()), "use counts must be consumed by the backward"
+    finally:
+        PF._tied_keep = keep
