@@ -212,7 +212,8 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                                     long long next_stride, long long pairs_per_group,
                                                                     long long group_stride, float* __restrict__ R,
                                                                     long long n_img, int chain_f, int h, int w, int lh, int lw, int mode,
-                                                                    double inv_fx, double inv_fy, FbTaps kt, FbPoly pk) {
+                                                                    double inv_fx, double inv_fy, FbTaps kt, FbPoly pk, int planar) {
+  // planar != 0: R[img][5][lh][lw] (what fb_iter_kernel stages and gathers), else R[img][lh][lw][5]
   __shared__ float bufA[64 * 64];        // source as float, later the blurred image, later PolyExp plane t0
   __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
   __shared__ float Tt12[2 * 64 * 64];    // vertical PolyExp planes t1, t2
@@ -324,12 +325,13 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
         b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[xp], t1r[xm]), pk.xg[k]));
         b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[xp], t2r[xm]), g0));
       }
-      float* d = R + (im * lpx + i) * 5;
-      d[1] = (float)__dmul_rn(b2, pk.ig11);
+      float* d = planar ? R + im * lpx * 5 + i : R + (im * lpx + i) * 5;
+      const int cs = planar ? lpx : 1;
+      d[cs] = (float)__dmul_rn(b2, pk.ig11);
       d[0] = (float)__dmul_rn(b3, pk.ig11);
-      d[3] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
-      d[2] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
-      d[4] = (float)__dmul_rn(b6, pk.ig55);
+      d[3 * cs] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+      d[2 * cs] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+      d[4 * cs] = (float)__dmul_rn(b6, pk.ig55);
     }
     __syncthreads();   // LDS is reused by the next image
   }
@@ -476,6 +478,30 @@ __device__ __forceinline__ fb_f32x2_t fb_upsampled_flow(const float* __restrict_
 #pragma unroll
   for (int c = 0; c < 2; ++c) o[c] = __fmul_rn(__fadd_rn(__fmul_rn(r0[c], b0), __fmul_rn(r1[c], b1)), mul);
   return o;
+}
+
+// the same without control flow (fb_iter_kernel evaluates it between other work: a branch would split the live ranges around
+// it): the right-hand taps are read at a clamped column and enter with weight 0 where the resize has none -- t00 * 1 + t01 * 0
+// is t00 itself, so the values are those of fb_upsampled_flow
+__device__ __forceinline__ fb_f32x2_t fb_upsampled_flow_nb(const float* __restrict__ src, size_t p, int sh, int sw, int x, int y,
+                                                           double inv_fx, double inv_fy, float mul) {
+  float fx = (float)((x + 0.5) * inv_fx - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  fx = (sx < 0 || sx >= sw - 1) ? 0.f : fx;
+  sx = sx < 0 ? 0 : (sx >= sw - 1 ? sw - 1 : sx);
+  float fy = (float)((y + 0.5) * inv_fy - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= sy;
+  fy = (sy < 0 || sy >= sh - 1) ? 0.f : fy;
+  sy = sy < 0 ? 0 : (sy >= sh - 1 ? sh - 1 : sy);
+  const int sy1 = min(sy + 1, sh - 1), sx1 = min(sx + 1, sw - 1);
+  const fb_f32x2_t* s0 = reinterpret_cast<const fb_f32x2_t*>(src) + (p * sh + sy) * sw;
+  const fb_f32x2_t* s1 = reinterpret_cast<const fb_f32x2_t*>(src) + (p * sh + sy1) * sw;
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+  const fb_f32x2_t t00 = s0[sx], t10 = s1[sx], t01 = s0[sx1], t11 = s1[sx1];
+  const fb_f32x2_t r0 = t00 * a0 + t01 * a1, r1 = t10 * a0 + t11 * a1;
+  return (r0 * b0 + r1 * b1) * mul;
 }
 
 // R: [n_img][lh][lw][5], the two images of pair p per fb_r_images_of; flow: [n_pairs][lh][lw][2];
@@ -1300,6 +1326,504 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
 #endif
 }
 
+// ---- one whole Farneback iteration per launch, second form (round 4): lane = column, f16 x 2 operands, 4 + 8 waves ------
+// What the counters and stamps of fb_fused_iter_q_kernel said (profiles/r03): its four producing waves are the critical
+// path, their R1 gathers hit the LDS four ways (20-byte records, a wave's four rows on the same banks), the multiplying
+// waves wait 40 %, and on the vector ALU the three-way bf16 split (5.5 instructions per element) and the f64 solve weigh as
+// much as UpdateMatrices itself.  This kernel keeps the producer / multiplier split and changes everything underneath:
+//   * R is PLANAR in memory ([image][5][h][w], written so by fb_prep_polyexp_tile_kernel) and in LDS (five 64 x 64 planes, a
+//     fixed row stride of 64 floats whatever the level's size; MOSAIC: the four 32 x 32 tiles side by side in the same
+//     planes).  A producer lane owns one COLUMN and walks 8 rows, so the 64 lanes of a gather read consecutive floats of a
+//     row (displaced by the flow): no bank conflicts for a smooth flow field, and every channel / neighbour is a constant
+//     offset from one address.
+//   * EIGHT producing waves (two per SIMD, 8 pixels per lane) beside the four multiplying ones: one hides the other's LDS
+//     round trips; the pixel arithmetic runs on channel pairs (v_pk_*_f32), same expressions and rounding order as
+//     fb_update_pixel, so M is bit-identical to the two-launch form.
+//   * the window blur runs on the F16 matrix cores with TWO-term operands: x = h + l, h = rne_f16(x), l = rne_f16(x - h)
+//     carries 22 significant bits, so three products (hh, hl, lh) reach 2^-22 where the bf16 split needs six -- half the
+//     matrix work and 2.5 instead of 5.5 vector instructions per element split.  f16 has a narrow range, so every operand
+//     is scaled by an exact power of two first: the window matrices by 2^15 (taps 4e-3 .. 0.5 -> 130 .. 16384), M by a
+//     per-pair factor s = 2^(15 - e) from the pair's largest |M| (reduced by the producers, one extra barrier per pair) so
+//     that |M s| < 2^15; residuals land in f16's subnormals at worst, which v_mfma_f32_32x32x16_f16 honours
+//     (tools/probes/mfma_f16_denorm.hip).  The blurred sums carry the factor k = 2^15 s into the solve, which is
+//     homogeneous but for the regulariser: flow = num k^2 / (det k^2 + 1e-3 k^2).
+//   * the image is handed over TRANSPOSED (X^T[x][y'], a producer lane's 8 rows are 16 contiguous bytes per plane: two
+//     ds_write_b128 per channel instead of twelve ds_write_b64), so the products are V^T = X^T Gv^T, Out^T = Gh V^T -- the
+//     first product's accumulators are again the second one's B operand -- and a multiplying lane ends with one ROW y and 16
+//     columns: four 32-byte runs of flow per lane.
+//   * the 2 x 2 solve in f32 with error-free products (Kahan's ad - bc with fma): 1.5 ulp per determinant, where the f64
+//     form cost 3 200 cycles per pair at half rate.
+// Hand-over protocol per unit (pair, or four pairs in MOSAIC): barriers B0..B4 publish channels 0..4 (double-buffered
+// image), B5 publishes the NEXT unit's largest |M|.  R1 of the next unit is requested right after B5 (every producer is
+// through with this unit's gathers by then), awaited before B1, and the next unit's 8 pixels per lane are evaluated two at
+// a time after B1..B4 -- under the multiplying waves' products.
+typedef _Float16 fb_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fb_f16x2 __attribute__((ext_vector_type(2)));
+typedef float fb_f2 __attribute__((ext_vector_type(2)));
+struct FbSplit2 { fb_f16x8 h, l; };
+constexpr float FB_G_SCALE = 32768.f, FB_G_UNSCALE = 1.f / 32768.f;
+
+// x[0..7] * scale (an exact power of two) -> h + l with h = rne_f16, l = rne_f16(x - h) (x - h is exact in f32)
+__device__ __forceinline__ FbSplit2 fb_split2(const float (&x)[8], float scale) {
+  u32x4 hw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const fb_f2 v = (fb_f2){x[2 * j], x[2 * j + 1]} * scale;
+    const fb_f16x2 h = __builtin_convertvector(v, fb_f16x2);
+    const fb_f2 r = v - __builtin_convertvector(h, fb_f2);
+    const fb_f16x2 l = __builtin_convertvector(r, fb_f16x2);
+    hw[j] = __builtin_bit_cast(uint32_t, h);
+    lw[j] = __builtin_bit_cast(uint32_t, l);
+  }
+  FbSplit2 o;
+  o.h = __builtin_bit_cast(fb_f16x8, hw);
+  o.l = __builtin_bit_cast(fb_f16x8, lw);
+  return o;
+}
+// acc += A B on two-term operands: the three partial products above 2^-22, smallest first
+__device__ __forceinline__ fb_v16f fb_mfma2(const FbSplit2& a, const FbSplit2& b, fb_v16f acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.l, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ void fb_lds_dma16_s(uint32_t lds_addr, uint32_t voff, uint32_t soff, fb_i32x4 rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
+}
+// ad - bc with one rounding error of the result (Kahan): w = bc rounded, e = w - bc exactly, f = ad - w rounded once
+__device__ __forceinline__ float fb_det2(float a, float d, float b, float c) {
+  const float w = __fmul_rn(b, c);
+  const float e = __builtin_fmaf(-b, c, w);
+  const float f = __builtin_fmaf(a, d, -w);
+  return __fadd_rn(f, e);
+}
+// FarnebackUpdateMatrices of one pixel from its four R1 neighbours (planar gather) -- the expressions and the rounding
+// order of fb_update_pixel, channel pairs on the packed f32 instructions
+struct FbTaps4 { float t00[5], t01[5], t10[5], t11[5]; float fx, fy; bool inside; };
+__device__ __forceinline__ void fb_update_pixel_planar(const float (&R0)[5], const FbTaps4& g, float dx, float dy, float scale,
+                                                        float (&m)[5]) {
+  const float fx = g.fx, fy = g.fy;
+  const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+  const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+  fb_f2 b01, b23;
+  {
+    const fb_f2 p00 = {g.t00[0], g.t00[1]}, p01 = {g.t01[0], g.t01[1]}, p10 = {g.t10[0], g.t10[1]}, p11 = {g.t11[0], g.t11[1]};
+    b01 = ((p00 * a00 + p01 * a01) + p10 * a10) + p11 * a11;
+    const fb_f2 q00 = {g.t00[2], g.t00[3]}, q01 = {g.t01[2], g.t01[3]}, q10 = {g.t10[2], g.t10[3]}, q11 = {g.t11[2], g.t11[3]};
+    b23 = ((q00 * a00 + q01 * a01) + q10 * a10) + q11 * a11;
+  }
+  float r6 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, g.t00[4]), __fmul_rn(a01, g.t01[4])), __fmul_rn(a10, g.t10[4])),
+                       __fmul_rn(a11, g.t11[4]));
+  fb_f2 r45 = ((fb_f2){R0[2], R0[3]} + b23) * 0.5f;
+  r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
+  fb_f2 r23 = g.inside ? b01 : (fb_f2){0.f, 0.f};
+  r45 = g.inside ? r45 : (fb_f2){R0[2], R0[3]};
+  r6 = g.inside ? r6 : __fmul_rn(R0[4], 0.5f);
+  r23 = ((fb_f2){R0[0], R0[1]} - r23) * 0.5f;
+  // r2 += r4 dy + r6 dx;  r3 += r6 dy + r5 dx
+  r23 = r23 + ((fb_f2){r45[0], r6} * dy + (fb_f2){r6, r45[1]} * dx);
+  r23 = r23 * scale;
+  r45 = r45 * scale;
+  r6 = __fmul_rn(r6, scale);
+  const fb_f2 sq = r45 * r45;
+  const float r66 = __fmul_rn(r6, r6);
+  m[0] = __fadd_rn(sq[0], r66);
+  m[2] = __fadd_rn(sq[1], r66);
+  m[1] = __fmul_rn(__fadd_rn(r45[0], r45[1]), r6);
+  const fb_f2 h = (fb_f2){r45[0], r6} * r23[0] + (fb_f2){r6, r45[1]} * r23[1];      // (r4 r2 + r6 r3, r6 r2 + r5 r3)
+  m[3] = h[0];
+  m[4] = h[1];
+}
+
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long fb_iter_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
+template <int FLOW_SRC, bool MOSAIC>
+__global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ R, const float* flow_in, float* flow_out,
+                                                      const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
+                                                      int width, long long n_pairs, long long pairs_per_group, int chain_f,
+                                                      FbUpsample up) {
+  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
+  constexpr int WAIT_C = 1;      // the next unit's R1 is awaited before barrier B<WAIT_C>
+  __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];           // 80 KB: five planes, row stride 64
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][2][PLANE];       // X^T, (h, l) f16 planes, double buffered
+  __shared__ u32x4 GhS[2 * KS * 2][64];                                    // A operand of the second product, lane-major
+  __shared__ __attribute__((aligned(16))) float pmax[16];                 // largest |M| per (producing wave, lane half)
+  const int tid = threadIdx.x, lane = tid & 63, wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave12 >= 4;
+  const int col = lane & 31, half = lane >> 5;
+  const int lpx = height * width;
+  constexpr int NP = MOSAIC ? 4 : 1;
+  constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside every descriptor below: reads zeros
+  const long long n_units = (n_pairs + NP - 1) / NP;
+  const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
+
+  // Gh as the A operand of the second product: k-slot i of lane-half h in step (blk, s) = accumulator row
+  // fb_acc_row(8 s + i, h) of row block blk of the first product
+  for (int j = wave12; j < 2 * KS; j += 12) {
+    const int mb = j / KS, ks = j - mb * KS;
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    const FbSplit2 g = fb_split2(t, FB_G_SCALE);
+    GhS[j * 2 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
+    GhS[j * 2 + 1][lane] = __builtin_bit_cast(u32x4, g.l);
+  }
+  // exponent e of a unit's (MOSAIC: of tile (ty, tx)'s) largest |M| = f 2^e, 0.5 <= f < 1, clamped so that every power of
+  // two formed from it is a normal f32; M 2^(15 - e) then lies below 2^15
+  auto unit_exp = [&](int ty, int tx) -> int {
+    const f32x4* pm4 = reinterpret_cast<const f32x4*>(pmax);
+    float mx;
+    if constexpr (MOSAIC) {
+      const f32x4 a = pm4[2 * ty], b = pm4[2 * ty + 1];
+      mx = tx ? fmaxf(fmaxf(a[1], a[3]), fmaxf(b[1], b[3])) : fmaxf(fmaxf(a[0], a[2]), fmaxf(b[0], b[2]));
+    } else {
+      const f32x4 a = pm4[0], b = pm4[1], c = pm4[2], d = pm4[3];
+      const f32x4 m4 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    }
+    const int e = __builtin_amdgcn_frexp_expf(mx);
+    return e < -25 ? -25 : (e > 100 ? 100 : e);
+  };
+
+  if (producer) {
+    // ================================ producing waves ===================================================================
+    const int pw = wave12 - 4;                                  // 0..7: rows 8 pw .. 8 pw + 7 of the 64 x 64 image
+    const int m_ty = pw >> 2, m_tx = lane >> 5;                 // MOSAIC: this wave's tile row, this lane's tile column
+    const int xl = MOSAIC ? (lane & 31) : lane;                 // column inside the pair's image
+    const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
+    const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane
+    const bool col_ok = xl < width;
+    const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
+    // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
+    auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
+    const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
+    // LDS-direct staging: chunk k (of 80) = plane k >> 4, rows 4 (k & 15) .. + 3 of the LDS image = 1 KB = one wave
+    // instruction; lane j brings 16 bytes: row (j >> 4) of the chunk, columns 4 (j & 15) ..
+    const int dj_row = lane >> 4, dj_x = MOSAIC ? ((lane & 15) & 7) * 4 : (lane & 15) * 4, dj_tx = (lane & 15) >> 3;
+    const uint32_t dma_lane = (uint32_t)(dj_row * width + dj_x) * 4;
+
+    float mA[5][8], mB[5][8];      // [channel][pixel]: a channel's 8 values are what a hand-over writes
+    float r0[8][5];
+    fb_f2 fl[8];
+    float pm;      // running largest |M| of the unit being evaluated
+    // per-unit addressing of the unit being PREPARED (descriptors in scalar registers, lane offsets in vector registers)
+    __amdgpu_buffer_rsrc_t r0rs, flrs;
+    uint32_t r0_voff, fl_voff;
+    bool pair_ok, lane_ok;      // lane_ok: the lane's column exists in an existing pair
+    long long pair_of_lane;
+    auto setup_unit = [&](long long unit, const long long (&i0)[NP]) {
+      if constexpr (MOSAIC) {
+        const long long pl = unit * 4 + 2 * m_ty + m_tx;
+        pair_ok = pl < n_pairs;
+        lane_ok = pair_ok && col_ok;
+        pair_of_lane = pair_ok ? pl : 0;
+        const long long img_l = m_ty ? i0[2] : i0[0], img_r = m_ty ? i0[3] : i0[1];
+        const long long img = m_tx ? img_r : img_l;
+        r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+        flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000);
+        r0_voff = pair_ok && col_ok ? (uint32_t)(img * lpx * 20) + (uint32_t)xl * 4 : NOT_THERE;
+        fl_voff = pair_ok && col_ok ? (uint32_t)(pl * lpx * 8) + (uint32_t)xl * 8 : NOT_THERE;
+      } else {
+        pair_ok = true;
+        lane_ok = col_ok;
+        pair_of_lane = unit;
+        r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0[0] * lpx * 5), 0, lpx * 20, 0x00020000);
+        flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? unit * lpx * 2 : 0)), 0, lpx * 8, 0x00020000);
+        r0_voff = col_ok ? (uint32_t)xl * 4 : NOT_THERE;
+        fl_voff = col_ok ? (uint32_t)xl * 8 : NOT_THERE;
+      }
+    };
+    // R0 and the starting flow of pixel i (row yl0 + i) of the unit being prepared
+    auto prefetch = [&](int i) {
+      const int y = yl0 + i;
+      const bool row_ok = y < height;      // uniform
+      const uint32_t rv = row_ok ? r0_voff : NOT_THERE, fv = row_ok ? fl_voff : NOT_THERE;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+        r0[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0rs, rv, (uint32_t)(c * lpx + y * width) * 4, 0));
+      if constexpr (FLOW_SRC == 0) {
+        fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(flrs, fv, (uint32_t)(y * width) * 8, 0));
+      } else if constexpr (FLOW_SRC == 1) {
+        // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which would
+        // keep them for all 8 rows in registers around the unit loop)
+        int xo = xl, yo = y;
+        asm volatile("" : "+v"(xo), "+s"(yo));
+        const fb_f32x2_t f = fb_upsampled_flow_nb(flow_in, (size_t)pair_of_lane, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
+                                               up.inv_fx, up.inv_fy, up.mul);
+        fl[i] = (fb_f2){f[0], f[1]};
+      } else {
+        float z = 0.f;      // (opaque: with a known zero flow every gather address and weight becomes a per-lane invariant)
+        asm volatile("" : "+v"(z));
+        fl[i] = (fb_f2){z, z};
+      }
+    };
+    // FarnebackUpdateMatrices of pixels ia and ib (both rows' gathers are issued before the first pixel's arithmetic)
+    auto gather = [&](int i, FbTaps4& g) {
+      const int y = yl0 + i;
+      const float fx = __fadd_rn((float)xl, fl[i][0]), fy = __fadd_rn((float)y, fl[i][1]);
+      const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+      g.fx = __fsub_rn(fx, (float)x1);
+      g.fy = __fsub_rn(fy, (float)y1);
+      g.inside = (int)lane_ok & (int)(y < height) & (int)((unsigned)x1 < (unsigned)(width - 1)) & (int)((unsigned)y1 < (unsigned)(height - 1));
+      const float* ptr = R1s + (g.inside ? lds_org + y1 * 64 + x1 : 0);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        g.t00[c] = ptr[c * 4096], g.t01[c] = ptr[c * 4096 + 1];
+        g.t10[c] = ptr[c * 4096 + 64], g.t11[c] = ptr[c * 4096 + 65];
+      }
+    };
+    auto finish = [&](int i, const FbTaps4& g, float (&mo)[5][8]) {
+      const int y = yl0 + i;
+      const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
+      float m[5];
+      fb_update_pixel_planar(r0[i], g, fl[i][0], fl[i][1], scale, m);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) mo[c][i] = m[c];
+      pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
+    };
+    // pixels ia, ia + 1: the second pixel's reads are issued before the first one's arithmetic (one gather ahead, not more:
+    // registers); R0 / flow of the pair after next are requested behind them by the caller
+    auto update2 = [&](int ia, float (&mo)[5][8]) {
+      FbTaps4 ga, gb;
+      gather(ia, ga);
+      __builtin_amdgcn_sched_barrier(0);
+      gather(ia + 1, gb);
+      finish(ia, ga, mo);
+      __builtin_amdgcn_sched_barrier(0);
+      finish(ia + 1, gb, mo);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // the unit's largest |M| per lane half -> pmax (MOSAIC: a half is a tile column)
+    auto publish_max = [&]() {
+      float v = pm;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+      if ((lane & 31) == 0) pmax[2 * pw + half] = v;
+    };
+    auto request_r1 = [&](const long long (&i1)[NP], long long unit) {
+#pragma unroll
+      for (int n = 0; n < 10; ++n) {
+        const int k = pw + 8 * n, c = k >> 4, rg = k & 15;
+        if constexpr (MOSAIC) {
+          const int ty = rg >> 3, yb = 4 * (rg & 7);
+          if (yb >= height) continue;
+          const long long pl = unit * 4 + 2 * ty + dj_tx;
+          const long long img_l = ty ? i1[2] : i1[0], img_r = ty ? i1[3] : i1[1];      // (selects: no indexed private array)
+          const long long img = dj_tx ? img_r : img_l;
+          const uint32_t voff = pl < n_pairs && dj_x < width ? (uint32_t)(img * lpx * 20) + dma_lane : NOT_THERE;
+          const uintptr_t a = (uintptr_t)R;
+          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)((c * height + yb) * width) * 4,
+                         (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000});
+        } else {
+          if (4 * rg >= height) continue;
+          const uint32_t voff = dj_x < width ? dma_lane : NOT_THERE;
+          const uintptr_t a = (uintptr_t)(R + i1[0] * lpx * 5);
+          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)((c * height + 4 * rg) * width) * 4,
+                         (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), lpx * 20, 0x00020000});
+        }
+      }
+    };
+    auto write_channel = [&](const float (&m)[5][8], int c, float s, int buf) {
+      const FbSplit2 sp = fb_split2(m[c], s);
+      uint16_t* Xc = &Xs[buf][0][0] + lane * XS + 8 * pw;      // row x of X^T, rows y' = 8 pw .. + 7: 16 contiguous bytes
+      *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
+      *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
+    };
+    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
+    // range without a 64-bit division per pair
+    long long i0_run, i1_unused;
+    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
+    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
+    auto take_unit = [&](long long (&i0)[NP], long long (&i1)[NP]) {
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        i0[t] = i0_run, i1[t] = i0_run + 1;
+        if (chain_f > 0) {
+          i0_run += 1;
+          if (++q_run == pairs_per_group) q_run = 0, i0_run += chain_f - pairs_per_group;      // the next stack's first frame
+        } else {
+          i0_run += 2;
+        }
+      }
+    };
+#ifdef PV_DIAG_STAMPS
+    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
+#endif
+    {
+      long long i0a[NP], i1a[NP];
+      take_unit(i0a, i1a);
+      setup_unit(p_lo, i0a);
+      request_r1(i1a, p_lo);
+      prefetch(0), prefetch(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();      // P1: R1 of the first unit (and GhS) in place
+      pm = 0.f;
+      prefetch(2), prefetch(3), update2(0, mA);
+      prefetch(4), prefetch(5), update2(2, mA);
+      prefetch(6), prefetch(7), update2(4, mA);
+      update2(6, mA);
+      publish_max();
+      __syncthreads();      // P2 = B5 of "unit p_lo - 1"
+    }
+    int k = 0;
+    auto unit_body = [&](float (&mc)[5][8], float (&mn)[5][8], long long p, auto more_tag) {
+      constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
+      PV_STAMP(s0);
+      const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
+      if constexpr (more) {
+        long long i0n[NP], i1n[NP];
+        take_unit(i0n, i1n);
+        setup_unit(p + 1, i0n);
+        request_r1(i1n, p + 1);      // before any other vector-memory request: the compiler's own counts stay sufficient
+        prefetch(0), prefetch(1);    // R0 / flow of a pixel pair are requested one hand-over before its evaluation
+        pm = 0.f;
+      }
+      PV_STAMP(s1);
+#ifdef PV_DIAG_STAMPS
+      dg[3] += s1 - s0;
+#endif
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        PV_STAMP(s0);
+        write_channel(mc, c, s, k & 1);
+        ++k;
+        if (more && c == WAIT_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
+        PV_STAMP(s1);
+        __syncthreads();      // B<c>
+        PV_STAMP(s2);
+        if constexpr (more) {
+          if (c == 1) prefetch(2), prefetch(3), update2(0, mn);
+          if (c == 2) prefetch(4), prefetch(5), update2(2, mn);
+          if (c == 3) prefetch(6), prefetch(7), update2(4, mn);
+          if (c == 4) update2(6, mn), publish_max();
+        }
+        PV_STAMP(s3);
+#ifdef PV_DIAG_STAMPS
+        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[2] += s3 - s2;
+#endif
+      }
+      PV_STAMP(s0);
+      __syncthreads();      // B5: the next unit's largest |M| is published
+      PV_STAMP(s1);
+#ifdef PV_DIAG_STAMPS
+      dg[1] += s1 - s0, dg[7] += 1;
+#endif
+    };
+    for (long long p = p_lo; p + 1 < p_hi; ++p) {
+      unit_body(mA, mB, p, std::true_type{});
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) mA[c][n] = mB[c][n];
+    }
+    unit_body(mA, mB, p_hi - 1, std::false_type{});
+#ifdef PV_DIAG_STAMPS
+    if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
+      for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 12 + wave12) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+    return;
+  }
+
+  // ================================ multiplying waves =====================================================================
+  // wave (strip, mbo): output rows y of block `strip` (one per lane), columns x of block `mbo`; MOSAIC: that is tile
+  // (ty, tx) = (strip, mbo) = pair 4 u + 2 strip + mbo
+  const int strip = wave12 & 1, mbo = wave12 >> 1;
+  FbSplit2 gv[KS];      // Gv^T as the B operand of the first product: n = y (this lane's row), k = y' in natural order
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    gv[ks] = fb_split2(t, FB_G_SCALE);
+  }
+  __syncthreads();      // P1
+  __syncthreads();      // P2
+  int k = 0;
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2;
+#endif
+  for (long long p = p_lo; p < p_hi; ++p) {
+    const int e = unit_exp(strip, mbo);
+    fb_v16f res[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      PV_STAMP(s0);
+      __syncthreads();      // B<c>: channel k is in its buffer
+      PV_STAMP(s1);
+      const uint16_t* Xc = &Xs[k & 1][0][0];
+      ++k;
+      fb_v16f u[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          FbSplit2 a;
+          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+          a.h = *reinterpret_cast<const fb_f16x8*>(xa);
+          a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
+          u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+        const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
+        FbSplit2 g;
+        g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
+        g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
+        res[c] = fb_mfma2(g, b, res[c]);
+      }
+      PV_STAMP(s2);
+#ifdef PV_DIAG_STAMPS
+      dg[0] += s1 - s0, dg[1] += s2 - s1;
+#endif
+    }
+    PV_STAMP(s0);
+    // ---- 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x ---------
+    {
+      const float lam = ldexpf(1e-3f, 2 * (30 - e));
+      const int y = (MOSAIC ? 0 : 32 * strip) + col;
+      const long long pr = MOSAIC ? p * 4 + 2 * strip + mbo : p;
+      float* frow = flow_out + (pr * lpx + (long long)y * width) * 2;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+          const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
+          o[2 * j] = fb_det2(g11, h2, g12, h1) / det;
+          o[2 * j + 1] = fb_det2(g22, h1, g12, h2) / det;
+        }
+        if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
+          *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(frow + x0 * 2 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
+    PV_STAMP(s1);
+    __syncthreads();      // B5
+    PV_STAMP(s2);
+#ifdef PV_DIAG_STAMPS
+    dg[2] += s1 - s0, dg[0] += s2 - s1, dg[7] += 1;
+#endif
+  }
+#ifdef PV_DIAG_STAMPS
+  if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
+    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 12 + wave12) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+}
+
 // ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
 __global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
                                                          long long n_pairs, int height, int width, FbTaps kt) {
@@ -1625,12 +2149,26 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     if (lw == w && lh == h) mode = 0;
     else if (fabs(inv_fx - 2.0) < 2.220446049250313e-16 && fabs(inv_fy - 2.0) < 2.220446049250313e-16) mode = 1;
     else mode = 2;
+    const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
+    // Levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the window blur and the
+    // solve; M is never written.  33..64-pixel levels: one pair per 64 x 64 tile; levels up to 32 x 32: four pairs per tile
+    // (MOSAIC; its buffer offsets are 31-bit).  Rows of whole 4-pixel quads: R and the flow move as 16-byte vectors.
+    const bool small_level = lh <= 32 && lw <= 32;
+    const bool fused_iter = tile_path && fuse_init && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
+                            (!small_level || ((long long)n_img * lpx * 20 < 0x7fffffffLL && n_pairs * lpx * 8 < 0x7fffffffLL &&
+                                              (long long)prev_h * prev_w * n_pairs * 8 < 0x7fffffffLL &&
+                                              !getenv("PV_FARNEBACK_TWO_LAUNCH_SMALL_LEVELS")));
+    // fb_iter_kernel (planar R, f16 x 2 operands) unless the round-3 kernel is asked for (A/B on one device) or its
+    // preconditions fail: the fused prep + PolyExp kernel must have written R planar (source images up to 64 x 64), flow rows
+    // are stored as 16-byte vectors
+    const bool polyexp_tile = h <= 64 && w <= 64 && smooth_sz <= 63;
+    const bool iter_v2 = fused_iter && polyexp_tile && ((uintptr_t)flow & 15) == 0 && !getenv("PV_FARNEBACK_FUSED_V1");
     stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
-    if (h <= 64 && w <= 64 && smooth_sz <= 63) {
+    if (polyexp_tile) {
       const unsigned grid = (unsigned)std::min<long long>(n_img, 4096);
       hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
                          (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
-                         n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk);
+                         n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, iter_v2 ? 1 : 0);
     } else {
     hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st, prev, next,
                        (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,
@@ -1641,16 +2179,6 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     hipLaunchKernelGGL(fb_polyexp_h_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st,
                        (const float*)T, R, n_img, lh, lw, pk);
     }
-    const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
-    // Levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the window blur and the
-    // solve (fb_fused_iter_q_kernel); M is never written.  33..64-pixel levels: one pair per 64 x 64 tile; levels up to
-    // 32 x 32: four pairs per tile (MOSAIC; its buffer offsets are 31-bit).  Rows of whole 4-pixel quads: the producers read
-    // R0 / flow as 16-byte vectors.
-    const bool small_level = lh <= 32 && lw <= 32;
-    const bool fused_iter = tile_path && fuse_init && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
-                            (!small_level || ((long long)n_img * lpx * 20 < 0x7fffffffLL && n_pairs * lpx * 8 < 0x7fffffffLL &&
-                                              (long long)prev_h * prev_w * n_pairs * 8 < 0x7fffffffLL &&
-                                              !getenv("PV_FARNEBACK_TWO_LAUNCH_SMALL_LEVELS")));
     if (fused_iter) {
       float* Gv = (float*)(ws + L.off_G);
       float* Gh = lh == lw ? Gv : Gv + 64 * 64;
@@ -1663,7 +2191,13 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
       const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);      // one workgroup per CU (LDS)
 #define PV_FUSED_ITER(SRC, FLOW_IN)                                                                                       \
   do {                                                                                                                    \
-    if (small_level)                                                                                                      \
+    if (iter_v2 && small_level)                                                                                           \
+      hipLaunchKernelGGL((fb_iter_kernel<SRC, true>), dim3(grid), dim3(768), 0, st, (const float*)R, (const float*)(FLOW_IN), \
+                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
+    else if (iter_v2)                                                                                                     \
+      hipLaunchKernelGGL((fb_iter_kernel<SRC, false>), dim3(grid), dim3(768), 0, st, (const float*)R, (const float*)(FLOW_IN), \
+                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
+    else if (small_level)                                                                                                 \
       hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, true>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
                          flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
     else                                                                                                                  \
@@ -1757,5 +2291,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
 #ifdef PV_DIAG_STAMPS
 extern "C" int pv_diag_read_fb_fused(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_fused_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+extern "C" int pv_diag_read_fb_iter(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_iter_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

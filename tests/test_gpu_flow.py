@@ -231,13 +231,17 @@ def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkey
 
 @pytest.mark.parametrize("h,w,t,batch", [(64, 64, 12, 3), (64, 64, 4, 100), (64, 64, 12, 100), (40, 56, 3, 3), (48, 64, 4, 3),
                                          (64, 36, 2, 3), (50, 62, 3, 3)])
-def test_fused_iteration_equals_the_two_launch_form_bit_for_bit(device, monkeypatch, h, w, t, batch):
-    """Levels up to 64 x 64 run UpdateMatrices + window blur + solve as ONE launch per iteration (fb_fused_iter_q_kernel:
-    producer waves + matrix-core waves, M never written; levels up to 32 x 32 as four pairs per 64 x 64 tile with
-    block-diagonal window matrices).  Same arithmetic per output element as the two-launch form
-    (PV_FARNEBACK_TWO_LAUNCH_ITERATION=1): identical bits, for frame stacks (chained R images, ranges of pairs that cross
-    stack boundaries, a last unit of fewer than four pairs), for separate pairs, for partial tiles, and for a width that is
-    no multiple of 4 (which the fused form does not take: both calls then run the same kernels)."""
+def test_fused_iteration_against_the_two_launch_form(device, monkeypatch, h, w, t, batch):
+    """Levels up to 64 x 64 run UpdateMatrices + window blur + solve as ONE launch per iteration (fb_iter_kernel: eight
+    producing + four matrix-core waves, M never written; levels up to 32 x 32 as four pairs per 64 x 64 tile with
+    block-diagonal window matrices).  UpdateMatrices is the same arithmetic as in the two-launch form
+    (PV_FARNEBACK_TWO_LAUNCH_ITERATION=1); the blur runs on two-term f16 operands (2^-22) and the solve in compensated f32
+    instead of three-term bf16 and f64, so the flows agree to a few 1e-6 px, not bit for bit (bound: 2e-5 px, 50 x under
+    the 1e-3 px contract).  What MUST be identical bits: the same pairs handed over as frame stacks (chained R images,
+    ranges of pairs that cross stack boundaries, a last unit of fewer than four pairs) and as separate prev / next tensors
+    -- a pair's flow may not depend on which other pairs share its launch, its workgroup or its 64 x 64 mosaic (the f16
+    operand scale is per pair).  A width that is no multiple of 4 is not taken by the fused form: both calls then run the
+    same kernels and must agree exactly."""
     K = _ops()
     # batch = 100: 200 stacks x 3 pairs = 600 pairs over 256 workgroups -- ranges of 2..3 pairs that cross stack boundaries;
     # with t = 12 (2 200 pairs) the coarse level's units of four pairs come in ranges of two or more as well
@@ -252,8 +256,17 @@ def test_fused_iteration_equals_the_two_launch_form_bit_for_bit(device, monkeypa
     two_stack, two_pairs = K.farneback_stack(u8), K.farneback_pairs(prev, nxt)
     two_it1 = K.farneback_stack(u8, iterations=1)
     monkeypatch.delenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION")
-    assert torch.equal(fused_stack, two_stack) and torch.equal(fused_pairs, two_pairs) and torch.equal(fused_it1, two_it1)
     assert torch.isfinite(fused_stack).all()
+    assert torch.equal(fused_stack.reshape(-1, h, w, 2), fused_pairs) and torch.equal(two_stack.reshape(-1, h, w, 2), two_pairs)
+    if w % 4:
+        assert torch.equal(fused_stack, two_stack) and torch.equal(fused_it1, two_it1)
+    else:
+        assert not torch.equal(fused_stack, two_stack), "the two forms are different kernels: identical bits mean the switch is dead"
+        for a, b in ((fused_stack, two_stack), (fused_it1, two_it1)):
+            assert float((a - b).abs().max()) <= 2e-5, float((a - b).abs().max())
+    # one pair evaluated alone (a launch of its own) has the bits it has inside the batch
+    alone = K.farneback_pairs(prev[5:6].contiguous(), nxt[5:6].contiguous())
+    assert torch.equal(alone[0], fused_pairs[5])
     ref = fo.calc_optical_flow_farneback(u8[2, 0].cpu().numpy(), u8[2, 1].cpu().numpy())
     assert np.abs(fused_stack[2, 0].cpu().numpy() - ref).max() <= 1e-3
 

@@ -59,23 +59,25 @@ def run():
         return fn, "first"
     if which == "flow":
         from predict_pv_yield_amd import optical_flow as of
-        raw = torch.randint(0, 1021, (b, 12, 11, 64, 64), dtype=torch.int16, device=dev)
+        from predict_pv_yield_amd.data.synthetic import advected_counts
+        raw = torch.from_numpy(advected_counts(batch=b, seed=1234)[0]).to(dev)      # the SURVEY section-8(d) input
         return (lambda: of.advect_future_frames(raw, 6)), "flow"
     raise SystemExit(__doc__)
 
 
 def flow_report(d):
-    """fb_fused_iter_q_kernel: waves 0..3 of a workgroup multiply, waves 4..7 produce; the last launch's stamps"""
-    d = d[: (d[:, 7] > 0).nonzero()[0].max() + 1].reshape(-1, 8, SLOTS)
-    for name, sl, labels in (("multiplying waves", slice(0, 4), ["barrier (waiting for a channel)", "channel: 24 + 12 products", "solve + flow store"]),
-                             ("producing waves", slice(4, 8), ["split + write a channel", "vmcnt(0) (next R1)", "barrier", "request R1",
-                                                               "UpdateMatrices of the next pair"])):
+    """fb_iter_kernel: waves 0..3 of a workgroup multiply, waves 4..11 produce; the last launch's stamps"""
+    d = d[: (d[:, 7] > 0).nonzero()[0].max() + 1]
+    d = d[: len(d) // 12 * 12].reshape(-1, 12, SLOTS)
+    for name, sl, labels in (("multiplying waves", slice(0, 4), ["barrier (waiting for a channel / the next unit)", "channel: 24 + 12 products", "solve + flow store"]),
+                             ("producing waves", slice(4, 12), ["split + write a channel (+ wait for R1)", "barrier", "after the barrier: requests + UpdateMatrices of the next unit",
+                                                                "unit start: scale, R1 requests, first R0 / flow requests"])):
         w = d[:, sl].reshape(-1, SLOTS)
         w = w[w[:, 7] > 0]
         tot = w[:, : len(labels)].sum(1).mean()
-        print(f"  {name}: {len(w)} waves, {w[:, 7].mean():.1f} pairs per wave, {tot / w[:, 7].mean():.0f} cycles / pair")
+        print(f"  {name}: {len(w)} waves, {w[:, 7].mean():.1f} units per wave, {tot / w[:, 7].mean():.0f} cycles / unit")
         for i, lab in enumerate(labels):
-            print(f"    {lab:36s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / pair  {100 * w[:, i].mean() / tot:5.1f} %")
+            print(f"    {lab:60s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / unit  {100 * w[:, i].mean() / tot:5.1f} %")
 
 
 fn, kind = run()
@@ -87,7 +89,7 @@ e0.record()
 fn()
 e1.record()
 torch.cuda.synchronize()
-sym, labels = LABELS.get(kind, ("pv_diag_read_fb_fused", None))
+sym, labels = LABELS.get(kind, ("pv_diag_read_fb_iter", None))
 buf = np.zeros(WAVES * SLOTS, dtype=np.uint64)
 lib = get_lib()
 f = getattr(lib, sym)

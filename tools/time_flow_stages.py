@@ -7,7 +7,13 @@ from predict_pv_yield_amd import optical_flow as of
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda:0")
-raw = torch.randint(0, 1021, (b, 12, 11, 64, 64), dtype=torch.int16, device=dev)
+# the SURVEY section-8(d) input (the tensor bench.py's config-3 leg, the CPU leg and the joined-model parity test use);
+# "noise" as a second argument gives the uniform-noise stacks of rounds 1-3
+if len(sys.argv) > 2 and sys.argv[2] == "noise":
+    raw = torch.randint(0, 1021, (b, 12, 11, 64, 64), dtype=torch.int16, device=dev)
+else:
+    from predict_pv_yield_amd.data.synthetic import advected_counts
+    raw = torch.from_numpy(advected_counts(batch=b, seed=1234)[0]).to(dev)
 for _ in range(3):
     of.advect_future_frames(raw, 6)
 iters = 10
