@@ -207,13 +207,15 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 // 64 KB of LDS (the first PolyExp plane reuses the buffer of the blurred image, dead by then) and <= 64 registers: TWO
 // 16-wave workgroups share a CU, so one's barrier-separated phases overlap the other's.
 constexpr int FB_PP_NT = 1024;
+typedef float fb_pp_f2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
                                                                     const uint8_t* __restrict__ next, long long prev_stride,
                                                                     long long next_stride, long long pairs_per_group,
                                                                     long long group_stride, float* __restrict__ R,
                                                                     long long n_img, int chain_f, int h, int w, int lh, int lw, int mode,
                                                                     double inv_fx, double inv_fy, FbTaps kt, FbPoly pk, int planar) {
-  // planar != 0: R[img][5][lh][lw] (what fb_iter_kernel stages and gathers), else R[img][lh][lw][5]
+  // planar != 0: pair-planar R (per image (c0, c1) float2 [lh][lw] | (c2, c3) float2 [lh][lw] | c4 float [lh][lw]: what
+  // fb_iter_kernel stages and gathers; lh * lw a multiple of 2), else R[img][lh][lw][5]
   __shared__ float bufA[64 * 64];        // source as float, later the blurred image, later PolyExp plane t0
   __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
   __shared__ float Tt12[2 * 64 * 64];    // vertical PolyExp planes t1, t2
@@ -325,13 +327,19 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
         b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[xp], t1r[xm]), pk.xg[k]));
         b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[xp], t2r[xm]), g0));
       }
-      float* d = planar ? R + im * lpx * 5 + i : R + (im * lpx + i) * 5;
-      const int cs = planar ? lpx : 1;
-      d[cs] = (float)__dmul_rn(b2, pk.ig11);
-      d[0] = (float)__dmul_rn(b3, pk.ig11);
-      d[3 * cs] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
-      d[2 * cs] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
-      d[4 * cs] = (float)__dmul_rn(b6, pk.ig55);
+      const float d1 = (float)__dmul_rn(b2, pk.ig11), d0 = (float)__dmul_rn(b3, pk.ig11);
+      const float d3 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+      const float d2 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+      const float d4 = (float)__dmul_rn(b6, pk.ig55);
+      if (planar) {
+        float* d = R + im * lpx * 5;
+        reinterpret_cast<fb_pp_f2*>(d)[i] = (fb_pp_f2){d0, d1};
+        reinterpret_cast<fb_pp_f2*>(d + 2 * lpx)[i] = (fb_pp_f2){d2, d3};
+        d[4 * lpx + i] = d4;
+      } else {
+        float* d = R + (im * lpx + i) * 5;
+        d[0] = d0, d[1] = d1, d[2] = d2, d[3] = d3, d[4] = d4;
+      }
     }
     __syncthreads();   // LDS is reused by the next image
   }
@@ -1331,14 +1339,20 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
 // path, their R1 gathers hit the LDS four ways (20-byte records, a wave's four rows on the same banks), the multiplying
 // waves wait 40 %, and on the vector ALU the three-way bf16 split (5.5 instructions per element) and the f64 solve weigh as
 // much as UpdateMatrices itself.  This kernel keeps the producer / multiplier split and changes everything underneath:
-//   * R is PLANAR in memory ([image][5][h][w], written so by fb_prep_polyexp_tile_kernel) and in LDS (five 64 x 64 planes, a
-//     fixed row stride of 64 floats whatever the level's size; MOSAIC: the four 32 x 32 tiles side by side in the same
-//     planes).  A producer lane owns one COLUMN and walks 8 rows, so the 64 lanes of a gather read consecutive floats of a
-//     row (displaced by the flow): no bank conflicts for a smooth flow field, and every channel / neighbour is a constant
-//     offset from one address.
+//   * R is PAIR-PLANAR in memory (per image: (c0, c1) as float2 [h][w], (c2, c3) as float2 [h][w], c4 as float [h][w];
+//     written so by fb_prep_polyexp_tile_kernel) and in LDS (the same three planes with a fixed row stride of 64 pixels
+//     whatever the level's size; MOSAIC: the four 32 x 32 tiles side by side in the same planes).  A producer lane owns one
+//     COLUMN and walks 8 rows, so the 64 lanes of a gather read consecutive pixels of a row (displaced by the flow): no bank
+//     conflicts for a smooth flow field, every neighbour is a constant offset from one address, and a channel pair arrives
+//     as the register pair the packed f32 instructions take (12 LDS reads per pixel instead of 20, no register shuffling).
 //   * EIGHT producing waves (two per SIMD, 8 pixels per lane) beside the four multiplying ones: one hides the other's LDS
-//     round trips; the pixel arithmetic runs on channel pairs (v_pk_*_f32), same expressions and rounding order as
-//     fb_update_pixel, so M is bit-identical to the two-launch form.
+//     round trips; same expressions and rounding order as fb_update_pixel, so M is bit-identical to the two-launch form.
+//   * a unit's gathers are ONE short phase (G: 8 pixels x (12 reads + the bilinear blend), right after hand-over 0), and the
+//     rest of UpdateMatrices (F) follows from registers, two pixels after each later hand-over.  The R1 image is therefore
+//     free again after a fifth of the unit, and the NEXT unit's R1 is requested right then (after barrier B1) -- it has four
+//     hand-overs to arrive.  (First form: request after the last gather, i.e. at the unit's end, wait at its start -- the
+//     stamps showed 6 800 cycles per unit in the request instructions alone, every CU bursting 80 KB at once, and the
+//     producers idle meanwhile.)
 //   * the window blur runs on the F16 matrix cores with TWO-term operands: x = h + l, h = rne_f16(x), l = rne_f16(x - h)
 //     carries 22 significant bits, so three products (hh, hl, lh) reach 2^-22 where the bf16 split needs six -- half the
 //     matrix work and 2.5 instead of 5.5 vector instructions per element split.  f16 has a narrow range, so every operand
@@ -1351,12 +1365,11 @@ __global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __
 //     ds_write_b128 per channel instead of twelve ds_write_b64), so the products are V^T = X^T Gv^T, Out^T = Gh V^T -- the
 //     first product's accumulators are again the second one's B operand -- and a multiplying lane ends with one ROW y and 16
 //     columns: four 32-byte runs of flow per lane.
-//   * the 2 x 2 solve in f32 with error-free products (Kahan's ad - bc with fma): 1.5 ulp per determinant, where the f64
-//     form cost 3 200 cycles per pair at half rate.
-// Hand-over protocol per unit (pair, or four pairs in MOSAIC): barriers B0..B4 publish channels 0..4 (double-buffered
-// image), B5 publishes the NEXT unit's largest |M|.  R1 of the next unit is requested right after B5 (every producer is
-// through with this unit's gathers by then), awaited before B1, and the next unit's 8 pixels per lane are evaluated two at
-// a time after B1..B4 -- under the multiplying waves' products.
+//   * the 2 x 2 solve in f32 with error-free products (Kahan's ad - bc with fma) and one refined reciprocal per pixel, where
+//     the f64 form cost 3 200 cycles per pair at half rate.
+// Hand-over protocol per unit p (a pair, or four pairs in MOSAIC): barriers B0..B4 publish channels 0..4 (double-buffered
+// image), B5 publishes unit p + 1's largest |M|.  Under unit p's hand-overs the producers prepare unit p + 1: G after B0,
+// F after B1..B4; unit p + 2's R1 is requested after B1, its starting flow after B4; both are awaited at unit p + 1's start.
 typedef _Float16 fb_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fb_f16x2 __attribute__((ext_vector_type(2)));
 typedef float fb_f2 __attribute__((ext_vector_type(2)));
@@ -1398,29 +1411,21 @@ __device__ __forceinline__ float fb_det2(float a, float d, float b, float c) {
   const float f = __builtin_fmaf(a, d, -w);
   return __fadd_rn(f, e);
 }
-// FarnebackUpdateMatrices of one pixel from its four R1 neighbours (planar gather) -- the expressions and the rounding
-// order of fb_update_pixel, channel pairs on the packed f32 instructions
-struct FbTaps4 { float t00[5], t01[5], t10[5], t11[5]; float fx, fy; bool inside; };
-__device__ __forceinline__ void fb_update_pixel_planar(const float (&R0)[5], const FbTaps4& g, float dx, float dy, float scale,
-                                                        float (&m)[5]) {
-  const float fx = g.fx, fy = g.fy;
-  const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
-  const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
-  fb_f2 b01, b23;
-  {
-    const fb_f2 p00 = {g.t00[0], g.t00[1]}, p01 = {g.t01[0], g.t01[1]}, p10 = {g.t10[0], g.t10[1]}, p11 = {g.t11[0], g.t11[1]};
-    b01 = ((p00 * a00 + p01 * a01) + p10 * a10) + p11 * a11;
-    const fb_f2 q00 = {g.t00[2], g.t00[3]}, q01 = {g.t01[2], g.t01[3]}, q10 = {g.t10[2], g.t10[3]}, q11 = {g.t11[2], g.t11[3]};
-    b23 = ((q00 * a00 + q01 * a01) + q10 * a10) + q11 * a11;
-  }
-  float r6 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, g.t00[4]), __fmul_rn(a01, g.t01[4])), __fmul_rn(a10, g.t10[4])),
-                       __fmul_rn(a11, g.t11[4]));
-  fb_f2 r45 = ((fb_f2){R0[2], R0[3]} + b23) * 0.5f;
-  r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
-  fb_f2 r23 = g.inside ? b01 : (fb_f2){0.f, 0.f};
-  r45 = g.inside ? r45 : (fb_f2){R0[2], R0[3]};
-  r6 = g.inside ? r6 : __fmul_rn(R0[4], 0.5f);
-  r23 = ((fb_f2){R0[0], R0[1]} - r23) * 0.5f;
+// FarnebackUpdateMatrices of one pixel in two halves -- the expressions and the rounding order of fb_update_pixel, channel
+// pairs on the packed f32 instructions.  G: the bilinear blend of the four R1 neighbours (r2..r6 of the reference before R0
+// enters); F: everything after it.
+struct FbBlend { fb_f2 b01, b23; float b4; };      // b4 = NaN: the displaced point lies outside the image
+struct FbTapsP { fb_f2 u00, u01, u10, u11, v00, v01, v10, v11; float w00, w01, w10, w11, fx, fy; bool inside; };
+struct FbImgs { long long a, b, c, d; };      // first coefficient images of a unit's pairs (one pair: a)
+__device__ __forceinline__ void fb_update_pixel_finish2(const fb_f2 R01, const fb_f2 R23, const float R4, const FbBlend& g, float dx,
+                                                         float dy, float scale, float (&m)[5]) {
+  const bool inside = g.b4 == g.b4;
+  fb_f2 r45 = (R23 + g.b23) * 0.5f;
+  float r6 = __fmul_rn(__fadd_rn(R4, g.b4), 0.25f);
+  fb_f2 r23 = inside ? g.b01 : (fb_f2){0.f, 0.f};
+  r45 = inside ? r45 : R23;
+  r6 = inside ? r6 : __fmul_rn(R4, 0.5f);
+  r23 = (R01 - r23) * 0.5f;
   // r2 += r4 dy + r6 dx;  r3 += r6 dy + r5 dx
   r23 = r23 + ((fb_f2){r45[0], r6} * dy + (fb_f2){r6, r45[1]} * dx);
   r23 = r23 * scale;
@@ -1445,8 +1450,8 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
                                                       int width, long long n_pairs, long long pairs_per_group, int chain_f,
                                                       FbUpsample up) {
   constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
-  constexpr int WAIT_C = 1;      // the next unit's R1 is awaited before barrier B<WAIT_C>
-  __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];           // 80 KB: five planes, row stride 64
+  // R1 of the unit whose gathers come next: (c0, c1) float2 [64][64] | (c2, c3) float2 [64][64] | c4 float [64][64]
+  __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];
   __shared__ __attribute__((aligned(16))) uint16_t Xs[2][2][PLANE];       // X^T, (h, l) f16 planes, double buffered
   __shared__ u32x4 GhS[2 * KS * 2][64];                                    // A operand of the second product, lane-major
   __shared__ __attribute__((aligned(16))) float pmax[16];                 // largest |M| per (producing wave, lane half)
@@ -1493,134 +1498,203 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
     const int m_ty = pw >> 2, m_tx = lane >> 5;                 // MOSAIC: this wave's tile row, this lane's tile column
     const int xl = MOSAIC ? (lane & 31) : lane;                 // column inside the pair's image
     const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
-    const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane
+    const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane (pixels)
     const bool col_ok = xl < width;
     const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
     // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
     auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
     const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
-    // LDS-direct staging: chunk k (of 80) = plane k >> 4, rows 4 (k & 15) .. + 3 of the LDS image = 1 KB = one wave
-    // instruction; lane j brings 16 bytes: row (j >> 4) of the chunk, columns 4 (j & 15) ..
-    const int dj_row = lane >> 4, dj_x = MOSAIC ? ((lane & 15) & 7) * 4 : (lane & 15) * 4, dj_tx = (lane & 15) >> 3;
-    const uint32_t dma_lane = (uint32_t)(dj_row * width + dj_x) * 4;
+    // LDS-direct staging, 80 chunks of 1 KB (one wave instruction each): chunks 0..31 = plane (c0, c1), two rows of 64
+    // float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each.  Lane j brings 16 bytes: in the
+    // pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane row (j >> 4), pixels 4 (j & 15) .. + 3
+    const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
+    const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
+    const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
 
     float mA[5][8], mB[5][8];      // [channel][pixel]: a channel's 8 values are what a hand-over writes
-    float r0[8][5];
-    fb_f2 fl[8];
-    float pm;      // running largest |M| of the unit being evaluated
-    // per-unit addressing of the unit being PREPARED (descriptors in scalar registers, lane offsets in vector registers)
-    __amdgpu_buffer_rsrc_t r0rs, flrs;
-    uint32_t r0_voff, fl_voff;
-    bool pair_ok, lane_ok;      // lane_ok: the lane's column exists in an existing pair
-    long long pair_of_lane;
-    auto setup_unit = [&](long long unit, const long long (&i0)[NP]) {
-      if constexpr (MOSAIC) {
-        const long long pl = unit * 4 + 2 * m_ty + m_tx;
-        pair_ok = pl < n_pairs;
-        lane_ok = pair_ok && col_ok;
-        pair_of_lane = pair_ok ? pl : 0;
-        const long long img_l = m_ty ? i0[2] : i0[0], img_r = m_ty ? i0[3] : i0[1];
-        const long long img = m_tx ? img_r : img_l;
-        r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
-        flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000);
-        r0_voff = pair_ok && col_ok ? (uint32_t)(img * lpx * 20) + (uint32_t)xl * 4 : NOT_THERE;
-        fl_voff = pair_ok && col_ok ? (uint32_t)(pl * lpx * 8) + (uint32_t)xl * 8 : NOT_THERE;
-      } else {
-        pair_ok = true;
-        lane_ok = col_ok;
-        pair_of_lane = unit;
-        r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0[0] * lpx * 5), 0, lpx * 20, 0x00020000);
-        flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? unit * lpx * 2 : 0)), 0, lpx * 8, 0x00020000);
-        r0_voff = col_ok ? (uint32_t)xl * 4 : NOT_THERE;
-        fl_voff = col_ok ? (uint32_t)xl * 8 : NOT_THERE;
-      }
+    FbBlend bl[8];
+    fb_f2 fl[8];                   // starting flow of the unit whose gathers come next
+    fb_f2 r01[8], r23[8];
+    float r4[8];
+    float pm;                      // running largest |M| of the unit being evaluated
+    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
+    // range without a 64-bit division per pair
+    long long i0_run, i1_unused;
+    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
+    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
+    const long long img_step = chain_f > 0 ? 1 : 2, img_jump = chain_f > 0 ? chain_f - pairs_per_group : 0;
+    auto next_image = [&]() -> long long {      // (arithmetic, no branches: see request_r1)
+      const long long r = i0_run;
+      q_run += 1;
+      const long long wrap = (long long)((int)(chain_f > 0) & (int)(q_run == pairs_per_group));      // the next stack's first frame
+      i0_run += img_step + wrap * img_jump;
+      q_run -= wrap * q_run;
+      return r;
     };
-    // R0 and the starting flow of pixel i (row yl0 + i) of the unit being prepared
-    auto prefetch = [&](int i) {
-      const int y = yl0 + i;
-      const bool row_ok = y < height;      // uniform
-      const uint32_t rv = row_ok ? r0_voff : NOT_THERE, fv = row_ok ? fl_voff : NOT_THERE;
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-        r0[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0rs, rv, (uint32_t)(c * lpx + y * width) * 4, 0));
+    auto take_unit = [&](FbImgs& i0) {
+      i0.a = next_image();
+      if constexpr (MOSAIC) i0.b = next_image(), i0.c = next_image(), i0.d = next_image();
+    };
+    // this lane's pair of a unit and whether it exists (MOSAIC: the tail unit may hold fewer than four pairs; a unit beyond
+    // the workgroup's range -- asked for by the look-ahead of the last units -- does not exist either)
+    auto lane_pair = [&](long long unit, bool& ok) -> long long {
+      const long long pl = MOSAIC ? unit * 4 + 2 * m_ty + m_tx : unit;
+      ok = (int)(unit < p_hi) & (int)(pl < n_pairs);
+      return ok ? pl : 0;
+    };
+    // starting flow of the 8 pixels of `unit` -> fl
+    auto load_flow = [&](long long unit) {
+      bool pair_ok;
+      const long long pl = lane_pair(unit, pair_ok);
       if constexpr (FLOW_SRC == 0) {
-        fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(flrs, fv, (uint32_t)(y * width) * 8, 0));
+        const __amdgpu_buffer_rsrc_t rs =
+            MOSAIC ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000)
+                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + pl * lpx * 2), 0, lpx * 8, 0x00020000);
+        uint32_t there = (MOSAIC ? (uint32_t)(pl * lpx * 8) : 0u) + (uint32_t)xl * 8;
+        asm volatile("" : "+v"(there));
+        const uint32_t voff = (int)pair_ok & (int)col_ok ? there : NOT_THERE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int y = yl0 + i;
+          fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, y < height ? voff : NOT_THERE, (uint32_t)(y * width) * 8, 0));
+        }
       } else if constexpr (FLOW_SRC == 1) {
-        // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which would
-        // keep them for all 8 rows in registers around the unit loop)
-        int xo = xl, yo = y;
-        asm volatile("" : "+v"(xo), "+s"(yo));
-        const fb_f32x2_t f = fb_upsampled_flow_nb(flow_in, (size_t)pair_of_lane, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
-                                               up.inv_fx, up.inv_fy, up.mul);
-        fl[i] = (fb_f2){f[0], f[1]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which
+          // would keep them for all 8 rows in registers around the unit loop)
+          int xo = xl, yo = yl0 + i;
+          asm volatile("" : "+v"(xo), "+s"(yo));
+          const fb_f32x2_t f = fb_upsampled_flow_nb(flow_in, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
+                                                    up.inv_fx, up.inv_fy, up.mul);
+          fl[i] = (fb_f2){f[0], f[1]};
+        }
       } else {
-        float z = 0.f;      // (opaque: with a known zero flow every gather address and weight becomes a per-lane invariant)
-        asm volatile("" : "+v"(z));
-        fl[i] = (fb_f2){z, z};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float z = 0.f;      // (opaque: with a known zero flow every gather address and weight becomes a per-lane invariant)
+          asm volatile("" : "+v"(z));
+          fl[i] = (fb_f2){z, z};
+        }
       }
     };
-    // FarnebackUpdateMatrices of pixels ia and ib (both rows' gathers are issued before the first pixel's arithmetic)
-    auto gather = [&](int i, FbTaps4& g) {
+    // G: the four R1 neighbours of pixel i (R1 is in LDS, the flow in fl): reads, then the bilinear blend -> bl[i]
+    auto gather = [&](int i, bool lane_ok, FbTapsP& t) {
       const int y = yl0 + i;
-      const float fx = __fadd_rn((float)xl, fl[i][0]), fy = __fadd_rn((float)y, fl[i][1]);
-      const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-      g.fx = __fsub_rn(fx, (float)x1);
-      g.fy = __fsub_rn(fy, (float)y1);
-      g.inside = (int)lane_ok & (int)(y < height) & (int)((unsigned)x1 < (unsigned)(width - 1)) & (int)((unsigned)y1 < (unsigned)(height - 1));
-      const float* ptr = R1s + (g.inside ? lds_org + y1 * 64 + x1 : 0);
+      const float fx0 = __fadd_rn((float)xl, fl[i][0]), fy0 = __fadd_rn((float)y, fl[i][1]);
+      const int x1 = (int)floorf(fx0), y1 = (int)floorf(fy0);
+      t.fx = __fsub_rn(fx0, (float)x1), t.fy = __fsub_rn(fy0, (float)y1);
+      t.inside = (int)lane_ok & (int)(y < height) & (int)((unsigned)x1 < (unsigned)(width - 1)) & (int)((unsigned)y1 < (unsigned)(height - 1));
+      int idx = lds_org + y1 * 64 + x1;
+      asm volatile("" : "+v"(idx));
+      idx = t.inside ? idx : 0;
+      const fb_f2* p0 = reinterpret_cast<const fb_f2*>(R1s) + idx;
+      const fb_f2* p1 = reinterpret_cast<const fb_f2*>(R1s + 2 * T * T) + idx;
+      const float* p2 = R1s + 4 * T * T + idx;
+      t.u00 = p0[0], t.u01 = p0[1], t.u10 = p0[64], t.u11 = p0[65];
+      t.v00 = p1[0], t.v01 = p1[1], t.v10 = p1[64], t.v11 = p1[65];
+      t.w00 = p2[0], t.w01 = p2[1], t.w10 = p2[64], t.w11 = p2[65];
+    };
+    auto blend = [&](int i, const FbTapsP& t) {
+      const float fx = t.fx, fy = t.fy;
+      const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+      const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+      bl[i].b01 = ((t.u00 * a00 + t.u01 * a01) + t.u10 * a10) + t.u11 * a11;
+      bl[i].b23 = ((t.v00 * a00 + t.v01 * a01) + t.v10 * a10) + t.v11 * a11;
+      const float b4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t.w00), __fmul_rn(a01, t.w01)), __fmul_rn(a10, t.w10)), __fmul_rn(a11, t.w11));
+      bl[i].b4 = t.inside ? b4 : __builtin_nanf("");
+    };
+    auto gather_blend_all = [&](bool lane_ok) {      // one pixel at a time (registers): the other waves cover the LDS round trip
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        g.t00[c] = ptr[c * 4096], g.t01[c] = ptr[c * 4096 + 1];
-        g.t10[c] = ptr[c * 4096 + 64], g.t11[c] = ptr[c * 4096 + 65];
+      for (int i = 0; i < 8; ++i) {
+        FbTapsP t;
+        gather(i, lane_ok, t);
+        blend(i, t);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto finish = [&](int i, const FbTaps4& g, float (&mo)[5][8]) {
-      const int y = yl0 + i;
-      const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
-      float m[5];
-      fb_update_pixel_planar(r0[i], g, fl[i][0], fl[i][1], scale, m);
+    // R0 of pixels i, i + 1 of `unit` (first coefficient images i0) -> r01 / r23 / r4
+    auto load_r0 = [&](int ia, long long unit, const FbImgs& i0) {
+      bool pair_ok;
+      (void)lane_pair(unit, pair_ok);
+      __amdgpu_buffer_rsrc_t rs;
+      uint32_t base;
+      if constexpr (MOSAIC) {
+        const long long img_l = i0.a + m_ty * (i0.c - i0.a), img_r = i0.b + m_ty * (i0.d - i0.b);      // (no select of addresses)
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+        base = (uint32_t)((m_tx ? img_r : img_l) * lpx * 20);
+      } else {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0.a * lpx * 5), 0, lpx * 20, 0x00020000);
+        base = 0;
+      }
+      const bool ok = (int)pair_ok & (int)col_ok;
+      uint32_t t8 = base + (uint32_t)xl * 8, t4 = base + (uint32_t)xl * 4;
+      asm volatile("" : "+v"(t8), "+v"(t4));      // (computed on every path: the selects below must stay selects)
+      const uint32_t v8 = ok ? t8 : NOT_THERE, v4 = ok ? t4 : NOT_THERE;
 #pragma unroll
-      for (int c = 0; c < 5; ++c) mo[c][i] = m[c];
-      pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
+      for (int i = ia; i < ia + 2; ++i) {
+        const int y = yl0 + i;
+        const bool row_ok = y < height;
+        r01[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(y * width) * 8, 0));
+        r23[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(lpx + y * width) * 8, 0));
+        r4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row_ok ? v4 : NOT_THERE, (uint32_t)(4 * lpx + y * width) * 4, 0));
+      }
     };
-    // pixels ia, ia + 1: the second pixel's reads are issued before the first one's arithmetic (one gather ahead, not more:
-    // registers); R0 / flow of the pair after next are requested behind them by the caller
-    auto update2 = [&](int ia, float (&mo)[5][8]) {
-      FbTaps4 ga, gb;
-      gather(ia, ga);
-      __builtin_amdgcn_sched_barrier(0);
-      gather(ia + 1, gb);
-      finish(ia, ga, mo);
-      __builtin_amdgcn_sched_barrier(0);
-      finish(ia + 1, gb, mo);
-      __builtin_amdgcn_sched_barrier(0);
+    // F: the rest of UpdateMatrices for pixels ia, ia + 1 -> mo; pm collects the unit's largest |M|
+    auto finish2 = [&](int ia, float (&mo)[5][8]) {
+#pragma unroll
+      for (int i = ia; i < ia + 2; ++i) {
+        const int y = yl0 + i;
+        const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
+        float m[5];
+        fb_update_pixel_finish2(r01[i], r23[i], r4[i], bl[i], fl[i][0], fl[i][1], scale, m);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) mo[c][i] = m[c];
+        pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     // the unit's largest |M| per lane half -> pmax (MOSAIC: a half is a tile column)
     auto publish_max = [&]() {
       float v = pm;
 #pragma unroll
       for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-      if ((lane & 31) == 0) pmax[2 * pw + half] = v;
+      pmax[2 * pw + half] = v;      // every lane of the half holds the maximum: 32 identical stores, no branch
     };
-    auto request_r1 = [&](const long long (&i1)[NP], long long unit) {
+    // R1 of `unit` (second coefficient images = i0 + 1) -> LDS: this wave's 10 of the 80 chunks.  No branches (a branch in
+    // the middle of a unit's straight-line code splits every live range around it: 140 more spills): a unit beyond the
+    // range, a missing pair, rows or columns beyond the image all become the offset that reads zeros
+    auto request_r1 = [&](const FbImgs& i0, long long unit) {
+      const bool unit_ok = unit < p_hi;
 #pragma unroll
       for (int n = 0; n < 10; ++n) {
-        const int k = pw + 8 * n, c = k >> 4, rg = k & 15;
+        const int k = pw + 8 * n;
+        const bool pair_plane = n < 8;                       // compile-time per n
+        const int kk = pair_plane ? (k & 31) : (k - 64);     // chunk inside its plane
+        const int rows = pair_plane ? 2 : 4;                 // LDS rows per chunk
+        const int plane_off = pair_plane ? (n < 4 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
+        const int px_bytes = pair_plane ? 8 : 4;
+        const int d_x = pair_plane ? dp_x : ds_x;
+        const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
         if constexpr (MOSAIC) {
-          const int ty = rg >> 3, yb = 4 * (rg & 7);
-          if (yb >= height) continue;
-          const long long pl = unit * 4 + 2 * ty + dj_tx;
-          const long long img_l = ty ? i1[2] : i1[0], img_r = ty ? i1[3] : i1[1];      // (selects: no indexed private array)
-          const long long img = dj_tx ? img_r : img_l;
-          const uint32_t voff = pl < n_pairs && dj_x < width ? (uint32_t)(img * lpx * 20) + dma_lane : NOT_THERE;
+          const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
+          const int d_tx = pair_plane ? dp_tx : ds_tx;
+          const long long pl = unit * 4 + 2 * ty + d_tx;
+          const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
+          const long long img = d_tx ? img_r : img_l;
+          const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
+          uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
+          asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
+          const uint32_t voff = ok ? there : NOT_THERE;
           const uintptr_t a = (uintptr_t)R;
-          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)((c * height + yb) * width) * 4,
+          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
                          (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000});
         } else {
-          if (4 * rg >= height) continue;
-          const uint32_t voff = dj_x < width ? dma_lane : NOT_THERE;
-          const uintptr_t a = (uintptr_t)(R + i1[0] * lpx * 5);
-          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)((c * height + 4 * rg) * width) * 4,
+          const int yb = rows * kk;
+          const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
+          const uint32_t voff = ok ? lane_off : NOT_THERE;
+          const uintptr_t a = (uintptr_t)(R + (i0.a + 1) * lpx * 5);
+          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
                          (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), lpx * 20, 0x00020000});
         }
       }
@@ -1631,53 +1705,47 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
       *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
       *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
     };
-    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
-    // range without a 64-bit division per pair
-    long long i0_run, i1_unused;
-    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
-    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
-    auto take_unit = [&](long long (&i0)[NP], long long (&i1)[NP]) {
-#pragma unroll
-      for (int t = 0; t < NP; ++t) {
-        i0[t] = i0_run, i1[t] = i0_run + 1;
-        if (chain_f > 0) {
-          i0_run += 1;
-          if (++q_run == pairs_per_group) q_run = 0, i0_run += chain_f - pairs_per_group;      // the next stack's first frame
-        } else {
-          i0_run += 2;
-        }
-      }
-    };
 #ifdef PV_DIAG_STAMPS
     unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
 #endif
+    // i0n: first images of the unit whose M is evaluated next; i0nn: of the unit after it (its R1 = i0nn + 1 is staged ahead)
+    FbImgs i0n, i0nn;
     {
-      long long i0a[NP], i1a[NP];
-      take_unit(i0a, i1a);
-      setup_unit(p_lo, i0a);
-      request_r1(i1a, p_lo);
-      prefetch(0), prefetch(1);
+      take_unit(i0n);
+      take_unit(i0nn);
+      bool ok;
+      (void)lane_pair(p_lo, ok);
+      request_r1(i0n, p_lo);
+      load_flow(p_lo);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();      // P1: R1 of the first unit (and GhS) in place
+      gather_blend_all(ok && col_ok);
+      __syncthreads();      // P1b: every wave is through with the first unit's R1
+      request_r1(i0nn, p_lo + 1);
       pm = 0.f;
-      prefetch(2), prefetch(3), update2(0, mA);
-      prefetch(4), prefetch(5), update2(2, mA);
-      prefetch(6), prefetch(7), update2(4, mA);
-      update2(6, mA);
+      load_r0(0, p_lo, i0n);
+      load_r0(2, p_lo, i0n), finish2(0, mA);
+      load_r0(4, p_lo, i0n), finish2(2, mA);
+      load_r0(6, p_lo, i0n), finish2(4, mA);
+      finish2(6, mA);
       publish_max();
+      load_flow(p_lo + 1);
+      i0n = i0nn;
+      take_unit(i0nn);
       __syncthreads();      // P2 = B5 of "unit p_lo - 1"
     }
     int k = 0;
+    // unit p is handed over (mc, complete); unit p + 1 is evaluated into mn meanwhile (i0n, fl); unit p + 2's R1 (i0nn) and
+    // flow are requested
     auto unit_body = [&](float (&mc)[5][8], float (&mn)[5][8], long long p, auto more_tag) {
       constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
       PV_STAMP(s0);
       const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
+      bool ok = false;
       if constexpr (more) {
-        long long i0n[NP], i1n[NP];
-        take_unit(i0n, i1n);
-        setup_unit(p + 1, i0n);
-        request_r1(i1n, p + 1);      // before any other vector-memory request: the compiler's own counts stay sufficient
-        prefetch(0), prefetch(1);    // R0 / flow of a pixel pair are requested one hand-over before its evaluation
+        (void)lane_pair(p + 1, ok);
+        ok = ok && col_ok;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of unit p + 1's R1 (and its flow) has landed
         pm = 0.f;
       }
       PV_STAMP(s1);
@@ -1689,20 +1757,35 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
         PV_STAMP(s0);
         write_channel(mc, c, s, k & 1);
         ++k;
-        if (more && c == WAIT_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
         PV_STAMP(s1);
         __syncthreads();      // B<c>
         PV_STAMP(s2);
         if constexpr (more) {
-          if (c == 1) prefetch(2), prefetch(3), update2(0, mn);
-          if (c == 2) prefetch(4), prefetch(5), update2(2, mn);
-          if (c == 3) prefetch(6), prefetch(7), update2(4, mn);
-          if (c == 4) update2(6, mn), publish_max();
+          if (c == 0) {
+            gather_blend_all(ok);
+            load_r0(0, p + 1, i0n);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (c == 1) {
+            request_r1(i0nn, p + 2);      // every wave passed B1: unit p + 1's gathers are done
+            load_r0(2, p + 1, i0n), finish2(0, mn);
+          }
+          if (c == 2) load_r0(4, p + 1, i0n), finish2(2, mn);
+          if (c == 3) load_r0(6, p + 1, i0n), finish2(4, mn);
+          if (c == 4) {
+            finish2(6, mn);
+            publish_max();
+            load_flow(p + 2);
+          }
         }
         PV_STAMP(s3);
 #ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[2] += s3 - s2;
+        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[c == 0 ? 4 : 2] += s3 - s2;
 #endif
+      }
+      if constexpr (more) {
+        i0n = i0nn;
+        take_unit(i0nn);
       }
       PV_STAMP(s0);
       __syncthreads();      // B5: the next unit's largest |M| is published
@@ -1739,6 +1822,7 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
     gv[ks] = fb_split2(t, FB_G_SCALE);
   }
   __syncthreads();      // P1
+  __syncthreads();      // P1b
   __syncthreads();      // P2
   int k = 0;
 #ifdef PV_DIAG_STAMPS
@@ -1801,9 +1885,15 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g4 + j;
           const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+          // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
+          // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
           const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
-          o[2 * j] = fb_det2(g11, h2, g12, h1) / det;
-          o[2 * j + 1] = fb_det2(g22, h1, g12, h2) / det;
+          float rc = __builtin_amdgcn_rcpf(det);
+          rc = __builtin_fmaf(__builtin_fmaf(-det, rc, 1.f), rc, rc);
+          const float nx = fb_det2(g11, h2, g12, h1), ny = fb_det2(g22, h1, g12, h2);
+          const float qx = __fmul_rn(nx, rc), qy = __fmul_rn(ny, rc);
+          o[2 * j] = __builtin_fmaf(__builtin_fmaf(-det, qx, nx), rc, qx);
+          o[2 * j + 1] = __builtin_fmaf(__builtin_fmaf(-det, qy, ny), rc, qy);
         }
         if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
           *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
