@@ -1444,11 +1444,20 @@ __device__ __forceinline__ void fb_update_pixel_finish2(const fb_f2 R01, const f
 #ifdef PV_DIAG_STAMPS
 __device__ unsigned long long fb_iter_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
 #endif
-template <int FLOW_SRC, bool MOSAIC>
-__global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ R, const float* flow_in, float* flow_out,
-                                                      const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
-                                                      int width, long long n_pairs, long long pairs_per_group, int chain_f,
-                                                      FbUpsample up) {
+// One launch per pyramid LEVEL: a workgroup keeps a unit's R1 in LDS and its R0 in registers through all `iterations`
+// (the launch-per-iteration form read R0, R1 and the flow again for every iteration: 0.95 GB per level-0 launch by the
+// counters, three launches per level, and ran at the memory system's pace).  The flow between two iterations of a unit goes
+// through memory (written by the multiplying waves, read back by the producers of the same workgroup after a barrier: L2).
+// Iteration it + 1 of a unit needs iteration it's flow, so inside a unit the two kinds of waves take turns (hand-over ->
+// blur -> solve -> UpdateMatrices -> hand-over ...); the overlap is at the unit boundary: while the LAST iteration of unit u is
+// handed over and blurred, the producers evaluate the FIRST iteration of unit u + 1 (its R1 was requested right after unit
+// u's last gathers).  FLOW_INIT: 1 = the level starts from the coarser level's flow, resized on the fly; 2 = from zero.
+// SINGLE_IT: iterations == 1 (every stage is a unit's last: R1 two units ahead, as the per-iteration kernel did).
+template <int FLOW_INIT, bool MOSAIC, bool SINGLE_IT>
+__global__ __launch_bounds__(768) void fb_level_kernel(const float* __restrict__ R, const float* __restrict__ flow_prev, float* flow,
+                                                       const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
+                                                       int width, long long n_pairs, long long pairs_per_group, int chain_f,
+                                                       FbUpsample up, int iterations) {
   constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
   // R1 of the unit whose gathers come next: (c0, c1) float2 [64][64] | (c2, c3) float2 [64][64] | c4 float [64][64]
   __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];
@@ -1463,6 +1472,7 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
   constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside every descriptor below: reads zeros
   const long long n_units = (n_pairs + NP - 1) / NP;
   const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
+  const int n_it = SINGLE_IT ? 1 : iterations;
 
   // Gh as the A operand of the second product: k-slot i of lane-half h in step (blk, s) = accumulator row
   // fb_acc_row(8 s + i, h) of row block blk of the first product
@@ -1492,6 +1502,114 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
     return e < -25 ? -25 : (e > 100 ? 100 : e);
   };
 
+  // ---- both kinds of waves: the unit -> coefficient image bookkeeping and the LDS-direct staging of R1 --------------------
+  // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
+  // range without a 64-bit division per pair
+  long long i0_run, i1_unused;
+  fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
+  long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
+  const long long img_step = chain_f > 0 ? 1 : 2, img_jump = chain_f > 0 ? chain_f - pairs_per_group : 0;
+  auto next_image = [&]() -> long long {      // (arithmetic, no branches: see request_r1)
+    const long long r = i0_run;
+    q_run += 1;
+    const long long wrap = (long long)((int)(chain_f > 0) & (int)(q_run == pairs_per_group));      // the next stack's first frame
+    i0_run += img_step + wrap * img_jump;
+    q_run -= wrap * q_run;
+    return r;
+  };
+  auto take_unit = [&](FbImgs& i0) {
+    i0.a = next_image();
+    if constexpr (MOSAIC) i0.b = next_image(), i0.c = next_image(), i0.d = next_image();
+  };
+  // LDS-direct staging, 80 chunks of 1 KB (one wave instruction each): chunks 0..31 = plane (c0, c1), two rows of 64
+  // float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each.  Lane j brings 16 bytes: in the
+  // pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane row (j >> 4), pixels 4 (j & 15) .. + 3
+  const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
+  const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
+  const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
+  const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
+  // R1 of `unit` (second coefficient images = i0 + 1) -> LDS: chunks K0 .. K0 + KN - 1, wave wi of NW issuing waves takes
+  // K0 + wi, K0 + wi + NW, ...  (K0 and NW multiples of 4: a wave instruction's plane is known at compile time.)
+  // No branches (a branch in the middle of a unit's straight-line code splits every live range around it: 140 more
+  // spills): a unit beyond the range, a missing pair, rows or columns beyond the image all become the offset that reads zeros
+  auto request_r1 = [&](const FbImgs& i0, long long unit, int wi, auto nw_tag, auto k0_tag, auto kn_tag) {
+    constexpr int NW = decltype(nw_tag)::value, K0 = decltype(k0_tag)::value, KN = decltype(kn_tag)::value;
+    const bool unit_ok = unit < p_hi;
+#pragma unroll
+    for (int n = 0; n < KN / NW; ++n) {
+      const int k = K0 + wi + NW * n;
+      const bool pair_plane = K0 + n * NW < 64;                   // compile-time per n
+      const int kk = pair_plane ? (k & 31) : (k - 64);            // chunk inside its plane
+      const int rows = pair_plane ? 2 : 4;                        // LDS rows per chunk
+      const int plane_off = pair_plane ? (K0 + n * NW < 32 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
+      const int px_bytes = pair_plane ? 8 : 4;
+      const int d_x = pair_plane ? dp_x : ds_x;
+      const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
+      if constexpr (MOSAIC) {
+        const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
+        const int d_tx = pair_plane ? dp_tx : ds_tx;
+        const long long pl = unit * 4 + 2 * ty + d_tx;
+        const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
+        const long long img = d_tx ? img_r : img_l;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
+        uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
+        asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
+        const uint32_t voff = ok ? there : NOT_THERE;
+        const uintptr_t a = (uintptr_t)R;
+        fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
+                       (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000});
+      } else {
+        const int yb = rows * kk;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
+        const uint32_t voff = ok ? lane_off : NOT_THERE;
+        const uintptr_t a = (uintptr_t)(R + (i0.a + 1) * lpx * 5);
+        fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
+                       (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), lpx * 20, 0x00020000});
+      }
+    }
+  };
+
+  // The same chunks through registers, for waves that have registers to spare and time to wait: plain 16-byte loads do not
+  // hold the issuing wave the way an LDS-direct instruction does (300 to 700 cycles apiece here, measured on either kind of
+  // wave), and the fetch may start before the image in LDS is free -- only the commit has to wait for the last gathers.
+  // Wave wi of 8 takes chunks wi, wi + 8, ... (10 of the 80).
+  auto r1_fetch = [&](const FbImgs& i0, long long unit, int wi, u32x4 (&buf)[10]) {
+    const bool unit_ok = unit < p_hi;
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+      const int k = wi + 8 * n;
+      const bool pair_plane = n < 8;                              // compile-time per n
+      const int kk = pair_plane ? (k & 31) : (k - 64);            // chunk inside its plane
+      const int rows = pair_plane ? 2 : 4;                        // LDS rows per chunk
+      const int plane_off = pair_plane ? (n < 4 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
+      const int px_bytes = pair_plane ? 8 : 4;
+      const int d_x = pair_plane ? dp_x : ds_x;
+      const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
+      if constexpr (MOSAIC) {
+        const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
+        const int d_tx = pair_plane ? dp_tx : ds_tx;
+        const long long pl = unit * 4 + 2 * ty + d_tx;
+        const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
+        const long long img = d_tx ? img_r : img_l;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
+        uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
+        asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? there : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
+      } else {
+        const int yb = rows * kk;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (i0.a + 1) * lpx * 5), 0, lpx * 20, 0x00020000);
+        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? lane_off : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
+      }
+    }
+  };
+  auto r1_commit = [&](int wi, const u32x4 (&buf)[10]) {
+    u32x4* dst = reinterpret_cast<u32x4*>(R1s) + lane;
+#pragma unroll
+    for (int n = 0; n < 10; ++n) dst[(wi + 8 * n) * 64] = buf[n];
+  };
+
   if (producer) {
     // ================================ producing waves ===================================================================
     const int pw = wave12 - 4;                                  // 0..7: rows 8 pw .. 8 pw + 7 of the 64 x 64 image
@@ -1500,41 +1618,15 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
     const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
     const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane (pixels)
     const bool col_ok = xl < width;
-    const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
     // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
     auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
     const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
-    // LDS-direct staging, 80 chunks of 1 KB (one wave instruction each): chunks 0..31 = plane (c0, c1), two rows of 64
-    // float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each.  Lane j brings 16 bytes: in the
-    // pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane row (j >> 4), pixels 4 (j & 15) .. + 3
-    const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
-    const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
-    const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
-
     float mA[5][8], mB[5][8];      // [channel][pixel]: a channel's 8 values are what a hand-over writes
     FbBlend bl[8];
-    fb_f2 fl[8];                   // starting flow of the unit whose gathers come next
-    fb_f2 r01[8], r23[8];
+    fb_f2 fl[8];                   // the flow the next UpdateMatrices starts from
+    fb_f2 r01[8], r23[8];          // R0 of the pixels evaluated next (two pixels ahead of their use)
     float r4[8];
     float pm;                      // running largest |M| of the unit being evaluated
-    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
-    // range without a 64-bit division per pair
-    long long i0_run, i1_unused;
-    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
-    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
-    const long long img_step = chain_f > 0 ? 1 : 2, img_jump = chain_f > 0 ? chain_f - pairs_per_group : 0;
-    auto next_image = [&]() -> long long {      // (arithmetic, no branches: see request_r1)
-      const long long r = i0_run;
-      q_run += 1;
-      const long long wrap = (long long)((int)(chain_f > 0) & (int)(q_run == pairs_per_group));      // the next stack's first frame
-      i0_run += img_step + wrap * img_jump;
-      q_run -= wrap * q_run;
-      return r;
-    };
-    auto take_unit = [&](FbImgs& i0) {
-      i0.a = next_image();
-      if constexpr (MOSAIC) i0.b = next_image(), i0.c = next_image(), i0.d = next_image();
-    };
     // this lane's pair of a unit and whether it exists (MOSAIC: the tail unit may hold fewer than four pairs; a unit beyond
     // the workgroup's range -- asked for by the look-ahead of the last units -- does not exist either)
     auto lane_pair = [&](long long unit, bool& ok) -> long long {
@@ -1542,30 +1634,18 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
       ok = (int)(unit < p_hi) & (int)(pl < n_pairs);
       return ok ? pl : 0;
     };
-    // starting flow of the 8 pixels of `unit` -> fl
-    auto load_flow = [&](long long unit) {
+    // the flow a unit's first iteration starts from -> fl
+    auto load_flow_init = [&](long long unit) {
       bool pair_ok;
       const long long pl = lane_pair(unit, pair_ok);
-      if constexpr (FLOW_SRC == 0) {
-        const __amdgpu_buffer_rsrc_t rs =
-            MOSAIC ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000)
-                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + pl * lpx * 2), 0, lpx * 8, 0x00020000);
-        uint32_t there = (MOSAIC ? (uint32_t)(pl * lpx * 8) : 0u) + (uint32_t)xl * 8;
-        asm volatile("" : "+v"(there));
-        const uint32_t voff = (int)pair_ok & (int)col_ok ? there : NOT_THERE;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int y = yl0 + i;
-          fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, y < height ? voff : NOT_THERE, (uint32_t)(y * width) * 8, 0));
-        }
-      } else if constexpr (FLOW_SRC == 1) {
+      if constexpr (FLOW_INIT == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which
           // would keep them for all 8 rows in registers around the unit loop)
           int xo = xl, yo = yl0 + i;
           asm volatile("" : "+v"(xo), "+s"(yo));
-          const fb_f32x2_t f = fb_upsampled_flow_nb(flow_in, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
+          const fb_f32x2_t f = fb_upsampled_flow_nb(flow_prev, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
                                                     up.inv_fx, up.inv_fy, up.mul);
           fl[i] = (fb_f2){f[0], f[1]};
         }
@@ -1576,6 +1656,23 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
           asm volatile("" : "+v"(z));
           fl[i] = (fb_f2){z, z};
         }
+      }
+    };
+    // the flow the unit's multiplying waves stored in the previous iteration -> fl (sc0 loads: never a line this compute
+    // unit's vector cache kept from the iteration before)
+    auto load_flow_back = [&](long long unit) {
+      bool pair_ok;
+      const long long pl = lane_pair(unit, pair_ok);
+      const __amdgpu_buffer_rsrc_t rs =
+          MOSAIC ? __builtin_amdgcn_make_buffer_rsrc(flow, 0, 0x7fffffff, 0x00020000)
+                 : __builtin_amdgcn_make_buffer_rsrc(flow + pl * lpx * 2, 0, lpx * 8, 0x00020000);
+      uint32_t there = (MOSAIC ? (uint32_t)(pl * lpx * 8) : 0u) + (uint32_t)xl * 8;
+      asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
+      const uint32_t voff = (int)pair_ok & (int)col_ok ? there : NOT_THERE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int y = yl0 + i;
+        fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, y < height ? voff : NOT_THERE, (uint32_t)(y * width) * 8, 1));
       }
     };
     // G: the four R1 neighbours of pixel i (R1 is in LDS, the flow in fl): reads, then the bilinear blend -> bl[i]
@@ -1604,16 +1701,21 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
       const float b4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t.w00), __fmul_rn(a01, t.w01)), __fmul_rn(a10, t.w10)), __fmul_rn(a11, t.w11));
       bl[i].b4 = t.inside ? b4 : __builtin_nanf("");
     };
-    auto gather_blend_all = [&](bool lane_ok) {      // one pixel at a time (registers): the other waves cover the LDS round trip
+    auto gather_blend_all = [&](bool lane_ok) {      // the next pixel's reads are issued before this pixel's blend, not more (registers)
+      FbTapsP ta, tb;
+      gather(0, lane_ok, ta);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        FbTapsP t;
-        gather(i, lane_ok, t);
-        blend(i, t);
+      for (int i = 0; i < 8; i += 2) {
         __builtin_amdgcn_sched_barrier(0);
+        gather(i + 1, lane_ok, tb);
+        blend(i, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < 8) gather(i + 2, lane_ok, ta);
+        blend(i + 1, tb);
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
-    // R0 of pixels i, i + 1 of `unit` (first coefficient images i0) -> r01 / r23 / r4
+    // R0 of pixels ia, ia + 1 of `unit` (first coefficient images i0) -> r01 / r23 / r4
     auto load_r0 = [&](int ia, long long unit, const FbImgs& i0) {
       bool pair_ok;
       (void)lane_pair(unit, pair_ok);
@@ -1661,44 +1763,6 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
       for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
       pmax[2 * pw + half] = v;      // every lane of the half holds the maximum: 32 identical stores, no branch
     };
-    // R1 of `unit` (second coefficient images = i0 + 1) -> LDS: this wave's 10 of the 80 chunks.  No branches (a branch in
-    // the middle of a unit's straight-line code splits every live range around it: 140 more spills): a unit beyond the
-    // range, a missing pair, rows or columns beyond the image all become the offset that reads zeros
-    auto request_r1 = [&](const FbImgs& i0, long long unit) {
-      const bool unit_ok = unit < p_hi;
-#pragma unroll
-      for (int n = 0; n < 10; ++n) {
-        const int k = pw + 8 * n;
-        const bool pair_plane = n < 8;                       // compile-time per n
-        const int kk = pair_plane ? (k & 31) : (k - 64);     // chunk inside its plane
-        const int rows = pair_plane ? 2 : 4;                 // LDS rows per chunk
-        const int plane_off = pair_plane ? (n < 4 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
-        const int px_bytes = pair_plane ? 8 : 4;
-        const int d_x = pair_plane ? dp_x : ds_x;
-        const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
-        if constexpr (MOSAIC) {
-          const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
-          const int d_tx = pair_plane ? dp_tx : ds_tx;
-          const long long pl = unit * 4 + 2 * ty + d_tx;
-          const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
-          const long long img = d_tx ? img_r : img_l;
-          const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
-          uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
-          asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
-          const uint32_t voff = ok ? there : NOT_THERE;
-          const uintptr_t a = (uintptr_t)R;
-          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
-                         (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000});
-        } else {
-          const int yb = rows * kk;
-          const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
-          const uint32_t voff = ok ? lane_off : NOT_THERE;
-          const uintptr_t a = (uintptr_t)(R + (i0.a + 1) * lpx * 5);
-          fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
-                         (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), lpx * 20, 0x00020000});
-        }
-      }
-    };
     auto write_channel = [&](const float (&m)[5][8], int c, float s, int buf) {
       const FbSplit2 sp = fb_split2(m[c], s);
       uint16_t* Xc = &Xs[buf][0][0] + lane * XS + 8 * pw;      // row x of X^T, rows y' = 8 pw .. + 7: 16 contiguous bytes
@@ -1708,100 +1772,161 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
 #ifdef PV_DIAG_STAMPS
     unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
 #endif
-    // i0n: first images of the unit whose M is evaluated next; i0nn: of the unit after it (its R1 = i0nn + 1 is staged ahead)
-    FbImgs i0n, i0nn;
+    // i0c: first images of the unit in hand; i0n: of the unit after it; i0nn: two ahead (SINGLE_IT stages R1 that far ahead)
+    FbImgs i0c, i0n, i0nn;
+    take_unit(i0c);
+    take_unit(i0n);
+    take_unit(i0nn);
     {
-      take_unit(i0n);
-      take_unit(i0nn);
       bool ok;
       (void)lane_pair(p_lo, ok);
-      request_r1(i0n, p_lo);
-      load_flow(p_lo);
+      request_r1(i0c, p_lo, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});
+      load_flow_init(p_lo);
+      load_r0(0, p_lo, i0c);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();      // P1: R1 of the first unit (and GhS) in place
       gather_blend_all(ok && col_ok);
-      __syncthreads();      // P1b: every wave is through with the first unit's R1
-      request_r1(i0nn, p_lo + 1);
+      __syncthreads();      // Pg: every wave is through with the first unit's R1
+      if constexpr (SINGLE_IT) request_r1(i0n, p_lo + 1, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});
       pm = 0.f;
-      load_r0(0, p_lo, i0n);
-      load_r0(2, p_lo, i0n), finish2(0, mA);
-      load_r0(4, p_lo, i0n), finish2(2, mA);
-      load_r0(6, p_lo, i0n), finish2(4, mA);
+      load_r0(2, p_lo, i0c), finish2(0, mA);
+      load_r0(4, p_lo, i0c), finish2(2, mA);
+      load_r0(6, p_lo, i0c), finish2(4, mA);
       finish2(6, mA);
       publish_max();
-      load_flow(p_lo + 1);
-      i0n = i0nn;
-      take_unit(i0nn);
-      __syncthreads();      // P2 = B5 of "unit p_lo - 1"
+      __syncthreads();      // P2 = X0 of the first stage
     }
     int k = 0;
-    // unit p is handed over (mc, complete); unit p + 1 is evaluated into mn meanwhile (i0n, fl); unit p + 2's R1 (i0nn) and
-    // flow are requested
-    auto unit_body = [&](float (&mc)[5][8], float (&mn)[5][8], long long p, auto more_tag) {
-      constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
+    // hand-over of a complete M (mc): barriers B0..B4 publish channels 0..4
+    auto hand_over = [&](float (&mc)[5][8]) {
       PV_STAMP(s0);
       const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
-      bool ok = false;
-      if constexpr (more) {
-        (void)lane_pair(p + 1, ok);
-        ok = ok && col_ok;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of unit p + 1's R1 (and its flow) has landed
-        pm = 0.f;
-      }
-      PV_STAMP(s1);
-#ifdef PV_DIAG_STAMPS
-      dg[3] += s1 - s0;
-#endif
 #pragma unroll
       for (int c = 0; c < 5; ++c) {
-        PV_STAMP(s0);
         write_channel(mc, c, s, k & 1);
         ++k;
         PV_STAMP(s1);
         __syncthreads();      // B<c>
         PV_STAMP(s2);
-        if constexpr (more) {
+#ifdef PV_DIAG_STAMPS
+        dg[0] += s1 - s0, dg[1] += s2 - s1;
+        s0 = s2;
+#endif
+      }
+    };
+    // the same with the FIRST iteration of unit u + 1 evaluated into mn between the barriers (its R1 has been requested, its
+    // starting flow does not depend on anything this workgroup computes)
+    auto hand_over_and_next = [&](float (&mc)[5][8], float (&mn)[5][8], long long u) {
+      PV_STAMP(s0);
+      const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
+      bool ok;
+      (void)lane_pair(u + 1, ok);
+      ok = ok && col_ok;
+      pm = 0.f;
+      PV_STAMP(s1);
+#ifdef PV_DIAG_STAMPS
+      dg[3] += s1 - s0;
+#endif
+      // SINGLE_IT: unit u + 1's R1 was requested a whole unit ago -- gathers right after B0, as in the per-iteration form.
+      // Otherwise it was requested one UpdateMatrices ago (after unit u's last gathers): the gathers wait until B2, the
+      // request has the first two channels' products to arrive, and F follows four pixels per hand-over
+      constexpr int G_AT = SINGLE_IT ? 0 : 2;
+      u32x4 r1buf[10];
+      if constexpr (!SINGLE_IT) r1_fetch(i0n, u + 1, pw, r1buf);      // unit u's gathers are all done: into LDS after B1
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        PV_STAMP(s0);
+        write_channel(mc, c, s, k & 1);
+        ++k;
+        if (SINGLE_IT && c == G_AT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of unit u + 1's R1 has landed
+        PV_STAMP(s1);
+        __syncthreads();      // B<c>
+        PV_STAMP(s2);
+        if constexpr (SINGLE_IT) {
           if (c == 0) {
+            load_flow_init(u + 1);
             gather_blend_all(ok);
-            load_r0(0, p + 1, i0n);
+            load_r0(0, u + 1, i0n);
             __builtin_amdgcn_sched_barrier(0);
           }
           if (c == 1) {
-            request_r1(i0nn, p + 2);      // every wave passed B1: unit p + 1's gathers are done
-            load_r0(2, p + 1, i0n), finish2(0, mn);
+            request_r1(i0nn, u + 2, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});      // every wave passed B1: unit u + 1's gathers are done
+            load_r0(2, u + 1, i0n), finish2(0, mn);
           }
-          if (c == 2) load_r0(4, p + 1, i0n), finish2(2, mn);
-          if (c == 3) load_r0(6, p + 1, i0n), finish2(4, mn);
-          if (c == 4) {
-            finish2(6, mn);
-            publish_max();
-            load_flow(p + 2);
+          if (c == 2) load_r0(4, u + 1, i0n), finish2(2, mn);
+          if (c == 3) load_r0(6, u + 1, i0n), finish2(4, mn);
+          if (c == 4) finish2(6, mn), publish_max();
+        } else {
+          if (c == 0) load_flow_init(u + 1), load_r0(0, u + 1, i0n), load_r0(2, u + 1, i0n);
+          if (c == 1) r1_commit(pw, r1buf);      // (the compiler's own wait for the fetch; visible to all behind B2)
+          if (c == 2) {
+            gather_blend_all(ok);
+            load_r0(4, u + 1, i0n), load_r0(6, u + 1, i0n);
+            __builtin_amdgcn_sched_barrier(0);
           }
+          if (c == 3) finish2(0, mn), finish2(2, mn);
+          if (c == 4) finish2(4, mn), finish2(6, mn), publish_max();
         }
         PV_STAMP(s3);
 #ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[c == 0 ? 4 : 2] += s3 - s2;
+        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[c == G_AT ? 4 : 2] += s3 - s2;
 #endif
       }
-      if constexpr (more) {
-        i0n = i0nn;
+    };
+    // iteration it + 1 of unit u (R1 in LDS, R0 in registers) from the flow iteration it left in memory -> mc
+    auto update_from_memory = [&](float (&mc)[5][8], long long u) {
+      // R0 again from memory (L2 by now: the unit read it an iteration ago) rather than 40 registers held through the
+      // hand-over; requested before the wait for the multiplying waves, so that F finds it in registers
+      load_r0(0, u, i0c), load_r0(2, u, i0c), load_r0(4, u, i0c), load_r0(6, u, i0c);
+      PV_STAMP(s0);
+      __syncthreads();      // X1: the multiplying waves have stored this iteration's flow
+      PV_STAMP(s1);
+      bool ok;
+      (void)lane_pair(u, ok);
+      load_flow_back(u);
+      gather_blend_all(ok && col_ok);
+      PV_STAMP(s2);
+      __syncthreads();      // Xg: every wave is through with this iteration's gathers (after the unit's last ones the
+      PV_STAMP(s3);         // multiplying waves, idle until the next hand-over, request the next unit's R1)
+      pm = 0.f;
+      finish2(0, mc), finish2(2, mc), finish2(4, mc), finish2(6, mc);
+      publish_max();
+#ifdef PV_DIAG_STAMPS
+      dg[1] += s1 - s0 + s3 - s2, dg[4] += s2 - s1;
+      PV_STAMP(s0);
+      dg[2] += s0 - s3;
+#endif
+    };
+    for (long long u = p_lo; u < p_hi; ++u) {
+      const bool more = u + 1 < p_hi;
+      for (int it = 0; it + 1 < n_it; ++it) {      // every iteration but the unit's last
+        hand_over(mA);
+        update_from_memory(mA, u);
+        PV_STAMP(s0);
+        __syncthreads();      // X0: the next iteration's largest |M| is published
+        PV_STAMP(s1);
+#ifdef PV_DIAG_STAMPS
+        dg[1] += s1 - s0;
+#endif
+      }
+      if (more) {
+        hand_over_and_next(mA, mB, u);
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+          for (int n = 0; n < 8; ++n) mA[c][n] = mB[c][n];
+        i0c = i0n, i0n = i0nn;
         take_unit(i0nn);
+      } else {
+        hand_over(mA);
       }
       PV_STAMP(s0);
-      __syncthreads();      // B5: the next unit's largest |M| is published
+      __syncthreads();      // B5 = X0 of the next unit's first stage
       PV_STAMP(s1);
 #ifdef PV_DIAG_STAMPS
       dg[1] += s1 - s0, dg[7] += 1;
 #endif
-    };
-    for (long long p = p_lo; p + 1 < p_hi; ++p) {
-      unit_body(mA, mB, p, std::true_type{});
-#pragma unroll
-      for (int c = 0; c < 5; ++c)
-#pragma unroll
-        for (int n = 0; n < 8; ++n) mA[c][n] = mB[c][n];
     }
-    unit_body(mA, mB, p_hi - 1, std::false_type{});
 #ifdef PV_DIAG_STAMPS
     if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
       for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 12 + wave12) * PV_DIAG_SLOTS + i] = dg[i];
@@ -1822,91 +1947,98 @@ __global__ __launch_bounds__(768) void fb_iter_kernel(const float* __restrict__ 
     gv[ks] = fb_split2(t, FB_G_SCALE);
   }
   __syncthreads();      // P1
-  __syncthreads();      // P1b
+  __syncthreads();      // Pg
   __syncthreads();      // P2
   int k = 0;
 #ifdef PV_DIAG_STAMPS
   unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2;
 #endif
   for (long long p = p_lo; p < p_hi; ++p) {
-    const int e = unit_exp(strip, mbo);
-    fb_v16f res[5];
+    for (int it = 0; it < n_it; ++it) {
+      const int e = unit_exp(strip, mbo);
+      fb_v16f res[5];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      PV_STAMP(s0);
-      __syncthreads();      // B<c>: channel k is in its buffer
-      PV_STAMP(s1);
-      const uint16_t* Xc = &Xs[k & 1][0][0];
-      ++k;
-      fb_v16f u[2];
+      for (int c = 0; c < 5; ++c) {
+        PV_STAMP(s0);
+        __syncthreads();      // B<c>: channel k is in its buffer
+        PV_STAMP(s1);
+        const uint16_t* Xc = &Xs[k & 1][0][0];
+        ++k;
+        fb_v16f u[2];
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+          for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            FbSplit2 a;
+            const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+            a.h = *reinterpret_cast<const fb_f16x8*>(xa);
+            a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
+            u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          FbSplit2 a;
-          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-          a.h = *reinterpret_cast<const fb_f16x8*>(xa);
-          a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
-          u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+          float t[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+          const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
+          FbSplit2 g;
+          g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
+          g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
+          res[c] = fb_mfma2(g, b, res[c]);
+        }
+        PV_STAMP(s2);
+#ifdef PV_DIAG_STAMPS
+        dg[0] += s1 - s0, dg[1] += s2 - s1;
+#endif
+      }
+      PV_STAMP(s0);
+      // ---- 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x -------
+      {
+        const float lam = ldexpf(1e-3f, 2 * (30 - e));
+        const int y = (MOSAIC ? 0 : 32 * strip) + col;
+        const long long pr = MOSAIC ? p * 4 + 2 * strip + mbo : p;
+        float* frow = flow + (pr * lpx + (long long)y * width) * 2;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * g4 + j;
+            const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+            // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
+            // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
+            const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
+            float rc = __builtin_amdgcn_rcpf(det);
+            rc = __builtin_fmaf(__builtin_fmaf(-det, rc, 1.f), rc, rc);
+            const float nx = fb_det2(g11, h2, g12, h1), ny = fb_det2(g22, h1, g12, h2);
+            const float qx = __fmul_rn(nx, rc), qy = __fmul_rn(ny, rc);
+            o[2 * j] = __builtin_fmaf(__builtin_fmaf(-det, qx, nx), rc, qx);
+            o[2 * j + 1] = __builtin_fmaf(__builtin_fmaf(-det, qy, ny), rc, qy);
+          }
+          if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
+            *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(frow + x0 * 2 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+          }
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
-        const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
-        FbSplit2 g;
-        g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
-        g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
-        res[c] = fb_mfma2(g, b, res[c]);
+      PV_STAMP(s1);
+      if (it + 1 < n_it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the flow is on its way to L2 before the producers are released
+        __syncthreads();      // X1
+        __syncthreads();      // Xg
       }
+      __syncthreads();      // X0 / B5
       PV_STAMP(s2);
 #ifdef PV_DIAG_STAMPS
-      dg[0] += s1 - s0, dg[1] += s2 - s1;
+      dg[2] += s1 - s0, dg[0] += s2 - s1, dg[7] += 1;
 #endif
     }
-    PV_STAMP(s0);
-    // ---- 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x ---------
-    {
-      const float lam = ldexpf(1e-3f, 2 * (30 - e));
-      const int y = (MOSAIC ? 0 : 32 * strip) + col;
-      const long long pr = MOSAIC ? p * 4 + 2 * strip + mbo : p;
-      float* frow = flow_out + (pr * lpx + (long long)y * width) * 2;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g4 + j;
-          const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
-          // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
-          // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
-          const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
-          float rc = __builtin_amdgcn_rcpf(det);
-          rc = __builtin_fmaf(__builtin_fmaf(-det, rc, 1.f), rc, rc);
-          const float nx = fb_det2(g11, h2, g12, h1), ny = fb_det2(g22, h1, g12, h2);
-          const float qx = __fmul_rn(nx, rc), qy = __fmul_rn(ny, rc);
-          o[2 * j] = __builtin_fmaf(__builtin_fmaf(-det, qx, nx), rc, qx);
-          o[2 * j + 1] = __builtin_fmaf(__builtin_fmaf(-det, qy, ny), rc, qy);
-        }
-        if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
-          *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<f32x4*>(frow + x0 * 2 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-        }
-      }
-    }
-    PV_STAMP(s1);
-    __syncthreads();      // B5
-    PV_STAMP(s2);
-#ifdef PV_DIAG_STAMPS
-    dg[2] += s1 - s0, dg[0] += s2 - s1, dg[7] += 1;
-#endif
   }
 #ifdef PV_DIAG_STAMPS
   if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
@@ -2279,26 +2411,35 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (float)(1. / p->pyr_scale)};
       const long long n_units = small_level ? (n_pairs + 3) / 4 : n_pairs;
       const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);      // one workgroup per CU (LDS)
+#define PV_LEVEL(INIT, MOS, SINGLE)                                                                                       \
+  hipLaunchKernelGGL((fb_level_kernel<INIT, MOS, SINGLE>), dim3(grid), dim3(768), 0, st, (const float*)R,                 \
+                     (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
+                     (long long)pairs_per_group, chain_f, up, (int)p->iterations)
 #define PV_FUSED_ITER(SRC, FLOW_IN)                                                                                       \
   do {                                                                                                                    \
-    if (iter_v2 && small_level)                                                                                           \
-      hipLaunchKernelGGL((fb_iter_kernel<SRC, true>), dim3(grid), dim3(768), 0, st, (const float*)R, (const float*)(FLOW_IN), \
-                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
-    else if (iter_v2)                                                                                                     \
-      hipLaunchKernelGGL((fb_iter_kernel<SRC, false>), dim3(grid), dim3(768), 0, st, (const float*)R, (const float*)(FLOW_IN), \
-                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
-    else if (small_level)                                                                                                 \
+    if (small_level)                                                                                                      \
       hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, true>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
                          flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
     else                                                                                                                  \
       hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, false>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
                          flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
   } while (0)
+      if (iter_v2) {      // one launch for all of the level's iterations
+        const bool single = p->iterations == 1;
+        if (prev_flow) {
+          if (small_level) { if (single) PV_LEVEL(1, true, true); else PV_LEVEL(1, true, false); }
+          else { if (single) PV_LEVEL(1, false, true); else PV_LEVEL(1, false, false); }
+        } else {
+          if (small_level) { if (single) PV_LEVEL(2, true, true); else PV_LEVEL(2, true, false); }
+          else { if (single) PV_LEVEL(2, false, true); else PV_LEVEL(2, false, false); }
+        }
+      } else
       for (int it = 0; it < p->iterations; ++it) {
         if (it > 0) PV_FUSED_ITER(0, flow);
         else if (prev_flow) PV_FUSED_ITER(1, prev_flow);
         else PV_FUSED_ITER(2, nullptr);
       }
+#undef PV_LEVEL
 #undef PV_FUSED_ITER
       prev_flow = flow;
       prev_w = lw;
