@@ -205,9 +205,12 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 // re-reads I and T: 130 bytes per level-pixel of extra traffic and two more launches).  Every expression is the one of
 // fb_prep_kernel / fb_polyexp_v_kernel / fb_polyexp_h_kernel, evaluated in the same order: bit-identical results.
 // 64 KB of LDS (the first PolyExp plane reuses the buffer of the blurred image, dead by then) and <= 64 registers: TWO
-// 16-wave workgroups share a CU, so one's barrier-separated phases overlap the other's.
+// 16-wave workgroups share a CU, so one's barrier-separated phases overlap the other's.  (Round 4 tried four pixels of a
+// row per thread with 16-byte window reads and 8-wave workgroups: no faster -- 254 against 198 us at level 0 -- the phases
+// are short and barrier-separated, and half the waves cover each other's LDS round trips half as well.)
 constexpr int FB_PP_NT = 1024;
 typedef float fb_pp_f2 __attribute__((ext_vector_type(2)));
+template <bool F64_ACC>      // F64_ACC: the horizontal pass on double accumulators (the reference's); else f32 with fused multiply-adds
 __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void fb_prep_polyexp_tile_kernel(const uint8_t* __restrict__ prev,
                                                                     const uint8_t* __restrict__ next, long long prev_stride,
                                                                     long long next_stride, long long pairs_per_group,
@@ -308,29 +311,54 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
       bufA[i] = t0, Tt12[i] = t1, Tt12[lpx + i] = t2;   // bufA (blurred image) was consumed by the resize above
     }
     __syncthreads();
-    // PolyExp, horizontal pass (double accumulators) -> R
+    // PolyExp, horizontal pass -> R.  F64_ACC: the reference's double accumulators.  Otherwise f32 accumulators and fused
+    // multiply-adds (one rounding per tap: ~3e-7 relative on R, ~1e-6 px on the flow, against a contract of 1e-3 px): the
+    // double form is 45 % of this kernel's vector instructions (half rate, a conversion per operand)
     for (int i = tid; i < lpx; i += FB_PP_NT) {
       const int y = row_lw(i), x = i - y * lw;
       const float* t0r = bufA + y * lw;
       const float* t1r = Tt12 + y * lw;
       const float* t2r = Tt12 + lpx + y * lw;
       float g0 = pk.g[0];
-      double b1 = __fmul_rn(t0r[x], g0), b2 = 0, b3 = __fmul_rn(t1r[x], g0), b4 = 0, b5 = __fmul_rn(t2r[x], g0), b6 = 0;
-      for (int k = 1; k <= pk.n; ++k) {
-        const int xp = min(x + k, lw - 1), xm = max(x - k, 0);
-        const double tg = (double)__fadd_rn(t0r[xp], t0r[xm]);
-        g0 = pk.g[k];
-        b1 = __dadd_rn(b1, __dmul_rn(tg, (double)g0));
-        b4 = __dadd_rn(b4, __dmul_rn(tg, (double)pk.xxg[k]));
-        b2 = __dadd_rn(b2, (double)__fmul_rn(__fsub_rn(t0r[xp], t0r[xm]), pk.xg[k]));
-        b3 = __dadd_rn(b3, (double)__fmul_rn(__fadd_rn(t1r[xp], t1r[xm]), g0));
-        b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[xp], t1r[xm]), pk.xg[k]));
-        b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[xp], t2r[xm]), g0));
+      float d0, d1, d2, d3, d4;
+      if constexpr (F64_ACC) {
+        double b1 = __fmul_rn(t0r[x], g0), b2 = 0, b3 = __fmul_rn(t1r[x], g0), b4 = 0, b5 = __fmul_rn(t2r[x], g0), b6 = 0;
+        for (int k = 1; k <= pk.n; ++k) {
+          const int xp = min(x + k, lw - 1), xm = max(x - k, 0);
+          const double tg = (double)__fadd_rn(t0r[xp], t0r[xm]);
+          g0 = pk.g[k];
+          b1 = __dadd_rn(b1, __dmul_rn(tg, (double)g0));
+          b4 = __dadd_rn(b4, __dmul_rn(tg, (double)pk.xxg[k]));
+          b2 = __dadd_rn(b2, (double)__fmul_rn(__fsub_rn(t0r[xp], t0r[xm]), pk.xg[k]));
+          b3 = __dadd_rn(b3, (double)__fmul_rn(__fadd_rn(t1r[xp], t1r[xm]), g0));
+          b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[xp], t1r[xm]), pk.xg[k]));
+          b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[xp], t2r[xm]), g0));
+        }
+        d1 = (float)__dmul_rn(b2, pk.ig11), d0 = (float)__dmul_rn(b3, pk.ig11);
+        d3 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+        d2 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+        d4 = (float)__dmul_rn(b6, pk.ig55);
+      } else {
+        float b1 = __fmul_rn(t0r[x], g0), b2 = 0.f, b3 = __fmul_rn(t1r[x], g0), b4 = 0.f, b5 = __fmul_rn(t2r[x], g0), b6 = 0.f;
+        for (int k = 1; k <= pk.n; ++k) {
+          const int xp = min(x + k, lw - 1), xm = max(x - k, 0);
+          const float p0 = t0r[xp], m0 = t0r[xm], p1 = t1r[xp], m1 = t1r[xm], p2 = t2r[xp], m2 = t2r[xm];
+          const float gk = pk.g[k], xgk = pk.xg[k];
+          const float tg = __fadd_rn(p0, m0);
+          b1 = __builtin_fmaf(tg, gk, b1);
+          b4 = __builtin_fmaf(tg, pk.xxg[k], b4);
+          b2 = __builtin_fmaf(__fsub_rn(p0, m0), xgk, b2);
+          b3 = __builtin_fmaf(__fadd_rn(p1, m1), gk, b3);
+          b6 = __builtin_fmaf(__fsub_rn(p1, m1), xgk, b6);
+          b5 = __builtin_fmaf(__fadd_rn(p2, m2), gk, b5);
+        }
+        const float ig11 = (float)pk.ig11, ig03 = (float)pk.ig03, ig33 = (float)pk.ig33, ig55 = (float)pk.ig55;
+        const float b1s = __fmul_rn(b1, ig03);
+        d1 = __fmul_rn(b2, ig11), d0 = __fmul_rn(b3, ig11);
+        d3 = __builtin_fmaf(b4, ig33, b1s);
+        d2 = __builtin_fmaf(b5, ig33, b1s);
+        d4 = __fmul_rn(b6, ig55);
       }
-      const float d1 = (float)__dmul_rn(b2, pk.ig11), d0 = (float)__dmul_rn(b3, pk.ig11);
-      const float d3 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
-      const float d2 = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
-      const float d4 = (float)__dmul_rn(b6, pk.ig55);
       if (planar) {
         float* d = R + im * lpx * 5;
         reinterpret_cast<fb_pp_f2*>(d)[i] = (fb_pp_f2){d0, d1};
@@ -2388,9 +2416,15 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
     if (polyexp_tile) {
       const unsigned grid = (unsigned)std::min<long long>(n_img, 4096);
-      hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
-                         (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
-                         n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, iter_v2 ? 1 : 0);
+      // (PV_FARNEBACK_POLYEXP_F64=1: the horizontal pass on the reference's double accumulators, as in rounds 1-3)
+      if (getenv("PV_FARNEBACK_POLYEXP_F64"))
+        hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel<true>, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
+                           (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
+                           n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, iter_v2 ? 1 : 0);
+      else
+        hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel<false>, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
+                           (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
+                           n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, iter_v2 ? 1 : 0);
     } else {
     hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st, prev, next,
                        (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,
