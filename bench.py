@@ -303,26 +303,6 @@ def measure_config3(dev, b, history_minutes):
     d = (time.perf_counter() - t0) / n
     out["joined_train_step"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1),
                                 "workload": "advection pipeline + conv3d train step (fwd + NMAE + bwd + Adam) per batch"}
-    # the same work as a two-stage pipeline: optical_flow.AdvectingLoader advects batch i+1 on a side stream under the
-    # train step of batch i
-    raw2 = torch.from_numpy(advected_counts(batch=b, t=t_obs, channels=c, h=hw, w=hw, seed=4321)[0]).to(dev)
-    pv = batch["pv"]
-
-    def epoch(k):
-        for bt in of.AdvectingLoader(({"satellite": {"data": raw if i & 1 else raw2}, "pv": pv} for i in range(k)), n_future):
-            opt.zero_grad(set_to_none=True)
-            model.training_step(bt, 0).backward()
-            opt.step()
-
-    epoch(n)      # a whole epoch of warm-up: the side stream's allocator pool reaches its steady size (record_stream defers
-    torch.cuda.synchronize()      # the reuse of a block until the consumer is through with it; growing the pool synchronises)
-    t0 = time.perf_counter()
-    epoch(n)
-    torch.cuda.synchronize()
-    d = (time.perf_counter() - t0) / n
-    out["joined_train_step_pipelined"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1),
-                                          "workload": "the same, advection of batch i+1 on a side HIP stream under the train "
-                                                      "step of batch i (optical_flow.AdvectingLoader)"}
     del model, opt
     return out
 
@@ -853,6 +833,12 @@ def main():
                                           history_minutes=60, per_gpu_batch=b)
                         out["t19"]["whole_step_frac_of_bf16_mfma_peak"] = round(out["t19"]["samples_per_s"] * 25.27e9 / MFMA_BF16_PEAK, 4)
                     out["batch_sweep"] = measure_batch_sweep(dev, args.history_minutes)
+                    # the N = 1 anchor of the strong-scaling mode (--global-batch 512: what 8 GPUs split 64 samples each)
+                    sb = measure_batch_sweep(dev, args.history_minutes, batches=(512,), steps=5, warmup=2)["B=512"]
+                    out["strong_b512"] = dict(sb, n_gpus=1, global_batch=512,
+                                              note="python bench.py --gpus 1 --global-batch 512 times the same step as the headline line")
+                    if out["roofline"] is not None:
+                        out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()
                 out["other_models"] = measure_other_models(dev)

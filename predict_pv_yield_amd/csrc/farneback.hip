@@ -428,60 +428,6 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
   m[4] = __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3));
 }
 
-// fb_update_pixel without control flow and in two halves, for a wave that evaluates many pixels in a row
-// (fb_fused_iter_q_kernel): fb_gather_r1 reads the 2 x 2 neighbourhood of R1 at a clamped position whether or not the
-// displaced point lies inside the image, fb_update_pixel_finish does the arithmetic and selects the results -- the caller
-// issues the next pixel's reads before this pixel's arithmetic.  Same expressions and operation order on either side of
-// every select as in fb_update_pixel (interior pixels multiply by a border scale of exactly 1): bit-identical.
-struct FbGather { float v[20]; float fx, fy; bool inside; };
-__device__ __forceinline__ void fb_gather_r1(const float* __restrict__ R1, float dx, float dy, int x, int y, int width,
-                                             int height, FbGather& g) {
-  const int step1 = width * 5;
-  float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
-  const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-  g.fx = __fsub_rn(fx, (float)x1);
-  g.fy = __fsub_rn(fy, (float)y1);
-  g.inside = (unsigned)x1 < (unsigned)(width - 1) && (unsigned)y1 < (unsigned)(height - 1);
-  const float* ptr = R1 + (g.inside ? y1 * step1 + x1 * 5 : 0);
-#pragma unroll
-  for (int i = 0; i < 10; ++i) g.v[i] = ptr[i], g.v[10 + i] = ptr[step1 + i];
-}
-__device__ __forceinline__ void fb_update_pixel_finish(const float* __restrict__ R0, const FbGather& g, float dx, float dy, int x,
-                                                       int y, int width, int height, bool valid, float* m) {
-  const float fx = g.fx, fy = g.fy;
-  const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
-  const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
-#define PV_BILIN(c) \
-  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, g.v[c]), __fmul_rn(a01, g.v[5 + c])), __fmul_rn(a10, g.v[10 + c])), \
-            __fmul_rn(a11, g.v[15 + c]))
-  float r2 = PV_BILIN(0), r3 = PV_BILIN(1), r4 = PV_BILIN(2), r5 = PV_BILIN(3), r6 = PV_BILIN(4);
-#undef PV_BILIN
-  r4 = __fmul_rn(__fadd_rn(R0[2], r4), 0.5f);
-  r5 = __fmul_rn(__fadd_rn(R0[3], r5), 0.5f);
-  r6 = __fmul_rn(__fadd_rn(R0[4], r6), 0.25f);
-  r2 = g.inside ? r2 : 0.f;
-  r3 = g.inside ? r3 : 0.f;
-  r4 = g.inside ? r4 : R0[2];
-  r5 = g.inside ? r5 : R0[3];
-  r6 = g.inside ? r6 : __fmul_rn(R0[4], 0.5f);
-  r2 = __fmul_rn(__fsub_rn(R0[0], r2), 0.5f);
-  r3 = __fmul_rn(__fsub_rn(R0[1], r3), 0.5f);
-  r2 = __fadd_rn(r2, __fadd_rn(__fmul_rn(r4, dy), __fmul_rn(r6, dx)));
-  r3 = __fadd_rn(r3, __fadd_rn(__fmul_rn(r6, dy), __fmul_rn(r5, dx)));
-  auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
-  float scale = border(x);
-  scale = __fmul_rn(scale, border(width - x - 1));
-  scale = __fmul_rn(scale, border(y));
-  scale = __fmul_rn(scale, border(height - y - 1));
-  r2 = __fmul_rn(r2, scale); r3 = __fmul_rn(r3, scale); r4 = __fmul_rn(r4, scale);
-  r5 = __fmul_rn(r5, scale); r6 = __fmul_rn(r6, scale);
-  m[0] = valid ? __fadd_rn(__fmul_rn(r4, r4), __fmul_rn(r6, r6)) : 0.f;      // !valid: zero padding of the tile
-  m[1] = valid ? __fmul_rn(__fadd_rn(r4, r5), r6) : 0.f;
-  m[2] = valid ? __fadd_rn(__fmul_rn(r5, r5), __fmul_rn(r6, r6)) : 0.f;
-  m[3] = valid ? __fadd_rn(__fmul_rn(r4, r2), __fmul_rn(r6, r3)) : 0.f;
-  m[4] = valid ? __fadd_rn(__fmul_rn(r6, r2), __fmul_rn(r5, r3)) : 0.f;
-}
-
 // one pixel of cv::resize(prevFlow -> (dw, dh), INTER_LINEAR) * (1 / pyr_scale): the expressions of fb_flow_upsample_kernel
 typedef float fb_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ fb_f32x2_t fb_upsampled_flow(const float* __restrict__ src, size_t p, int sh, int sw, int x, int y,
@@ -604,7 +550,7 @@ typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt, int mosaic) {
   // G[64][64]; rows / columns >= n stay zero.  mosaic (n <= 32): the n x n matrix twice on the diagonal, at 0 and at 32 --
-  // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_fused_iter_q_kernel<.., true>)
+  // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_level_kernel<.., MOSAIC = true>)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 64; i += gridDim.x * blockDim.x) {
     int y = i >> 6, yp = i & 63;
     const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
@@ -980,388 +926,8 @@ __global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __r
   }
 }
 
-// ---- one whole Farneback iteration per launch for 64 x 64 tiles: UpdateMatrices + window blur + 2x2 solve --------------
-// The two-launch form writes M (5 floats per pixel and pair) and reads it back a few microseconds later, and its
-// UpdateMatrices launch gathers the four bilinear neighbours of R1 as 20 dword loads of 20-byte records per pixel (ten cache
-// lines per wave instruction).  Here M never leaves the chip and the gathers are LDS reads.  A workgroup owns a contiguous
-// range of pairs and has two kinds of waves:
-//   * waves 4..7 PRODUCE: they bring the second image's coefficient plane R1 (<= 80 KB) into LDS with LDS-direct loads,
-//     evaluate FarnebackUpdateMatrices (fb_update_pixel, the expressions of fb_update_matrices_kernel in the same order) for
-//     16 pixels per lane -- 4 quads of 4 consecutive columns, R0 and the flow read as 16-byte loads -- and keep the 80
-//     results in registers; channel by channel they split them into the three bf16 planes of the blur's A operand and write
-//     them into a double-buffered LDS image;
-//   * waves 0..3 MULTIPLY: the quadrant scheme of fb_tile_mfma_q_kernel (horizontal pass of both row blocks of the strip,
-//     vertical pass of the own row block, six bf16 partial products per f32 product), then the 2x2 solve and the flow store.
-// One barrier per channel (k = running channel number) hands an image over: before barrier k the producers wrote channel k
-// and the multiplying waves finished channel k-1, so the producers may overwrite the buffer of channel k-1 (= that of k+1)
-// right after it.  The same barriers order the producers among themselves: R1 of the next pair is requested after the
-// barriers of channels 0..3, a quarter each (every producer has finished the pair's gathers before it wrote channel 0), each
-// wave waits for its own requests before the barrier of channel 4, and the next pair's pixels are evaluated after that
-// barrier, under the multiplying waves' last channel and solve.
-// FLOW_SRC as in fb_update_matrices_kernel (0: flow_in is this level's flow -- the launch updates it in place, a pair's flow
-// is read in full by its producers before its multiplying waves store the new one; 1: the coarser level's flow, resized on
-// the fly; 2: zero).  Same arithmetic per output element as UpdateMatrices + fb_tile_mfma_q_kernel: bit-identical flows.
-#ifdef PV_DIAG_STAMPS
-__device__ unsigned long long fb_fused_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
-#endif
 typedef int fb_i32x4 __attribute__((ext_vector_type(4)));
-typedef float fb_f32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned char* fb_lds_ptr;
-// 16 bytes per lane from a raw buffer straight into LDS at lds_addr + 16 * lane (inline assembly: see w2_lds_dma16 in
-// conv3d_wgrad_bf16_v2.hip for why not the builtin); lanes whose voff is outside the descriptor write zeros
-__device__ __forceinline__ void fb_lds_dma16(uint32_t lds_addr, uint32_t voff, fb_i32x4 rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
-               : "memory");
-}
-template <int FLOW_SRC, bool MOSAIC>
-__global__ __launch_bounds__(512, 2) void fb_fused_iter_q_kernel(const float* __restrict__ R, const float* flow_in,
-                                                                 float* flow_out, const float* __restrict__ Gv,
-                                                                 const float* __restrict__ Gh, int height, int width,
-                                                                 long long n_pairs, long long pairs_per_group, int chain_f,
-                                                                 FbUpsample up) {
-  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
-  __shared__ __attribute__((aligned(16))) float R1s[T * T * 5];
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][3][PLANE];
-  __shared__ u32x4 GvS[2 * KS * 3][64];      // [mbo][ks][plane], lane-major
-  const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave8 >= 4;
-  const int col = lane & 31, half = lane >> 5;
-  const long long per_img = (long long)height * width;
-  // MOSAIC: levels up to 32 x 32 (height, width = the level's size).  A unit of work is FOUR consecutive pairs laid out as
-  // the 2 x 2 tiles of one 64 x 64 image: pair 4 u + 2 ty + tx at rows 32 ty.., columns 32 tx...  Gv / Gh are then block
-  // diagonal (fb_window_matrix_kernel), so the two matrix products below blur the four tiles independently -- the zero
-  // blocks add exact zeros -- and everything the multiplying waves do stays as it is; the producers address R0 / R1 / flow
-  // per tile.  p_lo .. p_hi count units.
-  constexpr int NP = MOSAIC ? 4 : 1;
-  constexpr int TILE_F = 32 * 32 * 5;      // floats of one tile's R1 slot in LDS
-  constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside the 2 GB descriptors below: reads zeros
-  const long long n_units = (n_pairs + NP - 1) / NP;
-  const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
-
-  for (int j = wave8; j < 2 * KS; j += 8) {      // Gv split operands, dealt to the eight waves
-    const int mb = j / KS, ks = j - mb * KS;
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
-    const FbSplit3 g = fb_split3(t);
-    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
-    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
-    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
-  }
-
-  // coefficient image i1 -> LDS, a quarter per producing wave (measured: the same requests issued by the multiplying waves in
-  // their waiting time cost them ~300 cycles apiece and the hand-over waits for the data: 825 -> 926 us per level)
-  const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
-  const int img_bytes = (int)per_img * 20;
-  const uint32_t lane16 = (uint32_t)lane * 16;
-  // not MOSAIC: chunks j_lo .. j_hi - 1 (of 20) of image i1[0]; MOSAIC: the whole images of tiles j_lo .. j_hi - 1 (of 4)
-  auto request_r1 = [&](const long long (&i1)[NP], long long unit, int j_lo, int j_hi) {
-    if constexpr (MOSAIC) {
-#pragma unroll
-      for (int t = j_lo; t < j_hi; ++t) {
-        if (unit * 4 + t >= n_pairs) continue;
-        const uintptr_t a = (uintptr_t)(R + i1[t] * per_img * 5);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int off = (4 * j + (wave8 & 3)) * 1024;
-          if (off < img_bytes) {
-            const uintptr_t ac = a + (uintptr_t)off;
-            fb_lds_dma16(r1_lds + (uint32_t)(t * TILE_F * 4 + off), lane16,
-                         (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
-          }
-        }
-      }
-    } else {
-      const uintptr_t a = (uintptr_t)(R + i1[0] * per_img * 5);
-#pragma unroll
-      for (int j = j_lo; j < j_hi; ++j) {      // 1 KB per wave instruction, the four waves interleaved
-        const int off = (4 * j + (wave8 & 3)) * 1024;
-        if (off < img_bytes) {      // one lane offset for all: the chunk's start goes into the descriptor, which still ends at the image
-          const uintptr_t ac = a + (uintptr_t)off;
-          fb_lds_dma16(r1_lds + (uint32_t)off, lane16, (fb_i32x4){(int)(uint32_t)ac, (int)((ac >> 32) & 0xffffu), img_bytes - off, 0x00020000});
-        }
-      }
-    }
-  };
-
-  if (producer) {
-    // ================================ producing waves ===================================================================
-    const int ptid = tid - 256;
-    // two sets of results: the pair being handed over and the next one, which is evaluated quad by quad between the
-    // hand-overs (a channel's 16 registers are free once it is written, so the two sets overlap in the register file)
-    float mA[16][5], mB[16][5];
-    fb_f32x4_t r0q[4][5], flq[4][2];
-    // raw buffer loads: one lane offset for R0 and one for the flow, the quad's rows in the scalar offset; a quad below the
-    // image reads zeros (one beside it is never used: its results are zero-filled).  MOSAIC: the lane's tile column picks one
-    // of two pairs, so the image / pair part of the address is per lane too (descriptors over the whole arrays)
-    const int m_tx = (ptid & 15) >> 3, m_xl0 = ((ptid & 15) & 7) * 4;      // MOSAIC: tile column, first local column of the quad
-    const uint32_t quad_px = (uint32_t)((ptid >> 4) * width + (MOSAIC ? m_xl0 : (ptid & 15) * 4));
-    const uint32_t r0_lane = quad_px * 20, fl_lane = quad_px * 8;
-    auto prefetch_quad = [&](long long unit, const long long (&i0)[NP], int e) {      // R0 and flow of pixels 4 e .. 4 e + 3
-      if constexpr (MOSAIC) {
-        const int ty = e >> 1, yl = (ptid >> 4) + 16 * (e & 1);
-        const long long pl = unit * 4 + 2 * ty + m_tx;
-        const bool ok = yl < height && m_xl0 < width && pl < n_pairs;
-        const long long img = m_tx ? i0[2 * ty + 1] : i0[2 * ty];
-        const uint32_t rows = (uint32_t)(16 * (e & 1) * width);
-        const uint32_t r0_off = ok ? (uint32_t)(img * img_bytes) + r0_lane + rows * 20 : NOT_THERE;
-        const uint32_t fl_off = ok ? (uint32_t)(pl * per_img * 8) + fl_lane + rows * 8 : NOT_THERE;
-        const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t flrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_off + 16 * i, 0, 0));
-        if constexpr (FLOW_SRC == 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_off + 16 * i, 0, 0));
-        }
-      } else {
-        const long long p = unit;
-        const __amdgpu_buffer_rsrc_t r0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0[0] * per_img * 5), 0, img_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t flrs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_in + (FLOW_SRC == 0 ? p * per_img * 2 : 0)), 0, (int)per_img * 8, 0x00020000);
-        const uint32_t rows = (uint32_t)(16 * e * width);
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-          r0q[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r0rs, r0_lane + 16 * i, rows * 20, 0));
-        if constexpr (FLOW_SRC == 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            flq[e][i] = __builtin_bit_cast(fb_f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(flrs, fl_lane + 16 * i, rows * 8, 0));
-        }
-      }
-    };
-    // FarnebackUpdateMatrices of quad e of pair p -> mo[4 e .. 4 e + 3]; pixel j's R1 neighbourhood is read while pixel
-    // j - 1 is computed
-    auto update_quad = [&](float (&mo)[16][5], long long unit, int e) {
-      // the lane's pixel coordinates, border scales, ... are the same for every pair: hidden from the loop-invariant code
-      // motion, which would otherwise keep dozens of them in registers around the whole pair loop
-      int pt = ptid;
-      asm volatile("" : "+v"(pt));
-      // (y, x0): the quad's position inside its image; p: its pair; R1t: its R1 in LDS
-      const int q = pt + 256 * e;
-      const int y = MOSAIC ? (q >> 4) & 31 : q >> 4, x0 = MOSAIC ? ((q & 15) & 7) * 4 : (q & 15) * 4;
-      const int tile = MOSAIC ? 2 * (q >> 9) + ((q & 15) >> 3) : 0;
-      const long long p = MOSAIC ? unit * 4 + tile : unit;
-      const float* R1t = R1s + tile * TILE_F;
-      const bool pair_there = !MOSAIC || p < n_pairs;
-      FbGather g[2];
-      float dxs[2], dys[2];
-      auto flow_of = [&](int j, float& fdx, float& fdy) {
-        fdx = 0.f, fdy = 0.f;
-        if constexpr (FLOW_SRC == 0) {
-          fdx = flq[e][j >> 1][2 * (j & 1)], fdy = flq[e][j >> 1][2 * (j & 1) + 1];
-        } else if constexpr (FLOW_SRC == 1) {
-          const fb_f32x2_t f = fb_upsampled_flow(flow_in, (size_t)(pair_there ? p : 0), up.sh, up.sw, min(x0 + j, width - 1),
-                                                 min(y, height - 1), up.inv_fx, up.inv_fy, up.mul);
-          fdx = f[0], fdy = f[1];
-        }
-      };
-      flow_of(0, dxs[0], dys[0]);
-      fb_gather_r1(R1t, dxs[0], dys[0], x0, y, width, height, g[0]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j + 1 < 4) {
-          flow_of(j + 1, dxs[(j + 1) & 1], dys[(j + 1) & 1]);
-          fb_gather_r1(R1t, dxs[(j + 1) & 1], dys[(j + 1) & 1], x0 + j + 1, y, width, height, g[(j + 1) & 1]);
-        }
-        float r0[5];
-#pragma unroll
-        for (int c = 0; c < 5; ++c) r0[c] = r0q[e][(5 * j + c) >> 2][(5 * j + c) & 3];
-        fb_update_pixel_finish(r0, g[j & 1], dxs[j & 1], dys[j & 1], x0 + j, y, width, height, pair_there && y < height && x0 + j < width, mo[4 * e + j]);
-        __builtin_amdgcn_sched_barrier(0);      // one pixel's reads ahead, not more (registers)
-      }
-    };
-    auto write_channel = [&](const float (&m)[16][5], int c, int buf) {
-      uint16_t* Xc = &Xs[buf][0][0];
-#pragma unroll
-      for (int e8 = 0; e8 < 2; ++e8) {
-        const float t[8] = {m[8 * e8][c], m[8 * e8 + 1][c], m[8 * e8 + 2][c], m[8 * e8 + 3][c],
-                            m[8 * e8 + 4][c], m[8 * e8 + 5][c], m[8 * e8 + 6][c], m[8 * e8 + 7][c]};
-        const FbSplit3 sp = fb_split3(t);
-        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
-#pragma unroll
-        for (int u2 = 0; u2 < 2; ++u2) {        // two quads of 4 consecutive columns
-          const int q = ptid + 256 * (2 * e8 + u2);
-          const int y = q >> 4, x = (q & 15) * 4;
-          *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u2], hw[2 * u2 + 1]};
-          *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u2], mw[2 * u2 + 1]};
-          *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u2], lw[2 * u2 + 1]};
-        }
-      }
-    };
-    // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
-    // range without a 64-bit division per pair: i0_run / q_run describe the next pair not yet handed out
-    long long i0_run, i1_unused;
-    fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
-    long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
-    auto take_unit = [&](long long (&i0)[NP], long long (&i1)[NP]) {
-#pragma unroll
-      for (int t = 0; t < NP; ++t) {
-        i0[t] = i0_run, i1[t] = i0_run + 1;
-        if (chain_f > 0) {
-          i0_run += 1;
-          if (++q_run == pairs_per_group) q_run = 0, i0_run += chain_f - pairs_per_group;      // the next stack's first frame
-        } else {
-          i0_run += 2;
-        }
-      }
-    };
-    long long i0a[NP], i1a[NP];
-    take_unit(i0a, i1a);
-    request_r1(i1a, p_lo, 0, MOSAIC ? 4 : 20);
-    prefetch_quad(p_lo, i0a, 0);
-    prefetch_quad(p_lo, i0a, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();      // R1 of the first unit (and GvS) in place
-    update_quad(mA, p_lo, 0);
-    prefetch_quad(p_lo, i0a, 2);
-    update_quad(mA, p_lo, 1);
-    prefetch_quad(p_lo, i0a, 3);
-    update_quad(mA, p_lo, 2);
-    update_quad(mA, p_lo, 3);
-    int k = 0;
-#ifdef PV_DIAG_STAMPS
-    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
-#endif
-    // pair p: its results mc are complete on entry; channel c is written before hand-over c, and between the hand-overs
-    // the next pair is prepared -- R1 requested after hand-overs 0 and 1 (every producer is through with this pair's R1
-    // when it arrives at hand-over 0; ~100 cycles per 1 KB request when the four waves issue together, so not in one
-    // place), waited for before hand-over 2, quad 0 evaluated after hand-over 2, quad 1 after 3, quads 2 and 3 after 4 (under
-    // the multiplying waves' last channel and solve); each quad's R0 / flow requested one step before its evaluation
-    auto pair_body = [&](float (&mc)[16][5], float (&mn)[16][5], long long p, auto more_tag) {
-      constexpr bool more = decltype(more_tag)::value;      // compile-time: a run-time test would keep both sets live throughout
-      long long i0n[NP], i1n[NP];
-      if constexpr (more) take_unit(i0n, i1n);
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        PV_STAMP(s0);
-        write_channel(mc, c, k & 1);
-        ++k;
-        if (c == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next R1 has landed
-        PV_STAMP(s1);
-        __syncthreads();
-        PV_STAMP(s2);
-        if constexpr (more) {
-          if (c == 0) request_r1(i1n, p + 1, 0, MOSAIC ? 2 : 10), prefetch_quad(p + 1, i0n, 0);
-          if (c == 1) request_r1(i1n, p + 1, MOSAIC ? 2 : 10, MOSAIC ? 4 : 20);
-          if (c == 2) prefetch_quad(p + 1, i0n, 1), update_quad(mn, p + 1, 0);
-          if (c == 3) prefetch_quad(p + 1, i0n, 2), update_quad(mn, p + 1, 1);
-          if (c == 4) prefetch_quad(p + 1, i0n, 3), update_quad(mn, p + 1, 2), update_quad(mn, p + 1, 3);
-        }
-        PV_STAMP(s3);
-#ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[2] += s2 - s1, dg[c < 2 ? 3 : 4] += s3 - s2;
-#endif
-      }
-#ifdef PV_DIAG_STAMPS
-      dg[7] += 1;
-#endif
-    };
-    // one copy of the body in the loop (the register moves at its end are ~1 % of a pair; two copies with the sets swapped
-    // would not fit the instruction cache next to the multiplying waves' loop), the last pair peeled
-    for (long long p = p_lo; p + 1 < p_hi; ++p) {
-      pair_body(mA, mB, p, std::true_type{});
-#pragma unroll
-      for (int n = 0; n < 16; ++n)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) mA[n][c] = mB[n][c];
-    }
-    pair_body(mA, mB, p_hi - 1, std::false_type{});
-#ifdef PV_DIAG_STAMPS
-    if (lane == 0 && blockIdx.x * 8 + wave8 < PV_DIAG_WAVES)
-      for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_fused_diag[(size_t)(blockIdx.x * 8 + wave8) * PV_DIAG_SLOTS + i] = dg[i];
-#endif
-    return;
-  }
-
-  // ================================ multiplying waves =====================================================================
-  const int wave = wave8, strip = wave & 1, mbo = wave >> 1;
-  FbSplit3 gh[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
-    gh[ks] = fb_split3(t);
-  }
-  __syncthreads();      // the producers' prologue barrier; GvS published
-  int k = 0;
-#ifdef PV_DIAG_STAMPS
-  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2;
-#endif
-  for (long long p = p_lo; p < p_hi; ++p) {
-    fb_v16f res[5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      PV_STAMP(s0);
-      __syncthreads();      // channel k is in its buffer
-      PV_STAMP(s1);
-      const uint16_t* Xc = &Xs[k & 1][0][0];
-      ++k;
-      fb_v16f u[2];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          FbSplit3 a;
-          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-          a.h = *reinterpret_cast<const bf16x8*>(xa);
-          a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
-          a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
-          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
-        const FbSplit3 b = fb_split3(t);
-        FbSplit3 g;
-        g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
-        g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
-        g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
-        res[c] = fb_mfma3(g, b, res[c]);
-      }
-      PV_STAMP(s2);
-#ifdef PV_DIAG_STAMPS
-      dg[0] += s1 - s0, dg[1] += s2 - s1;
-#endif
-    }
-    PV_STAMP(s0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // MOSAIC: this wave's quadrant IS tile (mbo, strip) = pair 4 p + 2 mbo + strip, (y, x) local to it
-      const int y = (MOSAIC ? 0 : 32 * mbo) + fb_acc_row(r, half), x = (MOSAIC ? 0 : 32 * strip) + col;
-      const long long pr = MOSAIC ? p * 4 + 2 * mbo + strip : p;
-      if (y < height && x < width && pr < n_pairs) {
-        double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
-        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-        double idet = __ddiv_rn(1.0, det);
-        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-        float* fl = flow_out + (pr * per_img + (long long)y * width + x) * 2;
-        fl[0] = fxv;
-        fl[1] = fyv;
-      }
-    }
-    PV_STAMP(s1);
-#ifdef PV_DIAG_STAMPS
-    dg[2] += s1 - s0, dg[7] += 1;
-#endif
-  }
-#ifdef PV_DIAG_STAMPS
-  if (lane == 0 && blockIdx.x * 8 + wave8 < PV_DIAG_WAVES)
-    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_fused_diag[(size_t)(blockIdx.x * 8 + wave8) * PV_DIAG_SLOTS + i] = dg[i];
-#endif
-}
-
 // ---- one whole Farneback iteration per launch, second form (round 4): lane = column, f16 x 2 operands, 4 + 8 waves ------
 // What the counters and stamps of fb_fused_iter_q_kernel said (profiles/r03): its four producing waves are the critical
 // path, their R1 gathers hit the LDS four ways (20-byte records, a wave's four rows on the same banks), the multiplying
@@ -2400,19 +1966,20 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     else if (fabs(inv_fx - 2.0) < 2.220446049250313e-16 && fabs(inv_fy - 2.0) < 2.220446049250313e-16) mode = 1;
     else mode = 2;
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
-    // Levels whose starting flow is formed on the fly: one launch per iteration does UpdateMatrices, the window blur and the
-    // solve; M is never written.  33..64-pixel levels: one pair per 64 x 64 tile; levels up to 32 x 32: four pairs per tile
-    // (MOSAIC; its buffer offsets are 31-bit).  Rows of whole 4-pixel quads: R and the flow move as 16-byte vectors.
+    // Levels up to 64 x 64 whose source images are up to 64 x 64 (the PV-site tiles): ONE launch per level does every
+    // iteration -- UpdateMatrices, the window blur and the solve (fb_level_kernel); M is never written.  33..64-pixel
+    // levels: one pair per 64 x 64 tile; levels up to 32 x 32: four pairs per tile (MOSAIC; its buffer offsets are 31-bit).
+    // Rows of whole 4-pixel quads and a 16-byte-aligned flow: R and the flow move as 16-byte vectors.  Everything else (a
+    // width that is no multiple of 4, larger source images, PV_FARNEBACK_TWO_LAUNCH_ITERATION=1) takes the two-launch
+    // form below: UpdateMatrices writes M, the window blur + solve read it back.
     const bool small_level = lh <= 32 && lw <= 32;
-    const bool fused_iter = tile_path && fuse_init && (lw & 3) == 0 && !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
+    const bool polyexp_tile = h <= 64 && w <= 64 && smooth_sz <= 63;
+    const bool fused_iter = tile_path && fuse_init && polyexp_tile && (lw & 3) == 0 && ((uintptr_t)flow & 15) == 0 &&
+                            !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
                             (!small_level || ((long long)n_img * lpx * 20 < 0x7fffffffLL && n_pairs * lpx * 8 < 0x7fffffffLL &&
                                               (long long)prev_h * prev_w * n_pairs * 8 < 0x7fffffffLL &&
                                               !getenv("PV_FARNEBACK_TWO_LAUNCH_SMALL_LEVELS")));
-    // fb_iter_kernel (planar R, f16 x 2 operands) unless the round-3 kernel is asked for (A/B on one device) or its
-    // preconditions fail: the fused prep + PolyExp kernel must have written R planar (source images up to 64 x 64), flow rows
-    // are stored as 16-byte vectors
-    const bool polyexp_tile = h <= 64 && w <= 64 && smooth_sz <= 63;
-    const bool iter_v2 = fused_iter && polyexp_tile && ((uintptr_t)flow & 15) == 0 && !getenv("PV_FARNEBACK_FUSED_V1");
+    const bool iter_v2 = fused_iter;      // R pair-planar for the level kernel, [h][w][5] for the two-launch form
     stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
     if (polyexp_tile) {
       const unsigned grid = (unsigned)std::min<long long>(n_img, 4096);
@@ -2449,16 +2016,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
   hipLaunchKernelGGL((fb_level_kernel<INIT, MOS, SINGLE>), dim3(grid), dim3(768), 0, st, (const float*)R,                 \
                      (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
                      (long long)pairs_per_group, chain_f, up, (int)p->iterations)
-#define PV_FUSED_ITER(SRC, FLOW_IN)                                                                                       \
-  do {                                                                                                                    \
-    if (small_level)                                                                                                      \
-      hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, true>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
-                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((fb_fused_iter_q_kernel<SRC, false>), dim3(grid), dim3(512), 0, st, (const float*)R, (const float*)(FLOW_IN), \
-                         flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs, (long long)pairs_per_group, chain_f, up); \
-  } while (0)
-      if (iter_v2) {      // one launch for all of the level's iterations
+      {      // one launch for all of the level's iterations
         const bool single = p->iterations == 1;
         if (prev_flow) {
           if (small_level) { if (single) PV_LEVEL(1, true, true); else PV_LEVEL(1, true, false); }
@@ -2467,14 +2025,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
           if (small_level) { if (single) PV_LEVEL(2, true, true); else PV_LEVEL(2, true, false); }
           else { if (single) PV_LEVEL(2, false, true); else PV_LEVEL(2, false, false); }
         }
-      } else
-      for (int it = 0; it < p->iterations; ++it) {
-        if (it > 0) PV_FUSED_ITER(0, flow);
-        else if (prev_flow) PV_FUSED_ITER(1, prev_flow);
-        else PV_FUSED_ITER(2, nullptr);
       }
 #undef PV_LEVEL
-#undef PV_FUSED_ITER
       prev_flow = flow;
       prev_w = lw;
       prev_h = lh;
@@ -2554,9 +2106,6 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
 }  // extern "C"
 
 #ifdef PV_DIAG_STAMPS
-extern "C" int pv_diag_read_fb_fused(unsigned long long* host, size_t n) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_fused_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
 extern "C" int pv_diag_read_fb_iter(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_iter_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }

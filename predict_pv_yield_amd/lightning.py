@@ -245,8 +245,10 @@ class Trainer:
                  num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
                  default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, **unused):
         self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
-        # config 3 only (Model(future_frames="optical_flow") fed raw int16 counts): run the optical-flow advection of batch
-        # i+1 on a side HIP stream under the train step of batch i (optical_flow.AdvectingLoader); same batches, bit for bit
+        # config 3 only (Model(future_frames="optical_flow") fed raw int16 counts): advect in the loader wrapper
+        # (optical_flow.AdvectingLoader) instead of inside the model's forward; same batches, bit for bit.  The name is
+        # historical: rounds 2-3 ran the wrapper's advection on a side HIP stream, which round 4 removed (it bought
+        # 3 % at best and cost 50 % on one device; optical_flow.AdvectingLoader's docstring)
         self.advect_on_side_stream = bool(advect_on_side_stream)
         self.fast_dev_run = bool(fast_dev_run)
         self.callbacks: List[Callback] = list(callbacks or [])
@@ -402,7 +404,7 @@ class Trainer:
 
     def _train_batches(self, loader, model, lim):
         """The epoch's batches on the device; with advect_on_side_stream (and a model / batch pair of config 3) the advection
-        pipeline of the next batch runs one batch ahead on its own stream."""
+        pipeline runs in the loader wrapper (optical_flow.AdvectingLoader), on the training stream."""
         def moved():
             for i, batch in enumerate(loader):
                 if lim is not None and i >= lim:

@@ -104,7 +104,7 @@ class Model(BaseModel):
     def _satellite_input(self, x: BatchML) -> torch.Tensor:
         sat = x.satellite.data
         if self.future_frames == "optical_flow":
-            if getattr(sat, "_pv_advected", False):      # optical_flow.AdvectingLoader already ran the pipeline (side stream)
+            if getattr(sat, "_pv_advected", False):      # optical_flow.AdvectingLoader already ran the pipeline
                 return sat
             if sat.dtype == torch.int16:
                 # config 3 proper: the batch carries the OBSERVED frames only, as raw 10-bit counts in

@@ -200,63 +200,29 @@ def replace_future_frames_with_flow(sat_data: torch.Tensor, n_future: int, borde
     return out
 
 
-_SIDE_STREAMS = {}
-
-
 class AdvectingLoader:
     """Wraps an iterable of config-3 batches (dicts whose batch["satellite"]["data"] holds the OBSERVED frames as raw
     int16 counts [B, T_obs, C, H, W]) and yields the same batches with that entry replaced by the advected model input
-    [B, C, T_obs + n_future, H, W] -- computed ONE BATCH AHEAD on a side HIP stream, so the Farneback / remap pipeline
-    of batch i+1 runs under the train step of batch i (the reference fans `compute_optical_flow` out to a process pool
-    in front of training, notebooks/13_...ipynb:175-240; here the overlap is two streams of one GPU).  The tensor that
-    is handed over is tagged so that Model(future_frames="optical_flow") takes it as is; results are bit-identical to the
-    inline call.  Measured at B = 32 (tools/overlap_flow_train.py): 4.03 -> 3.85 ms per batch -- both stages fill the
-    chip, the gain is what their stalls leave each other."""
+    [B, C, T_obs + n_future, H, W] (the reference fans `compute_optical_flow` out to a process pool in front of training,
+    notebooks/13_...ipynb:175-240).  The tensor that is handed over is tagged so that
+    Model(future_frames="optical_flow") takes it as is; results are bit-identical to the inline call.
 
-    def __init__(self, loader, n_future: int, stream: Optional[torch.cuda.Stream] = None, **advect_kwargs):
+    The advection runs on the CONSUMER's stream, right before the batch is yielded.  Rounds 2-3 ran it one batch ahead on a
+    side HIP stream under the train step of the previous batch: both stages fill the chip, so the overlap bought 3 % at best
+    (3.04-3.16 against 3.03-3.24 ms per batch) and on the round-3 driver's device it cost 50 % (4.97 against 3.24 ms:
+    the side stream's allocator pool, record_stream's deferred reuse).  A mode that cannot beat the plain call by 5 % is not
+    worth a second stream's failure modes: removed in round 4."""
+
+    def __init__(self, loader, n_future: int, **advect_kwargs):
         self.loader, self.n_future, self.kw = loader, n_future, advect_kwargs
-        self.stream = stream
 
     def __len__(self):
         return len(self.loader)
 
-    def _launch(self, batch):
-        sat = batch["satellite"]["data"]
-        consumer = torch.cuda.current_stream(sat.device)
-        self.stream.wait_stream(consumer)          # the raw batch may have been produced on the consumer's stream
-        with torch.cuda.stream(self.stream):
-            out = advect_future_frames(sat, self.n_future, **self.kw)
-            done = torch.cuda.Event()
-            done.record(self.stream)
-        out._pv_advected = True
-        new = dict(batch)
-        new["satellite"] = dict(batch["satellite"], data=out)
-        return new, done, sat
-
     def __iter__(self):
-        it = iter(self.loader)
-        try:
-            first = next(it)
-        except StopIteration:
-            return
-        if self.stream is None:       # one side stream per device for the life of the process: the caching allocator keeps a
-            dev = first["satellite"]["data"].device     # pool per stream, a fresh stream per epoch would grow it every time
-            self.stream = _SIDE_STREAMS.get(dev)
-            if self.stream is None:
-                self.stream = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
-        pending = self._launch(first)
-        for nxt in it:
-            cur, done, raw = pending
-            consumer = torch.cuda.current_stream(raw.device)
-            consumer.wait_event(done)
-            cur["satellite"]["data"].record_stream(consumer)
-            raw.record_stream(self.stream)
-            pending = self._launch(nxt)           # batch i+1 starts before batch i is consumed
-            yield cur
-        cur, done, raw = pending
-        consumer = torch.cuda.current_stream(raw.device)
-        consumer.wait_event(done)
-        cur["satellite"]["data"].record_stream(consumer)
-        raw.record_stream(self.stream)
-        yield cur
-
+        for batch in self.loader:
+            out = advect_future_frames(batch["satellite"]["data"], self.n_future, **self.kw)
+            out._pv_advected = True
+            new = dict(batch)
+            new["satellite"] = dict(batch["satellite"], data=out)
+            yield new

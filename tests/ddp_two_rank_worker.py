@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_ddp.py: one data-parallel rank training the reduced Conv3D model for a few steps in a given
 large-gradient mode and saving the consolidated parameters of rank 0.  Either one of two ranks that SHARE the single GPU of
-the test box (gloo for the collectives, PV_SINGLE_DEVICE=1), or the only rank of a one-rank RCCL group
+the test box (gloo for the collectives, PV_SINGLE_DEVICE=1; WORLD_SIZE 2 or 8, PV_TEST_GLOBAL_BATCH samples split among them), or the only rank of a one-rank RCCL group
 (WORLD_SIZE=1, PV_DIST_SINGLE_RANK=1, backend "nccl": the collectives of the N > 1 path really run through RCCL).
 The process group is initialised BEFORE anything touches the GPU.
 Usage: python ddp_two_rank_worker.py <mode> <out.pt> <steps>"""
@@ -34,9 +34,10 @@ def main():
     opt.set_large_grad_mode(mode)
     sync = D.OverlappedGradSync(model, large_numel=model.fc1.weight.numel())
     g = torch.Generator().manual_seed(7)
-    sat = torch.randn(4, 11, 25, 16, 16, generator=g)
-    pv = torch.rand(4, 25, 128, generator=g)
-    lo, hi = D.shard_range(4)             # each rank trains on its half of the global batch
+    n_global = int(os.environ.get("PV_TEST_GLOBAL_BATCH", "4"))
+    sat = torch.randn(n_global, 11, 25, 16, 16, generator=g)
+    pv = torch.rand(n_global, 25, 128, generator=g)
+    lo, hi = D.shard_range(n_global)      # each rank trains on its contiguous share of the global batch
     batch = {"satellite": {"data": sat[lo:hi].to(dev)}, "pv": {"pv_yield": pv[lo:hi].to(dev)}}
     losses = []
     for _ in range(steps):

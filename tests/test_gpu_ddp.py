@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_two_ranks(mode, out_path, steps=3):
+def _run_two_ranks(mode, out_path, steps=3, world=2, global_batch=4):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1")
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_TEST_GLOBAL_BATCH=str(global_batch))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_two_rank_worker.py"), mode, out_path,
                                        str(steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -119,3 +119,64 @@ def test_rccl_branches_run_on_one_rank(device, tmp_path):
         assert run["losses"] == losses
         for k, v in model.state_dict().items():
             assert torch.equal(v.cpu(), run["state"][k]), (run["mode"], k)
+
+
+def test_eight_ranks_on_one_gpu_sharded_equals_allreduce_and_follows_one_process(device, tmp_path):
+    """The 8-GPU job's shape on the one GPU of the test box: 8 ranks (gloo, PV_SINGLE_DEVICE=1), a global batch of 8 samples
+    split one per rank (distributed.shard_range, the --global-batch rule of bench.py), fc1's 16 rows sharded two per rank.
+    The row-sharded exchange must give the bits of the bf16 all-reduce, and both must follow a single process that trains
+    on the whole batch within the bounds of the two-rank test (eight bf16 addends instead of two: same bounds hold)."""
+    a = _run_two_ranks("bf16", str(tmp_path / "allreduce8.pt"), world=8, global_batch=8)
+    b = _run_two_ranks("sharded", str(tmp_path / "sharded8.pt"), world=8, global_batch=8)
+    assert a["world"] == 8 and b["world"] == 8 and a["mode"] == "bf16" and b["mode"] == "sharded"
+    assert a["losses"] == b["losses"]
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), k
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+    from tests.ddp_two_rank_worker import SMALL
+    old = HipAdam.FUSE_MIN_NUMEL
+    HipAdam.FUSE_MIN_NUMEL = 1
+    try:
+        torch.manual_seed(518)
+        model = Model(**SMALL, precision="bf16").to(device)
+        opt = model.configure_optimizers()
+        opt.set_large_grad_mode("bf16")
+        g = torch.Generator().manual_seed(7)
+        sat, pv = torch.randn(8, 11, 25, 16, 16, generator=g), torch.rand(8, 25, 128, generator=g)
+        batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            model.training_step(batch, 0).backward()
+            opt.step()
+    finally:
+        HipAdam.FUSE_MIN_NUMEL = old
+    for k, v in model.state_dict().items():
+        d = (v.cpu() - b["state"][k]).abs()
+        whole_step = (d > 5e-4).float().mean().item()
+        assert whole_step <= 0.02 and d.mean().item() <= 0.3 * 5e-4, (k, whole_step, d.mean().item())
+
+
+def test_bench_global_batch_path_with_eight_ranks_on_one_gpu(device, tmp_path):
+    """bench.py --gpus 8 --global-batch 64 as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in
+    the environment), on the one GPU of the test box with gloo: the strong-scaling branch (shard_range of the global batch,
+    negotiate_grad_sync, the sharded exchange of the full 128 M-parameter fc1, max-over-ranks timing) runs to its JSON
+    line before an 8-GPU node ever sees it."""
+    import json
+    port = _free_port()
+    root = os.path.dirname(HERE)
+    procs = []
+    for rank in range(8):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--global-batch", "64",
+                                       "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    line = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["global_batch"] == 64
+    assert line["config"]["per_gpu_batch"] == 8 and "sharded" in line["config"]["parallelism"] or "bf16" in line["config"]["parallelism"]
+    assert line["value"] > 0 and line["train_nmae_last_step"] == line["train_nmae_last_step"]      # finite
+    assert all(o.decode().strip() == "" for o, _ in outs[1:]), "only rank 0 prints"

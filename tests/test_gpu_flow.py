@@ -299,7 +299,7 @@ def test_errors_are_loud(device):
 
 @pytest.mark.gpu
 def test_advecting_loader_matches_inline_pipeline(device):
-    """optical_flow.AdvectingLoader (advection one batch ahead on a side stream) hands out exactly what the inline call
+    """optical_flow.AdvectingLoader (the advection in front of the model, on the training stream) hands out exactly what the inline call
     computes, for every batch and in order, and Model(future_frames="optical_flow") consumes the tagged tensor as is."""
     from predict_pv_yield_amd import optical_flow as of
     g = torch.Generator(device=device).manual_seed(7)

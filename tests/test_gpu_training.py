@@ -392,9 +392,10 @@ def test_tiled_moments_are_private_to_the_one_pass_backward(device, monkeypatch)
 
 
 @pytest.mark.gpu
-def test_trainer_advects_on_a_side_stream(device):
-    """Trainer(advect_on_side_stream=True) on config 3 (raw int16 counts -> Model(future_frames="optical_flow")): the same
-    parameters after the same batches as the inline pipeline, bit for bit."""
+def test_trainer_advects_in_the_loader_wrapper(device):
+    """Trainer(advect_on_side_stream=True) (optical_flow.AdvectingLoader in front of the model; the side stream itself was
+    removed in round 4) on config 3 (raw int16 counts -> Model(future_frames="optical_flow")): the same parameters after
+    the same batches as the advection inside the model's forward, bit for bit."""
     import copy
     from predict_pv_yield_amd.lightning import Trainer
     from predict_pv_yield_amd.models.conv3d.model import Model

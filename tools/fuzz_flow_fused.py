@@ -1,4 +1,6 @@
-"""Random sizes / parameters: the fused Farneback iteration (both forms) against the two-launch form, bit for bit."""
+"""Random sizes / parameters: the level kernel (one launch per pyramid level, f16 x 2 blur operands) against the two-launch
+form (bf16 x 3 operands, f64 solve): <= 2e-5 px (bit for bit where the width is no multiple of 4: same kernels), and the
+same pairs as stacks and as separate prev / next tensors bit for bit."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,7 +31,8 @@ for case in range(n_cases):
         got_pairs = K.farneback_pairs(prev, nxt, **kw)
     finally:
         os.environ.pop("PV_FARNEBACK_TWO_LAUNCH_ITERATION", None)
-    ok = torch.equal(got, ref) and torch.equal(got_pairs.reshape(ref.shape), ref) and bool(torch.isfinite(got).all())
+    close = torch.equal(got, ref) if w % 4 else float((got - ref).abs().max()) <= 2e-5
+    ok = close and torch.equal(got_pairs.reshape(got.shape), got) and bool(torch.isfinite(got).all())
     if not ok:
         bad += 1
         print("MISMATCH", (h, w, t, stacks), kw, int((got != ref).sum()), float((got - ref).abs().max()))
