@@ -468,17 +468,24 @@ def linear_bwd_f32(x, weight, dy, y_mask, need_dx=True):
     return dx, dw, db
 
 
+LINEAR_FWD_MAX_ROWS = 128      # pv_linear_fwd_bf16: rows of x per call
+
+
 def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
     require_cuda(x_bf16, w_bf16, bias)
     m, k = x_bf16.shape
     n = w_bf16.shape[0]
     need = c_sz(0)
     lib = get_lib()
-    check(lib.pv_linear_bf16_workspace_bytes(m, n, k, ctypes.byref(need)), "pv_linear_bf16_workspace_bytes")
+    check(lib.pv_linear_bf16_workspace_bytes(min(m, LINEAR_FWD_MAX_ROWS), n, k, ctypes.byref(need)), "pv_linear_bf16_workspace_bytes")
     ws = _workspace("linear_bf16", need.value, x_bf16.device)
     y = torch.empty((m, n), dtype=torch.float32, device=x_bf16.device)
-    check(lib.pv_linear_fwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(bias), ptr(y), m, n, k, int(relu), ptr(ws), ws.numel(),
-                                 current_stream_ptr()), "pv_linear_fwd_bf16")
+    # the kernel takes up to 128 rows per call (its x tile lives in LDS); larger batches (bench.py --global-batch 512 on one
+    # GPU: the strong-scaling anchor) go through in row blocks, each one its own stream over the weight
+    for r0 in range(0, m, LINEAR_FWD_MAX_ROWS):
+        rows = min(LINEAR_FWD_MAX_ROWS, m - r0)
+        check(lib.pv_linear_fwd_bf16(ptr(x_bf16[r0:r0 + rows]), ptr(w_bf16), ptr(bias), ptr(y[r0:r0 + rows]), rows, n, k, int(relu),
+                                     ptr(ws), ws.numel(), current_stream_ptr()), "pv_linear_fwd_bf16")
     return y
 
 
