@@ -527,7 +527,7 @@ def learnable_task(n, t_frames, seed):
     return sat, pv
 
 
-def seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail, hip_val_factory=None, hip_seeds=(1, 2, 3), oracle_seeds=(1,)):
+def seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail, hip_seeds=(1, 2, 3), oracle_seeds=(1,)):
     """The matched-training figure (mean validation NMAE over the tail checkpoints) for further seeds: other initial weights
     and other batches.  HIP bf16 and HIP fp32 for every seed of hip_seeds; the CPU oracle only for oracle_seeds (50 s each)."""
     from oracle import conv3d_oracle as co
@@ -719,9 +719,14 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
                  "max_rel_diff_hip_fp32_vs_oracle": round(rel(early["fp32"], early["oracle"]), 5),
                  "max_rel_diff_hip_bf16_vs_oracle": round(rel(early["bf16"], early["oracle"]), 5),
                  "first_4_steps_hip_fp32_vs_oracle": round(rel(early["fp32"][:4], early["oracle"][:4]), 6),
-                 "first_4_steps_hip_bf16_vs_oracle": round(rel(early["bf16"][:4], early["oracle"][:4]), 6)}
+                 "step_1_hip_bf16_vs_oracle": round(rel(early["bf16"][:1], early["oracle"][:1]), 7),
+                 "step_2_hip_bf16_vs_oracle": round(rel(early["bf16"][1:2], early["oracle"][1:2]), 6),
+                 "note": "step 1 compares forwards on identical weights; from step 2 on Adam's first updates (lr * sign of the "
+                         "gradient for every one of 128 M weights) turn bf16 rounding of near-zero gradients into whole steps of "
+                         "opposite sign, so the bf16 run's losses leave the f32 runs' by percents within a few steps while the "
+                         "two f32 runs stay within 1e-3 of each other for all 16"}
     # (ii) more seeds for the two HIP sides (cheap) and one more for the oracle: mean +- standard error at the common step count
-    seeds = seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail, hip_val_factory=None)
+    seeds = seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail)
     seeds["hip_bf16"].insert(0, b_mean), seeds["hip_fp32"].insert(0, f_mean), seeds["oracle_f32_cpu"].insert(0, o_mean)
     import statistics
     se = lambda v: (statistics.stdev(v) / len(v) ** 0.5) if len(v) > 1 else float("nan")
@@ -731,11 +736,14 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
     se_bf = (se(seeds["hip_bf16"]) ** 2 + se(seeds["hip_fp32"]) ** 2) ** 0.5
     # (iii) same weights, two scorers (the oracle's own forward on the CPU and the HIP fp32 forward)
     same_w = abs(own - oracle_curve[eval_at[-1]]) / own
-    # bounds: twice what the committed collections show (profiles/r04/README.md); a bf16 path that lost a further bit of
-    # operand precision, or an f32 path that lost accumulation precision, breaks the early-loss bounds; a forward that
-    # drifted from the oracle's breaks the same-weights bound
+    # bounds: about twice what the committed collection shows (profiles/r04/: f32 8.1e-5 over 4 steps and 6.4e-4 over 16; bf16
+    # 2e-6 at step 1 and 6.1e-3 at step 2; the kernels are deterministic, so these figures repeat to the digit).  A bf16 path
+    # that lost a further bit of operand precision doubles its step-2 figure; an f32 path that lost accumulation precision
+    # breaks the f32 bounds; a forward that drifted from the oracle's breaks step 1 and the same-weights bound
     checks = {"early_loss_first_4_steps_hip_fp32_vs_oracle <= 2e-4": early_cmp["first_4_steps_hip_fp32_vs_oracle"] <= 2e-4,
-              "early_loss_first_4_steps_hip_bf16_vs_oracle <= 1e-2": early_cmp["first_4_steps_hip_bf16_vs_oracle"] <= 1e-2,
+              "early_loss_16_steps_hip_fp32_vs_oracle <= 2e-3": early_cmp["max_rel_diff_hip_fp32_vs_oracle"] <= 2e-3,
+              "early_loss_step_1_hip_bf16_vs_oracle <= 2e-5": early_cmp["step_1_hip_bf16_vs_oracle"] <= 2e-5,
+              "early_loss_step_2_hip_bf16_vs_oracle <= 1.2e-2": early_cmp["step_2_hip_bf16_vs_oracle"] <= 1.2e-2,
               "same_weights_two_scorers <= 1e-4": same_w <= 1e-4,
               "seed_means_hip_bf16_vs_hip_fp32 within 3 standard errors": d_bf <= 3.0 * se_bf}
     val["early_train_loss"] = early_cmp
