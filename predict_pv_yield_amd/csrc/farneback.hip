@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void fb_polyexp_h_kernel(const float* __restri
 // 64 KB of LDS (the first PolyExp plane reuses the buffer of the blurred image, dead by then) and <= 64 registers: TWO
 // 16-wave workgroups share a CU, so one's barrier-separated phases overlap the other's.  (Round 4 tried four pixels of a
 // row per thread with 16-byte window reads and 8-wave workgroups: no faster -- 254 against 198 us at level 0 -- the phases
-// are short and barrier-separated, and half the waves cover each other's LDS round trips half as well.)
+// are short and barrier-separated, and half the waves cover each other's LDS round trips half as well; and planes padded with
+// replicated borders so that every tap is an immediate offset, taps unrolled over a template parameter: 178 against 156 us --
+// at 64 registers the unrolled taps spill.)
 constexpr int FB_PP_NT = 1024;
 typedef float fb_pp_f2 __attribute__((ext_vector_type(2)));
 template <bool F64_ACC>      // F64_ACC: the horizontal pass on double accumulators (the reference's); else f32 with fused multiply-adds
@@ -1558,51 +1560,32 @@ __global__ __launch_bounds__(768) void fb_level_kernel(const float* __restrict__
         PV_STAMP(s1);
         const uint16_t* Xc = &Xs[k & 1][0][0];
         ++k;
-        // first product, 8 groups (row block mb, k-step ks) of three matrix instructions each; the A operand of group g + 1 is
-        // read from LDS before group g's instructions are issued (the compiler's own order read, waited and multiplied group
-        // by group: eight exposed LDS round trips per channel)
         fb_v16f u[2];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
-        auto load_a = [&](int g) {
-          FbSplit2 a;
-          const uint16_t* xa = Xc + (32 * (g >> 2) + col) * XS + 16 * (g & 3) + 8 * half;
-          a.h = *reinterpret_cast<const fb_f16x8*>(xa);
-          a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
-          return a;
-        };
-        FbSplit2 a_cur = load_a(0);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-          FbSplit2 a_nxt = a_cur;
-          if (g + 1 < 8) a_nxt = load_a(g + 1);
-          u[g >> 2] = fb_mfma2(a_cur, gv[g & 3], u[g >> 2]);
-          a_cur = a_nxt;
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // this group: the next group's two LDS reads,
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      // then its own three matrix instructions
+          for (int ks = 0; ks < KS; ++ks) {
+            FbSplit2 a;
+            const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+            a.h = *reinterpret_cast<const fb_f16x8*>(xa);
+            a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
+            u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
-        // second product: the A operand (Gh, from LDS) of step ks + 1 is read before step ks's split and instructions
-        auto load_g = [&](int ks) {
-          FbSplit2 g;
-          g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
-          g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
-          return g;
-        };
-        FbSplit2 g_cur = load_g(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          FbSplit2 g_nxt = g_cur;
-          if (ks + 1 < KS) g_nxt = load_g(ks + 1);
           float t[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
           const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
-          res[c] = fb_mfma2(g_cur, b, res[c]);
-          g_cur = g_nxt;
+          FbSplit2 g;
+          g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
+          g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
+          res[c] = fb_mfma2(g, b, res[c]);
         }
         PV_STAMP(s2);
 #ifdef PV_DIAG_STAMPS
