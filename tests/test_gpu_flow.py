@@ -271,6 +271,19 @@ def test_fused_iteration_against_the_two_launch_form(device, monkeypatch, h, w, 
     assert np.abs(fused_stack[2, 0].cpu().numpy() - ref).max() <= 1e-3
 
 
+def test_level_kernel_repeated_launches_give_identical_bits(device):
+    """1 200 pairs (4-5 units per workgroup, the unit-boundary overlap of fb_level_kernel in play), ten launches: identical
+    bits every time.  (Round 4: a scheduling hint in the multiplying waves' operand reads made repeated launches differ by
+    ~1e-6 px -- a read of a hand-over buffer ahead of its barrier; tools/stress_flow_fused.py is the longer form of this.)"""
+    K = _ops()
+    raw, _ = advected_counts(batch=300, t=3, channels=2, h=64, w=64, seed=11)
+    stacks = np.ascontiguousarray(raw.transpose(0, 2, 1, 3, 4)).reshape(600, 3, 64, 64)
+    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(stacks, 0)[0]).to(device)
+    first = K.farneback_stack(u8)
+    for _ in range(10):
+        assert torch.equal(K.farneback_stack(u8), first)
+
+
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 5, 3, 8, 8), (1, 12, 11, 64, 64), (3, 2, 1, 4, 6)])
 def test_prepare_stacks_equals_permute_u8_normalise(device, dtype, shape):
