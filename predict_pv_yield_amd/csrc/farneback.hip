@@ -1642,6 +1642,457 @@ __global__ __launch_bounds__(768) void fb_level_kernel(const float* __restrict__
 #endif
 }
 
+// ---- one launch per pyramid level, second form: UNIFORM waves -----------------------------------------------------------
+// What fb_level_kernel's stamps and counters said: its two kinds of waves take turns inside a unit anyway (iteration it + 1
+// needs iteration it's flow), a stage is a serial chain of 28-30 000 cycles, and at three waves per SIMD (168 registers) a
+// unit's R0 and the flow between two iterations do not fit in registers: R0 is read again from memory for every iteration
+// (0.9 of the launch's 1.9 GB) and the flow goes through memory and back.  Here a 512-thread workgroup (two waves per SIMD,
+// 256 registers) does every phase with ALL eight waves:
+//   P  UpdateMatrices: wave w owns rows 8 w .. 8 w + 7, a lane one column (fb_level_kernel's G and F, same expressions); the
+//      unit's R0 stays in 40 registers through all its iterations, R1 in LDS;
+//   M  the window blur: wave (strip, mbo, g) multiplies for block (strip, mbo) the channels of group g (g = 0: 0, 1, 2;
+//      g = 1: 3, 4) -- the two waves of a SIMD cover each other's LDS reads and operand splits.  Channels are handed over two
+//      at a time through a double-buffered LDS image (rounds (0, 3), (1, 4), (2, -)); both window operands live in registers;
+//   S  group 1 passes its two blurred channels to group 0 through LDS, group 0 solves and leaves the flow in LDS (row-major,
+//      rows of 528 bytes), from where every lane takes its 8 pixels for the next iteration: the flow between two iterations
+//      never leaves the CU.  The unit's last iteration stores it to memory instead.
+// During the unit's last M phase the eight waves bring the next unit's R1 through the registers R0 no longer needs.
+// Per stage: six barriers, no memory traffic but the flow store of the last iteration and 160 KB per UNIT of R.
+// Same operation order as fb_level_kernel in every phase: the flows are bit-identical to it.
+template <int FLOW_INIT, bool MOSAIC>
+__global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict__ R, const float* __restrict__ flow_prev, float* flow,
+                                                         const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
+                                                         int width, long long n_pairs, long long pairs_per_group, int chain_f,
+                                                         FbUpsample up, int iterations) {
+  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
+  constexpr int FROW = 528;      // bytes per row of the flow image in LDS (64 float2 + 16: 16-byte rows on rotating banks)
+  // R1 of the unit in hand: (c0, c1) float2 [64][64] | (c2, c3) float2 [64][64] | c4 float [64][64]
+  __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];
+  // X^T of two channels per round, (h, l) f16 planes: [round parity][slot: group 0's channel, group 1's][h, l][PLANE].
+  // Xs[1] doubles as group 1 -> group 0's mailbox (32 KB), Xs[0] as the flow image (33 KB) once the products have read them
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][2][2][PLANE];
+  __shared__ __attribute__((aligned(16))) float pmax[16];                 // largest |M| per (wave, lane half)
+  const int tid = threadIdx.x, lane = tid & 63, pw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 31, half = lane >> 5;
+  const int lpx = height * width;
+  constexpr int NP = MOSAIC ? 4 : 1;
+  constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside every descriptor below: reads zeros
+  const long long n_units = (n_pairs + NP - 1) / NP;
+  const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
+  const int n_it = iterations;
+  // multiplying role: block (strip, mbo) of the 64 x 64 image (MOSAIC: tile (ty, tx) = pair 4 u + 2 strip + mbo), group g
+  const int sm = pw & 3, strip = sm & 1, mbo = sm >> 1, grp = pw >> 2;
+  // producing role: rows 8 pw .. + 7, column = lane (MOSAIC: tile row pw >> 2, tile column lane >> 5)
+  const int m_ty = pw >> 2, m_tx = lane >> 5;
+  const int xl = MOSAIC ? (lane & 31) : lane;                 // column inside the pair's image
+  const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
+  const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane (pixels)
+  const bool col_ok = xl < width;
+
+  // window operands, both in registers: Gv^T as the B operand of the first product (n = y, this lane's row of the strip; k =
+  // y' in natural order); Gh as the A operand of the second (k-slot i of lane half h in step ks = accumulator row
+  // fb_acc_row(8 (ks & 1) + i, h) of row block ks >> 1 of the first product)
+  FbSplit2 gv[KS], gh[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    gv[ks] = fb_split2(t, FB_G_SCALE);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    gh[ks] = fb_split2(t, FB_G_SCALE);
+  }
+  // exponent e of a unit's (MOSAIC: of tile (ty, tx)'s) largest |M| = f 2^e, 0.5 <= f < 1, clamped so that every power of
+  // two formed from it is a normal f32; M 2^(15 - e) then lies below 2^15
+  auto unit_exp = [&](int ty, int tx) -> int {
+    const f32x4* pm4 = reinterpret_cast<const f32x4*>(pmax);
+    float mx;
+    if constexpr (MOSAIC) {
+      const f32x4 a = pm4[2 * ty], b = pm4[2 * ty + 1];
+      mx = tx ? fmaxf(fmaxf(a[1], a[3]), fmaxf(b[1], b[3])) : fmaxf(fmaxf(a[0], a[2]), fmaxf(b[0], b[2]));
+    } else {
+      const f32x4 a = pm4[0], b = pm4[1], c = pm4[2], d = pm4[3];
+      const f32x4 m4 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    }
+    const int e = __builtin_amdgcn_frexp_expf(mx);
+    return e < -25 ? -25 : (e > 100 ? 100 : e);
+  };
+
+  // ---- the unit -> coefficient image bookkeeping (as fb_level_kernel) -------------------------------------------------------
+  long long i0_run, i1_unused;
+  fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
+  long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
+  const long long img_step = chain_f > 0 ? 1 : 2, img_jump = chain_f > 0 ? chain_f - pairs_per_group : 0;
+  auto next_image = [&]() -> long long {
+    const long long r = i0_run;
+    q_run += 1;
+    const long long wrap = (long long)((int)(chain_f > 0) & (int)(q_run == pairs_per_group));      // the next stack's first frame
+    i0_run += img_step + wrap * img_jump;
+    q_run -= wrap * q_run;
+    return r;
+  };
+  auto take_unit = [&](FbImgs& i0) {
+    i0.a = next_image();
+    if constexpr (MOSAIC) i0.b = next_image(), i0.c = next_image(), i0.d = next_image();
+  };
+  // R1 of `unit` (second coefficient images = i0 + 1) through registers: 80 chunks of 1 KB (chunks 0..31 = plane (c0, c1), two
+  // rows of 64 float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each), wave pw takes chunks pw,
+  // pw + 8, ...  Lane j brings 16 bytes: in the pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane
+  // row (j >> 4), pixels 4 (j & 15) .. + 3.  A unit beyond the range, a missing pair, rows or columns beyond the image read zeros
+  const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
+  const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
+  const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
+  auto r1_fetch = [&](const FbImgs& i0, long long unit, u32x4 (&buf)[10]) {
+    const bool unit_ok = unit < p_hi;
+#pragma unroll
+    for (int n = 0; n < 10; ++n) {
+      const int k = pw + 8 * n;
+      const bool pair_plane = n < 8;                              // compile-time per n
+      const int kk = pair_plane ? (k & 31) : (k - 64);            // chunk inside its plane
+      const int rows = pair_plane ? 2 : 4;                        // LDS rows per chunk
+      const int plane_off = pair_plane ? (n < 4 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
+      const int px_bytes = pair_plane ? 8 : 4;
+      const int d_x = pair_plane ? dp_x : ds_x;
+      const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
+      if constexpr (MOSAIC) {
+        const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
+        const int d_tx = pair_plane ? dp_tx : ds_tx;
+        const long long pl = unit * 4 + 2 * ty + d_tx;
+        const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
+        const long long img = d_tx ? img_r : img_l;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
+        uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
+        asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? there : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
+      } else {
+        const int yb = rows * kk;
+        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (i0.a + 1) * lpx * 5), 0, lpx * 20, 0x00020000);
+        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? lane_off : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
+      }
+    }
+  };
+  auto r1_commit = [&](const u32x4 (&buf)[10]) {
+    u32x4* dst = reinterpret_cast<u32x4*>(R1s) + lane;
+#pragma unroll
+    for (int n = 0; n < 10; ++n) dst[(pw + 8 * n) * 64] = buf[n];
+  };
+
+  // ---- producing role ----------------------------------------------------------------------------------------------------
+  // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
+  auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
+  const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
+  float mA[5][8];                // [channel][pixel]: a channel's 8 values are what a hand-over writes
+  FbBlend bl[8];
+  fb_f2 fl[8];                   // the flow the next UpdateMatrices starts from
+  fb_f2 r01[8], r23[8];          // R0 of this lane's 8 pixels, resident through the unit's iterations
+  float r4[8];
+  float pm;                      // running largest |M| of the unit being evaluated
+  auto lane_pair = [&](long long unit, bool& ok) -> long long {
+    const long long pl = MOSAIC ? unit * 4 + 2 * m_ty + m_tx : unit;
+    ok = (int)(unit < p_hi) & (int)(pl < n_pairs);
+    return ok ? pl : 0;
+  };
+  // the flow a unit's first iteration starts from -> fl
+  auto load_flow_init = [&](long long unit) {
+    bool pair_ok;
+    const long long pl = lane_pair(unit, pair_ok);
+    if constexpr (FLOW_INIT == 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which
+        // would keep them for all 8 rows in registers around the unit loop)
+        int xo = xl, yo = __builtin_amdgcn_readfirstlane(yl0 + i);
+        asm volatile("" : "+v"(xo), "+s"(yo));
+        const fb_f32x2_t f = fb_upsampled_flow_nb(flow_prev, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
+                                                  up.inv_fx, up.inv_fy, up.mul);
+        fl[i] = (fb_f2){f[0], f[1]};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float z = 0.f;      // (opaque: with a known zero flow every gather address and weight becomes a per-lane invariant)
+        asm volatile("" : "+v"(z));
+        fl[i] = (fb_f2){z, z};
+      }
+    }
+  };
+  // G: the four R1 neighbours of pixel i (R1 is in LDS, the flow in fl): reads, then the bilinear blend -> bl[i]
+  auto gather = [&](int i, bool lane_ok, FbTapsP& t) {
+    const int y = yl0 + i;
+    const float fx0 = __fadd_rn((float)xl, fl[i][0]), fy0 = __fadd_rn((float)y, fl[i][1]);
+    const int x1 = (int)floorf(fx0), y1 = (int)floorf(fy0);
+    t.fx = __fsub_rn(fx0, (float)x1), t.fy = __fsub_rn(fy0, (float)y1);
+    t.inside = (int)lane_ok & (int)(y < height) & (int)((unsigned)x1 < (unsigned)(width - 1)) & (int)((unsigned)y1 < (unsigned)(height - 1));
+    int idx = lds_org + y1 * 64 + x1;
+    asm volatile("" : "+v"(idx));
+    idx = t.inside ? idx : 0;
+    const fb_f2* p0 = reinterpret_cast<const fb_f2*>(R1s) + idx;
+    const fb_f2* p1 = reinterpret_cast<const fb_f2*>(R1s + 2 * T * T) + idx;
+    const float* p2 = R1s + 4 * T * T + idx;
+    t.u00 = p0[0], t.u01 = p0[1], t.u10 = p0[64], t.u11 = p0[65];
+    t.v00 = p1[0], t.v01 = p1[1], t.v10 = p1[64], t.v11 = p1[65];
+    t.w00 = p2[0], t.w01 = p2[1], t.w10 = p2[64], t.w11 = p2[65];
+  };
+  auto blend = [&](int i, const FbTapsP& t) {
+    const float fx = t.fx, fy = t.fy;
+    const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
+    const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+    bl[i].b01 = ((t.u00 * a00 + t.u01 * a01) + t.u10 * a10) + t.u11 * a11;
+    bl[i].b23 = ((t.v00 * a00 + t.v01 * a01) + t.v10 * a10) + t.v11 * a11;
+    const float b4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t.w00), __fmul_rn(a01, t.w01)), __fmul_rn(a10, t.w10)), __fmul_rn(a11, t.w11));
+    bl[i].b4 = t.inside ? b4 : __builtin_nanf("");
+  };
+  auto gather_blend_all = [&](bool lane_ok) {      // the next pixel's reads are issued before this pixel's blend
+    FbTapsP ta, tb;
+    gather(0, lane_ok, ta);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      gather(i + 1, lane_ok, tb);
+      blend(i, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < 8) gather(i + 2, lane_ok, ta);
+      blend(i + 1, tb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // R0 of this lane's 8 pixels of `unit` (first coefficient images i0) -> r01 / r23 / r4
+  auto load_r0 = [&](long long unit, const FbImgs& i0) {
+    bool pair_ok;
+    (void)lane_pair(unit, pair_ok);
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t base;
+    if constexpr (MOSAIC) {
+      const long long img_l = i0.a + m_ty * (i0.c - i0.a), img_r = i0.b + m_ty * (i0.d - i0.b);      // (no select of addresses)
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
+      base = (uint32_t)((m_tx ? img_r : img_l) * lpx * 20);
+    } else {
+      rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0.a * lpx * 5), 0, lpx * 20, 0x00020000);
+      base = 0;
+    }
+    const bool ok = (int)pair_ok & (int)col_ok;
+    uint32_t t8 = base + (uint32_t)xl * 8, t4 = base + (uint32_t)xl * 4;
+    asm volatile("" : "+v"(t8), "+v"(t4));      // (computed on every path: the selects below must stay selects)
+    const uint32_t v8 = ok ? t8 : NOT_THERE, v4 = ok ? t4 : NOT_THERE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int y = yl0 + i;
+      const bool row_ok = y < height;
+      r01[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(y * width) * 8, 0));
+      r23[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(lpx + y * width) * 8, 0));
+      r4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row_ok ? v4 : NOT_THERE, (uint32_t)(4 * lpx + y * width) * 4, 0));
+    }
+  };
+  // F: the rest of UpdateMatrices for pixels ia, ia + 1 -> mA; pm collects the unit's largest |M|
+  auto finish2 = [&](int ia) {
+#pragma unroll
+    for (int i = ia; i < ia + 2; ++i) {
+      const int y = yl0 + i;
+      const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
+      float m[5];
+      fb_update_pixel_finish2(r01[i], r23[i], r4[i], bl[i], fl[i][0], fl[i][1], scale, m);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) mA[c][i] = m[c];
+      pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the unit's largest |M| per lane half -> pmax (MOSAIC: a half is a tile column)
+  auto publish_max = [&]() {
+    float v = pm;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    pmax[2 * pw + half] = v;      // every lane of the half holds the maximum: 32 identical stores, no branch
+  };
+  // channel c of mA, scaled and split, as rows y' = 8 pw .. + 7 of row x of X^T: 16 contiguous bytes per plane
+  auto write_channel = [&](int c, float s, uint16_t* X) {
+    const FbSplit2 sp = fb_split2(mA[c], s);
+    uint16_t* Xc = X + lane * XS + 8 * pw;
+    *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
+    *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
+  };
+  // ---- multiplying role: Out^T block (mbo, strip) of one channel = Gh (X^T Gv^T) --------------------------------------------
+  auto product = [&](const uint16_t* Xc) -> fb_v16f {
+    fb_v16f u[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        FbSplit2 a;
+        const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+        a.h = *reinterpret_cast<const fb_f16x8*>(xa);
+        a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
+        u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+      }
+    }
+    fb_v16f res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+      const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
+      res = fb_mfma2(gh[ks], b, res);
+    }
+    return res;
+  };
+  uint16_t* const X00 = &Xs[0][0][0][0];
+  uint16_t* const X01 = &Xs[0][1][0][0];
+  uint16_t* const X10 = &Xs[1][0][0][0];
+  uint16_t* const X11 = &Xs[1][1][0][0];
+  f32x4* const mailbox = reinterpret_cast<f32x4*>(X10) + sm * 512 + lane;      // [block][channel][quad][lane], 16 bytes each
+  unsigned char* const flow_img = reinterpret_cast<unsigned char*>(X00);
+
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1;
+#define FBU_PHASE(slot) do { PV_STAMP(s1); dg[slot] += s1 - s0; s0 = s1; } while (0)
+#else
+#define FBU_PHASE(slot) do { } while (0)
+#endif
+
+  // one iteration of unit u; LAST: the unit's last (the next unit is prepared under it, the flow goes to memory)
+  FbImgs i0c, i0n;
+  auto stage = [&](long long u, bool lane_ok, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    PV_STAMP(s0);
+    // ---- P -----------------------------------------------------------------------------------------------------------------
+    gather_blend_all(lane_ok);
+    FBU_PHASE(0);
+    pm = 0.f;
+    finish2(0), finish2(2), finish2(4), finish2(6);
+    publish_max();
+    FBU_PHASE(1);
+    __syncthreads();      // Bm: the unit's largest |M| is published; every wave is through with this iteration's gathers
+    FBU_PHASE(7);
+    u32x4 r1buf[10];
+    if constexpr (LAST) r1_fetch(i0n, u + 1, r1buf);      // (into the registers R0 has left)
+    const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
+    write_channel(0, s, X00), write_channel(3, s, X01);
+    FBU_PHASE(2);
+    __syncthreads();      // B0
+    FBU_PHASE(7);
+    // ---- M -----------------------------------------------------------------------------------------------------------------
+    write_channel(1, s, X10), write_channel(4, s, X11);
+    fb_v16f res[5];
+    res[0] = product(grp ? X01 : X00);      // group 0: channel 0; group 1: channel 3
+    FBU_PHASE(3);
+    __syncthreads();      // B1
+    FBU_PHASE(7);
+    if constexpr (LAST) r1_commit(r1buf);      // (the compiler's own wait for the fetch; the next gathers are behind B4)
+    write_channel(2, s, X00);
+    res[1] = product(grp ? X11 : X10);      // group 0: channel 1; group 1: channel 4
+    FBU_PHASE(3);
+    __syncthreads();      // B2
+    FBU_PHASE(7);
+    if (grp) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mailbox[(c * 4 + q) * 64] = (f32x4){res[c][4 * q], res[c][4 * q + 1], res[c][4 * q + 2], res[c][4 * q + 3]};
+    } else {
+      res[2] = product(X00);
+    }
+    FBU_PHASE(3);
+    __syncthreads();      // B3: group 1's channels are in the mailbox; nobody reads an X image any more
+    FBU_PHASE(7);
+    // ---- S: 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x ------------
+    if (!grp) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = mailbox[(c * 4 + q) * 64];
+          res[3 + c][4 * q] = v[0], res[3 + c][4 * q + 1] = v[1], res[3 + c][4 * q + 2] = v[2], res[3 + c][4 * q + 3] = v[3];
+        }
+      const int e = unit_exp(strip, mbo);
+      const float lam = ldexpf(1e-3f, 2 * (30 - e));
+      const int y = (MOSAIC ? 0 : 32 * strip) + col;
+      const long long pr = MOSAIC ? u * 4 + 2 * strip + mbo : u;
+      float* frow = flow + (pr * lpx + (long long)y * width) * 2;
+      unsigned char* fimg = flow_img + (32 * strip + col) * FROW + (32 * mbo + 4 * half) * 8;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g4 + j;
+          const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+          // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
+          // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
+          const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
+          float rc = __builtin_amdgcn_rcpf(det);
+          rc = __builtin_fmaf(__builtin_fmaf(-det, rc, 1.f), rc, rc);
+          const float nx = fb_det2(g11, h2, g12, h1), ny = fb_det2(g22, h1, g12, h2);
+          const float qx = __fmul_rn(nx, rc), qy = __fmul_rn(ny, rc);
+          o[2 * j] = __builtin_fmaf(__builtin_fmaf(-det, qx, nx), rc, qx);
+          o[2 * j + 1] = __builtin_fmaf(__builtin_fmaf(-det, qy, ny), rc, qy);
+        }
+        if constexpr (LAST) {
+          if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
+            *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(frow + x0 * 2 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+          }
+        } else {
+          *reinterpret_cast<f32x4*>(fimg + g4 * 64) = (f32x4){o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(fimg + g4 * 64 + 16) = (f32x4){o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
+    FBU_PHASE(4);
+    if constexpr (LAST) {
+      // the next unit: its starting flow and its R0 (R1 is already on its way into LDS)
+      load_flow_init(u + 1);
+      load_r0(u + 1, i0n);
+    }
+    __syncthreads();      // B4: the flow image (not LAST) / the next unit's R1 (LAST) is complete
+    FBU_PHASE(7);
+    if constexpr (!LAST) {
+      const unsigned char* fsrc = flow_img + (8 * pw) * FROW + lane * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const fb_f2 v = *reinterpret_cast<const fb_f2*>(fsrc + i * FROW);
+        const bool px_ok = (int)lane_ok & (int)(yl0 + i < height);
+        fl[i] = px_ok ? v : (fb_f2){0.f, 0.f};
+      }
+    }
+    FBU_PHASE(5);
+  };
+
+  take_unit(i0c);
+  take_unit(i0n);
+  {
+    u32x4 r1buf[10];
+    r1_fetch(i0c, p_lo, r1buf);
+    load_flow_init(p_lo);
+    load_r0(p_lo, i0c);
+    r1_commit(r1buf);
+    __syncthreads();      // R1 of the first unit is in place
+  }
+  for (long long u = p_lo; u < p_hi; ++u) {
+    bool ok;
+    (void)lane_pair(u, ok);
+    ok = ok && col_ok;
+    for (int it = 0; it + 1 < n_it; ++it) stage(u, ok, std::false_type{});
+    stage(u, ok, std::true_type{});
+    i0c = i0n;
+    take_unit(i0n);
+  }
+#undef FBU_PHASE
+#ifdef PV_DIAG_STAMPS
+  if (lane == 0 && blockIdx.x * 8 + pw < PV_DIAG_WAVES)
+    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 8 + pw) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+}
+
 // ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
 __global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
                                                          long long n_pairs, int height, int width, FbTaps kt) {
@@ -2018,7 +2469,14 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
   hipLaunchKernelGGL((fb_level_kernel<INIT, MOS, SINGLE>), dim3(grid), dim3(768), 0, st, (const float*)R,                 \
                      (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
                      (long long)pairs_per_group, chain_f, up, (int)p->iterations)
-      {      // one launch for all of the level's iterations
+#define PV_LEVEL_U(INIT, MOS)                                                                                             \
+  hipLaunchKernelGGL((fb_level_u_kernel<INIT, MOS>), dim3(grid), dim3(512), 0, st, (const float*)R,                       \
+                     (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
+                     (long long)pairs_per_group, chain_f, up, (int)p->iterations)
+      if (!getenv("PV_FARNEBACK_SPLIT_WAVES")) {      // uniform waves (R0 and the flow between iterations stay on the CU)
+        if (prev_flow) { if (small_level) PV_LEVEL_U(1, true); else PV_LEVEL_U(1, false); }
+        else { if (small_level) PV_LEVEL_U(2, true); else PV_LEVEL_U(2, false); }
+      } else {      // producing + multiplying waves (the first form; kept as the cross-check)
         const bool single = p->iterations == 1;
         if (prev_flow) {
           if (small_level) { if (single) PV_LEVEL(1, true, true); else PV_LEVEL(1, true, false); }
@@ -2029,6 +2487,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         }
       }
 #undef PV_LEVEL
+#undef PV_LEVEL_U
       prev_flow = flow;
       prev_w = lw;
       prev_h = lh;
