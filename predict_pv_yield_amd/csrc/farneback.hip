@@ -1668,12 +1668,19 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   constexpr int FROW = 528;      // bytes per row of the flow image in LDS (64 float2 + 16: 16-byte rows on rotating banks)
   // R1 of the unit in hand: (c0, c1) float2 [64][64] | (c2, c3) float2 [64][64] | c4 float [64][64]
   __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];
-  // X^T of two channels per round, (h, l) f16 planes: [round parity][slot: group 0's channel, group 1's][h, l][PLANE].
-  // Xs[1] doubles as group 1 -> group 0's mailbox (32 KB), Xs[0] as the flow image (33 KB) once the products have read them
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][2][2][PLANE];
+  // X^T of two channels per round, (h, l) f16 planes: four images X00 X01 | X10 X11 = [round parity][group 0's channel, group
+  // 1's].  Once the products have read them the same bytes are the flow image (the first 33 KB) and, behind it, the mailboxes
+  // through which the two groups of a block swap blurred channels for the solve (X00, still read in round 2, lies below them)
+  constexpr int XIMG = 2 * PLANE * 2;      // bytes of one channel's X^T image (h and l planes)
+  constexpr int MAIL0 = 64 * FROW;         // the mailboxes start behind the flow image: 4 blocks x 10 slots x 1 KB
+  __shared__ __attribute__((aligned(16))) unsigned char XsB[MAIL0 + 4 * 10 * 1024];
+  static_assert(MAIL0 >= XIMG && MAIL0 + 4 * 10 * 1024 >= 4 * XIMG, "LDS image plan");
   __shared__ __attribute__((aligned(16))) float pmax[16];                 // largest |M| per (wave, lane half)
-  const int tid = threadIdx.x, lane = tid & 63, pw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Everything derived from the lane number is re-derived at every phase boundary from an opaque copy (rederive below):
+  // otherwise each phase's addresses and per-lane constants -- some fifty registers -- stay alive through all the others
+  int lane_src = threadIdx.x & 63;
+  int tid = threadIdx.x, lane = tid & 63, col = lane & 31, half = lane >> 5;
   const int lpx = height * width;
   constexpr int NP = MOSAIC ? 4 : 1;
   constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside every descriptor below: reads zeros
@@ -1683,11 +1690,12 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   // multiplying role: block (strip, mbo) of the 64 x 64 image (MOSAIC: tile (ty, tx) = pair 4 u + 2 strip + mbo), group g
   const int sm = pw & 3, strip = sm & 1, mbo = sm >> 1, grp = pw >> 2;
   // producing role: rows 8 pw .. + 7, column = lane (MOSAIC: tile row pw >> 2, tile column lane >> 5)
-  const int m_ty = pw >> 2, m_tx = lane >> 5;
-  const int xl = MOSAIC ? (lane & 31) : lane;                 // column inside the pair's image
+  const int m_ty = pw >> 2;
+  int m_tx = lane >> 5;
+  int xl = MOSAIC ? (lane & 31) : lane;                       // column inside the pair's image
   const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
-  const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane (pixels)
-  const bool col_ok = xl < width;
+  int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;            // the tile's origin in an LDS plane (pixels)
+  bool col_ok = xl < width;
 
   // window operands, both in registers: Gv^T as the B operand of the first product (n = y, this lane's row of the strip; k =
   // y' in natural order); Gh as the A operand of the second (k-slot i of lane half h in step ks = accumulator row
@@ -1705,7 +1713,7 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   }
   // exponent e of a unit's (MOSAIC: of tile (ty, tx)'s) largest |M| = f 2^e, 0.5 <= f < 1, clamped so that every power of
   // two formed from it is a normal f32; M 2^(15 - e) then lies below 2^15
-  auto unit_exp = [&](int ty, int tx) -> int {
+  auto unit_exp = [&](int ty, int tx) __attribute__((always_inline)) -> int {
     const f32x4* pm4 = reinterpret_cast<const f32x4*>(pmax);
     float mx;
     if constexpr (MOSAIC) {
@@ -1741,10 +1749,10 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   // rows of 64 float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each), wave pw takes chunks pw,
   // pw + 8, ...  Lane j brings 16 bytes: in the pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane
   // row (j >> 4), pixels 4 (j & 15) .. + 3.  A unit beyond the range, a missing pair, rows or columns beyond the image read zeros
-  const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
-  const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
-  const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
-  auto r1_fetch = [&](const FbImgs& i0, long long unit, u32x4 (&buf)[10]) {
+  int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
+  int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
+  uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
+  auto r1_fetch = [&](const FbImgs& i0, long long unit, u32x4 (&buf)[10]) __attribute__((always_inline)) {
     const bool unit_ok = unit < p_hi;
 #pragma unroll
     for (int n = 0; n < 10; ++n) {
@@ -1775,7 +1783,7 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
       }
     }
   };
-  auto r1_commit = [&](const u32x4 (&buf)[10]) {
+  auto r1_commit = [&](const u32x4 (&buf)[10]) __attribute__((always_inline)) {
     u32x4* dst = reinterpret_cast<u32x4*>(R1s) + lane;
 #pragma unroll
     for (int n = 0; n < 10; ++n) dst[(pw + 8 * n) * 64] = buf[n];
@@ -1784,9 +1792,8 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   // ---- producing role ----------------------------------------------------------------------------------------------------
   // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
   auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
-  const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
+  float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
   float mA[5][8];                // [channel][pixel]: a channel's 8 values are what a hand-over writes
-  FbBlend bl[8];
   fb_f2 fl[8];                   // the flow the next UpdateMatrices starts from
   fb_f2 r01[8], r23[8];          // R0 of this lane's 8 pixels, resident through the unit's iterations
   float r4[8];
@@ -1796,20 +1803,55 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
     ok = (int)(unit < p_hi) & (int)(pl < n_pairs);
     return ok ? pl : 0;
   };
-  // the flow a unit's first iteration starts from -> fl
-  auto load_flow_init = [&](long long unit) {
+  // the flow a unit's first iteration starts from -> fl.  FLOW_INIT == 1: cv::resize(INTER_LINEAR) of the coarser level's flow,
+  // times 1 / pyr_scale, evaluated on the fly (fb_upsampled_flow_nb's expressions).  The source coordinates are the same for
+  // every unit: the column's (tap, weight) once per lane, the 8 rows' once per wave -- in scalar registers
+  uint32_t up_v0 = 0, up_v1 = 0;      // byte offsets of the column's two taps inside a source row
+  float up_fx = 0.f;
+  uint32_t up_rows[8];                // byte offsets of the two source rows, (row1 << 16) | row0 (a source image is <= 32 KB)
+  float up_fy[8];
+  if constexpr (FLOW_INIT == 1) {
+    const int x = min(xl, width - 1);
+    float fx = (float)((x + 0.5) * up.inv_fx - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    fx = (sx < 0 || sx >= up.sw - 1) ? 0.f : fx;
+    sx = sx < 0 ? 0 : (sx >= up.sw - 1 ? up.sw - 1 : sx);
+    up_v0 = (uint32_t)sx * 8, up_v1 = (uint32_t)min(sx + 1, up.sw - 1) * 8, up_fx = fx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int y = min(__builtin_amdgcn_readfirstlane(yl0 + i), height - 1);
+      float fy = (float)((y + 0.5) * up.inv_fy - 0.5);
+      int sy = (int)floorf(fy);
+      fy -= sy;
+      fy = (sy < 0 || sy >= up.sh - 1) ? 0.f : fy;
+      sy = sy < 0 ? 0 : (sy >= up.sh - 1 ? up.sh - 1 : sy);
+      up_rows[i] = __builtin_amdgcn_readfirstlane((uint32_t)(sy * up.sw * 8) | ((uint32_t)(min(sy + 1, up.sh - 1) * up.sw * 8) << 16));
+      up_fy[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fy)));
+    }
+  }
+  auto load_flow_init = [&](long long unit) __attribute__((always_inline)) {
     bool pair_ok;
     const long long pl = lane_pair(unit, pair_ok);
     if constexpr (FLOW_INIT == 1) {
+      const int src_bytes = up.sh * up.sw * 8;
+      // (MOSAIC: the lanes of a wave read two pairs' images, 31-bit offsets into the whole array -- the launcher's condition)
+      const __amdgpu_buffer_rsrc_t rs =
+          MOSAIC ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_prev), 0, 0x7fffffff, 0x00020000)
+                 : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_prev + pl * (src_bytes / 4)), 0, src_bytes, 0x00020000);
+      const uint32_t img = MOSAIC ? (uint32_t)pl * (uint32_t)src_bytes : 0u;
+      const uint32_t v0 = img + up_v0, v1 = img + up_v1;
+      const float a0 = 1.f - up_fx, a1 = up_fx;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which
-        // would keep them for all 8 rows in registers around the unit loop)
-        int xo = xl, yo = __builtin_amdgcn_readfirstlane(yl0 + i);
-        asm volatile("" : "+v"(xo), "+s"(yo));
-        const fb_f32x2_t f = fb_upsampled_flow_nb(flow_prev, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
-                                                  up.inv_fx, up.inv_fy, up.mul);
-        fl[i] = (fb_f2){f[0], f[1]};
+        const uint32_t row0 = up_rows[i] & 0xffffu, row1 = up_rows[i] >> 16;
+        const float b0 = 1.f - up_fy[i], b1 = up_fy[i];
+        const fb_f2 t00 = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, v0, row0, 0));
+        const fb_f2 t10 = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, v0, row1, 0));
+        const fb_f2 t01 = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, v1, row0, 0));
+        const fb_f2 t11 = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, v1, row1, 0));
+        const fb_f2 r0 = t00 * a0 + t01 * a1, r1 = t10 * a0 + t11 * a1;
+        fl[i] = (r0 * b0 + r1 * b1) * up.mul;
       }
     } else {
 #pragma unroll
@@ -1820,8 +1862,54 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
       }
     }
   };
+  // The same from LDS: during a unit's last iteration the flow image's bytes are free, and the NEXT unit's source flow (its
+  // pairs' images are contiguous: NP x sh x sw x 8 bytes, 32 KB at most) is brought there through registers -- requested
+  // after B2, stored after B3 -- so that the next unit starts from LDS taps instead of waiting for memory
+  const int src_bytes = FLOW_INIT == 1 ? up.sh * up.sw * 8 : 0;
+  const int src_passes = (NP * src_bytes + 8191) >> 13;      // 512 lanes x 16 bytes per pass
+  auto src_fetch = [&](long long unit, u32x4 (&b)[4]) __attribute__((always_inline)) {
+    if constexpr (FLOW_INIT == 1) {
+      const long long first = unit * NP;
+      long long left = unit < p_hi ? (n_pairs - first) * src_bytes : 0;
+      left = left < (long long)NP * src_bytes ? left : (long long)NP * src_bytes;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(flow_prev + first * (src_bytes / 4)), 0, (int)left, 0x00020000);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (n < src_passes) b[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(n * 512 + tid) * 16, 0, 0));
+    }
+  };
+  auto src_commit = [&](const u32x4 (&b)[4]) __attribute__((always_inline)) {
+    if constexpr (FLOW_INIT == 1) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (n < src_passes) *reinterpret_cast<u32x4*>(XsB + (n * 512 + tid) * 16) = b[n];
+    }
+  };
+  auto flow_init_from_lds = [&]() __attribute__((always_inline)) {
+    if constexpr (FLOW_INIT == 1) {
+      const unsigned char* img = XsB + (MOSAIC ? (2 * m_ty + m_tx) * src_bytes : 0);
+      const float a0 = 1.f - up_fx, a1 = up_fx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t row0 = up_rows[i] & 0xffffu, row1 = up_rows[i] >> 16;
+        const float b0 = 1.f - up_fy[i], b1 = up_fy[i];
+        const fb_f2 t00 = *reinterpret_cast<const fb_f2*>(img + row0 + up_v0), t10 = *reinterpret_cast<const fb_f2*>(img + row1 + up_v0);
+        const fb_f2 t01 = *reinterpret_cast<const fb_f2*>(img + row0 + up_v1), t11 = *reinterpret_cast<const fb_f2*>(img + row1 + up_v1);
+        const fb_f2 r0 = t00 * a0 + t01 * a1, r1 = t10 * a0 + t11 * a1;
+        fl[i] = (r0 * b0 + r1 * b1) * up.mul;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float z = 0.f;
+        asm volatile("" : "+v"(z));
+        fl[i] = (fb_f2){z, z};
+      }
+    }
+  };
   // G: the four R1 neighbours of pixel i (R1 is in LDS, the flow in fl): reads, then the bilinear blend -> bl[i]
-  auto gather = [&](int i, bool lane_ok, FbTapsP& t) {
+  auto gather = [&](int i, bool lane_ok, FbTapsP& t) __attribute__((always_inline)) {
     const int y = yl0 + i;
     const float fx0 = __fadd_rn((float)xl, fl[i][0]), fy0 = __fadd_rn((float)y, fl[i][1]);
     const int x1 = (int)floorf(fx0), y1 = (int)floorf(fy0);
@@ -1837,31 +1925,46 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
     t.v00 = p1[0], t.v01 = p1[1], t.v10 = p1[64], t.v11 = p1[65];
     t.w00 = p2[0], t.w01 = p2[1], t.w10 = p2[64], t.w11 = p2[65];
   };
-  auto blend = [&](int i, const FbTapsP& t) {
+  auto blend = [&](const FbTapsP& t, FbBlend& b) __attribute__((always_inline)) {
     const float fx = t.fx, fy = t.fy;
     const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
     const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
-    bl[i].b01 = ((t.u00 * a00 + t.u01 * a01) + t.u10 * a10) + t.u11 * a11;
-    bl[i].b23 = ((t.v00 * a00 + t.v01 * a01) + t.v10 * a10) + t.v11 * a11;
+    b.b01 = ((t.u00 * a00 + t.u01 * a01) + t.u10 * a10) + t.u11 * a11;
+    b.b23 = ((t.v00 * a00 + t.v01 * a01) + t.v10 * a10) + t.v11 * a11;
     const float b4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t.w00), __fmul_rn(a01, t.w01)), __fmul_rn(a10, t.w10)), __fmul_rn(a11, t.w11));
-    bl[i].b4 = t.inside ? b4 : __builtin_nanf("");
+    b.b4 = t.inside ? b4 : __builtin_nanf("");
   };
-  auto gather_blend_all = [&](bool lane_ok) {      // the next pixel's reads are issued before this pixel's blend
+  // F: the rest of UpdateMatrices for pixel i -> mA; pm collects the unit's largest |M|
+  auto finish1 = [&](int i, const FbBlend& b) __attribute__((always_inline)) {
+    const int y = yl0 + i;
+    const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
+    float m[5];
+    fb_update_pixel_finish2(r01[i], r23[i], r4[i], b, fl[i][0], fl[i][1], scale, m);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) mA[c][i] = m[c];
+    pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
+  };
+  // UpdateMatrices of the lane's 8 pixels: the next pixel's reads are issued before this pixel's arithmetic
+  auto update_matrices = [&](bool lane_ok) __attribute__((always_inline)) {
     FbTapsP ta, tb;
+    FbBlend b;
+    pm = 0.f;
     gather(0, lane_ok, ta);
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
       __builtin_amdgcn_sched_barrier(0);
       gather(i + 1, lane_ok, tb);
-      blend(i, ta);
+      blend(ta, b);
+      finish1(i, b);
       __builtin_amdgcn_sched_barrier(0);
       if (i + 2 < 8) gather(i + 2, lane_ok, ta);
-      blend(i + 1, tb);
+      blend(tb, b);
+      finish1(i + 1, b);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   // R0 of this lane's 8 pixels of `unit` (first coefficient images i0) -> r01 / r23 / r4
-  auto load_r0 = [&](long long unit, const FbImgs& i0) {
+  auto load_r0 = [&](long long unit, const FbImgs& i0) __attribute__((always_inline)) {
     bool pair_ok;
     (void)lane_pair(unit, pair_ok);
     __amdgpu_buffer_rsrc_t rs;
@@ -1887,36 +1990,22 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
       r4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row_ok ? v4 : NOT_THERE, (uint32_t)(4 * lpx + y * width) * 4, 0));
     }
   };
-  // F: the rest of UpdateMatrices for pixels ia, ia + 1 -> mA; pm collects the unit's largest |M|
-  auto finish2 = [&](int ia) {
-#pragma unroll
-    for (int i = ia; i < ia + 2; ++i) {
-      const int y = yl0 + i;
-      const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
-      float m[5];
-      fb_update_pixel_finish2(r01[i], r23[i], r4[i], bl[i], fl[i][0], fl[i][1], scale, m);
-#pragma unroll
-      for (int c = 0; c < 5; ++c) mA[c][i] = m[c];
-      pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
   // the unit's largest |M| per lane half -> pmax (MOSAIC: a half is a tile column)
-  auto publish_max = [&]() {
+  auto publish_max = [&]() __attribute__((always_inline)) {
     float v = pm;
 #pragma unroll
     for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     pmax[2 * pw + half] = v;      // every lane of the half holds the maximum: 32 identical stores, no branch
   };
   // channel c of mA, scaled and split, as rows y' = 8 pw .. + 7 of row x of X^T: 16 contiguous bytes per plane
-  auto write_channel = [&](int c, float s, uint16_t* X) {
+  auto write_channel = [&](int c, float s, uint16_t* X) __attribute__((always_inline)) {
     const FbSplit2 sp = fb_split2(mA[c], s);
     uint16_t* Xc = X + lane * XS + 8 * pw;
     *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
     *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
   };
   // ---- multiplying role: Out^T block (mbo, strip) of one channel = Gh (X^T Gv^T) --------------------------------------------
-  auto product = [&](const uint16_t* Xc) -> fb_v16f {
+  auto product = [&](const uint16_t* Xc) __attribute__((always_inline)) -> fb_v16f {
     fb_v16f u[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -1944,88 +2033,115 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
     }
     return res;
   };
-  uint16_t* const X00 = &Xs[0][0][0][0];
-  uint16_t* const X01 = &Xs[0][1][0][0];
-  uint16_t* const X10 = &Xs[1][0][0][0];
-  uint16_t* const X11 = &Xs[1][1][0][0];
-  f32x4* const mailbox = reinterpret_cast<f32x4*>(X10) + sm * 512 + lane;      // [block][channel][quad][lane], 16 bytes each
-  unsigned char* const flow_img = reinterpret_cast<unsigned char*>(X00);
+  uint16_t* const X00 = reinterpret_cast<uint16_t*>(XsB);
+  uint16_t* const X01 = reinterpret_cast<uint16_t*>(XsB + XIMG);
+  uint16_t* const X10 = reinterpret_cast<uint16_t*>(XsB + 2 * XIMG);
+  uint16_t* const X11 = reinterpret_cast<uint16_t*>(XsB + 3 * XIMG);
+  // mailbox of block sm: slots 0..3 = group 1's channels (3, 4) x accumulator quads (0, 1) for group 0; slots 4..9 = group 0's
+  // channels (0, 1, 2) x quads (2, 3) for group 1; a slot = 64 lanes x 16 bytes
+  f32x4* mailbox = reinterpret_cast<f32x4*>(XsB + MAIL0) + sm * 640 + lane;
+  unsigned char* const flow_img = XsB;
+  auto rederive = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane_src));
+    lane = lane_src, tid = pw * 64 + lane, col = lane & 31, half = lane >> 5;
+    m_tx = lane >> 5, xl = MOSAIC ? (lane & 31) : lane;
+    lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;
+    col_ok = xl < width;
+    dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
+    ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
+    dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
+    scale_x = __fmul_rn(border(xl), border(width - xl - 1));
+    mailbox = reinterpret_cast<f32x4*>(XsB + MAIL0) + sm * 640 + lane;
+  };
 
 #ifdef PV_DIAG_STAMPS
   unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1;
+#ifdef FBU_BARRIER_DETAIL      // slots 0..5 = the waits at Bm, B0..B4, slot 6 = everything else
+#define FBU_PHASE(slot) do { PV_STAMP(s1); dg[6] += s1 - s0; s0 = s1; } while (0)
+#define FBU_BAR(n) do { PV_STAMP(s1); dg[n] += s1 - s0; s0 = s1; } while (0)
+#else
 #define FBU_PHASE(slot) do { PV_STAMP(s1); dg[slot] += s1 - s0; s0 = s1; } while (0)
+#define FBU_BAR(n) FBU_PHASE(6)
+#endif
 #else
 #define FBU_PHASE(slot) do { } while (0)
+#define FBU_BAR(n) do { } while (0)
 #endif
 
   // one iteration of unit u; LAST: the unit's last (the next unit is prepared under it, the flow goes to memory)
   FbImgs i0c, i0n;
-  auto stage = [&](long long u, bool lane_ok, auto last_tag) {
+  auto stage = [&](long long u, bool lane_ok, auto last_tag) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_tag)::value;
     PV_STAMP(s0);
+    rederive();
+    lane_ok = (int)lane_ok & (int)col_ok;      // (the column test with this phase's lane number)
     // ---- P -----------------------------------------------------------------------------------------------------------------
-    gather_blend_all(lane_ok);
+    update_matrices(lane_ok);
     FBU_PHASE(0);
-    pm = 0.f;
-    finish2(0), finish2(2), finish2(4), finish2(6);
     publish_max();
     FBU_PHASE(1);
     __syncthreads();      // Bm: the unit's largest |M| is published; every wave is through with this iteration's gathers
-    FBU_PHASE(7);
+    FBU_BAR(0);
+    rederive();
     u32x4 r1buf[10];
     if constexpr (LAST) r1_fetch(i0n, u + 1, r1buf);      // (into the registers R0 has left)
     const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
     write_channel(0, s, X00), write_channel(3, s, X01);
     FBU_PHASE(2);
     __syncthreads();      // B0
-    FBU_PHASE(7);
+    FBU_BAR(1);
     // ---- M -----------------------------------------------------------------------------------------------------------------
     write_channel(1, s, X10), write_channel(4, s, X11);
-    fb_v16f res[5];
+    fb_v16f res[3];
     res[0] = product(grp ? X01 : X00);      // group 0: channel 0; group 1: channel 3
     FBU_PHASE(3);
     __syncthreads();      // B1
-    FBU_PHASE(7);
+    FBU_BAR(2);
     if constexpr (LAST) r1_commit(r1buf);      // (the compiler's own wait for the fetch; the next gathers are behind B4)
     write_channel(2, s, X00);
     res[1] = product(grp ? X11 : X10);      // group 0: channel 1; group 1: channel 4
     FBU_PHASE(3);
     __syncthreads();      // B2
-    FBU_PHASE(7);
+    FBU_BAR(3);
+    u32x4 srcbuf[4];
+    if constexpr (LAST) src_fetch(u + 1, srcbuf);
+    // each group sends the other the half of its blurred channels it will not solve itself: accumulator quads 0, 1 (columns
+    // 8 g4 + 4 half .. + 3 for g4 = 0, 1) are solved by group 0, quads 2, 3 by group 1
     if (grp) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mailbox[(c * 4 + q) * 64] = (f32x4){res[c][4 * q], res[c][4 * q + 1], res[c][4 * q + 2], res[c][4 * q + 3]};
+        for (int q = 0; q < 2; ++q) mailbox[(c * 2 + q) * 64] = (f32x4){res[c][4 * q], res[c][4 * q + 1], res[c][4 * q + 2], res[c][4 * q + 3]};
     } else {
       res[2] = product(X00);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 2; q < 4; ++q) mailbox[(4 + c * 2 + q - 2) * 64] = (f32x4){res[c][4 * q], res[c][4 * q + 1], res[c][4 * q + 2], res[c][4 * q + 3]};
     }
     FBU_PHASE(3);
-    __syncthreads();      // B3: group 1's channels are in the mailbox; nobody reads an X image any more
-    FBU_PHASE(7);
+    __syncthreads();      // B3: the mailboxes are filled; nobody reads an X image any more
+    FBU_BAR(4);
+    rederive();
+    if constexpr (LAST) {
+      src_commit(srcbuf);
+      load_r0(u + 1, i0n);   // into the registers R0 of this unit has left; wanted after the next unit's first gathers
+    }
     // ---- S: 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x ------------
-    if (!grp) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = mailbox[(c * 4 + q) * 64];
-          res[3 + c][4 * q] = v[0], res[3 + c][4 * q + 1] = v[1], res[3 + c][4 * q + 2] = v[2], res[3 + c][4 * q + 3] = v[3];
-        }
+    {
       const int e = unit_exp(strip, mbo);
       const float lam = ldexpf(1e-3f, 2 * (30 - e));
       const int y = (MOSAIC ? 0 : 32 * strip) + col;
       const long long pr = MOSAIC ? u * 4 + 2 * strip + mbo : u;
       float* frow = flow + (pr * lpx + (long long)y * width) * 2;
       unsigned char* fimg = flow_img + (32 * strip + col) * FROW + (32 * mbo + 4 * half) * 8;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
+      // quad g4 of the block from the five blurred channels' registers q5[channel][j]
+      auto solve_quad = [&](int g4, const float (&q5)[5][4]) {
         const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
         float o[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int r = 4 * g4 + j;
-          const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
+          const float g11 = q5[0][j], g12 = q5[1][j], g22 = q5[2][j], h1 = q5[3][j], h2 = q5[4][j];
           // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
           // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
           const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
@@ -2045,17 +2161,46 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
           *reinterpret_cast<f32x4*>(fimg + g4 * 64) = (f32x4){o[0], o[1], o[2], o[3]};
           *reinterpret_cast<f32x4*>(fimg + g4 * 64 + 16) = (f32x4){o[4], o[5], o[6], o[7]};
         }
+      };
+      if (grp) {
+#pragma unroll
+        for (int q = 2; q < 4; ++q) {
+          float q5[5][4];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x4 v = mailbox[(4 + c * 2 + q - 2) * 64];
+            q5[c][0] = v[0], q5[c][1] = v[1], q5[c][2] = v[2], q5[c][3] = v[3];
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q5[3 + c][j] = res[c][4 * q + j];
+          solve_quad(q, q5);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float q5[5][4];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q5[c][j] = res[c][4 * q + j];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f32x4 v = mailbox[(c * 2 + q) * 64];
+            q5[3 + c][0] = v[0], q5[3 + c][1] = v[1], q5[3 + c][2] = v[2], q5[3 + c][3] = v[3];
+          }
+          solve_quad(q, q5);
+        }
       }
     }
     FBU_PHASE(4);
+    __syncthreads();      // B4: the flow image (not LAST) / the next unit's R1 and source flow (LAST) are complete
+    FBU_BAR(5);
+    rederive();
     if constexpr (LAST) {
-      // the next unit: its starting flow and its R0 (R1 is already on its way into LDS)
-      load_flow_init(u + 1);
-      load_r0(u + 1, i0n);
-    }
-    __syncthreads();      // B4: the flow image (not LAST) / the next unit's R1 (LAST) is complete
-    FBU_PHASE(7);
-    if constexpr (!LAST) {
+      flow_init_from_lds();
+    } else {
       const unsigned char* fsrc = flow_img + (8 * pw) * FROW + lane * 8;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -2065,6 +2210,9 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
       }
     }
     FBU_PHASE(5);
+#ifdef PV_DIAG_STAMPS
+    dg[7] += 1;
+#endif
   };
 
   take_unit(i0c);
@@ -2080,13 +2228,13 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   for (long long u = p_lo; u < p_hi; ++u) {
     bool ok;
     (void)lane_pair(u, ok);
-    ok = ok && col_ok;
     for (int it = 0; it + 1 < n_it; ++it) stage(u, ok, std::false_type{});
     stage(u, ok, std::true_type{});
     i0c = i0n;
     take_unit(i0n);
   }
 #undef FBU_PHASE
+#undef FBU_BAR
 #ifdef PV_DIAG_STAMPS
   if (lane == 0 && blockIdx.x * 8 + pw < PV_DIAG_WAVES)
     for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 8 + pw) * PV_DIAG_SLOTS + i] = dg[i];

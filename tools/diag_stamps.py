@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PV_YIELD_LIB"] = os.path.join(ROOT, "predict_pv_yield_amd", "lib", "libpvyield_diag.so")
+os.environ["PV_YIELD_LIB"] = os.environ.get("PV_DIAG_LIB") or os.path.join(ROOT, "predict_pv_yield_amd", "lib", "libpvyield_diag.so")
 import numpy as np
 import torch
 from predict_pv_yield_amd import hip_ops as K
@@ -66,8 +66,26 @@ def run():
 
 
 def flow_report(d):
-    """fb_iter_kernel: waves 0..3 of a workgroup multiply, waves 4..11 produce; the last launch's stamps"""
+    """fb_level_u_kernel (8 uniform waves per workgroup; waves 0..3 = group 0: three channels + the solve, waves 4..7 = group
+    1: two channels) or, with PV_FARNEBACK_SPLIT_WAVES=1, fb_level_kernel (waves 0..3 multiply, 4..11 produce); the last
+    launch's stamps"""
     d = d[: (d[:, 7] > 0).nonzero()[0].max() + 1]
+    if not os.environ.get("PV_FARNEBACK_SPLIT_WAVES"):
+        d = d[: len(d) // 8 * 8].reshape(-1, 8, SLOTS)
+        if os.environ.get("PV_DIAG_BARRIER_DETAIL"):      # a library built with -DFBU_BARRIER_DETAIL
+            labels = ["wait at Bm", "wait at B0", "wait at B1", "wait at B2", "wait at B3", "wait at B4", "everything else"]
+        else:
+          labels = ["G: gathers + blend", "F: rest of UpdateMatrices + publish max", "scale, split + write channels (+ R1 fetch issue)",
+                  "products (+ split + write of the next channels, mailbox write)", "mailbox read + solve + flow to LDS / memory",
+                  "flow from LDS / next unit's flow + R0 requests", "barrier waits"]
+        for name, sl in (("group 0", slice(0, 4)), ("group 1", slice(4, 8))):
+            w = d[:, sl].reshape(-1, SLOTS)
+            w = w[w[:, 7] > 0]
+            tot = w[:, :7].sum(1).mean()
+            print(f"  {name}: {len(w)} waves, {w[:, 7].mean():.1f} stages per wave, {tot / w[:, 7].mean():.0f} cycles / stage")
+            for i, lab in enumerate(labels):
+                print(f"    {lab:64s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / stage  {100 * w[:, i].mean() / tot:5.1f} %")
+        return
     d = d[: len(d) // 12 * 12].reshape(-1, 12, SLOTS)
     for name, sl, labels in (("multiplying waves", slice(0, 4), ["barrier (waiting for a channel / the next unit)", "channel: 24 + 12 products", "solve + flow store"]),
                              ("producing waves", slice(4, 12), ["split + write a channel (+ wait for R1)", "barrier", "after the barrier: requests + UpdateMatrices of the next unit",
