@@ -284,6 +284,25 @@ def test_level_kernel_repeated_launches_give_identical_bits(device):
         assert torch.equal(K.farneback_stack(u8), first)
 
 
+@pytest.mark.parametrize("h,w,t,stacks,kw", [
+    (64, 64, 12, 40, {}),                                                    # the PV-site tiles, default parameters
+    (64, 64, 3, 300, {}),                                                    # several units per workgroup
+    (40, 56, 4, 7, dict(levels=3, iterations=2)),                            # 64-px tile with margins, three levels (two MOSAIC)
+    (24, 28, 3, 11, dict(levels=2, winsize=9, iterations=1)),                # MOSAIC level 0, one iteration per level
+    (64, 36, 2, 5, dict(levels=1, winsize=21, iterations=3, poly_n=7, poly_sigma=1.5)),      # starts from a zero flow
+])
+def test_uniform_wave_level_kernel_equals_the_split_wave_kernel(device, monkeypatch, h, w, t, stacks, kw):
+    """fb_level_u_kernel (8 uniform waves, R0 and the flow between iterations kept on the CU) evaluates the same expressions in
+    the same order as fb_level_kernel (4 multiplying + 8 producing waves, PV_FARNEBACK_SPLIT_WAVES=1): identical bits."""
+    K = _ops()
+    raw, _ = advected_counts(batch=stacks, t=t, channels=1, h=h, w=w, seed=5 * h + w)
+    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(np.ascontiguousarray(raw[:, :, 0]), 0)[0]).to(device)
+    uniform = K.farneback_stack(u8, **kw)
+    monkeypatch.setenv("PV_FARNEBACK_SPLIT_WAVES", "1")
+    split = K.farneback_stack(u8, **kw)
+    assert bool(torch.isfinite(uniform).all()) and torch.equal(uniform, split)
+
+
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 5, 3, 8, 8), (1, 12, 11, 64, 64), (3, 2, 1, 4, 6)])
 def test_prepare_stacks_equals_permute_u8_normalise(device, dtype, shape):
