@@ -226,6 +226,13 @@ int pv_bf16_cpad(int32_t c);   /* 16 for c<=16, 32 for c<=32, else PV_ESIZE */
  * Needs t*h*w % 4 == 0 and 16-byte aligned buffers. */
 int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint16_t* xp_m, uint16_t* xp_l, int32_t batch,
                                            int32_t c, int32_t t, int32_t h, int32_t w, void* stream);
+/* The two-term HALF-FLOAT split x s = h + l (h = rne_f16(x s), l = rne_f16(x s - h): 22 significant bits), s = 2^(14 - e) from
+ * the tensor's largest magnitude (max |x| < 2^e; found by a pass of the same call): three matrix-core launches
+ * (pv_conv3d_bwd_weight_f16 on (l,h), (h,l), (h,h), summed in that order, un-scaled by state[2] of both tensors) give the weight
+ * gradient of the f32 model (predict_pv_yield/models/conv3d/model.py:80-90 under autograd) where the three-term bf16 split
+ * needs six.  state: 3 device words: [0] bits of max |x| (scratch), [1] = s, [2] = 1 / s.  Same alignment rules as above. */
+int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t batch, int32_t c,
+                                          int32_t t, int32_t h, int32_t w, void* stream);
 int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c,
                                     int32_t t, int32_t h, int32_t w, void* stream);
 /* inverse, dropping pad channels (used by tests and for the fc head's NCDHW flatten). */
@@ -285,6 +292,10 @@ int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* b
 int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint16_t* y_relu_mask,
                               float* dw, float* dbias, const pv_conv3d_dims* d,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* The same on HALF-FLOAT operand images (pv_pack_split2_...; the LDS-staged kernel only: no mask, 16-byte aligned x / dy,
+ * workspace as above). */
+int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, const pv_conv3d_dims* d,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fully connected head (F.linear; model.py:92-103,125-152) ------------ */
 /* y[M,N] = relu?(x[M,K] · w[N,K]^T + bias[N]); fp32, split-K with fp32 slab reduce.

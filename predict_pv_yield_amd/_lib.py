@@ -105,6 +105,7 @@ SIGNATURES = {
     "pv_bf16_cpad": [c_i32],
     "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_pack_split2_ncdhw_f32_to_ndhwc_f16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_unpack_ndhwc_bf16_to_ncdhw_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_repack_gate_ncdhw_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_conv3d_packed_weight_elems": [c_i32],
@@ -116,6 +117,7 @@ SIGNATURES = {
     "pv_conv3d_fwd_bf16_f32in": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_vp],
     "pv_conv3d_bwd_weight_bf16_workspace_bytes": [_PCD, ctypes.POINTER(c_sz)],
     "pv_conv3d_bwd_weight_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
+    "pv_conv3d_bwd_weight_f16": [c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
     "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],

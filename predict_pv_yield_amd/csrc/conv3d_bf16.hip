@@ -595,6 +595,97 @@ __global__ __launch_bounds__(256, 2) void pack_split3_ncdhw_to_ndhwc_v4_kernel(c
   }
 }
 
+// ---- two-term f16 split (round 4): x s = h + l, h = rne_f16(x s), l = rne_f16(x s - h): 22 significant bits in two half-float
+// images, so that an f32-accurate product needs THREE matrix-core launches (l h, h l, h h) where the bf16 split needs six, and
+// the split pass writes 4 instead of 6 bytes per element.  Half floats have a narrow range: s = 2^(14 - e) is an exact power of
+// two from the tensor's largest magnitude (max |x| < 2^e), found by a pass of its own (maxabs_f32_kernel, one atomic per wave);
+// elements more than 2^11 below the largest lose low bits of l to the subnormal range -- an absolute error of 2^-39 of the
+// largest element.  state[0] = bits of max |x| (in), state[1] = s, state[2] = 1 / s (out, for the caller's un-scaling).
+__global__ __launch_bounds__(256) void maxabs_f32_kernel(const float* __restrict__ x, long long n4, uint32_t* __restrict__ state) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  uint32_t m = 0;
+  auto fold = [&](const u32x4 v) { m = max(max(m, v[0] & 0x7fffffffu), max(max(v[1] & 0x7fffffffu, v[2] & 0x7fffffffu), v[3] & 0x7fffffffu)); };
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 7 * stride < n4; i += 8 * stride) {      // eight independent 16-byte loads in flight per lane
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u32x4*>(x + 4 * (i + j * stride));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fold(v[j]);
+  }
+  for (; i < n4; i += stride) fold(*reinterpret_cast<const u32x4*>(x + 4 * i));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+  // one atomic per WORKGROUP (512 in all): same-address atomics serialise at the L2 channel, ~15 ns apiece -- one per wave of a
+  // 2 048-workgroup grid was 120 us of this pass
+  __shared__ uint32_t wave_max[4];
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m) atomicMax(state, m);
+  }
+}
+
+__device__ __forceinline__ float split2_scale(const uint32_t* __restrict__ state) {
+  const uint32_t bits = state[0];
+  if (bits == 0u || bits >= 0x7f800000u) return 1.f;      // all zeros / a non-finite element: nothing to protect
+  int e = __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, bits));      // max = f 2^e, 0.5 <= f < 1
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.f, 14 - e);
+}
+
+template <int CPAD>
+__global__ __launch_bounds__(256, 2) void pack_split2_ncdhw_to_ndhwc_f16_kernel(const float* __restrict__ x,
+                                                                                uint16_t* __restrict__ xp_h,
+                                                                                uint16_t* __restrict__ xp_l, int c,
+                                                                                long long vox_per_sample, long long total_quads,
+                                                                                uint32_t* __restrict__ state) {
+  constexpr int NCH = 4 * CPAD * 2 / 16;
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) unsigned char patch[4][NCH * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long qps = vox_per_sample / 4;
+  const float s = split2_scale(state);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    reinterpret_cast<float*>(state)[1] = s;
+    reinterpret_cast<float*>(state)[2] = 1.f / s;
+  }
+  for (long long base = (long long)blockIdx.x * blockDim.x + wave * 64; base < total_quads; base += stride) {
+    const long long i = base + lane;
+    u32x4 oh[NCH], ol[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) oh[k] = ol[k] = (u32x4){0u, 0u, 0u, 0u};
+    if (i < total_quads) {
+      const long long bi = i / qps;
+      const long long v = (i - bi * qps) * 4;
+      const float* src = x + (size_t)bi * c * vox_per_sample + v;
+#pragma unroll
+      for (int k = 0; k < CPAD; k += 2) {      // channels k, k + 1 -> one 32-bit word per voxel and image
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (k < c) a0 = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
+        if (k + 1 < c) a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * vox_per_sample);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2_t f = (f32x2_t){a0[q], a1[q]} * s;
+          const f16x2_t h = __builtin_convertvector(f, f16x2_t);
+          const f32x2_t r = f - __builtin_convertvector(h, f32x2_t);
+          const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+          const int chunk = q * (CPAD / 8) + (k >> 3), word = (k & 7) >> 1;
+          oh[chunk][word] = __builtin_bit_cast(uint32_t, h);
+          ol[chunk][word] = __builtin_bit_cast(uint32_t, l);
+        }
+      }
+    }
+    const size_t off = (size_t)base * (NCH * 16);
+    const long long valid = (total_quads - base) * (NCH * 16);
+    wave_store_run<NCH>(patch[wave], oh, reinterpret_cast<unsigned char*>(xp_h) + off, valid);
+    wave_store_run<NCH>(patch[wave], ol, reinterpret_cast<unsigned char*>(xp_l) + off, valid);
+  }
+}
+
 template <int CPAD>
 __global__ __launch_bounds__(256) void unpack_ndhwc_to_ncdhw_kernel(const uint16_t* __restrict__ xp,
                                                                      float* __restrict__ x, int c,
@@ -819,6 +910,29 @@ int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint1
     hipLaunchKernelGGL(pack_split3_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp_h, xp_m, xp_l, c,
                        vps, total / 4);
   return check_launch("pv_pack_split3_ncdhw_f32_to_ndhwc_bf16");
+}
+
+int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t batch, int32_t c,
+                                          int32_t t, int32_t h, int32_t w, void* stream) {
+  PV_REQUIRE(x && xp_h && xp_l && state, PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: null pointer");
+  const int cpad = pv_bf16_cpad(c);
+  PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: c=%d not in 1..32", c);
+  const long long vps = (long long)t * h * w, total = vps * batch;
+  PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: empty tensor");
+  PV_REQUIRE(vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp_h % 16 == 0) && ((uintptr_t)xp_l % 16 == 0) &&
+                 ((uintptr_t)state % 4 == 0),
+             PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: needs t*h*w %% 4 == 0 and 16-byte aligned buffers");
+  hipStream_t st = as_stream(stream);
+  uint32_t* st_bits = reinterpret_cast<uint32_t*>(state);
+  PV_REQUIRE(hipMemsetAsync(st_bits, 0, sizeof(uint32_t), st) == hipSuccess, PV_ELAUNCH, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: memset failed");
+  const long long n4 = total * c / 4;
+  hipLaunchKernelGGL(maxabs_f32_kernel, dim3(std::min<unsigned>(stream_grid((size_t)n4, 256), 2 * kNumCU)), dim3(256), 0, st, x, n4, st_bits);
+  const unsigned g4 = stream_grid((size_t)(total / 4), 256);
+  if (cpad == 16)
+    hipLaunchKernelGGL(pack_split2_ncdhw_to_ndhwc_f16_kernel<16>, dim3(g4), dim3(256), 0, st, x, xp_h, xp_l, c, vps, total / 4, st_bits);
+  else
+    hipLaunchKernelGGL(pack_split2_ncdhw_to_ndhwc_f16_kernel<32>, dim3(g4), dim3(256), 0, st, x, xp_h, xp_l, c, vps, total / 4, st_bits);
+  return check_launch("pv_pack_split2_ncdhw_f32_to_ndhwc_f16");
 }
 
 int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c, int32_t t, int32_t h,

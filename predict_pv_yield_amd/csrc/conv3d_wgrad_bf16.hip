@@ -393,7 +393,7 @@ static void wgrad_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, in
 // LDS-direct form (conv3d_wgrad_bf16_v2.hip): serves every launch whose dY needs no gate while it is staged
 size_t wgrad_v2_workspace_bytes(const pv_conv3d_dims* d);
 int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* slabs, const pv_conv3d_dims* d, int to, int ho,
-                                int wo, hipStream_t st, int* n_slabs);
+                                int wo, hipStream_t st, int* n_slabs, bool f16);
 
 }  // namespace pv
 
@@ -432,7 +432,7 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
   hipStream_t st = as_stream(stream);
   if (!y_relu_mask && workspace_bytes >= wgrad_v2_workspace_bytes(d)) {
     int n2 = 0;
-    if (launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2) == 0) {
+    if (launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2, false) == 0) {
       hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st,
                          (const float*)workspace, n2, dw, dbias, d->c_out, d->c_in);
       return check_launch("pv_conv3d_bwd_weight_bf16(v2)");
@@ -452,6 +452,28 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
   hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st,
                      (const float*)workspace, n_slabs, dw, dbias, d->c_out, d->c_in);
   return check_launch("pv_conv3d_bwd_weight_bf16");
+}
+
+int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, const pv_conv3d_dims* d,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  PV_REQUIRE(d && x && dy && workspace, PV_EINVAL, "pv_conv3d_bwd_weight_f16: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_bwd_weight_f16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_bwd_weight_f16: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_bwd_weight_f16: input smaller than the kernel");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_bwd_weight_f16: batch too large for grid.z");
+  PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_bwd_weight_f16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
+  PV_REQUIRE(workspace_bytes >= wgrad_v2_workspace_bytes(d), PV_ESIZE, "pv_conv3d_bwd_weight_f16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  int n2 = 0;
+  PV_REQUIRE(launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2, true) == 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_f16: x and dy must be 16-byte aligned");
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st, (const float*)workspace, n2,
+                     dw, dbias, d->c_out, d->c_in);
+  return check_launch("pv_conv3d_bwd_weight_f16");
 }
 
 #ifdef PV_DIAG_STAMPS

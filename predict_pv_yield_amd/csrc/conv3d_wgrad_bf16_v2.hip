@@ -64,7 +64,9 @@ __device__ __forceinline__ void w2_interleave() {
   }
 }
 
-template <int CPAD>
+// F16: the operand images hold IEEE half floats (the two-term split of the f32 path, pv_pack_split2_...): the same data
+// movement, v_mfma_f32_32x32x16_f16 instead of ..._bf16 and 1.0 as a half in the ones-tap
+template <int CPAD, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, float* __restrict__ slabs, int t_in, int h_in, int w_in,
     int t_out, int h_out, int w_out, int pad_t, int pad_h, int pad_w, int n_colblk, int t_chunk) {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
     }
   } else if (n_items > 0) {
     // =============================== multiplying waves =================================================================
-    if (tid < 64) reinterpret_cast<uint32_t*>(lds_const)[tid] = tid < 32 ? 0x3f803f80u : 0u;
+    if (tid < 64) reinterpret_cast<uint32_t*>(lds_const)[tid] = tid < 32 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u;
 
     // ---- per-lane byte offsets of the transposed reads (identical to conv3d_wgrad_bf16.hip) ----------------------
     int aoff[2];
@@ -277,12 +279,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
       };
       auto mfma_step = [&](const s16x4 (&ra)[2], const s16x4 (&rb)[NACC][2]) {
         const s16x8 a8 = {ra[0][0], ra[0][1], ra[0][2], ra[0][3], ra[1][0], ra[1][1], ra[1][2], ra[1][3]};
-        const bf16x8 afr = __builtin_bit_cast(bf16x8, a8);
+        typedef _Float16 w2_f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
           s16x8 t8 = {rb[i][0][0], rb[i][0][1], rb[i][0][2], rb[i][0][3], rb[i][1][0], rb[i][1][1], rb[i][1][2], rb[i][1][3]};
-          bf16x8 bfr = __builtin_bit_cast(bf16x8, t8);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr, acc[i], 0, 0, 0);
+          if constexpr (F16)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w2_f16x8, a8), __builtin_bit_cast(w2_f16x8, t8), acc[i], 0, 0, 0);
+          else
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), __builtin_bit_cast(bf16x8, t8), acc[i], 0, 0, 0);
         }
       };
       s16x4 ra0[2], ra1[2], rb0[NACC][2], rb1[NACC][2];
@@ -363,18 +367,18 @@ size_t wgrad_v2_workspace_bytes(const pv_conv3d_dims* d) {
 
 // 0 = launched (n_slabs set), 1 = shape / alignment not covered (the caller uses the register-staged kernel)
 int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* slabs, const pv_conv3d_dims* d, int to, int ho,
-                                int wo, hipStream_t st, int* n_slabs) {
+                                int wo, hipStream_t st, int* n_slabs, bool f16) {
   if (((uintptr_t)x % 16) != 0 || ((uintptr_t)dy % 16) != 0) return 1;
   int nrb, ncb, ntc, tch;
   wgrad_v2_grid(d, &nrb, &ncb, &ntc, &tch);
   *n_slabs = d->batch * nrb * ntc;
   dim3 grid((unsigned)nrb, (unsigned)ntc, (unsigned)d->batch);
-  if (pv_bf16_cpad(d->c_in) == 16)
-    hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<16>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, to, ho,
-                       wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
-  else
-    hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<32>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, to, ho,
-                       wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch);
+#define PV_W2(CP, HALF)                                                                                                       \
+  hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<CP, HALF>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, to, \
+                     ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
+  if (pv_bf16_cpad(d->c_in) == 16) { if (f16) PV_W2(16, true); else PV_W2(16, false); }
+  else { if (f16) PV_W2(32, true); else PV_W2(32, false); }
+#undef PV_W2
   return 0;
 }
 

@@ -324,6 +324,7 @@ def linear_bf16(x, weight, bias, relu=False, x_is_relu_output=False):
 
 
 F32_WGRAD_ON_BF16X3 = True      # tools/ab_step-style switch: False = always the f32 matrix-core weight gradient
+F32_WGRAD_SPLIT = "f16x2"       # "f16x2": two half-float terms, three launches; "bf16x3": three bf16 terms, six launches
 
 
 def _triple(v):
@@ -368,7 +369,8 @@ class Conv3dGeneralF32(torch.autograd.Function):
         if _wgrad_on_bf16x3(x, dy, y, weight, ctx.stride):
             # the PV-yield model's 3x3x3 layers: six launches of the bf16 weight-gradient kernel on split operands instead of
             # one at the f32 matrix rate (0.9-1.35 ms -> ~0.6 ms per layer at B = 32), f32-accurate (hip_ops docstring)
-            dw, db = K.conv3d_bwd_weight_f32_on_bf16x3(x, dy, _triple(ctx.padding))
+            wgrad = K.conv3d_bwd_weight_f32_on_f16x2 if F32_WGRAD_SPLIT == "f16x2" else K.conv3d_bwd_weight_f32_on_bf16x3
+            dw, db = wgrad(x, dy, _triple(ctx.padding))
             return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
         dw, db = K.conv3d_general_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.stride, ctx.padding,
                                                  need_bias=ctx.has_bias)

@@ -312,6 +312,61 @@ def conv3d_bwd_weight_f32_on_bf16x3(x: torch.Tensor, dy: torch.Tensor, padding=(
     return dw, db
 
 
+def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor):
+    """x f32 [B,C,T,H,W] -> (h, l, state): two half-float [B,T,H,W,CPAD] images with x s = h + l (22 significant bits) and
+    state = device f32[3] (scratch, s, 1/s), s the power of two that brings max |x| below 2^14.  T*H*W must be a multiple of 4."""
+    require_cuda(x)
+    if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
+        raise TypeError("pack_split2_ncdhw_f32_to_ndhwc_f16: a contiguous float32 [B,C,T,H,W] tensor is expected")
+    b, c, t, h, w = x.shape
+    planes = torch.empty((2, b, t, h, w, bf16_cpad(c)), dtype=torch.float16, device=x.device)
+    state = torch.empty(3, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_pack_split2_ncdhw_f32_to_ndhwc_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(state), b, c, t, h, w,
+                                                          current_stream_ptr()), "pv_pack_split2_ncdhw_f32_to_ndhwc_f16")
+    return planes[0], planes[1], state
+
+
+def conv3d_bwd_weight_f16(x: torch.Tensor, dy: torch.Tensor, c_in: int, c_out: int, padding=(0, 0, 0)):
+    """conv3d_bwd_weight_bf16 on half-float operand images: x [B,T,H,W,CPAD] f16, dy [B,To,Ho,Wo,32] f16."""
+    require_cuda(x, dy)
+    b, t, h, w, cpad = x.shape
+    d = conv_dims(b, c_in, c_out, t, h, w, padding)
+    need = c_sz(0)
+    lib = get_lib()
+    check(lib.pv_conv3d_bwd_weight_bf16_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "wgrad workspace")
+    ws = _workspace("wgrad", need.value, x.device)
+    dw = torch.empty((c_out, c_in, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+    check(lib.pv_conv3d_bwd_weight_f16(ptr(x), ptr(dy), ptr(dw), ptr(db), ctypes.byref(d), ptr(ws), ws.numel(),
+                                       current_stream_ptr()), "pv_conv3d_bwd_weight_f16")
+    return dw, db
+
+
+def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0, 0, 0)):
+    """Weight and bias gradient of a 3x3x3, stride-1 Conv3d with 32 output channels at f32 accuracy on the F16 matrix cores:
+    x f32 [B,Ci<=32,T,H,W] and dy f32 [B,32,To,Ho,Wo] (already multiplied by the ReLU derivative) are each scaled by a power of
+    two and split in two half-float terms (22 bits), the weight-gradient kernel runs on the three operand pairs whose product
+    is above 2^-22 of the result -- (l,h), (h,l), (h,h) -- and the three f32 results are added in that order, then un-scaled.
+    Half the matrix work and 4/5 of the split traffic of conv3d_bwd_weight_f32_on_bf16x3.  -> (dw [32,Ci,3,3,3], db [32])."""
+    ci = x.shape[1]
+    xh, xl, xs = pack_split2_ncdhw_f32_to_ndhwc_f16(x)
+    dh, dl, ds = pack_split2_ncdhw_f32_to_ndhwc_f16(dy)
+    parts = torch.empty((3, 32 * ci * 27), dtype=torch.float32, device=x.device)
+    dbp = torch.empty((2, 32), dtype=torch.float32, device=x.device)
+    for i, (px, pd) in enumerate(((xl, dh), (xh, dl), (xh, dh))):
+        dw_i, db_i = conv3d_bwd_weight_f16(px, pd, ci, 32, padding)
+        parts[i].copy_(dw_i.reshape(-1))
+        if i >= 1:
+            dbp[i - 1].copy_(db_i)       # the bias gradient is the plain sum of dy: one term per plane of dy (l, then h)
+    dw = torch.empty((32, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
+    check(get_lib().pv_sum_slabs_acc_f32(ptr(parts), ptr(dw), parts.shape[1], 3, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
+    db = torch.empty(32, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_sum_slabs_acc_f32(ptr(dbp), ptr(db), 32, 2, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
+    dw.mul_(xs[2]).mul_(ds[2])      # exact: powers of two (device scalars: no host round trip)
+    db.mul_(ds[2])
+    return dw, db
+
+
 def unpack_ndhwc_bf16_to_ncdhw_f32(xp: torch.Tensor, c: int) -> torch.Tensor:
     require_cuda(xp)
     b, t, h, w, cpad = xp.shape

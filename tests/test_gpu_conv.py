@@ -313,6 +313,37 @@ def test_three_way_split_is_exact_and_the_weight_gradient_built_on_it_is_f32_acc
         assert (db.cpu().double() - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("magnitude", [3.0, 2e-7, 5e4])
+def test_two_term_half_float_split_and_the_weight_gradient_built_on_it(device, magnitude):
+    """pv_pack_split2_...: x s = h + l to 2^-22 of the largest element (s the power of two the call reports), whatever the
+    tensor's magnitude (gradients of 1e-7 would vanish in a half float without the scale); and the weight gradient formed from
+    three f16 matrix-core launches on the planes, un-scaled, equals torch's f64 gradient to a few 1e-6."""
+    K, _ = _mods()
+    shape = (3, 11, 6, 10, 12)
+    b, c, t, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(shape, generator=g) * magnitude).to(device)
+    hh, ll, st = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x)
+    s, inv = float(st[1]), float(st[2])
+    assert s * inv == 1.0 and np.log2(s) == round(np.log2(s))
+    assert 2.0 ** 13 <= float(x.abs().max()) * s < 2.0 ** 14
+    rec = ((hh.double() + ll.double()) * inv).permute(0, 4, 1, 2, 3)[:, :c]
+    assert float((rec - x.double()).abs().max()) <= 2.0 ** -22 * float(x.abs().max())
+    assert bool((hh[..., c:] == 0).all()) and bool((ll[..., c:] == 0).all())
+    wt = torch.randn(32, c, 3, 3, 3, generator=g) * 0.1
+    xr = x.cpu().double()
+    wr = wt.double().requires_grad_(True)
+    br = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(xr, wr, br)
+    gy = torch.randn(y.shape, generator=g) * (1e-3 / magnitude)
+    y.backward(gy.double())
+    dw, db = K.conv3d_bwd_weight_f32_on_f16x2(x, gy.to(device).contiguous())
+    assert (dw.cpu().double() - wr.grad).abs().max().item() <= 2e-5 * wr.grad.abs().max().item()
+    assert (db.cpu().double() - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item()
+    dw3, db3 = K.conv3d_bwd_weight_f32_on_bf16x3(x, gy.to(device).contiguous())
+    assert (dw - dw3).abs().max().item() <= 2e-5 * dw3.abs().max().item()
+
+
 def _mask_bits(mask, y_shape):
     """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
     b, t, h, w, c = y_shape
