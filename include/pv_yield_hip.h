@@ -328,6 +328,12 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
                               float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow, int32_t m, int32_t n,
                               int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
                               void* stream);
+/* The same pass for the f32 model (precision="fp32"): x in f32, exact f32 products accumulated in batch order, no operand copy
+ * to maintain.  Replaces the f32 weight-gradient GEMM (0.5 GB written, read back by the optimiser) + torch.optim.Adam's pass
+ * over fc1 (base_model.py:146). */
+int pv_linear_wgrad_adam_f32(const float* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                             float* exp_avg_sq, int32_t m, int32_t n, int64_t k, double lr, double beta1, double beta2,
+                             double eps, int32_t step, void* stream);
 
 /* The same pass ALSO produces dx = (dy ⊙ (y>0)) · W (bf16 [M,K], may be NULL) from the pre-update weights it streams, rounded
  * to bf16 as the operand copy held them during the forward: fc1's whole backward in one pass over the matrix (m <= 32,

@@ -126,6 +126,7 @@ SIGNATURES = {
     "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_wgrad_adam_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
                                   c_i32, c_vp],
+    "pv_linear_wgrad_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_i32, c_vp],
     "pv_linear_wgrad_dx_adam_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64,
                                      c_f64, c_f64, c_i32, c_i32, c_i32, c_vp],
     "pv_linear_wgrad_bf16out": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],

@@ -217,8 +217,10 @@ struct AdamScalars {
   float one_minus_b1, beta2, one_minus_b2, bc2_sqrt, eps, neg_step_size;
 };
 
-template <int MODE>  // 0: write dw f32; 1: fused Adam update (dw = parameter); 2: write dw bf16 (dw reinterpreted)
-__global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t* __restrict__ x,
+// XT: uint16_t = x in bf16 (the bf16 model); float = x in f32 (precision="fp32": exact f32 products, f32 accumulation in batch
+// order -- the fused form of that model's fc1 weight gradient + Adam, pv_linear_wgrad_adam_f32)
+template <int MODE, typename XT = uint16_t>  // 0: write dw f32; 1: fused Adam update (dw = parameter); 2: write dw bf16 (dw reinterpreted)
+__global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const XT* __restrict__ x,
                                                                   const float* __restrict__ dy,
                                                                   const float* __restrict__ ymask,
                                                                   float* __restrict__ dw, int m, int n, long long k,
@@ -252,11 +254,16 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_bf16_kernel(const uint16_t*
     for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
 #pragma unroll 4
   for (int rr = 0; rr < m; ++rr) {
-    u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)rr * k + k8);
     f32x2_t xv2[4];
+    if constexpr (sizeof(XT) == 4) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(x + (size_t)rr * k + k8), hi = *reinterpret_cast<const f32x4*>(x + (size_t)rr * k + k8 + 4);
+      xv2[0] = (f32x2_t){lo[0], lo[1]}, xv2[1] = (f32x2_t){lo[2], lo[3]}, xv2[2] = (f32x2_t){hi[0], hi[1]}, xv2[3] = (f32x2_t){hi[2], hi[3]};
+    } else {
+      u32x4 raw = *reinterpret_cast<const u32x4*>(x + (size_t)rr * k + k8);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
+      for (int q = 0; q < 4; ++q)
+        xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
+    }
     f32x4 gq[BT / 4];
 #pragma unroll
     for (int q = 0; q < BT / 4; ++q) gq[q] = *reinterpret_cast<const f32x4*>(g + rr * BT + 4 * q);
@@ -956,6 +963,25 @@ int pv_linear_wgrad_adam_bf16(const uint16_t* x, const float* dy, const float* y
   hipLaunchKernelGGL(linear_bwd_dw_bf16_kernel<1>, dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds,
                      as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, bf16_shadow, ad);
   return check_launch("pv_linear_wgrad_adam_bf16");
+}
+
+int pv_linear_wgrad_adam_f32(const float* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
+                             float* exp_avg_sq, int32_t m, int32_t n, int64_t k, double lr, double beta1, double beta2,
+                             double eps, int32_t step, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_adam_f32: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_adam_f32: bad sizes (k must be a multiple of 8)");
+  PV_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)param % 16) == 0 && ((uintptr_t)exp_avg % 16) == 0 && ((uintptr_t)exp_avg_sq % 16) == 0,
+             PV_EINVAL, "pv_linear_wgrad_adam_f32: 16-byte aligned buffers expected");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_adam_f32: step must be >= 1");
+  size_t lds = (size_t)m * BT * sizeof(float);
+  PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_wgrad_adam_f32: m=%d too large", m);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                 (float)(-(lr / bc1))};
+  unsigned kb = (unsigned)((k / 8 + 255) / 256);
+  hipLaunchKernelGGL((linear_bwd_dw_bf16_kernel<1, float>), dim3(xcd_grid(kb, (unsigned)((n + BT - 1) / BT))), dim3(256), lds,
+                     as_stream(stream), x, dy, y_relu_mask, param, m, n, (long long)k, exp_avg, exp_avg_sq, (uint16_t*)nullptr, ad);
+  return check_launch("pv_linear_wgrad_adam_f32");
 }
 
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,

@@ -49,6 +49,7 @@ class LinearF32(torch.autograd.Function):
         y = K.linear_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
+        ctx.weight_param = weight
         return y
 
     @staticmethod
@@ -58,7 +59,15 @@ class LinearF32(torch.autograd.Function):
             # fc1-sized: the two products on the matrix cores at f32 accuracy (pv_gemm_f32), 650 us against 790 us
             g = K.relu_gate_f32(dy, y) if y is not None else dy.contiguous()
             dx = K.gemm(g, weight) if ctx.needs_input_grad[0] else None
-            dw = K.gemm(g.t(), x)
+            owner = ctx.weight_param
+            if (getattr(owner, "_pv_grad_mode", "autograd") == "fused" and getattr(owner, "_pv_takes_f32_pending", False)
+                    and x.shape[1] % 8 == 0):
+                # HipAdam owns this parameter (single process): it forms the gradient inside its pass over p / m / v
+                # (pv_linear_wgrad_adam_f32): the 0.5 GB gradient is neither written nor read back
+                owner._pv_pending_f32 = (x, g)
+                dw = None
+            else:
+                dw = K.gemm(g.t(), x)
             return dx, dw, (K.colsum(g) if ctx.has_bias else None), None
         dx, dw, db = K.linear_bwd_f32(x, weight.contiguous(), dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
         return dx, dw, (db if ctx.has_bias else None), None

@@ -645,6 +645,18 @@ def linear_wgrad_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_
                                               step, current_stream_ptr()), "pv_linear_wgrad_adam_bf16")
 
 
+def linear_wgrad_adam_f32(x, dy, y_mask, param, exp_avg, exp_avg_sq, step: int, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
+    """The f32 model's fc1: gradient (dy ⊙ (y>0))^T x from the f32 activations (exact products, f32 accumulation in batch order)
+    applied by Adam in the same pass over p, m, v -- no gradient tensor (y_mask may be None: dy already gated)."""
+    require_cuda(x, dy, y_mask, param, exp_avg, exp_avg_sq)
+    if x.dtype != torch.float32 or not x.is_contiguous() or not dy.is_contiguous():
+        raise TypeError("linear_wgrad_adam_f32: contiguous float32 x [M,K] and dy [M,N] expected")
+    m, k = x.shape
+    n = param.shape[0]
+    check(get_lib().pv_linear_wgrad_adam_f32(ptr(x), ptr(dy), ptr(y_mask), ptr(param), ptr(exp_avg), ptr(exp_avg_sq), m, n, k, lr,
+                                             betas[0], betas[1], eps, step, current_stream_ptr()), "pv_linear_wgrad_adam_f32")
+
+
 def linear_wgrad_dx_adam_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4,
                               betas=(0.9, 0.999), eps=1e-8, need_dx=True, need_db=False, gate_dx_by_x=False,
                               moments_tiled=False):

@@ -99,6 +99,8 @@ class HipAdam(torch.optim.Optimizer):
         for p in self.large_params():
             p._pv_grad_mode = mode
             p._pv_pending = None
+            p._pv_pending_f32 = None
+            p._pv_takes_f32_pending = mode == "fused" and not self.capturable
             p._pv_grad_bf16 = None
             p._pv_grad_shard = None
             p._pv_eager_update = self._make_eager_update(p) if (mode == "fused" and self.overlap_large_update) else None
@@ -272,9 +274,10 @@ class HipAdam(torch.optim.Optimizer):
             stepped = []
             for p in group["params"]:
                 pending = getattr(p, "_pv_pending", None)
+                pending32 = getattr(p, "_pv_pending_f32", None)
                 gb = getattr(p, "_pv_grad_bf16", None)
                 gs = getattr(p, "_pv_grad_shard", None)
-                if p.grad is None and pending is None and gb is None and gs is None:
+                if p.grad is None and pending is None and pending32 is None and gb is None and gs is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("HipAdam steps parameters on the MI355X only (no CPU path)")
@@ -284,6 +287,15 @@ class HipAdam(torch.optim.Optimizer):
                 if self.capturable and (pending is not None or gs is not None or gb is not None):
                     raise NotImplementedError("HipAdam(capturable=True) covers the single-process paths (fc1's one-pass "
                                               "backward + the multi-tensor step); not the deferred / exchanged fc1 gradients")
+                if pending32 is not None and p.grad is None:
+                    # the f32 model's fc1 (functional.LinearF32): gradient from the f32 activations + Adam in one pass
+                    x, g = pending32
+                    p._pv_pending_f32 = None
+                    K.linear_wgrad_adam_f32(x, g, None, p, st["exp_avg"], st["exp_avg_sq"], int(st["step"].item()),
+                                            lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    if getattr(p, "_pv_bf16_shadow", None) is not None:
+                        p._pv_bf16_shadow = None      # (a bf16 operand copy from an earlier bf16 forward is stale now)
+                    continue
                 if pending is not None and p.grad is None:
                     from .functional import bf16_shadow_of
                     x, dy, y = pending

@@ -515,6 +515,36 @@ def test_fused_wgrad_adam_is_bit_identical_to_two_pass(device):
         assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb), step
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 128, 8192), (5, 24, 1024 + 8)])
+def test_f32_fused_wgrad_adam_follows_torch_adam_on_the_f64_gradient(device, m, n, k):
+    """pv_linear_wgrad_adam_f32 (the f32 model's fc1: gradient from the f32 activations + Adam in one pass): three steps against
+    torch.optim.Adam fed with the gradient computed in f64 -- parameters and moments to a few ulps."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(78)
+    p0 = torch.randn(n, k, generator=g) * 0.01
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref], lr=5e-4)
+    pb = p0.clone().to(device)
+    mb, vb = torch.zeros_like(pb), torch.zeros_like(pb)
+    for step in (1, 2, 3):
+        x = torch.randn(m, k, generator=g)
+        dy = torch.randn(m, n, generator=g)
+        y = torch.relu(torch.randn(m, n, generator=g))
+        gated = dy * (y > 0)
+        ref.grad = gated.double().t() @ x.double()
+        opt.step()
+        if step == 2:      # dy already gated by the caller (functional.LinearF32 passes relu_gate_f32's result)
+            K.linear_wgrad_adam_f32(x.to(device), gated.to(device), None, pb, mb, vb, step, lr=5e-4)
+        else:
+            K.linear_wgrad_adam_f32(x.to(device), dy.to(device), y.to(device), pb, mb, vb, step, lr=5e-4)
+        st = opt.state[ref]
+        # (f32 accumulation of 32 products with mixed signs: absolute error ~ 1e-6 of the largest term)
+        assert torch.allclose(mb.cpu().double(), st["exp_avg"], rtol=1e-5, atol=2e-6), step
+        assert torch.allclose(vb.cpu().double(), st["exp_avg_sq"], rtol=2e-5, atol=1e-8), step
+        # (Adam's update is lr * m / (sqrt(v) + eps): where the gradient is ~0 its sign decides a whole lr)
+        assert float((pb.cpu().double() - ref.detach()).abs().max()) <= 2e-6, step
+
+
 @pytest.mark.parametrize("m,n,k", [(32, 128, 8192), (7, 128, 1024 + 8), (32, 16, 4096), (4, 128, 128 * 33)])
 def test_fused_wgrad_dx_adam_single_pass(device, m, n, k):
     """pv_linear_wgrad_dx_adam_bf16: parameters / moments / operand copy bit-identical to pv_linear_wgrad_adam_bf16, and dx
