@@ -2241,6 +2241,297 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
 #endif
 }
 
+// ---- prep + PolyExp with the two PolyExp passes on the F16 matrix cores (round 4) -------------------------------------------
+// fb_prep_polyexp_tile_kernel spends 23 000 cycles per 64 x 64 image on the two separable 2n+1-tap passes (index arithmetic
+// and LDS reads of a per-pixel tap loop).  Both passes are products with banded 64 x 64 matrices that already contain the
+// border replication (fb_polyexp_matrix_kernel): vertically t_j = V_j I for V_g, V_xg, V_xxg, horizontally
+//   b1 = t0 H_g^T  b2 = t0 H_xg^T  b4 = t0 H_xxg^T  b3 = t1 H_g^T  b6 = t1 H_xg^T  b5 = t2 H_g^T,
+// nine products per image, evaluated exactly like the window blur of fb_level_u_kernel: the image handed over transposed as two
+// half-float planes (x s = h + l, 22 bits), first product U_j = X^T V_j^T, its accumulators re-split as the B operand of the
+// second, three matrix instructions per two-term pair.  Every scale is a power of two fixed by the taps (the image is 8-bit:
+// |I| <= 255, |t_j| <= 255 max-row-sum(V_j)): no reductions.  Eight waves: wave (strip, mbo, g) owns output block (strip, mbo);
+// group 0 takes t0 (b1, b2, b4), group 1 takes t1 and t2 (b3, b6, b5) and hands b3 and b5 over through LDS, so that group 0
+// stores the (c0, c1) and (c2, c3) pairs whole and group 1 the c4 plane.  The 3-tap Gaussian and the resize before it stay on
+// the vector ALU (fb_prep_polyexp_tile_kernel's expressions).  MOSAIC (levels up to 32 x 32): four images per tile, block-
+// diagonal matrices.  Accumulation order differs from the tap loops: results agree to ~1e-6 relative, not bit for bit.
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long fb_polyexp_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
+struct FbPolyScales {
+  float sV[3], sH[3], fU[3];      // scales of V_g, V_xg, V_xxg / H_g, H_xg, H_xxg; re-split factors of U_0..U_2
+  float c11_b3, c11_b2, c03_b1, c33_b5, c33_b4, c55_b6;      // ig.. with the products' scales divided out
+};
+
+__global__ __launch_bounds__(256) void fb_polyexp_matrix_kernel(float* __restrict__ P6, int lh, int lw, FbPoly pk, int mosaic) {
+  // P6[3 v + j][64][64]: v = 0 vertical (size lh), 1 horizontal (size lw); j = 0: g, 1: x g (odd), 2: x^2 g.  Row y, column y':
+  // the weight of input y' in output y, border replicated.  mosaic (sizes <= 32): the matrix twice on the diagonal (0 and 32)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 6 * 64 * 64; i += gridDim.x * blockDim.x) {
+    const int which = i >> 12, j = which % 3, n = which < 3 ? lh : lw;
+    int y = (i >> 6) & 63, yp = i & 63;
+    const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
+    if (mosaic) y &= 31, yp &= 31;
+    float s = 0.f;
+    if (same_block && y < n && yp < n) {
+      if (j == 0 && y == yp) s = pk.g[0];
+      for (int k = 1; k <= pk.n; ++k) {
+        const float c = j == 0 ? pk.g[k] : (j == 1 ? pk.xg[k] : pk.xxg[k]);
+        if (min(y + k, n - 1) == yp) s += c;
+        if (max(y - k, 0) == yp) s += j == 1 ? -c : c;
+      }
+    }
+    P6[i] = s;
+  }
+}
+
+template <bool MOSAIC>
+__global__ __launch_bounds__(512) void fb_prep_polyexp_mfma_kernel(const uint8_t* __restrict__ prev, const uint8_t* __restrict__ next,
+                                                                   long long prev_stride, long long next_stride,
+                                                                   long long pairs_per_group, long long group_stride,
+                                                                   float* __restrict__ R, long long n_img, int chain_f, int h, int w,
+                                                                   int lh, int lw, int mode, double inv_fx, double inv_fy, FbTaps kt,
+                                                                   const float* __restrict__ P6, FbPolyScales sc) {
+  constexpr int XS = 64 + 8, PLANE = 64 * XS, KS = 4, NI = MOSAIC ? 4 : 1;
+  __shared__ float bufA[64 * 64];        // source as float, later the blurred image
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][PLANE];      // the level image(s), transposed, (h, l) half-float planes
+  __shared__ __attribute__((aligned(16))) f32x4 mail[4][2][4][64];    // group 1 -> group 0: b3, b5 of block sm
+  const int pw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // (everything derived from the lane number is re-derived per phase from an opaque copy, as in fb_level_u_kernel: the phases'
+  // addresses would otherwise stay alive through each other -- some sixty registers beside 128 of operands)
+  int lane_src = threadIdx.x & 63;
+  int lane = lane_src, tid = pw * 64 + lane, col = lane & 31, half = lane >> 5;
+  const int sm = pw & 3, strip = sm & 1, mbo = sm >> 1, grp = pw >> 2;
+  const int npx = h * w, lpx = lh * lw;
+
+  // operands (128 registers): group 0: V_g | H_g, H_xg, H_xxg; group 1: V_xg, V_xxg | H_g, H_xg.  opX is the group's fourth
+  // matrix: H_xxg (an A operand) for group 0, V_xxg (a B operand) for group 1
+  FbSplit2 gvA[KS], opX[KS], ghA[KS], ghB[KS];
+  {
+    const float* va = P6 + (grp ? 1 : 0) * 4096;
+    const float sva = grp ? sc.sV[1] : sc.sV[0];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = va[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+      gvA[ks] = fb_split2(t, sva);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = P6[3 * 4096 + (32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+      ghA[ks] = fb_split2(t, sc.sH[0]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = P6[4 * 4096 + (32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+      ghB[ks] = fb_split2(t, sc.sH[1]);
+      // (one address expression for both groups: the group picks the matrix, the row and the column order by arithmetic)
+      const int xrow = grp ? 32 * strip + col : 32 * mbo + col;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int xcol = grp ? 16 * ks + 8 * half + i : 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half);
+        t[i] = P6[(grp ? 2 : 5) * 4096 + xrow * 64 + xcol];
+      }
+      opX[ks] = fb_split2(t, grp ? sc.sV[2] : sc.sH[2]);
+    }
+  }
+  auto first = [&](const FbSplit2 (&gv)[KS], float f, FbSplit2 (&b)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {      // row block mb of U becomes k-steps 2 mb, 2 mb + 1 of the second product: one block alive
+      fb_v16f u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        FbSplit2 a;
+        const uint16_t* xa = &Xs[0][0] + (32 * mb + col) * XS + 16 * ks + 8 * half;
+        a.h = *reinterpret_cast<const fb_f16x8*>(xa);
+        a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
+        u = fb_mfma2(a, gv[ks], u);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = u[8 * k2 + i];
+        b[2 * mb + k2] = fb_split2(t, f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto second = [&](const FbSplit2 (&gh)[KS], const FbSplit2 (&b)[KS]) __attribute__((always_inline)) -> fb_v16f {
+    fb_v16f res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = 0.f;
+#pragma unroll
+    // U as the A operand, the window matrix as B (the same register contents: the two operand layouts mirror each other): the
+    // result is the block itself rather than its transpose -- lane = COLUMN x, registers = rows -- so that the 32 lanes of a
+    // half wave store 256 contiguous bytes of a row
+    for (int ks = 0; ks < KS; ++ks) res = fb_mfma2(b[ks], gh[ks], res);
+    return res;
+  };
+
+  const long long n_units = (n_img + NI - 1) / NI;
+  // The Gaussian before the resize is the 3-tap one here (the launcher's condition: sigma 0 / 0.5 at pyr_scale 0.5), the resize a
+  // copy (mode 0) or the exact 2 x 2 mean (mode 1): a thread owns ONE column and 8 rows of the source -- the row filter of its
+  // 10 rows straight from the source in LDS (3 reads per row, consecutive lanes), the column filter and the resize from
+  // registers (mode 1: the right-hand neighbour by a lane shuffle), one barrier per image.  Same expressions and rounding
+  // order as fb_prep_polyexp_tile_kernel's filters.
+  const float k0 = kt.k[1], k1 = kt.k[2];      // taps (k1, k0, k1) of the 3-tap kernel: kt.k[rr], kt.k[rr + 1] with rr = 1
+  int xm = lane == 0 ? 1 : lane - 1, xp = lane == w - 1 ? w - 2 : lane + 1;      // BORDER_REFLECT_101
+  auto rederive = [&]() __attribute__((always_inline)) {
+    asm volatile("" : "+v"(lane_src));
+    lane = lane_src, tid = pw * 64 + lane, col = lane & 31, half = lane >> 5;
+    xm = lane == 0 ? 1 : lane - 1, xp = lane == w - 1 ? w - 2 : lane + 1;
+  };
+  // the source image of (unit, q) as two 32-bit words per thread (8 pixels: row tid / (w / 8)... flat index 8 tid), prefetched
+  auto fetch_src = [&](long long unit, int q) __attribute__((always_inline)) -> u32x2 {
+    const long long im = unit * NI + q;
+    const bool ok = (int)(unit < n_units) & (int)(im < n_img) & (int)(8 * tid < npx);
+    const uint8_t* img = fb_image_of(ok ? im : 0, prev, next, prev_stride, next_stride, pairs_per_group, group_stride, chain_f);
+    u32x2 v = {0u, 0u};
+    if (ok) v = *reinterpret_cast<const u32x2*>(img + 8 * tid);
+    return v;
+  };
+  u32x2 src_next = fetch_src(blockIdx.x, 0);
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1;
+#define FBP_PHASE(slot) do { PV_STAMP(s1); dg[slot] += s1 - s0; s0 = s1; } while (0)
+  PV_STAMP(s0);
+#else
+#define FBP_PHASE(slot) do { } while (0)
+#endif
+  for (long long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    // ---- the level image(s): u8 -> 3-tap Gaussian -> resize -> half-float planes, transposed ---------------------------------
+#pragma unroll 1
+    for (int q = 0; q < NI; ++q) {
+      const bool im_ok = unit * NI + q < n_img;
+      rederive();
+      {      // the source as floats in LDS, rows of w
+        const u32x2 sv = src_next;
+        if (8 * tid < npx) {
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (float)((sv[e >> 2] >> (8 * (e & 3))) & 0xffu);
+          *reinterpret_cast<f32x4*>(bufA + 8 * tid) = (f32x4){f[0], f[1], f[2], f[3]};
+          *reinterpret_cast<f32x4*>(bufA + 8 * tid + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+        }
+      }
+      // the next source image's words are on their way while this one is filtered and multiplied
+      src_next = q + 1 < NI ? fetch_src(unit, q + 1) : fetch_src(unit + gridDim.x, 0);
+      FBP_PHASE(0);
+      __syncthreads();
+      FBP_PHASE(1);
+      float bl[8];      // the blurred image at (rows 8 pw .. + 7, column lane)
+      {
+        float rf[10];      // row-filtered rows 8 pw - 1 .. 8 pw + 8 (reflected at the image's edge)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+          int y = 8 * pw - 1 + i;
+          y = y < 0 ? 1 : (y > h - 1 ? 2 * h - 2 - y : y);
+          y = y > h - 1 ? h - 1 : (y < 0 ? 0 : y);      // (rows of waves beyond the image: any valid row)
+          const float* srow = bufA + y * w;
+          const float c = lane < w ? srow[lane] : 0.f, l = lane < w ? srow[xm] : 0.f, r = lane < w ? srow[xp] : 0.f;
+          rf[i] = __fadd_rn(c * k0, __fmul_rn(l + r, k1));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bl[i] = __fadd_rn(__fmul_rn(rf[i + 1], k0), __fmul_rn(__fadd_rn(rf[i], rf[i + 2]), k1));
+      }
+      if (mode == 0) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (int)im_ok & (int)(lane < lw) & (int)(8 * pw + i < lh) ? bl[i] : 0.f;
+        const FbSplit2 sp = fb_split2(v, 64.f);      // |I| <= 255: below 2^14
+        if (!MOSAIC || (pw < 4 && lane < 32)) {      // (MOSAIC: a source of up to 32 x 32 fills tile (q >> 1, q & 1))
+          const int ty = MOSAIC ? q >> 1 : 0, tx = MOSAIC ? q & 1 : 0;
+          uint16_t* Xc = &Xs[0][0] + (32 * tx + lane) * XS + 32 * ty + 8 * pw;
+          *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
+          *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
+        }
+      } else {
+        // mode 1: level pixel (y', x') = mean of the 2 x 2 block at (2 y', 2 x'): the even lanes combine their column with the
+        // next lane's; this wave's rows 8 pw .. + 7 give level rows 4 pw .. + 3
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = __fadd_rn(bl[2 * i], __shfl_down(bl[2 * i], 1, 64));
+          const float b = __fadd_rn(bl[2 * i + 1], __shfl_down(bl[2 * i + 1], 1, 64));
+          const int xo = lane >> 1, yo = 4 * pw + i;
+          v[i] = (int)im_ok & (int)(xo < lw) & (int)(yo < lh) ? __fmul_rn(__fadd_rn(a, b), 0.25f) : 0.f;
+        }
+        const FbSplit2 sp = fb_split2(v, 64.f);
+        if ((lane & 1) == 0) {
+          const int ty = MOSAIC ? q >> 1 : 0, tx = MOSAIC ? q & 1 : 0;
+          uint16_t* Xc = &Xs[0][0] + (32 * tx + (lane >> 1)) * XS + 32 * ty + 4 * pw;
+          const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), lw4 = __builtin_bit_cast(u32x4, sp.l);
+          *reinterpret_cast<u32x2*>(Xc) = (u32x2){hw[0], hw[1]};
+          *reinterpret_cast<u32x2*>(Xc + PLANE) = (u32x2){lw4[0], lw4[1]};
+        }
+      }
+      FBP_PHASE(2);
+      __syncthreads();      // X complete (last image of the unit) / bufA free for the next image
+      FBP_PHASE(1);
+    }
+    // ---- the nine products ---------------------------------------------------------------------------------------------------
+    rederive();
+    FbSplit2 b[KS];
+    fb_v16f r0, r1, r2;      // group 0: b1, b2, b4; group 1: b3, b6, b5
+    if (grp == 0) {
+      first(gvA, sc.fU[0], b);
+      r0 = second(ghA, b), r1 = second(ghB, b), r2 = second(opX, b);
+    } else {
+      first(gvA, sc.fU[1], b);
+      r0 = second(ghA, b);      // b3: handed over at once
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) mail[sm][0][qd][lane] = (f32x4){r0[4 * qd], r0[4 * qd + 1], r0[4 * qd + 2], r0[4 * qd + 3]};
+      __builtin_amdgcn_sched_barrier(0);
+      r1 = second(ghB, b);      // b6: this group's own plane
+      first(opX, sc.fU[2], b);
+      r2 = second(ghA, b);      // b5
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) mail[sm][1][qd][lane] = (f32x4){r2[4 * qd], r2[4 * qd + 1], r2[4 * qd + 2], r2[4 * qd + 3]};
+    }
+    FBP_PHASE(3);
+    __syncthreads();      // the mailboxes are filled; nobody reads X any more
+    FBP_PHASE(1);
+    rederive();
+    // ---- R = the polynomial coefficients; lane = column x of the block, registers = its rows ---------------------------------------
+    {
+      const long long im = MOSAIC ? unit * 4 + 2 * strip + mbo : unit;
+      const int x = (MOSAIC ? 0 : 32 * mbo) + col;
+      float* d = R + im * lpx * 5;
+      if (im < n_img && x < lw) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 b3 = {0.f, 0.f, 0.f, 0.f}, b5 = {0.f, 0.f, 0.f, 0.f};
+          if (grp == 0) b3 = mail[sm][0][qd][lane], b5 = mail[sm][1][qd][lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const int y = (MOSAIC ? 0 : 32 * strip) + fb_acc_row(r, half);
+            if (y < lh) {
+              if (grp == 0) {
+                const float b1s = __fmul_rn(r0[r], sc.c03_b1);
+                *reinterpret_cast<fb_f2*>(d + ((size_t)y * lw + x) * 2) = (fb_f2){__fmul_rn(b3[e], sc.c11_b3), __fmul_rn(r1[r], sc.c11_b2)};
+                *reinterpret_cast<fb_f2*>(d + 2 * lpx + ((size_t)y * lw + x) * 2) =
+                    (fb_f2){__builtin_fmaf(b5[e], sc.c33_b5, b1s), __builtin_fmaf(r2[r], sc.c33_b4, b1s)};
+              } else {
+                d[4 * lpx + (size_t)y * lw + x] = __fmul_rn(r1[r], sc.c55_b6);
+              }
+            }
+          }
+        }
+      }
+    }
+    FBP_PHASE(4);
+    __syncthreads();      // the mailboxes and X are reused by the next unit
+    FBP_PHASE(1);
+#ifdef PV_DIAG_STAMPS
+    dg[7] += 1;
+#endif
+  }
+#undef FBP_PHASE
+#ifdef PV_DIAG_STAMPS
+  if (lane == 0 && blockIdx.x * 8 + pw < PV_DIAG_WAVES)
+    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_polyexp_diag[(size_t)(blockIdx.x * 8 + pw) * PV_DIAG_SLOTS + i] = dg[i];
+#endif
+}
+
 // ---- Gaussian window blur of the 5-channel M, vertical then horizontal (+ 2x2 solve) --------------
 __global__ __launch_bounds__(256) void fb_blur_v_kernel(const float* __restrict__ M, float* __restrict__ V,
                                                          long long n_pairs, int height, int width, FbTaps kt) {
@@ -2445,6 +2736,51 @@ static int fb_num_levels(int h, int w, double pyr_scale, int levels) {
   return k;
 }
 
+// power-of-two scales of fb_prep_polyexp_mfma_kernel's operands, from the taps alone (the image is 8-bit)
+static void host_polyexp_scales(const FbPoly& pk, int lh, int lw, FbPolyScales* sc) {
+  auto pow2_below_2_13 = [](double bound) -> double {      // s with bound * s < 2^13 (a binade of margin for rounding)
+    if (!(bound > 0)) return 1.0;
+    int e;
+    frexp(bound, &e);
+    return ldexp(1.0, 13 - e);
+  };
+  double tU[3], sH[3];
+  for (int j = 0; j < 3; ++j) {
+    for (int dir = 0; dir < 2; ++dir) {
+      const int n = dir ? lw : lh;
+      double mx = 0, rs = 0;
+      for (int y = 0; y < n; ++y) {
+        double row[64] = {0};
+        if (j == 0) row[y] += pk.g[0];
+        for (int k = 1; k <= pk.n; ++k) {
+          const double c = j == 0 ? pk.g[k] : (j == 1 ? pk.xg[k] : pk.xxg[k]);
+          row[std::min(y + k, n - 1)] += c;
+          row[std::max(y - k, 0)] += j == 1 ? -c : c;
+        }
+        double ssum = 0;
+        for (int yp = 0; yp < n; ++yp) ssum += fabs(row[yp]), mx = std::max(mx, fabs(row[yp]));
+        rs = std::max(rs, ssum);
+      }
+      if (dir == 0) {
+        const double sV = pow2_below_2_13(mx);
+        tU[j] = pow2_below_2_13(255.0 * rs);
+        sc->sV[j] = (float)sV;
+        sc->fU[j] = (float)(tU[j] / (64.0 * sV));
+      } else {
+        sH[j] = pow2_below_2_13(mx);
+        sc->sH[j] = (float)sH[j];
+      }
+    }
+  }
+  // b1 = (H_g, U_0), b2 = (H_xg, U_0), b4 = (H_xxg, U_0), b3 = (H_g, U_1), b6 = (H_xg, U_1), b5 = (H_g, U_2)
+  sc->c03_b1 = (float)(pk.ig03 / (sH[0] * tU[0]));
+  sc->c11_b2 = (float)(pk.ig11 / (sH[1] * tU[0]));
+  sc->c33_b4 = (float)(pk.ig33 / (sH[2] * tU[0]));
+  sc->c11_b3 = (float)(pk.ig11 / (sH[0] * tU[1]));
+  sc->c55_b6 = (float)(pk.ig55 / (sH[1] * tU[1]));
+  sc->c33_b5 = (float)(pk.ig33 / (sH[0] * tU[2]));
+}
+
 struct FbLayout {
   size_t off_I, off_T, off_R, off_M, off_V, off_flowA, off_flowB, off_G, total;
 };
@@ -2460,7 +2796,7 @@ static FbLayout fb_layout(long long n_pairs, int h, int w) {
   L.off_V = o; o = align(o + (size_t)n_pairs * px * 20);
   L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
-  L.off_G = o; o = align(o + 2 * 64 * 64 * sizeof(float));   // window matrices of the current pyramid level
+  L.off_G = o; o = align(o + 8 * 64 * 64 * sizeof(float));   // window matrices (2) and PolyExp matrices (6) of the current pyramid level
   L.total = o;
   return L;
 }
@@ -2582,7 +2918,29 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                                               !getenv("PV_FARNEBACK_TWO_LAUNCH_SMALL_LEVELS")));
     const bool iter_v2 = fused_iter;      // R pair-planar for the level kernel, [h][w][5] for the two-launch form
     stage_mark(coarse ? "farneback.coarse.prep_polyexp" : "farneback.level0.prep_polyexp", st);
-    if (polyexp_tile) {
+    // (its pre-filter stage is written for the 3-tap Gaussian, a copy or the exact 2 x 2 mean as the resize, and 8-byte words
+    // of the source: any other case keeps the vector-ALU kernel)
+    const bool polyexp_mfma = polyexp_tile && iter_v2 && smooth_sz == 3 && mode != 2 && w >= 2 && (h * w) % 8 == 0 &&
+                              (((uintptr_t)prev | (uintptr_t)next | (uintptr_t)prev_stride | (uintptr_t)next_stride |
+                                (uintptr_t)group_stride) & 7) == 0 &&
+                              !getenv("PV_FARNEBACK_POLYEXP_VALU") && !getenv("PV_FARNEBACK_POLYEXP_F64");
+    if (polyexp_mfma) {
+      // the two PolyExp passes as nine products on the f16 matrix cores (fb_prep_polyexp_mfma_kernel)
+      float* P6 = (float*)(ws + L.off_G) + 2 * 64 * 64;
+      FbPolyScales sc;
+      host_polyexp_scales(pk, lh, lw, &sc);
+      hipLaunchKernelGGL(fb_polyexp_matrix_kernel, dim3(96), dim3(256), 0, st, P6, lh, lw, pk, small_level ? 1 : 0);
+      const long long n_units = small_level ? (n_img + 3) / 4 : n_img;
+      const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);
+      if (small_level)
+        hipLaunchKernelGGL(fb_prep_polyexp_mfma_kernel<true>, dim3(grid), dim3(512), 0, st, prev, next, (long long)prev_stride,
+                           (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R, n_img, chain_f, h, w,
+                           lh, lw, mode, inv_fx, inv_fy, sm, (const float*)P6, sc);
+      else
+        hipLaunchKernelGGL(fb_prep_polyexp_mfma_kernel<false>, dim3(grid), dim3(512), 0, st, prev, next, (long long)prev_stride,
+                           (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R, n_img, chain_f, h, w,
+                           lh, lw, mode, inv_fx, inv_fy, sm, (const float*)P6, sc);
+    } else if (polyexp_tile) {
       const unsigned grid = (unsigned)std::min<long long>(n_img, 4096);
       // (PV_FARNEBACK_POLYEXP_F64=1: the horizontal pass on the reference's double accumulators, as in rounds 1-3)
       if (getenv("PV_FARNEBACK_POLYEXP_F64"))
@@ -2715,6 +3073,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
 }  // extern "C"
 
 #ifdef PV_DIAG_STAMPS
+extern "C" int pv_diag_read_fb_polyexp(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_polyexp_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 extern "C" int pv_diag_read_fb_iter(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::fb_iter_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }

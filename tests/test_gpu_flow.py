@@ -243,6 +243,9 @@ def test_fused_iteration_against_the_two_launch_form(device, monkeypatch, h, w, 
     operand scale is per pair).  A width that is no multiple of 4 is not taken by the fused form: both calls then run the
     same kernels and must agree exactly."""
     K = _ops()
+    # (both forms on the vector-ALU PolyExp, which is the only one the two-launch form has: this test compares the ITERATION
+    # kernels; the matrix-core PolyExp has its own test below)
+    monkeypatch.setenv("PV_FARNEBACK_POLYEXP_VALU", "1")
     # batch = 100: 200 stacks x 3 pairs = 600 pairs over 256 workgroups -- ranges of 2..3 pairs that cross stack boundaries;
     # with t = 12 (2 200 pairs) the coarse level's units of four pairs come in ranges of two or more as well
     raw, _ = advected_counts(batch=batch, t=t, channels=2, h=h, w=w, seed=3 * h + t)
@@ -269,6 +272,32 @@ def test_fused_iteration_against_the_two_launch_form(device, monkeypatch, h, w, 
     assert torch.equal(alone[0], fused_pairs[5])
     ref = fo.calc_optical_flow_farneback(u8[2, 0].cpu().numpy(), u8[2, 1].cpu().numpy())
     assert np.abs(fused_stack[2, 0].cpu().numpy() - ref).max() <= 1e-3
+
+
+@pytest.mark.parametrize("h,w,t,stacks,kw", [
+    (64, 64, 12, 40, {}),                                                    # the PV-site tiles, default parameters
+    (64, 64, 3, 300, {}),                                                    # 16-17 images per workgroup at level 0
+    (40, 56, 4, 7, dict(levels=3, iterations=2)),                            # margins; the 20 x 28 and 10 x 14 levels as mosaics
+    (24, 28, 3, 11, dict(levels=2, winsize=9)),                              # a source that is itself a mosaic tile (mode 0)
+    (64, 36, 2, 5, dict(levels=2, winsize=21, poly_n=7, poly_sigma=1.5)),    # 15-tap PolyExp
+])
+def test_polyexp_on_the_matrix_cores_against_the_vector_alu_form(device, monkeypatch, h, w, t, stacks, kw):
+    """fb_prep_polyexp_mfma_kernel (the two PolyExp passes as nine products with two-term half-float operands) against
+    fb_prep_polyexp_tile_kernel (tap loops, PV_FARNEBACK_POLYEXP_VALU=1): different summation order and operand precision
+    (2^-22), so not bit for bit -- the flows built on them agree to 1e-4 px, both sit within the 1e-3 px contract of the
+    oracle, and the same pairs as stacks and as separate tensors stay bit-identical."""
+    K = _ops()
+    raw, _ = advected_counts(batch=stacks, t=t, channels=1, h=h, w=w, seed=7 * h + w)
+    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(np.ascontiguousarray(raw[:, :, 0]), 0)[0]).to(device)
+    mfma = K.farneback_stack(u8, **kw)
+    pairs = K.farneback_pairs(u8[:, :-1].reshape(-1, h, w).contiguous(), u8[:, 1:].reshape(-1, h, w).contiguous(), **kw)
+    monkeypatch.setenv("PV_FARNEBACK_POLYEXP_VALU", "1")
+    valu = K.farneback_stack(u8, **kw)
+    assert bool(torch.isfinite(mfma).all()) and torch.equal(mfma.reshape(-1, h, w, 2), pairs)
+    assert not torch.equal(mfma, valu), "the two forms are different kernels: identical bits mean the switch is dead"
+    assert float((mfma - valu).abs().max()) <= 1e-4, float((mfma - valu).abs().max())
+    ref = fo.calc_optical_flow_farneback(u8[1, 0].cpu().numpy(), u8[1, 1].cpu().numpy(), **kw)
+    assert np.abs(mfma[1, 0].cpu().numpy() - ref).max() <= 1e-3 and np.abs(valu[1, 0].cpu().numpy() - ref).max() <= 1e-3
 
 
 def test_level_kernel_repeated_launches_give_identical_bits(device):

@@ -117,6 +117,20 @@ d = buf.reshape(WAVES, SLOTS).astype(np.float64)
 if kind == "flow":
     print(f"flow B={b}: stamped pipeline {e0.elapsed_time(e1) * 1e3:.1f} us")
     flow_report(d)
+    # fb_prep_polyexp_mfma_kernel (the last launch = level 0): 8 waves per workgroup
+    f2 = lib.pv_diag_read_fb_polyexp
+    f2.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    buf2 = np.zeros(WAVES * SLOTS, dtype=np.uint64)
+    assert f2(buf2.ctypes.data, buf2.size) == 0
+    p = buf2.reshape(WAVES, SLOTS).astype(np.float64)
+    p = p[p[:, 7] > 0]
+    if len(p):
+        labels = ["source words -> floats in LDS, next image requested", "barrier waits", "3-tap filters, resize, split, X write",
+                  "products (+ mailbox write)", "epilogue: coefficients, stores"]
+        tot = p[:, :5].sum(1).mean()
+        print(f"  PolyExp (matrix cores), level 0: {len(p)} waves, {p[:, 7].mean():.1f} images per wave, {tot / p[:, 7].mean():.0f} cycles / image")
+        for i, lab in enumerate(labels):
+            print(f"    {lab:64s} {(p[:, i] / p[:, 7]).mean():9.0f} cycles / image  {100 * p[:, i].mean() / tot:5.1f} %")
     raise SystemExit(0)
 count_col = len(labels) - 1
 live = d[:, count_col] > 0

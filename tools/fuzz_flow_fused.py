@@ -25,6 +25,8 @@ for case in range(n_cases):
     frames = np.ascontiguousarray((frames.astype(np.int16) + rng.integers(0, 6, frames.shape)).clip(0, 255).astype(np.uint8))
     u8 = torch.from_numpy(frames).to(dev)
     try:
+        mfma = K.farneback_stack(u8, **kw)      # the product path: PolyExp on the matrix cores where its conditions hold
+        os.environ["PV_FARNEBACK_POLYEXP_VALU"] = "1"      # the rest compares the ITERATION kernels on one PolyExp
         os.environ["PV_FARNEBACK_TWO_LAUNCH_ITERATION"] = "1"
         ref = K.farneback_stack(u8, **kw)
         del os.environ["PV_FARNEBACK_TWO_LAUNCH_ITERATION"]
@@ -37,14 +39,24 @@ for case in range(n_cases):
     finally:
         os.environ.pop("PV_FARNEBACK_TWO_LAUNCH_ITERATION", None)
         os.environ.pop("PV_FARNEBACK_SPLIT_WAVES", None)
+        os.environ.pop("PV_FARNEBACK_POLYEXP_VALU", None)
     # 5-pixel windows on this input (shifted noise, flows of 10-25 px) are ill-conditioned: either form is 1e-4 .. 6e-4 px from
     # the CPU oracle there (tools/probes/fuzz_vs_oracle.py) and they differ from each other by as much
     tol = (1e-3 if kw["winsize"] < 9 else 5e-6) * max(1.0, float(ref.abs().max()))
     close = torch.equal(got, ref) if w % 4 else float((got - ref).abs().max()) <= tol
-    ok = close and torch.equal(got_pairs.reshape(got.shape), got) and bool(torch.isfinite(got).all()) and torch.equal(got, split)
+    # the matrix-core PolyExp against the vector-ALU one, through the flows: 1e-4 of the largest flow (20 x that with 5-pixel windows)
+    # (all but 1e-4 of the elements: on this input -- shifted noise, flows of 10-20 px -- a difference of 1e-5 px in the first
+    # iteration moves a gather across the image's edge in the second for a pixel here and there: whole-pixel changes in 1-4 of
+    # several hundred pairs, whichever two implementations are compared; tools/probes/polyexp_mismatch.py)
+    dpe = (mfma - got).abs().flatten()
+    kth = max(1, int(dpe.numel() * (1 - 1e-4)))
+    close_pe = float(dpe.kthvalue(kth).values) <= (2e-3 if kw["winsize"] < 9 else 1e-4) * max(1.0, float(ref.abs().max()))
+    ok = (close and close_pe and torch.equal(got_pairs.reshape(got.shape), got) and bool(torch.isfinite(got).all())
+          and bool(torch.isfinite(mfma).all()) and torch.equal(got, split))
     if not ok:
         bad += 1
         print("MISMATCH", (h, w, t, stacks), kw, "differ from the two-launch form:", int((got != ref).sum()), float((got - ref).abs().max()),
               "| from the split-wave level kernel:", int((got != split).sum()), float((got - split).abs().max()),
-              "| split-wave vs two-launch:", float((split - ref).abs().max()), "| max |flow|", float(ref.abs().max()), flush=True)
+              "| split-wave vs two-launch:", float((split - ref).abs().max()), "| matrix-core vs vector-ALU PolyExp:",
+              float((mfma - got).abs().max()), "| max |flow|", float(ref.abs().max()), flush=True)
 print(f"{n_cases} cases, {bad} mismatches")
