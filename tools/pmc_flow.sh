@@ -7,7 +7,7 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_MF
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 $R/tools/time_flow_stages.py 32 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 $R/tools/time_flow_stages.py 32 > /dev/null 2>&1
 cd $R
-for k in fb_prep_polyexp_tile_kernel "fb_level_u_kernel<1, false>" "fb_level_u_kernel<2, true>" prepare_stacks remap_lds weighted_mean; do python3 tools/pmc_kernel_summary.py "$k" 1 $O/A $O/B $O/C > "$O/pmc_flow_$(echo $k | tr "<>, " "____").json"; done
+for k in "fb_prep_polyexp_mfma_kernel<false>" "fb_prep_polyexp_mfma_kernel<true>" "fb_level_u_kernel<1, false>" "fb_level_u_kernel<2, true>" prepare_stacks remap_lds weighted_mean; do python3 tools/pmc_kernel_summary.py "$k" 1 $O/A $O/B $O/C > "$O/pmc_flow_$(echo $k | tr "<>, " "____").json"; done
 python3 tools/pmc_flow_traffic.py 32 $O/fetch $O/write > $O/pmc_flow_traffic_B32.json
 find $O -name "*.csv" -size +5M -delete
 python3 - <<PY
