@@ -220,7 +220,7 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                                     long long n_img, int chain_f, int h, int w, int lh, int lw, int mode,
                                                                     double inv_fx, double inv_fy, FbTaps kt, FbPoly pk, int planar) {
   // planar != 0: pair-planar R (per image (c0, c1) float2 [lh][lw] | (c2, c3) float2 [lh][lw] | c4 float [lh][lw]: what
-  // fb_iter_kernel stages and gathers; lh * lw a multiple of 2), else R[img][lh][lw][5]
+  // fb_level_u_kernel stages and gathers; lh * lw a multiple of 2), else R[img][lh][lw][5]
   __shared__ float bufA[64 * 64];        // source as float, later the blurred image, later PolyExp plane t0
   __shared__ float bufB[64 * 64];        // row-filtered image, later the level image I
   __shared__ float Tt12[2 * 64 * 64];    // vertical PolyExp planes t1, t2
@@ -464,7 +464,7 @@ __device__ __forceinline__ fb_f32x2_t fb_upsampled_flow(const float* __restrict_
   return o;
 }
 
-// the same without control flow (fb_iter_kernel evaluates it between other work: a branch would split the live ranges around
+// the same without control flow (the level kernel evaluates it between other work: a branch would split the live ranges around
 // it): the right-hand taps are read at a clamped column and enter with weight 0 where the resize has none -- t00 * 1 + t01 * 0
 // is t00 itself, so the values are those of fb_upsampled_flow
 __device__ __forceinline__ fb_f32x2_t fb_upsampled_flow_nb(const float* __restrict__ src, size_t p, int sh, int sw, int x, int y,
@@ -552,7 +552,7 @@ typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt, int mosaic) {
   // G[64][64]; rows / columns >= n stay zero.  mosaic (n <= 32): the n x n matrix twice on the diagonal, at 0 and at 32 --
-  // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_level_kernel<.., MOSAIC = true>)
+  // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_level_u_kernel<.., MOSAIC = true>)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 64; i += gridDim.x * blockDim.x) {
     int y = i >> 6, yp = i & 63;
     const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
@@ -930,42 +930,29 @@ __global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __r
 
 typedef int fb_i32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned char* fb_lds_ptr;
-// ---- one whole Farneback iteration per launch, second form (round 4): lane = column, f16 x 2 operands, 4 + 8 waves ------
-// What the counters and stamps of fb_fused_iter_q_kernel said (profiles/r03): its four producing waves are the critical
-// path, their R1 gathers hit the LDS four ways (20-byte records, a wave's four rows on the same banks), the multiplying
-// waves wait 40 %, and on the vector ALU the three-way bf16 split (5.5 instructions per element) and the f64 solve weigh as
-// much as UpdateMatrices itself.  This kernel keeps the producer / multiplier split and changes everything underneath:
-//   * R is PAIR-PLANAR in memory (per image: (c0, c1) as float2 [h][w], (c2, c3) as float2 [h][w], c4 as float [h][w];
-//     written so by fb_prep_polyexp_tile_kernel) and in LDS (the same three planes with a fixed row stride of 64 pixels
-//     whatever the level's size; MOSAIC: the four 32 x 32 tiles side by side in the same planes).  A producer lane owns one
-//     COLUMN and walks 8 rows, so the 64 lanes of a gather read consecutive pixels of a row (displaced by the flow): no bank
-//     conflicts for a smooth flow field, every neighbour is a constant offset from one address, and a channel pair arrives
-//     as the register pair the packed f32 instructions take (12 LDS reads per pixel instead of 20, no register shuffling).
-//   * EIGHT producing waves (two per SIMD, 8 pixels per lane) beside the four multiplying ones: one hides the other's LDS
-//     round trips; same expressions and rounding order as fb_update_pixel, so M is bit-identical to the two-launch form.
-//   * a unit's gathers are ONE short phase (G: 8 pixels x (12 reads + the bilinear blend), right after hand-over 0), and the
-//     rest of UpdateMatrices (F) follows from registers, two pixels after each later hand-over.  The R1 image is therefore
-//     free again after a fifth of the unit, and the NEXT unit's R1 is requested right then (after barrier B1) -- it has four
-//     hand-overs to arrive.  (First form: request after the last gather, i.e. at the unit's end, wait at its start -- the
-//     stamps showed 6 800 cycles per unit in the request instructions alone, every CU bursting 80 KB at once, and the
-//     producers idle meanwhile.)
-//   * the window blur runs on the F16 matrix cores with TWO-term operands: x = h + l, h = rne_f16(x), l = rne_f16(x - h)
+// ---- building blocks of the level kernel (fb_level_u_kernel) and of the matrix-core PolyExp (round 4) ------------------------
+// What the counters and stamps of round 3's fused iteration said (profiles/r03): its R1 gathers hit the LDS four ways (20-byte
+// records, a wave's four rows on the same banks), and on the vector ALU the three-way bf16 split (5.5 instructions per
+// element) and the f64 solve weighed as much as UpdateMatrices itself.  Hence:
+//   * R is PAIR-PLANAR in memory (per image: (c0, c1) as float2 [h][w], (c2, c3) as float2 [h][w], c4 as float [h][w]; written
+//     so by the PolyExp kernels) and in LDS (the same three planes with a fixed row stride of 64 pixels whatever the level's
+//     size; MOSAIC: the four 32 x 32 tiles side by side in the same planes).  A lane owns one COLUMN and walks 8 rows, so the
+//     64 lanes of a gather read consecutive pixels of a row (displaced by the flow): no bank conflicts for a smooth flow
+//     field, every neighbour is a constant offset from one address, and a channel pair arrives as the register pair the
+//     packed f32 instructions take (12 LDS reads per pixel instead of 20, no register shuffling).
+//   * matrix products run on the F16 matrix cores with TWO-term operands: x = h + l, h = rne_f16(x), l = rne_f16(x - h)
 //     carries 22 significant bits, so three products (hh, hl, lh) reach 2^-22 where the bf16 split needs six -- half the
 //     matrix work and 2.5 instead of 5.5 vector instructions per element split.  f16 has a narrow range, so every operand
 //     is scaled by an exact power of two first: the window matrices by 2^15 (taps 4e-3 .. 0.5 -> 130 .. 16384), M by a
-//     per-pair factor s = 2^(15 - e) from the pair's largest |M| (reduced by the producers, one extra barrier per pair) so
-//     that |M s| < 2^15; residuals land in f16's subnormals at worst, which v_mfma_f32_32x32x16_f16 honours
-//     (tools/probes/mfma_f16_denorm.hip).  The blurred sums carry the factor k = 2^15 s into the solve, which is
-//     homogeneous but for the regulariser: flow = num k^2 / (det k^2 + 1e-3 k^2).
-//   * the image is handed over TRANSPOSED (X^T[x][y'], a producer lane's 8 rows are 16 contiguous bytes per plane: two
-//     ds_write_b128 per channel instead of twelve ds_write_b64), so the products are V^T = X^T Gv^T, Out^T = Gh V^T -- the
-//     first product's accumulators are again the second one's B operand -- and a multiplying lane ends with one ROW y and 16
-//     columns: four 32-byte runs of flow per lane.
+//     per-pair factor s = 2^(15 - e) from the pair's largest |M| (one extra barrier per stage) so that |M s| < 2^15;
+//     residuals land in f16's subnormals at worst, which v_mfma_f32_32x32x16_f16 honours (tools/probes/mfma_f16_denorm.hip).
+//     The blurred sums carry the factor k = 2^15 s into the solve, which is homogeneous but for the regulariser:
+//     flow = num k^2 / (det k^2 + 1e-3 k^2).
+//   * an image is handed over TRANSPOSED (X^T[x][y'], a lane's 8 rows are 16 contiguous bytes per plane: two ds_write_b128
+//     per channel), so the products are V^T = X^T Gv^T, Out^T = Gh V^T -- the first product's accumulators are the second
+//     one's operand without an exchange through LDS.
 //   * the 2 x 2 solve in f32 with error-free products (Kahan's ad - bc with fma) and one refined reciprocal per pixel, where
 //     the f64 form cost 3 200 cycles per pair at half rate.
-// Hand-over protocol per unit p (a pair, or four pairs in MOSAIC): barriers B0..B4 publish channels 0..4 (double-buffered
-// image), B5 publishes unit p + 1's largest |M|.  Under unit p's hand-overs the producers prepare unit p + 1: G after B0,
-// F after B1..B4; unit p + 2's R1 is requested after B1, its starting flow after B4; both are awaited at unit p + 1's start.
 typedef _Float16 fb_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fb_f16x2 __attribute__((ext_vector_type(2)));
 typedef float fb_f2 __attribute__((ext_vector_type(2)));
@@ -995,10 +982,6 @@ __device__ __forceinline__ fb_v16f fb_mfma2(const FbSplit2& a, const FbSplit2& b
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.l, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h, b.h, acc, 0, 0, 0);
   return acc;
-}
-__device__ __forceinline__ void fb_lds_dma16_s(uint32_t lds_addr, uint32_t voff, uint32_t soff, fb_i32x4 rsrc) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
 }
 // ad - bc with one rounding error of the result (Kahan): w = bc rounded, e = w - bc exactly, f = ad - w rounded once
 __device__ __forceinline__ float fb_det2(float a, float d, float b, float c) {
@@ -1040,625 +1023,25 @@ __device__ __forceinline__ void fb_update_pixel_finish2(const fb_f2 R01, const f
 #ifdef PV_DIAG_STAMPS
 __device__ unsigned long long fb_iter_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
 #endif
-// One launch per pyramid LEVEL: a workgroup keeps a unit's R1 in LDS and its R0 in registers through all `iterations`
-// (the launch-per-iteration form read R0, R1 and the flow again for every iteration: 0.95 GB per level-0 launch by the
-// counters, three launches per level, and ran at the memory system's pace).  The flow between two iterations of a unit goes
-// through memory (written by the multiplying waves, read back by the producers of the same workgroup after a barrier: L2).
-// Iteration it + 1 of a unit needs iteration it's flow, so inside a unit the two kinds of waves take turns (hand-over ->
-// blur -> solve -> UpdateMatrices -> hand-over ...); the overlap is at the unit boundary: while the LAST iteration of unit u is
-// handed over and blurred, the producers evaluate the FIRST iteration of unit u + 1 (its R1 was requested right after unit
-// u's last gathers).  FLOW_INIT: 1 = the level starts from the coarser level's flow, resized on the fly; 2 = from zero.
-// SINGLE_IT: iterations == 1 (every stage is a unit's last: R1 two units ahead, as the per-iteration kernel did).
-template <int FLOW_INIT, bool MOSAIC, bool SINGLE_IT>
-__global__ __launch_bounds__(768) void fb_level_kernel(const float* __restrict__ R, const float* __restrict__ flow_prev, float* flow,
-                                                       const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
-                                                       int width, long long n_pairs, long long pairs_per_group, int chain_f,
-                                                       FbUpsample up, int iterations) {
-  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
-  // R1 of the unit whose gathers come next: (c0, c1) float2 [64][64] | (c2, c3) float2 [64][64] | c4 float [64][64]
-  __shared__ __attribute__((aligned(16))) float R1s[5 * T * T];
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][2][PLANE];       // X^T, (h, l) f16 planes, double buffered
-  __shared__ u32x4 GhS[2 * KS * 2][64];                                    // A operand of the second product, lane-major
-  __shared__ __attribute__((aligned(16))) float pmax[16];                 // largest |M| per (producing wave, lane half)
-  const int tid = threadIdx.x, lane = tid & 63, wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave12 >= 4;
-  const int col = lane & 31, half = lane >> 5;
-  const int lpx = height * width;
-  constexpr int NP = MOSAIC ? 4 : 1;
-  constexpr uint32_t NOT_THERE = 0x80000000u;      // buffer offset outside every descriptor below: reads zeros
-  const long long n_units = (n_pairs + NP - 1) / NP;
-  const long long p_lo = n_units * blockIdx.x / gridDim.x, p_hi = n_units * (blockIdx.x + 1) / gridDim.x;
-  const int n_it = SINGLE_IT ? 1 : iterations;
-
-  // Gh as the A operand of the second product: k-slot i of lane-half h in step (blk, s) = accumulator row
-  // fb_acc_row(8 s + i, h) of row block blk of the first product
-  for (int j = wave12; j < 2 * KS; j += 12) {
-    const int mb = j / KS, ks = j - mb * KS;
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
-    const FbSplit2 g = fb_split2(t, FB_G_SCALE);
-    GhS[j * 2 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
-    GhS[j * 2 + 1][lane] = __builtin_bit_cast(u32x4, g.l);
-  }
-  // exponent e of a unit's (MOSAIC: of tile (ty, tx)'s) largest |M| = f 2^e, 0.5 <= f < 1, clamped so that every power of
-  // two formed from it is a normal f32; M 2^(15 - e) then lies below 2^15
-  auto unit_exp = [&](int ty, int tx) -> int {
-    const f32x4* pm4 = reinterpret_cast<const f32x4*>(pmax);
-    float mx;
-    if constexpr (MOSAIC) {
-      const f32x4 a = pm4[2 * ty], b = pm4[2 * ty + 1];
-      mx = tx ? fmaxf(fmaxf(a[1], a[3]), fmaxf(b[1], b[3])) : fmaxf(fmaxf(a[0], a[2]), fmaxf(b[0], b[2]));
-    } else {
-      const f32x4 a = pm4[0], b = pm4[1], c = pm4[2], d = pm4[3];
-      const f32x4 m4 = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
-      mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    }
-    const int e = __builtin_amdgcn_frexp_expf(mx);
-    return e < -25 ? -25 : (e > 100 ? 100 : e);
-  };
-
-  // ---- both kinds of waves: the unit -> coefficient image bookkeeping and the LDS-direct staging of R1 --------------------
-  // a pair's first coefficient image (the second is the one after it in both layouts, fb_r_images_of), stepped along the
-  // range without a 64-bit division per pair
-  long long i0_run, i1_unused;
-  fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
-  long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
-  const long long img_step = chain_f > 0 ? 1 : 2, img_jump = chain_f > 0 ? chain_f - pairs_per_group : 0;
-  auto next_image = [&]() -> long long {      // (arithmetic, no branches: see request_r1)
-    const long long r = i0_run;
-    q_run += 1;
-    const long long wrap = (long long)((int)(chain_f > 0) & (int)(q_run == pairs_per_group));      // the next stack's first frame
-    i0_run += img_step + wrap * img_jump;
-    q_run -= wrap * q_run;
-    return r;
-  };
-  auto take_unit = [&](FbImgs& i0) {
-    i0.a = next_image();
-    if constexpr (MOSAIC) i0.b = next_image(), i0.c = next_image(), i0.d = next_image();
-  };
-  // LDS-direct staging, 80 chunks of 1 KB (one wave instruction each): chunks 0..31 = plane (c0, c1), two rows of 64
-  // float2 each; 32..63 = plane (c2, c3); 64..79 = plane c4, four rows of 64 floats each.  Lane j brings 16 bytes: in the
-  // pair planes row (j >> 5) of the chunk, pixels 2 (j & 31), + 1; in the c4 plane row (j >> 4), pixels 4 (j & 15) .. + 3
-  const uint32_t r1_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(fb_lds_ptr)R1s);
-  const int dp_x = MOSAIC ? 2 * ((lane & 31) & 15) : 2 * (lane & 31), dp_tx = (lane & 31) >> 4;
-  const int ds_x = MOSAIC ? 4 * ((lane & 15) & 7) : 4 * (lane & 15), ds_tx = (lane & 15) >> 3;
-  const uint32_t dma_lane_p = (uint32_t)((lane >> 5) * width + dp_x) * 8, dma_lane_s = (uint32_t)((lane >> 4) * width + ds_x) * 4;
-  // R1 of `unit` (second coefficient images = i0 + 1) -> LDS: chunks K0 .. K0 + KN - 1, wave wi of NW issuing waves takes
-  // K0 + wi, K0 + wi + NW, ...  (K0 and NW multiples of 4: a wave instruction's plane is known at compile time.)
-  // No branches (a branch in the middle of a unit's straight-line code splits every live range around it: 140 more
-  // spills): a unit beyond the range, a missing pair, rows or columns beyond the image all become the offset that reads zeros
-  auto request_r1 = [&](const FbImgs& i0, long long unit, int wi, auto nw_tag, auto k0_tag, auto kn_tag) {
-    constexpr int NW = decltype(nw_tag)::value, K0 = decltype(k0_tag)::value, KN = decltype(kn_tag)::value;
-    const bool unit_ok = unit < p_hi;
-#pragma unroll
-    for (int n = 0; n < KN / NW; ++n) {
-      const int k = K0 + wi + NW * n;
-      const bool pair_plane = K0 + n * NW < 64;                   // compile-time per n
-      const int kk = pair_plane ? (k & 31) : (k - 64);            // chunk inside its plane
-      const int rows = pair_plane ? 2 : 4;                        // LDS rows per chunk
-      const int plane_off = pair_plane ? (K0 + n * NW < 32 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
-      const int px_bytes = pair_plane ? 8 : 4;
-      const int d_x = pair_plane ? dp_x : ds_x;
-      const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
-      if constexpr (MOSAIC) {
-        const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
-        const int d_tx = pair_plane ? dp_tx : ds_tx;
-        const long long pl = unit * 4 + 2 * ty + d_tx;
-        const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
-        const long long img = d_tx ? img_r : img_l;
-        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
-        uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
-        asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
-        const uint32_t voff = ok ? there : NOT_THERE;
-        const uintptr_t a = (uintptr_t)R;
-        fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
-                       (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), 0x7fffffff, 0x00020000});
-      } else {
-        const int yb = rows * kk;
-        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
-        const uint32_t voff = ok ? lane_off : NOT_THERE;
-        const uintptr_t a = (uintptr_t)(R + (i0.a + 1) * lpx * 5);
-        fb_lds_dma16_s(r1_lds + (uint32_t)k * 1024, voff, (uint32_t)(plane_off + yb * width * px_bytes),
-                       (fb_i32x4){(int)(uint32_t)a, (int)((a >> 32) & 0xffffu), lpx * 20, 0x00020000});
-      }
-    }
-  };
-
-  // The same chunks through registers, for waves that have registers to spare and time to wait: plain 16-byte loads do not
-  // hold the issuing wave the way an LDS-direct instruction does (300 to 700 cycles apiece here, measured on either kind of
-  // wave), and the fetch may start before the image in LDS is free -- only the commit has to wait for the last gathers.
-  // Wave wi of 8 takes chunks wi, wi + 8, ... (10 of the 80).
-  auto r1_fetch = [&](const FbImgs& i0, long long unit, int wi, u32x4 (&buf)[10]) {
-    const bool unit_ok = unit < p_hi;
-#pragma unroll
-    for (int n = 0; n < 10; ++n) {
-      const int k = wi + 8 * n;
-      const bool pair_plane = n < 8;                              // compile-time per n
-      const int kk = pair_plane ? (k & 31) : (k - 64);            // chunk inside its plane
-      const int rows = pair_plane ? 2 : 4;                        // LDS rows per chunk
-      const int plane_off = pair_plane ? (n < 4 ? 0 : lpx * 8) : lpx * 16;      // bytes from the image's start
-      const int px_bytes = pair_plane ? 8 : 4;
-      const int d_x = pair_plane ? dp_x : ds_x;
-      const uint32_t lane_off = pair_plane ? dma_lane_p : dma_lane_s;
-      if constexpr (MOSAIC) {
-        const int r0w = rows * kk, ty = r0w >> 5, yb = r0w & 31;
-        const int d_tx = pair_plane ? dp_tx : ds_tx;
-        const long long pl = unit * 4 + 2 * ty + d_tx;
-        const long long img_l = i0.a + ty * (i0.c - i0.a) + 1, img_r = i0.b + ty * (i0.d - i0.b) + 1;
-        const long long img = d_tx ? img_r : img_l;
-        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(pl < n_pairs) & (int)(d_x < width);
-        uint32_t there = (uint32_t)(img * lpx * 20) + lane_off;
-        asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
-        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? there : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
-      } else {
-        const int yb = rows * kk;
-        const bool ok = (int)unit_ok & (int)(yb < height) & (int)(d_x < width);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + (i0.a + 1) * lpx * 5), 0, lpx * 20, 0x00020000);
-        buf[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? lane_off : NOT_THERE, (uint32_t)(plane_off + yb * width * px_bytes), 0));
-      }
-    }
-  };
-  auto r1_commit = [&](int wi, const u32x4 (&buf)[10]) {
-    u32x4* dst = reinterpret_cast<u32x4*>(R1s) + lane;
-#pragma unroll
-    for (int n = 0; n < 10; ++n) dst[(wi + 8 * n) * 64] = buf[n];
-  };
-
-  if (producer) {
-    // ================================ producing waves ===================================================================
-    const int pw = wave12 - 4;                                  // 0..7: rows 8 pw .. 8 pw + 7 of the 64 x 64 image
-    const int m_ty = pw >> 2, m_tx = lane >> 5;                 // MOSAIC: this wave's tile row, this lane's tile column
-    const int xl = MOSAIC ? (lane & 31) : lane;                 // column inside the pair's image
-    const int yl0 = MOSAIC ? 8 * (pw & 3) : 8 * pw;             // first row inside the pair's image
-    const int lds_org = MOSAIC ? (32 * m_ty) * 64 + 32 * m_tx : 0;      // the tile's origin in an LDS plane (pixels)
-    const bool col_ok = xl < width;
-    // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by distance from the edge; the column's two factors once per lane
-    auto border = [](int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); };
-    const float scale_x = __fmul_rn(border(xl), border(width - xl - 1));
-    float mA[5][8], mB[5][8];      // [channel][pixel]: a channel's 8 values are what a hand-over writes
-    FbBlend bl[8];
-    fb_f2 fl[8];                   // the flow the next UpdateMatrices starts from
-    fb_f2 r01[8], r23[8];          // R0 of the pixels evaluated next (two pixels ahead of their use)
-    float r4[8];
-    float pm;                      // running largest |M| of the unit being evaluated
-    // this lane's pair of a unit and whether it exists (MOSAIC: the tail unit may hold fewer than four pairs; a unit beyond
-    // the workgroup's range -- asked for by the look-ahead of the last units -- does not exist either)
-    auto lane_pair = [&](long long unit, bool& ok) -> long long {
-      const long long pl = MOSAIC ? unit * 4 + 2 * m_ty + m_tx : unit;
-      ok = (int)(unit < p_hi) & (int)(pl < n_pairs);
-      return ok ? pl : 0;
-    };
-    // the flow a unit's first iteration starts from -> fl
-    auto load_flow_init = [&](long long unit) {
-      bool pair_ok;
-      const long long pl = lane_pair(unit, pair_ok);
-      if constexpr (FLOW_INIT == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          // (the lane's resize coordinates are the same for every unit: hidden from the loop-invariant code motion, which
-          // would keep them for all 8 rows in registers around the unit loop)
-          int xo = xl, yo = yl0 + i;
-          asm volatile("" : "+v"(xo), "+s"(yo));
-          const fb_f32x2_t f = fb_upsampled_flow_nb(flow_prev, (size_t)pl, up.sh, up.sw, min(xo, width - 1), min(yo, height - 1),
-                                                    up.inv_fx, up.inv_fy, up.mul);
-          fl[i] = (fb_f2){f[0], f[1]};
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float z = 0.f;      // (opaque: with a known zero flow every gather address and weight becomes a per-lane invariant)
-          asm volatile("" : "+v"(z));
-          fl[i] = (fb_f2){z, z};
-        }
-      }
-    };
-    // the flow the unit's multiplying waves stored in the previous iteration -> fl (sc0 loads: never a line this compute
-    // unit's vector cache kept from the iteration before)
-    auto load_flow_back = [&](long long unit) {
-      bool pair_ok;
-      const long long pl = lane_pair(unit, pair_ok);
-      const __amdgpu_buffer_rsrc_t rs =
-          MOSAIC ? __builtin_amdgcn_make_buffer_rsrc(flow, 0, 0x7fffffff, 0x00020000)
-                 : __builtin_amdgcn_make_buffer_rsrc(flow + pl * lpx * 2, 0, lpx * 8, 0x00020000);
-      uint32_t there = (MOSAIC ? (uint32_t)(pl * lpx * 8) : 0u) + (uint32_t)xl * 8;
-      asm volatile("" : "+v"(there));      // (computed on every path: the select below must stay a select)
-      const uint32_t voff = (int)pair_ok & (int)col_ok ? there : NOT_THERE;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int y = yl0 + i;
-        fl[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, y < height ? voff : NOT_THERE, (uint32_t)(y * width) * 8, 1));
-      }
-    };
-    // G: the four R1 neighbours of pixel i (R1 is in LDS, the flow in fl): reads, then the bilinear blend -> bl[i]
-    auto gather = [&](int i, bool lane_ok, FbTapsP& t) {
-      const int y = yl0 + i;
-      const float fx0 = __fadd_rn((float)xl, fl[i][0]), fy0 = __fadd_rn((float)y, fl[i][1]);
-      const int x1 = (int)floorf(fx0), y1 = (int)floorf(fy0);
-      t.fx = __fsub_rn(fx0, (float)x1), t.fy = __fsub_rn(fy0, (float)y1);
-      t.inside = (int)lane_ok & (int)(y < height) & (int)((unsigned)x1 < (unsigned)(width - 1)) & (int)((unsigned)y1 < (unsigned)(height - 1));
-      int idx = lds_org + y1 * 64 + x1;
-      asm volatile("" : "+v"(idx));
-      idx = t.inside ? idx : 0;
-      const fb_f2* p0 = reinterpret_cast<const fb_f2*>(R1s) + idx;
-      const fb_f2* p1 = reinterpret_cast<const fb_f2*>(R1s + 2 * T * T) + idx;
-      const float* p2 = R1s + 4 * T * T + idx;
-      t.u00 = p0[0], t.u01 = p0[1], t.u10 = p0[64], t.u11 = p0[65];
-      t.v00 = p1[0], t.v01 = p1[1], t.v10 = p1[64], t.v11 = p1[65];
-      t.w00 = p2[0], t.w01 = p2[1], t.w10 = p2[64], t.w11 = p2[65];
-    };
-    auto blend = [&](int i, const FbTapsP& t) {
-      const float fx = t.fx, fy = t.fy;
-      const float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
-      const float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
-      bl[i].b01 = ((t.u00 * a00 + t.u01 * a01) + t.u10 * a10) + t.u11 * a11;
-      bl[i].b23 = ((t.v00 * a00 + t.v01 * a01) + t.v10 * a10) + t.v11 * a11;
-      const float b4 = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t.w00), __fmul_rn(a01, t.w01)), __fmul_rn(a10, t.w10)), __fmul_rn(a11, t.w11));
-      bl[i].b4 = t.inside ? b4 : __builtin_nanf("");
-    };
-    auto gather_blend_all = [&](bool lane_ok) {      // the next pixel's reads are issued before this pixel's blend, not more (registers)
-      FbTapsP ta, tb;
-      gather(0, lane_ok, ta);
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        gather(i + 1, lane_ok, tb);
-        blend(i, ta);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < 8) gather(i + 2, lane_ok, ta);
-        blend(i + 1, tb);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // R0 of pixels ia, ia + 1 of `unit` (first coefficient images i0) -> r01 / r23 / r4
-    auto load_r0 = [&](int ia, long long unit, const FbImgs& i0) {
-      bool pair_ok;
-      (void)lane_pair(unit, pair_ok);
-      __amdgpu_buffer_rsrc_t rs;
-      uint32_t base;
-      if constexpr (MOSAIC) {
-        const long long img_l = i0.a + m_ty * (i0.c - i0.a), img_r = i0.b + m_ty * (i0.d - i0.b);      // (no select of addresses)
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R), 0, 0x7fffffff, 0x00020000);
-        base = (uint32_t)((m_tx ? img_r : img_l) * lpx * 20);
-      } else {
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(R + i0.a * lpx * 5), 0, lpx * 20, 0x00020000);
-        base = 0;
-      }
-      const bool ok = (int)pair_ok & (int)col_ok;
-      uint32_t t8 = base + (uint32_t)xl * 8, t4 = base + (uint32_t)xl * 4;
-      asm volatile("" : "+v"(t8), "+v"(t4));      // (computed on every path: the selects below must stay selects)
-      const uint32_t v8 = ok ? t8 : NOT_THERE, v4 = ok ? t4 : NOT_THERE;
-#pragma unroll
-      for (int i = ia; i < ia + 2; ++i) {
-        const int y = yl0 + i;
-        const bool row_ok = y < height;
-        r01[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(y * width) * 8, 0));
-        r23[i] = __builtin_bit_cast(fb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, row_ok ? v8 : NOT_THERE, (uint32_t)(lpx + y * width) * 8, 0));
-        r4[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row_ok ? v4 : NOT_THERE, (uint32_t)(4 * lpx + y * width) * 4, 0));
-      }
-    };
-    // F: the rest of UpdateMatrices for pixels ia, ia + 1 -> mo; pm collects the unit's largest |M|
-    auto finish2 = [&](int ia, float (&mo)[5][8]) {
-#pragma unroll
-      for (int i = ia; i < ia + 2; ++i) {
-        const int y = yl0 + i;
-        const float scale = __fmul_rn(__fmul_rn(scale_x, border(y)), border(height - y - 1));
-        float m[5];
-        fb_update_pixel_finish2(r01[i], r23[i], r4[i], bl[i], fl[i][0], fl[i][1], scale, m);
-#pragma unroll
-        for (int c = 0; c < 5; ++c) mo[c][i] = m[c];
-        pm = fmaxf(pm, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fmaxf(fabsf(m[2]), fabsf(m[3])), fabsf(m[4]))));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    // the unit's largest |M| per lane half -> pmax (MOSAIC: a half is a tile column)
-    auto publish_max = [&]() {
-      float v = pm;
-#pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-      pmax[2 * pw + half] = v;      // every lane of the half holds the maximum: 32 identical stores, no branch
-    };
-    auto write_channel = [&](const float (&m)[5][8], int c, float s, int buf) {
-      const FbSplit2 sp = fb_split2(m[c], s);
-      uint16_t* Xc = &Xs[buf][0][0] + lane * XS + 8 * pw;      // row x of X^T, rows y' = 8 pw .. + 7: 16 contiguous bytes
-      *reinterpret_cast<u32x4*>(Xc) = __builtin_bit_cast(u32x4, sp.h);
-      *reinterpret_cast<u32x4*>(Xc + PLANE) = __builtin_bit_cast(u32x4, sp.l);
-    };
-#ifdef PV_DIAG_STAMPS
-    unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2, s3;
-#endif
-    // i0c: first images of the unit in hand; i0n: of the unit after it; i0nn: two ahead (SINGLE_IT stages R1 that far ahead)
-    FbImgs i0c, i0n, i0nn;
-    take_unit(i0c);
-    take_unit(i0n);
-    take_unit(i0nn);
-    {
-      bool ok;
-      (void)lane_pair(p_lo, ok);
-      request_r1(i0c, p_lo, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});
-      load_flow_init(p_lo);
-      load_r0(0, p_lo, i0c);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();      // P1: R1 of the first unit (and GhS) in place
-      gather_blend_all(ok && col_ok);
-      __syncthreads();      // Pg: every wave is through with the first unit's R1
-      if constexpr (SINGLE_IT) request_r1(i0n, p_lo + 1, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});
-      pm = 0.f;
-      load_r0(2, p_lo, i0c), finish2(0, mA);
-      load_r0(4, p_lo, i0c), finish2(2, mA);
-      load_r0(6, p_lo, i0c), finish2(4, mA);
-      finish2(6, mA);
-      publish_max();
-      __syncthreads();      // P2 = X0 of the first stage
-    }
-    int k = 0;
-    // hand-over of a complete M (mc): barriers B0..B4 publish channels 0..4
-    auto hand_over = [&](float (&mc)[5][8]) {
-      PV_STAMP(s0);
-      const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        write_channel(mc, c, s, k & 1);
-        ++k;
-        PV_STAMP(s1);
-        __syncthreads();      // B<c>
-        PV_STAMP(s2);
-#ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1;
-        s0 = s2;
-#endif
-      }
-    };
-    // the same with the FIRST iteration of unit u + 1 evaluated into mn between the barriers (its R1 has been requested, its
-    // starting flow does not depend on anything this workgroup computes)
-    auto hand_over_and_next = [&](float (&mc)[5][8], float (&mn)[5][8], long long u) {
-      PV_STAMP(s0);
-      const float s = ldexpf(1.f, 15 - unit_exp(m_ty, m_tx));
-      bool ok;
-      (void)lane_pair(u + 1, ok);
-      ok = ok && col_ok;
-      pm = 0.f;
-      PV_STAMP(s1);
-#ifdef PV_DIAG_STAMPS
-      dg[3] += s1 - s0;
-#endif
-      // SINGLE_IT: unit u + 1's R1 was requested a whole unit ago -- gathers right after B0, as in the per-iteration form.
-      // Otherwise it was requested one UpdateMatrices ago (after unit u's last gathers): the gathers wait until B2, the
-      // request has the first two channels' products to arrive, and F follows four pixels per hand-over
-      constexpr int G_AT = SINGLE_IT ? 0 : 2;
-      u32x4 r1buf[10];
-      if constexpr (!SINGLE_IT) r1_fetch(i0n, u + 1, pw, r1buf);      // unit u's gathers are all done: into LDS after B1
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        PV_STAMP(s0);
-        write_channel(mc, c, s, k & 1);
-        ++k;
-        if (SINGLE_IT && c == G_AT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of unit u + 1's R1 has landed
-        PV_STAMP(s1);
-        __syncthreads();      // B<c>
-        PV_STAMP(s2);
-        if constexpr (SINGLE_IT) {
-          if (c == 0) {
-            load_flow_init(u + 1);
-            gather_blend_all(ok);
-            load_r0(0, u + 1, i0n);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (c == 1) {
-            request_r1(i0nn, u + 2, pw, std::integral_constant<int, 8>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 80>{});      // every wave passed B1: unit u + 1's gathers are done
-            load_r0(2, u + 1, i0n), finish2(0, mn);
-          }
-          if (c == 2) load_r0(4, u + 1, i0n), finish2(2, mn);
-          if (c == 3) load_r0(6, u + 1, i0n), finish2(4, mn);
-          if (c == 4) finish2(6, mn), publish_max();
-        } else {
-          if (c == 0) load_flow_init(u + 1), load_r0(0, u + 1, i0n), load_r0(2, u + 1, i0n);
-          if (c == 1) r1_commit(pw, r1buf);      // (the compiler's own wait for the fetch; visible to all behind B2)
-          if (c == 2) {
-            gather_blend_all(ok);
-            load_r0(4, u + 1, i0n), load_r0(6, u + 1, i0n);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (c == 3) finish2(0, mn), finish2(2, mn);
-          if (c == 4) finish2(4, mn), finish2(6, mn), publish_max();
-        }
-        PV_STAMP(s3);
-#ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1, dg[c == G_AT ? 4 : 2] += s3 - s2;
-#endif
-      }
-    };
-    // iteration it + 1 of unit u (R1 in LDS, R0 in registers) from the flow iteration it left in memory -> mc
-    auto update_from_memory = [&](float (&mc)[5][8], long long u) {
-      // R0 again from memory (L2 by now: the unit read it an iteration ago) rather than 40 registers held through the
-      // hand-over; requested before the wait for the multiplying waves, so that F finds it in registers
-      load_r0(0, u, i0c), load_r0(2, u, i0c), load_r0(4, u, i0c), load_r0(6, u, i0c);
-      PV_STAMP(s0);
-      __syncthreads();      // X1: the multiplying waves have stored this iteration's flow
-      PV_STAMP(s1);
-      bool ok;
-      (void)lane_pair(u, ok);
-      load_flow_back(u);
-      gather_blend_all(ok && col_ok);
-      PV_STAMP(s2);
-      __syncthreads();      // Xg: every wave is through with this iteration's gathers (after the unit's last ones the
-      PV_STAMP(s3);         // multiplying waves, idle until the next hand-over, request the next unit's R1)
-      pm = 0.f;
-      finish2(0, mc), finish2(2, mc), finish2(4, mc), finish2(6, mc);
-      publish_max();
-#ifdef PV_DIAG_STAMPS
-      dg[1] += s1 - s0 + s3 - s2, dg[4] += s2 - s1;
-      PV_STAMP(s0);
-      dg[2] += s0 - s3;
-#endif
-    };
-    for (long long u = p_lo; u < p_hi; ++u) {
-      const bool more = u + 1 < p_hi;
-      for (int it = 0; it + 1 < n_it; ++it) {      // every iteration but the unit's last
-        hand_over(mA);
-        update_from_memory(mA, u);
-        PV_STAMP(s0);
-        __syncthreads();      // X0: the next iteration's largest |M| is published
-        PV_STAMP(s1);
-#ifdef PV_DIAG_STAMPS
-        dg[1] += s1 - s0;
-#endif
-      }
-      if (more) {
-        hand_over_and_next(mA, mB, u);
-#pragma unroll
-        for (int c = 0; c < 5; ++c)
-#pragma unroll
-          for (int n = 0; n < 8; ++n) mA[c][n] = mB[c][n];
-        i0c = i0n, i0n = i0nn;
-        take_unit(i0nn);
-      } else {
-        hand_over(mA);
-      }
-      PV_STAMP(s0);
-      __syncthreads();      // B5 = X0 of the next unit's first stage
-      PV_STAMP(s1);
-#ifdef PV_DIAG_STAMPS
-      dg[1] += s1 - s0, dg[7] += 1;
-#endif
-    }
-#ifdef PV_DIAG_STAMPS
-    if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
-      for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 12 + wave12) * PV_DIAG_SLOTS + i] = dg[i];
-#endif
-    return;
-  }
-
-  // ================================ multiplying waves =====================================================================
-  // wave (strip, mbo): output rows y of block `strip` (one per lane), columns x of block `mbo`; MOSAIC: that is tile
-  // (ty, tx) = (strip, mbo) = pair 4 u + 2 strip + mbo
-  const int strip = wave12 & 1, mbo = wave12 >> 1;
-  FbSplit2 gv[KS];      // Gv^T as the B operand of the first product: n = y (this lane's row), k = y' in natural order
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
-    gv[ks] = fb_split2(t, FB_G_SCALE);
-  }
-  __syncthreads();      // P1
-  __syncthreads();      // Pg
-  __syncthreads();      // P2
-  int k = 0;
-#ifdef PV_DIAG_STAMPS
-  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, s0, s1, s2;
-#endif
-  for (long long p = p_lo; p < p_hi; ++p) {
-    for (int it = 0; it < n_it; ++it) {
-      const int e = unit_exp(strip, mbo);
-      fb_v16f res[5];
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        PV_STAMP(s0);
-        __syncthreads();      // B<c>: channel k is in its buffer
-        PV_STAMP(s1);
-        const uint16_t* Xc = &Xs[k & 1][0][0];
-        ++k;
-        fb_v16f u[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            FbSplit2 a;
-            const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-            a.h = *reinterpret_cast<const fb_f16x8*>(xa);
-            a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
-            u[mb] = fb_mfma2(a, gv[ks], u[mb]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          float t[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
-          const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
-          FbSplit2 g;
-          g.h = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 0][lane]);
-          g.l = __builtin_bit_cast(fb_f16x8, GhS[(mbo * KS + ks) * 2 + 1][lane]);
-          res[c] = fb_mfma2(g, b, res[c]);
-        }
-        PV_STAMP(s2);
-#ifdef PV_DIAG_STAMPS
-        dg[0] += s1 - s0, dg[1] += s2 - s1;
-#endif
-      }
-      PV_STAMP(s0);
-      // ---- 2 x 2 solve on sums that carry the factor kk = 2^15 s = 2^(30 - e); lane = row y, registers = columns x -------
-      {
-        const float lam = ldexpf(1e-3f, 2 * (30 - e));
-        const int y = (MOSAIC ? 0 : 32 * strip) + col;
-        const long long pr = MOSAIC ? p * 4 + 2 * strip + mbo : p;
-        float* frow = flow + (pr * lpx + (long long)y * width) * 2;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int x0 = (MOSAIC ? 0 : 32 * mbo) + 8 * g4 + 4 * half;
-          float o[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * g4 + j;
-            const float g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
-            // det >= lam > 0 (a sum of squares' determinant plus the regulariser), well inside the normal range: one hardware
-            // reciprocal (1 ulp), one Newton step (0.5 ulp), then each quotient corrected once by its residual
-            const float det = __fadd_rn(fb_det2(g11, g22, g12, g12), lam);
-            float rc = __builtin_amdgcn_rcpf(det);
-            rc = __builtin_fmaf(__builtin_fmaf(-det, rc, 1.f), rc, rc);
-            const float nx = fb_det2(g11, h2, g12, h1), ny = fb_det2(g22, h1, g12, h2);
-            const float qx = __fmul_rn(nx, rc), qy = __fmul_rn(ny, rc);
-            o[2 * j] = __builtin_fmaf(__builtin_fmaf(-det, qx, nx), rc, qx);
-            o[2 * j + 1] = __builtin_fmaf(__builtin_fmaf(-det, qy, ny), rc, qy);
-          }
-          if (y < height && x0 < width && pr < n_pairs) {      // rows of whole 4-pixel quads (the launcher's condition)
-            *reinterpret_cast<f32x4*>(frow + x0 * 2) = (f32x4){o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<f32x4*>(frow + x0 * 2 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
-          }
-        }
-      }
-      PV_STAMP(s1);
-      if (it + 1 < n_it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the flow is on its way to L2 before the producers are released
-        __syncthreads();      // X1
-        __syncthreads();      // Xg
-      }
-      __syncthreads();      // X0 / B5
-      PV_STAMP(s2);
-#ifdef PV_DIAG_STAMPS
-      dg[2] += s1 - s0, dg[0] += s2 - s1, dg[7] += 1;
-#endif
-    }
-  }
-#ifdef PV_DIAG_STAMPS
-  if (lane == 0 && blockIdx.x * 12 + wave12 < PV_DIAG_WAVES)
-    for (int i = 0; i < PV_DIAG_SLOTS; ++i) fb_iter_diag[(size_t)(blockIdx.x * 12 + wave12) * PV_DIAG_SLOTS + i] = dg[i];
-#endif
-}
-
-// ---- one launch per pyramid level, second form: UNIFORM waves -----------------------------------------------------------
-// What fb_level_kernel's stamps and counters said: its two kinds of waves take turns inside a unit anyway (iteration it + 1
-// needs iteration it's flow), a stage is a serial chain of 28-30 000 cycles, and at three waves per SIMD (168 registers) a
-// unit's R0 and the flow between two iterations do not fit in registers: R0 is read again from memory for every iteration
-// (0.9 of the launch's 1.9 GB) and the flow goes through memory and back.  Here a 512-thread workgroup (two waves per SIMD,
-// 256 registers) does every phase with ALL eight waves:
-//   P  UpdateMatrices: wave w owns rows 8 w .. 8 w + 7, a lane one column (fb_level_kernel's G and F, same expressions); the
-//      unit's R0 stays in 40 registers through all its iterations, R1 in LDS;
+// ---- one launch per pyramid LEVEL: every iteration of every pair, eight UNIFORM waves ------------------------------------------
+// (The round's first form -- four multiplying + eight producing waves, 768 threads -- showed in its stamps that the two kinds
+// of waves take turns inside a unit anyway (iteration it + 1 needs iteration it's flow: a stage is a serial chain), and in its
+// counters that at three waves per SIMD (168 registers) a unit's R0 and the flow between two iterations do not fit in
+// registers: R0 was read again from memory for every iteration (0.9 of that launch's 1.9 GB) and the flow went through memory
+// and back.  This kernel evaluates the same expressions in the same order: its flows were bit-identical to that form's, which
+// was removed at the end of the round; profiles/r04/split_wave_kernel_* are its measurements.)
+// A 512-thread workgroup (two waves per SIMD, 256 registers) does every phase with ALL eight waves:
+//   P  UpdateMatrices: wave w owns rows 8 w .. 8 w + 7, a lane one column (G: 12 LDS reads + the bilinear blend per pixel, F: the
+//      rest, per pixel right behind it); the unit's R0 stays in 40 registers through all its iterations, R1 in LDS;
 //   M  the window blur: wave (strip, mbo, g) multiplies for block (strip, mbo) the channels of group g (g = 0: 0, 1, 2;
 //      g = 1: 3, 4) -- the two waves of a SIMD cover each other's LDS reads and operand splits.  Channels are handed over two
 //      at a time through a double-buffered LDS image (rounds (0, 3), (1, 4), (2, -)); both window operands live in registers;
-//   S  group 1 passes its two blurred channels to group 0 through LDS, group 0 solves and leaves the flow in LDS (row-major,
-//      rows of 528 bytes), from where every lane takes its 8 pixels for the next iteration: the flow between two iterations
-//      never leaves the CU.  The unit's last iteration stores it to memory instead.
-// During the unit's last M phase the eight waves bring the next unit's R1 through the registers R0 no longer needs.
-// Per stage: six barriers, no memory traffic but the flow store of the last iteration and 160 KB per UNIT of R.
-// Same operation order as fb_level_kernel in every phase: the flows are bit-identical to it.
+//   S  the two groups of a block swap half of their blurred channels through LDS mailboxes and solve half of the block's pixels
+//      each; the flow goes to an LDS image (row-major, rows of 528 bytes) from where every lane takes its 8 pixels for the next
+//      iteration: the flow between two iterations never leaves the CU.  The unit's last iteration stores it to memory instead.
+// During the unit's last M phase the eight waves bring the next unit's R1 through the registers R0 no longer needs, then its
+// R0, and its source flow into the free flow image.  Per stage: six barriers, no memory traffic but the flow store of the last
+// iteration and 160 KB per UNIT of R.
 template <int FLOW_INIT, bool MOSAIC>
 __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict__ R, const float* __restrict__ flow_prev, float* flow,
                                                          const float* __restrict__ Gv, const float* __restrict__ Gh, int height,
@@ -1728,7 +1111,7 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
     return e < -25 ? -25 : (e > 100 ? 100 : e);
   };
 
-  // ---- the unit -> coefficient image bookkeeping (as fb_level_kernel) -------------------------------------------------------
+  // ---- the unit -> coefficient image bookkeeping --------------------------------------------------------------------------------
   long long i0_run, i1_unused;
   fb_r_images_of(p_lo * NP, pairs_per_group, chain_f, &i0_run, &i1_unused);
   long long q_run = chain_f > 0 ? (p_lo * NP) % pairs_per_group : 0;
@@ -2904,7 +2287,7 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     else mode = 2;
     const bool tile_path = lw <= 64 && lh <= 64 && n_pairs <= 0x7fffffffLL;   // any window: it is a precomputed matrix
     // Levels up to 64 x 64 whose source images are up to 64 x 64 (the PV-site tiles): ONE launch per level does every
-    // iteration -- UpdateMatrices, the window blur and the solve (fb_level_kernel); M is never written.  33..64-pixel
+    // iteration -- UpdateMatrices, the window blur and the solve (fb_level_u_kernel); M is never written.  33..64-pixel
     // levels: one pair per 64 x 64 tile; levels up to 32 x 32: four pairs per tile (MOSAIC; its buffer offsets are 31-bit).
     // Rows of whole 4-pixel quads and a 16-byte-aligned flow: R and the flow move as 16-byte vectors.  Everything else (a
     // width that is no multiple of 4, larger source images, PV_FARNEBACK_TWO_LAUNCH_ITERATION=1) takes the two-launch
@@ -2971,28 +2354,12 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (float)(1. / p->pyr_scale)};
       const long long n_units = small_level ? (n_pairs + 3) / 4 : n_pairs;
       const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);      // one workgroup per CU (LDS)
-#define PV_LEVEL(INIT, MOS, SINGLE)                                                                                       \
-  hipLaunchKernelGGL((fb_level_kernel<INIT, MOS, SINGLE>), dim3(grid), dim3(768), 0, st, (const float*)R,                 \
-                     (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
-                     (long long)pairs_per_group, chain_f, up, (int)p->iterations)
 #define PV_LEVEL_U(INIT, MOS)                                                                                             \
   hipLaunchKernelGGL((fb_level_u_kernel<INIT, MOS>), dim3(grid), dim3(512), 0, st, (const float*)R,                       \
                      (const float*)prev_flow, flow, (const float*)Gv, (const float*)Gh, lh, lw, (long long)n_pairs,       \
                      (long long)pairs_per_group, chain_f, up, (int)p->iterations)
-      if (!getenv("PV_FARNEBACK_SPLIT_WAVES")) {      // uniform waves (R0 and the flow between iterations stay on the CU)
-        if (prev_flow) { if (small_level) PV_LEVEL_U(1, true); else PV_LEVEL_U(1, false); }
-        else { if (small_level) PV_LEVEL_U(2, true); else PV_LEVEL_U(2, false); }
-      } else {      // producing + multiplying waves (the first form; kept as the cross-check)
-        const bool single = p->iterations == 1;
-        if (prev_flow) {
-          if (small_level) { if (single) PV_LEVEL(1, true, true); else PV_LEVEL(1, true, false); }
-          else { if (single) PV_LEVEL(1, false, true); else PV_LEVEL(1, false, false); }
-        } else {
-          if (small_level) { if (single) PV_LEVEL(2, true, true); else PV_LEVEL(2, true, false); }
-          else { if (single) PV_LEVEL(2, false, true); else PV_LEVEL(2, false, false); }
-        }
-      }
-#undef PV_LEVEL
+      if (prev_flow) { if (small_level) PV_LEVEL_U(1, true); else PV_LEVEL_U(1, false); }
+      else { if (small_level) PV_LEVEL_U(2, true); else PV_LEVEL_U(2, false); }
 #undef PV_LEVEL_U
       prev_flow = flow;
       prev_w = lw;

@@ -232,8 +232,8 @@ def test_farneback_stack_computes_each_frame_once_bit_identically(device, monkey
 @pytest.mark.parametrize("h,w,t,batch", [(64, 64, 12, 3), (64, 64, 4, 100), (64, 64, 12, 100), (40, 56, 3, 3), (48, 64, 4, 3),
                                          (64, 36, 2, 3), (50, 62, 3, 3)])
 def test_fused_iteration_against_the_two_launch_form(device, monkeypatch, h, w, t, batch):
-    """Levels up to 64 x 64 run UpdateMatrices + window blur + solve as ONE launch per iteration (fb_iter_kernel: eight
-    producing + four matrix-core waves, M never written; levels up to 32 x 32 as four pairs per 64 x 64 tile with
+    """Levels up to 64 x 64 run every iteration's UpdateMatrices + window blur + solve in ONE launch per level
+    (fb_level_u_kernel: eight uniform waves, M never written; levels up to 32 x 32 as four pairs per 64 x 64 tile with
     block-diagonal window matrices).  UpdateMatrices is the same arithmetic as in the two-launch form
     (PV_FARNEBACK_TWO_LAUNCH_ITERATION=1); the blur runs on two-term f16 operands (2^-22) and the solve in compensated f32
     instead of three-term bf16 and f64, so the flows agree to a few 1e-6 px, not bit for bit (bound: 2e-5 px, 50 x under
@@ -301,7 +301,7 @@ def test_polyexp_on_the_matrix_cores_against_the_vector_alu_form(device, monkeyp
 
 
 def test_level_kernel_repeated_launches_give_identical_bits(device):
-    """1 200 pairs (4-5 units per workgroup, the unit-boundary overlap of fb_level_kernel in play), ten launches: identical
+    """1 200 pairs (4-5 units per workgroup, the next unit's prefetches under a unit's last iteration in play), ten launches: identical
     bits every time.  (Round 4: a scheduling hint in the multiplying waves' operand reads made repeated launches differ by
     ~1e-6 px -- a read of a hand-over buffer ahead of its barrier; tools/stress_flow_fused.py is the longer form of this.)"""
     K = _ops()
@@ -311,25 +311,6 @@ def test_level_kernel_repeated_launches_give_identical_bits(device):
     first = K.farneback_stack(u8)
     for _ in range(10):
         assert torch.equal(K.farneback_stack(u8), first)
-
-
-@pytest.mark.parametrize("h,w,t,stacks,kw", [
-    (64, 64, 12, 40, {}),                                                    # the PV-site tiles, default parameters
-    (64, 64, 3, 300, {}),                                                    # several units per workgroup
-    (40, 56, 4, 7, dict(levels=3, iterations=2)),                            # 64-px tile with margins, three levels (two MOSAIC)
-    (24, 28, 3, 11, dict(levels=2, winsize=9, iterations=1)),                # MOSAIC level 0, one iteration per level
-    (64, 36, 2, 5, dict(levels=1, winsize=21, iterations=3, poly_n=7, poly_sigma=1.5)),      # starts from a zero flow
-])
-def test_uniform_wave_level_kernel_equals_the_split_wave_kernel(device, monkeypatch, h, w, t, stacks, kw):
-    """fb_level_u_kernel (8 uniform waves, R0 and the flow between iterations kept on the CU) evaluates the same expressions in
-    the same order as fb_level_kernel (4 multiplying + 8 producing waves, PV_FARNEBACK_SPLIT_WAVES=1): identical bits."""
-    K = _ops()
-    raw, _ = advected_counts(batch=stacks, t=t, channels=1, h=h, w=w, seed=5 * h + w)
-    u8 = torch.from_numpy(fo.convert_10bpp_to_uint8(np.ascontiguousarray(raw[:, :, 0]), 0)[0]).to(device)
-    uniform = K.farneback_stack(u8, **kw)
-    monkeypatch.setenv("PV_FARNEBACK_SPLIT_WAVES", "1")
-    split = K.farneback_stack(u8, **kw)
-    assert bool(torch.isfinite(uniform).all()) and torch.equal(uniform, split)
 
 
 @pytest.mark.parametrize("dtype", [torch.int16, torch.float32])

@@ -1,4 +1,4 @@
-"""fb_level_u_kernel (round 4) against the oracle, the split-wave level kernel and the two-launch form: largest flow differences (px) over a few shapes, and
+"""The flow path (matrix-core PolyExp + fb_level_u_kernel) against the oracle, the vector-ALU PolyExp and the two-launch form: largest flow differences (px) over a few shapes, and
 stack == pairs bit-identity.  Usage: python tools/check_flow_iter.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,7 @@ for h, w, t, batch in [(64, 64, 12, 3), (64, 64, 4, 100), (40, 56, 3, 3), (48, 6
     nxt = u8[:, 1:].reshape(-1, h, w).contiguous()
     new_stack, new_pairs = K.farneback_stack(u8), K.farneback_pairs(prev, nxt)
     two = run(["PV_FARNEBACK_TWO_LAUNCH_ITERATION"], lambda: K.farneback_stack(u8))
-    split = run(["PV_FARNEBACK_SPLIT_WAVES"], lambda: K.farneback_stack(u8))
+    valu = run(["PV_FARNEBACK_POLYEXP_VALU"], lambda: K.farneback_stack(u8))
     torch.cuda.synchronize()
     errs = []
     for (i, j) in [(0, 0), (2, 0), (2 * batch - 1, t - 2)]:
@@ -37,6 +37,6 @@ for h, w, t, batch in [(64, 64, 12, 3), (64, 64, 4, 100), (40, 56, 3, 3), (48, 6
         errs.append(float(np.abs(new_stack[i, j].cpu().numpy() - ref).max()))
     print(f"{h}x{w} t={t} stacks={2 * batch}: finite={bool(torch.isfinite(new_stack).all())} "
           f"stack==pairs {torch.equal(new_stack.reshape(-1, h, w, 2), new_pairs)}  "
-          f"== split-wave kernel {torch.equal(new_stack, split)} ({float((new_stack - split).abs().max()):.1e})  "
+          f"|matrix-core - vector-ALU PolyExp|max {float((new_stack - valu).abs().max()):.1e}  "
           f"|new-two|max {float((new_stack - two).abs().max()):.3e}  "
           f"|new-oracle|max {max(errs):.3e}  max|flow| {float(two.abs().max()):.2f}", flush=True)

@@ -66,11 +66,10 @@ def run():
 
 
 def flow_report(d):
-    """fb_level_u_kernel (8 uniform waves per workgroup; waves 0..3 = group 0: three channels + the solve, waves 4..7 = group
-    1: two channels) or, with PV_FARNEBACK_SPLIT_WAVES=1, fb_level_kernel (waves 0..3 multiply, 4..11 produce); the last
-    launch's stamps"""
+    """fb_level_u_kernel (8 uniform waves per workgroup; waves 0..3 = group 0: three channels, waves 4..7 = group 1: two
+    channels; half of the solve each); the last launch's stamps"""
     d = d[: (d[:, 7] > 0).nonzero()[0].max() + 1]
-    if not os.environ.get("PV_FARNEBACK_SPLIT_WAVES"):
+    if True:
         d = d[: len(d) // 8 * 8].reshape(-1, 8, SLOTS)
         if os.environ.get("PV_DIAG_BARRIER_DETAIL"):      # a library built with -DFBU_BARRIER_DETAIL
             labels = ["wait at Bm", "wait at B0", "wait at B1", "wait at B2", "wait at B3", "wait at B4", "everything else"]
@@ -86,16 +85,6 @@ def flow_report(d):
             for i, lab in enumerate(labels):
                 print(f"    {lab:64s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / stage  {100 * w[:, i].mean() / tot:5.1f} %")
         return
-    d = d[: len(d) // 12 * 12].reshape(-1, 12, SLOTS)
-    for name, sl, labels in (("multiplying waves", slice(0, 4), ["barrier (waiting for a channel / the next unit)", "channel: 24 + 12 products", "solve + flow store"]),
-                             ("producing waves", slice(4, 12), ["split + write a channel (+ wait for R1)", "barrier", "after the barrier: requests + UpdateMatrices of the next unit",
-                                                                "unit start: scale, R1 requests, first R0 / flow requests"])):
-        w = d[:, sl].reshape(-1, SLOTS)
-        w = w[w[:, 7] > 0]
-        tot = w[:, : len(labels)].sum(1).mean()
-        print(f"  {name}: {len(w)} waves, {w[:, 7].mean():.1f} units per wave, {tot / w[:, 7].mean():.0f} cycles / unit")
-        for i, lab in enumerate(labels):
-            print(f"    {lab:60s} {(w[:, i] / w[:, 7]).mean():9.0f} cycles / unit  {100 * w[:, i].mean() / tot:5.1f} %")
 
 
 fn, kind = run()
