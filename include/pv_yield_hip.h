@@ -424,6 +424,11 @@ int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, con
  * (perceiver_pytorch: `x = cross_attn(x, ...) + x`, `x = cross_ff(x) + x`, ...) folded into the epilogue of fn's last Linear. */
 int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
                     const pv_gemm_desc* d, int relu, void* stream);
+/* C (bf16, row-major, ldc elements per row) = A B + bias for ONE tall row-major A with K <= 64: to_kv of a cross-attention
+ * (perceiver_pytorch Attention.to_kv, models/perceiver/perceiver.py:70-80) writing the K / V the bf16-operand attention kernels
+ * read (pv_attention_*_bf16kv).  f32-accurate products, one rounding in the store. */
+int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, uint16_t* c_bf16, const pv_gemm_desc* d,
+                             void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
 /* accumulate != 0: out += the sum -- a weight that several layers share (weight_tie_layers=True,
  * predict_pv_yield/models/perceiver/perceiver.py:70-80) collects its gradient contributions in place, in arrival order,
@@ -462,7 +467,15 @@ int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float*
                           float* workspace, void* stream);   /* workspace NULL: no key split */
 int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
                           float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
-                          void* stream);   /* accumulate_dkv != 0: dk, dv += (keys / values shared by weight-tied layers) */
+                          void* stream);
+/* The same two with K and V stored as bf16 (the values the kernels above round to on their way into LDS): half the bytes of
+ * these HBM-bound launches (128 queries make 64 flop per byte of f32 K / V).  k / v: bf16 [batch, n_k, ...] with the
+ * descriptor's k_*_stride counted in bf16 elements (multiples of 8); dk / dv stay f32 with the same element strides. */
+int pv_attention_fwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, float* o, float* lse, const pv_attention_desc* d,
+                            float* workspace, void* stream);
+int pv_attention_bwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout, const float* lse,
+                            float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
+                            void* stream);   /* accumulate_dkv != 0: dk, dv += (keys / values shared by weight-tied layers) */
 
 /* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
  * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */

@@ -147,6 +147,7 @@ SIGNATURES = {
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
     "pv_gemm_res_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
+    "pv_gemm_rows_bf16out_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_vp],
     "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
     "pv_sum_slabs_acc_f32": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
     "pv_colsum_f32": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp],
@@ -154,8 +155,10 @@ SIGNATURES = {
     "pv_attention_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp],
     "pv_attention_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp, c_vp],
+    "pv_attention_fwd_bf16kv": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_vp, c_vp],
     "pv_attention_fwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_attention_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_i32, c_vp],
+    "pv_attention_bwd_bf16kv": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(AttentionDesc), c_i32, c_vp],
     "pv_attention_bwd_workspace_floats": [ctypes.POINTER(AttentionDesc)],
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],

@@ -53,8 +53,12 @@ __device__ __forceinline__ bf16x8 att_load8(const float* p, bool ok) {   // 8 co
 // and leaves its UNNORMALISED accumulator, running maximum and running sum in `part` ([split][b][h][query][64 + 2]);
 // attn_fwd_combine merges the splits in split order.  (152 (batch, head) groups of one query tile each leave 40 % of
 // the chip idle and one wave per SIMD: with 4 splits two or three workgroups share a CU and overlap each other's softmax.)
-__global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, float* __restrict__ o,
+// KV = float: K / V f32 in memory, rounded to bf16 on the way into LDS; KV = uint16_t: K / V already bf16 in memory (the
+// projection that produced them wrote bf16: half the bytes of this HBM-bound kernel -- 128 queries make 64 flop per byte of
+// f32 K / V) -- same values, same results
+template <typename KV>
+__global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q, const KV* __restrict__ k,
+                                                      const KV* __restrict__ v, float* __restrict__ o,
                                                       float* __restrict__ lse, AttnGeomB g, int n_splits, int keys_per_split,
                                                       float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) uint16_t Ks[BTJ * B_KLD];   // [key][d]
@@ -77,8 +81,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
   const int key_hi = key_lo + keys_per_split < g.n_k ? key_lo + keys_per_split : g.n_k;
   const int i = qt * 128 + wave * 32 + col;           // this lane's query
   const float* qb = q + b * g.q_bs + h * BD;
-  const float* kb = k + b * g.k_bs + h * BD;
-  const float* vb = v + b * g.k_bs + h * BD;
+  const KV* kb = k + b * g.k_bs + h * BD;
+  const KV* vb = v + b * g.k_bs + h * BD;
+  constexpr bool KV16 = sizeof(KV) == 2;
   // B operand of S^T = K Q^T: lane (query = col, d = 16 ks + 8 half + 0..7)
   bf16x8 qreg[4];
 #pragma unroll
@@ -92,20 +97,26 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
 
   // staging: thread t moves 8 floats of K and of V of the 32 x 64 tile: key t / 8, d = 8 (t % 8) ..
   const int st_row = tid >> 3, st_col = (tid & 7) * 8;
-  f32x4 k0, k1, v0, v1;
+  // (Four key tiles in flight per thread instead of one were tried for the bf16-stored K / V: 332 against 314 us, and the
+  // f32-stored form went 269 -> 357 us: the loop is not waiting for memory.)
+  f32x4 k0, k1, v0, v1;      // (KV16: k0 / v0 hold the 8 bf16 values as they are)
   auto load_tile = [&](int j0) {
     const int j = j0 + st_row;
     const bool ok = j < key_hi;
-    const float* kp = kb + (long long)(ok ? j : 0) * g.k_rs + st_col;
-    const float* vp = vb + (long long)(ok ? j : 0) * g.k_rs + st_col;
-    k0 = *reinterpret_cast<const f32x4*>(kp); k1 = *reinterpret_cast<const f32x4*>(kp + 4);
-    v0 = *reinterpret_cast<const f32x4*>(vp); v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+    const KV* kp = kb + (long long)(ok ? j : 0) * g.k_rs + st_col;
+    const KV* vp = vb + (long long)(ok ? j : 0) * g.k_rs + st_col;
+    k0 = *reinterpret_cast<const f32x4*>(kp);
+    v0 = *reinterpret_cast<const f32x4*>(vp);
+    if constexpr (!KV16) { k1 = *reinterpret_cast<const f32x4*>(kp + 4); v1 = *reinterpret_cast<const f32x4*>(vp + 4); }
     if (!ok) { k0 = k1 = v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   };
   load_tile(key_lo);
   for (int j0 = key_lo; j0 < key_hi; j0 += BTJ) {
     __syncthreads();
-    {
+    if constexpr (KV16) {
+      *reinterpret_cast<f32x4*>(Ks + st_row * B_KLD + st_col) = k0;
+      *reinterpret_cast<f32x4*>(Vs + st_row * B_KLD + st_col) = v0;
+    } else {
       const float kx[8] = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
       *reinterpret_cast<bf16x8*>(Ks + st_row * B_KLD + st_col) = att_pack8(kx);
       const float vx[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -209,8 +220,9 @@ __global__ __launch_bounds__(256) void attn_fwd_combine(const float* __restrict_
 // dV^T += dO^T P, dK^T += Q^T dS).  Wave w walks the key tiles w, w+4, ... on its own (no barriers inside the loop): K and V
 // of the tile are B operands in registers, K^T a per-wave LDS tile (A operand of dQ^T += K^T dS^T), dS goes through a
 // per-wave LDS tile to be read back along the keys.
-__global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, const float* __restrict__ dout,
+template <typename KV>      // float or uint16_t (bf16 K / V in memory), as attn_fwd_bf16
+__global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q, const KV* __restrict__ k,
+                                                      const KV* __restrict__ v, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
                                                       AttnGeomB g, int tiles_per_split, long long dq_ss, int accumulate_dkv) {
@@ -244,8 +256,9 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   const int b = blockIdx.z, h = blockIdx.y;
   const float* qb = q + b * g.q_bs + h * BD;
   const float* ob = dout + b * g.q_bs + h * BD;
-  const float* kb = k + b * g.k_bs + h * BD;
-  const float* vb = v + b * g.k_bs + h * BD;
+  const KV* kb = k + b * g.k_bs + h * BD;
+  const KV* vb = v + b * g.k_bs + h * BD;
+  constexpr bool KV16 = sizeof(KV) == 2;
   const int n_tiles = (g.n_k + BTJ - 1) / BTJ;
   const int n_qt = (g.n_q + 31) / 32;
   const float scale_log2e = g.scale * 1.44269504088896340736f;
@@ -258,12 +271,13 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   auto load_kv = [&](int tile) {
     const int jj = tile * BTJ + col;
     const bool ok = tile < tile1 && jj < g.n_k;
-    const float* kp = kb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
-    const float* vp = vb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
+    const KV* kp = kb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
+    const KV* vp = vb + (long long)(ok ? jj : 0) * g.k_rs + 8 * half;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      kn[ks][0] = *reinterpret_cast<const f32x4*>(kp + 16 * ks); kn[ks][1] = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4);
-      vn[ks][0] = *reinterpret_cast<const f32x4*>(vp + 16 * ks); vn[ks][1] = *reinterpret_cast<const f32x4*>(vp + 16 * ks + 4);
+    for (int ks = 0; ks < 4; ++ks) {      // (KV16: kn / vn [ks][0] hold the 8 bf16 values as they are)
+      kn[ks][0] = *reinterpret_cast<const f32x4*>(kp + 16 * ks);
+      vn[ks][0] = *reinterpret_cast<const f32x4*>(vp + 16 * ks);
+      if constexpr (!KV16) { kn[ks][1] = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4); vn[ks][1] = *reinterpret_cast<const f32x4*>(vp + 16 * ks + 4); }
       if (!ok) kn[ks][0] = kn[ks][1] = vn[ks][0] = vn[ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -304,10 +318,15 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
     bf16x8 kreg[4], vreg[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const float kx[8] = {kn[ks][0][0], kn[ks][0][1], kn[ks][0][2], kn[ks][0][3], kn[ks][1][0], kn[ks][1][1], kn[ks][1][2], kn[ks][1][3]};
-      const float vx[8] = {vn[ks][0][0], vn[ks][0][1], vn[ks][0][2], vn[ks][0][3], vn[ks][1][0], vn[ks][1][1], vn[ks][1][2], vn[ks][1][3]};
-      kreg[ks] = att_pack8(kx);
-      vreg[ks] = att_pack8(vx);
+      if constexpr (KV16) {
+        kreg[ks] = __builtin_bit_cast(bf16x8, kn[ks][0]);
+        vreg[ks] = __builtin_bit_cast(bf16x8, vn[ks][0]);
+      } else {
+        const float kx[8] = {kn[ks][0][0], kn[ks][0][1], kn[ks][0][2], kn[ks][0][3], kn[ks][1][0], kn[ks][1][1], kn[ks][1][2], kn[ks][1][3]};
+        const float vx[8] = {vn[ks][0][0], vn[ks][0][1], vn[ks][0][2], vn[ks][0][3], vn[ks][1][0], vn[ks][1][1], vn[ks][1][2], vn[ks][1][3]};
+        kreg[ks] = att_pack8(kx);
+        vreg[ks] = att_pack8(vx);
+      }
       *reinterpret_cast<bf16x8*>(Kr + col * B_KLD + 16 * ks + 8 * half) = kreg[ks];   // row-major; read transposed for dQ
     }
     if (ATT_BWD_PREFETCH) load_kv(tile + 4);
@@ -473,11 +492,14 @@ size_t pv_attention_fwd_workspace_floats(const pv_attention_desc* d) {
   return nsp > 1 ? (size_t)nsp * d->batch * d->heads * d->n_q * (BD + 2) : 0;
 }
 
-int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
-                          float* workspace, void* stream) {
+extern "C++" template <typename KV>
+static int attention_fwd_bf16_any(const float* q, const KV* k, const KV* v, float* o, float* lse, const pv_attention_desc* d,
+                                  float* workspace, void* stream) {
   AttnGeomB g;
   int rc = attn_geom_b(d, &g, "pv_attention_fwd_bf16");
   if (rc) return rc;
+  PV_REQUIRE(sizeof(KV) == 4 || (d->k_row_stride % 8 == 0 && d->k_batch_stride % 8 == 0), PV_EINVAL,
+             "pv_attention_fwd_bf16kv: K / V strides must be multiples of 8 elements (16-byte rows)");
   PV_REQUIRE(q && k && v && o && lse, PV_EINVAL, "pv_attention_fwd_bf16: null pointer");
   PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0), PV_EINVAL,
              "pv_attention_fwd_bf16: q / k / v must be 16-byte aligned");
@@ -486,7 +508,7 @@ int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float*
   const int n_qt = (d->n_q + 127) / 128;
   hipStream_t st = as_stream(stream);
   dim3 grid((unsigned)(n_qt * nsp), (unsigned)d->heads, (unsigned)d->batch);
-  hipLaunchKernelGGL(attn_fwd_bf16, grid, dim3(256), 0, st, q, k, v, o, lse, g, nsp, nsp > 1 ? per : d->n_k, workspace);
+  hipLaunchKernelGGL(attn_fwd_bf16<KV>, grid, dim3(256), 0, st, q, k, v, o, lse, g, nsp, nsp > 1 ? per : d->n_k, workspace);
   if (nsp > 1) {
     const long long rows = (long long)d->batch * d->heads * d->n_q;
     hipLaunchKernelGGL(attn_fwd_combine, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)workspace, o, lse, g,
@@ -495,12 +517,25 @@ int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float*
   return check_launch("pv_attention_fwd_bf16");
 }
 
-int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
-                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
-                          void* stream) {
+int pv_attention_fwd_bf16(const float* q, const float* k, const float* v, float* o, float* lse, const pv_attention_desc* d,
+                          float* workspace, void* stream) {
+  return attention_fwd_bf16_any<float>(q, k, v, o, lse, d, workspace, stream);
+}
+
+int pv_attention_fwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, float* o, float* lse, const pv_attention_desc* d,
+                            float* workspace, void* stream) {
+  return attention_fwd_bf16_any<uint16_t>(q, k, v, o, lse, d, workspace, stream);
+}
+
+extern "C++" template <typename KV>
+static int attention_bwd_bf16_any(const float* q, const KV* k, const KV* v, const float* o, const float* dout, const float* lse,
+                                  float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d,
+                                  int32_t accumulate_dkv, void* stream) {
   AttnGeomB g;
   int rc = attn_geom_b(d, &g, "pv_attention_bwd_bf16");
   if (rc) return rc;
+  PV_REQUIRE(sizeof(KV) == 4 || (d->k_row_stride % 8 == 0 && d->k_batch_stride % 8 == 0), PV_EINVAL,
+             "pv_attention_bwd_bf16kv: K / V strides must be multiples of 8 elements (16-byte rows)");
   PV_REQUIRE(q && k && v && o && dout && lse && delta_ws && dq && dk && dv, PV_EINVAL, "pv_attention_bwd_bf16: null pointer");
   PV_REQUIRE(d->n_q <= 128, PV_ESIZE, "pv_attention_bwd_bf16: n_q=%d > 128 queries per (batch, head) is not built", d->n_q);
   PV_REQUIRE(((uintptr_t)q % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
@@ -523,14 +558,26 @@ int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const 
   if (nsp > 1) {
     float* part = delta_ws + rows;
     const long long n = (long long)d->batch * d->q_batch_stride;
-    hipLaunchKernelGGL(attn_bwd_bf16, dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
+    hipLaunchKernelGGL(attn_bwd_bf16<KV>, dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
                        lse, (const float*)delta_ws, part, dk, dv, g, per, n, accumulate_dkv);
     launch_sum_slabs(part, dq, n, nsp, n, 0, st);
   } else {
-    hipLaunchKernelGGL(attn_bwd_bf16, dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
+    hipLaunchKernelGGL(attn_bwd_bf16<KV>, dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
                        (const float*)delta_ws, dq, dk, dv, g, n_tiles, 0ll, accumulate_dkv);
   }
   return check_launch("pv_attention_bwd_bf16");
+}
+
+int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
+                          float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
+                          void* stream) {
+  return attention_bwd_bf16_any<float>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
+}
+
+int pv_attention_bwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout, const float* lse,
+                            float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
+                            void* stream) {
+  return attention_bwd_bf16_any<uint16_t>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
 }
 
 }  // extern "C"

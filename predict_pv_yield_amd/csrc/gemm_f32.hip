@@ -337,7 +337,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 //   * a wave owns blocks of 32 rows and fetches their A operand STRAIGHT INTO REGISTERS in MFMA layout (lane = (row, k half):
 //     8 consecutive k of its own row, 32 bytes) -- no LDS image of A, no barrier anywhere in the loop; the next block's
 //     rows are in flight while the current block is split, multiplied and stored.
-template <int KSTEPS, int VEC>
+// OUT_BF16: C is a bf16 matrix (round to nearest even in the store): the key / value projection of a cross-attention whose
+// bf16-operand kernels would round those values anyway -- the 1.3 GB of f32 K / V of experiments/003's context (2.5 M rows x 128)
+// is what bounds both this kernel's store and the attention kernels' reads
+template <int KSTEPS, int VEC, bool OUT_BF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks) {
   constexpr int KP = 16 * KSTEPS;
   constexpr int BRS = 2 * KP + 16;                       // bytes per n-row of a B plane (16 rows x 16 B cover the 64 banks)
@@ -432,7 +435,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
           float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
           if (rp) v += rp[(long long)dr * g.ldr];
           if (g.relu) v = v > 0.f ? v : 0.f;
-          cp[(long long)dr * g.ldc] = v;
+          if constexpr (OUT_BF16) reinterpret_cast<uint16_t*>(C)[(m_lane + dr) * g.ldc + nn] = f32_to_bf16_bits(v);
+          else cp[(long long)dr * g.ldc] = v;
         }
       }
     }
@@ -624,6 +628,38 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), g);
   }
   return check_launch("pv_gemm_f32");
+}
+
+int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, uint16_t* c_bf16, const pv_gemm_desc* d,
+                             void* stream) {
+  PV_REQUIRE(a && b && c_bf16 && d, PV_EINVAL, "pv_gemm_rows_bf16out_f32: null pointer");
+  PV_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0 && d->ldc >= d->n, PV_EINVAL, "pv_gemm_rows_bf16out_f32: bad extents");
+  PV_REQUIRE((long long)d->batch1 * d->batch2 * d->k_splits == 1 && d->a_cs == 1 && d->k <= 64 && ((uintptr_t)a % 16 == 0), PV_ESIZE,
+             "pv_gemm_rows_bf16out_f32: built for one tall row-major A with K <= 64 (got K=%d, batch %d x %d, k_splits %d)", d->k,
+             d->batch1, d->batch2, d->k_splits);
+  GemmK g;
+  g.a = a, g.b = b, g.bias = bias, g.c = reinterpret_cast<float*>(c_bf16);
+  g.res = nullptr, g.ldr = 0;
+  g.m = d->m, g.n = d->n, g.k = d->k;
+  g.a_rs = d->a_rs, g.a_cs = d->a_cs, g.b_rs = d->b_rs, g.b_cs = d->b_cs, g.ldc = d->ldc;
+  g.batch2 = 1, g.k_splits = 1, g.k_chunk = (d->k + G_BK - 1) / G_BK * G_BK;
+  g.a_bs1 = g.a_bs2 = g.b_bs1 = g.b_bs2 = g.c_bs1 = g.c_bs2 = 0, g.c_ss = 0;
+  g.relu = 0;
+  const int n_tiles = (d->n + G_BN - 1) / G_BN;
+  const int n_rb = (d->m + 31) / 32;
+  int per_col = 512 / n_tiles;
+  if (per_col < 1) per_col = 1;
+  if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
+  dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
+  const int vec = (d->a_rs % 4 == 0 && d->k % 4 == 0) ? 4 : ((d->a_rs % 2 == 0 && d->k % 2 == 0) ? 2 : 1);
+  const int ksteps = (d->k + 15) / 16;
+#define PV_ROWS16(KS)                                                                                                        \
+    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
+    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
+    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
+  if (ksteps <= 3) { PV_ROWS16(3); } else { PV_ROWS16(4); }
+#undef PV_ROWS16
+  return check_launch("pv_gemm_rows_bf16out_f32");
 }
 
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream) {

@@ -885,6 +885,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+def gemm_rows_bf16out_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """pv_gemm_rows_bf16out_f32's shape rule: one tall row-major A [M, K <= 64] (16-byte aligned), B [K, N]."""
+    return (a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and a.stride(1) == 1 and a.shape[1] <= 64
+            and a.shape[0] >= 2048 and a.data_ptr() % 16 == 0)
+
+
+def gemm_rows_bf16out(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C (bf16) = A @ B (+ bias) for a tall row-major A with K <= 64: f32-accurate products, ONE rounding in the store (the
+    key / value projection of a cross-attention in bf16-operand mode)."""
+    _require_device(a, b)
+    require_cuda(bias)
+    if not gemm_rows_bf16out_supported(a, b):
+        raise ValueError("gemm_rows_bf16out: a tall row-major float32 A [M >= 2048, K <= 64] is expected")
+    m, k, n = a.shape[0], a.shape[1], b.shape[1]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0)
+    check(get_lib().pv_gemm_rows_bf16out_f32(ptr(a), ptr(b), ptr(bias), ptr(out), ctypes.byref(d), current_stream_ptr()),
+          "pv_gemm_rows_bf16out_f32")
+    return out
+
+
 # split-K sizing: enough workgroups to fill the chip, but a K chunk long enough to amortise a workgroup's fixed costs
 SPLITK_TARGET_WORKGROUPS = 1024
 SPLITK_MIN_CHUNK = 256
@@ -1054,12 +1075,16 @@ def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, b
     d = attention_desc(q, kv, heads, scale)
     out = torch.empty_like(q)
     lse = torch.empty((b, heads, n_q), dtype=torch.float32, device=q.device)
-    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
+    kv16 = kv.dtype == torch.bfloat16      # K / V stored as bf16 (gemm_rows_bf16out): bf16-operand kernels only
+    if kv16 and not bf16_operands:
+        raise ValueError("attention_fwd: a bfloat16 kv needs bf16_operands=True")
+    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * kv.element_size())
     if bf16_operands:
         n_ws = get_lib().pv_attention_fwd_workspace_floats(ctypes.byref(d))
         ws = _workspace("attention_fwd", n_ws * 4, q.device) if n_ws else None
-        check(get_lib().pv_attention_fwd_bf16(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), ptr(ws),
-                                              current_stream_ptr()), "pv_attention_fwd_bf16")
+        fn = get_lib().pv_attention_fwd_bf16kv if kv16 else get_lib().pv_attention_fwd_bf16
+        check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), ptr(ws), current_stream_ptr()),
+              "pv_attention_fwd_bf16kv" if kv16 else "pv_attention_fwd_bf16")
     else:
         check(get_lib().pv_attention_fwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(lse), ctypes.byref(d), current_stream_ptr()),
               "pv_attention_fwd_f32")
@@ -1073,20 +1098,26 @@ def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands
     b, n_q, inner = q.shape
     d = attention_desc(q, kv, heads, scale)
     dq = torch.empty_like(q)
+    kv16 = kv.dtype == torch.bfloat16
+    if kv16 and not bf16_operands:
+        raise ValueError("attention_bwd: a bfloat16 kv needs bf16_operands=True")
     if accumulate_dkv_into is not None:
-        if not bf16_operands or accumulate_dkv_into.shape != kv.shape or not accumulate_dkv_into.is_contiguous():
-            raise ValueError("attention_bwd: accumulate_dkv_into needs the bf16-operand kernels and a contiguous tensor like kv")
+        if (not bf16_operands or accumulate_dkv_into.shape != kv.shape or not accumulate_dkv_into.is_contiguous()
+                or accumulate_dkv_into.dtype != torch.float32):
+            raise ValueError("attention_bwd: accumulate_dkv_into needs the bf16-operand kernels and a contiguous float32 tensor "
+                             "shaped like kv")
         dkv = accumulate_dkv_into
     else:
-        dkv = torch.empty_like(kv)
+        dkv = torch.empty(kv.shape, dtype=torch.float32, device=kv.device)
     n_ws = get_lib().pv_attention_bwd_workspace_floats(ctypes.byref(d))
     delta = _workspace("attention_bwd", n_ws * 4, q.device)
-    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * 4)
+    v_ptr = ctypes.c_void_p(kv.data_ptr() + inner * kv.element_size())
     dv_ptr = ctypes.c_void_p(dkv.data_ptr() + inner * 4)
     if bf16_operands:
-        check(get_lib().pv_attention_bwd_bf16(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
-                                              dv_ptr, ctypes.byref(d), int(accumulate_dkv_into is not None), current_stream_ptr()),
-              "pv_attention_bwd_bf16")
+        fn = get_lib().pv_attention_bwd_bf16kv if kv16 else get_lib().pv_attention_bwd_bf16
+        check(fn(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv), dv_ptr, ctypes.byref(d),
+                 int(accumulate_dkv_into is not None), current_stream_ptr()),
+              "pv_attention_bwd_bf16kv" if kv16 else "pv_attention_bwd_bf16")
     else:
         check(get_lib().pv_attention_bwd_f32(ptr(q), ptr(kv), v_ptr, ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
                                              dv_ptr, ctypes.byref(d), current_stream_ptr()), "pv_attention_bwd_f32")

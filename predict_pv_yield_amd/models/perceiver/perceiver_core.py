@@ -63,6 +63,9 @@ class Attention(nn.Module):
 FUSE_RESIDUALS = True   # `fn(norm(x)) + x`: by-pass added in fn's last GEMM epilogue / the LayerNorm backward store (False: torch adds)
 
 
+KV_STORED_AS_BF16 = True      # tools/ab-style switch: False = f32 K / V in memory, rounded inside the attention kernels
+
+
 def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False, residual=None) -> torch.Tensor:
     """Attention.forward given the normalised query input and the (already projected) keys/values [b, j, 2*inner];
     `residual` (the block's `+ x`) is added in the epilogue of to_out."""
@@ -152,7 +155,10 @@ class Perceiver(nn.Module):
             if id(cross_attn) not in kv_of:
                 ctx = PF.layer_norm(data, cross_attn.norm_context.weight, cross_attn.norm_context.bias,
                                     cross_attn.norm_context.eps)
-                kv_of[id(cross_attn)] = PF.mark_shared(PF.linear(ctx, cross_attn.fn.to_kv.weight))   # consumed by every tied layer
+                # consumed by every tied layer.  bf16-operand mode: K / V are STORED as bf16 (the values the attention kernels
+                # round to anyway): the projection's store and the attention's reads are both bound by these bytes
+                project = PF.linear_kv16 if (self.operand_dtype == "bf16" and KV_STORED_AS_BF16) else PF.linear
+                kv_of[id(cross_attn)] = PF.mark_shared(project(ctx, cross_attn.fn.to_kv.weight))
             # every `fn(norm(x)) + x`: the by-pass is added in the epilogue of fn's last Linear (forward) and in the LayerNorm
             # backward kernel's store (backward) -- no elementwise launches
             bf = self.operand_dtype == "bf16"

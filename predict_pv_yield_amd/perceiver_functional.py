@@ -128,6 +128,42 @@ def linear(x, weight, bias=None, residual=None):
     return LinearRowsF32.apply(x, weight, bias, residual)
 
 
+class LinearRowsKV16(torch.autograd.Function):
+    """The key / value projection of a cross-attention in bf16-operand mode: the product is written as bf16 (what the attention
+    kernels would round K and V to anyway), half the bytes of both the HBM-bound projection store and the HBM-bound attention
+    reads.  Autograd sees an f32 tensor of the projection's shape -- a zero-stride placeholder that owns no memory and holds
+    NaN -- because the gradient that comes back for it IS f32 (dK / dV of the attention backward); the values travel beside it
+    as `._pv_bf16` (set by linear_kv16) and only AttentionCoreF32's fused bf16 kernels take them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        kv16 = K.gemm_rows_bf16out(x2, weight.t(), bias=bias).view(x.shape[:-1] + (weight.shape[0],))
+        ctx.save_for_backward(x2, weight, bias)
+        ctx.has_bias, ctx.x_shape = bias is not None, x.shape
+        ctx.mark_non_differentiable(kv16)
+        ctx.set_materialize_grads(False)      # (else every backward fills a zero bf16 "gradient" of kv16's size: 85 us)
+        placeholder = torch.full((), float("nan"), dtype=torch.float32, device=x.device).expand(kv16.shape)
+        return placeholder, kv16
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        return LinearRowsF32.backward(ctx, dy)[:3]
+
+
+def linear_kv16(x, weight, bias=None):
+    """linear() whose values are stored as bf16 (see LinearRowsKV16); falls back to linear() where the kernel's shape rule
+    (a tall input with <= 64 features) does not hold."""
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else None
+    if x2 is None or not K.gemm_rows_bf16out_supported(x2, weight.t()) or weight.shape[0] % 8:
+        return linear(x, weight, bias)
+    _note_use(weight)
+    _note_use(bias)
+    y, kv16 = LinearRowsKV16.apply(x, weight, bias)
+    y._pv_bf16 = kv16
+    return y
+
+
 class MatmulF32(torch.autograd.Function):
     """C = A @ B for strided batched views; dA = dC @ B^T, dB = A^T @ dC (same kernel, transposed views)."""
 
@@ -165,7 +201,16 @@ class AttentionCoreF32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, kv, heads, scale, bf16_operands=False):
-        q, kv = q.contiguous(), kv.contiguous()
+        kv16 = getattr(kv, "_pv_bf16", None)      # the projection stored its values as bf16 (linear_kv16): kv is a placeholder
+        if kv16 is not None and not (bf16_operands and q.shape[-1] // heads == 64 and q.shape[1] <= 128):
+            raise NotImplementedError("a bf16-stored kv is for the fused bf16-operand kernels (head_dim 64, <= 128 queries)")
+        q = q.contiguous()
+        if kv16 is not None:
+            if getattr(kv, "_pv_shared", False):
+                kv16._pv_shared = True      # (the gradient of a context shared by weight-tied layers collects in one tensor)
+            kv = kv16
+        else:
+            kv = kv.contiguous()
         inner = q.shape[-1]
         ctx.heads, ctx.scale = heads, scale
         ctx.fused = inner // heads == 64 and q.shape[1] <= 128

@@ -63,6 +63,56 @@ def test_bf16_attention_forward_and_backward(b, h, nq, nk, device):
     assert _rel(out32.cpu(), ref32.detach()) <= 1e-5 and not torch.equal(out32, out)
 
 
+@pytest.mark.parametrize("b,h,nq,nk", [(2, 1, 128, 16384), (2, 2, 40, 72), (1, 1, 100, 2104)])
+def test_attention_with_keys_and_values_stored_as_bf16(b, h, nq, nk, device):
+    """pv_attention_*_bf16kv read K / V that are bf16 in memory: the same values the f32-K/V kernels round to on the way into
+    LDS, so output, log-sum-exp, dq and dkv are identical bits; and pv_gemm_rows_bf16out_f32 (the projection that writes them)
+    equals the f32 product rounded to nearest even."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(nk + nq)
+    q = torch.randn(b, nq, h * 64, generator=g).to(device)
+    kv = torch.randn(b, nk, 2 * h * 64, generator=g).to(device)
+    dout = torch.randn(b, nq, h * 64, generator=g).to(device)
+    kv16 = kv.to(torch.bfloat16)
+    out, lse = K.attention_fwd(q, kv, h, 0.125, bf16_operands=True)
+    out16, lse16 = K.attention_fwd(q, kv16, h, 0.125, bf16_operands=True)
+    assert torch.equal(out, out16) and torch.equal(lse, lse16)
+    dq, dkv = K.attention_bwd(q, kv, out, dout, lse, h, 0.125, bf16_operands=True)
+    dq16, dkv16 = K.attention_bwd(q, kv16, out16, dout, lse16, h, 0.125, bf16_operands=True)
+    assert dkv16.dtype == torch.float32 and torch.equal(dq, dq16) and torch.equal(dkv, dkv16)
+    acc = torch.ones_like(dkv)
+    K.attention_bwd(q, kv16, out16, dout, lse16, h, 0.125, bf16_operands=True, accumulate_dkv_into=acc)
+    torch.testing.assert_close(acc, dkv + 1.0, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="bf16_operands"):
+        K.attention_fwd(q, kv16, h, 0.125)
+    x = torch.randn(b * nk, 38, generator=g).to(device)
+    w = (torch.randn(2 * h * 64, 38, generator=g) * 0.2).to(device)
+    if x.shape[0] >= 2048:
+        assert torch.equal(K.gemm_rows_bf16out(x, w.t()), K.gemm(x, w.t()).to(torch.bfloat16))
+
+
+def test_exp003_is_the_same_model_with_keys_and_values_stored_as_bf16(device):
+    """operand_dtype="bf16": storing the projected context as bf16 (perceiver_core.KV_STORED_AS_BF16, the default) changes where
+    K / V are rounded, not to what: output, loss and every gradient equal those of the f32-stored form bit for bit."""
+    from predict_pv_yield_amd.models.perceiver import perceiver_core
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    batch = make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(5))
+    results = []
+    for stored in (True, False):
+        perceiver_core.KV_STORED_AS_BF16 = stored
+        try:
+            _, model = _pair(device, "bf16", seed=1)
+            y = model(_to(batch, device))
+            loss = model.training_step(_to(batch, device), 0)
+            loss.backward()
+            results.append([y.detach(), loss.detach()] + [p.grad.clone() for p in model.parameters() if p.grad is not None])
+        finally:
+            perceiver_core.KV_STORED_AS_BF16 = True
+    assert len(results[0]) == len(results[1]) > 10
+    for a, b_ in zip(*results):
+        assert torch.equal(a, b_)
+
+
 def _pair(device, operand_dtype, seed=0):
     from predict_pv_yield_amd.models.perceiver.exp003 import LitModel
     torch.manual_seed(seed)
