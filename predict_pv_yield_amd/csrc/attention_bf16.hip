@@ -132,27 +132,35 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
     for (int ks = 0; ks < 4; ++ks)
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Ks + col * B_KLD + 16 * ks + 8 * half),
                                                   qreg[ks], s, 0, 0, 0);
-    float m_tile = -INFINITY;
+    // Online softmax with a LAZY reference: p = exp2(scale log2e s - m_run) where m_run is only moved (and the accumulators
+    // rescaled) when a tile's maximum exceeds it by more than 2^LAZY -- p then stays below 2^LAZY, which a bf16 operand and the
+    // f32 sums hold without loss, and the 33 multiplications + one exponential of a rescale leave almost every tile (the
+    // exact-maximum form rescaled in ~2/3 of the tiles of a 3 000-key range).  One fused multiply-add and one v_exp_f32 per
+    // score; keys beyond the range are masked in the (single) ragged tile only.
+    constexpr float LAZY = 8.f;
+    if (j0 + BTJ > key_hi) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = j0 + att_acc_row(r, half) < key_hi;
-      s[r] = ok ? s[r] * scale_log2e : -INFINITY;        // scores in log2 units: every exponential below is one v_exp_f32
-      m_tile = fmaxf(m_tile, s[r]);
+      for (int r = 0; r < 16; ++r) s[r] = j0 + att_acc_row(r, half) < key_hi ? s[r] : -INFINITY;
     }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // first tile: exp2(-inf) = 0 on zero accumulators
+    float m_tile = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+    m_tile = fmaxf(m_tile, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64)) * scale_log2e;      // (scale > 0)
+    if (__builtin_amdgcn_ballot_w64(m_tile > m_run + LAZY) != 0) {      // wave-uniform: some query of this wave needs a new reference
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // first tile: exp2(-inf) = 0 on zero accumulators
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[r] *= alpha, acc1[r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], scale_log2e, -m_run));
       psum += s[r];
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] *= alpha, acc1[r] *= alpha;
+    l_run += psum;
     // O^T += V^T P^T: contraction slot 8 half + t of step st is key att_acc_row(8 st + t, half): P comes straight from
     // the S accumulator, V^T from the permuted transposed tile
 #pragma unroll
