@@ -56,6 +56,9 @@ __device__ __forceinline__ bf16x8 att_load8(const float* p, bool ok) {   // 8 co
 // KV = float: K / V f32 in memory, rounded to bf16 on the way into LDS; KV = uint16_t: K / V already bf16 in memory (the
 // projection that produced them wrote bf16: half the bytes of this HBM-bound kernel -- 128 queries make 64 flop per byte of
 // f32 K / V) -- same values, same results
+#ifdef PV_DIAG_STAMPS
+__device__ unsigned long long attn_fwd_diag[PV_DIAG_WAVES * PV_DIAG_SLOTS];
+#endif
 template <typename KV>
 __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q, const KV* __restrict__ k,
                                                       const KV* __restrict__ v, float* __restrict__ o,
@@ -108,11 +111,21 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
     k0 = *reinterpret_cast<const f32x4*>(kp);
     v0 = *reinterpret_cast<const f32x4*>(vp);
     if constexpr (!KV16) { k1 = *reinterpret_cast<const f32x4*>(kp + 4); v1 = *reinterpret_cast<const f32x4*>(vp + 4); }
-    if (!ok) { k0 = k1 = v0 = v1 = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // (rows beyond the range read row 0 instead of being zeroed: their scores are masked to -inf below, so their p is 0 and
+    // any finite K / V will do.  The select that zeroed them made the bf16-stored form WAIT for the load right here, in the
+    // middle of the tile it was meant to run under: 2 800 of its 4 500 cycles per tile, found with stamps)
   };
   load_tile(key_lo);
+#ifdef PV_DIAG_STAMPS
+  unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, t0, t1;
+#define ATT_PHASE(slot) do { PV_STAMP(t1); dg[slot] += t1 - t0; t0 = t1; } while (0)
+  PV_STAMP(t0);
+#else
+#define ATT_PHASE(slot) do { } while (0)
+#endif
   for (int j0 = key_lo; j0 < key_hi; j0 += BTJ) {
     __syncthreads();
+    ATT_PHASE(0);
     if constexpr (KV16) {
       *reinterpret_cast<f32x4*>(Ks + st_row * B_KLD + st_col) = k0;
       *reinterpret_cast<f32x4*>(Vs + st_row * B_KLD + st_col) = v0;
@@ -122,7 +135,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       const float vx[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       *reinterpret_cast<bf16x8*>(Vs + st_row * B_KLD + st_col) = att_pack8(vx);
     }
+    ATT_PHASE(1);      // (includes the wait for this tile's K / V to arrive from memory)
     __syncthreads();
+    ATT_PHASE(2);
     if (j0 + BTJ < key_hi) load_tile(j0 + BTJ);
     // S^T tile: rows = keys, column = this lane's query
     v16f_b s;
@@ -142,6 +157,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = j0 + att_acc_row(r, half) < key_hi ? s[r] : -INFINITY;
     }
+    ATT_PHASE(3);
     float m_tile = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
     m_tile = fmaxf(m_tile, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64)) * scale_log2e;      // (scale > 0)
@@ -161,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
     }
     psum += __shfl_xor(psum, 32, 64);
     l_run += psum;
+    ATT_PHASE(4);
     // O^T += V^T P^T: contraction slot 8 half + t of step st is key att_acc_row(8 st + t, half): P comes straight from
     // the S accumulator, V^T from the permuted transposed tile
 #pragma unroll
@@ -173,7 +190,19 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16(const float* __restrict__ q
       acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Vs, B_KLD, k_lo, k_lo + 8, 0), pb, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Vs, B_KLD, k_lo, k_lo + 8, 32), pb, acc1, 0, 0, 0);
     }
+    ATT_PHASE(5);
+#ifdef PV_DIAG_STAMPS
+    dg[7] += 1;
+#endif
   }
+#undef ATT_PHASE
+#ifdef PV_DIAG_STAMPS
+  {
+    const int wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+    if (lane == 0 && wid < PV_DIAG_WAVES)
+      for (int ii = 0; ii < PV_DIAG_SLOTS; ++ii) attn_fwd_diag[(size_t)wid * PV_DIAG_SLOTS + ii] = dg[ii];
+  }
+#endif
   if (n_splits > 1) {
     if (i < g.n_q) {
       float* pb = part + ((((long long)split * gridDim.z + b) * g.heads + h) * g.n_q + i) * (BD + 2);
@@ -267,6 +296,9 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
   const KV* kb = k + b * g.k_bs + h * BD;
   const KV* vb = v + b * g.k_bs + h * BD;
   constexpr bool KV16 = sizeof(KV) == 2;
+  // the next tile's K / V in registers while the current one is processed: with bf16 in memory they take the 32 registers the
+  // f32 form needs for the tile in hand (which has none to spare: 256 + 80 registers, one wave per SIMD)
+  constexpr bool PREFETCH = KV16 || ATT_BWD_PREFETCH;
   const int n_tiles = (g.n_k + BTJ - 1) / BTJ;
   const int n_qt = (g.n_q + 31) / 32;
   const float scale_log2e = g.scale * 1.44269504088896340736f;
@@ -286,10 +318,11 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       kn[ks][0] = *reinterpret_cast<const f32x4*>(kp + 16 * ks);
       vn[ks][0] = *reinterpret_cast<const f32x4*>(vp + 16 * ks);
       if constexpr (!KV16) { kn[ks][1] = *reinterpret_cast<const f32x4*>(kp + 16 * ks + 4); vn[ks][1] = *reinterpret_cast<const f32x4*>(vp + 16 * ks + 4); }
-      if (!ok) kn[ks][0] = kn[ks][1] = vn[ks][0] = vn[ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (keys beyond the range read key 0: their P and dS are zeroed below (j_ok), so any finite K / V will do -- a select on
+      // the loaded values makes the wave wait for them at once)
     }
   };
-  if (ATT_BWD_PREFETCH) load_kv(tile0 + wave);   // in flight while Q / dO are staged
+  if (PREFETCH) load_kv(tile0 + wave);   // in flight while Q / dO are staged
   // ---- stage Q, dO (zero rows beyond n_q), lse (+inf beyond n_q so that P = 0 there), delta ---------------------------
   for (int idx = tid; idx < 128 * 8; idx += 256) {
     const int i = idx >> 3, c8 = (idx & 7) * 8;
@@ -319,7 +352,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqa[it][t][r] = 0.f;
   for (int tile = tile0 + wave; tile < tile1; tile += 4) {
-    if (!ATT_BWD_PREFETCH) load_kv(tile);
+    if (!PREFETCH) load_kv(tile);
     const int j0 = tile * BTJ;
     const int j = j0 + col;                       // this lane's key (B-operand column)
     const bool j_ok = j < g.n_k;
@@ -337,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
       }
       *reinterpret_cast<bf16x8*>(Kr + col * B_KLD + 16 * ks + 8 * half) = kreg[ks];   // row-major; read transposed for dQ
     }
-    if (ATT_BWD_PREFETCH) load_kv(tile + 4);
+    if (PREFETCH) load_kv(tile + 4);
     v16f_b dv0, dv1, dk0, dk1;   // dV^T / dK^T of this key tile: rows d, column = key
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv0[r] = 0.f, dv1[r] = 0.f, dk0[r] = 0.f, dk1[r] = 0.f;
@@ -485,7 +518,7 @@ static int attn_geom_b(const pv_attention_desc* d, AttnGeomB* g, const char* who
 static int attn_fwd_splits(const pv_attention_desc* d, int* keys_per_split) {
   const long long groups = (long long)d->batch * d->heads * ((d->n_q + 127) / 128);
   const int n_tiles = (d->n_k + BTJ - 1) / BTJ;
-  int splits = (int)((768 + groups - 1) / groups);       // aim at three workgroups per CU
+  int splits = (int)((768 + groups - 1) / groups);       // aim at three workgroups per CU (more: slower, measured in round 4)
   if (splits > n_tiles / 16) splits = n_tiles / 16;       // at least 16 key tiles (512 keys) per workgroup
   if (splits < 1) splits = 1;
   const int per = (n_tiles + splits - 1) / splits;
@@ -587,5 +620,11 @@ int pv_attention_bwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v
                             void* stream) {
   return attention_bwd_bf16_any<uint16_t>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
 }
+
+#ifdef PV_DIAG_STAMPS
+int pv_diag_read_attn_fwd(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pv::attn_fwd_diag), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"
