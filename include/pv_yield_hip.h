@@ -428,7 +428,13 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
  * (perceiver_pytorch Attention.to_kv, models/perceiver/perceiver.py:70-80) writing the K / V the bf16-operand attention kernels
  * read (pv_attention_*_bf16kv).  f32-accurate products, one rounding in the store. */
 int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, uint16_t* c_bf16, const pv_gemm_desc* d,
-                             void* stream);
+                             int32_t flags, void* stream);
+/* pv_gemm_res_f32 with flags.  PV_GEMM_BF16_OPERANDS: both operands rounded ONCE to bf16 (nearest even), one matrix-core
+ * product, f32 accumulation -- what torch.autocast makes of nn.Linear / matmul under Lightning precision=16
+ * (experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294); default: the f32-accurate three-term form. */
+#define PV_GEMM_BF16_OPERANDS 1
+int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                   const pv_gemm_desc* d, int relu, int32_t flags, void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
 /* accumulate != 0: out += the sum -- a weight that several layers share (weight_tie_layers=True,
  * predict_pv_yield/models/perceiver/perceiver.py:70-80) collects its gradient contributions in place, in arrival order,

@@ -67,7 +67,7 @@ class GEGLU(nn.Module):
 class FeedForward(nn.Module):
     def __init__(self, dim, mult=4):
         super().__init__()
-        self.net = nn.Sequential(nn.Linear(dim, dim * mult * 2), GEGLU(), nn.Linear(dim * mult, dim))
+        self.net = nn.Sequential(_Linear(dim, dim * mult * 2), GEGLU(), _Linear(dim * mult, dim))
 
     def forward(self, x):
         return self.net(x)
@@ -86,6 +86,38 @@ class _RoundBF16(torch.autograd.Function):
 
 
 EMULATE_BF16_ATTENTION = False   # tests flip this to compare the bf16-operand HIP kernels at tighter tolerance
+EMULATE_BF16_LINEAR = False      # the same for the Perceiver's Linear layers (operand_dtype="bf16" rounds their operands too)
+
+
+class _LinearBF16Ops(torch.autograd.Function):
+    """nn.Linear whose three matrix products take bf16-rounded operands (f32 arithmetic on the rounded values = f32
+    accumulation): y = R(x) R(w)^T + b, dx = R(dy) R(w), dw = R(dy)^T R(x), db = sum dy."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(r(x), r(w), b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        g = r(dy)
+        dx = g @ r(w)
+        dw = g.reshape(-1, g.shape[-1]).t() @ r(x).reshape(-1, x.shape[-1])
+        db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+class _Linear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys) that can emulate 16-bit operands."""
+
+    def forward(self, x):
+        if EMULATE_BF16_LINEAR:
+            return _LinearBF16Ops.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 class Attention(nn.Module):
@@ -95,9 +127,9 @@ class Attention(nn.Module):
         context_dim = query_dim if context_dim is None else context_dim
         self.scale = dim_head ** -0.5
         self.heads = heads
-        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
-        self.to_kv = nn.Linear(context_dim, inner_dim * 2, bias=False)
-        self.to_out = nn.Linear(inner_dim, query_dim)
+        self.to_q = _Linear(query_dim, inner_dim, bias=False)
+        self.to_kv = _Linear(context_dim, inner_dim * 2, bias=False)
+        self.to_out = _Linear(inner_dim, query_dim)
 
     def forward(self, x, context=None):
         h = self.heads
@@ -147,7 +179,7 @@ class OraclePerceiver(nn.Module):
             self_attns = nn.ModuleList([nn.ModuleList([get("latent_attn", c), get("latent_ff", c)])
                                         for _ in range(self_per_cross_attn)])
             self.layers.append(nn.ModuleList([get("cross_attn", c), get("cross_ff", c), self_attns]))
-        self.to_logits = nn.Sequential(nn.Identity(), nn.LayerNorm(latent_dim), nn.Linear(latent_dim, num_classes))
+        self.to_logits = nn.Sequential(nn.Identity(), nn.LayerNorm(latent_dim), _Linear(latent_dim, num_classes))
 
     def forward(self, data):
         b, *axis, _ = data.shape

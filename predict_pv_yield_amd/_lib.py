@@ -147,7 +147,8 @@ SIGNATURES = {
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
     "pv_gemm_res_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
-    "pv_gemm_rows_bf16out_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_vp],
+    "pv_gemm_rows_bf16out_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_i32, c_vp],
+    "pv_gemm_ex_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(GemmDesc), c_int, c_i32, c_vp],
     "pv_sum_slabs_f32": [c_vp, c_vp, c_i64, c_i32, c_vp],
     "pv_sum_slabs_acc_f32": [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp],
     "pv_colsum_f32": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp],

@@ -149,7 +149,11 @@ __device__ __forceinline__ void x3_split_pair(float x0, float x1, uint32_t& h, u
   l = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
 }
 
-template <bool A_KC, bool B_KC>
+// TERMS = 3: the f32-accurate form above.  TERMS = 1: every operand rounded ONCE to bf16 (nearest even), one product, f32
+// accumulation -- torch.autocast's linear / matmul (the reference trains its Perceiver under Lightning precision=16:
+// experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294); a sixth of the matrix work, a third of the LDS
+// traffic
+template <bool A_KC, bool B_KC, int TERMS = 3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   __shared__ __attribute__((aligned(16))) unsigned char As[3 * X3_A_PLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * X3_B_PLANE];
@@ -260,28 +264,42 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
     __syncthreads();  // previous panel fully consumed
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint32_t h0, m0_, l0, h1, m1_, l1;
-      x3_split_pair(ar[i][0], ar[i][1], h0, m0_, l0);
-      x3_split_pair(ar[i][2], ar[i][3], h1, m1_, l1);
-      const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
-      *reinterpret_cast<u32x2*>(As + a_w[i]) = h;
-      *reinterpret_cast<u32x2*>(As + X3_A_PLANE + a_w[i]) = m;
-      *reinterpret_cast<u32x2*>(As + 2 * X3_A_PLANE + a_w[i]) = l;
+      if constexpr (TERMS == 1) {
+        *reinterpret_cast<u32x2*>(As + a_w[i]) = (u32x2){pack_bf16_pair(ar[i][0], ar[i][1]), pack_bf16_pair(ar[i][2], ar[i][3])};
+      } else {
+        uint32_t h0, m0_, l0, h1, m1_, l1;
+        x3_split_pair(ar[i][0], ar[i][1], h0, m0_, l0);
+        x3_split_pair(ar[i][2], ar[i][3], h1, m1_, l1);
+        const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
+        *reinterpret_cast<u32x2*>(As + a_w[i]) = h;
+        *reinterpret_cast<u32x2*>(As + X3_A_PLANE + a_w[i]) = m;
+        *reinterpret_cast<u32x2*>(As + 2 * X3_A_PLANE + a_w[i]) = l;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      uint32_t h0, m0_, l0, h1, m1_, l1;
-      x3_split_pair(br[i][0], br[i][1], h0, m0_, l0);
-      x3_split_pair(br[i][2], br[i][3], h1, m1_, l1);
-      const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
-      *reinterpret_cast<u32x2*>(Bs + b_w[i]) = h;
-      *reinterpret_cast<u32x2*>(Bs + X3_B_PLANE + b_w[i]) = m;
-      *reinterpret_cast<u32x2*>(Bs + 2 * X3_B_PLANE + b_w[i]) = l;
+      if constexpr (TERMS == 1) {
+        *reinterpret_cast<u32x2*>(Bs + b_w[i]) = (u32x2){pack_bf16_pair(br[i][0], br[i][1]), pack_bf16_pair(br[i][2], br[i][3])};
+      } else {
+        uint32_t h0, m0_, l0, h1, m1_, l1;
+        x3_split_pair(br[i][0], br[i][1], h0, m0_, l0);
+        x3_split_pair(br[i][2], br[i][3], h1, m1_, l1);
+        const u32x2 h = {h0, h1}, m = {m0_, m1_}, l = {l0, l1};
+        *reinterpret_cast<u32x2*>(Bs + b_w[i]) = h;
+        *reinterpret_cast<u32x2*>(Bs + X3_B_PLANE + b_w[i]) = m;
+        *reinterpret_cast<u32x2*>(Bs + 2 * X3_B_PLANE + b_w[i]) = l;
+      }
     }
     __syncthreads();
     if (k0 + X3_BK < kend) load(k0 + X3_BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (TERMS == 1) {
+        const bf16x8 a1 = fetch(As, a_rd, A_KC, ks, X3_A_MC_RS);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, fetch(Bs, b_rd[0], B_KC, ks, X3_B_MC_RS), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, fetch(Bs, b_rd[1], B_KC, ks, X3_B_MC_RS), acc1, 0, 0, 0);
+        continue;
+      }
       bf16x8 a3[3], b3[2][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 // OUT_BF16: C is a bf16 matrix (round to nearest even in the store): the key / value projection of a cross-attention whose
 // bf16-operand kernels would round those values anyway -- the 1.3 GB of f32 K / V of experiments/003's context (2.5 M rows x 128)
 // is what bounds both this kernel's store and the attention kernels' reads
-template <int KSTEPS, int VEC, bool OUT_BF16 = false>
+template <int KSTEPS, int VEC, bool OUT_BF16 = false, int TERMS = 3>      // TERMS as in gemm_bf16x3_kernel
 __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks) {
   constexpr int KP = 16 * KSTEPS;
   constexpr int BRS = 2 * KP + 16;                       // bytes per n-row of a B plane (16 rows x 16 B cover the 64 banks)
@@ -390,6 +408,15 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
+      if constexpr (TERMS == 1) {
+        u32x4 w1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w1[j] = pack_bf16_pair(ar[ks][2 * j], ar[ks][2 * j + 1]);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(Bs + b_rd0 + 32 * ks), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(Bs + b_rd1 + 32 * ks), acc1, 0, 0, 0);
+        continue;
+      }
       u32x4 hw, mw, lw;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -458,6 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
       uint32_t h0, m0_, l0, h1, m1_, l1;
       x3_split_pair(x[0], x[1], h0, m0_, l0);
       x3_split_pair(x[2], x[3], h1, m1_, l1);
+      if constexpr (TERMS == 1) h0 = pack_bf16_pair(x[0], x[1]), h1 = pack_bf16_pair(x[2], x[3]);      // (plane 0 rounded, not truncated)
       const int off = n * BRS + q * 8;
       *reinterpret_cast<u32x2*>(Bs + off) = u32x2{h0, h1};
       *reinterpret_cast<u32x2*>(Bs + BPLANE + off) = u32x2{m0_, m1_};
@@ -471,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
       const float x1 = (nn < g.n && k + 1 < g.k) ? B[(long long)(k + 1) * g.b_rs + (long long)nn * g.b_cs] : 0.f;
       uint32_t h, m, l;
       x3_split_pair(x0, x1, h, m, l);
+      if constexpr (TERMS == 1) h = pack_bf16_pair(x0, x1);
       const int off = n * BRS + k * 2;
       *reinterpret_cast<uint32_t*>(Bs + off) = h;
       *reinterpret_cast<uint32_t*>(Bs + BPLANE + off) = m;
@@ -568,12 +597,21 @@ extern "C" {
 int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
                     const pv_gemm_desc* d, int relu, void* stream);
 
+int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                   const pv_gemm_desc* d, int relu, int32_t flags, void* stream);
+
 int pv_gemm_f32(const float* a, const float* b, const float* bias, float* c, const pv_gemm_desc* d, int relu, void* stream) {
-  return pv_gemm_res_f32(a, b, bias, nullptr, 0, c, d, relu, stream);
+  return pv_gemm_ex_f32(a, b, bias, nullptr, 0, c, d, relu, 0, stream);
 }
 
 int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
                     const pv_gemm_desc* d, int relu, void* stream) {
+  return pv_gemm_ex_f32(a, b, bias, residual, ldr, c, d, relu, 0, stream);
+}
+
+int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
+                   const pv_gemm_desc* d, int relu, int32_t flags, void* stream) {
+  const bool one_term = (flags & PV_GEMM_BF16_OPERANDS) != 0;
   PV_REQUIRE(a && b && c && d, PV_EINVAL, "pv_gemm_f32: null pointer");
   PV_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, PV_EINVAL, "pv_gemm_f32: non-positive extent (%d,%d,%d)", d->m, d->n, d->k);
   PV_REQUIRE(d->batch1 > 0 && d->batch2 > 0 && d->k_splits > 0, PV_EINVAL, "pv_gemm_f32: batch counts and k_splits must be >= 1");
@@ -600,9 +638,9 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
   // f32 matrix instruction (bit-exact f32 products)
   static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;
   static const bool no_rows_form = getenv("PV_GEMM_NO_ROWS_FORM") != nullptr;
-  const bool rows_form = !exact_f32 && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 && d->m >= 2048 &&
+  const bool rows_form = (!exact_f32 || one_term) && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 && d->m >= 2048 &&
                          ((uintptr_t)a % 16 == 0);
-  if (exact_f32) {
+  if (exact_f32 && !one_term) {
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), g);
   } else if (rows_form) {
     const int n_tiles = (d->n + G_BN - 1) / G_BN;
@@ -613,25 +651,29 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
     dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
     const int vec = (d->a_rs % 4 == 0 && d->k % 4 == 0) ? 4 : ((d->a_rs % 2 == 0 && d->k % 2 == 0) ? 2 : 1);
     const int ksteps = (d->k + 15) / 16;
-#define PV_ROWS(KS)                                                                                                   \
-    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
-    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
-    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
-    if (ksteps <= 3) { PV_ROWS(3); } else { PV_ROWS(4); }
+#define PV_ROWS(KS, T)                                                                                                           \
+    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4, false, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
+    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2, false, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
+    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1, false, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
+    if (one_term) { if (ksteps <= 3) { PV_ROWS(3, 1); } else { PV_ROWS(4, 1); } }
+    else { if (ksteps <= 3) { PV_ROWS(3, 3); } else { PV_ROWS(4, 3); } }
 #undef PV_ROWS
   } else {
     const bool a_kc = d->a_cs == 1 && d->a_rs != 1;
     const bool b_kc = d->b_cs != 1;
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, as_stream(stream), g);
-    else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, as_stream(stream), g);
-    else if (b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, as_stream(stream), g);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, as_stream(stream), g);
+#define PV_TILED(T)                                                                                                          \
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, T>), grid, dim3(256), 0, as_stream(stream), g);            \
+    else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, T>), grid, dim3(256), 0, as_stream(stream), g);              \
+    else if (b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, T>), grid, dim3(256), 0, as_stream(stream), g);              \
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, T>), grid, dim3(256), 0, as_stream(stream), g)
+    if (one_term) { PV_TILED(1); } else { PV_TILED(3); }
+#undef PV_TILED
   }
   return check_launch("pv_gemm_f32");
 }
 
 int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, uint16_t* c_bf16, const pv_gemm_desc* d,
-                             void* stream) {
+                             int32_t flags, void* stream) {
   PV_REQUIRE(a && b && c_bf16 && d, PV_EINVAL, "pv_gemm_rows_bf16out_f32: null pointer");
   PV_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0 && d->ldc >= d->n, PV_EINVAL, "pv_gemm_rows_bf16out_f32: bad extents");
   PV_REQUIRE((long long)d->batch1 * d->batch2 * d->k_splits == 1 && d->a_cs == 1 && d->k <= 64 && ((uintptr_t)a % 16 == 0), PV_ESIZE,
@@ -653,11 +695,12 @@ int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, 
   dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
   const int vec = (d->a_rs % 4 == 0 && d->k % 4 == 0) ? 4 : ((d->a_rs % 2 == 0 && d->k % 2 == 0) ? 2 : 1);
   const int ksteps = (d->k + 15) / 16;
-#define PV_ROWS16(KS)                                                                                                        \
-    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
-    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
-    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
-  if (ksteps <= 3) { PV_ROWS16(3); } else { PV_ROWS16(4); }
+#define PV_ROWS16(KS, T)                                                                                                        \
+    if (vec == 4) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 4, true, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);       \
+    else if (vec == 2) hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 2, true, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb);  \
+    else hipLaunchKernelGGL((gemm_rows_x3_kernel<KS, 1, true, T>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb)
+  if (flags & PV_GEMM_BF16_OPERANDS) { if (ksteps <= 3) { PV_ROWS16(3, 1); } else { PV_ROWS16(4, 1); } }
+  else { if (ksteps <= 3) { PV_ROWS16(3, 3); } else { PV_ROWS16(4, 3); } }
 #undef PV_ROWS16
   return check_launch("pv_gemm_rows_bf16out_f32");
 }

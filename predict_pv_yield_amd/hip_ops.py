@@ -855,11 +855,16 @@ def _gemm_views(a: torch.Tensor, b: torch.Tensor):
     return a, b, batch
 
 
+GEMM_BF16_OPERANDS = 1      # PV_GEMM_BF16_OPERANDS of include/pv_yield_hip.h
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-         out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, bf16_operands: bool = False) -> torch.Tensor:
     """C = A @ B (+ bias) (+ residual) for arbitrarily STRIDED views (transposes, column slices and per-head permutes are
     free: only the strides change).  `out`: optional view [..., M, N] with unit last stride to write into.
-    `residual`: a [M, N] tensor with unit last stride added in the epilogue (2-D products only)."""
+    `residual`: a [M, N] tensor with unit last stride added in the epilogue (2-D products only).
+    bf16_operands: both operands rounded once to bf16, one matrix-core product, f32 accumulation (torch.autocast's linear);
+    default: the f32-accurate three-term form."""
     _require_device(a, b, out, residual)
     require_cuda(bias)
     lead = tuple(a.shape[:-2])
@@ -877,11 +882,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if residual is not None:
         if batch != (1, 1) or tuple(residual.shape) != (m, n) or residual.stride(-1) != 1 or residual.dtype != torch.float32:
             raise ValueError("gemm: residual must be a float32 [M, N] tensor with unit last stride (2-D products only)")
-        check(get_lib().pv_gemm_res_f32(ptr(a4), ptr(b4), ptr(bias), ptr(residual), residual.stride(0), ptr(c4),
-                                        ctypes.byref(d), int(relu), current_stream_ptr()), "pv_gemm_res_f32")
-        return out
-    check(get_lib().pv_gemm_f32(ptr(a4), ptr(b4), ptr(bias), ptr(c4), ctypes.byref(d), int(relu), current_stream_ptr()),
-          "pv_gemm_f32")
+    check(get_lib().pv_gemm_ex_f32(ptr(a4), ptr(b4), ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0,
+                                   ptr(c4), ctypes.byref(d), int(relu), GEMM_BF16_OPERANDS if bf16_operands else 0,
+                                   current_stream_ptr()), "pv_gemm_ex_f32")
     return out
 
 
@@ -891,7 +894,7 @@ def gemm_rows_bf16out_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
             and a.shape[0] >= 2048 and a.data_ptr() % 16 == 0)
 
 
-def gemm_rows_bf16out(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_rows_bf16out(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, bf16_operands: bool = False) -> torch.Tensor:
     """C (bf16) = A @ B (+ bias) for a tall row-major A with K <= 64: f32-accurate products, ONE rounding in the store (the
     key / value projection of a cross-attention in bf16-operand mode)."""
     _require_device(a, b)
@@ -901,7 +904,8 @@ def gemm_rows_bf16out(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Ten
     m, k, n = a.shape[0], a.shape[1], b.shape[1]
     out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
     d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0)
-    check(get_lib().pv_gemm_rows_bf16out_f32(ptr(a), ptr(b), ptr(bias), ptr(out), ctypes.byref(d), current_stream_ptr()),
+    check(get_lib().pv_gemm_rows_bf16out_f32(ptr(a), ptr(b), ptr(bias), ptr(out), ctypes.byref(d),
+                                             GEMM_BF16_OPERANDS if bf16_operands else 0, current_stream_ptr()),
           "pv_gemm_rows_bf16out_f32")
     return out
 
@@ -911,7 +915,8 @@ SPLITK_TARGET_WORKGROUPS = 1024
 SPLITK_MIN_CHUNK = 256
 
 
-def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torch.Tensor] = None,
+                bf16_operands: bool = False) -> torch.Tensor:
     """C[M, N] = A[M, K] @ B[K, N] for small M, N and a huge K (weight gradients): K is cut over workgroups, the partial
     products are summed in index order (deterministic).  accumulate_into: a contiguous [M, N] tensor that receives
     `+= C` (the slab sum adds into it) and is returned."""
@@ -927,7 +932,8 @@ def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torc
         return gemm(a, b)
     slabs = _workspace("gemm_splitk", splits * m * n * 4, a.device)
     d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, splits, m * n)
-    check(get_lib().pv_gemm_f32(ptr(a), ptr(b), None, ptr(slabs), ctypes.byref(d), 0, current_stream_ptr()), "pv_gemm_f32")
+    check(get_lib().pv_gemm_ex_f32(ptr(a), ptr(b), None, None, 0, ptr(slabs), ctypes.byref(d), 0,
+                                   GEMM_BF16_OPERANDS if bf16_operands else 0, current_stream_ptr()), "pv_gemm_ex_f32")
     out = accumulate_into if accumulate_into is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
     check(get_lib().pv_sum_slabs_acc_f32(ptr(slabs), ptr(out), m * n, splits, int(accumulate_into is not None),
                                          current_stream_ptr()), "pv_sum_slabs_acc_f32")

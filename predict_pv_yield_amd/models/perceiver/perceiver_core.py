@@ -64,6 +64,7 @@ FUSE_RESIDUALS = True   # `fn(norm(x)) + x`: by-pass added in fn's last GEMM epi
 
 
 KV_STORED_AS_BF16 = True      # tools/ab-style switch: False = f32 K / V in memory, rounded inside the attention kernels
+LINEARS_FOLLOW_OPERAND_DTYPE = True      # False: the Linears keep f32-accurate products in "bf16" mode (rounds 2-3)
 
 
 def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False, residual=None) -> torch.Tensor:
@@ -95,7 +96,8 @@ class Perceiver(nn.Module):
                  operand_dtype: str = "f32"):
         super().__init__()
         # operand_dtype (new, optional): "f32" = exact-f32 matrix-core products everywhere; "bf16" = the attention products
-        # (q k^T, p v and their backward) take bf16 operands with f32 accumulation and an f32 softmax -- what Lightning's
+        # (q k^T, p v and their backward) AND the Linear layers take bf16 operands with f32 accumulation, softmax / LayerNorm
+        # stay f32 -- what Lightning's
         # precision=16 does to them in experiments/003 (:40, :290)
         if operand_dtype not in ("f32", "bf16"):
             raise ValueError("operand_dtype must be 'f32' or 'bf16'")
@@ -144,6 +146,12 @@ class Perceiver(nn.Module):
         if not data.is_cuda:
             raise RuntimeError("predict_pv_yield_amd Perceiver runs on the MI355X only: move the module and the batch to "
                                "cuda (there is no CPU fallback)")
+        # operand_dtype="bf16": every Linear of the Perceiver takes bf16 operands too (one product, f32 accumulation), as
+        # torch.autocast does under the reference's precision=16; LayerNorm, softmax, GEGLU and the residual stream stay f32
+        with PF.linear_operands(self.operand_dtype if LINEARS_FOLLOW_OPERAND_DTYPE else "f32"):
+            return self._forward(data)
+
+    def _forward(self, data):
         b, *axis, _ = data.shape
         assert len(axis) == self.input_axis, "input data must have the right number of axis"
         enc = self._position_features(axis, data.device)

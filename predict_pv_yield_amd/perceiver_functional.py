@@ -85,6 +85,30 @@ def _shared_activation_slot(t: torch.Tensor):
     return key, _SHARED_ACT.get(key)
 
 
+# Operand precision of every linear() issued while the flag is set: "bf16" = both operands rounded once to bf16, one
+# matrix-core product, f32 accumulation -- what torch.autocast makes of nn.Linear under the reference's Lightning precision=16
+# (experiments/003_...py:40,288-294); "f32" = the f32-accurate three-term products.  A layer's backward products follow the
+# precision its forward ran in.
+_LINEAR_BF16 = [False]
+
+
+class linear_operands:
+    """with linear_operands("bf16"): ... -- the Perceiver core wraps its forward in it (operand_dtype)."""
+
+    def __init__(self, dtype: str):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("linear_operands: 'f32' or 'bf16'")
+        self.bf16 = dtype == "bf16"
+
+    def __enter__(self):
+        self.prev = _LINEAR_BF16[0]
+        _LINEAR_BF16[0] = self.bf16
+
+    def __exit__(self, *exc):
+        _LINEAR_BF16[0] = self.prev
+        return False
+
+
 class LinearRowsF32(torch.autograd.Function):
     """y[..., out] = x[..., in] @ W[out, in]^T (+ bias) (+ residual): nn.Linear over an arbitrary number of rows
     (rows >> in, out); `residual` (shaped like y) rides in the GEMM epilogue and receives dy unchanged."""
@@ -93,7 +117,8 @@ class LinearRowsF32(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual=None):
         x2 = x.contiguous().view(-1, x.shape[-1])
         res2 = residual.contiguous().view(-1, weight.shape[0]) if residual is not None else None
-        y = K.gemm(x2, weight.t(), bias=bias, residual=res2)
+        ctx.bf16 = _LINEAR_BF16[0]
+        y = K.gemm(x2, weight.t(), bias=bias, residual=res2, bf16_operands=ctx.bf16)
         ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         return y.view(x.shape[:-1] + (weight.shape[0],))
@@ -103,13 +128,14 @@ class LinearRowsF32(torch.autograd.Function):
         x2, weight, bias = ctx.saved_tensors
         dy = dy.contiguous()
         dy2 = dy.view(-1, weight.shape[0])
-        dx = K.gemm(dy2, weight).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        bf = getattr(ctx, "bf16", False)
+        dx = K.gemm(dy2, weight, bf16_operands=bf).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         key, acc = _tied_slot(weight)
         if acc is not None:
-            K.gemm_splitk(dy2.t(), x2, accumulate_into=acc)                # [out, rows] @ [rows, in], += into the kept tensor
+            K.gemm_splitk(dy2.t(), x2, accumulate_into=acc, bf16_operands=bf)   # [out, rows] @ [rows, in], += into the kept tensor
             dw = None
         else:
-            dw = K.gemm_splitk(dy2.t(), x2)
+            dw = K.gemm_splitk(dy2.t(), x2, bf16_operands=bf)
             _tied_keep(key, dw)
         db = None
         if ctx.has_bias:
@@ -138,7 +164,8 @@ class LinearRowsKV16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x2 = x.contiguous().view(-1, x.shape[-1])
-        kv16 = K.gemm_rows_bf16out(x2, weight.t(), bias=bias).view(x.shape[:-1] + (weight.shape[0],))
+        ctx.bf16 = _LINEAR_BF16[0]
+        kv16 = K.gemm_rows_bf16out(x2, weight.t(), bias=bias, bf16_operands=ctx.bf16).view(x.shape[:-1] + (weight.shape[0],))
         ctx.save_for_backward(x2, weight, bias)
         ctx.has_bias, ctx.x_shape = bias is not None, x.shape
         ctx.mark_non_differentiable(kv16)

@@ -147,13 +147,13 @@ def test_exp003_at_128px_forward_loss_and_gradients(device, operand_dtype):
     from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
     oracle, model = _pair(device, operand_dtype)
     batch = make_fake_exp003_batch(2, 128, torch.Generator().manual_seed(3))
-    po.EMULATE_BF16_ATTENTION = operand_dtype == "bf16"
+    po.EMULATE_BF16_ATTENTION = po.EMULATE_BF16_LINEAR = operand_dtype == "bf16"
     try:
         y_ref = oracle(batch)
         mse_ref, nmae_ref = oracle.losses(batch)
         nmae_ref.backward()
     finally:
-        po.EMULATE_BF16_ATTENTION = False
+        po.EMULATE_BF16_ATTENTION = po.EMULATE_BF16_LINEAR = False
     y = model(_to(batch, device))
     assert y.shape == (2, 12)
     tol = 2e-4 if operand_dtype == "f32" else 3e-3

@@ -265,3 +265,29 @@ def test_gemm_rows_form_matches_f64(m, k, n, bias, relu):
             ref = ref.clamp_min(0)
         err = float((c.double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-6, (m, k, n, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,k,n", [(300, 256, 96), (4099, 38, 128), (2048, 64, 64), (257, 1000, 130)])
+def test_gemm_with_bf16_operands_is_the_product_of_the_rounded_operands(m, k, n):
+    """bf16_operands=True (PV_GEMM_BF16_OPERANDS): both operands rounded once to bf16 (nearest even), f32 accumulation -- the
+    f64 product of the ROUNDED operands to f32 accuracy, and visibly not the f32-accurate product; tiled form, rows form
+    (tall A, K <= 64), the bf16-storing rows form and the split-K weight-gradient form."""
+    K, _ = _mods()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(m + n)
+    a = torch.randn(m, k, generator=g, device=dev)
+    w = torch.randn(n, k, generator=g, device=dev)
+    bias = torch.randn(n, generator=g, device=dev)
+    r = lambda t: t.to(torch.bfloat16).double()
+    ref16 = r(a) @ r(w).t() + bias.double()
+    ref32 = a.double() @ w.double().t() + bias.double()
+    c = K.gemm(a, w.t(), bias=bias, bf16_operands=True)
+    assert float((c.double() - ref16).abs().max() / ref16.abs().max()) < 2e-6
+    assert float((c.double() - ref32).abs().max() / ref32.abs().max()) > 1e-4
+    assert float((K.gemm(a, w.t(), bias=bias).double() - ref32).abs().max() / ref32.abs().max()) < 2e-6
+    if K.gemm_rows_bf16out_supported(a, w.t()):
+        assert torch.equal(K.gemm_rows_bf16out(a, w.t(), bias=bias, bf16_operands=True), c.to(torch.bfloat16))
+    dw = K.gemm_splitk(c.t(), a, bf16_operands=True)      # [n, m] @ [m, k]
+    refw = r(c).t() @ r(a)
+    assert float((dw.double() - refw).abs().max() / refw.abs().max()) < 1e-5
