@@ -230,9 +230,10 @@ int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint1
  * the tensor's largest magnitude (max |x| < 2^e; found by a pass of the same call): three matrix-core launches
  * (pv_conv3d_bwd_weight_f16 on (l,h), (h,l), (h,h), summed in that order, un-scaled by state[2] of both tensors) give the weight
  * gradient of the f32 model (predict_pv_yield/models/conv3d/model.py:80-90 under autograd) where the three-term bf16 split
- * needs six.  state: 3 device words: [0] bits of max |x| (scratch), [1] = s, [2] = 1 / s.  Same alignment rules as above. */
-int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t batch, int32_t c,
-                                          int32_t t, int32_t h, int32_t w, void* stream);
+ * needs six.  state: 3 device words: [0] bits of max |x| (scratch), [1] = s, [2] = 1 / s.  have_max != 0: state[0] already holds
+ * the bits of max |x| (pv_relu_gate_max_f32 produced x) and the pass that finds it is skipped.  Same alignment rules as above. */
+int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t have_max, int32_t batch,
+                                          int32_t c, int32_t t, int32_t h, int32_t w, void* stream);
 int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c,
                                     int32_t t, int32_t h, int32_t w, void* stream);
 /* inverse, dropping pad channels (used by tests and for the fc head's NCDHW flatten). */
@@ -394,6 +395,8 @@ int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream)
  * input gradient so that the last conv layer's dgrad / wgrad receive an already gated gradient (their matrix-core kernels
  * stage operands global -> LDS directly and cannot gate on the way). */
 int pv_relu_gate_f32(const float* dy, const float* y, float* out, size_t n, void* stream);
+/* The same, and state[0] receives the bits of the largest |out| (the scale of pv_pack_split2_...'s split of `out`). */
+int pv_relu_gate_max_f32(const float* dy, const float* y, float* out, size_t n, float* state, void* stream);
 
 /* replaces: nn.Embedding(num_embeddings=940, embedding_dim=16)(id) and its backward
  * (predict_pv_yield/models/conv3d/model_sat_nwp.py:149-151, 251-260).  ids: device int64[n_ids]; out-of-range ids give a

@@ -105,7 +105,7 @@ SIGNATURES = {
     "pv_bf16_cpad": [c_i32],
     "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
-    "pv_pack_split2_ncdhw_f32_to_ndhwc_f16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
+    "pv_pack_split2_ncdhw_f32_to_ndhwc_f16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_unpack_ndhwc_bf16_to_ncdhw_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_repack_gate_ncdhw_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_conv3d_packed_weight_elems": [c_i32],
@@ -176,6 +176,7 @@ SIGNATURES = {
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],
     "pv_relu_gate_f32": [c_vp, c_vp, c_vp, c_sz, c_vp],
+    "pv_relu_gate_max_f32": [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp],
     "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }

@@ -912,8 +912,8 @@ int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint1
   return check_launch("pv_pack_split3_ncdhw_f32_to_ndhwc_bf16");
 }
 
-int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t batch, int32_t c,
-                                          int32_t t, int32_t h, int32_t w, void* stream) {
+int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t have_max, int32_t batch,
+                                          int32_t c, int32_t t, int32_t h, int32_t w, void* stream) {
   PV_REQUIRE(x && xp_h && xp_l && state, PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: null pointer");
   const int cpad = pv_bf16_cpad(c);
   PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: c=%d not in 1..32", c);
@@ -924,9 +924,11 @@ int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16
              PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: needs t*h*w %% 4 == 0 and 16-byte aligned buffers");
   hipStream_t st = as_stream(stream);
   uint32_t* st_bits = reinterpret_cast<uint32_t*>(state);
-  PV_REQUIRE(hipMemsetAsync(st_bits, 0, sizeof(uint32_t), st) == hipSuccess, PV_ELAUNCH, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: memset failed");
-  const long long n4 = total * c / 4;
-  hipLaunchKernelGGL(maxabs_f32_kernel, dim3(std::min<unsigned>(stream_grid((size_t)n4, 256), 2 * kNumCU)), dim3(256), 0, st, x, n4, st_bits);
+  if (!have_max) {      // (have_max: state[0] already holds the bits of max |x| -- pv_relu_gate_max_f32 left them there)
+    PV_REQUIRE(hipMemsetAsync(st_bits, 0, sizeof(uint32_t), st) == hipSuccess, PV_ELAUNCH, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: memset failed");
+    const long long n4 = total * c / 4;
+    hipLaunchKernelGGL(maxabs_f32_kernel, dim3(std::min<unsigned>(stream_grid((size_t)n4, 256), 2 * kNumCU)), dim3(256), 0, st, x, n4, st_bits);
+  }
   const unsigned g4 = stream_grid((size_t)(total / 4), 256);
   if (cpad == 16)
     hipLaunchKernelGGL(pack_split2_ncdhw_to_ndhwc_f16_kernel<16>, dim3(g4), dim3(256), 0, st, x, xp_h, xp_l, c, vps, total / 4, st_bits);

@@ -100,15 +100,32 @@ __global__ __launch_bounds__(256) void linear_fwd_tile_f32(const float* __restri
 
 // out = dy where y > 0, else 0: the backward of F.relu (model.py:117-120) as its own pass, for consumers whose kernel cannot
 // gate while it stages (the f32 matrix-core dgrad reads its operand global -> LDS directly)
+// maxbits (may be NULL): receives, by atomicMax, the bits of the largest |out| -- the scale the two-term half-float split of
+// the gated gradient needs (pv_pack_split2_..., have_max): this pass streams the values anyway, a pass of its own costs 62 us
 __global__ __launch_bounds__(256) void relu_gate_f32_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             float* __restrict__ out, size_t n4) {
+                                                             float* __restrict__ out, size_t n4, uint32_t* __restrict__ maxbits) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  uint32_t m = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const f32x4 d = reinterpret_cast<const f32x4*>(dy)[i], g = reinterpret_cast<const f32x4*>(y)[i];
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = g[e] > 0.f ? d[e] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+      o[e] = g[e] > 0.f ? d[e] : 0.f;
+      m = max(m, __builtin_bit_cast(uint32_t, o[e]) & 0x7fffffffu);
+    }
     reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+  if (maxbits) {      // one atomic per workgroup (same-address atomics serialise at ~15 ns apiece)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    __shared__ uint32_t wave_max[4];
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+      if (m) atomicMax(maxbits, m);
+    }
   }
 }
 
@@ -622,8 +639,22 @@ int pv_relu_gate_f32(const float* dy, const float* y, float* out, size_t n, void
   PV_REQUIRE(n % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)out % 16) == 0, PV_EINVAL,
              "pv_relu_gate_f32: 16-byte aligned buffers of a multiple of 4 elements");
   if (n == 0) return PV_OK;
-  hipLaunchKernelGGL(relu_gate_f32_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, as_stream(stream), dy, y, out, n / 4);
+  hipLaunchKernelGGL(relu_gate_f32_kernel, dim3(stream_grid(n / 4, 256)), dim3(256), 0, as_stream(stream), dy, y, out, n / 4,
+                     (uint32_t*)nullptr);
   return check_launch("pv_relu_gate_f32");
+}
+
+int pv_relu_gate_max_f32(const float* dy, const float* y, float* out, size_t n, float* state, void* stream) {
+  PV_REQUIRE(dy && y && out && state, PV_EINVAL, "pv_relu_gate_max_f32: null pointer");
+  PV_REQUIRE(n % 4 == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                 ((uintptr_t)state % 4) == 0, PV_EINVAL,
+             "pv_relu_gate_max_f32: 16-byte aligned buffers of a multiple of 4 elements");
+  hipStream_t st = as_stream(stream);
+  PV_REQUIRE(hipMemsetAsync(state, 0, sizeof(uint32_t), st) == hipSuccess, PV_ELAUNCH, "pv_relu_gate_max_f32: memset failed");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL(relu_gate_f32_kernel, dim3(std::min<unsigned>(stream_grid(n / 4, 256), 4 * kNumCU)), dim3(256), 0, st, dy, y, out,
+                     n / 4, reinterpret_cast<uint32_t*>(state));
+  return check_launch("pv_relu_gate_max_f32");
 }
 
 int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_stride, int64_t y_col_stride, int32_t m,

@@ -378,12 +378,24 @@ class Conv3dGeneralF32(torch.autograd.Function):
         if _wgrad_on_bf16x3(x, dy, y, weight, ctx.stride):
             # the PV-yield model's 3x3x3 layers: six launches of the bf16 weight-gradient kernel on split operands instead of
             # one at the f32 matrix rate (0.9-1.35 ms -> ~0.6 ms per layer at B = 32), f32-accurate (hip_ops docstring)
-            wgrad = K.conv3d_bwd_weight_f32_on_f16x2 if F32_WGRAD_SPLIT == "f16x2" else K.conv3d_bwd_weight_f32_on_bf16x3
-            dw, db = wgrad(x, dy, _triple(ctx.padding))
+            if F32_WGRAD_SPLIT == "f16x2":
+                dw, db = K.conv3d_bwd_weight_f32_on_f16x2(x, dy, _triple(ctx.padding), dy_maxabs_state=_gated_max_of(dy))
+            else:
+                dw, db = K.conv3d_bwd_weight_f32_on_bf16x3(x, dy, _triple(ctx.padding))
             return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
         dw, db = K.conv3d_general_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.stride, ctx.padding,
                                                  need_bias=ctx.has_bias)
         return dx, dw, db, None, None, None, None, None
+
+
+_GATED_MAX = {}
+_GATED_MAX_TASK = [-1]
+
+
+def _gated_max_of(t: torch.Tensor):
+    if _GATED_MAX_TASK[0] != torch._C._current_graph_task_id():
+        return None
+    return _GATED_MAX.get((t.data_ptr(), t.numel()))
 
 
 class ReluGateF32(torch.autograd.Function):
@@ -398,7 +410,15 @@ class ReluGateF32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
-        return K.relu_gate_f32(dy, y)
+        g, state = K.relu_gate_f32(dy, y, want_max=True)
+        # the gated gradient's largest magnitude, for the two-term split of the producing layer's weight gradient (keyed by the
+        # tensor's storage like _PREGATED_DX, valid inside this backward pass)
+        task = torch._C._current_graph_task_id()
+        if _GATED_MAX_TASK[0] != task:
+            _GATED_MAX.clear()
+            _GATED_MAX_TASK[0] = task
+        _GATED_MAX[(g.data_ptr(), g.numel())] = state
+        return g
 
 
 def relu_gate_f32(y):

@@ -312,17 +312,22 @@ def conv3d_bwd_weight_f32_on_bf16x3(x: torch.Tensor, dy: torch.Tensor, padding=(
     return dw, db
 
 
-def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor):
+def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor, maxabs_state: Optional[torch.Tensor] = None):
     """x f32 [B,C,T,H,W] -> (h, l, state): two half-float [B,T,H,W,CPAD] images with x s = h + l (22 significant bits) and
-    state = device f32[3] (scratch, s, 1/s), s the power of two that brings max |x| below 2^14.  T*H*W must be a multiple of 4."""
+    state = device f32[3] (scratch, s, 1/s), s the power of two that brings max |x| below 2^14.  T*H*W must be a multiple of 4.
+    maxabs_state: the state relu_gate_f32(..., want_max=True) produced together with x (its word 0 holds the bits of max |x|):
+    the pass that finds the maximum is skipped."""
     require_cuda(x)
     if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
         raise TypeError("pack_split2_ncdhw_f32_to_ndhwc_f16: a contiguous float32 [B,C,T,H,W] tensor is expected")
     b, c, t, h, w = x.shape
     planes = torch.empty((2, b, t, h, w, bf16_cpad(c)), dtype=torch.float16, device=x.device)
-    state = torch.empty(3, dtype=torch.float32, device=x.device)
-    check(get_lib().pv_pack_split2_ncdhw_f32_to_ndhwc_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(state), b, c, t, h, w,
-                                                          current_stream_ptr()), "pv_pack_split2_ncdhw_f32_to_ndhwc_f16")
+    state = maxabs_state
+    have_max = state is not None
+    if not have_max:
+        state = torch.empty(3, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_pack_split2_ncdhw_f32_to_ndhwc_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(state), int(have_max), b, c, t,
+                                                          h, w, current_stream_ptr()), "pv_pack_split2_ncdhw_f32_to_ndhwc_f16")
     return planes[0], planes[1], state
 
 
@@ -342,7 +347,7 @@ def conv3d_bwd_weight_f16(x: torch.Tensor, dy: torch.Tensor, c_in: int, c_out: i
     return dw, db
 
 
-def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0, 0, 0)):
+def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0, 0, 0), dy_maxabs_state=None):
     """Weight and bias gradient of a 3x3x3, stride-1 Conv3d with 32 output channels at f32 accuracy on the F16 matrix cores:
     x f32 [B,Ci<=32,T,H,W] and dy f32 [B,32,To,Ho,Wo] (already multiplied by the ReLU derivative) are each scaled by a power of
     two and split in two half-float terms (22 bits), the weight-gradient kernel runs on the three operand pairs whose product
@@ -350,7 +355,7 @@ def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0
     Half the matrix work and 4/5 of the split traffic of conv3d_bwd_weight_f32_on_bf16x3.  -> (dw [32,Ci,3,3,3], db [32])."""
     ci = x.shape[1]
     xh, xl, xs = pack_split2_ncdhw_f32_to_ndhwc_f16(x)
-    dh, dl, ds = pack_split2_ncdhw_f32_to_ndhwc_f16(dy)
+    dh, dl, ds = pack_split2_ncdhw_f32_to_ndhwc_f16(dy, maxabs_state=dy_maxabs_state)
     parts = torch.empty((3, 32 * ci * 27), dtype=torch.float32, device=x.device)
     dbp = torch.empty((2, 32), dtype=torch.float32, device=x.device)
     for i, (px, pd) in enumerate(((xl, dh), (xh, dl), (xh, dh))):
@@ -757,13 +762,20 @@ def conv_geom(batch, c_in, c_out, t, h, w, kernel, stride=1, padding=0) -> Conv3
     return Conv3dGeom(batch, c_in, c_out, t, h, w, *_triple(kernel), *_triple(stride), *_triple(padding))
 
 
-def relu_gate_f32(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """dy where y > 0, else 0 (the backward of F.relu, model.py:117-120), f32."""
+def relu_gate_f32(dy: torch.Tensor, y: torch.Tensor, want_max: bool = False) -> torch.Tensor:
+    """dy where y > 0, else 0 (the backward of F.relu, model.py:117-120), f32.  want_max: -> (out, state): the pass also
+    leaves the bits of the largest |out| in state[0] -- the scale pack_split2_ncdhw_f32_to_ndhwc_f16 needs, found without a pass
+    of its own (hand it over as maxabs_state)."""
     require_cuda(dy, y)
     if dy.dtype != torch.float32 or y.dtype != torch.float32 or dy.numel() != y.numel() or dy.numel() % 4:
         raise TypeError("relu_gate_f32: two float32 tensors of equal size (a multiple of 4 elements)")
     dy, y = dy.contiguous(), y.contiguous()
     out = torch.empty_like(dy)
+    if want_max:
+        state = torch.empty(3, dtype=torch.float32, device=dy.device)
+        check(get_lib().pv_relu_gate_max_f32(ptr(dy), ptr(y), ptr(out), dy.numel(), ptr(state), current_stream_ptr()),
+              "pv_relu_gate_max_f32")
+        return out, state
     check(get_lib().pv_relu_gate_f32(ptr(dy), ptr(y), ptr(out), dy.numel(), current_stream_ptr()), "pv_relu_gate_f32")
     return out
 

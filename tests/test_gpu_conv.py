@@ -342,6 +342,14 @@ def test_two_term_half_float_split_and_the_weight_gradient_built_on_it(device, m
     assert (db.cpu().double() - br.grad).abs().max().item() <= 2e-5 * br.grad.abs().max().item()
     dw3, db3 = K.conv3d_bwd_weight_f32_on_bf16x3(x, gy.to(device).contiguous())
     assert (dw - dw3).abs().max().item() <= 2e-5 * dw3.abs().max().item()
+    # the gate pass that produces a gated gradient can leave its largest magnitude for the split: same planes, same result
+    yy = torch.randn(gy.shape, generator=g).to(device)
+    gated, st = K.relu_gate_f32(gy.to(device).contiguous(), yy, want_max=True)
+    assert torch.equal(gated, K.relu_gate_f32(gy.to(device).contiguous(), yy))
+    assert st[0:1].view(torch.int32).item() == gated.abs().max().view(torch.int32).item()
+    a = K.pack_split2_ncdhw_f32_to_ndhwc_f16(gated)
+    b_ = K.pack_split2_ncdhw_f32_to_ndhwc_f16(gated, maxabs_state=st)
+    assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2][1:], b_[2][1:])
 
 
 def _mask_bits(mask, y_shape):

@@ -1,5 +1,5 @@
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03f; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04f; mkdir -p $O; cd $R
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 $R/bench.py --no-roofline --no-cpu-baseline --no-extras > $O/kt.log 2>&1
@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/flow -o p -- python3 
 cd $R
 python3 tools/step_timeline.py $O/kt > $O/step_timeline.txt
 python3 tools/pmc_traffic.py $O/fetch $O/write > $O/pmc.json
-python3 tools/diag_stamps.py flow 32 > $O/flow_fused_iteration_stamps.txt 2>&1
+python3 tools/diag_stamps.py flow 32 > $O/flow_level_kernel_stamps.txt 2>&1
 for k in wgrad wgrad16 fwd dgrad first; do python3 tools/diag_stamps.py $k 32; done > $O/conv_stamps.txt 2>&1
 python3 tools/time_conv.py > $O/time_conv.txt 2>&1
 python3 tools/time_fp32_step.py > $O/fp32_step_kernels.txt 2>&1
