@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK = 2.5e15     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12    # f32 matrix cores (xf32-free exact f32)
 HBM_PEAK = 8.0e12
-TRAFFIC_PROFILE = os.path.join("profiles", "r03", "pmc_hbm_traffic_bench_B32.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r04", "pmc_hbm_traffic_bench_B32.json")
 FLOW_TRAFFIC_PROFILE = os.path.join("profiles", "r04", "pmc_flow_traffic_B32.json")
 
 MODEL_KW = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, number_of_conv3d_layers=4,
