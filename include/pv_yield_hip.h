@@ -436,6 +436,9 @@ int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, 
  * product, f32 accumulation -- what torch.autocast makes of nn.Linear / matmul under Lightning precision=16
  * (experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294); default: the f32-accurate three-term form. */
 #define PV_GEMM_BF16_OPERANDS 1
+/* with PV_GEMM_BF16_OPERANDS: `a` points at a bf16 matrix (strides in elements) -- e.g. the dK / dV a bf16-operand attention
+ * backward stored as bf16 (pv_attention_bwd_bf16kv16): the values the product would round A to anyway, half the bytes */
+#define PV_GEMM_A_IS_BF16 2
 int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
                    const pv_gemm_desc* d, int relu, int32_t flags, void* stream);
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream);
@@ -484,7 +487,12 @@ int pv_attention_fwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v
                             float* workspace, void* stream);
 int pv_attention_bwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout, const float* lse,
                             float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
-                            void* stream);   /* accumulate_dkv != 0: dk, dv += (keys / values shared by weight-tied layers) */
+                            void* stream);
+/* ... and dK / dV stored as bf16 too (rounded to nearest even; element strides as k / v): for a consumer that rounds them to
+ * bf16 anyway -- pv_gemm_ex_f32 with PV_GEMM_BF16_OPERANDS | PV_GEMM_A_IS_BF16, the two backward products of to_kv. */
+int pv_attention_bwd_bf16kv16(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout,
+                              const float* lse, float* delta_ws, float* dq, uint16_t* dk, uint16_t* dv, const pv_attention_desc* d,
+                              void* stream);   /* accumulate_dkv != 0: dk, dv += (keys / values shared by weight-tied layers) */
 
 /* F.layer_norm over the last dimension d <= 256 (PreNorm.norm / norm_context, to_logits' LayerNorm); mean / rstd [rows]
  * are saved for the backward, which also returns dw = sum dy*xhat and db = sum dy (dx may be NULL). */

@@ -257,11 +257,14 @@ __global__ __launch_bounds__(256) void attn_fwd_combine(const float* __restrict_
 // dV^T += dO^T P, dK^T += Q^T dS).  Wave w walks the key tiles w, w+4, ... on its own (no barriers inside the loop): K and V
 // of the tile are B operands in registers, K^T a per-wave LDS tile (A operand of dQ^T += K^T dS^T), dS goes through a
 // per-wave LDS tile to be read back along the keys.
-template <typename KV>      // float or uint16_t (bf16 K / V in memory), as attn_fwd_bf16
+// KV: float or uint16_t (bf16 K / V in memory), as attn_fwd_bf16.  DKV: float, or uint16_t = dK / dV STORED as bf16 (rounded
+// to nearest even; no accumulate form): for a consumer that rounds them to bf16 anyway (the bf16-operand GEMMs of to_kv's
+// backward) -- the 1.27 GB of f32 dK / dV were two thirds of this launch's bytes
+template <typename KV, typename DKV = float>
 __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q, const KV* __restrict__ k,
                                                       const KV* __restrict__ v, const float* __restrict__ dout,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
-                                                      float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+                                                      float* __restrict__ dq, DKV* __restrict__ dk, DKV* __restrict__ dv,
                                                       AttnGeomB g, int tiles_per_split, long long dq_ss, int accumulate_dkv) {
   // LDS: Q and dO of all (<= 128) queries, row-major bf16 [query][d] (A operands of S = Q K^T and dP = dO V^T with one
   // ds_read_b128; the TRANSPOSED operands of dV^T += dO^T P and dK^T += Q^T dS come from the same images through
@@ -437,9 +440,22 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16(const float* __restrict__ q
     // dK / dV of the tile: a lane owns ONE key (accumulator column) and, per register quad, 4 consecutive d: 16-byte pieces
     // (accumulate_dkv: added to what is there -- the keys / values of weight-tied layers collect their gradient over the
     // layers in place, instead of through one 1-GB elementwise add per layer)
-    if (j_ok) {
-      float* dkp = dk + b * g.k_bs + (long long)j * g.k_rs + h * BD;
-      float* dvp = dv + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+    if constexpr (sizeof(DKV) == 2) {
+      if (j_ok) {
+        uint16_t* dkp = reinterpret_cast<uint16_t*>(dk) + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+        uint16_t* dvp = reinterpret_cast<uint16_t*>(dv) + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int d = 8 * q4 + 4 * half;
+          *reinterpret_cast<u32x2*>(dkp + d) = (u32x2){pack_bf16_pair(dk0[4 * q4], dk0[4 * q4 + 1]), pack_bf16_pair(dk0[4 * q4 + 2], dk0[4 * q4 + 3])};
+          *reinterpret_cast<u32x2*>(dkp + 32 + d) = (u32x2){pack_bf16_pair(dk1[4 * q4], dk1[4 * q4 + 1]), pack_bf16_pair(dk1[4 * q4 + 2], dk1[4 * q4 + 3])};
+          *reinterpret_cast<u32x2*>(dvp + d) = (u32x2){pack_bf16_pair(dv0[4 * q4], dv0[4 * q4 + 1]), pack_bf16_pair(dv0[4 * q4 + 2], dv0[4 * q4 + 3])};
+          *reinterpret_cast<u32x2*>(dvp + 32 + d) = (u32x2){pack_bf16_pair(dv1[4 * q4], dv1[4 * q4 + 1]), pack_bf16_pair(dv1[4 * q4 + 2], dv1[4 * q4 + 3])};
+        }
+      }
+    } else if (j_ok) {
+      float* dkp = reinterpret_cast<float*>(dk) + b * g.k_bs + (long long)j * g.k_rs + h * BD;
+      float* dvp = reinterpret_cast<float*>(dv) + b * g.k_bs + (long long)j * g.k_rs + h * BD;
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
         const int d = 8 * q4 + 4 * half;            // att_acc_row(4 q4 + 0..3, half) = d + 0..3
@@ -568,10 +584,11 @@ int pv_attention_fwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v
   return attention_fwd_bf16_any<uint16_t>(q, k, v, o, lse, d, workspace, stream);
 }
 
-extern "C++" template <typename KV>
+extern "C++" template <typename KV, typename DKV>
 static int attention_bwd_bf16_any(const float* q, const KV* k, const KV* v, const float* o, const float* dout, const float* lse,
-                                  float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d,
+                                  float* delta_ws, float* dq, DKV* dk, DKV* dv, const pv_attention_desc* d,
                                   int32_t accumulate_dkv, void* stream) {
+  PV_REQUIRE(sizeof(DKV) == 4 || !accumulate_dkv, PV_EINVAL, "pv_attention_bwd_bf16kv16: bf16 dK / dV cannot be accumulated into");
   AttnGeomB g;
   int rc = attn_geom_b(d, &g, "pv_attention_bwd_bf16");
   if (rc) return rc;
@@ -599,11 +616,11 @@ static int attention_bwd_bf16_any(const float* q, const KV* k, const KV* v, cons
   if (nsp > 1) {
     float* part = delta_ws + rows;
     const long long n = (long long)d->batch * d->q_batch_stride;
-    hipLaunchKernelGGL(attn_bwd_bf16<KV>, dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
+    hipLaunchKernelGGL((attn_bwd_bf16<KV, DKV>), dim3((unsigned)nsp, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout,
                        lse, (const float*)delta_ws, part, dk, dv, g, per, n, accumulate_dkv);
     launch_sum_slabs(part, dq, n, nsp, n, 0, st);
   } else {
-    hipLaunchKernelGGL(attn_bwd_bf16<KV>, dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
+    hipLaunchKernelGGL((attn_bwd_bf16<KV, DKV>), dim3(1, (unsigned)d->heads, (unsigned)d->batch), dim3(256), 0, st, q, k, v, dout, lse,
                        (const float*)delta_ws, dq, dk, dv, g, n_tiles, 0ll, accumulate_dkv);
   }
   return check_launch("pv_attention_bwd_bf16");
@@ -612,13 +629,19 @@ static int attention_bwd_bf16_any(const float* q, const KV* k, const KV* v, cons
 int pv_attention_bwd_bf16(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
                           float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
                           void* stream) {
-  return attention_bwd_bf16_any<float>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
+  return attention_bwd_bf16_any<float, float>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
 }
 
 int pv_attention_bwd_bf16kv(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout, const float* lse,
                             float* delta_ws, float* dq, float* dk, float* dv, const pv_attention_desc* d, int32_t accumulate_dkv,
                             void* stream) {
-  return attention_bwd_bf16_any<uint16_t>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
+  return attention_bwd_bf16_any<uint16_t, float>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, accumulate_dkv, stream);
+}
+
+int pv_attention_bwd_bf16kv16(const float* q, const uint16_t* k, const uint16_t* v, const float* o, const float* dout,
+                              const float* lse, float* delta_ws, float* dq, uint16_t* dk, uint16_t* dv, const pv_attention_desc* d,
+                              void* stream) {
+  return attention_bwd_bf16_any<uint16_t, uint16_t>(q, k, v, o, dout, lse, delta_ws, dq, dk, dv, d, 0, stream);
 }
 
 #ifdef PV_DIAG_STAMPS

@@ -153,14 +153,18 @@ __device__ __forceinline__ void x3_split_pair(float x0, float x1, uint32_t& h, u
 // accumulation -- torch.autocast's linear / matmul (the reference trains its Perceiver under Lightning precision=16:
 // experiments/003_perceiver_processes_single_sat_image_then_rnn.py:40,288-294); a sixth of the matrix work, a third of the LDS
 // traffic
-template <bool A_KC, bool B_KC, int TERMS = 3>
+// A_BF16 (TERMS = 1 only): A is a bf16 matrix in memory (g.a reinterpreted, strides in elements): the gradient of a
+// cross-attention's keys / values stored as bf16 by the attention backward -- the values this kernel would round A to anyway
+template <bool A_KC, bool B_KC, int TERMS = 3, bool A_BF16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
+  static_assert(!A_BF16 || TERMS == 1, "a bf16 A operand is for the one-term form");
   __shared__ __attribute__((aligned(16))) unsigned char As[3 * X3_A_PLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * X3_B_PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int z = blockIdx.z / g.k_splits, split = blockIdx.z % g.k_splits;
   const int z1 = z / g.batch2, z2 = z % g.batch2;
-  const float* __restrict__ A = g.a + z1 * g.a_bs1 + z2 * g.a_bs2;
+  const float* __restrict__ A = g.a + (A_BF16 ? 0 : z1 * g.a_bs1 + z2 * g.a_bs2);      // (A_BF16: A16 below is the operand)
+  const uint16_t* __restrict__ A16 = reinterpret_cast<const uint16_t*>(g.a) + z1 * g.a_bs1 + z2 * g.a_bs2;
   const float* __restrict__ B = g.b + z1 * g.b_bs1 + z2 * g.b_bs2;
   float* __restrict__ C = g.c + z1 * g.c_bs1 + z2 * g.c_bs2 + split * g.c_ss;
   const int m0 = blockIdx.x * G_BM, n0 = blockIdx.y * G_BN;   // row tiles along grid.x (2^31 - 1 of them), column tiles along y
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
   }
   const long long a_us = A_KC ? g.a_cs : g.a_rs, a_os = A_KC ? g.a_rs : g.a_cs;   // unit / other stride of A
   const long long b_us = B_KC ? g.b_rs : g.b_cs, b_os = B_KC ? g.b_cs : g.b_rs;
-  const bool a_fast = a_us == 1 && (a_os & 3) == 0 && ((uintptr_t)A & 15) == 0 && m0 + G_BM <= g.m;
+  const bool a_fast = a_us == 1 && (a_os & 3) == 0 && ((uintptr_t)(A_BF16 ? (const void*)A16 : (const void*)A) & 15) == 0 && m0 + G_BM <= g.m;
   const bool b_fast = b_us == 1 && (b_os & 3) == 0 && ((uintptr_t)B & 15) == 0 && n0 + G_BN <= g.n;
   long long a_off[4], b_off[2];   // element offset of the quad at k = 0
 #pragma unroll
@@ -196,9 +200,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) b_off[i] = (long long)(n0 + b_n[i]) * g.b_cs + (long long)b_k[i] * g.b_rs;
   f32x4 ar[4], br[2];
+  u32x2 ar16[4];            // A_BF16, whole quads: the four bf16 values as they are
+  bool a_raw = false;       // (uniform) the panel in ar16 rather than in ar
   auto load = [&](int k0) {
     const bool full_k = k0 + X3_BK <= kend;
-    if (a_fast && full_k) {
+    a_raw = A_BF16 && a_fast && full_k;
+    if (a_raw) {
+      const uint16_t* ap = A16 + (long long)k0 * g.a_cs;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ar16[i] = *reinterpret_cast<const u32x2*>(ap + a_off[i]);
+    } else if (a_fast && full_k) {
       const float* ap = A + (long long)k0 * g.a_cs;
 #pragma unroll
       for (int i = 0; i < 4; ++i) ar[i] = *reinterpret_cast<const f32x4*>(ap + a_off[i]);
@@ -208,7 +219,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int mm = m0 + a_m[i] + (A_KC ? 0 : e), kk = k0 + a_k[i] + (A_KC ? e : 0);
-          ar[i][e] = (mm < g.m && kk < kend) ? A[(long long)mm * g.a_rs + (long long)kk * g.a_cs] : 0.f;
+          const long long off = (long long)mm * g.a_rs + (long long)kk * g.a_cs;
+          ar[i][e] = (mm < g.m && kk < kend) ? (A_BF16 ? bf16_bits_to_f32(A16[off]) : A[off]) : 0.f;
         }
     }
     if (b_fast && full_k) {
@@ -265,7 +277,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (TERMS == 1) {
-        *reinterpret_cast<u32x2*>(As + a_w[i]) = (u32x2){pack_bf16_pair(ar[i][0], ar[i][1]), pack_bf16_pair(ar[i][2], ar[i][3])};
+        *reinterpret_cast<u32x2*>(As + a_w[i]) =
+            a_raw ? ar16[i] : (u32x2){pack_bf16_pair(ar[i][0], ar[i][1]), pack_bf16_pair(ar[i][2], ar[i][3])};
       } else {
         uint32_t h0, m0_, l0, h1, m1_, l1;
         x3_split_pair(ar[i][0], ar[i][1], h0, m0_, l0);
@@ -612,6 +625,8 @@ int pv_gemm_res_f32(const float* a, const float* b, const float* bias, const flo
 int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const float* residual, int64_t ldr, float* c,
                    const pv_gemm_desc* d, int relu, int32_t flags, void* stream) {
   const bool one_term = (flags & PV_GEMM_BF16_OPERANDS) != 0;
+  const bool a_bf16 = (flags & PV_GEMM_A_IS_BF16) != 0;
+  PV_REQUIRE(!a_bf16 || one_term, PV_EINVAL, "pv_gemm_ex_f32: PV_GEMM_A_IS_BF16 needs PV_GEMM_BF16_OPERANDS");
   PV_REQUIRE(a && b && c && d, PV_EINVAL, "pv_gemm_f32: null pointer");
   PV_REQUIRE(d->m > 0 && d->n > 0 && d->k > 0, PV_EINVAL, "pv_gemm_f32: non-positive extent (%d,%d,%d)", d->m, d->n, d->k);
   PV_REQUIRE(d->batch1 > 0 && d->batch2 > 0 && d->k_splits > 0, PV_EINVAL, "pv_gemm_f32: batch counts and k_splits must be >= 1");
@@ -638,8 +653,8 @@ int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const floa
   // f32 matrix instruction (bit-exact f32 products)
   static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;
   static const bool no_rows_form = getenv("PV_GEMM_NO_ROWS_FORM") != nullptr;
-  const bool rows_form = (!exact_f32 || one_term) && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 && d->m >= 2048 &&
-                         ((uintptr_t)a % 16 == 0);
+  const bool rows_form = (!exact_f32 || one_term) && !a_bf16 && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 &&
+                         d->m >= 2048 && ((uintptr_t)a % 16 == 0);
   if (exact_f32 && !one_term) {
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, as_stream(stream), g);
   } else if (rows_form) {
@@ -666,7 +681,12 @@ int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const floa
     else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, T>), grid, dim3(256), 0, as_stream(stream), g);              \
     else if (b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, T>), grid, dim3(256), 0, as_stream(stream), g);              \
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, T>), grid, dim3(256), 0, as_stream(stream), g)
-    if (one_term) { PV_TILED(1); } else { PV_TILED(3); }
+    if (a_bf16) {
+      if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, 1, true>), grid, dim3(256), 0, as_stream(stream), g);
+      else if (a_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, 1, true>), grid, dim3(256), 0, as_stream(stream), g);
+      else if (b_kc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 1, true>), grid, dim3(256), 0, as_stream(stream), g);
+      else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 1, true>), grid, dim3(256), 0, as_stream(stream), g);
+    } else if (one_term) { PV_TILED(1); } else { PV_TILED(3); }
 #undef PV_TILED
   }
   return check_launch("pv_gemm_f32");

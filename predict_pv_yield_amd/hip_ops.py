@@ -859,7 +859,7 @@ def _gemm_views(a: torch.Tensor, b: torch.Tensor):
     """a [..., M, K], b [..., K, N] with the same (<= 2) leading batch dims (stride-0 broadcast allowed)."""
     if a.dim() != b.dim() or a.dim() < 2 or a.dim() > 4 or a.shape[:-2] != b.shape[:-2] or a.shape[-1] != b.shape[-2]:
         raise ValueError(f"gemm: incompatible shapes {tuple(a.shape)} x {tuple(b.shape)}")
-    if a.dtype != torch.float32 or b.dtype != torch.float32:
+    if a.dtype not in (torch.float32, torch.bfloat16) or b.dtype != torch.float32:      # (a bf16 A: see gemm's bf16_operands)
         raise TypeError("gemm: float32 operands expected")
     batch = tuple(a.shape[:-2])
     while len(batch) < 2:
@@ -868,6 +868,7 @@ def _gemm_views(a: torch.Tensor, b: torch.Tensor):
 
 
 GEMM_BF16_OPERANDS = 1      # PV_GEMM_BF16_OPERANDS of include/pv_yield_hip.h
+GEMM_A_IS_BF16 = 2          # PV_GEMM_A_IS_BF16
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
@@ -879,6 +880,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     default: the f32-accurate three-term form."""
     _require_device(a, b, out, residual)
     require_cuda(bias)
+    a_bf16 = a.dtype == torch.bfloat16      # (with bf16_operands: A may be STORED as bf16 -- read as it is)
+    if a_bf16 and not bf16_operands:
+        raise ValueError("gemm: a bfloat16 A needs bf16_operands=True")
     lead = tuple(a.shape[:-2])
     a4, b4, batch = _gemm_views(a, b)
     m, k, n = a4.shape[-2], a4.shape[-1], b4.shape[-1]
@@ -895,7 +899,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         if batch != (1, 1) or tuple(residual.shape) != (m, n) or residual.stride(-1) != 1 or residual.dtype != torch.float32:
             raise ValueError("gemm: residual must be a float32 [M, N] tensor with unit last stride (2-D products only)")
     check(get_lib().pv_gemm_ex_f32(ptr(a4), ptr(b4), ptr(bias), ptr(residual), residual.stride(0) if residual is not None else 0,
-                                   ptr(c4), ctypes.byref(d), int(relu), GEMM_BF16_OPERANDS if bf16_operands else 0,
+                                   ptr(c4), ctypes.byref(d), int(relu),
+                                   (GEMM_BF16_OPERANDS if bf16_operands else 0) | (GEMM_A_IS_BF16 if a_bf16 else 0),
                                    current_stream_ptr()), "pv_gemm_ex_f32")
     return out
 
@@ -944,8 +949,12 @@ def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torc
         return gemm(a, b)
     slabs = _workspace("gemm_splitk", splits * m * n * 4, a.device)
     d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, splits, m * n)
+    a_bf16 = a.dtype == torch.bfloat16
+    if a_bf16 and not bf16_operands:
+        raise ValueError("gemm_splitk: a bfloat16 A needs bf16_operands=True")
     check(get_lib().pv_gemm_ex_f32(ptr(a), ptr(b), None, None, 0, ptr(slabs), ctypes.byref(d), 0,
-                                   GEMM_BF16_OPERANDS if bf16_operands else 0, current_stream_ptr()), "pv_gemm_ex_f32")
+                                   (GEMM_BF16_OPERANDS if bf16_operands else 0) | (GEMM_A_IS_BF16 if a_bf16 else 0),
+                                   current_stream_ptr()), "pv_gemm_ex_f32")
     out = accumulate_into if accumulate_into is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
     check(get_lib().pv_sum_slabs_acc_f32(ptr(slabs), ptr(out), m * n, splits, int(accumulate_into is not None),
                                          current_stream_ptr()), "pv_sum_slabs_acc_f32")
@@ -1109,9 +1118,11 @@ def attention_fwd(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, b
     return out, lse
 
 
-def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands: bool = False, accumulate_dkv_into=None):
+def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands: bool = False, accumulate_dkv_into=None,
+                  dkv_bf16: bool = False):
     """Backward of attention_fwd (n_q <= 128): returns (dq like q, dkv like kv).
-    accumulate_dkv_into (bf16 operands only): a tensor like kv that receives `+= dkv` in the kernel's store."""
+    accumulate_dkv_into (bf16 operands only): a tensor like kv that receives `+= dkv` in the kernel's store.
+    dkv_bf16 (bf16-stored kv only): dkv is STORED as bf16 too -- for a consumer that rounds it to bf16 anyway."""
     require_cuda(q, kv, out, dout, lse, accumulate_dkv_into)
     b, n_q, inner = q.shape
     d = attention_desc(q, kv, heads, scale)
@@ -1119,6 +1130,17 @@ def attention_bwd(q, kv, out, dout, lse, heads: int, scale: float, bf16_operands
     kv16 = kv.dtype == torch.bfloat16
     if kv16 and not bf16_operands:
         raise ValueError("attention_bwd: a bfloat16 kv needs bf16_operands=True")
+    if dkv_bf16:
+        if not kv16 or accumulate_dkv_into is not None:
+            raise ValueError("attention_bwd: dkv_bf16 needs a bfloat16 kv and no accumulate_dkv_into")
+        dkv = torch.empty(kv.shape, dtype=torch.bfloat16, device=kv.device)
+        n_ws = get_lib().pv_attention_bwd_workspace_floats(ctypes.byref(d))
+        delta = _workspace("attention_bwd", n_ws * 4, q.device)
+        check(get_lib().pv_attention_bwd_bf16kv16(ptr(q), ptr(kv), ctypes.c_void_p(kv.data_ptr() + inner * 2), ptr(out), ptr(dout),
+                                                  ptr(lse), ptr(delta), ptr(dq), ptr(dkv),
+                                                  ctypes.c_void_p(dkv.data_ptr() + inner * 2), ctypes.byref(d),
+                                                  current_stream_ptr()), "pv_attention_bwd_bf16kv16")
+        return dq, dkv
     if accumulate_dkv_into is not None:
         if (not bf16_operands or accumulate_dkv_into.shape != kv.shape or not accumulate_dkv_into.is_contiguous()
                 or accumulate_dkv_into.dtype != torch.float32):

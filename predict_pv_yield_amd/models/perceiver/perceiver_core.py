@@ -75,6 +75,18 @@ def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: 
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
 
 
+def _attend_context(attn: Attention, xn: torch.Tensor, context: torch.Tensor, residual=None) -> torch.Tensor:
+    """Attention.forward in bf16-operand mode given the normalised query input and the NORMALISED, not yet projected context of
+    a cross-attention that is this context's only consumer: to_kv + attention as one node (falls back to the separate nodes
+    where the kernels' shape rules do not hold)."""
+    q = PF.linear(xn, attn.to_q.weight)
+    if PF.cross_attention_kv16_supported(q, context, attn.to_kv.weight, attn.heads):
+        out = PF.cross_attention_kv16(q, context, attn.to_kv.weight, attn.heads, attn.scale)
+    else:
+        out = PF.attention_core(q, PF.linear_kv16(context, attn.to_kv.weight), attn.heads, attn.scale, bf16_operands=True)
+    return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
+
+
 def _feed_forward(block: PreNorm, x: torch.Tensor) -> torch.Tensor:
     """`block(x) + x` of a PreNorm(FeedForward): the by-pass rides in the last Linear's epilogue forward and in the LayerNorm
     kernel backward."""
@@ -159,23 +171,35 @@ class Perceiver(nn.Module):
         data = data.reshape(b, -1, data.shape[-1])                         # [b, positions, channels + fourier]
         x = self.latents.unsqueeze(0).expand(b, -1, -1)
         kv_of = {}                                                         # cross-attention block -> projected context
+        ctx_of = {}                                                        # ... -> normalised context (one-consumer blocks)
+        uses = {}
+        for cross_attn, _, _ in self.layers:
+            uses[id(cross_attn)] = uses.get(id(cross_attn), 0) + 1
+        bf = self.operand_dtype == "bf16"
         for cross_attn, cross_ff, self_attns in self.layers:
-            if id(cross_attn) not in kv_of:
+            key = id(cross_attn)
+            if key not in kv_of and key not in ctx_of:
                 ctx = PF.layer_norm(data, cross_attn.norm_context.weight, cross_attn.norm_context.bias,
                                     cross_attn.norm_context.eps)
-                # consumed by every tied layer.  bf16-operand mode: K / V are STORED as bf16 (the values the attention kernels
-                # round to anyway): the projection's store and the attention's reads are both bound by these bytes
-                project = PF.linear_kv16 if (self.operand_dtype == "bf16" and KV_STORED_AS_BF16) else PF.linear
-                kv_of[id(cross_attn)] = PF.mark_shared(project(ctx, cross_attn.fn.to_kv.weight))
+                if bf and KV_STORED_AS_BF16 and LINEARS_FOLLOW_OPERAND_DTYPE and uses[key] == 1:
+                    # a context ONE layer consumes: to_kv and the attention run as one node (PF.cross_attention_kv16), K / V
+                    # and their gradient bf16 between the kernels
+                    ctx_of[key] = ctx
+                else:
+                    # consumed by every tied layer.  bf16-operand mode: K / V are STORED as bf16 (the values the attention
+                    # kernels round to anyway): the projection's store and the attention's reads are both bound by these bytes
+                    project = PF.linear_kv16 if (bf and KV_STORED_AS_BF16) else PF.linear
+                    kv_of[key] = PF.mark_shared(project(ctx, cross_attn.fn.to_kv.weight))
             # every `fn(norm(x)) + x`: the by-pass is added in the epilogue of fn's last Linear (forward) and in the LayerNorm
             # backward kernel's store (backward) -- no elementwise launches
-            bf = self.operand_dtype == "bf16"
             if FUSE_RESIDUALS:
                 xn, x_pass = PF.layer_norm_fork(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-                x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], bf, residual=x_pass)
+                x = (_attend_context(cross_attn.fn, xn, ctx_of[key], residual=x_pass) if key in ctx_of else
+                     _attend(cross_attn.fn, xn, kv_of[key], bf, residual=x_pass))
             else:
                 xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-                x = _attend(cross_attn.fn, xn, kv_of[id(cross_attn)], bf) + x
+                x = (_attend_context(cross_attn.fn, xn, ctx_of[key]) if key in ctx_of else
+                     _attend(cross_attn.fn, xn, kv_of[key], bf)) + x
             x = _feed_forward(cross_ff, x)
             for self_attn, self_ff in self_attns:
                 if FUSE_RESIDUALS:

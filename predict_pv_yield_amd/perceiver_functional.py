@@ -191,6 +191,50 @@ def linear_kv16(x, weight, bias=None):
     return y
 
 
+class CrossAttentionKV16(torch.autograd.Function):
+    """A whole cross-attention against a context that ONE layer consumes, in bf16-operand mode: to_kv (bias-free) and the
+    attention as one node, so that K / V AND their gradient can stay bf16 between the kernels -- the projection writes bf16, the
+    attention reads it and writes dK / dV as bf16, and to_kv's two backward products (which round that operand to bf16 anyway:
+    identical bits) read 2 instead of 4 bytes per element.  (A context shared by weight-tied layers keeps the separate nodes:
+    its gradient is a sum over the layers, collected in f32 -- linear_kv16 + attention_core.)"""
+
+    @staticmethod
+    def forward(ctx, q, context, w_kv, heads, scale):
+        q = q.contiguous()
+        c2 = context.contiguous().view(-1, context.shape[-1])
+        kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(context.shape[:-1] + (w_kv.shape[0],))
+        out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
+        ctx.save_for_backward(q, c2, w_kv, kv16, out, lse)
+        ctx.heads, ctx.scale, ctx.c_shape = heads, scale, context.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, c2, w_kv, kv16, out, lse = ctx.saved_tensors
+        dq, dkv16 = K.attention_bwd(q, kv16, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=True, dkv_bf16=True)
+        g2 = dkv16.view(-1, w_kv.shape[0])
+        dc = K.gemm(g2, w_kv, bf16_operands=True).view(ctx.c_shape) if ctx.needs_input_grad[1] else None
+        key, acc = _tied_slot(w_kv)
+        if acc is not None:
+            K.gemm_splitk(g2.t(), c2, accumulate_into=acc, bf16_operands=True)
+            dw = None
+        else:
+            dw = K.gemm_splitk(g2.t(), c2, bf16_operands=True)
+            _tied_keep(key, dw)
+        return dq, dc, dw, None, None
+
+
+def cross_attention_kv16_supported(q, context, w_kv, heads) -> bool:
+    c2 = context.reshape(-1, context.shape[-1]) if context.is_contiguous() else None
+    return (c2 is not None and K.gemm_rows_bf16out_supported(c2, w_kv.t()) and w_kv.shape[0] == 2 * q.shape[-1]
+            and q.shape[-1] // heads == 64 and q.shape[1] <= 128 and w_kv.shape[0] % 8 == 0)
+
+
+def cross_attention_kv16(q, context, w_kv, heads, scale):
+    _note_use(w_kv)
+    return CrossAttentionKV16.apply(q, context, w_kv, heads, scale)
+
+
 class MatmulF32(torch.autograd.Function):
     """C = A @ B for strided batched views; dA = dC @ B^T, dB = A^T @ dC (same kernel, transposed views)."""
 

@@ -91,6 +91,28 @@ def test_attention_with_keys_and_values_stored_as_bf16(b, h, nq, nk, device):
         assert torch.equal(K.gemm_rows_bf16out(x, w.t()), K.gemm(x, w.t()).to(torch.bfloat16))
 
 
+def test_bf16_stored_key_value_gradients_feed_the_bf16_operand_products_unchanged(device):
+    """dK / dV stored as bf16 by the attention backward (pv_attention_bwd_bf16kv16) are the nearest-even roundings of the f32
+    ones, and a bf16-operand GEMM that reads them as they are (PV_GEMM_A_IS_BF16) gives the bits it gives on the f32 ones."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(9)
+    b, h, nq, nk = 2, 1, 128, 4096
+    q = torch.randn(b, nq, 64, generator=g).to(device)
+    kv16 = torch.randn(b, nk, 128, generator=g).to(device).to(torch.bfloat16)
+    dout = torch.randn(b, nq, 64, generator=g).to(device)
+    out, lse = K.attention_fwd(q, kv16, h, 0.125, bf16_operands=True)
+    dq, dkv = K.attention_bwd(q, kv16, out, dout, lse, h, 0.125, bf16_operands=True)
+    dq16, dkv16 = K.attention_bwd(q, kv16, out, dout, lse, h, 0.125, bf16_operands=True, dkv_bf16=True)
+    assert dkv16.dtype == torch.bfloat16 and torch.equal(dq, dq16) and torch.equal(dkv16, dkv.to(torch.bfloat16))
+    w = (torch.randn(128, 38, generator=g) * 0.2).to(device)
+    x = torch.randn(b * nk, 38, generator=g).to(device)
+    g32, g16 = dkv.view(-1, 128), dkv16.view(-1, 128)
+    assert torch.equal(K.gemm(g16, w, bf16_operands=True), K.gemm(g32, w, bf16_operands=True))
+    assert torch.equal(K.gemm_splitk(g16.t(), x, bf16_operands=True), K.gemm_splitk(g32.t(), x, bf16_operands=True))
+    with pytest.raises(ValueError, match="bf16_operands"):
+        K.gemm(g16, w)
+
+
 def test_exp003_is_the_same_model_with_keys_and_values_stored_as_bf16(device):
     """operand_dtype="bf16": storing the projected context as bf16 (perceiver_core.KV_STORED_AS_BF16, the default) changes where
     K / V are rounded, not to what: output, loss and every gradient equal those of the f32-stored form bit for bit."""
