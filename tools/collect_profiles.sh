@@ -9,6 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/flow -o p -- python3 
 cd $R
 python3 tools/step_timeline.py $O/kt > $O/step_timeline.txt
 python3 tools/pmc_traffic.py $O/fetch $O/write > $O/pmc.json
+make -C predict_pv_yield_amd/csrc -j8 diag > /dev/null 2>&1
 python3 tools/diag_stamps.py flow 32 > $O/flow_level_kernel_stamps.txt 2>&1
 for k in wgrad wgrad16 fwd dgrad first; do python3 tools/diag_stamps.py $k 32; done > $O/conv_stamps.txt 2>&1
 python3 tools/time_conv.py > $O/time_conv.txt 2>&1
