@@ -405,7 +405,7 @@ def measure_fp32_headline(dev, b, history_minutes, steps=5):
     return {"dtype": "fp32", "ms_per_step": round(d * 1e3, 3), "value": round(b / d, 1), "unit": "samples/s",
             "steps": steps, "per_gpu_batch": b,
             "frac_of_f32_mfma_peak": round(b / d * 23.37e9 / MFMA_F32_PEAK, 4),
-            "note": "precision=\"fp32\": forward / dgrad on the f32 matrix cores (v_mfma_f32_32x32x2f32, exact f32 products), weight gradients and fc1 as bf16 x 3 products on the bf16 matrix cores (f32-accurate), f32 Adam; rtol 1e-4 parity path, same step definition"}
+            "note": "precision=\"fp32\": forward / dgrad on the f32 matrix cores (v_mfma_f32_32x32x2f32, exact f32 products), weight gradients as two-term f16 splits (three products) and fc1 as bf16 x 3 products on the 16-bit matrix cores (f32-accurate), f32 Adam; rtol 1e-4 parity path, same step definition"}
 
 
 def measure_other_models(dev):
