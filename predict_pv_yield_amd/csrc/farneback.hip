@@ -1969,6 +1969,91 @@ __global__ __launch_bounds__(256) void fb_blur_h_solve_kernel(const float* __res
   }
 }
 
+// ---- the same two passes for FRAMES (levels larger than one 64 x 64 tile: the 704 x 548 images of the notebooks) ------
+// Each thread keeps a RUN + 2 MW window of its column in registers and slides the MW-tap window down it: RUN + 2 MW loads
+// for RUN outputs instead of 2 MW + 1 per output, every one of them coalesced across the wave.  The vertical pass writes
+// its result TRANSPOSED and planar (Vt[pair][channel][x][y], rows padded to hp) so that the horizontal pass is the same
+// walk: a lane per image row, the window sliding along x.  Operation order as in the two kernels above: identical bits.
+template <int MW, int RUN>
+__global__ __launch_bounds__(256) void fb_blur_v_run_kernel(const float* __restrict__ M, float* __restrict__ Vt, int height,
+                                                             int width, int hp, int n_runs, int n_xb, FbTaps kt) {
+  const int xb = blockIdx.x % n_xb;
+  const long long pr = blockIdx.x / n_xb;
+  const int run = (int)(pr % n_runs);
+  const long long p = pr / n_runs;
+  const int row_elems = width * 5;
+  const int xe = xb * 256 + threadIdx.x;
+  if (xe >= row_elems) return;
+  const int y0 = run * RUN;
+  const float* src = M + p * (long long)height * row_elems + xe;
+  float wv[RUN + 2 * MW];
+#pragma unroll
+  for (int j = 0; j < RUN + 2 * MW; ++j) {
+    const int y = min(max(y0 - MW + j, 0), height - 1);
+    wv[j] = src[(size_t)y * row_elems];
+  }
+  const int x = xe / 5, c = xe - x * 5;
+  float* dst = Vt + ((p * 5 + c) * (long long)width + x) * hp + y0;   // hp is a multiple of RUN (and of 4): 16-byte rows
+#pragma unroll
+  for (int r4 = 0; r4 < RUN; r4 += 4) {
+    float o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r4 + q;
+      float s0 = __fmul_rn(wv[r + MW], kt.k[0]);
+#pragma unroll
+      for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(wv[r + MW + k], wv[r + MW - k]), kt.k[k]));
+      o[q] = s0;
+    }
+    *reinterpret_cast<float4*>(dst + r4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int MW, int RUN>
+__global__ __launch_bounds__(64) void fb_blur_h_solve_run_kernel(const float* __restrict__ Vt, float* __restrict__ flow,
+                                                                  int height, int width, int hp, int n_runs, int n_yb,
+                                                                  FbTaps kt) {
+  __shared__ float hs[5][RUN][64];   // the five blurred channels of the lane's RUN pixels (each lane reads back its own words)
+  const int yb = blockIdx.x % n_yb;
+  const long long pr = blockIdx.x / n_yb;
+  const int run = (int)(pr % n_runs);
+  const long long p = pr / n_runs;
+  const int y = yb * 64 + threadIdx.x;
+  if (y >= height) return;
+  const int x0 = run * RUN;
+  const float* base = Vt + p * 5 * (long long)width * hp + y;
+#pragma unroll 1
+  for (int c = 0; c < 5; ++c) {   // one channel's window in registers at a time
+    const float* src = base + (size_t)c * width * hp;
+    float wv[RUN + 2 * MW];
+#pragma unroll
+    for (int j = 0; j < RUN + 2 * MW; ++j) {
+      const int x = min(max(x0 - MW + j, 0), width - 1);
+      wv[j] = src[(unsigned)(x * hp)];
+    }
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) {
+      float s0 = __fmul_rn(wv[r + MW], kt.k[0]);
+#pragma unroll
+      for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(kt.k[k], __fadd_rn(wv[r + MW - k], wv[r + MW + k])));
+      hs[c][r][threadIdx.x] = s0;
+    }
+  }
+  float* fl = flow + ((p * height + y) * (long long)width + x0) * 2;
+#pragma unroll
+  for (int r = 0; r < RUN; ++r) {
+    if (x0 + r < width) {
+      const double g11 = hs[0][r][threadIdx.x], g12 = hs[1][r][threadIdx.x], g22 = hs[2][r][threadIdx.x],
+                   h1 = hs[3][r][threadIdx.x], h2 = hs[4][r][threadIdx.x];
+      const double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
+      const double idet = __ddiv_rn(1.0, det);
+      *reinterpret_cast<float2*>(fl + 2 * r) = make_float2((float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet),
+                                                           (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet));
+    }
+  }
+}
+constexpr int FB_RUN_V = 16, FB_RUN_H = 8;    // outputs per thread of the two frame passes
+
 // ---- flow upsample: cv::resize(prevFlow -> (lw, lh), INTER_LINEAR) * (1 / pyr_scale) --------------
 // IDX = int when the whole output fits 31 bits (the per-element 64-bit division otherwise dominates the kernel); both
 // flow components of a tap travel as one 8-byte load / store.
@@ -2176,7 +2261,7 @@ static FbLayout fb_layout(long long n_pairs, int h, int w) {
   L.off_T = o; o = align(o + (size_t)n_pairs * 2 * px * 12);
   L.off_R = o; o = align(o + (size_t)n_pairs * 2 * px * 20);
   L.off_M = o; o = align(o + (size_t)n_pairs * px * 20);
-  L.off_V = o; o = align(o + (size_t)n_pairs * px * 20);
+  L.off_V = o; o = align(o + (size_t)n_pairs * (size_t)w * (size_t)((h + 15) / 16 * 16) * 20);   // frames: transposed, rows padded to 16
   L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_G = o; o = align(o + 8 * 64 * 64 * sizeof(float));   // window matrices (2) and PolyExp matrices (6) of the current pyramid level
@@ -2418,10 +2503,22 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         continue;
       }
       stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
+      // the reference's 41-tap window (winsize 40): register-window passes; any other window: one load per tap
+      const int hp = (lh + 15) / 16 * 16;
+      const long long v_runs = (lh + FB_RUN_V - 1) / FB_RUN_V, v_xb = (lw * 5 + 255) / 256;
+      const long long h_runs = (lw + FB_RUN_H - 1) / FB_RUN_H, h_yb = (lh + 63) / 64;
+      if (win.n == 20 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)flow & 7) == 0 && n_pairs * v_runs * v_xb < 0x7fffffffLL &&
+          n_pairs * h_runs * h_yb < 0x7fffffffLL && !getenv("PV_FARNEBACK_TAP_LOADS")) {
+        hipLaunchKernelGGL((fb_blur_v_run_kernel<20, FB_RUN_V>), dim3((unsigned)(n_pairs * v_runs * v_xb)), dim3(256), 0, st,
+                           (const float*)M, V, lh, lw, hp, (int)v_runs, (int)v_xb, win);
+        hipLaunchKernelGGL((fb_blur_h_solve_run_kernel<20, FB_RUN_H>), dim3((unsigned)(n_pairs * h_runs * h_yb)), dim3(64), 0, st,
+                           (const float*)V, flow, lh, lw, hp, (int)h_runs, (int)h_yb, win);
+      } else {
       hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
                          (const float*)M, V, (long long)n_pairs, lh, lw, win);
       hipLaunchKernelGGL(fb_blur_h_solve_kernel, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
                          (const float*)V, flow, (long long)n_pairs, lh, lw, win);
+      }
       if (update) {
         stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
         hipLaunchKernelGGL(fb_update_matrices_kernel<0>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,

@@ -192,6 +192,23 @@ def test_farneback_full_extent_vs_oracle(device):
     assert np.percentile(np.abs(inner[..., 0] - 2.2), 95) < 0.25 and np.percentile(np.abs(inner[..., 1] + 1.4), 95) < 0.25
 
 
+@pytest.mark.parametrize("h,w,n", [(548, 704, 3), (160, 200, 2), (96, 80, 5), (70, 131, 2), (65, 67, 1)])
+def test_frame_window_blur_in_register_windows_is_bit_identical_to_one_load_per_tap(device, monkeypatch, h, w, n):
+    """Levels larger than a 64 x 64 tile (the notebooks' 704 x 548 frames): the 41-tap window blur as sliding register
+    windows over a transposed intermediate (fb_blur_v_run_kernel / fb_blur_h_solve_run_kernel) performs the operations of the
+    one-load-per-tap kernels in the same order -- the flow is the same bits, for any height / width (odd ones, runs that end
+    beyond the image, clamped borders)."""
+    K = _ops()
+    rng = np.random.default_rng(h * 1000 + w)
+    u8 = torch.from_numpy(rng.integers(0, 256, (n + 1, h, w), dtype=np.uint8)).to(device)
+    fast = K.farneback_stack(u8)
+    monkeypatch.setenv("PV_FARNEBACK_TAP_LOADS", "1")
+    slow = K.farneback_stack(u8)
+    monkeypatch.delenv("PV_FARNEBACK_TAP_LOADS")
+    assert torch.isfinite(fast).all()
+    assert torch.equal(fast, slow)
+
+
 def test_farneback_stack_and_params(device):
     K = _ops()
     raw, _ = advected_counts(batch=1, t=5, channels=2, h=64, w=64, seed=5)
