@@ -1976,14 +1976,21 @@ __global__ __launch_bounds__(256) void fb_blur_h_solve_kernel(const float* __res
 // walk: a lane per image row, the window sliding along x.  Operation order as in the two kernels above: identical bits.
 template <int MW, int RUN>
 __global__ __launch_bounds__(256) void fb_blur_v_run_kernel(const float* __restrict__ M, float* __restrict__ Vt, int height,
-                                                             int width, int hp, int n_runs, int n_xb, FbTaps kt) {
-  const int xb = blockIdx.x % n_xb;
-  const long long pr = blockIdx.x / n_xb;
-  const int run = (int)(pr % n_runs);
-  const long long p = pr / n_runs;
+                                                             int width, int hp, int n_runs, int n_xb, long long n_strips,
+                                                             FbTaps kt) {
+  static_assert(RUN == 32, "the transposing store below moves 32-row segments, two per wave instruction");
+  __shared__ float ot[RUN][257];        // the block's RUN x 256 outputs, transposed on the way out (odd row stride: no conflicts)
+  __shared__ unsigned seg_off[256];     // where each element column's RUN-float segment starts in Vt (elements, per pair)
+  // workgroups go round-robin over the 8 XCDs: a strip (one pair, 256 element columns, every run of rows) stays on ONE XCD,
+  // its runs back to back, so the 2 MW rows two neighbouring runs share are hits in that XCD's L2
+  const long long jx = blockIdx.x >> 3;
+  const long long strip = (jx / n_runs) * 8 + (blockIdx.x & 7);
+  if (strip >= n_strips) return;
+  const int run = (int)(jx % n_runs);
+  const int xb = (int)(strip % n_xb);
+  const long long p = strip / n_xb;
   const int row_elems = width * 5;
-  const int xe = xb * 256 + threadIdx.x;
-  if (xe >= row_elems) return;
+  const int xe = min(xb * 256 + (int)threadIdx.x, row_elems - 1);   // (lanes beyond the row repeat its last column; not stored)
   const int y0 = run * RUN;
   const float* src = M + p * (long long)height * row_elems + xe;
   float wv[RUN + 2 * MW];
@@ -1993,31 +2000,36 @@ __global__ __launch_bounds__(256) void fb_blur_v_run_kernel(const float* __restr
     wv[j] = src[(size_t)y * row_elems];
   }
   const int x = xe / 5, c = xe - x * 5;
-  float* dst = Vt + ((p * 5 + c) * (long long)width + x) * hp + y0;   // hp is a multiple of RUN (and of 4): 16-byte rows
+  seg_off[threadIdx.x] = (unsigned)((c * width + x) * hp + y0);   // hp is a multiple of RUN: 128-byte segments
 #pragma unroll
-  for (int r4 = 0; r4 < RUN; r4 += 4) {
-    float o[4];
+  for (int r = 0; r < RUN; ++r) {
+    float s0 = __fmul_rn(wv[r + MW], kt.k[0]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = r4 + q;
-      float s0 = __fmul_rn(wv[r + MW], kt.k[0]);
-#pragma unroll
-      for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(wv[r + MW + k], wv[r + MW - k]), kt.k[k]));
-      o[q] = s0;
-    }
-    *reinterpret_cast<float4*>(dst + r4) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(wv[r + MW + k], wv[r + MW - k]), kt.k[k]));
+    ot[r][threadIdx.x] = s0;
+  }
+  __syncthreads();
+  float* dst = Vt + p * 5 * (long long)width * hp;
+  const int n_cols = min(256, row_elems - xb * 256);
+  const int yy = threadIdx.x & 31, s8 = threadIdx.x >> 5;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {        // a half wave per segment: 128 contiguous bytes
+    const int sg = i * 8 + s8;
+    if (sg < n_cols) dst[seg_off[sg] + yy] = ot[yy][sg];
   }
 }
 
 template <int MW, int RUN>
 __global__ __launch_bounds__(64) void fb_blur_h_solve_run_kernel(const float* __restrict__ Vt, float* __restrict__ flow,
                                                                   int height, int width, int hp, int n_runs, int n_yb,
-                                                                  FbTaps kt) {
-  __shared__ float hs[5][RUN][64];   // the five blurred channels of the lane's RUN pixels (each lane reads back its own words)
-  const int yb = blockIdx.x % n_yb;
-  const long long pr = blockIdx.x / n_yb;
-  const int run = (int)(pr % n_runs);
-  const long long p = pr / n_runs;
+                                                                  long long n_strips, FbTaps kt) {
+  __shared__ __attribute__((aligned(16))) float hs[5][64][RUN];   // the five blurred channels of the lane's RUN pixels (each lane reads back its own words)
+  const long long jx = blockIdx.x >> 3;                      // (a strip = one pair, 64 rows, every run of columns: one XCD)
+  const long long strip = (jx / n_runs) * 8 + (blockIdx.x & 7);
+  if (strip >= n_strips) return;
+  const int run = (int)(jx % n_runs);
+  const int yb = (int)(strip % n_yb);
+  const long long p = strip / n_yb;
   const int y = yb * 64 + threadIdx.x;
   if (y >= height) return;
   const int x0 = run * RUN;
@@ -2031,20 +2043,23 @@ __global__ __launch_bounds__(64) void fb_blur_h_solve_run_kernel(const float* __
       const int x = min(max(x0 - MW + j, 0), width - 1);
       wv[j] = src[(unsigned)(x * hp)];
     }
+    float o[RUN];
 #pragma unroll
     for (int r = 0; r < RUN; ++r) {
       float s0 = __fmul_rn(wv[r + MW], kt.k[0]);
 #pragma unroll
-      for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(kt.k[k], __fadd_rn(wv[r + MW - k], wv[r + MW + k])));
-      hs[c][r][threadIdx.x] = s0;
+      for (int k = 1; k <= MW; ++k) s0 = __fadd_rn(s0, __fmul_rn(__fadd_rn(wv[r + MW - k], wv[r + MW + k]), kt.k[k]));
+      o[r] = s0;
     }
+#pragma unroll
+    for (int r = 0; r < RUN; r += 4) *reinterpret_cast<float4*>(&hs[c][threadIdx.x][r]) = make_float4(o[r], o[r + 1], o[r + 2], o[r + 3]);
   }
   float* fl = flow + ((p * height + y) * (long long)width + x0) * 2;
 #pragma unroll
   for (int r = 0; r < RUN; ++r) {
     if (x0 + r < width) {
-      const double g11 = hs[0][r][threadIdx.x], g12 = hs[1][r][threadIdx.x], g22 = hs[2][r][threadIdx.x],
-                   h1 = hs[3][r][threadIdx.x], h2 = hs[4][r][threadIdx.x];
+      const double g11 = hs[0][threadIdx.x][r], g12 = hs[1][threadIdx.x][r], g22 = hs[2][threadIdx.x][r],
+                   h1 = hs[3][threadIdx.x][r], h2 = hs[4][threadIdx.x][r];
       const double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
       const double idet = __ddiv_rn(1.0, det);
       *reinterpret_cast<float2*>(fl + 2 * r) = make_float2((float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet),
@@ -2052,7 +2067,7 @@ __global__ __launch_bounds__(64) void fb_blur_h_solve_run_kernel(const float* __
     }
   }
 }
-constexpr int FB_RUN_V = 16, FB_RUN_H = 8;    // outputs per thread of the two frame passes
+constexpr int FB_RUN_V = 32, FB_RUN_H = 8; static_assert(FB_RUN_V <= 32 && FB_RUN_V % 4 == 0, "fb_layout pads the transposed rows to 32");   // outputs per thread of the two frame passes
 
 // ---- flow upsample: cv::resize(prevFlow -> (lw, lh), INTER_LINEAR) * (1 / pyr_scale) --------------
 // IDX = int when the whole output fits 31 bits (the per-element 64-bit division otherwise dominates the kernel); both
@@ -2261,7 +2276,7 @@ static FbLayout fb_layout(long long n_pairs, int h, int w) {
   L.off_T = o; o = align(o + (size_t)n_pairs * 2 * px * 12);
   L.off_R = o; o = align(o + (size_t)n_pairs * 2 * px * 20);
   L.off_M = o; o = align(o + (size_t)n_pairs * px * 20);
-  L.off_V = o; o = align(o + (size_t)n_pairs * (size_t)w * (size_t)((h + 15) / 16 * 16) * 20);   // frames: transposed, rows padded to 16
+  L.off_V = o; o = align(o + (size_t)n_pairs * (size_t)w * (size_t)((h + 31) / 32 * 32) * 20);   // frames: transposed, rows padded to a whole run
   L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_G = o; o = align(o + 8 * 64 * 64 * sizeof(float));   // window matrices (2) and PolyExp matrices (6) of the current pyramid level
@@ -2504,15 +2519,17 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
       }
       stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
       // the reference's 41-tap window (winsize 40): register-window passes; any other window: one load per tap
-      const int hp = (lh + 15) / 16 * 16;
+      const int hp = (lh + FB_RUN_V - 1) / FB_RUN_V * FB_RUN_V;
       const long long v_runs = (lh + FB_RUN_V - 1) / FB_RUN_V, v_xb = (lw * 5 + 255) / 256;
       const long long h_runs = (lw + FB_RUN_H - 1) / FB_RUN_H, h_yb = (lh + 63) / 64;
-      if (win.n == 20 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)flow & 7) == 0 && n_pairs * v_runs * v_xb < 0x7fffffffLL &&
-          n_pairs * h_runs * h_yb < 0x7fffffffLL && !getenv("PV_FARNEBACK_TAP_LOADS")) {
-        hipLaunchKernelGGL((fb_blur_v_run_kernel<20, FB_RUN_V>), dim3((unsigned)(n_pairs * v_runs * v_xb)), dim3(256), 0, st,
-                           (const float*)M, V, lh, lw, hp, (int)v_runs, (int)v_xb, win);
-        hipLaunchKernelGGL((fb_blur_h_solve_run_kernel<20, FB_RUN_H>), dim3((unsigned)(n_pairs * h_runs * h_yb)), dim3(64), 0, st,
-                           (const float*)V, flow, lh, lw, hp, (int)h_runs, (int)h_yb, win);
+      const long long v_strips = n_pairs * v_xb, h_strips = n_pairs * h_yb;
+      const long long v_blocks = (v_strips + 7) / 8 * 8 * v_runs, h_blocks = (h_strips + 7) / 8 * 8 * h_runs;
+      if (win.n == 20 && ((uintptr_t)V & 15) == 0 && ((uintptr_t)flow & 7) == 0 && v_blocks < 0x7fffffffLL &&
+          h_blocks < 0x7fffffffLL && 5LL * lw * hp < 0x7fffffffLL && !getenv("PV_FARNEBACK_TAP_LOADS")) {
+        hipLaunchKernelGGL((fb_blur_v_run_kernel<20, FB_RUN_V>), dim3((unsigned)v_blocks), dim3(256), 0, st, (const float*)M, V,
+                           lh, lw, hp, (int)v_runs, (int)v_xb, v_strips, win);
+        hipLaunchKernelGGL((fb_blur_h_solve_run_kernel<20, FB_RUN_H>), dim3((unsigned)h_blocks), dim3(64), 0, st,
+                           (const float*)V, flow, lh, lw, hp, (int)h_runs, (int)h_yb, h_strips, win);
       } else {
       hipLaunchKernelGGL(fb_blur_v_kernel, dim3(stream_grid((size_t)(n_pairs * lpx * 5), 256)), dim3(256), 0, st,
                          (const float*)M, V, (long long)n_pairs, lh, lw, win);
