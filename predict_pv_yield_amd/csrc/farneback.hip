@@ -10,6 +10,7 @@
 // Stages per level:  prep (u8 -> f32, Gaussian smooth, resize)  ->  PolyExp (vertical, horizontal)
 //                    -> UpdateMatrices -> iterations x { window blur V, window blur H + 2x2 solve,
 //                    UpdateMatrices }  -> (next level) bilinear flow upsample x 1/pyr_scale.
+#include <type_traits>
 #include "pv_common.h"
 #include <stdlib.h>
 
@@ -372,6 +373,268 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
       }
     }
     __syncthreads();   // LDS is reused by the next image
+  }
+}
+
+// ---- prep + PolyExp fused for FRAMES (source images larger than a tile: the 704 x 548 images of the notebooks) ----------
+// One workgroup = one ty x tx tile of a level image.  What the tile needs of each stage lives in LDS with its halo: the
+// source window as floats -> row-filtered -> blurred (the level's Gaussian, BORDER_REFLECT_101 in image coordinates) ->
+// the level image I on the tile + poly_n rows / columns (coordinates clamped to the image: the PolyExp taps that replicate
+// the border become plain offsets) -> the vertical PolyExp planes -> R.  I and T never go to memory and every index is 32-bit
+// (the three-kernel path writes and re-reads 32 bytes per level pixel and divides 64-bit indices per pixel).  Expressions as in
+// fb_prep_kernel / fb_polyexp_v_kernel / fb_polyexp_h_kernel (double accumulators in the horizontal pass): identical bits.
+struct FbFrameTile {
+  int ty, tx;            // tile of the level image
+  int n_ty, n_tx;        // tiles per image
+  int cap_sy, cap_sx;    // capacity (rows, columns) of the source window; the other windows fit inside it
+};
+constexpr int FB_FR_NT = 512;
+__global__ __launch_bounds__(FB_FR_NT) void fb_prep_polyexp_frame_kernel(const uint8_t* __restrict__ prev,
+                                                                          const uint8_t* __restrict__ next, long long prev_stride,
+                                                                          long long next_stride, long long pairs_per_group,
+                                                                          long long group_stride, float* __restrict__ R,
+                                                                          long long n_img, int chain_f, int h, int w, int lh, int lw,
+                                                                          int mode, double inv_fx, double inv_fy, FbTaps kt, FbPoly pk,
+                                                                          FbFrameTile ft, int stage, float* __restrict__ Iimg) {
+  // stage 0: everything (levels at the source's scale).  Coarse levels, whose tile + PolyExp halo would sample a source window
+  // many times the tile: stage 1 = smoothing + resize of a tile WITHOUT halo -> the level image Iimg[n_img][lh][lw];
+  // stage 2 = both PolyExp passes from Iimg (tile + halo).
+  extern __shared__ float fr_lds[];
+  const int tid = threadIdx.x;
+  const int ks = kt.n, r = ks >> 1, n = stage == 1 ? 0 : pk.n;
+  const int cap = ft.cap_sy * ft.cap_sx;
+  float* bufA = fr_lds;                 // source window as floats, later the blurred window
+  float* bufB = fr_lds + cap;           // row-filtered window, later the level image I (tile + halo)
+  float* T0 = fr_lds + 2 * cap;         // vertical PolyExp planes [ty][tx + 2 n]
+  const int IY = ft.ty + 2 * n, IX = ft.tx + 2 * n;
+  float* T1 = T0 + ft.ty * IX;
+  float* T2 = T1 + ft.ty * IX;
+  // source row / column the level pixel (sampling mode 2) starts from, as in fb_prep_kernel
+  auto src_lo = [&](int v, double inv, int lim) {
+    float f = (float)((v + 0.5) * inv - 0.5);
+    int sv = (int)floorf(f);
+    if (sv < 0) sv = 0;
+    if (sv >= lim - 1) sv = lim - 1;
+    return sv;
+  };
+  const long long tiles_per_img = (long long)ft.n_ty * ft.n_tx;
+  for (long long t = blockIdx.x; t < n_img * tiles_per_img; t += gridDim.x) {
+    const long long im = t / tiles_per_img;
+    const int tt = (int)(t - im * tiles_per_img);
+    const int ty0 = (tt / ft.n_tx) * ft.ty, tx0 = (tt % ft.n_tx) * ft.tx;
+    const uint8_t* img = fb_image_of(im, prev, next, prev_stride, next_stride, pairs_per_group, group_stride, chain_f);
+    // level rows / columns the tile touches (clamped), the blurred rows / columns those sample, the rows / columns of the
+    // source the two filter passes read (reflections of rows beyond the border fall inside the range)
+    const int iy_lo = max(ty0 - n, 0), iy_hi = min(ty0 + ft.ty + n - 1, lh - 1);
+    const int ix_lo = max(tx0 - n, 0), ix_hi = min(tx0 + ft.tx + n - 1, lw - 1);
+    int by_lo, by_hi, bx_lo, bx_hi;
+    if (mode == 0) {
+      by_lo = iy_lo, by_hi = iy_hi, bx_lo = ix_lo, bx_hi = ix_hi;
+    } else if (mode == 1) {
+      by_lo = 2 * iy_lo, by_hi = 2 * iy_hi + 1, bx_lo = 2 * ix_lo, bx_hi = 2 * ix_hi + 1;
+    } else {
+      by_lo = src_lo(iy_lo, inv_fy, h), by_hi = min(src_lo(iy_hi, inv_fy, h) + 1, h - 1);
+      bx_lo = src_lo(ix_lo, inv_fx, w), bx_hi = min(src_lo(ix_hi, inv_fx, w) + 1, w - 1);
+    }
+    const int ry_lo = max(by_lo - r, 0), ry_hi = min(by_hi + r, h - 1);
+    const int sx_lo = max(bx_lo - r, 0), sx_hi = min(bx_hi + r, w - 1);
+    const int SY = ry_hi - ry_lo + 1, SX = sx_hi - sx_lo + 1;       // source window
+    const int BY = by_hi - by_lo + 1, BX = bx_hi - bx_lo + 1;       // blurred window
+    if (stage == 2) {   // the level image exists: tile + halo, coordinates clamped to the image
+      for (int i = tid; i < IY * IX; i += FB_FR_NT) {
+        const int yy = i / IX, xx = i - yy * IX;
+        const int y = min(max(ty0 - n + yy, 0), lh - 1), x = min(max(tx0 - n + xx, 0), lw - 1);
+        bufB[i] = Iimg[(im * lh + y) * (long long)lw + x];
+      }
+      __syncthreads();
+    } else {
+    // 1. the source window as floats
+    const unsigned inv_sx = 0xffffffffu / (unsigned)SX + 1;
+    for (int i0 = tid; i0 < SY * SX; i0 += 4 * FB_FR_NT) {   // four byte loads in flight per thread
+      uint8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * FB_FR_NT, SY * SX - 1);
+        const int y = (int)__umulhi((unsigned)i, inv_sx), x = i - y * SX;
+        v[u] = img[(size_t)(ry_lo + y) * w + sx_lo + x];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * FB_FR_NT < SY * SX) bufA[i0 + u * FB_FR_NT] = (float)v[u];
+    }
+    __syncthreads();
+    // 2. row filter on the window's rows, for the blurred window's columns (tap order of row_filter()).  Tiles whose taps stay
+    // inside the image (all but the frame's rim) with the 3- and 9-tap kernels of the reference's pyramid: no reflection, taps
+    // unrolled; flat index -> (row, column) by a multiplication with the rounded-up reciprocal (exact below 2^16 rows x columns)
+    const unsigned inv_bx = 0xffffffffu / (unsigned)BX + 1;
+    const bool inner_x = bx_lo - r >= 0 && bx_hi + r <= w - 1, inner_y = by_lo - r >= 0 && by_hi + r <= h - 1;
+    if (inner_x && ks == 3) {
+      for (int i = tid; i < SY * BX; i += FB_FR_NT) {
+        const int y = (int)__umulhi((unsigned)i, inv_bx), x = i - y * BX;
+        const float* sp = bufA + y * SX + (bx_lo - sx_lo) + x;
+        float acc = sp[0] * kt.k[1];
+        acc = __fadd_rn(acc, __fmul_rn(sp[-1] + sp[1], kt.k[2]));
+        bufB[i] = acc;
+      }
+    } else if (inner_x && ks == 9) {
+      for (int i = tid; i < SY * BX; i += FB_FR_NT) {
+        const int y = (int)__umulhi((unsigned)i, inv_bx), x = i - y * BX;
+        const float* sp = bufA + y * SX + (bx_lo - sx_lo) + x - 4;
+        float acc = sp[0] * kt.k[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) acc = __fadd_rn(acc, __fmul_rn(sp[q], kt.k[q]));
+        bufB[i] = acc;
+      }
+    } else {
+    for (int i = tid; i < SY * BX; i += FB_FR_NT) {
+      const int y = i / BX, x = i - y * BX;
+      const int ax = bx_lo + x;
+      const float* srow = bufA + y * SX - sx_lo;
+      float acc;
+      if (ks <= 5) {
+        acc = srow[ax] * kt.k[r];
+        for (int q = 1; q <= r; ++q)
+          acc = __fadd_rn(acc, __fmul_rn(srow[reflect101(ax - q, w)] + srow[reflect101(ax + q, w)], kt.k[r + q]));
+      } else {
+        acc = srow[reflect101(ax - r, w)] * kt.k[0];
+        for (int q = 1; q < ks; ++q) acc = __fadd_rn(acc, __fmul_rn(srow[reflect101(ax + q - r, w)], kt.k[q]));
+      }
+      bufB[i] = acc;
+    }
+    }
+    __syncthreads();
+    // 3. column filter -> the blurred window (over the source window, dead by now)
+    if (inner_y && ks == 3) {
+      for (int i = tid; i < BY * BX; i += FB_FR_NT) {
+        const float* cp = bufB + i + (by_lo - ry_lo) * BX;
+        float acc = __fmul_rn(cp[0], kt.k[1]);
+        acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(cp[-BX], cp[BX]), kt.k[2]));
+        bufA[i] = acc;
+      }
+    } else if (inner_y && ks == 9) {
+      for (int i = tid; i < BY * BX; i += FB_FR_NT) {
+        const float* cp = bufB + i + (by_lo - ry_lo) * BX;
+        float acc = __fmul_rn(cp[0], kt.k[4]);
+#pragma unroll
+        for (int q = 1; q <= 4; ++q) acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(cp[-q * BX], cp[q * BX]), kt.k[4 + q]));
+        bufA[i] = acc;
+      }
+    } else {
+    for (int i = tid; i < BY * BX; i += FB_FR_NT) {
+      const int y = i / BX, x = i - y * BX;
+      const int ay = by_lo + y;
+      const float* col = bufB + x - ry_lo * BX;
+      float acc = __fmul_rn(col[ay * BX], kt.k[r]);
+      for (int q = 1; q <= r; ++q) {
+        const float a = col[reflect101(ay - q, h) * BX], b = col[reflect101(ay + q, h) * BX];
+        acc = __fadd_rn(acc, __fmul_rn(__fadd_rn(a, b), kt.k[r + q]));
+      }
+      bufA[i] = acc;
+    }
+    }
+    __syncthreads();
+    // 4. the level image on the tile + halo, coordinates clamped to the image (into the row-filtered window's buffer)
+    const float* bl = bufA - by_lo * BX - bx_lo;    // blurred(y, x) = bl[y * BX + x]
+    const unsigned inv_ix4 = 0xffffffffu / (unsigned)IX + 1;
+    for (int i = tid; i < IY * IX; i += FB_FR_NT) {
+      const int yy = (int)__umulhi((unsigned)i, inv_ix4), xx = i - yy * IX;
+      const int y = min(max(ty0 - n + yy, 0), lh - 1), x = min(max(tx0 - n + xx, 0), lw - 1);
+      float v;
+      if (mode == 0) {
+        v = bl[y * BX + x];
+      } else if (mode == 1) {
+        const float a = __fadd_rn(bl[(2 * y) * BX + 2 * x], bl[(2 * y) * BX + 2 * x + 1]);
+        const float b = __fadd_rn(bl[(2 * y + 1) * BX + 2 * x], bl[(2 * y + 1) * BX + 2 * x + 1]);
+        v = __fmul_rn(__fadd_rn(a, b), 0.25f);
+      } else {
+        float fx = (float)((x + 0.5) * inv_fx - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= w - 1) { fx = 0; sx = w - 1; }
+        float fy = (float)((y + 0.5) * inv_fy - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        if (sy < 0) { fy = 0; sy = 0; }
+        if (sy >= h - 1) { fy = 0; sy = h - 1; }
+        const int sy1 = clampi_d(sy + 1, 0, h - 1);
+        float r0, r1;
+        if (sx + 1 < w) {
+          const float a0 = 1.f - fx, a1 = fx;
+          r0 = __fadd_rn(__fmul_rn(bl[sy * BX + sx], a0), __fmul_rn(bl[sy * BX + sx + 1], a1));
+          r1 = __fadd_rn(__fmul_rn(bl[sy1 * BX + sx], a0), __fmul_rn(bl[sy1 * BX + sx + 1], a1));
+        } else {
+          r0 = bl[sy * BX + sx];
+          r1 = bl[sy1 * BX + sx];
+        }
+        v = __fadd_rn(__fmul_rn(r0, 1.f - fy), __fmul_rn(r1, fy));
+      }
+      if (stage == 1) {
+        if (ty0 + yy < lh && tx0 + xx < lw) Iimg[(im * lh + ty0 + yy) * (long long)lw + tx0 + xx] = v;
+      } else {
+        bufB[i] = v;
+      }
+    }
+    __syncthreads();
+    if (stage == 1) continue;
+    }
+    // 5. PolyExp, vertical pass on the tile's rows, every column of the halo (taps unrolled for the reference's poly_n = 5)
+    const unsigned inv_ix = 0xffffffffu / (unsigned)IX + 1, inv_tx = 0xffffffffu / (unsigned)ft.tx + 1;
+    auto vertical = [&](auto nn) __attribute__((always_inline)) {
+      constexpr int NN = decltype(nn)::value;
+      const int nt = NN ? NN : n;
+      for (int i = tid; i < ft.ty * IX; i += FB_FR_NT) {
+        const int y = (int)__umulhi((unsigned)i, inv_ix);
+        const float* c = bufB + i + n * IX;
+        float t0 = __fmul_rn(c[0], pk.g[0]), t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= nt; ++k) {
+          const float s0 = c[-k * IX];
+          const float s1 = c[k * IX];
+          const float pp = __fadd_rn(s0, s1);
+          t0 = __fadd_rn(t0, __fmul_rn(pk.g[k], pp));
+          t1 = __fadd_rn(t1, __fmul_rn(pk.xg[k], __fsub_rn(s1, s0)));
+          t2 = __fadd_rn(t2, __fmul_rn(pk.xxg[k], pp));
+        }
+        (void)y;
+        T0[i] = t0, T1[i] = t1, T2[i] = t2;
+      }
+    };
+    if (n == 5) vertical(std::integral_constant<int, 5>{}); else vertical(std::integral_constant<int, 0>{});
+    __syncthreads();
+    // 6. PolyExp, horizontal pass (the reference's double accumulators) -> R[img][lh][lw][5]
+    auto horizontal = [&](auto nn) __attribute__((always_inline)) {
+      constexpr int NN = decltype(nn)::value;
+      const int nt = NN ? NN : n;
+      for (int i = tid; i < ft.ty * ft.tx; i += FB_FR_NT) {
+        const int y = (int)__umulhi((unsigned)i, inv_tx), x = i - y * ft.tx;
+        if (ty0 + y >= lh || tx0 + x >= lw) continue;
+        const float* t0r = T0 + y * IX + x + n;
+        const float* t1r = T1 + y * IX + x + n;
+        const float* t2r = T2 + y * IX + x + n;
+        float g0 = pk.g[0];
+        double b1 = __fmul_rn(t0r[0], g0), b2 = 0, b3 = __fmul_rn(t1r[0], g0), b4 = 0, b5 = __fmul_rn(t2r[0], g0), b6 = 0;
+#pragma unroll
+        for (int k = 1; k <= nt; ++k) {
+          const double tg = (double)__fadd_rn(t0r[k], t0r[-k]);
+          g0 = pk.g[k];
+          b1 = __dadd_rn(b1, __dmul_rn(tg, (double)g0));
+          b4 = __dadd_rn(b4, __dmul_rn(tg, (double)pk.xxg[k]));
+          b2 = __dadd_rn(b2, (double)__fmul_rn(__fsub_rn(t0r[k], t0r[-k]), pk.xg[k]));
+          b3 = __dadd_rn(b3, (double)__fmul_rn(__fadd_rn(t1r[k], t1r[-k]), g0));
+          b6 = __dadd_rn(b6, (double)__fmul_rn(__fsub_rn(t1r[k], t1r[-k]), pk.xg[k]));
+          b5 = __dadd_rn(b5, (double)__fmul_rn(__fadd_rn(t2r[k], t2r[-k]), g0));
+        }
+        float* d = R + ((im * lh + ty0 + y) * (long long)lw + tx0 + x) * 5;
+        d[1] = (float)__dmul_rn(b2, pk.ig11);
+        d[0] = (float)__dmul_rn(b3, pk.ig11);
+        d[3] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b4, pk.ig33));
+        d[2] = (float)__dadd_rn(__dmul_rn(b1, pk.ig03), __dmul_rn(b5, pk.ig33));
+        d[4] = (float)__dmul_rn(b6, pk.ig55);
+      }
+    };
+    if (n == 5) horizontal(std::integral_constant<int, 5>{}); else horizontal(std::integral_constant<int, 0>{});
+    __syncthreads();   // LDS is reused by the next tile
   }
 }
 
@@ -2407,6 +2670,35 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                               (((uintptr_t)prev | (uintptr_t)next | (uintptr_t)prev_stride | (uintptr_t)next_stride |
                                 (uintptr_t)group_stride) & 7) == 0 &&
                               !getenv("PV_FARNEBACK_POLYEXP_VALU") && !getenv("PV_FARNEBACK_POLYEXP_F64");
+    // frames: a tile of the level image per workgroup, its stages in LDS (fb_prep_polyexp_frame_kernel).  Levels at the source's
+    // scale: one launch.  Coarse levels: smoothing + resize of tiles without halo -> I, then PolyExp from I (a tile + PolyExp halo
+    // of a coarse level would filter a source window many times the tile).  Tiles: the largest of a short list whose windows fit
+    // 150 KB (a level that samples the source very sparsely keeps the three kernels).
+    FbFrameTile frame_tile = {0, 0, 0, 0, 0, 0}, frame_tile_poly = {0, 0, 0, 0, 0, 0};
+    size_t frame_lds = 0, frame_lds_poly = 0;
+    if (!polyexp_tile && !getenv("PV_FARNEBACK_THREE_KERNEL_POLYEXP")) {
+      static const int cand[][2] = {{32, 64}, {16, 64}, {16, 32}, {8, 32}, {8, 16}};
+      const int halo = mode == 0 ? pk.n : 0;
+      // the largest tile whose windows leave room for two workgroups per CU (75 KB); failing that, the largest that fits at all
+      for (size_t limit : {(size_t)75 * 1024, (size_t)150 * 1024}) {
+        for (auto& c : cand) {
+          const int ty = c[0], tx = c[1], IY = ty + 2 * halo, IX = tx + 2 * halo, r = smooth_sz >> 1;
+          const int by = mode == 0 ? IY : (mode == 1 ? 2 * IY : (int)ceil(IY * inv_fy) + 3);
+          const int bx = mode == 0 ? IX : (mode == 1 ? 2 * IX : (int)ceil(IX * inv_fx) + 3);
+          const int cap_sy = by + 2 * r, cap_sx = std::max(bx + 2 * r, (IY * IX + by + 2 * r - 1) / (by + 2 * r));
+          const size_t words = 2 * (size_t)cap_sy * cap_sx + (mode == 0 ? 3 * (size_t)ty * IX : 0);   // (the T planes: stage 0 only)
+          if (words * 4 <= limit) {
+            frame_tile = {ty, tx, (lh + ty - 1) / ty, (lw + tx - 1) / tx, cap_sy, cap_sx};
+            frame_lds = words * 4;
+            break;
+          }
+        }
+        if (frame_tile.ty) break;
+      }
+      const int ty = 32, tx = 64, IY = ty + 2 * pk.n, IX = tx + 2 * pk.n;
+      frame_tile_poly = {ty, tx, (lh + ty - 1) / ty, (lw + tx - 1) / tx, IY, IX};
+      frame_lds_poly = (2 * (size_t)IY * IX + 3 * (size_t)ty * IX) * 4;
+    }
     if (polyexp_mfma) {
       // the two PolyExp passes as nine products on the f16 matrix cores (fb_prep_polyexp_mfma_kernel)
       float* P6 = (float*)(ws + L.off_G) + 2 * 64 * 64;
@@ -2434,6 +2726,19 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
         hipLaunchKernelGGL(fb_prep_polyexp_tile_kernel<false>, dim3(grid), dim3(FB_PP_NT), 0, st, prev, next, (long long)prev_stride,
                            (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, R,
                            n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, iter_v2 ? 1 : 0);
+    } else if (frame_tile.ty > 0) {
+      auto launch = [&](const FbFrameTile& ft, size_t lds, int stage) {
+        const long long n_tiles = n_img * ft.n_ty * ft.n_tx;
+        if (hipFuncSetAttribute((const void*)fb_prep_polyexp_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)std::max(frame_lds, frame_lds_poly)) != hipSuccess) return false;
+        hipLaunchKernelGGL(fb_prep_polyexp_frame_kernel, dim3((unsigned)std::min<long long>(n_tiles, 16 * kNumCU)), dim3(FB_FR_NT),
+                           lds, st, prev, next, (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group,
+                           (long long)group_stride, R, n_img, chain_f, h, w, lh, lw, mode, inv_fx, inv_fy, sm, pk, ft, stage, I);
+        return true;
+      };
+      const bool ok = mode == 0 ? launch(frame_tile, frame_lds, 0)
+                                : launch(frame_tile, frame_lds, 1) && launch(frame_tile_poly, frame_lds_poly, 2);
+      PV_REQUIRE(ok, PV_ELAUNCH, "pv_farneback_batch_u8: LDS size refused");
     } else {
     hipLaunchKernelGGL(fb_prep_kernel, dim3(stream_grid((size_t)(n_img * lpx), 256)), dim3(256), 0, st, prev, next,
                        (long long)prev_stride, (long long)next_stride, (long long)pairs_per_group, (long long)group_stride, I,

@@ -209,6 +209,29 @@ def test_frame_window_blur_in_register_windows_is_bit_identical_to_one_load_per_
     assert torch.equal(fast, slow)
 
 
+@pytest.mark.parametrize("h,w,n,kw", [
+    (548, 704, 2, {}),                                   # the notebooks' frames: levels at scale 1, 1/2 (2 x 2 mean), 1/4 (bilinear)
+    (160, 200, 2, {}),
+    (131, 70, 3, {}),                                    # odd sizes: the coarse level is no exact half
+    (97, 150, 2, dict(pyr_scale=0.7, levels=3)),         # every coarse level resampled bilinearly, 5- and 7-tap smoothing
+    (200, 120, 1, dict(poly_n=7, poly_sigma=1.5, levels=1)),
+])
+def test_frame_prep_polyexp_in_one_kernel_is_bit_identical_to_the_three_kernels(device, monkeypatch, h, w, n, kw):
+    """Frames larger than a tile: smoothing, resize and both PolyExp passes of a level as ONE launch with the stages in LDS
+    (fb_prep_polyexp_frame_kernel) against the three global-memory kernels: same expressions, same bits in the flow."""
+    K = _ops()
+    rng = np.random.default_rng(h * 1000 + w)
+    u8 = torch.from_numpy(rng.integers(0, 256, (n + 1, h, w), dtype=np.uint8)).to(device)
+    fused = K.farneback_stack(u8, **kw)
+    pairs = K.farneback_pairs(u8[:-1].contiguous(), u8[1:].contiguous(), **kw)     # unchained image indexing
+    monkeypatch.setenv("PV_FARNEBACK_THREE_KERNEL_POLYEXP", "1")
+    three = K.farneback_stack(u8, **kw)
+    monkeypatch.delenv("PV_FARNEBACK_THREE_KERNEL_POLYEXP")
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, three)
+    assert torch.equal(fused, pairs)
+
+
 def test_farneback_stack_and_params(device):
     K = _ops()
     raw, _ = advected_counts(batch=1, t=5, channels=2, h=64, w=64, seed=5)
