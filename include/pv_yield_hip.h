@@ -504,6 +504,15 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
                          const float* dx_add, void* stream);
 /* accumulate != 0: dw, db += (see pv_sum_slabs_acc_f32); db == dw + d: one launch; dx_add (may be NULL): dx = ... + dx_add,
  * the gradient that reaches x past the block (the residual branch of `fn(norm(x)) + x`) folded into this kernel's store */
+/* The same two sums for the LayerNorm of a cross-attention's context (PreNorm.norm_context -> Attention.to_kv,
+ * perceiver_pytorch as used by predict_pv_yield/models/perceiver/perceiver.py:119-131) straight from the gradient of the
+ * projection, when x itself needs no gradient: dy = dkv16 [rows, kdim] (bf16, as pv_attention_bwd_bf16kv16 stores it) times
+ * the Linear weight w_kv [kdim, d] (rounded to bf16: the operands of pv_gemm_ex_f32 with PV_GEMM_BF16_OPERANDS) is formed per
+ * 32-row block on the matrix cores and folded into dw / db at once -- dy [rows, d] is never written.  d <= 64, kdim 64 | 128. */
+int pv_layernorm_bwd_params_from_proj_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
+int pv_layernorm_bwd_params_from_proj_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean,
+                                           const float* rstd, float* dw, float* db, int64_t rows, int32_t d, int32_t kdim,
+                                           void* ws, size_t ws_bytes, int32_t accumulate, void* stream);
 /* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
  * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);

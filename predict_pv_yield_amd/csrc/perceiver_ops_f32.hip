@@ -405,6 +405,99 @@ static int ln_blocks(long long rows, int* rows_per_block) {
   return (int)((rows + per - 1) / per);
 }
 
+// ---- d(LayerNorm weight, bias) of a normalised context straight from the gradient of its bf16 projection -----------------
+// A cross-attention's context goes  x -> LayerNorm -> ctx -> to_kv (bias-free Linear) -> K | V.  When x needs no gradient (the
+// images of a Perceiver), the backward of that chain needs from d(K | V) only dW_kv and (d gamma, d beta) -- d ctx = dKV W is an
+// intermediate of [rows, d] floats (0.38 GB for experiments/003's 2.5 M-row context) that the two-kernel form writes (GEMM) and
+// reads back together with x (LayerNorm backward).  Here a wave forms d ctx for 32 rows on the matrix cores (A = the bf16
+// gradient rows as they are, B = W rounded to bf16 once, in LDS for the whole kernel: the values the one-term GEMM uses) and
+// folds it in the accumulators into the column sums  d gamma[n] += d ctx[r, n] xhat[r, n],  d beta[n] += d ctx[r, n].
+// Reads: 2 kdim + 4 d + 8 bytes per row.  Sums: per lane over its rows in order, then halves, waves (LDS), workgroups
+// (pv_sum_slabs order) -- a fixed order.
+constexpr int LPB_KMAX = 128;                 // kdim <= 128 (eight 16-deep steps)
+constexpr int LPB_BRS = 2 * LPB_KMAX + 16;    // bytes per n-row of W^T in LDS (the 16-byte pad walks the banks)
+template <int KSTEPS>
+__global__ __launch_bounds__(256, 2) void layernorm_bwd_params_from_proj_kernel(const uint16_t* __restrict__ g16,
+                                                                                const float* __restrict__ wkv,
+                                                                                const float* __restrict__ x,
+                                                                                const float* __restrict__ mean,
+                                                                                const float* __restrict__ rstd,
+                                                                                float* __restrict__ part, long long rows, int d,
+                                                                                long long n_rowblocks) {
+  typedef __attribute__((ext_vector_type(16))) float v16f;
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[64 * LPB_BRS];
+  __shared__ float red[4][2][64];
+  constexpr int kdim = 16 * KSTEPS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // W^T as bf16: Bs[n][k] = bf16(W[k][n]) for the Linear weight W [kdim, d] (n >= d: zero)
+  for (int i = tid; i < 64 * kdim; i += 256) {
+    const int n = i / kdim, k = i - n * kdim;
+    const float v = n < d ? wkv[(size_t)k * d + n] : 0.f;
+    *reinterpret_cast<uint16_t*>(Bs + n * LPB_BRS + 2 * k) = f32_to_bf16_bits(v);
+  }
+  __syncthreads();
+  const int row = lane & 31, half = lane >> 5;
+  const int n0 = row, n1 = 32 + row;
+  float dg0 = 0.f, db0 = 0.f, dg1 = 0.f, db1 = 0.f;
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long rb = (long long)blockIdx.x * 4 + wave; rb < n_rowblocks; rb += stride) {
+    const long long r0 = rb * 32;
+    // A: lane (row, half) holds k = 16 ks + 8 half .. + 7 of its row: one 16-byte load per step
+    const long long ar = r0 + row < rows ? r0 + row : rows - 1;
+    const u32x4* ap = reinterpret_cast<const u32x4*>(g16 + ar * kdim + 8 * half);
+    u32x4 a[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) a[ks] = ap[2 * ks];
+    // the rows' statistics and x at the accumulators' positions: row 8 (i / 4) + 4 half + i % 4, columns n0 | n1
+    float mu[16], rs[16], x0[16], x1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long r = r0 + 8 * (i >> 2) + 4 * half + (i & 3);
+      const bool ok = r < rows;
+      const long long rc = ok ? r : rows - 1;
+      mu[i] = mean[rc];
+      rs[i] = ok ? rstd[rc] : 0.f;             // (a row beyond the end: xhat = 0 and its d ctx is masked below)
+      x0[i] = n0 < d ? x[rc * d + n0] : 0.f;
+      x1[i] = n1 < d ? x[rc * d + n1] : 0.f;
+    }
+    v16f acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0.f, acc1[i] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const bf16x8 av = __builtin_bit_cast(bf16x8, a[ks]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(Bs + n0 * LPB_BRS + 32 * ks + 16 * half), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *reinterpret_cast<const bf16x8*>(Bs + n1 * LPB_BRS + 32 * ks + 16 * half), acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool ok = r0 + 8 * (i >> 2) + 4 * half + (i & 3) < rows;
+      const float g0 = ok ? acc0[i] : 0.f, g1 = ok ? acc1[i] : 0.f;
+      dg0 += g0 * ((x0[i] - mu[i]) * rs[i]);
+      db0 += g0;
+      dg1 += g1 * ((x1[i] - mu[i]) * rs[i]);
+      db1 += g1;
+    }
+  }
+  // halves of a wave (the two lanes of a column), then the four waves
+  dg0 += __shfl_xor(dg0, 32), db0 += __shfl_xor(db0, 32), dg1 += __shfl_xor(dg1, 32), db1 += __shfl_xor(db1, 32);
+  if (half == 0) {
+    red[wave][0][n0] = dg0, red[wave][1][n0] = db0;
+    red[wave][0][n1] = dg1, red[wave][1][n1] = db1;
+  }
+  __syncthreads();
+  if (tid < 2 * d) {
+    const int which = tid / d, n = tid - which * d;
+    part[(size_t)blockIdx.x * 2 * d + tid] = ((red[0][which][n] + red[1][which][n]) + red[2][which][n]) + red[3][which][n];
+  }
+}
+
+static int lpb_blocks(long long rows) {
+  const long long rbs = (rows + 31) / 32;
+  return (int)std::min<long long>((rbs + 3) / 4, 2 * kNumCU);
+}
+
+
 }  // namespace pv
 
 using namespace pv;
@@ -470,6 +563,39 @@ int pv_layernorm_bwd_f32(const float* x, const float* w, const float* dy, const 
     launch_sum_slabs(part, db, d, nbl, 2 * d, d, st, accumulate);
   }
   return check_launch("pv_layernorm_bwd_f32");
+}
+
+int pv_layernorm_bwd_params_from_proj_workspace_bytes(int64_t rows, int32_t d, size_t* bytes) {
+  PV_REQUIRE(bytes && rows > 0 && d > 0, PV_EINVAL, "pv_layernorm_bwd_params_from_proj_workspace_bytes: bad arguments");
+  *bytes = (size_t)lpb_blocks(rows) * 2 * d * sizeof(float);
+  return PV_OK;
+}
+
+int pv_layernorm_bwd_params_from_proj_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean,
+                                           const float* rstd, float* dw, float* db, int64_t rows, int32_t d, int32_t kdim,
+                                           void* ws, size_t ws_bytes, int32_t accumulate, void* stream) {
+  PV_REQUIRE(dkv16 && w_kv && x && mean && rstd && dw && db, PV_EINVAL, "pv_layernorm_bwd_params_from_proj_bf16: null pointer");
+  PV_REQUIRE(rows > 0 && d > 0 && d <= 64, PV_ESIZE, "pv_layernorm_bwd_params_from_proj_bf16: d=%d must be in 1..64", d);
+  PV_REQUIRE(kdim == 64 || kdim == 128, PV_ESIZE, "pv_layernorm_bwd_params_from_proj_bf16: kdim=%d must be 64 or 128", kdim);
+  PV_REQUIRE(((uintptr_t)dkv16 & 15) == 0, PV_EINVAL, "pv_layernorm_bwd_params_from_proj_bf16: gradient rows must be 16-byte aligned");
+  const int nb = lpb_blocks(rows);
+  PV_REQUIRE(ws && ws_bytes >= (size_t)nb * 2 * d * sizeof(float), PV_EINVAL, "pv_layernorm_bwd_params_from_proj_bf16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* part = (float*)ws;
+  const long long rbs = (rows + 31) / 32;
+  if (kdim == 128)
+    hipLaunchKernelGGL(layernorm_bwd_params_from_proj_kernel<8>, dim3((unsigned)nb), dim3(256), 0, st, dkv16, w_kv, x, mean, rstd,
+                       part, (long long)rows, d, rbs);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_params_from_proj_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, dkv16, w_kv, x, mean, rstd,
+                       part, (long long)rows, d, rbs);
+  if (db == dw + d) {
+    launch_sum_slabs(part, dw, 2 * d, nb, 2 * d, 0, st, accumulate);
+  } else {
+    launch_sum_slabs(part, dw, d, nb, 2 * d, 0, st, accumulate);
+    launch_sum_slabs(part, db, d, nb, 2 * d, d, st, accumulate);
+  }
+  return check_launch("pv_layernorm_bwd_params_from_proj_bf16");
 }
 
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream) {

@@ -1014,6 +1014,40 @@ def layernorm_bwd(x, w, dy, mean, rstd, need_dx: bool = True, accumulate_into=No
     return dx, dw, db
 
 
+def layernorm_bwd_params_from_proj_supported(dkv16: torch.Tensor, w_kv: torch.Tensor, x: torch.Tensor) -> bool:
+    return (dkv16.dtype == torch.bfloat16 and dkv16.is_contiguous() and w_kv.is_contiguous() and x.is_contiguous()
+            and x.dtype == torch.float32 and w_kv.dtype == torch.float32 and w_kv.shape[0] in (64, 128)
+            and x.shape[-1] == w_kv.shape[1] <= 64 and dkv16.shape[-1] == w_kv.shape[0]
+            and dkv16.numel() // dkv16.shape[-1] == x.numel() // x.shape[-1] and dkv16.data_ptr() % 16 == 0)
+
+
+def layernorm_bwd_params_from_proj(dkv16, w_kv, x, mean, rstd, accumulate_into=None):
+    """(dw, db) of the LayerNorm in  x -> LayerNorm -> to_kv  from the bf16 gradient of the projection, d(LayerNorm output)
+    never materialised (pv_layernorm_bwd_params_from_proj_bf16).  dw / db as layernorm_bwd returns them."""
+    require_cuda(dkv16, w_kv, x, mean, rstd)
+    if not layernorm_bwd_params_from_proj_supported(dkv16, w_kv, x):
+        raise ValueError("layernorm_bwd_params_from_proj: bf16 gradient rows [rows, 64 | 128], f32 weight [kdim, d <= 64], f32 x")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    nbytes = ctypes.c_size_t(0)
+    check(get_lib().pv_layernorm_bwd_params_from_proj_workspace_bytes(rows, d, ctypes.byref(nbytes)),
+          "pv_layernorm_bwd_params_from_proj_workspace_bytes")
+    ws = _workspace("layernorm_bwd_proj", nbytes.value, x.device)
+    if accumulate_into is not None:
+        dw, db = accumulate_into
+    elif d % 4 == 0:
+        dwdb = torch.empty(2 * d, dtype=torch.float32, device=x.device)
+        dw, db = dwdb[:d], dwdb[d:]
+    else:
+        dw = torch.empty(d, dtype=torch.float32, device=x.device)
+        db = torch.empty(d, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_layernorm_bwd_params_from_proj_bf16(ptr(dkv16), ptr(w_kv), ptr(x), ptr(mean), ptr(rstd), ptr(dw), ptr(db),
+                                                           rows, d, w_kv.shape[0], ptr(ws), nbytes.value,
+                                                           int(accumulate_into is not None), current_stream_ptr()),
+          "pv_layernorm_bwd_params_from_proj_bf16")
+    return dw, db
+
+
 def softmax_fwd_(x: torch.Tensor, scale: float) -> torch.Tensor:
     """In place: x <- softmax(scale * x) over the last dimension (contiguous)."""
     require_cuda(x)

@@ -65,6 +65,12 @@ FUSE_RESIDUALS = True   # `fn(norm(x)) + x`: by-pass added in fn's last GEMM epi
 
 KV_STORED_AS_BF16 = True      # tools/ab-style switch: False = f32 K / V in memory, rounded inside the attention kernels
 LINEARS_FOLLOW_OPERAND_DTYPE = True      # False: the Linears keep f32-accurate products in "bf16" mode (rounds 2-3)
+NORM_CONTEXT_IN_THE_ATTENTION_NODE = True      # False: norm_context as its own node (d(normalised context) through memory)
+
+
+def _query_probe(x: torch.Tensor, block) -> torch.Tensor:
+    """The shape the block's queries will have (a meta tensor: the fused node's shape rules look at nothing else of q)."""
+    return torch.empty((x.shape[0], x.shape[1], block.fn.to_q.weight.shape[0]), device="meta")
 
 
 def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: bool = False, residual=None) -> torch.Tensor:
@@ -72,6 +78,16 @@ def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: 
     `residual` (the block's `+ x`) is added in the epilogue of to_out."""
     q = PF.linear(xn, attn.to_q.weight)                                  # [b, i, inner]
     out = PF.attention_core(q, kv, attn.heads, attn.scale, bf16_operands=bf16_operands)   # softmax(scale q k^T) v, per head
+    return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
+
+
+def _attend_raw_context(block: "PreNorm", xn: torch.Tensor, data: torch.Tensor, residual=None) -> torch.Tensor:
+    """_attend_context given the context BEFORE its LayerNorm (a context that takes no gradient: the images): norm_context,
+    to_kv and the attention as one node, whose backward forms the LayerNorm's parameter gradients straight from d(K | V)."""
+    attn = block.fn
+    q = PF.linear(xn, attn.to_q.weight)
+    out = PF.cross_attention_norm_kv16(q, data, block.norm_context.weight, block.norm_context.bias, block.norm_context.eps,
+                                       attn.to_kv.weight, attn.heads, attn.scale)
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
 
 
@@ -172,16 +188,22 @@ class Perceiver(nn.Module):
         x = self.latents.unsqueeze(0).expand(b, -1, -1)
         kv_of = {}                                                         # cross-attention block -> projected context
         ctx_of = {}                                                        # ... -> normalised context (one-consumer blocks)
+        raw_of = {}                                                        # ... -> the context before its LayerNorm (one consumer, no gradient)
         uses = {}
         for cross_attn, _, _ in self.layers:
             uses[id(cross_attn)] = uses.get(id(cross_attn), 0) + 1
         bf = self.operand_dtype == "bf16"
         for cross_attn, cross_ff, self_attns in self.layers:
             key = id(cross_attn)
-            if key not in kv_of and key not in ctx_of:
+            one_use = bf and KV_STORED_AS_BF16 and LINEARS_FOLLOW_OPERAND_DTYPE and uses[key] == 1
+            if (one_use and NORM_CONTEXT_IN_THE_ATTENTION_NODE and key not in raw_of and
+                    PF.cross_attention_norm_kv16_supported(_query_probe(x, cross_attn), data, cross_attn.norm_context.weight,
+                                                           cross_attn.fn.to_kv.weight, cross_attn.fn.heads)):
+                raw_of[key] = data
+            if key not in kv_of and key not in ctx_of and key not in raw_of:
                 ctx = PF.layer_norm(data, cross_attn.norm_context.weight, cross_attn.norm_context.bias,
                                     cross_attn.norm_context.eps)
-                if bf and KV_STORED_AS_BF16 and LINEARS_FOLLOW_OPERAND_DTYPE and uses[key] == 1:
+                if one_use:
                     # a context ONE layer consumes: to_kv and the attention run as one node (PF.cross_attention_kv16), K / V
                     # and their gradient bf16 between the kernels
                     ctx_of[key] = ctx
@@ -194,11 +216,13 @@ class Perceiver(nn.Module):
             # backward kernel's store (backward) -- no elementwise launches
             if FUSE_RESIDUALS:
                 xn, x_pass = PF.layer_norm_fork(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-                x = (_attend_context(cross_attn.fn, xn, ctx_of[key], residual=x_pass) if key in ctx_of else
+                x = (_attend_raw_context(cross_attn, xn, raw_of[key], residual=x_pass) if key in raw_of else
+                     _attend_context(cross_attn.fn, xn, ctx_of[key], residual=x_pass) if key in ctx_of else
                      _attend(cross_attn.fn, xn, kv_of[key], bf, residual=x_pass))
             else:
                 xn = PF.layer_norm(x, cross_attn.norm.weight, cross_attn.norm.bias, cross_attn.norm.eps)
-                x = (_attend_context(cross_attn.fn, xn, ctx_of[key]) if key in ctx_of else
+                x = (_attend_raw_context(cross_attn, xn, raw_of[key]) if key in raw_of else
+                     _attend_context(cross_attn.fn, xn, ctx_of[key]) if key in ctx_of else
                      _attend(cross_attn.fn, xn, kv_of[key], bf)) + x
             x = _feed_forward(cross_ff, x)
             for self_attn, self_ff in self_attns:

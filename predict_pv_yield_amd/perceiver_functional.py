@@ -224,6 +224,64 @@ class CrossAttentionKV16(torch.autograd.Function):
         return dq, dc, dw, None, None
 
 
+class CrossAttentionNormKV16(torch.autograd.Function):
+    """CrossAttentionKV16 with the context's LayerNorm inside the node, for a context that needs no gradient itself (the
+    images): norm_context + to_kv + attention.  The backward then needs from d(K | V) only dW_kv and the LayerNorm's
+    (d weight, d bias), and those two sums are formed straight from the bf16 gradient rows
+    (K.layernorm_bwd_params_from_proj: the product dKV W per 32-row block on the matrix cores, folded into the sums in the
+    accumulators) -- the [rows, d] gradient of the normalised context is neither written by a GEMM nor read back by a LayerNorm
+    backward."""
+
+    @staticmethod
+    def forward(ctx, q, data, ln_w, ln_b, eps, w_kv, heads, scale):
+        q = q.contiguous()
+        x = data.contiguous()
+        y, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, eps)
+        c2 = y.view(-1, y.shape[-1])
+        kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(x.shape[:-1] + (w_kv.shape[0],))
+        out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
+        ctx.save_for_backward(q, x, ln_w, mean, rstd, c2, w_kv, kv16, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, x, ln_w, mean, rstd, c2, w_kv, kv16, out, lse = ctx.saved_tensors
+        dq, dkv16 = K.attention_bwd(q, kv16, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=True, dkv_bf16=True)
+        g2 = dkv16.view(-1, w_kv.shape[0])
+        key, acc = _tied_slot(w_kv)
+        if acc is not None:
+            K.gemm_splitk(g2.t(), c2, accumulate_into=acc, bf16_operands=True)
+            dw = None
+        else:
+            dw = K.gemm_splitk(g2.t(), c2, bf16_operands=True)
+            _tied_keep(key, dw)
+        nkey, nacc = _tied_slot(ln_w)
+        if nacc is not None:
+            K.layernorm_bwd_params_from_proj(g2, w_kv, x, mean, rstd, accumulate_into=nacc)
+            dlw = dlb = None
+        else:
+            dlw, dlb = K.layernorm_bwd_params_from_proj(g2, w_kv, x, mean, rstd)
+            _tied_keep(nkey, (dlw, dlb))
+        return dq, None, dlw, dlb, None, dw, None, None
+
+
+def cross_attention_norm_kv16_supported(q, data, ln_w, w_kv, heads) -> bool:
+    """The fused node's shape rules, plus: the un-normalised context takes no gradient and the LayerNorm is narrow enough for
+    the accumulator-side sums (d <= 64)."""
+    if data.requires_grad or not data.is_contiguous() or data.dtype != torch.float32 or data.shape[-1] > 64:
+        return False
+    if w_kv.shape[0] not in (64, 128) or not w_kv.is_contiguous() or ln_w.shape[0] != data.shape[-1]:
+        return False
+    return cross_attention_kv16_supported(q, data, w_kv, heads)
+
+
+def cross_attention_norm_kv16(q, data, ln_w, ln_b, eps, w_kv, heads, scale):
+    _note_use(w_kv)
+    _note_use(ln_w)
+    return CrossAttentionNormKV16.apply(q, data, ln_w, ln_b, eps, w_kv, heads, scale)
+
+
 def cross_attention_kv16_supported(q, context, w_kv, heads) -> bool:
     c2 = context.reshape(-1, context.shape[-1]) if context.is_contiguous() else None
     return (c2 is not None and K.gemm_rows_bf16out_supported(c2, w_kv.t()) and w_kv.shape[0] == 2 * q.shape[-1]

@@ -113,6 +113,70 @@ def test_bf16_stored_key_value_gradients_feed_the_bf16_operand_products_unchange
         K.gemm(g16, w)
 
 
+@pytest.mark.parametrize("rows,d,kdim", [(70_000, 38, 128), (4097, 38, 128), (33, 64, 64), (100_003, 20, 128)])
+def test_layernorm_parameter_gradients_straight_from_the_projection_gradient(device, rows, d, kdim):
+    """pv_layernorm_bwd_params_from_proj_bf16 against the two kernels it replaces (d ctx = dKV W as a bf16-operand GEMM, then the
+    LayerNorm backward's two column sums): the same products and the same f32 d ctx, summed in another (fixed) order."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(device)
+    lw = (1 + 0.1 * torch.randn(d, generator=g)).to(device)
+    lb = (0.1 * torch.randn(d, generator=g)).to(device)
+    w = (torch.randn(kdim, d, generator=g) * 0.2).to(device)
+    g16 = torch.randn(rows, kdim, generator=g).to(device).to(torch.bfloat16)
+    _, mean, rstd = K.layernorm_fwd(x, lw, lb, 1e-5)
+    dctx = K.gemm(g16, w, bf16_operands=True)
+    _, dw_ref, db_ref = K.layernorm_bwd(x, lw, dctx, mean, rstd, need_dx=False)
+    assert K.layernorm_bwd_params_from_proj_supported(g16, w, x)
+    dw, db = K.layernorm_bwd_params_from_proj(g16, w, x, mean, rstd)
+    # f64 reference of the same sums: both forms must sit within f32 summation error of it
+    xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    dw64, db64 = (dctx.double() * xh).sum(0), dctx.double().sum(0)
+    scale_w = (dctx.double() * xh).abs().sum(0).max().item()
+    scale_b = dctx.double().abs().sum(0).max().item()
+    assert (dw.double() - dw64).abs().max().item() <= 2e-6 * scale_w
+    assert (db.double() - db64).abs().max().item() <= 2e-6 * scale_b
+    assert (dw - dw_ref).abs().max().item() <= 4e-6 * scale_w and (db - db_ref).abs().max().item() <= 4e-6 * scale_b
+    # accumulate_into adds
+    acc = (dw.clone(), db.clone())
+    K.layernorm_bwd_params_from_proj(g16, w, x, mean, rstd, accumulate_into=acc)
+    assert torch.allclose(acc[0], 2 * dw, rtol=1e-6, atol=1e-6 * scale_w) and torch.allclose(acc[1], 2 * db, rtol=1e-6, atol=1e-6 * scale_b)
+    # run to run: a fixed summation order
+    dw2, db2 = K.layernorm_bwd_params_from_proj(g16, w, x, mean, rstd)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_exp003_with_the_context_norm_inside_the_attention_node(device):
+    """perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE (the default for a context one layer consumes): output and loss are
+    the same bits as with norm_context as its own node, every gradient but norm_context's too; norm_context's weight / bias
+    gradients are the same sums in another order."""
+    from predict_pv_yield_amd.models.perceiver import perceiver_core
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    batch = make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(6))
+    results = []
+    for inside in (True, False):
+        perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE = inside
+        try:
+            _, model = _pair(device, "bf16", seed=2)
+            y = model(_to(batch, device))
+            loss = model.training_step(_to(batch, device), 0)
+            loss.backward()
+            results.append((y.detach(), loss.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE = True
+    (y1, l1, g1), (y0, l0, g0) = results
+    assert torch.equal(y1, y0) and torch.equal(l1, l0) and g1.keys() == g0.keys() and len(g1) > 10
+    n_norm = 0
+    for name in g1:
+        if "norm_context" in name:
+            n_norm += 1
+            scale = g0[name].abs().max().item()
+            assert (g1[name] - g0[name]).abs().max().item() <= 1e-4 * scale + 1e-9, name
+        else:
+            assert torch.equal(g1[name], g0[name]), name
+    assert n_norm == 4      # two cross-attention blocks, weight and bias each
+
+
 def test_exp003_is_the_same_model_with_keys_and_values_stored_as_bf16(device):
     """operand_dtype="bf16": storing the projected context as bf16 (perceiver_core.KV_STORED_AS_BF16, the default) changes where
     K / V are rounded, not to what: output, loss and every gradient equal those of the f32-stored form bit for bit."""
@@ -122,6 +186,8 @@ def test_exp003_is_the_same_model_with_keys_and_values_stored_as_bf16(device):
     results = []
     for stored in (True, False):
         perceiver_core.KV_STORED_AS_BF16 = stored
+        # (norm_context as its own node on both sides: inside the attention node its two sums have another order)
+        perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE = False
         try:
             _, model = _pair(device, "bf16", seed=1)
             y = model(_to(batch, device))
@@ -130,6 +196,7 @@ def test_exp003_is_the_same_model_with_keys_and_values_stored_as_bf16(device):
             results.append([y.detach(), loss.detach()] + [p.grad.clone() for p in model.parameters() if p.grad is not None])
         finally:
             perceiver_core.KV_STORED_AS_BF16 = True
+            perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE = True
     assert len(results[0]) == len(results[1]) > 10
     for a, b_ in zip(*results):
         assert torch.equal(a, b_)
