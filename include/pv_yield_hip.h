@@ -513,6 +513,13 @@ int pv_layernorm_bwd_params_from_proj_workspace_bytes(int64_t rows, int32_t d, s
 int pv_layernorm_bwd_params_from_proj_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean,
                                            const float* rstd, float* dw, float* db, int64_t rows, int32_t d, int32_t kdim,
                                            void* ws, size_t ws_bytes, int32_t accumulate, void* stream);
+/* ... and the whole backward of that chain in ONE pass over dkv16 and x: also dw_kv [kdim, d] = dkv16^T ctx with
+ * ctx = LayerNorm(x) rounded to bf16 (formed per 32-row block in LDS: the operand the weight-gradient GEMM would read from
+ * memory).  kdim = 128.  accumulate_kv / accumulate_ln != 0: += into dw_kv / (dln_w, dln_b). */
+int pv_context_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
+int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean, const float* rstd,
+                        const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w, float* dln_b, int64_t rows, int32_t d,
+                        int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv, int32_t accumulate_ln, void* stream);
 /* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
  * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);

@@ -498,6 +498,147 @@ static int lpb_blocks(long long rows) {
 }
 
 
+// ---- the whole backward of  x -> LayerNorm -> to_kv  for a context that takes no gradient: dW_kv, d gamma, d beta ---------
+// One pass over the bf16 gradient rows dKV [rows, 128] and x [rows, d]: a workgroup stages 32 rows of each in LDS (x as the
+// normalised context ctx = xhat gamma + beta rounded to bf16 -- the operand the separate weight-gradient GEMM reads from memory --
+// and as xhat in f32), then wave w of the four
+//   * adds  ctx^T [d, 32 rows] dKV[32 rows, columns 32 w .. 32 w + 31]  to its block of dW^T (both operands read transposed from
+//     their row-major tiles: ds_read_tr16_b64), and
+//   * forms the part of  d ctx = dKV W  that comes from ITS 32 columns of dKV and folds it into its own partial column sums
+//     d gamma += d ctx xhat, d beta += d ctx  (the sums are linear in d ctx: no exchange between the waves).
+// The next block's rows are in flight (registers) under the current block's products.  Neither ctx nor d ctx exists in memory:
+// the weight-gradient GEMM (dKV and ctx read: 1.0 GB for experiments/003's context) and the kernel above (dKV and x again) become
+// one pass over 1.0 GB.  Sums over the row blocks of a workgroup in order, then workgroups in index order (pv_sum_slabs).
+constexpr int CBK_G_RS = 320;      // bytes per row of the dKV tile [32][128] bf16 (4 rows x 64 B walk the banks for the transposed reads)
+constexpr int CBK_C_RS = 192;      // ... of the ctx tile [32][64] bf16
+constexpr int CBK_XLD = 66;        // floats per row of the xhat tile [32][64 + 2]
+typedef __attribute__((address_space(3))) s16x4 cbk_lds_s16x4;
+__global__ __launch_bounds__(256) void context_bwd_kernel(const uint16_t* __restrict__ g16, const float* __restrict__ wkv,
+                                                              const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ lnw,
+                                                              const float* __restrict__ lnb, float* __restrict__ part_dw,
+                                                              float* __restrict__ part_ln, long long rows, int d,
+                                                              long long n_rowblocks) {
+  typedef __attribute__((ext_vector_type(16))) float v16f;
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[32 * CBK_G_RS];
+  __shared__ __attribute__((aligned(16))) unsigned char Cs[32 * CBK_C_RS];
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[64 * LPB_BRS];
+  __shared__ float Xh[32 * CBK_XLD];
+  __shared__ float red[4][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 64 * 128; i += 256) {      // W^T as bf16: Ws[n][k] = bf16(W[k][n]), zero for n >= d
+    const int n = i >> 7, k = i & 127;
+    *reinterpret_cast<uint16_t*>(Ws + n * LPB_BRS + 2 * k) = f32_to_bf16_bits(n < d ? wkv[(size_t)k * d + n] : 0.f);
+  }
+  for (int i = tid; i < 32 * CBK_C_RS / 4; i += 256) reinterpret_cast<uint32_t*>(Cs)[i] = 0u;   // columns >= d stay zero
+  for (int i = tid; i < 32 * CBK_XLD; i += 256) Xh[i] = 0.f;
+  const int row = lane & 31, half = lane >> 5;
+  const int qi = (lane & 15) >> 2, pi = lane & 3, cb = 16 * ((lane >> 4) & 1);
+  // transposed operand reads (two 4 x 16-bit pieces per 16-deep step): ctx^T tiles t = 0, 1 and this wave's block of dKV
+  int c_rd[2][2], g_rd[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    g_rd[s2] = (8 * half + 4 * s2 + qi) * CBK_G_RS + (32 * wave + cb + 4 * pi) * 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) c_rd[t][s2] = (8 * half + 4 * s2 + qi) * CBK_C_RS + (32 * t + cb + 4 * pi) * 2;
+  }
+  auto fetch_tr = [&](const unsigned char* plane, const int (&rd)[2], int ks, int rs) -> bf16x8 {
+    typedef __attribute__((ext_vector_type(8))) short s16x8c;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cbk_lds_s16x4*)(plane + rd[0] + 16 * ks * rs));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cbk_lds_s16x4*)(plane + rd[1] + 16 * ks * rs));
+    const s16x8c v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  // staging: two 16-byte pieces of the (contiguous) dKV tile per thread; wave w brings rows 8 w .. 8 w + 7 of x, a lane per
+  // column (their mean / rstd are wave-uniform: scalar loads)
+  u32x4 gq[2];
+  float xq[8], muq[8], rsq[8];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const float gam = lane < d ? lnw[lane] : 0.f, bet = lane < d ? lnb[lane] : 0.f;
+  auto prefetch = [&](long long rb) {
+    const long long r0 = rb * 32;
+    const uint16_t* gp = g16 + r0 * 128 + (size_t)tid * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      gq[i] = r0 + (tid >> 4) + 16 * i < rows ? *reinterpret_cast<const u32x4*>(gp + 2048 * i) : (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long r = r0 + 8 * wave_u + i;
+      const bool ok = r < rows;
+      const long long rc = ok ? r : rows - 1;
+      muq[i] = mean[rc];
+      rsq[i] = ok ? rstd[rc] : 0.f;
+      xq[i] = (ok && lane < d) ? x[rc * d + lane] : 0.f;
+    }
+  };
+  v16f accW[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accW[0][i] = 0.f, accW[1][i] = 0.f;
+  float dg0 = 0.f, db0 = 0.f;
+  long long rb = blockIdx.x;
+  if (rb < n_rowblocks) prefetch(rb);
+  __syncthreads();
+  for (; rb < n_rowblocks; rb += gridDim.x) {
+    // registers -> tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(Gs + ((tid >> 4) + 16 * i) * CBK_G_RS + 16 * (tid & 15)) = gq[i];
+    if (lane < d) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * wave_u + i;
+        Xh[r * CBK_XLD + lane] = (xq[i] - muq[i]) * rsq[i];
+        // (the LayerNorm kernel's expression; a row beyond the end has rstd = 0 here: its ctx must be 0, not beta)
+        const float c = rsq[i] != 0.f ? (xq[i] - muq[i]) * rsq[i] * gam + bet : 0.f;
+        *reinterpret_cast<uint16_t*>(Cs + r * CBK_C_RS + 2 * lane) = f32_to_bf16_bits(c);
+      }
+    }
+    __syncthreads();
+    if (rb + gridDim.x < n_rowblocks) prefetch(rb + gridDim.x);
+    // d ctx: wave (t = w & 1, kh = w >> 1) forms columns 32 t .. 32 t + 31 from the dKV columns 64 kh .. 64 kh + 63
+    v16f accD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accD[i] = 0.f;
+    const int dt = wave_u & 1, dkh = wave_u >> 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 gb = fetch_tr(Gs, g_rd, ks, CBK_G_RS);
+      accW[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fetch_tr(Cs, c_rd[0], ks, CBK_C_RS), gb, accW[0], 0, 0, 0);
+      accW[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fetch_tr(Cs, c_rd[1], ks, CBK_C_RS), gb, accW[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kb = (64 * dkh + 16 * ks + 8 * half) * 2;
+      accD = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Gs + row * CBK_G_RS + kb),
+                                                     *reinterpret_cast<const bf16x8*>(Ws + (32 * dt + row) * LPB_BRS + kb), accD, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 8 * (i >> 2) + 4 * half + (i & 3);
+      dg0 += accD[i] * Xh[r * CBK_XLD + 32 * dt + row];
+      db0 += accD[i];
+    }
+    __syncthreads();   // the tiles are overwritten by the next block
+  }
+  // dW^T of this workgroup: wave w holds [n = 32 t + row_i][j = 32 w + lane % 32]
+  float* pw = part_dw + (size_t)blockIdx.x * 128 * d;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = 32 * t + 8 * (i >> 2) + 4 * half + (i & 3);
+      if (n < d) pw[(size_t)(32 * wave + row) * d + n] = accW[t][i];
+    }
+  dg0 += __shfl_xor(dg0, 32), db0 += __shfl_xor(db0, 32);
+  if (half == 0) red[wave][0][row] = dg0, red[wave][1][row] = db0;      // wave w: columns 32 (w & 1) + row, dKV half w >> 1
+  __syncthreads();
+  if (tid < 2 * d) {
+    const int which = tid / d, n = tid - which * d;
+    part_ln[(size_t)blockIdx.x * 2 * d + tid] = red[n >> 5][which][n & 31] + red[2 + (n >> 5)][which][n & 31];
+  }
+}
+
+static int cbk_blocks(long long rows) { return (int)std::min<long long>((rows + 31) / 32, 3 * kNumCU); }   // three workgroups share a CU (LDS, registers): all resident
+
 }  // namespace pv
 
 using namespace pv;
@@ -596,6 +737,37 @@ int pv_layernorm_bwd_params_from_proj_bf16(const uint16_t* dkv16, const float* w
     launch_sum_slabs(part, db, d, nb, 2 * d, d, st, accumulate);
   }
   return check_launch("pv_layernorm_bwd_params_from_proj_bf16");
+}
+
+int pv_context_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes) {
+  PV_REQUIRE(bytes && rows > 0 && d > 0 && d <= 64, PV_EINVAL, "pv_context_bwd_workspace_bytes: bad arguments");
+  *bytes = (size_t)cbk_blocks(rows) * (128 + 2) * d * sizeof(float);
+  return PV_OK;
+}
+
+int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean, const float* rstd,
+                        const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w, float* dln_b, int64_t rows, int32_t d,
+                        int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv, int32_t accumulate_ln, void* stream) {
+  PV_REQUIRE(dkv16 && w_kv && x && mean && rstd && ln_w && ln_b && dw_kv && dln_w && dln_b, PV_EINVAL,
+             "pv_context_bwd_bf16: null pointer");
+  PV_REQUIRE(rows > 0 && d > 0 && d <= 64, PV_ESIZE, "pv_context_bwd_bf16: d=%d must be in 1..64", d);
+  PV_REQUIRE(kdim == 128, PV_ESIZE, "pv_context_bwd_bf16: kdim=%d must be 128", kdim);
+  PV_REQUIRE(((uintptr_t)dkv16 & 15) == 0, PV_EINVAL, "pv_context_bwd_bf16: gradient rows must be 16-byte aligned");
+  const int nb = cbk_blocks(rows);
+  PV_REQUIRE(ws && ws_bytes >= (size_t)nb * (128 + 2) * d * sizeof(float), PV_EINVAL, "pv_context_bwd_bf16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  float* part_dw = (float*)ws;
+  float* part_ln = part_dw + (size_t)nb * 128 * d;
+  hipLaunchKernelGGL(context_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dkv16, w_kv, x, mean, rstd, ln_w, ln_b, part_dw,
+                     part_ln, (long long)rows, d, (long long)((rows + 31) / 32));
+  launch_sum_slabs(part_dw, dw_kv, 128LL * d, nb, 128LL * d, 0, st, accumulate_kv);
+  if (dln_b == dln_w + d) {
+    launch_sum_slabs(part_ln, dln_w, 2 * d, nb, 2 * d, 0, st, accumulate_ln);
+  } else {
+    launch_sum_slabs(part_ln, dln_w, d, nb, 2 * d, 0, st, accumulate_ln);
+    launch_sum_slabs(part_ln, dln_b, d, nb, 2 * d, d, st, accumulate_ln);
+  }
+  return check_launch("pv_context_bwd_bf16");
 }
 
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream) {

@@ -946,7 +946,7 @@ def gemm_splitk(a: torch.Tensor, b: torch.Tensor, accumulate_into: Optional[torc
     tiles = ((m + 127) // 128) * ((n + 63) // 64)
     splits = max(1, min((SPLITK_TARGET_WORKGROUPS + tiles - 1) // tiles, (k + SPLITK_MIN_CHUNK - 1) // SPLITK_MIN_CHUNK, 4096))
     if splits == 1 and accumulate_into is None:
-        return gemm(a, b)
+        return gemm(a, b, bf16_operands=bf16_operands)
     slabs = _workspace("gemm_splitk", splits * m * n * 4, a.device)
     d = _lib.GemmDesc(m, n, k, a.stride(0), a.stride(1), b.stride(0), b.stride(1), n, 1, 1, 0, 0, 0, 0, 0, 0, splits, m * n)
     a_bf16 = a.dtype == torch.bfloat16
@@ -1046,6 +1046,37 @@ def layernorm_bwd_params_from_proj(dkv16, w_kv, x, mean, rstd, accumulate_into=N
                                                            int(accumulate_into is not None), current_stream_ptr()),
           "pv_layernorm_bwd_params_from_proj_bf16")
     return dw, db
+
+
+def context_bwd_supported(dkv16: torch.Tensor, w_kv: torch.Tensor, x: torch.Tensor) -> bool:
+    return layernorm_bwd_params_from_proj_supported(dkv16, w_kv, x) and w_kv.shape[0] == 128
+
+
+def context_bwd(dkv16, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=None, accumulate_ln_into=None):
+    """The backward of  x -> LayerNorm -> to_kv  for an x that takes no gradient, from the bf16 gradient rows of K | V, in one
+    pass (pv_context_bwd_bf16): -> (dw_kv [128, d], dln_w, dln_b).  accumulate_*_into: tensors that receive `+=` instead."""
+    require_cuda(dkv16, w_kv, x, mean, rstd, ln_w, ln_b)
+    if not context_bwd_supported(dkv16, w_kv, x):
+        raise ValueError("context_bwd: bf16 gradient rows [rows, 128], f32 weight [128, d <= 64], f32 x [rows, d]")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    nbytes = ctypes.c_size_t(0)
+    check(get_lib().pv_context_bwd_workspace_bytes(rows, d, ctypes.byref(nbytes)), "pv_context_bwd_workspace_bytes")
+    ws = _workspace("context_bwd", nbytes.value, x.device)
+    dw = accumulate_kv_into if accumulate_kv_into is not None else torch.empty_like(w_kv)
+    if accumulate_ln_into is not None:
+        dlw, dlb = accumulate_ln_into
+    elif d % 4 == 0:
+        both = torch.empty(2 * d, dtype=torch.float32, device=x.device)
+        dlw, dlb = both[:d], both[d:]
+    else:
+        dlw = torch.empty(d, dtype=torch.float32, device=x.device)
+        dlb = torch.empty(d, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_context_bwd_bf16(ptr(dkv16), ptr(w_kv), ptr(x), ptr(mean), ptr(rstd), ptr(ln_w), ptr(ln_b), ptr(dw),
+                                        ptr(dlw), ptr(dlb), rows, d, w_kv.shape[0], ptr(ws), nbytes.value,
+                                        int(accumulate_kv_into is not None), int(accumulate_ln_into is not None),
+                                        current_stream_ptr()), "pv_context_bwd_bf16")
+    return dw, dlw, dlb
 
 
 def softmax_fwd_(x: torch.Tensor, scale: float) -> torch.Tensor:

@@ -240,23 +240,36 @@ class CrossAttentionNormKV16(torch.autograd.Function):
         c2 = y.view(-1, y.shape[-1])
         kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(x.shape[:-1] + (w_kv.shape[0],))
         out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
-        ctx.save_for_backward(q, x, ln_w, mean, rstd, c2, w_kv, kv16, out, lse)
+        ctx.one_pass = ONE_PASS_CONTEXT_BACKWARD and w_kv.shape[0] == 128
+        # (the one-pass backward re-forms the normalised context from x, mean, rstd: it is not kept)
+        ctx.save_for_backward(q, x, ln_w, ln_b, mean, rstd, None if ctx.one_pass else c2, w_kv, kv16, out, lse)
         ctx.heads, ctx.scale = heads, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, x, ln_w, mean, rstd, c2, w_kv, kv16, out, lse = ctx.saved_tensors
+        q, x, ln_w, ln_b, mean, rstd, c2, w_kv, kv16, out, lse = ctx.saved_tensors
         dq, dkv16 = K.attention_bwd(q, kv16, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=True, dkv_bf16=True)
         g2 = dkv16.view(-1, w_kv.shape[0])
         key, acc = _tied_slot(w_kv)
+        nkey, nacc = _tied_slot(ln_w)
+        if ctx.one_pass:
+            dw, dlw, dlb = K.context_bwd(g2, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=acc, accumulate_ln_into=nacc)
+            if acc is None:
+                _tied_keep(key, dw)
+            else:
+                dw = None
+            if nacc is None:
+                _tied_keep(nkey, (dlw, dlb))
+            else:
+                dlw = dlb = None
+            return dq, None, dlw, dlb, None, dw, None, None
         if acc is not None:
             K.gemm_splitk(g2.t(), c2, accumulate_into=acc, bf16_operands=True)
             dw = None
         else:
             dw = K.gemm_splitk(g2.t(), c2, bf16_operands=True)
             _tied_keep(key, dw)
-        nkey, nacc = _tied_slot(ln_w)
         if nacc is not None:
             K.layernorm_bwd_params_from_proj(g2, w_kv, x, mean, rstd, accumulate_into=nacc)
             dlw = dlb = None
@@ -264,6 +277,9 @@ class CrossAttentionNormKV16(torch.autograd.Function):
             dlw, dlb = K.layernorm_bwd_params_from_proj(g2, w_kv, x, mean, rstd)
             _tied_keep(nkey, (dlw, dlb))
         return dq, None, dlw, dlb, None, dw, None, None
+
+
+ONE_PASS_CONTEXT_BACKWARD = True      # False: weight-gradient GEMM + the LayerNorm-parameter kernel (two passes over dK | dV)
 
 
 def cross_attention_norm_kv16_supported(q, data, ln_w, w_kv, heads) -> bool:

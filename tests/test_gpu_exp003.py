@@ -146,6 +146,71 @@ def test_layernorm_parameter_gradients_straight_from_the_projection_gradient(dev
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("rows,d", [(70_000, 38), (4097, 38), (31, 64), (100_003, 20)])
+def test_context_backward_in_one_pass(device, rows, d):
+    """pv_context_bwd_bf16 (dW_kv, d gamma, d beta from one pass over dK | dV and x) against the weight-gradient GEMM on the
+    LayerNorm kernel's output and the LayerNorm-parameter kernel: the same bf16 operands (ctx re-formed in LDS with the LayerNorm
+    kernel's expression), f32 sums in another fixed order."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(rows * 3 + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(device)
+    lw = (1 + 0.1 * torch.randn(d, generator=g)).to(device)
+    lb = (0.1 * torch.randn(d, generator=g)).to(device)
+    w = (torch.randn(128, d, generator=g) * 0.2).to(device)
+    g16 = torch.randn(rows, 128, generator=g).to(device).to(torch.bfloat16)
+    ctx, mean, rstd = K.layernorm_fwd(x, lw, lb, 1e-5)
+    dw_ref = K.gemm_splitk(g16.t(), ctx, bf16_operands=True)
+    dlw_ref, dlb_ref = K.layernorm_bwd_params_from_proj(g16, w, x, mean, rstd)
+    assert K.context_bwd_supported(g16, w, x)
+    dw, dlw, dlb = K.context_bwd(g16, w, x, mean, rstd, lw, lb)
+    # f64 sums of the same bf16-rounded operands
+    dw64 = g16.double().t() @ ctx.to(torch.bfloat16).double()
+    scale = (g16.double().abs().t() @ ctx.to(torch.bfloat16).double().abs()).max().item()
+    assert dw.shape == (128, d)
+    assert (dw.double() - dw64).abs().max().item() <= 2e-6 * scale
+    assert (dw_ref.double() - dw64).abs().max().item() <= 2e-6 * scale
+    sw, sb = dlw_ref.abs().max().item() + 1e-6, dlb_ref.abs().max().item() + 1e-6
+    bound = 3e-5 * (rows ** 0.5)      # sums of `rows` signed terms of order 1, f32 partial sums in two different orders
+    assert (dlw - dlw_ref).abs().max().item() <= bound * 1e-2 * max(1.0, sw) and (dlb - dlb_ref).abs().max().item() <= bound * 1e-2 * max(1.0, sb)
+    dw2, dlw2, dlb2 = K.context_bwd(g16, w, x, mean, rstd, lw, lb)
+    assert torch.equal(dw, dw2) and torch.equal(dlw, dlw2) and torch.equal(dlb, dlb2)
+    acc_w, acc_ln = dw.clone(), (dlw.clone(), dlb.clone())
+    K.context_bwd(g16, w, x, mean, rstd, lw, lb, accumulate_kv_into=acc_w, accumulate_ln_into=acc_ln)
+    assert torch.allclose(acc_w, 2 * dw, rtol=1e-6, atol=1e-6 * scale)
+    assert torch.allclose(acc_ln[0], 2 * dlw, rtol=1e-5, atol=1e-5 * sw) and torch.allclose(acc_ln[1], 2 * dlb, rtol=1e-5, atol=1e-5 * sb)
+
+
+def test_exp003_with_the_context_backward_in_one_pass(device):
+    """perceiver_functional.ONE_PASS_CONTEXT_BACKWARD (the default): same output, loss and gradients as with the weight-gradient
+    GEMM + LayerNorm-parameter kernel, except to_kv's weight and norm_context's parameters of the cross-attention blocks, which
+    are the same sums in another order."""
+    from predict_pv_yield_amd import perceiver_functional as PF
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    batch = make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(7))
+    results = []
+    for one_pass in (True, False):
+        PF.ONE_PASS_CONTEXT_BACKWARD = one_pass
+        try:
+            _, model = _pair(device, "bf16", seed=3)
+            y = model(_to(batch, device))
+            loss = model.training_step(_to(batch, device), 0)
+            loss.backward()
+            results.append((y.detach(), loss.detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            PF.ONE_PASS_CONTEXT_BACKWARD = True
+    (y1, l1, g1), (y0, l0, g0) = results
+    assert torch.equal(y1, y0) and torch.equal(l1, l0) and g1.keys() == g0.keys()
+    n_close = 0
+    for name in g1:
+        if "norm_context" in name or ("to_kv" in name and not torch.equal(g1[name], g0[name])):
+            n_close += 1
+            scale = g0[name].abs().max().item()
+            assert (g1[name] - g0[name]).abs().max().item() <= 1e-4 * scale + 1e-9, name
+        else:
+            assert torch.equal(g1[name], g0[name]), name
+    assert 4 <= n_close <= 6      # norm_context weight + bias and to_kv of the two cross-attention blocks
+
+
 def test_exp003_with_the_context_norm_inside_the_attention_node(device):
     """perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE (the default for a context one layer consumes): output and loss are
     the same bits as with norm_context as its own node, every gradient but norm_context's too; norm_context's weight / bias
@@ -168,7 +233,9 @@ def test_exp003_with_the_context_norm_inside_the_attention_node(device):
     assert torch.equal(y1, y0) and torch.equal(l1, l0) and g1.keys() == g0.keys() and len(g1) > 10
     n_norm = 0
     for name in g1:
-        if "norm_context" in name:
+        if "to_kv" in name and not torch.equal(g1[name], g0[name]):     # (one-pass context backward: to_kv's sum has another order too)
+            assert (g1[name] - g0[name]).abs().max().item() <= 1e-4 * g0[name].abs().max().item() + 1e-9, name
+        elif "norm_context" in name:
             n_norm += 1
             scale = g0[name].abs().max().item()
             assert (g1[name] - g0[name]).abs().max().item() <= 1e-4 * scale + 1e-9, name
