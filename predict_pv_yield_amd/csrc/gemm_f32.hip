@@ -371,8 +371,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmK g) {
 // OUT_BF16: C is a bf16 matrix (round to nearest even in the store): the key / value projection of a cross-attention whose
 // bf16-operand kernels would round those values anyway -- the 1.3 GB of f32 K / V of experiments/003's context (2.5 M rows x 128)
 // is what bounds both this kernel's store and the attention kernels' reads
-template <int KSTEPS, int VEC, bool OUT_BF16 = false, int TERMS = 3>      // TERMS as in gemm_bf16x3_kernel
-__global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks) {
+// LN_A: the rows of A pass through a LayerNorm on their way into the product -- A = the un-normalised context of a
+// cross-attention, the product its key / value projection (pv_context_fwd_bf16).  The two lanes that share a row exchange their
+// halves, each forms mean and rstd with the serial sums of layernorm_fwd_rows_f32 (same order: same bits) and normalises the
+// values it holds with that kernel's expression; the column block 0 workgroups also store mean / rstd.  The normalised context is
+// never written: LayerNorm kernel (x read, ctx written) + projection (ctx read) become one read of x.
+struct GemmLnA {
+  const float* w;
+  const float* b;
+  float* mean;
+  float* rstd;
+  float eps;
+};
+template <int KSTEPS, int VEC, bool OUT_BF16 = false, int TERMS = 3, bool LN_A = false>      // TERMS as in gemm_bf16x3_kernel
+__global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks, GemmLnA ln = GemmLnA{}) {
   constexpr int KP = 16 * KSTEPS;
   constexpr int BRS = 2 * KP + 16;                       // bytes per n-row of a B plane (16 rows x 16 B cover the 64 banks)
   constexpr int BPLANE = G_BN * BRS;
@@ -415,7 +427,56 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
       }
     }
   };
-  auto process = [&](int rb, const float (&ar)[KSTEPS][8]) {
+  float lnw_r[LN_A ? KSTEPS : 1][8], lnb_r[LN_A ? KSTEPS : 1][8];      // gamma / beta of the k slots this lane holds
+  if constexpr (LN_A) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const int k = 16 * ks + 8 * half + v;
+        lnw_r[ks][v] = k < g.k ? ln.w[k] : 0.f;
+        lnb_r[ks][v] = k < g.k ? ln.b[k] : 0.f;
+      }
+  }
+  auto process = [&](int rb, const float (&ar_in)[KSTEPS][8]) {
+    float ar[KSTEPS][8];
+    if constexpr (LN_A) {
+      // element k = 16 ks + 8 h + v of the row: this lane's value (h == half) or its partner's
+      float lo[KSTEPS][8], hi[KSTEPS][8];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const float other = __shfl_xor(ar_in[ks][v], 32);
+          lo[ks][v] = half ? other : ar_in[ks][v];
+          hi[ks][v] = half ? ar_in[ks][v] : other;
+        }
+      auto at = [&](int k) { return ((k >> 3) & 1) ? hi[k >> 4][k & 7] : lo[k >> 4][k & 7]; };
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8 * KSTEPS; ++j) s += at(2 * j) + at(2 * j + 1);      // (slots >= K hold zeros, as the LayerNorm kernel's do)
+      const float mu = s / (float)g.k;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8 * KSTEPS; ++j)
+        if (2 * j < g.k) {
+          const float t0 = at(2 * j) - mu, t1 = at(2 * j + 1) - mu;
+          q += t0 * t0 + t1 * t1;
+        }
+      const float rs = 1.0f / sqrtf(q / (float)g.k + ln.eps);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+          ar[ks][v] = 16 * ks + 8 * half + v < g.k ? (ar_in[ks][v] - mu) * rs * lnw_r[ks][v] + lnb_r[ks][v] : 0.f;
+      const long long mm = (long long)rb * 32 + row;
+      if (blockIdx.x == 0 && half == 0 && rb < n_rowblocks && mm < g.m) ln.mean[mm] = mu, ln.rstd[mm] = rs;
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) ar[ks][v] = ar_in[ks][v];
+    }
     v16f_t acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc0[r] = 0.f, acc1[r] = 0.f;
@@ -723,6 +784,32 @@ int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, 
   else { if (ksteps <= 3) { PV_ROWS16(3, 3); } else { PV_ROWS16(4, 3); } }
 #undef PV_ROWS16
   return check_launch("pv_gemm_rows_bf16out_f32");
+}
+
+int pv_context_fwd_bf16(const float* x, const float* ln_w, const float* ln_b, const float* w_kv, uint16_t* kv16, float* mean,
+                        float* rstd, int64_t rows, int32_t d, int32_t kdim, float eps, void* stream) {
+  PV_REQUIRE(x && ln_w && ln_b && w_kv && kv16 && mean && rstd, PV_EINVAL, "pv_context_fwd_bf16: null pointer");
+  PV_REQUIRE(rows > 0 && rows <= 0x7fffffffLL && d > 0 && d <= 48 && d % 2 == 0, PV_ESIZE,
+             "pv_context_fwd_bf16: d=%d must be even and in 2..48", d);
+  PV_REQUIRE(kdim > 0 && kdim % 64 == 0, PV_ESIZE, "pv_context_fwd_bf16: kdim=%d must be a multiple of 64", kdim);
+  PV_REQUIRE(((uintptr_t)x & 15) == 0, PV_EINVAL, "pv_context_fwd_bf16: x must be 16-byte aligned");
+  GemmK g;
+  g.a = x, g.b = w_kv, g.bias = nullptr, g.c = reinterpret_cast<float*>(kv16);      // B = w_kv^T: [K = d, N = kdim], k-contiguous
+  g.res = nullptr, g.ldr = 0;
+  g.m = (int)rows, g.n = kdim, g.k = d;
+  g.a_rs = d, g.a_cs = 1, g.b_rs = 1, g.b_cs = d, g.ldc = kdim;
+  g.batch2 = 1, g.k_splits = 1, g.k_chunk = (d + G_BK - 1) / G_BK * G_BK;
+  g.a_bs1 = g.a_bs2 = g.b_bs1 = g.b_bs2 = g.c_bs1 = g.c_bs2 = 0, g.c_ss = 0;
+  g.relu = 0;
+  const int n_tiles = kdim / G_BN;
+  const int n_rb = (int)((rows + 31) / 32);
+  int per_col = 512 / n_tiles;
+  if (per_col < 1) per_col = 1;
+  if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
+  dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
+  const GemmLnA ln = {ln_w, ln_b, mean, rstd, eps};
+  hipLaunchKernelGGL((gemm_rows_x3_kernel<3, 2, true, 1, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb, ln);
+  return check_launch("pv_context_fwd_bf16");
 }
 
 int pv_sum_slabs_f32(const float* slabs, float* out, int64_t n, int32_t n_slabs, void* stream) {

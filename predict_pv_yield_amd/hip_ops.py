@@ -1048,6 +1048,27 @@ def layernorm_bwd_params_from_proj(dkv16, w_kv, x, mean, rstd, accumulate_into=N
     return dw, db
 
 
+def context_fwd_supported(x: torch.Tensor, w_kv: torch.Tensor) -> bool:
+    return (x.dtype == torch.float32 and x.is_contiguous() and w_kv.is_contiguous() and w_kv.dtype == torch.float32
+            and w_kv.shape[0] == 128 and x.shape[-1] == w_kv.shape[1] <= 48 and x.shape[-1] % 2 == 0
+            and x.data_ptr() % 16 == 0 and x.numel() // x.shape[-1] >= 2048)
+
+
+def context_fwd(x, ln_w, ln_b, w_kv, eps: float = 1e-5):
+    """K | V (bf16) = LayerNorm(x) @ w_kv^T in one pass (pv_context_fwd_bf16) -> (kv16 [..., 128], mean, rstd)."""
+    require_cuda(x, ln_w, ln_b, w_kv)
+    if not context_fwd_supported(x, w_kv):
+        raise ValueError("context_fwd: contiguous f32 x [..., d <= 64, even] and w_kv [128, d] expected")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    kv16 = torch.empty(x.shape[:-1] + (128,), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(get_lib().pv_context_fwd_bf16(ptr(x), ptr(ln_w), ptr(ln_b), ptr(w_kv), ptr(kv16), ptr(mean), ptr(rstd), rows, d, 128,
+                                        float(eps), current_stream_ptr()), "pv_context_fwd_bf16")
+    return kv16, mean, rstd
+
+
 def context_bwd_supported(dkv16: torch.Tensor, w_kv: torch.Tensor, x: torch.Tensor) -> bool:
     return layernorm_bwd_params_from_proj_supported(dkv16, w_kv, x) and w_kv.shape[0] == 128
 

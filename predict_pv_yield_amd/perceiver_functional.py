@@ -236,11 +236,15 @@ class CrossAttentionNormKV16(torch.autograd.Function):
     def forward(ctx, q, data, ln_w, ln_b, eps, w_kv, heads, scale):
         q = q.contiguous()
         x = data.contiguous()
-        y, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, eps)
-        c2 = y.view(-1, y.shape[-1])
-        kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(x.shape[:-1] + (w_kv.shape[0],))
-        out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
         ctx.one_pass = ONE_PASS_CONTEXT_BACKWARD and w_kv.shape[0] == 128
+        if ctx.one_pass and ONE_PASS_CONTEXT_FORWARD and K.context_fwd_supported(x, w_kv):
+            kv16, mean, rstd = K.context_fwd(x, ln_w, ln_b, w_kv, eps)      # the normalised context is never written
+            c2 = None
+        else:
+            y, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, eps)
+            c2 = y.view(-1, y.shape[-1])
+            kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(x.shape[:-1] + (w_kv.shape[0],))
+        out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
         # (the one-pass backward re-forms the normalised context from x, mean, rstd: it is not kept)
         ctx.save_for_backward(q, x, ln_w, ln_b, mean, rstd, None if ctx.one_pass else c2, w_kv, kv16, out, lse)
         ctx.heads, ctx.scale = heads, scale
@@ -280,6 +284,7 @@ class CrossAttentionNormKV16(torch.autograd.Function):
 
 
 ONE_PASS_CONTEXT_BACKWARD = True      # False: weight-gradient GEMM + the LayerNorm-parameter kernel (two passes over dK | dV)
+ONE_PASS_CONTEXT_FORWARD = True       # False: LayerNorm kernel + projection GEMM (the normalised context through memory)
 
 
 def cross_attention_norm_kv16_supported(q, data, ln_w, w_kv, heads) -> bool:

@@ -211,6 +211,57 @@ def test_exp003_with_the_context_backward_in_one_pass(device):
     assert 4 <= n_close <= 6      # norm_context weight + bias and to_kv of the two cross-attention blocks
 
 
+@pytest.mark.parametrize("shape", [(5, 16384, 38), (70_001, 38), (3, 16384, 38), (4096, 48), (4099, 20)])
+def test_context_forward_in_one_pass_against_the_layernorm_and_projection_kernels(device, shape):
+    """pv_context_fwd_bf16 (x -> LayerNorm -> to_kv, K | V stored as bf16, the normalised context only in registers) against
+    pv_layernorm_fwd_f32 + pv_gemm_rows_bf16out_f32 with bf16 operands.  Where the LayerNorm runs its row-per-thread kernel
+    (>= 65 536 short rows: the cross-attention contexts) the statistics are the same serial sums, the operands the same roundings,
+    the matrix instructions in the same order: identical bits.  Elsewhere the LayerNorm kernel sums a row across a wave: the
+    statistics agree to rounding and K | V to a bf16 unit in the last place on a few values."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(sum(shape))
+    d = shape[-1]
+    x = (torch.randn(*shape, generator=g) * 3 + 1).to(device)
+    lw = (1 + 0.1 * torch.randn(d, generator=g)).to(device)
+    lb = (0.1 * torch.randn(d, generator=g)).to(device)
+    w = (torch.randn(128, d, generator=g) * 0.2).to(device)
+    ctx, mean_ref, rstd_ref = K.layernorm_fwd(x, lw, lb, 1e-5)
+    kv_ref = K.gemm_rows_bf16out(ctx.view(-1, d), w.t(), bf16_operands=True)
+    assert K.context_fwd_supported(x, w)
+    kv16, mean, rstd = K.context_fwd(x, lw, lb, w, 1e-5)
+    assert kv16.shape == shape[:-1] + (128,) and kv16.dtype == torch.bfloat16
+    rows = x.numel() // d
+    if rows >= 65536 and d % 8 != 0:
+        assert torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+        assert torch.equal(kv16.view(-1, 128), kv_ref)
+    else:
+        assert torch.allclose(mean, mean_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rstd, rstd_ref, rtol=1e-5)
+        a, b_ = kv16.view(-1, 128).float(), kv_ref.float()
+        assert (a - b_).abs().max().item() <= 2.0 ** -6 * b_.abs().max().item()
+        assert (a != b_).float().mean().item() < 0.02
+
+
+def test_exp003_with_the_context_forward_in_one_pass(device):
+    """perceiver_functional.ONE_PASS_CONTEXT_FORWARD (the default) changes no bit of output, loss or any gradient."""
+    from predict_pv_yield_amd import perceiver_functional as PF
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    batch = make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(8))
+    results = []
+    for one_pass in (True, False):
+        PF.ONE_PASS_CONTEXT_FORWARD = one_pass
+        try:
+            _, model = _pair(device, "bf16", seed=4)
+            y = model(_to(batch, device))
+            loss = model.training_step(_to(batch, device), 0)
+            loss.backward()
+            results.append([y.detach(), loss.detach()] + [p.grad.clone() for p in model.parameters() if p.grad is not None])
+        finally:
+            PF.ONE_PASS_CONTEXT_FORWARD = True
+    assert len(results[0]) == len(results[1]) > 10
+    for a, b_ in zip(*results):
+        assert torch.equal(a, b_)
+
+
 def test_exp003_with_the_context_norm_inside_the_attention_node(device):
     """perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE (the default for a context one layer consumes): output and loss are
     the same bits as with norm_context as its own node, every gradient but norm_context's too; norm_context's weight / bias
