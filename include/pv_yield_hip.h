@@ -516,15 +516,20 @@ int pv_layernorm_bwd_params_from_proj_bf16(const uint16_t* dkv16, const float* w
 /* The forward of the chain in one pass: kv16 [rows, kdim] (bf16) = LayerNorm(x) w_kv^T with the normalised context formed
  * in the registers of the rows-form product (never written) and rounded to bf16 as pv_gemm_rows_bf16out_f32 with PV_GEMM_BF16_OPERANDS rounds
  * its operands; mean / rstd [rows] as pv_layernorm_fwd_f32 returns them.  d even, <= 48; kdim % 64 == 0; w_kv [kdim, d]. */
-int pv_context_fwd_bf16(const float* x, const float* ln_w, const float* ln_b, const float* w_kv, uint16_t* kv16, float* mean,
-                        float* rstd, int64_t rows, int32_t d, int32_t kdim, float eps, void* stream);
+int pv_context_fwd_bf16(const float* x, const float* x2, int32_t d1, int64_t period, const float* ln_w, const float* ln_b,
+                        const float* w_kv, uint16_t* kv16, float* mean, float* rstd, int64_t rows, int32_t d, int32_t kdim,
+                        float eps, void* stream);
+/* x2 != NULL (here and in pv_context_bwd_bf16): row r of the context is [ x[r][0 .. d1) | x2[r % period][0 .. d - d1) ] -- the image
+ * channels followed by the Fourier features of the pixel position (perceiver_pytorch's fourier_encode + torch.cat), which every
+ * image shares: the concatenated [rows, d] tensor is never written.  d1 even.  x2 == NULL: x is [rows, d]. */
 /* ... and the whole backward of that chain in ONE pass over dkv16 and x: also dw_kv [kdim, d] = dkv16^T ctx with
  * ctx = LayerNorm(x) rounded to bf16 (formed per 32-row block in LDS: the operand the weight-gradient GEMM would read from
  * memory).  kdim = 128.  accumulate_kv / accumulate_ln != 0: += into dw_kv / (dln_w, dln_b). */
 int pv_context_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes);
-int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean, const float* rstd,
-                        const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w, float* dln_b, int64_t rows, int32_t d,
-                        int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv, int32_t accumulate_ln, void* stream);
+int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* x2, int32_t d1, int64_t period,
+                        const float* mean, const float* rstd, const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w,
+                        float* dln_b, int64_t rows, int32_t d, int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv,
+                        int32_t accumulate_ln, void* stream);
 /* y = softmax(scale * x) over rows of `len` (sim.softmax(dim=-1) with the dim_head**-0.5 scale folded in; x == y allowed);
  * bwd: dx = scale * p * (dp - sum(dp * p)) (dx == dp allowed). */
 int pv_softmax_fwd_f32(const float* x, float* y, int64_t rows, int32_t len, float scale, void* stream);

@@ -165,10 +165,10 @@ SIGNATURES = {
     "pv_layernorm_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],
     "pv_layernorm_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
     "pv_layernorm_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_sz, c_i32, c_vp, c_vp],
-    "pv_context_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.c_float, c_vp],
+    "pv_context_fwd_bf16": [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.c_float, c_vp],
     "pv_context_bwd_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
-    "pv_context_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_sz, c_i32,
-                            c_i32, c_vp],
+    "pv_context_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
+                            c_vp, c_sz, c_i32, c_i32, c_vp],
     "pv_layernorm_bwd_params_from_proj_workspace_bytes": [c_i64, c_i32, ctypes.POINTER(c_sz)],
     "pv_layernorm_bwd_params_from_proj_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_sz, c_i32, c_vp],
     "pv_softmax_fwd_f32": [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp],

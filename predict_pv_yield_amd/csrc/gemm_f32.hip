@@ -382,6 +382,11 @@ struct GemmLnA {
   float* mean;
   float* rstd;
   float eps;
+  // optional second source of the rows: row r = [ a[r][0 .. d1) | x2[r % period][0 .. K - d1) ] -- the images' channels followed by
+  // the Fourier features of the pixel's position, which every image of the batch shares (the concatenation is never written)
+  const float* x2;
+  int d1;
+  int period;
 };
 template <int KSTEPS, int VEC, bool OUT_BF16 = false, int TERMS = 3, bool LN_A = false>      // TERMS as in gemm_bf16x3_kernel
 __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_rowblocks, GemmLnA ln = GemmLnA{}) {
@@ -415,6 +420,18 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
           dst[ks][4 * v] = t.x, dst[ks][4 * v + 1] = t.y, dst[ks][4 * v + 2] = t.z, dst[ks][4 * v + 3] = t.w;
         }
       } else if constexpr (VEC == 2) {
+        if (LN_A && ln.x2) {      // two sources (d1 and K even: a pair never straddles them)
+          const float* a1 = A + (row_ok ? mm : 0) * ln.d1;
+          const float* a2 = ln.x2 + (size_t)((unsigned)(row_ok ? mm : 0) % (unsigned)ln.period) * (g.k - ln.d1) - ln.d1;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int k = k0 + 2 * v;
+            float2 t = make_float2(0.f, 0.f);
+            if (row_ok && k < g.k) t = *reinterpret_cast<const float2*>((k < ln.d1 ? a1 : a2) + k);
+            dst[ks][2 * v] = t.x, dst[ks][2 * v + 1] = t.y;
+          }
+          continue;
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           float2 t = make_float2(0.f, 0.f);
@@ -786,9 +803,12 @@ int pv_gemm_rows_bf16out_f32(const float* a, const float* b, const float* bias, 
   return check_launch("pv_gemm_rows_bf16out_f32");
 }
 
-int pv_context_fwd_bf16(const float* x, const float* ln_w, const float* ln_b, const float* w_kv, uint16_t* kv16, float* mean,
-                        float* rstd, int64_t rows, int32_t d, int32_t kdim, float eps, void* stream) {
+int pv_context_fwd_bf16(const float* x, const float* x2, int32_t d1, int64_t period, const float* ln_w, const float* ln_b,
+                        const float* w_kv, uint16_t* kv16, float* mean, float* rstd, int64_t rows, int32_t d, int32_t kdim,
+                        float eps, void* stream) {
   PV_REQUIRE(x && ln_w && ln_b && w_kv && kv16 && mean && rstd, PV_EINVAL, "pv_context_fwd_bf16: null pointer");
+  PV_REQUIRE(!x2 || (d1 > 0 && d1 < d && d1 % 2 == 0 && period > 0 && period <= 0x7fffffffLL && ((uintptr_t)x2 & 7) == 0), PV_EINVAL,
+             "pv_context_fwd_bf16: two sources need an even 0 < d1 < d, a period and an 8-byte aligned x2");
   PV_REQUIRE(rows > 0 && rows <= 0x7fffffffLL && d > 0 && d <= 48 && d % 2 == 0, PV_ESIZE,
              "pv_context_fwd_bf16: d=%d must be even and in 2..48", d);
   PV_REQUIRE(kdim > 0 && kdim % 64 == 0, PV_ESIZE, "pv_context_fwd_bf16: kdim=%d must be a multiple of 64", kdim);
@@ -797,7 +817,7 @@ int pv_context_fwd_bf16(const float* x, const float* ln_w, const float* ln_b, co
   g.a = x, g.b = w_kv, g.bias = nullptr, g.c = reinterpret_cast<float*>(kv16);      // B = w_kv^T: [K = d, N = kdim], k-contiguous
   g.res = nullptr, g.ldr = 0;
   g.m = (int)rows, g.n = kdim, g.k = d;
-  g.a_rs = d, g.a_cs = 1, g.b_rs = 1, g.b_cs = d, g.ldc = kdim;
+  g.a_rs = x2 ? d1 : d, g.a_cs = 1, g.b_rs = 1, g.b_cs = d, g.ldc = kdim;
   g.batch2 = 1, g.k_splits = 1, g.k_chunk = (d + G_BK - 1) / G_BK * G_BK;
   g.a_bs1 = g.a_bs2 = g.b_bs1 = g.b_bs2 = g.c_bs1 = g.c_bs2 = 0, g.c_ss = 0;
   g.relu = 0;
@@ -807,7 +827,7 @@ int pv_context_fwd_bf16(const float* x, const float* ln_w, const float* ln_b, co
   if (per_col < 1) per_col = 1;
   if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
   dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
-  const GemmLnA ln = {ln_w, ln_b, mean, rstd, eps};
+  const GemmLnA ln = {ln_w, ln_b, mean, rstd, eps, x2, d1, (int)period};
   hipLaunchKernelGGL((gemm_rows_x3_kernel<3, 2, true, 1, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb, ln);
   return check_launch("pv_context_fwd_bf16");
 }

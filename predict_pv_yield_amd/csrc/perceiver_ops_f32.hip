@@ -518,7 +518,8 @@ __global__ __launch_bounds__(256) void context_bwd_kernel(const uint16_t* __rest
                                                               const float* __restrict__ rstd, const float* __restrict__ lnw,
                                                               const float* __restrict__ lnb, float* __restrict__ part_dw,
                                                               float* __restrict__ part_ln, long long rows, int d,
-                                                              long long n_rowblocks) {
+                                                              long long n_rowblocks, const float* __restrict__ x2, int d1,
+                                                              int period) {
   typedef __attribute__((ext_vector_type(16))) float v16f;
   __shared__ __attribute__((aligned(16))) unsigned char Gs[32 * CBK_G_RS];
   __shared__ __attribute__((aligned(16))) unsigned char Cs[32 * CBK_C_RS];
@@ -557,18 +558,28 @@ __global__ __launch_bounds__(256) void context_bwd_kernel(const uint16_t* __rest
   const float gam = lane < d ? lnw[lane] : 0.f, bet = lane < d ? lnb[lane] : 0.f;
   auto prefetch = [&](long long rb) {
     const long long r0 = rb * 32;
+    const unsigned pbase = x2 ? (unsigned)((unsigned long long)r0 % (unsigned)period) : 0u;      // (period >= 32 is checked by the host)
     const uint16_t* gp = g16 + r0 * 128 + (size_t)tid * 8;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       gq[i] = r0 + (tid >> 4) + 16 * i < rows ? *reinterpret_cast<const u32x4*>(gp + 2048 * i) : (u32x4){0u, 0u, 0u, 0u};
+    // this lane's column of the 8 rows: one base address and one stride per block (two sources: see pv_context_fwd_bf16 -- the
+    // lane reads either the channels or the position features, whose row index wraps at most once inside a block)
+    const long long rw = r0 + 8 * wave_u;
+    unsigned rp0 = pbase + 8 * wave_u;
+    rp0 = rp0 >= (unsigned)period && x2 ? rp0 - (unsigned)period : rp0;
+    const bool second = x2 && lane >= d1;
+    const float* pl = !x2 ? x + rw * d + lane : (second ? x2 + (size_t)rp0 * (d - d1) + (lane - d1) : x + rw * d1 + lane);
+    const int stride_l = !x2 ? d : (second ? d - d1 : d1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const long long r = r0 + 8 * wave_u + i;
+      const long long r = rw + i;
       const bool ok = r < rows;
       const long long rc = ok ? r : rows - 1;
       muq[i] = mean[rc];
       rsq[i] = ok ? rstd[rc] : 0.f;
-      xq[i] = (ok && lane < d) ? x[rc * d + lane] : 0.f;
+      const long long wrap = (second && rp0 + i >= (unsigned)period) ? (long long)period * (d - d1) : 0;
+      xq[i] = (ok && lane < d) ? pl[(long long)i * stride_l - wrap] : 0.f;
     }
   };
   v16f accW[2];
@@ -745,9 +756,12 @@ int pv_context_bwd_workspace_bytes(int64_t rows, int32_t d, size_t* bytes) {
   return PV_OK;
 }
 
-int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* mean, const float* rstd,
-                        const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w, float* dln_b, int64_t rows, int32_t d,
-                        int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv, int32_t accumulate_ln, void* stream) {
+int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x, const float* x2, int32_t d1, int64_t period,
+                        const float* mean, const float* rstd, const float* ln_w, const float* ln_b, float* dw_kv, float* dln_w,
+                        float* dln_b, int64_t rows, int32_t d, int32_t kdim, void* ws, size_t ws_bytes, int32_t accumulate_kv,
+                        int32_t accumulate_ln, void* stream) {
+  PV_REQUIRE(!x2 || (d1 > 0 && d1 < d && period >= 32 && period <= 0x7fffffffLL && rows <= 0x7fffffffLL), PV_EINVAL,
+             "pv_context_bwd_bf16: two sources need 0 < d1 < d and a period >= 32");
   PV_REQUIRE(dkv16 && w_kv && x && mean && rstd && ln_w && ln_b && dw_kv && dln_w && dln_b, PV_EINVAL,
              "pv_context_bwd_bf16: null pointer");
   PV_REQUIRE(rows > 0 && d > 0 && d <= 64, PV_ESIZE, "pv_context_bwd_bf16: d=%d must be in 1..64", d);
@@ -759,7 +773,7 @@ int pv_context_bwd_bf16(const uint16_t* dkv16, const float* w_kv, const float* x
   float* part_dw = (float*)ws;
   float* part_ln = part_dw + (size_t)nb * 128 * d;
   hipLaunchKernelGGL(context_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dkv16, w_kv, x, mean, rstd, ln_w, ln_b, part_dw,
-                     part_ln, (long long)rows, d, (long long)((rows + 31) / 32));
+                     part_ln, (long long)rows, d, (long long)((rows + 31) / 32), x2, d1, (int)period);
   launch_sum_slabs(part_dw, dw_kv, 128LL * d, nb, 128LL * d, 0, st, accumulate_kv);
   if (dln_b == dln_w + d) {
     launch_sum_slabs(part_ln, dln_w, 2 * d, nb, 2 * d, 0, st, accumulate_ln);

@@ -1048,39 +1048,59 @@ def layernorm_bwd_params_from_proj(dkv16, w_kv, x, mean, rstd, accumulate_into=N
     return dw, db
 
 
-def context_fwd_supported(x: torch.Tensor, w_kv: torch.Tensor) -> bool:
+def _context_rows(x: torch.Tensor, x2):
+    """(rows, d, d1, period) of a context given as x [..., d] or as x [..., P, d1] + x2 [P, d2] (row r = x row r followed by
+    x2 row r % P: image channels + the position features every image shares)."""
+    d1 = x.shape[-1]
+    rows = x.numel() // d1
+    if x2 is None:
+        return rows, d1, 0, 0
+    return rows, d1 + x2.shape[-1], d1, x2.shape[0]
+
+
+def context_fwd_supported(x: torch.Tensor, w_kv: torch.Tensor, x2=None) -> bool:
+    rows, d, d1, period = _context_rows(x, x2)
+    if x2 is not None and not (x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and x.dim() >= 2
+                               and x.shape[-2] == period and d1 % 2 == 0 and x2.data_ptr() % 8 == 0 and x2.device == x.device):
+        return False
     return (x.dtype == torch.float32 and x.is_contiguous() and w_kv.is_contiguous() and w_kv.dtype == torch.float32
-            and w_kv.shape[0] == 128 and x.shape[-1] == w_kv.shape[1] <= 48 and x.shape[-1] % 2 == 0
-            and x.data_ptr() % 16 == 0 and x.numel() // x.shape[-1] >= 2048)
+            and w_kv.shape[0] == 128 and d == w_kv.shape[1] <= 48 and d % 2 == 0
+            and x.data_ptr() % 16 == 0 and 2048 <= rows < 2 ** 31)
 
 
-def context_fwd(x, ln_w, ln_b, w_kv, eps: float = 1e-5):
-    """K | V (bf16) = LayerNorm(x) @ w_kv^T in one pass (pv_context_fwd_bf16) -> (kv16 [..., 128], mean, rstd)."""
-    require_cuda(x, ln_w, ln_b, w_kv)
-    if not context_fwd_supported(x, w_kv):
-        raise ValueError("context_fwd: contiguous f32 x [..., d <= 64, even] and w_kv [128, d] expected")
-    d = x.shape[-1]
-    rows = x.numel() // d
+def context_fwd(x, ln_w, ln_b, w_kv, eps: float = 1e-5, x2=None):
+    """K | V (bf16) = LayerNorm(context) @ w_kv^T in one pass (pv_context_fwd_bf16) -> (kv16 [..., 128], mean, rstd).
+    context = x [..., d], or x [..., P, d1] with x2 [P, d2] appended to every group of P rows (never concatenated in memory)."""
+    require_cuda(x, ln_w, ln_b, w_kv, x2)
+    if not context_fwd_supported(x, w_kv, x2):
+        raise ValueError("context_fwd: contiguous f32 x [..., d <= 48, even] (or x [..., P, d1] + x2 [P, d2]) and w_kv [128, d] expected")
+    rows, d, d1, period = _context_rows(x, x2)
     kv16 = torch.empty(x.shape[:-1] + (128,), dtype=torch.bfloat16, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(get_lib().pv_context_fwd_bf16(ptr(x), ptr(ln_w), ptr(ln_b), ptr(w_kv), ptr(kv16), ptr(mean), ptr(rstd), rows, d, 128,
-                                        float(eps), current_stream_ptr()), "pv_context_fwd_bf16")
+    check(get_lib().pv_context_fwd_bf16(ptr(x), ptr(x2), d1, period, ptr(ln_w), ptr(ln_b), ptr(w_kv), ptr(kv16), ptr(mean),
+                                        ptr(rstd), rows, d, 128, float(eps), current_stream_ptr()), "pv_context_fwd_bf16")
     return kv16, mean, rstd
 
 
-def context_bwd_supported(dkv16: torch.Tensor, w_kv: torch.Tensor, x: torch.Tensor) -> bool:
-    return layernorm_bwd_params_from_proj_supported(dkv16, w_kv, x) and w_kv.shape[0] == 128
+def context_bwd_supported(dkv16: torch.Tensor, w_kv: torch.Tensor, x: torch.Tensor, x2=None) -> bool:
+    rows, d, d1, period = _context_rows(x, x2)
+    if x2 is not None and not (x2.dim() == 2 and x2.dtype == torch.float32 and x2.is_contiguous() and x.dim() >= 2
+                               and x.shape[-2] == period and x2.device == x.device):
+        return False
+    return (dkv16.dtype == torch.bfloat16 and dkv16.is_contiguous() and w_kv.is_contiguous() and x.is_contiguous()
+            and x.dtype == torch.float32 and w_kv.dtype == torch.float32 and w_kv.shape[0] == 128 and d == w_kv.shape[1] <= 64
+            and dkv16.shape[-1] == 128 and dkv16.numel() // 128 == rows < 2 ** 31 and dkv16.data_ptr() % 16 == 0)
 
 
-def context_bwd(dkv16, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=None, accumulate_ln_into=None):
-    """The backward of  x -> LayerNorm -> to_kv  for an x that takes no gradient, from the bf16 gradient rows of K | V, in one
-    pass (pv_context_bwd_bf16): -> (dw_kv [128, d], dln_w, dln_b).  accumulate_*_into: tensors that receive `+=` instead."""
-    require_cuda(dkv16, w_kv, x, mean, rstd, ln_w, ln_b)
-    if not context_bwd_supported(dkv16, w_kv, x):
-        raise ValueError("context_bwd: bf16 gradient rows [rows, 128], f32 weight [128, d <= 64], f32 x [rows, d]")
-    d = x.shape[-1]
-    rows = x.numel() // d
+def context_bwd(dkv16, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=None, accumulate_ln_into=None, x2=None):
+    """The backward of  context -> LayerNorm -> to_kv  for a context that takes no gradient, from the bf16 gradient rows of K | V,
+    in one pass (pv_context_bwd_bf16): -> (dw_kv [128, d], dln_w, dln_b).  accumulate_*_into: tensors that receive `+=` instead.
+    x2: as in context_fwd."""
+    require_cuda(dkv16, w_kv, x, mean, rstd, ln_w, ln_b, x2)
+    if not context_bwd_supported(dkv16, w_kv, x, x2):
+        raise ValueError("context_bwd: bf16 gradient rows [rows, 128], f32 weight [128, d <= 64], f32 context rows")
+    rows, d, d1, period = _context_rows(x, x2)
     nbytes = ctypes.c_size_t(0)
     check(get_lib().pv_context_bwd_workspace_bytes(rows, d, ctypes.byref(nbytes)), "pv_context_bwd_workspace_bytes")
     ws = _workspace("context_bwd", nbytes.value, x.device)
@@ -1093,8 +1113,8 @@ def context_bwd(dkv16, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=None,
     else:
         dlw = torch.empty(d, dtype=torch.float32, device=x.device)
         dlb = torch.empty(d, dtype=torch.float32, device=x.device)
-    check(get_lib().pv_context_bwd_bf16(ptr(dkv16), ptr(w_kv), ptr(x), ptr(mean), ptr(rstd), ptr(ln_w), ptr(ln_b), ptr(dw),
-                                        ptr(dlw), ptr(dlb), rows, d, w_kv.shape[0], ptr(ws), nbytes.value,
+    check(get_lib().pv_context_bwd_bf16(ptr(dkv16), ptr(w_kv), ptr(x), ptr(x2), d1, period, ptr(mean), ptr(rstd), ptr(ln_w),
+                                        ptr(ln_b), ptr(dw), ptr(dlw), ptr(dlb), rows, d, w_kv.shape[0], ptr(ws), nbytes.value,
                                         int(accumulate_kv_into is not None), int(accumulate_ln_into is not None),
                                         current_stream_ptr()), "pv_context_bwd_bf16")
     return dw, dlw, dlb

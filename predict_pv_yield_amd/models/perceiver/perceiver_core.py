@@ -66,6 +66,7 @@ FUSE_RESIDUALS = True   # `fn(norm(x)) + x`: by-pass added in fn's last GEMM epi
 KV_STORED_AS_BF16 = True      # tools/ab-style switch: False = f32 K / V in memory, rounded inside the attention kernels
 LINEARS_FOLLOW_OPERAND_DTYPE = True      # False: the Linears keep f32-accurate products in "bf16" mode (rounds 2-3)
 NORM_CONTEXT_IN_THE_ATTENTION_NODE = True      # False: norm_context as its own node (d(normalised context) through memory)
+SPLIT_CONTEXT = True      # False: always build the [b, positions, channels + fourier] tensor
 
 
 def _query_probe(x: torch.Tensor, block) -> torch.Tensor:
@@ -81,13 +82,14 @@ def _attend(attn: Attention, xn: torch.Tensor, kv: torch.Tensor, bf16_operands: 
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
 
 
-def _attend_raw_context(block: "PreNorm", xn: torch.Tensor, data: torch.Tensor, residual=None) -> torch.Tensor:
+def _attend_raw_context(block: "PreNorm", xn: torch.Tensor, data, residual=None) -> torch.Tensor:
     """_attend_context given the context BEFORE its LayerNorm (a context that takes no gradient: the images): norm_context,
     to_kv and the attention as one node, whose backward forms the LayerNorm's parameter gradients straight from d(K | V)."""
     attn = block.fn
     q = PF.linear(xn, attn.to_q.weight)
+    data, pos = data if isinstance(data, tuple) else (data, None)      # (channels, position features) kept apart, or one tensor
     out = PF.cross_attention_norm_kv16(q, data, block.norm_context.weight, block.norm_context.bias, block.norm_context.eps,
-                                       attn.to_kv.weight, attn.heads, attn.scale)
+                                       attn.to_kv.weight, attn.heads, attn.scale, pos)
     return PF.linear(out, attn.to_out.weight, attn.to_out.bias, residual=residual)
 
 
@@ -183,20 +185,39 @@ class Perceiver(nn.Module):
         b, *axis, _ = data.shape
         assert len(axis) == self.input_axis, "input data must have the right number of axis"
         enc = self._position_features(axis, data.device)
-        data = torch.cat((data.float(), enc.unsqueeze(0).expand(b, *enc.shape)), dim=-1)
-        data = data.reshape(b, -1, data.shape[-1])                         # [b, positions, channels + fourier]
         x = self.latents.unsqueeze(0).expand(b, -1, -1)
+        bf = self.operand_dtype == "bf16"
+        # When EVERY cross-attention block takes its context through the one-pass kernels (one consumer each, bf16-operand mode, no
+        # gradient into the images), those read a pixel's channels and its position features from where they are: the
+        # [b, positions, channels + fourier] tensor of Perceiver.forward is not built (b x positions x (c + f) floats written
+        # once and read by every block, forward and backward)
+        split = None
+        if SPLIT_CONTEXT and bf and KV_STORED_AS_BF16 and LINEARS_FOLLOW_OPERAND_DTYPE and NORM_CONTEXT_IN_THE_ATTENTION_NODE:
+            chans = data.float().reshape(b, -1, data.shape[-1]).contiguous()
+            pos = enc.reshape(-1, enc.shape[-1]).contiguous()
+            blocks = {id(l[0]): l[0] for l in self.layers}
+            counts = {}
+            for l in self.layers:
+                counts[id(l[0])] = counts.get(id(l[0]), 0) + 1
+            if all(counts[k] == 1 and PF.cross_attention_norm_kv16_supported(_query_probe(x, blk), chans, blk.norm_context.weight,
+                                                                              blk.fn.to_kv.weight, blk.fn.heads, pos)
+                   for k, blk in blocks.items()):
+                split = (chans, pos)
+        if split is None:
+            data = torch.cat((data.float(), enc.unsqueeze(0).expand(b, *enc.shape)), dim=-1)
+            data = data.reshape(b, -1, data.shape[-1])                     # [b, positions, channels + fourier]
         kv_of = {}                                                         # cross-attention block -> projected context
         ctx_of = {}                                                        # ... -> normalised context (one-consumer blocks)
         raw_of = {}                                                        # ... -> the context before its LayerNorm (one consumer, no gradient)
         uses = {}
         for cross_attn, _, _ in self.layers:
             uses[id(cross_attn)] = uses.get(id(cross_attn), 0) + 1
-        bf = self.operand_dtype == "bf16"
         for cross_attn, cross_ff, self_attns in self.layers:
             key = id(cross_attn)
             one_use = bf and KV_STORED_AS_BF16 and LINEARS_FOLLOW_OPERAND_DTYPE and uses[key] == 1
-            if (one_use and NORM_CONTEXT_IN_THE_ATTENTION_NODE and key not in raw_of and
+            if split is not None:
+                raw_of[key] = split
+            elif (one_use and NORM_CONTEXT_IN_THE_ATTENTION_NODE and key not in raw_of and
                     PF.cross_attention_norm_kv16_supported(_query_probe(x, cross_attn), data, cross_attn.norm_context.weight,
                                                            cross_attn.fn.to_kv.weight, cross_attn.fn.heads)):
                 raw_of[key] = data

@@ -233,12 +233,16 @@ class CrossAttentionNormKV16(torch.autograd.Function):
     backward."""
 
     @staticmethod
-    def forward(ctx, q, data, ln_w, ln_b, eps, w_kv, heads, scale):
+    def forward(ctx, q, data, ln_w, ln_b, eps, w_kv, heads, scale, pos=None):
+        # pos (optional): position features [P, d2] that follow the channels of every pixel (data [..., P, d1]): the context rows
+        # are read from the two tensors by the one-pass kernels, never concatenated
         q = q.contiguous()
         x = data.contiguous()
         ctx.one_pass = ONE_PASS_CONTEXT_BACKWARD and w_kv.shape[0] == 128
-        if ctx.one_pass and ONE_PASS_CONTEXT_FORWARD and K.context_fwd_supported(x, w_kv):
-            kv16, mean, rstd = K.context_fwd(x, ln_w, ln_b, w_kv, eps)      # the normalised context is never written
+        if pos is not None and not (ctx.one_pass and ONE_PASS_CONTEXT_FORWARD):
+            raise RuntimeError("cross_attention_norm_kv16: separate position features need the one-pass context kernels")
+        if ctx.one_pass and ONE_PASS_CONTEXT_FORWARD and K.context_fwd_supported(x, w_kv, pos):
+            kv16, mean, rstd = K.context_fwd(x, ln_w, ln_b, w_kv, eps, x2=pos)      # the normalised context is never written
             c2 = None
         else:
             y, mean, rstd = K.layernorm_fwd(x, ln_w, ln_b, eps)
@@ -246,19 +250,19 @@ class CrossAttentionNormKV16(torch.autograd.Function):
             kv16 = K.gemm_rows_bf16out(c2, w_kv.t(), bf16_operands=True).view(x.shape[:-1] + (w_kv.shape[0],))
         out, lse = K.attention_fwd(q, kv16, heads, scale, bf16_operands=True)
         # (the one-pass backward re-forms the normalised context from x, mean, rstd: it is not kept)
-        ctx.save_for_backward(q, x, ln_w, ln_b, mean, rstd, None if ctx.one_pass else c2, w_kv, kv16, out, lse)
+        ctx.save_for_backward(q, x, ln_w, ln_b, mean, rstd, None if ctx.one_pass else c2, w_kv, kv16, out, lse, pos)
         ctx.heads, ctx.scale = heads, scale
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, x, ln_w, ln_b, mean, rstd, c2, w_kv, kv16, out, lse = ctx.saved_tensors
+        q, x, ln_w, ln_b, mean, rstd, c2, w_kv, kv16, out, lse, pos = ctx.saved_tensors
         dq, dkv16 = K.attention_bwd(q, kv16, out, dout.contiguous(), lse, ctx.heads, ctx.scale, bf16_operands=True, dkv_bf16=True)
         g2 = dkv16.view(-1, w_kv.shape[0])
         key, acc = _tied_slot(w_kv)
         nkey, nacc = _tied_slot(ln_w)
         if ctx.one_pass:
-            dw, dlw, dlb = K.context_bwd(g2, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=acc, accumulate_ln_into=nacc)
+            dw, dlw, dlb = K.context_bwd(g2, w_kv, x, mean, rstd, ln_w, ln_b, accumulate_kv_into=acc, accumulate_ln_into=nacc, x2=pos)
             if acc is None:
                 _tied_keep(key, dw)
             else:
@@ -267,7 +271,7 @@ class CrossAttentionNormKV16(torch.autograd.Function):
                 _tied_keep(nkey, (dlw, dlb))
             else:
                 dlw = dlb = None
-            return dq, None, dlw, dlb, None, dw, None, None
+            return dq, None, dlw, dlb, None, dw, None, None, None
         if acc is not None:
             K.gemm_splitk(g2.t(), c2, accumulate_into=acc, bf16_operands=True)
             dw = None
@@ -280,27 +284,33 @@ class CrossAttentionNormKV16(torch.autograd.Function):
         else:
             dlw, dlb = K.layernorm_bwd_params_from_proj(g2, w_kv, x, mean, rstd)
             _tied_keep(nkey, (dlw, dlb))
-        return dq, None, dlw, dlb, None, dw, None, None
+        return dq, None, dlw, dlb, None, dw, None, None, None
 
 
 ONE_PASS_CONTEXT_BACKWARD = True      # False: weight-gradient GEMM + the LayerNorm-parameter kernel (two passes over dK | dV)
 ONE_PASS_CONTEXT_FORWARD = True       # False: LayerNorm kernel + projection GEMM (the normalised context through memory)
 
 
-def cross_attention_norm_kv16_supported(q, data, ln_w, w_kv, heads) -> bool:
+def cross_attention_norm_kv16_supported(q, data, ln_w, w_kv, heads, pos=None) -> bool:
     """The fused node's shape rules, plus: the un-normalised context takes no gradient and the LayerNorm is narrow enough for
-    the accumulator-side sums (d <= 64)."""
-    if data.requires_grad or not data.is_contiguous() or data.dtype != torch.float32 or data.shape[-1] > 64:
+    the accumulator-side sums (d <= 64).  pos: position features kept apart from the channels (see the node)."""
+    d = data.shape[-1] + (pos.shape[-1] if pos is not None else 0)
+    if data.requires_grad or not data.is_contiguous() or data.dtype != torch.float32 or d > 64:
         return False
-    if w_kv.shape[0] not in (64, 128) or not w_kv.is_contiguous() or ln_w.shape[0] != data.shape[-1]:
+    if w_kv.shape[0] not in (64, 128) or not w_kv.is_contiguous() or ln_w.shape[0] != d or w_kv.shape[1] != d:
         return False
-    return cross_attention_kv16_supported(q, data, w_kv, heads)
+    if not (q.shape[-1] // heads == 64 and q.shape[1] <= 128 and w_kv.shape[0] == 2 * q.shape[-1]):
+        return False
+    if pos is not None:
+        return (ONE_PASS_CONTEXT_BACKWARD and ONE_PASS_CONTEXT_FORWARD and not pos.requires_grad
+                and K.context_fwd_supported(data, w_kv, pos) and data.numel() // data.shape[-1] < 2 ** 31)
+    return K.gemm_rows_bf16out_supported(data.view(-1, d), w_kv.t())
 
 
-def cross_attention_norm_kv16(q, data, ln_w, ln_b, eps, w_kv, heads, scale):
+def cross_attention_norm_kv16(q, data, ln_w, ln_b, eps, w_kv, heads, scale, pos=None):
     _note_use(w_kv)
     _note_use(ln_w)
-    return CrossAttentionNormKV16.apply(q, data, ln_w, ln_b, eps, w_kv, heads, scale)
+    return CrossAttentionNormKV16.apply(q, data, ln_w, ln_b, eps, w_kv, heads, scale, pos)
 
 
 def cross_attention_kv16_supported(q, context, w_kv, heads) -> bool:

@@ -262,6 +262,52 @@ def test_exp003_with_the_context_forward_in_one_pass(device):
         assert torch.equal(a, b_)
 
 
+@pytest.mark.parametrize("b,p,d1,d2", [(5, 16384, 12, 26), (3, 4099, 2, 36), (70, 1000, 30, 8)])
+def test_context_kernels_read_channels_and_position_features_from_two_tensors(device, b, p, d1, d2):
+    """pv_context_fwd_bf16 / pv_context_bwd_bf16 with the context rows given as channels [b, P, d1] + position features [P, d2]:
+    the bits they give on the concatenated [b, P, d1 + d2] tensor (which Perceiver.forward would build with torch.cat)."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(b * p + d1)
+    d = d1 + d2
+    chans = (torch.randn(b, p, d1, generator=g) * 3 + 1).to(device)
+    pos = torch.randn(p, d2, generator=g).to(device)
+    full = torch.cat((chans, pos.unsqueeze(0).expand(b, p, d2)), dim=-1).contiguous()
+    lw = (1 + 0.1 * torch.randn(d, generator=g)).to(device)
+    lb = (0.1 * torch.randn(d, generator=g)).to(device)
+    w = (torch.randn(128, d, generator=g) * 0.2).to(device)
+    assert K.context_fwd_supported(chans, w, pos) and K.context_fwd_supported(full, w)
+    kv_a, mean_a, rstd_a = K.context_fwd(chans, lw, lb, w, 1e-5, x2=pos)
+    kv_b, mean_b, rstd_b = K.context_fwd(full, lw, lb, w, 1e-5)
+    assert torch.equal(kv_a, kv_b) and torch.equal(mean_a, mean_b) and torch.equal(rstd_a, rstd_b)
+    g16 = torch.randn(b * p, 128, generator=g).to(device).to(torch.bfloat16)
+    got = K.context_bwd(g16, w, chans, mean_a, rstd_a, lw, lb, x2=pos)
+    ref = K.context_bwd(g16, w, full, mean_a, rstd_a, lw, lb)
+    for a_, b_ in zip(got, ref):
+        assert torch.equal(a_, b_)
+
+
+def test_exp003_without_the_concatenated_context(device):
+    """perceiver_core.SPLIT_CONTEXT (the default where every cross-attention block runs the one-pass context kernels): the
+    [b, positions, channels + fourier] tensor is not built; output, loss and every gradient keep their bits."""
+    from predict_pv_yield_amd.models.perceiver import perceiver_core
+    from predict_pv_yield_amd.models.perceiver.exp003 import make_fake_exp003_batch
+    batch = make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(9))
+    results = []
+    for split in (True, False):
+        perceiver_core.SPLIT_CONTEXT = split
+        try:
+            _, model = _pair(device, "bf16", seed=5)
+            y = model(_to(batch, device))
+            loss = model.training_step(_to(batch, device), 0)
+            loss.backward()
+            results.append([y.detach(), loss.detach()] + [p.grad.clone() for p in model.parameters() if p.grad is not None])
+        finally:
+            perceiver_core.SPLIT_CONTEXT = True
+    assert len(results[0]) == len(results[1]) > 10
+    for a, b_ in zip(*results):
+        assert torch.equal(a, b_)
+
+
 def test_exp003_with_the_context_norm_inside_the_attention_node(device):
     """perceiver_core.NORM_CONTEXT_IN_THE_ATTENTION_NODE (the default for a context one layer consumes): output and loss are
     the same bits as with norm_context as its own node, every gradient but norm_context's too; norm_context's weight / bias
