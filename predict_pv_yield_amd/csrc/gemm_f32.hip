@@ -729,7 +729,8 @@ int pv_gemm_ex_f32(const float* a, const float* b, const float* bias, const floa
   PV_REQUIRE(grid.y <= 65535, PV_ESIZE, "pv_gemm_f32: n too large for one launch");
   // default: the bf16 x 3 form (f32 accuracy at 3/8 of the matrix-pipe time); PV_GEMM_EXACT_F32=1 keeps the products on the
   // f32 matrix instruction (bit-exact f32 products)
-  static const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr;
+  // (PV_EXACT_F32=1 is the one switch for every split product of the precision="fp32" path; read per call so that a test can flip it)
+  const bool exact_f32 = getenv("PV_GEMM_EXACT_F32") != nullptr || getenv("PV_EXACT_F32") != nullptr;
   static const bool no_rows_form = getenv("PV_GEMM_NO_ROWS_FORM") != nullptr;
   const bool rows_form = (!exact_f32 || one_term) && !a_bf16 && !no_rows_form && zs == 1 && d->a_cs == 1 && d->k <= 64 &&
                          d->m >= 2048 && ((uintptr_t)a % 16 == 0);

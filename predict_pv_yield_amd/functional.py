@@ -5,7 +5,10 @@ Reference operators replaced (all third-party torch in the reference):
   F.relu(nn.Linear(...)(x))   model.py:125-126,151-152
   (y_hat - y).abs().mean()    predict_pv_yield/models/base_model.py:99
 Two numeric modes:
-  "fp32": reference layout NCDHW, exact-f32 FMA kernels (tight parity with torch CPU);
+  "fp32": reference layout NCDHW, f32-accurate kernels (rtol-1e-4 parity with torch CPU): forward / dgrad on the f32 matrix
+          cores (exact f32 products), the weight gradients of the 32-channel layers and fc1's products as split half-float /
+          bf16 terms on the 16-bit matrix cores (f32-accurate to ~1e-6, not bit-exact f32).  PV_EXACT_F32=1 in the environment
+          puts every one of those products back on the f32 kernels (exact_f32() below; pv_gemm reads the same variable);
   "bf16": NDHWC bf16 activations, MFMA kernels with f32 accumulation (throughput path).
 """
 import ctypes
@@ -42,6 +45,13 @@ class Conv3dReLUF32(torch.autograd.Function):
 LINEAR_F32_GEMM_K = 1 << 16     # the same threshold as pv_linear_fwd_f32 (dense_f32.hip GEMM_K)
 
 
+def exact_f32() -> bool:
+    """PV_EXACT_F32=1: the precision="fp32" path keeps every product on the f32 kernels (conv weight gradient on the f32 matrix
+    cores, fc1 on the f32 tile kernels / pv_gemm's f32 matrix instruction) instead of the split 16-bit forms."""
+    import os
+    return bool(os.environ.get("PV_EXACT_F32"))
+
+
 class LinearF32(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
@@ -55,7 +65,9 @@ class LinearF32(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        if x.shape[1] >= LINEAR_F32_GEMM_K and dy.numel() % 4 == 0:
+        # (the GEMM's limits: its column tiles ride grid.y -- 65 535 x 64 input features -- and rows x features in 31 bits)
+        if (x.shape[1] >= LINEAR_F32_GEMM_K and dy.numel() % 4 == 0 and not exact_f32() and x.shape[1] <= 65535 * 64
+                and x.shape[0] * x.shape[1] < 2 ** 31):
             # fc1-sized: the two products on the matrix cores at f32 accuracy (pv_gemm_f32), 650 us against 790 us
             g = K.relu_gate_f32(dy, y) if y is not None else dy.contiguous()
             dx = K.gemm(g, weight) if ctx.needs_input_grad[0] else None
@@ -343,16 +355,21 @@ def _triple(v):
 def _wgrad_on_bf16x3(x, dy, y, weight, stride) -> bool:
     """3x3x3, stride 1, 32 output channels, <= 32 input channels, dy already gated (y is None), a batch worth the six
     launches, and the split kernel's alignment (voxels per sample % 4 == 0 on both tensors)."""
-    if not F32_WGRAD_ON_BF16X3 or y is not None or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
+    if not F32_WGRAD_ON_BF16X3 or exact_f32() or y is not None or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
         return False
     if weight.shape[0] != 32 or weight.shape[1] > 32:
         return False
     vx, vy = x.shape[2] * x.shape[3] * x.shape[4], dy.shape[2] * dy.shape[3] * dy.shape[4]
+    # the split kernels' own limits (pv_conv3d_bwd_weight_bf16: batch on grid.z, 1 GiB of packed voxels per sample): beyond them
+    # the general f32 kernel runs, as before the split existed
+    if x.shape[0] > 65535 or vx * 64 > (1 << 30):
+        return False
     return vx % 4 == 0 and vy % 4 == 0 and x.shape[0] * vy >= (1 << 16)
 
 
 class Conv3dGeneralF32(torch.autograd.Function):
-    """nn.Conv3d with kernel extents 1..3, any stride / padding (+ optional fused ReLU) on the exact-f32 kernels:
+    """nn.Conv3d with kernel extents 1..3, any stride / padding (+ optional fused ReLU) on the f32 kernels (weight gradient of
+    32-channel 3x3x3 layers: f32-accurate split products, see exact_f32()):
     the layers of the optical-flow notebook model (13_…ipynb:969-985) and Conv3dMaxPool's conv.
     In a conv+ReLU chain the ReLU gating of the activation gradient is moved into the PRODUCING dgrad kernel:
     x_is_relu_output -> this layer's dx leaves already zeroed where x <= 0; dy_pregated -> the incoming dy was gated

@@ -62,7 +62,8 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
             c_in = channels
         out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
         return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True, x_is_relu_output=True)   # out = relu(last conv)
-    # precision="fp32": exact-f32 arithmetic on the reference layout.  32-channel 3x3x3 layers run on the f32 matrix cores
+    # precision="fp32": f32-accurate arithmetic on the reference layout (exact f32 products forward / dgrad; split 16-bit products
+    # for weight gradients and fc1 unless PV_EXACT_F32=1, functional.exact_f32()).  32-channel 3x3x3 layers run on the f32 matrix cores
     # (v_mfma_f32_32x32x2_f32: forward / dgrad conv3d_fwd_mfma_f32<3,3,3>, weight gradient conv3d_wgrad_mfma_f32<3,3,3>),
     # the first layer and odd shapes on the register-tiled FMA kernels; each dgrad gates dx with its producer's ReLU
     out = data.float() if data.dtype != torch.float32 else data

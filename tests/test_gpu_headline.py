@@ -171,8 +171,13 @@ def test_bf16_adam_steps_with_the_fused_fc1_kernel(device, emulate):
         _check(f"emulate={emulate} step3 exp_avg {k} rel", _rel(opt.moments(p)[0].cpu(), rst["exp_avg"]), tol)
 
 
-def test_fp32_path_at_headline_size(device):
-    """precision="fp32": exact-f32 FMA kernels on the reference layout, rtol 1e-4 against torch CPU."""
+@pytest.mark.parametrize("exact", [False, True])
+def test_fp32_path_at_headline_size(device, monkeypatch, exact):
+    """precision="fp32" on the reference layout, rtol 1e-4 against torch CPU -- in its default form (weight gradients and fc1 as split
+    products on the 16-bit matrix cores, fc1's gradient inside the Adam pass) and with PV_EXACT_F32=1 (every product on the f32
+    kernels)."""
+    if exact:
+        monkeypatch.setenv("PV_EXACT_F32", "1")
     oracle, model = _pair("fp32", device)
     sat, pv = _data(2)
     y_ref, ref_losses = _oracle_backward(oracle, sat, pv)
