@@ -421,11 +421,16 @@ __global__ __launch_bounds__(256) void prepare_stacks_kernel(const T* __restrict
                                                               const float* __restrict__ mean, const float* __restrict__ std_,
                                                               int32_t* range_flag) {
   bool bad = false;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-    // i enumerates [B][T][C][frame8] (source order)
-    const int px = (int)(i % frame8);
-    long long f = i / frame8;
+  // a workgroup takes 256 vectors of ONE frame: (b, t, c) of the frame are wave-uniform (scalar divisions once per trip; the
+  // per-thread form -- five 64-bit divisions per 8 pixels -- made this streaming kernel instruction-bound: 0.42 of HBM)
+  const int bpf = (frame8 + 255) / 256;
+  const long long n_frames = n_vec / frame8;
+  for (long long blk = blockIdx.x; blk < n_frames * bpf; blk += gridDim.x) {
+    const long long fr = __builtin_amdgcn_readfirstlane((int)(blk / bpf));     // (frames < 2^31: n_vec / frame8)
+    const int px = (int)(blk - fr * bpf) * 256 + (int)threadIdx.x;
+    if (px >= frame8) continue;
+    const long long i = fr * frame8 + px;      // [B][T][C][frame8] (source order)
+    long long f = fr;
     const int ci = (int)(f % c);
     f /= c;
     const int ti = (int)(f % t);
@@ -480,8 +485,10 @@ static int prepare_stacks_launch(const T* raw, uint8_t* u8, float* out, int64_t 
   PV_REQUIRE(((uintptr_t)raw % 16 == 0) && ((uintptr_t)u8 % 8 == 0) && ((uintptr_t)out % 16 == 0), PV_EINVAL,
              "pv_prepare_stacks: unaligned operand");
   const long long n_vec = (long long)batch * t * c * (frame / 8);
-  hipLaunchKernelGGL((prepare_stacks_kernel<T>), dim3(stream_grid((size_t)n_vec, 256)), dim3(256), 0, as_stream(stream), raw, u8,
-                     out, n_vec, t, c, (int)(frame / 8), t_out, mode, mean, std_, range_flag);
+  PV_REQUIRE((long long)batch * t * c <= 0x7fffffffLL, PV_ESIZE, "pv_prepare_stacks: too many frames");
+  const long long n_blk = (long long)batch * t * c * ((frame / 8 + 255) / 256);      // 256 vectors of one frame per workgroup trip
+  hipLaunchKernelGGL((prepare_stacks_kernel<T>), dim3((unsigned)std::min<long long>(n_blk, 1 << 20)), dim3(256), 0,
+                     as_stream(stream), raw, u8, out, n_vec, t, c, (int)(frame / 8), t_out, mode, mean, std_, range_flag);
   return check_launch("pv_prepare_stacks");
 }
 
