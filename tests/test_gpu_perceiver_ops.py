@@ -204,6 +204,33 @@ def test_gru_vs_torch(b, t, inp, h, layers, device):
     torch.testing.assert_close(out2.cpu(), ref(x.detach())[0], rtol=1e-4, atol=1e-5)
 
 
+def test_gru_with_the_weights_in_registers_against_the_general_kernels(device, monkeypatch):
+    """Hidden size 16 (every GRU of the reference's models) runs kernels that keep W_hh and dW_hh in registers
+    (gru_seq_{fwd,bwd}_hs_f32<16>): the forward is the general kernel's bits, the backward too except the gradient that flows
+    through the hidden state (summed over the units in index order instead of a shuffle tree)."""
+    _, PF = _mods()
+    torch.manual_seed(3)
+    mod = torch.nn.GRU(input_size=24, hidden_size=16, num_layers=2, batch_first=True).to(device)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(8, 19, 24, generator=g).to(device)
+    d_out = torch.randn(8, 19, 16, generator=g).to(device)
+    res = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("PV_GRU_GENERAL", "1")
+        mod.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        out, hn = PF.gru(xd, mod)
+        (out * d_out).sum().add(hn.sum()).backward()
+        res.append((out.detach(), hn.detach(), xd.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
+    monkeypatch.delenv("PV_GRU_GENERAL")
+    (o1, h1, gx1, gp1), (o0, h0, gx0, gp0) = res
+    assert torch.equal(o1, o0) and torch.equal(h1, h0)
+    torch.testing.assert_close(gx1, gx0, rtol=1e-5, atol=1e-6)
+    for a, b_ in zip(gp1, gp0):
+        torch.testing.assert_close(a, b_, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("b,h,nq,nk", [(3, 1, 128, 4096), (2, 8, 128, 128), (2, 2, 40, 70), (1, 1, 130, 33)])
 def test_fused_attention_forward(b, h, nq, nk, device):
     """pv_attention_fwd_f32 (online softmax, scores never materialised) vs softmax(scale q k^T) v with torch on the CPU."""
