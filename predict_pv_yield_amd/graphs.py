@@ -22,6 +22,12 @@ def _map_tensors(obj: Any, fn):
         return {k: _map_tensors(v, fn) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
         return type(obj)(_map_tensors(v, fn) for v in obj)
+    if hasattr(obj, "__dict__") and not isinstance(obj, type):      # attribute containers: data.batch.BatchML and its sections
+        import copy
+        out = copy.copy(obj)
+        for k, v in vars(obj).items():
+            setattr(out, k, _map_tensors(v, fn))
+        return out
     return obj
 
 
@@ -37,6 +43,9 @@ def _copy_into(dst: Any, src: Any) -> None:
     elif isinstance(dst, (list, tuple)):
         for d, s in zip(dst, src):
             _copy_into(d, s)
+    elif hasattr(dst, "__dict__") and not isinstance(dst, type):
+        for k, d in vars(dst).items():
+            _copy_into(d, getattr(src, k))
 
 
 class GraphedTrainStep:

@@ -380,6 +380,39 @@ def _to(batch, device):
     return {k: v.to(device) for k, v in batch.items()}
 
 
+def test_exp003_train_step_replays_as_a_hip_graph(device):
+    """graphs.GraphedTrainStep on experiments/003's LitModel (operand_dtype="bf16": the one-pass context kernels, the tied-gradient
+    bookkeeping, ~600 launches per step): the replayed step gives the eager step's losses bit for bit over several batches."""
+    from predict_pv_yield_amd.graphs import GraphedTrainStep
+    from predict_pv_yield_amd.models.perceiver.exp003 import LitModel, make_fake_exp003_batch
+    from predict_pv_yield_amd.optim import HipAdam
+    batches = [_to(make_fake_exp003_batch(2, 64, torch.Generator().manual_seed(s)), device) for s in range(3)]
+
+    def make(capturable):
+        torch.manual_seed(11)
+        model = LitModel(operand_dtype="bf16").to(device)
+        return model, HipAdam(model.parameters(), lr=0.0005, capturable=capturable)
+
+    model_e, opt_e = make(False)
+    model_g, opt_g = make(True)
+    step = GraphedTrainStep(model_g, opt_g, batches[0], warmup=2)
+    try:
+        for _ in range(2):      # the helper's warm-up steps are training steps: the same two on the eager side
+            opt_e.zero_grad(set_to_none=True)
+            model_e.training_step(batches[0], 0).backward()
+            opt_e.step()
+        for i in range(5):
+            opt_e.zero_grad(set_to_none=True)
+            loss = model_e.training_step(batches[i % 3], 0)
+            loss.backward()
+            opt_e.step()
+            assert float(step(batches[i % 3])) == float(loss), f"step {i}"
+        for p, q in zip(model_g.parameters(), model_e.parameters()):
+            assert torch.equal(p, q)
+    finally:
+        step.close()
+
+
 def test_exp003_structure_and_batch_contract():
     from predict_pv_yield_amd.models.perceiver import exp003
     m = exp003.LitModel()

@@ -401,3 +401,25 @@ def test_every_experiment_names_an_existing_dataset_configuration():
                 assert os.path.isabs(path) and os.path.exists(os.path.join(path, "configuration.yaml")), (name, path)
     finally:
         os.chdir(cwd)
+
+
+def test_graph_helper_maps_and_refills_attribute_container_batches():
+    """graphs.GraphedTrainStep keeps a static copy of the example batch and copies every new batch into it: that must reach the
+    tensors of a BatchML (sections as attribute namespaces), not only those of dicts -- a container it does not look into would
+    make the graph replay the captured batch for ever."""
+    import torch
+    from predict_pv_yield_amd.data.batch import BatchML
+    from predict_pv_yield_amd.graphs import _copy_into, _map_tensors
+    a = BatchML(satellite={"data": torch.arange(6.).reshape(2, 3)}, gsp={"gsp_yield": torch.ones(2, 4), "note": "x"})
+    static = _map_tensors(a, lambda t: t.clone())
+    assert isinstance(static, BatchML) and static.satellite.data is not a.satellite.data
+    assert torch.equal(static.satellite.data, a.satellite.data) and static.gsp.note == "x"
+    b = BatchML(satellite={"data": torch.full((2, 3), 7.)}, gsp={"gsp_yield": torch.zeros(2, 4), "note": "x"})
+    kept = static.satellite.data
+    _copy_into(static, b)
+    assert static.satellite.data is kept and torch.equal(kept, b.satellite.data)
+    assert torch.equal(static["gsp_yield"], b["gsp_yield"])
+    nested = {"k": [torch.zeros(2), (torch.ones(1),)]}
+    st = _map_tensors(nested, lambda t: t.clone())
+    _copy_into(st, {"k": [torch.full((2,), 3.), (torch.full((1,), 5.),)]})
+    assert st["k"][0].tolist() == [3.0, 3.0] and st["k"][1][0].item() == 5.0
