@@ -511,6 +511,21 @@ def measure_other_models(dev):
         out["exp003_perceiver_rnn"][f"attention_operands_{dt}"] = entry
         del em, eopt
         torch.cuda.empty_cache()
+    # the same step (bf16 operands) replayed as ONE HIP graph: ~600 launches per step keep the host as busy as the device in
+    # eager mode (graphs.GraphedTrainStep; losses identical to the eager step: tests/test_gpu_exp003.py)
+    try:
+        from predict_pv_yield_amd.graphs import GraphedTrainStep
+        from predict_pv_yield_amd.optim import HipAdam
+        torch.manual_seed(0)
+        em = LitModel(operand_dtype="bf16").to(dev)
+        gstep = GraphedTrainStep(em, HipAdam(em.parameters(), lr=0.0005, capturable=True), ebatch, warmup=3)
+        d = time_steps(lambda: gstep(ebatch), 8, 3)
+        out["exp003_perceiver_rnn"]["attention_operands_bf16"]["hip_graph_ms_per_step"] = round(d * 1e3, 2)
+        gstep.close()
+        del em, gstep
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the bench line down
+        out["exp003_perceiver_rnn"]["attention_operands_bf16"]["hip_graph_ms_per_step"] = f"failed: {type(e).__name__}: {e}"
+    torch.cuda.empty_cache()
     return out
 
 
