@@ -641,9 +641,18 @@ __global__ __launch_bounds__(FB_FR_NT) void fb_prep_polyexp_frame_kernel(const u
 // ---- UpdateMatrices --------------------------------------------------------------------------------
 // one pixel of FarnebackUpdateMatrices: R0 = this pixel's 5 coefficients, R1 = base of the second image's
 // coefficient plane, (dx, dy) = current flow; out = (G11, G12, G22, h1, h2)
-__device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, const float* __restrict__ R1, float dx,
+// five consecutive floats (one pixel's coefficients, 20-byte stride: 4-byte aligned only) as ONE 16-byte + one 4-byte load:
+// lane-by-lane dword loads of such records touch every cache line five times (the frame kernel was bound by that, not by HBM)
+typedef float fb_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void fb_load5(const float* __restrict__ p, float (&v)[5]) {
+  const fb_f4u a = *reinterpret_cast<const fb_f4u*>(p);
+  v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = p[4];
+}
+__device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0p, const float* __restrict__ R1, float dx,
                                                 float dy, int x, int y, int width, int height, float* m) {
   const size_t step1 = (size_t)width * 5;
+  float R0[5];
+  fb_load5(R0p, R0);
   float fx = __fadd_rn((float)x, dx), fy = __fadd_rn((float)y, dy);
   int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
   float r2, r3, r4, r5, r6;
@@ -653,9 +662,14 @@ __device__ __forceinline__ void fb_update_pixel(const float* __restrict__ R0, co
     const float* ptr = R1 + (size_t)y1 * step1 + (size_t)x1 * 5;
     float a00 = __fmul_rn(1.f - fx, 1.f - fy), a01 = __fmul_rn(fx, 1.f - fy);
     float a10 = __fmul_rn(1.f - fx, fy), a11 = __fmul_rn(fx, fy);
+    float t00[5], t01[5], t10[5], t11[5];
+    fb_load5(ptr, t00);
+    fb_load5(ptr + 5, t01);
+    fb_load5(ptr + step1, t10);
+    fb_load5(ptr + step1 + 5, t11);
 #define PV_BILIN(c) \
-  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, ptr[c]), __fmul_rn(a01, ptr[5 + c])), __fmul_rn(a10, ptr[step1 + c])), \
-            __fmul_rn(a11, ptr[step1 + 5 + c]))
+  __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a00, t00[c]), __fmul_rn(a01, t01[c])), __fmul_rn(a10, t10[c])), \
+            __fmul_rn(a11, t11[c]))
     r2 = PV_BILIN(0);
     r3 = PV_BILIN(1);
     r4 = PV_BILIN(2);
@@ -787,8 +801,8 @@ __global__ __launch_bounds__(256) void fb_update_matrices_kernel(const float* __
       for (int c = 0; c < 5; ++c) M[(p * 5 + c) * per_img + rem] = m[c];
     } else {
       float* d = M + i * 5;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) d[c] = m[c];
+      *reinterpret_cast<fb_f4u*>(d) = (fb_f4u){m[0], m[1], m[2], m[3]};
+      d[4] = m[4];
     }
   }
 }
