@@ -14,6 +14,8 @@ python3 tools/diag_stamps.py flow 32 > $O/flow_level_kernel_stamps.txt 2>&1
 for k in wgrad wgrad16 fwd dgrad first; do python3 tools/diag_stamps.py $k 32; done > $O/conv_stamps.txt 2>&1
 python3 tools/time_conv.py > $O/time_conv.txt 2>&1
 python3 tools/time_fp32_step.py > $O/fp32_step_kernels.txt 2>&1
+bash tools/probes/fullframe_run.sh > $O/flow_fullframe_704x548.txt 2>&1      # Farneback on one 25-frame 704x548 super-batch (+ kernel stats in gpurun_out/ff)
+bash tools/probes/exp003_kernel_table.sh > $O/exp003_step_kernel_stats.txt 2>&1   # experiments/003 train step, kernel table
 find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*counter_collection.csv" -size +20M -delete
 ls -la $O $O/kt $O/flow
