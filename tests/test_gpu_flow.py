@@ -157,7 +157,7 @@ def _pair(rng, h, w, v):
     return u8
 
 
-@pytest.mark.parametrize("h,w", [(64, 64), (32, 48), (96, 80), (160, 200)])
+@pytest.mark.parametrize("h,w", [(64, 64), (32, 48), (96, 80), (160, 200), (65, 67), (20, 200), (131, 70)])     # (the last three: frame kernels on odd sizes)
 def test_farneback_vs_oracle(device, h, w):
     K = _ops()
     rng = np.random.default_rng(h + w)
@@ -192,7 +192,8 @@ def test_farneback_full_extent_vs_oracle(device):
     assert np.percentile(np.abs(inner[..., 0] - 2.2), 95) < 0.25 and np.percentile(np.abs(inner[..., 1] + 1.4), 95) < 0.25
 
 
-@pytest.mark.parametrize("h,w,n", [(548, 704, 3), (160, 200, 2), (96, 80, 5), (70, 131, 2), (65, 67, 1)])
+@pytest.mark.parametrize("h,w,n", [(548, 704, 3), (160, 200, 2), (96, 80, 5), (70, 131, 2), (65, 67, 1), (20, 200, 2), (200, 20, 2),
+                                   (64, 65, 1), (65, 64, 3), (33, 300, 1)])
 def test_frame_window_blur_in_register_windows_is_bit_identical_to_one_load_per_tap(device, monkeypatch, h, w, n):
     """Levels larger than a 64 x 64 tile (the notebooks' 704 x 548 frames): the 41-tap window blur as sliding register
     windows over a transposed intermediate (fb_blur_v_run_kernel / fb_blur_h_solve_run_kernel) performs the operations of the
@@ -215,6 +216,7 @@ def test_frame_window_blur_in_register_windows_is_bit_identical_to_one_load_per_
     (131, 70, 3, {}),                                    # odd sizes: the coarse level is no exact half
     (97, 150, 2, dict(pyr_scale=0.7, levels=3)),         # every coarse level resampled bilinearly, 5- and 7-tap smoothing
     (200, 120, 1, dict(poly_n=7, poly_sigma=1.5, levels=1)),
+    (20, 200, 2, {}), (200, 20, 1, {}), (64, 65, 2, {}), (65, 64, 1, {}), (33, 300, 1, dict(levels=3)),
 ])
 def test_frame_prep_polyexp_in_one_kernel_is_bit_identical_to_the_three_kernels(device, monkeypatch, h, w, n, kw):
     """Frames larger than a tile: smoothing, resize and both PolyExp passes of a level as ONE launch with the stages in LDS
