@@ -394,6 +394,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
   constexpr int BRS = 2 * KP + 16;                       // bytes per n-row of a B plane (16 rows x 16 B cover the 64 banks)
   constexpr int BPLANE = G_BN * BRS;
   __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BPLANE];
+  constexpr int CW_RS = 2 * G_BN + 16;                   // bytes per row of a wave's bf16 output tile (OUT_BF16)
+  __shared__ __attribute__((aligned(16))) unsigned char Cw[OUT_BF16 ? 4 * 32 * CW_RS : 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * G_BN;
   const float* __restrict__ A = g.a;
@@ -538,6 +540,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
     // C layout of the 32x32 accumulator: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  One 64-bit
     // address per (block, column half) and lane; the row offsets are wave-uniform.  Only a ragged last block tests rows.
     const bool whole = (long long)rb * 32 + 32 <= g.m;
+    if constexpr (OUT_BF16) {
+      // bf16 output of a whole 64-column block with rows of whole 16-byte pieces: the wave's 32 x 64 tile goes through its own
+      // LDS tile and leaves as 128 contiguous bytes per row (16 bytes per lane, four store instructions) instead of 32
+      // instructions of 2-byte stores that each touch 2 x 32 cache lines -- the store side was what bounded the key / value
+      // projection of a 2.5 M-row context (0.64 GB written)
+      if (n0 + G_BN <= g.n && !g.res && (g.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        unsigned char* ct = Cw + wave * (32 * CW_RS);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float bv = t == 0 ? bias0 : bias1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = (t == 0 ? acc0[r] : acc1[r]) + bv;
+            if (g.relu) v = v > 0.f ? v : 0.f;
+            *reinterpret_cast<uint16_t*>(ct + ((r & 3) + 8 * (r >> 2) + 4 * half) * CW_RS + 2 * (32 * t + row)) = f32_to_bf16_bits(v);
+          }
+        }
+        // (the same wave reads what it wrote: LDS operations of a wave complete in order)
+        uint16_t* cb = reinterpret_cast<uint16_t*>(C) + (long long)rb * 32 * g.ldc + n0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rr = 8 * j + (lane >> 3), c16 = lane & 7;
+          if (whole || (long long)rb * 32 + rr < g.m)
+            *reinterpret_cast<u32x4*>(cb + (long long)rr * g.ldc + 8 * c16) = *reinterpret_cast<const u32x4*>(ct + rr * CW_RS + 16 * c16);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int nn = n0 + 32 * t + row;
