@@ -637,6 +637,127 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_x3_kernel(GemmK g, int n_row
   }
 }
 
+// ---- norm_context + to_kv of a cross-attention in one pass, all 128 output columns per row block --------------------------
+// gemm_rows_x3_kernel<.., LN_A> walks the rows once per 64-column block: for the 128 columns of K | V the rows are read, exchanged
+// between partner lanes and normalised TWICE, and that vector work (~900 instructions per 32-row block), not memory, set its pace
+// (395 us for 1.0 GB).  Here a wave keeps four accumulator tiles: one read of the rows, one LayerNorm, twelve matrix instructions
+// in the rows-form kernel's order (same bits), the 32 x 128 bf16 tile out through the wave's LDS tile as whole 256-byte rows.
+// gamma / beta come from LDS (the lanes of a half read the same words: broadcasts) instead of 48 registers.
+constexpr int CF_KP = 48;                        // d <= 48: three 16-deep steps
+constexpr int CF_WRS = 2 * CF_KP + 16;           // bytes per n-row of W in LDS
+constexpr int CF_CRS = 2 * 128 + 16;             // bytes per row of a wave's output tile
+__global__ __launch_bounds__(256, 2) void context_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                                    int d1, int period, const float* __restrict__ lnw,
+                                                                    const float* __restrict__ lnb, const float* __restrict__ wkv,
+                                                                    uint16_t* __restrict__ kv16, float* __restrict__ mean,
+                                                                    float* __restrict__ rstd, long long rows, int d, float eps,
+                                                                    int n_rowblocks) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[128 * CF_WRS];
+  __shared__ __attribute__((aligned(16))) unsigned char Cw[4 * 32 * CF_CRS];
+  __shared__ __attribute__((aligned(16))) float Gs[CF_KP], Bt[CF_KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 31, half = lane >> 5;
+  for (int i = tid; i < 128 * CF_KP; i += 256) {      // Ws[n][k] = bf16(W[n][k]) (the Linear weight is [128, d]), zero for k >= d
+    const int n = i / CF_KP, k = i - n * CF_KP;
+    *reinterpret_cast<uint16_t*>(Ws + n * CF_WRS + 2 * k) = f32_to_bf16_bits(k < d ? wkv[(size_t)n * d + k] : 0.f);
+  }
+  if (tid < CF_KP) Gs[tid] = tid < d ? lnw[tid] : 0.f, Bt[tid] = tid < d ? lnb[tid] : 0.f;
+  const int stride = gridDim.x * 4;
+  float araw[2][3][8];
+  auto load_a = [&](int rb, float (&dst)[3][8]) {
+    const long long mm = (long long)rb * 32 + row;
+    const bool row_ok = rb < n_rowblocks && mm < rows;
+    const long long mc = row_ok ? mm : 0;
+    const float* a1 = x + mc * (x2 ? d1 : d);
+    const float* a2 = x2 ? x2 + (size_t)((unsigned)mc % (unsigned)period) * (d - d1) - d1 : a1;
+    const int split = x2 ? d1 : d;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {      // pairs: d and d1 are even, a pair never straddles the two sources
+        const int k = 16 * ks + 8 * half + 2 * v;
+        float2 t = make_float2(0.f, 0.f);
+        if (row_ok && k < d) t = *reinterpret_cast<const float2*>((k < split ? a1 : a2) + k);
+        dst[ks][2 * v] = t.x, dst[ks][2 * v + 1] = t.y;
+      }
+  };
+  auto process = [&](int rb, const float (&ar_in)[3][8]) {
+    // the partner lane's half of the row; the serial sums of layernorm_fwd_rows_f32 (same order: same bits)
+    float lo[3][8], hi[3][8];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float other = __shfl_xor(ar_in[ks][v], 32);
+        lo[ks][v] = half ? other : ar_in[ks][v];
+        hi[ks][v] = half ? ar_in[ks][v] : other;
+      }
+    auto at = [&](int k) { return ((k >> 3) & 1) ? hi[k >> 4][k & 7] : lo[k >> 4][k & 7]; };
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CF_KP / 2; ++j) s += at(2 * j) + at(2 * j + 1);
+    const float mu = s / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < CF_KP / 2; ++j)
+      if (2 * j < d) {
+        const float t0 = at(2 * j) - mu, t1 = at(2 * j + 1) - mu;
+        q += t0 * t0 + t1 * t1;
+      }
+    const float rs = 1.0f / sqrtf(q / (float)d + eps);
+    const long long mm = (long long)rb * 32 + row;
+    if (half == 0 && mm < rows) mean[mm] = mu, rstd[mm] = rs;
+    typedef __attribute__((ext_vector_type(16))) float v16f;
+    v16f acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int kb = 16 * ks + 8 * half;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(Gs + kb), g1 = *reinterpret_cast<const f32x4*>(Gs + kb + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bt + kb), b1 = *reinterpret_cast<const f32x4*>(Bt + kb + 4);
+      float an[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float gw = v < 4 ? g0[v] : g1[v - 4], bw = v < 4 ? b0[v] : b1[v - 4];
+        an[v] = kb + v < d ? (ar_in[ks][v] - mu) * rs * gw + bw : 0.f;
+      }
+      u32x4 w1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w1[j] = pack_bf16_pair(an[2 * j], an[2 * j + 1]);
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, w1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, *reinterpret_cast<const bf16x8*>(Ws + (32 * t + row) * CF_WRS + 2 * kb), acc[t], 0, 0, 0);
+    }
+    unsigned char* ct = Cw + wave * (32 * CF_CRS);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<uint16_t*>(ct + ((r & 3) + 8 * (r >> 2) + 4 * half) * CF_CRS + 2 * (32 * t + row)) = f32_to_bf16_bits(acc[t][r]);
+    uint16_t* cb = kv16 + (long long)rb * 32 * 128;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // (the same wave reads what it wrote: a wave's LDS operations complete in order)
+      const int rr = 4 * j + (lane >> 4), c16 = lane & 15;
+      if ((long long)rb * 32 + rr < rows)
+        *reinterpret_cast<u32x4*>(cb + (long long)rr * 128 + 8 * c16) = *reinterpret_cast<const u32x4*>(ct + rr * CF_CRS + 16 * c16);
+    }
+  };
+  int rb = blockIdx.x * 4 + wave;
+  load_a(rb, araw[0]);
+  __syncthreads();
+  for (; rb < n_rowblocks; rb += 2 * stride) {
+    load_a(rb + stride, araw[1]);
+    process(rb, araw[0]);
+    if (rb + stride >= n_rowblocks) break;
+    load_a(rb + 2 * stride, araw[0]);
+    process(rb + stride, araw[1]);
+  }
+}
+
 // out[i] = sum over s of slabs[s * stride + offset + i], i < n.  Workgroup = 32 columns x 8 slab groups: thread (c, g)
 // adds slabs g, g+8, ... in index order, the 8 group sums are then added in group order -- a fixed order, 8-way parallel.
 // accumulate != 0: out[i] += the sum (a tied weight's gradient contributions added in arrival order, as autograd would).
@@ -858,6 +979,13 @@ int pv_context_fwd_bf16(const float* x, const float* x2, int32_t d1, int64_t per
   if (per_col < 1) per_col = 1;
   if (per_col > (n_rb + 3) / 4) per_col = (n_rb + 3) / 4;
   dim3 rgrid((unsigned)n_tiles, (unsigned)per_col);
+  if (kdim == 128 && ((uintptr_t)kv16 & 15) == 0 && !getenv("PV_CONTEXT_FWD_TWO_COLUMN_BLOCKS")) {
+    // all 128 columns per row block: the rows are read and normalised once
+    const int nb = std::min((n_rb + 3) / 4, 2 * kNumCU);
+    hipLaunchKernelGGL(context_fwd_rows_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), x, x2, d1, (int)period, ln_w,
+                       ln_b, w_kv, kv16, mean, rstd, (long long)rows, d, eps, n_rb);
+    return check_launch("pv_context_fwd_bf16");
+  }
   const GemmLnA ln = {ln_w, ln_b, mean, rstd, eps, x2, d1, (int)period};
   hipLaunchKernelGGL((gemm_rows_x3_kernel<3, 2, true, 1, true>), rgrid, dim3(256), 0, as_stream(stream), g, n_rb, ln);
   return check_launch("pv_context_fwd_bf16");
