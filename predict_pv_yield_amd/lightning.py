@@ -243,8 +243,13 @@ class Trainer:
                  resume_from_checkpoint=None, precision=32, weights_summary=None, progress_bar_refresh_rate=None,
                  profiler=None, limit_train_batches=1.0, limit_val_batches=1.0, limit_test_batches=1.0,
                  num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
-                 default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, **unused):
+                 default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, hip_graph=False, **unused):
         self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
+        # hip_graph (new, opt-in; also PV_TRAINER_HIP_GRAPH=1): single-process fits with ONE HipAdam optimiser replay the train
+        # step as a HIP graph (graphs.GraphedTrainStep) after three eager steps -- same losses, parameters and logged values
+        # as the eager loop, without the Python / autograd / launch work of the hundreds of launches of a Perceiver step
+        self.hip_graph = bool(hip_graph) or bool(os.environ.get("PV_TRAINER_HIP_GRAPH"))
+        self._graph_step = None
         # config 3 only (Model(future_frames="optical_flow") fed raw int16 counts): advect in the loader wrapper
         # (optical_flow.AdvectingLoader) instead of inside the model's forward; same batches, bit for bit.  The name is
         # historical: rounds 2-3 ran the wrapper's advection on a side HIP stream, which round 4 removed (it bought
@@ -425,6 +430,73 @@ class Trainer:
         from .optical_flow import AdvectingLoader
         return iter(AdvectingLoader(rest, n_future=model.forecast_len_5))
 
+    # -- opt-in HIP-graph replay of the train step (hip_graph=True) ---------------------------------------------------------
+    GRAPH_EAGER_STEPS = 3      # ordinary steps before the capture: workspaces, optimiser state and allocator pools exist by then
+
+    def _enter_graph_mode(self, model) -> bool:
+        """Swaps the model's HipAdam for a capturable twin (step counter and bias corrections in device memory) carrying the
+        same state.  False (eager loop) for anything but one HipAdam on one process."""
+        self._graph_step, self._graph_logs, self._graph_eager, self._graph_side = None, [], 0, None
+        if not self.hip_graph:
+            return False
+        from .optim import HipAdam
+        if self.world_size > 1 or len(self.optimizers) != 1 or not isinstance(self.optimizers[0], HipAdam):
+            return False
+        old = self.optimizers[0]
+        if not old.capturable:
+            if len(old.param_groups) != 1:
+                return False
+            g = old.param_groups[0]
+            twin = HipAdam(g["params"], lr=g["lr"], betas=g["betas"], eps=g["eps"], capturable=True)
+            if len(old.state):
+                twin.load_state_dict(old.state_dict())
+            self.optimizers = [twin]
+        return True
+
+    def _graph_train_step(self, model, batch, batch_idx) -> bool:
+        """One train step in graph mode: True if it ran here (captured replay), False if the caller's eager path must run it
+        (the first steps, or a batch whose shapes differ from the captured one)."""
+        from .graphs import GraphedTrainStep
+        if self._graph_step is None:
+            if self._graph_eager < self.GRAPH_EAGER_STEPS:
+                # ordinary steps, but on a side stream: the parameters' gradient-accumulation nodes are created by the first
+                # backward and remember its stream -- on the default stream they would make the capture wait for it, which a
+                # capturing stream must not do
+                self._graph_eager += 1
+                if self._graph_side is None:
+                    self._graph_side = torch.cuda.Stream()
+                cur = torch.cuda.current_stream()
+                self._graph_side.wait_stream(cur)
+                with torch.cuda.stream(self._graph_side):
+                    opt = self.optimizers[0]
+                    opt.zero_grad(set_to_none=True)
+                    loss = self._timed("training_step", model.training_step, batch, batch_idx)
+                    self._timed("backward", self._backward, loss)
+                    self._timed("optimizer_step", opt.step)
+                cur.wait_stream(self._graph_side)
+                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():
+                    raise ValueError("loss is NaN or inf")
+                return True
+            n0 = len(self._pending_logs)
+            self._graph_step = GraphedTrainStep(model, self.optimizers[0], batch, batch_idx=batch_idx, warmup=0)
+            # what training_step logged during the capture are the graph's own output tensors: each replay refreshes them
+            self._graph_logs = self._pending_logs[n0:]
+            del self._pending_logs[n0:]
+        try:
+            loss = self._timed("training_step", self._graph_step, batch)
+        except ValueError:          # other shapes (a ragged last batch): this one runs eagerly
+            return False
+        for keys, vec, on_step, on_epoch, _ in self._graph_logs:
+            self._pending_logs.append((keys, vec.clone(), on_step, on_epoch, self.global_step))
+        if self.terminate_on_nan and not torch.isfinite(loss).all():
+            raise ValueError("loss is NaN or inf")
+        return True
+
+    def _leave_graph_mode(self) -> None:
+        if self._graph_step is not None:
+            self._graph_step.close()
+            self._graph_step = None
+
     @staticmethod
     def _backward(loss):
         """loss.backward() with a cached unit root gradient on the device (no per-step fill / multiply launches)."""
@@ -501,6 +573,7 @@ class Trainer:
                 for o in self.optimizers:
                     if hasattr(o, "set_large_grad_mode"):
                         o.set_large_grad_mode("autograd")
+        graph_mode = self._enter_graph_mode(model)
         for cb in self.callbacks:
             cb.on_fit_start(self, model)
         max_epochs = 1 if self.fast_dev_run else self.max_epochs
@@ -509,6 +582,14 @@ class Trainer:
             loader = self._loader("train", train_dataloaders)
             lim = self._limit("train", loader)
             for i, batch in enumerate(self._train_batches(loader, model, lim)):
+                if graph_mode and self._graph_train_step(model, batch, i):
+                    self.global_step += 1
+                    if self.global_step % self.log_every_n_steps == 0:
+                        self._drain()
+                    if self.max_steps and self.global_step >= self.max_steps:
+                        self.should_stop = True
+                        break
+                    continue
                 for o in self.optimizers:
                     o.zero_grad(set_to_none=True)
                 loss = self._timed("training_step", model.training_step, batch, i)
@@ -547,6 +628,7 @@ class Trainer:
             self.current_epoch += 1
             if self.current_epoch < self.min_epochs:
                 self.should_stop = False
+        self._leave_graph_mode()
         for o in self.optimizers:          # sharded large-parameter update: make every rank's f32 copy complete
             if hasattr(o, "consolidate_sharded"):
                 o.consolidate_sharded()

@@ -489,6 +489,35 @@ def test_exp003_train_steps_and_trainer(device, tmp_path, monkeypatch):
     assert np.isfinite(trainer.callback_metrics["NMAE/Train_epoch"]) and np.isfinite(trainer.callback_metrics["NMAE/Validation_epoch"])
 
 
+def test_trainer_replays_the_train_step_as_a_hip_graph(device, tmp_path, monkeypatch):
+    """Trainer(hip_graph=True): three eager steps, then the captured step replayed per batch (two epochs, validation in between):
+    the parameters, the optimiser's step count and every logged metric equal the eager Trainer's."""
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.models.perceiver.exp003 import FakeExp003Dataset, LitModel
+    monkeypatch.chdir(tmp_path)
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(21)
+        model = LitModel(operand_dtype="bf16")
+        train = torch.utils.data.DataLoader(FakeExp003Dataset(batch_size=2, image_size_pixels=64, length=6), batch_size=None)
+        val = torch.utils.data.DataLoader(FakeExp003Dataset(batch_size=2, image_size_pixels=64, length=2, seed=99), batch_size=None)
+        trainer = pl.Trainer(gpus=1, max_epochs=2, precision=16, hip_graph=graph, log_every_n_steps=1)
+        trainer.fit(model, train, val)
+        assert (trainer._graph_step is None)      # released at the end of fit
+        opt = trainer.optimizers[0]
+        steps = {int(st["step"].item()) for st in opt.state_dict()["state"].values()}
+        results.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, dict(trainer.callback_metrics), steps,
+                        getattr(opt, "capturable", False)))
+    (p0, m0, s0, c0), (p1, m1, s1, c1) = results
+    assert not c0 and c1 and s0 == s1 == {12}
+    assert p0.keys() == p1.keys()
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    assert m0.keys() == m1.keys() and len(m0) >= 2
+    for k in m0:
+        assert m0[k] == m1[k], (k, m0[k], m1[k])
+
+
 def test_exp003_config_composes_and_trains(device, tmp_path, monkeypatch):
     import os
     from predict_pv_yield_amd import hydra_lite as H
