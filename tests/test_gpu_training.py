@@ -57,6 +57,30 @@ def test_model_trainer_fit_and_predict(device):
     assert len(out) == 2 and out[0].shape == (2, model.forecast_len_5)
 
 
+def test_trainer_in_hip_graph_mode_equals_the_eager_trainer_on_the_conv3d_model(device):
+    """Trainer(hip_graph=True) on the Conv3D model fed BatchML batches (attribute containers, the large-layer fused backward in
+    its capturable form): parameters and metrics of the eager fit, bit for bit."""
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.utils import load_config
+    config = load_config("tests/configs/model/conv3d.yaml")
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(33)
+        model = Model(**config)
+        ds = FakeDataset(FakeDataConfiguration(batch_size=2, history_minutes=60, forecast_minutes=60,
+                                               satellite_image_size_pixels=16), length=7)
+        loader = torch.utils.data.DataLoader(ds, batch_size=None)
+        trainer = pl.Trainer(gpus=1, max_epochs=1, hip_graph=graph, log_every_n_steps=1)
+        trainer.fit(model, loader)
+        results.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, dict(trainer.callback_metrics)))
+    (p0, m0), (p1, m1) = results
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    assert m0.keys() == m1.keys() and all(m0[k] == m1[k] for k in m0), (m0, m1)
+
+
 def test_advect_future_frames_matches_oracle(device):
     from predict_pv_yield_amd import optical_flow as of
     from predict_pv_yield_amd.data.synthetic import advected_counts
