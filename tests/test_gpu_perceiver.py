@@ -211,3 +211,27 @@ def test_perceiver_model_trainer_fit(device):
     out = trainer.predict(model, loader)
     assert len(out) == 2 and out[0].shape == (2, model.forecast_len_5)
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("operand_dtype", ["f32", "bf16"])
+def test_perceiver_model_trainer_in_hip_graph_mode_equals_the_eager_trainer(device, operand_dtype):
+    """Trainer(hip_graph=True) on the weight-tied PerceiverModel (gradients of tied parameters accumulate into kept buffers, the
+    shared context's gradient collects over the layers): parameters and metrics of the eager fit, bit for bit."""
+    from predict_pv_yield_amd import lightning as pl
+    from predict_pv_yield_amd.data.fake import FakeDataConfiguration, FakeDataset
+    from predict_pv_yield_amd.models.perceiver.perceiver import PerceiverModel
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(12)
+        model = PerceiverModel(history_minutes=10, forecast_minutes=20, batch_size=2, num_latents=16, latent_dim=64,
+                               operand_dtype=operand_dtype)
+        ds = FakeDataset(FakeDataConfiguration(batch_size=2, history_minutes=10, forecast_minutes=20, satellite_image_size_pixels=8,
+                                               nwp_image_size_pixels=64), length=6)
+        loader = torch.utils.data.DataLoader(ds, batch_size=None)
+        trainer = pl.Trainer(gpus=1, max_epochs=1, hip_graph=graph, log_every_n_steps=1)
+        trainer.fit(model, loader)
+        results.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, dict(trainer.callback_metrics)))
+    (p0, m0), (p1, m1) = results
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    assert m0.keys() == m1.keys() and all(m0[k] == m1[k] for k in m0), (m0, m1)
