@@ -43,6 +43,8 @@ class Conv3dReLUF32(torch.autograd.Function):
 
 
 LINEAR_F32_GEMM_K = 1 << 16     # the same threshold as pv_linear_fwd_f32 (dense_f32.hip GEMM_K)
+F32_PENDING_MAX_ROWS = 1024     # pv_linear_wgrad_adam_f32 keeps m x 16 gradient values in 64 KB of LDS
+DENSE_CHAIN = True              # tools/ab_step.py switch: False = fc2 .. fc4 as one launch per layer each way
 
 
 def exact_f32() -> bool:
@@ -72,17 +74,62 @@ class LinearF32(torch.autograd.Function):
             g = K.relu_gate_f32(dy, y) if y is not None else dy.contiguous()
             dx = K.gemm(g, weight) if ctx.needs_input_grad[0] else None
             owner = ctx.weight_param
+            earlier = getattr(owner, "_pv_pending_f32", None)
             if (getattr(owner, "_pv_grad_mode", "autograd") == "fused" and getattr(owner, "_pv_takes_f32_pending", False)
-                    and x.shape[1] % 8 == 0):
+                    and x.shape[1] % 8 == 0 and x.shape[0] <= F32_PENDING_MAX_ROWS and x.is_contiguous() and earlier is None
+                    and owner.grad is None):
                 # HipAdam owns this parameter (single process): it forms the gradient inside its pass over p / m / v
                 # (pv_linear_wgrad_adam_f32): the 0.5 GB gradient is neither written nor read back
                 owner._pv_pending_f32 = (x, g)
                 dw = None
             else:
+                if earlier is not None:
+                    # a second backward before step() (gradient accumulation, several losses): the pair parked by the first one
+                    # becomes an ordinary gradient now, and this call's joins it through autograd's accumulation
+                    x0, g0 = earlier
+                    owner._pv_pending_f32 = None
+                    dw0 = K.gemm(g0.t(), x0)
+                    owner.grad = dw0 if owner.grad is None else owner.grad + dw0
                 dw = K.gemm(g.t(), x)
             return dx, dw, (K.colsum(g) if ctx.has_bias else None), None
         dx, dw, db = K.linear_bwd_f32(x, weight.contiguous(), dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
         return dx, dw, (db if ctx.has_bias else None), None
+
+
+class DenseChainF32(torch.autograd.Function):
+    """relu?(... relu?(x W0^T + b0) ... Wn^T + bn) for the small head (fc2 -> fc3 -> fc4, model.py:126,151-156) as one launch
+    each way (pv_dense_chain_{fwd,bwd}_f32).  args = (w0, b0, w1, b1, ...); relus = one flag per layer."""
+
+    @staticmethod
+    def forward(ctx, x, relus, *args):
+        x = x.contiguous()
+        layers = [(args[2 * i], args[2 * i + 1], relus[i]) for i in range(len(relus))]
+        ys = K.dense_chain_fwd(x, layers)
+        ctx.save_for_backward(x, *[w for w, _, _ in layers], *ys)
+        ctx.relus = tuple(relus)
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = len(ctx.relus)
+        saved = ctx.saved_tensors
+        x, ws, ys = saved[0], saved[1:1 + n], saved[1 + n:]
+        dx, dws, dbs = K.dense_chain_bwd(x, list(ws), ctx.relus, list(ys), dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        grads = []
+        for dw, db in zip(dws, dbs):
+            grads += [dw, db]
+        return (dx, None, *grads)
+
+
+def dense_chain_f32(x, layers):
+    """layers: [(weight, bias, relu), ...]; one launch each way where the shapes allow (hip_ops.dense_chain_supported: a batch
+    of at most 32 rows, at most 128 features, a bias everywhere), the per-layer kernels otherwise."""
+    if DENSE_CHAIN and K.dense_chain_supported(x, layers):
+        flat = [t for w, b, _ in layers for t in (w, b)]
+        return DenseChainF32.apply(x, tuple(bool(r) for _, _, r in layers), *flat)
+    for w, b, r in layers:
+        x = linear_f32(x, w, b, relu=r)
+    return x
 
 
 def conv3d_relu_f32(x, weight, bias, padding=(0, 0, 0), relu=True):
@@ -178,6 +225,8 @@ class Conv3dReLUBF16(torch.autograd.Function):
             # fc1 kernel already applied this layer's ReLU derivative)
             dy = K.repack_gate_ncdhw_to_ndhwc_bf16(dy, None if _take_pregated(dy) else y)
             gate = None
+        elif dy_pregated == "ask":
+            gate = None if _take_pregated(dy) else y   # the last layer under a channels-last fc1: gated by fc1's one-pass backward?
         elif dy_pregated:
             gate = None   # the consumer's dgrad epilogue already applied this layer's ReLU derivative
         else:
@@ -412,7 +461,7 @@ _GATED_MAX_TASK = [-1]
 def _gated_max_of(t: torch.Tensor):
     if _GATED_MAX_TASK[0] != torch._C._current_graph_task_id():
         return None
-    return _GATED_MAX.get((t.data_ptr(), t.numel()))
+    return _GATED_MAX.pop((t.data_ptr(), t.numel()), None)   # consumed once: a later tensor at the same address must not find it
 
 
 class ReluGateF32(torch.autograd.Function):

@@ -31,8 +31,26 @@ def _map_tensors(obj: Any, fn):
     return obj
 
 
+# Python-side marks a loader leaves on a batch tensor and the model reads (optical_flow.AdvectingLoader tags the frames it
+# has already advected: Model._satellite_input then takes them as they are).  clone() drops Python attributes, and a static
+# batch without the mark would be advected a second time inside the captured step.
+_TENSOR_MARKS = ("_pv_advected",)
+
+
+def _clone_keeping_marks(t: torch.Tensor) -> torch.Tensor:
+    c = t.clone()
+    for name in _TENSOR_MARKS:
+        if hasattr(t, name):
+            setattr(c, name, getattr(t, name))
+    return c
+
+
 def _copy_into(dst: Any, src: Any) -> None:
     if torch.is_tensor(dst):
+        for name in _TENSOR_MARKS:
+            if bool(getattr(dst, name, False)) != bool(getattr(src, name, False)):
+                raise ValueError(f"GraphedTrainStep: batch tensor mark {name} = {getattr(src, name, False)!r} differs from the "
+                                 f"captured step's ({getattr(dst, name, False)!r}): the captured step was recorded for the other form")
         if dst.shape != src.shape or dst.dtype != src.dtype:
             raise ValueError(f"GraphedTrainStep: batch tensor {tuple(src.shape)} {src.dtype} does not match the captured "
                              f"{tuple(dst.shape)} {dst.dtype} (a graph replays fixed shapes)")
@@ -58,7 +76,7 @@ class GraphedTrainStep:
         if not getattr(optimizer, "capturable", False):
             raise ValueError("GraphedTrainStep needs HipAdam(capturable=True): the by-value Adam step would be frozen at capture")
         self.model, self.optimizer = model, optimizer
-        self.static_batch = _map_tensors(example_batch, lambda t: t.clone())
+        self.static_batch = _map_tensors(example_batch, _clone_keeping_marks)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -446,8 +446,13 @@ class Trainer:
         if not old.capturable:
             if len(old.param_groups) != 1:
                 return False
+            if old.overlap_large_update or old.large_grad_mode not in ("fused", "autograd"):
+                return False      # a side-stream update or an exchanged gradient cannot be captured: eager loop
             g = old.param_groups[0]
-            twin = HipAdam(g["params"], lr=g["lr"], betas=g["betas"], eps=g["eps"], capturable=True)
+            # the twin steps exactly like the optimiser it replaces: same treatment of the large matrix, same gradient scale
+            twin = HipAdam(g["params"], lr=g["lr"], betas=g["betas"], eps=g["eps"], capturable=True,
+                           fuse_large_linear=old.large_grad_mode == "fused")
+            twin.grad_scale = old.grad_scale
             if len(old.state):
                 twin.load_state_dict(old.state_dict())
             self.optimizers = [twin]
@@ -471,11 +476,12 @@ class Trainer:
                     opt = self.optimizers[0]
                     opt.zero_grad(set_to_none=True)
                     loss = self._timed("training_step", model.training_step, batch, batch_idx)
+                    # as in the eager loop: a fused optimiser steps fc1 inside backward, so the loss is tested BEFORE it
+                    if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():
+                        raise ValueError("loss is NaN or inf")
                     self._timed("backward", self._backward, loss)
                     self._timed("optimizer_step", opt.step)
                 cur.wait_stream(self._graph_side)
-                if self.terminate_on_nan and not torch.isfinite(loss.detach()).all():
-                    raise ValueError("loss is NaN or inf")
                 return True
             n0 = len(self._pending_logs)
             self._graph_step = GraphedTrainStep(model, self.optimizers[0], batch, batch_idx=batch_idx, warmup=0)

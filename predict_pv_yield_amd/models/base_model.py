@@ -164,4 +164,7 @@ class BaseModel(LightningModule):
     def configure_optimizers(self):
         """torch.optim.Adam(self.parameters(), lr=0.0005) (base_model.py:255-257), stepped by pv_adam_step_f32."""
         from ..optim import HipAdam
+        mark = getattr(self, "_mark_fc1_layout", None)
+        if mark is not None:
+            mark()        # (parameter-level layout marks do not survive copy.deepcopy: models/conv3d/_fc1_layout.py)
         return HipAdam(self.parameters(), lr=0.0005)

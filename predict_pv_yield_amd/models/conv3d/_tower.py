@@ -25,8 +25,10 @@ def bf16_tower_supported(c_in: int, channels: int, flat_features: int) -> bool:
 
 
 def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, padding, flat_features: int,
-                   use_bf16: bool) -> torch.Tensor:
-    """relu(fc1(flatten_NCDHW(relu(conv_n(... relu(conv_0(data))))))) — model.py:117-125 / model_sat_nwp.py:188-197,236-246."""
+                   use_bf16: bool, fc1_channels_last: bool = False) -> torch.Tensor:
+    """relu(fc1(flatten_NCDHW(relu(conv_n(... relu(conv_0(data))))))) — model.py:117-125 / model_sat_nwp.py:188-197,236-246.
+    fc1_channels_last (bf16 tower): fc1.weight's columns are stored in (t, h, w, c) order (_fc1_layout.py), so the last layer
+    writes NDHWC like every other and fc1's input gradient returns in the order its dgrad reads."""
     if not data.is_cuda:
         raise RuntimeError("predict_pv_yield_amd Conv3D model runs on the MI355X only: move the module and the "
                            "batch to cuda (there is no CPU fallback)")
@@ -52,15 +54,19 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
             if fused_first and i == 0:
                 continue
             last = i == len(convs) - 1
-            # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one
-            out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, tuple(padding), relu=True, y_ncdhw=last,
-                                      x_is_relu_output=i > 0, dy_pregated=not last, x_relu_mask=mask if i > 0 else None,
-                                      want_relu_mask=masks and not last)
+            # layers >= 1 consume a ReLU output and gate their own dx; every layer but the last is followed by one; the last
+            # one's gradient comes from fc1, whose one-pass backward gates it too when it runs ("ask": functional._take_pregated)
+            out = Fn.conv3d_relu_bf16(out, layer.weight, layer.bias, c_in, tuple(padding), relu=True,
+                                      y_ncdhw=last and not fc1_channels_last, x_is_relu_output=i > 0,
+                                      dy_pregated=(not last) or ("ask" if fc1_channels_last else False),
+                                      x_relu_mask=mask if i > 0 else None, want_relu_mask=masks and not last)
             mask = None
             if masks and not last:
                 out, mask = out
             c_in = channels
-        out = out.reshape(batch_size, flat_features)  # NCDHW flatten order
+        if fc1_channels_last and channels != 32:
+            raise RuntimeError("fc1_channels_last needs 32 conv channels (the NDHWC image has no padding channels then)")
+        out = out.reshape(batch_size, flat_features)  # NCDHW flatten order, or (t, h, w, c) with fc1_channels_last
         return Fn.linear_bf16(out, fc1.weight, fc1.bias, relu=True, x_is_relu_output=True)   # out = relu(last conv)
     # precision="fp32": f32-accurate arithmetic on the reference layout (exact f32 products forward / dgrad; split 16-bit products
     # for weight gradients and fc1 unless PV_EXACT_F32=1, functional.exact_f32()).  32-channel 3x3x3 layers run on the f32 matrix cores

@@ -26,6 +26,11 @@ logging.basicConfig()
 _LOG = logging.getLogger("predict_pv_yield_amd")
 
 
+# fc1.weight's columns in the tower's own (t, h, w, c) order for precision="bf16" (no NCDHW epilogue in the last layer, no
+# repack of fc1's input gradient: -42 us of the 1.54 ms step); False restores the reference's column order in memory
+FC1_CHANNELS_LAST = True
+
+
 class Model(BaseModel):
 
     name = "conv3d"
@@ -93,9 +98,20 @@ class Model(BaseModel):
         self.fc3 = nn.Linear(in_features=fc3_in_features, out_features=self.fc3_output_features)
         self.fc4 = nn.Linear(in_features=self.fc3_output_features, out_features=self.forecast_len)
 
+        # bf16 tower: fc1 consumes the last conv activation as the tower keeps it ([B, T, H, W, C]) -- the columns of
+        # fc1.weight are stored in that order; state_dict() / load_state_dict() speak the reference's (_fc1_layout.py)
+        self._fc1_k_channels = 0
+        if FC1_CHANNELS_LAST and precision == "bf16" and conv3d_channels == 32 and self._bf16_supported():
+            from . import _fc1_layout
+            _fc1_layout.install(self, conv3d_channels)
+
     # ------------------------------------------------------------------------------------------
     def _conv_layers(self):
         return [self.sat_conv0] + [getattr(self, f"conv3d_{i + 1}") for i in range(self.number_of_conv3d_layers - 1)]
+
+    def _mark_fc1_layout(self) -> None:
+        from . import _fc1_layout
+        _fc1_layout.mark(self)
 
     def _bf16_supported(self) -> bool:
         from ._tower import bf16_tower_supported
@@ -129,7 +145,13 @@ class Model(BaseModel):
 
         batch_size = sat_data.shape[0]
         out = conv_tower_fc1(sat_data, self._conv_layers(), self.fc1, self.number_sat_channels, self.conv3d_channels,
-                             (0, 0, 0), self.cnn_output_size, self.precision == "bf16" and self._bf16_supported())
+                             (0, 0, 0), self.cnn_output_size, self.precision == "bf16" and self._bf16_supported(),
+                             fc1_channels_last=bool(self._fc1_k_channels))
+        if not self.include_pv_yield and not self.include_nwp:
+            # nothing is concatenated between fc2 and fc3: the three small layers as one launch each way where the shapes allow
+            out = Fn.dense_chain_f32(out, [(self.fc2.weight, self.fc2.bias, True), (self.fc3.weight, self.fc3.bias, True),
+                                           (self.fc4.weight, self.fc4.bias, False)])
+            return out.reshape(batch_size, self.forecast_len)
         out = Fn.linear_f32(out, self.fc2.weight, self.fc2.bias, relu=True)
 
         if self.include_pv_yield:

@@ -30,6 +30,16 @@ FUSE_DX_INTO_UPDATE = True
 TILE_LARGE_MOMENTS = True
 
 
+def _k_to_reference(t, c):
+    from .models.conv3d._fc1_layout import to_reference
+    return to_reference(t, c)
+
+
+def _k_to_channels_last(t, c):
+    from .models.conv3d._fc1_layout import to_channels_last
+    return to_channels_last(t, c)
+
+
 class HipAdam(torch.optim.Optimizer):
     # 2-D parameters at least this large whose gradient comes from functional.LinearBF16 (fc1) can bypass autograd's
     # f32 .grad:  "fused" -- wgrad + Adam in one pass, the gradient is never materialised (single process);
@@ -140,9 +150,12 @@ class HipAdam(torch.optim.Optimizer):
         if self._is_tiled(p):
             return True
         st = self._init_state(p)
+        c = self._k_channels(p)
         for key in ("exp_avg", "exp_avg_sq"):
             st[key] = K.moments_to_tiled(st[key])
             st[key]._pv_tiled = True
+        if c:
+            st["exp_avg"]._pv_k_channels = c
         return True
 
     def _moments_rows(self, p=None) -> None:
@@ -151,15 +164,39 @@ class HipAdam(torch.optim.Optimizer):
         for q in ([p] if p is not None else [q for g in self.param_groups for q in g["params"]]):
             if self._is_tiled(q):
                 st = self.state[q]
+                c = self._k_channels(q)
                 for key in ("exp_avg", "exp_avg_sq"):
                     st[key] = K.moments_to_rows(st[key])
+                if c:
+                    st["exp_avg"]._pv_k_channels = c
 
     def moments(self, p):
-        """(exp_avg, exp_avg_sq) of p in torch's row-major layout (copies when the stored layout is tiled)."""
+        """(exp_avg, exp_avg_sq) of p in torch's row-major layout and the reference's column order (copies when the stored
+        layout is tiled, or when p's columns are stored channels-last: models/conv3d/_fc1_layout.py)."""
         st = self.state[p]
         if self._is_tiled(p):
-            return K.moments_to_rows(st["exp_avg"]), K.moments_to_rows(st["exp_avg_sq"])
-        return st["exp_avg"], st["exp_avg_sq"]
+            m, v = K.moments_to_rows(st["exp_avg"]), K.moments_to_rows(st["exp_avg_sq"])
+        else:
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+        c = self._k_channels(p)
+        return (_k_to_reference(m, c), _k_to_reference(v, c)) if c else (m, v)
+
+    def _k_channels(self, p) -> int:
+        """C when p's columns are stored channels-last (models/conv3d/_fc1_layout.py), else 0.  The mark lives on the Parameter;
+        a copy of it travels on exp_avg (like `_pv_tiled`): copy.deepcopy(optimizer) creates fresh Parameter objects without
+        Python attributes, but copies a plain tensor's."""
+        c = int(getattr(p, "_pv_k_channels", 0) or 0)
+        st = self.state.get(p)
+        ea = st.get("exp_avg") if st else None
+        if ea is not None:
+            if c:
+                ea._pv_k_channels = c
+            else:
+                c = int(getattr(ea, "_pv_k_channels", 0) or 0)
+        return c
+
+    def _params_in_order(self):
+        return [p for g in self.param_groups for p in g["params"]]      # the index torch's state_dict() gives each parameter
 
     def state_dict(self):
         self._moments_rows()
@@ -170,10 +207,29 @@ class HipAdam(torch.optim.Optimizer):
             for st in self.state.values():
                 if "step" in st:
                     st["step"].fill_(n)
-        return super().state_dict()
+        sd = super().state_dict()
+        # a parameter whose columns are stored channels-last leaves with its moments in the reference's column order (the
+        # packed state holds the live dicts: replaced by copies, never edited)
+        for i, p in enumerate(self._params_in_order()):
+            c = self._k_channels(p)
+            if c and i in sd["state"]:
+                st = dict(sd["state"][i])
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key in st:
+                        st[key] = _k_to_reference(st[key], c)
+                sd["state"][i] = st
+        return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        for p in self._params_in_order():
+            c = self._k_channels(p)
+            st = self.state.get(p)
+            if c and st:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if key in st:
+                        st[key] = _k_to_channels_last(st[key], c).contiguous()
+                st["exp_avg"]._pv_k_channels = c
         if self.capturable:
             steps = [int(st["step"].item()) for st in self.state.values() if "step" in st]
             if self._dev_step is not None:
@@ -193,6 +249,7 @@ class HipAdam(torch.optim.Optimizer):
             st["step"] = torch.tensor(0.0)
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            self._k_channels(p)      # copies the parameter's layout mark onto exp_avg
         return st
 
     def _make_eager_update(self, p):
@@ -245,6 +302,16 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_applied = True
             return out if need_db else (out, None)
         return fused
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Also drops what a backward() parked on the large matrices for a step() that never came (a skipped step would otherwise
+        keep the activations alive and apply a stale gradient later)."""
+        for p in self.large_params():
+            p._pv_pending = None
+            p._pv_pending_f32 = None
+            p._pv_grad_bf16 = None
+            p._pv_grad_shard = None
+        return super().zero_grad(set_to_none=set_to_none)
 
     def _wait_inflight(self):
         if self._inflight:

@@ -410,3 +410,30 @@ def test_advecting_loader_matches_inline_pipeline(device):
         y_inline = model({"satellite": {"data": raws[1]}, "pv": {"pv_yield": torch.rand(2, 18, 128, device=device)}})
         y_loader = model({"satellite": {"data": got[1]["satellite"]["data"]}, "pv": {"pv_yield": torch.rand(2, 18, 128, device=device)}})
     assert torch.equal(y_inline, y_loader)
+
+
+def test_hip_forecasts_score_like_the_oracles_under_skimage_ssim(device):
+    """The reference's own quality number for its optical-flow forecasts (notebooks/optical_flow_1.ipynb cells 31, 35, 38:
+    metrics.structural_similarity(ground_truth, remap_image(image_t0, flow * i))): the HIP pipeline -- Farneback of the
+    warm-up pairs, weighted average, uint8 remap with BORDER_REPLICATE -- on the frames of tests/golden/ssim_skimage.npz,
+    scored with oracle/ssim.py (pinned to scikit-image 0.18.3's scores by tests/test_oracle_flow.py), against the scores
+    scikit-image gave the oracle's forecasts.  Bounds: each score within 1e-3 of the golden; forecasts differ from the oracle's
+    in at most 1e-3 of the pixels (a flow that differs by 1e-6 px can move a fixed-point remap result by one count)."""
+    import os
+    from oracle.ssim import structural_similarity
+    from predict_pv_yield_amd import optical_flow as of
+    K = _ops()
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_skimage.npz"))
+    frames, w0 = d["frames"], int(d["warm_up"])
+    n_steps = d["forecasts"].shape[0] - 1
+    fr = torch.from_numpy(frames[:w0]).to(device)
+    flows = K.farneback_pairs(fr[:-1].contiguous(), fr[1:].contiguous())
+    flow = K.flow_weighted_mean(flows[None])[0]
+    assert np.abs(flow.cpu().numpy() - d["flow"]).max() <= 1e-3
+    got = K.remap_bilinear(fr[w0 - 1:w0].contiguous(), flow[None].contiguous(), n_steps=n_steps, step0=1.0,
+                           border_mode=of.BORDER_REPLICATE, border_value=0)[0].cpu().numpy()
+    for i in range(1, n_steps + 1):
+        assert (got[i - 1] != d["forecasts"][i]).mean() <= 1e-3, i
+        score = structural_similarity(frames[w0 - 1 + i], got[i - 1])
+        assert abs(score - d["ssim_flow"][i]) <= 1e-3, (i, score, d["ssim_flow"][i])
+        assert score > d["ssim_persistence"][i] + 0.05

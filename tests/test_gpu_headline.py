@@ -22,6 +22,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import ref_order
+
 from oracle import conv3d_oracle as co
 from oracle import flow_oracle as fo
 
@@ -98,7 +100,7 @@ def test_bf16_forward_losses_and_all_gradients_tight(device, batch):
     losses[1].backward()           # no optimiser attached: fc1's gradient is materialised by autograd
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         assert p.grad is not None, k
-        _check(f"B={batch} grad {k} rel", _rel(p.grad.cpu(), q.grad), 2e-2)
+        _check(f"B={batch} grad {k} rel", _rel(ref_order(p, p.grad).cpu(), q.grad), 2e-2)
 
 
 def test_bf16_gradients_vs_f32_oracle_loose(device):
@@ -113,7 +115,7 @@ def test_bf16_gradients_vs_f32_oracle_loose(device):
     loss.backward()
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
         bound = 0.15 if "conv" in k else (6e-3 if k.startswith(("fc1", "fc2")) else 1e-3)
-        _check(f"loose grad {k} rel", _rel(p.grad.cpu(), q.grad), bound)
+        _check(f"loose grad {k} rel", _rel(ref_order(p, p.grad).cpu(), q.grad), bound)
 
 
 def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, frac_whole_step, tag=""):
@@ -122,7 +124,7 @@ def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, frac_whole_step, ta
     the gradient's size, so a bound on the largest difference -- 2 lr after one step, 6 lr after three -- can never fail;
     a weight that is a whole step apart went the other way on one side: the sign of a near-zero gradient flipped.)"""
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
-        d = (p.detach().cpu() - q.detach()).abs().flatten()
+        d = (ref_order(p).cpu() - q.detach()).abs().flatten()
         _check(f"{tag} {k} mean |dp|/lr", d.mean().item() / LR, lr_frac_mean)
         _check(f"{tag} {k} fraction with |dp| > lr", (d > LR).float().mean().item(), frac_whole_step)
 
@@ -259,7 +261,7 @@ def test_joined_config3_model_matches_the_oracle_chain(device, precision):
     _check(f"joined {precision} loss rel", abs(float(loss) - ref_losses[1]) / ref_losses[1], 1e-4 if precision == "fp32" else 1e-3)
     loss.backward()
     for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
-        _check(f"joined {precision} grad {k} rel", _rel(p.grad.cpu(), q.grad), 5e-3 if precision == "fp32" else 2e-2)
+        _check(f"joined {precision} grad {k} rel", _rel(ref_order(p, p.grad).cpu(), q.grad), 5e-3 if precision == "fp32" else 2e-2)
 
 
 def test_joined_model_rejects_malformed_raw_batches(device):

@@ -2,6 +2,8 @@
 (oracle/pv_oracle.c).  OpenCV is absent and the reference has no tests for this path, so parity with cv2 is
 UNPINNED; these are the analytic KATs of SURVEY.md §8c (K1-K5, R1-R5) plus independent cross-checks against
 NumPy / SciPy."""
+import os
+
 import numpy as np
 import pytest
 from scipy import ndimage
@@ -270,3 +272,89 @@ def test_advect_frames_pipeline_shapes_and_known_motion():
     # the advected frame t0+1 should look like the texture moved one more step: compare with persistence
     nxt = blob_texture_sequence(np.random.default_rng(9), 1, 64, 64, (0, 0))  # only a smoke check on statistics
     assert out[0, 0, 5, 16:-16, 16:-16].std() > 0.1 and nxt.shape == (1, 64, 64)
+
+
+# ---- two independent restatements of cv.calcOpticalFlowFarneback (what can be pinned without cv2) -------
+@pytest.mark.parametrize("h,w", [(64, 64), (32, 48), (96, 80), (160, 200), (65, 67), (20, 200), (131, 70)])
+def test_two_independent_statements_agree(h, w):
+    """oracle/pv_oracle.c (OpenCV's loop structure and float accumulators, transcribed) against oracle/farneback_f64.py
+    (float64 NumPy written from SURVEY.md Appendix A.1): <= 1e-4 px on the sizes the GPU parity test uses -- one- and
+    two-level pyramids, odd sizes, a level whose height is 20 px.  Measured 1e-6 .. 3e-6 px."""
+    from oracle import farneback_f64 as f64
+    from predict_pv_yield_amd.data.synthetic import blob_texture_sequence
+    rng = np.random.default_rng(h + w)
+    for v in [(1.5, 0.75), (-2.25, 1.3), (0.4, -2.6)]:
+        seq = blob_texture_sequence(rng, 2, h, w, v)
+        u8, _ = fo.convert_10bpp_to_uint8(np.clip(np.rint(seq), 0, 1023).astype(np.int16), 0)
+        a = fo.calc_optical_flow_farneback(u8[0], u8[1])
+        b = f64.calc_optical_flow_farneback(u8[0], u8[1])
+        assert f64.num_levels(h, w, 0.5, 2) == fo.farneback_num_levels(h, w)
+        err = np.abs(a - b).max()
+        assert err <= 1e-4, (h, w, v, err)
+
+
+def test_two_statements_on_a_degenerate_motion():
+    """A flow component that is exactly zero (velocity (1, 0)) puts fy = y + dy on an integer: the sign of a 1e-9 decides
+    whether row 0 samples inside the image (Appendix A.1 item 4's branch), and the 41-tap window spreads that choice -- the two
+    statements (float against double sums) then differ by 1e-3 .. 2e-2 px on a few per cent of the pixels.  Bounded here so
+    that the sensitivity is on record: it is a property of the algorithm at such inputs, cv2's included."""
+    from oracle import farneback_f64 as f64
+    from predict_pv_yield_amd.data.synthetic import blob_texture_sequence
+    for h, w in [(64, 64), (160, 200)]:
+        rng = np.random.default_rng(h + w)
+        seq = blob_texture_sequence(rng, 2, h, w, (1.0, 0.0))
+        u8, _ = fo.convert_10bpp_to_uint8(np.clip(np.rint(seq), 0, 1023).astype(np.int16), 0)
+        d = np.abs(fo.calc_optical_flow_farneback(u8[0], u8[1]) - f64.calc_optical_flow_farneback(u8[0], u8[1])).max(axis=-1)
+        assert d.max() <= 5e-2 and np.median(d) <= 1e-5 and (d > 1e-4).mean() <= 0.2, (h, w, d.max(), np.median(d))
+
+
+def test_f64_statement_pieces_against_the_c_oracle():
+    """Stage by stage, so that a disagreement of the whole can be located: PolyExp, UpdateMatrices, window blur + solve."""
+    from oracle import farneback_f64 as f64
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 255, (48, 56)).astype(np.float32)
+    R_c, R_n = fo.poly_exp(img), f64.poly_exp(img, 5, 0.7)
+    assert np.abs(R_c - R_n).max() <= 2e-4 * np.abs(R_n).max()
+    img2 = np.roll(img, (1, 2), axis=(0, 1))
+    R1_c = fo.poly_exp(img2)
+    flow = rng.uniform(-3, 3, (48, 56, 2)).astype(np.float32)
+    M_c = fo.update_matrices(R_c, R1_c, flow)
+    M_n = f64.update_matrices(R_c.astype(np.float64), R1_c.astype(np.float64), flow.astype(np.float64))
+    assert np.abs(M_c - M_n).max() <= 1e-5 * np.abs(M_n).max()
+    _, fl_c = fo.window_blur_solve(M_c, 40)
+    fl_n = f64.blur_and_solve(M_c.astype(np.float64), 40)
+    assert np.abs(fl_c - fl_n).max() <= 1e-4
+    assert np.allclose(f64.window_taps(40)[20:], fo.farneback_window_taps(40), rtol=0, atol=0)
+    g, xg, xxg, ig = fo.farneback_poly_tables(5, 0.7)
+    g2, xg2, xxg2, ig2 = f64.poly_tables(5, 0.7)
+    assert np.array_equal(g, g2.astype(np.float32)) and np.array_equal(xg, xg2.astype(np.float32))
+    assert np.allclose(ig, ig2, rtol=1e-8)      # (two 6 x 6 inversions in double: LU here, the C statement's own elimination)
+
+
+# ---- structural similarity of the forecasts: the reference's quality number (optical_flow_1.ipynb cells 31, 35, 38) ----------
+SSIM_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_skimage.npz")
+
+
+def test_ssim_restatement_reproduces_skimage():
+    """oracle/ssim.py against scikit-image 0.18.3's own scores (tests/golden/make_ssim_golden.py)."""
+    from oracle.ssim import structural_similarity
+    d = np.load(SSIM_GOLDEN)
+    frames, forecasts, w0 = d["frames"], d["forecasts"], int(d["warm_up"])
+    for i in range(forecasts.shape[0]):
+        assert abs(structural_similarity(frames[w0 - 1 + i], forecasts[i]) - d["ssim_flow"][i]) <= 1e-12
+        assert abs(structural_similarity(frames[w0 - 1], frames[w0 - 1 + i]) - d["ssim_persistence"][i]) <= 1e-12
+
+
+def test_oracle_forecasts_score_as_in_the_golden_and_beat_persistence():
+    """The oracle's pipeline (u8 conversion, Farneback per warm-up pair, weighted average, remap of image_t0 by flow * i)
+    re-run here reproduces the fixture's forecasts bit for bit, and the scores behave as the notebook's plot shows: the
+    advected forecast stays near 1 while persistence decays."""
+    d = np.load(SSIM_GOLDEN)
+    frames, w0 = d["frames"], int(d["warm_up"])
+    flows = np.stack([fo.calc_optical_flow_farneback(frames[i], frames[i + 1]) for i in range(w0 - 1)])
+    flow = fo.weighted_average(flows)
+    assert np.array_equal(flow, d["flow"])
+    for i in range(d["forecasts"].shape[0]):
+        assert np.array_equal(fo.remap_image(frames[w0 - 1], flow, float(i), fo.BORDER_REPLICATE, 0), d["forecasts"][i])
+    assert (d["ssim_flow"][1:] > 0.97).all() and (d["ssim_flow"][1:] > d["ssim_persistence"][1:] + 0.05).all()
+    assert d["ssim_persistence"][-1] < 0.3
