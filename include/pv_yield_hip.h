@@ -311,26 +311,6 @@ int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const flo
                       float* dx, float* dw, float* db,
                       int32_t m, int32_t n, int64_t k, void* stream);
 
-/* The small head as ONE launch each way: a chain of up to PV_DENSE_CHAIN_MAX_LAYERS layers  in_{l+1} = relu_l?(in_l . w_l^T +
- * bias_l)  with at most 128 features everywhere -- fc2 -> fc3 -> fc4 (model.py:126,151-156; F.relu(self.fc2(out)) ...).
- * w / bias / y / dw / db: HOST arrays of n_layers device pointers (read at launch).  Exact f32 products on the f32 matrix
- * instruction; the summation order is fixed but not pv_linear_*_f32's (agreement to f32 rounding).
- * fwd: any m (blocks of 32 rows); every layer's output y[l] [m, n[l]] is written (the backward reads them).
- * bwd: m <= 32.  dy [m, n_last]; dw[l] [n[l], k_l], db[l] [n[l]] (db[l] may be NULL), dx [m, k0] (may be NULL; NOT multiplied by
- * any ReLU derivative of the producer of x). */
-#define PV_DENSE_CHAIN_MAX_LAYERS 3
-typedef struct pv_dense_chain {
-  int32_t n_layers;                        /* 1..PV_DENSE_CHAIN_MAX_LAYERS */
-  int32_t m;                               /* rows */
-  int32_t k0;                              /* input features of layer 0, <= 128 */
-  int32_t n[PV_DENSE_CHAIN_MAX_LAYERS];    /* output features per layer, <= 128 */
-  int32_t relu[PV_DENSE_CHAIN_MAX_LAYERS]; /* != 0: the layer's output goes through a ReLU */
-} pv_dense_chain;
-int pv_dense_chain_fwd_f32(const float* x, const float* const* w, const float* const* bias, float* const* y,
-                           const pv_dense_chain* d, void* stream);
-int pv_dense_chain_bwd_f32(const float* x, const float* const* w, const float* const* y, const float* dy, float* const* dw,
-                           float* const* db, float* dx, const pv_dense_chain* d, void* stream);
-
 /* bf16 variants for the big fc1 (x bf16 [M,K], w bf16 shadow [N,K], fp32 accumulate/outputs).
  * k must be a multiple of 8, m <= 128; workspace: pv_linear_bf16_workspace_bytes(M,N,K). */
 int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes);

@@ -63,15 +63,6 @@ class AttentionDesc(ctypes.Structure):
                 ("scale", c_f32)]
 
 
-PV_DENSE_CHAIN_MAX_LAYERS = 3
-
-
-class DenseChain(ctypes.Structure):
-    """struct pv_dense_chain."""
-    _fields_ = [("n_layers", c_i32), ("m", c_i32), ("k0", c_i32), ("n", c_i32 * PV_DENSE_CHAIN_MAX_LAYERS),
-                ("relu", c_i32 * PV_DENSE_CHAIN_MAX_LAYERS)]
-
-
 PV_ADAM_MAX_TENSORS = 32
 PV_PACK_MAX_JOBS = 16
 
@@ -130,10 +121,6 @@ SIGNATURES = {
     "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
-    "pv_dense_chain_fwd_f32": [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), ctypes.POINTER(DenseChain),
-                               c_vp],
-    "pv_dense_chain_bwd_f32": [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
-                               c_vp, ctypes.POINTER(DenseChain), c_vp],
     "pv_linear_bf16_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],

@@ -66,7 +66,13 @@ __device__ __forceinline__ void w2_interleave() {
 
 // F16: the operand images hold IEEE half floats (the two-term split of the f32 path, pv_pack_split2_...): the same data
 // movement, v_mfma_f32_32x32x16_f16 instead of ..._bf16 and 1.0 as a half in the ones-tap
-template <int CPAD, bool F16 = false>
+// PACK12 (CPAD == 16, at most 12 real input channels: the first layer's 11 satellite channels): the N axis of the product is
+// (tap, 4-channel piece) with THREE pieces per tap instead of four -- 27 x 12 + the ones-tap = 82 pieces = 11 column tiles of
+// 32 where the paired form multiplies 14 (two taps x 16 padded channels each): three accumulators per wave instead of four.
+// A transposed read lets every lane address its own 4-channel piece, so a column tile may mix taps freely: piece P = 8 T +
+// 4 (lane group & 1) + pi of tile T belongs to tap P / 3, channels 4 (P % 3) .. + 3; P = 81 is the ones-tap, larger ones read
+// zeros.
+template <int CPAD, bool F16 = false, bool PACK12 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, float* __restrict__ slabs, int t_in, int h_in, int w_in,
     int t_out, int h_out, int w_out, int pad_t, int pad_h, int pad_w, int n_colblk, int t_chunk) {
@@ -106,8 +112,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
   const int wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   float* slab = slabs + (size_t)wg_id * W2_SLAB_ELEMS;
 
-  constexpr bool PAIRED = CPAD == 16;      // two taps per accumulator
-  constexpr int NACC = PAIRED ? 4 : 7;
+  static_assert(!PACK12 || CPAD == 16, "PACK12 packs the 16-channel image");
+  constexpr bool PAIRED = CPAD == 16;      // two taps per accumulator (PACK12: eight 4-channel pieces of consecutive taps)
+  constexpr int NACC = PACK12 ? 3 : (PAIRED ? 4 : 7);
   f32x16 acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i)
@@ -223,7 +230,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
     int my_tap[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      int tap = PAIRED ? 2 * (wave + 4 * i) + (grp & 1) : wave + 4 * i;
+      int tap, c4 = 0;
+      if constexpr (PACK12) {
+        const int piece = 8 * (wave + 4 * i) + 4 * (grp & 1) + pi;      // 0 .. 95; 81 = the ones-tap, beyond it nothing
+        tap = piece / 3;
+        c4 = piece - 3 * tap;
+        if (piece > 81) tap = 28;
+      } else {
+        tap = PAIRED ? 2 * (wave + 4 * i) + (grp & 1) : wave + 4 * i;
+      }
       my_tap[i] = tap;
       if (tap > 26) tap = 26;
       const int kt = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
@@ -232,12 +247,13 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int v = kw + 8 * hh + 4 * s + qi;
-        const int chunk = (cbx + 4 * pi) >> 3;
-        boff[i][s] = kh * ROWB + v * VOXB + ((chunk ^ ((v / VPR) % NCH)) << 4) + (pi & 1) * 8;
+        const int chunk = PACK12 ? (c4 >> 1) : ((cbx + 4 * pi) >> 3);
+        const int sub = PACK12 ? (c4 & 1) : (pi & 1);
+        boff[i][s] = kh * ROWB + v * VOXB + ((chunk ^ ((v / VPR) % NCH)) << 4) + sub * 8;
       }
     }
     typedef __attribute__((ext_vector_type(8))) short s16x8;
-    const int last_tap = PAIRED ? my_tap[NACC - 1] : (wave == 3 ? 27 : 0);
+    const int last_tap = (PAIRED || PACK12) ? my_tap[NACC - 1] : (wave == 3 ? 27 : 0);
     const unsigned char* const_frag = last_tap < 27 ? nullptr : lds_const + (last_tap == 27 ? 0 : 128) + (lane & 15) * 8;
 
 #ifdef PV_DIAG_STAMPS
@@ -325,8 +341,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
   const int half = lane >> 5;
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    const int tapslot = PAIRED ? 2 * (wave + 4 * i) + ((lane & 31) >> 4) : wave + 4 * i;  // 27 = ones-tap
-    const int ci = PAIRED ? (lane & 15) : (lane & 31);
+    int tapslot = PAIRED ? 2 * (wave + 4 * i) + ((lane & 31) >> 4) : wave + 4 * i;  // 27 = ones-tap
+    int ci = PAIRED ? (lane & 15) : (lane & 31);
+    if constexpr (PACK12) {      // column (lane & 31) of tile wave + 4 i = piece 8 T + column / 4, channel 4 (piece % 3) + column % 4
+      const int piece = 8 * (wave + 4 * i) + ((lane & 31) >> 2);
+      tapslot = piece / 3;
+      ci = 4 * (piece - 3 * tapslot) + (lane & 3);
+      if (piece > 81) tapslot = 28;
+    }
     if (tapslot <= 27) {
       float* dst = slab + (size_t)tapslot * 1024 + ci;
 #pragma unroll
@@ -376,8 +398,16 @@ int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* sl
 #define PV_W2(CP, HALF)                                                                                                       \
   hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<CP, HALF>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, to, \
                      ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
-  if (pv_bf16_cpad(d->c_in) == 16) { if (f16) PV_W2(16, true); else PV_W2(16, false); }
-  else { if (f16) PV_W2(32, true); else PV_W2(32, false); }
+#define PV_W2P(HALF)                                                                                                        \
+  hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<16, HALF, true>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, \
+                     to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
+  if (pv_bf16_cpad(d->c_in) == 16) {
+    // (PV_WGRAD_NO_PACK12: the paired form for channel counts it also covers -- the cross-check of tests/test_gpu_conv.py)
+    const bool pack12 = d->c_in <= 12 && !getenv("PV_WGRAD_NO_PACK12");
+    if (pack12) { if (f16) PV_W2P(true); else PV_W2P(false); }
+    else { if (f16) PV_W2(16, true); else PV_W2(16, false); }
+  } else { if (f16) PV_W2(32, true); else PV_W2(32, false); }
+#undef PV_W2P
 #undef PV_W2
   return 0;
 }

@@ -44,7 +44,6 @@ class Conv3dReLUF32(torch.autograd.Function):
 
 LINEAR_F32_GEMM_K = 1 << 16     # the same threshold as pv_linear_fwd_f32 (dense_f32.hip GEMM_K)
 F32_PENDING_MAX_ROWS = 1024     # pv_linear_wgrad_adam_f32 keeps m x 16 gradient values in 64 KB of LDS
-DENSE_CHAIN = True              # tools/ab_step.py switch: False = fc2 .. fc4 as one launch per layer each way
 
 
 def exact_f32() -> bool:
@@ -94,42 +93,6 @@ class LinearF32(torch.autograd.Function):
             return dx, dw, (K.colsum(g) if ctx.has_bias else None), None
         dx, dw, db = K.linear_bwd_f32(x, weight.contiguous(), dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
         return dx, dw, (db if ctx.has_bias else None), None
-
-
-class DenseChainF32(torch.autograd.Function):
-    """relu?(... relu?(x W0^T + b0) ... Wn^T + bn) for the small head (fc2 -> fc3 -> fc4, model.py:126,151-156) as one launch
-    each way (pv_dense_chain_{fwd,bwd}_f32).  args = (w0, b0, w1, b1, ...); relus = one flag per layer."""
-
-    @staticmethod
-    def forward(ctx, x, relus, *args):
-        x = x.contiguous()
-        layers = [(args[2 * i], args[2 * i + 1], relus[i]) for i in range(len(relus))]
-        ys = K.dense_chain_fwd(x, layers)
-        ctx.save_for_backward(x, *[w for w, _, _ in layers], *ys)
-        ctx.relus = tuple(relus)
-        return ys[-1]
-
-    @staticmethod
-    def backward(ctx, dy):
-        n = len(ctx.relus)
-        saved = ctx.saved_tensors
-        x, ws, ys = saved[0], saved[1:1 + n], saved[1 + n:]
-        dx, dws, dbs = K.dense_chain_bwd(x, list(ws), ctx.relus, list(ys), dy.contiguous(), need_dx=ctx.needs_input_grad[0])
-        grads = []
-        for dw, db in zip(dws, dbs):
-            grads += [dw, db]
-        return (dx, None, *grads)
-
-
-def dense_chain_f32(x, layers):
-    """layers: [(weight, bias, relu), ...]; one launch each way where the shapes allow (hip_ops.dense_chain_supported: a batch
-    of at most 32 rows, at most 128 features, a bias everywhere), the per-layer kernels otherwise."""
-    if DENSE_CHAIN and K.dense_chain_supported(x, layers):
-        flat = [t for w, b, _ in layers for t in (w, b)]
-        return DenseChainF32.apply(x, tuple(bool(r) for _, _, r in layers), *flat)
-    for w, b, r in layers:
-        x = linear_f32(x, w, b, relu=r)
-    return x
 
 
 def conv3d_relu_f32(x, weight, bias, padding=(0, 0, 0), relu=True):

@@ -528,75 +528,6 @@ def linear_bwd_f32(x, weight, dy, y_mask, need_dx=True):
     return dx, dw, db
 
 
-DENSE_CHAIN_MAX_LAYERS, DENSE_CHAIN_MAX_FEATURES, DENSE_CHAIN_MAX_ROWS = _lib.PV_DENSE_CHAIN_MAX_LAYERS, 128, 32
-
-
-def dense_chain_supported(x, layers) -> bool:
-    """layers: [(weight [n, k], bias [n] or None, relu), ...] -- the shapes pv_dense_chain_{fwd,bwd}_f32 take (one block of
-    rows, at most 128 features everywhere, a bias on every layer, contiguous f32)."""
-    if not (1 <= len(layers) <= DENSE_CHAIN_MAX_LAYERS) or x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda:
-        return False
-    if not (1 <= x.shape[0] <= DENSE_CHAIN_MAX_ROWS and 1 <= x.shape[1] <= DENSE_CHAIN_MAX_FEATURES):
-        return False
-    k = x.shape[1]
-    for w, b, _ in layers:
-        if (b is None or w.dim() != 2 or w.shape[1] != k or not (1 <= w.shape[0] <= DENSE_CHAIN_MAX_FEATURES)
-                or w.dtype != torch.float32 or b.dtype != torch.float32 or not w.is_contiguous() or not b.is_contiguous()
-                or b.shape != (w.shape[0],) or w.device != x.device or b.device != x.device):
-            return False
-        k = w.shape[0]
-    return True
-
-
-def _dense_chain_desc(x, layers):
-    d = _lib.DenseChain()
-    d.n_layers, d.m, d.k0 = len(layers), x.shape[0], x.shape[1]
-    for i, (w, _, relu) in enumerate(layers):
-        d.n[i], d.relu[i] = w.shape[0], int(bool(relu))
-    return d
-
-
-def _ptr_array(tensors):
-    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
-
-
-def dense_chain_fwd(x, layers):
-    """The head's layers in one launch (pv_dense_chain_fwd_f32): returns every layer's output [y_0, ..., y_last]."""
-    require_cuda(x, *[t for w, b, _ in layers for t in (w, b)])
-    if not dense_chain_supported(x, layers) or not x.is_contiguous():
-        raise ValueError("dense_chain_fwd: shapes outside pv_dense_chain_fwd_f32 (see dense_chain_supported)")
-    ys = [torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device) for w, _, _ in layers]
-    d = _dense_chain_desc(x, layers)
-    check(get_lib().pv_dense_chain_fwd_f32(ptr(x), _ptr_array([w for w, _, _ in layers]), _ptr_array([b for _, b, _ in layers]),
-                                           _ptr_array(ys), ctypes.byref(d), current_stream_ptr()), "pv_dense_chain_fwd_f32")
-    return ys
-
-
-def dense_chain_bwd(x, weights, relus, ys, dy, need_dx=True):
-    """Backward of dense_chain_fwd in one launch: -> (dx or None, [dw_l], [db_l]).  dx is the plain input gradient."""
-    require_cuda(x, dy, *ys, *weights)
-    layers = [(w, None, r) for w, r in zip(weights, relus)]
-    ok = (1 <= len(weights) <= DENSE_CHAIN_MAX_LAYERS and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
-          and 1 <= x.shape[0] <= DENSE_CHAIN_MAX_ROWS and 1 <= x.shape[1] <= DENSE_CHAIN_MAX_FEATURES
-          and dy.is_contiguous() and dy.dtype == torch.float32 and len(ys) == len(weights) and dy.shape == ys[-1].shape)
-    k = x.shape[1]
-    for w, y in zip(weights, ys):
-        ok = ok and (w.dim() == 2 and w.shape[1] == k and 1 <= w.shape[0] <= DENSE_CHAIN_MAX_FEATURES and w.is_contiguous()
-                     and w.dtype == torch.float32 and y.is_contiguous() and y.dtype == torch.float32
-                     and y.shape == (x.shape[0], w.shape[0]))
-        k = w.shape[0]
-    if not ok:
-        raise ValueError("dense_chain_bwd: shapes outside pv_dense_chain_bwd_f32 (see dense_chain_supported)")
-    dws = [torch.empty_like(w) for w in weights]
-    dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=x.device) for w in weights]
-    dx = torch.empty_like(x) if need_dx else None
-    d = _dense_chain_desc(x, layers)
-    check(get_lib().pv_dense_chain_bwd_f32(ptr(x), _ptr_array(list(weights)), _ptr_array(list(ys)), ptr(dy), _ptr_array(dws),
-                                           _ptr_array(dbs), ptr(dx), ctypes.byref(d), current_stream_ptr()),
-          "pv_dense_chain_bwd_f32")
-    return dx, dws, dbs
-
-
 LINEAR_FWD_MAX_ROWS = 128      # pv_linear_fwd_bf16: rows of x per call
 
 

@@ -147,11 +147,6 @@ class Model(BaseModel):
         out = conv_tower_fc1(sat_data, self._conv_layers(), self.fc1, self.number_sat_channels, self.conv3d_channels,
                              (0, 0, 0), self.cnn_output_size, self.precision == "bf16" and self._bf16_supported(),
                              fc1_channels_last=bool(self._fc1_k_channels))
-        if not self.include_pv_yield and not self.include_nwp:
-            # nothing is concatenated between fc2 and fc3: the three small layers as one launch each way where the shapes allow
-            out = Fn.dense_chain_f32(out, [(self.fc2.weight, self.fc2.bias, True), (self.fc3.weight, self.fc3.bias, True),
-                                           (self.fc4.weight, self.fc4.bias, False)])
-            return out.reshape(batch_size, self.forecast_len)
         out = Fn.linear_f32(out, self.fc2.weight, self.fc2.bias, relu=True)
 
         if self.include_pv_yield:

@@ -286,6 +286,30 @@ def test_conv3d_bf16_weight_gradient_and_first_layer_random_shapes(device):
             torch.testing.assert_close(y1.float().cpu().permute(0, 4, 1, 2, 3), y_ref.detach(), rtol=1e-2, atol=2e-3, msg=msg)
 
 
+@pytest.mark.parametrize("ci", [1, 3, 11, 12])
+def test_weight_gradient_packed_three_pieces_per_tap_equals_the_paired_form(device, monkeypatch, ci):
+    """At most 12 input channels (the first layer's 11): the loader-wave weight-gradient kernel packs the N axis as (tap,
+    4-channel piece) with three pieces per tap -- 11 column tiles instead of 14.  Every dW element is the same sequence of
+    matrix-instruction terms as in the paired form (PV_WGRAD_NO_PACK12=1): bit for bit, incl. the bias gradient, ragged sizes,
+    padding, several column tiles and time chunks."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(40 + ci)
+    for (b, t, h, w, pad) in [(2, 5, 11, 70, (0, 0, 0)), (3, 4, 9, 33, (1, 1, 1)), (32, 6, 16, 16, (0, 1, 0)), (1, 3, 5, 5, (0, 0, 0))]:
+        x = torch.randn(b, ci, t, h, w, generator=g)
+        to, ho, wo = t + 2 * pad[0] - 2, h + 2 * pad[1] - 2, w + 2 * pad[2] - 2
+        gy = torch.randn(b, 32, to, ho, wo, generator=g)
+        xp = K.pack_ncdhw_f32_to_ndhwc_bf16(x.to(device))
+        gyp = K.pack_ncdhw_f32_to_ndhwc_bf16(gy.to(device))
+        monkeypatch.delenv("PV_WGRAD_NO_PACK12", raising=False)
+        dw_a, db_a = K.conv3d_bwd_weight_bf16(xp, gyp, None, ci, 32, pad)
+        monkeypatch.setenv("PV_WGRAD_NO_PACK12", "1")
+        dw_b, db_b = K.conv3d_bwd_weight_bf16(xp, gyp, None, ci, 32, pad)
+        monkeypatch.delenv("PV_WGRAD_NO_PACK12", raising=False)
+        assert torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b), (ci, b, t, h, w, pad)
+        ref = torch.nn.grad.conv3d_weight(co.bf16_round(x), (32, ci, 3, 3, 3), co.bf16_round(gy), padding=pad)
+        assert (dw_a.cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-4
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 4, 6, 6), (3, 11, 5, 8, 8), (1, 16, 3, 10, 14), (2, 3, 2, 4, 6)])
 def test_three_way_split_is_exact_and_the_weight_gradient_built_on_it_is_f32_accurate(device, shape):
     """pv_pack_split3_...: x = h + m + l EXACTLY for these magnitudes (24 mantissa bits in three bf16 images), h is the

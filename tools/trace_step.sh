@@ -1,6 +1,6 @@
 # Kernel trace of the headline train step (both arms of a tools/ab_step.py switch): per-kernel averages under gpurun_out/<name>/
-#   gpurun -- 'bash tools/trace_step.sh functional.DENSE_CHAIN head'
-R=$GRAFT_REPO_ROOT; SW=${1:-functional.DENSE_CHAIN}; O=$R/gpurun_out/${2:-trace}; mkdir -p $O
+#   gpurun -- 'bash tools/trace_step.sh functional.USE_RELU_MASKS masks'
+R=$GRAFT_REPO_ROOT; SW=${1:-functional.USE_RELU_MASKS}; O=$R/gpurun_out/${2:-trace}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 $R/tools/ab_step.py $SW > $O/kt.log 2>&1
 cd $R
