@@ -378,6 +378,63 @@ def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10, warmup=
     return out
 
 
+def measure_sharded_rank_compute(dev, history_minutes, world=8, global_batch=512, steps=10, warmup=3):
+    """What ONE rank of the strong-scaling run computes per step, measured on this one GPU without any exchange: per-GPU batch
+    global_batch / world, fc1's gradient written once as bf16 (pv_linear_wgrad_bf16out), Adam over this rank's 1 / world of the
+    rows (the row shard of HipAdam's "sharded" mode), the other kernels as in every mode.  The reduce-scatter and the
+    all-gather are left out (their inputs / outputs exist, nothing moves): world x (global_batch / world) / this time is the
+    aggregate rate the job reaches if the exchange hides completely -- the ceiling the measured 8-GPU number is read against
+    (it decides whether 6 x over the one-GPU global-batch run is reachable at all)."""
+    from unittest import mock
+    from predict_pv_yield_amd import distributed as D
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    b = global_batch // world
+    torch.manual_seed(518)
+    model = Model(**MODEL_KW, history_minutes=history_minutes, precision="bf16").to(dev)
+    model.batch_size = max(model.batch_size, b)
+    opt = model.configure_optimizers()
+    opt.grad_scale = 1.0 / world
+    rows = model.fc1.weight.shape[0]
+    if rows % world:
+        return {"skipped": f"fc1's {rows} rows do not divide over {world} ranks"}
+    shard = (0, rows // world)
+    t = model.history_len_5 + model.forecast_len_5 + 1
+    g = torch.Generator(device=dev).manual_seed(518)
+    batch = {"satellite": {"data": torch.randn(b, 11, t, 64, 64, generator=g, device=dev)},
+             "pv": {"pv_yield": torch.rand(b, t, 128, generator=g, device=dev)}}
+    with mock.patch.object(D, "row_shard", lambda n_rows, rank=None, world=None: shard), \
+            mock.patch.object(D, "all_gather_rows", lambda full, async_op=True: None):
+        opt.set_large_grad_mode("sharded")
+        for p in opt.large_params():        # the hand-over OverlappedGradSync installs, minus the reduce-scatter itself
+            p._pv_on_grad = lambda gb, param=None: setattr(param, "_pv_grad_shard", gb[shard[0]:shard[1]])
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            model.training_step(batch, 0).backward()
+            opt.step()
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+    mode = opt.large_grad_mode
+    del model, opt, batch
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(d * 1e3, 3), "per_gpu_batch": b, "emulated_world": world, "rows_stepped": shard[1], "mode": mode,
+            "aggregate_samples_per_s_if_exchange_hides": round(world * b / d, 1),
+            "exchange_bytes_per_rank_and_step": {"reduce_scatter_in_bf16": rows * model_k(t) * 2,
+                                                 "all_gather_out_bf16": rows * model_k(t) * 2},
+            "what": "one rank's kernels of bench.py --gpus 8 --global-batch 512 (sharded fc1 update), no exchange"}
+
+
+def model_k(t_frames):
+    return 32 * (t_frames - 8) * 56 * 56      # fc1 input features of the headline model
+
+
 def measure_fp32_headline(dev, b, history_minutes, steps=5):
     from predict_pv_yield_amd.models.conv3d.model import Model
     torch.manual_seed(518)
@@ -545,68 +602,154 @@ def learnable_task(n, t_frames, seed):
     return sat, pv
 
 
-def seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail, hip_seeds=(1, 2, 3), oracle_seeds=(1,)):
-    """The matched-training figure (mean validation NMAE over the tail checkpoints) for further seeds: other initial weights
-    and other batches.  HIP bf16 and HIP fp32 for every seed of hip_seeds; the CPU oracle only for oracle_seeds (50 s each)."""
+def learnable_task_on_device(n, t_frames, gen, dev):
+    """learnable_task generated on the device (another random stream, the same distribution): 26 M normals per batch take the
+    host 0.15 s and the device 0.1 ms."""
+    sat = torch.randn(n, 11, t_frames, 64, 64, generator=gen, device=dev)
+    level = torch.rand(n, generator=gen, device=dev) * 2.0 - 1.0
+    sat[:, :3, : t_frames - 6] += level[:, None, None, None, None]
+    pv = torch.rand(n, t_frames, 128, generator=gen, device=dev)
+    steps = torch.arange(6, dtype=torch.float32, device=dev)
+    pv[:, -6:, 0] = torch.sigmoid(2.0 * level[:, None] + 0.2 * steps[None])
+    return sat, pv
+
+
+# Bounds of the matched-validation experiment, fixed BEFORE its first run (VERDICT r4 item 4: SURVEY section 8c asks for "matched
+# validation NMAE" at 1e-3 .. 2e-3 absolute; a difference inside twice its own standard error is not a difference):
+#   |mean over seeds of (bf16 - fp32)| <= max(2e-3, 2 standard errors of that paired difference)
+#   |fp32 - CPU oracle| at the oracle's last common step, same weights, same batches  <= 2e-3
+VAL_GATE_ABS, VAL_GATE_SE = 2e-3, 2.0
+
+
+def matched_validation_experiment(dev, history_minutes, seeds=8, n_steps=512, batch=32, n_val=1024, tail=64, oracle_seconds=60.0,
+                                  oracle_checkpoints=(4, 8, 12, 16, 20, 24, 32, 40, 48, 64)):
+    """"At matched validation NMAE" with statistical power.  Per seed: ONE set of initial weights and ONE sequence of batches
+    (B = 32, the benched batch) of the learnable synthetic task; the HIP bf16 model (the benched path) and the HIP fp32 model
+    (the rtol 1e-4 parity path) each take n_steps Adam steps on them; the figure of a run is its validation NMAE on n_val
+    held-out samples AVERAGED OVER THE LAST `tail` STEPS (a single checkpoint swings by sigma ~ 0.02 under Adam(5e-4) on 128 M
+    weights: 64 steps at B = 8 on 256 samples -- round 4 -- was a noise experiment).  The two runs of a seed share weights and
+    batches, so the statistic is the PAIRED difference bf16 - fp32 over the seeds, with its standard error.  The torch-CPU oracle
+    (the reference's arithmetic) follows seed 0 for as many steps as `oracle_seconds` allow and is compared with the HIP runs at
+    its last checkpoint (scored through the HIP fp32 forward: same weights through both scorers agree to 2e-5, val_nmae.
+    same_weights_rel_diff)."""
+    import statistics
     from oracle import conv3d_oracle as co
     from predict_pv_yield_amd.models.conv3d.model import Model
-    out = {"hip_bf16": [], "hip_fp32": [], "oracle_f32_cpu": []}
     t_frames = 18 if history_minutes == 55 else 19
-    scorer = Model(**MODEL_KW, history_minutes=history_minutes, precision="fp32").to(dev)
-    scorer.batch_size = max(scorer.batch_size, n_val)
-    for seed in hip_seeds:
-        torch.manual_seed(518 + 1000 * seed)
-        oracle = co.OracleConv3dModel(**MODEL_KW, history_minutes=history_minutes)
-        init = {k: v.clone() for k, v in oracle.state_dict().items()}
-        val_sat, val_pv = learnable_task(n_val, t_frames, seed=2 + 1000 * seed)
-        y_val = co.select_target(val_pv, 6, batch_size=n_val).to(dev)
-        val_sat_d, val_pv_d = val_sat.to(dev), val_pv.to(dev)
+    models = {}
+    for prec in ("fp32", "bf16"):
+        m = Model(**MODEL_KW, history_minutes=history_minutes, precision=prec).to(dev)
+        m.batch_size = max(m.batch_size, n_val, batch)
+        models[prec] = m
+    vgen = torch.Generator(device=dev).manual_seed(77)
+    val_sat, val_pv = learnable_task_on_device(n_val, t_frames, vgen, dev)
+    y_val = val_pv[:, -6:, 0]
 
-        def hip_val(m):
-            with torch.no_grad():
-                ys = [m({"satellite": {"data": val_sat_d[i:i + 64]}, "pv": {"pv_yield": val_pv_d[i:i + 64]}}) for i in range(0, n_val, 64)]
-            return float((torch.cat(ys) - y_val).abs().mean())
+    def hip_val(m):
+        with torch.no_grad():
+            ys = [m({"satellite": {"data": val_sat[i:i + 64]}, "pv": {"pv_yield": val_pv[i:i + 64]}}) for i in range(0, n_val, 64)]
+        return float((torch.cat(ys) - y_val).abs().mean())
 
-        batches = [learnable_task(batch, t_frames, seed=100 + i + 1000 * seed) for i in range(n_steps)]
+    def reinitialise(m, seed):      # torch's default initialisation (U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases), on the device
+        g = torch.Generator(device=dev).manual_seed(518 + 1000 * seed)
+        with torch.no_grad():
+            for name, mod in m.named_modules():
+                w = getattr(mod, "weight", None)
+                if w is None or not isinstance(w, torch.nn.Parameter):
+                    continue
+                fan_in = w[0].numel()
+                bound = 1.0 / fan_in ** 0.5
+                w.uniform_(-bound, bound, generator=g)
+                if getattr(mod, "bias", None) is not None:
+                    mod.bias.uniform_(-bound, bound, generator=g)
+
+    def batches_of(seed):
+        g = torch.Generator(device=dev).manual_seed(100 + 1000 * seed)
+        for _ in range(n_steps):
+            yield learnable_task_on_device(batch, t_frames, g, dev)
+
+    runs = {"bf16": [], "fp32": []}
+    at_ckpt = {"bf16": {}, "fp32": {}}
+    t_hip = time.perf_counter()
+    init0 = None
+    for seed in range(seeds):
+        reinitialise(models["fp32"], seed)
+        init = {k: v.clone() for k, v in models["fp32"].state_dict().items()}      # reference layout (the hook's)
+        if seed == 0:
+            init0 = {k: v.cpu() for k, v in init.items()}
         for prec in ("bf16", "fp32"):
-            m = Model(**MODEL_KW, history_minutes=history_minutes, precision=prec)
+            m = models[prec]
             m.load_state_dict(init)
-            m.to(dev)
-            m.batch_size = max(m.batch_size, n_val)
             opt = m.configure_optimizers()
             acc = []
-            for i, (sat, pv) in enumerate(batches):
+            for i, (sat, pv) in enumerate(batches_of(seed)):
                 opt.zero_grad(set_to_none=True)
-                m.training_step({"satellite": {"data": sat.to(dev)}, "pv": {"pv_yield": pv.to(dev)}}, 0).backward()
+                m.training_step({"satellite": {"data": sat}, "pv": {"pv_yield": pv}}, 0).backward()
                 opt.step()
-                if i + 1 in tail:
+                if i + 1 > n_steps - tail:
                     acc.append(hip_val(m))
-            out["hip_" + prec].append(sum(acc) / len(acc))
-            del m, opt
+                if seed == 0 and i + 1 in oracle_checkpoints:
+                    at_ckpt[prec][i + 1] = hip_val(m)
+            runs[prec].append(sum(acc) / len(acc))
+            del opt
             torch.cuda.empty_cache()
-        if seed in oracle_seeds:
-            ref_opt = co.make_optimizer(oracle)
-            acc = []
-            for i, (sat, pv) in enumerate(batches):
-                co.train_steps(oracle, sat, pv, 1, ref_opt)
-                if i + 1 in tail:
-                    scorer.load_state_dict(oracle.state_dict())
-                    acc.append(hip_val(scorer))
-            out["oracle_f32_cpu"].append(sum(acc) / len(acc))
+    t_hip = time.perf_counter() - t_hip
+    diffs = [a - b for a, b in zip(runs["bf16"], runs["fp32"])]
+    se = lambda v: statistics.stdev(v) / len(v) ** 0.5 if len(v) > 1 else float("nan")
+    d_mean, d_se = statistics.fmean(diffs), se(diffs)
+    # ---- the CPU oracle on seed 0's weights and batches, for as long as the budget lasts ----------------------------------
+    oracle = co.OracleConv3dModel(**MODEL_KW, history_minutes=history_minutes)
+    oracle.load_state_dict(init0)
+    ref_opt = co.make_optimizer(oracle)
+    scorer = models["fp32"]
+    o_ckpt, done, t0 = {}, 0, time.perf_counter()
+    for sat, pv in batches_of(0):
+        if time.perf_counter() - t0 > oracle_seconds or done >= max(oracle_checkpoints):
+            break
+        co.train_steps(oracle, sat.cpu(), pv.cpu(), 1, ref_opt)
+        done += 1
+        if done in oracle_checkpoints:
+            scorer.load_state_dict(oracle.state_dict())
+            o_ckpt[done] = hip_val(scorer)
+    oracle_s = time.perf_counter() - t0
+    last = max(o_ckpt) if o_ckpt else None
+    out = {"definition": f"validation NMAE on {n_val} held-out samples, mean over the last {tail} of {n_steps} Adam steps at B = {batch}; "
+                         f"{seeds} seeds (initial weights + batches), the bf16 and the fp32 run of a seed share both",
+           "hip_bf16": {"runs": [round(v, 5) for v in runs["bf16"]], "mean": round(statistics.fmean(runs["bf16"]), 5),
+                        "standard_error": round(se(runs["bf16"]), 5)},
+           "hip_fp32": {"runs": [round(v, 5) for v in runs["fp32"]], "mean": round(statistics.fmean(runs["fp32"]), 5),
+                        "standard_error": round(se(runs["fp32"]), 5)},
+           "paired_bf16_minus_fp32": {"per_seed": [round(v, 5) for v in diffs], "mean": round(d_mean, 5), "standard_error": round(d_se, 5),
+                                      "in_standard_errors": round(abs(d_mean) / d_se, 2) if d_se > 0 else None},
+           "oracle_seed0": {"steps_in_budget": done, "seconds": round(oracle_s, 1), "compared_after_step": last,
+                            "oracle_f32_cpu": {k: round(v, 5) for k, v in o_ckpt.items()},
+                            "hip_fp32": {k: round(at_ckpt["fp32"][k], 5) for k in o_ckpt},
+                            "hip_bf16": {k: round(at_ckpt["bf16"][k], 5) for k in o_ckpt},
+                            "note": "single checkpoints early in the run (the CPU cannot follow further in its budget): the two f32 "
+                                    "sides share every bit of input and differ by summation order only"},
+           "hip_seconds": round(t_hip, 1),
+           "gates_fixed_before_the_first_run": {"abs": VAL_GATE_ABS, "standard_errors": VAL_GATE_SE}}
+    checks = {f"|mean paired bf16 - fp32| <= max({VAL_GATE_ABS}, {VAL_GATE_SE} s.e.)":
+              abs(d_mean) <= max(VAL_GATE_ABS, VAL_GATE_SE * d_se)}
+    if last is not None:
+        checks[f"|hip_fp32 - oracle| after step {last} <= {VAL_GATE_ABS}"] = abs(at_ckpt["fp32"][last] - o_ckpt[last]) <= VAL_GATE_ABS
+    out["checks"], out["pass"] = checks, all(checks.values())
+    del models, oracle, scorer, val_sat, val_pv
+    torch.cuda.empty_cache()
     return out
 
 
 def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8, n_val=256, first_eval=16, eval_every=4,
-                                      hip_steps=256):
+                                      hip_steps=64):
     """Three training runs from the same initial weights on the same batches of a learnable synthetic task: the torch-CPU
     oracle (oracle/conv3d_oracle.py: the reference's f32 arithmetic), the HIP bf16 path (the benched one) and the HIP fp32
     path.  All three are scored on the same 256 held-out samples at the same step counts.  A single checkpoint of an
     Adam(5e-4) run of this model swings from step to step on every side (each step moves all 128 M fc1 weights by ~lr), so
     the compared figure is the MEAN over the checkpoints of the second half of the common run.  The oracle's checkpoints
     are scored by loading its weights into the HIP fp32 model (parity-tested forward, ms instead of ~7 s of CPU per
-    checkpoint); the LAST one is also scored on the CPU by the oracle itself, and both figures are reported.  The two HIP
-    runs then go on to `hip_steps` (the CPU cannot follow in the time a bench line may take).  The oracle's train steps
-    are timed (evaluation excluded): that is the cpu_baseline."""
+    checkpoint); the LAST one is also scored on the CPU by the oracle itself, and both figures are reported.  The oracle's train steps
+    are timed (evaluation excluded): that is the cpu_baseline.  (The figure with statistical power -- B = 32, 512 steps, 8 seeds,
+    1 024 held-out samples -- is matched_validation_experiment; this run keeps the first-steps comparison and the CPU timing.)"""
     from oracle import conv3d_oracle as co
     from predict_pv_yield_amd.models.conv3d.model import Model
     torch.manual_seed(518)
@@ -697,7 +840,6 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
     tail = [k for k in eval_at if k > n_steps // 2]
     mean = lambda c, ks: sum(c[k] for k in ks) / len(ks)
     o_mean, b_mean, f_mean = mean(oracle_curve, tail), mean(curves["bf16"], tail), mean(curves["fp32"], tail)
-    late = [k for k in hip_eval_at if k > hip_steps // 2]
     # how much a mean over the tail checkpoints can differ between two runs by the step-to-step swing alone: the standard
     # error of the difference of two such means (checkpoints treated as independent draws around each run's level)
     std = lambda c, ks: (sum((c[k] - mean(c, ks)) ** 2 for k in ks) / max(len(ks) - 1, 1)) ** 0.5
@@ -720,10 +862,6 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
            "oracle_last_checkpoint": {"scored_by_the_oracle_on_cpu": round(own, 6),
                                       "scored_through_hip_fp32_forward": round(oracle_curve[eval_at[-1]], 6),
                                       "cpu_scoring_seconds": round(own_s, 1)},
-           "hip_only_continuation": {"steps": hip_steps, "mean_over_steps": late,
-                                     "hip_bf16": round(mean(curves["bf16"], late), 6), "hip_fp32": round(mean(curves["fp32"], late), 6),
-                                     "rel_diff": round(abs(mean(curves["bf16"], late) - mean(curves["fp32"], late))
-                                                       / mean(curves["fp32"], late), 4)},
            "train_steps": done, "train_batch": batch, "val_samples": n_val,
            "task": "BASELINE config 2 model (T=18, 64 px, fc 128/128/64), same initial weights, same batches; every sample has "
                    "a brightness offset u ~ U(-1, 1) on 3 channels of its observed frames, yield = sigmoid(2 u + 0.2 step)"}
@@ -743,15 +881,6 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
                          "gradient for every one of 128 M weights) turn bf16 rounding of near-zero gradients into whole steps of "
                          "opposite sign, so the bf16 run's losses leave the f32 runs' by percents within a few steps while the "
                          "two f32 runs stay within 1e-3 of each other for all 16"}
-    # (ii) more seeds for the two HIP sides (cheap) and one more for the oracle: mean +- standard error at the common step count
-    seeds = seed_statistics(dev, history_minutes, n_steps, batch, n_val, tail)
-    seeds["hip_bf16"].insert(0, b_mean), seeds["hip_fp32"].insert(0, f_mean), seeds["oracle_f32_cpu"].insert(0, o_mean)
-    import statistics
-    se = lambda v: (statistics.stdev(v) / len(v) ** 0.5) if len(v) > 1 else float("nan")
-    seed_stats = {k: {"runs": [round(x, 5) for x in v], "mean": round(statistics.fmean(v), 5), "standard_error": round(se(v), 5)}
-                  for k, v in seeds.items()}
-    d_bf = abs(statistics.fmean(seeds["hip_bf16"]) - statistics.fmean(seeds["hip_fp32"]))
-    se_bf = (se(seeds["hip_bf16"]) ** 2 + se(seeds["hip_fp32"]) ** 2) ** 0.5
     # (iii) same weights, two scorers (the oracle's own forward on the CPU and the HIP fp32 forward)
     same_w = abs(own - oracle_curve[eval_at[-1]]) / own
     # bounds: about twice what the committed collection shows (profiles/r04/: f32 8.1e-5 over 4 steps and 6.4e-4 over 16; bf16
@@ -762,11 +891,8 @@ def matched_training_and_cpu_baseline(dev, history_minutes, n_steps=64, batch=8,
               "early_loss_16_steps_hip_fp32_vs_oracle <= 2e-3": early_cmp["max_rel_diff_hip_fp32_vs_oracle"] <= 2e-3,
               "early_loss_step_1_hip_bf16_vs_oracle <= 2e-5": early_cmp["step_1_hip_bf16_vs_oracle"] <= 2e-5,
               "early_loss_step_2_hip_bf16_vs_oracle <= 1.2e-2": early_cmp["step_2_hip_bf16_vs_oracle"] <= 1.2e-2,
-              "same_weights_two_scorers <= 1e-4": same_w <= 1e-4,
-              "seed_means_hip_bf16_vs_hip_fp32 within 3 standard errors": d_bf <= 3.0 * se_bf}
+              "same_weights_two_scorers <= 1e-4": same_w <= 1e-4}
     val["early_train_loss"] = early_cmp
-    val["seeds"] = dict(seed_stats, hip_bf16_minus_hip_fp32_in_standard_errors=round(d_bf / se_bf, 2) if se_bf > 0 else None,
-                        note="run 0 is the main run above; further runs change the initial weights and the batches")
     val["same_weights_rel_diff"] = round(same_w, 7)
     val["checks"] = checks
     val["pass"] = all(checks.values())
@@ -809,6 +935,95 @@ def flow_cpu_baseline(n_single=4, per_thread=2):
                                 "author's CPU (notebooks/optical_flow_1.ipynb:269) = 2.2 Mpx/s; a 64 x 64 tile is 1/94 of that frame"}
 
 
+class ClockSampler:
+    """Samples the amdgpu driver's current engine / memory clock levels (sysfs pp_dpm_sclk / pp_dpm_mclk: the line marked '*')
+    and the board power from a host thread while the timed steps run -- no device work, no HIP call.  The same binary steps
+    in 1.54 ms on one box of the pool and 1.71 ms on another (fc1's HBM-bound backward 0.64 against 0.78 ms); the clocks the
+    device held under THIS load are logged beside the bench line so that a slow box can be told from a slow kernel.  The
+    box may expose several cards while one is visible to the process: the card with the highest median engine clock during the
+    run is taken to be the one under load."""
+
+    def __init__(self, period_s=0.05):
+        import glob
+        self.period = period_s
+        self.cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples = {c: {"sclk": [], "mclk": [], "power": []} for c in self.cards}
+        self._stop = None
+
+    @staticmethod
+    def _active_mhz(path):
+        try:
+            for ln in open(path).read().splitlines():
+                if ln.rstrip().endswith("*"):
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        except Exception:      # noqa: BLE001 -- sysfs absent or unreadable: no sample
+            pass
+        return None
+
+    def __enter__(self):
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            import glob
+            while not self._stop.is_set():
+                for c in self.cards:
+                    d = os.path.dirname(c)
+                    s_, m_ = self._active_mhz(c), self._active_mhz(os.path.join(d, "pp_dpm_mclk"))
+                    if s_ is not None:
+                        self.samples[c]["sclk"].append(s_)
+                    if m_ is not None:
+                        self.samples[c]["mclk"].append(m_)
+                    for pw in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average"))[:1]:
+                        try:
+                            self.samples[c]["power"].append(int(open(pw).read()) / 1e6)
+                        except Exception:      # noqa: BLE001
+                            pass
+                self._stop.wait(self.period)
+
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        return False
+
+    def summary(self):
+        import statistics
+        best, best_med = None, -1
+        for c, smp in self.samples.items():
+            if smp["sclk"]:
+                med = statistics.median(smp["sclk"])
+                if med > best_med:
+                    best, best_med = c, med
+        if best is None:
+            return {"available": False}
+        smp = self.samples[best]
+        q = lambda v: {"min": min(v), "median": statistics.median(v), "max": max(v)} if v else None
+        return {"available": True, "card": best.split("/")[4], "cards_seen": len(self.cards), "samples": len(smp["sclk"]),
+                "sclk_MHz": q(smp["sclk"]), "mclk_MHz": q(smp["mclk"]), "power_W": q([round(x, 1) for x in smp["power"]]),
+                "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (active level) sampled every 50 ms during the timed steps"}
+
+
+def collectives_info(world, requested, in_force):
+    """What the job's exchange really ran on, read from the live process group: the first 8-GPU run certifies itself."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": world}
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "requested_mode": requested, "mode_in_force": in_force,
+            "visible_devices": torch.cuda.device_count()}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        info["rccl_version"] = f"unavailable ({type(e).__name__})"
+    for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "PV_DIST_BACKEND", "PV_SINGLE_DEVICE"):
+        if k in os.environ:
+            info[k] = os.environ[k]
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -831,6 +1046,9 @@ def main():
     ap.add_argument("--grad-sync", choices=["sharded", "allreduce"], default="sharded",
                     help="N > 1, bf16 gradients: 'sharded' = reduce-scatter + per-rank Adam over its rows of fc1 + all-gather "
                          "of the bf16 operand copy (default); 'allreduce' = every rank steps the whole matrix")
+    ap.add_argument("--allow-demotion", action="store_true",
+                    help="N > 1: accept a simpler gradient-exchange mode than the requested one when its trial step fails "
+                         "(default: exit non-zero -- a scaling number on another exchange is not the number asked for)")
     args = ap.parse_args()
 
     from predict_pv_yield_amd import distributed as D
@@ -876,7 +1094,8 @@ def main():
         # The row-sharded exchange (reduce-scatter / all-gather) is tried ONCE, untimed, in this process; if RCCL refuses
         # it on every rank alike the run continues on the plain bf16 all-reduce (never a re-exec: the GPU is initialised).
         grad_sync_mode = "autograd" if args.f32_grads else ("sharded" if args.grad_sync == "sharded" else "bf16")
-        grad_sync_mode = D.negotiate_grad_sync(model, opt, batch, grad_sync_mode)
+        requested_mode = grad_sync_mode
+        grad_sync_mode = D.negotiate_grad_sync(model, opt, batch, grad_sync_mode, allow_demotion=args.allow_demotion)
         sync = D.OverlappedGradSync(model)
 
     from predict_pv_yield_amd.lightning import Trainer
@@ -898,13 +1117,15 @@ def main():
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if distributed:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+    clocks = ClockSampler()
+    with clocks:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            last = step()
+        torch.cuda.synchronize()
+        if distributed:
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -922,7 +1143,9 @@ def main():
             "config": {"workload": f"conv3d train step (fwd + NMAE + bwd + Adam): sat [B,11,{t_frames},64,64] N(0,1), "
                                    f"4x Conv3d(3x3x3, 32ch) + fc 128/128/64, {sum(p.numel() for p in model.parameters())/1e6:.1f} M params",
                        "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
-                       "parallelism": f"dp{world} ({grad_sync_mode})" if world > 1 else "single"},
+                       "parallelism": f"dp{world} ({grad_sync_mode})" if world > 1 else "single",
+                       "collectives": collectives_info(world, requested_mode if distributed else None, grad_sync_mode)},
+            "device_clocks_during_timed_steps": clocks.summary(),
             "train_nmae_first_step": round(first, 6) if first is not None else None,
             "train_nmae_last_step": round(last, 6),
             "whole_step_frac_of_bf16_mfma_peak": round(value / world * (23.37e9 if t_frames == 18 else 25.27e9) / MFMA_BF16_PEAK, 4),
@@ -955,8 +1178,13 @@ def main():
                     sb = measure_batch_sweep(dev, args.history_minutes, batches=(512,), steps=5, warmup=2)["B=512"]
                     out["strong_b512"] = dict(sb, n_gpus=1, global_batch=512,
                                               note="python bench.py --gpus 1 --global-batch 512 times the same step as the headline line")
+                    out["strong_b512"]["one_rank_of_8"] = measure_sharded_rank_compute(dev, args.history_minutes)
+                    r8 = out["strong_b512"]["one_rank_of_8"]
+                    if "aggregate_samples_per_s_if_exchange_hides" in r8:
+                        r8["ceiling_over_one_gpu"] = round(r8["aggregate_samples_per_s_if_exchange_hides"] / sb["samples_per_s"], 2)
                     if out["roofline"] is not None:
                         out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
+                        out["roofline"]["strong_8gpu_ceiling_over_one_gpu"] = r8.get("ceiling_over_one_gpu")
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     torch.cuda.empty_cache()
                 out["other_models"] = measure_other_models(dev)
@@ -965,6 +1193,13 @@ def main():
             out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:
             out["val_nmae"], out["cpu_baseline"] = matched_training_and_cpu_baseline(dev, args.history_minutes)
+            out["val_nmae"]["experiment"] = matched_validation_experiment(dev, args.history_minutes)
+            out["val_nmae"]["pass"] = bool(out["val_nmae"]["pass"] and out["val_nmae"]["experiment"]["pass"])
+            if out.get("roofline"):      # scalars the driver's record keeps
+                ex = out["val_nmae"]["experiment"]
+                out["roofline"]["val_nmae_bf16_minus_fp32"] = ex["paired_bf16_minus_fp32"]["mean"]
+                out["roofline"]["val_nmae_bf16_minus_fp32_se"] = ex["paired_bf16_minus_fp32"]["standard_error"]
+                out["roofline"]["val_nmae_pass"] = out["val_nmae"]["pass"]
             flow_cpu = flow_cpu_baseline()
             if "config3" in out:
                 out["config3"]["cpu_baseline"] = flow_cpu

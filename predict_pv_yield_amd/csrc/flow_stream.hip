@@ -414,6 +414,10 @@ static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* ra
 // u8_from_10bit_kernel) and (b) the normalised f32 frames (x - mean_c) / std_c written straight into the model input
 // [B, C, T + n_future, H, W] (slices 0..T-1).  Replaces a permute copy, the u8 pass, the normalise pass and a strided
 // copy: the raw tensor is read once.  One thread = 8 consecutive pixels of one (b, t, c) frame; frame % 8 == 0.
+// VPT vectors (of 8 pixels) per thread and trip, all loaded before the first is converted: with one 16-byte load in flight per
+// thread the launch reached 0.51 of HBM on the 64 x 64 tiles (121 MB in 30 us: a CU had ~32 KB in flight, about what the
+// memory latency needs at full rate and nothing to spare; profiles/r04/pmc_flow_prepare_stacks.json).
+constexpr int PS_VPT = 2;
 template <typename T>
 __global__ __launch_bounds__(256) void prepare_stacks_kernel(const T* __restrict__ raw, uint8_t* __restrict__ u8,
                                                               float* __restrict__ out, long long n_vec, int t, int c,
@@ -421,54 +425,69 @@ __global__ __launch_bounds__(256) void prepare_stacks_kernel(const T* __restrict
                                                               const float* __restrict__ mean, const float* __restrict__ std_,
                                                               int32_t* range_flag) {
   bool bad = false;
-  // a workgroup takes 256 vectors of ONE frame: (b, t, c) of the frame are wave-uniform (scalar divisions once per trip; the
-  // per-thread form -- five 64-bit divisions per 8 pixels -- made this streaming kernel instruction-bound: 0.42 of HBM)
-  const int bpf = (frame8 + 255) / 256;
+  // a workgroup takes 256 x VPT vectors of ONE frame: (b, t, c) of the frame are wave-uniform (scalar divisions once per trip;
+  // the per-thread form -- five 64-bit divisions per 8 pixels -- made this streaming kernel instruction-bound: 0.42 of HBM)
+  const int bpf = (frame8 + 256 * PS_VPT - 1) / (256 * PS_VPT);
   const long long n_frames = n_vec / frame8;
   for (long long blk = blockIdx.x; blk < n_frames * bpf; blk += gridDim.x) {
     const long long fr = __builtin_amdgcn_readfirstlane((int)(blk / bpf));     // (frames < 2^31: n_vec / frame8)
-    const int px = (int)(blk - fr * bpf) * 256 + (int)threadIdx.x;
-    if (px >= frame8) continue;
-    const long long i = fr * frame8 + px;      // [B][T][C][frame8] (source order)
+    const int px0 = (int)(blk - fr * bpf) * (256 * PS_VPT) + (int)threadIdx.x;
     long long f = fr;
     const int ci = (int)(f % c);
     f /= c;
     const int ti = (int)(f % t);
     const long long bi = f / t;
-    float x[8];
-    uint32_t lo = 0, hi = 0;
-    if constexpr (sizeof(T) == 2) {
-      const u32x4 r = *reinterpret_cast<const u32x4*>(raw + i * 8);
+    const long long bc = bi * c + ci;
+    const float m = mean[ci], sd = std_[ci];
+    u32x4 r16[PS_VPT];
+    f32x4 ra[PS_VPT], rb[PS_VPT];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int xi = (int)(int16_t)((r[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-        x[j] = (float)xi;
-        const uint32_t v = (uint32_t)u8_from_i16(xi, mode, bad);
-        if (j < 4) lo |= v << (8 * j); else hi |= v << (8 * (j - 4));
+    for (int v = 0; v < PS_VPT; ++v) {
+      const int px = px0 + 256 * v;
+      if (px < frame8) {
+        const long long i = fr * frame8 + px;      // [B][T][C][frame8] (source order)
+        if constexpr (sizeof(T) == 2) {
+          r16[v] = *reinterpret_cast<const u32x4*>(raw + i * 8);
+        } else {
+          ra[v] = *reinterpret_cast<const f32x4*>(raw + i * 8);
+          rb[v] = *reinterpret_cast<const f32x4*>(raw + i * 8 + 4);
+        }
       }
-    } else {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(raw + i * 8);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(raw + i * 8 + 4);
+    }
+#pragma unroll
+    for (int v = 0; v < PS_VPT; ++v) {
+      const int px = px0 + 256 * v;
+      if (px >= frame8) continue;
+      float x[8];
+      uint32_t lo = 0, hi = 0;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int xi = (int)(int16_t)((r16[v][j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+          x[j] = (float)xi;
+          const uint32_t u = (uint32_t)u8_from_i16(xi, mode, bad);
+          if (j < 4) lo |= u << (8 * j); else hi |= u << (8 * (j - 4));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = ra[v][j]; x[j + 4] = rb[v][j];
+          lo |= (uint32_t)u8_from_f32(ra[v][j], mode, bad) << (8 * j);
+          hi |= (uint32_t)u8_from_f32(rb[v][j], mode, bad) << (8 * j);
+        }
+      }
+      const u32x2 o8 = {lo, hi};
+      *reinterpret_cast<u32x2*>(u8 + ((bc * t + ti) * (long long)frame8 + px) * 8) = o8;
+      f32x4 r0, r1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        x[j] = a[j]; x[j + 4] = b4[j];
-        lo |= (uint32_t)u8_from_f32(a[j], mode, bad) << (8 * j);
-        hi |= (uint32_t)u8_from_f32(b4[j], mode, bad) << (8 * j);
+        r0[j] = __fdiv_rn(__fsub_rn(x[j], m), sd);
+        r1[j] = __fdiv_rn(__fsub_rn(x[j + 4], m), sd);
       }
+      float* dst = out + ((bc * t_out + ti) * (long long)frame8 + px) * 8;
+      *reinterpret_cast<f32x4*>(dst) = r0;
+      *reinterpret_cast<f32x4*>(dst + 4) = r1;
     }
-    const long long bc = bi * c + ci;
-    const u32x2 o8 = {lo, hi};
-    *reinterpret_cast<u32x2*>(u8 + ((bc * t + ti) * (long long)frame8 + px) * 8) = o8;
-    const float m = mean[ci], sd = std_[ci];
-    f32x4 r0, r1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      r0[j] = __fdiv_rn(__fsub_rn(x[j], m), sd);
-      r1[j] = __fdiv_rn(__fsub_rn(x[j + 4], m), sd);
-    }
-    float* dst = out + ((bc * t_out + ti) * (long long)frame8 + px) * 8;
-    *reinterpret_cast<f32x4*>(dst) = r0;
-    *reinterpret_cast<f32x4*>(dst + 4) = r1;
   }
   if (range_flag && bad) atomicOr(range_flag, 1);
 }
@@ -486,7 +505,7 @@ static int prepare_stacks_launch(const T* raw, uint8_t* u8, float* out, int64_t 
              "pv_prepare_stacks: unaligned operand");
   const long long n_vec = (long long)batch * t * c * (frame / 8);
   PV_REQUIRE((long long)batch * t * c <= 0x7fffffffLL, PV_ESIZE, "pv_prepare_stacks: too many frames");
-  const long long n_blk = (long long)batch * t * c * ((frame / 8 + 255) / 256);      // 256 vectors of one frame per workgroup trip
+  const long long n_blk = (long long)batch * t * c * ((frame / 8 + 256 * PS_VPT - 1) / (256 * PS_VPT));      // 256 x VPT vectors of one frame per workgroup trip
   hipLaunchKernelGGL((prepare_stacks_kernel<T>), dim3((unsigned)std::min<long long>(n_blk, 1 << 20)), dim3(256), 0,
                      as_stream(stream), raw, u8, out, n_vec, t, c, (int)(frame / 8), t_out, mode, mean, std_, range_flag);
   return check_launch("pv_prepare_stacks");

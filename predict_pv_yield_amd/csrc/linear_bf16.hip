@@ -446,10 +446,9 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   auto fetch = [&](int i) {
     const int r = min(8 * rg + i, n - 1);
     const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
-    const size_t moff = (mv_tiled & 1) ? mv_tile_base + (size_t)r * FD_KT : off;
-    const size_t woff = (mv_tiled & 2) ? mv_tile_base + (size_t)r * FD_KT : off;
-    nxt[0] = *reinterpret_cast<const f32x4*>(w + woff);
-    nxt[1] = *reinterpret_cast<const f32x4*>(w + woff + 4);
+    const size_t moff = mv_tiled ? mv_tile_base + (size_t)r * FD_KT : off;
+    nxt[0] = *reinterpret_cast<const f32x4*>(w + off);
+    nxt[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
     nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + moff);
     nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + moff + 4);
     nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff);
@@ -471,7 +470,7 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     for (int q = 0; q < 4; ++q)
       wold[i][q] = row_ok ? (pack_bf16_pair(pv[2 * q], pv[2 * q + 1])) : 0u;
     if (row_ok) {
-      const size_t off = (mv_tiled & 2) ? mv_tile_base + (size_t)(8 * rg + i) * FD_KT : (size_t)(8 * rg + i) * k + k8;
+      const size_t off = (size_t)(8 * rg + i) * k + k8;
       uint32_t sh[4];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -485,7 +484,7 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
       }
       *reinterpret_cast<f32x4*>(w + off) = *reinterpret_cast<const f32x4*>(pv);
       *reinterpret_cast<f32x4*>(w + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
-      const size_t moff = (mv_tiled & 1) ? mv_tile_base + (size_t)(8 * rg + i) * FD_KT : (size_t)(8 * rg + i) * k + k8;
+      const size_t moff = mv_tiled ? mv_tile_base + (size_t)(8 * rg + i) * FD_KT : off;
       *reinterpret_cast<f32x4*>(exp_avg + moff) = *reinterpret_cast<const f32x4*>(mv);
       *reinterpret_cast<f32x4*>(exp_avg + moff + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
       *reinterpret_cast<f32x4*>(exp_avg_sq + moff) = *reinterpret_cast<const f32x4*>(vv);
@@ -759,7 +758,7 @@ constexpr int V3_KC = 128, V3_ROWS = 160, V3_TILEB = V3_ROWS * 256, V3_STAGES = 
 
 __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                                   float* __restrict__ partial, int m, int n, long long k,
-                                                                  int n_tiles, int tiles_per_wg, int w_tiled) {
+                                                                  int n_tiles, int tiles_per_wg) {
   __shared__ __attribute__((aligned(1024))) unsigned char ring[V3_STAGES * V3_TILEB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -783,8 +782,7 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
       const int c = (spos - row) & 15;
       const bool c_ok = k0 + c * 8 < k;
       if (blk < 32) {
-        const uint32_t off = (c_ok && row < n) ? (w_tiled ? (uint32_t)((((size_t)t * n + row) * V3_KC + c * 8) * 2)
-                                                          : (uint32_t)(((size_t)row * k + k0 + c * 8) * 2)) : INVALID;
+        const uint32_t off = (c_ok && row < n) ? (uint32_t)(((size_t)row * k + k0 + c * 8) * 2) : INVALID;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(dst + blk * 1024), 16, off, 0, 0, 0);
       } else {
         const int xr = row - 128;
@@ -896,7 +894,7 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
                          n_tiles, tiles);
     else
       hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
-                         n_tiles, tiles, getenv("PV_FC1_PROBE_TILED_PARAM") ? 1 : 0);
+                         n_tiles, tiles);
     hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
                        bias, y, m, n, nwg2, relu ? 1 : 0);
     return check_launch("pv_linear_fwd_bf16");
@@ -1002,7 +1000,7 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
                      (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr,
-                     (moments_tiled ? 1 : 0) | (getenv("PV_FC1_PROBE_TILED_PARAM") ? 2 : 0));   // bit 1: timing probe only
+                     moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
 }
 

@@ -252,13 +252,17 @@ class OverlappedGradSync:
 _FALLBACKS = {"sharded": ("sharded", "bf16", "autograd"), "bf16": ("bf16", "autograd"), "autograd": ("autograd",)}
 
 
-def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> str:
+def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str, allow_demotion: bool = True) -> str:
     """Collective.  Tries the requested gradient-exchange mode of the big layer with ONE untimed train step in THIS
     process -- "sharded" (reduce-scatter -> row-sharded Adam -> all-gather of the bf16 operand copy), "bf16" (one bf16
     all-reduce), "autograd" (f32 all-reduce of .grad) -- and, if the step raises on any rank, moves every rank to the
     next simpler mode together (the outcome is agreed with an all-reduce, parameters are re-broadcast).  Returns the
     mode in force.  Exits non-zero with a clear message if none works; never re-executes the process (the GPU is
-    initialised: an exec would take the node down)."""
+    initialised: an exec would take the node down).
+    allow_demotion=False (bench.py without --allow-demotion): ANY outcome other than the requested mode -- a failed trial
+    step, or an optimiser that silently chose a simpler mode (rows that do not divide over the ranks) -- ends every rank
+    with a non-zero status instead: a scaling number measured on another exchange than the one asked for is not that number.
+    PV_DIST_FAIL_MODES=<mode>[,<mode>] makes the trial step of those modes raise (test hook for exactly this rule)."""
     if mode not in _FALLBACKS:
         raise ValueError(mode)
     if not is_distributed():
@@ -302,6 +306,8 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> 
             # phase 2: one whole train step with the real collectives
             finished = trial_watchdog(candidate)
             try:
+                if candidate in os.environ.get("PV_DIST_FAIL_MODES", "").split(","):
+                    raise RuntimeError(f"PV_DIST_FAIL_MODES: injected failure of mode '{candidate}'")
                 sync = OverlappedGradSync(model)
                 optimizer.zero_grad(set_to_none=True)
                 model.training_step(batch, 0).backward()
@@ -319,8 +325,13 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str) -> 
             finished.set()
         else:
             ok = 0
-        if ok:
+        if ok and (allow_demotion or optimizer.large_grad_mode == mode):
             return optimizer.large_grad_mode
+        if not allow_demotion:
+            why = (errors[-1] if errors else "on another rank") if not ok else \
+                f"the optimiser chose '{optimizer.large_grad_mode}' (rows of the large matrix do not divide over the ranks)"
+            raise SystemExit(f"predict_pv_yield_amd: gradient exchange mode '{mode}' was requested but is not in force ({why}); "
+                             f"refusing to continue on a simpler mode (pass --allow-demotion / allow_demotion=True to accept it)")
         if dist.get_rank() == 0:
             print(f"[predict_pv_yield_amd] gradient exchange mode '{candidate}' failed on at least one rank"
                   f" ({errors[-1] if errors else 'on another rank'}); trying the next simpler mode", flush=True)

@@ -106,6 +106,28 @@ def _worker(rank, world, port, ret):
     both = [torch.zeros_like(wv) for _ in range(world)]
     dist.all_gather(both, wv)
     assert torch.equal(both[0], both[1])                # re-broadcast after the failed attempt, then one common step
+    # ... unless the caller refuses a demotion (bench.py without --allow-demotion): EVERY rank leaves with SystemExit, also the
+    # one on which the requested mode would have worked
+    o2 = _Opt(m.parameters())
+    try:
+        D.negotiate_grad_sync(m, o2, torch.ones(2, 3), "sharded", allow_demotion=False)
+        raise AssertionError("a refused demotion must end the run")
+    except SystemExit as e:
+        assert "'sharded' was requested but is not in force" in str(e) and o2.tried == ["sharded"]
+    # the injected-failure hook (what tests/test_gpu_ddp.py uses against bench.py itself) and a mode that holds
+    import os as _os
+    _os.environ["PV_DIST_FAIL_MODES"] = "bf16"
+    try:
+        o3 = _Opt(m.parameters())
+        assert D.negotiate_grad_sync(m, o3, torch.ones(2, 3), "bf16") == "autograd"
+        try:
+            D.negotiate_grad_sync(m, _Opt(m.parameters()), torch.ones(2, 3), "bf16", allow_demotion=False)
+            raise AssertionError("a refused demotion must end the run")
+        except SystemExit:
+            pass
+    finally:
+        del _os.environ["PV_DIST_FAIL_MODES"]
+    assert D.negotiate_grad_sync(m, _Opt(m.parameters()), torch.ones(2, 3), "bf16", allow_demotion=False) == "bf16"
     # the Trainer drives the same helpers: a toy fit keeps the replicas identical
     from predict_pv_yield_amd import lightning as pl
 

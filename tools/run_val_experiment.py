@@ -1,0 +1,13 @@
+"""bench.py's matched-validation experiment (val_nmae.experiment) on its own: python tools/run_val_experiment.py [seeds] [steps]"""
+import json
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+oracle_s = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
+out = bench.matched_validation_experiment(torch.device("cuda:0"), 55, seeds=seeds, n_steps=steps, oracle_seconds=oracle_s)
+print(json.dumps(out, indent=1))
