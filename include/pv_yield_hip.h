@@ -165,17 +165,6 @@ typedef struct pv_conv3d_dims {
   /* output extent is t_in + 2*pad_t - 2 etc. */
 } pv_conv3d_dims;
 
-/* ---- exact-fp32 path (reference layout NCDHW, fp32 FMA chains) --------- */
-/* y[B,Co,To,Ho,Wo] = conv3d(x[B,Ci,Ti,Hi,Wi], w[Co,Ci,3,3,3]) + bias, optional fused ReLU. */
-int pv_conv3d_fwd_f32(const float* x, const float* w, const float* bias, float* y,
-                      const pv_conv3d_dims* d, int relu, void* stream);
-/* dx = conv3d_transpose(dy ⊙ (y>0 if y_relu_mask given), w); `d` describes the FORWARD conv. */
-int pv_conv3d_bwd_data_f32(const float* dy, const float* y_relu_mask, const float* w,
-                           float* dx, const pv_conv3d_dims* d, void* stream);
-/* dw[Co,Ci,3,3,3], dbias[Co] (either may be NULL) from x and dy ⊙ (y>0). Overwrites. */
-int pv_conv3d_bwd_weight_f32(const float* x, const float* dy, const float* y_relu_mask,
-                             float* dw, float* dbias, const pv_conv3d_dims* d, void* stream);
-
 /* ---- general Conv3D / MaxPool3d / MSE (optical-flow notebook model, Conv3dMaxPool) ---------------- */
 /* Geometry of one Conv3D or MaxPool3d with kernel extents 1..3, any stride, symmetric zero (conv) / -inf (pool)
  * padding 0..2, dilation 1, groups 1.  Output extent = (in + 2*pad - k) / stride + 1 (floor).

@@ -99,9 +99,6 @@ SIGNATURES = {
     "pv_prepare_stacks_f32": [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp],
     "pv_normalise_i16": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
     "pv_normalise_f32": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
-    "pv_conv3d_fwd_f32": [c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_vp],
-    "pv_conv3d_bwd_data_f32": [c_vp, c_vp, c_vp, c_vp, _PCD, c_vp],
-    "pv_conv3d_bwd_weight_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp],
     "pv_bf16_cpad": [c_i32],
     "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

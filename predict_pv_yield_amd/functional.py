@@ -20,28 +20,8 @@ from ._lib import check, current_stream_ptr, get_lib, ptr
 
 
 # ---------------------------------------------------------------------------------------------
-# fp32 path
+# fp32 path (Conv3D: Conv3dGeneralF32 below -- one set of f32 kernels for every kernel extent / stride / padding)
 # ---------------------------------------------------------------------------------------------
-class Conv3dReLUF32(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, padding, relu):
-        x = x.contiguous()
-        y = K.conv3d_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, padding, relu)
-        ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.padding, ctx.has_bias = padding, bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight, y = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = K.conv3d_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.padding)
-        dw, db = K.conv3d_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.padding, need_bias=ctx.has_bias)
-        return dx, dw, db, None, None
-
-
 LINEAR_F32_GEMM_K = 1 << 16     # the same threshold as pv_linear_fwd_f32 (dense_f32.hip GEMM_K)
 F32_PENDING_MAX_ROWS = 1024     # pv_linear_wgrad_adam_f32 keeps m x 16 gradient values in 64 KB of LDS
 
@@ -93,10 +73,6 @@ class LinearF32(torch.autograd.Function):
             return dx, dw, (K.colsum(g) if ctx.has_bias else None), None
         dx, dw, db = K.linear_bwd_f32(x, weight.contiguous(), dy.contiguous(), y, need_dx=ctx.needs_input_grad[0])
         return dx, dw, (db if ctx.has_bias else None), None
-
-
-def conv3d_relu_f32(x, weight, bias, padding=(0, 0, 0), relu=True):
-    return Conv3dReLUF32.apply(x, weight, bias, tuple(padding), relu)
 
 
 def linear_f32(x, weight, bias, relu=False):

@@ -86,6 +86,10 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
+        if hasattr(optimizer, "freeze_layout"):
+            # from here on the optimiser's state tensors are never replaced: the moments of the large matrix keep the layout the
+            # eager steps left (tiled after one fused backward) -- a layout conversion must not be RECORDED into the graph either
+            optimizer.freeze_layout(True)
         with torch.cuda.graph(self.graph):
             loss = model.training_step(self.static_batch, batch_idx)
             self._backward(loss)
@@ -105,6 +109,8 @@ class GraphedTrainStep:
         from . import hip_ops as K
         K.unpin_workspaces(getattr(self, "_pins", None))
         self._pins = None
+        if getattr(self, "optimizer", None) is not None and hasattr(self.optimizer, "freeze_layout"):
+            self.optimizer.freeze_layout(False)
         self.graph = None
 
     def __del__(self):

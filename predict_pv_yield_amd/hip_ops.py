@@ -224,39 +224,6 @@ def conv_dims(batch, c_in, c_out, t, h, w, padding=(0, 0, 0)) -> Conv3dDims:
     return Conv3dDims(batch, c_in, c_out, t, h, w, padding[0], padding[1], padding[2])
 
 
-def conv3d_fwd_f32(x, weight, bias, padding=(0, 0, 0), relu=False):
-    require_cuda(x, weight, bias)
-    b, ci, t, h, w = x.shape
-    co = weight.shape[0]
-    d = conv_dims(b, ci, co, t, h, w, padding)
-    to, ho, wo = d.out_shape()
-    y = torch.empty((b, co, to, ho, wo), dtype=torch.float32, device=x.device)
-    check(get_lib().pv_conv3d_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(y), ctypes.byref(d), int(relu),
-                                      current_stream_ptr()), "pv_conv3d_fwd_f32")
-    return y
-
-
-def conv3d_bwd_data_f32(dy, y_mask, weight, x_shape, padding=(0, 0, 0)):
-    require_cuda(dy, y_mask, weight)
-    b, ci, t, h, w = x_shape
-    d = conv_dims(b, ci, weight.shape[0], t, h, w, padding)
-    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
-    check(get_lib().pv_conv3d_bwd_data_f32(ptr(dy), ptr(y_mask), ptr(weight), ptr(dx), ctypes.byref(d),
-                                           current_stream_ptr()), "pv_conv3d_bwd_data_f32")
-    return dx
-
-
-def conv3d_bwd_weight_f32(x, dy, y_mask, weight_shape, padding=(0, 0, 0), need_bias=True):
-    require_cuda(x, dy, y_mask)
-    b, ci, t, h, w = x.shape
-    d = conv_dims(b, ci, weight_shape[0], t, h, w, padding)
-    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
-    db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if need_bias else None
-    check(get_lib().pv_conv3d_bwd_weight_f32(ptr(x), ptr(dy), ptr(y_mask), ptr(dw), ptr(db), ctypes.byref(d),
-                                             current_stream_ptr()), "pv_conv3d_bwd_weight_f32")
-    return dw, db
-
-
 def bf16_cpad(c: int) -> int:
     v = get_lib().pv_bf16_cpad(c)
     if v <= 0:

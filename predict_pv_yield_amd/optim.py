@@ -58,6 +58,7 @@ class HipAdam(torch.optim.Optimizer):
         # (graphs.GraphedTrainStep); the by-value form freezes the step at capture.  One parameter group, every parameter
         # stepping together.
         self.capturable = bool(capturable)
+        self._layout_frozen = False
         self._dev_scalars = None
         self._dev_step = None
         self._dev_fresh = False
@@ -143,8 +144,11 @@ class HipAdam(torch.optim.Optimizer):
 
     def _moments_tiled(self, p) -> bool:
         """Puts exp_avg / exp_avg_sq of p into the tile layout (if the shape allows); True when they are tiled afterwards."""
-        # (capturable: a captured HIP graph holds the state tensors' addresses, so they must never be replaced -- no tiling)
-        if not TILE_LARGE_MOMENTS or self.capturable or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
+        if self._layout_frozen:
+            # a captured HIP graph holds the state tensors' addresses and the kernel argument that names their layout: whatever
+            # the eager steps before the capture left (tiled, normally) stays
+            return self._is_tiled(p)
+        if not TILE_LARGE_MOMENTS or p.dim() != 2 or p.shape[1] % K.MOMENT_TILE:
             self._moments_rows(p)
             return False
         if self._is_tiled(p):
@@ -158,9 +162,21 @@ class HipAdam(torch.optim.Optimizer):
             st["exp_avg"]._pv_k_channels = c
         return True
 
+    def freeze_layout(self, frozen: bool = True) -> None:
+        """graphs.GraphedTrainStep: from the capture until the graph is released the state tensors of this optimiser are never
+        replaced (a replay writes to the addresses it recorded).  state_dict() / moments() then hand out row-major COPIES of
+        tiled moments instead of converting them in place; anything that would have to convert in place raises."""
+        self._layout_frozen = bool(frozen)
+
     def _moments_rows(self, p=None) -> None:
         """Back to row-major (torch's layout) for p, or for every parameter: before anything but the one-pass backward
         reads or writes the moments."""
+        if self._layout_frozen:
+            if any(self._is_tiled(q) for q in ([p] if p is not None else self._params_in_order())):
+                raise RuntimeError("HipAdam: a captured HIP graph (graphs.GraphedTrainStep) holds this optimiser's state tensors; "
+                                   "the operation would replace the tiled moments of the large matrix -- release the graph first "
+                                   "(GraphedTrainStep.close())")
+            return
         for q in ([p] if p is not None else [q for g in self.param_groups for q in g["params"]]):
             if self._is_tiled(q):
                 st = self.state[q]
@@ -199,7 +215,8 @@ class HipAdam(torch.optim.Optimizer):
         return [p for g in self.param_groups for p in g["params"]]      # the index torch's state_dict() gives each parameter
 
     def state_dict(self):
-        self._moments_rows()
+        if not self._layout_frozen:
+            self._moments_rows()
         if self.capturable and self._dev_step is not None:
             # graph replays advance only the DEVICE counter: it is the truth, the host-side `step` entries are brought up to
             # it so that a checkpoint resumes with the right bias corrections
@@ -212,11 +229,13 @@ class HipAdam(torch.optim.Optimizer):
         # packed state holds the live dicts: replaced by copies, never edited)
         for i, p in enumerate(self._params_in_order()):
             c = self._k_channels(p)
-            if c and i in sd["state"]:
+            tiled = self._is_tiled(p)        # (only under a frozen layout: the live tensors stay tiled, the dict gets copies)
+            if (c or tiled) and i in sd["state"]:
                 st = dict(sd["state"][i])
                 for key in ("exp_avg", "exp_avg_sq"):
                     if key in st:
-                        st[key] = _k_to_reference(st[key], c)
+                        t = K.moments_to_rows(st[key]) if tiled else st[key]
+                        st[key] = _k_to_reference(t, c) if c else t
                 sd["state"][i] = st
         return sd
 

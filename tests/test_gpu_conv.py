@@ -52,7 +52,7 @@ def test_conv3d_f32_forward_backward(device, case):
     xd = x.detach().to(device).requires_grad_(True)
     wd = wt.detach().to(device).requires_grad_(True)
     bd = bias.detach().to(device).requires_grad_(True)
-    y = Fn.conv3d_relu_f32(xd, wd, bd, pad, relu=True)
+    y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True)
     y.backward(gy.to(device))
     torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)

@@ -1,4 +1,4 @@
-"""bench.py's matched-validation experiment (val_nmae.experiment) on its own: python tools/run_val_experiment.py [seeds] [steps]"""
+"""bench.py's matched-validation leg (val_nmae + cpu_baseline) on its own: python tools/run_val_experiment.py [seeds] [steps]"""
 import json
 import os
 import sys
@@ -9,5 +9,5 @@ import bench
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 oracle_s = float(sys.argv[3]) if len(sys.argv) > 3 else 60.0
-out = bench.matched_validation_experiment(torch.device("cuda:0"), 55, seeds=seeds, n_steps=steps, oracle_seconds=oracle_s)
-print(json.dumps(out, indent=1))
+val, cpu = bench.matched_validation_and_cpu_baseline(torch.device("cuda:0"), 55, seeds=seeds, n_steps=steps, oracle_seconds=oracle_s)
+print(json.dumps({"val_nmae": val, "cpu_baseline": cpu}, indent=1))
