@@ -114,6 +114,17 @@ TIMED_OPS = ("conv3d_fwd_bf16", "conv3d_fwd_bf16_f32in", "conv3d_bwd_weight_bf16
              "conv3d_pack_weights_multi")
 
 
+def settle():
+    """Between two legs: collect what the last one left (models and optimisers sit in reference cycles -- a parameter's
+    fused-backward closure holds its optimiser -- so `del` alone frees nothing), then hand the cached blocks back.  Otherwise the
+    collector runs whenever it pleases INSIDE the next leg's timed loop: freeing a captured graph's 3.6 GB there cost the T = 19
+    sweep one 87 ms stall (5.2 ms per step over 30 steps instead of 1.8: tools/probes/t19_after_graph.py)."""
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def committed_hbm_traffic():
     """HBM bytes per launch from the COMMITTED PMC passes (tools/pmc_traffic.py: separate --pmc FETCH_SIZE / WRITE_SIZE runs
     of this bench, gfx950-corrected).  PMC counters cannot be collected from inside the timed run."""
@@ -378,6 +389,7 @@ def measure_graph_step(dev, b, history_minutes, steps=20):
     out = {"replay_ms": round(d * 1e3, 3), "samples_per_s": round(b / d, 1), "with_batch_copy_ms": round(d2 * 1e3, 3),
            "loss_after": round(float(step.static_loss), 6), "optimizer_steps_on_device": opt.device_step(),
            "what": "forward + NMAE + backward + Adam of the headline step as ONE captured HIP graph, replayed"}
+    step.close()      # release the graph, its pinned workspaces and the optimiser's frozen layout NOW, not at some later collection
     del step, model, opt
     return out
 
@@ -412,7 +424,7 @@ def measure_batch_sweep(dev, history_minutes, batches=(8, 64), steps=10, warmup=
         d = (time.perf_counter() - t0) / steps
         out[f"B={b}"] = {"ms_per_step": round(d * 1e3, 3), "samples_per_s": round(b / d, 1)}
         del model, opt, batch
-        torch.cuda.empty_cache()
+        settle()
     return out
 
 
@@ -461,7 +473,7 @@ def measure_sharded_rank_compute(dev, history_minutes, world=8, global_batch=512
         d = (time.perf_counter() - t0) / steps
     mode = opt.large_grad_mode
     del model, opt, batch
-    torch.cuda.empty_cache()
+    settle()
     return {"ms_per_step": round(d * 1e3, 3), "per_gpu_batch": b, "emulated_world": world, "rows_stepped": shard[1], "mode": mode,
             "aggregate_samples_per_s_if_exchange_hides": round(world * b / d, 1),
             "exchange_bytes_per_rank_and_step": {"reduce_scatter_in_bf16": rows * model_k(t) * 2,
@@ -566,7 +578,7 @@ def measure_other_models(dev):
         d = time_steps(p_step, 3, 1)
         out["perceiver"][f"attention_operands_{dt}"] = {"ms_per_step": round(d * 1e3, 1), "samples_per_s": round(b / d, 1)}
         del pm, popt
-        torch.cuda.empty_cache()
+        settle()
     del pbatch
 
     # BASELINE configs[4]: experiments/003 LitModel, 128 x 128 x 12 images (16 384-position context), NWP, precision 16
@@ -605,7 +617,7 @@ def measure_other_models(dev):
                                       "peak": "bf16 dense 2.5 PF" if dt == "bf16" else "f32 matrix 157 TF"}
         out["exp003_perceiver_rnn"][f"attention_operands_{dt}"] = entry
         del em, eopt
-        torch.cuda.empty_cache()
+        settle()
     # the same step (bf16 operands) replayed as ONE HIP graph: ~600 launches per step keep the host as busy as the device in
     # eager mode (graphs.GraphedTrainStep; losses identical to the eager step: tests/test_gpu_exp003.py)
     try:
@@ -620,7 +632,7 @@ def measure_other_models(dev):
         del em, gstep
     except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the bench line down
         out["exp003_perceiver_rnn"]["attention_operands_bf16"]["hip_graph_ms_per_step"] = f"failed: {type(e).__name__}: {e}"
-    torch.cuda.empty_cache()
+    settle()
     return out
 
 
@@ -722,7 +734,7 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
                     acc.append(hip_val(m))
             runs[prec].append(sum(acc) / len(acc))
             del opt
-            torch.cuda.empty_cache()
+            settle()
     t_hip = time.perf_counter() - t_hip
     diffs = [a - b for a, b in zip(runs["bf16"], runs["fp32"])]
     se = lambda v: statistics.stdev(v) / len(v) ** 0.5 if len(v) > 1 else float("nan")
@@ -807,7 +819,7 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
            "sample": f"{done} Adam steps at B={batch} (the benched batch), T={t_frames}, fp32, torch-CPU oracle (oracle/conv3d_oracle.py: "
                      f"the reference's Conv3D / fc / NMAE / Adam operators), {train_s:.1f} s of train steps; samples/s by thread count {rate}"}
     del models, oracle, val_sat, val_pv
-    torch.cuda.empty_cache()
+    settle()
     return val, cpu
 
 
@@ -1066,17 +1078,17 @@ def main():
             else:
                 out["roofline"] = None
             del model, opt, batch
-            torch.cuda.empty_cache()
+            settle()
             if not args.no_extras:
                 out["config3"] = measure_config3(dev, b, args.history_minutes)
-                torch.cuda.empty_cache()
+                settle()
                 if out["roofline"] is not None:      # scalars the driver's record keeps (it drops nested objects)
                     out["roofline"]["config3_pipeline_ms"] = out["config3"]["pipeline_ms"]
                     out["roofline"]["config3_frac"] = out["config3"]["frac_of_survey_roofline"]
                     out["roofline"]["config3_joined_step_ms"] = out["config3"]["joined_train_step"]["ms_per_step"]
                 if args.precision == "bf16":
                     out["hip_graph_step"] = measure_graph_step(dev, b, args.history_minutes)
-                    torch.cuda.empty_cache()
+                    settle()
                     if args.history_minutes != 60:   # the reference default (model.py:22-23 history_minutes=60): 19 frames
                         out["t19"] = dict(measure_batch_sweep(dev, 60, batches=(b,), steps=30, warmup=8)[f"B={b}"], t_frames=19,
                                           history_minutes=60, per_gpu_batch=b)
@@ -1094,9 +1106,9 @@ def main():
                         out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
                         out["roofline"]["strong_8gpu_ceiling_over_one_gpu"] = r8.get("ceiling_over_one_gpu")
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
-                    torch.cuda.empty_cache()
+                    settle()
                 out["other_models"] = measure_other_models(dev)
-                torch.cuda.empty_cache()
+                settle()
         else:
             out["roofline"] = None
         if not args.no_cpu_baseline and world == 1:

@@ -75,7 +75,9 @@ __device__ __forceinline__ void w2_interleave() {
 template <int CPAD, bool F16 = false, bool PACK12 = false>
 __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, float* __restrict__ slabs, int t_in, int h_in, int w_in,
-    int t_out, int h_out, int w_out, int pad_t, int pad_h, int pad_w, int n_colblk, int t_chunk) {
+    int t_out, int h_out, int w_out, int pad_t, int pad_h, int pad_w, int n_colblk, int t_chunk, int rpb) {
+  // rpb: output rows per workgroup, 1 .. 8 (W2TR).  56 output rows at B = 32 are 7 blocks of 8 = 224 workgroups on 256 CUs; as
+  // 8 blocks of 7 every CU has one and each walks 14 of the 16 k-steps of a slice (the launcher decides, wgrad_v2_grid).
   constexpr int NCH = CPAD / 8;       // 16-byte chunks per X voxel
   constexpr int VPR = 16 / NCH;
   constexpr int VOXB = CPAD * 2;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
   const int hh = grp >> 1;          // k half (voxels 8*hh ..)
   const int cb = 16 * (grp & 1);    // channel base of the group
 
-  const int h0 = blockIdx.x * W2TR;
+  const int h0 = blockIdx.x * rpb;
   const int b = blockIdx.z;
   const int tc0 = blockIdx.y * t_chunk;
   const int tc1 = min(tc0 + t_chunk, t_out);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int hi = h0 - pad_h + wave + 4 * i;
-      xrow_in[i] = (unsigned)hi < (unsigned)h_in && wave + 4 * i < W2TRI;
+      xrow_in[i] = (unsigned)hi < (unsigned)h_in && wave + 4 * i < rpb + 2;
       xrow_src[i] = xrow_in[i] ? (uint32_t)hi * x_row_b : 0u;
     }
     uint32_t drow_src[2];
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ho = h0 + wave + 4 * i;
-      drow_in[i] = ho < h_out;
+      drow_in[i] = ho < h_out && wave + 4 * i < rpb;
       drow_src[i] = drow_in[i] ? (uint32_t)ho * d_row_b : 0u;
     }
     const bool has_third_row = wave + 8 < W2TRI;
@@ -306,9 +308,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
         }
       };
       s16x4 ra0[2], ra1[2], rb0[NACC][2], rb1[NACC][2];
+      // rows >= rpb of the tile belong to the next workgroup: the loaders leave them zero, so their k-steps add nothing; the
+      // LAST row's two k-steps are skipped outright when the workgroup has fewer than 8 rows (one wave-uniform branch around
+      // the last unrolled iteration -- a run-time trip count in this software-pipelined loop cost 819 spills)
+      const bool skip_last_row = rpb < W2TR;
       read_step(0, ra0, rb0);
 #pragma unroll
       for (int st = 0; st < W2TR * 2; st += 2) {
+        if (st == W2TR * 2 - 2 && skip_last_row) break;
         __builtin_amdgcn_sched_barrier(0);
         read_step(st + 1, ra1, rb1);
         mfma_step(ra0, rb0);
@@ -362,9 +369,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_wgrad_bf16_v2_kernel(
 
 // one workgroup (8 waves, 142 / 87 KB of LDS) per CU; a workgroup owns 8 output rows of a sample over ALL columns.  Cut the
 // time march only when there are fewer row blocks than CUs: rounds x (slices per chunk + the two extra X slices per tile)
-void wgrad_v2_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, int* n_tchunk, int* t_chunk) {
+void wgrad_v2_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, int* n_tchunk, int* t_chunk, int* rows_per_blk) {
   const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
   *n_rowblk = (ho + W2TR - 1) / W2TR;
+  // rows per workgroup: as few as cover the image with that many blocks (a 9-row image is two blocks of 5: 10 of the 16 k-steps
+  // of a slice); and one more block where that shortens every workgroup and fills CUs the 8-row split leaves idle (56 rows at
+  // B = 32: 7 blocks of 8 on 224 CUs -> 8 blocks of 7 on 256)
+  if ((long long)d->batch * *n_rowblk < 256 && (long long)d->batch * (*n_rowblk + 1) <= 256 &&
+      (ho + *n_rowblk) / (*n_rowblk + 1) < (ho + *n_rowblk - 1) / *n_rowblk)
+    *n_rowblk += 1;
+  *rows_per_blk = (ho + *n_rowblk - 1) / *n_rowblk;
   *n_colblk = (wo + W2TW - 1) / W2TW;
   const long long tiles = (long long)d->batch * *n_rowblk;
   int max_chunks = (to + 1) / 2;
@@ -382,8 +396,8 @@ void wgrad_v2_grid(const pv_conv3d_dims* d, int* n_rowblk, int* n_colblk, int* n
 }
 
 size_t wgrad_v2_workspace_bytes(const pv_conv3d_dims* d) {
-  int nrb, ncb, ntc, tch;
-  wgrad_v2_grid(d, &nrb, &ncb, &ntc, &tch);
+  int nrb, ncb, ntc, tch, rpb;
+  wgrad_v2_grid(d, &nrb, &ncb, &ntc, &tch, &rpb);
   return (size_t)d->batch * nrb * ntc * W2_SLAB_ELEMS * sizeof(float);
 }
 
@@ -391,16 +405,16 @@ size_t wgrad_v2_workspace_bytes(const pv_conv3d_dims* d) {
 int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* slabs, const pv_conv3d_dims* d, int to, int ho,
                                 int wo, hipStream_t st, int* n_slabs, bool f16) {
   if (((uintptr_t)x % 16) != 0 || ((uintptr_t)dy % 16) != 0) return 1;
-  int nrb, ncb, ntc, tch;
-  wgrad_v2_grid(d, &nrb, &ncb, &ntc, &tch);
+  int nrb, ncb, ntc, tch, rpb;
+  wgrad_v2_grid(d, &nrb, &ncb, &ntc, &tch, &rpb);
   *n_slabs = d->batch * nrb * ntc;
   dim3 grid((unsigned)nrb, (unsigned)ntc, (unsigned)d->batch);
 #define PV_W2(CP, HALF)                                                                                                       \
   hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<CP, HALF>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, to, \
-                     ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
+                     ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch, rpb)
 #define PV_W2P(HALF)                                                                                                        \
   hipLaunchKernelGGL((conv3d_wgrad_bf16_v2_kernel<16, HALF, true>), grid, dim3(512), 0, st, x, dy, slabs, d->t_in, d->h_in, d->w_in, \
-                     to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch)
+                     to, ho, wo, d->pad_t, d->pad_h, d->pad_w, ncb, tch, rpb)
   if (pv_bf16_cpad(d->c_in) == 16) {
     // (PV_WGRAD_NO_PACK12: the paired form for channel counts it also covers -- the cross-check of tests/test_gpu_conv.py)
     const bool pack12 = d->c_in <= 12 && !getenv("PV_WGRAD_NO_PACK12");

@@ -166,6 +166,17 @@ __device__ __forceinline__ void linear_bwd_dx_body(float* g /* LDS [n][M_TILE] *
 #pragma unroll
   for (int i = 0; i < M_TILE; ++i) acc[i] = 0.f;
   int col = 0;
+  // thirty-two weight rows in flight where there are as many (same order of additions): with eight, the 128-feature layers of
+  // the head were a chain of sixteen dependent memory latencies (10 us for fc2's 64 KB)
+  for (; col + 32 <= n; col += 32) {
+    float wv[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) wv[j] = w[(size_t)(col + j) * k + kk];
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+#pragma unroll
+      for (int i = 0; i < M_TILE; ++i) acc[i] = fmaf(g[(col + j) * M_TILE + i], wv[j], acc[i]);
+  }
   for (; col + 8 <= n; col += 8) {       // eight weight rows in flight (same order of additions)
     float wv[8];
 #pragma unroll
@@ -215,6 +226,15 @@ __device__ __forceinline__ void linear_bwd_dw_body(float* g /* LDS [m][N_TILE] *
 #pragma unroll
   for (int j = 0; j < N_TILE; ++j) acc[j] = 0.f;
   int r = 0;
+  for (; r + 32 <= m; r += 32) {         // thirty-two rows of x in flight where there are as many (same order of additions)
+    float xv[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) xv[q] = x[(size_t)(r + q) * k + kk];
+#pragma unroll
+    for (int q = 0; q < 32; ++q)
+#pragma unroll
+      for (int j = 0; j < N_TILE; ++j) acc[j] = fmaf(g[(r + q) * N_TILE + j], xv[q], acc[j]);
+  }
   for (; r + 8 <= m; r += 8) {           // eight rows of x in flight (same order of additions)
     float xv[8];
 #pragma unroll
@@ -296,6 +316,18 @@ __global__ __launch_bounds__(256) void linear_fwd_small_f32(const float* __restr
   // 32 values of x and of w per trip, loaded before the first multiply-add (one value at a time this launch was a chain
   // of k / 4 dependent cache latencies: 7 us for 128 x 128); the additions keep their order
   if ((((uintptr_t)xr | (uintptr_t)wr) & 15) == 0) {
+    for (; kk + 64 <= k; kk += 64) {      // 64 values of x and of w per trip where there are as many (two trips for k = 128)
+      f32x4 xv[16], wv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xv[j] = *reinterpret_cast<const f32x4*>(xr + kk + 4 * j), wv[j] = *reinterpret_cast<const f32x4*>(wr + kk + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        s0 = fmaf(xv[j][0], wv[j][0], s0);
+        s1 = fmaf(xv[j][1], wv[j][1], s1);
+        s2 = fmaf(xv[j][2], wv[j][2], s2);
+        s3 = fmaf(xv[j][3], wv[j][3], s3);
+      }
+    }
     for (; kk + 32 <= k; kk += 32) {
       f32x4 xv[8], wv[8];
 #pragma unroll
