@@ -306,10 +306,11 @@ int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* byte
 int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, float* y,
                        int32_t m, int32_t n, int64_t k, int relu,
                        void* workspace, size_t workspace_bytes, void* stream);
-/* dx bf16 [M,K] (may be NULL), dw f32 [N,K], db f32 [N]. */
+/* dx bf16 [M,K] (may be NULL), dw f32 [N,K], db f32 [N].  gate_dx_by_x != 0: x is a ReLU output; dx leaves multiplied by
+ * (x > 0), the ReLU derivative of the layer that produced x (F.relu(conv(..)) in front of fc1, model.py:120-125). */
 int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy,
                        const float* y_relu_mask, uint16_t* dx, float* dw, float* db,
-                       int32_t m, int32_t n, int64_t k, void* stream);
+                       int32_t m, int32_t n, int64_t k, int32_t gate_dx_by_x, void* stream);
 
 /* Fused fc1 weight-gradient + Adam: param[N,K] (f32, updated in place), exp_avg, exp_avg_sq and the bf16 shadow are
  * updated with the gradient (dy ⊙ (y>0))^T · x computed on the fly -- the 0.5 GB gradient is never materialised.

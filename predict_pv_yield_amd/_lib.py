@@ -120,7 +120,7 @@ SIGNATURES = {
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_bf16_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
-    "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_linear_bwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp],
     "pv_linear_wgrad_adam_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
                                   c_i32, c_vp],
     "pv_linear_wgrad_adam_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64, c_i32, c_vp],

@@ -747,6 +747,125 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_bf16_v2_kernel(const uint16
 }
 
 // ---------------------------------------------------------------------------------------------
+// fc1's weight gradient written once as bf16 (the data-parallel wire format, pv_linear_wgrad_bf16out) on the matrix cores.
+// dW[n][k] = sum_m g[m][n] x[m][k], g = dy (.) relu'.  The register-tiled form (linear_bwd_dw_bf16_kernel<2>) multiplies on the
+// vector ALU: 8.2 GFLOP at m = 32 for 0.32 GB of traffic -- 202 us where the bytes need 75 (345 us at m = 64: every rank of the
+// 8-GPU run pays it per step).  Here a workgroup owns all n <= 128 rows x 128 k-columns: the x tile [m][128] (bf16) sits in LDS
+// and is read transposed (ds_read_b64_tr_b16) as the B operand, g^T is the A operand as a bf16 hi + lo pair (two MFMAs per
+// 16 batch rows: ~16 mantissa bits of g, as linear_bwd_dx_bf16_v2_kernel), wave w multiplies rows 32 w .. + 31; the finished
+// tile goes through LDS and leaves as 256-byte runs of a row.  f32 accumulation; the result is the bf16 rounding of a sum that
+// differs from the register-tiled kernel's in the last bits of f32 (tests: <= 1 bf16 ulp apart, > 99 % of the elements equal).
+// ---------------------------------------------------------------------------------------------
+constexpr int WB_KC = 128, WB_XS = WB_KC * 2 + 64, WB_OS = WB_KC + 8, WB_MAXM = 64;
+
+__global__ __launch_bounds__(256, 2) void linear_wgrad_bf16out_mfma_kernel(const uint16_t* __restrict__ x, const float* __restrict__ dy,
+                                                                            const float* __restrict__ ymask, uint16_t* __restrict__ dw,
+                                                                            int m, int n, long long k, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char xs[WB_MAXM * WB_XS];     // x tile [m][128] bf16, rows of 320 bytes
+  __shared__ __attribute__((aligned(16))) uint16_t ot[128 * WB_OS];               // dW tile [n][128] bf16 on its way out
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int mk = (m + 15) >> 4;      // k-steps of 16 batch rows
+  // ---- A operand of this wave, ONCE per workgroup (g does not depend on the tile): g^T rows 32 wave .. + 31, bf16 hi + lo ------
+  bf16x8 ahi[WB_MAXM / 16], alo[WB_MAXM / 16];
+  const int nn = 32 * wave + r;
+#pragma unroll
+  for (int ks = 0; ks < WB_MAXM / 16; ++ks) {
+    s16x4 h0, h1, l0, l1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = 16 * ks + 8 * hh + j;
+      float v = 0.f;
+      if (ks < mk && row < m && nn < n) {
+        v = dy[(size_t)row * n + nn];
+        if (ymask && !(ymask[(size_t)row * n + nn] > 0.f)) v = 0.f;
+      }
+      const uint16_t hb = f32_to_bf16_bits(v);
+      const float hf = __builtin_bit_cast(float, (uint32_t)hb << 16);
+      const uint16_t lb = f32_to_bf16_bits(v - hf);
+      if (j < 4) h0[j] = (short)hb, l0[j] = (short)lb; else h1[j - 4] = (short)hb, l1[j - 4] = (short)lb;
+    }
+    const __attribute__((ext_vector_type(8))) short h8 = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    const __attribute__((ext_vector_type(8))) short l8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    ahi[ks] = __builtin_bit_cast(bf16x8, h8);
+    alo[ks] = __builtin_bit_cast(bf16x8, l8);
+  }
+  // transposed-read address of this lane (as in linear_bwd_dx_bf16_v2_kernel): 16-lane group G covers columns 16 (G & 1) ..,
+  // contraction rows 8 (G >> 1) + 4 s + q
+  const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int tr_off = (8 * (G >> 1) + q) * WB_XS + (16 * (G & 1) + 4 * p) * 2;
+  // the x tile as 16-byte chunks: thread t holds chunks t, t + 256, ... (row = chunk / 16), requested one tile ahead
+  constexpr int XCH = WB_MAXM * (WB_KC / 8) / 256;      // 4
+  u32x4 xr[XCH];
+  auto fetch_x = [&](int t) {
+    const long long k0 = (long long)t * WB_KC;
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, c = id & 15;
+      xr[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (t < n_tiles && row < m && k0 + 8 * c < k) xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)row * k + k0 + 8 * c);
+    }
+  };
+  fetch_x(blockIdx.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const long long k0 = (long long)t * WB_KC;
+    __syncthreads();      // the previous tile's transposed reads and its copy-out are done
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int id = tid + 256 * i, row = id >> 4, c = id & 15;
+      if (row < 16 * mk) *reinterpret_cast<u32x4*>(xs + row * WB_XS + 16 * c) = xr[i];      // (zero beyond the rows / columns that exist)
+    }
+    __syncthreads();
+    fetch_x(t + gridDim.x);
+    if (32 * wave < n) {
+#pragma unroll
+      for (int c = 0; c < WB_KC / 32; ++c) {
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < WB_MAXM / 16; ++ks) {
+          if (ks < mk) {      // wave-uniform
+            const unsigned char* bp = xs + tr_off + ks * 16 * WB_XS + c * 64;
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(bp));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(bp + 4 * WB_XS));
+            const __attribute__((ext_vector_type(8))) short b8s = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            const bf16x8 b8 = __builtin_bit_cast(bf16x8, b8s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[ks], b8, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[ks], b8, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int row = 32 * wave + (j & 3) + 8 * (j >> 2) + 4 * hh;
+          ot[row * WB_OS + 32 * c + r] = f32_to_bf16_bits(acc[j]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 128 * (WB_KC / 8); i += 256) {          // 16-byte chunks: 256 contiguous bytes per row of dW
+      const int row = i >> 4, c = i & 15;
+      if (row < n && k0 + 8 * c < k)
+        *reinterpret_cast<u32x4*>(dw + (size_t)row * k + k0 + 8 * c) = *reinterpret_cast<const u32x4*>(ot + row * WB_OS + 8 * c);
+    }
+  }
+}
+
+// dx ⊙ (x > 0) in place, 8 bf16 per thread: pv_linear_bwd_bf16(gate_dx_by_x) -- x is a ReLU output, (x > 0) the ReLU derivative of
+// the layer that produced it (what the one-pass kernel's gate_dx does; the consumer then needs no gate operand of its own).  A
+// pass of its own (192 MB at B = 32: ~38 us): inside the dx kernel, whose accumulator layout gives a lane one 2-byte element
+// per row, the gate was 2-byte loads -- 95 -> 231 us.
+__global__ __launch_bounds__(256) void gate_bf16_by_relu_kernel(uint16_t* __restrict__ dx, const uint16_t* __restrict__ x, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    u32x4 d = reinterpret_cast<const u32x4*>(dx)[i];
+    const u32x4 xv = reinterpret_cast<const u32x4*>(x)[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) d[q] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, relu_pair01(xv[q])) * (u16x2_t){0xffff, 0xffff});
+    reinterpret_cast<u32x4*>(dx)[i] = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // v3 forward for the fc1 shapes: the same k-tile march, but the tile ([128 weight rows + 32 x rows] x 128 k-columns,
 // 40 KB) goes global -> LDS directly (buffer_load_dwordx4 ... lds) into a 3-stage ring: two tiles (80 KB per CU) are
 // always in flight, no staging registers, no ds_write, one barrier per tile.  A wave instruction fills 1 KB = 4 rows x
@@ -884,19 +1003,25 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
   int nwg = bf16_fwd_split(k, &per);
   hipStream_t st = as_stream(stream);
   float* part = (float*)workspace;
-  if (v2_shapes(m, n)) {
+  if (v2_shapes(m < 32 ? m : 32, n)) {
+    // the LDS-staged kernels take 32 rows of x: more rows (a per-GPU batch of 64 in the strong-scaling run) go in blocks of 32, each
+    // a pass over the weights at the memory system's rate (150 us for 64 rows where the register-tiled kernel took 292)
     int tiles, n_tiles;
     const bool fits32 = (size_t)n * k * 2 < 0xfffffff0ull;  // the v3 kernel's raw-buffer offsets are 32-bit
     const int nwg2 = !fits32 ? v2_split(k, &tiles, &n_tiles) : v3_split(k, &tiles, &n_tiles);
-    PV_REQUIRE(workspace_bytes >= (size_t)nwg2 * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
-    if (!fits32)
-      hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
-                         n_tiles, tiles);
-    else
-      hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, x, w, part, m, n, (long long)k,
-                         n_tiles, tiles);
-    hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((m * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
-                       bias, y, m, n, nwg2, relu ? 1 : 0);
+    PV_REQUIRE(workspace_bytes >= (size_t)nwg2 * (m < 32 ? m : 32) * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
+    for (int m0 = 0; m0 < m; m0 += 32) {
+      const int mb = m - m0 < 32 ? m - m0 : 32;
+      const uint16_t* xb = x + (size_t)m0 * k;
+      if (!fits32)
+        hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, part, mb, n, (long long)k,
+                           n_tiles, tiles);
+      else
+        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, part, mb, n, (long long)k,
+                           n_tiles, tiles);
+      hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((mb * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
+                         bias, y + (size_t)m0 * n, mb, n, nwg2, relu ? 1 : 0);
+    }
     return check_launch("pv_linear_fwd_bf16");
   }
   PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
@@ -914,24 +1039,38 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
 }
 
 int pv_linear_bwd_bf16(const uint16_t* x, const uint16_t* w, const float* dy, const float* y_relu_mask, uint16_t* dx,
-                       float* dw, float* db, int32_t m, int32_t n, int64_t k, void* stream) {
+                       float* dw, float* db, int32_t m, int32_t n, int64_t k, int32_t gate_dx_by_x, void* stream) {
   PV_REQUIRE(dy, PV_EINVAL, "pv_linear_bwd_bf16: null dy");
+  PV_REQUIRE(!gate_dx_by_x || (x && dx), PV_EINVAL, "pv_linear_bwd_bf16: gate_dx_by_x needs x and dx");
   PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_bwd_bf16: bad sizes (k must be a multiple of 8)");
   hipStream_t st = as_stream(stream);
   unsigned kb = (unsigned)((k / 8 + 255) / 256);
   if (dx) {
     PV_REQUIRE(w, PV_EINVAL, "pv_linear_bwd_bf16: dx needs w");
-    if (v2_shapes(m, n)) {
+    if (v2_shapes(m < 32 ? m : 32, n)) {
       int tiles, n_tiles;
       const int nwg2 = v2_split(k, &tiles, &n_tiles);
-      hipLaunchKernelGGL(linear_bwd_dx_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, w, dy, y_relu_mask, dx, m, n,
-                         (long long)k, n_tiles, tiles, db);
-      db = nullptr;  // done by the dx kernel
+      if (m <= 32) {
+        hipLaunchKernelGGL(linear_bwd_dx_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, w, dy, y_relu_mask, dx, m, n,
+                           (long long)k, n_tiles, tiles, db);
+        db = nullptr;  // done by the dx kernel
+      } else {
+        // more than 32 rows: blocks of 32 through the same kernel (the bias gradient, a sum over ALL rows, by its own kernel below)
+        for (int m0 = 0; m0 < m; m0 += 32)
+          hipLaunchKernelGGL(linear_bwd_dx_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, w, dy + (size_t)m0 * n,
+                             y_relu_mask ? y_relu_mask + (size_t)m0 * n : (const float*)nullptr, dx + (size_t)m0 * k,
+                             m - m0 < 32 ? m - m0 : 32, n, (long long)k, n_tiles, tiles, (float*)nullptr);
+      }
     } else {
     size_t lds = (size_t)n * BT * sizeof(float);
     PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_bwd_bf16: n=%d too large", n);
     hipLaunchKernelGGL(linear_bwd_dx_bf16_kernel, dim3(xcd_grid(kb, (unsigned)((m + BT - 1) / BT))), dim3(256), lds, st, w, dy,
                        y_relu_mask, dx, m, n, (long long)k);
+    }
+    if (gate_dx_by_x) {
+      PV_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dx % 16) == 0, PV_EINVAL, "pv_linear_bwd_bf16: gate_dx_by_x needs 16-byte aligned x and dx");
+      const size_t n8 = (size_t)m * (size_t)k / 8;
+      hipLaunchKernelGGL(gate_bf16_by_relu_kernel, dim3(stream_grid(n8, 256)), dim3(256), 0, st, dx, x, n8);
     }
   }
   if (dw) {
@@ -1025,6 +1164,13 @@ int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_r
                             int32_t n, int64_t k, void* stream) {
   PV_REQUIRE(x && dy && dw_bf16, PV_EINVAL, "pv_linear_wgrad_bf16out: null pointer");
   PV_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_bf16out: bad sizes (k must be a multiple of 8)");
+  // (PV_WGRAD_BF16OUT_VALU: the register-tiled form for the shapes the matrix-core kernel also covers -- the tests' cross-check)
+  if (m <= WB_MAXM && n <= 128 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dw_bf16 % 16) == 0 && !getenv("PV_WGRAD_BF16OUT_VALU")) {
+    const long long n_tiles = (k + WB_KC - 1) / WB_KC;
+    hipLaunchKernelGGL(linear_wgrad_bf16out_mfma_kernel, dim3((unsigned)std::min<long long>(n_tiles, 2 * kNumCU)), dim3(256), 0,
+                       as_stream(stream), x, dy, y_relu_mask, dw_bf16, m, n, (long long)k, (int)n_tiles);
+    return check_launch("pv_linear_wgrad_bf16out");
+  }
   size_t lds = (size_t)m * BT * sizeof(float);
   PV_REQUIRE(lds <= 64 * 1024, PV_ESIZE, "pv_linear_wgrad_bf16out: m=%d too large", m);
   unsigned kb = (unsigned)((k / 8 + 255) / 256);

@@ -290,7 +290,12 @@ class LinearBF16(torch.autograd.Function):
                 if ctx.x_is_relu_output:
                     _mark_pregated(out[0])
                 return out[0], None, out[1], None, None
-        dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=(mode == "autograd"))
+        # (x a ReLU output: dx leaves gated, as from the one-pass kernel, so the producing conv layer's backward takes the
+        # pre-gated kernels -- in the data-parallel modes too)
+        dx, dw, db = K.linear_bwd_bf16(x, wb, dy, y, need_dx=ctx.needs_input_grad[0], need_dw=(mode == "autograd"),
+                                       gate_dx_by_x=ctx.x_is_relu_output)
+        if ctx.x_is_relu_output and dx is not None:
+            _mark_pregated(dx)
         if mode == "fused":
             # HipAdam owns this parameter (single process): hand it (x, dy, relu mask); the weight gradient is formed
             # inside the optimiser's pass over p/m/v and never written to memory

@@ -516,7 +516,8 @@ def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
     return y
 
 
-def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True):
+def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True, gate_dx_by_x=False):
+    """gate_dx_by_x: x is a ReLU output; dx leaves multiplied by (x > 0) (the producer's ReLU derivative)."""
     require_cuda(x_bf16, w_bf16, dy, y_mask)
     m, k = x_bf16.shape
     n = w_bf16.shape[0]
@@ -524,7 +525,7 @@ def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True):
     dw = torch.empty((n, k), dtype=torch.float32, device=dy.device) if need_dw else None
     db = torch.empty(n, dtype=torch.float32, device=dy.device)
     check(get_lib().pv_linear_bwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(dy), ptr(y_mask), ptr(dx), ptr(dw), ptr(db), m, n,
-                                       k, current_stream_ptr()), "pv_linear_bwd_bf16")
+                                       k, int(bool(gate_dx_by_x and need_dx)), current_stream_ptr()), "pv_linear_bwd_bf16")
     return dx, dw, db
 
 

@@ -456,6 +456,26 @@ def test_linear_f32(device, m, n, k):
     torch.testing.assert_close(bd.grad.cpu(), bias.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 128, 4096 + 64), (5, 64, 1024), (40, 128, 2048), (3, 6, 64)])
+def test_linear_bwd_bf16_gates_dx_by_the_producers_relu(device, m, n, k):
+    """pv_linear_bwd_bf16(gate_dx_by_x): dx multiplied by (x > 0) by a vectorised pass behind either dx kernel (the LDS-staged one
+    for m <= 32, n in 32..128; the register-tiled one otherwise): bit for bit the ungated dx with the non-positive positions
+    (incl. -0) zeroed."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g)
+    x[0, :8] = -0.0
+    xb = x.to(torch.bfloat16).to(device)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).to(torch.bfloat16).to(device)
+    dy = torch.randn(m, n, generator=g).to(device)
+    y = torch.rand(m, n, generator=g).sub_(0.3).to(device)
+    plain, _, db0 = K.linear_bwd_bf16(xb, w, dy, y, need_dx=True, need_dw=False)
+    gated, _, db1 = K.linear_bwd_bf16(xb, w, dy, y, need_dx=True, need_dw=False, gate_dx_by_x=True)
+    want = torch.where(xb.float() > 0, plain, torch.zeros_like(plain))
+    assert torch.equal(gated.view(torch.int16), want.view(torch.int16)) and torch.equal(db0, db1)
+    assert (gated != 0).any() and (gated == 0).sum() > (plain == 0).sum()
+
+
 @pytest.mark.parametrize("m,n,k", [(2, 16, 34816), (33, 128, 4096 + 64), (64, 128, 8200), (7, 5, 72),
                                    # LDS-staged v2 kernels (m <= 32, n in 32..128): ragged k tiles, partial rows
                                    (32, 128, 256 * 37), (5, 128, 256 * 3 + 72), (32, 64, 1000), (17, 96, 131072 + 8)])
@@ -626,18 +646,30 @@ def test_fused_wgrad_dx_adam_single_pass(device, m, n, k):
             K.linear_wgrad_dx_adam_bf16(x, dy, y, pc, mc, vc, sc, 2, lr=5e-4, moments_tiled=True)
 
 
-def test_bf16_gradient_wire_format(device):
-    """pv_linear_wgrad_bf16out = bf16(RNE) of the f32 gradient; pv_adam_step_bf16grad = Adam on the widened gradient."""
+@pytest.mark.parametrize("m,n,k", [(16, 24, 4096), (32, 128, 4096 + 72), (64, 128, 2048), (7, 40, 1000), (70, 128, 1024)])
+def test_bf16_gradient_wire_format(device, monkeypatch, m, n, k):
+    """pv_linear_wgrad_bf16out = bf16(RNE) of the f32 gradient -- bit for bit in the register-tiled form (PV_WGRAD_BF16OUT_VALU=1,
+    and rows beyond 64); the matrix-core form (g as a bf16 hi + lo pair, another summation order in f32) within one bf16 ulp of it
+    with more than 99 % of the elements equal; pv_adam_step_bf16grad = Adam on the widened gradient."""
     K, _ = _mods()
-    g = torch.Generator().manual_seed(78)
-    m, n, k = 16, 24, 4096
+    g = torch.Generator().manual_seed(78 + m)
     x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(device)
     dy = torch.randn(m, n, generator=g).to(device)
     y = torch.relu(torch.randn(m, n, generator=g)).to(device)
     wb = torch.zeros(n, k, dtype=torch.bfloat16, device=device)
     _, dw, _ = K.linear_bwd_bf16(x, wb, dy, y, need_dx=False)
+    monkeypatch.setenv("PV_WGRAD_BF16OUT_VALU", "1")
+    assert torch.equal(K.linear_wgrad_bf16out(x, dy, y, n), dw.to(torch.bfloat16))
+    monkeypatch.delenv("PV_WGRAD_BF16OUT_VALU")
     dwb = K.linear_wgrad_bf16out(x, dy, y, n)
-    assert torch.equal(dwb, dw.to(torch.bfloat16))
+    ref = dw.to(torch.bfloat16)
+    same = (dwb == ref).float().mean().item()
+    gg = torch.where(y > 0, dy, torch.zeros_like(dy)).double()
+    exact, terms = torch.einsum("mn,mk->nk", gg, x.double()), torch.einsum("mn,mk->nk", gg.abs(), x.double().abs())
+    # one bf16 ulp of the result, plus the hi + lo pair's 2^-16 of the TERMS (a sum that cancels keeps the terms' absolute error)
+    ulp = (dwb.double() - ref.double()).abs() <= ref.double().abs() * 2.0 ** -7 + terms * 2.0 ** -15
+    assert same > 0.99 and bool(ulp.all()), (same, (~ulp).sum().item())
+    assert ((dwb.double() - exact).abs() <= exact.abs() * 2.0 ** -8 + terms * 2.0 ** -15).all()      # half a bf16 ulp of the exact sum
     p0 = (torch.randn(n, k, generator=g) * 0.01).to(device)
     pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
     pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
