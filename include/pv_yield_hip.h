@@ -342,7 +342,9 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
 
 /* Data-parallel wire format for fc1's gradient (SURVEY.md §7.2 "keep bf16 grads on the wire"): the weight gradient is
  * written once as bf16 [N,K] (half the bytes of the f32 gradient on HBM and on xGMI), all-reduced by RCCL in bf16,
- * and consumed by pv_adam_step_bf16grad (same arithmetic as pv_adam_step_f32 after widening the gradient). */
+ * and consumed by pv_adam_step_bf16grad (same arithmetic as pv_adam_step_f32 after widening the gradient).
+ * m <= 64, n <= 128, 16-byte aligned x / dw: on the matrix cores (g^T as a bf16 hi + lo pair, f32 accumulate:
+ * each element within one bf16 ulp + 2^-15 of its terms of the f32 product rounded once); other shapes on the vector ALU. */
 int pv_linear_wgrad_bf16out(const uint16_t* x, const float* dy, const float* y_relu_mask, uint16_t* dw_bf16,
                             int32_t m, int32_t n, int64_t k, void* stream);
 /* Multi-tensor form of pv_adam_step_f32: one launch steps up to PV_ADAM_MAX_TENSORS parameter tensors that share the
