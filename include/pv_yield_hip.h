@@ -287,6 +287,30 @@ int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint1
 int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, const pv_conv3d_dims* d,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- f32 Conv3d forward / data gradient on the 16-bit matrix cores (conv3d_f16x2.hip) --------------------------------------
+ * nn.Conv3d in float32 (predict_pv_yield/models/conv3d/model.py:80-90,113-120 with precision 32) for 17..32 -> 32 channel
+ * 3x3x3 stride-1 layers: x and w are split in two half-float terms each (pv_pack_split2_ncdhw_f32_to_ndhwc_f16 /
+ * pv_conv3d_pack_weight_split2_f16), the three products x_l w_h, x_h w_l, x_h w_h run as three pv_conv3d_fwd_f16_f32out
+ * launches into parts[0..2], pv_sum3_ndhwc_to_ncdhw_f32 adds them (in that order), un-scales, adds the bias, applies the ReLU
+ * or a ReLU gate and writes the reference's NCDHW layout.  The data gradient is the same three launches on the split of dy with
+ * the transposed-and-flipped operator (wp + 2 * elems / 4) and pad = 2 - forward pad.  Agrees with the f32 kernels to ~1e-6
+ * relative (22-bit operands, f32 accumulation). */
+/* half-float elements of wp: four operators' fragments -- forward (h, l), data gradient (h, l) */
+size_t pv_conv3d_split2_weight_elems(void);
+/* w [c_out, c_in, 3,3,3] f32 -> wp; state: 3 device floats (bits of max |w|, s, 1 / s) */
+int pv_conv3d_pack_weight_split2_f16(const float* w, uint16_t* wp, float* state, int32_t c_out, int32_t c_in, void* stream);
+/* x [B,T,H,W,32] half floats (one term), wp: ONE operator's fragments (elems / 4 of the above), y [B,To,Ho,Wo,32] f32 = the
+ * raw accumulators (no bias, no activation, scaled by s_x s_w).  d as for pv_conv3d_fwd_bf16 (its pad: 0..2). */
+int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, float* y, const pv_conv3d_dims* d, void* stream);
+/* 1 when pv_conv3d_fwd_f16_f32out takes these dims (else the caller keeps pv_conv3d_general_fwd_f32 / _bwd_data_f32) */
+int pv_conv3d_fwd_f16_f32out_covers(const pv_conv3d_dims* d);
+/* parts [3][B][vox][32] f32 -> y [B,32,vox] f32 = ((p0 + p1) + p2) * sx_state[2] * sw_state[2] + bias (NULL: none), then
+ * relu != 0: max(y, 0); gate != NULL (f32, y's layout): y where gate > 0, else 0.  max_state != NULL: atomicMax of the bits of
+ * |y| into max_state[0] (zeroed by the caller) -- the have_max input of the next pv_pack_split2.  vox_per_sample % 4 == 0. */
+int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const float* sx_state, const float* sw_state, const float* bias,
+                               const float* gate, float* y, float* max_state, int32_t relu, int32_t batch, int64_t vox_per_sample,
+                               void* stream);
+
 /* ---- fully connected head (F.linear; model.py:92-103,125-152) ------------ */
 /* y[M,N] = relu?(x[M,K] · w[N,K]^T + bias[N]); fp32, split-K with fp32 slab reduce.
  * workspace: pv_linear_workspace_bytes(M,N,K). */

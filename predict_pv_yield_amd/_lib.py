@@ -115,6 +115,11 @@ SIGNATURES = {
     "pv_conv3d_bwd_weight_bf16_workspace_bytes": [_PCD, ctypes.POINTER(c_sz)],
     "pv_conv3d_bwd_weight_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
     "pv_conv3d_bwd_weight_f16": [c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
+    "pv_conv3d_split2_weight_elems": [],
+    "pv_conv3d_pack_weight_split2_f16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
+    "pv_conv3d_fwd_f16_f32out": [c_vp, c_vp, c_vp, _PCD, c_vp],
+    "pv_conv3d_fwd_f16_f32out_covers": [_PCD],
+    "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
@@ -184,7 +189,7 @@ SIGNATURES = {
     "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }
-_RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz,
+_RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz, "pv_conv3d_split2_weight_elems": c_sz,
              "pv_attention_bwd_workspace_floats": c_sz, "pv_colsum_workspace_floats": c_sz,
              "pv_attention_fwd_workspace_floats": c_sz}
 

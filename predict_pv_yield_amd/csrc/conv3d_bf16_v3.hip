@@ -64,7 +64,17 @@ __device__ __forceinline__ uint32_t v3_pk_gate(uint32_t x, uint32_t g) {   // ke
 // MFMAs (see PV_V3_STEP): a burst of them right behind the barrier kept the wave at the issue of its 10..17 memory
 // instructions for a fifth of the step (in-kernel stamps), the queue of the texture-address unit being a few entries deep.
 // W1_LDS: the kt = 1 tap plane of the weights is read from LDS like kt = 2 (w2 - V3_W2B), only kt = 0 stays in registers.
-template <int P, int KT_LO, int KT_HI, int KW, bool W1_LDS, typename Side>
+// F16: the operands are half floats (the f32-accurate two-term form, conv3d_f16x2.hip): same fragment layouts, the f16 instruction.
+typedef _Float16 v3_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 v3_mfma(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v3_f16x8, a), __builtin_bit_cast(v3_f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int P, int KT_LO, int KT_HI, int KW, bool W1_LDS, bool F16, typename Side>
 __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const int (&voff)[3],
                                               const bf16x8 (&wfrag)[W1_LDS ? 9 : 18], const unsigned char* w2,
                                               f32x4 (&acc)[3][4][2], const f32x4& b4, Side&& side) {
@@ -97,9 +107,9 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
           if (orow >= 0 && orow < 4) {
 #pragma unroll
             for (int half = 0; half < 2; ++half)
-              acc[(P - kt + 3) % 3][orow][half] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              acc[(P - kt + 3) % 3][orow][half] = v3_mfma<F16>(
                   kt == 2 ? wk2[kh] : ((W1_LDS && kt == 1) ? wk1[kh] : wfrag[kt * 9 + kh * 3 + kw]), cur[half],
-                  (kt == 0 && kh == 0 && KW == 0) ? b4 : acc[(P - kt + 3) % 3][orow][half], 0, 0, 0);
+                  (kt == 0 && kh == 0 && KW == 0) ? b4 : acc[(P - kt + 3) % 3][orow][half]);
           }
         }
       }
@@ -124,7 +134,11 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
 // which a lane holds 8 consecutive couts = 16 bytes of a voxel and an instruction covers 32 half-lines instead of 64
 // eighth-lines: 4 dwordx4 stores (and 4 dwordx4 gate loads in the same lane geometry) per step instead of 8 + 8 dwordx2.
 // The gate is applied to the packed bf16 pairs in that swapped geometry (3 packed integer ops per pair), ReLU likewise.
-template <bool OUT_GATE, bool Y_NCDHW>
+// F32OUT (round 5, the f32 model's forward / dgrad on the 16-bit cores): half-float operand images (one term of a two-term
+// split each), the accumulators leave as they are -- f32 NDHWC, 16 bytes per lane and accumulator (4 couts of a voxel), no bias,
+// no activation: one of the three partial products conv3d_f16x2.hip's sum pass adds up.  Eight stores per tile in the side slots
+// the bf16 form uses for four stores + four gate loads (the same 32 registers).
+template <bool OUT_GATE, bool Y_NCDHW, bool F32OUT = false>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
@@ -139,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   unsigned char* lds_w2 = lds + 2 * V3_SLOTB + (W1_LDS ? V3_W2B : 0);
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
   static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
+  static_assert(!(F32OUT && (OUT_GATE || Y_NCDHW)), "the f32 partial-product form writes plain NDHWC");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -241,12 +256,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const bool ok = (w0 + col_t) < w_out;
     st_off = ok ? ((uint32_t)((h0 + 4 * wr) * w_out + w0 + col_t) * 32u + 16u * ch + 8u * (kg >> 1)) * 2u : V3_INVALID;
   }
-  const size_t out_sample_b = (size_t)t_out * plane_out * 64;
+  // F32OUT: accumulator [orow][half] as it is: couts 16ch + 4kg .. +3 (16 bytes) of voxel (row, column w0 + 16half + vox), 128 bytes per voxel
+  constexpr uint32_t VOX_OUT_B = F32OUT ? 128u : 64u;
+  uint32_t st_off_f[2] = {V3_INVALID, V3_INVALID};
+  if constexpr (F32OUT) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int col_t = 16 * half + vox;
+      if ((w0 + col_t) < w_out) st_off_f[half] = (uint32_t)((h0 + 4 * wr) * w_out + w0 + col_t) * 128u + 64u * ch + 16u * kg;
+    }
+  }
+  const size_t out_sample_b = (size_t)t_out * plane_out * VOX_OUT_B;
   // wave-uniform part of an output address: slice o, tile row orow (SGPR offset); rows below the image select the
   // zero-sized descriptor
-  const uint32_t out_plane_b = (uint32_t)plane_out * 64u, out_row_b = (uint32_t)w_out * 64u;
+  const uint32_t out_plane_b = (uint32_t)plane_out * VOX_OUT_B, out_row_b = (uint32_t)w_out * VOX_OUT_B;
   const int rows_left = h_out - (h0 + 4 * wr);   // tile rows orow < rows_left exist
-  void* const y_sample = y + (size_t)b * t_out * plane_out * 32;
+  void* const y_sample = reinterpret_cast<unsigned char*>(y) + (size_t)b * out_sample_b;
   const void* const og_sample = (OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32;
   // finished tile in the store geometry (16 bytes per lane and tile row), stored one step later so the stores never sit in
   // front of a wait; its gate, fetched in the same geometry during the last two thirds of the step that finishes the tile
@@ -259,6 +284,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   const size_t n_base = ((size_t)b * c_out + 16 * ch + n_co) * cstride + (size_t)(h0 + 4 * wr + n_orow) * w_out + w0 + n_piece * 8;
   u32x4 pend[4];
   u32x4 og[OUT_GATE ? 4 : 1];
+  // F32OUT: a finished tile leaves straight from its accumulators at the end of the step that finishes it (8 stores; held for the
+  // next step's side slots like the bf16 tile, its 32 registers + the new slice's accumulators do not fit: 181 spills).  The
+  // wait at the top of the next step then lets exactly these 8 newest operations stay in flight (vmcnt counts in issue order)
+  auto store_acc = [&](const f32x4& v, int o, int orow, int half, bool live) {
+    const bool ok = live && orow < rows_left;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(y_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, st_off_f[half],
+                                           ok ? (uint32_t)o * out_plane_b + (uint32_t)orow * out_row_b : 0u, 0);
+  };
   auto store_row = [&](int o, int orow, bool live) {   // NDHWC only; live: the tile exists (wave-uniform)
     const bool ok = live && orow < rows_left;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(y_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
@@ -280,6 +314,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         if (n_ok && 16 * ch + 4 * i + n_co < c_out)
           *reinterpret_cast<u32x4*>(y + n_base + (size_t)(4 * i) * cstride + (size_t)o * plane_out) = v;
       }
+    } else if constexpr (F32OUT) {
+      // (every tile has left in the step that finished it)
     } else {
 #pragma unroll
       for (int orow = 0; orow < 4; ++orow) store_row(o, orow, true);
@@ -306,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
 #define PV_V3_STEP(P, KT_LO, KT_HI)                                                                               \
   {                                                                                                               \
     PV_STAMP(q0);                                                                                                 \
-    __builtin_amdgcn_s_waitcnt(0x0f70); /* vmcnt(0): this wave's LDS-direct loads of slice s (and the gate) landed */ \
+    /* vmcnt(0): this wave's LDS-direct loads of slice s (and the gate) landed; F32OUT: vmcnt(8), see store_acc */ \
+    if (F32OUT) __builtin_amdgcn_s_waitcnt(0x0f78); else __builtin_amdgcn_s_waitcnt(0x0f70);                      \
     PV_STAMP(q1);                                                                                                 \
     __syncthreads();                    /* ... everybody's; and every wave is done reading slice s-1 */            \
     PV_STAMP(q2);                                                                                                 \
@@ -316,7 +353,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
        together with the previous tile), then the 9 staging pieces of slice s+1 (into the slot slice s-1 occupied) */    \
     const bool do_load = s + 1 <= s_last, do_store = s - 3 >= tc0;                                                \
     auto side = [&](int j) {                                                                                      \
-      if (j < 4) {                                                                                                \
+      if (F32OUT && j < 8) {                                                                                      \
+      } else if (j < 4) {                                                                                         \
         if (!Y_NCDHW) store_row(s - 3, j, do_store);                                                              \
       } else if (j < 8) {                                                                                         \
         if (OUT_GATE && KT_HI == 2) load_gate_row(s - 2, j - 4);                                                  \
@@ -337,27 +375,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
        ends unless the march has fewer than three slices, and its code stays branch-free */                          \
     const bool slice_live = ((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in;             \
     if (slice_live && Y_NCDHW) {                                                                                  \
-      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
       PV_STAMP(q4);                                                                                               \
-      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
-      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
     } else if (slice_live) {                                                                                      \
-      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
       PV_STAMP(q4);                                                                                               \
-      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
-      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
     } else {                                                                                                      \
+      if (!Y_NCDHW) { /* (first: F32OUT stores the previous tile from the accumulators armed below) */            \
+        _Pragma("unroll") for (int j = 0; j < 18; ++j) side(j);                                                   \
+      }                                                                                                           \
       if ((KT_LO) == 0) { /* output slice s receives nothing from this step: arm its accumulators */              \
         _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) _Pragma("unroll") for (int half = 0; half < 2; ++half)   \
           acc[P][r4][half] = b4;                                                                                  \
       }                                                                                                           \
-      if (!Y_NCDHW) {                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < 18; ++j) side(j);                                                   \
-      }                                                                                                           \
       PV_STAMP(q4);                                                                                               \
     }                                                                                                             \
     PV_STAMP(q6);                                                                                                 \
-    if (KT_HI == 2) { /* output slice s-2 is complete: convert it into the store geometry */                      \
+    if (KT_HI == 2 && F32OUT) { /* output slice s-2 is complete: its accumulators are the stores' data */         \
+      /* (through a copy the compiler may not fold: stored straight from the accumulators, the matrix instructions of  \
+         the interior steps stop accumulating in place and two slots' worth of registers goes to scratch) */          \
+      _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) _Pragma("unroll") for (int half = 0; half < 2; ++half) { \
+        f32x4 tv = acc[((P) + 1) % 3][orow][half];                                                                \
+        asm volatile("" : "+v"(tv));                                                                              \
+        store_acc(tv, s - 2, orow, half, true);                                                                   \
+      }                                                                                                           \
+    } else if (KT_HI == 2) { /* output slice s-2 is complete: convert it into the store geometry */               \
       _Pragma("unroll") for (int orow = 0; orow < 4; ++orow) {                                                    \
         u32x2 o[2];                                                                                               \
         _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
@@ -470,12 +516,8 @@ void launch_pack_weight_v3(const float* w, uint16_t* wp2, int c_out, int c_in, i
 // (v3_writes_mask() == false).
 bool v3_writes_mask(int, const void*, const void*) { return false; }
 
-int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
-                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int y_ncdhw, hipStream_t st, const uint32_t* /*out_gate_mask*/, uint32_t* /*mask_out*/) {
-  if (to < 2) return 1;
-  if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
-  if (!y_ncdhw && (((uintptr_t)y % 16) != 0 || ((uintptr_t)out_gate % 16) != 0)) return 1;
+// grid of a v3 launch (tiles x time chunks x samples); false when no chunking leaves every chunk two output slices
+static bool v3_grid(const pv_conv3d_dims* d, int to, int ho, int wo, dim3* grid_out, int* n_colblk_out, int* t_chunk_out) {
   const int n_rowblk = (ho + V3_TR - 1) / V3_TR;
   const int n_colblk = (wo + V3_TW_VALID - 1) / V3_TW_VALID;
   // two workgroups per CU: split the time march only when the (sample, tile) grid alone cannot fill 512 slots
@@ -497,9 +539,23 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
   if (to - (n_tchunk - 1) * t_chunk < 2) {  // a single-slice remainder: fold it into longer chunks
     ++t_chunk;
     n_tchunk = (to + t_chunk - 1) / t_chunk;
-    if (to - (n_tchunk - 1) * t_chunk < 2) return 1;
+    if (to - (n_tchunk - 1) * t_chunk < 2) return false;
   }
-  dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
+  *grid_out = dim3((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
+  *n_colblk_out = n_colblk;
+  *t_chunk_out = t_chunk;
+  return true;
+}
+
+int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
+                              const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
+                              int y_ncdhw, hipStream_t st, const uint32_t* /*out_gate_mask*/, uint32_t* /*mask_out*/) {
+  if (to < 2) return 1;
+  if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
+  if (!y_ncdhw && (((uintptr_t)y % 16) != 0 || ((uintptr_t)out_gate % 16) != 0)) return 1;
+  dim3 grid;
+  int n_colblk, t_chunk;
+  if (!v3_grid(d, to, ho, wo, &grid, &n_colblk, &t_chunk)) return 1;
 #define PV_LAUNCH_V3(OG, YN)                                                                                          \
   hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in,     \
                      d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out)
@@ -508,6 +564,26 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
   else PV_LAUNCH_V3(false, false);
 #undef PV_LAUNCH_V3
   return check_launch("pv_conv3d_fwd_bf16(v3)");
+}
+
+bool v3_f32out_covers(const pv_conv3d_dims* d, int to, int ho, int wo) {
+  dim3 grid;
+  int n_colblk, t_chunk;
+  return to >= 2 && (size_t)to * ho * wo * 128 <= 0x7fffffffull && v3_grid(d, to, ho, wo, &grid, &n_colblk, &t_chunk);
+}
+
+// One partial product of the f32-accurate form: x, wp2 half floats (a term of a two-term split each), y f32 NDHWC [B,To,Ho,Wo,32]
+// = the raw accumulators.  Returns 1 when the shape does not fit (the caller keeps the f32 kernels).
+int launch_conv3d_fwd_f16_f32out_v3(const uint16_t* x, const uint16_t* wp2, float* y, const pv_conv3d_dims* d, int to, int ho,
+                                    int wo, hipStream_t st) {
+  if (!v3_f32out_covers(d, to, ho, wo) || ((uintptr_t)y % 16) != 0 || ((uintptr_t)x % 16) != 0) return 1;
+  dim3 grid;
+  int n_colblk, t_chunk;
+  if (!v3_grid(d, to, ho, wo, &grid, &n_colblk, &t_chunk)) return 1;
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<false, false, true>), grid, dim3(256), 0, st, x, wp2, (const float*)nullptr,
+                     reinterpret_cast<uint16_t*>(y), (const uint16_t*)nullptr, d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t,
+                     d->pad_h, d->pad_w, 0, n_colblk, t_chunk, d->c_out);
+  return check_launch("pv_conv3d_fwd_f16_f32out(v3)");
 }
 
 }  // namespace pv

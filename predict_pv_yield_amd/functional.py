@@ -360,6 +360,76 @@ def _wgrad_on_bf16x3(x, dy, y, weight, stride) -> bool:
     return vx % 4 == 0 and vy % 4 == 0 and x.shape[0] * vy >= (1 << 16)
 
 
+F32_CONV_ON_F16X2 = True        # 32 -> 32 channel 3x3x3 layers of the f32 model: forward / dgrad as three half-float launches (False: f32 matrix instruction)
+
+
+def _conv_on_f16x2(x, weight, stride, padding) -> bool:
+    """The f32 model's 32 -> 32 channel 3x3x3 stride-1 layers at a size worth three launches + a sum pass, inside the
+    input-stationary kernel's limits (hip_ops.conv3d_f16x2_covers) for the forward AND the data gradient (pad = 2 - pad)."""
+    if not F32_CONV_ON_F16X2 or exact_f32() or tuple(weight.shape) != (32, 32, 3, 3, 3) or _triple(stride) != (1, 1, 1):
+        return False
+    p = _triple(padding)
+    if any(q < 0 or q > 2 for q in p) or x.dim() != 5 or x.shape[1] != 32:
+        return False
+    b, _, t, h, w = x.shape
+    to, ho, wo = t + 2 * p[0] - 2, h + 2 * p[1] - 2, w + 2 * p[2] - 2
+    if min(to, ho, wo) <= 0 or (t * h * w) % 4 or (to * ho * wo) % 4 or b * to * ho * wo < (1 << 16):
+        return False
+    return (K.conv3d_f16x2_covers(b, 32, 32, t, h, w, p) and
+            K.conv3d_f16x2_covers(b, 32, 32, to, ho, wo, tuple(2 - q for q in p)))
+
+
+def _register_gated_max(t: torch.Tensor, state) -> None:
+    """The largest magnitude of a gradient tensor, for the two-term split of its consumer (keyed by storage, valid inside this
+    backward pass; see ReluGateF32.backward)."""
+    task = torch._C._current_graph_task_id()
+    if _GATED_MAX_TASK[0] != task:
+        _GATED_MAX.clear()
+        _GATED_MAX_TASK[0] = task
+    _GATED_MAX[(t.data_ptr(), t.numel())] = state
+
+
+class Conv3dF32OnF16x2(torch.autograd.Function):
+    """nn.Conv3d(32, 32, 3) + optional ReLU in float32 (reference: models/conv3d/model.py:80-90,113-120) with every product on
+    the half-float matrix cores at f32 accuracy (csrc/conv3d_f16x2.hip): x and w split in two half-float terms, three launches
+    per pass, one ordered-sum pass.  The operand images of x made here serve the weight gradient, those of dy made in backward
+    serve both gradients; each sum pass leaves the largest magnitude of its output for the next split.
+    x_is_relu_output / dy_pregated as in Conv3dGeneralF32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding, relu, x_is_relu_output, dy_pregated):
+        x = x.contiguous()
+        p = _triple(padding)
+        xh, xl, xs = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, maxabs_state=getattr(x, "_pv_maxabs", None))
+        wp, ws = K.conv3d_pack_weight_split2_f16(weight.contiguous())
+        y, ymax = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
+                                        relu=relu, want_max=True)
+        ctx.save_for_backward(x if x_is_relu_output else None, y if (relu and not dy_pregated) else None, xh, xl, xs, wp, ws)
+        ctx.padding, ctx.has_bias, ctx.x_shape = p, bias is not None, tuple(x.shape)
+        _FWD_MAX[0] = (y.data_ptr(), ymax)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_gate, y, xh, xl, xs, wp, ws = ctx.saved_tensors
+        dy = dy.contiguous()
+        if y is not None:
+            dy, dmax = K.relu_gate_f32(dy, y, want_max=True)
+        else:
+            dmax = _gated_max_of(dy)
+        dh, dl, ds = K.pack_split2_ncdhw_f32_to_ndhwc_f16(dy, maxabs_state=dmax)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, dxmax = K.conv3d_f32_on_f16x2(dh, dl, ds, wp[2], wp[3], ws, 32, 32, tuple(2 - q for q in ctx.padding), gate=x_gate,
+                                              want_max=True)
+            _register_gated_max(dx, dxmax)
+        dw, db = K.conv3d_bwd_weight_f32_from_split2(xh, xl, xs, dh, dl, ds, 32, ctx.padding)
+        return dx, dw, (db if ctx.has_bias else None), None, None, None, None
+
+
+_FWD_MAX = [None]      # (data_ptr of the newest f16x2 forward's output, its max-magnitude state): attached to the tensor by the wrapper
+
+
 class Conv3dGeneralF32(torch.autograd.Function):
     """nn.Conv3d with kernel extents 1..3, any stride / padding (+ optional fused ReLU) on the f32 kernels (weight gradient of
     32-channel 3x3x3 layers: f32-accurate split products, see exact_f32()):
@@ -436,6 +506,13 @@ def relu_gate_f32(y):
 
 
 def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_relu_output=False, dy_pregated=False):
+    if x.is_cuda and x.dtype == torch.float32 and _conv_on_f16x2(x, weight, stride, padding):
+        y = Conv3dF32OnF16x2.apply(x, weight, bias, padding, relu, x_is_relu_output, dy_pregated)
+        # the sum pass's largest |y| travels with the tensor object: the next layer's split skips its maximum pass
+        tag, _FWD_MAX[0] = _FWD_MAX[0], None
+        if tag is not None and tag[0] == y.data_ptr():
+            y._pv_maxabs = tag[1]
+        return y
     return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu, x_is_relu_output, dy_pregated)
 
 

@@ -339,6 +339,69 @@ def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0
     return dw, db
 
 
+def conv3d_bwd_weight_f32_from_split2(xh, xl, xs, dh, dl, ds, c_in: int, padding=(0, 0, 0)):
+    """conv3d_bwd_weight_f32_on_f16x2 on operand images that already exist (the f16x2 forward made x's, the f16x2 data gradient
+    made dy's): three launches, no split pass.  -> (dw [32,c_in,3,3,3], db [32])."""
+    parts = torch.empty((3, 32 * c_in * 27), dtype=torch.float32, device=xh.device)
+    dbp = torch.empty((2, 32), dtype=torch.float32, device=xh.device)
+    for i, (px, pd) in enumerate(((xl, dh), (xh, dl), (xh, dh))):
+        dw_i, db_i = conv3d_bwd_weight_f16(px, pd, c_in, 32, padding)
+        parts[i].copy_(dw_i.reshape(-1))
+        if i >= 1:
+            dbp[i - 1].copy_(db_i)
+    dw = torch.empty((32, c_in, 3, 3, 3), dtype=torch.float32, device=xh.device)
+    check(get_lib().pv_sum_slabs_acc_f32(ptr(parts), ptr(dw), parts.shape[1], 3, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
+    db = torch.empty(32, dtype=torch.float32, device=xh.device)
+    check(get_lib().pv_sum_slabs_acc_f32(ptr(dbp), ptr(db), 32, 2, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
+    dw.mul_(xs[2]).mul_(ds[2])
+    db.mul_(ds[2])
+    return dw, db
+
+
+def conv3d_pack_weight_split2_f16(w: torch.Tensor):
+    """w f32 [c_out<=32, c_in<=32, 3,3,3] -> (wp f16 [4, elems]: forward operator (h, l), data-gradient operator (h, l); state f32[3])."""
+    require_cuda(w)
+    if w.dtype != torch.float32 or w.dim() != 5 or tuple(w.shape[2:]) != (3, 3, 3) or not w.is_contiguous():
+        raise TypeError("conv3d_pack_weight_split2_f16: a contiguous float32 [Co,Ci,3,3,3] weight is expected")
+    lib = get_lib()
+    n = int(lib.pv_conv3d_split2_weight_elems())
+    wp = torch.empty((4, n // 4), dtype=torch.float16, device=w.device)
+    state = torch.empty(3, dtype=torch.float32, device=w.device)
+    check(lib.pv_conv3d_pack_weight_split2_f16(ptr(w), ptr(wp), ptr(state), w.shape[0], w.shape[1], current_stream_ptr()),
+          "pv_conv3d_pack_weight_split2_f16")
+    return wp, state
+
+
+def conv3d_f16x2_covers(batch, c_in, c_out, t, h, w, padding) -> bool:
+    """Does the f16x2 form (conv3d_f32_on_f16x2) take this layer?  (64-byte voxels, >= 2 output slices per time chunk, size limits)"""
+    d = conv_dims(batch, c_in, c_out, t, h, w, padding)
+    return bool(get_lib().pv_conv3d_fwd_f16_f32out_covers(ctypes.byref(d)))
+
+
+def conv3d_f32_on_f16x2(xh, xl, xs, wp_h, wp_l, ws, c_in: int, c_out: int, padding=(0, 0, 0), bias=None, relu=False, gate=None,
+                        want_max=False):
+    """One f32 Conv3d (3x3x3, stride 1, 32 output channels of the OPERATOR) from split operand images: xh / xl f16 [B,T,H,W,32]
+    with scale state xs, wp_h / wp_l ONE operator's fragments with state ws.  Three matrix-core launches into f32 partial tensors,
+    then one pass: ordered sum, un-scale, bias, ReLU / gate (f32 [B,32,To,Ho,Wo]), NCDHW.  -> (y f32 [B,32,To,Ho,Wo], max_state or None)."""
+    require_cuda(xh, xl)
+    b, t, h, w, cpad = xh.shape
+    if cpad != 32:
+        raise ValueError("conv3d_f32_on_f16x2: 64-byte voxels (17..32 input channels) are expected")
+    d = conv_dims(b, c_in, c_out, t, h, w, padding)
+    to, ho, wo = t + 2 * padding[0] - 2, h + 2 * padding[1] - 2, w + 2 * padding[2] - 2
+    parts = torch.empty((3, b, to, ho, wo, 32), dtype=torch.float32, device=xh.device)
+    lib = get_lib()
+    st = current_stream_ptr()
+    for i, (px, pw) in enumerate(((xl, wp_h), (xh, wp_l), (xh, wp_h))):
+        check(lib.pv_conv3d_fwd_f16_f32out(ptr(px), ptr(pw), ptr(parts[i]), ctypes.byref(d), st), "pv_conv3d_fwd_f16_f32out")
+    y = torch.empty((b, 32, to, ho, wo), dtype=torch.float32, device=xh.device)
+    state = torch.zeros(3, dtype=torch.float32, device=xh.device) if want_max else None
+    check(lib.pv_sum3_ndhwc_to_ncdhw_f32(ptr(parts), ptr(xs), ptr(ws), ptr(bias) if bias is not None else None,
+                                         ptr(gate) if gate is not None else None, ptr(y), ptr(state) if want_max else None,
+                                         int(bool(relu)), b, to * ho * wo, st), "pv_sum3_ndhwc_to_ncdhw_f32")
+    return y, state
+
+
 def unpack_ndhwc_bf16_to_ncdhw_f32(xp: torch.Tensor, c: int) -> torch.Tensor:
     require_cuda(xp)
     b, t, h, w, cpad = xp.shape

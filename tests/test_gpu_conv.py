@@ -376,6 +376,66 @@ def test_two_term_half_float_split_and_the_weight_gradient_built_on_it(device, m
     assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.equal(a[2][1:], b_[2][1:])
 
 
+@pytest.mark.parametrize("shape,pad,magnitude", [
+    ((8, 32, 8, 44, 44), (0, 0, 0), 1.0),        # the model's layers: valid convolution
+    ((6, 32, 6, 40, 52), (1, 1, 1), 3e-6),       # 'same' padding, gradient-sized activations (the scale matters)
+    ((8, 32, 5, 58, 58), (0, 0, 0), 40.0),       # 56-pixel planes: ragged tiles (8-row blocks, 32-column blocks)
+    ((128, 32, 4, 20, 20), (0, 0, 0), 1.0),      # many samples of few voxels (648 = 20.25 tiles of the sum pass each)
+])
+def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, pad, magnitude):
+    """csrc/conv3d_f16x2.hip: nn.Conv3d(32, 32, 3) in float32 from two-term half-float splits of x and w -- three launches of
+    the input-stationary kernel in its half-float form (f32 accumulators out) + one ordered-sum pass -- against float64 on the
+    CPU: forward (+ bias, ReLU), data gradient (+ the producer's ReLU gate), weight and bias gradient from the same operand
+    images.  Bound: 4e-6 of the largest element (22-bit operands, f32 accumulation over 864 terms; the f32 kernels sit at
+    1-2e-6 on the same data, the bf16 path at 1e-2).  The sum passes' maxima equal the tensors' own."""
+    K, _ = _mods()
+    from predict_pv_yield_amd import functional as Fn
+    b, c, t, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + pad[0])
+    x = (torch.randn(shape, generator=g).abs() * magnitude)      # a ReLU output: its zeros gate dx
+    x[torch.rand(shape, generator=g) < 0.3] = 0.0
+    wt = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    bias = torch.randn(32, generator=g) * 0.1 * magnitude
+    xr = x.double().requires_grad_(True)
+    wr, br = wt.double().requires_grad_(True), bias.double().requires_grad_(True)
+    y_ref = F.relu(F.conv3d(xr, wr, br, padding=pad))
+    gy = torch.randn(y_ref.shape, generator=g) * 1e-4
+    # (no gradient where the pre-activation is within rounding of zero: there the ReLU's derivative is a coin toss between any two
+    # arithmetics, and one flipped voxel moves dx by |gy w| = 1e-5 of its largest element)
+    gy = gy * (y_ref.detach() > 1e-4 * float(y_ref.max())).float()
+    (y_ref * gy.double()).sum().backward()
+    dx_ref = xr.grad * (x > 0)
+
+    xd = x.to(device).requires_grad_(True)
+    wd, bd = wt.to(device).requires_grad_(True), bias.to(device).requires_grad_(True)
+    assert Fn._conv_on_f16x2(xd, wd, (1, 1, 1), pad)
+    y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=True, dy_pregated=False)
+    assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("Conv3dF32OnF16x2")
+    assert y._pv_maxabs[0:1].view(torch.int32).item() == y.detach().abs().max().view(torch.int32).item()
+    y.backward(gy.to(device))
+
+    def close(a, ref, what):
+        err = float((a.detach().cpu().double() - ref).abs().max())
+        assert err <= 4e-6 * float(ref.abs().max()), (what, err, float(ref.abs().max()))
+    close(y, y_ref.detach(), "y")
+    close(xd.grad, dx_ref, "dx")
+    close(wd.grad, wr.grad, "dw")
+    close(bd.grad, br.grad, "db")
+    # the f32 matrix-instruction kernels on the same data: both forms within the bound of each other
+    Fn.F32_CONV_ON_F16X2 = False
+    try:
+        x2 = x.to(device).requires_grad_(True)
+        w2, b2 = wt.to(device).requires_grad_(True), bias.to(device).requires_grad_(True)
+        y2 = Fn.conv3d_general_f32(x2, w2, b2, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=True, dy_pregated=False)
+        assert type(y2.grad_fn).__name__.startswith("Conv3dGeneralF32")
+        y2.backward(gy.to(device))
+    finally:
+        Fn.F32_CONV_ON_F16X2 = True
+    close(y2, y_ref.detach(), "y (f32 kernels)")
+    close(x2.grad, dx_ref, "dx (f32 kernels)")
+    assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
+
+
 def _mask_bits(mask, y_shape):
     """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
     b, t, h, w, c = y_shape
