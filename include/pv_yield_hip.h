@@ -220,7 +220,8 @@ int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint1
  * (pv_conv3d_bwd_weight_f16 on (l,h), (h,l), (h,h), summed in that order, un-scaled by state[2] of both tensors) give the weight
  * gradient of the f32 model (predict_pv_yield/models/conv3d/model.py:80-90 under autograd) where the three-term bf16 split
  * needs six.  state: 3 device words: [0] bits of max |x| (scratch), [1] = s, [2] = 1 / s.  have_max != 0: state[0] already holds
- * the bits of max |x| (pv_relu_gate_max_f32 produced x) and the pass that finds it is skipped.  Same alignment rules as above. */
+ * the bits of max |x| (pv_relu_gate_max_f32 produced x) and the pass that finds it is skipped.  have_max & 2: images of 32 channels
+ * (64-byte voxels) whatever c, zero padded -- what pv_conv3d_fwd_f16_f32out reads.  Same alignment rules as above. */
 int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t have_max, int32_t batch,
                                           int32_t c, int32_t t, int32_t h, int32_t w, void* stream);
 int pv_pack_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp, int32_t batch, int32_t c,

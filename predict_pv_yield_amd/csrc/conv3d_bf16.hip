@@ -915,8 +915,10 @@ int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint1
 int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t have_max, int32_t batch,
                                           int32_t c, int32_t t, int32_t h, int32_t w, void* stream) {
   PV_REQUIRE(x && xp_h && xp_l && state, PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: null pointer");
-  const int cpad = pv_bf16_cpad(c);
+  int cpad = pv_bf16_cpad(c);
   PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: c=%d not in 1..32", c);
+  if (have_max & 2) cpad = 32;      // 64-byte voxels whatever c (the operand images of pv_conv3d_fwd_f16_f32out)
+  have_max &= 1;
   const long long vps = (long long)t * h * w, total = vps * batch;
   PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_split2_ncdhw_f32_to_ndhwc_f16: empty tensor");
   PV_REQUIRE(vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp_h % 16 == 0) && ((uintptr_t)xp_l % 16 == 0) &&

@@ -366,10 +366,12 @@ F32_CONV_ON_F16X2 = True        # 32 -> 32 channel 3x3x3 layers of the f32 model
 def _conv_on_f16x2(x, weight, stride, padding) -> bool:
     """The f32 model's 32 -> 32 channel 3x3x3 stride-1 layers at a size worth three launches + a sum pass, inside the
     input-stationary kernel's limits (hip_ops.conv3d_f16x2_covers) for the forward AND the data gradient (pad = 2 - pad)."""
-    if not F32_CONV_ON_F16X2 or exact_f32() or tuple(weight.shape) != (32, 32, 3, 3, 3) or _triple(stride) != (1, 1, 1):
+    if not F32_CONV_ON_F16X2 or exact_f32() or weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
         return False
     p = _triple(padding)
-    if any(q < 0 or q > 2 for q in p) or x.dim() != 5 or x.shape[1] != 32:
+    if weight.shape[0] != 32 or weight.shape[1] > 32 or any(q < 0 or q > 2 for q in p) or x.dim() != 5 or x.shape[1] != weight.shape[1]:
+        return False
+    if weight.shape[1] < 32 and x.requires_grad:      # (the first layer: its operand image is padded to 32 channels, its dx is not formed)
         return False
     b, _, t, h, w = x.shape
     to, ho, wo = t + 2 * p[0] - 2, h + 2 * p[1] - 2, w + 2 * p[2] - 2
@@ -400,12 +402,12 @@ class Conv3dF32OnF16x2(torch.autograd.Function):
     def forward(ctx, x, weight, bias, padding, relu, x_is_relu_output, dy_pregated):
         x = x.contiguous()
         p = _triple(padding)
-        xh, xl, xs = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, maxabs_state=getattr(x, "_pv_maxabs", None))
+        xh, xl, xs = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, maxabs_state=getattr(x, "_pv_maxabs", None), cpad32=True)
         wp, ws = K.conv3d_pack_weight_split2_f16(weight.contiguous())
         y, ymax = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
                                         relu=relu, want_max=True)
         ctx.save_for_backward(x if x_is_relu_output else None, y if (relu and not dy_pregated) else None, xh, xl, xs, wp, ws)
-        ctx.padding, ctx.has_bias, ctx.x_shape = p, bias is not None, tuple(x.shape)
+        ctx.padding, ctx.has_bias, ctx.c_in = p, bias is not None, weight.shape[1]
         _FWD_MAX[0] = (y.data_ptr(), ymax)
         return y
 
@@ -424,6 +426,8 @@ class Conv3dF32OnF16x2(torch.autograd.Function):
                                               want_max=True)
             _register_gated_max(dx, dxmax)
         dw, db = K.conv3d_bwd_weight_f32_from_split2(xh, xl, xs, dh, dl, ds, 32, ctx.padding)
+        if ctx.c_in < 32:
+            dw = dw[:, :ctx.c_in].contiguous()      # (the padded channels' gradient is zero)
         return dx, dw, (db if ctx.has_bias else None), None, None, None, None
 
 

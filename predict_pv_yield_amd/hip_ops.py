@@ -279,21 +279,21 @@ def conv3d_bwd_weight_f32_on_bf16x3(x: torch.Tensor, dy: torch.Tensor, padding=(
     return dw, db
 
 
-def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor, maxabs_state: Optional[torch.Tensor] = None):
+def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor, maxabs_state: Optional[torch.Tensor] = None, cpad32: bool = False):
     """x f32 [B,C,T,H,W] -> (h, l, state): two half-float [B,T,H,W,CPAD] images with x s = h + l (22 significant bits) and
     state = device f32[3] (scratch, s, 1/s), s the power of two that brings max |x| below 2^14.  T*H*W must be a multiple of 4.
     maxabs_state: the state relu_gate_f32(..., want_max=True) produced together with x (its word 0 holds the bits of max |x|):
-    the pass that finds the maximum is skipped."""
+    the pass that finds the maximum is skipped.  cpad32: images of 32 channels whatever C (conv3d_f32_on_f16x2's operands)."""
     require_cuda(x)
     if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
         raise TypeError("pack_split2_ncdhw_f32_to_ndhwc_f16: a contiguous float32 [B,C,T,H,W] tensor is expected")
     b, c, t, h, w = x.shape
-    planes = torch.empty((2, b, t, h, w, bf16_cpad(c)), dtype=torch.float16, device=x.device)
+    planes = torch.empty((2, b, t, h, w, 32 if cpad32 else bf16_cpad(c)), dtype=torch.float16, device=x.device)
     state = maxabs_state
     have_max = state is not None
     if not have_max:
         state = torch.empty(3, dtype=torch.float32, device=x.device)
-    check(get_lib().pv_pack_split2_ncdhw_f32_to_ndhwc_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(state), int(have_max), b, c, t,
+    check(get_lib().pv_pack_split2_ncdhw_f32_to_ndhwc_f16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(state), int(have_max) | (2 if cpad32 else 0), b, c, t,
                                                           h, w, current_stream_ptr()), "pv_pack_split2_ncdhw_f32_to_ndhwc_f16")
     return planes[0], planes[1], state
 

@@ -381,6 +381,7 @@ def test_two_term_half_float_split_and_the_weight_gradient_built_on_it(device, m
     ((6, 32, 6, 40, 52), (1, 1, 1), 3e-6),       # 'same' padding, gradient-sized activations (the scale matters)
     ((8, 32, 5, 58, 58), (0, 0, 0), 40.0),       # 56-pixel planes: ragged tiles (8-row blocks, 32-column blocks)
     ((128, 32, 4, 20, 20), (0, 0, 0), 1.0),      # many samples of few voxels (648 = 20.25 tiles of the sum pass each)
+    ((8, 11, 8, 44, 44), (0, 0, 0), 2.0),        # the first layer: 11 channels in an operand image padded to 32, no dx
 ])
 def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, pad, magnitude):
     """csrc/conv3d_f16x2.hip: nn.Conv3d(32, 32, 3) in float32 from two-term half-float splits of x and w -- three launches of
@@ -394,7 +395,10 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     g = torch.Generator().manual_seed(sum(shape) + pad[0])
     x = (torch.randn(shape, generator=g).abs() * magnitude)      # a ReLU output: its zeros gate dx
     x[torch.rand(shape, generator=g) < 0.3] = 0.0
-    wt = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    first = c < 32
+    if first:
+        x = x - 0.5 * magnitude      # (the model's input is normalised data, not a ReLU output)
+    wt = torch.randn(32, c, 3, 3, 3, generator=g) * 0.05
     bias = torch.randn(32, generator=g) * 0.1 * magnitude
     xr = x.double().requires_grad_(True)
     wr, br = wt.double().requires_grad_(True), bias.double().requires_grad_(True)
@@ -406,10 +410,10 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     (y_ref * gy.double()).sum().backward()
     dx_ref = xr.grad * (x > 0)
 
-    xd = x.to(device).requires_grad_(True)
+    xd = x.to(device).requires_grad_(not first)
     wd, bd = wt.to(device).requires_grad_(True), bias.to(device).requires_grad_(True)
     assert Fn._conv_on_f16x2(xd, wd, (1, 1, 1), pad)
-    y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=True, dy_pregated=False)
+    y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=not first, dy_pregated=False)
     assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("Conv3dF32OnF16x2")
     assert y._pv_maxabs[0:1].view(torch.int32).item() == y.detach().abs().max().view(torch.int32).item()
     y.backward(gy.to(device))
@@ -418,21 +422,24 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
         err = float((a.detach().cpu().double() - ref).abs().max())
         assert err <= 4e-6 * float(ref.abs().max()), (what, err, float(ref.abs().max()))
     close(y, y_ref.detach(), "y")
-    close(xd.grad, dx_ref, "dx")
+    if not first:
+        close(xd.grad, dx_ref, "dx")
+    assert wd.grad.shape == wt.shape
     close(wd.grad, wr.grad, "dw")
     close(bd.grad, br.grad, "db")
     # the f32 matrix-instruction kernels on the same data: both forms within the bound of each other
     Fn.F32_CONV_ON_F16X2 = False
     try:
-        x2 = x.to(device).requires_grad_(True)
+        x2 = x.to(device).requires_grad_(not first)
         w2, b2 = wt.to(device).requires_grad_(True), bias.to(device).requires_grad_(True)
-        y2 = Fn.conv3d_general_f32(x2, w2, b2, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=True, dy_pregated=False)
+        y2 = Fn.conv3d_general_f32(x2, w2, b2, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=not first, dy_pregated=False)
         assert type(y2.grad_fn).__name__.startswith("Conv3dGeneralF32")
         y2.backward(gy.to(device))
     finally:
         Fn.F32_CONV_ON_F16X2 = True
     close(y2, y_ref.detach(), "y (f32 kernels)")
-    close(x2.grad, dx_ref, "dx (f32 kernels)")
+    if not first:
+        close(x2.grad, dx_ref, "dx (f32 kernels)")
     assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
 
 
