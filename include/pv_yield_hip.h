@@ -301,16 +301,19 @@ size_t pv_conv3d_split2_weight_elems(void);
 /* w [c_out, c_in, 3,3,3] f32 -> wp; state: 3 device floats (bits of max |w|, s, 1 / s) */
 int pv_conv3d_pack_weight_split2_f16(const float* w, uint16_t* wp, float* state, int32_t c_out, int32_t c_in, void* stream);
 /* x [B,T,H,W,32] half floats (one term), wp: ONE operator's fragments (elems / 4 of the above), y [B,To,Ho,Wo,32] f32 = the
- * raw accumulators (no bias, no activation, scaled by s_x s_w).  d as for pv_conv3d_fwd_bf16 (its pad: 0..2). */
-int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, float* y, const pv_conv3d_dims* d, void* stream);
+ * raw accumulators (no bias, no activation, scaled by s_x s_w); y_is_f16 != 0: y is a HALF-FLOAT image of the accumulators times
+ * 2^-12 -- for the two small products (x_l w_h, x_h w_l: 2^-11 of the result, 11 bits of them are all the sum can use).
+ * d as for pv_conv3d_fwd_bf16 (its pad: 0..2). */
+int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, void* y, int32_t y_is_f16, const pv_conv3d_dims* d, void* stream);
 /* 1 when pv_conv3d_fwd_f16_f32out takes these dims (else the caller keeps pv_conv3d_general_fwd_f32 / _bwd_data_f32) */
 int pv_conv3d_fwd_f16_f32out_covers(const pv_conv3d_dims* d);
-/* parts [3][B][vox][32] f32 -> y [B,32,vox] f32 = ((p0 + p1) + p2) * sx_state[2] * sw_state[2] + bias (NULL: none), then
+/* parts [3][B][vox][32] f32 -- or, p01_f16 != NULL: parts = p2 alone and p01_f16 = [2][B][vox][32] half floats (y_is_f16 above) --
+ * -> y [B,32,vox] f32 = ((p0 + p1) + p2) * sx_state[2] * sw_state[2] + bias (NULL: none), then
  * relu != 0: max(y, 0); gate != NULL (f32, y's layout): y where gate > 0, else 0.  max_state != NULL: atomicMax of the bits of
  * |y| into max_state[0] (zeroed by the caller) -- the have_max input of the next pv_pack_split2.  vox_per_sample % 4 == 0. */
-int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const float* sx_state, const float* sw_state, const float* bias,
-                               const float* gate, float* y, float* max_state, int32_t relu, int32_t batch, int64_t vox_per_sample,
-                               void* stream);
+int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, const float* sx_state, const float* sw_state,
+                               const float* bias, const float* gate, float* y, float* max_state, int32_t relu, int32_t batch,
+                               int64_t vox_per_sample, void* stream);
 
 /* ---- fully connected head (F.linear; model.py:92-103,125-152) ------------ */
 /* y[M,N] = relu?(x[M,K] · w[N,K]^T + bias[N]); fp32, split-K with fp32 slab reduce.

@@ -117,9 +117,9 @@ SIGNATURES = {
     "pv_conv3d_bwd_weight_f16": [c_vp, c_vp, c_vp, c_vp, _PCD, c_vp, c_sz, c_vp],
     "pv_conv3d_split2_weight_elems": [],
     "pv_conv3d_pack_weight_split2_f16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
-    "pv_conv3d_fwd_f16_f32out": [c_vp, c_vp, c_vp, _PCD, c_vp],
+    "pv_conv3d_fwd_f16_f32out": [c_vp, c_vp, c_vp, c_i32, _PCD, c_vp],
     "pv_conv3d_fwd_f16_f32out_covers": [_PCD],
-    "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],

@@ -138,7 +138,17 @@ __device__ __forceinline__ void v3_accumulate(const unsigned char* slot, const i
 // split each), the accumulators leave as they are -- f32 NDHWC, 16 bytes per lane and accumulator (4 couts of a voxel), no bias,
 // no activation: one of the three partial products conv3d_f16x2.hip's sum pass adds up.  Eight stores per tile in the side slots
 // the bf16 form uses for four stores + four gate loads (the same 32 registers).
-template <bool OUT_GATE, bool Y_NCDHW, bool F32OUT = false>
+// OUTM 2: half-float operands, HALF-FLOAT output = the accumulators times 2^-12 (V3_F16OUT_SCALE), through the bf16 form's packed
+// epilogue: the two small partial products (x_l w_h, x_h w_l: 2^-11 of the result, so 11 more bits of them are all the sum can use)
+// written and read back at half the bytes.  |x_l| <= 4, |w_h| < 2^14, 864 terms: below 2^26 before, 2^14 after the scale.
+constexpr float V3_F16OUT_SCALE = 1.f / 4096.f;
+typedef _Float16 v3_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t v3_pack_f16_pair(float a, float b) {      // one v_cvt_pk_f16_f32 (RNE)
+  const pv_f32x2_t v = {a * V3_F16OUT_SCALE, b * V3_F16OUT_SCALE};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v3_f16x2));
+}
+
+template <bool OUT_GATE, bool Y_NCDHW, int OUTM = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   // ring of 2 slices | [kt = 1 weight plane] | kt = 2 weight plane | 32 bias floats | [NCDHW patches]
   // NDHWC variants: 80 512 B, two workgroups per CU use 161 024 of the 163 840 B; the NCDHW variant keeps the kt = 1 plane
   // in registers (its patches take the room) and issues its memory work in bursts
+  constexpr bool F32OUT = OUTM == 1, F16 = OUTM != 0;
   constexpr bool W1_LDS = !Y_NCDHW;
   constexpr int NWREG = W1_LDS ? 9 : 18;
   __shared__ __attribute__((aligned(1024))) unsigned char
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   unsigned char* lds_w2 = lds + 2 * V3_SLOTB + (W1_LDS ? V3_W2B : 0);
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
   static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
-  static_assert(!(F32OUT && (OUT_GATE || Y_NCDHW)), "the f32 partial-product form writes plain NDHWC");
+  static_assert(!(F16 && (OUT_GATE || Y_NCDHW)), "the partial-product forms write plain NDHWC");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -375,15 +386,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
        ends unless the march has fewer than three slices, and its code stays branch-free */                          \
     const bool slice_live = ((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in;             \
     if (slice_live && Y_NCDHW) {                                                                                  \
-      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
       PV_STAMP(q4);                                                                                               \
-      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
-      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
     } else if (slice_live) {                                                                                      \
-      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, side);                            \
       PV_STAMP(q4);                                                                                               \
-      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
-      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F32OUT>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 1, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, side);                            \
+      v3_accumulate<P, KT_LO, KT_HI, 2, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, side);                            \
     } else {                                                                                                      \
       if (!Y_NCDHW) { /* (first: F32OUT stores the previous tile from the accumulators armed below) */            \
         _Pragma("unroll") for (int j = 0; j < 18; ++j) side(j);                                                   \
@@ -408,8 +419,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         u32x2 o[2];                                                                                               \
         _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                  \
           const f32x4 a = acc[((P) + 1) % 3][orow][half];                                                         \
-          o[half][0] = pack_bf16_pair(a[0], a[1]);                                                                \
-          o[half][1] = pack_bf16_pair(a[2], a[3]);                                                                \
+          o[half][0] = OUTM == 2 ? v3_pack_f16_pair(a[0], a[1]) : pack_bf16_pair(a[0], a[1]);                     \
+          o[half][1] = OUTM == 2 ? v3_pack_f16_pair(a[2], a[3]) : pack_bf16_pair(a[2], a[3]);                     \
           o[half][0] = v3_pk_max(o[half][0], relu_floor);                                                         \
           o[half][1] = v3_pk_max(o[half][1], relu_floor);                                                         \
           if constexpr (Y_NCDHW) {                                                                                \
@@ -574,15 +585,19 @@ bool v3_f32out_covers(const pv_conv3d_dims* d, int to, int ho, int wo) {
 
 // One partial product of the f32-accurate form: x, wp2 half floats (a term of a two-term split each), y f32 NDHWC [B,To,Ho,Wo,32]
 // = the raw accumulators.  Returns 1 when the shape does not fit (the caller keeps the f32 kernels).
-int launch_conv3d_fwd_f16_f32out_v3(const uint16_t* x, const uint16_t* wp2, float* y, const pv_conv3d_dims* d, int to, int ho,
-                                    int wo, hipStream_t st) {
+// f16_out: y is a half-float image holding the accumulators times 2^-12 (OUTM 2) instead of the f32 accumulators.
+int launch_conv3d_fwd_f16_f32out_v3(const uint16_t* x, const uint16_t* wp2, void* y, int f16_out, const pv_conv3d_dims* d, int to,
+                                    int ho, int wo, hipStream_t st) {
   if (!v3_f32out_covers(d, to, ho, wo) || ((uintptr_t)y % 16) != 0 || ((uintptr_t)x % 16) != 0) return 1;
   dim3 grid;
   int n_colblk, t_chunk;
   if (!v3_grid(d, to, ho, wo, &grid, &n_colblk, &t_chunk)) return 1;
-  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<false, false, true>), grid, dim3(256), 0, st, x, wp2, (const float*)nullptr,
-                     reinterpret_cast<uint16_t*>(y), (const uint16_t*)nullptr, d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t,
-                     d->pad_h, d->pad_w, 0, n_colblk, t_chunk, d->c_out);
+#define PV_LAUNCH_V3P(M)                                                                                                      \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<false, false, M>), grid, dim3(256), 0, st, x, wp2, (const float*)nullptr,     \
+                     reinterpret_cast<uint16_t*>(y), (const uint16_t*)nullptr, d->t_in, d->h_in, d->w_in, to, ho, wo, d->pad_t, \
+                     d->pad_h, d->pad_w, 0, n_colblk, t_chunk, d->c_out)
+  if (f16_out) PV_LAUNCH_V3P(2); else PV_LAUNCH_V3P(1);
+#undef PV_LAUNCH_V3P
   return check_launch("pv_conv3d_fwd_f16_f32out(v3)");
 }
 

@@ -17,8 +17,8 @@
 
 namespace pv {
 
-int launch_conv3d_fwd_f16_f32out_v3(const uint16_t* x, const uint16_t* wp2, float* y, const pv_conv3d_dims* d, int to, int ho,
-                                    int wo, hipStream_t st);
+int launch_conv3d_fwd_f16_f32out_v3(const uint16_t* x, const uint16_t* wp2, void* y, int f16_out, const pv_conv3d_dims* d, int to,
+                                    int ho, int wo, hipStream_t st);
 
 bool v3_f32out_covers(const pv_conv3d_dims* d, int to, int ho, int wo);
 
@@ -32,13 +32,14 @@ __device__ __forceinline__ float f2_scale_of(uint32_t maxbits) {      // = split
 }
 
 // w [32,32,27] f32 -> four fragment images [27][2 cout halves][64 lanes][8] half floats: forward operator (h, l), dgrad operator
-// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s).  One workgroup (27 648 weights).
+// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s).  Every workgroup finds the maximum of the 27 648 weights
+// for itself (110 KB from L2; one workgroup doing everything took 34 us) and packs its share of the fragments.
 __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp,
                                                                       float* __restrict__ state, int c_out, int c_in) {
   __shared__ uint32_t red[16];
   const int n = c_out * c_in * 27;
   uint32_t m = 0;
-  for (int i = threadIdx.x; i < n; i += 1024) m = max(m, __builtin_bit_cast(uint32_t, w[i]) & 0x7fffffffu);
+  for (int i = threadIdx.x; i < n; i += 1024) m = max(m, *reinterpret_cast<const uint32_t*>(w + i) & 0x7fffffffu);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -47,12 +48,12 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
 #pragma unroll
   for (int i = 1; i < 16; ++i) m = max(m, red[i]);
   const float s = f2_scale_of(m);
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     state[0] = __builtin_bit_cast(float, m);
     state[1] = s;
     state[2] = 1.f / s;
   }
-  for (int i = threadIdx.x; i < 2 * F2_WFRAG; i += 1024) {
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < 2 * F2_WFRAG; i += gridDim.x * 1024) {
     const int flip = i >= F2_WFRAG, e = flip ? i - F2_WFRAG : i;
     const int j = e & 7, lane = (e >> 3) & 63, half = (e >> 9) & 1, tap = e >> 10;
     const int row = 16 * half + (lane & 15);  // output channel of this operator
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
 //   y = ((p0 + p1) + p2) / (s_x s_w) + bias,  then ReLU (relu) or zero where gate <= 0 (gate: NCDHW like y);
 // the largest |y| goes to max_state (bits, atomicMax; the caller zeroes it) for the split of y.
 // A wave owns tiles of 32 voxels x 32 channels: 16-byte reads along the channels, an LDS transpose, 16-byte writes along the voxels.
+// P01_F16: the two small partial products are half-float images scaled by 2^-12 (conv3d_bf16_v3.hip OUTM 2): parts = p2 alone, p01 =
+// [2][B][vox][32] half floats
+template <bool P01_F16>
 __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* __restrict__ parts, size_t part_stride,
+                                                                   const uint16_t* __restrict__ p01,
                                                                    const float* __restrict__ sx, const float* __restrict__ sw,
                                                                    const float* __restrict__ bias, const float* __restrict__ gate,
                                                                    float* __restrict__ y, uint32_t* __restrict__ max_state, int relu,
@@ -98,9 +103,20 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
       const long long v = v0 + 8 * i + rv;
       const bool ok = v < vps;
       const size_t off = ((size_t)(bi * vps + (ok ? v : 0)) * 32) + 4 * rq;
+      if constexpr (P01_F16) {
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        a[i][2] = ok ? *reinterpret_cast<const f32x4*>(parts + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[i][p] = ok ? *reinterpret_cast<const f32x4*>(parts + p * part_stride + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < 2; ++p) {
+          f16x4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+          if (ok) hv = *reinterpret_cast<const f16x4_t*>(p01 + p * part_stride + off);
+          a[i][p] = __builtin_convertvector(hv, f32x4) * 4096.f;
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          a[i][p] = ok ? *reinterpret_cast<const f32x4*>(parts + p * part_stride + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -159,7 +175,7 @@ int pv_conv3d_pack_weight_split2_f16(const float* w, uint16_t* wp, float* state,
   PV_REQUIRE(w && wp && state, PV_EINVAL, "pv_conv3d_pack_weight_split2_f16: null pointer");
   PV_REQUIRE(c_out > 0 && c_out <= 32 && c_in > 0 && c_in <= 32, PV_ESIZE,
              "pv_conv3d_pack_weight_split2_f16: channels (%d,%d) must be in 1..32", c_out, c_in);
-  hipLaunchKernelGGL(pack_weight_v3_split2_kernel, dim3(1), dim3(1024), 0, as_stream(stream), w, wp, state, c_out, c_in);
+  hipLaunchKernelGGL(pack_weight_v3_split2_kernel, dim3(27), dim3(1024), 0, as_stream(stream), w, wp, state, c_out, c_in);
   return check_launch("pv_conv3d_pack_weight_split2_f16");
 }
 
@@ -171,7 +187,7 @@ int pv_conv3d_fwd_f16_f32out_covers(const pv_conv3d_dims* d) {
   return v3_f32out_covers(d, to, ho, wo) ? 1 : 0;
 }
 
-int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, float* y, const pv_conv3d_dims* d, void* stream) {
+int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, void* y, int32_t y_is_f16, const pv_conv3d_dims* d, void* stream) {
   PV_REQUIRE(d && x && wp && y, PV_EINVAL, "pv_conv3d_fwd_f16_f32out: null pointer");
   PV_REQUIRE(d->batch > 0 && d->batch <= 65535 && d->c_in > 16 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
              "pv_conv3d_fwd_f16_f32out: channels (%d -> %d): 17..32 in (64-byte voxels), 1..32 out", d->c_in, d->c_out);
@@ -181,25 +197,30 @@ int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, float* y, co
   PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_fwd_f16_f32out: input smaller than the kernel");
   PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
              "pv_conv3d_fwd_f16_f32out: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
-  const int rc = launch_conv3d_fwd_f16_f32out_v3(x, wp, y, d, to, ho, wo, as_stream(stream));
+  const int rc = launch_conv3d_fwd_f16_f32out_v3(x, wp, y, y_is_f16 ? 1 : 0, d, to, ho, wo, as_stream(stream));
   PV_REQUIRE(rc != 1, PV_ESIZE, "pv_conv3d_fwd_f16_f32out: shape not covered (fewer than two output slices per time chunk, a sample of "
                                 "y beyond 2 GiB, or unaligned tensors); the caller keeps pv_conv3d_general_fwd_f32");
   return rc;
 }
 
-int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const float* sx_state, const float* sw_state, const float* bias,
-                               const float* gate, float* y, float* max_state, int32_t relu, int32_t batch, int64_t vox_per_sample,
-                               void* stream) {
+int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, const float* sx_state, const float* sw_state,
+                               const float* bias, const float* gate, float* y, float* max_state, int32_t relu, int32_t batch,
+                               int64_t vox_per_sample, void* stream) {
   PV_REQUIRE(parts && sx_state && sw_state && y, PV_EINVAL, "pv_sum3_ndhwc_to_ncdhw_f32: null pointer");
   PV_REQUIRE(batch > 0 && vox_per_sample > 0 && vox_per_sample % 4 == 0, PV_ESIZE,
              "pv_sum3_ndhwc_to_ncdhw_f32: voxels per sample must be a positive multiple of 4");
-  PV_REQUIRE((((uintptr_t)parts | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)bias) & 15) == 0, PV_EINVAL,
+  PV_REQUIRE((((uintptr_t)parts | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)p01_f16) & 15) == 0, PV_EINVAL,
              "pv_sum3_ndhwc_to_ncdhw_f32: 16-byte aligned tensors");
   const long long tps = (vox_per_sample + 31) / 32, total = tps * batch;
   const unsigned grid = (unsigned)std::min<long long>((total + 3) / 4, (long long)kNumCU * 8);
-  hipLaunchKernelGGL(sum3_ndhwc_to_ncdhw_kernel, dim3(grid), dim3(256), 0, as_stream(stream), parts,
-                     (size_t)batch * vox_per_sample * 32, sx_state, sw_state, bias, gate, y, reinterpret_cast<uint32_t*>(max_state),
-                     relu ? 1 : 0, (long long)vox_per_sample, tps, total);
+  if (p01_f16)
+    hipLaunchKernelGGL(sum3_ndhwc_to_ncdhw_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), parts,
+                       (size_t)batch * vox_per_sample * 32, p01_f16, sx_state, sw_state, bias, gate, y,
+                       reinterpret_cast<uint32_t*>(max_state), relu ? 1 : 0, (long long)vox_per_sample, tps, total);
+  else
+    hipLaunchKernelGGL(sum3_ndhwc_to_ncdhw_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), parts,
+                       (size_t)batch * vox_per_sample * 32, (const uint16_t*)nullptr, sx_state, sw_state, bias, gate, y,
+                       reinterpret_cast<uint32_t*>(max_state), relu ? 1 : 0, (long long)vox_per_sample, tps, total);
   return check_launch("pv_sum3_ndhwc_to_ncdhw_f32");
 }
 

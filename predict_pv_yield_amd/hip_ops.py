@@ -298,8 +298,9 @@ def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor, maxabs_state: Optional[t
     return planes[0], planes[1], state
 
 
-def conv3d_bwd_weight_f16(x: torch.Tensor, dy: torch.Tensor, c_in: int, c_out: int, padding=(0, 0, 0)):
-    """conv3d_bwd_weight_bf16 on half-float operand images: x [B,T,H,W,CPAD] f16, dy [B,To,Ho,Wo,32] f16."""
+def conv3d_bwd_weight_f16(x: torch.Tensor, dy: torch.Tensor, c_in: int, c_out: int, padding=(0, 0, 0), out=None):
+    """conv3d_bwd_weight_bf16 on half-float operand images: x [B,T,H,W,CPAD] f16, dy [B,To,Ho,Wo,32] f16.
+    out: (dw, db) contiguous f32 tensors of c_out * c_in * 27 / c_out elements to write into (else fresh ones)."""
     require_cuda(x, dy)
     b, t, h, w, cpad = x.shape
     d = conv_dims(b, c_in, c_out, t, h, w, padding)
@@ -307,8 +308,13 @@ def conv3d_bwd_weight_f16(x: torch.Tensor, dy: torch.Tensor, c_in: int, c_out: i
     lib = get_lib()
     check(lib.pv_conv3d_bwd_weight_bf16_workspace_bytes(ctypes.byref(d), ctypes.byref(need)), "wgrad workspace")
     ws = _workspace("wgrad", need.value, x.device)
-    dw = torch.empty((c_out, c_in, 3, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+    if out is None:
+        dw = torch.empty((c_out, c_in, 3, 3, 3), dtype=torch.float32, device=x.device)
+        db = torch.empty(c_out, dtype=torch.float32, device=x.device)
+    else:
+        dw, db = out
+        if dw.numel() != c_out * c_in * 27 or db.numel() != c_out or not (dw.is_contiguous() and db.is_contiguous()):
+            raise ValueError("conv3d_bwd_weight_f16: out = (dw, db) must be contiguous f32 tensors of the gradients' sizes")
     check(lib.pv_conv3d_bwd_weight_f16(ptr(x), ptr(dy), ptr(dw), ptr(db), ctypes.byref(d), ptr(ws), ws.numel(),
                                        current_stream_ptr()), "pv_conv3d_bwd_weight_f16")
     return dw, db
@@ -343,17 +349,14 @@ def conv3d_bwd_weight_f32_from_split2(xh, xl, xs, dh, dl, ds, c_in: int, padding
     """conv3d_bwd_weight_f32_on_f16x2 on operand images that already exist (the f16x2 forward made x's, the f16x2 data gradient
     made dy's): three launches, no split pass.  -> (dw [32,c_in,3,3,3], db [32])."""
     parts = torch.empty((3, 32 * c_in * 27), dtype=torch.float32, device=xh.device)
-    dbp = torch.empty((2, 32), dtype=torch.float32, device=xh.device)
+    dbp = torch.empty((3, 32), dtype=torch.float32, device=xh.device)      # (row 0: the bias sum of dy's l image against x_l: not a term)
     for i, (px, pd) in enumerate(((xl, dh), (xh, dl), (xh, dh))):
-        dw_i, db_i = conv3d_bwd_weight_f16(px, pd, c_in, 32, padding)
-        parts[i].copy_(dw_i.reshape(-1))
-        if i >= 1:
-            dbp[i - 1].copy_(db_i)
+        conv3d_bwd_weight_f16(px, pd, c_in, 32, padding, out=(parts[i], dbp[(i + 2) % 3]))      # db: (dh, dl, dh) -> rows 2, 0, 1: rows 0, 1 = l, h
     dw = torch.empty((32, c_in, 3, 3, 3), dtype=torch.float32, device=xh.device)
     check(get_lib().pv_sum_slabs_acc_f32(ptr(parts), ptr(dw), parts.shape[1], 3, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
     db = torch.empty(32, dtype=torch.float32, device=xh.device)
     check(get_lib().pv_sum_slabs_acc_f32(ptr(dbp), ptr(db), 32, 2, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
-    dw.mul_(xs[2]).mul_(ds[2])
+    dw.mul_(xs[2] * ds[2])      # exact: powers of two (device scalars: no host round trip)
     db.mul_(ds[2])
     return dw, db
 
@@ -370,6 +373,9 @@ def conv3d_pack_weight_split2_f16(w: torch.Tensor):
     check(lib.pv_conv3d_pack_weight_split2_f16(ptr(w), ptr(wp), ptr(state), w.shape[0], w.shape[1], current_stream_ptr()),
           "pv_conv3d_pack_weight_split2_f16")
     return wp, state
+
+
+F16X2_SMALL_PRODUCTS_F16 = True      # conv3d_f32_on_f16x2: x_l w_h and x_h w_l leave the matrix cores as half floats (False: f32, the cross-check)
 
 
 def conv3d_f16x2_covers(batch, c_in, c_out, t, h, w, padding) -> bool:
@@ -389,15 +395,21 @@ def conv3d_f32_on_f16x2(xh, xl, xs, wp_h, wp_l, ws, c_in: int, c_out: int, paddi
         raise ValueError("conv3d_f32_on_f16x2: 64-byte voxels (17..32 input channels) are expected")
     d = conv_dims(b, c_in, c_out, t, h, w, padding)
     to, ho, wo = t + 2 * padding[0] - 2, h + 2 * padding[1] - 2, w + 2 * padding[2] - 2
-    parts = torch.empty((3, b, to, ho, wo, 32), dtype=torch.float32, device=xh.device)
     lib = get_lib()
     st = current_stream_ptr()
-    for i, (px, pw) in enumerate(((xl, wp_h), (xh, wp_l), (xh, wp_h))):
-        check(lib.pv_conv3d_fwd_f16_f32out(ptr(px), ptr(pw), ptr(parts[i]), ctypes.byref(d), st), "pv_conv3d_fwd_f16_f32out")
+    if F16X2_SMALL_PRODUCTS_F16:      # the two small products as half floats (2^-12 of the accumulators): half their bytes
+        p01 = torch.empty((2, b, to, ho, wo, 32), dtype=torch.float16, device=xh.device)
+        parts = torch.empty((1, b, to, ho, wo, 32), dtype=torch.float32, device=xh.device)
+        outs = ((p01[0], 1), (p01[1], 1), (parts[0], 0))
+    else:
+        p01 = None
+        parts = torch.empty((3, b, to, ho, wo, 32), dtype=torch.float32, device=xh.device)
+        outs = ((parts[0], 0), (parts[1], 0), (parts[2], 0))
+    for (px, pw), (out, is16) in zip(((xl, wp_h), (xh, wp_l), (xh, wp_h)), outs):
+        check(lib.pv_conv3d_fwd_f16_f32out(ptr(px), ptr(pw), ptr(out), is16, ctypes.byref(d), st), "pv_conv3d_fwd_f16_f32out")
     y = torch.empty((b, 32, to, ho, wo), dtype=torch.float32, device=xh.device)
     state = torch.zeros(3, dtype=torch.float32, device=xh.device) if want_max else None
-    check(lib.pv_sum3_ndhwc_to_ncdhw_f32(ptr(parts), ptr(xs), ptr(ws), ptr(bias) if bias is not None else None,
-                                         ptr(gate) if gate is not None else None, ptr(y), ptr(state) if want_max else None,
+    check(lib.pv_sum3_ndhwc_to_ncdhw_f32(ptr(parts), ptr(p01), ptr(xs), ptr(ws), ptr(bias), ptr(gate), ptr(y), ptr(state),
                                          int(bool(relu)), b, to * ho * wo, st), "pv_sum3_ndhwc_to_ncdhw_f32")
     return y, state
 

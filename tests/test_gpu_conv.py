@@ -427,6 +427,19 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     assert wd.grad.shape == wt.shape
     close(wd.grad, wr.grad, "dw")
     close(bd.grad, br.grad, "db")
+    # the two small products kept as f32 instead of half floats (the switch's other arm): same bound, not the same bits
+    K.F16X2_SMALL_PRODUCTS_F16 = False
+    try:
+        x3 = x.to(device).requires_grad_(not first)
+        w3, b3 = wt.to(device).requires_grad_(True), bias.to(device).requires_grad_(True)
+        y3 = Fn.conv3d_general_f32(x3, w3, b3, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=not first, dy_pregated=False)
+        y3.backward(gy.to(device))
+    finally:
+        K.F16X2_SMALL_PRODUCTS_F16 = True
+    close(y3, y_ref.detach(), "y (f32 small products)")
+    if not first:
+        close(x3.grad, dx_ref, "dx (f32 small products)")
+    assert not torch.equal(y3.detach(), y.detach()), "the two arms are different kernels: identical bits mean the switch is dead"
     # the f32 matrix-instruction kernels on the same data: both forms within the bound of each other
     Fn.F32_CONV_ON_F16X2 = False
     try:
