@@ -315,6 +315,17 @@ int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, cons
                                const float* bias, const float* gate, float* y, float* max_state, int32_t relu, int32_t batch,
                                int64_t vox_per_sample, void* stream);
 
+/* ---- fc1 of the f32 model as streams over the weight (linear_f32_skinny.hip) --------------------------------------------------
+ * F.linear in float32 (predict_pv_yield/models/conv3d/model.py:92-103,125-130) for m <= 32 rows, n <= 128 outputs, k % 128 == 0,
+ * k >= 65 536: exact f32 products (v_mfma_f32_32x32x2_f32), f32 accumulation; the forward's split-k slabs are summed in order. */
+int pv_linear_f32_skinny_covers(int32_t m, int32_t n, int64_t k);
+size_t pv_linear_fwd_f32_skinny_workspace_bytes(int32_t n);
+/* y[m,n] = relu?(x[m,k] w[n,k]^T + bias[n]) */
+int pv_linear_fwd_f32_skinny(const float* x, const float* w, const float* bias, float* y, int32_t m, int32_t n, int64_t k, int32_t relu,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* dx[m,k] = g[m,n] w[n,k] (g: the output gradient, already multiplied by the ReLU derivative) */
+int pv_linear_dx_f32_skinny(const float* g, const float* w, float* dx, int32_t m, int32_t n, int64_t k, void* stream);
+
 /* ---- fully connected head (F.linear; model.py:92-103,125-152) ------------ */
 /* y[M,N] = relu?(x[M,K] · w[N,K]^T + bias[N]); fp32, split-K with fp32 slab reduce.
  * workspace: pv_linear_workspace_bytes(M,N,K). */

@@ -120,6 +120,10 @@ SIGNATURES = {
     "pv_conv3d_fwd_f16_f32out": [c_vp, c_vp, c_vp, c_i32, _PCD, c_vp],
     "pv_conv3d_fwd_f16_f32out_covers": [_PCD],
     "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_linear_f32_skinny_covers": [c_i32, c_i32, c_i64],
+    "pv_linear_fwd_f32_skinny_workspace_bytes": [c_i32],
+    "pv_linear_fwd_f32_skinny": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_sz, c_vp],
+    "pv_linear_dx_f32_skinny": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_workspace_bytes": [c_i32, c_i32, c_i64, ctypes.POINTER(c_sz)],
     "pv_linear_fwd_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_int, c_vp, c_sz, c_vp],
     "pv_linear_bwd_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
@@ -190,6 +194,7 @@ SIGNATURES = {
     "pv_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_f64, c_f64, c_f64, c_f64, c_i32, c_f32, c_vp],
 }
 _RESTYPES = {"pv_last_error": ctypes.c_char_p, "pv_conv3d_packed_weight_elems": c_sz, "pv_conv3d_split2_weight_elems": c_sz,
+             "pv_linear_fwd_f32_skinny_workspace_bytes": c_sz,
              "pv_attention_bwd_workspace_floats": c_sz, "pv_colsum_workspace_floats": c_sz,
              "pv_attention_fwd_workspace_floats": c_sz}
 

@@ -37,7 +37,12 @@ class LinearF32(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x = x.contiguous()
-        y = K.linear_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, relu)
+        if (not exact_f32() and x.dtype == torch.float32 and weight.is_contiguous()
+                and K.linear_f32_skinny_covers(x.shape[0], weight.shape[0], x.shape[1])):
+            # fc1-sized: one stream over the weight, exact f32 products on the f32 matrix instruction
+            y = K.linear_fwd_f32_skinny(x, weight, bias.contiguous() if bias is not None else None, relu)
+        else:
+            y = K.linear_fwd_f32(x, weight.contiguous(), bias.contiguous() if bias is not None else None, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
         ctx.weight_param = weight
@@ -51,7 +56,12 @@ class LinearF32(torch.autograd.Function):
                 and x.shape[0] * x.shape[1] < 2 ** 31):
             # fc1-sized: the two products on the matrix cores at f32 accuracy (pv_gemm_f32), 650 us against 790 us
             g = K.relu_gate_f32(dy, y) if y is not None else dy.contiguous()
-            dx = K.gemm(g, weight) if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                if weight.is_contiguous() and K.linear_f32_skinny_covers(g.shape[0], g.shape[1], weight.shape[1]):
+                    dx = K.linear_dx_f32_skinny(g.contiguous(), weight)
+                else:
+                    dx = K.gemm(g, weight)
             owner = ctx.weight_param
             earlier = getattr(owner, "_pv_pending_f32", None)
             if (getattr(owner, "_pv_grad_mode", "autograd") == "fused" and getattr(owner, "_pv_takes_f32_pending", False)

@@ -558,6 +558,36 @@ def linear_fwd_f32(x, weight, bias, relu=False):
     return y
 
 
+LINEAR_F32_SKINNY = True      # fc1-sized f32 Linears (<= 32 rows, <= 128 outputs): forward / dx as streams over the weight (False: the split-product GEMM)
+
+
+def linear_f32_skinny_covers(m: int, n: int, k: int) -> bool:
+    return LINEAR_F32_SKINNY and bool(get_lib().pv_linear_f32_skinny_covers(m, n, k))
+
+
+def linear_fwd_f32_skinny(x, weight, bias, relu=False):
+    """y = relu?(x w^T + bias), f32, exact products: x [m <= 32, k], w [n <= 128, k] (linear_f32_skinny.hip)."""
+    require_cuda(x, weight, bias)
+    m, k = x.shape
+    n = weight.shape[0]
+    lib = get_lib()
+    ws = _workspace("linear_skinny", int(lib.pv_linear_fwd_f32_skinny_workspace_bytes(n)), x.device)
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.pv_linear_fwd_f32_skinny(ptr(x), ptr(weight), ptr(bias), ptr(y), m, n, k, int(relu), ptr(ws), ws.numel(),
+                                       current_stream_ptr()), "pv_linear_fwd_f32_skinny")
+    return y
+
+
+def linear_dx_f32_skinny(g, weight):
+    """dx = g w, f32, exact products: g [m <= 32, n <= 128], w [n, k]."""
+    require_cuda(g, weight)
+    m, n = g.shape
+    k = weight.shape[1]
+    dx = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    check(get_lib().pv_linear_dx_f32_skinny(ptr(g), ptr(weight), ptr(dx), m, n, k, current_stream_ptr()), "pv_linear_dx_f32_skinny")
+    return dx
+
+
 def linear_bwd_f32(x, weight, dy, y_mask, need_dx=True):
     require_cuda(x, weight, dy, y_mask)
     m, k = x.shape

@@ -456,6 +456,45 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 128, 1 << 18), (5, 64, 65536 + 128), (32, 100, 1 << 17), (1, 128, 1 << 16)])
+def test_f32_linear_as_streams_over_the_weight(device, m, n, k):
+    """csrc/linear_f32_skinny.hip: fc1-sized F.linear in float32 (<= 32 rows, <= 128 outputs) -- forward and input gradient with
+    exact f32 products on the f32 matrix instruction, one pass over the weight each -- against float64, and against the
+    split-product GEMM they replace (hip_ops.LINEAR_F32_SKINNY = False).  Bound: 2e-6 of the largest element at these k."""
+    K, _ = _mods()
+    from predict_pv_yield_amd import functional as Fn
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * 0.01
+    b = torch.randn(n, generator=g)
+    gy = torch.randn(m, n, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double(), b.double()
+    y_ref = F.relu(F.linear(xr, wr, br))
+    gy = gy * (y_ref.detach() > 1e-4 * float(y_ref.max())).float()      # (no gradient through pre-activations within rounding of zero)
+    (y_ref * gy.double()).sum().backward()
+
+    def run():
+        xd = x.to(device).requires_grad_(True)
+        wd, bd = w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+        y = Fn.linear_f32(xd, wd, bd, relu=True)
+        y.backward(gy.to(device))
+        return y.detach(), xd.grad, wd.grad
+
+    assert K.linear_f32_skinny_covers(m, n, k)
+    y, dx, dw = run()
+    K.LINEAR_F32_SKINNY = False
+    try:
+        y2, dx2, dw2 = run()
+    finally:
+        K.LINEAR_F32_SKINNY = True
+    for a, a2, ref, what in ((y, y2, y_ref.detach(), "y"), (dx, dx2, xr.grad, "dx")):
+        scale = float(ref.abs().max())
+        assert float((a.cpu().double() - ref).abs().max()) <= 2e-6 * scale, what
+        assert float((a2.cpu().double() - ref).abs().max()) <= 2e-6 * scale, what + " (GEMM)"
+        assert not torch.equal(a, a2), "the two arms are different kernels: identical bits mean the switch is dead"
+    assert torch.equal(dw, dw2)      # (the weight gradient is the same call in both arms)
+
+
 def _mask_bits(mask, y_shape):
     """int32 [B,T,hp,wp] relu mask -> bool [B,T,H,W,32]."""
     b, t, h, w, c = y_shape
