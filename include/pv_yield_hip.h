@@ -298,7 +298,8 @@ int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, f
  * relative (22-bit operands, f32 accumulation). */
 /* half-float elements of wp: four operators' fragments -- forward (h, l), data gradient (h, l) */
 size_t pv_conv3d_split2_weight_elems(void);
-/* w [c_out, c_in, 3,3,3] f32 -> wp; state: 3 device floats (bits of max |w|, s, 1 / s) */
+/* w [c_out, c_in, 3,3,3] f32 -> wp; state: 5 device floats (bits of max |w|, s, 1 / s, the largest absolute row sum of the
+ * forward operator and of the data-gradient operator) */
 int pv_conv3d_pack_weight_split2_f16(const float* w, uint16_t* wp, float* state, int32_t c_out, int32_t c_in, void* stream);
 /* x [B,T,H,W,32] half floats (one term), wp: ONE operator's fragments (elems / 4 of the above), y [B,To,Ho,Wo,32] f32 = the
  * raw accumulators (no bias, no activation, scaled by s_x s_w); y_is_f16 != 0: y is a HALF-FLOAT image of the accumulators times
@@ -308,12 +309,15 @@ int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, void* y, int
 /* 1 when pv_conv3d_fwd_f16_f32out takes these dims (else the caller keeps pv_conv3d_general_fwd_f32 / _bwd_data_f32) */
 int pv_conv3d_fwd_f16_f32out_covers(const pv_conv3d_dims* d);
 /* parts [3][B][vox][32] f32 -- or, p01_f16 != NULL: parts = p2 alone and p01_f16 = [2][B][vox][32] half floats (y_is_f16 above) --
- * -> y [B,32,vox] f32 = ((p0 + p1) + p2) * sx_state[2] * sw_state[2] + bias (NULL: none), then
- * relu != 0: max(y, 0); gate != NULL (f32, y's layout): y where gate > 0, else 0.  max_state != NULL: atomicMax of the bits of
- * |y| into max_state[0] (zeroed by the caller) -- the have_max input of the next pv_pack_split2.  vox_per_sample % 4 == 0. */
+ * -> y [B,32,vox] f32 = ((p0 + p1) + p2) * sx_state[2] * sw_state[2] + bias (NULL: none), then relu != 0: max(y, 0); gate_h != NULL
+ * (the h image of the gating activation, [B][vox][32] half floats): y where it is > 0, else 0.  max_state != NULL: atomicMax of the
+ * bits of |y| into max_state[0] (zeroed by the caller).  out_h / out_l != NULL: y's own two-term split ([B][vox][32] half floats
+ * each) with the scale s_y written to max_state[1], 1 / s_y to max_state[2]: s_y brings the bound max |x| (sx_state[0]) *
+ * sw_state[3 + data_gradient] + max |bias| below 2^14 -- known before the first element, so no split pass reads y again; y may
+ * then be NULL (a consumer that reads the images only).  vox_per_sample % 4 == 0. */
 int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, const float* sx_state, const float* sw_state,
-                               const float* bias, const float* gate, float* y, float* max_state, int32_t relu, int32_t batch,
-                               int64_t vox_per_sample, void* stream);
+                               int32_t data_gradient, const float* bias, const uint16_t* gate_h, float* y, uint16_t* out_h,
+                               uint16_t* out_l, float* max_state, int32_t relu, int32_t batch, int64_t vox_per_sample, void* stream);
 
 /* ---- fc1 of the f32 model as streams over the weight (linear_f32_skinny.hip) --------------------------------------------------
  * F.linear in float32 (predict_pv_yield/models/conv3d/model.py:92-103,125-130) for m <= 32 rows, n <= 128 outputs, k % 128 == 0,

@@ -119,7 +119,7 @@ SIGNATURES = {
     "pv_conv3d_pack_weight_split2_f16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
     "pv_conv3d_fwd_f16_f32out": [c_vp, c_vp, c_vp, c_i32, _PCD, c_vp],
     "pv_conv3d_fwd_f16_f32out_covers": [_PCD],
-    "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
+    "pv_sum3_ndhwc_to_ncdhw_f32": [c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp],
     "pv_linear_f32_skinny_covers": [c_i32, c_i32, c_i64],
     "pv_linear_fwd_f32_skinny_workspace_bytes": [c_i32],
     "pv_linear_fwd_f32_skinny": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_sz, c_vp],

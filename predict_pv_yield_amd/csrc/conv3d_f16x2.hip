@@ -32,7 +32,7 @@ __device__ __forceinline__ float f2_scale_of(uint32_t maxbits) {      // = split
 }
 
 // w [32,32,27] f32 -> four fragment images [27][2 cout halves][64 lanes][8] half floats: forward operator (h, l), dgrad operator
-// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s).  Every workgroup finds the maximum of the 27 648 weights
+// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s, L1 bound forward, L1 bound data gradient).  Every workgroup finds the maximum of the 27 648 weights
 // for itself (110 KB from L2; one workgroup doing everything took 34 us) and packs its share of the fragments.
 __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp,
                                                                       float* __restrict__ state, int c_out, int c_in) {
@@ -52,6 +52,28 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
     state[0] = __builtin_bit_cast(float, m);
     state[1] = s;
     state[2] = 1.f / s;
+  }
+  // state[3], state[4]: the largest absolute row sum of the forward / the data-gradient operator (sum over what an output element
+  // contracts): |y| <= max |x| state[3] + max |bias| bounds an output before it exists -- the scale of ITS split (sum pass below).
+  // Block 0, one thread per row, sequential sums: the same bits every time.
+  if (blockIdx.x == 0) {
+    __shared__ float l1[64];
+    if (threadIdx.x < 64) {
+      const int r = threadIdx.x & 31, back = threadIdx.x >> 5;
+      float acc = 0.f;
+      if (!back) {
+        if (r < c_out) for (int i = 0; i < c_in * 27; ++i) acc += fabsf(w[(size_t)r * c_in * 27 + i]);
+      } else {
+        if (r < c_in) for (int co = 0; co < c_out; ++co) for (int tp = 0; tp < 27; ++tp) acc += fabsf(w[((size_t)co * c_in + r) * 27 + tp]);
+      }
+      l1[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      float mx = 0.f;
+      for (int i = 0; i < 32; ++i) mx = fmaxf(mx, l1[32 * threadIdx.x + i]);
+      state[3 + threadIdx.x] = mx;
+    }
   }
   for (int i = blockIdx.x * 1024 + threadIdx.x; i < 2 * F2_WFRAG; i += gridDim.x * 1024) {
     const int flip = i >= F2_WFRAG, e = flip ? i - F2_WFRAG : i;
@@ -78,21 +100,41 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
 // A wave owns tiles of 32 voxels x 32 channels: 16-byte reads along the channels, an LDS transpose, 16-byte writes along the voxels.
 // P01_F16: the two small partial products are half-float images scaled by 2^-12 (conv3d_bf16_v3.hip OUTM 2): parts = p2 alone, p01 =
 // [2][B][vox][32] half floats
-template <bool P01_F16>
+// PLANES: the pass also writes y's OWN two-term split (out_h, out_l: NDHWC half-float images, the layout the partial products
+// came in) for the next layer's launches, so that no split pass reads y again.  Its scale must be known before the first
+// element: s_y = the power of two that brings a BOUND of |y| below 2^14 -- max |x| (sx[0]) times the operator's largest absolute
+// row sum (*l1) plus max |bias| -- an upper bound by the triangle inequality, ~2^7 above the largest |y| on these layers; half
+// floats have the range to spare (absolute error of an element <= 2^-32 of the largest).  out_state = (bits of max |y| by
+// atomicMax -- zeroed by the caller --, s_y, 1 / s_y).  gate_h: the gating activation's h image (NDHWC): y where it is > 0.
+template <bool P01_F16, bool PLANES>
 __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* __restrict__ parts, size_t part_stride,
                                                                    const uint16_t* __restrict__ p01,
                                                                    const float* __restrict__ sx, const float* __restrict__ sw,
-                                                                   const float* __restrict__ bias, const float* __restrict__ gate,
-                                                                   float* __restrict__ y, uint32_t* __restrict__ max_state, int relu,
+                                                                   const float* __restrict__ l1,
+                                                                   const float* __restrict__ bias, const uint16_t* __restrict__ gate_h,
+                                                                   float* __restrict__ y, uint16_t* __restrict__ out_h,
+                                                                   uint16_t* __restrict__ out_l, uint32_t* __restrict__ max_state, int relu,
                                                                    long long vps, long long tiles_per_sample, long long total_tiles) {
   __shared__ float tile[4][32 * 33];
   __shared__ uint32_t wave_max[4];
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* t = tile[wave];
   const float unscale = sx[2] * sw[2];
   const int rq = lane & 7, rv = lane >> 3;      // read: 4 channels 4 rq .. of voxel 8 i + rv;  write: 4 voxels 4 rq .. of channel 8 i + rv
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
   if (bias) b4 = *reinterpret_cast<const f32x4*>(bias + 4 * rq);
+  float s_y = 1.f;
+  if constexpr (PLANES) {
+    float bmax = 0.f;
+    if (bias) for (int i = 0; i < 32; ++i) bmax = fmaxf(bmax, fabsf(bias[i]));
+    const float bound = __builtin_bit_cast(float, reinterpret_cast<const uint32_t*>(sx)[0]) * l1[0] * 1.01f + bmax;
+    s_y = f2_scale_of(__builtin_bit_cast(uint32_t, bound));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      reinterpret_cast<float*>(max_state)[1] = s_y;
+      reinterpret_cast<float*>(max_state)[2] = 1.f / s_y;
+    }
+  }
   uint32_t m = 0;
   for (long long tl = (long long)blockIdx.x * 4 + wave; tl < total_tiles; tl += (long long)gridDim.x * 4) {
     const long long bi = tl / tiles_per_sample;
@@ -104,7 +146,6 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
       const bool ok = v < vps;
       const size_t off = ((size_t)(bi * vps + (ok ? v : 0)) * 32) + 4 * rq;
       if constexpr (P01_F16) {
-        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
         a[i][2] = ok ? *reinterpret_cast<const f32x4*>(parts + off) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -120,9 +161,39 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const long long v = v0 + 8 * i + rv;
+      const bool ok = v < vps;
+      f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) t[(8 * i + rv) * 33 + 4 * rq + j] = __fadd_rn(__fmul_rn(__fadd_rn(__fadd_rn(a[i][0][j], a[i][1][j]), a[i][2][j]), unscale), b4[j]);
+      for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(__fadd_rn(__fadd_rn(a[i][0][j], a[i][1][j]), a[i][2][j]), unscale), b4[j]);
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
+      }
+      const size_t voff = ((size_t)(bi * vps + (ok ? v : 0)) * 32) + 4 * rq;
+      if (gate_h) {
+        f16x4_t gv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (ok) gv = *reinterpret_cast<const f16x4_t*>(gate_h + voff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gv[j] > (_Float16)0.f ? o[j] : 0.f;
+      }
+      if (ok) {
+        const u32x4 ob = __builtin_bit_cast(u32x4, o);
+        m = max(max(m, ob[0] & 0x7fffffffu), max(max(ob[1] & 0x7fffffffu, ob[2] & 0x7fffffffu), ob[3] & 0x7fffffffu));
+        if constexpr (PLANES) {
+          const f32x4 f = o * s_y;
+          const f16x4_t hh = __builtin_convertvector(f, f16x4_t);
+          const f16x4_t ll = __builtin_convertvector(f - __builtin_convertvector(hh, f32x4), f16x4_t);
+          *reinterpret_cast<f16x4_t*>(out_h + voff) = hh;
+          *reinterpret_cast<f16x4_t*>(out_l + voff) = ll;
+        }
+      }
+      if (y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[(8 * i + rv) * 33 + 4 * rq + j] = o[j];
+      }
     }
+    if (!y) continue;      // (the consumer reads the operand images: no f32 tensor, no transpose)
     __builtin_amdgcn_wave_barrier();      // (a wave's LDS operations execute in order: its own writes are visible to its reads)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -133,19 +204,6 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = t[(4 * rq + j) * 33 + ch];
         const size_t off = (size_t)(bi * 32 + ch) * vps + v;
-        if (gate) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(gate + off);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = g[j] > 0.f ? o[j] : 0.f;
-        }
-        if (relu) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
-        }
-        {
-          const u32x4 ob = __builtin_bit_cast(u32x4, o);
-          m = max(max(m, ob[0] & 0x7fffffffu), max(max(ob[1] & 0x7fffffffu, ob[2] & 0x7fffffffu), ob[3] & 0x7fffffffu));
-        }
         *reinterpret_cast<f32x4*>(y + off) = o;
       }
     }
@@ -204,23 +262,29 @@ int pv_conv3d_fwd_f16_f32out(const uint16_t* x, const uint16_t* wp, void* y, int
 }
 
 int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, const float* sx_state, const float* sw_state,
-                               const float* bias, const float* gate, float* y, float* max_state, int32_t relu, int32_t batch,
-                               int64_t vox_per_sample, void* stream) {
-  PV_REQUIRE(parts && sx_state && sw_state && y, PV_EINVAL, "pv_sum3_ndhwc_to_ncdhw_f32: null pointer");
+                               int32_t data_gradient, const float* bias, const uint16_t* gate_h, float* y, uint16_t* out_h,
+                               uint16_t* out_l, float* max_state, int32_t relu, int32_t batch, int64_t vox_per_sample, void* stream) {
+  PV_REQUIRE(parts && sx_state && sw_state && (y || out_h), PV_EINVAL, "pv_sum3_ndhwc_to_ncdhw_f32: null pointer");
+  PV_REQUIRE((out_h != nullptr) == (out_l != nullptr) && (!out_h || max_state), PV_EINVAL,
+             "pv_sum3_ndhwc_to_ncdhw_f32: out_h, out_l and max_state come together");
   PV_REQUIRE(batch > 0 && vox_per_sample > 0 && vox_per_sample % 4 == 0, PV_ESIZE,
              "pv_sum3_ndhwc_to_ncdhw_f32: voxels per sample must be a positive multiple of 4");
-  PV_REQUIRE((((uintptr_t)parts | (uintptr_t)y | (uintptr_t)gate | (uintptr_t)bias | (uintptr_t)p01_f16) & 15) == 0, PV_EINVAL,
+  PV_REQUIRE((((uintptr_t)parts | (uintptr_t)y | (uintptr_t)gate_h | (uintptr_t)bias | (uintptr_t)p01_f16 | (uintptr_t)out_h |
+               (uintptr_t)out_l) & 15) == 0, PV_EINVAL,
              "pv_sum3_ndhwc_to_ncdhw_f32: 16-byte aligned tensors");
   const long long tps = (vox_per_sample + 31) / 32, total = tps * batch;
   const unsigned grid = (unsigned)std::min<long long>((total + 3) / 4, (long long)kNumCU * 8);
-  if (p01_f16)
-    hipLaunchKernelGGL(sum3_ndhwc_to_ncdhw_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), parts,
-                       (size_t)batch * vox_per_sample * 32, p01_f16, sx_state, sw_state, bias, gate, y,
-                       reinterpret_cast<uint32_t*>(max_state), relu ? 1 : 0, (long long)vox_per_sample, tps, total);
-  else
-    hipLaunchKernelGGL(sum3_ndhwc_to_ncdhw_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), parts,
-                       (size_t)batch * vox_per_sample * 32, (const uint16_t*)nullptr, sx_state, sw_state, bias, gate, y,
-                       reinterpret_cast<uint32_t*>(max_state), relu ? 1 : 0, (long long)vox_per_sample, tps, total);
+  const float* l1 = sw_state + (data_gradient ? 4 : 3);
+#define PV_LAUNCH_SUM3(F16P, PL)                                                                                              \
+  hipLaunchKernelGGL((sum3_ndhwc_to_ncdhw_kernel<F16P, PL>), dim3(grid), dim3(256), 0, as_stream(stream), parts,               \
+                     (size_t)batch * vox_per_sample * 32, p01_f16, sx_state, sw_state, l1, bias, gate_h, y, out_h, out_l,     \
+                     reinterpret_cast<uint32_t*>(max_state), relu ? 1 : 0, (long long)vox_per_sample, tps, total)
+  if (p01_f16) {
+    if (out_h) PV_LAUNCH_SUM3(true, true); else PV_LAUNCH_SUM3(true, false);
+  } else {
+    if (out_h) PV_LAUNCH_SUM3(false, true); else PV_LAUNCH_SUM3(false, false);
+  }
+#undef PV_LAUNCH_SUM3
   return check_launch("pv_sum3_ndhwc_to_ncdhw_f32");
 }
 

@@ -373,75 +373,123 @@ def _wgrad_on_bf16x3(x, dy, y, weight, stride) -> bool:
 F32_CONV_ON_F16X2 = True        # 32 -> 32 channel 3x3x3 layers of the f32 model: forward / dgrad as three half-float launches (False: f32 matrix instruction)
 
 
-def _conv_on_f16x2(x, weight, stride, padding) -> bool:
-    """The f32 model's 32 -> 32 channel 3x3x3 stride-1 layers at a size worth three launches + a sum pass, inside the
-    input-stationary kernel's limits (hip_ops.conv3d_f16x2_covers) for the forward AND the data gradient (pad = 2 - pad)."""
+def conv_f16x2_takes(batch, c_in, t, h, w, weight, stride, padding, x_requires_grad=True) -> bool:
+    """Does the half-float form of the f32 Conv3d (Conv3dF32OnF16x2) take a layer of this geometry?  3x3x3, stride 1, 32 output
+    channels, <= 32 input channels, a size worth three launches + a sum pass, inside the input-stationary kernel's limits
+    (hip_ops.conv3d_f16x2_covers) for the forward AND the data gradient (pad = 2 - pad)."""
     if not F32_CONV_ON_F16X2 or exact_f32() or weight.dim() != 5 or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
         return False
     p = _triple(padding)
-    if weight.shape[0] != 32 or weight.shape[1] > 32 or any(q < 0 or q > 2 for q in p) or x.dim() != 5 or x.shape[1] != weight.shape[1]:
+    if weight.shape[0] != 32 or weight.shape[1] > 32 or any(q < 0 or q > 2 for q in p) or c_in != weight.shape[1]:
         return False
-    if weight.shape[1] < 32 and x.requires_grad:      # (the first layer: its operand image is padded to 32 channels, its dx is not formed)
+    if weight.shape[1] < 32 and x_requires_grad:      # (the first layer: its operand image is padded to 32 channels, its dx is not formed)
         return False
-    b, _, t, h, w = x.shape
     to, ho, wo = t + 2 * p[0] - 2, h + 2 * p[1] - 2, w + 2 * p[2] - 2
-    if min(to, ho, wo) <= 0 or (t * h * w) % 4 or (to * ho * wo) % 4 or b * to * ho * wo < (1 << 16):
+    if min(to, ho, wo) <= 0 or (t * h * w) % 4 or (to * ho * wo) % 4 or batch * to * ho * wo < (1 << 16):
         return False
-    return (K.conv3d_f16x2_covers(b, 32, 32, t, h, w, p) and
-            K.conv3d_f16x2_covers(b, 32, 32, to, ho, wo, tuple(2 - q for q in p)))
+    return (K.conv3d_f16x2_covers(batch, 32, 32, t, h, w, p) and
+            K.conv3d_f16x2_covers(batch, 32, 32, to, ho, wo, tuple(2 - q for q in p)))
 
 
-def _register_gated_max(t: torch.Tensor, state) -> None:
-    """The largest magnitude of a gradient tensor, for the two-term split of its consumer (keyed by storage, valid inside this
-    backward pass; see ReluGateF32.backward)."""
+def is_operand_images(x) -> bool:
+    """A chained f16x2 conv's output: the two half-float operand images [2, B, T, H, W, 32] with their scale state attached."""
+    return x.dtype == torch.float16 and x.dim() == 6 and x.shape[0] == 2 and x.shape[5] == 32 and hasattr(x, "_pv_state")
+
+
+def _conv_on_f16x2(x, weight, stride, padding) -> bool:
+    if is_operand_images(x):
+        return conv_f16x2_takes(x.shape[1], 32, x.shape[2], x.shape[3], x.shape[4], weight, stride, padding)
+    if x.dim() != 5 or x.dtype != torch.float32:
+        return False
+    return conv_f16x2_takes(x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4], weight, stride, padding, x.requires_grad)
+
+
+def _register_gated(t: torch.Tensor, registry: dict, value) -> None:
+    """Something a gradient tensor's producer leaves for its consumer -- the largest magnitude (_GATED_MAX) or the finished
+    operand images (_GATED_PLANES) of the two-term split -- keyed by storage, valid inside this backward pass (see
+    ReluGateF32.backward)."""
     task = torch._C._current_graph_task_id()
     if _GATED_MAX_TASK[0] != task:
         _GATED_MAX.clear()
+        _GATED_PLANES.clear()
         _GATED_MAX_TASK[0] = task
-    _GATED_MAX[(t.data_ptr(), t.numel())] = state
+    registry[(t.data_ptr(), t.numel())] = value
+
+
+def _gated_planes_of(t: torch.Tensor):
+    if _GATED_MAX_TASK[0] != torch._C._current_graph_task_id():
+        return None
+    return _GATED_PLANES.pop((t.data_ptr(), t.numel()), None)
 
 
 class Conv3dF32OnF16x2(torch.autograd.Function):
-    """nn.Conv3d(32, 32, 3) + optional ReLU in float32 (reference: models/conv3d/model.py:80-90,113-120) with every product on
-    the half-float matrix cores at f32 accuracy (csrc/conv3d_f16x2.hip): x and w split in two half-float terms, three launches
-    per pass, one ordered-sum pass.  The operand images of x made here serve the weight gradient, those of dy made in backward
-    serve both gradients; each sum pass leaves the largest magnitude of its output for the next split.
+    """nn.Conv3d(c_in <= 32, 32, 3) + optional ReLU in float32 (reference: models/conv3d/model.py:80-90,113-120) with every
+    product on the half-float matrix cores at f32 accuracy (csrc/conv3d_f16x2.hip): x and w split in two half-float terms, three
+    launches per pass, one ordered-sum pass that also writes its output's OWN split.
+    x: a float32 [B,C,T,H,W] tensor (split here) or the operand images of a chained producer (is_operand_images).
+    chain_out: the consumer is another layer of this kind -- the output IS the pair of operand images (f16 [2,B,To,Ho,Wo,32],
+    scale state attached by the wrapper), no float32 tensor is written; its gradient arrives in the same form (exactly one
+    consumer).  The operand images of x serve the weight gradient, those of dy both gradients.
     x_is_relu_output / dy_pregated as in Conv3dGeneralF32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, padding, relu, x_is_relu_output, dy_pregated):
-        x = x.contiguous()
+    def forward(ctx, x, weight, bias, padding, relu, x_is_relu_output, dy_pregated, chain_out):
         p = _triple(padding)
-        xh, xl, xs = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, maxabs_state=getattr(x, "_pv_maxabs", None), cpad32=True)
+        ctx.x_is_images = is_operand_images(x)
+        if ctx.x_is_images:
+            xh, xl, xs = x[0], x[1], x._pv_state
+        else:
+            x = x.contiguous()
+            planes = getattr(x, "_pv_planes", None)      # (xh, xl, state) left by the sum pass that produced x
+            if planes is None or planes[0].shape[:4] != (x.shape[0],) + tuple(x.shape[2:]):
+                planes = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, cpad32=True)
+            xh, xl, xs = planes
         wp, ws = K.conv3d_pack_weight_split2_f16(weight.contiguous())
-        y, ymax = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
-                                        relu=relu, want_max=True)
-        ctx.save_for_backward(x if x_is_relu_output else None, y if (relu and not dy_pregated) else None, xh, xl, xs, wp, ws)
-        ctx.padding, ctx.has_bias, ctx.c_in = p, bias is not None, weight.shape[1]
-        _FWD_MAX[0] = (y.data_ptr(), ymax)
+        y, ys, yp = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
+                                          relu=relu, want_f32=not chain_out)
+        ctx.save_for_backward(y if (relu and not dy_pregated) else None, xh, xl, xs, wp, ws)
+        ctx.padding, ctx.has_bias, ctx.c_in, ctx.gate_dx, ctx.chain_out = p, bias is not None, weight.shape[1], x_is_relu_output, chain_out
+        if chain_out:
+            _FWD_PLANES[0] = (yp.data_ptr(), ys)
+            return yp
+        _FWD_PLANES[0] = (y.data_ptr(), (yp[0], yp[1], ys))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_gate, y, xh, xl, xs, wp, ws = ctx.saved_tensors
+        y, xh, xl, xs, wp, ws = ctx.saved_tensors
         dy = dy.contiguous()
-        if y is not None:
+        planes = None
+        if ctx.chain_out:
+            planes = _gated_planes_of(dy)
+            if planes is None:
+                raise RuntimeError("Conv3dF32OnF16x2: the gradient of a chained output (operand images) must come from exactly one "
+                                   "Conv3dF32OnF16x2 consumer's backward; build the layer with chain_out=False for any other use")
+        elif y is not None:
             dy, dmax = K.relu_gate_f32(dy, y, want_max=True)
         else:
-            dmax = _gated_max_of(dy)
-        dh, dl, ds = K.pack_split2_ncdhw_f32_to_ndhwc_f16(dy, maxabs_state=dmax)
+            planes = _gated_planes_of(dy)
+            dmax = None if planes is not None else _gated_max_of(dy)
+        if planes is None:
+            planes = K.pack_split2_ncdhw_f32_to_ndhwc_f16(dy, maxabs_state=dmax)
+        dh, dl, ds = planes
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, dxmax = K.conv3d_f32_on_f16x2(dh, dl, ds, wp[2], wp[3], ws, 32, 32, tuple(2 - q for q in ctx.padding), gate=x_gate,
-                                              want_max=True)
-            _register_gated_max(dx, dxmax)
+            # (the gate: x > 0 read off x's h image -- rne_f16(x s) > 0 exactly when x > 2^-25 / s, i.e. for every x a ReLU produced
+            # above 2^-39 of the tensor's largest value)
+            dx, dxs, dxp = K.conv3d_f32_on_f16x2(dh, dl, ds, wp[2], wp[3], ws, 32, 32, tuple(2 - q for q in ctx.padding),
+                                                 gate_h=xh if ctx.gate_dx else None, data_gradient=True, want_f32=not ctx.x_is_images)
+            if ctx.x_is_images:
+                dx = dxp
+            _register_gated(dx, _GATED_PLANES, (dxp[0], dxp[1], dxs))
         dw, db = K.conv3d_bwd_weight_f32_from_split2(xh, xl, xs, dh, dl, ds, 32, ctx.padding)
         if ctx.c_in < 32:
             dw = dw[:, :ctx.c_in].contiguous()      # (the padded channels' gradient is zero)
-        return dx, dw, (db if ctx.has_bias else None), None, None, None, None
+        return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
 
 
-_FWD_MAX = [None]      # (data_ptr of the newest f16x2 forward's output, its max-magnitude state): attached to the tensor by the wrapper
+_FWD_PLANES = [None]      # (data_ptr of the newest f16x2 forward's output, its operand images + state): attached to the tensor by the wrapper
+_GATED_PLANES = {}
 
 
 class Conv3dGeneralF32(torch.autograd.Function):
@@ -507,11 +555,7 @@ class ReluGateF32(torch.autograd.Function):
         g, state = K.relu_gate_f32(dy, y, want_max=True)
         # the gated gradient's largest magnitude, for the two-term split of the producing layer's weight gradient (keyed by the
         # tensor's storage like _PREGATED_DX, valid inside this backward pass)
-        task = torch._C._current_graph_task_id()
-        if _GATED_MAX_TASK[0] != task:
-            _GATED_MAX.clear()
-            _GATED_MAX_TASK[0] = task
-        _GATED_MAX[(g.data_ptr(), g.numel())] = state
+        _register_gated(g, _GATED_MAX, state)
         return g
 
 
@@ -519,14 +563,23 @@ def relu_gate_f32(y):
     return ReluGateF32.apply(y)
 
 
-def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_relu_output=False, dy_pregated=False):
-    if x.is_cuda and x.dtype == torch.float32 and _conv_on_f16x2(x, weight, stride, padding):
-        y = Conv3dF32OnF16x2.apply(x, weight, bias, padding, relu, x_is_relu_output, dy_pregated)
-        # the sum pass's largest |y| travels with the tensor object: the next layer's split skips its maximum pass
-        tag, _FWD_MAX[0] = _FWD_MAX[0], None
+def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_relu_output=False, dy_pregated=False, chain_out=False):
+    """chain_out: the ONE consumer of the result is another conv3d_general_f32 that the half-float form takes (conv_f16x2_takes):
+    the result may then be the pair of operand images (is_operand_images) instead of a float32 tensor."""
+    if x.is_cuda and _conv_on_f16x2(x, weight, stride, padding):
+        chain = bool(chain_out) and (dy_pregated or not relu)
+        y = Conv3dF32OnF16x2.apply(x, weight, bias, padding, relu, x_is_relu_output, dy_pregated, chain)
+        # the sum pass's split of y travels with the tensor object: the next layer reads it instead of splitting y again
+        tag, _FWD_PLANES[0] = _FWD_PLANES[0], None
         if tag is not None and tag[0] == y.data_ptr():
-            y._pv_maxabs = tag[1]
+            if chain:
+                y._pv_state = tag[1]
+            else:
+                y._pv_planes = tag[1]
         return y
+    if is_operand_images(x):
+        raise RuntimeError("conv3d_general_f32: operand images (a chained half-float conv's output) reached a layer the half-float "
+                           "form does not take; the producer must be called with chain_out=False")
     return Conv3dGeneralF32.apply(x, weight, bias, stride, padding, relu, x_is_relu_output, dy_pregated)
 
 

@@ -369,7 +369,7 @@ def conv3d_pack_weight_split2_f16(w: torch.Tensor):
     lib = get_lib()
     n = int(lib.pv_conv3d_split2_weight_elems())
     wp = torch.empty((4, n // 4), dtype=torch.float16, device=w.device)
-    state = torch.empty(3, dtype=torch.float32, device=w.device)
+    state = torch.empty(5, dtype=torch.float32, device=w.device)
     check(lib.pv_conv3d_pack_weight_split2_f16(ptr(w), ptr(wp), ptr(state), w.shape[0], w.shape[1], current_stream_ptr()),
           "pv_conv3d_pack_weight_split2_f16")
     return wp, state
@@ -384,11 +384,16 @@ def conv3d_f16x2_covers(batch, c_in, c_out, t, h, w, padding) -> bool:
     return bool(get_lib().pv_conv3d_fwd_f16_f32out_covers(ctypes.byref(d)))
 
 
-def conv3d_f32_on_f16x2(xh, xl, xs, wp_h, wp_l, ws, c_in: int, c_out: int, padding=(0, 0, 0), bias=None, relu=False, gate=None,
-                        want_max=False):
+def conv3d_f32_on_f16x2(xh, xl, xs, wp_h, wp_l, ws, c_in: int, c_out: int, padding=(0, 0, 0), bias=None, relu=False, gate_h=None,
+                        data_gradient=False, want_planes=True, want_f32=True):
     """One f32 Conv3d (3x3x3, stride 1, 32 output channels of the OPERATOR) from split operand images: xh / xl f16 [B,T,H,W,32]
-    with scale state xs, wp_h / wp_l ONE operator's fragments with state ws.  Three matrix-core launches into f32 partial tensors,
-    then one pass: ordered sum, un-scale, bias, ReLU / gate (f32 [B,32,To,Ho,Wo]), NCDHW.  -> (y f32 [B,32,To,Ho,Wo], max_state or None)."""
+    with scale state xs, wp_h / wp_l ONE operator's fragments with state ws (data_gradient: the transposed-flipped operator's).
+    Three matrix-core launches into partial tensors, then one pass: ordered sum, un-scale, bias, ReLU / gate (gate_h: the h image
+    [B,To,Ho,Wo,32] of the gating activation), NCDHW -- and, want_planes, y's own split for the next layer.
+    want_f32=False: only the split is written (a consumer that reads operand images).
+    -> (y f32 [B,32,To,Ho,Wo] or None, state f32[3] = (bits of max |y|, s_y, 1 / s_y), planes f16 [2,B,To,Ho,Wo,32] or None)."""
+    if not (want_planes or want_f32):
+        raise ValueError("conv3d_f32_on_f16x2: nothing to write")
     require_cuda(xh, xl)
     b, t, h, w, cpad = xh.shape
     if cpad != 32:
@@ -407,11 +412,13 @@ def conv3d_f32_on_f16x2(xh, xl, xs, wp_h, wp_l, ws, c_in: int, c_out: int, paddi
         outs = ((parts[0], 0), (parts[1], 0), (parts[2], 0))
     for (px, pw), (out, is16) in zip(((xl, wp_h), (xh, wp_l), (xh, wp_h)), outs):
         check(lib.pv_conv3d_fwd_f16_f32out(ptr(px), ptr(pw), ptr(out), is16, ctypes.byref(d), st), "pv_conv3d_fwd_f16_f32out")
-    y = torch.empty((b, 32, to, ho, wo), dtype=torch.float32, device=xh.device)
-    state = torch.zeros(3, dtype=torch.float32, device=xh.device) if want_max else None
-    check(lib.pv_sum3_ndhwc_to_ncdhw_f32(ptr(parts), ptr(p01), ptr(xs), ptr(ws), ptr(bias), ptr(gate), ptr(y), ptr(state),
-                                         int(bool(relu)), b, to * ho * wo, st), "pv_sum3_ndhwc_to_ncdhw_f32")
-    return y, state
+    y = torch.empty((b, 32, to, ho, wo), dtype=torch.float32, device=xh.device) if want_f32 else None
+    state = torch.zeros(3, dtype=torch.float32, device=xh.device)
+    planes = torch.empty((2, b, to, ho, wo, 32), dtype=torch.float16, device=xh.device) if want_planes else None
+    check(lib.pv_sum3_ndhwc_to_ncdhw_f32(ptr(parts), ptr(p01), ptr(xs), ptr(ws), int(bool(data_gradient)), ptr(bias), ptr(gate_h),
+                                         ptr(y), ptr(planes[0]) if want_planes else None, ptr(planes[1]) if want_planes else None,
+                                         ptr(state), int(bool(relu)), b, to * ho * wo, st), "pv_sum3_ndhwc_to_ncdhw_f32")
+    return y, state, planes
 
 
 def unpack_ndhwc_bf16_to_ncdhw_f32(xp: torch.Tensor, c: int) -> torch.Tensor:

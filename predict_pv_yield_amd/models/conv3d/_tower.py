@@ -78,8 +78,18 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
     # gate of fc1's input gradient (sizes that are no multiple of 4: the last layer gates while it stages, on the tiled kernel)
     gate_last = (batch_size * flat_features) % 4 == 0
     for i, layer in enumerate(convs):
+        # a layer whose consumer is another layer of the half-float form hands over its operand images, not a float32 tensor
+        chain = False
+        if i + 1 < n:
+            if Fn.is_operand_images(out):
+                geo = (out.shape[1], 32) + tuple(out.shape[2:5])
+            else:
+                geo = (out.shape[0], out.shape[1]) + tuple(out.shape[2:])
+            if Fn.conv_f16x2_takes(*geo, layer.weight, (1, 1, 1), padding, out.requires_grad):
+                nxt = (geo[0], 32) + tuple(d + 2 * q - 2 for d, q in zip(geo[2:], Fn._triple(padding)))
+                chain = Fn.conv_f16x2_takes(*nxt, convs[i + 1].weight, (1, 1, 1), padding)
         out = Fn.conv3d_general_f32(out, layer.weight, layer.bias, stride=(1, 1, 1), padding=tuple(padding), relu=True,
-                                    x_is_relu_output=i > 0, dy_pregated=(i + 1 < n) or gate_last)
+                                    x_is_relu_output=i > 0, dy_pregated=(i + 1 < n) or gate_last, chain_out=chain)
     if gate_last:
         out = Fn.relu_gate_f32(out)
     out = out.reshape(batch_size, flat_features)

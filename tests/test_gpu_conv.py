@@ -388,7 +388,7 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     the input-stationary kernel in its half-float form (f32 accumulators out) + one ordered-sum pass -- against float64 on the
     CPU: forward (+ bias, ReLU), data gradient (+ the producer's ReLU gate), weight and bias gradient from the same operand
     images.  Bound: 4e-6 of the largest element (22-bit operands, f32 accumulation over 864 terms; the f32 kernels sit at
-    1-2e-6 on the same data, the bf16 path at 1e-2).  The sum passes' maxima equal the tensors' own."""
+    1-2e-6 on the same data, the bf16 path at 1e-2).  The sum pass's own split of y reconstructs it to 2^-21 of its largest element."""
     K, _ = _mods()
     from predict_pv_yield_amd import functional as Fn
     b, c, t, h, w = shape
@@ -415,7 +415,14 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     assert Fn._conv_on_f16x2(xd, wd, (1, 1, 1), pad)
     y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=not first, dy_pregated=False)
     assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("Conv3dF32OnF16x2")
-    assert y._pv_maxabs[0:1].view(torch.int32).item() == y.detach().abs().max().view(torch.int32).item()
+    # the sum pass leaves y's own two-term split for the next layer (scale from a bound of |y| known beforehand), and y's maximum
+    yh, yl, ys = y._pv_planes
+    assert ys[0:1].view(torch.int32).item() == y.detach().abs().max().view(torch.int32).item()
+    s_y = float(ys[1])
+    assert s_y * float(ys[2]) == 1.0 and np.log2(s_y) == round(np.log2(s_y)) and float(y.detach().abs().max()) * s_y < 2.0 ** 14
+    rec = ((yh.double() + yl.double()) * float(ys[2])).permute(0, 4, 1, 2, 3)
+    assert float((rec - y.detach().double()).abs().max()) <= 2.0 ** -21 * float(y.detach().abs().max())
+    assert float(y.detach().abs().max()) * s_y >= 2.0 ** 3, "the bound is more than 2^11 above the largest element: the split loses bits"
     y.backward(gy.to(device))
 
     def close(a, ref, what):
@@ -454,6 +461,73 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     if not first:
         close(x2.grad, dx_ref, "dx (f32 kernels)")
     assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
+
+
+def test_f32_conv_layers_chained_through_their_operand_images(device):
+    """Three Conv3d(32, 32, 3) + ReLU in float32, the first two called with chain_out=True: what travels between them forward
+    (and backward) is the pair of half-float operand images the producing sum pass wrote -- no float32 activation, no split
+    pass -- and every result has the bits of the unchained call's (whose layers find the same images attached to the float32
+    tensors); both sit at the single layer's bound against float64 wherever no inner ReLU flips."""
+    K, _ = _mods()
+    from predict_pv_yield_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    shape = (8, 32, 10, 52, 52)      # 160 000, 110 592 and 67 712 output voxels: every layer is worth the three launches
+    x = torch.randn(shape, generator=g).abs()
+    x[torch.rand(shape, generator=g) < 0.3] = 0.0
+    ws = [torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05 for _ in range(3)]
+    bs = [torch.randn(32, generator=g) * 0.1 for _ in range(3)]
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    h = xr
+    pre = []
+    for w, b in zip(wr, br):
+        h = F.relu(F.conv3d(h, w, b))
+        pre.append(h)
+    gy = torch.randn(h.shape, generator=g) * 1e-3
+    gy = gy * (h.detach() > 1e-4 * float(h.max())).float()
+    (h * gy.double()).sum().backward()
+
+    def run(chain):
+        xd = x.to(device).requires_grad_(True)
+        wd = [w.to(device).requires_grad_(True) for w in ws]
+        bd = [b.to(device).requires_grad_(True) for b in bs]
+        out = xd
+        kinds = []
+        for i in range(3):
+            out = Fn.conv3d_general_f32(out, wd[i], bd[i], stride=(1, 1, 1), padding=(0, 0, 0), relu=True, x_is_relu_output=True,
+                                        dy_pregated=i < 2, chain_out=chain and i < 2)
+            kinds.append(Fn.is_operand_images(out))
+        out = Fn.relu_gate_f32(out)      # (the last layer's ReLU derivative, as the model's tower applies it)
+        out.backward(gy.to(device))
+        return out.detach(), xd.grad, [w.grad for w in wd], [b.grad for b in bd], kinds
+
+    y_c, dx_c, dw_c, db_c, kinds_c = run(True)
+    y_u, dx_u, dw_u, db_u, kinds_u = run(False)
+    assert kinds_c == [True, True, False] and kinds_u == [False, False, False]
+
+    def close(a, ref, what, tol=4e-6):
+        err = float((a.detach().cpu().double() - ref).abs().max())
+        assert err <= tol * float(ref.abs().max()), (what, err, float(ref.abs().max()))
+    def close_but_for_flips(a, ref, what):
+        # the ReLUs of the two inner layers are not masked: a pre-activation within rounding of zero (a voxel or two per layer)
+        # switches a unit in one arithmetic and not the other, and every gradient element that unit feeds moves by up to a few
+        # per cent of the largest -- a sparse set, everything else sits at the single-layer bound
+        err = (a.detach().cpu().double() - ref).abs()
+        scale = float(ref.abs().max())
+        off = (err > 4e-6 * scale)
+        assert float(off.double().mean()) <= 1e-3 and float(err.max()) <= 0.1 * scale, (what, float(off.double().mean()), float(err.max()), scale)
+    for y, dx, dw, db, tag in ((y_c, dx_c, dw_c, db_c, "chained"), (y_u, dx_u, dw_u, db_u, "unchained")):
+        close(y, h.detach(), "y " + tag)
+        close_but_for_flips(dx, xr.grad * (x > 0), "dx " + tag)
+        for i in range(3):
+            close(dw[i], wr[i].grad, f"dw{i} " + tag, 5e-3)      # (sums over every voxel: a flipped unit is one term, up to 1e-3 of the largest sum)
+            close(db[i], br[i].grad, f"db{i} " + tag, 5e-3)
+    # the two arms against each other: the unchained layers read the same operand images (they ride on the float32 tensor) and
+    # gate with the same h image, so every bit agrees -- what chaining drops is only the float32 copy nobody reads
+    assert torch.equal(y_c, y_u) and torch.equal(dx_c, dx_u)
+    for i in range(3):
+        assert torch.equal(dw_c[i], dw_u[i]) and torch.equal(db_c[i], db_u[i])
 
 
 @pytest.mark.parametrize("m,n,k", [(32, 128, 1 << 18), (5, 64, 65536 + 128), (32, 100, 1 << 17), (1, 128, 1 << 16)])
