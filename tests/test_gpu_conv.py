@@ -531,7 +531,7 @@ def test_f32_conv_layers_chained_through_their_operand_images(device):
 
 
 @pytest.mark.parametrize("m,n,k", [(32, 128, 1 << 18), (5, 64, 65536 + 128), (32, 100, 1 << 17), (1, 128, 1 << 16)])
-def test_f32_linear_as_streams_over_the_weight(device, m, n, k):
+def test_f32_linear_as_streams_over_the_weight(device, monkeypatch, m, n, k):
     """csrc/linear_f32_skinny.hip: fc1-sized F.linear in float32 (<= 32 rows, <= 128 outputs) -- forward and input gradient with
     exact f32 products on the f32 matrix instruction, one pass over the weight each -- against float64, and against the
     split-product GEMM they replace (hip_ops.LINEAR_F32_SKINNY = False).  Bound: 2e-6 of the largest element at these k."""
@@ -567,6 +567,11 @@ def test_f32_linear_as_streams_over_the_weight(device, m, n, k):
         assert float((a2.cpu().double() - ref).abs().max()) <= 2e-6 * scale, what + " (GEMM)"
         assert not torch.equal(a, a2), "the two arms are different kernels: identical bits mean the switch is dead"
     assert torch.equal(dw, dw2)      # (the weight gradient is the same call in both arms)
+    # the forward's first form (fragments straight from memory, PV_LINEAR_F32_SKINNY_DIRECT=1) against the LDS-staged one: other
+    # split-k slabs, so not the same bits
+    monkeypatch.setenv("PV_LINEAR_F32_SKINNY_DIRECT", "1")
+    y3, _, _ = run()
+    assert float((y3.cpu().double() - y_ref.detach()).abs().max()) <= 2e-6 * float(y_ref.abs().max())
 
 
 def _mask_bits(mask, y_shape):
