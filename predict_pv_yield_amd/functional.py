@@ -440,10 +440,10 @@ class Conv3dF32OnF16x2(torch.autograd.Function):
             xh, xl, xs = x[0], x[1], x._pv_state
         else:
             x = x.contiguous()
-            planes = getattr(x, "_pv_planes", None)      # (xh, xl, state) left by the sum pass that produced x
-            if planes is None or planes[0].shape[:4] != (x.shape[0],) + tuple(x.shape[2:]):
-                planes = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, cpad32=True)
-            xh, xl, xs = planes
+            planes = getattr(x, "_pv_planes", None)      # (xh, xl, state, x's version then) left by the sum pass that produced x
+            if planes is None or planes[3] != x._version or planes[0].shape[:4] != (x.shape[0],) + tuple(x.shape[2:]):
+                planes = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, cpad32=True)      # (none, or x was changed in place since)
+            xh, xl, xs = planes[:3]
         wp, ws = K.conv3d_pack_weight_split2_f16(weight.contiguous())
         y, ys, yp = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
                                           relu=relu, want_f32=not chain_out)
@@ -575,7 +575,7 @@ def conv3d_general_f32(x, weight, bias, stride=1, padding=0, relu=False, x_is_re
             if chain:
                 y._pv_state = tag[1]
             else:
-                y._pv_planes = tag[1]
+                y._pv_planes = tag[1] + (y._version,)
         return y
     if is_operand_images(x):
         raise RuntimeError("conv3d_general_f32: operand images (a chained half-float conv's output) reached a layer the half-float "

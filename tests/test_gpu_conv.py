@@ -416,7 +416,7 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     y = Fn.conv3d_general_f32(xd, wd, bd, stride=(1, 1, 1), padding=pad, relu=True, x_is_relu_output=not first, dy_pregated=False)
     assert y.grad_fn is not None and type(y.grad_fn).__name__.startswith("Conv3dF32OnF16x2")
     # the sum pass leaves y's own two-term split for the next layer (scale from a bound of |y| known beforehand), and y's maximum
-    yh, yl, ys = y._pv_planes
+    yh, yl, ys, _ = y._pv_planes
     assert ys[0:1].view(torch.int32).item() == y.detach().abs().max().view(torch.int32).item()
     s_y = float(ys[1])
     assert s_y * float(ys[2]) == 1.0 and np.log2(s_y) == round(np.log2(s_y)) and float(y.detach().abs().max()) * s_y < 2.0 ** 14
@@ -505,6 +505,15 @@ def test_f32_conv_layers_chained_through_their_operand_images(device):
     y_c, dx_c, dw_c, db_c, kinds_c = run(True)
     y_u, dx_u, dw_u, db_u, kinds_u = run(False)
     assert kinds_c == [True, True, False] and kinds_u == [False, False, False]
+    # operand images that ride on a float32 tensor are dropped when the tensor was changed in place since
+    with torch.no_grad():
+        xd = x.to(device)
+        y1 = Fn.conv3d_general_f32(xd, ws[0].to(device), bs[0].to(device), stride=(1, 1, 1), padding=(0, 0, 0), relu=True)
+        assert y1._pv_planes[3] == y1._version
+        ref2 = Fn.conv3d_general_f32(y1.clone().mul_(2.0), ws[1].to(device), bs[1].to(device), stride=(1, 1, 1), padding=(0, 0, 0), relu=True)
+        y1.mul_(2.0)
+        got2 = Fn.conv3d_general_f32(y1, ws[1].to(device), bs[1].to(device), stride=(1, 1, 1), padding=(0, 0, 0), relu=True)
+        assert torch.equal(got2, ref2)
 
     def close(a, ref, what, tol=4e-6):
         err = float((a.detach().cpu().double() - ref).abs().max())
