@@ -511,11 +511,12 @@ def measure_fp32_headline(dev, b, history_minutes, steps=5):
     d = (time.perf_counter() - t0) / steps
     return {"dtype": "fp32", "ms_per_step": round(d * 1e3, 3), "value": round(b / d, 1), "unit": "samples/s",
             "steps": steps, "per_gpu_batch": b,
-            # the step's 23.37 GFLOP per sample over the f32 matrix peak: an EQUIVALENT rate -- only the conv forward and dgrad (14.68 GFLOP
-            # per sample) issue on the f32 pipe, the weight gradients and fc1 run as split products on the 16-bit matrix cores
+            # the step's 23.37 GFLOP per sample over the f32 matrix peak: an EQUIVALENT rate (it can exceed 1) -- since round 5 only
+            # fc1's forward and dx (0.52 GFLOP per sample) issue on the f32 pipe; every conv product runs as three half-float
+            # products on the 16-bit matrix cores
             "equivalent_f32_flops_over_f32_peak": round(b / d * 23.37e9 / MFMA_F32_PEAK, 4),
-            "f32_pipe_share_of_flops": round(14.68 / 23.37, 3),
-            "note": "precision=\"fp32\": forward / dgrad on the f32 matrix cores (v_mfma_f32_32x32x2f32, exact f32 products), weight gradients as two-term f16 splits (three products) and fc1 as bf16 x 3 products on the 16-bit matrix cores (f32-accurate), f32 Adam; rtol 1e-4 parity path, same step definition"}
+            "f32_pipe_share_of_flops": round(0.52 / 23.37, 3),
+            "note": "precision=\"fp32\": conv forward / data gradient / weight gradient as two-term half-float splits (three matrix-core products each, f32 accumulation, 4e-6 of float64), fc1 forward and dx with exact f32 products (v_mfma_f32_32x32x2f32), its weight gradient inside the f32 Adam pass; rtol 1e-4 parity path, same step definition"}
 
 
 def measure_other_models(dev):
