@@ -21,6 +21,7 @@ cp $(find $O/flow -name "p_kernel_stats.csv" | head -1) $O/flow_pipeline_B32_ker
 cp $O/pmc_hbm_traffic_bench_B32.json $O/pmc_flow_*.json profiles/r05/
 python3 bench.py > $O/bench_conv3d_B32_default_run.json 2> $O/bench_default.err
 python3 tools/time_fp32_step.py > $O/fp32_step_kernels.txt 2>&1
+bash tools/trace_fp32_step.sh > /dev/null 2>&1; cp gpurun_out/fp32_trace/kernel_stats.txt $O/fp32_step_kernel_stats.txt
 find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*counter_collection.csv" -size +5M -delete
 rm -rf $O/fetch $O/write $O/flowpmc/A $O/flowpmc/B $O/flowpmc/C $O/flowpmc/fetch $O/flowpmc/write
