@@ -463,6 +463,37 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
 
 
+def test_f32_conv_on_half_floats_is_exactly_homogeneous_at_the_headline_layer_size(device):
+    """A size-independent property at the full size of the model's second layer (B = 32, 32 x 16 x 62 x 62 -> 14 x 60 x 60): with
+    no bias, conv(2^a x, 2^b w) = 2^(a+b) conv(x, w) BIT FOR BIT, and so are dx, dw, db under the matching scaling of the output
+    gradient -- every scale of the half-float form (operand splits from the tensors' maxima, the output's split from a bound,
+    the 2^-12 of the small products) is a power of two derived from the data, so scaling the data by powers of two may not
+    change a single mantissa.  (An arithmetic that clipped, flushed or mis-scaled any term would break this at some exponent.)"""
+    K, _ = _mods()
+    from predict_pv_yield_amd import functional as Fn
+    g = torch.Generator(device=device).manual_seed(21)
+    x = torch.randn(32, 32, 16, 62, 62, generator=g, device=device).abs_()
+    x[torch.rand(x.shape, generator=g, device=device) < 0.3] = 0.0
+    w = torch.randn(32, 32, 3, 3, 3, generator=g, device=device) * 0.05
+    gy = torch.randn(32, 32, 14, 60, 60, generator=g, device=device) * 1e-4
+
+    def run(a, b, c):      # x 2^a, w 2^b, gy 2^c
+        xd = (x * 2.0 ** a).requires_grad_(True)
+        wd = (w * 2.0 ** b).requires_grad_(True)
+        assert Fn._conv_on_f16x2(xd, wd, (1, 1, 1), (0, 0, 0))
+        y = Fn.conv3d_general_f32(xd, wd, None, stride=(1, 1, 1), padding=(0, 0, 0), relu=True, x_is_relu_output=True, dy_pregated=False)
+        y.backward(gy * 2.0 ** c)
+        return y.detach(), xd.grad, wd.grad
+
+    y0, dx0, dw0 = run(0, 0, 0)
+    assert float(y0.abs().max()) > 0 and float(dx0.abs().max()) > 0
+    for a, b, c in ((7, -3, 0), (-20, 5, 9), (0, -12, -6)):
+        y1, dx1, dw1 = run(a, b, c)
+        assert torch.equal(y1, y0 * 2.0 ** (a + b)), (a, b, c)
+        assert torch.equal(dx1, dx0 * 2.0 ** (b + c)), (a, b, c)
+        assert torch.equal(dw1, dw0 * 2.0 ** (a + c)), (a, b, c)
+
+
 def test_f32_conv_layers_chained_through_their_operand_images(device):
     """Three Conv3d(32, 32, 3) + ReLU in float32, the first two called with chain_out=True: what travels between them forward
     (and backward) is the pair of half-float operand images the producing sum pass wrote -- no float32 activation, no split

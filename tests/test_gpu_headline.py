@@ -228,6 +228,25 @@ def test_b32_first_step_loss(device):
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_a_sample_does_not_depend_on_its_batch_at_the_benched_size(device, precision):
+    """A size-independent property at the benched batch (B = 32, no oracle needed): the forecast of a PV site may not depend on
+    which other sites share its launch.  bf16: every kernel works sample by sample (conv tiles, 32-row fc1 blocks with rows
+    independent in the matrix instruction), so the rows of the B = 32 forward have the BITS of a B = 4 forward of the same
+    samples.  fp32: the half-float conv form scales a tensor by a power of two taken from the whole batch's largest value, so
+    a different batch can move an element's low split bits: 2e-6 of the largest forecast, not bit for bit."""
+    _, model = _pair(precision, device)
+    sat, pv = _data(32, seed=11)
+    with torch.no_grad():
+        full = model(_batch(sat, pv, device))
+        for lo in (0, 12, 28):
+            part = model(_batch(sat[lo:lo + 4], pv[lo:lo + 4], device))
+            if precision == "bf16":
+                assert torch.equal(part, full[lo:lo + 4]), lo
+            else:
+                assert float((part - full[lo:lo + 4]).abs().max()) <= 2e-6 * float(full.abs().max()), lo
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_joined_config3_model_matches_the_oracle_chain(device, precision):
     """BASELINE config 3: raw 10-bit counts [2, 12, 11, 64, 64] -> u8 -> 121 Farnebäck fields per sample -> weighted
