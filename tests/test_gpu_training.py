@@ -238,10 +238,13 @@ def test_validation_results_csv_and_horizon_metrics_on_the_gpu(device, tmp_path)
 
 
 @pytest.mark.gpu
-def test_hip_graph_train_step_matches_eager(device):
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_hip_graph_train_step_matches_eager(device, precision):
     """graphs.GraphedTrainStep (forward + NMAE + backward + HipAdam(capturable=True) in ONE captured HIP graph, replayed per
     batch) against the same steps taken eagerly with the same device-side Adam scalars: identical losses and parameters,
-    bit for bit, over replays with different batches; and against the default (host-scalar) HipAdam within float rounding."""
+    bit for bit, over replays with different batches; and against the default (host-scalar) HipAdam within float rounding.
+    fp32: the half-float conv form's scales and maxima are device-side values, its operand images ride on tensors whose
+    addresses a graph keeps -- the captured step replays them like any other launch."""
     import copy
     from predict_pv_yield_amd.graphs import GraphedTrainStep
     from predict_pv_yield_amd.models.conv3d.model import Model
@@ -249,7 +252,7 @@ def test_hip_graph_train_step_matches_eager(device):
 
     kw = dict(include_pv_yield=False, include_nwp=False, forecast_minutes=30, history_minutes=55, number_of_conv3d_layers=4,
               conv3d_channels=32, image_size_pixels=64, number_sat_channels=11, fc1_output_features=128,
-              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision="bf16")
+              fc2_output_features=128, fc3_output_features=64, output_variable="pv_yield", precision=precision)
     torch.manual_seed(3)
     base = Model(**kw).to(device)
     g = torch.Generator(device=device).manual_seed(5)
