@@ -630,8 +630,8 @@ __global__ __launch_bounds__(256) void maxabs_f32_kernel(const float* __restrict
 __device__ __forceinline__ float split2_scale(const uint32_t* __restrict__ state) {
   const uint32_t bits = state[0];
   if (bits == 0u || bits >= 0x7f800000u) return 1.f;      // all zeros / a non-finite element: nothing to protect
-  int e = __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, bits));      // max = f 2^e, 0.5 <= f < 1
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  int e = __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, bits));      // max = f 2^e, 0.5 <= f < 1, e <= 128
+  e = e < -112 ? -112 : e;      // (s and 1 / s stay normal floats; rounds 4-5 clamped e to +-100: tensors beyond 2^100 overflowed their h image)
   return ldexpf(1.f, 14 - e);
 }
 

@@ -26,8 +26,8 @@ constexpr int F2_WFRAG = 27 * 2 * 64 * 8;      // one operator's 16x16x32 A frag
 
 __device__ __forceinline__ float f2_scale_of(uint32_t maxbits) {      // = split2_scale of conv3d_bf16.hip
   if (maxbits == 0u || maxbits >= 0x7f800000u) return 1.f;
-  int e = __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, maxbits));
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  int e = __builtin_amdgcn_frexp_expf(__builtin_bit_cast(float, maxbits));      // max = f 2^e, 0.5 <= f < 1, e <= 128
+  e = e < -112 ? -112 : e;      // (s and 1 / s stay normal floats: 2^-114 .. 2^126; a tensor below 2^-112 is scaled by 2^126)
   return ldexpf(1.f, 14 - e);
 }
 
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(__fadd_rn(__fadd_rn(a[i][0][j], a[i][1][j]), a[i][2][j]), unscale), b4[j]);
-      if (relu) {
+      if (relu) {      // (as torch: a NaN stays a NaN)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
+        for (int j = 0; j < 4; ++j) o[j] = o[j] < 0.f ? 0.f : o[j];
       }
       const size_t voff = ((size_t)(bi * vps + (ok ? v : 0)) * 32) + 4 * rq;
       if (gate_h) {

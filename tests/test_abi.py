@@ -58,6 +58,40 @@ def test_argument_errors_without_gpu():
     assert lib.pv_farneback_workspace_bytes(4, 64, 64, ctypes.byref(p), ctypes.byref(need)) == 0 and need.value > 0
 
 
+def test_shape_predicates_of_the_f32_path_without_gpu():
+    """Host-side shape rules of the round-5 f32 kernels (pure C, no launch): which Conv3d geometries the half-float form takes
+    (pv_conv3d_fwd_f16_f32out_covers: 64-byte voxels, padding 0..2, at least two output slices per time chunk, samples within the
+    buffer descriptors) and which Linears the streamed fc1 kernels take (pv_linear_f32_skinny_covers); argument errors are loud."""
+    lib = _lib.get_lib()
+
+    def covers(b, ci, co, t, h, w, pad):
+        d = _lib.Conv3dDims(b, ci, co, t, h, w, pad[0], pad[1], pad[2])
+        return bool(lib.pv_conv3d_fwd_f16_f32out_covers(ctypes.byref(d)))
+
+    assert covers(32, 32, 32, 16, 62, 62, (0, 0, 0))          # the model's second layer, forward
+    assert covers(32, 32, 32, 14, 60, 60, (2, 2, 2))          # ... and its data gradient (pad = 2 - pad)
+    assert covers(32, 32, 32, 18, 64, 64, (0, 0, 0))          # the first layer (11 channels in a 32-channel operand image)
+    assert covers(6, 32, 32, 6, 40, 52, (1, 1, 1))
+    assert not covers(32, 16, 32, 16, 62, 62, (0, 0, 0))      # 32-byte voxels: the caller pads the image to 32 channels
+    assert not covers(32, 32, 32, 3, 62, 62, (0, 0, 0))       # one output slice: no time march
+    assert not covers(32, 32, 32, 16, 62, 62, (3, 0, 0))      # padding beyond 2
+    assert not covers(32, 32, 32, 2, 62, 62, (0, 0, 0))       # input shorter than the kernel
+    assert not covers(70000, 32, 32, 16, 62, 62, (0, 0, 0))   # batch beyond grid.z
+    assert not covers(1, 32, 32, 600, 512, 512, (0, 0, 0))    # one sample beyond 1 GiB of operand image
+    assert lib.pv_conv3d_split2_weight_elems() == 4 * 27 * 2 * 64 * 8
+    assert lib.pv_linear_f32_skinny_covers(32, 128, 1003520) == 1 and lib.pv_linear_f32_skinny_covers(1, 64, 65536) == 1
+    assert lib.pv_linear_f32_skinny_covers(33, 128, 1003520) == 0 and lib.pv_linear_f32_skinny_covers(32, 129, 1003520) == 0
+    assert lib.pv_linear_f32_skinny_covers(32, 128, 1003520 + 64) == 0 and lib.pv_linear_f32_skinny_covers(32, 128, 32768) == 0
+    assert lib.pv_linear_fwd_f32_skinny_workspace_bytes(128) >= 512 * 32 * 128 * 4
+    assert lib.pv_linear_fwd_f32_skinny(None, None, None, None, 32, 128, 1003520, 0, None, 0, None) == -1
+    assert b"null pointer" in lib.pv_last_error()
+    assert lib.pv_sum3_ndhwc_to_ncdhw_f32(None, None, None, None, 0, None, None, None, None, None, None, 0, 1, 64, None) == -1
+    d = _lib.Conv3dDims(32, 16, 32, 16, 62, 62, 0, 0, 0)
+    one = ctypes.c_float(0)
+    assert lib.pv_conv3d_fwd_f16_f32out(ctypes.byref(one), ctypes.byref(one), ctypes.byref(one), 0, ctypes.byref(d), None) != 0
+    assert b"channels" in lib.pv_last_error()
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "predict_pv_yield_amd")
     for dirpath, _, files in os.walk(pkg):

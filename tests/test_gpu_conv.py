@@ -463,6 +463,35 @@ def test_f32_conv_forward_and_dgrad_as_three_half_float_products(device, shape, 
     assert float((y - y2).abs().max()) <= 4e-6 * float(y_ref.abs().max())
 
 
+def test_f32_conv_on_half_floats_edge_inputs(device):
+    """Edges of the half-float form's scaling: an all-zero input (maximum 0: scale 1, output = ReLU(bias) exactly, zero
+    gradients for w), an input whose largest element is 10^20 times the typical one (the scale follows the outlier; the
+    result still sits within 4e-6 of float64 at ITS largest element, and the ordinary voxels keep an absolute error of 2^-32
+    of it), and magnitudes at the ends of the float32 range (1e-30, 1e30)."""
+    K, _ = _mods()
+    from predict_pv_yield_amd import functional as Fn
+    g = torch.Generator().manual_seed(99)
+    shape = (8, 32, 8, 44, 44)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    b = torch.randn(32, generator=g) * 0.1
+    wd, bd = w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    xz = torch.zeros(shape, device=device, requires_grad=True)
+    y = Fn.conv3d_general_f32(xz, wd, bd, stride=(1, 1, 1), padding=(0, 0, 0), relu=True, x_is_relu_output=True)
+    assert type(y.grad_fn).__name__.startswith("Conv3dF32OnF16x2")
+    assert torch.equal(y, torch.relu(bd.detach()).view(1, 32, 1, 1, 1).expand_as(y))
+    y.sum().backward()
+    assert float(wd.grad.abs().max()) == 0.0 and float(xz.grad.abs().max()) == 0.0 and bool(torch.isfinite(bd.grad).all())
+    for magnitude, outlier in ((1.0, 1e20), (1e-30, None), (1e30, None)):
+        x = torch.randn(shape, generator=g).abs() * magnitude
+        if outlier:
+            x[3, 7, 4, 20, 20] = outlier
+        ref = F.relu(F.conv3d(x.double(), w.double() * (1.0 if magnitude == 1.0 else 1.0), b.double() * magnitude))
+        with torch.no_grad():
+            y = Fn.conv3d_general_f32(x.to(device), wd.detach(), (b * magnitude).to(device), stride=(1, 1, 1), padding=(0, 0, 0), relu=True)
+        assert bool(torch.isfinite(y).all())
+        assert float((y.cpu().double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()), (magnitude, outlier)
+
+
 def test_f32_conv_on_half_floats_is_exactly_homogeneous_at_the_headline_layer_size(device):
     """A size-independent property at the full size of the model's second layer (B = 32, 32 x 16 x 62 x 62 -> 14 x 60 x 60): with
     no bias, conv(2^a x, 2^b w) = 2^(a+b) conv(x, w) BIT FOR BIT, and so are dx, dw, db under the matching scaling of the output
