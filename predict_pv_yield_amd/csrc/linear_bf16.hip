@@ -7,6 +7,7 @@
 //   bwd : dx[M,K] = g[M,N] . w[N,K]     (bf16 out);  dw[N,K] = g^T . x (f32 out);  db[N] = colsum(g)
 //         with g = dy ⊙ (y > 0)
 #include "pv_common.h"
+#include <string.h>
 
 namespace pv {
 
@@ -373,6 +374,8 @@ constexpr int FD_KT = 128;                 // k-columns per workgroup
 constexpr int FD_XLD = FD_KT + 8;          // bf16 row stride of the x / dx tile
 constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed weight tile [k][n]
 
+// AHEAD rows of p / m / v in flight per thread; EARLY: the first of them requested at the top of the kernel
+template <int AHEAD, bool EARLY>
 __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
     int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
@@ -390,6 +393,31 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = tid & 15, rg = tid >> 4;
   const long long k0 = (long long)blockIdx.x * FD_KT;
+  const long long k8 = k0 + 8 * kq;
+  const bool k_ok = k8 < k;
+  // the first rows' p / m / v are requested before anything else (round 5): they used to be requested after the gradient
+  // tile was formed, so a workgroup had no load of the 3.4 GB stream in flight during its prologue and its ~4 000 cycles of
+  // gradient FMAs
+  f32x4 nxt[AHEAD][6];      // the rows in flight (EARLY = false, AHEAD = 1: one row, requested after the gradient tile -- rounds 3-4)
+  // mv_tiled: the two moment arrays are stored tile by tile, [k / 128][n][128]: a workgroup's share is ONE contiguous
+  // n x 512-byte block per array instead of n segments 4 MB apart
+  const size_t mv_tile_base = (size_t)blockIdx.x * (size_t)n * FD_KT + 8 * kq;
+  auto fetch = [&](int i) {
+    const int r = min(8 * rg + i, n - 1);
+    const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
+    const size_t moff = mv_tiled ? mv_tile_base + (size_t)r * FD_KT : off;
+    f32x4 (&d)[6] = nxt[i % AHEAD];
+    d[0] = *reinterpret_cast<const f32x4*>(w + off);
+    d[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
+    d[2] = *reinterpret_cast<const f32x4*>(exp_avg + moff);
+    d[3] = *reinterpret_cast<const f32x4*>(exp_avg + moff + 4);
+    d[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff);
+    d[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff + 4);
+  };
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) fetch(i);
+  }
   for (int i = tid; i < 32 * 128; i += 256) {
     const int b = i >> 7, nn = i & 127;
     float v = 0.f;
@@ -412,8 +440,6 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     for (int b = 0; b < m; ++b) sacc += gs[b * 128 + tid];
     db[tid] = sacc;
   }
-  const long long k8 = k0 + 8 * kq;
-  const bool k_ok = k8 < k;
   // ---- weight gradient tile: rows 8 rg .. +7, columns k8 .. +7 (packed f32 FMAs, gradient value broadcast) ----------------
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   f32x2_t acc2[8][4];
@@ -439,32 +465,20 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   }
   // ---- Adam, row by row (next row's p / m / v in flight under this row's arithmetic); the old weights are kept as bf16 ------
   uint32_t wold[8][4];     // bf16 pairs of the PRE-update weights: [row i][column pair]
-  f32x4 nxt[6];
-  // mv_tiled: the two moment arrays are stored tile by tile, [k / 128][n][128]: a workgroup's share is ONE contiguous
-  // n x 512-byte block per array instead of n segments 4 MB apart
-  const size_t mv_tile_base = (size_t)blockIdx.x * (size_t)n * FD_KT + 8 * kq;
-  auto fetch = [&](int i) {
-    const int r = min(8 * rg + i, n - 1);
-    const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
-    const size_t moff = mv_tiled ? mv_tile_base + (size_t)r * FD_KT : off;
-    nxt[0] = *reinterpret_cast<const f32x4*>(w + off);
-    nxt[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
-    nxt[2] = *reinterpret_cast<const f32x4*>(exp_avg + moff);
-    nxt[3] = *reinterpret_cast<const f32x4*>(exp_avg + moff + 4);
-    nxt[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff);
-    nxt[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff + 4);
-  };
-  fetch(0);
+  if constexpr (!EARLY) {
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) fetch(i);
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float pv[8], mv[8], vv[8];
-    *reinterpret_cast<f32x4*>(pv) = nxt[0];
-    *reinterpret_cast<f32x4*>(pv + 4) = nxt[1];
-    *reinterpret_cast<f32x4*>(mv) = nxt[2];
-    *reinterpret_cast<f32x4*>(mv + 4) = nxt[3];
-    *reinterpret_cast<f32x4*>(vv) = nxt[4];
-    *reinterpret_cast<f32x4*>(vv + 4) = nxt[5];
-    if (i + 1 < 8) fetch(i + 1);
+    *reinterpret_cast<f32x4*>(pv) = nxt[i % AHEAD][0];
+    *reinterpret_cast<f32x4*>(pv + 4) = nxt[i % AHEAD][1];
+    *reinterpret_cast<f32x4*>(mv) = nxt[i % AHEAD][2];
+    *reinterpret_cast<f32x4*>(mv + 4) = nxt[i % AHEAD][3];
+    *reinterpret_cast<f32x4*>(vv) = nxt[i % AHEAD][4];
+    *reinterpret_cast<f32x4*>(vv + 4) = nxt[i % AHEAD][5];
+    if (i + AHEAD < 8) fetch(i + AHEAD);
     const bool row_ok = 8 * rg + i < n && k_ok;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -1123,6 +1137,19 @@ int pv_linear_wgrad_adam_f32(const float* x, const float* dy, const float* y_rel
   return check_launch("pv_linear_wgrad_adam_f32");
 }
 
+// the one-pass fc1 backward by fetch schedule (same arithmetic, same bits).  Default (round 5): TWO rows of p / m / v in flight per
+// thread, the first two requested at the top of the kernel -- 147 KB in flight per CU at three workgroups; same-process A/B of the
+// whole train step on a fast and a slow box: 1.5340 -> 1.5206 ms and 1.6858 -> 1.6722 ms (-13.5 us).  PV_FC1_FETCH=early1: one row
+// in flight, requested at the top (-0 .. -7 us); =late: rounds 3-4 (one row, first request after the gradient tile).  Three or four
+// rows at two workgroups per CU: -6 us; two rows at two workgroups: no gain.
+#define PV_LAUNCH_FC1_ONE_PASS(grid, st, ...)                                                                         \
+  do {                                                                                                                \
+    const char* fs_ = getenv("PV_FC1_FETCH");                                                                         \
+    if (fs_ && !strcmp(fs_, "late")) hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<1, false>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); \
+    else if (fs_ && !strcmp(fs_, "early1")) hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<1, true>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<2, true>), dim3(grid), dim3(256), 0, st, __VA_ARGS__);       \
+  } while (0)
+
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
                                  float* exp_avg_sq, uint16_t* bf16_shadow, uint16_t* dx, float* db, int32_t m, int32_t n,
                                  int64_t k, double lr, double beta1, double beta2, double eps, int32_t step,
@@ -1137,7 +1164,7 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                  (float)(-(lr / bc1))};
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
-  hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
+  PV_LAUNCH_FC1_ONE_PASS(grid, as_stream(stream), x, dy, y_relu_mask, param, m, n,
                      (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr,
                      moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
@@ -1154,7 +1181,7 @@ int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const f
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_dev_bf16: k must be a multiple of 8");
   PV_REQUIRE(!moments_tiled || k % FD_KT == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_dev_bf16: tiled moments need k %% %d == 0", FD_KT);
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
-  hipLaunchKernelGGL(linear_bwd_dw_dx_adam_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, dy, y_relu_mask, param, m, n,
+  PV_LAUNCH_FC1_ONE_PASS(grid, as_stream(stream), x, dy, y_relu_mask, param, m, n,
                      (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, AdamScalars{}, gate_dx_by_x, adam_scalars_dev,
                      moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_dev_bf16");
