@@ -870,12 +870,34 @@ class ClockSampler:
     box may expose several cards while one is visible to the process: the card with the highest median engine clock during the
     run is taken to be the one under load."""
 
-    def __init__(self, period_s=0.05):
+    def __init__(self, period_s=0.01):
         import glob
         self.period = period_s
         self.cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples = {c: {"sclk": [], "mclk": [], "power": []} for c in self.cards}
+        self.samples = {c: {"sclk": [], "mclk": [], "fclk": [], "power": [], "sclk_now": [], "temp": []} for c in self.cards}
+        # hwmon: freq1_input = the engine clock the device is running at NOW (Hz; the pp_dpm level is the state it was asked for),
+        # power1_average or power1_input (uW), the hottest temp*_input (millidegrees)
+        self.hwmon = {}
+        for c in self.cards:
+            d = os.path.dirname(c)
+            hw = (glob.glob(os.path.join(d, "hwmon", "hwmon*")) + [None])[0]
+            files = {}
+            if hw:
+                for key, names in (("sclk_now", ("freq1_input",)), ("power", ("power1_average", "power1_input"))):
+                    for nme in names:
+                        if os.path.exists(os.path.join(hw, nme)):
+                            files[key] = os.path.join(hw, nme)
+                            break
+                files["temps"] = sorted(glob.glob(os.path.join(hw, "temp*_input")))
+            self.hwmon[c] = files
         self._stop = None
+
+    @staticmethod
+    def _read_int(path):
+        try:
+            return int(open(path).read())
+        except Exception:      # noqa: BLE001 -- absent or unreadable: no sample
+            return None
 
     @staticmethod
     def _active_mhz(path):
@@ -901,11 +923,19 @@ class ClockSampler:
                         self.samples[c]["sclk"].append(s_)
                     if m_ is not None:
                         self.samples[c]["mclk"].append(m_)
-                    for pw in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average"))[:1]:
-                        try:
-                            self.samples[c]["power"].append(int(open(pw).read()) / 1e6)
-                        except Exception:      # noqa: BLE001
-                            pass
+                    f_ = self._active_mhz(os.path.join(d, "pp_dpm_fclk"))
+                    if f_ is not None:
+                        self.samples[c]["fclk"].append(f_)
+                    hw = self.hwmon.get(c, {})
+                    v = self._read_int(hw["sclk_now"]) if "sclk_now" in hw else None
+                    if v is not None:
+                        self.samples[c]["sclk_now"].append(round(v / 1e6))
+                    v = self._read_int(hw["power"]) if "power" in hw else None
+                    if v is not None:
+                        self.samples[c]["power"].append(v / 1e6)
+                    ts = [t for t in (self._read_int(tp) for tp in hw.get("temps", [])) if t is not None]
+                    if ts:
+                        self.samples[c]["temp"].append(max(ts) / 1e3)
                 self._stop.wait(self.period)
 
         self._thread = threading.Thread(target=loop, daemon=True)
@@ -919,19 +949,21 @@ class ClockSampler:
 
     def summary(self):
         import statistics
-        best, best_med = None, -1
-        for c, smp in self.samples.items():
+        best, best_key = None, (-1, -1)
+        for c, smp in self.samples.items():      # the card under load: the highest median power, then engine clock
             if smp["sclk"]:
-                med = statistics.median(smp["sclk"])
-                if med > best_med:
-                    best, best_med = c, med
+                key = (statistics.median(smp["power"]) if smp["power"] else -1, statistics.median(smp["sclk"]))
+                if key > best_key:
+                    best, best_key = c, key
         if best is None:
             return {"available": False}
         smp = self.samples[best]
         q = lambda v: {"min": min(v), "median": statistics.median(v), "max": max(v)} if v else None
         return {"available": True, "card": best.split("/")[4], "cards_seen": len(self.cards), "samples": len(smp["sclk"]),
-                "sclk_MHz": q(smp["sclk"]), "mclk_MHz": q(smp["mclk"]), "power_W": q([round(x, 1) for x in smp["power"]]),
-                "source": "sysfs pp_dpm_sclk / pp_dpm_mclk (active level) sampled every 50 ms during the timed steps"}
+                "sclk_MHz": q(smp["sclk"]), "sclk_now_MHz": q(smp["sclk_now"]), "mclk_MHz": q(smp["mclk"]), "fclk_MHz": q(smp["fclk"]),
+                "power_W": q([round(x, 1) for x in smp["power"]]), "hottest_sensor_C": q([round(x, 1) for x in smp["temp"]]),
+                "source": "sysfs pp_dpm_sclk / _mclk / _fclk (active level), hwmon freq1_input (engine clock now), power1_*, temp*_input; "
+                          "sampled every 10 ms during the timed steps"}
 
 
 def collectives_info(world, requested, in_force):
