@@ -182,7 +182,8 @@ def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
         # p, m, v read + written, shadow written, x read once (+ dx written by the single-pass form)
         byt = nrows * kcols * (3 * 4 * 2 + 2) + b * kcols * 2 * (2 if single_pass else 1)
         kname = "pv::linear_bwd_dw_dx_adam_kernel" if single_pass else "pv::linear_bwd_dw_bf16_kernel<1>"
-        tr = traffic.get(kname, {}).get("hbm_bytes_per_launch")
+        # (the one-pass kernel is a template since round 5: "pv::linear_bwd_dw_dx_adam_kernel<2, true>")
+        tr = next((v.get("hbm_bytes_per_launch") for k_, v in traffic.items() if k_ == kname or k_.startswith(kname + "<")), None)
         out.update({"bound": "hbm", "kernel": (kname[4:] + " (fc1 backward in one pass: wgrad + Adam + dx + db, 128.45 M weights)")
                     if single_pass else "linear_bwd_dw_bf16_kernel<1> (fc1 wgrad + Adam fused, 128.45 M weights)",
                     "achieved": round(byt / secs / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
