@@ -298,11 +298,12 @@ def measure_config3(dev, b, history_minutes):
         if bound == "hbm":
             entry["frac"] = round(t_mem / secs, 4)          # of 8 TB/s, on the ALGORITHMIC bytes
             if "prep_polyexp" in label:
-                # priced by SURVEY's bytes and flops the stage is memory-side; the IMPLEMENTATION multiplies dense 64 x 64 products
-                # with banded operands on the matrix cores, and that is what bounds it (in-kernel stamps, profiles/r05/NOTES.md)
-                entry["implementation_bound"] = ("product phase 90 % matrix-pipe-bound (4 608 of 5 126 cycles per image), the other "
-                                                 "phases serial behind barriers; not store-bound: write-only kernels reach 5.4-5.7 TB/s "
-                                                 "in the same store shape (tools/probes/store_rate.hip)")
+                # priced by SURVEY's bytes and flops the stage is memory-side; the IMPLEMENTATION is a latency chain of phases
+                # (in-kernel stamps and three negative experiments, profiles/r05/NOTES.md)
+                entry["implementation_bound"] = ("latency: per image four phases behind barriers (source, filters, products, epilogue) at two "
+                                                 "waves per SIMD; the product phase is a chain LDS read -> product -> re-split -> product "
+                                                 "(a quarter fewer matrix instructions changed nothing); not store-bound: write-only kernels "
+                                                 "reach 5.4-5.7 TB/s in the same store shape (tools/probes/store_rate.hip, profiles/r05/NOTES.md)")
         else:
             # a stage bound by its instructions: the fraction of the f32 flop peak its SURVEY flops reach, and -- from the
             # committed SQ-counter passes -- how busy the vector and the matrix pipes were while its waves were resident
