@@ -375,7 +375,8 @@ constexpr int FD_XLD = FD_KT + 8;          // bf16 row stride of the x / dx tile
 constexpr int FD_WLD = 128 + 8;            // bf16 row stride of the transposed weight tile [k][n]
 
 // AHEAD rows of p / m / v in flight per thread; EARLY: the first of them requested at the top of the kernel
-template <int AHEAD, bool EARLY>
+// GR: rows of the gradient tile formed at a time (8: all at once; 4 / 2: in halves / quarters, each right before its Adam rows)
+template <int AHEAD, bool EARLY, int GR = 8>
 __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask, float* __restrict__ w,
     int m, int n, long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
@@ -442,28 +443,33 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   }
   // ---- weight gradient tile: rows 8 rg .. +7, columns k8 .. +7 (packed f32 FMAs, gradient value broadcast) ----------------
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  f32x2_t acc2[8][4];
+  f32x2_t acc2[GR][4];
+  auto form_gradient = [&](int r0) __attribute__((always_inline)) {      // rows 8 rg + r0 .. + GR - 1
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < GR; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
 #pragma unroll 4
-  for (int b = 0; b < m; ++b) {
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * kq);
-    f32x2_t xv2[4];
+    for (int b = 0; b < m; ++b) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * kq);
+      f32x2_t xv2[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg), g1 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + 4);
+      for (int q = 0; q < 4; ++q)
+        xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + (r0 & 4));
+      f32x4 g1 = g0;
+      if constexpr (GR == 8) g1 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + 4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float gv = i < 4 ? g0[i] : g1[i - 4];
-      const f32x2_t g2 = {gv, gv};
+      for (int i = 0; i < GR; ++i) {
+        const float gv = GR == 8 ? (i < 4 ? g0[i] : g1[i - 4]) : g0[(r0 & 3) + i];
+        const f32x2_t g2 = {gv, gv};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
+        for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
+      }
     }
-  }
-  // ---- Adam, row by row (next row's p / m / v in flight under this row's arithmetic); the old weights are kept as bf16 ------
+  };
+  form_gradient(0);
+  // ---- Adam, row by row (next rows' p / m / v in flight under this row's arithmetic); the old weights are kept as bf16 ------
   uint32_t wold[8][4];     // bf16 pairs of the PRE-update weights: [row i][column pair]
   if constexpr (!EARLY) {
 #pragma unroll
@@ -471,6 +477,9 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    if constexpr (GR < 8) {
+      if (i > 0 && i % GR == 0) form_gradient(i);
+    }
     float pv[8], mv[8], vv[8];
     *reinterpret_cast<f32x4*>(pv) = nxt[i % AHEAD][0];
     *reinterpret_cast<f32x4*>(pv + 4) = nxt[i % AHEAD][1];
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
       uint32_t sh[4];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gr = acc2[i][j >> 1][j & 1];
+        const float gr = acc2[i % GR][j >> 1][j & 1];
         const float mm = mv[j] + ad.one_minus_b1 * (gr - mv[j]);
         const float v2 = vv[j] * ad.beta2 + (ad.one_minus_b2 * gr) * gr;
         const float denom = sqrtf(v2) / ad.bc2_sqrt + ad.eps;
@@ -1137,17 +1146,20 @@ int pv_linear_wgrad_adam_f32(const float* x, const float* dy, const float* y_rel
   return check_launch("pv_linear_wgrad_adam_f32");
 }
 
-// the one-pass fc1 backward by fetch schedule (same arithmetic, same bits).  Default (round 5): TWO rows of p / m / v in flight per
-// thread, the first two requested at the top of the kernel -- 147 KB in flight per CU at three workgroups; same-process A/B of the
-// whole train step on a fast and a slow box: 1.5340 -> 1.5206 ms and 1.6858 -> 1.6722 ms (-13.5 us).  PV_FC1_FETCH=early1: one row
-// in flight, requested at the top (-0 .. -7 us); =late: rounds 3-4 (one row, first request after the gradient tile).  Three or four
-// rows at two workgroups per CU: -6 us; two rows at two workgroups: no gain.
+// the one-pass fc1 backward by schedule (same arithmetic, same bits).  Default (round 5): TWO rows of p / m / v in flight per thread,
+// the first two requested at the top of the kernel -- 147 KB in flight per CU at three workgroups -- and the gradient tile formed in
+// two halves of four rows, each right before its Adam rows.  Same-process A/Bs of the whole train step on a fast and a slow box:
+// one row -> two rows in flight 1.5340 -> 1.5206 ms and 1.6858 -> 1.6722 ms (-13.5 us); gradient in halves another -4 .. -8 us
+// (three runs).  PV_FC1_FETCH=early2: two rows, gradient at once; =early1: one row in flight, requested at the top (-0 .. -7 us
+// against late); =late: rounds 3-4 (one row, first request after the gradient tile).  Measured and dropped: three or four rows at
+// two workgroups per CU (-6 us), three rows with the gradient in quarters (no spill, +5 us), a persistent form (88 spills, +124 us).
 #define PV_LAUNCH_FC1_ONE_PASS(grid, st, ...)                                                                         \
   do {                                                                                                                \
     const char* fs_ = getenv("PV_FC1_FETCH");                                                                         \
     if (fs_ && !strcmp(fs_, "late")) hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<1, false>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); \
     else if (fs_ && !strcmp(fs_, "early1")) hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<1, true>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<2, true>), dim3(grid), dim3(256), 0, st, __VA_ARGS__);       \
+    else if (fs_ && !strcmp(fs_, "early2")) hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<2, true>), dim3(grid), dim3(256), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((linear_bwd_dw_dx_adam_kernel<2, true, 4>), dim3(grid), dim3(256), 0, st, __VA_ARGS__);    \
   } while (0)
 
 int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,
