@@ -298,8 +298,8 @@ int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, f
  * relative (22-bit operands, f32 accumulation). */
 /* half-float elements of wp: four operators' fragments -- forward (h, l), data gradient (h, l) */
 size_t pv_conv3d_split2_weight_elems(void);
-/* w [c_out, c_in, 3,3,3] f32 -> wp; state: 5 device floats (bits of max |w|, s, 1 / s, the largest absolute row sum of the
- * forward operator and of the data-gradient operator) */
+/* w [c_out, c_in, 3,3,3] f32 -> wp; state: 69 device floats (bits of max |w|, s, 1 / s, two unused, the 32 absolute row sums of
+ * the forward operator, the 32 of the data-gradient operator) */
 int pv_conv3d_pack_weight_split2_f16(const float* w, uint16_t* wp, float* state, int32_t c_out, int32_t c_in, void* stream);
 /* x [B,T,H,W,32] half floats (one term), wp: ONE operator's fragments (elems / 4 of the above), y [B,To,Ho,Wo,32] f32 = the
  * raw accumulators (no bias, no activation, scaled by s_x s_w); y_is_f16 != 0: y is a HALF-FLOAT image of the accumulators times
@@ -313,7 +313,7 @@ int pv_conv3d_fwd_f16_f32out_covers(const pv_conv3d_dims* d);
  * (the h image of the gating activation, [B][vox][32] half floats): y where it is > 0, else 0.  max_state != NULL: atomicMax of the
  * bits of |y| into max_state[0] (zeroed by the caller).  out_h / out_l != NULL: y's own two-term split ([B][vox][32] half floats
  * each) with the scale s_y written to max_state[1], 1 / s_y to max_state[2]: s_y brings the bound max |x| (sx_state[0]) *
- * sw_state[3 + data_gradient] + max |bias| below 2^14 -- known before the first element, so no split pass reads y again; y may
+ * the largest of the operator's row sums (sw_state[5..36], data_gradient: [37..68]) + max |bias| below 2^14 -- known before the first element, so no split pass reads y again; y may
  * then be NULL (a consumer that reads the images only).  vox_per_sample % 4 == 0. */
 int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, const float* sx_state, const float* sw_state,
                                int32_t data_gradient, const float* bias, const uint16_t* gate_h, float* y, uint16_t* out_h,

@@ -32,7 +32,8 @@ __device__ __forceinline__ float f2_scale_of(uint32_t maxbits) {      // = split
 }
 
 // w [32,32,27] f32 -> four fragment images [27][2 cout halves][64 lanes][8] half floats: forward operator (h, l), dgrad operator
-// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s, L1 bound forward, L1 bound data gradient).  Every workgroup finds the maximum of the 27 648 weights
+// (transposed and flipped: h, l); state = (bits of max |w|, s, 1 / s, -, -, 32 absolute row sums of the forward operator, 32 of
+// the data-gradient operator).  Every workgroup finds the maximum of the 27 648 weights
 // for itself (110 KB from L2; one workgroup doing everything took 34 us) and packs its share of the fragments.
 __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp,
                                                                       float* __restrict__ state, int c_out, int c_in) {
@@ -53,15 +54,15 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
     state[1] = s;
     state[2] = 1.f / s;
   }
-  // state[3], state[4]: the largest absolute row sum of the forward / the data-gradient operator (sum over what an output element
-  // contracts): |y| <= max |x| state[3] + max |bias| bounds an output before it exists -- the scale of ITS split (sum pass below).
-  // Block 0, a wave per four rows, lanes over the row's elements in a fixed order + a butterfly: the same bits every time
-  // (one thread per row, 864 dependent-address loads each, took 60 us).
-  if (blockIdx.x == 0) {
-    __shared__ float l1[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int q = 0; q < 4; ++q) {
-      const int row = 4 * wave + q, r = row & 31, back = row >> 5;
+  // state[5 + r], state[37 + r] (r < 32): the absolute row sums of the forward / the data-gradient operator (sum over what an
+  // output element contracts): |y| <= max |x| max_r state[5 + r] + max |bias| bounds an output before it exists -- the scale of
+  // ITS split (sum pass below, which takes the maximum of the 32 sums itself).  A wave per row, lanes over the row's elements in
+  // a fixed order + a butterfly: the same bits every time; the 64 rows are dealt out over the first 4 workgroups (one workgroup
+  // doing all of them took 60 us one thread per row, 18 us one wave per four rows).
+  {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (row < 64) {
+      const int r = row & 31, back = row >> 5;
       float acc = 0.f;
       if (!back) {
         if (r < c_out) for (int i = lane; i < c_in * 27; i += 64) acc += fabsf(w[(size_t)r * c_in * 27 + i]);
@@ -70,13 +71,7 @@ __global__ __launch_bounds__(1024) void pack_weight_v3_split2_kernel(const float
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-      if (lane == 0) l1[row] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-      float mx = 0.f;
-      for (int i = 0; i < 32; ++i) mx = fmaxf(mx, l1[32 * threadIdx.x + i]);
-      state[3 + threadIdx.x] = mx;
+      if (lane == 0) state[5 + row] = acc;
     }
   }
   for (int i = blockIdx.x * 1024 + threadIdx.x; i < 2 * F2_WFRAG; i += gridDim.x * 1024) {
@@ -132,7 +127,9 @@ __global__ __launch_bounds__(256) void sum3_ndhwc_to_ncdhw_kernel(const float* _
   if constexpr (PLANES) {
     float bmax = 0.f;
     if (bias) for (int i = 0; i < 32; ++i) bmax = fmaxf(bmax, fabsf(bias[i]));
-    const float bound = __builtin_bit_cast(float, reinterpret_cast<const uint32_t*>(sx)[0]) * l1[0] * 1.01f + bmax;
+    float l1max = 0.f;
+    for (int i = 0; i < 32; ++i) l1max = fmaxf(l1max, l1[i]);
+    const float bound = __builtin_bit_cast(float, reinterpret_cast<const uint32_t*>(sx)[0]) * l1max * 1.01f + bmax;
     s_y = f2_scale_of(__builtin_bit_cast(uint32_t, bound));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       reinterpret_cast<float*>(max_state)[1] = s_y;
@@ -278,7 +275,7 @@ int pv_sum3_ndhwc_to_ncdhw_f32(const float* parts, const uint16_t* p01_f16, cons
              "pv_sum3_ndhwc_to_ncdhw_f32: 16-byte aligned tensors");
   const long long tps = (vox_per_sample + 31) / 32, total = tps * batch;
   const unsigned grid = (unsigned)std::min<long long>((total + 3) / 4, (long long)kNumCU * 8);
-  const float* l1 = sw_state + (data_gradient ? 4 : 3);
+  const float* l1 = sw_state + (data_gradient ? 37 : 5);      // the operator's 32 absolute row sums
 #define PV_LAUNCH_SUM3(F16P, PL)                                                                                              \
   hipLaunchKernelGGL((sum3_ndhwc_to_ncdhw_kernel<F16P, PL>), dim3(grid), dim3(256), 0, as_stream(stream), parts,               \
                      (size_t)batch * vox_per_sample * 32, p01_f16, sx_state, sw_state, l1, bias, gate_h, y, out_h, out_l,     \

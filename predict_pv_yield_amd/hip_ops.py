@@ -369,7 +369,7 @@ def conv3d_pack_weight_split2_f16(w: torch.Tensor):
     lib = get_lib()
     n = int(lib.pv_conv3d_split2_weight_elems())
     wp = torch.empty((4, n // 4), dtype=torch.float16, device=w.device)
-    state = torch.empty(5, dtype=torch.float32, device=w.device)
+    state = torch.empty(69, dtype=torch.float32, device=w.device)      # (max bits, s, 1 / s, -, -, 32 + 32 absolute row sums)
     check(lib.pv_conv3d_pack_weight_split2_f16(ptr(w), ptr(wp), ptr(state), w.shape[0], w.shape[1], current_stream_ptr()),
           "pv_conv3d_pack_weight_split2_f16")
     return wp, state
