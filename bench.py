@@ -16,10 +16,10 @@ region, GPU legs first, the CPU leg last):
   config3       BASELINE configs[2]: joined train step (raw counts -> Farnebäck advection -> Conv3D) and a roofline
                 PER STAGE of the advection pipeline (pv_stage_timing: HIP events at every stage boundary);
   fp32          the same headline step on the exact-f32 kernels (precision="fp32");
-  val_nmae      "at matched validation NMAE": 8 seeds x 512 Adam steps at B = 32, HIP bf16 against HIP fp32 on the same weights
-                and batches, validation NMAE on 1 024 held-out samples averaged over the last 64 steps; the paired
-                difference with its standard error is gated at max(2e-3, 2 s.e.); the torch-CPU oracle follows seed 0 for
-                its time budget (first-steps train losses side by side, same weights through both scorers);
+  val_nmae      "at matched validation NMAE": seeds x 512 Adam steps at B = 32, HIP bf16 against HIP fp32 on the same weights
+                and batches, validation NMAE on 1 024 held-out samples averaged over the last 64 steps; gate: |mean paired
+                difference| <= 2e-3 AND its standard error <= 7e-4 (seeds added in blocks of 8 until the second holds);
+                the torch-CPU oracle follows seed 0 for its time budget (first-steps train losses, two scorers);
   cpu_baseline  those oracle steps, timed, at the benched batch (identical arithmetic to the reference's Lightning path).
 """
 import argparse
@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK = 2.5e15     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK = 157.3e12    # f32 matrix cores (xf32-free exact f32)
 HBM_PEAK = 8.0e12
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 TRAFFIC_PROFILE = os.path.join("profiles", PROFILE_ROUND, "pmc_hbm_traffic_bench_B32.json")
 FLOW_TRAFFIC_PROFILE = os.path.join("profiles", PROFILE_ROUND, "pmc_flow_traffic_B32.json")
 # advection stage -> (kernel of the committed PMC passes, its SQ-counter summary): tools/pmc_flow.sh
@@ -661,14 +661,17 @@ def learnable_task_on_device(n, t_frames, gen, dev):
     return sat, pv
 
 
-# Gate of the matched-validation experiment, fixed BEFORE its first run (SURVEY section 8c asks for "matched
-# validation NMAE" at 1e-3 .. 2e-3 absolute; a difference inside twice its own standard error is not a difference):
-#   |mean over seeds of the paired difference (bf16 - fp32)| <= max(2e-3, 2 standard errors of that difference)
-VAL_GATE_ABS, VAL_GATE_SE = 2e-3, 2.0
+# Gate of the matched-validation experiment (round 6, VERDICT r5 item 4: the round-5 gate max(2e-3, 2 s.e.) WIDENED with the
+# noise of the run; SURVEY section 8c asks for "matched validation NMAE" at 1e-3 .. 2e-3 absolute):
+#   |mean over seeds of the paired difference (bf16 - fp32)| <= 2e-3   AND   its standard error <= 7e-4,
+# seeds added in blocks of VAL_SEED_BLOCK until the second clause holds (or VAL_SEEDS_MAX is reached: then the gate FAILS --
+# an estimate that noisy decides nothing)
+VAL_GATE_ABS, VAL_GATE_SE_MAX = 2e-3, 7e-4
+VAL_SEED_BLOCK, VAL_SEEDS_MAX = 8, 48
 
 
-def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=512, batch=32, n_val=1024, tail=64, tail_stride=2,
-                                        oracle_seconds=55.0, early=8):
+def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=None, n_steps=512, batch=32, n_val=1024, tail=64, tail_stride=4,
+                                        oracle_seconds=30.0, early=8):
     """"At matched validation NMAE" with statistical power, and the CPU baseline from the same oracle steps.
 
     Per seed: ONE set of initial weights and ONE sequence of batches (B = 32, the benched batch) of the learnable synthetic
@@ -722,7 +725,18 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
     early_loss = {"bf16": [], "fp32": []}
     t_hip = time.perf_counter()
     init0 = None
-    for seed in range(seeds):
+    se = lambda v: statistics.stdev(v) / len(v) ** 0.5 if len(v) > 1 else float("nan")
+    seed = -1
+    while True:
+        seed += 1
+        if seeds is not None:
+            if seed >= seeds:
+                break
+        elif seed and seed % VAL_SEED_BLOCK == 0:
+            # sequential rule, fixed beforehand: stop at the first block boundary where the paired difference's standard
+            # error is below the gate's bound (the MEAN is not looked at), or at VAL_SEEDS_MAX
+            if se([a - b for a, b in zip(runs["bf16"], runs["fp32"])]) <= VAL_GATE_SE_MAX or seed >= VAL_SEEDS_MAX:
+                break
         reinitialise(models["fp32"], seed)
         init = {k: v.clone() for k, v in models["fp32"].state_dict().items()}      # reference layout (the state-dict hook's)
         if seed == 0:
@@ -746,7 +760,7 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
             settle()
     t_hip = time.perf_counter() - t_hip
     diffs = [a - b for a, b in zip(runs["bf16"], runs["fp32"])]
-    se = lambda v: statistics.stdev(v) / len(v) ** 0.5 if len(v) > 1 else float("nan")
+    seeds = len(diffs)
     d_mean, d_se = statistics.fmean(diffs), se(diffs)
 
     # ---- the CPU oracle on seed 0's weights and batches: timed train steps, first-steps losses, last checkpoint ----------
@@ -800,14 +814,17 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
                  "note": "same weights, same batches (B = 32): step 1 compares forwards on identical weights; from step 2 on Adam's "
                          "first updates (lr x sign of the gradient for every one of 128 M weights) turn bf16 rounding of near-zero "
                          "gradients into whole steps of opposite sign; the two f32 sides differ by summation order only"}
-    val = {"definition": f"validation NMAE on {n_val} held-out samples, mean over every {tail_stride}nd of the last {tail} of {n_steps} Adam "
-                         f"steps at B = {batch}; {seeds} seeds (initial weights + batches), the bf16 and the fp32 run of a seed share both",
+    val = {"definition": f"validation NMAE on {n_val} held-out samples, mean over every {tail_stride}th of the last {tail} of {n_steps} Adam "
+                         f"steps at B = {batch}; {seeds} seeds (initial weights + batches; blocks of {VAL_SEED_BLOCK} until the paired "
+                         f"difference's standard error is <= {VAL_GATE_SE_MAX}, at most {VAL_SEEDS_MAX}), the bf16 and the fp32 run of a seed share both",
+           "n_seeds": seeds,
            "hip_bf16": round(statistics.fmean(runs["bf16"]), 6), "hip_fp32": round(statistics.fmean(runs["fp32"]), 6),
            "seeds": {"hip_bf16": {"runs": [round(v, 5) for v in runs["bf16"]], "standard_error": round(se(runs["bf16"]), 5)},
                      "hip_fp32": {"runs": [round(v, 5) for v in runs["fp32"]], "standard_error": round(se(runs["fp32"]), 5)}},
            "paired_bf16_minus_fp32": {"per_seed": [round(v, 5) for v in diffs], "mean": round(d_mean, 5), "standard_error": round(d_se, 5),
                                       "in_standard_errors": round(abs(d_mean) / d_se, 2) if d_se > 0 else None},
-           "gate_fixed_before_the_first_run": {"abs": VAL_GATE_ABS, "standard_errors": VAL_GATE_SE},
+           "gate": {"abs_mean_at_most": VAL_GATE_ABS, "standard_error_at_most": VAL_GATE_SE_MAX,
+                    "rule": "both clauses; seeds are added until the second holds, the mean is not looked at while adding"},
            "early_train_loss": early_cmp,
            "same_weights_rel_diff": round(same_w, 7),
            "oracle_seed0": {"steps_in_budget": done, "train_seconds": round(train_s, 1)},
@@ -818,7 +835,8 @@ def matched_validation_and_cpu_baseline(dev, history_minutes, seeds=8, n_steps=5
     # are deterministic, so these figures repeat to the digit on a given input.  A bf16 path that lost a further bit of operand
     # precision doubles its step-2 figure; an f32 path that lost accumulation precision breaks the f32 bounds; a forward that
     # drifted from the oracle's breaks step 1 and the same-weights bound
-    checks = {f"|mean paired bf16 - fp32| <= max({VAL_GATE_ABS}, {VAL_GATE_SE} s.e.)": abs(d_mean) <= max(VAL_GATE_ABS, VAL_GATE_SE * d_se),
+    checks = {f"|mean paired bf16 - fp32| <= {VAL_GATE_ABS}": abs(d_mean) <= VAL_GATE_ABS,
+              f"standard error of the paired difference <= {VAL_GATE_SE_MAX}": d_se <= VAL_GATE_SE_MAX,
               "early_loss_first_4_steps_hip_fp32_vs_oracle <= 2e-4": early_cmp["first_4_steps_hip_fp32_vs_oracle"] <= 2e-4,
               "early_loss_step_1_hip_bf16_vs_oracle <= 2e-5": early_cmp["step_1_hip_bf16_vs_oracle"] <= 2e-5,
               "early_loss_step_2_hip_bf16_vs_oracle <= 1.2e-2": early_cmp["step_2_hip_bf16_vs_oracle"] <= 1.2e-2,
@@ -1001,6 +1019,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (matched training + cpu_baseline)")
     ap.add_argument("--no-roofline", action="store_true", help="skip every secondary GPU leg")
     ap.add_argument("--no-extras", action="store_true", help="keep roofline but skip config 3, fp32 and the other models")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the in-process device calibration before the timed steps")
     ap.add_argument("--overlap-update", action="store_true",
                     help="N = 1: launch fc1's fused wgrad+Adam from backward on a side stream (under the conv backward)")
     ap.add_argument("--f32-grads", action="store_true", help="N > 1: all-reduce fc1's gradient in f32 instead of bf16")
@@ -1075,6 +1094,14 @@ def main():
         l = step()
         if i == 0:
             first = float(l.detach())
+    # what THIS device sustains (copy rate, bare bf16 matrix-instruction rate), in this process, right before the timed steps:
+    # one binary runs 1.52-1.71 ms per step across a pool's boxes, so fractions are reported against the spec peaks AND these
+    calibration = None
+    if args.warmup > 0 and not args.no_calibration:
+        from predict_pv_yield_amd import hip_ops as K
+        calibration = K.device_calibration()
+        for _ in range(3):          # back into the step's own rhythm (allocator, clocks) before timing
+            step()
     if distributed:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -1106,6 +1133,7 @@ def main():
                        "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
                        "parallelism": f"dp{world} ({grad_sync_mode})" if world > 1 else "single",
                        "collectives": collectives_info(world, requested_mode if distributed else None, grad_sync_mode)},
+            "device_calibration": calibration,
             "device_clocks_during_timed_steps": clocks.summary(),
             "train_nmae_first_step": round(first, 6) if first is not None else None,
             "train_nmae_last_step": round(last, 6),
@@ -1116,6 +1144,14 @@ def main():
                 out["roofline"] = measure_step_rooflines(step, model, b, t_frames)
                 if "avg_launch_ms" in out["roofline"]:
                     out["roofline"]["share_of_step"] = round(out["roofline"]["avg_launch_ms"] / ms_step, 3)
+                if calibration:      # the same fractions against this device's own rates (scalars: the driver's record keeps them)
+                    r = out["roofline"]
+                    r["calibrated_copy_TBps"], r["calibrated_mfma_bf16_TFLOPs"] = calibration["copy_TBps"], calibration["mfma_bf16_TFLOPs"]
+                    if "achieved" in r:
+                        r["frac_of_calibrated_copy"] = round(r["achieved"] / 1e3 / calibration["copy_TBps"], 4)
+                    r["all_conv_frac_calibrated"] = round(r["all_conv_frac"] * MFMA_BF16_PEAK / 1e12 / calibration["mfma_bf16_TFLOPs"], 4)
+                    if "conv_fwd_dgrad_frac" in r:
+                        r["conv_fwd_dgrad_frac_calibrated"] = round(r["conv_fwd_dgrad_frac"] * MFMA_BF16_PEAK / 1e12 / calibration["mfma_bf16_TFLOPs"], 4)
             else:
                 out["roofline"] = None
             del model, opt, batch
@@ -1147,6 +1183,8 @@ def main():
                         out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
                         out["roofline"]["strong_8gpu_ceiling_over_one_gpu"] = r8.get("ceiling_over_one_gpu")
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
+                    if out["roofline"] is not None:      # (a scalar the driver's record keeps)
+                        out["roofline"]["fp32_samples_per_s"] = out["fp32"]["value"]
                     settle()
                 out["other_models"] = measure_other_models(dev)
                 settle()
@@ -1157,6 +1195,7 @@ def main():
             if out.get("roofline"):      # scalars the driver's record keeps
                 out["roofline"]["val_nmae_bf16_minus_fp32"] = out["val_nmae"]["paired_bf16_minus_fp32"]["mean"]
                 out["roofline"]["val_nmae_bf16_minus_fp32_se"] = out["val_nmae"]["paired_bf16_minus_fp32"]["standard_error"]
+                out["roofline"]["val_nmae_seeds"] = out["val_nmae"]["n_seeds"]
                 out["roofline"]["val_nmae_pass"] = out["val_nmae"]["pass"]
             flow_cpu = flow_cpu_baseline()
             if "config3" in out:

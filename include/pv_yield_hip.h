@@ -618,6 +618,15 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
 int pv_stage_timing_begin(void);
 int pv_stage_timing_end(const char** names, float* ms, int32_t* counts, int32_t capacity, int32_t* n_out);
 
+/* ---- device calibration (bench.py `device_calibration`) -------------------------------------------------------------
+ * The reference quotes wall-clock timings per box (notebooks/optical_flow_1.ipynb:269, experiments/2021-08/2021-08-31/
+ * experiments.txt:5-6); here every roofline fraction is also reported against what THIS device sustains, measured in-process
+ * right before the timed steps: a plain 16-byte-per-lane copy of n floats (bytes moved = 8 n), and `workgroups` x 4 waves x
+ * `iters` x 8 back-to-back v_mfma_f32_16x16x32_bf16 (16 384 flop each) on register operands.  sink: device f32[workgroups],
+ * never written in practice.  Not part of the product path. */
+int pv_calibrate_copy_f32(const float* src, float* dst, size_t n, void* stream);
+int pv_calibrate_mfma_bf16(float* sink, int32_t workgroups, int32_t iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

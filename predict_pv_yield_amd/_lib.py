@@ -110,6 +110,8 @@ SIGNATURES = {
     "pv_relu_mask_dims": [c_i32, c_i32, c_vp, c_vp],
     "pv_stage_timing_begin": [],
     "pv_stage_timing_end": [c_vp, c_vp, c_vp, c_i32, c_vp],
+    "pv_calibrate_copy_f32": [c_vp, c_vp, c_sz, c_vp],
+    "pv_calibrate_mfma_bf16": [c_vp, c_i32, c_i32, c_vp],
     "pv_conv3d_fwd_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_int, c_vp],
     "pv_conv3d_fwd_bf16_f32in": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, _PCD, c_int, c_vp],
     "pv_conv3d_bwd_weight_bf16_workspace_bytes": [_PCD, ctypes.POINTER(c_sz)],

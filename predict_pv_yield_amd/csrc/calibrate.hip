@@ -1,0 +1,73 @@
+// Device calibration for the bench line: one binary reads 1.52-1.71 ms per train step across the boxes of a
+// pool, so a fraction of the SPEC peak cannot tell a 4 % kernel gain from a lucky lease.  Two microkernels, timed by bench.py
+// with HIP events right before the timed steps, give what THIS device sustains:
+//   pv_calibrate_copy_f32     a plain 16-bytes-per-lane device copy (the guide's 6.29 TB/s figure is this kernel's shape)
+//   pv_calibrate_mfma_bf16    back-to-back v_mfma_f32_16x16x32_bf16 on operands in registers (the instruction of the Conv3D
+//                             kernels), non-trivial data -- the clock a chip holds under matrix load depends on the operands
+// Nothing in the product path calls them.
+#include "pv_common.h"
+
+namespace pv {
+
+__global__ __launch_bounds__(256) void calibrate_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+// one wave per SIMD and workgroup (256 threads), WG_PER_CU workgroups per CU; eight independent accumulators per wave, so the
+// matrix pipe never waits for a result (the guide: 16 cycles per 16x16x32 on one SIMD whatever the number of accumulators)
+__global__ __launch_bounds__(256) void calibrate_mfma_bf16_kernel(float* __restrict__ sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  // operands from a hash of the lane: normal-sized bf16 values of both signs (0x3f80 +- a few mantissa bits)
+  bf16x8 a, b;
+  uint32_t h = 0x9e3779b9u * (uint32_t)(threadIdx.x + 1) + 0x85ebca6bu * (uint32_t)(blockIdx.x + 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h = h * 1664525u + 1013904223u;
+    const uint16_t ua = (uint16_t)(0x3f00u | ((h >> 9) & 0x7fu) | ((h >> 3) & 0x8000u));
+    const uint16_t ub = (uint16_t)(0x3e80u | ((h >> 17) & 0x7fu) | ((h >> 1) & 0x8000u));
+    a[i] = __builtin_bit_cast(__bf16, ua);
+    b[i] = __builtin_bit_cast(__bf16, ub);
+  }
+  f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    // (accumulators pinned to the accumulation registers in place: as a plain array the compiler rotated them through
+    // v_accvgpr moves, 40 per iteration)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %8, %9, %0\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %1, %8, %9, %1\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %2, %8, %9, %2\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %3, %8, %9, %3\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %4, %8, %9, %4\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %5, %8, %9, %5\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %6, %8, %9, %6\n\t"
+                 "v_mfma_f32_16x16x32_bf16 %7, %8, %9, %7"
+                 : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7)
+                 : "v"(a), "v"(b));
+  }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // (the last results leave the matrix pipe before they are read)
+  const f32x4 s = ((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7));
+  if (lane == 0 && s[0] == 12345.678f) sink[blockIdx.x] = s[0] + s[1] + s[2] + s[3];      // (keeps the loop alive)
+}
+
+}  // namespace pv
+
+extern "C" {
+
+int pv_calibrate_copy_f32(const float* src, float* dst, size_t n, void* stream) {
+  PV_REQUIRE(src && dst, PV_EINVAL, "pv_calibrate_copy_f32: null pointer");
+  PV_REQUIRE(n % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0, PV_EINVAL, "pv_calibrate_copy_f32: 16-byte vectors");
+  if (n == 0) return PV_OK;
+  hipLaunchKernelGGL(pv::calibrate_copy_kernel, dim3(pv::kNumCU * 8), dim3(256), 0, pv::as_stream(stream),
+                     reinterpret_cast<const pv::f32x4*>(src), reinterpret_cast<pv::f32x4*>(dst), n / 4);
+  return pv::check_launch("pv_calibrate_copy_f32");
+}
+
+int pv_calibrate_mfma_bf16(float* sink, int32_t workgroups, int32_t iters, void* stream) {
+  PV_REQUIRE(sink, PV_EINVAL, "pv_calibrate_mfma_bf16: null pointer");
+  PV_REQUIRE(workgroups > 0 && iters > 0, PV_EINVAL, "pv_calibrate_mfma_bf16: workgroups, iters > 0");
+  hipLaunchKernelGGL(pv::calibrate_mfma_bf16_kernel, dim3(workgroups), dim3(256), 0, pv::as_stream(stream), sink, iters);
+  return pv::check_launch("pv_calibrate_mfma_bf16");
+}
+
+}  // extern "C"

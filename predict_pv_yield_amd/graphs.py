@@ -45,14 +45,18 @@ def _clone_keeping_marks(t: torch.Tensor) -> torch.Tensor:
     return c
 
 
+class GraphBatchMismatch(ValueError):
+    """The batch handed to a captured step differs (shape, dtype or mark) from the one it was captured for."""
+
+
 def _copy_into(dst: Any, src: Any) -> None:
     if torch.is_tensor(dst):
         for name in _TENSOR_MARKS:
             if bool(getattr(dst, name, False)) != bool(getattr(src, name, False)):
-                raise ValueError(f"GraphedTrainStep: batch tensor mark {name} = {getattr(src, name, False)!r} differs from the "
+                raise GraphBatchMismatch(f"GraphedTrainStep: batch tensor mark {name} = {getattr(src, name, False)!r} differs from the "
                                  f"captured step's ({getattr(dst, name, False)!r}): the captured step was recorded for the other form")
         if dst.shape != src.shape or dst.dtype != src.dtype:
-            raise ValueError(f"GraphedTrainStep: batch tensor {tuple(src.shape)} {src.dtype} does not match the captured "
+            raise GraphBatchMismatch(f"GraphedTrainStep: batch tensor {tuple(src.shape)} {src.dtype} does not match the captured "
                              f"{tuple(dst.shape)} {dst.dtype} (a graph replays fixed shapes)")
         dst.copy_(src, non_blocking=True)
     elif isinstance(dst, dict):

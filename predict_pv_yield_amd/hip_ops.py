@@ -473,6 +473,36 @@ class stage_timing:
         return False
 
 
+def device_calibration(copy_floats: int = 128 * 1003520, mfma_iters: int = 20000, reps: int = 5) -> dict:
+    """What THIS device sustains, measured with HIP events on the current stream (pv_calibrate_*): a plain device copy of
+    `copy_floats` floats (default: the size of fc1's weight) and a bare bf16 matrix-instruction loop on every SIMD."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = torch.empty(copy_floats, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    wgs = 256 * 2                                   # two 4-wave workgroups per CU: two waves per SIMD
+    sink = torch.zeros(wgs, dtype=torch.float32, device=dev)
+    lib = get_lib()
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3       # seconds per call
+
+    t_copy = timed(lambda: check(lib.pv_calibrate_copy_f32(ptr(a), ptr(b), copy_floats, current_stream_ptr()), "pv_calibrate_copy_f32"), reps * 2)
+    t_mfma = timed(lambda: check(lib.pv_calibrate_mfma_bf16(ptr(sink), wgs, mfma_iters, current_stream_ptr()), "pv_calibrate_mfma_bf16"), reps)
+    flops = wgs * 4 * mfma_iters * 8 * 16384.0
+    return {"copy_TBps": round(8.0 * copy_floats / t_copy / 1e12, 3), "copy_bytes": 8 * copy_floats,
+            "mfma_bf16_TFLOPs": round(flops / t_mfma / 1e12, 1), "mfma_ms": round(t_mfma * 1e3, 3),
+            "what": "pv_calibrate_copy_f32 (16 B per lane, read + write bytes) and pv_calibrate_mfma_bf16 (v_mfma_f32_16x16x32_bf16 "
+                    "back to back on register operands, two waves per SIMD, non-trivial data), HIP events, this process, this device"}
+
+
 def relu_mask_shape(b: int, t: int, h: int, w: int):
     """Shape of the 1-bit relu mask of an NDHWC activation [b, t, h, w, 32]: int32 [b, t, hp, wp], the plane padded to
     whole 8 x 32 tiles (pv_relu_mask_dims)."""

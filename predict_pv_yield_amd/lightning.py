@@ -461,7 +461,7 @@ class Trainer:
     def _graph_train_step(self, model, batch, batch_idx) -> bool:
         """One train step in graph mode: True if it ran here (captured replay), False if the caller's eager path must run it
         (the first steps, or a batch whose shapes differ from the captured one)."""
-        from .graphs import GraphedTrainStep
+        from .graphs import GraphBatchMismatch, GraphedTrainStep
         if self._graph_step is None:
             if self._graph_eager < self.GRAPH_EAGER_STEPS:
                 # ordinary steps, but on a side stream: the parameters' gradient-accumulation nodes are created by the first
@@ -490,7 +490,11 @@ class Trainer:
             del self._pending_logs[n0:]
         try:
             loss = self._timed("training_step", self._graph_step, batch)
-        except ValueError:          # other shapes (a ragged last batch): this one runs eagerly
+        except GraphBatchMismatch:
+            # other shapes (a ragged last batch): this one runs eagerly.  The graph is released first: while it lives the
+            # optimiser's layout is frozen, and an eager step of a shape the one-pass fc1 backward does not take would have to
+            # convert the tiled moments in place (HipAdam._moments_rows raises); the next matching batch captures again
+            self._leave_graph_mode()
             return False
         for keys, vec, on_step, on_epoch, _ in self._graph_logs:
             self._pending_logs.append((keys, vec.clone(), on_step, on_epoch, self.global_step))

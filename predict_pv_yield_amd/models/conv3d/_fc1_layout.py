@@ -12,9 +12,10 @@ What leaves or enters the process is the reference's layout:
   * Module.state_dict() / load_state_dict(): hooks below (checkpoints are interchangeable with the reference's);
   * HipAdam.state_dict() / load_state_dict() / moments(): the two moment tensors of a marked parameter, likewise;
   * reference_layout(param, tensor): for anyone who reads `model.fc1.weight` (or a gradient of it) directly.
-The mark is `param._pv_k_channels = C` (0 / absent: reference order); Model._mark_fc1_layout() sets it in __init__ and again in
-configure_optimizers() (copy.deepcopy of a module creates fresh Parameter objects without Python attributes; the module-level
-`_fc1_k_channels` is what survives and is re-applied)."""
+The mark is `param._pv_k_channels = C` (0 / absent: reference order).  The MODULE attribute `_fc1_k_channels` is the truth:
+copy.deepcopy / pickle / a converting _apply create fresh Parameter objects without Python attributes, so Model re-applies the
+mark in __setstate__, _apply, forward() and configure_optimizers() (Model._mark_fc1_layout), and `Model.precision` is
+read-only after construction -- the stored column order cannot come apart from the arithmetic that reads it."""
 import torch
 
 

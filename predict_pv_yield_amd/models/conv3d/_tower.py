@@ -29,6 +29,9 @@ def conv_tower_fc1(data: torch.Tensor, convs, fc1, c_in: int, channels: int, pad
     """relu(fc1(flatten_NCDHW(relu(conv_n(... relu(conv_0(data))))))) — model.py:117-125 / model_sat_nwp.py:188-197,236-246.
     fc1_channels_last (bf16 tower): fc1.weight's columns are stored in (t, h, w, c) order (_fc1_layout.py), so the last layer
     writes NDHWC like every other and fc1's input gradient returns in the order its dgrad reads."""
+    if fc1_channels_last and not use_bf16:
+        raise RuntimeError("fc1.weight is stored channels-last (bf16 tower, models/conv3d/_fc1_layout.py) but the f32 tower was "
+                           "asked for: it flattens NCDHW and would multiply by column-permuted weights")
     if not data.is_cuda:
         raise RuntimeError("predict_pv_yield_amd Conv3D model runs on the MI355X only: move the module and the "
                            "batch to cuda (there is no CPU fallback)")

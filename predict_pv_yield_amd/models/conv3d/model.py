@@ -66,7 +66,7 @@ class Model(BaseModel):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         if future_frames not in ("true", "optical_flow"):
             raise ValueError("future_frames must be 'true' or 'optical_flow'")
-        self.precision = precision
+        self.__dict__["_precision"] = precision      # read-only from here on (property below): fc1's stored layout follows it
         self.future_frames = future_frames
         self.number_sat_channels = number_sat_channels
         self.conv3d_channels = conv3d_channels
@@ -109,9 +109,33 @@ class Model(BaseModel):
     def _conv_layers(self):
         return [self.sat_conv0] + [getattr(self, f"conv3d_{i + 1}") for i in range(self.number_of_conv3d_layers - 1)]
 
+    @property
+    def precision(self) -> str:
+        """ "bf16" | "fp32", fixed at construction: the bf16 tower stores fc1.weight's columns channels-last
+        (_fc1_layout.py); flipping the arithmetic afterwards would multiply an NCDHW flatten by a column-permuted weight."""
+        return self.__dict__["_precision"]
+
+    @precision.setter
+    def precision(self, value):
+        raise AttributeError("Model.precision is fixed at construction (fc1.weight's stored column order depends on it): "
+                             "build Model(precision=...) and load_state_dict() instead")
+
     def _mark_fc1_layout(self) -> None:
         from . import _fc1_layout
         _fc1_layout.mark(self)
+
+    # The layout mark of fc1.weight is a Python attribute of the Parameter object; whatever creates fresh Parameter objects
+    # (copy.deepcopy / pickle: __setstate__; .to() / .half() / .cuda() of a module whose parameters get replaced: _apply)
+    # loses it, while the MODULE attribute `_fc1_k_channels` -- the truth -- survives.  Re-applied after each of them and at the
+    # top of forward(), so HipAdam(model.parameters()) sees the mark however the module came to be.
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._mark_fc1_layout()
+        return out
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._mark_fc1_layout()
 
     def _bf16_supported(self) -> bool:
         from ._tower import bf16_tower_supported
@@ -142,6 +166,7 @@ class Model(BaseModel):
         sat_data = self._satellite_input(x)
         from ... import functional as Fn
         from ._tower import conv_tower_fc1
+        self._mark_fc1_layout()
 
         batch_size = sat_data.shape[0]
         out = conv_tower_fc1(sat_data, self._conv_layers(), self.fc1, self.number_sat_channels, self.conv3d_channels,

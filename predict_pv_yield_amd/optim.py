@@ -101,6 +101,9 @@ class HipAdam(torch.optim.Optimizer):
     def set_large_grad_mode(self, mode: str) -> None:
         if mode not in ("fused", "bf16", "sharded", "autograd"):
             raise ValueError(mode)
+        if getattr(self, "_layout_frozen", False) and mode != getattr(self, "large_grad_mode", mode):
+            raise RuntimeError("HipAdam.set_large_grad_mode(): a captured HIP graph holds this optimiser's state tensors and the "
+                               "gradient mode it was captured with -- release the graph first (GraphedTrainStep.close())")
         if mode == "sharded":
             from . import distributed as D
             if any(D.row_shard(p.shape[0]) is None for p in self.large_params()):
@@ -166,7 +169,9 @@ class HipAdam(torch.optim.Optimizer):
         """graphs.GraphedTrainStep: from the capture until the graph is released the state tensors of this optimiser are never
         replaced (a replay writes to the addresses it recorded).  state_dict() / moments() then hand out row-major COPIES of
         tiled moments instead of converting them in place; anything that would have to convert in place raises."""
-        self._layout_frozen = bool(frozen)
+        # a counter: two GraphedTrainSteps on one optimiser each freeze once; the layout thaws when the last one is released
+        self._freeze_count = max(0, getattr(self, "_freeze_count", 0) + (1 if frozen else -1))
+        self._layout_frozen = self._freeze_count > 0
 
     def _moments_rows(self, p=None) -> None:
         """Back to row-major (torch's layout) for p, or for every parameter: before anything but the one-pass backward
@@ -240,6 +245,11 @@ class HipAdam(torch.optim.Optimizer):
         return sd
 
     def load_state_dict(self, state_dict):
+        if self._layout_frozen:
+            # super().load_state_dict() REPLACES the state tensors; a captured graph would keep replaying on the old addresses
+            # (with moments_tiled = 1 baked into its kernel arguments) and silently ignore the loaded state
+            raise RuntimeError("HipAdam.load_state_dict(): a captured HIP graph (graphs.GraphedTrainStep) holds this optimiser's "
+                               "state tensors -- release the graph first (GraphedTrainStep.close()), load, capture again")
         super().load_state_dict(state_dict)
         for p in self._params_in_order():
             c = self._k_channels(p)

@@ -45,10 +45,9 @@ def test_state_dict_speaks_the_reference_layout():
     assert torch.equal(model.fc1.weight.detach(), L.to_channels_last(keep["fc1.weight"], 32))
     assert torch.equal(model.state_dict()["fc1.weight"], keep["fc1.weight"])
     assert torch.equal(L.reference_layout(model.fc1.weight), keep["fc1.weight"])
-    # a deep copy keeps the layout (module attribute + hooks) and gets its parameter mark back from configure_optimizers()
+    # a deep copy keeps the layout (module attribute + hooks) AND the parameter mark (Model.__setstate__)
     twin = copy.deepcopy(model)
     assert torch.equal(twin.state_dict()["fc1.weight"], keep["fc1.weight"])
-    twin.configure_optimizers()
     assert L.k_channels(twin.fc1.weight) == 32
     # the f32 model keeps the reference's order in memory
     plain = Model(**KW, precision="fp32")
@@ -97,3 +96,62 @@ def test_a_deep_copied_optimizer_still_knows_the_layout():
     q = [t for g in twin.param_groups for t in g["params"] if t.shape == p.shape][0]
     assert not hasattr(q, "_pv_k_channels")
     assert torch.equal(twin.moments(q)[0], ref)
+
+
+def test_the_layout_mark_follows_the_module_not_the_parameter_object():
+    """ADVICE r5: whatever creates fresh Parameter objects (deepcopy, pickle, a converting _apply) drops their Python attributes;
+    the module re-applies the mark, so HipAdam(copied_model.parameters()) -- built WITHOUT configure_optimizers() -- still
+    writes and reads checkpoints in the reference's column order."""
+    import pickle
+    torch.manual_seed(3)
+    model = Model(**KW, precision="bf16")
+    ref_w = model.state_dict()["fc1.weight"].clone()
+    for twin in (copy.deepcopy(model), pickle.loads(pickle.dumps(model))):
+        assert L.k_channels(twin.fc1.weight) == 32
+        assert torch.equal(twin.state_dict()["fc1.weight"], ref_w)
+        opt = HipAdam(twin.parameters(), lr=5e-4)                 # not through configure_optimizers()
+        p = twin.fc1.weight
+        st = opt._init_state(p)
+        st["exp_avg"].copy_(torch.randn_like(p))
+        st["exp_avg_sq"].copy_(torch.rand_like(p))
+        stored = st["exp_avg"].clone()
+        idx = [i for i, q in enumerate(opt._params_in_order()) if q is p][0]
+        sd = opt.state_dict()
+        assert torch.equal(sd["state"][idx]["exp_avg"], L.to_reference(stored, 32))      # reference order leaves
+        opt2 = HipAdam(copy.deepcopy(twin).parameters(), lr=5e-4)
+        full = {"state": {i: {"step": torch.tensor(1.0), "exp_avg": torch.zeros_like(q), "exp_avg_sq": torch.zeros_like(q)}
+                          for i, q in enumerate(opt2._params_in_order())}, "param_groups": sd["param_groups"]}
+        full["state"][idx] = copy.deepcopy(sd["state"][idx])
+        opt2.load_state_dict(full)                                                       # ... and enters
+        assert torch.equal(opt2.state[opt2._params_in_order()[idx]]["exp_avg"], stored)
+    # an _apply that REPLACES the parameters (torch.__future__ overwrite mode, as .to(device) does for some backends)
+    torch.__future__.set_overwrite_module_params_on_conversion(True)
+    try:
+        old = model.fc1.weight
+        model.double()
+        assert model.fc1.weight is not old and L.k_channels(model.fc1.weight) == 32
+        model.float()
+        assert L.k_channels(model.fc1.weight) == 32
+    finally:
+        torch.__future__.set_overwrite_module_params_on_conversion(False)
+    # a mark removed by hand comes back at the next forward (it raises for the CPU tensor, but after marking)
+    del model.fc1.weight._pv_k_channels
+    x = {"satellite": {"data": torch.zeros(1, 11, 25, 16, 16)}}
+    try:
+        model(x)
+    except Exception:
+        pass
+    assert L.k_channels(model.fc1.weight) == 32
+
+
+def test_precision_is_fixed_at_construction():
+    import pytest
+    from predict_pv_yield_amd.models.conv3d._tower import conv_tower_fc1
+    model = Model(**KW, precision="bf16")
+    assert model.precision == "bf16"
+    with pytest.raises(AttributeError, match="fixed at construction"):
+        model.precision = "fp32"
+    # and the tower itself refuses the combination the setter used to allow: channels-last weights under the f32 arithmetic
+    with pytest.raises(RuntimeError, match="channels-last"):
+        conv_tower_fc1(torch.zeros(1, 11, 25, 16, 16), model._conv_layers(), model.fc1, 11, 32, (0, 0, 0), model.cnn_output_size,
+                       use_bf16=False, fc1_channels_last=True)
