@@ -421,6 +421,14 @@ int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_av
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,
                           int32_t step, float grad_scale, void* stream);
 
+/* replaces: the bias + ReLU epilogue of `F.relu(self.fc1(out))` (predict_pv_yield/models/conv3d/model.py:125) when fc1's
+ * product was summed OUTSIDE the kernel -- the K-sharded data-parallel mode, where every rank multiplies its column shard of
+ * the weight and the partial products are added in rank order -- and the 1 / world scaling of an output gradient
+ * (the averaging of DDP's all-reduce, experiments/003_...py:292-293):  y[i][j] = act(alpha x[i][j] + bias[j]),
+ * bias may be NULL, relu != 0 applies max(., 0) (a NaN stays a NaN); y may alias x. */
+int pv_scale_bias_relu_f32(const float* x, const float* bias, float* y, int32_t m, int32_t n, float alpha, int32_t relu,
+                           void* stream);
+
 /* dst[i] = bf16(src[i]) (round to nearest even): first fill of a parameter's bf16 shadow; afterwards
  * pv_adam_step_f32 keeps the shadow current. */
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream);

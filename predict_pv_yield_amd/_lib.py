@@ -190,6 +190,7 @@ SIGNATURES = {
     "pv_embedding_fwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_embedding_bwd_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp],
     "pv_cast_f32_to_bf16": [c_vp, c_vp, c_sz, c_vp],
+    "pv_scale_bias_relu_f32": [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_i32, c_vp],
     "pv_relu_gate_f32": [c_vp, c_vp, c_vp, c_sz, c_vp],
     "pv_relu_gate_max_f32": [c_vp, c_vp, c_vp, c_sz, c_vp, c_vp],
     "pv_forecast_losses_f32": [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],

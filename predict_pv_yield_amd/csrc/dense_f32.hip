@@ -474,6 +474,18 @@ __global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __re
   }
 }
 
+// y[i][j] = act(alpha x[i][j] + bias[j]): the epilogue of a Linear whose product was summed elsewhere (K-sharded fc1: partial
+// products of the ranks' column shards), and the 1 / world scaling of an output gradient
+__global__ __launch_bounds__(256) void scale_bias_relu_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                               float* __restrict__ y, size_t total, int n, float alpha, int relu) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    float v = __fmul_rn(alpha, x[i]);
+    if (bias) v = __fadd_rn(v, bias[i % (size_t)n]);
+    y[i] = (relu && !(v > 0.f)) ? (v != v ? v : 0.f) : v;      // (a NaN stays a NaN, as torch's relu keeps it)
+  }
+}
+
 // ---- embedding (nn.Embedding(940, 16) on pv_system_row_number / gsp_id, model_sat_nwp.py:149-151,251-260) ------------
 __global__ __launch_bounds__(256) void embedding_fwd_f32(const float* __restrict__ table, const int64_t* __restrict__ ids,
                                                           float* __restrict__ out, int n_ids, int dim, int n_rows) {
@@ -711,6 +723,17 @@ int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream)
   hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(stream_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), src,
                      dst, n);
   return check_launch("pv_cast_f32_to_bf16");
+}
+
+int pv_scale_bias_relu_f32(const float* x, const float* bias, float* y, int32_t m, int32_t n, float alpha, int32_t relu,
+                           void* stream) {
+  PV_REQUIRE(x && y, PV_EINVAL, "pv_scale_bias_relu_f32: null pointer");
+  PV_REQUIRE(m >= 0 && n > 0, PV_ESIZE, "pv_scale_bias_relu_f32: bad sizes");
+  const size_t total = (size_t)m * (size_t)n;
+  if (total == 0) return PV_OK;
+  hipLaunchKernelGGL(scale_bias_relu_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream), x, bias, y, total, n,
+                     alpha, relu);
+  return check_launch("pv_scale_bias_relu_f32");
 }
 
 int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint16_t* bf16_shadow,

@@ -170,6 +170,109 @@ def all_gather_rows(full: torch.Tensor, async_op: bool = True):
     return None
 
 
+# ---- K-sharded fc1 (HipAdam large_grad_mode "ksharded"; VERDICT r5 item 3, SURVEY section 8e "alternative noted") ---------------
+# The conv tower stays data-parallel; fc1's COLUMNS (its 1 003 520 input features) are dealt over the ranks, rank r owning
+# columns [r K/W, (r+1) K/W) of the weight, its moments and its bf16 operand copy for ALL samples of the global batch.  Per step
+# a rank exchanges activations instead of weights: its samples' last-layer activation goes out by one all-to-all ([B, K/W]
+# slices, forward), the input gradient comes back by another (backward), plus a reduce-scatter of the [W B, N] partial outputs
+# and an all-gather of the [B, N] output gradients -- 2 x 56 MB per rank and step at B = 32, W = 8 instead of the 2 x 257 MB of
+# the row-sharded exchange, no weight or gradient of fc1 ever crosses a link, and fc1's traffic (3.47 GB of p / m / v per step
+# on one GPU) divides by W.  The reference's DDP all-reduce (experiments/003_...py:292-293) has no counterpart for this layer.
+def column_shard(n_cols: int, rank: int = None, world: int = None, multiple: int = 8):
+    """Equal column shard [k0, k1) of a matrix; None if the columns do not divide into shards of a multiple of `multiple`."""
+    if rank is None:
+        rank = dist.get_rank() if is_distributed() else 0
+    if world is None:
+        world = dist.get_world_size() if is_distributed() else 1
+    if n_cols % world != 0 or (n_cols // world) % multiple != 0:
+        return None
+    per = n_cols // world
+    return rank * per, (rank + 1) * per
+
+
+def all_to_all_columns(x_local: torch.Tensor) -> torch.Tensor:
+    """x_local [B, K] (this rank's samples, all columns) -> [W B, K/W] (ALL samples in rank order, this rank's columns).
+    RCCL: one all_to_all_single of W chunks [B, K/W] (the chunk-major staging copy is the only extra pass); gloo (tests):
+    all-gather + slice, same bytes in the same places."""
+    world = dist.get_world_size()
+    b, k = x_local.shape
+    kr = k // world
+    if dist.get_backend() == "nccl":
+        send = x_local.view(b, world, kr).transpose(0, 1).contiguous()          # [W, B, K/W]: chunk s = my samples, rank s's columns
+        recv = torch.empty_like(send)                                            # chunk s = rank s's samples, my columns
+        dist.all_to_all_single(recv, send)
+        return recv.view(world * b, kr)
+    r = dist.get_rank()
+    full = [torch.empty_like(x_local) for _ in range(world)]
+    dist.all_gather(full, x_local.contiguous())
+    return torch.cat([t[:, r * kr:(r + 1) * kr] for t in full], dim=0).contiguous()
+
+
+def all_to_all_rows_back(dx_cols: torch.Tensor) -> torch.Tensor:
+    """The inverse exchange: dx_cols [W B, K/W] (all samples, this rank's columns) -> [B, K] (this rank's samples, all columns)."""
+    world = dist.get_world_size()
+    wb, kr = dx_cols.shape
+    b = wb // world
+    if dist.get_backend() == "nccl":
+        send = dx_cols.contiguous().view(world, b, kr)                           # chunk s = rank s's samples, my columns
+        recv = torch.empty_like(send)                                            # chunk s = my samples, rank s's columns
+        dist.all_to_all_single(recv, send)
+        return recv.transpose(0, 1).reshape(b, world * kr)
+    r = dist.get_rank()
+    full = [torch.empty_like(dx_cols) for _ in range(world)]
+    dist.all_gather(full, dx_cols.contiguous())
+    return torch.cat([t[r * b:(r + 1) * b] for t in full], dim=1).contiguous()
+
+
+def reduce_scatter_sample_rows(partial: torch.Tensor) -> torch.Tensor:
+    """partial [W B, N] (every rank's partial sums for ALL samples) -> the summed rows of this rank's samples [B, N].
+    The sum runs in RANK ORDER on every backend (all-gather of the W slices this rank needs, then a fixed-order add): the
+    K-sharded forward must not depend on a collective's internal reduction order -- 2 x the bytes of a reduce-scatter on a
+    [W B, 128] f32 matrix (128 KB at B = 32, W = 8) buys bit-reproducibility across backends and runs."""
+    world = dist.get_world_size()
+    wb, n = partial.shape
+    b = wb // world
+    if dist.get_backend() == "nccl":
+        send = partial.contiguous().view(world, b, n)
+        recv = torch.empty_like(send)                    # chunk s = rank s's partial sums for MY samples
+        dist.all_to_all_single(recv, send)
+    else:
+        r = dist.get_rank()
+        full = [torch.empty_like(partial) for _ in range(world)]
+        dist.all_gather(full, partial.contiguous())
+        recv = torch.stack([t[r * b:(r + 1) * b] for t in full])
+    if recv.is_cuda:
+        from . import hip_ops as K      # pv_colsum_f32 over the W slices: partial sums added in rank order
+        return K.colsum(recv.view(world, b * n)).view(b, n)
+    out = recv[0].clone()               # (CPU tensors: the gloo tests of the exchange itself)
+    for s_ in range(1, world):
+        out += recv[s_]
+    return out
+
+
+def all_gather_sample_rows(local: torch.Tensor) -> torch.Tensor:
+    """local [B, N] (this rank's samples) -> [W B, N] (all samples, rank order)."""
+    world = dist.get_world_size()
+    local = local.contiguous()
+    if dist.get_backend() == "nccl":
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+        return out
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    return torch.cat(parts, dim=0)
+
+
+def all_gather_columns(shard: torch.Tensor, full: torch.Tensor) -> None:
+    """Every rank's column shard [N, K/W] into `full` [N, K] (checkpoints: HipAdam.consolidate_sharded)."""
+    world = dist.get_world_size()
+    kr = shard.shape[1]
+    parts = [torch.empty_like(shard) for _ in range(world)]
+    dist.all_gather(parts, shard.contiguous())
+    for r, t in enumerate(parts):
+        full[:, r * kr:(r + 1) * kr].copy_(t)
+
+
 class OverlappedGradSync:
     """DDP-style overlap: the all-reduce of a LARGE parameter's gradient is launched from an autograd hook the
     moment that gradient is final, on RCCL's own stream, and is waited for only before the optimiser step.
@@ -249,7 +352,8 @@ class OverlappedGradSync:
                 del p._pv_on_grad
 
 
-_FALLBACKS = {"sharded": ("sharded", "bf16", "autograd"), "bf16": ("bf16", "autograd"), "autograd": ("autograd",)}
+_FALLBACKS = {"ksharded": ("ksharded", "sharded", "bf16", "autograd"), "sharded": ("sharded", "bf16", "autograd"),
+              "bf16": ("bf16", "autograd"), "autograd": ("autograd",)}
 
 
 def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str, allow_demotion: bool = True) -> str:
@@ -338,6 +442,7 @@ def negotiate_grad_sync(model: torch.nn.Module, optimizer, batch, mode: str, all
         # drop whatever the failed attempt left behind, then make the replicas identical again
         for p in optimizer.large_params():
             p._pv_pending = p._pv_grad_bf16 = p._pv_grad_shard = None
+            p._pv_kshard_pending = None
             p._pv_shadow_work = None
             if hasattr(p, "_pv_bf16_shadow"):
                 del p._pv_bf16_shadow

@@ -332,6 +332,52 @@ class LinearBF16(torch.autograd.Function):
         return dx, dw, (db if ctx.has_bias else None), None, None
 
 
+class LinearBF16KSharded(torch.autograd.Function):
+    """fc1 with its COLUMNS dealt over the data-parallel ranks (HipAdam large_grad_mode "ksharded", distributed.py): the
+    ranks exchange the last conv layer's ACTIVATIONS (one all-to-all each way) instead of fc1's gradient or weights.
+      forward   x_cols = all_to_all(x) [W B, K/W]; partial = x_cols . W[:, shard]^T (the same streaming kernel, on the shard);
+                y = relu(sum over ranks in rank order of the partial rows of this rank's samples + bias)
+      backward  g = dy * (y > 0); g_all = all_gather(g) [W B, N]; dx_cols = g_all . W[:, shard] (gated by x > 0 when x is a
+                ReLU output) -> all_to_all back [B, K]; (x_cols, g_all) are parked on the parameter: HipAdam.step() forms this
+                rank's columns of the weight gradient over the WHOLE global batch inside its Adam pass over the shard.
+    The reference's counterpart is DDP's all-reduce of fc1.weight.grad (experiments/003_...py:292-293): same update, up to
+    f32 summation order, without moving 0.5 GB per rank and step."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, x_is_relu_output=False):
+        from . import distributed as D
+        ks = weight._pv_kshard
+        x_cols = D.all_to_all_columns(x.contiguous())
+        partial = K.linear_fwd_bf16(x_cols, ks["shadow"], None, False)
+        y = K.scale_bias_relu_f32(D.reduce_scatter_sample_rows(partial), bias.contiguous() if bias is not None else None, 1.0, relu)
+        ctx.save_for_backward(x_cols, y if relu else None)
+        ctx.cfg = (bias is not None, bool(x_is_relu_output), x.shape[0])
+        ctx.weight_param = weight
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import distributed as D
+        x_cols, y = ctx.saved_tensors
+        has_bias, x_is_relu_output, b_local = ctx.cfg
+        weight = ctx.weight_param
+        ks = weight._pv_kshard
+        g = K.relu_gate_f32(dy.contiguous(), y) if y is not None else dy.contiguous()
+        g_all = D.all_gather_sample_rows(g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx_cols, _, _ = K.linear_bwd_bf16(x_cols, ks["shadow"], g_all, None, need_dx=True, need_dw=False,
+                                              gate_dx_by_x=x_is_relu_output)
+            dx = D.all_to_all_rows_back(dx_cols)
+            if x_is_relu_output:
+                _mark_pregated(dx)
+        if getattr(weight, "_pv_kshard_pending", None) is not None:
+            raise RuntimeError("K-sharded fc1: backward() ran twice without optimizer.step() in between (gradient accumulation "
+                               "needs another large_grad_mode)")
+        weight._pv_kshard_pending = (x_cols, g_all)
+        return dx, None, (K.colsum(g) if has_bias else None), None, None
+
+
 def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncdhw=False, x_is_relu_output=False,
                      dy_pregated=False, x_relu_mask=None, want_relu_mask=False):
     """x_is_relu_output: xp is the ReLU output of the previous conv3d_relu_bf16 (its dgrad then gates dx itself);
@@ -344,6 +390,8 @@ def conv3d_relu_bf16(xp, weight, bias, c_in, padding=(0, 0, 0), relu=True, y_ncd
 
 
 def linear_bf16(x, weight, bias, relu=False, x_is_relu_output=False):
+    if getattr(weight, "_pv_grad_mode", None) == "ksharded" and getattr(weight, "_pv_kshard", None) is not None:
+        return LinearBF16KSharded.apply(x, weight, bias, relu, x_is_relu_output)
     return LinearBF16.apply(x, weight, bias, relu, x_is_relu_output)
 
 

@@ -845,6 +845,30 @@ def adam_step_bf16grad(param, grad_bf16, exp_avg, exp_avg_sq, step: int, lr=5e-4
                                           current_stream_ptr()), "pv_adam_step_bf16grad")
 
 
+def scale_bias_relu_f32(x: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0, relu: bool = False) -> torch.Tensor:
+    """act(alpha x + bias) over the rows of x [M, N] (pv_scale_bias_relu_f32)."""
+    require_cuda(x, bias)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    m = x.numel() // x.shape[-1]
+    check(get_lib().pv_scale_bias_relu_f32(ptr(x), ptr(bias), ptr(y), m, x.shape[-1], float(alpha), int(bool(relu)),
+                                           current_stream_ptr()), "pv_scale_bias_relu_f32")
+    return y
+
+
+def scale_f32(x: torch.Tensor, alpha: float) -> torch.Tensor:
+    return scale_bias_relu_f32(x, None, alpha, False)
+
+
+def cast_f32_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """bf16 (round to nearest even) copy of a contiguous f32 tensor (pv_cast_f32_to_bf16)."""
+    require_cuda(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(get_lib().pv_cast_f32_to_bf16(ptr(x), ptr(out), x.numel(), current_stream_ptr()), "pv_cast_f32_to_bf16")
+    return out
+
+
 def embedding_fwd(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     require_cuda(table, ids)
     ids = ids.to(torch.int64).contiguous()

@@ -45,6 +45,8 @@ class HipAdam(torch.optim.Optimizer):
     # f32 .grad:  "fused" -- wgrad + Adam in one pass, the gradient is never materialised (single process);
     #             "bf16"  -- gradient written as bf16 and all-reduced in bf16 (data parallel);
     #             "autograd" -- plain f32 .grad.
+    #             "sharded" -- bf16 gradient, reduce-scatter over rows, Adam on this rank's rows, all-gather of the operand copy;
+    #             "ksharded" -- fc1's COLUMNS dealt over the ranks: activations are exchanged, no weight or gradient is.
     FUSE_MIN_NUMEL = 1 << 22
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fuse_large_linear=True, overlap_large_update=False,
@@ -99,11 +101,20 @@ class HipAdam(torch.optim.Optimizer):
         return [p for g in self.param_groups for p in g["params"] if p.dim() == 2 and p.numel() >= self.FUSE_MIN_NUMEL]
 
     def set_large_grad_mode(self, mode: str) -> None:
-        if mode not in ("fused", "bf16", "sharded", "autograd"):
+        if mode not in ("fused", "bf16", "sharded", "ksharded", "autograd"):
             raise ValueError(mode)
         if getattr(self, "_layout_frozen", False) and mode != getattr(self, "large_grad_mode", mode):
             raise RuntimeError("HipAdam.set_large_grad_mode(): a captured HIP graph holds this optimiser's state tensors and the "
                                "gradient mode it was captured with -- release the graph first (GraphedTrainStep.close())")
+        if getattr(self, "large_grad_mode", None) == "ksharded" and mode != "ksharded":
+            self.consolidate_sharded()      # (collective) the column shards hold the truth: back into the full tensors first
+            for p in self.large_params():
+                p._pv_kshard = None
+        if mode == "ksharded":
+            from . import distributed as D
+            if self.capturable or not D.is_distributed() or any(
+                    D.column_shard(p.shape[1], multiple=K.MOMENT_TILE) is None for p in self.large_params()):
+                mode = "sharded"    # columns do not divide over the ranks (or nothing to shard over): the row-sharded exchange
         if mode == "sharded":
             from . import distributed as D
             if any(D.row_shard(p.shape[0]) is None for p in self.large_params()):
@@ -111,7 +122,10 @@ class HipAdam(torch.optim.Optimizer):
         self.large_grad_mode = mode
         self._moments_rows()
         for p in self.large_params():
+            if mode == "ksharded" and getattr(p, "_pv_kshard", None) is None:
+                self._make_column_shard(p)
             p._pv_grad_mode = mode
+            p._pv_kshard_pending = None
             p._pv_pending = None
             p._pv_pending_f32 = None
             p._pv_takes_f32_pending = mode == "fused" and not self.capturable
@@ -121,15 +135,43 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_fused_backward = self._make_fused_backward(p) if (mode == "fused" and not self.overlap_large_update) else None
             p._pv_applied = False
 
+    def _make_column_shard(self, p) -> None:
+        """large_grad_mode "ksharded": this rank's COLUMNS of p as contiguous tensors of their own -- f32 master, bf16 operand
+        copy, both moments -- cut from the full parameter / optimiser state (replicated at this point: after the initial
+        broadcast, a checkpoint load or consolidate_sharded()).  From here on the full tensors are stale until
+        consolidate_sharded(); the kernels only ever see the shard, an ordinary dense [N, K / W] matrix."""
+        from . import distributed as D
+        k0, k1 = D.column_shard(p.shape[1], multiple=K.MOMENT_TILE)
+        st = self.state.get(p) or {}
+        with torch.no_grad():
+            w = p.detach()[:, k0:k1].contiguous()
+            ks = {"k0": k0, "k1": k1, "w": w, "shadow": K.cast_f32_to_bf16(w),
+                  "exp_avg": (st["exp_avg"][:, k0:k1].contiguous() if "exp_avg" in st else torch.zeros_like(w)),
+                  "exp_avg_sq": (st["exp_avg_sq"][:, k0:k1].contiguous() if "exp_avg_sq" in st else torch.zeros_like(w)),
+                  "step": int(st["step"].item()) if "step" in st else 0}
+        p._pv_kshard = ks
+
     def consolidate_sharded(self) -> None:
-        """After sharded steps every rank holds current f32 values (parameter, exp_avg, exp_avg_sq) only for the rows it
-        owns.  All-gather them so that state_dict() / checkpoints are complete on every rank.  Collective: call on all ranks."""
+        """After sharded steps every rank holds current f32 values (parameter, exp_avg, exp_avg_sq) only for the rows
+        ("sharded") or columns ("ksharded") it owns.  All-gather them so that state_dict() / checkpoints are complete on
+        every rank.  Collective: call on all ranks."""
         if not getattr(self, "_sharded_dirty", False):
             return
         self._moments_rows()
         from . import distributed as D
         if D.is_distributed():
             for p in self.large_params():
+                ks = getattr(p, "_pv_kshard", None)
+                if getattr(p, "_pv_grad_mode", None) == "ksharded" and ks is not None:
+                    st = self._init_state(p)
+                    with torch.no_grad():
+                        D.all_gather_columns(ks["w"], p.data)
+                        D.all_gather_columns(ks["exp_avg"], st["exp_avg"])
+                        D.all_gather_columns(ks["exp_avg_sq"], st["exp_avg_sq"])
+                        st["step"].fill_(float(ks["step"]))
+                    if hasattr(p, "_pv_bf16_shadow"):
+                        p._pv_bf16_shadow = None      # (the full operand copy, if any mode built one earlier, is stale)
+                    continue
                 if getattr(p, "_pv_grad_mode", None) != "sharded":
                     continue
                 st = self.state.get(p, {})
@@ -340,6 +382,7 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_pending_f32 = None
             p._pv_grad_bf16 = None
             p._pv_grad_shard = None
+            p._pv_kshard_pending = None
         return super().zero_grad(set_to_none=set_to_none)
 
     def _wait_inflight(self):
@@ -373,6 +416,21 @@ class HipAdam(torch.optim.Optimizer):
                 pending32 = getattr(p, "_pv_pending_f32", None)
                 gb = getattr(p, "_pv_grad_bf16", None)
                 gs = getattr(p, "_pv_grad_shard", None)
+                kpend = getattr(p, "_pv_kshard_pending", None)
+                if kpend is not None and p.grad is None:
+                    # K-sharded fc1: the gradient of THIS RANK'S COLUMNS over the whole global batch, formed and applied in
+                    # one pass over the shard's p / m / v (no gradient tensor, no exchange: functional.LinearBF16KSharded
+                    # parked the exchanged activations and the all-gathered output gradients)
+                    x_cols, g_full = kpend
+                    p._pv_kshard_pending = None
+                    ks = p._pv_kshard
+                    ks["step"] += 1
+                    if self.grad_scale != 1.0:
+                        g_full = K.scale_f32(g_full, self.grad_scale)
+                    K.linear_wgrad_adam_bf16(x_cols, g_full, None, ks["w"], ks["exp_avg"], ks["exp_avg_sq"], ks["shadow"],
+                                             ks["step"], lr=group["lr"], betas=group["betas"], eps=group["eps"])
+                    self._sharded_dirty = True
+                    continue
                 if p.grad is None and pending is None and pending32 is None and gb is None and gs is None:
                     continue
                 if not p.is_cuda:

@@ -52,6 +52,7 @@ def main():
     y = model(batch).detach().cpu()        # forward AFTER the last step: waits for the all-gathered operand copy
     opt.consolidate_sharded()
     torch.cuda.synchronize()
+    assert opt.large_grad_mode == mode, (opt.large_grad_mode, mode)
     if rank == 0:
         torch.save({"backend": torch.distributed.get_backend(), "world": world, "state": {k: v.cpu() for k, v in model.state_dict().items()}, "losses": losses, "y": y,
                     "exp_avg_fc1": opt.state[model.fc1.weight]["exp_avg"].cpu(), "mode": opt.large_grad_mode}, out_path)

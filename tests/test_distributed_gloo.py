@@ -293,3 +293,59 @@ def test_eight_rank_gloo_row_shards_and_bf16_wire_sum():
     ret = mgr.dict()
     mp.spawn(_eight_rank_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world))
+
+
+def _ksharded_worker(rank, world, port, ret):
+    """The K-sharded fc1 exchange (distributed.py, HipAdam large_grad_mode "ksharded") on CPU tensors over gloo: the four
+    collectives move exactly the bytes a single process would index, and a Linear evaluated through them -- forward, input
+    gradient, weight gradient of this rank's columns -- equals the dense layer on the whole global batch."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from predict_pv_yield_amd import distributed as D
+    assert D.init_from_env(backend="gloo")
+    b, n, k = 3, 16, 64 * world                     # per-rank batch, outputs, input features (K / W = 64)
+    g = torch.Generator().manual_seed(11)
+    x_all = torch.randn(world * b, k, generator=g)               # the global batch, known to every rank here
+    w = torch.randn(n, k, generator=g)
+    dy_all = torch.randn(world * b, n, generator=g)
+    assert D.column_shard(k) == (rank * 64, (rank + 1) * 64)
+    assert D.column_shard(k + 8) is None and D.column_shard(world * 12) is None      # not divisible / shard not a multiple of 8
+    k0, k1 = D.column_shard(k)
+    x_loc = x_all[rank * b:(rank + 1) * b].contiguous()
+    # forward exchange: all samples, my columns -- the same values a single process would slice
+    x_cols = D.all_to_all_columns(x_loc)
+    assert x_cols.shape == (world * b, 64) and torch.equal(x_cols, x_all[:, k0:k1])
+    # partial products summed in RANK ORDER for my samples
+    partial = x_cols @ w[:, k0:k1].t()
+    y_loc = D.reduce_scatter_sample_rows(partial)
+    want = torch.zeros(b, n)
+    for r in range(world):                                       # the same order, spelled out
+        want += x_all[rank * b:(rank + 1) * b, r * 64:(r + 1) * 64] @ w[:, r * 64:(r + 1) * 64].t()
+    assert torch.equal(y_loc, want)
+    torch.testing.assert_close(y_loc, x_loc @ w.t(), rtol=1e-5, atol=1e-5)
+    # backward: output gradients of all samples, then the input gradient back to its owner
+    g_all = D.all_gather_sample_rows(dy_all[rank * b:(rank + 1) * b].contiguous())
+    assert torch.equal(g_all, dy_all)
+    dx_cols = g_all @ w[:, k0:k1]                                # [W b, K / W]: all samples, my columns
+    dx_loc = D.all_to_all_rows_back(dx_cols)
+    assert dx_loc.shape == (b, k) and torch.equal(dx_loc, dy_all[rank * b:(rank + 1) * b] @ w)
+    # this rank's columns of the weight gradient over the WHOLE global batch = the column slice of the dense gradient
+    dw_shard = g_all.t() @ x_cols
+    torch.testing.assert_close(dw_shard, (dy_all.t() @ x_all)[:, k0:k1], rtol=1e-6, atol=1e-6)
+    # checkpoints: column shards back into a full matrix
+    full = torch.zeros(n, k)
+    D.all_gather_columns(w[:, k0:k1] * 2.0, full)
+    assert torch.equal(full, w * 2.0)
+    ret[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 8])
+def test_ksharded_fc1_exchange_gloo(world):
+    port = 37500 + (os.getpid() % 2000) + world
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ksharded_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))

@@ -75,9 +75,10 @@ def test_sharded_update_equals_allreduce_update(device, tmp_path):
         assert whole_step <= 0.01 and d.mean().item() <= 0.2 * 5e-4, (k, whole_step, d.mean().item())
 
 
-def _run_one_rank_rccl(mode, out_path, steps=3):
+def _run_one_rank_rccl(mode, out_path, steps=3, fuse_min_numel=1):
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-               PV_DIST_SINGLE_RANK="1", PV_DIST_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               PV_DIST_SINGLE_RANK="1", PV_DIST_TIMEOUT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PV_TEST_FUSE_MIN_NUMEL=str(fuse_min_numel))
     env.pop("PV_DIST_BACKEND", None)
     env.pop("PV_SINGLE_DEVICE", None)
     p = subprocess.run([sys.executable, os.path.join(HERE, "ddp_two_rank_worker.py"), mode, out_path, str(steps)], env=env,
@@ -218,3 +219,70 @@ def test_bench_refuses_a_demoted_exchange_unless_allowed(device):
     assert "dp2 (bf16)" in line["config"]["parallelism"]
     c = line["config"]["collectives"]
     assert c["requested_mode"] == "sharded" and c["mode_in_force"] == "bf16" and c["world_size"] == 2 and c["backend"] == "gloo"
+
+
+def _single_process_reference(device, mode, n_samples, fuse_min_numel, steps=3):
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    from predict_pv_yield_amd.optim import HipAdam
+    from tests.ddp_two_rank_worker import SMALL
+    old = HipAdam.FUSE_MIN_NUMEL
+    HipAdam.FUSE_MIN_NUMEL = fuse_min_numel
+    try:
+        torch.manual_seed(518)
+        model = Model(**SMALL, precision="bf16").to(device)
+        opt = model.configure_optimizers()
+        opt.set_large_grad_mode(mode)
+        g = torch.Generator().manual_seed(7)
+        sat, pv = torch.randn(n_samples, 11, 25, 16, 16, generator=g), torch.rand(n_samples, 25, 128, generator=g)
+        batch = {"satellite": {"data": sat.to(device)}, "pv": {"pv_yield": pv.to(device)}}
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    finally:
+        HipAdam.FUSE_MIN_NUMEL = old
+    return model, losses
+
+
+@pytest.mark.parametrize("world,global_batch", [(2, 4), (8, 8)])
+def test_ksharded_fc1_follows_the_f32_allreduce_and_one_process(device, tmp_path, world, global_batch):
+    """fc1's COLUMNS dealt over the ranks (large_grad_mode "ksharded": activations are exchanged by two
+    all-to-alls, no gradient or weight of fc1 crosses a link).  Its update is the f32 all-reduce's up to summation order (the
+    partial products of the column shards are added in rank order; the weight gradient of a shard is formed over the whole
+    global batch in one pass instead of as a sum of per-rank gradients), so: the first step's loss is the all-reduce run's to
+    1e-6 relative, three Adam steps leave the consolidated parameters within the distance the sharded test allows its
+    single-process reference, and a whole-batch single process (exact f32 gradient, one-pass fc1 backward) is as close."""
+    a = _run_two_ranks("autograd", str(tmp_path / "f32.pt"), world=world, global_batch=global_batch, fuse_min_numel=100000)
+    b = _run_two_ranks("ksharded", str(tmp_path / "ksharded.pt"), world=world, global_batch=global_batch, fuse_min_numel=100000)
+    assert a["mode"] == "autograd" and b["mode"] == "ksharded" and b["world"] == world
+    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-6 * abs(a["losses"][0])
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert abs(la - lb) <= 2e-3 * abs(la), (a["losses"], b["losses"])
+    model, losses = _single_process_reference(device, "fused", global_batch, 100000)
+    # (rank 0's loss is the mean over ITS samples only: the single process is compared through the parameters)
+    for ref_state, what in ((a["state"], "f32 all-reduce"), ({k: v.cpu() for k, v in model.state_dict().items()}, "one process")):
+        for k, v in ref_state.items():
+            d = (v - b["state"][k]).abs()
+            whole_step = (d > 5e-4).float().mean().item()
+            assert whole_step <= 0.02 and d.mean().item() <= 0.3 * 5e-4, (what, k, whole_step, d.mean().item())
+    assert b["state"]["fc1.weight"].shape == a["state"]["fc1.weight"].shape          # consolidated: every column is there
+    assert torch.isfinite(b["exp_avg_fc1"]).all() and b["exp_avg_fc1"].abs().sum() > 0
+
+
+def test_ksharded_rccl_branches_on_one_rank(device, tmp_path):
+    """backend "nccl" (= RCCL), one rank: all_to_all_single / all_gather_into_tensor of the K-sharded exchange really run; with
+    one rank they are the identity and the shard is the whole matrix, so the run follows the single-process one-pass fc1 backward:
+    the same forward kernel (first loss bit for bit), then the weight gradient from the register-tiled kernel inside Adam's pass
+    instead of the matrix-core tile of the one-pass kernel (another f32 summation order: 1e-6 on the losses)."""
+    a = _run_one_rank_rccl("ksharded", str(tmp_path / "ksharded1.pt"), fuse_min_numel=100000)
+    assert a["backend"] == "nccl" and a["world"] == 1 and a["mode"] == "ksharded"
+    model, losses = _single_process_reference(device, "fused", 4, 100000)
+    assert a["losses"][0] == losses[0]
+    for la, lb in zip(a["losses"], losses):
+        assert abs(la - lb) <= 2e-6 * abs(lb), (a["losses"], losses)
+    for k, v in model.state_dict().items():
+        d = (v.cpu() - a["state"][k]).abs()
+        assert (d > 5e-4).float().mean().item() <= 0.005 and d.mean().item() <= 0.05 * 5e-4, (k, d.mean().item())
