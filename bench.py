@@ -489,6 +489,66 @@ def measure_sharded_rank_compute(dev, history_minutes, world=8, global_batch=512
             "what": "one rank's kernels of bench.py --gpus 8 --global-batch 512 (sharded fc1 update), no exchange"}
 
 
+def measure_ksharded_rank_compute(dev, history_minutes, world=8, per_gpu_batch=64, steps=10, warmup=3):
+    """One rank's kernels of the K-SHARDED run (HipAdam large_grad_mode "ksharded") on this one GPU, no exchange: the conv tower
+    on per_gpu_batch samples, the staging copies of the two all-to-alls, fc1's forward / input gradient / weight gradient + Adam
+    on this rank's 1 / world of the COLUMNS for world x per_gpu_batch rows.  The collectives are replaced by local stand-ins of
+    the same shapes (the send-side staging copy of an all-to-all is kept, the wire is not)."""
+    from unittest import mock
+    from predict_pv_yield_amd import distributed as D
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd.models.conv3d.model import Model
+    b = per_gpu_batch
+    torch.manual_seed(518)
+    model = Model(**MODEL_KW, history_minutes=history_minutes, precision="bf16").to(dev)
+    model.batch_size = max(model.batch_size, b)
+    opt = model.configure_optimizers()
+    opt.grad_scale = 1.0 / world
+    n, k = model.fc1.weight.shape
+    if k % (world * K.MOMENT_TILE):
+        return {"skipped": f"fc1's {k} columns do not divide over {world} ranks in multiples of {K.MOMENT_TILE}"}
+    kr = k // world
+    t = model.history_len_5 + model.forecast_len_5 + 1
+    g = torch.Generator(device=dev).manual_seed(518)
+    batch = {"satellite": {"data": torch.randn(b, 11, t, 64, 64, generator=g, device=dev)},
+             "pv": {"pv_yield": torch.rand(b, t, 128, generator=g, device=dev)}}
+    fwd = lambda x: x.view(x.shape[0], world, kr).transpose(0, 1).contiguous().view(world * x.shape[0], kr)
+    back = lambda d: d.view(world, d.shape[0] // world, kr).transpose(0, 1).reshape(d.shape[0] // world, world * kr)
+    ww = world
+    with mock.patch.object(D, "is_distributed", lambda: True), \
+            mock.patch.object(D, "column_shard", lambda n_cols, rank=None, world=None, multiple=8: (0, n_cols // ww)), \
+            mock.patch.object(D, "all_to_all_columns", fwd), mock.patch.object(D, "all_to_all_rows_back", back), \
+            mock.patch.object(D, "reduce_scatter_sample_rows",
+                              lambda p: K.colsum(p.view(world, p.numel() // world)).view(p.shape[0] // world, p.shape[1])), \
+            mock.patch.object(D, "all_gather_sample_rows", lambda loc: loc.repeat(world, 1)):
+        opt.set_large_grad_mode("ksharded")
+        if opt.large_grad_mode != "ksharded":
+            return {"skipped": f"the optimiser chose '{opt.large_grad_mode}'"}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            model.training_step(batch, 0).backward()
+            opt.step()
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        for p in opt.large_params():
+            p._pv_kshard = None
+        opt.large_grad_mode = "autograd"
+    ex = exchange_bytes("ksharded", world, b, model)
+    del model, opt, batch
+    settle()
+    return {"ms_per_step": round(d * 1e3, 3), "per_gpu_batch": b, "emulated_world": world, "columns_stepped": kr, "mode": "ksharded",
+            "aggregate_samples_per_s_if_exchange_hides": round(world * b / d, 1), "exchange_bytes_per_rank_and_step": ex,
+            "what": "one rank's kernels of bench.py --gpus 8 --grad-sync ksharded (fc1's columns dealt over the ranks), no exchange"}
+
+
 def model_k(t_frames):
     return 32 * (t_frames - 8) * 56 * 56      # fc1 input features of the headline model
 
@@ -986,6 +1046,20 @@ class ClockSampler:
                           "sampled every 10 ms during the timed steps"}
 
 
+def exchange_bytes(mode, world, b, model):
+    """Bytes one rank SENDS per step for fc1 under each exchange (the small tensors' flat bucket, ~0.6 MB, is the same in all)."""
+    n, k = model.fc1.weight.shape
+    f = (world - 1) / world
+    if mode == "ksharded":
+        return {"all_to_all_activations_bf16": int(b * k * 2 * f), "all_to_all_input_gradient_bf16": int(b * k * 2 * f),
+                "partial_outputs_f32": int(world * b * n * 4 * f), "all_gather_output_gradient_f32": int(b * n * 4 * (world - 1))}
+    if mode == "sharded":
+        return {"reduce_scatter_gradient_bf16": int(n * k * 2 * f), "all_gather_operand_copy_bf16": int(n * k * 2 * f)}
+    if mode == "bf16":
+        return {"all_reduce_gradient_bf16": int(2 * n * k * 2 * f)}
+    return {"all_reduce_gradient_f32": int(2 * n * k * 4 * f)}
+
+
 def collectives_info(world, requested, in_force):
     """What the job's exchange really ran on, read from the live process group: the first 8-GPU run certifies itself."""
     import torch.distributed as dist
@@ -1023,9 +1097,14 @@ def main():
     ap.add_argument("--overlap-update", action="store_true",
                     help="N = 1: launch fc1's fused wgrad+Adam from backward on a side stream (under the conv backward)")
     ap.add_argument("--f32-grads", action="store_true", help="N > 1: all-reduce fc1's gradient in f32 instead of bf16")
-    ap.add_argument("--grad-sync", choices=["sharded", "allreduce"], default="sharded",
+    ap.add_argument("--grad-sync", choices=["sharded", "allreduce", "ksharded"], default="sharded",
                     help="N > 1, bf16 gradients: 'sharded' = reduce-scatter + per-rank Adam over its rows of fc1 + all-gather "
-                         "of the bf16 operand copy (default); 'allreduce' = every rank steps the whole matrix")
+                         "of the bf16 operand copy (default); 'allreduce' = every rank steps the whole matrix; 'ksharded' = "
+                         "fc1's columns dealt over the ranks, activations exchanged by two all-to-alls (no weight or gradient "
+                         "of fc1 crosses a link)")
+    ap.add_argument("--only-requested-mode", action="store_true",
+                    help="N > 1: time the requested exchange only (default: the other modes are timed afterwards in the same "
+                         "invocation and reported under grad_sync_modes; `value` is always the requested mode's)")
     ap.add_argument("--allow-demotion", action="store_true",
                     help="N > 1: accept a simpler gradient-exchange mode than the requested one when its trial step fails "
                          "(default: exit non-zero -- a scaling number on another exchange is not the number asked for)")
@@ -1073,7 +1152,7 @@ def main():
         # the exchange needs a materialised fc1 gradient: bf16 on the wire (half the xGMI bytes), f32 with --f32-grads.
         # The row-sharded exchange (reduce-scatter / all-gather) is tried ONCE, untimed, in this process; if RCCL refuses
         # it on every rank alike the run continues on the plain bf16 all-reduce (never a re-exec: the GPU is initialised).
-        grad_sync_mode = "autograd" if args.f32_grads else ("sharded" if args.grad_sync == "sharded" else "bf16")
+        grad_sync_mode = "autograd" if args.f32_grads else {"sharded": "sharded", "allreduce": "bf16", "ksharded": "ksharded"}[args.grad_sync]
         requested_mode = grad_sync_mode
         grad_sync_mode = D.negotiate_grad_sync(model, opt, batch, grad_sync_mode, allow_demotion=args.allow_demotion)
         sync = D.OverlappedGradSync(model)
@@ -1120,6 +1199,45 @@ def main():
         elapsed = float(tt.item())
     last = float(last.detach())
 
+    # N > 1: the other exchanges of fc1, timed the same way in the SAME invocation (the first multi-GPU run
+    # decides between exchanges instead of testing one).  Every rank walks the same list; a mode whose trial step fails, or that
+    # the optimiser replaces by a simpler one, is recorded as such and skipped -- `value` above stays the requested mode's.
+    other_modes = {}
+    if distributed and not args.only_requested_mode:
+        def timed_steps(n):
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            tt1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt1, op=torch.distributed.ReduceOp.MAX)
+            return float(tt1.item())
+        for cand in ("ksharded", "sharded", "bf16", "autograd"):
+            if cand == grad_sync_mode:
+                continue
+            try:
+                opt.consolidate_sharded()                     # (collective) full tensors current before the layout changes
+                sync.remove()                                 # (the trial step installs and removes hooks of its own)
+                in_force = D.negotiate_grad_sync(model, opt, batch, cand, allow_demotion=True)
+                sync = D.OverlappedGradSync(model)
+            except SystemExit as e:
+                other_modes[cand] = {"status": f"failed: {e}"}
+                break                                          # no exchange works any more: nothing further can be timed
+            if in_force != cand:
+                other_modes[cand] = {"status": f"not available here: the trial step or the optimiser fell back to '{in_force}'"}
+                continue
+            for _ in range(min(5, max(2, args.warmup))):
+                step()
+            sec = timed_steps(args.steps)
+            other_modes[cand] = {"status": "ok", "ms_per_step": round(sec / args.steps * 1e3, 3),
+                                 "value": round(world * b * args.steps / sec, 2), "unit": "samples/s",
+                                 "collectives": collectives_info(world, cand, in_force),
+                                 "exchange_bytes_per_rank_and_step": exchange_bytes(cand, world, b, model)}
+        opt.consolidate_sharded()
+
     if rank == 0:
         value = world * b * args.steps / elapsed
         ms_step = elapsed / args.steps * 1e3
@@ -1135,6 +1253,11 @@ def main():
                        "collectives": collectives_info(world, requested_mode if distributed else None, grad_sync_mode)},
             "device_calibration": calibration,
             "device_clocks_during_timed_steps": clocks.summary(),
+            "grad_sync_modes": (dict({grad_sync_mode: {"status": "ok (the requested mode: `value`)", "ms_per_step": round(ms_step, 3),
+                                                        "value": round(value, 2), "unit": "samples/s",
+                                                        "collectives": collectives_info(world, requested_mode, grad_sync_mode),
+                                                        "exchange_bytes_per_rank_and_step": exchange_bytes(grad_sync_mode, world, b, model)}},
+                                     **other_modes) if distributed else None),
             "train_nmae_first_step": round(first, 6) if first is not None else None,
             "train_nmae_last_step": round(last, 6),
             "whole_step_frac_of_bf16_mfma_peak": round(value / world * (23.37e9 if t_frames == 18 else 25.27e9) / MFMA_BF16_PEAK, 4),
@@ -1179,9 +1302,15 @@ def main():
                     r8 = out["strong_b512"]["one_rank_of_8"]
                     if "aggregate_samples_per_s_if_exchange_hides" in r8:
                         r8["ceiling_over_one_gpu"] = round(r8["aggregate_samples_per_s_if_exchange_hides"] / sb["samples_per_s"], 2)
+                    # the K-sharded mix (fc1's columns dealt over the ranks): strong (64 per GPU) and weak (32 per GPU) scaling
+                    k8 = out["strong_b512"]["one_rank_of_8_ksharded"] = measure_ksharded_rank_compute(dev, args.history_minutes, per_gpu_batch=64)
+                    if "aggregate_samples_per_s_if_exchange_hides" in k8:
+                        k8["ceiling_over_one_gpu"] = round(k8["aggregate_samples_per_s_if_exchange_hides"] / sb["samples_per_s"], 2)
+                    out["weak_b32_one_rank_of_8_ksharded"] = measure_ksharded_rank_compute(dev, args.history_minutes, per_gpu_batch=b)
                     if out["roofline"] is not None:
                         out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
                         out["roofline"]["strong_8gpu_ceiling_over_one_gpu"] = r8.get("ceiling_over_one_gpu")
+                        out["roofline"]["strong_8gpu_ceiling_over_one_gpu_ksharded"] = k8.get("ceiling_over_one_gpu")
                     out["fp32"] = measure_fp32_headline(dev, b, args.history_minutes)
                     if out["roofline"] is not None:      # (a scalar the driver's record keeps)
                         out["roofline"]["fp32_samples_per_s"] = out["fp32"]["value"]

@@ -367,7 +367,7 @@ class LinearBF16KSharded(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx_cols, _, _ = K.linear_bwd_bf16(x_cols, ks["shadow"], g_all, None, need_dx=True, need_dw=False,
-                                              gate_dx_by_x=x_is_relu_output)
+                                              gate_dx_by_x=x_is_relu_output, need_db=False)
             dx = D.all_to_all_rows_back(dx_cols)
             if x_is_relu_output:
                 _mark_pregated(dx)

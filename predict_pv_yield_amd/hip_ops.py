@@ -658,14 +658,14 @@ def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
     return y
 
 
-def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True, gate_dx_by_x=False):
+def linear_bwd_bf16(x_bf16, w_bf16, dy, y_mask, need_dx=True, need_dw=True, gate_dx_by_x=False, need_db=True):
     """gate_dx_by_x: x is a ReLU output; dx leaves multiplied by (x > 0) (the producer's ReLU derivative)."""
     require_cuda(x_bf16, w_bf16, dy, y_mask)
     m, k = x_bf16.shape
     n = w_bf16.shape[0]
     dx = torch.empty((m, k), dtype=torch.bfloat16, device=dy.device) if need_dx else None
     dw = torch.empty((n, k), dtype=torch.float32, device=dy.device) if need_dw else None
-    db = torch.empty(n, dtype=torch.float32, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if need_db else None
     check(get_lib().pv_linear_bwd_bf16(ptr(x_bf16), ptr(w_bf16), ptr(dy), ptr(y_mask), ptr(dx), ptr(dw), ptr(db), m, n,
                                        k, int(bool(gate_dx_by_x and need_dx)), current_stream_ptr()), "pv_linear_bwd_bf16")
     return dx, dw, db

@@ -106,8 +106,10 @@ class HipAdam(torch.optim.Optimizer):
         if getattr(self, "_layout_frozen", False) and mode != getattr(self, "large_grad_mode", mode):
             raise RuntimeError("HipAdam.set_large_grad_mode(): a captured HIP graph holds this optimiser's state tensors and the "
                                "gradient mode it was captured with -- release the graph first (GraphedTrainStep.close())")
-        if getattr(self, "large_grad_mode", None) == "ksharded" and mode != "ksharded":
-            self.consolidate_sharded()      # (collective) the column shards hold the truth: back into the full tensors first
+        if getattr(self, "large_grad_mode", None) in ("sharded", "ksharded") and mode != self.large_grad_mode:
+            # (collective, a no-op unless sharded steps were taken) the row / column shards hold the truth: back into the full
+            # tensors before another mode reads them
+            self.consolidate_sharded()
             for p in self.large_params():
                 p._pv_kshard = None
         if mode == "ksharded":

@@ -172,7 +172,8 @@ def test_bench_global_batch_path_with_eight_ranks_on_one_gpu(device, tmp_path):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--global-batch", "64",
-                                       "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"], env=env,
+                                       "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
+                                       "--only-requested-mode"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
     outs = [p.communicate(timeout=1500) for p in procs]
     for p, (o, e) in zip(procs, outs):
@@ -286,3 +287,33 @@ def test_ksharded_rccl_branches_on_one_rank(device, tmp_path):
     for k, v in model.state_dict().items():
         d = (v.cpu() - a["state"][k]).abs()
         assert (d > 5e-4).float().mean().item() <= 0.005 and d.mean().item() <= 0.05 * 5e-4, (k, d.mean().item())
+
+
+def test_bench_times_every_exchange_mode_in_one_invocation(device):
+    """bench.py --gpus N (N > 1) times the requested exchange of fc1 AND the others in the same invocation --
+    two gloo ranks on the one GPU here, the full 128 M-parameter fc1: the line's `value` is the requested (row-sharded) mode's,
+    `grad_sync_modes` carries K-sharded, bf16 all-reduce and f32 all-reduce with their own ms_per_step, collectives and bytes."""
+    import json
+    root = os.path.dirname(HERE)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "1",
+                                       "--warmup", "1", "--no-roofline", "--no-cpu-baseline"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-3000:]
+    lines = [ln for ln in outs[0][0].decode().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    modes = line["grad_sync_modes"]
+    assert set(modes) == {"sharded", "ksharded", "bf16", "autograd"}, modes
+    assert "requested" in modes["sharded"]["status"] and modes["sharded"]["value"] == line["value"]
+    for m in ("ksharded", "bf16", "autograd"):
+        assert modes[m]["status"] == "ok" and modes[m]["value"] > 0 and modes[m]["collectives"]["mode_in_force"] == m, (m, modes[m])
+    k = 128 * 1003520
+    assert modes["sharded"]["exchange_bytes_per_rank_and_step"]["reduce_scatter_gradient_bf16"] == k        # (W - 1) / W of 2 bytes each
+    assert modes["ksharded"]["exchange_bytes_per_rank_and_step"]["all_to_all_activations_bf16"] == 4 * 1003520
