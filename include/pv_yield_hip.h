@@ -208,13 +208,6 @@ int pv_mse_loss_f32(const float* y_hat, const float* y, int64_t n, float grad_sc
 int pv_bf16_cpad(int32_t c);   /* 16 for c<=16, 32 for c<=32, else PV_ESIZE */
 
 /* x[B,C,T,H,W] f32 (reference layout) → xp[B,T,H,W,CPAD] bf16 (zero channel padding). */
-/* The same repack, but as the three-way truncation split x = h + m + l (three bf16 images, 8 + 8 + 8 mantissa bits; what is
- * dropped is below 2^-24 |x|): the operand planes from which the bf16 matrix-core kernels form an f32-accurate product out of
- * six partial products (pv_conv3d_bwd_weight_bf16 called on (m,m), (l,h), (h,l), (m,h), (h,m), (h,h) and summed in that
- * order = the weight gradient of the f32 model, predict_pv_yield/models/conv3d/model.py:80-90 under autograd).
- * Needs t*h*w % 4 == 0 and 16-byte aligned buffers. */
-int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint16_t* xp_m, uint16_t* xp_l, int32_t batch,
-                                           int32_t c, int32_t t, int32_t h, int32_t w, void* stream);
 /* The two-term HALF-FLOAT split x s = h + l (h = rne_f16(x s), l = rne_f16(x s - h): 22 significant bits), s = 2^(14 - e) from
  * the tensor's largest magnitude (max |x| < 2^e; found by a pass of the same call): three matrix-core launches
  * (pv_conv3d_bwd_weight_f16 on (l,h), (h,l), (h,h), summed in that order, un-scaled by state[2] of both tensors) give the weight

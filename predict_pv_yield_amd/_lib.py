@@ -101,7 +101,6 @@ SIGNATURES = {
     "pv_normalise_f32": [c_vp, c_vp, c_sz, c_i64, c_i32, c_vp, c_vp, c_vp],
     "pv_bf16_cpad": [c_i32],
     "pv_pack_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
-    "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_pack_split2_ncdhw_f32_to_ndhwc_f16": [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_unpack_ndhwc_bf16_to_ncdhw_f32": [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],
     "pv_repack_gate_ncdhw_to_ndhwc_bf16": [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp],

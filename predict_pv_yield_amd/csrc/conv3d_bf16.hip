@@ -541,60 +541,6 @@ __global__ __launch_bounds__(256) void pack_ncdhw_to_ndhwc_v4_kernel(const float
   }
 }
 
-// The same repack as the THREE-WAY TRUNCATION SPLIT x = h + m + l (8 + 8 + 8 mantissa bits, both subtractions exact; what is
-// dropped is below 2^-24 |x|): three bf16 images instead of one rounded one -- the operand planes with which the bf16
-// matrix-core kernels form an f32-accurate product from six partial products (hh, hm, mh, hl, lh, mm).  ONE pass: a channel
-// pair is loaded once and goes into all three images (the first version made one pass per plane and read x from HBM three
-// times: 261 us for a 63 M-element activation); the three images of a wave's 64 quads leave one after the other through
-// the same LDS patch.
-template <int CPAD>
-__global__ __launch_bounds__(256, 2) void pack_split3_ncdhw_to_ndhwc_v4_kernel(const float* __restrict__ x,
-                                                                               uint16_t* __restrict__ xp_h,
-                                                                               uint16_t* __restrict__ xp_m,
-                                                                               uint16_t* __restrict__ xp_l, int c,
-                                                                               long long vox_per_sample, long long total_quads) {
-  constexpr int NCH = 4 * CPAD * 2 / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char patch[4][NCH * 1024];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long qps = vox_per_sample / 4;
-  for (long long base = (long long)blockIdx.x * blockDim.x + wave * 64; base < total_quads; base += stride) {
-    const long long i = base + lane;
-    u32x4 oh[NCH], om[NCH], ol[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) oh[k] = om[k] = ol[k] = (u32x4){0u, 0u, 0u, 0u};
-    if (i < total_quads) {
-      const long long bi = i / qps;
-      const long long v = (i - bi * qps) * 4;
-      const float* src = x + (size_t)bi * c * vox_per_sample + v;
-#pragma unroll
-      for (int k = 0; k < CPAD; k += 2) {      // channels k, k + 1 -> one 32-bit word per voxel and image
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-        if (k < c) a0 = *reinterpret_cast<const f32x4*>(src + (size_t)k * vox_per_sample);
-        if (k + 1 < c) a1 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * vox_per_sample);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float f0 = a0[q], f1 = a1[q];      // (a bit cast of the vector ELEMENT expression itself reads element 0)
-          const uint32_t b0 = __builtin_bit_cast(uint32_t, f0), b1 = __builtin_bit_cast(uint32_t, f1);
-          const float r0 = f0 - __builtin_bit_cast(float, b0 & 0xffff0000u), r1 = f1 - __builtin_bit_cast(float, b1 & 0xffff0000u);
-          const uint32_t c0 = __builtin_bit_cast(uint32_t, r0), c1 = __builtin_bit_cast(uint32_t, r1);
-          const float s0 = r0 - __builtin_bit_cast(float, c0 & 0xffff0000u), s1 = r1 - __builtin_bit_cast(float, c1 & 0xffff0000u);
-          const uint32_t d0 = __builtin_bit_cast(uint32_t, s0), d1 = __builtin_bit_cast(uint32_t, s1);
-          const int chunk = q * (CPAD / 8) + (k >> 3), word = (k & 7) >> 1;
-          oh[chunk][word] = (b0 >> 16) | (b1 & 0xffff0000u);
-          om[chunk][word] = (c0 >> 16) | (c1 & 0xffff0000u);
-          ol[chunk][word] = (d0 >> 16) | (d1 & 0xffff0000u);
-        }
-      }
-    }
-    const size_t off = (size_t)base * (NCH * 16);
-    const long long valid = (total_quads - base) * (NCH * 16);
-    wave_store_run<NCH>(patch[wave], oh, reinterpret_cast<unsigned char*>(xp_h) + off, valid);
-    wave_store_run<NCH>(patch[wave], om, reinterpret_cast<unsigned char*>(xp_m) + off, valid);
-    wave_store_run<NCH>(patch[wave], ol, reinterpret_cast<unsigned char*>(xp_l) + off, valid);
-  }
-}
-
 // ---- two-term f16 split (round 4): x s = h + l, h = rne_f16(x s), l = rne_f16(x s - h): 22 significant bits in two half-float
 // images, so that an f32-accurate product needs THREE matrix-core launches (l h, h l, h h) where the bf16 split needs six, and
 // the split pass writes 4 instead of 6 bytes per element.  Half floats have a narrow range: s = 2^(14 - e) is an exact power of
@@ -890,26 +836,6 @@ int pv_bf16_cpad(int32_t c) {
   if (c <= 16) return 16;
   if (c <= 32) return 32;
   return PV_ESIZE;
-}
-
-int pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(const float* x, uint16_t* xp_h, uint16_t* xp_m, uint16_t* xp_l, int32_t batch,
-                                           int32_t c, int32_t t, int32_t h, int32_t w, void* stream) {
-  PV_REQUIRE(x && xp_h && xp_m && xp_l, PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: null pointer");
-  const int cpad = pv_bf16_cpad(c);
-  PV_REQUIRE(cpad > 0, PV_ESIZE, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: c=%d not in 1..32", c);
-  const long long vps = (long long)t * h * w, total = vps * batch;
-  PV_REQUIRE(total > 0, PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: empty tensor");
-  PV_REQUIRE(vps % 4 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)xp_h % 16 == 0) && ((uintptr_t)xp_m % 16 == 0) &&
-                 ((uintptr_t)xp_l % 16 == 0),
-             PV_EINVAL, "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16: needs t*h*w %% 4 == 0 and 16-byte aligned buffers");
-  const unsigned g4 = stream_grid((size_t)(total / 4), 256);
-  if (cpad == 16)
-    hipLaunchKernelGGL(pack_split3_ncdhw_to_ndhwc_v4_kernel<16>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp_h, xp_m, xp_l, c,
-                       vps, total / 4);
-  else
-    hipLaunchKernelGGL(pack_split3_ncdhw_to_ndhwc_v4_kernel<32>, dim3(g4), dim3(256), 0, as_stream(stream), x, xp_h, xp_m, xp_l, c,
-                       vps, total / 4);
-  return check_launch("pv_pack_split3_ncdhw_f32_to_ndhwc_bf16");
 }
 
 int pv_pack_split2_ncdhw_f32_to_ndhwc_f16(const float* x, uint16_t* xp_h, uint16_t* xp_l, float* state, int32_t have_max, int32_t batch,

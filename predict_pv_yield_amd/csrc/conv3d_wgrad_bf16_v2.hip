@@ -426,7 +426,139 @@ int launch_conv3d_wgrad_bf16_v2(const uint16_t* x, const uint16_t* dy, float* sl
   return 0;
 }
 
+
+// dw[co][ci][tap] = sum over slabs (fixed order: deterministic); dbias[co] from the ones-tap column 0.
+// block = 64 elements x 16 slab groups (one wave each, coalesced 256-byte reads): a thread adds slabs g, g + 16, ... with
+// all of its (<= 16 for 256 slabs) loads in flight, then the 16 group sums are combined in a fixed tree.  (4 groups of up to
+// 64 terms each, four loads at a time, made the launch a chain of ~16 memory latencies: 8.6-10 us for 29 MB.)
+constexpr int WR_GROUPS = 16;
+__global__ __launch_bounds__(64 * WR_GROUPS) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs,
+                                                                              float* __restrict__ dw, float* __restrict__ dbias,
+                                                                              int c_out, int c_in) {
+  __shared__ float part[WR_GROUPS][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;  // index into [28][32][32]; W2_SLAB_ELEMS % 64 == 0
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int k = grp; k < n_slabs; k += 16 * WR_GROUPS) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (k + WR_GROUPS * j < n_slabs) ? slabs[(size_t)(k + WR_GROUPS * j) * W2_SLAB_ELEMS + i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) s0 += v[j], s1 += v[j + 1], s2 += v[j + 2], s3 += v[j + 3];
+  }
+  part[grp][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0) {
+    float t[WR_GROUPS];
+#pragma unroll
+    for (int q = 0; q < WR_GROUPS; ++q) t[q] = part[q][lane];
+#pragma unroll
+    for (int w = WR_GROUPS / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int q = 0; q < w; ++q) t[q] = t[2 * q] + t[2 * q + 1];
+    const float s = t[0];
+    const int tap = i >> 10, co = (i >> 5) & 31, ci = i & 31;
+    if (tap < 27) {
+      if (dw && co < c_out && ci < c_in) dw[((size_t)co * c_in + ci) * 27 + tap] = s;
+    } else if (dbias && ci == 0 && co < c_out) {
+      dbias[co] = s;
+    }
+  }
+}
+
+// dY gated by the ReLU derivative of the layer's own output, as a copy: dst = dy where y > 0 (as bf16: sign clear and not +0),
+// else 0.  The loader-wave kernel above stages dY by LDS-direct loads and cannot gate on the way; callers that hand over a
+// gate (layers whose consumer did not pre-gate the gradient: the sat+NWP towers' last layers, eval-time probes) pay this one
+// streaming pass instead of the register-staged kernel of rounds 1-2 (removed in round 6: 380 lines that only those calls reached).
+__global__ __launch_bounds__(256) void wgrad_gate_copy_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ y,
+                                                              u32x4* __restrict__ dst, size_t n8) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const u32x4 g = dy[i], a = y[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] & (relu_pair01(a[j]) * 0xffffu);      // (bit 0 / bit 16 -> 0xffff in that half)
+    dst[i] = o;
+  }
+}
+
 }  // namespace pv
+
+using namespace pv;
+
+extern "C" {
+
+int pv_conv3d_bwd_weight_bf16_workspace_bytes(const pv_conv3d_dims* d, size_t* bytes) {
+  PV_REQUIRE(d && bytes, PV_EINVAL, "pv_conv3d_bwd_weight_bf16_workspace_bytes: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->t_in > 0 && d->h_in > 0 && d->w_in > 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_bf16_workspace_bytes: bad dims");
+  // the partial slabs, and behind them room for a gated copy of dY (used only when a gate is handed over)
+  const long long to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  const size_t dy_bytes = (to > 0 && ho > 0 && wo > 0) ? (size_t)d->batch * to * ho * wo * pv_bf16_cpad(d->c_out) * 2 : 0;
+  *bytes = ((wgrad_v2_workspace_bytes(d) + 255) & ~(size_t)255) + dy_bytes;
+  return PV_OK;
+}
+
+int pv_conv3d_bwd_weight_bf16(const uint16_t* x, const uint16_t* dy, const uint16_t* y_relu_mask, float* dw,
+                              float* dbias, const pv_conv3d_dims* d, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  PV_REQUIRE(d && x && dy && workspace, PV_EINVAL, "pv_conv3d_bwd_weight_bf16: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_bwd_weight_bf16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_bwd_weight_bf16: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_bwd_weight_bf16: input smaller than the kernel");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_bwd_weight_bf16: batch too large for grid.z");
+  PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_bwd_weight_bf16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
+  const size_t slab_bytes = (wgrad_v2_workspace_bytes(d) + 255) & ~(size_t)255;
+  PV_REQUIRE(workspace_bytes >= wgrad_v2_workspace_bytes(d), PV_ESIZE, "pv_conv3d_bwd_weight_bf16: workspace too small");
+  PV_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)workspace % 16) == 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_bf16: x, dy and the workspace must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  if (y_relu_mask) {
+    const size_t n = (size_t)d->batch * to * ho * wo * pv_bf16_cpad(d->c_out);      // bf16 elements of dY (a multiple of 16)
+    PV_REQUIRE(workspace_bytes >= slab_bytes + n * 2, PV_ESIZE,
+               "pv_conv3d_bwd_weight_bf16: a gate needs room for the gated copy of dY behind the slabs (workspace_bytes query)");
+    PV_REQUIRE(((uintptr_t)y_relu_mask % 16) == 0, PV_EINVAL, "pv_conv3d_bwd_weight_bf16: the gate must be 16-byte aligned");
+    uint16_t* gated = reinterpret_cast<uint16_t*>(static_cast<char*>(workspace) + slab_bytes);
+    hipLaunchKernelGGL(wgrad_gate_copy_kernel, dim3(stream_grid(n / 8, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const u32x4*>(dy), reinterpret_cast<const u32x4*>(y_relu_mask),
+                       reinterpret_cast<u32x4*>(gated), n / 8);
+    dy = gated;
+  }
+  int n2 = 0;
+  PV_REQUIRE(launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2, false) == 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_bf16: x and dy must be 16-byte aligned");
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(W2_SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st, (const float*)workspace, n2,
+                     dw, dbias, d->c_out, d->c_in);
+  return check_launch("pv_conv3d_bwd_weight_bf16");
+}
+
+int pv_conv3d_bwd_weight_f16(const uint16_t* x, const uint16_t* dy, float* dw, float* dbias, const pv_conv3d_dims* d,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  PV_REQUIRE(d && x && dy && workspace, PV_EINVAL, "pv_conv3d_bwd_weight_f16: null pointer");
+  PV_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_in <= 32 && d->c_out > 0 && d->c_out <= 32, PV_ESIZE,
+             "pv_conv3d_bwd_weight_f16: channels (%d -> %d) must be in 1..32", d->c_in, d->c_out);
+  PV_REQUIRE(d->pad_t >= 0 && d->pad_t <= 2 && d->pad_h >= 0 && d->pad_h <= 2 && d->pad_w >= 0 && d->pad_w <= 2,
+             PV_EINVAL, "pv_conv3d_bwd_weight_f16: padding must be 0..2");
+  const int to = d->t_in + 2 * d->pad_t - 2, ho = d->h_in + 2 * d->pad_h - 2, wo = d->w_in + 2 * d->pad_w - 2;
+  PV_REQUIRE(to > 0 && ho > 0 && wo > 0, PV_ESIZE, "pv_conv3d_bwd_weight_f16: input smaller than the kernel");
+  PV_REQUIRE(d->batch <= 65535, PV_ESIZE, "pv_conv3d_bwd_weight_f16: batch too large for grid.z");
+  PV_REQUIRE((size_t)d->t_in * d->h_in * d->w_in * 64 <= 0x40000000ull, PV_ESIZE,
+             "pv_conv3d_bwd_weight_f16: one sample exceeds 1 GiB (buffer-addressing limit of this kernel)");
+  PV_REQUIRE(workspace_bytes >= wgrad_v2_workspace_bytes(d), PV_ESIZE, "pv_conv3d_bwd_weight_f16: workspace too small");
+  hipStream_t st = as_stream(stream);
+  int n2 = 0;
+  PV_REQUIRE(launch_conv3d_wgrad_bf16_v2(x, dy, (float*)workspace, d, to, ho, wo, st, &n2, true) == 0, PV_EINVAL,
+             "pv_conv3d_bwd_weight_f16: x and dy must be 16-byte aligned");
+  hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(W2_SLAB_ELEMS / 64), dim3(64 * WR_GROUPS), 0, st, (const float*)workspace, n2,
+                     dw, dbias, d->c_out, d->c_in);
+  return check_launch("pv_conv3d_bwd_weight_f16");
+}
+
+}  // extern "C"
 
 #ifdef PV_DIAG_STAMPS
 extern "C" int pv_diag_read_wgrad2(unsigned long long* host, size_t n) {

@@ -111,8 +111,8 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     // iteration -- UpdateMatrices, the window blur and the solve (fb_level_u_kernel); M is never written.  33..64-pixel
     // levels: one pair per 64 x 64 tile; levels up to 32 x 32: four pairs per tile (MOSAIC; its buffer offsets are 31-bit).
     // Rows of whole 4-pixel quads and a 16-byte-aligned flow: R and the flow move as 16-byte vectors.  Everything else (a
-    // width that is no multiple of 4, larger source images, PV_FARNEBACK_TWO_LAUNCH_ITERATION=1) takes the two-launch
-    // form below: UpdateMatrices writes M, the window blur + solve read it back.
+    // width that is no multiple of 4, larger source images, PV_FARNEBACK_TWO_LAUNCH_ITERATION=1: the tests' cross-check) takes
+    // the frame family's kernels below: UpdateMatrices writes M, the window passes + solve read it back.
     const bool small_level = lh <= 32 && lw <= 32;
     const bool polyexp_tile = h <= 64 && w <= 64 && smooth_sz <= 63;
     const bool fused_iter = tile_path && fuse_init && polyexp_tile && (lw & 3) == 0 && ((uintptr_t)flow & 15) == 0 &&
@@ -236,50 +236,16 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (float)(1. / p->pyr_scale)};
       if (!fuse_init)
         hipLaunchKernelGGL(fb_update_matrices_kernel<0>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)flow, M,
-                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+                           (long long)n_pairs, lh, lw, 0, (long long)pairs_per_group, chain_f, up);
       else if (prev_flow)
         hipLaunchKernelGGL(fb_update_matrices_kernel<1>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)prev_flow, M,
-                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+                           (long long)n_pairs, lh, lw, 0, (long long)pairs_per_group, chain_f, up);
       else
         hipLaunchKernelGGL(fb_update_matrices_kernel<2>, um_grid, dim3(256), 0, st, (const float*)R, (const float*)nullptr, M,
-                           (long long)n_pairs, lh, lw, tile_path ? 1 : 0, (long long)pairs_per_group, chain_f, up);
+                           (long long)n_pairs, lh, lw, 0, (long long)pairs_per_group, chain_f, up);
     }
     for (int it = 0; it < p->iterations; ++it) {
       const int update = it < p->iterations - 1 ? 1 : 0;
-      if (tile_path) {
-        // window blur + solve on the matrix cores (UpdateMatrices stays a separate high-occupancy launch: its
-        // flow-dependent R1 gathers need many waves in flight)
-        float* Gv = (float*)(ws + L.off_G);
-        float* Gh = lh == lw ? Gv : Gv + 64 * 64;   // square levels: the vertical and horizontal window matrices coincide
-        stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
-        if (it == 0) {
-          hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win, 0);
-          if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win, 0);
-        }
-        if (lh <= 32 && lw <= 32) {
-          const unsigned grid = (unsigned)std::min<long long>((n_pairs + 3) / 4, 2048);
-          hipLaunchKernelGGL(fb_tile_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
-                             (const float*)Gh, flow, lh, lw, (long long)n_pairs);
-        } else {
-          // (width % 4 and the alignment of M decide between the quadrant kernel's 16-byte staging and the strip kernel)
-          if ((lw & 3) == 0 && ((uintptr_t)M & 15) == 0 && !getenv("PV_FARNEBACK_STRIP_KERNEL")) {
-            const unsigned grid = (unsigned)std::min<long long>(n_pairs, 4096);
-            hipLaunchKernelGGL(fb_tile_mfma_q_kernel, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
-                               (const float*)Gh, flow, lh, lw, (long long)n_pairs);
-          } else {
-            const unsigned grid = (unsigned)std::min<long long>((n_pairs + 1) / 2, 2048);
-            hipLaunchKernelGGL(fb_tile_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, (const float*)M, (const float*)Gv,
-                               (const float*)Gh, flow, lh, lw, (long long)n_pairs);
-          }
-        }
-        if (update) {
-          stage_mark(coarse ? "farneback.coarse.update_matrices" : "farneback.level0.update_matrices", st);
-          hipLaunchKernelGGL(fb_update_matrices_kernel<0>, dim3(stream_grid((size_t)(n_pairs * lpx), 256)), dim3(256), 0, st,
-                             (const float*)R, (const float*)flow, M, (long long)n_pairs, lh, lw, 1, (long long)pairs_per_group,
-                             chain_f, FbUpsample{});
-        }
-        continue;
-      }
       stage_mark(coarse ? "farneback.coarse.window_blur_solve" : "farneback.level0.window_blur_solve", st);
       // the reference's 41-tap window (winsize 40): register-window passes; any other window: one load per tap
       const int hp = (lh + FB_RUN_V - 1) / FB_RUN_V * FB_RUN_V;

@@ -183,24 +183,14 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
   }
 }
 
-// ---- window blur on the matrix cores ----------------------------------------------------------------------------------
+// ---- window blur as matrix products (fb_level_u_kernel below) -------------------------------------------------------------------
 // For images up to 64 x 64 the separable, border-replicated window blur is two small matrix products per channel,
 //   U = X Gh^T (along x),  Out = Gv U (along y),   G[y][y'] = sum of the taps k with clamp(y + k) == y'
 // (a banded 64 x 64 matrix that already contains the border replication, built per level by fb_window_matrix_kernel).
-//
-// The products run on the bf16 matrix cores at f32 accuracy: every f32 operand is split, by truncation, into three bf16
-// terms x = h + m + l (8 + 8 + 8 mantissa bits; the two subtractions are exact), and a product keeps the six partial
-// products down to 2^-16 (hh, hm, mh, hl, lh, mm) -- what is dropped is <= 2^-23 relative, the rounding of one f32
-// operation.  v_mfma_f32_32x32x16_bf16 contracts 16 elements in 8 passes where the exact-f32 v_mfma_f32_32x32x2_f32 needs
-// 8 instructions of 16 passes: six bf16 products cost 3/8 of the matrix-pipe time of one f32 product (the first version
-// of this kernel ran on the f32 cores: 314 us per level-0 iteration at B = 32, 41 % of that pipe's peak).  Accumulation
-// is f32 in both; only the summation order differs from the tap loop (parity bar: 1e-3 px, measured ~1e-6).
-//
-// One wave owns a (image pair, 32-column strip): the horizontal pass gives it U[all rows][its 32 columns] in accumulator
-// registers, which ARE the B operand of the vertical pass (the contraction index simply follows the accumulator's row
-// order, Gv is gathered accordingly once per launch) -- no exchange of U through LDS.  NB = 2 (images up to 64 x 64): two
-// waves per pair, two pairs per workgroup; NB = 1 (up to 32 x 32, the coarse level): one wave per pair, four per workgroup.
-// The channel image is staged zero-padded in LDS (double buffered, next channel's loads in flight under the MFMAs).
+// (Rounds 2-5 also kept a two-launch iteration for the same levels -- UpdateMatrices writing M, fb_tile_mfma_kernel /
+// fb_tile_mfma_q_kernel blurring it on the bf16 matrix cores with three-term operands -- for widths that are no multiple of
+// four and as a cross-check; removed in round 6: those levels take the frame family's kernels (farneback_frame.h), which are
+// also the level kernel's cross-check now.)
 typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt, int mosaic) {
@@ -224,365 +214,6 @@ __global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict
 
 __device__ __forceinline__ int fb_acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-struct FbSplit3 { bf16x8 h, m, l; };
-
-// x[0..7] -> three bf16x8 with x = h + m + l up to 2^-24 |x| (truncation split; element i in bf16 slot i)
-__device__ __forceinline__ FbSplit3 fb_split3(const float (&x)[8]) {
-  u32x4 hw, mw, lw;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const uint32_t a = __builtin_bit_cast(uint32_t, x[2 * j]), b = __builtin_bit_cast(uint32_t, x[2 * j + 1]);
-    hw[j] = __builtin_amdgcn_perm(b, a, 0x07060302u);                 // (b & 0xffff0000) | (a >> 16)
-    const float ra = x[2 * j] - __builtin_bit_cast(float, a & 0xffff0000u);
-    const float rb = x[2 * j + 1] - __builtin_bit_cast(float, b & 0xffff0000u);
-    const uint32_t a1 = __builtin_bit_cast(uint32_t, ra), b1 = __builtin_bit_cast(uint32_t, rb);
-    mw[j] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-    const float sa = ra - __builtin_bit_cast(float, a1 & 0xffff0000u);
-    const float sb = rb - __builtin_bit_cast(float, b1 & 0xffff0000u);
-    lw[j] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, sb), __builtin_bit_cast(uint32_t, sa), 0x07060302u);
-  }
-  FbSplit3 o;
-  o.h = __builtin_bit_cast(bf16x8, hw);
-  o.m = __builtin_bit_cast(bf16x8, mw);
-  o.l = __builtin_bit_cast(bf16x8, lw);
-  return o;
-}
-
-// acc += A B with both operands split: the six partial products above 2^-24, smallest first
-__device__ __forceinline__ fb_v16f fb_mfma3(const FbSplit3& a, const FbSplit3& b, fb_v16f acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
-  return acc;
-}
-
-template <int NB>   // tile edge = 32 NB; NB waves per image pair, 4 / NB pairs per workgroup
-// (NB == 1: 80 accumulator registers and 47 KB of LDS -- two workgroups per CU)
-__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void fb_tile_mfma_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
-                                                            const float* __restrict__ Gh, float* __restrict__ flow,
-                                                            int height, int width, long long n_pairs) {
-  constexpr int T = 32 * NB, XS = T + 8, PLANE = T * XS, PPW = 4 / NB, KS = 2 * NB;   // KS contraction steps of 16
-  constexpr int NE = T * T / (64 * NB);      // staged elements per lane and channel
-  // NB > 1: the channel image is split ONCE, while it is staged: three bf16 planes (h, m, l) per buffer -- both strips of a
-  // pair read the same image as their A operand, so splitting at the read would do the work twice (level-0 iteration
-  // 238 -> 218 us).  NB == 1: one wave per pair reads its image once, so it stays f32 in LDS (a third of the LDS bytes) and is
-  // split at the read (planes 1, 2 unused: 2 bf16 = 1 float per element of plane 0 ... the f32 image takes planes 0 and 1).
-  constexpr bool PRESPLIT = NB > 1;
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[PPW][2][PRESPLIT ? 3 : 2][PLANE];
-  // Gv split operands, lane-major: the same for every wave (they depend on the output row = lane, not on the strip)
-  __shared__ u32x4 GvS[NB * KS * 3][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, half = lane >> 5;
-  const int pw = wave / NB, strip = wave % NB;
-  const long long per_img = (long long)height * width;
-
-  // ---- constant operands, split once: Gh^T as B operand of the horizontal pass (k = x' in natural order), Gv as A operand of
-  // the vertical pass (k-slot i of lane-half h in step (blk, s) = accumulator row fb_acc_row(8 s + i, h) of row block blk)
-  FbSplit3 gh[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
-    gh[ks] = fb_split3(t);
-  }
-  for (int j = wave; j < NB * KS; j += 4) {      // (mbo, ks) pairs dealt to the four waves
-    const int mbo = j / KS, ks = j - mbo * KS;
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
-    const FbSplit3 g = fb_split3(t);
-    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
-    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
-    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
-  }
-  __syncthreads();
-
-  const bool vec = (width & 3) == 0 && ((uintptr_t)Min & 15) == 0;
-  const long long groups = (n_pairs + PPW - 1) / PPW;
-  for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    const long long p = grp * PPW + pw;
-    const bool p_ok = p < n_pairs;
-    fb_v16f res[5][NB];
-    float stg[NE];   // one channel image in flight: the loads of channel c + 1 are issued before the MFMAs of channel c
-    // staging element e of this lane: vec: quad q = strip*64 + lane + 64 NB (e / 4), column 4 (q % (T/4)) + e % 4;
-    // scalar: index i = strip*64 + lane + 64 NB e
-    auto load_channel = [&](int c) {
-      const float* src = Min + ((p_ok ? p : 0) * 5 + c) * per_img;
-      if (vec) {
-#pragma unroll
-        for (int e = 0; e < NE / 4; ++e) {
-          const int q = strip * 64 + lane + 64 * NB * e;      // quad of 4 consecutive columns
-          const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (p_ok && y < height && x < width) v = *reinterpret_cast<const f32x4*>(src + (long long)y * width + x);
-          stg[4 * e] = v[0]; stg[4 * e + 1] = v[1]; stg[4 * e + 2] = v[2]; stg[4 * e + 3] = v[3];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const int i = strip * 64 + lane + 64 * NB * e;
-          const int y = i / T, x = i - y * T;
-          stg[e] = (p_ok && y < height && x < width) ? src[(long long)y * width + x] : 0.f;
-        }
-      }
-    };
-    load_channel(0);
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      // ---- channel c (zero padded to the tile), split into its three bf16 planes, into this pair's LDS image; the next
-      // channel's loads start right away -----------------------------------------------------------------------------------
-      uint16_t* Xc = &Xs[pw][c & 1][0][0];
-      float* Xf = reinterpret_cast<float*>(Xc);     // !PRESPLIT: f32 image, row stride XS floats
-      if constexpr (!PRESPLIT) {
-        if (vec) {
-#pragma unroll
-          for (int e = 0; e < NE / 4; ++e) {
-            const int q = strip * 64 + lane + 64 * NB * e;
-            const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
-            *reinterpret_cast<f32x4*>(Xf + y * XS + x) = (f32x4){stg[4 * e], stg[4 * e + 1], stg[4 * e + 2], stg[4 * e + 3]};
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            const int i = strip * 64 + lane + 64 * NB * e;
-            const int y = i / T;
-            Xf[y * XS + (i - y * T)] = stg[e];
-          }
-        }
-      } else
-#pragma unroll
-      for (int e8 = 0; e8 < NE / 8; ++e8) {
-        const float t[8] = {stg[8 * e8], stg[8 * e8 + 1], stg[8 * e8 + 2], stg[8 * e8 + 3],
-                            stg[8 * e8 + 4], stg[8 * e8 + 5], stg[8 * e8 + 6], stg[8 * e8 + 7]};
-        const FbSplit3 sp = fb_split3(t);
-        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
-        if (vec) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {        // two quads of 4 consecutive columns
-            const int q = strip * 64 + lane + 64 * NB * (2 * e8 + u);
-            const int y = q / (T / 4), x = (q - y * (T / 4)) * 4;
-            *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u], hw[2 * u + 1]};
-            *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u], mw[2 * u + 1]};
-            *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u], lw[2 * u + 1]};
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = strip * 64 + lane + 64 * NB * (8 * e8 + u);
-            const int y = i / T, x = i - y * T;
-            const int sh = (u & 1) * 16;
-            Xc[y * XS + x] = (uint16_t)(hw[u >> 1] >> sh);
-            Xc[PLANE + y * XS + x] = (uint16_t)(mw[u >> 1] >> sh);
-            Xc[2 * PLANE + y * XS + x] = (uint16_t)(lw[u >> 1] >> sh);
-          }
-        }
-      }
-      if (NB > 1) __syncthreads();   // the image is staged by both waves of the pair (the buffer of channel c - 1 may still be read)
-      else __builtin_amdgcn_wave_barrier();
-      if (c < 4) load_channel(c + 1);
-      // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'], all row blocks, this wave's 32 columns ----------------------
-      fb_v16f u[NB];
-#pragma unroll
-      for (int mb = 0; mb < NB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          FbSplit3 a;
-          if constexpr (PRESPLIT) {
-            const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-            a.h = *reinterpret_cast<const bf16x8*>(xa);
-            a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
-            a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
-          } else {
-            const float* xa = Xf + (32 * mb + col) * XS + 16 * ks + 8 * half;
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(xa), x1 = *reinterpret_cast<const f32x4*>(xa + 4);
-            const float t[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            a = fb_split3(t);
-          }
-          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
-        }
-      }
-      // ---- vertical: Out[y][x] = sum_y' Gv[y][y'] U[y'][x]: the accumulators of the horizontal pass are the B operand -------
-#pragma unroll
-      for (int mbo = 0; mbo < NB; ++mbo)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[c][mbo][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
-        const FbSplit3 b = fb_split3(t);
-#pragma unroll
-        for (int mbo = 0; mbo < NB; ++mbo) {
-          FbSplit3 g;
-          g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
-          g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
-          g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
-          res[c][mbo] = fb_mfma3(g, b, res[c][mbo]);
-        }
-      }
-    }
-    if (NB > 1) __syncthreads();   // both image buffers free before the next pair's channels 0 / 1 are staged
-    // ---- 2x2 solve; accumulator register r = row y, lane = column x: coalesced flow rows ---------------------------------
-    if (p_ok) {
-#pragma unroll
-      for (int mbo = 0; mbo < NB; ++mbo)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
-          if (y < height && x < width) {
-            double g11 = res[0][mbo][r], g12 = res[1][mbo][r], g22 = res[2][mbo][r], h1 = res[3][mbo][r], h2 = res[4][mbo][r];
-            double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-            double idet = __ddiv_rn(1.0, det);
-            const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-            const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-            float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
-            fl[0] = fxv;
-            fl[1] = fyv;
-          }
-        }
-    }
-  }
-}
-
-// ---- 64 x 64 tiles, second form: one wave per QUADRANT of the output, two workgroups per CU ---------------------------
-// fb_tile_mfma_kernel<2> gives a wave a 64-row x 32-column strip: 5 channels x 2 row blocks of results = 160 accumulator
-// registers, which pins the kernel at one wave per SIMD -- and its counters read: matrix pipe busy 23 %, vector ALU 38 %,
-// parked 38 % of the wave's cycles (nothing covers a wave's splits, LDS round trips and barriers).  Here a wave owns ONE
-// 32 x 32 quadrant (strip, output row block mbo): the vertical pass needs U of both row blocks of its strip, so the
-// horizontal pass is computed by both waves of a strip (48 + 24 instead of 48 + 48 MFMA triples per channel and wave: half as
-// many again matrix instructions per pair), but the results are 5 x 16 registers and the workgroup (= one pair, 79 KB of
-// LDS) fits a CU TWICE: two waves per SIMD, each running while the other splits operands or waits.  Staging is shared by the
-// four waves (16 values per lane and channel, split once into the three bf16 planes), double buffered over the channels.
-// Same arithmetic as fb_tile_mfma_kernel<2> per output element (the products and their order inside fb_mfma3; the
-// contraction order of both passes), so the flows are bit-identical to it.
-__global__ __launch_bounds__(256, 2) void fb_tile_mfma_q_kernel(const float* __restrict__ Min, const float* __restrict__ Gv,
-                                                                const float* __restrict__ Gh, float* __restrict__ flow,
-                                                                int height, int width, long long n_pairs) {
-  constexpr int T = 64, XS = T + 8, PLANE = T * XS, KS = 4;
-  constexpr int NE = T * T / 256;            // staged elements per lane and channel
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[2][3][PLANE];
-  __shared__ u32x4 GvS[2 * KS * 3][64];      // [mbo][ks][plane], lane-major
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = lane & 31, half = lane >> 5;
-  const int strip = wave & 1, mbo = wave >> 1;
-  const long long per_img = (long long)height * width;
-
-  FbSplit3 gh[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
-    gh[ks] = fb_split3(t);
-  }
-  for (int j = wave; j < 2 * KS; j += 4) {      // (mbo, ks) pairs dealt to the four waves
-    const int mb = j / KS, ks = j - mb * KS;
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * mb + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
-    const FbSplit3 g = fb_split3(t);
-    GvS[j * 3 + 0][lane] = __builtin_bit_cast(u32x4, g.h);
-    GvS[j * 3 + 1][lane] = __builtin_bit_cast(u32x4, g.m);
-    GvS[j * 3 + 2][lane] = __builtin_bit_cast(u32x4, g.l);
-  }
-  __syncthreads();
-
-  for (long long p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-    fb_v16f res[5];
-    float stg[NE];
-    // staging element e of this thread: quad q = tid + 256 (e / 4) of 4 consecutive columns, column 4 (q % 16) + e % 4
-    auto load_channel = [&](int c) {
-      const float* src = Min + (p * 5 + c) * per_img;
-#pragma unroll
-      for (int e = 0; e < NE / 4; ++e) {
-        const int q = tid + 256 * e;
-        const int y = q >> 4, x = (q & 15) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y < height && x < width) v = *reinterpret_cast<const f32x4*>(src + (long long)y * width + x);
-        stg[4 * e] = v[0]; stg[4 * e + 1] = v[1]; stg[4 * e + 2] = v[2]; stg[4 * e + 3] = v[3];
-      }
-    };
-    load_channel(0);
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      uint16_t* Xc = &Xs[c & 1][0][0];
-#pragma unroll
-      for (int e8 = 0; e8 < NE / 8; ++e8) {
-        const float t[8] = {stg[8 * e8], stg[8 * e8 + 1], stg[8 * e8 + 2], stg[8 * e8 + 3],
-                            stg[8 * e8 + 4], stg[8 * e8 + 5], stg[8 * e8 + 6], stg[8 * e8 + 7]};
-        const FbSplit3 sp = fb_split3(t);
-        const u32x4 hw = __builtin_bit_cast(u32x4, sp.h), mw = __builtin_bit_cast(u32x4, sp.m), lw = __builtin_bit_cast(u32x4, sp.l);
-#pragma unroll
-        for (int u2 = 0; u2 < 2; ++u2) {        // two quads of 4 consecutive columns
-          const int q = tid + 256 * (2 * e8 + u2);
-          const int y = q >> 4, x = (q & 15) * 4;
-          *reinterpret_cast<u32x2*>(Xc + y * XS + x) = (u32x2){hw[2 * u2], hw[2 * u2 + 1]};
-          *reinterpret_cast<u32x2*>(Xc + PLANE + y * XS + x) = (u32x2){mw[2 * u2], mw[2 * u2 + 1]};
-          *reinterpret_cast<u32x2*>(Xc + 2 * PLANE + y * XS + x) = (u32x2){lw[2 * u2], lw[2 * u2 + 1]};
-        }
-      }
-      __syncthreads();   // the image is staged by all four waves (the buffer of channel c - 1 may still be read)
-      if (c < 4) load_channel(c + 1);
-      // ---- horizontal: U[y'][x] = sum_x' X[y'][x'] Gh[x][x'], both row blocks, this wave's 32 columns ----------------------
-      fb_v16f u[2];
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          FbSplit3 a;
-          const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
-          a.h = *reinterpret_cast<const bf16x8*>(xa);
-          a.m = *reinterpret_cast<const bf16x8*>(xa + PLANE);
-          a.l = *reinterpret_cast<const bf16x8*>(xa + 2 * PLANE);
-          u[mb] = fb_mfma3(a, gh[ks], u[mb]);
-        }
-      }
-      // ---- vertical, this wave's output row block: Out[y][x] = sum_y' Gv[y][y'] U[y'][x] -----------------------------------
-#pragma unroll
-      for (int r = 0; r < 16; ++r) res[c][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float t[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
-        const FbSplit3 b = fb_split3(t);
-        FbSplit3 g;
-        g.h = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 0][lane]);
-        g.m = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 1][lane]);
-        g.l = __builtin_bit_cast(bf16x8, GvS[(mbo * KS + ks) * 3 + 2][lane]);
-        res[c] = fb_mfma3(g, b, res[c]);
-      }
-    }
-    __syncthreads();   // both image buffers free before the next pair's channels 0 / 1 are staged
-    // ---- 2x2 solve; accumulator register r = row y, lane = column x: coalesced flow rows ---------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int y = 32 * mbo + fb_acc_row(r, half), x = 32 * strip + col;
-      if (y < height && x < width) {
-        double g11 = res[0][r], g12 = res[1][r], g22 = res[2][r], h1 = res[3][r], h2 = res[4][r];
-        double det = __dadd_rn(__dsub_rn(__dmul_rn(g11, g22), __dmul_rn(g12, g12)), 1e-3);
-        double idet = __ddiv_rn(1.0, det);
-        const float fxv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g11, h2), __dmul_rn(g12, h1)), idet);
-        const float fyv = (float)__dmul_rn(__dsub_rn(__dmul_rn(g22, h1), __dmul_rn(g12, h2)), idet);
-        float* fl = flow + (p * per_img + (long long)y * width + x) * 2;
-        fl[0] = fxv;
-        fl[1] = fyv;
-      }
-    }
-  }
-}
-
-typedef int fb_i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) unsigned char* fb_lds_ptr;
 // ---- building blocks of the level kernel (fb_level_u_kernel) and of the matrix-core PolyExp (round 4) ------------------------
 // What the counters and stamps of round 3's fused iteration said (profiles/r03): its R1 gathers hit the LDS four ways (20-byte
 // records, a wave's four rows on the same banks), and on the vector ALU the three-way bf16 split (5.5 instructions per

@@ -395,18 +395,17 @@ def linear_bf16(x, weight, bias, relu=False, x_is_relu_output=False):
     return LinearBF16.apply(x, weight, bias, relu, x_is_relu_output)
 
 
-F32_WGRAD_ON_BF16X3 = True      # tools/ab_step-style switch: False = always the f32 matrix-core weight gradient
-F32_WGRAD_SPLIT = "f16x2"       # "f16x2": two half-float terms, three launches; "bf16x3": three bf16 terms, six launches
+F32_WGRAD_ON_F16X2 = True       # tools/ab_step-style switch: False = always the f32 matrix-core weight gradient
 
 
 def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (int(v),) * 3
 
 
-def _wgrad_on_bf16x3(x, dy, y, weight, stride) -> bool:
+def _wgrad_on_f16x2(x, dy, y, weight, stride) -> bool:
     """3x3x3, stride 1, 32 output channels, <= 32 input channels, dy already gated (y is None), a batch worth the six
     launches, and the split kernel's alignment (voxels per sample % 4 == 0 on both tensors)."""
-    if not F32_WGRAD_ON_BF16X3 or exact_f32() or y is not None or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
+    if not F32_WGRAD_ON_F16X2 or exact_f32() or y is not None or tuple(weight.shape[2:]) != (3, 3, 3) or _triple(stride) != (1, 1, 1):
         return False
     if weight.shape[0] != 32 or weight.shape[1] > 32:
         return False
@@ -565,13 +564,10 @@ class Conv3dGeneralF32(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = K.conv3d_general_bwd_data_f32(dy, y, weight.contiguous(), tuple(x.shape), ctx.stride, ctx.padding,
                                                x_mask=x if ctx.x_is_relu_output else None)
-        if _wgrad_on_bf16x3(x, dy, y, weight, ctx.stride):
-            # the PV-yield model's 3x3x3 layers: six launches of the bf16 weight-gradient kernel on split operands instead of
-            # one at the f32 matrix rate (0.9-1.35 ms -> ~0.6 ms per layer at B = 32), f32-accurate (hip_ops docstring)
-            if F32_WGRAD_SPLIT == "f16x2":
-                dw, db = K.conv3d_bwd_weight_f32_on_f16x2(x, dy, _triple(ctx.padding), dy_maxabs_state=_gated_max_of(dy))
-            else:
-                dw, db = K.conv3d_bwd_weight_f32_on_bf16x3(x, dy, _triple(ctx.padding))
+        if _wgrad_on_f16x2(x, dy, y, weight, ctx.stride):
+            # the PV-yield model's 3x3x3 layers: three launches of the 16-bit weight-gradient kernel on two-term half-float
+            # operands instead of one at the f32 matrix rate, f32-accurate (hip_ops.conv3d_bwd_weight_f32_on_f16x2)
+            dw, db = K.conv3d_bwd_weight_f32_on_f16x2(x, dy, _triple(ctx.padding), dy_maxabs_state=_gated_max_of(dy))
             return dx, dw, (db if ctx.has_bias else None), None, None, None, None, None
         dw, db = K.conv3d_general_bwd_weight_f32(x, dy, y, tuple(weight.shape), ctx.stride, ctx.padding,
                                                  need_bias=ctx.has_bias)

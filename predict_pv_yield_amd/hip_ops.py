@@ -240,45 +240,6 @@ def pack_ncdhw_f32_to_ndhwc_bf16(x: torch.Tensor) -> torch.Tensor:
     return xp
 
 
-def pack_split3_ncdhw_f32_to_ndhwc_bf16(x: torch.Tensor):
-    """x f32 [B,C,T,H,W] -> (h, m, l), three bf16 [B,T,H,W,CPAD] images with x = h + m + l (truncation split: 8 + 8 + 8
-    mantissa bits, the rest below 2^-24 |x|).  T*H*W must be a multiple of 4."""
-    require_cuda(x)
-    if x.dtype != torch.float32 or x.dim() != 5 or not x.is_contiguous():
-        raise TypeError("pack_split3_ncdhw_f32_to_ndhwc_bf16: a contiguous float32 [B,C,T,H,W] tensor is expected")
-    b, c, t, h, w = x.shape
-    planes = torch.empty((3, b, t, h, w, bf16_cpad(c)), dtype=torch.bfloat16, device=x.device)
-    check(get_lib().pv_pack_split3_ncdhw_f32_to_ndhwc_bf16(ptr(x), ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), b, c, t, h, w,
-                                                           current_stream_ptr()), "pv_pack_split3_ncdhw_f32_to_ndhwc_bf16")
-    return planes[0], planes[1], planes[2]
-
-
-def conv3d_bwd_weight_f32_on_bf16x3(x: torch.Tensor, dy: torch.Tensor, padding=(0, 0, 0)):
-    """Weight and bias gradient of a 3x3x3, stride-1 Conv3d with 32 output channels at f32 accuracy on the BF16 matrix
-    cores: x f32 [B,Ci<=32,T,H,W] and dy f32 [B,32,To,Ho,Wo] (already multiplied by the ReLU derivative) are split three ways
-    (pack_split3_...), the bf16 weight-gradient kernel runs on the six operand pairs whose product is above 2^-24 of the
-    result -- (m,m), (l,h), (h,l), (m,h), (h,m), (h,h) -- and the six f32 results are added in that order (smallest first).
-    Six launches at the bf16 rate cost 3/8 of one launch at the f32 matrix rate.  -> (dw [32,Ci,3,3,3], db [32])."""
-    ci = x.shape[1]
-    xs = pack_split3_ncdhw_f32_to_ndhwc_bf16(x)
-    ds = pack_split3_ncdhw_f32_to_ndhwc_bf16(dy)
-    H, M, L = 0, 1, 2
-    order = ((M, M), (L, H), (H, L), (M, H), (H, M), (H, H))      # (plane of x, plane of dy)
-    parts = torch.empty((6, 32 * ci * 27), dtype=torch.float32, device=x.device)
-    dbs = {}
-    for i, (px, pd) in enumerate(order):
-        dw_i, db_i = conv3d_bwd_weight_bf16(xs[px], ds[pd], None, ci, 32, padding)
-        parts[i].copy_(dw_i.reshape(-1))
-        if px == H:
-            dbs[pd] = db_i.clone()       # the bias gradient is the plain sum of dy: one term per plane of dy
-    dw = torch.empty((32, ci, 3, 3, 3), dtype=torch.float32, device=x.device)
-    check(get_lib().pv_sum_slabs_acc_f32(ptr(parts), ptr(dw), parts.shape[1], 6, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
-    dbp = torch.stack((dbs[L], dbs[M], dbs[H]))
-    db = torch.empty(32, dtype=torch.float32, device=x.device)
-    check(get_lib().pv_sum_slabs_acc_f32(ptr(dbp), ptr(db), 32, 3, 0, current_stream_ptr()), "pv_sum_slabs_acc_f32")
-    return dw, db
-
-
 def pack_split2_ncdhw_f32_to_ndhwc_f16(x: torch.Tensor, maxabs_state: Optional[torch.Tensor] = None, cpad32: bool = False):
     """x f32 [B,C,T,H,W] -> (h, l, state): two half-float [B,T,H,W,CPAD] images with x s = h + l (22 significant bits) and
     state = device f32[3] (scratch, s, 1/s), s the power of two that brings max |x| below 2^14.  T*H*W must be a multiple of 4.
@@ -325,7 +286,8 @@ def conv3d_bwd_weight_f32_on_f16x2(x: torch.Tensor, dy: torch.Tensor, padding=(0
     x f32 [B,Ci<=32,T,H,W] and dy f32 [B,32,To,Ho,Wo] (already multiplied by the ReLU derivative) are each scaled by a power of
     two and split in two half-float terms (22 bits), the weight-gradient kernel runs on the three operand pairs whose product
     is above 2^-22 of the result -- (l,h), (h,l), (h,h) -- and the three f32 results are added in that order, then un-scaled.
-    Half the matrix work and 4/5 of the split traffic of conv3d_bwd_weight_f32_on_bf16x3.  -> (dw [32,Ci,3,3,3], db [32])."""
+    (Round 3's three-term bf16 split -- six launches, 10 bytes of split traffic per element -- was removed in round 6.)
+    -> (dw [32,Ci,3,3,3], db [32])."""
     ci = x.shape[1]
     xh, xl, xs = pack_split2_ncdhw_f32_to_ndhwc_f16(x)
     dh, dl, ds = pack_split2_ncdhw_f32_to_ndhwc_f16(dy, maxabs_state=dy_maxabs_state)

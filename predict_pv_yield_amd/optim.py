@@ -291,9 +291,10 @@ class HipAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         if self._layout_frozen:
             # super().load_state_dict() REPLACES the state tensors; a captured graph would keep replaying on the old addresses
-            # (with moments_tiled = 1 baked into its kernel arguments) and silently ignore the loaded state
-            raise RuntimeError("HipAdam.load_state_dict(): a captured HIP graph (graphs.GraphedTrainStep) holds this optimiser's "
-                               "state tensors -- release the graph first (GraphedTrainStep.close()), load, capture again")
+            # (with moments_tiled = 1 baked into its kernel arguments) and silently ignore the loaded state.  While a graph
+            # lives, the loaded values are copied INTO the tensors it holds instead, in the layout they have.
+            self._load_state_in_place(state_dict)
+            return
         super().load_state_dict(state_dict)
         for p in self._params_in_order():
             c = self._k_channels(p)
@@ -307,6 +308,35 @@ class HipAdam(torch.optim.Optimizer):
             steps = [int(st["step"].item()) for st in self.state.values() if "step" in st]
             if self._dev_step is not None:
                 # in place: a captured graph holds this tensor's address
+                self._dev_step.fill_(max(steps) if steps else 0)
+            self._dev_fresh = False
+
+    def _load_state_in_place(self, state_dict) -> None:
+        params = self._params_in_order()
+        packed = state_dict["state"]
+        if len(state_dict["param_groups"]) != len(self.param_groups) or \
+                sum(len(g["params"]) for g in state_dict["param_groups"]) != len(params):
+            raise ValueError("HipAdam.load_state_dict(): the state dict's parameter groups do not match this optimiser's")
+        with torch.no_grad():
+            for i, p in enumerate(params):
+                src = packed.get(i)
+                if src is None:
+                    continue
+                st = self._init_state(p)
+                c, tiled = self._k_channels(p), self._is_tiled(p)
+                for key in ("exp_avg", "exp_avg_sq"):
+                    t = src[key].to(device=st[key].device, dtype=st[key].dtype)
+                    if c:
+                        t = _k_to_channels_last(t, c).contiguous()
+                    if tiled:
+                        t = K.moments_to_tiled(t)
+                    st[key].copy_(t)
+                st["step"].fill_(float(src["step"]))
+        for g, sg in zip(self.param_groups, state_dict["param_groups"]):
+            g.update({k: v for k, v in sg.items() if k != "params"})
+        if self.capturable:
+            steps = [int(st["step"].item()) for st in self.state.values() if "step" in st]
+            if self._dev_step is not None:
                 self._dev_step.fill_(max(steps) if steps else 0)
             self._dev_fresh = False
 

@@ -337,9 +337,16 @@ def test_capturable_checkpoint_carries_the_device_step(device):
     for a, b, c in zip(p_host, p_dev, model.parameters()):
         torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
         assert torch.equal(b, c.detach())              # same device-side scalars: bit for bit
-    # a loaded state dict lands in the live device counter in place (the graph holds its address)
+    # a loaded state dict lands in the live device counter AND in the live moment tensors in place (the graph holds their
+    # addresses and, for fc1, the tile layout they were captured in): nothing is replaced under the graph
+    fc1 = model.fc1.weight
+    addr = opt.state[fc1]["exp_avg"].data_ptr()
     opt.load_state_dict(copy.deepcopy(sd))
     assert opt.device_step() == 8
+    assert opt.state[fc1]["exp_avg"].data_ptr() == addr
+    idx = [i for i, q in enumerate(opt._params_in_order()) if q is fc1][0]
+    m_live, v_live = opt.moments(fc1)                  # row-major, reference column order -- what the dict holds
+    assert torch.equal(m_live.cpu(), sd["state"][idx]["exp_avg"].cpu()) and torch.equal(v_live.cpu(), sd["state"][idx]["exp_avg_sq"].cpu())
     # kernel arguments are frozen: changing lr must not be ignored silently
     opt.param_groups[0]["lr"] = 1e-4
     with pytest.raises(RuntimeError, match="changed after capture"):

@@ -20,7 +20,6 @@ dev = torch.device("cuda:0")
 SLOTS, WAVES = 8, 1 << 14
 LABELS = {
     "wgrad": ("pv_diag_read_wgrad2", ["barrier (loaders / other waves)", "16 k-steps (MFMA)", "items"]),
-    "wgrad_v1": ("pv_diag_read_wgrad", ["wait loads + LDS writes", "barrier", "issue next loads", "32 k-steps (MFMA)", "barrier", "slices"]),
     "v3": ("pv_diag_read_v3", ["vmcnt(0)", "barrier", "issue loads/stores", "MFMA kw=0", "(unused)", "gate request + MFMA kw=1,2",
                                "convert + swap + gate", "steps"]),
     "first": ("pv_diag_read_first", ["barrier (waiting for the loaders)", "MFMA groups", "epilogue", "slices"]),
