@@ -118,6 +118,33 @@ def test_bf16_gradients_vs_f32_oracle_loose(device):
         _check(f"loose grad {k} rel", _rel(ref_order(p, p.grad).cpu(), q.grad), bound)
 
 
+def test_bf16_conv_gradients_within_2_percent_of_f32_with_its_relu_masks_forced(device):
+    """The GPU twin of tests/test_oracle_conv.py::test_bf16_gradient_distance_split_into_relu_flips_and_rounding (VERDICT r5
+    item 4): the loose test above admits 15 % on the conv gradients because ReLU units within bf16 rounding of zero flip.  With
+    the f32 oracle's masks forced on the HIP bf16 tower (tools/relu_masks.py rewrites every ReLU layer's output signs before
+    autograd saves them) no unit can flip, and what is left is operand rounding: every conv gradient within 2 % norm-wise
+    (the oracle-only split measured 0.5 %), the fc layers within the loose test's bounds."""
+    import torch.nn.functional as F
+    from tools.relu_masks import forced_relu_masks
+    oracle, model = _pair("bf16", device)
+    sat, pv = _data(4, seed=3)
+    y_ref, ref_losses = _oracle_backward(oracle, sat, pv)
+    with torch.no_grad():                       # the oracle's own masks, layer by layer (the reference's arithmetic)
+        out, conv_masks = sat, []
+        for layer in [oracle.sat_conv0] + [getattr(oracle, f"conv3d_{i + 1}") for i in range(3)]:
+            out = F.relu(F.conv3d(out, layer.weight, layer.bias))
+            conv_masks.append((out > 0).to(device))
+        fc1_mask = (F.linear(out.reshape(4, -1), oracle.fc1.weight, oracle.fc1.bias) > 0).to(device)
+    with forced_relu_masks(conv_masks, fc1_mask) as forced:
+        loss = model.training_step(_batch(sat, pv, device), 0)
+        loss.backward()
+    assert forced.forced == 5                   # four conv layers + fc1
+    assert abs(float(loss) - ref_losses[1]) <= 1e-2 * ref_losses[1]
+    for (k, p), (_, q) in zip(model.named_parameters(), oracle.named_parameters()):
+        bound = 0.02 if "conv" in k else (6e-3 if k.startswith(("fc1", "fc2")) else 1e-3)
+        _check(f"masks forced: grad {k} rel", _rel(ref_order(p, p.grad).cpu(), q.grad), bound)
+
+
 def _adam_compare(model, opt, oracle, ref_opt, lr_frac_mean, frac_whole_step, tag=""):
     """Parameters after the same number of Adam steps on both sides: mean abs difference in units of one step (lr), and
     the FRACTION of weights that disagree by more than a whole step.  (Adam moves a weight by at most ~lr per step whatever
