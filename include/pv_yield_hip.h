@@ -410,6 +410,18 @@ int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const f
                                      int64_t k, const float* adam_scalars_dev, int32_t gate_dx_by_x, int32_t moments_tiled,
                                      void* stream);
 
+/* The same one-pass backward for the K-SHARDED data-parallel mode (HipAdam large_grad_mode "ksharded"): param / exp_avg /
+ * exp_avg_sq / bf16_shadow are this rank's COLUMN shard [n][k = K / world] of fc1 (dense, row stride k), x [m][k] the exchanged
+ * activations and dy [m][n] the all-gathered, already gated output gradients of ALL m = world x per-GPU-batch samples (any m;
+ * taken in blocks of 32).  The weight gradient of the shard over the whole global batch is scaled by grad_scale (1 / world:
+ * the averaging of DDP's all-reduce, experiments/003_...py:292-293) on its way into Adam; dx [m][k] = dy . W_old is not, and is
+ * multiplied by (x > 0) when gate_dx_by_x.  No gradient or weight of fc1 crosses a link in this mode.  n <= 128, n % 8 == 0,
+ * k % 8 == 0, 16-byte aligned buffers; bf16_shadow and dx may be NULL. */
+int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
+                                      uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
+                                      double beta1, double beta2, double eps, int32_t step, float grad_scale,
+                                      int32_t gate_dx_by_x, void* stream);
+
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,
                           int32_t step, float grad_scale, void* stream);

@@ -579,6 +579,190 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass for the K-SHARDED fc1 (distributed.py, HipAdam large_grad_mode "ksharded"): this rank's COLUMN shard of the
+// weight, [n <= 128][k = K / W], and ALL samples of the global batch: m = W x per-GPU batch rows (256 at 8 x 32), taken in
+// blocks of 32.  A workgroup owns 128 k-columns as above and walks the row blocks twice: once to accumulate the gradient tile
+// (the x block and the g block staged in LDS per block), then -- after the Adam rows, with the pre-update weights parked
+// transposed in LDS -- once more for dx, block by block on the matrix cores.  The outgoing dx block has LDS bytes of its own
+// (the weight tile must survive all blocks): 59 KB, two workgroups per CU.  dy arrives already gated (the all-gathered
+// g = dy (.) relu' of every rank); the gradient is scaled by grad_scale (1 / world: the mean of DDP's all-reduce) on its way
+// into Adam, dx is not.  Replaces, per rank and step at 8 x 32 rows: eight dx launches + the register-tiled weight-gradient +
+// Adam launch (345 us) by one pass at the shard's memory traffic.
+// ---------------------------------------------------------------------------------------------
+template <int AHEAD>
+__global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
+    const uint16_t* __restrict__ x, const float* __restrict__ dy, float* __restrict__ w, int m, int n, long long k,
+    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow, uint16_t* __restrict__ dx,
+    AdamScalars ad, int gate_dx, float grad_scale) {
+  __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g block [b][n], zero padded
+  __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
+  __shared__ __attribute__((aligned(16))) uint16_t dxs[32 * FD_XLD];        // the outgoing dx block [b][k]
+  uint16_t* xs = wt;      // the x blocks [b][k] use wt's first bytes while the gradient is accumulated (wt is written after that)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = tid & 15, rg = tid >> 4;
+  const long long k0 = (long long)blockIdx.x * FD_KT;
+  const long long k8 = k0 + 8 * kq;
+  const bool k_ok = k8 < k;
+  f32x4 nxt[AHEAD][6];
+  auto fetch = [&](int i) {
+    const int r = min(8 * rg + i, n - 1);
+    const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
+    f32x4 (&d)[6] = nxt[i % AHEAD];
+    d[0] = *reinterpret_cast<const f32x4*>(w + off);
+    d[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
+    d[2] = *reinterpret_cast<const f32x4*>(exp_avg + off);
+    d[3] = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
+    d[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
+    d[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+  };
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) fetch(i);
+  auto load_g = [&](int mb) {
+    for (int i = tid; i < 32 * 128; i += 256) {
+      const int b = 32 * mb + (i >> 7), nn = i & 127;
+      gs[i] = (b < m && nn < n) ? dy[(size_t)b * n + nn] : 0.f;
+    }
+  };
+  auto load_x = [&](int mb) {
+    for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks of the x block
+      const int bl = i / (FD_KT / 8), c = i - bl * (FD_KT / 8), b = 32 * mb + bl;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (b < m && k0 + 8 * c < k) v = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+      *reinterpret_cast<u32x4*>(xs + bl * FD_XLD + 8 * c) = v;
+    }
+  };
+  const int nblk = (m + 31) / 32;
+  // ---- weight gradient tile: rows 8 rg .. +7, columns k8 .. +7, summed over every row block (rows beyond m are zeros in LDS) ----
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t acc2[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
+  for (int mb = 0; mb < nblk; ++mb) {
+    if (mb) __syncthreads();      // every thread is through with the previous block's tiles
+    load_g(mb);
+    load_x(mb);
+    __syncthreads();
+#pragma unroll 4
+    for (int b = 0; b < 32; ++b) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * kq);
+      f32x2_t xv2[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg);
+      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float gv = i < 4 ? g0[i] : g1[i - 4];
+        const f32x2_t g2 = {gv, gv};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
+      }
+    }
+  }
+  // ---- Adam, row by row; the old weights are kept as bf16 ----------------------------------------------------------------------
+  uint32_t wold[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float pv[8], mv[8], vv[8];
+    *reinterpret_cast<f32x4*>(pv) = nxt[i % AHEAD][0];
+    *reinterpret_cast<f32x4*>(pv + 4) = nxt[i % AHEAD][1];
+    *reinterpret_cast<f32x4*>(mv) = nxt[i % AHEAD][2];
+    *reinterpret_cast<f32x4*>(mv + 4) = nxt[i % AHEAD][3];
+    *reinterpret_cast<f32x4*>(vv) = nxt[i % AHEAD][4];
+    *reinterpret_cast<f32x4*>(vv + 4) = nxt[i % AHEAD][5];
+    if (i + AHEAD < 8) fetch(i + AHEAD);
+    const bool row_ok = 8 * rg + i < n && k_ok;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wold[i][q] = row_ok ? (pack_bf16_pair(pv[2 * q], pv[2 * q + 1])) : 0u;
+    if (row_ok) {
+      const size_t off = (size_t)(8 * rg + i) * k + k8;
+      uint32_t sh[4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gr = __fmul_rn(acc2[i][j >> 1][j & 1], grad_scale);
+        const float mm = mv[j] + ad.one_minus_b1 * (gr - mv[j]);
+        const float v2 = vv[j] * ad.beta2 + (ad.one_minus_b2 * gr) * gr;
+        const float denom = sqrtf(v2) / ad.bc2_sqrt + ad.eps;
+        const float pp = pv[j] + ad.neg_step_size * (mm / denom);
+        mv[j] = mm; vv[j] = v2; pv[j] = pp;
+        if (j & 1) sh[j >> 1] |= (uint32_t)f32_to_bf16_bits(pp) << 16; else sh[j >> 1] = f32_to_bf16_bits(pp);
+      }
+      *reinterpret_cast<f32x4*>(w + off) = *reinterpret_cast<const f32x4*>(pv);
+      *reinterpret_cast<f32x4*>(w + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg + off) = *reinterpret_cast<const f32x4*>(mv);
+      *reinterpret_cast<f32x4*>(exp_avg + off + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + off) = *reinterpret_cast<const f32x4*>(vv);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + off + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
+      if (shadow) {
+        u32x4 so = {sh[0], sh[1], sh[2], sh[3]};
+        *reinterpret_cast<u32x4*>(shadow + off) = so;
+      }
+    }
+  }
+  if (!dx) return;
+  __syncthreads();   // every thread is done reading the last x block: its bytes now become part of wt
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    u32x4 piece;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = (wold[2 * q][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      const uint32_t hi = (wold[2 * q + 1][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      piece[q] = lo | (hi << 16);
+    }
+    *reinterpret_cast<u32x4*>(wt + (8 * kq + j) * FD_WLD + 8 * rg) = piece;
+  }
+  // ---- dx block by block, last block first (its g is still in LDS): A = g rows (hi + lo), B = wt rows k ----------------------------
+  const int col = lane & 31, half = lane >> 5;
+  for (int mb = nblk - 1; mb >= 0; --mb) {
+    if (mb != nblk - 1) load_g(mb);      // (every wave is past the previous block's products: the barrier below the dxs writes)
+    __syncthreads();                     // wt (first trip) / the g block complete; the previous block's dxs rows have left
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half + 4);
+      const float gx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      u32x4 hw, lw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint16_t h0 = f32_to_bf16_bits(gx[2 * q]), h1 = f32_to_bf16_bits(gx[2 * q + 1]);
+        const uint16_t l0 = f32_to_bf16_bits(gx[2 * q] - bf16_bits_to_f32(h0)), l1 = f32_to_bf16_bits(gx[2 * q + 1] - bf16_bits_to_f32(h1));
+        hw[q] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        lw[q] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      }
+      const bf16x8 bw = *reinterpret_cast<const bf16x8*>(wt + (32 * wave + col) * FD_WLD + 16 * st + 8 * half);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lw), bw, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hw), bw, o, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int b = (r & 3) + 8 * (r >> 2) + 4 * half;
+      dxs[b * FD_XLD + 32 * wave + col] = f32_to_bf16_bits(o[r]);
+    }
+    __syncthreads();                     // the dx block is assembled; every wave is through with this g block
+    for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks: 256 contiguous bytes per row of dx
+      const int bl = i / (FD_KT / 8), c = i - bl * (FD_KT / 8), b = 32 * mb + bl;
+      if (b < m && k0 + 8 * c < k) {
+        u32x4 ov = *reinterpret_cast<const u32x4*>(dxs + bl * FD_XLD + 8 * c);
+        if (gate_dx) {
+          const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            ov[q] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, relu_pair01(xv[q])) * (u16x2_t){0xffff, 0xffff});
+        }
+        *reinterpret_cast<u32x4*>(dx + (size_t)b * k + k0 + 8 * c) = ov;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void linear_bwd_db_bf16path(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                                float* __restrict__ db, int m, int n) {
   int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1180,6 +1364,26 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
                      (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, db, ad, gate_dx_by_x, (const float*)nullptr,
                      moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
+}
+
+int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
+                                      uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
+                                      double beta1, double beta2, double eps, int32_t step, float grad_scale,
+                                      int32_t gate_dx_by_x, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: null pointer");
+  PV_REQUIRE(m > 0 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
+             "pv_linear_wgrad_dx_adam_tall_bf16: n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
+  PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_tall_bf16: k must be a multiple of 8");
+  PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: step must be >= 1");
+  PV_REQUIRE((((uintptr_t)x | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)bf16_shadow | (uintptr_t)dx) & 15) == 0,
+             PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
+                 (float)(-(lr / bc1))};
+  const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
+  hipLaunchKernelGGL((linear_bwd_dw_dx_adam_tall_kernel<2>), dim3(grid), dim3(256), 0, as_stream(stream), x, dy, param, m, n,
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, ad, gate_dx_by_x, grad_scale);
+  return check_launch("pv_linear_wgrad_dx_adam_tall_bf16");
 }
 
 int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const float* y_relu_mask, float* param, float* exp_avg,

@@ -364,6 +364,14 @@ class LinearBF16KSharded(torch.autograd.Function):
         ks = weight._pv_kshard
         g = K.relu_gate_f32(dy.contiguous(), y) if y is not None else dy.contiguous()
         g_all = D.all_gather_sample_rows(g)
+        one_pass = getattr(weight, "_pv_kshard_backward", None)
+        dx_cols = one_pass(x_cols, g_all, ctx.needs_input_grad[0], x_is_relu_output) if one_pass is not None else None
+        if dx_cols is not None:
+            # dx of every sample for this rank's columns AND the Adam update of the shard came out of ONE pass over it
+            dx = D.all_to_all_rows_back(dx_cols)
+            if x_is_relu_output:
+                _mark_pregated(dx)
+            return dx, None, (K.colsum(g) if has_bias else None), None, None
         dx = None
         if ctx.needs_input_grad[0]:
             dx_cols, _, _ = K.linear_bwd_bf16(x_cols, ks["shadow"], g_all, None, need_dx=True, need_dw=False,

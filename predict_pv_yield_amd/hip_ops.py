@@ -769,6 +769,25 @@ def linear_wgrad_dx_adam_dev_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq
     return (dx, db) if need_db else dx
 
 
+def linear_wgrad_dx_adam_tall_bf16(x_cols, g_all, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4, betas=(0.9, 0.999),
+                                   eps=1e-8, grad_scale=1.0, need_dx=True, gate_dx_by_x=False):
+    """K-sharded fc1 (pv_linear_wgrad_dx_adam_tall_bf16): this rank's column shard updated by Adam from the gradient over ALL
+    rows of the global batch (x_cols [M, K/W] bf16, g_all [M, N] f32, already gated), and dx_cols = g_all . W_old in the same pass."""
+    require_cuda(x_cols, g_all, param, exp_avg, exp_avg_sq, bf16_shadow)
+    m, k = x_cols.shape
+    n = param.shape[0]
+    dx = torch.empty((m, k), dtype=torch.bfloat16, device=g_all.device) if need_dx else None
+    check(get_lib().pv_linear_wgrad_dx_adam_tall_bf16(ptr(x_cols), ptr(g_all), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
+                                                      ptr(bf16_shadow), ptr(dx), m, n, k, lr, betas[0], betas[1], eps, step,
+                                                      float(grad_scale), int(bool(gate_dx_by_x)), current_stream_ptr()),
+          "pv_linear_wgrad_dx_adam_tall_bf16")
+    return dx
+
+
+def kshard_one_pass_supported(n: int, k: int) -> bool:
+    return n <= 128 and n % 8 == 0 and k % 8 == 0
+
+
 MOMENT_TILE = 128      # FD_KT of linear_bf16.hip: k-columns per workgroup of the one-pass fc1 backward
 
 

@@ -128,6 +128,7 @@ class HipAdam(torch.optim.Optimizer):
                 self._make_column_shard(p)
             p._pv_grad_mode = mode
             p._pv_kshard_pending = None
+            p._pv_kshard_backward = self._make_kshard_backward(p) if mode == "ksharded" else None
             p._pv_pending = None
             p._pv_pending_f32 = None
             p._pv_takes_f32_pending = mode == "fused" and not self.capturable
@@ -405,6 +406,27 @@ class HipAdam(torch.optim.Optimizer):
             p._pv_applied = True
             return out if need_db else (out, None)
         return fused
+
+    def _make_kshard_backward(self, p):
+        def one_pass(x_cols, g_all, need_dx, gate_dx):
+            """K-sharded fc1: dx_cols, with the Adam update of this rank's column shard applied in the same pass
+            (pv_linear_wgrad_dx_adam_tall_bf16); None if the shape is not covered (the caller then parks the pair for step())."""
+            ks = p._pv_kshard
+            if not need_dx or not K.kshard_one_pass_supported(ks["w"].shape[0], ks["w"].shape[1]):
+                return None
+            if p._pv_applied:
+                raise RuntimeError("HipAdam: backward() ran twice without optimizer.step() in between; the K-sharded fc1 pass has "
+                                   "already applied the first update (gradient accumulation needs another large_grad_mode)")
+            group = self._group_of(p)
+            with torch.no_grad():
+                ks["step"] += 1
+                dx = K.linear_wgrad_dx_adam_tall_bf16(x_cols, g_all, ks["w"], ks["exp_avg"], ks["exp_avg_sq"], ks["shadow"], ks["step"],
+                                                      lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                                                      grad_scale=self.grad_scale, need_dx=True, gate_dx_by_x=gate_dx)
+            p._pv_applied = True
+            self._sharded_dirty = True
+            return dx
+        return one_pass
 
     def zero_grad(self, set_to_none: bool = True):
         """Also drops what a backward() parked on the large matrices for a step() that never came (a skipped step would otherwise

@@ -317,3 +317,34 @@ def test_bench_times_every_exchange_mode_in_one_invocation(device):
     k = 128 * 1003520
     assert modes["sharded"]["exchange_bytes_per_rank_and_step"]["reduce_scatter_gradient_bf16"] == k        # (W - 1) / W of 2 bytes each
     assert modes["ksharded"]["exchange_bytes_per_rank_and_step"]["all_to_all_activations_bf16"] == 4 * 1003520
+
+
+@pytest.mark.parametrize("m,n,k,gate", [(256, 128, 128 * 37, True), (72, 16, 128 * 5 + 64, False), (512, 128, 128 * 9, True), (32, 64, 256, False)])
+def test_kshard_one_pass_backward_kernel_against_the_separate_kernels(device, m, n, k, gate):
+    """pv_linear_wgrad_dx_adam_tall_bf16 (the K-sharded fc1's whole backward on this rank's column shard: gradient over all m rows
+    of the global batch + Adam + dx in one pass, row blocks of 32) against the kernels it replaces: pv_linear_bwd_bf16 (dx, gated
+    by x > 0) and pv_linear_wgrad_adam_bf16 on g scaled by 1 / world -- same sums in the same order (the scale is a power of
+    two), so parameters, moments and operand copy agree bit for bit; dx (another tiling of the same bf16 hi + lo products) within
+    one bf16 ulp, with identical zeros where x gates it; ragged m, a k that is no multiple of the 128-column tile, n below 128."""
+    from predict_pv_yield_amd import hip_ops as K
+    g = torch.Generator(device=device).manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g, device=device).relu().to(torch.bfloat16)           # a ReLU output: zeros gate dx
+    dy = torch.randn(m, n, generator=g, device=device) * 1e-2
+    w0 = torch.randn(n, k, generator=g, device=device) * 0.05
+    m0, v0 = torch.randn(n, k, generator=g, device=device) * 1e-3, torch.rand(n, k, generator=g, device=device) * 1e-6
+    scale, step = 0.125, 3
+    # reference: the separate kernels
+    wa, ma, va = w0.clone(), m0.clone(), v0.clone()
+    sha = K.cast_f32_to_bf16(wa)
+    dx_ref, _, _ = K.linear_bwd_bf16(x, sha, dy, None, need_dx=True, need_dw=False, gate_dx_by_x=gate, need_db=False)
+    K.linear_wgrad_adam_bf16(x, K.scale_f32(dy, scale), None, wa, ma, va, sha, step)
+    # one pass
+    wb, mb_, vb = w0.clone(), m0.clone(), v0.clone()
+    shb = K.cast_f32_to_bf16(wb)
+    dx = K.linear_wgrad_dx_adam_tall_bf16(x, dy, wb, mb_, vb, shb, step, grad_scale=scale, need_dx=True, gate_dx_by_x=gate)
+    torch.cuda.synchronize()
+    assert torch.equal(dx == 0, dx_ref == 0)
+    assert float((dx.float() - dx_ref.float()).abs().max()) <= 2.0 ** -7 * float(dx_ref.float().abs().max())
+    for a, b, what in ((wa, wb, "param"), (ma, mb_, "exp_avg"), (va, vb, "exp_avg_sq"), (sha, shb, "operand copy")):
+        assert torch.equal(a, b), (what, float((a.float() - b.float()).abs().max()))
+    assert not torch.equal(wb, w0)
