@@ -103,9 +103,15 @@ class LaunchTimer:
         torch.cuda.synchronize()
         acc = {}
         for key, e0, e1 in self.records:
-            tot, n = acc.get(key, (0.0, 0))
-            acc[key] = (tot + e0.elapsed_time(e1) * 1e-3, n + 1)
-        return {k: (tot / n, n) for k, (tot, n) in acc.items()}     # seconds per launch, launches
+            acc.setdefault(key, []).append(e0.elapsed_time(e1) * 1e-3)
+        if os.environ.get("PV_BENCH_DEBUG_BRACKETS"):
+            for k, v in acc.items():
+                print("[brackets]", k, [round(x * 1e6, 1) for x in v], file=sys.stderr)
+        # the MEDIAN over the instrumented steps: a bracket also holds whatever the host does between the first event and the
+        # launch (output allocations), which shows when the device has run dry -- the first launch after a synchronisation read
+        # 557 us once where its kernel takes 66 (round 6); the mean carried that into the roofline fractions
+        import statistics
+        return {k: (statistics.median(v), len(v)) for k, v in acc.items()}     # seconds per launch, launches
 
 
 TIMED_OPS = ("conv3d_fwd_bf16", "conv3d_fwd_bf16_f32in", "conv3d_bwd_weight_bf16", "linear_wgrad_adam_bf16",
@@ -147,6 +153,8 @@ def committed_flow_traffic(b):
 def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
     """Runs n instrumented steps (same tensors, same launch sequence as the timed region) and prices the kernels."""
     with LaunchTimer(TIMED_OPS) as lt:
+        step()                      # one step to get the host ahead of the device again (the timed region ended with a sync)
+        lt.records.clear()
         for _ in range(n_steps):
             step()
     per = lt.summary()
@@ -209,8 +217,8 @@ def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
     if fam_n:
         out["conv_fwd_dgrad_frac"] = out["mfma_conv3d"]["frac"]
     out["kernels"] = kernels
-    out["method"] = (f"{n_steps} extra train steps with a HIP event pair around every launch (torch's current stream = the "
-                     "launching stream); traffic = committed rocprofv3 --pmc passes (" + TRAFFIC_PROFILE + ")")
+    out["method"] = (f"{n_steps} extra train steps (after one discarded) with a HIP event pair around every launch (torch's current "
+                     "stream = the launching stream), median per launch; traffic = committed rocprofv3 --pmc passes (" + TRAFFIC_PROFILE + ")")
     return out
 
 

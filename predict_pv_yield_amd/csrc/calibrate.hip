@@ -9,6 +9,7 @@
 
 namespace pv {
 
+// (four loads in flight per thread before the stores read 4.7-4.8 TB/s where this plain form reads 5.1-5.4 on the same devices)
 __global__ __launch_bounds__(256) void calibrate_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];

@@ -64,6 +64,25 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
   host_window_taps(p->winsize, &win);
 
   const int levels = fb_num_levels(h, w, p->pyr_scale, p->levels);
+  // the window and PolyExp matrices of every tile level (<= 64 x 64), all in one launch; slot_of[k] = the level's slot or -1
+  int slot_of[64];
+  {
+    FbLevelTables lv;
+    lv.n = 0;
+    for (int k = levels; k >= 0; --k) {
+      double scale = 1;
+      for (int i = 0; i < k; ++i) scale *= p->pyr_scale;
+      const int lw = host_cv_round(w * scale), lh = host_cv_round(h * scale);
+      slot_of[k] = -1;
+      if (k < 64 && lw <= 64 && lh <= 64 && lw >= 2 && lh >= 2 && lv.n < FB_MAX_TABLE_LEVELS) {
+        slot_of[k] = lv.n;
+        lv.lh[lv.n] = lh, lv.lw[lv.n] = lw, lv.mosaic[lv.n] = (lh <= 32 && lw <= 32) ? 1 : 0;
+        ++lv.n;
+      }
+    }
+    if (lv.n > 0)
+      hipLaunchKernelGGL(fb_level_tables_kernel, dim3(128, (unsigned)lv.n), dim3(256), 0, st, (float*)(ws + L.off_G), lv, win, pk);
+  }
   float* prev_flow = nullptr;
   int prev_w = 0, prev_h = 0;
   int pingpong = 0;
@@ -115,7 +134,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     // the frame family's kernels below: UpdateMatrices writes M, the window passes + solve read it back.
     const bool small_level = lh <= 32 && lw <= 32;
     const bool polyexp_tile = h <= 64 && w <= 64 && smooth_sz <= 63;
-    const bool fused_iter = tile_path && fuse_init && polyexp_tile && (lw & 3) == 0 && ((uintptr_t)flow & 15) == 0 &&
+    const int slot = k < 64 ? slot_of[k] : -1;
+    float* level_tables = (float*)(ws + L.off_G) + (size_t)(slot < 0 ? 0 : slot) * 8 * 64 * 64;
+    const bool fused_iter = tile_path && slot >= 0 && fuse_init && polyexp_tile && (lw & 3) == 0 && ((uintptr_t)flow & 15) == 0 &&
                             !getenv("PV_FARNEBACK_TWO_LAUNCH_ITERATION") &&
                             (!small_level || ((long long)n_img * lpx * 20 < 0x7fffffffLL && n_pairs * lpx * 8 < 0x7fffffffLL &&
                                               (long long)prev_h * prev_w * n_pairs * 8 < 0x7fffffffLL &&
@@ -159,10 +180,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
     }
     if (polyexp_mfma) {
       // the two PolyExp passes as nine products on the f16 matrix cores (fb_prep_polyexp_mfma_kernel)
-      float* P6 = (float*)(ws + L.off_G) + 2 * 64 * 64;
+      float* P6 = level_tables + 2 * 64 * 64;
       FbPolyScales sc;
       host_polyexp_scales(pk, lh, lw, &sc);
-      hipLaunchKernelGGL(fb_polyexp_matrix_kernel, dim3(96), dim3(256), 0, st, P6, lh, lw, pk, small_level ? 1 : 0);
       const long long n_units = small_level ? (n_img + 3) / 4 : n_img;
       const unsigned grid = (unsigned)std::min<long long>(n_units, kNumCU);
       if (small_level)
@@ -208,11 +228,9 @@ int pv_farneback_batch_u8(const uint8_t* prev, const uint8_t* next, int64_t prev
                        (const float*)T, R, n_img, lh, lw, pk);
     }
     if (fused_iter) {
-      float* Gv = (float*)(ws + L.off_G);
-      float* Gh = lh == lw ? Gv : Gv + 64 * 64;
+      float* Gv = level_tables;
+      float* Gh = Gv + 64 * 64;
       stage_mark(coarse ? "farneback.coarse.iterations_fused" : "farneback.level0.iterations_fused", st);
-      hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gv, lh, win, small_level ? 1 : 0);
-      if (Gh != Gv) hipLaunchKernelGGL(fb_window_matrix_kernel, dim3(16), dim3(256), 0, st, Gh, lw, win, small_level ? 1 : 0);
       FbUpsample up = {prev_h, prev_w, prev_flow ? (double)prev_w / lw : 1.0, prev_flow ? (double)prev_h / lh : 1.0,
                        (float)(1. / p->pyr_scale)};
       const long long n_units = small_level ? (n_pairs + 3) / 4 : n_pairs;

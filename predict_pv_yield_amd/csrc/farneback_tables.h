@@ -169,7 +169,7 @@ static FbLayout fb_layout(long long n_pairs, int h, int w) {
   L.off_V = o; o = align(o + (size_t)n_pairs * (size_t)w * (size_t)((h + 31) / 32 * 32) * 20);   // frames: transposed, rows padded to a whole run
   L.off_flowA = o; o = align(o + (size_t)n_pairs * px * 8);
   L.off_flowB = o; o = align(o + (size_t)n_pairs * px * 8);
-  L.off_G = o; o = align(o + 8 * 64 * 64 * sizeof(float));   // window matrices (2) and PolyExp matrices (6) of the current pyramid level
+  L.off_G = o; o = align(o + (size_t)FB_MAX_TABLE_LEVELS * 8 * 64 * 64 * sizeof(float));   // per tile level: window matrices (2) and PolyExp matrices (6)
   L.total = o;
   return L;
 }

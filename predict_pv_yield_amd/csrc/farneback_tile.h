@@ -186,17 +186,17 @@ __global__ __launch_bounds__(FB_PP_NT) __attribute__((amdgpu_waves_per_eu(8, 8))
 // ---- window blur as matrix products (fb_level_u_kernel below) -------------------------------------------------------------------
 // For images up to 64 x 64 the separable, border-replicated window blur is two small matrix products per channel,
 //   U = X Gh^T (along x),  Out = Gv U (along y),   G[y][y'] = sum of the taps k with clamp(y + k) == y'
-// (a banded 64 x 64 matrix that already contains the border replication, built per level by fb_window_matrix_kernel).
+// (a banded 64 x 64 matrix that already contains the border replication, built for every tile level of a call by fb_level_tables_kernel).
 // (Rounds 2-5 also kept a two-launch iteration for the same levels -- UpdateMatrices writing M, fb_tile_mfma_kernel /
 // fb_tile_mfma_q_kernel blurring it on the bf16 matrix cores with three-term operands -- for widths that are no multiple of
 // four and as a cross-check; removed in round 6: those levels take the frame family's kernels (farneback_frame.h), which are
 // also the level kernel's cross-check now.)
 typedef float fb_v16f __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void fb_window_matrix_kernel(float* __restrict__ G, int n, FbTaps kt, int mosaic) {
+__device__ __forceinline__ void fb_window_matrix_fill(float* __restrict__ G, int n, const FbTaps& kt, int mosaic, int first, int stride) {
   // G[64][64]; rows / columns >= n stay zero.  mosaic (n <= 32): the n x n matrix twice on the diagonal, at 0 and at 32 --
   // the blur of a 64 x 64 image made of 2 x 2 independent tiles (fb_level_u_kernel<.., MOSAIC = true>)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * 64; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < 64 * 64; i += stride) {
     int y = i >> 6, yp = i & 63;
     const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
     if (mosaic) y &= 31, yp &= 31;
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
 // ---- prep + PolyExp with the two PolyExp passes on the F16 matrix cores (round 4) -------------------------------------------
 // fb_prep_polyexp_tile_kernel spends 23 000 cycles per 64 x 64 image on the two separable 2n+1-tap passes (index arithmetic
 // and LDS reads of a per-pixel tap loop).  Both passes are products with banded 64 x 64 matrices that already contain the
-// border replication (fb_polyexp_matrix_kernel): vertically t_j = V_j I for V_g, V_xg, V_xxg, horizontally
+// border replication (fb_polyexp_matrix_fill): vertically t_j = V_j I for V_g, V_xg, V_xxg, horizontally
 //   b1 = t0 H_g^T  b2 = t0 H_xg^T  b4 = t0 H_xxg^T  b3 = t1 H_g^T  b6 = t1 H_xg^T  b5 = t2 H_g^T,
 // nine products per image, evaluated exactly like the window blur of fb_level_u_kernel: the image handed over transposed as two
 // half-float planes (x s = h + l, 22 bits), first product U_j = X^T V_j^T, its accumulators re-split as the B operand of the
@@ -929,10 +929,10 @@ struct FbPolyScales {
   float c11_b3, c11_b2, c03_b1, c33_b5, c33_b4, c55_b6;      // ig.. with the products' scales divided out
 };
 
-__global__ __launch_bounds__(256) void fb_polyexp_matrix_kernel(float* __restrict__ P6, int lh, int lw, FbPoly pk, int mosaic) {
+__device__ __forceinline__ void fb_polyexp_matrix_fill(float* __restrict__ P6, int lh, int lw, const FbPoly& pk, int mosaic, int first, int stride) {
   // P6[3 v + j][64][64]: v = 0 vertical (size lh), 1 horizontal (size lw); j = 0: g, 1: x g (odd), 2: x^2 g.  Row y, column y':
   // the weight of input y' in output y, border replicated.  mosaic (sizes <= 32): the matrix twice on the diagonal (0 and 32)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 6 * 64 * 64; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < 6 * 64 * 64; i += stride) {
     const int which = i >> 12, j = which % 3, n = which < 3 ? lh : lw;
     int y = (i >> 6) & 63, yp = i & 63;
     const bool same_block = !mosaic || (y >> 5) == (yp >> 5);
@@ -948,6 +948,23 @@ __global__ __launch_bounds__(256) void fb_polyexp_matrix_kernel(float* __restric
     }
     P6[i] = s;
   }
+}
+
+// Every matrix of every tile level of a call in ONE launch (round 6: two launches of ~5 us per level -- the window matrices and the
+// PolyExp matrices -- were 26 us of the 0.94 ms pipeline with their kernel boundaries).  blockIdx.y = level slot; per slot 8
+// matrices of 64 x 64 floats: Gv, Gh (window), P6 (PolyExp: vertical g / xg / xxg, horizontal g / xg / xxg).  blockIdx.x 0..15: Gv,
+// 16..31: Gh, 32..127: P6.
+constexpr int FB_MAX_TABLE_LEVELS = 8;
+struct FbLevelTables { int n; int lh[FB_MAX_TABLE_LEVELS], lw[FB_MAX_TABLE_LEVELS], mosaic[FB_MAX_TABLE_LEVELS]; };
+__global__ __launch_bounds__(256) void fb_level_tables_kernel(float* __restrict__ G, FbLevelTables lv, FbTaps win, FbPoly pk) {
+  const int slot = blockIdx.y;
+  if (slot >= lv.n) return;
+  float* base = G + (size_t)slot * 8 * 64 * 64;
+  const int lh = lv.lh[slot], lw = lv.lw[slot], mosaic = lv.mosaic[slot];
+  const int bx = blockIdx.x;
+  if (bx < 16) fb_window_matrix_fill(base, lh, win, mosaic, bx * 256 + threadIdx.x, 16 * 256);
+  else if (bx < 32) fb_window_matrix_fill(base + 64 * 64, lw, win, mosaic, (bx - 16) * 256 + threadIdx.x, 16 * 256);
+  else fb_polyexp_matrix_fill(base + 2 * 64 * 64, lh, lw, pk, mosaic, (bx - 32) * 256 + threadIdx.x, 96 * 256);
 }
 
 template <bool MOSAIC>

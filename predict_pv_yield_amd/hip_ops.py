@@ -459,6 +459,11 @@ def device_calibration(copy_floats: int = 128 * 1003520, mfma_iters: int = 20000
     t_copy = timed(lambda: check(lib.pv_calibrate_copy_f32(ptr(a), ptr(b), copy_floats, current_stream_ptr()), "pv_calibrate_copy_f32"), reps * 2)
     t_mfma = timed(lambda: check(lib.pv_calibrate_mfma_bf16(ptr(sink), wgs, mfma_iters, current_stream_ptr()), "pv_calibrate_mfma_bf16"), reps)
     flops = wgs * 4 * mfma_iters * 8 * 16384.0
+    # hand the gigabyte back to the driver: left in torch's cache it changed where the NEXT allocations of the caller land, and a
+    # bench leg that times individual launches read its first (HBM-bound) kernel at 160-200 us instead of 75 (round 6)
+    del a, b, sink
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     return {"copy_TBps": round(8.0 * copy_floats / t_copy / 1e12, 3), "copy_bytes": 8 * copy_floats,
             "mfma_bf16_TFLOPs": round(flops / t_mfma / 1e12, 1), "mfma_ms": round(t_mfma * 1e3, 3),
             "what": "pv_calibrate_copy_f32 (16 B per lane, read + write bytes) and pv_calibrate_mfma_bf16 (v_mfma_f32_16x16x32_bf16 "
