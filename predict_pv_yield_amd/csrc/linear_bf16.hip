@@ -101,12 +101,19 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const uint16_t* __
 }
 
 // y = relu?(bias + sum of split-K slabs), fixed order.  block = 64 outputs x 4 slab groups (one wave each)
+// (blockIdx.y: row block of 32 rows whose slabs start blk_stride floats further on -- the LDS-staged forward takes 32 rows per
+// launch, a call with more rows launches it per block and reduces ALL blocks here, once)
 __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __restrict__ partial,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int m, int n, int k_splits, int relu) {
+                                                               int m, int n, int k_splits, int relu, size_t blk_stride = 0) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
+  if (gridDim.y > 1) {
+    partial += (size_t)blockIdx.y * blk_stride;
+    y += (size_t)blockIdx.y * 32 * n;
+    m = m - 32 * (int)blockIdx.y < 32 ? m - 32 * (int)blockIdx.y : 32;
+  }
   const size_t mn = (size_t)m * n;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < m * n) {
@@ -1194,8 +1201,9 @@ extern "C" {
 int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes) {
   PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bf16_workspace_bytes: bad arguments");
   int per;
-  int nwg = bf16_fwd_split(k, &per);   // >= the v2 split (<= 512 workgroups)
-  *bytes = (size_t)nwg * m * n * sizeof(float);
+  int nwg = bf16_fwd_split(k, &per);   // >= the v2 / v3 splits (<= 512 workgroups)
+  const size_t rows = (size_t)((m + 31) / 32) * 32;      // (the LDS-staged forward keeps 32 rows of slabs per row block)
+  *bytes = (size_t)nwg * rows * n * sizeof(float);
   return PV_OK;
 }
 
@@ -1216,19 +1224,23 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
     int tiles, n_tiles;
     const bool fits32 = (size_t)n * k * 2 < 0xfffffff0ull;  // the v3 kernel's raw-buffer offsets are 32-bit
     const int nwg2 = !fits32 ? v2_split(k, &tiles, &n_tiles) : v3_split(k, &tiles, &n_tiles);
-    PV_REQUIRE(workspace_bytes >= (size_t)nwg2 * (m < 32 ? m : 32) * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
+    const int nblk = (m + 31) / 32;
+    const size_t blk_stride = (size_t)nwg2 * 32 * n;      // floats between two row blocks' slabs
+    PV_REQUIRE(workspace_bytes >= (size_t)nblk * blk_stride * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
     for (int m0 = 0; m0 < m; m0 += 32) {
       const int mb = m - m0 < 32 ? m - m0 : 32;
       const uint16_t* xb = x + (size_t)m0 * k;
+      float* pb = part + (size_t)(m0 / 32) * blk_stride;
       if (!fits32)
-        hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, part, mb, n, (long long)k,
+        hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
                            n_tiles, tiles);
       else
-        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, part, mb, n, (long long)k,
+        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
                            n_tiles, tiles);
-      hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((mb * n + 63) / 64)), dim3(256), 0, st, (const float*)part,
-                         bias, y + (size_t)m0 * n, mb, n, nwg2, relu ? 1 : 0);
     }
+    // one reduce for all row blocks (eight launches of ~5 us for the K-sharded fc1's 256 rows before)
+    hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((32 * n + 63) / 64), (unsigned)nblk), dim3(256), 0, st,
+                       (const float*)part, bias, y, m, n, nwg2, relu ? 1 : 0, blk_stride);
     return check_launch("pv_linear_fwd_bf16");
   }
   PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
