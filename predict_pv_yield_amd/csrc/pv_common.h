@@ -8,6 +8,12 @@
 #include <algorithm>
 #include "../../include/pv_yield_hip.h"
 
+// gfx950 only: the kernels size their LDS images for 160 KB per CU (linear_f32_skinny.hip alone declares 84 KB static), use
+// gfx950's matrix and transposed-read instructions and 64-wide waves; another --offload-arch must fail here, not at a launch
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "predict_pv_yield_amd/csrc is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace pv {
 
 // thread-local description of the last failure (pv_last_error()).

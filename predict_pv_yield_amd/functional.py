@@ -130,6 +130,21 @@ def packed_conv_weight(weight: torch.Tensor, transpose_flip: bool) -> torch.Tens
     return wp
 
 
+def split2_conv_weight(weight: torch.Tensor):
+    """(fragments, scale state) of a conv weight's two-term half-float split (pv_conv3d_pack_weight_split2_f16), cached on the
+    parameter: valid while neither torch (`_version`) nor HipAdam (`_pv_opt_gen`, bumped by every step that touches the
+    parameter -- its kernels write through raw pointers) has changed the weight.  A train step re-packs once, as before; a
+    no-grad scoring loop (validation: 16 forwards per 1 024 samples) no longer repeats the pack, its maximum and row-sum passes
+    and their allocations on every call."""
+    key = (weight._version, getattr(weight, "_pv_opt_gen", 0), weight.device)
+    cache = getattr(weight, "_pv_split2", None)
+    # (while a HIP graph is being captured the pack must be part of it: a replay updates the weights without passing here)
+    if cache is None or cache[0] != key or (weight.is_cuda and torch.cuda.is_current_stream_capturing()):
+        cache = (key, K.conv3d_pack_weight_split2_f16(weight.detach().contiguous()))
+        weight._pv_split2 = cache
+    return cache[1]
+
+
 def refresh_packed_conv_weights(params) -> None:
     """Re-pack, in one launch, every cached fragment image of the given (just updated) conv weights."""
     jobs = []
@@ -468,13 +483,17 @@ def _register_gated(t: torch.Tensor, registry: dict, value) -> None:
         _GATED_MAX.clear()
         _GATED_PLANES.clear()
         _GATED_MAX_TASK[0] = task
-    registry[(t.data_ptr(), t.numel())] = value
+    # the entry HOLDS the tensor: while it is registered its storage cannot be handed to another gradient of the same backward
+    # pass by the caching allocator, so a later tensor can never find a stale entry at "its" address; an entry
+    # nobody consumes lives until the next backward pass starts (one gradient tensor kept alive, at most)
+    registry[(t.data_ptr(), t.numel())] = (value, t)
 
 
 def _gated_planes_of(t: torch.Tensor):
     if _GATED_MAX_TASK[0] != torch._C._current_graph_task_id():
         return None
-    return _GATED_PLANES.pop((t.data_ptr(), t.numel()), None)
+    hit = _GATED_PLANES.pop((t.data_ptr(), t.numel()), None)
+    return hit[0] if hit is not None else None
 
 
 class Conv3dF32OnF16x2(torch.autograd.Function):
@@ -499,7 +518,7 @@ class Conv3dF32OnF16x2(torch.autograd.Function):
             if planes is None or planes[3] != x._version or planes[0].shape[:4] != (x.shape[0],) + tuple(x.shape[2:]):
                 planes = K.pack_split2_ncdhw_f32_to_ndhwc_f16(x, cpad32=True)      # (none, or x was changed in place since)
             xh, xl, xs = planes[:3]
-        wp, ws = K.conv3d_pack_weight_split2_f16(weight.contiguous())
+        wp, ws = split2_conv_weight(weight)
         y, ys, yp = K.conv3d_f32_on_f16x2(xh, xl, xs, wp[0], wp[1], ws, 32, 32, p, bias=bias.contiguous() if bias is not None else None,
                                           relu=relu, want_f32=not chain_out)
         ctx.save_for_backward(y if (relu and not dy_pregated) else None, xh, xl, xs, wp, ws)
@@ -589,7 +608,8 @@ _GATED_MAX_TASK = [-1]
 def _gated_max_of(t: torch.Tensor):
     if _GATED_MAX_TASK[0] != torch._C._current_graph_task_id():
         return None
-    return _GATED_MAX.pop((t.data_ptr(), t.numel()), None)   # consumed once: a later tensor at the same address must not find it
+    hit = _GATED_MAX.pop((t.data_ptr(), t.numel()), None)   # consumed once
+    return hit[0] if hit is not None else None
 
 
 class ReluGateF32(torch.autograd.Function):

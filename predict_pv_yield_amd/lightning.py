@@ -243,12 +243,19 @@ class Trainer:
                  resume_from_checkpoint=None, precision=32, weights_summary=None, progress_bar_refresh_rate=None,
                  profiler=None, limit_train_batches=1.0, limit_val_batches=1.0, limit_test_batches=1.0,
                  num_sanity_val_steps=0, terminate_on_nan=False, accelerator=None, max_steps=None,
-                 default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, hip_graph=False, **unused):
+                 default_root_dir=None, log_every_n_steps=50, advect_on_side_stream=False, hip_graph=False,
+                 large_grad_mode=None, **unused):
         self.gpus, self.min_epochs, self.max_epochs = gpus, min_epochs, max_epochs
         # hip_graph (new, opt-in; also PV_TRAINER_HIP_GRAPH=1): single-process fits with ONE HipAdam optimiser replay the train
         # step as a HIP graph (graphs.GraphedTrainStep) after three eager steps -- same losses, parameters and logged values
         # as the eager loop, without the Python / autograd / launch work of the hundreds of launches of a Perceiver step
         self.hip_graph = bool(hip_graph) or bool(os.environ.get("PV_TRAINER_HIP_GRAPH"))
+        # large_grad_mode (new, world_size > 1; also PV_GRAD_SYNC): how fc1's gradient is exchanged -- "sharded" (default:
+        # reduce-scatter over rows + all-gather of the operand copy), "ksharded" (fc1's columns dealt over the ranks, activations
+        # exchanged instead of gradients: distributed.py), "bf16" / "autograd" (bf16 / f32 all-reduce, what Lightning DDP does)
+        self.large_grad_mode = large_grad_mode or os.environ.get("PV_GRAD_SYNC") or "sharded"
+        if self.large_grad_mode not in ("sharded", "ksharded", "bf16", "autograd"):
+            raise ValueError("Trainer(large_grad_mode=...) must be 'sharded', 'ksharded', 'bf16' or 'autograd'")
         self._graph_step = None
         # config 3 only (Model(future_frames="optical_flow") fed raw int16 counts): advect in the loader wrapper
         # (optical_flow.AdvectingLoader) instead of inside the model's forward; same batches, bit for bit.  The name is
@@ -570,7 +577,7 @@ class Trainer:
                     # fc1's gradient travels in bf16 and is reduce-scattered: each rank steps its own rows of the
                     # matrix and the bf16 operand copy is all-gathered (falls back to a bf16 all-reduce when the rows
                     # do not divide over the ranks)
-                    o.set_large_grad_mode("sharded")
+                    o.set_large_grad_mode(self.large_grad_mode)
             # the in-backward exchange leaves SUMS; only optimisers that fold 1/world into their update (HipAdam) can
             # consume them.  Any other optimiser gets the plain averaged all-reduce after backward (no hooks: a hook
             # would have summed the large gradients already and they would be reduced twice)

@@ -536,6 +536,7 @@ class HipAdam(torch.optim.Optimizer):
                     continue
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 stepped.append(p)
+                p._pv_opt_gen = getattr(p, "_pv_opt_gen", 0) + 1      # (caches keyed on the weight's value: functional.split2_conv_weight)
                 plain.setdefault(int(st["step"].item()), []).append(
                     (p, g.float(), st["exp_avg"], st["exp_avg_sq"], getattr(p, "_pv_bf16_shadow", None)))
             if self.capturable and plain:
