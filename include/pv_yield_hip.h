@@ -621,6 +621,17 @@ int pv_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
                      uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2,
                      double eps, int32_t step, float grad_scale, void* stream);
 
+/* replaces: skimage.metrics.structural_similarity(ground_truth_image, remapped_image) with every option at its default
+ * (notebooks/optical_flow_1.ipynb:10235-10243 [cell 35], the `update` of cell 31 and compute_opt_flow_and_score of cell 38:
+ * the reference's only quality score for its optical-flow forecasts, and the objective of its Farneback parameter search).
+ * n_pairs image pairs [h][w], pair i at im1 + i * stride1 / im2 + i * stride2 (elements); out: device f64[n_pairs] = the mean of
+ * the SSIM map (7 x 7 uniform window, float64, sample covariance, K1 = 0.01, K2 = 0.03, a border of 3 cropped).
+ * data_range: 255 for uint8 images; scikit-image's default for float images is 2 (the dtype's range [-1, 1]). */
+int pv_ssim_mean_u8(const uint8_t* im1, int64_t stride1, const uint8_t* im2, int64_t stride2, int64_t n_pairs, int32_t h,
+                    int32_t w, double data_range, double* out, void* stream);
+int pv_ssim_mean_f32(const float* im1, int64_t stride1, const float* im2, int64_t stride2, int64_t n_pairs, int32_t h,
+                     int32_t w, double data_range, double* out, void* stream);
+
 /* ---- tracing: opt-in per-stage device timing ---------------------------------------------------------------------
  * The reference times its pipeline stages with wall-clock `%%time` cells (notebooks/optical_flow_1.ipynb:269,
  * 13_...ipynb:1161); here the multi-kernel entry points (pv_farneback_batch_u8, pv_prepare_stacks_*,

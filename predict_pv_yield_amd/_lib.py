@@ -107,6 +107,8 @@ SIGNATURES = {
     "pv_conv3d_packed_weight_elems": [c_i32],
     "pv_conv3d_pack_weight_bf16": [c_vp, c_vp, c_i32, c_i32, c_int, c_vp],
     "pv_relu_mask_dims": [c_i32, c_i32, c_vp, c_vp],
+    "pv_ssim_mean_u8": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_f64, c_vp, c_vp],
+    "pv_ssim_mean_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_f64, c_vp, c_vp],
     "pv_stage_timing_begin": [],
     "pv_stage_timing_end": [c_vp, c_vp, c_vp, c_i32, c_vp],
     "pv_calibrate_copy_f32": [c_vp, c_vp, c_sz, c_vp],

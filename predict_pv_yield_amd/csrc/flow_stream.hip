@@ -395,6 +395,51 @@ static int remap_launch(const T* src, int64_t src_stride, const float* flow, int
   return check_launch("pv_remap_bilinear");
 }
 
+// ---------------------------------------------------------------------------------------------
+// skimage.metrics.structural_similarity(im1, im2) with every option at its default -- the reference's only quality score
+// for its optical-flow forecasts (notebooks/optical_flow_1.ipynb cells 31, 35, 38: `metrics.structural_similarity(
+// ground_truth_image, remapped_image)`) and the objective of its parameter search (cells 38-42).  Definition (Wang et al.,
+// IEEE TIP 2004, as scikit-image 0.18 evaluates it): images as float64, 7 x 7 uniform window, sample covariance
+// (N / (N - 1), N = 49), C1 = (0.01 L)^2, C2 = (0.03 L)^2, the mean of the SSIM map over the pixels whose window lies inside
+// the image (a border of 3 cropped).  One workgroup per image pair; a thread sums the 49 taps of its pixels in double and
+// the map is reduced in a fixed order (lane order, wave order): the score does not depend on the launch.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ssim_mean_kernel(const T* __restrict__ a, const T* __restrict__ b, long long stride_a,
+                                                        long long stride_b, int h, int w, double c1, double c2,
+                                                        double* __restrict__ out) {
+  constexpr int WIN = 7, PAD = 3;
+  const T* ia = a + (long long)blockIdx.x * stride_a;
+  const T* ib = b + (long long)blockIdx.x * stride_b;
+  const int oh = h - 2 * PAD, ow = w - 2 * PAD;
+  const double inv_n = 1.0 / (WIN * WIN), cov_norm = (double)(WIN * WIN) / (WIN * WIN - 1);
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < oh * ow; i += 256) {
+    const int y = i / ow, x = i - y * ow;
+    double sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+    for (int dy = 0; dy < WIN; ++dy) {
+      const T* ra = ia + (long long)(y + dy) * w + x;
+      const T* rb = ib + (long long)(y + dy) * w + x;
+#pragma unroll
+      for (int dx = 0; dx < WIN; ++dx) {
+        const double va = (double)ra[dx], vb = (double)rb[dx];
+        sa += va, sb += vb, saa += va * va, sbb += vb * vb, sab += va * vb;
+      }
+    }
+    const double ux = sa * inv_n, uy = sb * inv_n;
+    const double vx = cov_norm * (saa * inv_n - ux * ux), vy = cov_norm * (sbb * inv_n - uy * uy), vxy = cov_norm * (sab * inv_n - ux * uy);
+    acc += ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+  }
+  __shared__ double part[256];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < 256; ++i) s += part[i];
+    out[blockIdx.x] = s / ((double)oh * ow);
+  }
+}
+
 template <typename T>
 static int u8_launch(const T* src, uint8_t* dst, size_t n, int mode, int32_t* range_flag, void* stream) {
   if (n == 0) return PV_OK;  // empty input: nothing to do (an empty tensor has no address)
@@ -535,6 +580,20 @@ static int normalise_launch(const T* src, float* dst, size_t n, int64_t inner, i
 
 using namespace pv;
 
+template <typename T>
+static int ssim_launch(const T* a, int64_t stride_a, const T* b, int64_t stride_b, int64_t n_pairs, int32_t h, int32_t w,
+                       double data_range, double* out, void* stream) {
+  PV_REQUIRE(a && b && out, PV_EINVAL, "pv_ssim_mean: null pointer");
+  PV_REQUIRE(n_pairs >= 0 && n_pairs <= 0x7fffffffLL, PV_EINVAL, "pv_ssim_mean: bad number of image pairs");
+  PV_REQUIRE(h >= 7 && w >= 7, PV_ESIZE, "pv_ssim_mean: images must be at least 7 x 7 (the window), got %d x %d", h, w);
+  PV_REQUIRE(data_range > 0, PV_EINVAL, "pv_ssim_mean: data_range must be positive");
+  if (n_pairs == 0) return PV_OK;
+  const double c1 = (0.01 * data_range) * (0.01 * data_range), c2 = (0.03 * data_range) * (0.03 * data_range);
+  hipLaunchKernelGGL((ssim_mean_kernel<T>), dim3((unsigned)n_pairs), dim3(256), 0, as_stream(stream), a, b, (long long)stride_a,
+                     (long long)stride_b, h, w, c1, c2, out);
+  return check_launch("pv_ssim_mean");
+}
+
 extern "C" {
 
 int pv_abi_version(void) { return PV_ABI_VERSION; }
@@ -621,6 +680,16 @@ int pv_normalise_i16(const int16_t* src, float* dst, size_t n, int64_t inner, in
 int pv_normalise_f32(const float* src, float* dst, size_t n, int64_t inner, int32_t n_channels,
                      const float* mean, const float* std_, void* stream) {
   return normalise_launch<float>(src, dst, n, inner, n_channels, mean, std_, stream);
+}
+
+int pv_ssim_mean_u8(const uint8_t* im1, int64_t stride1, const uint8_t* im2, int64_t stride2, int64_t n_pairs, int32_t h,
+                    int32_t w, double data_range, double* out, void* stream) {
+  return ssim_launch<uint8_t>(im1, stride1, im2, stride2, n_pairs, h, w, data_range, out, stream);
+}
+
+int pv_ssim_mean_f32(const float* im1, int64_t stride1, const float* im2, int64_t stride2, int64_t n_pairs, int32_t h,
+                     int32_t w, double data_range, double* out, void* stream) {
+  return ssim_launch<float>(im1, stride1, im2, stride2, n_pairs, h, w, data_range, out, stream);
 }
 
 }  // extern "C"

@@ -186,6 +186,21 @@ def remap_bilinear_strided(src_ptr: int, src_stride: int, flow: torch.Tensor, ou
           "pv_remap_bilinear_f32")
 
 
+def ssim_mean(im1: torch.Tensor, im2: torch.Tensor, data_range: Optional[float] = None) -> torch.Tensor:
+    """Mean structural similarity of image pairs [N, H, W] (uint8 or float32), skimage's defaults (pv_ssim_mean_*): f64 [N]."""
+    require_cuda(im1, im2)
+    if im1.shape != im2.shape or im1.dim() != 3 or im1.dtype != im2.dtype or im1.dtype not in (torch.uint8, torch.float32):
+        raise TypeError("ssim_mean: two uint8 or two float32 tensors [N, H, W] of one shape")
+    im1, im2 = im1.contiguous(), im2.contiguous()
+    n, h, w = im1.shape
+    if data_range is None:
+        data_range = 255.0 if im1.dtype == torch.uint8 else 2.0      # scikit-image: the dtype's range
+    out = torch.empty(n, dtype=torch.float64, device=im1.device)
+    fn = get_lib().pv_ssim_mean_u8 if im1.dtype == torch.uint8 else get_lib().pv_ssim_mean_f32
+    check(fn(ptr(im1), h * w, ptr(im2), h * w, n, h, w, float(data_range), ptr(out), current_stream_ptr()), "pv_ssim_mean")
+    return out
+
+
 def prepare_stacks(raw: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, t_out: int, mode: int = 0):
     """raw [B,T,C,H,W] int16/f32 counts -> (u8 [B,C,T,H,W], out f32 [B,C,t_out,H,W] with slices 0..T-1 normalised).
     One pass over raw (pv_prepare_stacks_*); H*W must be a multiple of 8."""

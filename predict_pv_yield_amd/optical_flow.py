@@ -8,6 +8,8 @@ Mirrors (same names, argument meaning and error behaviour):
   weighted_average                  notebooks/optical_flow_1.ipynb:293-294
   remap_image                       13_...ipynb:259-281 (BORDER_CONSTANT, NaN) / optical_flow_1.ipynb:415-430
   compute_optical_flow_predictions  13_...ipynb:284-333   ((n-1)n/2 predictions from n frames)
+  structural_similarity             skimage.metrics.structural_similarity as called at optical_flow_1.ipynb cells 31, 35, 38
+  compute_opt_flow_and_score, search_farneback_params   optical_flow_1.ipynb cells 38-42 (the one-at-a-time parameter search)
 and the join the reference leaves as a TODO (`# TODO: Use optical flow, not actual sat images of the
 future!`, predict_pv_yield/models/perceiver/perceiver.py:118):
   advect_future_frames / replace_future_frames_with_flow   
@@ -128,6 +130,73 @@ def compute_optical_flow_predictions(sat_data, flows, border_mode: int = BORDER_
         off += steps
     idx = torch.tensor(index, dtype=torch.int64)
     return _like_input(preds, sat_data), idx
+
+
+# ------------------------------------------------------------------------------------------------
+# scoring and the parameter search of notebooks/optical_flow_1.ipynb (cells 31, 35, 38-42)
+# ------------------------------------------------------------------------------------------------
+def structural_similarity(im1, im2, data_range: Optional[float] = None):
+    """skimage.metrics.structural_similarity(im1, im2) with its defaults (the reference's call: optical_flow_1.ipynb cells 31,
+    35, 38), on the device: two uint8 or two float32 images [H, W] -> float; stacks [N, H, W] -> float64 tensor [N]."""
+    a, b = _as_cuda(im1), _as_cuda(im2)
+    if a.dtype != b.dtype or a.dtype not in (torch.uint8, torch.float32):
+        a, b = a.float(), b.float()
+    if a.dim() == 2:
+        return float(K.ssim_mean(a[None], b[None], data_range)[0])
+    return K.ssim_mean(a, b, data_range)
+
+
+def compute_opt_flow_and_score(images, num_timesteps: int = 23, **farneback_kwargs):
+    """optical_flow_1.ipynb cell 38: the flow between images[0] and images[1] with the given Farneback arguments, then for
+    i = 1 .. num_timesteps - 1 the prediction remap_image(images[1], flow * i) (BORDER_REPLICATE) scored against images[i + 1]
+    by structural similarity.  images: uint8 [T >= num_timesteps + 1, H, W].  -> list of num_timesteps - 1 scores."""
+    img = _as_cuda(images)
+    if img.dtype != torch.uint8 or img.dim() != 3:
+        raise TypeError("compute_opt_flow_and_score: a uint8 stack [T, H, W] is expected (convert_10bpp_to_uint8 first)")
+    n = num_timesteps - 1
+    if img.shape[0] < n + 2:
+        raise ValueError(f"compute_opt_flow_and_score: {num_timesteps} time steps need {n + 2} images, got {img.shape[0]}")
+    kw = dict(REFERENCE_FARNEBACK_KWARGS)
+    kw.update(farneback_kwargs)
+    flow = K.farneback_pairs(img[0:1], img[1:2], **kw)                                             # [1, H, W, 2]
+    pred = K.remap_bilinear(img[1:2], flow, n_steps=n, step0=1.0, border_mode=BORDER_REPLICATE)     # [1, n, H, W]: flow * 1 .. n
+    return [float(v) for v in K.ssim_mean(img[2:2 + n], pred[0]).tolist()]
+
+
+# the grid of cell 40 (`flags` has one value there and is left out)
+REFERENCE_PARAM_RANGES = dict(pyr_scale=[round(0.1 * i, 1) for i in range(1, 10)], levels=list(range(1, 10)),
+                              winsize=[5, 35, 37, 40, 42, 45, 50, 60], iterations=[1, 3, 5, 10, 20, 50], poly_n=[1, 2, 3, 5, 9],
+                              poly_sigma=[0.1, 0.5, 0.6, 0.7, 1, 1.1, 1.2, 1.9])
+
+
+def search_farneback_params(images, param_defaults: Optional[dict] = None, param_ranges: Optional[dict] = None,
+                            num_timesteps: int = 23):
+    """optical_flow_1.ipynb cells 40-42: one parameter at a time is varied around `param_defaults` (default: the arguments the
+    search arrived at, REFERENCE_FARNEBACK_KWARGS); the score of a setting is the mean structural similarity of its
+    num_timesteps - 1 forecasts.  -> (all_scores {(name, value): mean score}, durations {(name, value): seconds},
+    best {name: the value with the highest score}).  A value this implementation does not take (poly_n other than 5 or 7, a
+    pyramid deeper than the smoothing kernel allows: the library says so) scores NaN and never wins."""
+    import time
+    defaults = dict(REFERENCE_FARNEBACK_KWARGS if param_defaults is None else param_defaults)
+    ranges = REFERENCE_PARAM_RANGES if param_ranges is None else param_ranges
+    all_scores, durations = {}, {}
+    for name, values in ranges.items():
+        for val in values:
+            params = dict(defaults)
+            params[name] = val
+            t0 = time.time()
+            try:
+                scores = compute_opt_flow_and_score(images, num_timesteps, **params)
+                score = float(np.mean(scores))
+            except (RuntimeError, ValueError):      # the library refused the setting (check() raises with its message)
+                score = float("nan")
+            durations[(name, val)] = time.time() - t0
+            all_scores[(name, val)] = score
+    best = {}
+    for name, values in ranges.items():
+        scored = [(all_scores[(name, v)], v) for v in values if all_scores[(name, v)] == all_scores[(name, v)]]
+        best[name] = max(scored, key=lambda sv: sv[0])[1] if scored else None
+    return all_scores, durations, best
 
 
 # ------------------------------------------------------------------------------------------------
