@@ -367,15 +367,20 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   // window operands, both in registers: Gv^T as the B operand of the first product (n = y, this lane's row of the strip; k =
   // y' in natural order); Gh as the A operand of the second (k-slot i of lane half h in step ks = accumulator row
   // fb_acc_row(8 (ks & 1) + i, h) of row block ks >> 1 of the first product)
-  FbSplit2 gv[KS], gh[KS];
+  // MOSAIC (round 6): the window matrices are block-diagonal (two 32 x 32 blocks), so of the four 16-wide contraction steps of a
+  // product only the two inside this wave's own block multiply anything but zeros, and the second product needs the first one's
+  // block mbo alone: 12 matrix-instruction triples per channel instead of 36 -- the same sums, the zero terms left out.
+  constexpr int KSE = MOSAIC ? 2 : KS;
+  FbSplit2 gv[KSE], gh[KSE];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+  for (int ks = 0; ks < KSE; ++ks) {
+    const int ksv = MOSAIC ? 2 * strip + ks : ks, ksh = MOSAIC ? 2 * mbo + ks : ks;      // the steps' numbers in the full matrices
     float t[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+    for (int i = 0; i < 8; ++i) t[i] = Gv[(32 * strip + col) * 64 + 16 * ksv + 8 * half + i];
     gv[ks] = fb_split2(t, FB_G_SCALE);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+    for (int i = 0; i < 8; ++i) t[i] = Gh[(32 * mbo + col) * 64 + 32 * (ksh >> 1) + fb_acc_row(8 * (ksh & 1) + i, half)];
     gh[ks] = fb_split2(t, FB_G_SCALE);
   }
   // exponent e of a unit's (MOSAIC: of tile (ty, tx)'s) largest |M| = f 2^e, 0.5 <= f < 1, clamped so that every power of
@@ -673,28 +678,30 @@ __global__ __launch_bounds__(512) void fb_level_u_kernel(const float* __restrict
   };
   // ---- multiplying role: Out^T block (mbo, strip) of one channel = Gh (X^T Gv^T) --------------------------------------------
   auto product = [&](const uint16_t* Xc) __attribute__((always_inline)) -> fb_v16f {
-    fb_v16f u[2];
+    constexpr int NMB = MOSAIC ? 1 : 2;      // row blocks of the first product this wave needs (MOSAIC: its own tile's)
+    fb_v16f u[NMB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mbi = 0; mbi < NMB; ++mbi) {
+      const int mb = MOSAIC ? mbo : mbi;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) u[mb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) u[mbi][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KSE; ++ks) {
         FbSplit2 a;
-        const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * ks + 8 * half;
+        const uint16_t* xa = Xc + (32 * mb + col) * XS + 16 * (MOSAIC ? 2 * strip + ks : ks) + 8 * half;
         a.h = *reinterpret_cast<const fb_f16x8*>(xa);
         a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
-        u[mb] = fb_mfma2(a, gv[ks], u[mb]);
+        u[mbi] = fb_mfma2(a, gv[ks], u[mbi]);
       }
     }
     fb_v16f res;
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSE; ++ks) {
       float t[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = u[ks >> 1][8 * (ks & 1) + i];
+      for (int i = 0; i < 8; ++i) t[i] = u[MOSAIC ? 0 : ks >> 1][8 * (ks & 1) + i];
       const FbSplit2 b = fb_split2(t, FB_G_UNSCALE);
       res = fb_mfma2(gh[ks], b, res);
     }
