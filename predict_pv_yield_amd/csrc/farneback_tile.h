@@ -995,42 +995,51 @@ __global__ __launch_bounds__(512) void fb_prep_polyexp_mfma_kernel(const uint8_t
 
   // operands (128 registers): group 0: V_g | H_g, H_xg, H_xxg; group 1: V_xg, V_xxg | H_g, H_xg.  opX is the group's fourth
   // matrix: H_xxg (an A operand) for group 0, V_xxg (a B operand) for group 1
-  FbSplit2 gvA[KS], opX[KS], ghA[KS], ghB[KS];
+  // MOSAIC (round 6): the matrices are block-diagonal (two 32 x 32 blocks): of a product's four 16-wide contraction steps only
+  // the two inside the wave's own block multiply anything but zeros, and a second product needs the first one's block mbo alone
+  // (as in fb_level_u_kernel): KSE steps per operand, numbered ksv / ksh in the full matrices.  One image per tile: the
+  // matrices are banded, poly_n <= 7 on either side, so the 32 output rows of block s reach inputs 32 s - 7 .. 32 s + 38: three
+  // of the four steps, numbers s .. s + 2 (round 5 skipped the fourth by a run-time vote on the operand registers and gained
+  // nothing; here the loops are simply shorter)
+  constexpr int KSE = MOSAIC ? 2 : 3, KSB = MOSAIC ? 2 : KS;
+  FbSplit2 gvA[KSE], opX[KSE], ghA[KSE], ghB[KSE];
   {
     const float* va = P6 + (grp ? 1 : 0) * 4096;
     const float sva = grp ? sc.sV[1] : sc.sV[0];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KSE; ++ks) {
+      const int ksv = MOSAIC ? 2 * strip + ks : strip + ks, ksh = MOSAIC ? 2 * mbo + ks : mbo + ks;
       float t[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = va[(32 * strip + col) * 64 + 16 * ks + 8 * half + i];
+      for (int i = 0; i < 8; ++i) t[i] = va[(32 * strip + col) * 64 + 16 * ksv + 8 * half + i];
       gvA[ks] = fb_split2(t, sva);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = P6[3 * 4096 + (32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+      for (int i = 0; i < 8; ++i) t[i] = P6[3 * 4096 + (32 * mbo + col) * 64 + 32 * (ksh >> 1) + fb_acc_row(8 * (ksh & 1) + i, half)];
       ghA[ks] = fb_split2(t, sc.sH[0]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = P6[4 * 4096 + (32 * mbo + col) * 64 + 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half)];
+      for (int i = 0; i < 8; ++i) t[i] = P6[4 * 4096 + (32 * mbo + col) * 64 + 32 * (ksh >> 1) + fb_acc_row(8 * (ksh & 1) + i, half)];
       ghB[ks] = fb_split2(t, sc.sH[1]);
       // (one address expression for both groups: the group picks the matrix, the row and the column order by arithmetic)
       const int xrow = grp ? 32 * strip + col : 32 * mbo + col;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int xcol = grp ? 16 * ks + 8 * half + i : 32 * (ks >> 1) + fb_acc_row(8 * (ks & 1) + i, half);
+        const int xcol = grp ? 16 * ksv + 8 * half + i : 32 * (ksh >> 1) + fb_acc_row(8 * (ksh & 1) + i, half);
         t[i] = P6[(grp ? 2 : 5) * 4096 + xrow * 64 + xcol];
       }
       opX[ks] = fb_split2(t, grp ? sc.sV[2] : sc.sH[2]);
     }
   }
-  auto first = [&](const FbSplit2 (&gv)[KS], float f, FbSplit2 (&b)[KS]) __attribute__((always_inline)) {
+  auto first = [&](const FbSplit2 (&gv)[KSE], float f, FbSplit2 (&b)[KSB]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {      // row block mb of U becomes k-steps 2 mb, 2 mb + 1 of the second product: one block alive
+    for (int mbi = 0; mbi < (MOSAIC ? 1 : 2); ++mbi) {      // row block mb of U becomes k-steps 2 mb, 2 mb + 1 of the second product: one block alive
+      const int mb = MOSAIC ? mbo : mbi;
       fb_v16f u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KSE; ++ks) {
         FbSplit2 a;
-        const uint16_t* xa = &Xs[0][0] + (32 * mb + col) * XS + 16 * ks + 8 * half;
+        const uint16_t* xa = &Xs[0][0] + (32 * mb + col) * XS + 16 * (MOSAIC ? 2 * strip + ks : strip + ks) + 8 * half;
         a.h = *reinterpret_cast<const fb_f16x8*>(xa);
         a.l = *reinterpret_cast<const fb_f16x8*>(xa + PLANE);
         u = fb_mfma2(a, gv[ks], u);
@@ -1040,12 +1049,12 @@ __global__ __launch_bounds__(512) void fb_prep_polyexp_mfma_kernel(const uint8_t
         float t[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) t[i] = u[8 * k2 + i];
-        b[2 * mb + k2] = fb_split2(t, f);
+        b[(MOSAIC ? 0 : 2 * mbi) + k2] = fb_split2(t, f);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto second = [&](const FbSplit2 (&gh)[KS], const FbSplit2 (&b)[KS]) __attribute__((always_inline)) -> fb_v16f {
+  auto second = [&](const FbSplit2 (&gh)[KSE], const FbSplit2 (&b)[KSB]) __attribute__((always_inline)) -> fb_v16f {
     fb_v16f res;
 #pragma unroll
     for (int r = 0; r < 16; ++r) res[r] = 0.f;
@@ -1053,7 +1062,16 @@ __global__ __launch_bounds__(512) void fb_prep_polyexp_mfma_kernel(const uint8_t
     // U as the A operand, the window matrix as B (the same register contents: the two operand layouts mirror each other): the
     // result is the block itself rather than its transpose -- lane = COLUMN x, registers = rows -- so that the 32 lanes of a
     // half wave store 256 contiguous bytes of a row
-    for (int ks = 0; ks < KS; ++ks) res = fb_mfma2(b[ks], gh[ks], res);
+    for (int ks = 0; ks < KSE; ++ks) {
+      if constexpr (MOSAIC) {
+        res = fb_mfma2(b[ks], gh[ks], res);
+      } else {      // steps mbo .. mbo + 2 of the first product's four (a wave-uniform choice between two registers' worth)
+        FbSplit2 bs;
+        bs.h = mbo ? b[ks + 1].h : b[ks].h;
+        bs.l = mbo ? b[ks + 1].l : b[ks].l;
+        res = fb_mfma2(bs, gh[ks], res);
+      }
+    }
     return res;
   };
 
@@ -1160,7 +1178,7 @@ __global__ __launch_bounds__(512) void fb_prep_polyexp_mfma_kernel(const uint8_t
     }
     // ---- the nine products ---------------------------------------------------------------------------------------------------
     rederive();
-    FbSplit2 b[KS];
+    FbSplit2 b[KSB];
     fb_v16f r0, r1, r2;      // group 0: b1, b2, b4; group 1: b3, b6, b5
     if (grp == 0) {
       first(gvA, sc.fU[0], b);
