@@ -214,6 +214,17 @@ def measure_step_rooflines(step, model, b, t_frames, n_steps=5):
     out["all_conv_kernels"] = {"gflop_per_step": round(tot_fl, 1), "us_per_step": round(tot_s, 1),
                                "frac_of_bf16_mfma_peak": round(tot_fl * 1e9 / (tot_s * 1e-6) / MFMA_BF16_PEAK, 4)}
     out["all_conv_frac"] = out["all_conv_kernels"]["frac_of_bf16_mfma_peak"]
+    # the same launches against the OTHER roof: at 32 channels a conv layer moves 128-192 bytes per 55 kflop, i.e. 290-430 flop / B
+    # where the device's ridge is 2.5 PF / 8 TB/s = 312 (470 against the copy rate it reaches): the family draws most of the
+    # memory system while it multiplies (PMC bytes of the committed counter passes, per step)
+    conv_tr = {k: v for k, v in traffic.items() if k.startswith("pv::conv3d_")}
+    n_tr_steps = next((v["launches"] for k, v in conv_tr.items() if k.startswith("pv::conv3d_first_f32in_kernel")), 0)
+    if n_tr_steps and tot_s > 0:
+        conv_bytes = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in conv_tr.values()) / n_tr_steps
+        out["all_conv_kernels"].update({"hbm_GB_per_step": round(conv_bytes / 1e9, 4),
+                                        "hbm_TBps": round(conv_bytes / (tot_s * 1e-6) / 1e12, 3),
+                                        "frac_of_hbm_peak": round(conv_bytes / (tot_s * 1e-6) / HBM_PEAK, 4)})
+        out["all_conv_hbm_frac"] = out["all_conv_kernels"]["frac_of_hbm_peak"]
     if fam_n:
         out["conv_fwd_dgrad_frac"] = out["mfma_conv3d"]["frac"]
     out["kernels"] = kernels
@@ -1113,6 +1124,9 @@ def main():
     ap.add_argument("--only-requested-mode", action="store_true",
                     help="N > 1: time the requested exchange only (default: the other modes are timed afterwards in the same "
                          "invocation and reported under grad_sync_modes; `value` is always the requested mode's)")
+    ap.add_argument("--other-modes-budget", type=float, default=float(os.environ.get("PV_BENCH_OTHER_MODES_BUDGET_S", "120")),
+                    help="N > 1: seconds the leg that times the OTHER fc1 exchanges may take; past it the requested mode's line is "
+                         "printed with what the leg has recorded and the process ends (a collective one rank never enters cannot be interrupted)")
     ap.add_argument("--allow-demotion", action="store_true",
                     help="N > 1: accept a simpler gradient-exchange mode than the requested one when its trial step fails "
                          "(default: exit non-zero -- a scaling number on another exchange is not the number asked for)")
@@ -1211,7 +1225,52 @@ def main():
     # decides between exchanges instead of testing one).  Every rank walks the same list; a mode whose trial step fails, or that
     # the optimiser replaces by a simpler one, is recorded as such and skipped -- `value` above stays the requested mode's.
     other_modes = {}
+    headline = None
+    if rank == 0:      # the requested mode's own result: everything below adds to it, nothing below may lose it
+        value = world * b * args.steps / elapsed
+        ms_step = elapsed / args.steps * 1e3
+        headline = {
+            "metric": "PV-site samples/sec (train step), conv3d 12->6 frames",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"conv3d train step (fwd + NMAE + bwd + Adam): sat [B,11,{t_frames},64,64] N(0,1), "
+                                   f"4x Conv3d(3x3x3, 32ch) + fc 128/128/64, {sum(p.numel() for p in model.parameters())/1e6:.1f} M params",
+                       "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
+                       "parallelism": f"dp{world} ({grad_sync_mode})" if world > 1 else "single",
+                       "collectives": collectives_info(world, requested_mode if distributed else None, grad_sync_mode)},
+            "device_calibration": calibration,
+            "device_clocks_during_timed_steps": clocks.summary(),
+        }
+
+    def modes_record():
+        if not distributed:
+            return None
+        return dict({grad_sync_mode: {"status": "ok (the requested mode: `value`)", "ms_per_step": headline["ms_per_step"],
+                                      "value": headline["value"], "unit": "samples/s",
+                                      "collectives": collectives_info(world, requested_mode, grad_sync_mode),
+                                      "exchange_bytes_per_rank_and_step": exchange_bytes(grad_sync_mode, world, b, model)}},
+                    **other_modes)
+
     if distributed and not args.only_requested_mode:
+        # A collective that one rank never enters cannot be interrupted from inside: a timer thread prints the requested mode's
+        # line with what the leg has recorded so far and ends the process (exit code 0 -- `value` was measured; never an exec).
+        import threading
+        current = {"mode": None}
+
+        def leg_expired():
+            if rank == 0:
+                other_modes.setdefault(current["mode"] or "?", {"status": f"no answer within {args.other_modes_budget:.0f} s: leg abandoned"})
+                line = dict(headline, grad_sync_modes=modes_record(), train_nmae_first_step=first, train_nmae_last_step=last,
+                            roofline=None, cpu_baseline=None)
+                print(json.dumps(line), flush=True)
+            else:
+                time.sleep(2.0)      # (rank 0 prints first)
+            os._exit(0)
+        watchdog = threading.Timer(args.other_modes_budget, leg_expired)
+        watchdog.daemon = True
+        watchdog.start()
+
         def timed_steps(n):
             torch.distributed.barrier()
             torch.cuda.synchronize()
@@ -1226,6 +1285,9 @@ def main():
         for cand in ("ksharded", "sharded", "bf16", "autograd"):
             if cand == grad_sync_mode:
                 continue
+            current["mode"] = cand
+            if os.environ.get("PV_BENCH_HANG_IN_MODE") == cand and rank == world - 1:      # (test hook: a rank that never arrives)
+                time.sleep(1e6)
             try:
                 opt.consolidate_sharded()                     # (collective) full tensors current before the layout changes
                 sync.remove()                                 # (the trial step installs and removes hooks of its own)
@@ -1237,39 +1299,30 @@ def main():
             if in_force != cand:
                 other_modes[cand] = {"status": f"not available here: the trial step or the optimiser fell back to '{in_force}'"}
                 continue
-            for _ in range(min(5, max(2, args.warmup))):
-                step()
-            sec = timed_steps(args.steps)
+            try:
+                for _ in range(min(5, max(2, args.warmup))):
+                    step()
+                sec = timed_steps(args.steps)
+            except Exception as e:      # this rank alone may have failed: the others wait in a collective until the timer ends the leg
+                other_modes[cand] = {"status": f"failed while stepping: {type(e).__name__}: {str(e)[:200]}"}
+                watchdog.join()
+                raise
             other_modes[cand] = {"status": "ok", "ms_per_step": round(sec / args.steps * 1e3, 3),
                                  "value": round(world * b * args.steps / sec, 2), "unit": "samples/s",
                                  "collectives": collectives_info(world, cand, in_force),
                                  "exchange_bytes_per_rank_and_step": exchange_bytes(cand, world, b, model)}
+        current["mode"] = "consolidation after the last mode"
         opt.consolidate_sharded()
+        watchdog.cancel()
 
     if rank == 0:
-        value = world * b * args.steps / elapsed
-        ms_step = elapsed / args.steps * 1e3
-        out = {
-            "metric": "PV-site samples/sec (train step), conv3d 12->6 frames",
-            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
-            "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"conv3d train step (fwd + NMAE + bwd + Adam): sat [B,11,{t_frames},64,64] N(0,1), "
-                                   f"4x Conv3d(3x3x3, 32ch) + fc 128/128/64, {sum(p.numel() for p in model.parameters())/1e6:.1f} M params",
-                       "per_gpu_batch": b, "global_batch": b * world, "t_frames": t_frames,
-                       "parallelism": f"dp{world} ({grad_sync_mode})" if world > 1 else "single",
-                       "collectives": collectives_info(world, requested_mode if distributed else None, grad_sync_mode)},
-            "device_calibration": calibration,
-            "device_clocks_during_timed_steps": clocks.summary(),
-            "grad_sync_modes": (dict({grad_sync_mode: {"status": "ok (the requested mode: `value`)", "ms_per_step": round(ms_step, 3),
-                                                        "value": round(value, 2), "unit": "samples/s",
-                                                        "collectives": collectives_info(world, requested_mode, grad_sync_mode),
-                                                        "exchange_bytes_per_rank_and_step": exchange_bytes(grad_sync_mode, world, b, model)}},
-                                     **other_modes) if distributed else None),
+        out = dict(headline)
+        out.update({
+            "grad_sync_modes": modes_record(),
             "train_nmae_first_step": round(first, 6) if first is not None else None,
             "train_nmae_last_step": round(last, 6),
             "whole_step_frac_of_bf16_mfma_peak": round(value / world * (23.37e9 if t_frames == 18 else 25.27e9) / MFMA_BF16_PEAK, 4),
-        }
+        })
         if not args.no_roofline and world == 1:
             if args.precision == "bf16":
                 out["roofline"] = measure_step_rooflines(step, model, b, t_frames)
@@ -1281,6 +1334,8 @@ def main():
                     if "achieved" in r:
                         r["frac_of_calibrated_copy"] = round(r["achieved"] / 1e3 / calibration["copy_TBps"], 4)
                     r["all_conv_frac_calibrated"] = round(r["all_conv_frac"] * MFMA_BF16_PEAK / 1e12 / calibration["mfma_bf16_TFLOPs"], 4)
+                    if "all_conv_hbm_frac" in r:
+                        r["all_conv_hbm_frac_calibrated"] = round(r["all_conv_hbm_frac"] * HBM_PEAK / 1e12 / calibration["copy_TBps"], 4)
                     if "conv_fwd_dgrad_frac" in r:
                         r["conv_fwd_dgrad_frac_calibrated"] = round(r["conv_fwd_dgrad_frac"] * MFMA_BF16_PEAK / 1e12 / calibration["mfma_bf16_TFLOPs"], 4)
             else:

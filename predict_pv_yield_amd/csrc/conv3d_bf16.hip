@@ -814,7 +814,7 @@ int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const floa
 bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void* out_gate_mask);
 // loader-wave first layer (conv3d_bf16_first.hip); 1 = request not covered
 int launch_conv3d_first_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
-                              const pv_conv3d_dims* d, int to, int ho, int wo, int relu, hipStream_t st);
+                              const pv_conv3d_dims* d, int to, int ho, int wo, int relu, hipStream_t st, uint32_t* mask_out);
 void launch_pack_weight_v3(const float* w, uint16_t* wp2, int c_out, int c_in, int transpose_flip, hipStream_t st);
 constexpr size_t V3_WEIGHT_ELEMS = (size_t)27 * 2 * 64 * 8;   // the 16x16x32 fragments of conv3d_bf16_v3.hip
 
@@ -1036,7 +1036,7 @@ int pv_conv3d_fwd_bf16_f32in(const float* x, uint16_t* xp_out, const uint16_t* w
   PV_REQUIRE(((uintptr_t)x % 4 == 0) && (!xp_out || (uintptr_t)xp_out % 16 == 0), PV_EINVAL,
              "pv_conv3d_fwd_bf16_f32in: unaligned operand");
   PV_REQUIRE(d->pad_w == 0, PV_EINVAL, "pv_conv3d_fwd_bf16_f32in: built for pad_w == 0 (quads of voxels start inside the image)");
-  if (!relu_mask_out && launch_conv3d_first_f32in(x, xp_out, wp, bias, y, d, to, ho, wo, relu, as_stream(stream)) == 0)
+  if (launch_conv3d_first_f32in(x, xp_out, wp, bias, y, d, to, ho, wo, relu, as_stream(stream), relu_mask_out) == 0)
     return check_launch("pv_conv3d_fwd_bf16_f32in(loader waves)");
   const int n_rowblk = (ho + TR - 1) / TR;
   const int n_colblk = (wo + TW_VALID - 1) / TW_VALID;

@@ -15,7 +15,7 @@
 //     holds 8 consecutive output channels = 16 bytes of a voxel;
 //   * one barrier per output slice.
 // Bit-identical to pv_pack_ncdhw_f32_to_ndhwc_bf16 + pv_conv3d_fwd_bf16 (same rounding points, same order of the 27 x 16
-// products per output).  pad_w == 0, no relu-mask output: other requests keep the one-role kernel.
+// products per output).  pad_w == 0: other requests keep the one-role kernel.  A requested relu mask (round 6) leaves with the tile.
 #include "pv_common.h"
 
 namespace pv {
@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t f_pk_max(uint32_t x, uint32_t floor2) {   //
 __global__ __launch_bounds__(512, 2) void conv3d_first_f32in_kernel(
     const float* __restrict__ x, const uint16_t* __restrict__ wp, const float* __restrict__ bias, uint16_t* __restrict__ y,
     uint16_t* __restrict__ xp_out, int c_in, int t_in, int h_in, int w_in, int t_out, int h_out, int w_out, int pad_t,
-    int pad_h, int relu, int n_colblk, int t_chunk, int c_out) {
+    int pad_h, int relu, int n_colblk, int t_chunk, int c_out, uint32_t* __restrict__ mask_out, int mask_hp, int mask_wp) {
   // ring of 4 slices | 256 B of zeros (tap reads of the last columns run 2 voxels past a slot) | 32 bias floats
   __shared__ __attribute__((aligned(256))) unsigned char lds[4 * F_SLOTB + 256 + 128];
   float* lds_bias = reinterpret_cast<float*>(lds + 4 * F_SLOTB + 256);
@@ -180,6 +180,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_first_f32in_kernel(
   const int rows_left = h_out - (h0 + 4 * wr);
   const uint32_t out_plane_b = (uint32_t)plane_out * 64u, out_row_b = (uint32_t)w_out * 64u;
   const uint32_t relu_floor = relu ? 0u : 0x80008000u;
+  // relu mask of the output (u32 per voxel, bit c = channel c > 0; pv_relu_mask_dims): after the half swap lane (r, hh) holds
+  // bytes hh and 2 + hh of its voxel's word; the hh = 1 lanes hand theirs over and the hh = 0 lanes store the word
+  const bool mk_ok = mask_out && hh == 0 && col_t < F_TW_VALID && (w0 + col_t) < mask_wp;
+  const uint32_t mk_off = mk_ok ? (uint32_t)((h0 + 4 * wr) * mask_wp + w0 + col_t) * 4u : F_INVALID;
+  const uint32_t mk_plane_b = (uint32_t)mask_hp * mask_wp * 4u;
+  void* const mk_sample = reinterpret_cast<unsigned char*>(mask_out) + (size_t)b * t_out * mk_plane_b;
 
 #ifdef PV_DIAG_STAMPS
   unsigned long long dg[PV_DIAG_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0}, q0, q1, q2, q3;
@@ -241,12 +247,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_first_f32in_kernel(
       const bool ok = orow < rows_left;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(y_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
       const uint32_t so = ok ? (uint32_t)t * out_plane_b + (uint32_t)orow * out_row_b : 0u;
+      uint32_t mword = 0;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {   // cout quads (0, 1) and (2, 3): upper half of the first <-> lower half of the second
         const auto a = __builtin_amdgcn_permlane32_swap(P[2 * pr][0], P[2 * pr + 1][0], false, false);
         const auto c = __builtin_amdgcn_permlane32_swap(P[2 * pr][1], P[2 * pr + 1][1], false, false);
         const u32x4 v = {a[0], c[0], a[1], c[1]};
         __builtin_amdgcn_raw_buffer_store_b128(v, rs, st_off + 32u * pr, so, 0);
+        if (mask_out) mword |= (relu_byte_of_pairs(v) & 0xffu) << (16 * pr);
+      }
+      if (mask_out) {      // (wave-uniform)
+        mword |= (uint32_t)__shfl_xor((int)mword, 32, 64) << 8;
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(mk_sample, 0, (int)((size_t)t_out * mk_plane_b), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(mword, mrs, mk_off, (uint32_t)t * mk_plane_b + (uint32_t)orow * mask_wp * 4u, 0);
       }
     }
 #ifdef PV_DIAG_STAMPS
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_first_f32in_kernel(
 
 // 0 = launched, 1 = not covered (the caller uses conv3d_bf16.hip's one-role kernel)
 int launch_conv3d_first_f32in(const float* x, uint16_t* xp_out, const uint16_t* wp, const float* bias, uint16_t* y,
-                              const pv_conv3d_dims* d, int to, int ho, int wo, int relu, hipStream_t st) {
+                              const pv_conv3d_dims* d, int to, int ho, int wo, int relu, hipStream_t st, uint32_t* mask_out) {
   if (d->pad_w != 0 || d->w_in % 4 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)xp_out % 16) != 0)
     return 1;
   if (to < 1) return 1;
@@ -286,7 +299,8 @@ int launch_conv3d_first_f32in(const float* x, uint16_t* xp_out, const uint16_t* 
   n_tchunk = (to + t_chunk - 1) / t_chunk;
   dim3 grid((unsigned)(n_rowblk * n_colblk), (unsigned)n_tchunk, (unsigned)d->batch);
   hipLaunchKernelGGL(conv3d_first_f32in_kernel, grid, dim3(512), 0, st, x, wp, bias, y, xp_out, d->c_in, d->t_in, d->h_in,
-                     d->w_in, to, ho, wo, d->pad_t, d->pad_h, relu ? 1 : 0, n_colblk, t_chunk, d->c_out);
+                     d->w_in, to, ho, wo, d->pad_t, d->pad_h, relu ? 1 : 0, n_colblk, t_chunk, d->c_out, mask_out, (ho + 7) & ~7,
+                     (wo + 31) & ~31);
   return 0;
 }
 

@@ -55,6 +55,14 @@ __device__ __forceinline__ uint32_t v3_pk_gate(uint32_t x, uint32_t g) {   // ke
   return r;
 }
 
+// the same from two bits of a mask byte: halves of x stay where bits `lo`, `lo + 1` of b are set
+__device__ __forceinline__ uint32_t v3_pk_gate_bits(uint32_t x, uint32_t b, int lo) {
+  uint32_t m = __builtin_amdgcn_ubfe(b, lo, 2);      // (b1 b0)
+  m = (m * 0x8001u) & 0x00010001u;                    // b0 -> bit 0, b1 -> bit 16 (a 24-bit multiply)
+  uint32_t r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+  return r;
+}
 // One input slice's contribution to output slices s - kt, kt in [KT_LO, KT_HI] (compile-time: head and tail steps of
 // the march feed fewer slices).  P = (s - tc0) % 3 names the accumulator slot of output slice s.
 // FIRST (KW == 0 call of a step with KT_LO == 0): the tap (kt 0, kh 0, kw 0) is the first contribution output slice s ever
@@ -148,11 +156,17 @@ __device__ __forceinline__ uint32_t v3_pack_f16_pair(float a, float b) {      //
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v3_f16x2));
 }
 
-template <bool OUT_GATE, bool Y_NCDHW, int OUTM = 0>
+// MASKM (round 6): the 1-bit ReLU masks of the C ABI (u32 per voxel, bit c = channel c > 0, planes padded to whole 8 x 32 tiles:
+// pv_relu_mask_dims).  1: the forward also WRITES the mask of its output -- a lane holds 8 consecutive couts of a voxel after the
+// row swap, i.e. one byte of the voxel's word, stored in the side slots the gated form uses for its gate loads.  2: the gated
+// dgrad reads that byte INSTEAD of the 16 bytes of the bf16 activation (out_gate is not touched): the conv family draws 0.5 of
+// the HBM peak while it multiplies (bench.py roofline.all_conv_hbm_frac), and a gate read is a third of a dgrad launch's bytes.
+template <bool OUT_GATE, bool Y_NCDHW, int OUTM = 0, int MASKM = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ wp2, const float* __restrict__ bias,
     uint16_t* __restrict__ y, const uint16_t* __restrict__ out_gate, int t_in, int h_in, int w_in, int t_out,
-    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out) {
+    int h_out, int w_out, int pad_t, int pad_h, int pad_w, int relu, int n_colblk, int t_chunk, int c_out,
+    uint32_t* __restrict__ mask = nullptr, int mask_hp = 0, int mask_wp = 0) {
   // ring of 2 slices | [kt = 1 weight plane] | kt = 2 weight plane | 32 bias floats | [NCDHW patches]
   // NDHWC variants: 80 512 B, two workgroups per CU use 161 024 of the 163 840 B; the NCDHW variant keeps the kt = 1 plane
   // in registers (its patches take the room) and issues its memory work in bursts
@@ -165,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   float* lds_bias = reinterpret_cast<float*>(lds_w2 + V3_W2B);
   static_assert(!(OUT_GATE && Y_NCDHW), "the gated epilogue writes NDHWC");
   static_assert(!(F16 && (OUT_GATE || Y_NCDHW)), "the partial-product forms write plain NDHWC");
+  static_assert(MASKM == 0 || (OUTM == 0 && !Y_NCDHW && (MASKM == 1) == !OUT_GATE), "mask forms: plain forward writes, gated dgrad reads");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -294,7 +309,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   const bool n_ok = (h0 + 4 * wr + n_orow) < h_out && (w0 + n_piece * 8) < w_out;
   const size_t n_base = ((size_t)b * c_out + 16 * ch + n_co) * cstride + (size_t)(h0 + 4 * wr + n_orow) * w_out + w0 + n_piece * 8;
   u32x4 pend[4];
-  u32x4 og[OUT_GATE ? 4 : 1];
+  u32x4 og[(OUT_GATE && MASKM != 2) ? 4 : 1];
+  uint32_t mbyte[MASKM != 0 ? 4 : 1];      // MASKM 1: the finished tile's mask bytes (stored with the tile); 2: the gate's
+  // a lane's byte of the mask: voxel (row h0 + 4 wr + orow, column w0 + 16 (kg & 1) + vox), byte 2 ch + (kg >> 1) of its word
+  const uint32_t mk_off = (uint32_t)(((h0 + 4 * wr) * mask_wp + w0 + 16 * (kg & 1) + vox) * 4 + 2 * ch + (kg >> 1));
+  const uint32_t mk_plane_b = (uint32_t)mask_hp * mask_wp * 4u, mk_row_b = (uint32_t)mask_wp * 4u;
+  unsigned char* const mk_sample = reinterpret_cast<unsigned char*>(mask) + (size_t)b * t_out * mk_plane_b;
+  const int mk_sample_b = (int)((size_t)t_out * mk_plane_b);
   // F32OUT: a finished tile leaves straight from its accumulators at the end of the step that finishes it (8 stores; held for the
   // next step's side slots like the bf16 tile, its 32 registers + the new slice's accumulators do not fit: 181 spills).  The
   // wait at the top of the next step then lets exactly these 8 newest operations stay in flight (vmcnt counts in issue order)
@@ -309,8 +330,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(y_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(pend[orow], rs, st_off, ok ? (uint32_t)o * out_plane_b + (uint32_t)orow * out_row_b : 0u, 0);
   };
+  auto store_mask_row = [&](int o, int orow, bool live) {      // MASKM 1 (the padded plane holds every tile row)
+    if constexpr (MASKM == 1) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mk_sample, 0, live ? mk_sample_b : 0, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)mbyte[orow], rs, mk_off,
+                                           live ? (uint32_t)o * mk_plane_b + (uint32_t)orow * mk_row_b : 0u, 0);
+    }
+  };
   auto load_gate_row = [&](int o, int orow) {
-    if constexpr (OUT_GATE) {
+    if constexpr (MASKM == 2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mk_sample, 0, mk_sample_b, 0x00020000);
+      mbyte[orow] = __builtin_amdgcn_raw_buffer_load_b8(rs, mk_off, (uint32_t)o * mk_plane_b + (uint32_t)orow * mk_row_b, 0);
+    } else if constexpr (OUT_GATE) {
       const bool ok = orow < rows_left;
       const __amdgpu_buffer_rsrc_t rs =
           __builtin_amdgcn_make_buffer_rsrc((void*)og_sample, 0, ok ? (int)out_sample_b : 0, 0x00020000);
@@ -330,6 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
     } else {
 #pragma unroll
       for (int orow = 0; orow < 4; ++orow) store_row(o, orow, true);
+#pragma unroll
+      for (int orow = 0; orow < 4; ++orow) store_mask_row(o, orow, true);
     }
   };
   // accumulators of the three output slices in flight: acc[(o - tc0) % 3][row][half], 16 couts x 16 voxels each; the first
@@ -369,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
         if (!Y_NCDHW) store_row(s - 3, j, do_store);                                                              \
       } else if (j < 8) {                                                                                         \
         if (OUT_GATE && KT_HI == 2) load_gate_row(s - 2, j - 4);                                                  \
+        if (MASKM == 1) store_mask_row(s - 3, j - 4, do_store);                                                   \
       } else if (j < 17) {                                                                                        \
         load_piece(s + 1, j - 8, do_load);                                                                        \
       }                                                                                                           \
@@ -437,9 +471,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
           const auto r0 = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);                       \
           const auto r1 = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);                       \
           u32x4 v = {r0[0], r1[0], r0[1], r1[1]};                                                                 \
-          if constexpr (OUT_GATE) {                                                                               \
+          if constexpr (MASKM == 2) {                                                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = v3_pk_gate_bits(v[j], mbyte[orow], 2 * j);       \
+          } else if constexpr (OUT_GATE) {                                                                        \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] = v3_pk_gate(v[j], og[orow][j]);                   \
           }                                                                                                       \
+          if constexpr (MASKM == 1) mbyte[orow] = relu_byte_of_pairs(v);                                                \
           pend[orow] = v;                                                                                         \
         }                                                                                                         \
       }                                                                                                           \
@@ -521,11 +558,10 @@ void launch_pack_weight_v3(const float* w, uint16_t* wp2, int c_out, int c_in, i
 }
 
 // Returns 1 (not a PV_* code) when the shape does not fit this kernel (fewer than 2 output slices per time chunk): the caller falls back
-// to the one-wave-per-SIMD kernel of conv3d_bf16.hip.  The 1-bit relu masks of the C ABI (out_gate_mask / relu_mask_out) have no path of their own here any
-// more: with the gate fetched as 16-byte pieces the bf16 tensor is as cheap to read as the mask was, so a mask that
-// accompanies out_gate is ignored (same result by definition) and a requested mask is written by the caller's pass over y
-// (v3_writes_mask() == false).
-bool v3_writes_mask(int, const void*, const void*) { return false; }
+// to the one-wave-per-SIMD kernel of conv3d_bf16.hip.  The 1-bit relu masks of the C ABI: the plain NDHWC forward writes a requested
+// mask itself (MASKM 1; v3_writes_mask()), the gated dgrad reads a mask that accompanies out_gate instead of the bf16 tensor (MASKM 2);
+// the NCDHW-writing forward leaves a requested mask to the caller's pass over y.
+bool v3_writes_mask(int y_ncdhw, const void* out_gate, const void*) { return !y_ncdhw && !out_gate; }
 
 // grid of a v3 launch (tiles x time chunks x samples); false when no chunking leaves every chunk two output slices
 static bool v3_grid(const pv_conv3d_dims* d, int to, int ho, int wo, dim3* grid_out, int* n_colblk_out, int* t_chunk_out) {
@@ -560,19 +596,23 @@ static bool v3_grid(const pv_conv3d_dims* d, int to, int ho, int wo, dim3* grid_
 
 int launch_conv3d_fwd_bf16_v3(const uint16_t* x, const uint16_t* wp2, const float* bias, uint16_t* y,
                               const uint16_t* out_gate, const pv_conv3d_dims* d, int to, int ho, int wo, int relu,
-                              int y_ncdhw, hipStream_t st, const uint32_t* /*out_gate_mask*/, uint32_t* /*mask_out*/) {
+                              int y_ncdhw, hipStream_t st, const uint32_t* out_gate_mask, uint32_t* mask_out) {
   if (to < 2) return 1;
   if (y_ncdhw && (wo % 8 != 0 || ((uintptr_t)y % 16) != 0)) return 1;  // 16-byte pieces of an output line
   if (!y_ncdhw && (((uintptr_t)y % 16) != 0 || ((uintptr_t)out_gate % 16) != 0)) return 1;
   dim3 grid;
   int n_colblk, t_chunk;
   if (!v3_grid(d, to, ho, wo, &grid, &n_colblk, &t_chunk)) return 1;
-#define PV_LAUNCH_V3(OG, YN)                                                                                          \
-  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in,     \
-                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out)
-  if (y_ncdhw) PV_LAUNCH_V3(false, true);
-  else if (out_gate) PV_LAUNCH_V3(true, false);
-  else PV_LAUNCH_V3(false, false);
+  const int mhp = (ho + V3_TR - 1) / V3_TR * V3_TR, mwp = (wo + V3_TW_VALID - 1) / V3_TW_VALID * V3_TW_VALID;      // pv_relu_mask_dims
+#define PV_LAUNCH_V3(OG, YN, MM, MPTR)                                                                                  \
+  hipLaunchKernelGGL((conv3d_fwd_bf16_v3_kernel<OG, YN, 0, MM>), grid, dim3(256), 0, st, x, wp2, bias, y, out_gate, d->t_in, \
+                     d->h_in, d->w_in, to, ho, wo, d->pad_t, d->pad_h, d->pad_w, relu ? 1 : 0, n_colblk, t_chunk, d->c_out, \
+                     MPTR, mhp, mwp)
+  if (y_ncdhw) PV_LAUNCH_V3(false, true, 0, (uint32_t*)nullptr);
+  else if (out_gate && out_gate_mask) PV_LAUNCH_V3(true, false, 2, const_cast<uint32_t*>(out_gate_mask));
+  else if (out_gate) PV_LAUNCH_V3(true, false, 0, (uint32_t*)nullptr);
+  else if (mask_out) PV_LAUNCH_V3(false, false, 1, mask_out);
+  else PV_LAUNCH_V3(false, false, 0, (uint32_t*)nullptr);
 #undef PV_LAUNCH_V3
   return check_launch("pv_conv3d_fwd_bf16(v3)");
 }

@@ -597,6 +597,11 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
 // into Adam, dx is not.  Replaces, per rank and step at 8 x 32 rows: eight dx launches + the register-tiled weight-gradient +
 // Adam launch (345 us) by one pass at the shard's memory traffic.
 // ---------------------------------------------------------------------------------------------
+constexpr int TL_XS = 320;      // bytes per row of an x block [32][128] bf16 (rows 64 B apart mod 256: conflict-free transposed reads)
+constexpr int TL_TS = 64 + 4;   // floats per row of a wave's transpose patch [32 rows][64 columns]
+typedef __attribute__((address_space(3))) s16x4 tl_lds_s16x4_t;
+static_assert(32 * TL_XS <= FD_KT * FD_WLD * 2 && 4 * 32 * TL_TS * 4 <= FD_KT * FD_WLD * 2, "x block / transpose patches live in the weight tile's bytes");
+
 template <int AHEAD>
 __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ dy, float* __restrict__ w, int m, int n, long long k,
@@ -605,7 +610,9 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
   __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g block [b][n], zero padded
   __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
   __shared__ __attribute__((aligned(16))) uint16_t dxs[32 * FD_XLD];        // the outgoing dx block [b][k]
-  uint16_t* xs = wt;      // the x blocks [b][k] use wt's first bytes while the gradient is accumulated (wt is written after that)
+  // wt's bytes hold the x blocks [b][k] (rows of TL_XS bytes) while the gradient is accumulated, then the waves' transpose patches;
+  // wt itself is written after the Adam rows
+  unsigned char* xsb = reinterpret_cast<unsigned char*>(wt);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = tid & 15, rg = tid >> 4;
   const long long k0 = (long long)blockIdx.x * FD_KT;
@@ -625,48 +632,114 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) fetch(i);
-  auto load_g = [&](int mb) {
+  auto load_g = [&](int mb) {      // (the dx walk: one block at a time)
     for (int i = tid; i < 32 * 128; i += 256) {
       const int b = 32 * mb + (i >> 7), nn = i & 127;
       gs[i] = (b < m && nn < n) ? dy[(size_t)b * n + nn] : 0.f;
     }
   };
-  auto load_x = [&](int mb) {
-    for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks of the x block
-      const int bl = i / (FD_KT / 8), c = i - bl * (FD_KT / 8), b = 32 * mb + bl;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (b < m && k0 + 8 * c < k) v = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
-      *reinterpret_cast<u32x4*>(xs + bl * FD_XLD + 8 * c) = v;
+  const int nblk = (m + 31) / 32;
+  // ---- weight gradient tile on the matrix cores (round 6; the vector-ALU form took 655 us for 512 rows where the shard's bytes need
+  // ~150): dW[n][k] += g^T[n][b] x[b][k] per block of 32 rows -- A = g^T rows 32 wave .. + 31 as THREE bf16 terms (an f32 splits
+  // exactly into three: the products are exact, only the order of the f32 additions differs from the register-tiled kernels),
+  // B = the x block read transposed from LDS (ds_read_b64_tr_b16), four 32-column tiles per wave.  The next block's x and g are
+  // requested before this block's products. -----------------------------------------------------------------------------------------
+  const int r = lane & 31, hh = lane >> 5;
+  const int G = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int tr_off = (8 * (G >> 1) + tq) * TL_XS + (16 * (G & 1) + 4 * tp) * 2;
+  u32x4 xr[2];
+  f32x4 gr[4];
+  auto prefetch = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, bl = id >> 4, c = id & 15, b = 32 * mb + bl;
+      xr[i] = (u32x4){0u, 0u, 0u, 0u};
+      if (mb < nblk && b < m && k0 + 8 * c < k) xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, bl = id >> 5, q4 = id & 31, b = 32 * mb + bl;
+      gr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (mb < nblk && b < m && 4 * q4 < n) gr[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)b * n + 4 * q4);
     }
   };
-  const int nblk = (m + 31) / 32;
-  // ---- weight gradient tile: rows 8 rg .. +7, columns k8 .. +7, summed over every row block (rows beyond m are zeros in LDS) ----
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[c][j] = 0.f;
+  prefetch(0);
+  for (int mb = 0; mb < nblk; ++mb) {
+    if (mb) __syncthreads();      // every wave is through with the previous block's tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i;
+      *reinterpret_cast<u32x4*>(xsb + (id >> 4) * TL_XS + 16 * (id & 15)) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i;
+      *reinterpret_cast<f32x4*>(gs + (id >> 5) * 128 + 4 * (id & 31)) = gr[i];
+    }
+    __syncthreads();
+    prefetch(mb + 1);
+    bf16x8 a3[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      s16x8_t t0, t1, t2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = gs[(16 * ks + 8 * hh + j) * 128 + 32 * wave + r];
+        const uint16_t b0 = f32_to_bf16_bits(v);
+        const float r1 = v - bf16_bits_to_f32(b0);
+        const uint16_t b1 = f32_to_bf16_bits(r1);
+        const uint16_t b2 = f32_to_bf16_bits(r1 - bf16_bits_to_f32(b1));
+        t0[j] = (short)b0, t1[j] = (short)b1, t2[j] = (short)b2;
+      }
+      a3[ks][0] = __builtin_bit_cast(bf16x8, t0);
+      a3[ks][1] = __builtin_bit_cast(bf16x8, t1);
+      a3[ks][2] = __builtin_bit_cast(bf16x8, t2);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned char* bp = xsb + tr_off + ks * 16 * TL_XS + c * 64;
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tl_lds_s16x4_t*)(bp));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tl_lds_s16x4_t*)(bp + 4 * TL_XS));
+        const __attribute__((ext_vector_type(8))) short b8s = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const bf16x8 b8 = __builtin_bit_cast(bf16x8, b8s);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks][2], b8, acc[c], 0, 0, 0);      // smallest term first
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks][1], b8, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[ks][0], b8, acc[c], 0, 0, 0);
+      }
+    }
+  }
+  // the tile reaches the Adam threads -- thread (kq, rg) owns rows 8 rg .. + 7 x columns 8 kq .. + 7, and rows 32 wave .. + 31 are
+  // this wave's own -- through a patch of [32][64] floats per wave, one column half at a time
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   f32x2_t acc2[8][4];
+  {
+    float* patch = reinterpret_cast<float*>(wt) + wave * (32 * TL_TS);
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int cc = 0; cc < 2; ++cc) {
+      __syncthreads();      // the x block's last readers / the previous half's readers are done
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x2_t){0.f, 0.f};
-  for (int mb = 0; mb < nblk; ++mb) {
-    if (mb) __syncthreads();      // every thread is through with the previous block's tiles
-    load_g(mb);
-    load_x(mb);
-    __syncthreads();
-#pragma unroll 4
-    for (int b = 0; b < 32; ++b) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(xs + b * FD_XLD + 8 * kq);
-      f32x2_t xv2[4];
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        xv2[q] = (f32x2_t){__builtin_bit_cast(float, raw[q] << 16), __builtin_bit_cast(float, raw[q] & 0xffff0000u)};
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg);
-      const f32x4 g1 = *reinterpret_cast<const f32x4*>(gs + b * 128 + 8 * rg + 4);
+        for (int j = 0; j < 16; ++j) patch[((j & 3) + 8 * (j >> 2) + 4 * hh) * TL_TS + 32 * t + r] = acc[2 * cc + t][j];
+      __syncthreads();
+      if ((kq >> 3) == cc) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float gv = i < 4 ? g0[i] : g1[i - 4];
-        const f32x2_t g2 = {gv, gv};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[i][j] = __builtin_elementwise_fma(g2, xv2[j], acc2[i][j]);
+        for (int i = 0; i < 8; ++i) {
+          const float* src = patch + (8 * (rg & 3) + i) * TL_TS + 8 * (kq & 7);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+          acc2[i][0] = (f32x2_t){lo[0], lo[1]};
+          acc2[i][1] = (f32x2_t){lo[2], lo[3]};
+          acc2[i][2] = (f32x2_t){hi[0], hi[1]};
+          acc2[i][3] = (f32x2_t){hi[2], hi[3]};
+        }
       }
     }
   }
@@ -1387,7 +1460,7 @@ int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float*
              "pv_linear_wgrad_dx_adam_tall_bf16: n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_tall_bf16: k must be a multiple of 8");
   PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: step must be >= 1");
-  PV_REQUIRE((((uintptr_t)x | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)bf16_shadow | (uintptr_t)dx) & 15) == 0,
+  PV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)bf16_shadow | (uintptr_t)dx) & 15) == 0,
              PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,

@@ -89,6 +89,20 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// the mask byte of 8 consecutive channels held as four bf16 pairs: bit c = channel c > 0
+__device__ __forceinline__ uint32_t relu_byte_of_pairs(const u32x4& v) {
+  uint32_t u = 0;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    uint32_t m;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(m) : "v"(v[j]));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "s"(0x00010001u));
+    u = (u << 2) | m;      // halves: bits 2 j (low) and 16 + 2 j (high)
+  }
+  return u | (u >> 15);      // bit 2 j + 1 <- bit 16 + 2 j (the byte store keeps bits 0..7)
+}
+
+
 }  // namespace pv
 
 // ---- diagnostic build only (make diag: -DPV_DIAG_STAMPS -> lib/libpvyield_diag.so, tools/diag_stamps.py) --------------------

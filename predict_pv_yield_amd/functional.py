@@ -92,13 +92,15 @@ def linear_f32(x, weight, bias, relu=False):
 # ---------------------------------------------------------------------------------------------
 # bf16 path
 # ---------------------------------------------------------------------------------------------
-# The conv towers CAN hand 1-bit relu masks from each layer's forward to the next layer's dgrad (see Conv3dReLUBF16),
-# replacing the dgrad epilogue's 64-byte-per-voxel read of the bf16 activation by 4 bytes.  Measured in one process on
-# MI355X (tools/ab_step.py, B = 32): inside the train step the mask-gated dgrad runs exactly as fast as the bf16-gated
-# one (81.1 vs 81.0 us average: the activation was just read by the layer's wgrad and is still in the 256 MB MALL), while
-# writing the masks costs the producing forwards 7-8 us each -- 1.843 vs 1.829 ms per step.  So the default is OFF; the
-# path stays parity-tested (tests/test_gpu_conv.py) for larger batches / models whose activations outgrow the cache.
-USE_RELU_MASKS = False
+# The conv towers hand 1-bit relu masks from each layer's forward to the next layer's dgrad (see Conv3dReLUBF16): the dgrad
+# epilogue reads one byte per lane instead of 16 of the bf16 activation -- 0.31 GB per step at B = 32, a tenth of what the conv
+# launches move.  Round 2 measured the mask path as a LOSS (the forwards wrote their masks in a pass of their own, 7-8 us
+# each, and the gate read hit the 256 MB Infinity Cache anyway); since round 6 the input-stationary forward and the
+# first-layer kernel write the mask with the tile (one byte store per lane and tile row in the side slots the gated form uses
+# for its gate loads) and the gated dgrad reads it in-kernel: same-box A/B (tools/ab_step.py, tools/probes/step_ab_libs.sh)
+# -3 to -4 us per step at B = 32 and B = 64 -- the time barely moves because these launches are not bound by their bytes
+# (profiles/r06/NOTES.md section 5), the traffic does.  Bit-identical either way (tests/test_gpu_conv.py).
+USE_RELU_MASKS = True
 
 
 class PackInputBF16(torch.autograd.Function):
