@@ -531,8 +531,9 @@ def measure_ksharded_rank_compute(dev, history_minutes, world=8, per_gpu_batch=6
     g = torch.Generator(device=dev).manual_seed(518)
     batch = {"satellite": {"data": torch.randn(b, 11, t, 64, 64, generator=g, device=dev)},
              "pv": {"pv_yield": torch.rand(b, t, 128, generator=g, device=dev)}}
-    fwd = lambda x: x.view(x.shape[0], world, kr).transpose(0, 1).contiguous().view(world * x.shape[0], kr)
-    back = lambda d: d.view(world, d.shape[0] // world, kr).transpose(0, 1).reshape(d.shape[0] // world, world * kr)
+    # (the staging copies of the two all-to-alls as distributed.py makes them, without the exchange between them)
+    fwd = lambda x: D._swap01(x.contiguous().view(x.shape[0], world, kr)).view(world * x.shape[0], kr)
+    back = lambda d: D._swap01(d.contiguous().view(world, d.shape[0] // world, kr)).view(d.shape[0] // world, world * kr)
     ww = world
     with mock.patch.object(D, "is_distributed", lambda: True), \
             mock.patch.object(D, "column_shard", lambda n_cols, rank=None, world=None, multiple=8: (0, n_cols // ww)), \

@@ -337,7 +337,8 @@ int pv_linear_bwd_f32(const float* x, const float* w, const float* dy, const flo
                       int32_t m, int32_t n, int64_t k, void* stream);
 
 /* bf16 variants for the big fc1 (x bf16 [M,K], w bf16 shadow [N,K], fp32 accumulate/outputs).
- * k must be a multiple of 8, m <= 128; workspace: pv_linear_bf16_workspace_bytes(M,N,K). */
+ * k must be a multiple of 8, m <= 1024 for the fc1 shapes (n <= 128, n % 16 == 0; rows go in blocks of 64 or 32, each a stream
+ * over the weights), m <= 128 otherwise; workspace: pv_linear_bf16_workspace_bytes(M,N,K). */
 int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* bytes);
 int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, float* y,
                        int32_t m, int32_t n, int64_t k, int relu,
@@ -416,11 +417,13 @@ int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const f
  * taken in blocks of 32).  The weight gradient of the shard over the whole global batch is scaled by grad_scale (1 / world:
  * the averaging of DDP's all-reduce, experiments/003_...py:292-293) on its way into Adam; dx [m][k] = dy . W_old is not, and is
  * multiplied by (x > 0) when gate_dx_by_x.  No gradient or weight of fc1 crosses a link in this mode.  n <= 128, n % 8 == 0,
- * k % 8 == 0, 16-byte aligned buffers; bf16_shadow and dx may be NULL. */
+ * k % 8 == 0, 16-byte aligned buffers; bf16_shadow and dx may be NULL; workspace: caller-owned scratch (query below). */
 int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
                                       uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
                                       double beta1, double beta2, double eps, int32_t step, float grad_scale,
-                                      int32_t gate_dx_by_x, void* stream);
+                                      int32_t gate_dx_by_x, void* workspace, size_t workspace_bytes, void* stream);
+/* bytes of that call's workspace (dy as matrix-core operand fragments, built once per call): 40 KB per 32 rows */
+int pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes(int32_t m, size_t* bytes);
 
 int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_avg, float* exp_avg_sq,
                           uint16_t* bf16_shadow, size_t n, double lr, double beta1, double beta2, double eps,
@@ -433,6 +436,12 @@ int pv_adam_step_bf16grad(float* param, const uint16_t* grad_bf16, float* exp_av
  * bias may be NULL, relu != 0 applies max(., 0) (a NaN stays a NaN); y may alias x. */
 int pv_scale_bias_relu_f32(const float* x, const float* bias, float* y, int32_t m, int32_t n, float alpha, int32_t relu,
                            void* stream);
+
+/* dst[i1][i0][:] = src[i0][i1][:] for contiguous segments of seg_bytes (a multiple of 16; 16-byte aligned buffers, not in place):
+ * the chunk-major staging copies around the K-sharded fc1's two all-to-alls, [B][W][K / W] <-> [W][B][K / W] -- what
+ * `.transpose(0, 1).contiguous()` does to the tensors DDP never had to move (experiments/003_...py:292-293 exchanges gradients;
+ * this mode exchanges activations). */
+int pv_swap01_segments(const void* src, void* dst, int64_t n0, int64_t n1, int64_t seg_bytes, void* stream);
 
 /* dst[i] = bf16(src[i]) (round to nearest even): first fill of a parameter's bf16 shadow; afterwards
  * pv_adam_step_f32 keeps the shadow current. */

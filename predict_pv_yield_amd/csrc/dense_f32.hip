@@ -6,6 +6,18 @@
 
 namespace pv {
 
+// dst[i1][i0][:] = src[i0][i1][:] for contiguous segments of seg16 x 16 bytes: the chunk-major staging of the K-sharded fc1's two
+// all-to-alls ([B][W][K / W] <-> [W][B][K / W], segments of 245 KB).  torch's strided copy moves these 2 x 128 MB at 2.8 TB/s.
+__global__ __launch_bounds__(256) void swap01_segments_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long long n0,
+                                                               long long n1, long long seg16) {
+  const size_t total = (size_t)n0 * n1 * seg16, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t seg = i / seg16, c = i - seg * seg16;      // destination segment (i1, i0)
+    const size_t i1 = seg / n0, i0 = seg - i1 * n0;
+    dst[i] = src[(i0 * n1 + i1) * seg16 + c];
+  }
+}
+
 constexpr int M_TILE = 8;
 constexpr long long SMALL_K = 4096, SMALL_MN = 1 << 16;   // "small layer": single-launch forward / backward
 
@@ -714,6 +726,18 @@ int pv_forecast_losses_f32(const float* y_hat, const float* y, int64_t y_row_str
   hipLaunchKernelGGL(forecast_losses_f32, dim3(1), dim3(256), 0, as_stream(stream), y_hat, y, (long long)y_row_stride,
                      (long long)y_col_stride, m, n, grad_scale, lw, out4, grad, per_horizon);
   return check_launch("pv_forecast_losses_f32");
+}
+
+int pv_swap01_segments(const void* src, void* dst, int64_t n0, int64_t n1, int64_t seg_bytes, void* stream) {
+  PV_REQUIRE(src && dst && src != dst, PV_EINVAL, "pv_swap01_segments: null pointer / in place");
+  PV_REQUIRE(n0 > 0 && n1 > 0 && seg_bytes > 0 && seg_bytes % 16 == 0, PV_ESIZE,
+             "pv_swap01_segments: n0, n1 > 0 and segments of a multiple of 16 bytes, got %lld x %lld x %lld", (long long)n0,
+             (long long)n1, (long long)seg_bytes);
+  PV_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, PV_EINVAL, "pv_swap01_segments: buffers must be 16-byte aligned");
+  const size_t total = (size_t)n0 * n1 * (seg_bytes / 16);
+  hipLaunchKernelGGL(swap01_segments_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const u32x4*>(src), static_cast<u32x4*>(dst), (long long)n0, (long long)n1, (long long)(seg_bytes / 16));
+  return check_launch("pv_swap01_segments");
 }
 
 int pv_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, void* stream) {

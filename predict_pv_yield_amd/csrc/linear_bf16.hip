@@ -105,14 +105,15 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_kernel(const uint16_t* __
 // launch, a call with more rows launches it per block and reduces ALL blocks here, once)
 __global__ __launch_bounds__(256) void linear_reduce_bf16path(const float* __restrict__ partial,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               int m, int n, int k_splits, int relu, size_t blk_stride = 0) {
+                                                               int m, int n, int k_splits, int relu, size_t blk_stride = 0,
+                                                               int rows_per_blk = 32) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   if (gridDim.y > 1) {
     partial += (size_t)blockIdx.y * blk_stride;
-    y += (size_t)blockIdx.y * 32 * n;
-    m = m - 32 * (int)blockIdx.y < 32 ? m - 32 * (int)blockIdx.y : 32;
+    y += (size_t)blockIdx.y * rows_per_blk * n;
+    m = m - rows_per_blk * (int)blockIdx.y < rows_per_blk ? m - rows_per_blk * (int)blockIdx.y : rows_per_blk;
   }
   const size_t mn = (size_t)m * n;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -590,24 +591,80 @@ __global__ __launch_bounds__(256, 3) void linear_bwd_dw_dx_adam_kernel(
 // The same pass for the K-SHARDED fc1 (distributed.py, HipAdam large_grad_mode "ksharded"): this rank's COLUMN shard of the
 // weight, [n <= 128][k = K / W], and ALL samples of the global batch: m = W x per-GPU batch rows (256 at 8 x 32), taken in
 // blocks of 32.  A workgroup owns 128 k-columns as above and walks the row blocks twice: once to accumulate the gradient tile
-// (the x block and the g block staged in LDS per block), then -- after the Adam rows, with the pre-update weights parked
-// transposed in LDS -- once more for dx, block by block on the matrix cores.  The outgoing dx block has LDS bytes of its own
-// (the weight tile must survive all blocks): 59 KB, two workgroups per CU.  dy arrives already gated (the all-gathered
-// g = dy (.) relu' of every rank); the gradient is scaled by grad_scale (1 / world: the mean of DDP's all-reduce) on its way
-// into Adam, dx is not.  Replaces, per rank and step at 8 x 32 rows: eight dx launches + the register-tiled weight-gradient +
-// Adam launch (345 us) by one pass at the shard's memory traffic.
+// on the matrix cores (x blocks staged in LDS and read transposed, g^T as three-term bf16 fragments), then -- after the Adam
+// rows, with the pre-update weights parked transposed in LDS -- once more for dx, block by block.  The outgoing dx block has LDS
+// bytes of its own (the weight tile must survive all blocks): 59 KB, two workgroups per CU.  dy arrives already gated (the
+// all-gathered g = dy (.) relu' of every rank) and is turned into operand fragments once per call (tall_split_g_kernel); the
+// gradient is scaled by grad_scale (1 / world: the mean of DDP's all-reduce) on its way into Adam, dx is not.
+// History (512 rows x 125 440 columns, one rank of 8 at 64 samples per GPU): eight dx launches + the register-tiled weight gradient
+// + Adam 0.9 ms; one pass with the gradient tile on the vector ALU 655 us; gradient on the matrix cores with g converted per
+// workgroup 408 us; with finished fragments: see profiles/r06/NOTES.md section 4.
 // ---------------------------------------------------------------------------------------------
 constexpr int TL_XS = 320;      // bytes per row of an x block [32][128] bf16 (rows 64 B apart mod 256: conflict-free transposed reads)
 constexpr int TL_TS = 64 + 4;   // floats per row of a wave's transpose patch [32 rows][64 columns]
+constexpr int TL_GA = 2 * 4 * 3 * 64, TL_GD = 2 * 8 * 64;      // 16-byte operand fragments per block of 32 rows: gradient / dx
 typedef __attribute__((address_space(3))) s16x4 tl_lds_s16x4_t;
 static_assert(32 * TL_XS <= FD_KT * FD_WLD * 2 && 4 * 32 * TL_TS * 4 <= FD_KT * FD_WLD * 2, "x block / transpose patches live in the weight tile's bytes");
 
+// g [m][n] (f32, already gated) as ready-made matrix-core operands, ONCE per call: every one of the shard's ~1 000 workgroups needs
+// the same fragments, and converting them per workgroup was most of the first matrix-core form's time (408 us at 512 rows, the
+// dx walk's column-strided f32 reads of g at 16-way bank conflicts the rest).  Per block mb of 32 rows:
+//   gradient (A = g^T): fragment ((mb, ks, wave), term t, lane (r, hh)) = bf16 term t of g[32 mb + 16 ks + 8 hh + j][32 wave + r],
+//     j = 0 .. 7 -- THREE terms (an f32 splits exactly into three bf16);
+//   dx (A = g): fragment ((mb, term, st), lane (col, half)) = g[32 mb + col][16 st + 8 half + j] as hi / lo (two terms, ~16 bits,
+//     as linear_bwd_dx_bf16_v2_kernel).
+// Rows beyond m and outputs beyond n are zeros.
+__global__ __launch_bounds__(256) void tall_split_g_kernel(const float* __restrict__ dy, int m, int n, u32x4* __restrict__ ga,
+                                                            u32x4* __restrict__ gd, int nblk) {
+  const int total = nblk * (TL_GA + TL_GD);
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < total; f += gridDim.x * blockDim.x) {
+    const int mb = f / (TL_GA + TL_GD), i = f - mb * (TL_GA + TL_GD);
+    float v[8];
+    int term;
+    if (i < TL_GA) {      // ((ks * 4 + wave) * 3 + term) * 64 + lane
+      const int lane = i & 63, q = i >> 6, ks = q / 12, wave = (q / 3) & 3, r = lane & 31, hh = lane >> 5;
+      term = q % 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = 32 * mb + 16 * ks + 8 * hh + j, nn = 32 * wave + r;
+        v[j] = (b < m && nn < n) ? dy[(size_t)b * n + nn] : 0.f;
+      }
+    } else {              // (term * 8 + st) * 64 + lane
+      const int i2 = i - TL_GA, lane = i2 & 63, q = i2 >> 6, st = q & 7, col = lane & 31, half = lane >> 5;
+      term = q >> 3;
+      const int b = 32 * mb + col;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int nn = 16 * st + 8 * half + j;
+        v[j] = (b < m && nn < n) ? dy[(size_t)b * n + nn] : 0.f;
+      }
+    }
+    u32x4 o;
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      uint16_t e[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float rem = v[2 * q2 + h];
+        uint16_t bits = f32_to_bf16_bits(rem);
+        for (int t = 0; t < term; ++t) {
+          rem -= bf16_bits_to_f32(bits);
+          bits = f32_to_bf16_bits(rem);
+        }
+        e[h] = bits;
+      }
+      o[q2] = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+    }
+    (i < TL_GA ? ga + (size_t)mb * TL_GA + i : gd + (size_t)mb * TL_GD + (i - TL_GA))[0] = o;
+  }
+}
+
 template <int AHEAD>
 __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
-    const uint16_t* __restrict__ x, const float* __restrict__ dy, float* __restrict__ w, int m, int n, long long k,
-    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow, uint16_t* __restrict__ dx,
-    AdamScalars ad, int gate_dx, float grad_scale) {
-  __shared__ __attribute__((aligned(16))) float gs[32 * 128];               // g block [b][n], zero padded
+    const uint16_t* __restrict__ x, const u32x4* __restrict__ ga, const u32x4* __restrict__ gd, float* __restrict__ w, int m, int n,
+    long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
+    uint16_t* __restrict__ dx, AdamScalars ad, int gate_dx, float grad_scale) {
+  __shared__ __attribute__((aligned(16))) u32x4 gfr[TL_GD];                 // the dx walk's A fragments of a block (16 KB)
   __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
   __shared__ __attribute__((aligned(16))) uint16_t dxs[32 * FD_XLD];        // the outgoing dx block [b][k]
   // wt's bytes hold the x blocks [b][k] (rows of TL_XS bytes) while the gradient is accumulated, then the waves' transpose patches;
@@ -632,23 +689,15 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) fetch(i);
-  auto load_g = [&](int mb) {      // (the dx walk: one block at a time)
-    for (int i = tid; i < 32 * 128; i += 256) {
-      const int b = 32 * mb + (i >> 7), nn = i & 127;
-      gs[i] = (b < m && nn < n) ? dy[(size_t)b * n + nn] : 0.f;
-    }
-  };
   const int nblk = (m + 31) / 32;
   // ---- weight gradient tile on the matrix cores (round 6; the vector-ALU form took 655 us for 512 rows where the shard's bytes need
-  // ~150): dW[n][k] += g^T[n][b] x[b][k] per block of 32 rows -- A = g^T rows 32 wave .. + 31 as THREE bf16 terms (an f32 splits
-  // exactly into three: the products are exact, only the order of the f32 additions differs from the register-tiled kernels),
-  // B = the x block read transposed from LDS (ds_read_b64_tr_b16), four 32-column tiles per wave.  The next block's x and g are
-  // requested before this block's products. -----------------------------------------------------------------------------------------
-  const int r = lane & 31, hh = lane >> 5;
+  // ~150): dW[n][k] += g^T[n][b] x[b][k] per block of 32 rows -- A = g^T rows 32 wave .. + 31 as three bf16 terms (exact: only the
+  // order of the f32 additions differs from the register-tiled kernels), fetched as finished fragments; B = the x block read
+  // transposed from LDS (ds_read_b64_tr_b16), four 32-column tiles per wave.  The next block's x and fragments are requested
+  // before this block's products. ---------------------------------------------------------------------------------------------
   const int G = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   const int tr_off = (8 * (G >> 1) + tq) * TL_XS + (16 * (G & 1) + 4 * tp) * 2;
-  u32x4 xr[2];
-  f32x4 gr[4];
+  u32x4 xr[2], ar[2][3];
   auto prefetch = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -656,12 +705,11 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
       xr[i] = (u32x4){0u, 0u, 0u, 0u};
       if (mb < nblk && b < m && k0 + 8 * c < k) xr[i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
     }
+    const u32x4* src = ga + (size_t)min(mb, nblk - 1) * TL_GA + lane;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i, bl = id >> 5, q4 = id & 31, b = 32 * mb + bl;
-      gr[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (mb < nblk && b < m && 4 * q4 < n) gr[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)b * n + 4 * q4);
-    }
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) ar[ks][t] = src[((ks * 4 + wave) * 3 + t) * 64];
   };
   f32x16 acc[4];
 #pragma unroll
@@ -670,37 +718,19 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
     for (int j = 0; j < 16; ++j) acc[c][j] = 0.f;
   prefetch(0);
   for (int mb = 0; mb < nblk; ++mb) {
-    if (mb) __syncthreads();      // every wave is through with the previous block's tiles
+    if (mb) __syncthreads();      // every wave is through with the previous block's x
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int id = tid + 256 * i;
       *reinterpret_cast<u32x4*>(xsb + (id >> 4) * TL_XS + 16 * (id & 15)) = xr[i];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int id = tid + 256 * i;
-      *reinterpret_cast<f32x4*>(gs + (id >> 5) * 128 + 4 * (id & 31)) = gr[i];
-    }
-    __syncthreads();
-    prefetch(mb + 1);
     bf16x8 a3[2][3];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-      s16x8_t t0, t1, t2;
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = gs[(16 * ks + 8 * hh + j) * 128 + 32 * wave + r];
-        const uint16_t b0 = f32_to_bf16_bits(v);
-        const float r1 = v - bf16_bits_to_f32(b0);
-        const uint16_t b1 = f32_to_bf16_bits(r1);
-        const uint16_t b2 = f32_to_bf16_bits(r1 - bf16_bits_to_f32(b1));
-        t0[j] = (short)b0, t1[j] = (short)b1, t2[j] = (short)b2;
-      }
-      a3[ks][0] = __builtin_bit_cast(bf16x8, t0);
-      a3[ks][1] = __builtin_bit_cast(bf16x8, t1);
-      a3[ks][2] = __builtin_bit_cast(bf16x8, t2);
-    }
+      for (int t = 0; t < 3; ++t) a3[ks][t] = __builtin_bit_cast(bf16x8, ar[ks][t]);
+    __syncthreads();
+    prefetch(mb + 1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -721,6 +751,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   f32x2_t acc2[8][4];
   {
+    const int r = lane & 31, hh = lane >> 5;
     float* patch = reinterpret_cast<float*>(wt) + wave * (32 * TL_TS);
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -784,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
     }
   }
   if (!dx) return;
-  __syncthreads();   // every thread is done reading the last x block: its bytes now become part of wt
+  __syncthreads();   // every thread is done reading its transpose patch: the bytes now become wt
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     u32x4 piece;
@@ -796,46 +827,57 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
     }
     *reinterpret_cast<u32x4*>(wt + (8 * kq + j) * FD_WLD + 8 * rg) = piece;
   }
-  // ---- dx block by block, last block first (its g is still in LDS): A = g rows (hi + lo), B = wt rows k ----------------------------
+  // ---- dx block by block: A = g rows (hi + lo) as finished fragments, staged through LDS once per workgroup (all four waves
+  // multiply the same g rows); B = wt rows k.  The next block's fragments and this block's gate words are requested a block ahead. ----
   const int col = lane & 31, half = lane >> 5;
-  for (int mb = nblk - 1; mb >= 0; --mb) {
-    if (mb != nblk - 1) load_g(mb);      // (every wave is past the previous block's products: the barrier below the dxs writes)
-    __syncthreads();                     // wt (first trip) / the g block complete; the previous block's dxs rows have left
+  u32x4 gdr[4], gx[2];
+  auto prefetch_dx = [&](int mb) {
+    const u32x4* src = gd + (size_t)min(mb, nblk - 1) * TL_GD + tid;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gdr[i] = src[256 * i];
+  };
+  auto prefetch_gate = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, bl = id >> 4, c = id & 15, b = 32 * mb + bl;
+      gx[i] = (u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      if (gate_dx && b < m && k0 + 8 * c < k) gx[i] = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
+    }
+  };
+  prefetch_dx(0);
+  for (int mb = 0; mb < nblk; ++mb) {
+    if (mb) __syncthreads();             // every wave is through with the previous block's fragments; its dxs rows have left
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gfr[tid + 256 * i] = gdr[i];
+    __syncthreads();                     // wt (first trip) and the fragments are complete
+    prefetch_dx(mb + 1);
+    prefetch_gate(mb);
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(gs + col * 128 + 16 * st + 8 * half + 4);
-      const float gx[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      u32x4 hw, lw;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint16_t h0 = f32_to_bf16_bits(gx[2 * q]), h1 = f32_to_bf16_bits(gx[2 * q + 1]);
-        const uint16_t l0 = f32_to_bf16_bits(gx[2 * q] - bf16_bits_to_f32(h0)), l1 = f32_to_bf16_bits(gx[2 * q + 1] - bf16_bits_to_f32(h1));
-        hw[q] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        lw[q] = (uint32_t)l0 | ((uint32_t)l1 << 16);
-      }
+      const bf16x8 hw = __builtin_bit_cast(bf16x8, gfr[st * 64 + lane]);
+      const bf16x8 lw = __builtin_bit_cast(bf16x8, gfr[(8 + st) * 64 + lane]);
       const bf16x8 bw = *reinterpret_cast<const bf16x8*>(wt + (32 * wave + col) * FD_WLD + 16 * st + 8 * half);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, lw), bw, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hw), bw, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lw, bw, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw, bw, o, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int b = (r & 3) + 8 * (r >> 2) + 4 * half;
       dxs[b * FD_XLD + 32 * wave + col] = f32_to_bf16_bits(o[r]);
     }
-    __syncthreads();                     // the dx block is assembled; every wave is through with this g block
-    for (int i = tid; i < 32 * (FD_KT / 8); i += 256) {          // 16-byte chunks: 256 contiguous bytes per row of dx
-      const int bl = i / (FD_KT / 8), c = i - bl * (FD_KT / 8), b = 32 * mb + bl;
+    __syncthreads();                     // the dx block is assembled
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {        // 16-byte chunks: 256 contiguous bytes per row of dx
+      const int id = tid + 256 * i, bl = id >> 4, c = id & 15, b = 32 * mb + bl;
       if (b < m && k0 + 8 * c < k) {
         u32x4 ov = *reinterpret_cast<const u32x4*>(dxs + bl * FD_XLD + 8 * c);
         if (gate_dx) {
-          const u32x4 xv = *reinterpret_cast<const u32x4*>(x + (size_t)b * k + k0 + 8 * c);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            ov[q] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, relu_pair01(xv[q])) * (u16x2_t){0xffff, 0xffff});
+            ov[q] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_t, relu_pair01(gx[i][q])) * (u16x2_t){0xffff, 0xffff});
         }
         *reinterpret_cast<u32x4*>(dx + (size_t)b * k + k0 + 8 * c) = ov;
       }
@@ -1160,11 +1202,15 @@ __global__ __launch_bounds__(256) void gate_bf16_by_relu_kernel(uint16_t* __rest
 // so the 16 rows an MFMA operand read touches fall into 16 different bank slots; the rotation is applied to the SOURCE
 // chunk each lane fetches, the LDS side of the instruction being linear by lane.
 // ---------------------------------------------------------------------------------------------
-constexpr int V3_KC = 128, V3_ROWS = 160, V3_TILEB = V3_ROWS * 256, V3_STAGES = 3;
+constexpr int V3_KC = 128, V3_STAGES = 3;
 
+// MB: row blocks of 32 x rows a tile carries beside the 128 weight rows (round 6: two -- 64 rows per stream over the weights, 144 KB
+// of ring -- for calls with more than 32 rows: a per-GPU batch of 64, the K-sharded fc1's 256 / 512 rows)
+template <int MB>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                                   float* __restrict__ partial, int m, int n, long long k,
                                                                   int n_tiles, int tiles_per_wg) {
+  constexpr int V3_ROWS = 128 + 32 * MB, V3_TILEB = V3_ROWS * 256, LOADS = V3_ROWS / 16;
   __shared__ __attribute__((aligned(1024))) unsigned char ring[V3_STAGES * V3_TILEB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1182,8 +1228,8 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
     const long long k0 = (long long)t * V3_KC;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #pragma unroll
-    for (int i = 0; i < V3_ROWS / 16; ++i) {
-      const int blk = wave + 4 * i;  // 4-row block 0..39: 0..31 weight rows, 32..39 x rows
+    for (int i = 0; i < LOADS; ++i) {
+      const int blk = wave + 4 * i;  // 4-row block: 0..31 weight rows, 32.. x rows
       const int row = 4 * blk + srow;
       const int c = (spos - row) & 15;
       const bool c_ok = k0 + c * 8 < k;
@@ -1197,9 +1243,11 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
       }
     }
   };
-  f32x16 acc;
+  f32x16 acc[MB];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int q = 0; q < MB; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
   // operand reads: x row r / weight row 32*wave + r, k-chunk 2*ks + hh, both rotated by r & 15
   int pos[V3_KC / 16];
 #pragma unroll
@@ -1209,8 +1257,8 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
   load_tile(t0);
   if (t0 + 1 < t1) load_tile(t0 + 1);
   for (int t = t0; t < t1; ++t) {
-    // this wave issues 10 loads per tile, in order: all but the newest tile's have landed
-    if (t + 1 < t1) __builtin_amdgcn_s_waitcnt(0x0f70 | 10);
+    // this wave issues LOADS loads per tile, in order: all but the newest tile's have landed
+    if (t + 1 < t1) __builtin_amdgcn_s_waitcnt(0x0f70 | LOADS);
     else __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();  // tile t complete for every wave; every wave is done with tile t-1 (whose stage tile t+2 reuses)
     if (t + 2 < t1) load_tile(t + 2);
@@ -1218,9 +1266,12 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
     if (wave * 32 < n) {
 #pragma unroll
       for (int ks = 0; ks < V3_KC / 16; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + a_row + pos[ks]);
         const bf16x8 b = *reinterpret_cast<const bf16x8*>(tile + b_row + pos[ks]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < MB; ++q) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(tile + a_row + q * (32 * 256) + pos[ks]);
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[q], 0, 0, 0);
+        }
       }
     }
   }
@@ -1228,10 +1279,12 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
   if (col < n) {
     float* dst = partial + (size_t)blockIdx.x * m * n + col;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
-      if (row < m) dst[(size_t)row * n] = acc[j];
-    }
+    for (int q = 0; q < MB; ++q)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = 32 * q + (j & 3) + 8 * (j >> 2) + 4 * hh;
+        if (row < m) dst[(size_t)row * n] = acc[q][j];
+      }
   }
 }
 
@@ -1275,7 +1328,7 @@ int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* byte
   PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bf16_workspace_bytes: bad arguments");
   int per;
   int nwg = bf16_fwd_split(k, &per);   // >= the v2 / v3 splits (<= 512 workgroups)
-  const size_t rows = (size_t)((m + 31) / 32) * 32;      // (the LDS-staged forward keeps 32 rows of slabs per row block)
+  const size_t rows = (size_t)((m + 63) / 64) * 64;      // (the LDS-staged forward keeps 32 or 64 rows of slabs per launch)
   *bytes = (size_t)nwg * rows * n * sizeof(float);
   return PV_OK;
 }
@@ -1285,7 +1338,7 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
   PV_REQUIRE(x && w && y && workspace, PV_EINVAL, "pv_linear_fwd_bf16: null pointer");
   PV_REQUIRE(m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_fwd_bf16: bad sizes");
   PV_REQUIRE(k % 8 == 0, PV_ESIZE, "pv_linear_fwd_bf16: k=%lld must be a multiple of 8", (long long)k);
-  PV_REQUIRE(m <= 128, PV_ESIZE, "pv_linear_fwd_bf16: m=%d > 128 rows per call", m);
+  PV_REQUIRE(m <= 1024, PV_ESIZE, "pv_linear_fwd_bf16: m=%d > 1024 rows per call", m);
   PV_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0), PV_EINVAL, "pv_linear_fwd_bf16: unaligned operand");
   int per;
   int nwg = bf16_fwd_split(k, &per);
@@ -1297,25 +1350,30 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
     int tiles, n_tiles;
     const bool fits32 = (size_t)n * k * 2 < 0xfffffff0ull;  // the v3 kernel's raw-buffer offsets are 32-bit
     const int nwg2 = !fits32 ? v2_split(k, &tiles, &n_tiles) : v3_split(k, &tiles, &n_tiles);
-    const int nblk = (m + 31) / 32;
-    const size_t blk_stride = (size_t)nwg2 * 32 * n;      // floats between two row blocks' slabs
+    const int rpb = (m > 32 && fits32) ? 64 : 32;      // rows per launch: two row blocks beside the weight tile when there are that many
+    const int nblk = (m + rpb - 1) / rpb;
+    const size_t blk_stride = (size_t)nwg2 * rpb * n;      // floats between two launches' slabs
     PV_REQUIRE(workspace_bytes >= (size_t)nblk * blk_stride * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
-    for (int m0 = 0; m0 < m; m0 += 32) {
-      const int mb = m - m0 < 32 ? m - m0 : 32;
+    for (int m0 = 0; m0 < m; m0 += rpb) {
+      const int mb = m - m0 < rpb ? m - m0 : rpb;
       const uint16_t* xb = x + (size_t)m0 * k;
-      float* pb = part + (size_t)(m0 / 32) * blk_stride;
+      float* pb = part + (size_t)(m0 / rpb) * blk_stride;
       if (!fits32)
         hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
                            n_tiles, tiles);
+      else if (rpb == 64)
+        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel<2>, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
+                           n_tiles, tiles);
       else
-        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
+        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel<1>, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
                            n_tiles, tiles);
     }
-    // one reduce for all row blocks (eight launches of ~5 us for the K-sharded fc1's 256 rows before)
-    hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((32 * n + 63) / 64), (unsigned)nblk), dim3(256), 0, st,
-                       (const float*)part, bias, y, m, n, nwg2, relu ? 1 : 0, blk_stride);
+    // one reduce for all launches (eight of ~5 us for the K-sharded fc1's 256 rows before)
+    hipLaunchKernelGGL(linear_reduce_bf16path, dim3((unsigned)((rpb * n + 63) / 64), (unsigned)nblk), dim3(256), 0, st,
+                       (const float*)part, bias, y, m, n, nwg2, relu ? 1 : 0, blk_stride, rpb);
     return check_launch("pv_linear_fwd_bf16");
   }
+  PV_REQUIRE(m <= 128, PV_ESIZE, "pv_linear_fwd_bf16: m=%d > 128 rows per call for this shape (n=%d: the register-tiled kernel)", m, n);
   PV_REQUIRE(workspace_bytes >= (size_t)nwg * m * n * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
   dim3 grid((unsigned)nwg, (unsigned)((n + 127) / 128));
   const int mt = (m + 31) / 32;
@@ -1451,22 +1509,36 @@ int pv_linear_wgrad_dx_adam_bf16(const uint16_t* x, const float* dy, const float
   return check_launch("pv_linear_wgrad_dx_adam_bf16");
 }
 
+int pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes(int32_t m, size_t* bytes) {
+  PV_REQUIRE(m > 0 && bytes, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes: bad arguments");
+  *bytes = (size_t)((m + 31) / 32) * (TL_GA + TL_GD) * 16;      // the output gradients as matrix-core operand fragments
+  return PV_OK;
+}
+
 int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
                                       uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
                                       double beta1, double beta2, double eps, int32_t step, float grad_scale,
-                                      int32_t gate_dx_by_x, void* stream) {
-  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: null pointer");
+                                      int32_t gate_dx_by_x, void* workspace, size_t workspace_bytes, void* stream) {
+  PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq && workspace, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: null pointer");
   PV_REQUIRE(m > 0 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
              "pv_linear_wgrad_dx_adam_tall_bf16: n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_tall_bf16: k must be a multiple of 8");
   PV_REQUIRE(step >= 1, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: step must be >= 1");
-  PV_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)bf16_shadow | (uintptr_t)dx) & 15) == 0,
+  PV_REQUIRE((((uintptr_t)x | (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)bf16_shadow | (uintptr_t)dx |
+               (uintptr_t)workspace) & 15) == 0,
              PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: buffers must be 16-byte aligned");
+  const int nblk = (m + 31) / 32;
+  PV_REQUIRE(workspace_bytes >= (size_t)nblk * (TL_GA + TL_GD) * 16, PV_ESIZE,
+             "pv_linear_wgrad_dx_adam_tall_bf16: workspace too small (pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes)");
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   AdamScalars ad{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps,
                  (float)(-(lr / bc1))};
+  u32x4* ga = static_cast<u32x4*>(workspace);
+  u32x4* gd = ga + (size_t)nblk * TL_GA;
+  hipLaunchKernelGGL(tall_split_g_kernel, dim3((unsigned)((nblk * (TL_GA + TL_GD) + 255) / 256)), dim3(256), 0, as_stream(stream), dy,
+                     m, n, ga, gd, nblk);
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
-  hipLaunchKernelGGL((linear_bwd_dw_dx_adam_tall_kernel<2>), dim3(grid), dim3(256), 0, as_stream(stream), x, dy, param, m, n,
+  hipLaunchKernelGGL((linear_bwd_dw_dx_adam_tall_kernel<2>), dim3(grid), dim3(256), 0, as_stream(stream), x, ga, gd, param, m, n,
                      (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, ad, gate_dx_by_x, grad_scale);
   return check_launch("pv_linear_wgrad_dx_adam_tall_bf16");
 }

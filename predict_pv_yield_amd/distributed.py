@@ -190,6 +190,15 @@ def column_shard(n_cols: int, rank: int = None, world: int = None, multiple: int
     return rank * per, (rank + 1) * per
 
 
+def _swap01(t: torch.Tensor) -> torch.Tensor:
+    """[n0, n1, seg] -> [n1, n0, seg], contiguous: the library's segment copy on the device when the segments allow it (16-byte
+    multiples), else torch's strided copy."""
+    if t.is_cuda and t.is_contiguous() and (t.shape[2] * t.element_size()) % 16 == 0:
+        from . import hip_ops as K
+        return K.swap01_segments(t)
+    return t.transpose(0, 1).contiguous()
+
+
 def all_to_all_columns(x_local: torch.Tensor) -> torch.Tensor:
     """x_local [B, K] (this rank's samples, all columns) -> [W B, K/W] (ALL samples in rank order, this rank's columns).
     RCCL: one all_to_all_single of W chunks [B, K/W] (the chunk-major staging copy is the only extra pass); gloo (tests):
@@ -198,7 +207,7 @@ def all_to_all_columns(x_local: torch.Tensor) -> torch.Tensor:
     b, k = x_local.shape
     kr = k // world
     if dist.get_backend() == "nccl":
-        send = x_local.view(b, world, kr).transpose(0, 1).contiguous()          # [W, B, K/W]: chunk s = my samples, rank s's columns
+        send = _swap01(x_local.contiguous().view(b, world, kr))                  # [W, B, K/W]: chunk s = my samples, rank s's columns
         recv = torch.empty_like(send)                                            # chunk s = rank s's samples, my columns
         dist.all_to_all_single(recv, send)
         return recv.view(world * b, kr)
@@ -217,7 +226,7 @@ def all_to_all_rows_back(dx_cols: torch.Tensor) -> torch.Tensor:
         send = dx_cols.contiguous().view(world, b, kr)                           # chunk s = rank s's samples, my columns
         recv = torch.empty_like(send)                                            # chunk s = my samples, rank s's columns
         dist.all_to_all_single(recv, send)
-        return recv.transpose(0, 1).reshape(b, world * kr)
+        return _swap01(recv).view(b, world * kr)
     r = dist.get_rank()
     full = [torch.empty_like(dx_cols) for _ in range(world)]
     dist.all_gather(full, dx_cols.contiguous())

@@ -619,7 +619,7 @@ def linear_bwd_f32(x, weight, dy, y_mask, need_dx=True):
     return dx, dw, db
 
 
-LINEAR_FWD_MAX_ROWS = 128      # pv_linear_fwd_bf16: rows of x per call
+LINEAR_FWD_MAX_ROWS = 1024     # pv_linear_fwd_bf16: rows of x per call
 
 
 def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
@@ -628,13 +628,14 @@ def linear_fwd_bf16(x_bf16, w_bf16, bias, relu=False):
     n = w_bf16.shape[0]
     need = c_sz(0)
     lib = get_lib()
-    check(lib.pv_linear_bf16_workspace_bytes(min(m, LINEAR_FWD_MAX_ROWS), n, k, ctypes.byref(need)), "pv_linear_bf16_workspace_bytes")
+    # rows per call: 1024 for the fc1 shapes (the LDS-staged kernel walks them 64 at a time, one stream over the weights each, and
+    # one reduce per call), 128 for the others (the register-tiled kernel's four row tiles)
+    cap = LINEAR_FWD_MAX_ROWS if (32 <= n <= 128 and n % 16 == 0) else 128
+    check(lib.pv_linear_bf16_workspace_bytes(min(m, cap), n, k, ctypes.byref(need)), "pv_linear_bf16_workspace_bytes")
     ws = _workspace("linear_bf16", need.value, x_bf16.device)
     y = torch.empty((m, n), dtype=torch.float32, device=x_bf16.device)
-    # the kernel takes up to 128 rows per call (its x tile lives in LDS); larger batches (bench.py --global-batch 512 on one
-    # GPU: the strong-scaling anchor) go through in row blocks, each one its own stream over the weight
-    for r0 in range(0, m, LINEAR_FWD_MAX_ROWS):
-        rows = min(LINEAR_FWD_MAX_ROWS, m - r0)
+    for r0 in range(0, m, cap):
+        rows = min(cap, m - r0)
         check(lib.pv_linear_fwd_bf16(ptr(x_bf16[r0:r0 + rows]), ptr(w_bf16), ptr(bias), ptr(y[r0:r0 + rows]), rows, n, k, int(relu),
                                      ptr(ws), ws.numel(), current_stream_ptr()), "pv_linear_fwd_bf16")
     return y
@@ -797,9 +798,13 @@ def linear_wgrad_dx_adam_tall_bf16(x_cols, g_all, param, exp_avg, exp_avg_sq, bf
     m, k = x_cols.shape
     n = param.shape[0]
     dx = torch.empty((m, k), dtype=torch.bfloat16, device=g_all.device) if need_dx else None
+    need = ctypes.c_size_t()
+    check(get_lib().pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes(m, ctypes.byref(need)), "pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=g_all.device)      # g_all as operand fragments (40 KB per 32 rows)
     check(get_lib().pv_linear_wgrad_dx_adam_tall_bf16(ptr(x_cols), ptr(g_all), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
                                                       ptr(bf16_shadow), ptr(dx), m, n, k, lr, betas[0], betas[1], eps, step,
-                                                      float(grad_scale), int(bool(gate_dx_by_x)), current_stream_ptr()),
+                                                      float(grad_scale), int(bool(gate_dx_by_x)), ptr(ws), need.value,
+                                                      current_stream_ptr()),
           "pv_linear_wgrad_dx_adam_tall_bf16")
     return dx
 
@@ -859,6 +864,18 @@ def scale_bias_relu_f32(x: torch.Tensor, bias: Optional[torch.Tensor] = None, al
 
 def scale_f32(x: torch.Tensor, alpha: float) -> torch.Tensor:
     return scale_bias_relu_f32(x, None, alpha, False)
+
+
+def swap01_segments(x: torch.Tensor) -> torch.Tensor:
+    """x [n0, n1, seg] contiguous -> [n1, n0, seg] contiguous (pv_swap01_segments; segments of a multiple of 16 bytes): the
+    staging copy of an all-to-all whose chunks are column slices."""
+    require_cuda(x)
+    if x.dim() != 3 or not x.is_contiguous() or (x.shape[2] * x.element_size()) % 16:
+        raise TypeError("swap01_segments: a contiguous [n0, n1, seg] tensor with segments of a multiple of 16 bytes")
+    out = torch.empty((x.shape[1], x.shape[0], x.shape[2]), dtype=x.dtype, device=x.device)
+    check(get_lib().pv_swap01_segments(ptr(x), ptr(out), x.shape[0], x.shape[1], x.shape[2] * x.element_size(), current_stream_ptr()),
+          "pv_swap01_segments")
+    return out
 
 
 def cast_f32_to_bf16(x: torch.Tensor) -> torch.Tensor:

@@ -738,6 +738,35 @@ def test_linear_bf16(device, m, n, k):
     torch.testing.assert_close(xd.grad.float().cpu(), x.grad, rtol=1e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize("m,n,k", [(64, 128, 256 * 9 + 72), (96, 128, 128 * 21), (200, 64, 128 * 7 + 8), (513, 128, 1024), (33, 96, 4096)])
+def test_linear_fwd_bf16_in_row_blocks_of_64(device, m, n, k):
+    """pv_linear_fwd_bf16 with more than 32 rows (a per-GPU batch of 64, the K-sharded fc1's 256 / 512 rows of the global batch):
+    the LDS-staged kernel carries two row blocks beside the weight tile (64 rows per stream over the weights) and one reduce
+    serves every launch of the call; ragged last blocks (96 = 64 + 32, 200 = 3 x 64 + 8, 513) and ragged k tiles.  Against the
+    float64 product of the same bf16 operands, and bit for bit against the same rows taken 32 at a time."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(device)
+    w = (torch.randn(n, k, generator=g) / np.sqrt(k)).to(torch.bfloat16).to(device)
+    bias = torch.randn(n, generator=g).to(device)
+    y = K.linear_fwd_bf16(x, w, bias, relu=True)
+    want = torch.relu(x.double() @ w.double().t() + bias.double())
+    torch.testing.assert_close(y.double(), want, rtol=1e-5, atol=1e-5)
+    y32 = torch.cat([K.linear_fwd_bf16(x[r:r + 32], w, bias, relu=True) for r in range(0, m, 32)])
+    assert torch.equal(y, y32)      # (same split of k over workgroups, same order inside a workgroup and in the reduce)
+
+
+def test_swap01_segments(device):
+    """pv_swap01_segments: [n0][n1][seg] -> [n1][n0][seg], the staging copy of the K-sharded fc1's all-to-alls, against torch."""
+    K, _ = _mods()
+    g = torch.Generator().manual_seed(3)
+    for n0, n1, seg, dt in ((4, 8, 1000, torch.bfloat16), (8, 3, 8, torch.bfloat16), (5, 2, 36, torch.float32), (1, 7, 16, torch.int16)):
+        x = (torch.randn(n0, n1, seg, generator=g) * 100).to(dt).to(device)
+        assert torch.equal(K.swap01_segments(x), x.transpose(0, 1).contiguous())
+    with pytest.raises(TypeError):
+        K.swap01_segments(torch.zeros(2, 2, 3, dtype=torch.bfloat16, device=device))      # 6-byte segments
+
+
 def test_forecast_losses(device):
     K, Fn = _mods()
     g = torch.Generator().manual_seed(9)

@@ -60,11 +60,18 @@ class forced_relu_masks:
             return y
 
         K.conv3d_fwd_bf16, K.conv3d_fwd_bf16_f32in, K.linear_fwd_bf16 = conv_w, first_w, lin_w
+        # the 1-bit masks the forwards write in-kernel would carry the UNFORCED signs: inside this context every dgrad gates by
+        # the (rewritten) bf16 activation instead -- bit-identical gradients by tests/test_gpu_conv.py's mask tests
+        from predict_pv_yield_amd import functional as Fn
+        self._use_masks = Fn.USE_RELU_MASKS
+        Fn.USE_RELU_MASKS = False
         return self
 
     def __exit__(self, *exc):
         for k, v in self._saved.items():
             setattr(K, k, v)
+        from predict_pv_yield_amd import functional as Fn
+        Fn.USE_RELU_MASKS = self._use_masks
         return False
 
 
