@@ -417,11 +417,14 @@ int pv_linear_wgrad_dx_adam_dev_bf16(const uint16_t* x, const float* dy, const f
  * taken in blocks of 32).  The weight gradient of the shard over the whole global batch is scaled by grad_scale (1 / world:
  * the averaging of DDP's all-reduce, experiments/003_...py:292-293) on its way into Adam; dx [m][k] = dy . W_old is not, and is
  * multiplied by (x > 0) when gate_dx_by_x.  No gradient or weight of fc1 crosses a link in this mode.  n <= 128, n % 8 == 0,
- * k % 8 == 0, 16-byte aligned buffers; bf16_shadow and dx may be NULL; workspace: caller-owned scratch (query below). */
+ * k % 8 == 0, 16-byte aligned buffers; bf16_shadow and dx may be NULL; workspace: caller-owned scratch (query below).
+ * moments_tiled: exp_avg / exp_avg_sq in the [k / 128][n][128] tile layout of pv_linear_wgrad_dx_adam_bf16 (k % 128 == 0) -- with
+ * world = 1, grad_scale = 1 and dy = dy (.) relu' this is that call for m > 32 rows (a per-GPU batch of 64, 512). */
 int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
                                       uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
                                       double beta1, double beta2, double eps, int32_t step, float grad_scale,
-                                      int32_t gate_dx_by_x, void* workspace, size_t workspace_bytes, void* stream);
+                                      int32_t gate_dx_by_x, int32_t moments_tiled, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 /* bytes of that call's workspace (dy as matrix-core operand fragments, built once per call): 40 KB per 32 rows */
 int pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes(int32_t m, size_t* bytes);
 

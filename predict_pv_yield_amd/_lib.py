@@ -154,7 +154,7 @@ SIGNATURES = {
     "pv_linear_wgrad_dx_adam_dev_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i32,
                                          c_vp],
     "pv_linear_wgrad_dx_adam_tall_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_f64, c_f64, c_f64, c_f64,
-                                          c_i32, c_f32, c_i32, c_vp, c_sz, c_vp],
+                                          c_i32, c_f32, c_i32, c_i32, c_vp, c_sz, c_vp],
     "pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes": [c_i32, ctypes.POINTER(c_sz)],
     "pv_swap01_segments": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp],
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],

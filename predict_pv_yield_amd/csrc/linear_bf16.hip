@@ -663,7 +663,7 @@ template <int AHEAD>
 __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
     const uint16_t* __restrict__ x, const u32x4* __restrict__ ga, const u32x4* __restrict__ gd, float* __restrict__ w, int m, int n,
     long long k, float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq, uint16_t* __restrict__ shadow,
-    uint16_t* __restrict__ dx, AdamScalars ad, int gate_dx, float grad_scale) {
+    uint16_t* __restrict__ dx, AdamScalars ad, int gate_dx, float grad_scale, int mv_tiled) {
   __shared__ __attribute__((aligned(16))) u32x4 gfr[TL_GD];                 // the dx walk's A fragments of a block (16 KB)
   __shared__ __attribute__((aligned(16))) uint16_t wt[FD_KT * FD_WLD];      // pre-update weights, bf16, [k][n]
   __shared__ __attribute__((aligned(16))) uint16_t dxs[32 * FD_XLD];        // the outgoing dx block [b][k]
@@ -676,16 +676,20 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
   const long long k8 = k0 + 8 * kq;
   const bool k_ok = k8 < k;
   f32x4 nxt[AHEAD][6];
+  // mv_tiled: the moments in the [k / 128][n][128] tile layout of the single-GPU one-pass kernel (the same optimiser state serves
+  // both kernels: per-GPU batches beyond 32 rows take this one)
+  const size_t mv_tile_base = (size_t)blockIdx.x * (size_t)n * FD_KT + 8 * kq;
   auto fetch = [&](int i) {
     const int r = min(8 * rg + i, n - 1);
     const size_t off = (size_t)r * k + (k_ok ? k8 : 0);
+    const size_t moff = mv_tiled ? mv_tile_base + (size_t)r * FD_KT : off;
     f32x4 (&d)[6] = nxt[i % AHEAD];
     d[0] = *reinterpret_cast<const f32x4*>(w + off);
     d[1] = *reinterpret_cast<const f32x4*>(w + off + 4);
-    d[2] = *reinterpret_cast<const f32x4*>(exp_avg + off);
-    d[3] = *reinterpret_cast<const f32x4*>(exp_avg + off + 4);
-    d[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off);
-    d[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + off + 4);
+    d[2] = *reinterpret_cast<const f32x4*>(exp_avg + moff);
+    d[3] = *reinterpret_cast<const f32x4*>(exp_avg + moff + 4);
+    d[4] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff);
+    d[5] = *reinterpret_cast<const f32x4*>(exp_avg_sq + moff + 4);
   };
 #pragma unroll
   for (int i = 0; i < AHEAD; ++i) fetch(i);
@@ -804,10 +808,11 @@ __global__ __launch_bounds__(256, 2) void linear_bwd_dw_dx_adam_tall_kernel(
       }
       *reinterpret_cast<f32x4*>(w + off) = *reinterpret_cast<const f32x4*>(pv);
       *reinterpret_cast<f32x4*>(w + off + 4) = *reinterpret_cast<const f32x4*>(pv + 4);
-      *reinterpret_cast<f32x4*>(exp_avg + off) = *reinterpret_cast<const f32x4*>(mv);
-      *reinterpret_cast<f32x4*>(exp_avg + off + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
-      *reinterpret_cast<f32x4*>(exp_avg_sq + off) = *reinterpret_cast<const f32x4*>(vv);
-      *reinterpret_cast<f32x4*>(exp_avg_sq + off + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
+      const size_t moff = mv_tiled ? mv_tile_base + (size_t)(8 * rg + i) * FD_KT : off;
+      *reinterpret_cast<f32x4*>(exp_avg + moff) = *reinterpret_cast<const f32x4*>(mv);
+      *reinterpret_cast<f32x4*>(exp_avg + moff + 4) = *reinterpret_cast<const f32x4*>(mv + 4);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + moff) = *reinterpret_cast<const f32x4*>(vv);
+      *reinterpret_cast<f32x4*>(exp_avg_sq + moff + 4) = *reinterpret_cast<const f32x4*>(vv + 4);
       if (shadow) {
         u32x4 so = {sh[0], sh[1], sh[2], sh[3]};
         *reinterpret_cast<u32x4*>(shadow + off) = so;
@@ -1518,8 +1523,10 @@ int pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes(int32_t m, size_t* bytes) 
 int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float* param, float* exp_avg, float* exp_avg_sq,
                                       uint16_t* bf16_shadow, uint16_t* dx, int32_t m, int32_t n, int64_t k, double lr,
                                       double beta1, double beta2, double eps, int32_t step, float grad_scale,
-                                      int32_t gate_dx_by_x, void* workspace, size_t workspace_bytes, void* stream) {
+                                      int32_t gate_dx_by_x, int32_t moments_tiled, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
   PV_REQUIRE(x && dy && param && exp_avg && exp_avg_sq && workspace, PV_EINVAL, "pv_linear_wgrad_dx_adam_tall_bf16: null pointer");
+  PV_REQUIRE(!moments_tiled || k % FD_KT == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_tall_bf16: tiled moments need k %% 128 == 0");
   PV_REQUIRE(m > 0 && n > 0 && n <= 128 && n % 8 == 0, PV_ESIZE,
              "pv_linear_wgrad_dx_adam_tall_bf16: n <= 128 (multiple of 8) outputs, got m=%d n=%d", m, n);
   PV_REQUIRE(k > 0 && k % 8 == 0, PV_ESIZE, "pv_linear_wgrad_dx_adam_tall_bf16: k must be a multiple of 8");
@@ -1539,7 +1546,7 @@ int pv_linear_wgrad_dx_adam_tall_bf16(const uint16_t* x, const float* dy, float*
                      m, n, ga, gd, nblk);
   const unsigned grid = (unsigned)((k + FD_KT - 1) / FD_KT);
   hipLaunchKernelGGL((linear_bwd_dw_dx_adam_tall_kernel<2>), dim3(grid), dim3(256), 0, as_stream(stream), x, ga, gd, param, m, n,
-                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, ad, gate_dx_by_x, grad_scale);
+                     (long long)k, exp_avg, exp_avg_sq, bf16_shadow, dx, ad, gate_dx_by_x, grad_scale, moments_tiled ? 1 : 0);
   return check_launch("pv_linear_wgrad_dx_adam_tall_bf16");
 }
 

@@ -791,7 +791,7 @@ def linear_wgrad_dx_adam_dev_bf16(x_bf16, dy, y_mask, param, exp_avg, exp_avg_sq
 
 
 def linear_wgrad_dx_adam_tall_bf16(x_cols, g_all, param, exp_avg, exp_avg_sq, bf16_shadow, step: int, lr=5e-4, betas=(0.9, 0.999),
-                                   eps=1e-8, grad_scale=1.0, need_dx=True, gate_dx_by_x=False):
+                                   eps=1e-8, grad_scale=1.0, need_dx=True, gate_dx_by_x=False, moments_tiled=False):
     """K-sharded fc1 (pv_linear_wgrad_dx_adam_tall_bf16): this rank's column shard updated by Adam from the gradient over ALL
     rows of the global batch (x_cols [M, K/W] bf16, g_all [M, N] f32, already gated), and dx_cols = g_all . W_old in the same pass."""
     require_cuda(x_cols, g_all, param, exp_avg, exp_avg_sq, bf16_shadow)
@@ -803,8 +803,8 @@ def linear_wgrad_dx_adam_tall_bf16(x_cols, g_all, param, exp_avg, exp_avg_sq, bf
     ws = torch.empty(need.value, dtype=torch.uint8, device=g_all.device)      # g_all as operand fragments (40 KB per 32 rows)
     check(get_lib().pv_linear_wgrad_dx_adam_tall_bf16(ptr(x_cols), ptr(g_all), ptr(param), ptr(exp_avg), ptr(exp_avg_sq),
                                                       ptr(bf16_shadow), ptr(dx), m, n, k, lr, betas[0], betas[1], eps, step,
-                                                      float(grad_scale), int(bool(gate_dx_by_x)), ptr(ws), need.value,
-                                                      current_stream_ptr()),
+                                                      float(grad_scale), int(bool(gate_dx_by_x)), int(bool(moments_tiled)), ptr(ws),
+                                                      need.value, current_stream_ptr()),
           "pv_linear_wgrad_dx_adam_tall_bf16")
     return dx
 
@@ -829,8 +829,10 @@ def moments_to_rows(t: torch.Tensor) -> torch.Tensor:
     return t.view(k // MOMENT_TILE, n, MOMENT_TILE).permute(1, 0, 2).contiguous().view(n, k)
 
 
-def fused_dx_update_supported(m: int, n: int, k: int) -> bool:
-    return m <= 32 and n <= 128 and n % 8 == 0 and k % 8 == 0
+def fused_dx_update_supported(m: int, n: int, k: int, capturable: bool = False) -> bool:
+    """m <= 32: pv_linear_wgrad_dx_adam_bf16 (or its device-scalar twin under a captured graph); more rows: the row-block form
+    pv_linear_wgrad_dx_adam_tall_bf16 (host scalars only)."""
+    return (m <= 32 or (m <= 4096 and not capturable)) and n <= 128 and n % 8 == 0 and k % 8 == 0
 
 
 def linear_wgrad_bf16out(x_bf16, dy, y_mask, n: int) -> torch.Tensor:

@@ -382,7 +382,8 @@ class HipAdam(torch.optim.Optimizer):
             """(dx, db) of the layer, with the Adam update of p applied in the same pass; None if the shape is not covered
             (the caller then takes the two-kernel path) or the switch is off."""
             from .functional import bf16_shadow_of
-            if not FUSE_DX_INTO_UPDATE or not need_dx or not K.fused_dx_update_supported(x.shape[0], p.shape[0], p.shape[1]):
+            if not FUSE_DX_INTO_UPDATE or not need_dx or not K.fused_dx_update_supported(x.shape[0], p.shape[0], p.shape[1],
+                                                                                         self.capturable):
                 return None
             if p._pv_applied:
                 raise RuntimeError("HipAdam: backward() ran twice without optimizer.step() in between; the fused fc1 pass has "
@@ -394,7 +395,17 @@ class HipAdam(torch.optim.Optimizer):
                 st = self._init_state(p)
                 tiled = self._moments_tiled(p)
                 st["step"] += 1
-                if self.capturable:
+                if x.shape[0] > 32:
+                    # more than 32 rows (a per-GPU batch of 64, the one-GPU form of a global batch of 512): the row-block form of the
+                    # same pass -- the gated output gradient as operand fragments, gradient tile on the matrix cores
+                    g = K.relu_gate_f32(dy, y) if y is not None else dy
+                    db = K.colsum(g) if need_db else None
+                    dx = K.linear_wgrad_dx_adam_tall_bf16(x, g, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
+                                                          int(st["step"].item()), lr=group["lr"], betas=group["betas"],
+                                                          eps=group["eps"], grad_scale=1.0, need_dx=True, gate_dx_by_x=gate_dx,
+                                                          moments_tiled=tiled)
+                    out = (dx, db) if need_db else dx
+                elif self.capturable:
                     out = K.linear_wgrad_dx_adam_dev_bf16(x, dy, y, p, st["exp_avg"], st["exp_avg_sq"], bf16_shadow_of(p),
                                                           self._advance_device_scalars(p.device), need_db=need_db,
                                                           gate_dx_by_x=gate_dx, moments_tiled=tiled)

@@ -200,6 +200,53 @@ def test_bf16_adam_steps_with_the_fused_fc1_kernel(device, emulate):
         _check(f"emulate={emulate} step3 exp_avg {k} rel", _rel(opt.moments(p)[0].cpu(), rst["exp_avg"]), tol)
 
 
+def test_fused_fc1_backward_takes_more_than_32_rows_through_the_row_block_kernel(device, monkeypatch):
+    """A per-GPU batch beyond 32 rows (bench.py's B = 64 sweep point, the one-GPU form of a global batch of 512): the single-process
+    fused mode runs fc1's whole backward as pv_linear_wgrad_dx_adam_tall_bf16 on the full matrix (moments in the one-pass kernel's
+    tile layout) instead of dx launches per 32 rows + the register-tiled weight gradient inside step().  Two steps at B = 40
+    against the same model on the two-kernel path (optim.FUSE_DX_INTO_UPDATE off): same losses, fc1's weight / moments / operand
+    copy to the order-of-summation tolerance of the kernel test; then a step at B = 8 on the SAME optimiser state (the m <= 32
+    kernel reads the tiled moments the row-block kernel wrote)."""
+    from predict_pv_yield_amd import optim as O
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd.functional import bf16_shadow_of
+    sat, pv = _data(40, seed=11)
+    batch = _batch(sat, pv, device)
+    small = _batch(sat[:8], pv[:8], device)
+    calls = []
+    real = K.linear_wgrad_dx_adam_tall_bf16
+    monkeypatch.setattr(K, "linear_wgrad_dx_adam_tall_bf16", lambda *a, **kw: (calls.append(a[0].shape[0]), real(*a, **kw))[1])
+    runs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(O, "FUSE_DX_INTO_UPDATE", fused)
+        _, model = _pair("bf16", device)
+        model.batch_size = 40
+        opt = model.configure_optimizers()
+        losses = []
+        for b in (batch, batch, small):
+            opt.zero_grad()
+            loss = model.training_step(b, 0)
+            loss.backward()
+            if fused:
+                assert model.fc1.weight._pv_applied and model.fc1.weight.grad is None
+            opt.step()
+            losses.append(float(loss))
+        m1, v1 = opt.moments(model.fc1.weight)
+        runs[fused] = (losses, model.fc1.weight.detach().clone(), m1.clone(), v1.clone(), bf16_shadow_of(model.fc1.weight).clone(),
+                       model.sat_conv0.weight.detach().clone() if hasattr(model, "sat_conv0") else None)
+    assert calls == [40, 40], calls                      # the row-block kernel ran for the 40-row steps only
+    (la, wa, ma, va, sa, ca), (lb, wb, mb, vb, sb, cb) = runs[True], runs[False]
+    np.testing.assert_allclose(la, lb, rtol=1e-5)
+    # (from the second step on the two runs' conv weights differ by what two tilings of the bf16 hi + lo dx products differ, so
+    # fc1's gradients agree to ~1e-3, and a weight whose gradient is noise may step the other way: norms, not elements)
+    _check("row-block fused fc1: exp_avg rel", _rel(ma, mb), 5e-3)
+    _check("row-block fused fc1: exp_avg_sq rel", _rel(va, vb), 1e-2)
+    _check("row-block fused fc1: mean |weight difference| / lr", float((wa - wb).abs().mean()) / 5e-4, 0.05)
+    _check("row-block fused fc1: operand copy, share of differing elements", float((sa.float() != sb.float()).float().mean()), 0.15)      # (|dw| ~ 0.1 bf16 ulp of a weight)
+    if ca is not None:
+        _check("row-block fused fc1: first conv layer's weights rel", _rel(ca, cb), 1e-3)
+
+
 @pytest.mark.parametrize("exact", [False, True])
 def test_fp32_path_at_headline_size(device, monkeypatch, exact):
     """precision="fp32" on the reference layout, rtol 1e-4 against torch CPU -- in its default form (weight gradients and fc1 as split
