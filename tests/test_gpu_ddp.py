@@ -162,8 +162,8 @@ def test_eight_ranks_on_one_gpu_sharded_equals_allreduce_and_follows_one_process
 def test_bench_global_batch_path_with_eight_ranks_on_one_gpu(device, tmp_path):
     """bench.py --gpus 8 --global-batch 64 as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in
     the environment), on the one GPU of the test box with gloo: the strong-scaling branch (shard_range of the global batch,
-    negotiate_grad_sync, the sharded exchange of the full 128 M-parameter fc1, max-over-ranks timing) runs to its JSON
-    line before an 8-GPU node ever sees it."""
+    negotiate_grad_sync, the default exchange -- K-sharded since round 6 -- of the full 128 M-parameter fc1, max-over-ranks
+    timing) runs to its JSON line before an 8-GPU node ever sees it."""
     import json
     port = _free_port()
     root = os.path.dirname(HERE)
@@ -182,7 +182,7 @@ def test_bench_global_batch_path_with_eight_ranks_on_one_gpu(device, tmp_path):
     assert len(json_lines(outs[0][0])) == 1
     line = json.loads(json_lines(outs[0][0])[0])
     assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["global_batch"] == 64
-    assert line["config"]["per_gpu_batch"] == 8 and "dp8 (sharded)" in line["config"]["parallelism"]
+    assert line["config"]["per_gpu_batch"] == 8 and "dp8 (ksharded)" in line["config"]["parallelism"]
     assert line["value"] > 0 and line["train_nmae_last_step"] == line["train_nmae_last_step"]      # finite
     assert all(not json_lines(o) for o, _ in outs[1:]), "only rank 0 prints the line"
 
@@ -203,7 +203,7 @@ def test_bench_refuses_a_demoted_exchange_unless_allowed(device):
                        MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900",
                        PV_DIST_FAIL_MODES="sharded")
             procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "2",
-                                           "--warmup", "1", "--no-roofline", "--no-cpu-baseline"] + extra, env=env,
+                                           "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--grad-sync", "sharded"] + extra, env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
         outs = [p.communicate(timeout=1200) for p in procs]
         return procs, outs
@@ -291,8 +291,9 @@ def test_ksharded_rccl_branches_on_one_rank(device, tmp_path):
 
 def test_bench_times_every_exchange_mode_in_one_invocation(device):
     """bench.py --gpus N (N > 1) times the requested exchange of fc1 AND the others in the same invocation --
-    two gloo ranks on the one GPU here, the full 128 M-parameter fc1: the line's `value` is the requested (row-sharded) mode's,
-    `grad_sync_modes` carries K-sharded, bf16 all-reduce and f32 all-reduce with their own ms_per_step, collectives and bytes."""
+    two gloo ranks on the one GPU here, the full 128 M-parameter fc1, default flags (--grad-sync auto: K-sharded first): the
+    line's `value` is the mode in force's and says so, `grad_sync_modes` carries the row-sharded form, the bf16 all-reduce and the
+    f32 all-reduce with their own ms_per_step, collectives and bytes."""
     import json
     root = os.path.dirname(HERE)
     port = _free_port()
@@ -311,8 +312,11 @@ def test_bench_times_every_exchange_mode_in_one_invocation(device):
     line = json.loads(lines[0])
     modes = line["grad_sync_modes"]
     assert set(modes) == {"sharded", "ksharded", "bf16", "autograd"}, modes
-    assert "requested" in modes["sharded"]["status"] and modes["sharded"]["value"] == line["value"]
-    for m in ("ksharded", "bf16", "autograd"):
+    assert "requested" in modes["ksharded"]["status"] and modes["ksharded"]["value"] == line["value"]
+    assert "dp2 (ksharded)" in line["config"]["parallelism"]
+    c = line["config"]["collectives"]
+    assert c["requested_mode"].startswith("auto") and c["mode_in_force"] == "ksharded"
+    for m in ("sharded", "bf16", "autograd"):
         assert modes[m]["status"] == "ok" and modes[m]["value"] > 0 and modes[m]["collectives"]["mode_in_force"] == m, (m, modes[m])
     k = 128 * 1003520
     assert modes["sharded"]["exchange_bytes_per_rank_and_step"]["reduce_scatter_gradient_bf16"] == k        # (W - 1) / W of 2 bytes each
@@ -341,8 +345,8 @@ def test_bench_keeps_the_requested_modes_line_when_another_mode_hangs(device):
     assert len(lines) == 1 and not [ln for ln in outs[1][0].decode().splitlines() if '"metric"' in ln]
     line = json.loads(lines[0])
     modes = line["grad_sync_modes"]
-    assert line["value"] > 0 and "requested" in modes["sharded"]["status"] and modes["sharded"]["value"] == line["value"]
-    assert modes["ksharded"]["status"] == "ok", modes           # timed before the hang
+    assert line["value"] > 0 and "requested" in modes["ksharded"]["status"] and modes["ksharded"]["value"] == line["value"]
+    assert modes["sharded"]["status"] == "ok", modes            # timed before the hang
     assert "no answer within" in modes["bf16"]["status"] and "autograd" not in modes, modes
 
 
