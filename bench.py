@@ -1378,6 +1378,10 @@ def main():
                         k8["ceiling_over_one_gpu"] = round(k8["aggregate_samples_per_s_if_exchange_hides"] / sb["samples_per_s"], 2)
                     out["weak_b32_one_rank_of_8_ksharded"] = measure_ksharded_rank_compute(dev, args.history_minutes, per_gpu_batch=b)
                     if out["roofline"] is not None:
+                        out["roofline"]["batch64_samples_per_s"] = out["batch_sweep"].get("B=64", {}).get("samples_per_s")
+                        out["roofline"]["one_rank_of_8_ms_at_64_per_gpu_sharded"] = r8.get("ms_per_step")
+                        out["roofline"]["one_rank_of_8_ms_at_64_per_gpu_ksharded"] = k8.get("ms_per_step")
+                        out["roofline"]["one_rank_of_8_ms_at_32_per_gpu_ksharded"] = out["weak_b32_one_rank_of_8_ksharded"].get("ms_per_step")
                         out["roofline"]["strong_b512_samples_per_s"] = sb["samples_per_s"]
                         out["roofline"]["strong_8gpu_ceiling_over_one_gpu"] = r8.get("ceiling_over_one_gpu")
                         out["roofline"]["strong_8gpu_ceiling_over_one_gpu_ksharded"] = k8.get("ceiling_over_one_gpu")
