@@ -383,6 +383,40 @@ def measure_config3(dev, b, history_minutes):
     return out
 
 
+def measure_engine_clocks(dev, b=32):
+    """The engine clock the device really holds under the step's kernel families (hip_ops.engine_clock_under: a one-wave watcher of
+    the shader-cycle counter against the 100 MHz counter).  The spec peak (2.5 PFLOP/s) is a 2.4 GHz figure; under the conv kernels'
+    matrix + LDS + HBM load the power management holds ~1.7-1.8 GHz, under the bare matrix-instruction loop ~2.15, under a copy 2.4."""
+    from predict_pv_yield_amd import hip_ops as K
+    from predict_pv_yield_amd._lib import check, current_stream_ptr, get_lib, ptr
+    g = torch.Generator(device=dev).manual_seed(1)
+    lib = get_lib()
+    out = {"what": "median engine clock (MHz) while one kind of kernel loops for 20 ms; idle device and plain copy: 2 400"}
+    sink = torch.zeros(4096, device=dev)
+    out["bare_mfma_loop"] = K.engine_clock_under(lambda: check(lib.pv_calibrate_mfma_bf16(ptr(sink), 512, 2000, current_stream_ptr())))
+    w = torch.randn(32, 32, 3, 3, 3, device=dev, generator=g) * 0.05
+    x = torch.randn(b, 16, 62, 62, 32, device=dev, generator=g).relu().to(torch.bfloat16)
+    dy = torch.randn(b, 14, 60, 60, 32, device=dev, generator=g).to(torch.bfloat16)
+    wp = K.conv3d_pack_weight_bf16(w, transpose_flip=False)
+    bias = torch.zeros(32, device=dev)
+    out["conv_forward_32_to_32"] = K.engine_clock_under(lambda: K.conv3d_fwd_bf16(x, None, wp, bias, 32, 32, (0, 0, 0), True, False))
+    out["conv_weight_gradient"] = K.engine_clock_under(lambda: K.conv3d_bwd_weight_bf16(x, dy, None, 32, 32, (0, 0, 0)))
+    del x, dy
+    k = 1003520
+    xf = torch.randn(b, k, device=dev, generator=g).relu().to(torch.bfloat16)
+    wf = torch.randn(128, k, device=dev, generator=g) * 0.01
+    m1, v1 = torch.zeros_like(wf), torch.zeros_like(wf)
+    sh = K.cast_f32_to_bf16(wf)
+    gy, yy = torch.randn(b, 128, device=dev, generator=g) * 1e-3, torch.rand(b, 128, device=dev, generator=g)
+    st = [0]
+
+    def fc1():
+        st[0] += 1
+        K.linear_wgrad_dx_adam_bf16(xf, gy, yy, wf, m1, v1, sh, st[0], need_dx=True, need_db=False, gate_dx_by_x=True)
+    out["fc1_one_pass_backward"] = K.engine_clock_under(fc1)
+    return out
+
+
 def measure_graph_step(dev, b, history_minutes, steps=20):
     """The same train step captured ONCE as a HIP graph (graphs.GraphedTrainStep: forward + NMAE + backward + HipAdam with
     its step counter and bias corrections in device memory) and replayed: what is left when no Python, autograd or launch
@@ -1349,6 +1383,21 @@ def main():
                 out["roofline"] = None
             del model, opt, batch
             settle()
+            if args.precision == "bf16" and out["roofline"] is not None:
+                # the clock the conv kernels really run at (a wave's own counters; sysfs above averages over ~10 ms), and the conv
+                # fraction against the matrix peak AT THAT CLOCK: the 2.5 PFLOP/s of the guide is a 2.4 GHz figure
+                try:
+                    ec = out["engine_clock_under_kernels"] = measure_engine_clocks(dev, b)
+                    r = out["roofline"]
+                    conv_mhz = [ec[k]["median_MHz"] for k in ("conv_forward_32_to_32", "conv_weight_gradient") if "median_MHz" in ec.get(k, {})]
+                    if conv_mhz:
+                        r["sclk_MHz_under_conv_kernels"] = round(sum(conv_mhz) / len(conv_mhz))
+                        r["sclk_MHz_under_bare_mfma_loop"] = ec["bare_mfma_loop"].get("median_MHz")
+                        r["sclk_MHz_under_fc1_pass"] = ec["fc1_one_pass_backward"].get("median_MHz")
+                        r["all_conv_frac_at_running_clock"] = round(r["all_conv_frac"] * 2400.0 / r["sclk_MHz_under_conv_kernels"], 4)
+                except Exception as e:      # noqa: BLE001 -- a diagnostic must not cost the line
+                    out["engine_clock_under_kernels"] = {"error": f"{type(e).__name__}: {e}"}
+                settle()
             if not args.no_extras:
                 out["config3"] = measure_config3(dev, b, args.history_minutes)
                 settle()

@@ -663,6 +663,11 @@ int pv_stage_timing_end(const char** names, float* ms, int32_t* counts, int32_t 
 int pv_calibrate_copy_f32(const float* src, float* dst, size_t n, void* stream);
 int pv_calibrate_mfma_bf16(float* sink, int32_t workgroups, int32_t iters, void* stream);
 
+/* (measurement) One wave that writes n_samples pairs (shader-cycle counter, 100 MHz counter) into samples[2 * n_samples],
+ * sleeping ~sleep_units x 64 cycles between two pairs: launched on a side stream before the kernels of interest, the ratio of the
+ * two counters' increments is the engine clock those kernels ran at. */
+int pv_clock_watch(unsigned long long* samples, int32_t n_samples, int32_t sleep_units, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

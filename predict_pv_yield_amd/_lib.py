@@ -157,6 +157,7 @@ SIGNATURES = {
                                           c_i32, c_f32, c_i32, c_i32, c_vp, c_sz, c_vp],
     "pv_linear_wgrad_dx_adam_tall_bf16_workspace_bytes": [c_i32, ctypes.POINTER(c_sz)],
     "pv_swap01_segments": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp],
+    "pv_clock_watch": [c_vp, c_i32, c_i32, c_vp],
     "pv_conv3d_pack_weights_multi_bf16": [ctypes.POINTER(PackJob), c_i32, c_vp],
     "pv_gemm_f32": [c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],
     "pv_gemm_res_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, ctypes.POINTER(GemmDesc), c_int, c_vp],

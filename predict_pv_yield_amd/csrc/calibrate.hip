@@ -51,9 +51,31 @@ __global__ __launch_bounds__(256) void calibrate_mfma_bf16_kernel(float* __restr
   if (lane == 0 && s[0] == 12345.678f) sink[blockIdx.x] = s[0] + s[1] + s[2] + s[3];      // (keeps the loop alive)
 }
 
+// A one-wave watcher of the engine clock (round 6): it samples the shader-cycle counter (s_memtime) and the constant 100 MHz
+// counter (s_memrealtime) every ~sleep_units x 64 cycles and writes both; launched on a side stream BEFORE the kernels of
+// interest it stays resident beside them (12 registers, no LDS: it fits beside two 246-register waves on a SIMD), and the ratio
+// of the two counters' increments is the clock those kernels really ran at -- sysfs averages over 10 ms and reads 2.17 GHz
+// where the conv kernels' own wave-cycle counters imply ~1.6.
+__global__ __launch_bounds__(64) void clock_watch_kernel(unsigned long long* __restrict__ out, int n_samples, int sleep_units) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < n_samples; ++i) {
+    unsigned long long t, r;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "=s"(r)::"memory");
+    out[2 * i] = t;
+    out[2 * i + 1] = r;
+    for (int k = 0; k < sleep_units; ++k) __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 }  // namespace pv
 
 extern "C" {
+
+int pv_clock_watch(unsigned long long* samples, int32_t n_samples, int32_t sleep_units, void* stream) {
+  PV_REQUIRE(samples && n_samples > 0 && sleep_units >= 0, PV_EINVAL, "pv_clock_watch: bad arguments");
+  hipLaunchKernelGGL(pv::clock_watch_kernel, dim3(1), dim3(64), 0, pv::as_stream(stream), samples, n_samples, sleep_units);
+  return pv::check_launch("pv_clock_watch");
+}
 
 int pv_calibrate_copy_f32(const float* src, float* dst, size_t n, void* stream) {
   PV_REQUIRE(src && dst, PV_EINVAL, "pv_calibrate_copy_f32: null pointer");

@@ -868,6 +868,42 @@ def scale_f32(x: torch.Tensor, alpha: float) -> torch.Tensor:
     return scale_bias_relu_f32(x, None, alpha, False)
 
 
+def clock_watch_launch(n_samples: int, sleep_units: int, stream) -> torch.Tensor:
+    """Starts the one-wave clock watcher on `stream` (a torch.cuda.Stream other than the one the kernels of interest run on) and
+    returns its sample buffer int64 [n_samples, 2] = (shader cycles, 100 MHz ticks); read it after stream.synchronize()."""
+    buf = torch.zeros((n_samples, 2), dtype=torch.int64, device="cuda")
+    check(get_lib().pv_clock_watch(ptr(buf), n_samples, sleep_units, ctypes.c_void_p(stream.cuda_stream)), "pv_clock_watch")
+    return buf
+
+
+def engine_clock_under(fn, seconds: float = 0.02) -> dict:
+    """The engine clock (MHz) the device holds while `fn` (something that launches kernels on the current stream) loops for
+    `seconds`: the one-wave watcher on a side stream, samples taken well inside the loop.  sysfs reads a ~10 ms average and cannot
+    see a 70 us kernel; the conv kernels run at ~1.7-1.8 GHz where the idle device and a plain copy read 2.4."""
+    import time
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    n = int((seconds + 0.012) * 1e6 / 1.1) + 1000
+    buf = clock_watch_launch(n, 40, side)
+    time.sleep(0.002)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+    torch.cuda.synchronize()
+    s = buf.cpu().numpy().astype(np.float64)
+    s = s[s[:, 1] > 0]
+    t_us = (s[:, 1] - s[0, 1]) / 100.0
+    dt, dr = np.diff(s[:, 0]), np.diff(s[:, 1])
+    ok = (dr > 0) & (t_us[1:] > 6000) & (t_us[1:] < 2000 + seconds * 1e6 - 3000)
+    mhz = dt[ok] / dr[ok] * 100.0
+    if len(mhz) < 50:
+        return {"samples": int(len(mhz))}
+    return {"median_MHz": round(float(np.median(mhz))), "p10_MHz": round(float(np.percentile(mhz, 10))),
+            "p90_MHz": round(float(np.percentile(mhz, 90))), "samples": int(len(mhz))}
+
+
 def swap01_segments(x: torch.Tensor) -> torch.Tensor:
     """x [n0, n1, seg] contiguous -> [n1, n0, seg] contiguous (pv_swap01_segments; segments of a multiple of 16 bytes): the
     staging copy of an all-to-all whose chunks are column slices."""
