@@ -91,3 +91,9 @@ def fc1():
 
 
 watch(fc1, "fc1 backward in one pass (HBM-bound)", nbytes=128 * k * 26 + 2 * b * k * 2)
+# the advection pipeline (config 3, SURVEY section-8(d) input): 55 % of it is the level-0 iteration kernel
+del xf, wf, m1, v1, sh
+from predict_pv_yield_amd import optical_flow as of
+from predict_pv_yield_amd.data.synthetic import advected_counts
+raw = torch.from_numpy(advected_counts(batch=b, seed=1234)[0]).to(dev)
+watch(lambda: of.advect_future_frames(raw, 6), "advection pipeline (121 Farneback pairs / sample)")
