@@ -1266,6 +1266,7 @@ def main():
     # decides between exchanges instead of testing one).  Every rank walks the same list; a mode whose trial step fails, or that
     # the optimiser replaces by a simpler one, is recorded as such and skipped -- `value` above stays the requested mode's.
     other_modes = {}
+    distributed_roofline = {}
     headline = None
     if rank == 0:      # the requested mode's own result: everything below adds to it, nothing below may lose it
         value = world * b * args.steps / elapsed
@@ -1303,7 +1304,7 @@ def main():
             if rank == 0:
                 other_modes.setdefault(current["mode"] or "?", {"status": f"no answer within {args.other_modes_budget:.0f} s: leg abandoned"})
                 line = dict(headline, grad_sync_modes=modes_record(), train_nmae_first_step=first, train_nmae_last_step=last,
-                            roofline=None, cpu_baseline=None)
+                            roofline=distributed_roofline or None, cpu_baseline=None)
                 print(json.dumps(line), flush=True)
             else:
                 time.sleep(2.0)      # (rank 0 prints first)
@@ -1311,6 +1312,26 @@ def main():
         watchdog = threading.Timer(args.other_modes_budget, leg_expired)
         watchdog.daemon = True
         watchdog.start()
+
+        # the roofline object of the line under N > 1 (mode in force, before the other modes are tried): rank 0 brackets its
+        # launches with HIP events over six more steps while every rank takes the same six.  fc1's pass is a 1 / N shard here:
+        # the step's dominant family is the 32 -> 32 conv forward / dgrad kernels, priced against the matrix peak
+        if args.precision == "bf16" and not args.no_roofline:
+            current["mode"] = "roofline leg of the mode in force"
+            if rank == 0:
+                try:
+                    roof = measure_step_rooflines(step, model, b, t_frames)
+                    if "bound" not in roof and "mfma_conv3d" in roof:
+                        fam = roof.pop("mfma_conv3d")
+                        roof = dict(fam, **roof)
+                    distributed_roofline.update(roof)
+                except Exception as e:      # noqa: BLE001 -- (a failure between two steps leaves the ranks out of step: the timer ends the leg)
+                    distributed_roofline.update({"error": f"{type(e).__name__}: {e}"})
+                    watchdog.join()
+            else:
+                for _ in range(6):
+                    step()
+            torch.distributed.barrier()
 
         def timed_steps(n):
             torch.distributed.barrier()
@@ -1441,7 +1462,7 @@ def main():
                 out["other_models"] = measure_other_models(dev)
                 settle()
         else:
-            out["roofline"] = None
+            out["roofline"] = distributed_roofline or None
         if not args.no_cpu_baseline and world == 1:
             out["val_nmae"], out["cpu_baseline"] = matched_validation_and_cpu_baseline(dev, args.history_minutes)
             if out.get("roofline"):      # scalars the driver's record keeps

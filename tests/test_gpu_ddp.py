@@ -302,7 +302,7 @@ def test_bench_times_every_exchange_mode_in_one_invocation(device):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PV_DIST_BACKEND="gloo", PV_SINGLE_DEVICE="1", PV_DIST_TIMEOUT_S="900")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "4", "--steps", "1",
-                                       "--warmup", "1", "--no-roofline", "--no-cpu-baseline"], env=env,
+                                       "--warmup", "1", "--no-cpu-baseline"], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=root))
     outs = [p.communicate(timeout=1500) for p in procs]
     for p, (o, e) in zip(procs, outs):
@@ -318,6 +318,11 @@ def test_bench_times_every_exchange_mode_in_one_invocation(device):
     assert c["requested_mode"].startswith("auto") and c["mode_in_force"] == "ksharded"
     for m in ("sharded", "bf16", "autograd"):
         assert modes[m]["status"] == "ok" and modes[m]["value"] > 0 and modes[m]["collectives"]["mode_in_force"] == m, (m, modes[m])
+    # the line's roofline object under N > 1: the conv forward / dgrad family of the mode in force, bracketed on rank 0 while both
+    # ranks took the same six extra steps
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and r["launches_per_step"] == 6, r
+    assert "all_conv_frac" in r and line["cpu_baseline"] is None
     k = 128 * 1003520
     assert modes["sharded"]["exchange_bytes_per_rank_and_step"]["reduce_scatter_gradient_bf16"] == k        # (W - 1) / W of 2 bytes each
     assert modes["ksharded"]["exchange_bytes_per_rank_and_step"]["all_to_all_activations_bf16"] == 4 * 1003520
