@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) void gate_bf16_by_relu_kernel(uint16_t* __rest
 // so the 16 rows an MFMA operand read touches fall into 16 different bank slots; the rotation is applied to the SOURCE
 // chunk each lane fetches, the LDS side of the instruction being linear by lane.
 // ---------------------------------------------------------------------------------------------
-constexpr int V3_KC = 128, V3_STAGES = 3;
+constexpr int V3_KC = 128;
 
 // MB: row blocks of 32 x rows a tile carries beside the 128 weight rows (round 6: two -- 64 rows per stream over the weights, 144 KB
 // of ring -- for calls with more than 32 rows: a per-GPU batch of 64, the K-sharded fc1's 256 / 512 rows)
@@ -1215,7 +1215,9 @@ template <int MB>
 __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                                   float* __restrict__ partial, int m, int n, long long k,
                                                                   int n_tiles, int tiles_per_wg) {
-  constexpr int V3_ROWS = 128 + 32 * MB, V3_TILEB = V3_ROWS * 256, LOADS = V3_ROWS / 16;
+  // MB = 4 (128 rows per stream over the weights: the K-sharded fc1's 256 / 512 rows): 64 KB per tile, TWO stages (one tile in
+  // flight while one is multiplied: 16 MB in flight chip-wide, what the memory system's latency asks for)
+  constexpr int V3_ROWS = 128 + 32 * MB, V3_TILEB = V3_ROWS * 256, LOADS = V3_ROWS / 16, V3_STAGES = MB <= 2 ? 3 : 2;
   __shared__ __attribute__((aligned(1024))) unsigned char ring[V3_STAGES * V3_TILEB];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1260,13 +1262,13 @@ __global__ __launch_bounds__(256) void linear_fwd_bf16_v3_kernel(const uint16_t*
   const int a_row = (128 + r) * 256, b_row = (wave * 32 + r) * 256;
 
   load_tile(t0);
-  if (t0 + 1 < t1) load_tile(t0 + 1);
+  if (V3_STAGES == 3 && t0 + 1 < t1) load_tile(t0 + 1);
   for (int t = t0; t < t1; ++t) {
-    // this wave issues LOADS loads per tile, in order: all but the newest tile's have landed
-    if (t + 1 < t1) __builtin_amdgcn_s_waitcnt(0x0f70 | LOADS);
+    // this wave issues LOADS loads per tile, in order: all but the newest tile's have landed (two stages: all have)
+    if (V3_STAGES == 3 && t + 1 < t1) __builtin_amdgcn_s_waitcnt(0x0f70 | (LOADS & 15));
     else __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();  // tile t complete for every wave; every wave is done with tile t-1 (whose stage tile t+2 reuses)
-    if (t + 2 < t1) load_tile(t + 2);
+    __syncthreads();  // tile t complete for every wave; every wave is done with tile t-1 (whose stage the next request reuses)
+    if (t + V3_STAGES - 1 < t1) load_tile(t + V3_STAGES - 1);
     const unsigned char* tile = ring + (t % V3_STAGES) * V3_TILEB;
     if (wave * 32 < n) {
 #pragma unroll
@@ -1333,7 +1335,7 @@ int pv_linear_bf16_workspace_bytes(int32_t m, int32_t n, int64_t k, size_t* byte
   PV_REQUIRE(bytes && m > 0 && n > 0 && k > 0, PV_EINVAL, "pv_linear_bf16_workspace_bytes: bad arguments");
   int per;
   int nwg = bf16_fwd_split(k, &per);   // >= the v2 / v3 splits (<= 512 workgroups)
-  const size_t rows = (size_t)((m + 63) / 64) * 64;      // (the LDS-staged forward keeps 32 or 64 rows of slabs per launch)
+  const size_t rows = (size_t)((m + 127) / 128) * 128;   // (the LDS-staged forward keeps 32, 64 or 128 rows of slabs per launch)
   *bytes = (size_t)nwg * rows * n * sizeof(float);
   return PV_OK;
 }
@@ -1355,7 +1357,8 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
     int tiles, n_tiles;
     const bool fits32 = (size_t)n * k * 2 < 0xfffffff0ull;  // the v3 kernel's raw-buffer offsets are 32-bit
     const int nwg2 = !fits32 ? v2_split(k, &tiles, &n_tiles) : v3_split(k, &tiles, &n_tiles);
-    const int rpb = (m > 32 && fits32) ? 64 : 32;      // rows per launch: two row blocks beside the weight tile when there are that many
+    // rows per launch: two row blocks beside the weight tile when there are that many, four for the tall calls
+    const int rpb = !fits32 ? 32 : (m > 128 ? 128 : (m > 32 ? 64 : 32));
     const int nblk = (m + rpb - 1) / rpb;
     const size_t blk_stride = (size_t)nwg2 * rpb * n;      // floats between two launches' slabs
     PV_REQUIRE(workspace_bytes >= (size_t)nblk * blk_stride * sizeof(float), PV_ESIZE, "pv_linear_fwd_bf16: workspace too small");
@@ -1365,6 +1368,9 @@ int pv_linear_fwd_bf16(const uint16_t* x, const uint16_t* w, const float* bias, 
       float* pb = part + (size_t)(m0 / rpb) * blk_stride;
       if (!fits32)
         hipLaunchKernelGGL(linear_fwd_bf16_v2_kernel, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
+                           n_tiles, tiles);
+      else if (rpb == 128)
+        hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel<4>, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
                            n_tiles, tiles);
       else if (rpb == 64)
         hipLaunchKernelGGL(linear_fwd_bf16_v3_kernel<2>, dim3((unsigned)nwg2), dim3(256), 0, st, xb, w, pb, mb, n, (long long)k,
