@@ -111,7 +111,14 @@ if kind == "flow":
     buf2 = np.zeros(WAVES * SLOTS, dtype=np.uint64)
     assert f2(buf2.ctypes.data, buf2.size) == 0
     p = buf2.reshape(WAVES, SLOTS).astype(np.float64)
-    p = p[p[:, 7] > 0]
+    grp_of_row = (np.arange(len(p)) % 8) >> 2          # waves 0..3 = group 0 (b1, b2, b4 + the pair stores), 4..7 = group 1
+    live = p[:, 7] > 0
+    for gsel in (0, 1):
+        pg = p[live & (grp_of_row == gsel)]
+        if len(pg):
+            print(f"  PolyExp level 0, group {gsel}: " + ", ".join(f"{lab.split(':')[0][:24]} {(pg[:, i] / pg[:, 7]).mean():.0f}"
+                                                                 for i, lab in enumerate(["source", "barrier waits", "filters + X write", "products", "epilogue"])))
+    p = p[live]
     if len(p):
         labels = ["source words -> floats in LDS, next image requested", "barrier waits", "3-tap filters, resize, split, X write",
                   "products (+ mailbox write)", "epilogue: coefficients, stores"]
