@@ -22,6 +22,8 @@ cp $O/pmc_hbm_traffic_bench_B32.json $O/pmc_flow_*.json profiles/r06/
 python3 bench.py > $O/bench_conv3d_B32_default_run.json 2> $O/bench_default.err
 python3 tools/time_fp32_step.py > $O/fp32_step_kernels.txt 2>&1
 bash tools/trace_fp32_step.sh > /dev/null 2>&1; cp gpurun_out/fp32_trace/kernel_stats.txt $O/fp32_step_kernel_stats.txt
+bash tools/pmc_conv.sh gpurun_out/r06/convpmc > $O/convpmc.log 2>&1; cp $O/convpmc/pmc_conv_*.json $O/
+python3 tools/probes/sclk_under_kernels.py > $O/sclk_under_kernels.txt 2>&1
 find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*counter_collection.csv" -size +5M -delete
 rm -rf $O/fetch $O/write $O/flowpmc/A $O/flowpmc/B $O/flowpmc/C $O/flowpmc/fetch $O/flowpmc/write
