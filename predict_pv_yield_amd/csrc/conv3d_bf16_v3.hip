@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
   // zero-sized descriptor
   const uint32_t out_plane_b = (uint32_t)plane_out * VOX_OUT_B, out_row_b = (uint32_t)w_out * VOX_OUT_B;
   const int rows_left = h_out - (h0 + 4 * wr);   // tile rows orow < rows_left exist
+  // a wave whose four tile rows all lie below the image (the second row quad of the last tile when h_out % 8 is 1..4: 60- and
+  // 58-row planes) multiplies nothing -- its stores are dropped anyway; it still stages its share and keeps the barriers.  The
+  // conv kernels are power-limited (profiles/r06/NOTES.md section 5): a matrix instruction not issued is clock for the others
+  const bool quad_live = rows_left > 0;
   void* const y_sample = reinterpret_cast<unsigned char*>(y) + (size_t)b * out_sample_b;
   const void* const og_sample = (OUT_GATE ? out_gate : y) + (size_t)b * t_out * plane_out * 32;
   // finished tile in the store geometry (16 bytes per lane and tile row), stored one step later so the stores never sit in
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_bf16_v3_kernel(
        whole march) is all zeros: its MFMAs are skipped (wave-uniform branch), the bookkeeping of the step is not.    \
        Only the head / tail instances test it: an interior step of a chunk never reads padding of a whole march's    \
        ends unless the march has fewer than three slices, and its code stays branch-free */                          \
-    const bool slice_live = ((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in;             \
+    const bool slice_live = quad_live && (((KT_LO) == 0 && (KT_HI) == 2) || (unsigned)(s - pad_t) < (unsigned)t_in); \
     if (slice_live && Y_NCDHW) {                                                                                  \
       v3_accumulate<P, KT_LO, KT_HI, 0, W1_LDS, F16>(slot, voff, wfrag, w2, acc, b4, no_side);                         \
       PV_STAMP(q4);                                                                                               \
